@@ -1,0 +1,205 @@
+/*
+ * juliet_hip.h — C ABI of libjuliet_hip.so: juliet's call+phase hot path on MI355X (gfx950).
+ *
+ * What this replaces.  The reference exposes NO library, plugin or FFI surface for this path — only the
+ * `juliet` process boundary (doc/JULIET.md:62-66) — and ships no source, so there is no
+ * reference interface file:line for an entry point to mirror.  Each entry point below therefore cites the
+ * reference TEXT whose behaviour it implements (doc/JULIET.md as J:line) and the docs/SPEC.md section that
+ * fixes the details the text leaves open.  A host (the C++ `juliet` front end in minorseq_amd/host/, or any
+ * FFI: ctypes in minorseq_amd/capi.py, cgo/JNI stubs in INTEGRATION.md) drives the path through these calls.
+ *
+ * Conventions.  Plain C, fixed-width PODs, no exceptions cross the boundary.  Every function returns
+ * JL_OK (0) or a negative jl_status; jl_last_error(ctx) has the detail.  The caller owns every host
+ * buffer; the ctx owns device memory unless a buffer is adopted.  One ctx per (thread, device); all work
+ * of a ctx is ordered on one HIP stream (its own, or the caller's — e.g. torch's current stream).
+ * `*_async` calls only enqueue; results are valid after jl_sync() or a `*_fetch`/blocking call.
+ * There is no CPU fallback: without a usable gfx950 device every call fails with JL_ERR_DEVICE.
+ */
+#ifndef JULIET_HIP_H
+#define JULIET_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define JL_ABI_VERSION 1
+
+/* symbol codes of the MSA (SPEC §1; J:99-100, 256-259, 372-381) */
+enum { JL_SYM_A = 0, JL_SYM_C = 1, JL_SYM_G = 2, JL_SYM_T = 3, JL_SYM_GAP = 4, JL_SYM_MASK = 5, JL_SYM_NONE = 6 };
+
+typedef enum {
+    JL_OK = 0,
+    JL_ERR_ARG = -1,      /* bad argument / shape */
+    JL_ERR_DEVICE = -2,   /* no gfx950 device, HIP error */
+    JL_ERR_MEMORY = -3,   /* allocation failed */
+    JL_ERR_STATE = -4,    /* call order: e.g. jl_call before jl_pileup */
+    JL_ERR_OVERFLOW = -5, /* an output capacity was exceeded (n_out holds the needed size) */
+    JL_ERR_COMM = -6      /* RCCL failure */
+} jl_status;
+
+enum { JL_MAX_HAPLOTYPES = 702 /* [A-Z][a-z]?  J:198 */, JL_HAP_INSUFFICIENT = 0xFFFE, JL_HAP_DAMAGED = 0xFFFF };
+
+typedef struct jl_ctx jl_ctx;
+typedef struct jl_comm jl_comm;
+
+/* gene / ORF: 1-based [begin, end) in alignment space (J:134-136) */
+typedef struct {
+    uint32_t begin;
+    uint32_t end;
+} jl_gene;
+
+/* ErrorEstimates (SPEC §5; J:40-41, 221-225).  Values are UNPINNED, hence parameters. */
+typedef struct {
+    double match;
+    double substitution; /* per target base */
+    double deletion;     /* reserved: indels are ignored (J:26-27) */
+} jl_error_model;
+
+typedef struct {
+    double alpha;           /* significance level after Bonferroni; default 0.01 */
+    double n_tests;         /* Bonferroni factor; <= 0 selects sum of codons over all genes passed to jl_pileup */
+    jl_error_model err;
+    int32_t expected_round; /* 0 ceil (default), 1 floor, 2 nearest */
+    int32_t tail;           /* 0 one-sided greater (only mode implemented) */
+    double min_perc;        /* --min-perc: keep 100*count/coverage >  min_perc; < 0 disables (J:342-344) */
+    double max_perc;        /* --max-perc: keep 100*count/coverage <  max_perc; < 0 disables (J:352-354) */
+} jl_params;
+
+/* one called variant codon (SPEC §6; J:94-98).  48 bytes, the all-gather payload row. */
+typedef struct {
+    uint32_t gene;      /* index into the genes passed to jl_pileup */
+    uint32_t codon_pos; /* 1-based amino-acid position in the gene */
+    uint32_t col;       /* window column of the codon's first base */
+    uint8_t ref_codon;  /* 0..63 = 16*b0+4*b1+b2 */
+    uint8_t codon;
+    uint16_t flags;
+    uint32_t count;
+    uint32_t coverage;
+    uint32_t expected;
+    uint32_t pad_;
+    double p_value; /* Bonferroni-adjusted, <= 1 */
+    double log_p;   /* ln of the unadjusted p */
+} jl_variant;
+
+/* read categories (J:372-381) and sizes of the phasing result */
+typedef struct {
+    uint32_t reported_reads;
+    uint32_t insufficient_reads;
+    uint32_t damaged_reads;
+    uint32_t marginal_gap;
+    uint32_t marginal_heteroduplex;
+    uint32_t marginal_partial;
+    uint32_t n_positions;  /* Vp: distinct variant columns */
+    uint32_t n_haplotypes; /* H */
+} jl_phase_summary;
+
+/* synthetic aligned-CCS generator (bench + tests) */
+typedef struct {
+    uint64_t seed;
+    double sub_rate;      /* per base, uniform over the other three bases */
+    double del_rate;      /* '-' */
+    double mask_rate;     /* 'N' */
+    double partial_rate;  /* fraction of reads that start late / end early */
+    uint32_t minor_permille[4]; /* frequency of the four minor haplotypes, in 1/1000 of the reads */
+    uint32_t reserved;
+} jl_synth_params;
+
+/* ---------------------------------------------------------------- context */
+
+int jl_abi_version(void);
+const char *jl_strerror(int status);
+/* Number of usable gfx950 devices (0 if none). Does not create a context. */
+int jl_device_count(void);
+/* `stream` = NULL: the ctx creates its own non-blocking stream; else a hipStream_t owned by the caller. */
+int jl_ctx_create(int device, void *stream, jl_ctx **out);
+void jl_ctx_destroy(jl_ctx *ctx);
+const char *jl_last_error(const jl_ctx *ctx);
+int jl_sync(jl_ctx *ctx);
+
+/* ---------------------------------------------------------------- MSA residency */
+
+/* Bytes per column for n_reads reads (ceil(n/2) rounded up to 128). */
+uint64_t jl_col_stride(uint64_t n_reads);
+/* Copy a host column-packed matrix [n_cols][col_stride] into device memory owned by the ctx. */
+int jl_msa_upload(jl_ctx *ctx, const uint8_t *colpacked, uint64_t n_reads, uint32_t n_cols, uint64_t col_stride,
+                  uint32_t win_begin);
+/* Allocate an uninitialised resident matrix (for jl_synth_fill / jl_msa_pack_rows). */
+int jl_msa_alloc(jl_ctx *ctx, uint64_t n_reads, uint32_t n_cols, uint32_t win_begin);
+/* Use caller-owned device memory (e.g. a torch tensor) as the resident matrix; not freed by the ctx. */
+int jl_msa_adopt(jl_ctx *ctx, void *d_colpacked, uint64_t n_reads, uint32_t n_cols, uint64_t col_stride,
+                 uint32_t win_begin);
+/* Device-side transpose of a host by-row matrix uint8[n_reads][n_cols] (codes 0..6) into the resident layout. */
+int jl_msa_pack_rows(jl_ctx *ctx, const uint8_t *rows, uint64_t n_reads, uint32_t n_cols, uint32_t win_begin);
+/* Copy the resident matrix back to the host (tests). */
+int jl_msa_download(jl_ctx *ctx, uint8_t *colpacked, uint64_t bytes);
+/* Fill the resident matrix with synthetic reads, on the device. `ref` = n_cols base codes (host). */
+int jl_synth_fill(jl_ctx *ctx, const jl_synth_params *sp, const uint8_t *ref);
+
+/* ---------------------------------------------------------------- call */
+
+/*
+ * Column pileup + per-codon histograms for every evaluated position of `genes` (SPEC §2-3; J:94-100).
+ * `refseq`: base codes of the whole reference (0..3, other = non-ACGT), 0-based, or NULL for
+ * majority-codon mode (J:133-134).  Enqueues; returns without waiting.
+ */
+int jl_pileup_async(jl_ctx *ctx, const jl_gene *genes, uint32_t n_genes, const uint8_t *refseq, uint32_t ref_len);
+/* Number of evaluated positions P of the last jl_pileup_async. */
+uint32_t jl_n_positions(const jl_ctx *ctx);
+/*
+ * Wait, then copy out: col_counts[n_cols][6] (A C G T - N), pos_gene/pos_codon/pos_col[P] (codon_pos 1-based),
+ * hist[P][64], coverage[P].  Any pointer may be NULL.
+ */
+int jl_pileup_fetch(jl_ctx *ctx, uint32_t *col_counts, uint32_t *pos_gene, uint32_t *pos_codon, uint32_t *pos_col,
+                    uint32_t *hist, uint32_t *coverage);
+/*
+ * Reference/majority codon, error model, Fisher's exact x Bonferroni, filters, variant table
+ * (SPEC §4-7; J:38-42).  `drm_masks`: optional [P] 64-bit codon masks; with --drm-only a codon is kept
+ * only if its bit is set (J:370); NULL disables.  Table stays on the device; enqueues only.
+ */
+int jl_call_async(jl_ctx *ctx, const jl_params *prm, const uint64_t *drm_masks);
+/* Wait and copy the table out.  *n_out = rows produced; JL_ERR_OVERFLOW if > cap (first cap rows are valid). */
+int jl_call_fetch(jl_ctx *ctx, jl_variant *out, uint32_t cap, uint32_t *n_out);
+/* Device address and capacity (rows) of the resident variant table and of its row counter (uint32). */
+int jl_variant_table_device(jl_ctx *ctx, void **d_rows, void **d_count, uint32_t *cap_rows);
+
+/* ---------------------------------------------------------------- phase */
+
+/*
+ * Read x variant phasing (SPEC §8; J:192-211, 253-254, 372-381).  `variants` = host table to phase
+ * against (e.g. all-gathered and filtered), or NULL to use the table jl_call_async left on the device.
+ * Enqueues only.
+ */
+int jl_phase_async(jl_ctx *ctx, const jl_variant *variants, uint32_t n_var, uint32_t min_reads);
+/*
+ * Wait and copy out.  pos_cols[Vp]; hap_count[H]; hap_pattern[H][Vp] (codon indices);
+ * hit[V][H] (J:207-209); read_hap[n_reads]; cooc[V][V].  Any pointer may be NULL; capacities are the
+ * caller's: pos_cols/hap_pattern rows are sized with cap_var, hap_* with JL_MAX_HAPLOTYPES.
+ */
+int jl_phase_fetch(jl_ctx *ctx, jl_phase_summary *summary, uint32_t *pos_cols, uint32_t *hap_count,
+                   uint8_t *hap_pattern, uint8_t *hit, uint16_t *read_hap, uint32_t *cooc, uint32_t cap_var);
+
+/* ---------------------------------------------------------------- timing hooks (bench) */
+
+/* Average device time in ms of `reps` back-to-back launches of the pileup kernel alone, by HIP events on the ctx stream. */
+int jl_time_pileup(jl_ctx *ctx, uint32_t reps, float *ms_avg);
+/* Name of the dominant kernel as rocprofv3 reports it. */
+const char *jl_pileup_kernel_name(void);
+
+/* ---------------------------------------------------------------- multi-GPU */
+
+/* Rank 0 makes a 128-byte RCCL unique id and hands it to the other ranks out of band. */
+int jl_comm_unique_id(uint8_t id[128]);
+int jl_comm_create(jl_ctx *ctx, const uint8_t id[128], int rank, int world, jl_comm **out);
+void jl_comm_destroy(jl_comm *comm);
+/*
+ * The one collective of the path: all-gather of the fixed-stride variant table over RCCL/xGMI.
+ * all_rows[world*cap_rows], all_counts[world] are HOST outputs; rows of rank r start at r*cap_rows.
+ */
+int jl_allgather_variants(jl_ctx *ctx, jl_comm *comm, jl_variant *all_rows, uint32_t *all_counts, uint32_t cap_rows);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* JULIET_HIP_H */
