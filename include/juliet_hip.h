@@ -180,6 +180,16 @@ int jl_phase_async(jl_ctx *ctx, const jl_variant *variants, uint32_t n_var, uint
 int jl_phase_fetch(jl_ctx *ctx, jl_phase_summary *summary, uint32_t *pos_cols, uint32_t *hap_count,
                    uint8_t *hap_pattern, uint8_t *hit, uint16_t *read_hap, uint32_t *cooc, uint32_t cap_var);
 
+/* ---------------------------------------------------------------- numerics self-check */
+
+/*
+ * Evaluate the device's Fisher routine on `n` tables [[a, cov-a], [c, cov-c]] (host arrays in and out):
+ * p[i] = P(X >= a[i]) unadjusted, log_p[i] = ln p.  Lets a host pin the device numerics against its own
+ * golden vectors (tests/golden/fisher_golden.json).
+ */
+int jl_fisher_eval(jl_ctx *ctx, const uint32_t *a, const uint32_t *c, const uint32_t *cov, uint32_t n, double *p,
+                   double *log_p);
+
 /* ---------------------------------------------------------------- timing hooks (bench) */
 
 /* Average device time in ms of `reps` back-to-back launches of the pileup kernel alone, by HIP events on the ctx stream. */

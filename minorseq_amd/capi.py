@@ -1,0 +1,290 @@
+"""ctypes binding of libjuliet_hip.so (include/juliet_hip.h) — the reference-side FFI stub, in Python.
+
+The reference has no API for this path beyond the `juliet` command line (doc/JULIET.md:62-66), so the
+class below mirrors the documented stages instead: pileup -> call (-> all-gather) -> phase, with the
+documented knobs (`--min-perc`, `--max-perc`, `--drm-only`, phasing on/off) as arguments.
+Fails loudly when the library or a gfx950 device is missing: there is no CPU fallback.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libjuliet_hip.so")
+
+MAX_HAPLOTYPES = 702
+HAP_INSUFFICIENT = 0xFFFE
+HAP_DAMAGED = 0xFFFF
+VARIANT_CAP = 4096
+
+GENE = np.dtype([("begin", "<u4"), ("end", "<u4")])
+VARIANT = np.dtype([("gene", "<u4"), ("codon_pos", "<u4"), ("col", "<u4"), ("ref_codon", "u1"), ("codon", "u1"),
+                    ("flags", "<u2"), ("count", "<u4"), ("coverage", "<u4"), ("expected", "<u4"), ("pad_", "<u4"),
+                    ("p_value", "<f8"), ("log_p", "<f8")])
+SUMMARY_FIELDS = ("reported_reads", "insufficient_reads", "damaged_reads", "marginal_gap", "marginal_heteroduplex",
+                  "marginal_partial", "n_positions", "n_haplotypes")
+SUMMARY = np.dtype([(n, "<u4") for n in SUMMARY_FIELDS])
+
+# every symbol include/juliet_hip.h declares (checked by tests/test_capi_exports.py)
+EXPORTS = ("jl_abi_version", "jl_strerror", "jl_device_count", "jl_ctx_create", "jl_ctx_destroy", "jl_last_error",
+           "jl_sync", "jl_col_stride", "jl_msa_upload", "jl_msa_alloc", "jl_msa_adopt", "jl_msa_pack_rows",
+           "jl_msa_download", "jl_synth_fill", "jl_pileup_async", "jl_n_positions", "jl_pileup_fetch",
+           "jl_call_async", "jl_call_fetch", "jl_variant_table_device", "jl_phase_async", "jl_phase_fetch",
+           "jl_fisher_eval", "jl_time_pileup", "jl_pileup_kernel_name", "jl_comm_unique_id", "jl_comm_create", "jl_comm_destroy",
+           "jl_allgather_variants")
+
+
+class ErrorModel(C.Structure):
+    _fields_ = [("match", C.c_double), ("substitution", C.c_double), ("deletion", C.c_double)]
+
+
+class Params(C.Structure):
+    _fields_ = [("alpha", C.c_double), ("n_tests", C.c_double), ("err", ErrorModel), ("expected_round", C.c_int32),
+                ("tail", C.c_int32), ("min_perc", C.c_double), ("max_perc", C.c_double)]
+
+
+class SynthParams(C.Structure):
+    _fields_ = [("seed", C.c_uint64), ("sub_rate", C.c_double), ("del_rate", C.c_double), ("mask_rate", C.c_double),
+                ("partial_rate", C.c_double), ("minor_permille", C.c_uint32 * 4), ("reserved", C.c_uint32)]
+
+
+ERROR_MODELS = {  # docs/SPEC.md §5 (values UNPINNED)
+    "sequel": (0.998826, 5.8e-5, 1.0e-3),
+    "permissive": (0.99764, 1.2e-4, 2.0e-3),
+}
+
+
+def default_params(n_tests=0.0, alpha=0.01, chemistry="sequel", min_perc=-1.0, max_perc=-1.0, expected_round=0):
+    m, s, d = ERROR_MODELS[chemistry]
+    return Params(alpha, n_tests, ErrorModel(m, s, d), expected_round, 0, min_perc, max_perc)
+
+
+class JulietError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__(f"libjuliet_hip: status {status}: {msg}")
+        self.status = status
+
+
+_lib = None
+
+
+def load_library(path=LIB_PATH):
+    """Load the C-ABI library; raises if it was not built (run `python -c 'import __graft_entry__ as g; g.build()'`)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(path):
+        raise ImportError(f"{path} is missing: build it with minorseq_amd/csrc/Makefile (hipcc, gfx950). "
+                          "There is no CPU fallback for the juliet hot path.")
+    lib = C.CDLL(path)
+    vp, u32, u64 = C.c_void_p, C.c_uint32, C.c_uint64
+    lib.jl_strerror.restype = C.c_char_p
+    lib.jl_last_error.restype = C.c_char_p
+    lib.jl_last_error.argtypes = [vp]
+    lib.jl_pileup_kernel_name.restype = C.c_char_p
+    lib.jl_col_stride.restype = u64
+    lib.jl_col_stride.argtypes = [u64]
+    lib.jl_ctx_create.argtypes = [C.c_int, vp, C.POINTER(vp)]
+    lib.jl_ctx_destroy.argtypes = [vp]
+    lib.jl_ctx_destroy.restype = None
+    lib.jl_sync.argtypes = [vp]
+    lib.jl_msa_upload.argtypes = [vp, vp, u64, u32, u64, u32]
+    lib.jl_msa_alloc.argtypes = [vp, u64, u32, u32]
+    lib.jl_msa_adopt.argtypes = [vp, vp, u64, u32, u64, u32]
+    lib.jl_msa_pack_rows.argtypes = [vp, vp, u64, u32, u32]
+    lib.jl_msa_download.argtypes = [vp, vp, u64]
+    lib.jl_synth_fill.argtypes = [vp, C.POINTER(SynthParams), vp]
+    lib.jl_pileup_async.argtypes = [vp, vp, u32, vp, u32]
+    lib.jl_n_positions.argtypes = [vp]
+    lib.jl_n_positions.restype = u32
+    lib.jl_pileup_fetch.argtypes = [vp] * 7
+    lib.jl_call_async.argtypes = [vp, C.POINTER(Params), vp]
+    lib.jl_call_fetch.argtypes = [vp, vp, u32, C.POINTER(u32)]
+    lib.jl_variant_table_device.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(u32)]
+    lib.jl_phase_async.argtypes = [vp, vp, u32, u32]
+    lib.jl_phase_fetch.argtypes = [vp] * 8 + [u32]
+    lib.jl_fisher_eval.argtypes = [vp, vp, vp, vp, u32, vp, vp]
+    lib.jl_time_pileup.argtypes = [vp, u32, C.POINTER(C.c_float)]
+    lib.jl_comm_unique_id.argtypes = [vp]
+    lib.jl_comm_create.argtypes = [vp, vp, C.c_int, C.c_int, C.POINTER(vp)]
+    lib.jl_comm_destroy.argtypes = [vp]
+    lib.jl_comm_destroy.restype = None
+    lib.jl_allgather_variants.argtypes = [vp, vp, vp, vp, u32]
+    if lib.jl_abi_version() != 1:
+        raise ImportError("libjuliet_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Juliet:
+    """One context = one GPU = one reference window of aligned CCS reads resident in HBM."""
+
+    def __init__(self, device=0, stream=None):
+        self.lib = load_library()
+        h = C.c_void_p()
+        rc = self.lib.jl_ctx_create(device, C.c_void_p(stream) if stream else None, C.byref(h))
+        if rc != 0:
+            raise JulietError(rc, self.lib.jl_last_error(None).decode())
+        self.h = h
+        self.n_reads = 0
+        self.n_cols = 0
+        self.col_stride = 0
+        self._keep = None
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.jl_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc, allow=()):
+        if rc != 0 and rc not in allow:
+            raise JulietError(rc, self.lib.jl_last_error(self.h).decode())
+        return rc
+
+    # ------------------------------------------------------------------ residency
+    def _shape(self, n_reads, n_cols, stride):
+        self.n_reads, self.n_cols, self.col_stride = int(n_reads), int(n_cols), int(stride)
+
+    def upload_columns(self, packed, n_reads, win_begin=0):
+        packed = np.ascontiguousarray(packed, dtype=np.uint8)
+        n_cols, stride = packed.shape
+        self._chk(self.lib.jl_msa_upload(self.h, _p(packed), n_reads, n_cols, stride, win_begin))
+        self._shape(n_reads, n_cols, stride)
+
+    def upload_rows(self, rows, win_begin=0):
+        """By-row uint8 codes; transposed and nibble-packed on the device."""
+        rows = np.ascontiguousarray(rows, dtype=np.uint8)
+        n, l = rows.shape
+        self._chk(self.lib.jl_msa_pack_rows(self.h, _p(rows), n, l, win_begin))
+        self._shape(n, l, self.lib.jl_col_stride(n))
+
+    def alloc(self, n_reads, n_cols, win_begin=0):
+        self._chk(self.lib.jl_msa_alloc(self.h, n_reads, n_cols, win_begin))
+        self._shape(n_reads, n_cols, self.lib.jl_col_stride(n_reads))
+
+    def adopt(self, device_ptr, n_reads, n_cols, col_stride, win_begin=0, keep_alive=None):
+        self._chk(self.lib.jl_msa_adopt(self.h, C.c_void_p(device_ptr), n_reads, n_cols, col_stride, win_begin))
+        self._shape(n_reads, n_cols, col_stride)
+        self._keep = keep_alive
+
+    def synth_fill(self, sp, ref):
+        """sp: minorseq_amd.synth.SynthParams; fills the resident matrix on the device."""
+        csp = SynthParams(sp.seed, sp.sub_rate, sp.del_rate, sp.mask_rate, sp.partial_rate,
+                          (C.c_uint32 * 4)(*sp.minor_permille), 0)
+        ref = np.ascontiguousarray(ref, dtype=np.uint8)
+        assert len(ref) == self.n_cols
+        self._chk(self.lib.jl_synth_fill(self.h, C.byref(csp), _p(ref)))
+
+    def download_columns(self):
+        out = np.empty((self.n_cols, self.col_stride), dtype=np.uint8)
+        self._chk(self.lib.jl_msa_download(self.h, _p(out), out.nbytes))
+        return out
+
+    # ------------------------------------------------------------------ stages
+    def pileup_async(self, genes, refseq=None):
+        genes = np.ascontiguousarray(genes, dtype=GENE)
+        if refseq is not None:
+            refseq = np.ascontiguousarray(refseq, dtype=np.uint8)
+        self._chk(self.lib.jl_pileup_async(self.h, _p(genes), len(genes), _p(refseq),
+                                           0 if refseq is None else len(refseq)))
+
+    def pileup_fetch(self):
+        p = self.lib.jl_n_positions(self.h)
+        col = np.zeros((self.n_cols, 6), dtype=np.uint32)
+        pg, pk, pc = (np.zeros(p, dtype=np.uint32) for _ in range(3))
+        hist = np.zeros((p, 64), dtype=np.uint32)
+        cov = np.zeros(p, dtype=np.uint32)
+        self._chk(self.lib.jl_pileup_fetch(self.h, _p(col), _p(pg), _p(pk), _p(pc), _p(hist), _p(cov)))
+        return dict(col_counts=col, pos_gene=pg, pos_codon=pk, pos_col=pc, hist=hist, coverage=cov)
+
+    def call_async(self, params=None, drm_masks=None):
+        prm = params or default_params()
+        if drm_masks is not None:
+            drm_masks = np.ascontiguousarray(drm_masks, dtype=np.uint64)
+            assert len(drm_masks) == self.lib.jl_n_positions(self.h)
+        self._chk(self.lib.jl_call_async(self.h, C.byref(prm), _p(drm_masks)))
+
+    def call_fetch(self, cap=VARIANT_CAP):
+        out = np.zeros(cap, dtype=VARIANT)
+        n = C.c_uint32()
+        self._chk(self.lib.jl_call_fetch(self.h, _p(out), cap, C.byref(n)))
+        return out[: n.value].copy()
+
+    def variant_table_device(self):
+        rows, cnt, cap = C.c_void_p(), C.c_void_p(), C.c_uint32()
+        self._chk(self.lib.jl_variant_table_device(self.h, C.byref(rows), C.byref(cnt), C.byref(cap)))
+        return rows.value, cnt.value, cap.value
+
+    def phase_async(self, variants=None, min_reads=10):
+        if variants is None:
+            self._chk(self.lib.jl_phase_async(self.h, None, 0, min_reads))
+        else:
+            variants = np.ascontiguousarray(variants, dtype=VARIANT)
+            # a zero-length table still needs a non-NULL pointer to mean "this table", not "the resident one"
+            buf = variants if len(variants) else np.zeros(1, dtype=VARIANT)
+            self._chk(self.lib.jl_phase_async(self.h, _p(buf), len(variants), min_reads))
+
+    def phase_fetch(self, want_reads=True, cap_var=VARIANT_CAP):
+        summ = np.zeros(1, dtype=SUMMARY)
+        pos_cols = np.zeros(cap_var, dtype=np.uint32)
+        hap_count = np.zeros(MAX_HAPLOTYPES, dtype=np.uint32)
+        hap_pattern = np.zeros((MAX_HAPLOTYPES, cap_var), dtype=np.uint8)
+        hit = np.zeros((cap_var, MAX_HAPLOTYPES), dtype=np.uint8)
+        read_hap = np.zeros(self.n_reads, dtype=np.uint16) if want_reads else None
+        cooc = np.zeros((cap_var, cap_var), dtype=np.uint32) if cap_var <= 1024 else None
+        self._chk(self.lib.jl_phase_fetch(self.h, _p(summ), _p(pos_cols), _p(hap_count), _p(hap_pattern), _p(hit),
+                                          _p(read_hap), _p(cooc), cap_var))
+        s = {k: int(summ[0][k]) for k in SUMMARY_FIELDS}
+        h, vp = s["n_haplotypes"], s["n_positions"]
+        return dict(summary=s, pos_cols=pos_cols[:vp].copy(), hap_count=hap_count[:h].copy(),
+                    hap_pattern=hap_pattern[:h, :vp].copy(), hit=hit, read_hap=read_hap, cooc=cooc)
+
+    def fisher_eval(self, a, c, cov):
+        a, c, cov = (np.ascontiguousarray(x, dtype=np.uint32) for x in (a, c, cov))
+        p = np.zeros(len(a), dtype=np.float64)
+        lp = np.zeros(len(a), dtype=np.float64)
+        self._chk(self.lib.jl_fisher_eval(self.h, _p(a), _p(c), _p(cov), len(a), _p(p), _p(lp)))
+        return p, lp
+
+    def sync(self):
+        self._chk(self.lib.jl_sync(self.h))
+
+    def time_pileup(self, reps=20):
+        ms = C.c_float()
+        self._chk(self.lib.jl_time_pileup(self.h, reps, C.byref(ms)))
+        return ms.value
+
+    # ------------------------------------------------------------------ convenience: the whole path
+    def run(self, genes, refseq=None, params=None, drm_masks=None, phasing=True, min_reads=10):
+        self.pileup_async(genes, refseq)
+        self.call_async(params, drm_masks)
+        if phasing:
+            self.phase_async(None, min_reads)
+        variants = self.call_fetch()
+        out = dict(variants=variants)
+        if phasing:
+            ph = self.phase_fetch(cap_var=max(1, min(VARIANT_CAP, len(variants))))
+            ph["hit"] = ph["hit"][: len(variants), : ph["summary"]["n_haplotypes"]].copy()
+            if ph["cooc"] is not None:
+                ph["cooc"] = ph["cooc"][: len(variants), : len(variants)].copy()
+            out["phase"] = ph
+        return out
+
+
+def haplotype_name(h: int) -> str:
+    """Haplotype ids `[A-Z]{1}[a-z]?` (doc/JULIET.md:198): A..Z, then Aa..Az, Ba.. (docs/SPEC.md §8)."""
+    if h < 26:
+        return chr(65 + h)
+    h -= 26
+    return chr(65 + h // 26) + chr(97 + h % 26)

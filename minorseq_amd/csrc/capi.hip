@@ -1,0 +1,672 @@
+// capi.hip — the C ABI of include/juliet_hip.h: context, residency, planning, launches, copies.
+// No compute happens on the host here and there is no CPU fallback: every entry point needs a gfx950 device.
+#include <rccl/rccl.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <new>
+
+#include "jl_internal.h"
+
+static thread_local std::string g_create_error;
+
+int jl_fail(jl_ctx *ctx, int status, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf;
+    else g_create_error = buf;
+    return status;
+}
+
+template <typename T>
+static int regrow(jl_ctx *ctx, T **p, size_t n)
+{
+    if (*p) hipFree(*p);
+    *p = nullptr;
+    JL_HIP(ctx, hipMalloc(p, n * sizeof(T)));
+    return JL_OK;
+}
+
+extern "C" {
+
+int jl_abi_version(void) { return JL_ABI_VERSION; }
+
+const char *jl_strerror(int status)
+{
+    switch (status) {
+    case JL_OK: return "ok";
+    case JL_ERR_ARG: return "bad argument";
+    case JL_ERR_DEVICE: return "no usable gfx950 device / HIP error";
+    case JL_ERR_MEMORY: return "device allocation failed";
+    case JL_ERR_STATE: return "call order violated";
+    case JL_ERR_OVERFLOW: return "output capacity exceeded";
+    case JL_ERR_COMM: return "RCCL failure";
+    default: return "unknown status";
+    }
+}
+
+int jl_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    int ok = 0;
+    for (int d = 0; d < n; ++d) {
+        hipDeviceProp_t p;
+        if (hipGetDeviceProperties(&p, d) == hipSuccess && strncmp(p.gcnArchName, "gfx950", 6) == 0) ++ok;
+    }
+    return ok;
+}
+
+const char *jl_last_error(const jl_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int jl_ctx_create(int device, void *stream, jl_ctx **out)
+{
+    if (!out) return JL_ERR_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return jl_fail(nullptr, JL_ERR_DEVICE, "no HIP device visible; this library has no CPU fallback");
+    if (device < 0 || device >= n) return jl_fail(nullptr, JL_ERR_ARG, "device %d out of range (%d visible)", device, n);
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return jl_fail(nullptr, JL_ERR_DEVICE, "hipGetDeviceProperties failed");
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return jl_fail(nullptr, JL_ERR_DEVICE, "device %d is %s; kernels are built for gfx950 only", device, prop.gcnArchName);
+    jl_ctx *ctx = new (std::nothrow) jl_ctx();
+    if (!ctx) return JL_ERR_MEMORY;
+    ctx->device = device;
+    if (hipSetDevice(device) != hipSuccess) { delete ctx; return jl_fail(nullptr, JL_ERR_DEVICE, "hipSetDevice failed"); }
+    if (stream) {
+        ctx->stream = (hipStream_t)stream;
+    } else {
+        if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+            delete ctx;
+            return jl_fail(nullptr, JL_ERR_DEVICE, "hipStreamCreate failed");
+        }
+        ctx->own_stream = true;
+    }
+    hipEventCreate(&ctx->ev0);
+    hipEventCreate(&ctx->ev1);
+    bool ok = hipMalloc(&ctx->d_variants, sizeof(jl_variant) * JL_VARIANT_CAP) == hipSuccess &&
+              hipMalloc(&ctx->d_nvar, 2 * sizeof(uint32_t)) == hipSuccess &&
+              hipMalloc(&ctx->d_meta, sizeof(jl_phase_meta)) == hipSuccess &&
+              hipMalloc(&ctx->d_vpcols, sizeof(uint32_t) * JL_VARIANT_CAP) == hipSuccess &&
+              hipMalloc(&ctx->d_hap_count, sizeof(uint32_t) * JL_MAX_HAPLOTYPES) == hipSuccess &&
+              hipMalloc(&ctx->d_hap_pattern, (size_t)JL_MAX_HAPLOTYPES * JL_VARIANT_CAP) == hipSuccess &&
+              hipMalloc(&ctx->d_hit, (size_t)JL_VARIANT_CAP * JL_MAX_HAPLOTYPES) == hipSuccess &&
+              hipMalloc(&ctx->d_cooc, sizeof(uint32_t) * ctx->cooc_cap * ctx->cooc_cap) == hipSuccess;
+    if (!ok) { jl_ctx_destroy(ctx); return jl_fail(nullptr, JL_ERR_MEMORY, "context allocation failed"); }
+    hipMemsetAsync(ctx->d_nvar, 0, 2 * sizeof(uint32_t), ctx->stream);
+    hipMemsetAsync(ctx->d_meta, 0, sizeof(jl_phase_meta), ctx->stream);
+    *out = ctx;
+    return JL_OK;
+}
+
+static void free_msa(jl_ctx *ctx)
+{
+    if (ctx->own_msa && ctx->d_msa) hipFree(ctx->d_msa);
+    ctx->d_msa = nullptr;
+    ctx->own_msa = false;
+    ctx->msa_capacity = 0;
+}
+
+void jl_ctx_destroy(jl_ctx *ctx)
+{
+    if (!ctx) return;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    free_msa(ctx);
+    void *ptrs[] = {ctx->d_pos_gene, ctx->d_pos_codon, ctx->d_pos_col, ctx->d_pos_refcfg, ctx->d_colflag, ctx->d_guess,
+                    ctx->d_counts, ctx->d_called, ctx->d_cand_p, ctx->d_cand_lp, ctx->d_cand_e, ctx->d_pos_cov,
+                    ctx->d_pos_ref, ctx->d_drm, ctx->d_variants, ctx->d_nvar, ctx->d_meta, ctx->d_vpcols,
+                    ctx->d_col2pos, ctx->d_varcol, ctx->d_keys, ctx->d_flagw, ctx->d_read_slot, ctx->d_read_hap,
+                    ctx->d_slot_rep, ctx->d_slot_count, ctx->d_slot_hap, ctx->d_occupied, ctx->d_hap_count,
+                    ctx->d_hap_pattern, ctx->d_hit, ctx->d_cooc};
+    for (void *p : ptrs)
+        if (p) hipFree(p);
+    if (ctx->ev0) hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) hipEventDestroy(ctx->ev1);
+    if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int jl_sync(jl_ctx *ctx)
+{
+    if (!ctx) return JL_ERR_ARG;
+    JL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return JL_OK;
+}
+
+/* ---------------------------------------------------------------- MSA residency */
+
+uint64_t jl_col_stride(uint64_t n_reads) { return ((n_reads + 1) / 2 + 127) / 128 * 128; }
+
+static int set_shape(jl_ctx *ctx, uint64_t n_reads, uint32_t n_cols, uint64_t col_stride, uint32_t win_begin)
+{
+    if (n_reads == 0 || n_cols == 0) return jl_fail(ctx, JL_ERR_ARG, "empty matrix (%llu reads x %u columns)", (unsigned long long)n_reads, n_cols);
+    if (n_reads > 0x7FFFFFFFull) return jl_fail(ctx, JL_ERR_ARG, "more than 2^31-1 reads per context");
+    if (col_stride % 128 != 0 || col_stride < (n_reads + 1) / 2)
+        return jl_fail(ctx, JL_ERR_ARG, "col_stride %llu must be a multiple of 128 and >= ceil(n_reads/2)", (unsigned long long)col_stride);
+    if (n_reads != ctx->n_reads || n_cols != ctx->n_cols || col_stride != ctx->col_stride || win_begin != ctx->win_begin)
+        ctx->plan_valid = false;
+    ctx->n_reads = n_reads;
+    ctx->n_cols = n_cols;
+    ctx->col_stride = col_stride;
+    ctx->win_begin = win_begin;
+    ctx->pileup_done = ctx->call_done = ctx->phase_done = false;
+    return JL_OK;
+}
+
+static int reserve_msa(jl_ctx *ctx, size_t bytes)
+{
+    if (ctx->own_msa && ctx->msa_capacity >= bytes) return JL_OK;
+    free_msa(ctx);
+    JL_HIP(ctx, hipMalloc(&ctx->d_msa, bytes));
+    ctx->own_msa = true;
+    ctx->msa_capacity = bytes;
+    return JL_OK;
+}
+
+int jl_msa_alloc(jl_ctx *ctx, uint64_t n_reads, uint32_t n_cols, uint32_t win_begin)
+{
+    if (!ctx) return JL_ERR_ARG;
+    JL_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = set_shape(ctx, n_reads, n_cols, jl_col_stride(n_reads), win_begin);
+    if (rc) return rc;
+    return reserve_msa(ctx, (size_t)ctx->col_stride * n_cols);
+}
+
+int jl_msa_upload(jl_ctx *ctx, const uint8_t *colpacked, uint64_t n_reads, uint32_t n_cols, uint64_t col_stride,
+                  uint32_t win_begin)
+{
+    if (!ctx || !colpacked) return JL_ERR_ARG;
+    JL_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = set_shape(ctx, n_reads, n_cols, col_stride, win_begin);
+    if (rc) return rc;
+    rc = reserve_msa(ctx, (size_t)col_stride * n_cols);
+    if (rc) return rc;
+    JL_HIP(ctx, hipMemcpyAsync(ctx->d_msa, colpacked, (size_t)col_stride * n_cols, hipMemcpyHostToDevice, ctx->stream));
+    JL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return JL_OK;
+}
+
+int jl_msa_adopt(jl_ctx *ctx, void *d_colpacked, uint64_t n_reads, uint32_t n_cols, uint64_t col_stride,
+                 uint32_t win_begin)
+{
+    if (!ctx || !d_colpacked) return JL_ERR_ARG;
+    if (((uintptr_t)d_colpacked & 15u) != 0) return jl_fail(ctx, JL_ERR_ARG, "adopted matrix must be 16-byte aligned");
+    int rc = set_shape(ctx, n_reads, n_cols, col_stride, win_begin);
+    if (rc) return rc;
+    free_msa(ctx);
+    ctx->d_msa = (uint8_t *)d_colpacked;
+    return JL_OK;
+}
+
+int jl_msa_pack_rows(jl_ctx *ctx, const uint8_t *rows, uint64_t n_reads, uint32_t n_cols, uint32_t win_begin)
+{
+    if (!ctx || !rows) return JL_ERR_ARG;
+    int rc = jl_msa_alloc(ctx, n_reads, n_cols, win_begin);
+    if (rc) return rc;
+    uint8_t *d_rows = nullptr;
+    JL_HIP(ctx, hipMalloc(&d_rows, (size_t)n_reads * n_cols));
+    hipError_t e = hipMemcpyAsync(d_rows, rows, (size_t)n_reads * n_cols, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) {
+        jl_launch_pack_rows(ctx, d_rows);
+        e = hipStreamSynchronize(ctx->stream);
+    }
+    hipFree(d_rows);
+    if (e != hipSuccess) return jl_fail(ctx, JL_ERR_DEVICE, "pack_rows: %s", hipGetErrorString(e));
+    return JL_OK;
+}
+
+int jl_msa_download(jl_ctx *ctx, uint8_t *colpacked, uint64_t bytes)
+{
+    if (!ctx || !colpacked || !ctx->d_msa) return JL_ERR_ARG;
+    if (bytes > (uint64_t)ctx->col_stride * ctx->n_cols) return jl_fail(ctx, JL_ERR_ARG, "download larger than the matrix");
+    JL_HIP(ctx, hipMemcpyAsync(colpacked, ctx->d_msa, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    JL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return JL_OK;
+}
+
+int jl_synth_fill(jl_ctx *ctx, const jl_synth_params *sp, const uint8_t *ref)
+{
+    if (!ctx || !sp || !ref || !ctx->d_msa) return JL_ERR_ARG;
+    jl_synth_plan plan;
+    jl_synth_make_plan(&plan, sp->seed, ctx->n_cols, sp->sub_rate, sp->del_rate, sp->mask_rate, sp->partial_rate,
+                       sp->minor_permille, ref);
+    uint8_t *d_ref = nullptr;
+    JL_HIP(ctx, hipMalloc(&d_ref, ctx->n_cols));
+    hipError_t e = hipMemcpyAsync(d_ref, ref, ctx->n_cols, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) {
+        jl_launch_synth(ctx, &plan, d_ref);
+        e = hipStreamSynchronize(ctx->stream);
+    }
+    hipFree(d_ref);
+    if (e != hipSuccess) return jl_fail(ctx, JL_ERR_DEVICE, "synth_fill: %s", hipGetErrorString(e));
+    ctx->pileup_done = ctx->call_done = ctx->phase_done = false;
+    return JL_OK;
+}
+
+/* ---------------------------------------------------------------- call */
+
+// SPEC §3: evaluated positions of every gene, in (gene, k) order
+static int build_plan(jl_ctx *ctx, const jl_gene *genes, uint32_t n_genes, const uint8_t *refseq, uint32_t ref_len)
+{
+    ctx->genes.assign(genes, genes + n_genes);
+    ctx->have_ref = refseq != nullptr;
+    if (refseq) ctx->refseq.assign(refseq, refseq + ref_len);
+    else ctx->refseq.clear();
+    ctx->h_pos_gene.clear();
+    ctx->h_pos_codon.clear();
+    ctx->h_pos_col.clear();
+    std::vector<uint8_t> refcfg, colflag(ctx->n_cols, 0), guess(ctx->n_cols, 0);
+    double n_tests = 0.0;
+    for (uint32_t g = 0; g < n_genes; ++g) {
+        if (genes[g].begin == 0 || genes[g].end <= genes[g].begin) continue;
+        const uint32_t ncod = (genes[g].end - genes[g].begin) / 3;
+        n_tests += (double)ncod;
+        for (uint32_t k = 0; k < ncod; ++k) {
+            const int64_t r = (int64_t)genes[g].begin - 1 + 3 * (int64_t)k;
+            const int64_t c = r - (int64_t)ctx->win_begin;
+            if (c < 0 || c + 2 >= (int64_t)ctx->n_cols) continue;
+            uint8_t cfg = JL_REF_MAJORITY;
+            if (refseq) {
+                if ((uint64_t)r + 2 >= ref_len || refseq[r] > 3 || refseq[r + 1] > 3 || refseq[r + 2] > 3) cfg = JL_REF_SKIP;
+                else cfg = (uint8_t)(16 * refseq[r] + 4 * refseq[r + 1] + refseq[r + 2]);
+            }
+            ctx->h_pos_gene.push_back(g);
+            ctx->h_pos_codon.push_back(k + 1);
+            ctx->h_pos_col.push_back((uint32_t)c);
+            refcfg.push_back(cfg);
+            colflag[c] |= 1;
+        }
+    }
+    ctx->default_n_tests = n_tests;
+    ctx->P = (uint32_t)ctx->h_pos_col.size();
+    if (refseq)
+        for (uint32_t c = 0; c < ctx->n_cols; ++c) {
+            const uint64_t r = (uint64_t)c + ctx->win_begin;
+            guess[c] = (r < ref_len && refseq[r] < 4) ? refseq[r] : 0;
+        }
+
+    int rc;
+    if (ctx->col_capacity < ctx->n_cols) {
+        if ((rc = regrow(ctx, &ctx->d_colflag, ctx->n_cols))) return rc;
+        if ((rc = regrow(ctx, &ctx->d_guess, ctx->n_cols))) return rc;
+        if ((rc = regrow(ctx, &ctx->d_col2pos, ctx->n_cols))) return rc;
+        if ((rc = regrow(ctx, &ctx->d_varcol, ctx->n_cols))) return rc;
+        ctx->counts_words = (size_t)ctx->n_cols * (6 + 64);
+        if ((rc = regrow(ctx, &ctx->d_counts, ctx->counts_words))) return rc;
+        ctx->col_capacity = ctx->n_cols;
+    }
+    ctx->counts_words = (size_t)ctx->n_cols * (6 + 64);
+    ctx->d_hist = ctx->d_counts + (size_t)ctx->n_cols * 6;
+    const size_t P = ctx->P ? ctx->P : 1;
+    if (ctx->pos_capacity < P) {
+        if ((rc = regrow(ctx, &ctx->d_pos_gene, P))) return rc;
+        if ((rc = regrow(ctx, &ctx->d_pos_codon, P))) return rc;
+        if ((rc = regrow(ctx, &ctx->d_pos_col, P))) return rc;
+        if ((rc = regrow(ctx, &ctx->d_pos_refcfg, P))) return rc;
+        if ((rc = regrow(ctx, &ctx->d_called, P))) return rc;
+        if ((rc = regrow(ctx, &ctx->d_cand_p, P * 64))) return rc;
+        if ((rc = regrow(ctx, &ctx->d_cand_lp, P * 64))) return rc;
+        if ((rc = regrow(ctx, &ctx->d_cand_e, P * 64))) return rc;
+        if ((rc = regrow(ctx, &ctx->d_pos_cov, P))) return rc;
+        if ((rc = regrow(ctx, &ctx->d_pos_ref, P))) return rc;
+        if ((rc = regrow(ctx, &ctx->d_drm, P))) return rc;
+        ctx->pos_capacity = P;
+    }
+    hipStream_t st = ctx->stream;
+    JL_HIP(ctx, hipMemcpyAsync(ctx->d_colflag, colflag.data(), ctx->n_cols, hipMemcpyHostToDevice, st));
+    JL_HIP(ctx, hipMemcpyAsync(ctx->d_guess, guess.data(), ctx->n_cols, hipMemcpyHostToDevice, st));
+    if (ctx->P) {
+        JL_HIP(ctx, hipMemcpyAsync(ctx->d_pos_gene, ctx->h_pos_gene.data(), P * 4, hipMemcpyHostToDevice, st));
+        JL_HIP(ctx, hipMemcpyAsync(ctx->d_pos_codon, ctx->h_pos_codon.data(), P * 4, hipMemcpyHostToDevice, st));
+        JL_HIP(ctx, hipMemcpyAsync(ctx->d_pos_col, ctx->h_pos_col.data(), P * 4, hipMemcpyHostToDevice, st));
+        JL_HIP(ctx, hipMemcpyAsync(ctx->d_pos_refcfg, refcfg.data(), P, hipMemcpyHostToDevice, st));
+    }
+    // the staging vectors above are pageable: wait before they go out of scope
+    JL_HIP(ctx, hipStreamSynchronize(st));
+    ctx->plan_valid = true;
+    return JL_OK;
+}
+
+static bool same_plan(const jl_ctx *ctx, const jl_gene *genes, uint32_t n_genes, const uint8_t *refseq, uint32_t ref_len)
+{
+    if (!ctx->plan_valid || ctx->genes.size() != n_genes) return false;
+    if (n_genes && memcmp(ctx->genes.data(), genes, n_genes * sizeof(jl_gene)) != 0) return false;
+    if (ctx->have_ref != (refseq != nullptr)) return false;
+    if (refseq && (ctx->refseq.size() != ref_len || memcmp(ctx->refseq.data(), refseq, ref_len) != 0)) return false;
+    return true;
+}
+
+int jl_pileup_async(jl_ctx *ctx, const jl_gene *genes, uint32_t n_genes, const uint8_t *refseq, uint32_t ref_len)
+{
+    if (!ctx || (!genes && n_genes)) return JL_ERR_ARG;
+    if (!ctx->d_msa) return jl_fail(ctx, JL_ERR_STATE, "no resident matrix: call jl_msa_upload/alloc/adopt first");
+    JL_HIP(ctx, hipSetDevice(ctx->device));
+    if (!same_plan(ctx, genes, n_genes, refseq, ref_len)) {
+        int rc = build_plan(ctx, genes, n_genes, refseq, ref_len);
+        if (rc) return rc;
+    }
+    JL_HIP(ctx, hipMemsetAsync(ctx->d_counts, 0, ctx->counts_words * sizeof(uint32_t), ctx->stream));
+    if (!ctx->have_ref) jl_launch_guess(ctx);
+    jl_launch_pileup(ctx);
+    JL_HIP(ctx, hipGetLastError());
+    ctx->pileup_done = true;
+    ctx->call_done = ctx->phase_done = false;
+    return JL_OK;
+}
+
+uint32_t jl_n_positions(const jl_ctx *ctx) { return ctx ? ctx->P : 0; }
+
+int jl_pileup_fetch(jl_ctx *ctx, uint32_t *col_counts, uint32_t *pos_gene, uint32_t *pos_codon, uint32_t *pos_col,
+                    uint32_t *hist, uint32_t *coverage)
+{
+    if (!ctx) return JL_ERR_ARG;
+    if (!ctx->pileup_done) return jl_fail(ctx, JL_ERR_STATE, "jl_pileup_fetch before jl_pileup_async");
+    hipStream_t st = ctx->stream;
+    if (col_counts)
+        JL_HIP(ctx, hipMemcpyAsync(col_counts, ctx->d_counts, (size_t)ctx->n_cols * 6 * 4, hipMemcpyDeviceToHost, st));
+    std::vector<uint32_t> full;
+    if ((hist || coverage) && ctx->P) {
+        full.resize((size_t)ctx->n_cols * 64);
+        JL_HIP(ctx, hipMemcpyAsync(full.data(), ctx->d_hist, full.size() * 4, hipMemcpyDeviceToHost, st));
+    }
+    JL_HIP(ctx, hipStreamSynchronize(st));
+    for (uint32_t p = 0; p < ctx->P; ++p) {
+        if (pos_gene) pos_gene[p] = ctx->h_pos_gene[p];
+        if (pos_codon) pos_codon[p] = ctx->h_pos_codon[p];
+        if (pos_col) pos_col[p] = ctx->h_pos_col[p];
+        if (hist || coverage) {
+            const uint32_t *src = full.data() + (size_t)ctx->h_pos_col[p] * 64;
+            uint32_t cov = 0;
+            for (int j = 0; j < 64; ++j) cov += src[j];
+            if (hist) memcpy(hist + (size_t)p * 64, src, 64 * 4);
+            if (coverage) coverage[p] = cov;
+        }
+    }
+    return JL_OK;
+}
+
+int jl_call_async(jl_ctx *ctx, const jl_params *prm, const uint64_t *drm_masks)
+{
+    if (!ctx || !prm) return JL_ERR_ARG;
+    if (!ctx->pileup_done) return jl_fail(ctx, JL_ERR_STATE, "jl_call_async before jl_pileup_async");
+    if (prm->tail != 0) return jl_fail(ctx, JL_ERR_ARG, "only the one-sided (greater) tail is implemented");
+    if (!(prm->alpha > 0.0) || !(prm->err.match > 0.0) || !(prm->err.substitution >= 0.0))
+        return jl_fail(ctx, JL_ERR_ARG, "alpha/match must be > 0 and substitution >= 0");
+    JL_HIP(ctx, hipSetDevice(ctx->device));
+    if (drm_masks && ctx->P) {
+        JL_HIP(ctx, hipMemcpyAsync(ctx->d_drm, drm_masks, (size_t)ctx->P * 8, hipMemcpyHostToDevice, ctx->stream));
+        JL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    const double n_tests = prm->n_tests > 0.0 ? prm->n_tests : ctx->default_n_tests;
+    jl_launch_call(ctx, prm, n_tests, drm_masks != nullptr);
+    JL_HIP(ctx, hipGetLastError());
+    ctx->call_done = true;
+    ctx->phase_done = false;
+    return JL_OK;
+}
+
+int jl_call_fetch(jl_ctx *ctx, jl_variant *out, uint32_t cap, uint32_t *n_out)
+{
+    if (!ctx || !n_out || (!out && cap)) return JL_ERR_ARG;
+    if (!ctx->call_done) return jl_fail(ctx, JL_ERR_STATE, "jl_call_fetch before jl_call_async");
+    uint32_t n = 0;
+    JL_HIP(ctx, hipMemcpyAsync(&n, ctx->d_nvar, 4, hipMemcpyDeviceToHost, ctx->stream));
+    JL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *n_out = n;
+    uint32_t have = n < JL_VARIANT_CAP ? n : JL_VARIANT_CAP;
+    uint32_t take = have < cap ? have : cap;
+    if (take) {
+        JL_HIP(ctx, hipMemcpyAsync(out, ctx->d_variants, (size_t)take * sizeof(jl_variant), hipMemcpyDeviceToHost, ctx->stream));
+        JL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    if (n > take) return jl_fail(ctx, JL_ERR_OVERFLOW, "%u variant rows, capacity %u (device table holds %u)", n, cap, JL_VARIANT_CAP);
+    return JL_OK;
+}
+
+int jl_variant_table_device(jl_ctx *ctx, void **d_rows, void **d_count, uint32_t *cap_rows)
+{
+    if (!ctx) return JL_ERR_ARG;
+    if (d_rows) *d_rows = ctx->d_variants;
+    if (d_count) *d_count = ctx->d_nvar;
+    if (cap_rows) *cap_rows = JL_VARIANT_CAP;
+    return JL_OK;
+}
+
+/* ---------------------------------------------------------------- phase */
+
+static int reserve_phase(jl_ctx *ctx, uint32_t kwords_needed)
+{
+    const size_t reads_pad = (size_t)ctx->col_stride * 2;
+    int rc;
+    if (ctx->reads_capacity < reads_pad) {
+        uint64_t slots = 1024;
+        while (slots < 2 * (uint64_t)ctx->n_reads) slots <<= 1;
+        ctx->table_slots = slots;
+        if ((rc = regrow(ctx, &ctx->d_flagw, reads_pad / 8))) return rc;
+        if ((rc = regrow(ctx, &ctx->d_read_slot, reads_pad))) return rc;
+        if ((rc = regrow(ctx, &ctx->d_read_hap, reads_pad))) return rc;
+        if ((rc = regrow(ctx, &ctx->d_occupied, reads_pad))) return rc;
+        if ((rc = regrow(ctx, &ctx->d_slot_rep, (size_t)slots))) return rc;
+        if ((rc = regrow(ctx, &ctx->d_slot_count, (size_t)slots))) return rc;
+        if ((rc = regrow(ctx, &ctx->d_slot_hap, (size_t)slots))) return rc;
+        ctx->reads_capacity = reads_pad;
+        ctx->keys_capacity = 0;
+    }
+    const size_t need = (size_t)kwords_needed * reads_pad;
+    if (ctx->keys_capacity < need) {
+        if ((rc = regrow(ctx, &ctx->d_keys, need))) return rc;
+        ctx->keys_capacity = need;
+    }
+    ctx->keys_words = (uint32_t)(ctx->keys_capacity / reads_pad);
+    return JL_OK;
+}
+
+int jl_phase_async(jl_ctx *ctx, const jl_variant *variants, uint32_t n_var, uint32_t min_reads)
+{
+    if (!ctx) return JL_ERR_ARG;
+    if (!ctx->d_msa) return jl_fail(ctx, JL_ERR_STATE, "no resident matrix");
+    if (!ctx->d_col2pos) return jl_fail(ctx, JL_ERR_STATE, "jl_phase_async before jl_pileup_async");
+    JL_HIP(ctx, hipSetDevice(ctx->device));
+    uint32_t kwords;
+    if (variants) {
+        if (n_var > JL_VARIANT_CAP) return jl_fail(ctx, JL_ERR_OVERFLOW, "%u variants, table holds %u", n_var, JL_VARIANT_CAP);
+        if (n_var) JL_HIP(ctx, hipMemcpyAsync(ctx->d_variants, variants, (size_t)n_var * sizeof(jl_variant), hipMemcpyHostToDevice, ctx->stream));
+        uint32_t cnt[2] = {n_var, 0};
+        JL_HIP(ctx, hipMemcpyAsync(ctx->d_nvar, cnt, 8, hipMemcpyHostToDevice, ctx->stream));
+        JL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        kwords = (n_var + JL_POS_PER_WORD - 1) / JL_POS_PER_WORD;
+    } else {
+        if (!ctx->call_done) return jl_fail(ctx, JL_ERR_STATE, "jl_phase_async(NULL) needs jl_call_async first");
+        // The row count lives on the device.  Keep what is allocated (at least 4 words = 40 variant
+        // positions); if a run needs more, the plan kernel flags it and jl_phase_fetch re-runs it exactly.
+        kwords = ctx->keys_words > 4 ? ctx->keys_words : 4;
+    }
+    if (kwords == 0) kwords = 1;
+    int rc = reserve_phase(ctx, kwords);
+    if (rc) return rc;
+    ctx->last_min_reads = min_reads;
+    jl_launch_phase(ctx, min_reads);
+    JL_HIP(ctx, hipGetLastError());
+    ctx->phase_done = true;
+    return JL_OK;
+}
+
+int jl_phase_fetch(jl_ctx *ctx, jl_phase_summary *summary, uint32_t *pos_cols, uint32_t *hap_count,
+                   uint8_t *hap_pattern, uint8_t *hit, uint16_t *read_hap, uint32_t *cooc, uint32_t cap_var)
+{
+    if (!ctx) return JL_ERR_ARG;
+    if (!ctx->phase_done) return jl_fail(ctx, JL_ERR_STATE, "jl_phase_fetch before jl_phase_async");
+    hipStream_t st = ctx->stream;
+    jl_phase_meta meta;
+    JL_HIP(ctx, hipMemcpyAsync(&meta, ctx->d_meta, sizeof meta, hipMemcpyDeviceToHost, st));
+    if (read_hap) JL_HIP(ctx, hipMemcpyAsync(read_hap, ctx->d_read_hap, (size_t)ctx->n_reads * 2, hipMemcpyDeviceToHost, st));
+    JL_HIP(ctx, hipStreamSynchronize(st));
+    if (meta.overflow & 4u) {
+        // more variant positions than the resident key buffer covered: grow it and run phasing again
+        int rc = reserve_phase(ctx, (meta.vp_true + JL_POS_PER_WORD - 1) / JL_POS_PER_WORD);
+        if (rc) return rc;
+        jl_launch_phase(ctx, ctx->last_min_reads);
+        JL_HIP(ctx, hipGetLastError());
+        JL_HIP(ctx, hipMemcpyAsync(&meta, ctx->d_meta, sizeof meta, hipMemcpyDeviceToHost, st));
+        if (read_hap) JL_HIP(ctx, hipMemcpyAsync(read_hap, ctx->d_read_hap, (size_t)ctx->n_reads * 2, hipMemcpyDeviceToHost, st));
+        JL_HIP(ctx, hipStreamSynchronize(st));
+    }
+    if (summary) *summary = meta.summary;
+    const uint32_t vp = meta.vp, H = meta.summary.n_haplotypes, nv = meta.n_var;
+    if ((pos_cols || hap_pattern) && vp > cap_var) return jl_fail(ctx, JL_ERR_OVERFLOW, "%u variant positions, caller capacity %u", vp, cap_var);
+    if ((hit || cooc) && nv > cap_var) return jl_fail(ctx, JL_ERR_OVERFLOW, "%u variants, caller capacity %u", nv, cap_var);
+    if (pos_cols && vp) JL_HIP(ctx, hipMemcpyAsync(pos_cols, ctx->d_vpcols, (size_t)vp * 4, hipMemcpyDeviceToHost, st));
+    if (hap_count && H) JL_HIP(ctx, hipMemcpyAsync(hap_count, ctx->d_hap_count, (size_t)H * 4, hipMemcpyDeviceToHost, st));
+    if (hap_pattern && H && vp)
+        JL_HIP(ctx, hipMemcpy2DAsync(hap_pattern, cap_var, ctx->d_hap_pattern, JL_VARIANT_CAP, vp, H, hipMemcpyDeviceToHost, st));
+    if (hit && nv && H)
+        JL_HIP(ctx, hipMemcpy2DAsync(hit, JL_MAX_HAPLOTYPES, ctx->d_hit, JL_MAX_HAPLOTYPES, H, nv, hipMemcpyDeviceToHost, st));
+    if (cooc && nv) {
+        const uint32_t n = nv < ctx->cooc_cap ? nv : ctx->cooc_cap;
+        JL_HIP(ctx, hipMemcpy2DAsync(cooc, (size_t)cap_var * 4, ctx->d_cooc, (size_t)ctx->cooc_cap * 4, (size_t)n * 4, n, hipMemcpyDeviceToHost, st));
+    }
+    JL_HIP(ctx, hipStreamSynchronize(st));
+    if (meta.overflow & 1u) return jl_fail(ctx, JL_ERR_OVERFLOW, "more than %u haplotype candidates", JL_CAND_CAP);
+    return JL_OK;
+}
+
+/* ---------------------------------------------------------------- numerics self-check */
+
+int jl_fisher_eval(jl_ctx *ctx, const uint32_t *a, const uint32_t *c, const uint32_t *cov, uint32_t n, double *p,
+                   double *log_p)
+{
+    if (!ctx || !a || !c || !cov || !p || !log_p) return JL_ERR_ARG;
+    if (n == 0) return JL_OK;
+    for (uint32_t i = 0; i < n; ++i)
+        if (a[i] > cov[i] || c[i] > cov[i]) return jl_fail(ctx, JL_ERR_ARG, "table %u: a and c must be <= cov", i);
+    JL_HIP(ctx, hipSetDevice(ctx->device));
+    uint32_t *d_in = nullptr;
+    double *d_out = nullptr;
+    JL_HIP(ctx, hipMalloc(&d_in, (size_t)n * 12));
+    if (hipMalloc(&d_out, (size_t)n * 16) != hipSuccess) { hipFree(d_in); return jl_fail(ctx, JL_ERR_MEMORY, "fisher_eval buffers"); }
+    hipStream_t st = ctx->stream;
+    hipError_t e = hipMemcpyAsync(d_in, a, (size_t)n * 4, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_in + n, c, (size_t)n * 4, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_in + 2 * (size_t)n, cov, (size_t)n * 4, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) {
+        jl_launch_fisher_eval(ctx, n, d_in, d_in + n, d_in + 2 * (size_t)n, d_out, d_out + n);
+        e = hipMemcpyAsync(p, d_out, (size_t)n * 8, hipMemcpyDeviceToHost, st);
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(log_p, d_out + n, (size_t)n * 8, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    hipFree(d_in);
+    hipFree(d_out);
+    if (e != hipSuccess) return jl_fail(ctx, JL_ERR_DEVICE, "fisher_eval: %s", hipGetErrorString(e));
+    return JL_OK;
+}
+
+/* ---------------------------------------------------------------- timing */
+
+int jl_time_pileup(jl_ctx *ctx, uint32_t reps, float *ms_avg)
+{
+    if (!ctx || !ms_avg || reps == 0) return JL_ERR_ARG;
+    if (!ctx->plan_valid) return jl_fail(ctx, JL_ERR_STATE, "jl_time_pileup needs a plan: call jl_pileup_async once first");
+    JL_HIP(ctx, hipSetDevice(ctx->device));
+    float total = 0.f;
+    for (uint32_t r = 0; r < reps; ++r) {
+        // the counters are zeroed outside the timed interval; only the kernel sits between the events
+        JL_HIP(ctx, hipMemsetAsync(ctx->d_counts, 0, ctx->counts_words * sizeof(uint32_t), ctx->stream));
+        JL_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+        jl_launch_pileup(ctx);
+        JL_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+        JL_HIP(ctx, hipEventSynchronize(ctx->ev1));
+        float ms = 0.f;
+        JL_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+        total += ms;
+    }
+    *ms_avg = total / (float)reps;
+    ctx->pileup_done = true;
+    ctx->call_done = ctx->phase_done = false;
+    return JL_OK;
+}
+
+/* ---------------------------------------------------------------- multi-GPU */
+
+struct jl_comm {
+    ncclComm_t comm = nullptr;
+    int rank = 0, world = 1;
+    jl_variant *d_all = nullptr;   // [world][JL_VARIANT_CAP]
+    uint32_t *d_counts = nullptr;  // [world][2]
+};
+
+int jl_comm_unique_id(uint8_t id[128])
+{
+    static_assert(sizeof(ncclUniqueId) == 128, "RCCL unique id is 128 bytes");
+    ncclUniqueId u;
+    if (ncclGetUniqueId(&u) != ncclSuccess) return JL_ERR_COMM;
+    memcpy(id, &u, 128);
+    return JL_OK;
+}
+
+int jl_comm_create(jl_ctx *ctx, const uint8_t id[128], int rank, int world, jl_comm **out)
+{
+    if (!ctx || !id || !out || world < 1 || rank < 0 || rank >= world) return JL_ERR_ARG;
+    JL_HIP(ctx, hipSetDevice(ctx->device));
+    jl_comm *c = new (std::nothrow) jl_comm();
+    if (!c) return JL_ERR_MEMORY;
+    c->rank = rank;
+    c->world = world;
+    ncclUniqueId u;
+    memcpy(&u, id, 128);
+    ncclResult_t r = ncclCommInitRank(&c->comm, world, u, rank);
+    if (r != ncclSuccess) {
+        delete c;
+        return jl_fail(ctx, JL_ERR_COMM, "ncclCommInitRank: %s", ncclGetErrorString(r));
+    }
+    if (hipMalloc(&c->d_all, sizeof(jl_variant) * JL_VARIANT_CAP * world) != hipSuccess ||
+        hipMalloc(&c->d_counts, 8 * world) != hipSuccess) {
+        jl_comm_destroy(c);
+        return jl_fail(ctx, JL_ERR_MEMORY, "comm buffers");
+    }
+    *out = c;
+    return JL_OK;
+}
+
+void jl_comm_destroy(jl_comm *c)
+{
+    if (!c) return;
+    if (c->comm) ncclCommDestroy(c->comm);
+    if (c->d_all) hipFree(c->d_all);
+    if (c->d_counts) hipFree(c->d_counts);
+    delete c;
+}
+
+int jl_allgather_variants(jl_ctx *ctx, jl_comm *c, jl_variant *all_rows, uint32_t *all_counts, uint32_t cap_rows)
+{
+    if (!ctx || !c || !all_rows || !all_counts) return JL_ERR_ARG;
+    if (!ctx->call_done) return jl_fail(ctx, JL_ERR_STATE, "jl_allgather_variants before jl_call_async");
+    if (cap_rows == 0 || cap_rows > JL_VARIANT_CAP) return jl_fail(ctx, JL_ERR_ARG, "cap_rows must be 1..%u", JL_VARIANT_CAP);
+    JL_HIP(ctx, hipSetDevice(ctx->device));
+    // the one collective of the path: fixed-stride table (+ row counts) over RCCL/xGMI, on the ctx stream
+    ncclResult_t r = ncclGroupStart();
+    if (r == ncclSuccess) r = ncclAllGather(ctx->d_variants, c->d_all, sizeof(jl_variant) * (size_t)cap_rows, ncclUint8, c->comm, ctx->stream);
+    if (r == ncclSuccess) r = ncclAllGather(ctx->d_nvar, c->d_counts, 8, ncclUint8, c->comm, ctx->stream);
+    if (r == ncclSuccess) r = ncclGroupEnd();
+    if (r != ncclSuccess) return jl_fail(ctx, JL_ERR_COMM, "ncclAllGather: %s", ncclGetErrorString(r));
+    std::vector<uint32_t> cnt(2 * (size_t)c->world);
+    JL_HIP(ctx, hipMemcpyAsync(all_rows, c->d_all, sizeof(jl_variant) * (size_t)cap_rows * c->world, hipMemcpyDeviceToHost, ctx->stream));
+    JL_HIP(ctx, hipMemcpyAsync(cnt.data(), c->d_counts, 8 * (size_t)c->world, hipMemcpyDeviceToHost, ctx->stream));
+    JL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    int rc = JL_OK;
+    for (int k = 0; k < c->world; ++k) {
+        all_counts[k] = cnt[2 * k];
+        if (cnt[2 * k] > cap_rows) rc = JL_ERR_OVERFLOW;
+    }
+    if (rc) return jl_fail(ctx, rc, "a rank produced more than %u variant rows", cap_rows);
+    return JL_OK;
+}
+
+}  // extern "C"

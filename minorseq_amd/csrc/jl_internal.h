@@ -1,0 +1,127 @@
+// jl_internal.h — private to libjuliet_hip.so: context layout, launch helpers, kernel entry points.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/juliet_hip.h"
+#include "jl_synth.h"
+
+#define JL_VARIANT_CAP 4096u      // rows of the resident variant table (all-gather stride)
+#define JL_CAND_CAP 4096u         // haplotype candidates (groups with >= min_reads) the selector can rank
+#define JL_POS_PER_WORD 10u       // variant positions per 64-bit key word (6 bits each)
+#define JL_PILEUP_TILE_BYTES 4096u  // bytes of one column a 256-thread block reads per iteration (16 B / lane)
+
+// resolved reference codon per position
+#define JL_REF_MAJORITY 0xFFu
+#define JL_REF_SKIP 0xFEu
+
+struct jl_phase_meta {  // device-resident scalars of one phasing run
+    uint32_t n_var;     // rows used
+    uint32_t vp;        // distinct variant columns
+    uint32_t kwords;    // 64-bit words per read key
+    uint32_t n_occupied;
+    uint32_t overflow;  // bit0: more than JL_CAND_CAP candidates; bit1: more than JL_MAX_HAPLOTYPES qualified;
+                        // bit2: the key buffer was too small for vp_true positions (phasing skipped, host re-runs)
+    uint32_t vp_true;   // distinct variant columns before the capacity check
+    uint32_t pad_[2];
+    jl_phase_summary summary;
+};
+
+struct jl_ctx {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string err;
+
+    // ---- resident MSA (column-packed nibbles)
+    uint8_t *d_msa = nullptr;
+    bool own_msa = false;
+    size_t msa_capacity = 0;
+    uint64_t n_reads = 0;
+    uint32_t n_cols = 0;
+    uint64_t col_stride = 0;
+    uint32_t win_begin = 0;
+
+    // ---- pileup plan (host copies + device arrays)
+    std::vector<jl_gene> genes;
+    std::vector<uint8_t> refseq;
+    bool have_ref = false;
+    bool plan_valid = false;
+    uint32_t P = 0;
+    double default_n_tests = 0.0;
+    std::vector<uint32_t> h_pos_gene, h_pos_codon, h_pos_col;
+    uint32_t *d_pos_gene = nullptr, *d_pos_codon = nullptr, *d_pos_col = nullptr;
+    uint8_t *d_pos_refcfg = nullptr;
+    size_t pos_capacity = 0;
+    uint8_t *d_colflag = nullptr;  // [n_cols] bit0: a codon starts here
+    uint8_t *d_guess = nullptr;    // [n_cols] base the codon compare is seeded with (never affects results)
+    size_t col_capacity = 0;
+
+    // ---- pileup outputs: one zeroed region = col counts [n_cols][6] then hist [n_cols][64]
+    uint32_t *d_counts = nullptr;
+    uint32_t *d_hist = nullptr;
+    size_t counts_words = 0;
+    bool pileup_done = false;
+
+    // ---- call
+    uint64_t *d_called = nullptr;  // [P] mask of called codons
+    double *d_cand_p = nullptr;    // [P][64]
+    double *d_cand_lp = nullptr;   // [P][64]
+    uint32_t *d_cand_e = nullptr;  // [P][64]
+    uint32_t *d_pos_cov = nullptr; // [P]
+    uint8_t *d_pos_ref = nullptr;  // [P] resolved reference codon or JL_REF_SKIP
+    uint64_t *d_drm = nullptr;     // [P] optional
+    jl_variant *d_variants = nullptr;  // [JL_VARIANT_CAP]
+    uint32_t *d_nvar = nullptr;        // [0] rows needed, [1] spare
+    bool call_done = false;
+
+    // ---- phase
+    jl_phase_meta *d_meta = nullptr;
+    uint32_t *d_vpcols = nullptr;   // [JL_VARIANT_CAP]
+    uint32_t *d_col2pos = nullptr;  // [n_cols]
+    uint8_t *d_varcol = nullptr;    // [n_cols] scratch flags
+    uint64_t *d_keys = nullptr;     // [kwords_cap][reads_pad]
+    size_t keys_capacity = 0;       // in uint64
+    uint32_t keys_words = 0;        // 64-bit words per read the key buffer holds
+    uint32_t last_min_reads = 10;
+    uint32_t *d_flagw = nullptr;    // [reads_pad/8] nibble flags
+    uint32_t *d_read_slot = nullptr;  // [reads_pad]
+    uint16_t *d_read_hap = nullptr;   // [reads_pad]
+    uint32_t *d_slot_rep = nullptr, *d_slot_count = nullptr;  // [M]
+    uint16_t *d_slot_hap = nullptr;                           // [M]
+    uint32_t *d_occupied = nullptr;                           // [reads_pad]
+    uint64_t table_slots = 0;
+    size_t reads_capacity = 0;
+    uint32_t *d_hap_count = nullptr;   // [JL_MAX_HAPLOTYPES]
+    uint8_t *d_hap_pattern = nullptr;  // [JL_MAX_HAPLOTYPES][JL_VARIANT_CAP]
+    uint8_t *d_hit = nullptr;          // [JL_VARIANT_CAP][JL_MAX_HAPLOTYPES]
+    uint32_t *d_cooc = nullptr;        // [cooc_cap][cooc_cap]
+    uint32_t cooc_cap = 256;
+    bool phase_done = false;
+
+    // ---- timing
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+// status helpers -----------------------------------------------------------------------------
+int jl_fail(jl_ctx *ctx, int status, const char *fmt, ...);
+#define JL_HIP(ctx, expr)                                                                            \
+    do {                                                                                             \
+        hipError_t e_ = (expr);                                                                      \
+        if (e_ != hipSuccess)                                                                        \
+            return jl_fail(ctx, e_ == hipErrorOutOfMemory ? JL_ERR_MEMORY : JL_ERR_DEVICE, "%s: %s", \
+                           #expr, hipGetErrorString(e_));                                            \
+    } while (0)
+
+// kernel launchers (defined in the .hip files) -------------------------------------------------
+void jl_launch_guess(jl_ctx *ctx);
+void jl_launch_pileup(jl_ctx *ctx);
+void jl_launch_call(jl_ctx *ctx, const jl_params *prm, double n_tests, bool use_drm);
+void jl_launch_phase(jl_ctx *ctx, uint32_t min_reads);
+void jl_launch_synth(jl_ctx *ctx, const jl_synth_plan *plan, const uint8_t *d_ref);
+void jl_launch_pack_rows(jl_ctx *ctx, const uint8_t *d_rows);
+void jl_launch_fisher_eval(jl_ctx *ctx, uint32_t n, const uint32_t *a, const uint32_t *c, const uint32_t *cov,
+                           double *p, double *lp);

@@ -74,7 +74,6 @@ JL_HD uint32_t jl_synth_cell(const jl_synth_plan *pl, uint64_t read, uint32_t co
 }
 
 // host-side plan construction (same in C++ and numpy): thresholds, edit sites
-#if !defined(__HIP_DEVICE_COMPILE__)
 #include <math.h>
 static inline void jl_synth_make_plan(jl_synth_plan *pl, uint64_t seed, uint32_t n_cols, double sub_rate,
                                       double del_rate, double mask_rate, double partial_rate,
@@ -111,4 +110,3 @@ static inline void jl_synth_reference(uint64_t seed, uint32_t n_cols, uint8_t *r
         if (cod == 48u || cod == 50u || cod == 56u) ref[c] = 1;  // TAA TAG TGA -> CAA CAG CGA
     }
 }
-#endif

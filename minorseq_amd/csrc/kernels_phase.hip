@@ -1,0 +1,408 @@
+// kernels_phase.hip — read x variant co-occurrence phasing.
+// Behaviour: doc/JULIET.md:192-211 (--mode-phasing, haplotype_hit, haplotype block), :253-254 (>= 10 reads),
+// :372-381 (reported / insufficient / damaged, overlapping marginals); docs/SPEC.md §8.
+//
+// Pipeline (all on the ctx stream, no host round trip):
+//   plan    distinct variant columns, ascending, from the resident variant table
+//   keys    per read: flags (gap / heteroduplex / partial) and the pattern of codon indices at the Vp
+//           positions, 6 bits each, 10 positions per 64-bit word, first position most significant so that
+//           word-wise unsigned comparison is the lexicographic order of patterns
+//   group   exact grouping of clean reads: wave-level match-any collapses equal keys, one leader per group
+//           inserts into an open-addressing table keyed by the FULL key (representative read + compare)
+//   select  groups with >= min_reads ranked by (count desc, pattern asc), haplotype ids, patterns, hit matrix
+//   assign  per-read haplotype id
+//   cooc    variant x variant co-occurrence over reported haplotypes
+#include "jl_internal.h"
+
+namespace {
+
+constexpr uint32_t kM1 = 0x11111111u;
+constexpr uint32_t kEmpty = 0xFFFFFFFFu;
+
+__device__ __forceinline__ uint32_t wave_sum_all(uint32_t v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ uint64_t mix64(uint64_t z)
+{
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+// ---------------------------------------------------------------------------------------- plan
+__global__ __launch_bounds__(1024) void phase_plan_kernel(const jl_variant *__restrict__ variants,
+                                                           const uint32_t *__restrict__ n_rows, uint32_t cap,
+                                                           uint32_t n_cols, uint8_t *__restrict__ varcol,
+                                                           uint32_t *__restrict__ vpcols,
+                                                           uint32_t *__restrict__ col2pos, uint32_t kwords_cap,
+                                                           jl_phase_meta *__restrict__ meta)
+{
+    __shared__ uint32_t s_wave[16];
+    __shared__ uint32_t s_running;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6;
+    uint32_t nv = n_rows[0];
+    if (nv > cap) nv = cap;
+    for (uint32_t c = tid; c < n_cols; c += 1024u) varcol[c] = 0;
+    if (tid == 0) s_running = 0;
+    __syncthreads();
+    for (uint32_t v = tid; v < nv; v += 1024u) {
+        const uint32_t c = variants[v].col;
+        if (c + 2u < n_cols) varcol[c] = 1;
+    }
+    __syncthreads();
+    for (uint32_t base = 0; base < n_cols; base += 1024u) {
+        const uint32_t c = base + tid;
+        const uint32_t f = c < n_cols ? varcol[c] : 0u;
+        uint32_t inc = f;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t u = __shfl_up(inc, o, 64);
+            if ((int)lane >= o) inc += u;
+        }
+        if (lane == 63) s_wave[wid] = inc;
+        __syncthreads();
+        uint32_t off = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) {
+            const uint32_t x = s_wave[w];
+            if (w < (int)wid) off += x;
+            total += x;
+        }
+        if (f) {
+            const uint32_t p = s_running + off + inc - 1u;
+            vpcols[p] = c;
+            col2pos[c] = p;
+        }
+        __syncthreads();
+        if (tid == 0) s_running += total;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        uint32_t vp = s_running;
+        uint32_t kw = (vp + JL_POS_PER_WORD - 1u) / JL_POS_PER_WORD;
+        meta->n_var = nv;
+        meta->vp_true = vp;
+        meta->overflow = 0;
+        if (kw > kwords_cap) {  // key buffer too small: skip, the host re-runs with the exact size
+            meta->overflow = 4u;
+            vp = 0;
+            kw = 0;
+        }
+        meta->vp = vp;
+        meta->kwords = kw;
+        meta->n_occupied = 0;
+        jl_phase_summary z = {0, 0, 0, 0, 0, 0, vp, 0};
+        meta->summary = z;
+    }
+}
+
+// ---------------------------------------------------------------------------------------- keys
+// One lane = one dword of every variant column = 8 consecutive reads.
+__global__ __launch_bounds__(256) void phase_keys_kernel(const uint8_t *__restrict__ msa, uint64_t col_stride,
+                                                          uint64_t n_reads, uint64_t reads_pad,
+                                                          const uint32_t *__restrict__ vpcols,
+                                                          jl_phase_meta *__restrict__ meta,
+                                                          uint64_t *__restrict__ keys, uint32_t *__restrict__ flagw)
+{
+    const uint32_t vp = meta->vp;
+    if (vp == 0) return;
+    const uint64_t t = (uint64_t)blockIdx.x * 256u + threadIdx.x;  // dword index within a column
+    const bool live = t * 4u < col_stride;
+    uint32_t gap = 0, het = 0, par = 0;
+    const uint32_t kwords = meta->kwords;
+    for (uint32_t gw = 0; gw < kwords; ++gw) {
+        uint64_t key[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        const uint32_t p0 = gw * JL_POS_PER_WORD;
+        const uint32_t p1 = min(vp, p0 + JL_POS_PER_WORD);
+        for (uint32_t p = p0; p < p1; ++p) {
+            const uint32_t c = vpcols[p];
+            uint32_t w[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                w[k] = live ? *reinterpret_cast<const uint32_t *>(msa + (uint64_t)(c + k) * col_stride + t * 4u)
+                            : 0x66666666u;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const uint32_t b0 = w[k] & kM1, b1 = (w[k] >> 1) & kM1, b2 = (w[k] >> 2) & kM1;
+                gap |= b2 & ~b1 & ~b0;  // 4 = '-'
+                het |= b2 & b0;         // 5 = 'N'
+                par |= b2 & b1;         // 6 = not covered
+            }
+            const uint32_t hi2 = w[0] & 0x33333333u;
+            const uint32_t lo4 = ((w[1] & 0x33333333u) << 2) | (w[2] & 0x33333333u);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const uint32_t code = (((hi2 >> (4 * r)) & 3u) << 4) | ((lo4 >> (4 * r)) & 15u);
+                key[r] = (key[r] << 6) | code;
+            }
+        }
+        if (live) {
+            uint64_t *dst = keys + (uint64_t)gw * reads_pad + t * 8u;
+#pragma unroll
+            for (int r = 0; r < 8; r += 2) {
+                ulonglong2 v;
+                v.x = key[r];
+                v.y = key[r + 1];
+                *reinterpret_cast<ulonglong2 *>(dst + r) = v;
+            }
+        }
+    }
+    // reads beyond n_reads are padding, not damaged reads
+    uint32_t valid = 0;
+    if (live) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+            if (t * 8u + r < n_reads) valid |= 1u << (4 * r);
+    }
+    gap &= valid; het &= valid; par &= valid;
+    if (live) flagw[t] = gap | (het << 1) | (par << 2) | ((valid ^ kM1) << 3);  // bit3: padding
+    const uint32_t n_gap = wave_sum_all(__popc(gap));
+    const uint32_t n_het = wave_sum_all(__popc(het));
+    const uint32_t n_par = wave_sum_all(__popc(par));
+    const uint32_t n_dam = wave_sum_all(__popc(gap | het | par));
+    if ((threadIdx.x & 63u) == 0) {
+        if (n_dam) atomicAdd(&meta->summary.damaged_reads, n_dam);
+        if (n_gap) atomicAdd(&meta->summary.marginal_gap, n_gap);
+        if (n_het) atomicAdd(&meta->summary.marginal_heteroduplex, n_het);
+        if (n_par) atomicAdd(&meta->summary.marginal_partial, n_par);
+    }
+}
+
+// ---------------------------------------------------------------------------------------- group
+__device__ __forceinline__ bool keys_equal(const uint64_t *__restrict__ keys, uint64_t reads_pad, uint32_t kwords,
+                                           uint64_t i, uint64_t j)
+{
+    for (uint32_t g = 0; g < kwords; ++g)
+        if (keys[(uint64_t)g * reads_pad + i] != keys[(uint64_t)g * reads_pad + j]) return false;
+    return true;
+}
+
+__global__ __launch_bounds__(256) void phase_group_kernel(uint64_t n_reads, uint64_t reads_pad,
+                                                           const uint64_t *__restrict__ keys,
+                                                           const uint32_t *__restrict__ flagw,
+                                                           jl_phase_meta *__restrict__ meta, uint64_t slots_mask,
+                                                           uint32_t *__restrict__ slot_rep,
+                                                           uint32_t *__restrict__ slot_count,
+                                                           uint32_t *__restrict__ occupied,
+                                                           uint32_t *__restrict__ read_slot)
+{
+    const uint32_t kwords = meta->kwords;
+    if (kwords == 0) return;
+    const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u;
+    bool active = false;
+    uint64_t k0 = 0;
+    if (i < n_reads) {
+        const uint32_t f = (flagw[i >> 3] >> (4u * (uint32_t)(i & 7u))) & 15u;
+        active = f == 0;
+        if (active) k0 = keys[i];
+    }
+    uint64_t todo = __ballot(active);
+    while (todo) {  // wave-uniform: one iteration per distinct key in the wave
+        const int leader = __ffsll((unsigned long long)todo) - 1;
+        const uint64_t lk0 = __shfl(k0, leader, 64);
+        const uint64_t li = __shfl(i, leader, 64);
+        bool same = active && k0 == lk0;
+        if (same && kwords > 1) {
+            for (uint32_t g = 1; g < kwords; ++g)
+                if (keys[(uint64_t)g * reads_pad + i] != keys[(uint64_t)g * reads_pad + li]) { same = false; break; }
+        }
+        const uint64_t grp = __ballot(same);
+        uint32_t slot = 0;
+        if ((int)lane == leader) {
+            uint64_t h = mix64(k0 + 0x9E3779B97F4A7C15ull);
+            for (uint32_t g = 1; g < kwords; ++g) h = mix64(h ^ keys[(uint64_t)g * reads_pad + i]);
+            uint64_t s = h & slots_mask;
+            const uint32_t cnt = (uint32_t)__popcll(grp);
+            for (;;) {
+                uint32_t rep = __hip_atomic_load(&slot_rep[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (rep == kEmpty) {
+                    rep = atomicCAS(&slot_rep[s], kEmpty, (uint32_t)i);
+                    if (rep == kEmpty) {
+                        occupied[atomicAdd(&meta->n_occupied, 1u)] = (uint32_t)s;
+                        rep = (uint32_t)i;
+                    }
+                }
+                if (rep == (uint32_t)i || keys_equal(keys, reads_pad, kwords, rep, i)) {
+                    atomicAdd(&slot_count[s], cnt);
+                    break;
+                }
+                s = (s + 1u) & slots_mask;
+            }
+            slot = (uint32_t)s;
+        }
+        slot = __shfl(slot, leader, 64);
+        if (same) {
+            read_slot[i] = slot;
+            active = false;
+        }
+        todo &= ~grp;
+    }
+}
+
+// ---------------------------------------------------------------------------------------- select
+__device__ __forceinline__ uint32_t pattern_code(const uint64_t *__restrict__ keys, uint64_t reads_pad, uint32_t vp,
+                                                 uint32_t rep, uint32_t p)
+{
+    const uint32_t g = p / JL_POS_PER_WORD;
+    const uint32_t in_word = min(JL_POS_PER_WORD, vp - g * JL_POS_PER_WORD);
+    const uint32_t sh = 6u * (in_word - 1u - (p - g * JL_POS_PER_WORD));
+    return (uint32_t)(keys[(uint64_t)g * reads_pad + rep] >> sh) & 63u;
+}
+
+__global__ __launch_bounds__(1024) void phase_select_kernel(uint32_t min_reads, uint64_t reads_pad,
+                                                             const uint64_t *__restrict__ keys,
+                                                             jl_phase_meta *__restrict__ meta,
+                                                             const uint32_t *__restrict__ slot_rep,
+                                                             const uint32_t *__restrict__ slot_count,
+                                                             const uint32_t *__restrict__ occupied,
+                                                             uint16_t *__restrict__ slot_hap,
+                                                             const jl_variant *__restrict__ variants,
+                                                             const uint32_t *__restrict__ col2pos, uint32_t n_cols,
+                                                             uint32_t *__restrict__ hap_count,
+                                                             uint8_t *__restrict__ hap_pattern,
+                                                             uint8_t *__restrict__ hit)
+{
+    __shared__ uint32_t s_cand[JL_CAND_CAP];  // slot of each candidate
+    __shared__ uint32_t s_hrep[JL_MAX_HAPLOTYPES];
+    __shared__ uint32_t s_ncand, s_insufficient, s_reported, s_nhap;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t vp = meta->vp, kwords = meta->kwords, nv = meta->n_var;
+    if (vp == 0) return;
+    if (tid == 0) { s_ncand = 0; s_insufficient = 0; s_reported = 0; s_nhap = 0; }
+    __syncthreads();
+    const uint32_t n_occ = meta->n_occupied;
+    for (uint32_t q = tid; q < n_occ; q += 1024u) {
+        const uint32_t s = occupied[q];
+        const uint32_t c = slot_count[s];
+        if (c >= min_reads) {
+            const uint32_t k = atomicAdd(&s_ncand, 1u);
+            if (k < JL_CAND_CAP) s_cand[k] = s;
+            else { atomicAdd(&s_insufficient, c); slot_hap[s] = JL_HAP_INSUFFICIENT; }
+        } else {
+            atomicAdd(&s_insufficient, c);
+            slot_hap[s] = JL_HAP_INSUFFICIENT;
+        }
+    }
+    __syncthreads();
+    uint32_t ncand = s_ncand;
+    if (ncand > JL_CAND_CAP) {
+        if (tid == 0) meta->overflow |= 1u;
+        ncand = JL_CAND_CAP;
+    }
+    // rank sort: (count desc, pattern asc); patterns are unique so ranks are a permutation
+    for (uint32_t a = tid; a < ncand; a += 1024u) {
+        const uint32_t sa = s_cand[a], ca = slot_count[sa], ra = slot_rep[sa];
+        uint32_t rank = 0;
+        for (uint32_t b = 0; b < ncand; ++b) {
+            if (b == a) continue;
+            const uint32_t sb = s_cand[b], cb = slot_count[sb];
+            if (cb > ca) { ++rank; continue; }
+            if (cb < ca) continue;
+            const uint32_t rb = slot_rep[sb];
+            for (uint32_t g = 0; g < kwords; ++g) {
+                const uint64_t ka = keys[(uint64_t)g * reads_pad + ra], kb = keys[(uint64_t)g * reads_pad + rb];
+                if (kb != ka) { if (kb < ka) ++rank; break; }
+            }
+        }
+        if (rank < JL_MAX_HAPLOTYPES) {
+            hap_count[rank] = ca;
+            s_hrep[rank] = ra;
+            slot_hap[sa] = (uint16_t)rank;
+            atomicAdd(&s_reported, ca);
+            atomicAdd(&s_nhap, 1u);
+        } else {
+            slot_hap[sa] = JL_HAP_INSUFFICIENT;
+            atomicAdd(&s_insufficient, ca);
+        }
+    }
+    __syncthreads();
+    const uint32_t H = s_nhap;
+    if (tid == 0) {
+        if (ncand > JL_MAX_HAPLOTYPES) meta->overflow |= 2u;
+        meta->summary.reported_reads = s_reported;
+        meta->summary.insufficient_reads = s_insufficient;
+        meta->summary.n_haplotypes = H;
+    }
+    for (uint32_t q = tid; q < H * vp; q += 1024u) {
+        const uint32_t h = q / vp, p = q - h * vp;
+        hap_pattern[(uint64_t)h * JL_VARIANT_CAP + p] = (uint8_t)pattern_code(keys, reads_pad, vp, s_hrep[h], p);
+    }
+    for (uint32_t q = tid; q < nv * H; q += 1024u) {
+        const uint32_t v = q / H, h = q - v * H;
+        const uint32_t c = variants[v].col;
+        uint8_t x = 0;
+        if (c + 2u < n_cols) {  // rows outside this window never hit
+            const uint32_t p = col2pos[c];
+            x = pattern_code(keys, reads_pad, vp, s_hrep[h], p) == variants[v].codon;
+        }
+        hit[(uint64_t)v * JL_MAX_HAPLOTYPES + h] = x;
+    }
+}
+
+// ---------------------------------------------------------------------------------------- assign
+__global__ __launch_bounds__(256) void phase_assign_kernel(uint64_t n_reads, const uint32_t *__restrict__ flagw,
+                                                            const jl_phase_meta *__restrict__ meta,
+                                                            const uint32_t *__restrict__ read_slot,
+                                                            const uint16_t *__restrict__ slot_hap,
+                                                            uint16_t *__restrict__ read_hap)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (i >= n_reads) return;
+    uint16_t h = JL_HAP_DAMAGED;
+    if (meta->vp != 0) {
+        const uint32_t f = (flagw[i >> 3] >> (4u * (uint32_t)(i & 7u))) & 15u;
+        if (f == 0) h = slot_hap[read_slot[i]];
+    }
+    read_hap[i] = h;
+}
+
+// ---------------------------------------------------------------------------------------- cooc
+__global__ __launch_bounds__(256) void phase_cooc_kernel(const jl_phase_meta *__restrict__ meta,
+                                                          const uint8_t *__restrict__ hit,
+                                                          const uint32_t *__restrict__ hap_count, uint32_t cooc_cap,
+                                                          uint32_t *__restrict__ cooc)
+{
+    const uint32_t nv = min(meta->n_var, cooc_cap);
+    const uint32_t H = meta->summary.n_haplotypes;
+    const uint32_t total = nv * nv;
+    for (uint32_t q = blockIdx.x * 256u + threadIdx.x; q < total; q += gridDim.x * 256u) {
+        const uint32_t v = q / nv, w = q - v * nv;
+        uint32_t s = 0;
+        for (uint32_t h = 0; h < H; ++h)
+            if (hit[(uint64_t)v * JL_MAX_HAPLOTYPES + h] && hit[(uint64_t)w * JL_MAX_HAPLOTYPES + h]) s += hap_count[h];
+        cooc[(uint64_t)v * cooc_cap + w] = s;
+    }
+}
+
+}  // namespace
+
+void jl_launch_phase(jl_ctx *ctx, uint32_t min_reads)
+{
+    hipStream_t st = ctx->stream;
+    const uint64_t reads_pad = ctx->col_stride * 2u;
+    hipLaunchKernelGGL(phase_plan_kernel, dim3(1), dim3(1024), 0, st, ctx->d_variants, ctx->d_nvar, JL_VARIANT_CAP,
+                       ctx->n_cols, ctx->d_varcol, ctx->d_vpcols, ctx->d_col2pos, ctx->keys_words, ctx->d_meta);
+    // table: representatives empty, counts zero
+    hipMemsetAsync(ctx->d_slot_rep, 0xFF, ctx->table_slots * sizeof(uint32_t), st);
+    hipMemsetAsync(ctx->d_slot_count, 0, ctx->table_slots * sizeof(uint32_t), st);
+    const uint32_t n_dwords = (uint32_t)(ctx->col_stride / 4u);
+    hipLaunchKernelGGL(phase_keys_kernel, dim3((n_dwords + 255u) / 256u), dim3(256), 0, st, ctx->d_msa,
+                       ctx->col_stride, ctx->n_reads, reads_pad, ctx->d_vpcols, ctx->d_meta, ctx->d_keys,
+                       ctx->d_flagw);
+    const uint32_t rblocks = (uint32_t)((ctx->n_reads + 255u) / 256u);
+    hipLaunchKernelGGL(phase_group_kernel, dim3(rblocks), dim3(256), 0, st, ctx->n_reads, reads_pad, ctx->d_keys,
+                       ctx->d_flagw, ctx->d_meta, ctx->table_slots - 1u, ctx->d_slot_rep, ctx->d_slot_count,
+                       ctx->d_occupied, ctx->d_read_slot);
+    hipLaunchKernelGGL(phase_select_kernel, dim3(1), dim3(1024), 0, st, min_reads, reads_pad, ctx->d_keys,
+                       ctx->d_meta, ctx->d_slot_rep, ctx->d_slot_count, ctx->d_occupied, ctx->d_slot_hap,
+                       ctx->d_variants, ctx->d_col2pos, ctx->n_cols, ctx->d_hap_count, ctx->d_hap_pattern, ctx->d_hit);
+    hipLaunchKernelGGL(phase_assign_kernel, dim3(rblocks), dim3(256), 0, st, ctx->n_reads, ctx->d_flagw, ctx->d_meta,
+                       ctx->d_read_slot, ctx->d_slot_hap, ctx->d_read_hap);
+    hipLaunchKernelGGL(phase_cooc_kernel, dim3(64), dim3(256), 0, st, ctx->d_meta, ctx->d_hit, ctx->d_hap_count,
+                       ctx->cooc_cap, ctx->d_cooc);
+}

@@ -1,0 +1,348 @@
+"""GPU parity: the HIP path through the C ABI vs the CPU oracle on the same inputs.
+
+Integer outputs (column counts, codon histograms, coverage, variant rows, haplotypes, read assignments,
+co-occurrence) must be bit-exact; p-values within 1e-10 absolute (BASELINE.json north_star), log-p within
+1e-9 relative.  Runs only on a real MI355X: `pytest -m gpu`.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib
+from minorseq_amd import capi, msa, synth
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+P_ABS_TOL = 1e-10     # north_star: "p-values within 1e-10"
+LOGP_REL_TOL = 1e-9
+
+
+@pytest.fixture(scope="module")
+def jl():
+    j = capi.Juliet(0)
+    yield j
+    j.close()
+
+
+def oracle_params(prm: capi.Params) -> oracle_lib.Params:
+    return oracle_lib.Params(prm.alpha, prm.n_tests,
+                             oracle_lib.ErrorModel(prm.err.match, prm.err.substitution, prm.err.deletion),
+                             prm.expected_round, prm.tail)
+
+
+def assert_variants_equal(got, exp):
+    assert len(got) == len(exp), (len(got), len(exp))
+    for k in ("gene", "codon_pos", "col", "ref_codon", "codon", "count", "coverage", "expected"):
+        assert (got[k] == exp[k]).all(), k
+    assert np.abs(got["p_value"] - exp["p_value"]).max(initial=0.0) <= P_ABS_TOL
+    fin = np.isfinite(exp["log_p"])
+    assert (np.isfinite(got["log_p"]) == fin).all()
+    if fin.any():
+        rel = np.abs(got["log_p"][fin] - exp["log_p"][fin]) / np.maximum(1.0, np.abs(exp["log_p"][fin]))
+        assert rel.max() <= LOGP_REL_TOL
+
+
+def assert_phase_equal(got, exp, n_var):
+    assert got["summary"] == exp["summary"]
+    h = exp["summary"]["n_haplotypes"]
+    assert (got["pos_cols"] == exp["pos_cols"]).all()
+    assert (got["hap_count"] == exp["hap_count"]).all()
+    assert (got["hap_pattern"] == exp["hap_pattern"]).all()
+    assert (got["hit"][:n_var, :h] == exp["hit"]).all()
+    assert (got["read_hap"] == exp["read_hap"]).all()
+    if got["cooc"] is not None and n_var <= 256:
+        assert (got["cooc"][:n_var, :n_var] == exp["cooc"]).all()
+
+
+# --------------------------------------------------------------------------------------------- layout
+@pytest.mark.parametrize("n,l", [(1, 3), (7, 10), (255, 33), (256, 36), (257, 5), (1000, 100), (8193, 41)])
+def test_pack_rows_on_device_matches_numpy(jl, n, l):
+    rows = np.random.default_rng(n * 131 + l).integers(0, 7, size=(n, l), dtype=np.uint8)
+    jl.upload_rows(rows)
+    assert (jl.download_columns() == msa.pack_columns(rows)).all()
+
+
+@pytest.mark.parametrize("n,l,partial", [(1000, 300, 0.0), (4100, 90, 0.3), (513, 3000, 0.1)])
+def test_synth_fill_matches_numpy_mirror(jl, n, l, partial):
+    sp = synth.SynthParams(seed=n + l, partial_rate=partial)
+    ref = synth.reference(sp.seed, l)
+    jl.alloc(n, l)
+    jl.synth_fill(sp, ref)
+    dev = msa.unpack_columns(jl.download_columns(), n)
+    assert (dev == synth.rows(sp, l, 0, n, ref)).all()
+    # padding reads are uncovered
+    full = msa.unpack_columns(jl.download_columns(), jl.col_stride * 2)
+    assert (full[n:] == msa.SYM_NONE).all()
+
+
+# --------------------------------------------------------------------------------------------- numerics
+def test_fisher_device_vs_golden(jl):
+    with open(os.path.join(HERE, "golden", "fisher_golden.json")) as f:
+        tables = [r for r in json.load(f)["tables"] if r["a"] + r["b"] == r["c"] + r["d"]]
+    a = np.array([r["a"] for r in tables], dtype=np.uint32)
+    c = np.array([r["c"] for r in tables], dtype=np.uint32)
+    cov = np.array([r["a"] + r["b"] for r in tables], dtype=np.uint32)
+    p, lp = jl.fisher_eval(a, c, cov)
+    gp = np.array([float(r["p"]) for r in tables])
+    glp = np.array([float(r["log_p"]) for r in tables])
+    assert np.abs(p - gp).max() <= P_ABS_TOL
+    big = gp > 1e-300
+    assert (np.abs(p[big] - gp[big]) / gp[big]).max() <= 1e-11
+    assert (np.abs(lp - glp) <= 1e-12 * np.maximum(1.0, np.abs(glp)) + 1e-13).all()
+
+
+def test_fisher_device_vs_oracle_random(jl, oracle):
+    rng = np.random.default_rng(9)
+    cov = rng.integers(1, 3_000_000, size=4000).astype(np.uint32)
+    a = np.minimum(cov, rng.integers(1, 500, size=4000)).astype(np.uint32)
+    c = np.minimum(cov, rng.integers(0, 60, size=4000)).astype(np.uint32)
+    p, lp = jl.fisher_eval(a, c, cov)
+    for i in range(len(a)):
+        op, olp = oracle.fisher(int(a[i]), int(cov[i] - a[i]), int(c[i]), int(cov[i] - c[i]))
+        assert abs(p[i] - op) <= P_ABS_TOL
+        assert abs(lp[i] - olp) <= LOGP_REL_TOL * max(1.0, abs(olp))
+
+
+# --------------------------------------------------------------------------------------------- pileup
+SHAPES = [  # n_reads, n_cols, partial_rate  — ragged sizes around the 8192-read tile and the 12-column chunk
+    (1, 3, 0.0), (2, 4, 0.0), (63, 12, 0.0), (64, 13, 0.5), (300, 11, 0.2), (1000, 36, 0.0), (1001, 37, 0.3),
+    (8192, 24, 0.0), (8193, 25, 0.1), (20000, 50, 0.2), (33000, 14, 0.0),
+]
+
+
+@pytest.mark.parametrize("n,l,partial", SHAPES)
+def test_pileup_and_histograms_bit_exact(jl, oracle, n, l, partial):
+    sp = synth.SynthParams(seed=3 * n + l, partial_rate=partial, mask_rate=0.05, del_rate=0.03, sub_rate=0.02,
+                           minor_permille=(100, 50, 30, 20))
+    ref = synth.reference(sp.seed, l)
+    rows = synth.rows(sp, l, 0, n, ref)
+    jl.upload_columns(msa.pack_columns(rows), n)
+    # three overlapping genes, all three frames, one running past the window end
+    genes = np.array([(1, l + 1), (2, l + 1), (3, l + 7)], dtype=capi.GENE)
+    for refseq in (None, ref):
+        jl.pileup_async(genes, refseq)
+        got = jl.pileup_fetch()
+        assert (got["col_counts"] == oracle.pileup(rows)).all()
+        hist, cov = oracle.codon_hist(rows, got["pos_col"])
+        assert (got["hist"] == hist).all()
+        assert (got["coverage"] == cov).all()
+        assert (got["col_counts"].sum(axis=1) == (rows != msa.SYM_NONE).sum(axis=0)).all()
+
+
+def test_pileup_empty_and_degenerate(jl, oracle):
+    # all-uncovered matrix, all-N matrix, single column
+    for fill in (msa.SYM_NONE, msa.SYM_MASK, msa.SYM_GAP):
+        rows = np.full((500, 9), fill, dtype=np.uint8)
+        jl.upload_columns(msa.pack_columns(rows), 500)
+        jl.pileup_async(np.array([(1, 10)], dtype=capi.GENE))
+        got = jl.pileup_fetch()
+        assert (got["col_counts"] == oracle.pileup(rows)).all()
+        assert got["hist"].sum() == 0 and (got["coverage"] == 0).all()
+        jl.call_async(capi.default_params())
+        assert len(jl.call_fetch()) == 0
+    rows = np.zeros((10, 1), dtype=np.uint8)
+    jl.upload_columns(msa.pack_columns(rows), 10)
+    jl.pileup_async(np.array([(1, 2)], dtype=capi.GENE))
+    got = jl.pileup_fetch()
+    assert len(got["pos_col"]) == 0 and got["col_counts"][0, 0] == 10
+    with pytest.raises(capi.JulietError):
+        jl.upload_columns(np.zeros((0, 128), dtype=np.uint8), 10)
+
+
+def test_seed_never_changes_results(jl, oracle):
+    """A wrong reference (bad seed for the codon fast path) must give the same histograms."""
+    sp = synth.SynthParams(seed=77, minor_permille=(200, 100, 100, 100))
+    ref = synth.reference(sp.seed, 60)
+    rows = synth.rows(sp, 60, 0, 5000, ref)
+    jl.upload_columns(msa.pack_columns(rows), 5000)
+    genes = np.array([(1, 61)], dtype=capi.GENE)
+    wrong = ((ref.astype(np.int64) + 1) % 4).astype(np.uint8)
+    jl.pileup_async(genes, wrong)
+    got = jl.pileup_fetch()
+    hist, cov = oracle.codon_hist(rows, got["pos_col"])
+    assert (got["hist"] == hist).all() and (got["coverage"] == cov).all()
+
+
+# --------------------------------------------------------------------------------------------- call
+@pytest.mark.parametrize("n,l,use_ref", [(3000, 300, True), (3000, 300, False), (12000, 99, True), (700, 48, False)])
+def test_call_matches_oracle(jl, oracle, n, l, use_ref):
+    sp = synth.SynthParams(seed=n + 7 * l, minor_permille=(40, 30, 20, 15), partial_rate=0.1)
+    ref = synth.reference(sp.seed, l)
+    rows = synth.rows(sp, l, 0, n, ref)
+    jl.upload_columns(msa.pack_columns(rows), n)
+    genes = np.array([(1, l + 1), (2, l - 1)], dtype=capi.GENE)
+    for prm in (capi.default_params(), capi.default_params(alpha=0.5, n_tests=1.0),
+                capi.default_params(chemistry="permissive", expected_round=1),
+                capi.default_params(alpha=0.5, n_tests=1.0, expected_round=2)):
+        jl.pileup_async(genes, ref if use_ref else None)
+        jl.call_async(prm)
+        got = jl.call_fetch()
+        exp = oracle.call(rows, genes, refseq=ref if use_ref else None, params=oracle_params(prm))
+        assert_variants_equal(got, exp)
+
+
+def test_call_window_offset_and_nonacgt_reference(jl, oracle):
+    sp = synth.SynthParams(seed=5, minor_permille=(60, 60, 60, 60))
+    L = 400
+    ref = synth.reference(sp.seed, L)
+    rows = synth.rows(sp, L, 0, 2500, ref)
+    ref_n = ref.copy()
+    ref_n[[30, 31, 200]] = 4          # non-ACGT reference bases: those codons are skipped (SPEC §4)
+    genes = np.array([(10, 390), (101, 161)], dtype=capi.GENE)
+    win = slice(90, 330)
+    jl.upload_columns(msa.pack_columns(rows[:, win]), 2500, win_begin=90)
+    jl.pileup_async(genes, ref_n)
+    jl.call_async(capi.default_params())
+    got = jl.call_fetch()
+    exp = oracle.call(rows[:, win], genes, win_begin=90, refseq=ref_n)
+    assert len(exp) > 0
+    assert_variants_equal(got, exp)
+
+
+def test_filters_min_max_perc_and_drm(jl, oracle):
+    sp = synth.SynthParams(seed=21, minor_permille=(300, 60, 30, 10))
+    ref = synth.reference(sp.seed, 3000)
+    rows = synth.rows(sp, 3000, 0, 4000, ref)
+    jl.upload_columns(msa.pack_columns(rows), 4000)
+    genes = np.array([(1, 3001)], dtype=capi.GENE)
+    base = oracle.call(rows, genes, refseq=ref)
+    perc = 100.0 * base["count"] / base["coverage"]
+    assert len(base) == 5
+    for lo, hi in ((-1.0, -1.0), (2.0, -1.0), (-1.0, 5.0), (2.0, 20.0)):
+        jl.pileup_async(genes, ref)
+        jl.call_async(capi.default_params(min_perc=lo, max_perc=hi))
+        keep = np.ones(len(base), dtype=bool)
+        if lo >= 0:
+            keep &= perc > lo          # doc/JULIET.md:342-344
+        if hi >= 0:
+            keep &= perc < hi          # doc/JULIET.md:352-354
+        assert_variants_equal(jl.call_fetch(), base[keep])
+    # --drm-only (doc/JULIET.md:370): per-position codon masks
+    jl.pileup_async(genes, ref)
+    masks = np.zeros(1000, dtype=np.uint64)
+    for r in base[:2]:
+        masks[r["codon_pos"] - 1] |= np.uint64(1) << np.uint64(r["codon"])
+    jl.call_async(capi.default_params(), drm_masks=masks)
+    assert_variants_equal(jl.call_fetch(), base[:2])
+
+
+# --------------------------------------------------------------------------------------------- phase
+@pytest.mark.parametrize("n,l,partial", [(1000, 3000, 0.0), (5000, 300, 0.2), (9000, 120, 0.0), (64, 30, 0.0)])
+def test_phase_matches_oracle(jl, oracle, n, l, partial):
+    sp = synth.SynthParams(seed=n + l, minor_permille=(80, 60, 50, 40), partial_rate=partial)
+    ref = synth.reference(sp.seed, l)
+    rows = synth.rows(sp, l, 0, n, ref)
+    jl.upload_columns(msa.pack_columns(rows), n)
+    genes = np.array([(1, l + 1)], dtype=capi.GENE)
+    out = jl.run(genes, ref, capi.default_params(), phasing=True, min_reads=10)
+    exp_v = oracle.call(rows, genes, refseq=ref)
+    assert_variants_equal(out["variants"], exp_v)
+    exp = oracle.phase(rows, exp_v, min_reads=10)
+    assert_phase_equal(out["phase"], exp, len(exp_v))
+    s = out["phase"]["summary"]
+    assert s["reported_reads"] + s["insufficient_reads"] + s["damaged_reads"] == n   # doc/JULIET.md:378-379
+
+
+def test_phase_with_host_table_many_positions(jl, oracle):
+    """Host-supplied table (the all-gather case), > 40 positions so the key spans several words and the
+    resident key buffer has to grow (re-run protocol)."""
+    n, l = 6000, 600
+    sp = synth.SynthParams(seed=31, sub_rate=0.01, minor_permille=(50, 50, 50, 50))
+    ref = synth.reference(sp.seed, l)
+    rows = synth.rows(sp, l, 0, n, ref)
+    jl.upload_columns(msa.pack_columns(rows), n)
+    genes = np.array([(1, l + 1)], dtype=capi.GENE)
+    loose = capi.default_params(alpha=0.9, n_tests=1.0)
+    jl.pileup_async(genes, None)
+    jl.call_async(loose)
+    table = jl.call_fetch()
+    assert len(np.unique(table["col"])) > 45
+    exp_v = oracle.call(rows, genes, params=oracle_params(loose))
+    assert_variants_equal(table, exp_v)
+    for sub in (table, table[::3], table[:11], table[:0]):
+        jl.phase_async(sub, min_reads=3)
+        got = jl.phase_fetch(cap_var=max(1, len(sub)))
+        exp = oracle.phase(rows, sub, min_reads=3)
+        assert_phase_equal(got, exp, len(sub))
+    # resident-table path with many positions: grows the key buffer transparently
+    j2 = capi.Juliet(0)
+    j2.upload_columns(msa.pack_columns(rows), n)
+    j2.pileup_async(genes, None)
+    j2.call_async(loose)
+    j2.phase_async(None, min_reads=3)
+    got = j2.phase_fetch(cap_var=len(table))
+    assert_phase_equal(got, oracle.phase(rows, table, min_reads=3), len(table))
+    j2.close()
+
+
+def test_phase_all_damaged_and_threshold(jl, oracle):
+    # every read has a deletion in the variant codon: no haplotypes (doc/JULIET.md:285-288)
+    rows = np.zeros((300, 6), dtype=np.uint8)
+    rows[:, 1] = msa.SYM_GAP
+    var = np.zeros(1, dtype=capi.VARIANT)
+    var["col"], var["codon"] = 0, 5
+    jl.upload_columns(msa.pack_columns(rows), 300)
+    jl.pileup_async(np.array([(1, 7)], dtype=capi.GENE))
+    jl.phase_async(var)
+    got = jl.phase_fetch(cap_var=1)
+    assert_phase_equal(got, oracle.phase(rows, var), 1)
+    assert got["summary"]["n_haplotypes"] == 0 and got["summary"]["damaged_reads"] == 300
+    # >= 10 reads to report (doc/JULIET.md:253-254)
+    rows = np.zeros((200, 3), dtype=np.uint8)
+    rows[:10, 0] = 1
+    rows[10:19, 0] = 2
+    var = np.zeros(2, dtype=capi.VARIANT)
+    var["codon"] = [msa.codon_index("CAA"), msa.codon_index("GAA")]
+    jl.upload_columns(msa.pack_columns(rows), 200)
+    jl.pileup_async(np.array([(1, 4)], dtype=capi.GENE))
+    jl.phase_async(var, min_reads=10)
+    got = jl.phase_fetch(cap_var=2)
+    assert_phase_equal(got, oracle.phase(rows, var, min_reads=10), 2)
+    assert got["hap_count"].tolist() == [181, 10] and got["summary"]["insufficient_reads"] == 9
+
+
+def test_permutation_invariance_on_device(jl):
+    sp = synth.SynthParams(seed=13, minor_permille=(70, 60, 50, 40))
+    ref = synth.reference(sp.seed, 300)
+    rows = synth.rows(sp, 300, 0, 7000, ref)
+    perm = np.random.default_rng(1).permutation(len(rows))
+    genes = np.array([(1, 301)], dtype=capi.GENE)
+    jl.upload_columns(msa.pack_columns(rows), len(rows))
+    a = jl.run(genes, ref)
+    jl.upload_columns(msa.pack_columns(rows[perm]), len(rows))
+    b = jl.run(genes, ref)
+    assert (a["variants"] == b["variants"]).all()
+    assert a["phase"]["summary"] == b["phase"]["summary"]
+    assert (a["phase"]["hap_pattern"] == b["phase"]["hap_pattern"]).all()
+    assert (a["phase"]["read_hap"][perm] == b["phase"]["read_hap"]).all()
+
+
+# --------------------------------------------------------------------------------------------- full size
+def test_config2_full_size_against_oracle(jl, oracle):
+    """BASELINE.json configs[1]/[2]: 100k CCS reads x 3 kb, call + phase, device-generated reads."""
+    n, l = 100_000, 3000
+    sp = synth.SynthParams(seed=2)
+    ref = synth.reference(sp.seed, l)
+    jl.alloc(n, l)
+    jl.synth_fill(sp, ref)
+    genes = np.array([(1, l + 1)], dtype=capi.GENE)
+    out = jl.run(genes, ref)
+    rows = msa.unpack_columns(jl.download_columns(), n)
+    pf = jl.pileup_fetch()
+    # size-independent properties
+    assert (pf["col_counts"].sum(axis=1) == n).all()                 # full-span reads: one symbol per read and column
+    assert (pf["hist"].sum(axis=1) == pf["coverage"]).all()
+    real_depth = pf["col_counts"][:, :4].sum(axis=1)
+    assert (pf["coverage"] <= np.minimum.reduce([real_depth[pf["pos_col"] + k] for k in range(3)])).all()
+    s = out["phase"]["summary"]
+    assert s["reported_reads"] + s["insufficient_reads"] + s["damaged_reads"] == n
+    assert abs((100.0 * out["phase"]["hap_count"] / s["reported_reads"]).sum() - 100.0) < 1e-9
+    assert len(out["variants"]) == 5 and s["n_haplotypes"] == 5
+    # and the oracle on the very same reads
+    assert (pf["col_counts"] == oracle.pileup(rows)).all()
+    exp_v = oracle.call(rows, genes, refseq=ref)
+    assert_variants_equal(out["variants"], exp_v)
+    assert_phase_equal(out["phase"], oracle.phase(rows, exp_v), len(exp_v))
