@@ -174,9 +174,9 @@ def test_call_matches_oracle(jl, oracle, n, l, use_ref):
     rows = synth.rows(sp, l, 0, n, ref)
     jl.upload_columns(msa.pack_columns(rows), n)
     genes = np.array([(1, l + 1), (2, l - 1)], dtype=capi.GENE)
-    for prm in (capi.default_params(), capi.default_params(alpha=0.5, n_tests=1.0),
+    for prm in (capi.default_params(), capi.default_params(alpha=0.3, n_tests=1.0),
                 capi.default_params(chemistry="permissive", expected_round=1),
-                capi.default_params(alpha=0.5, n_tests=1.0, expected_round=2)):
+                capi.default_params(alpha=0.3, n_tests=1.0, expected_round=2)):
         jl.pileup_async(genes, ref if use_ref else None)
         jl.call_async(prm)
         got = jl.call_fetch()
@@ -192,13 +192,13 @@ def test_call_window_offset_and_nonacgt_reference(jl, oracle):
     ref_n = ref.copy()
     ref_n[[30, 31, 200]] = 4          # non-ACGT reference bases: those codons are skipped (SPEC §4)
     genes = np.array([(10, 390), (101, 161)], dtype=capi.GENE)
-    win = slice(90, 330)
-    jl.upload_columns(msa.pack_columns(rows[:, win]), 2500, win_begin=90)
+    win = slice(9, 330)
+    jl.upload_columns(msa.pack_columns(rows[:, win]), 2500, win_begin=9)
     jl.pileup_async(genes, ref_n)
     jl.call_async(capi.default_params())
     got = jl.call_fetch()
-    exp = oracle.call(rows[:, win], genes, win_begin=90, refseq=ref_n)
-    assert len(exp) > 0
+    exp = oracle.call(rows[:, win], genes, win_begin=9, refseq=ref_n)
+    assert len(exp) >= 3
     assert_variants_equal(got, exp)
 
 
@@ -243,7 +243,8 @@ def test_phase_matches_oracle(jl, oracle, n, l, partial):
     exp = oracle.phase(rows, exp_v, min_reads=10)
     assert_phase_equal(out["phase"], exp, len(exp_v))
     s = out["phase"]["summary"]
-    assert s["reported_reads"] + s["insufficient_reads"] + s["damaged_reads"] == n   # doc/JULIET.md:378-379
+    if s["n_positions"]:   # SPEC §8: no variant positions => no phasing, all counters 0
+        assert s["reported_reads"] + s["insufficient_reads"] + s["damaged_reads"] == n   # doc/JULIET.md:378-379
 
 
 def test_phase_with_host_table_many_positions(jl, oracle):
