@@ -124,7 +124,7 @@ void jl_ctx_destroy(jl_ctx *ctx)
                     ctx->d_counts, ctx->d_called, ctx->d_cand_p, ctx->d_cand_lp, ctx->d_cand_e, ctx->d_pos_cov,
                     ctx->d_pos_ref, ctx->d_drm, ctx->d_variants, ctx->d_nvar, ctx->d_meta, ctx->d_vpcols,
                     ctx->d_col2pos, ctx->d_varcol, ctx->d_keys, ctx->d_flagw, ctx->d_read_slot, ctx->d_read_hap,
-                    ctx->d_slot_rep, ctx->d_slot_count, ctx->d_slot_hap, ctx->d_occupied, ctx->d_hap_count,
+                    ctx->d_slot_rep, ctx->d_slot_count, ctx->d_slot_key, ctx->d_slot_hap, ctx->d_occupied, ctx->d_hap_count,
                     ctx->d_hap_pattern, ctx->d_hit, ctx->d_cooc};
     for (void *p : ptrs)
         if (p) hipFree(p);
@@ -456,6 +456,7 @@ static int reserve_phase(jl_ctx *ctx, uint32_t kwords_needed)
         if ((rc = regrow(ctx, &ctx->d_occupied, reads_pad))) return rc;
         if ((rc = regrow(ctx, &ctx->d_slot_rep, (size_t)slots))) return rc;
         if ((rc = regrow(ctx, &ctx->d_slot_count, (size_t)slots))) return rc;
+        if ((rc = regrow(ctx, &ctx->d_slot_key, (size_t)slots))) return rc;
         if ((rc = regrow(ctx, &ctx->d_slot_hap, (size_t)slots))) return rc;
         ctx->reads_capacity = reads_pad;
         ctx->keys_capacity = 0;

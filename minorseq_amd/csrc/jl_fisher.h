@@ -38,11 +38,12 @@ JL_FHD double stirlerr(double n)
                             0.005554733551962801};
     if (n < 16.0) return tab[(int)n];
     const double S0 = 1.0 / 12.0, S1 = 1.0 / 360.0, S2 = 1.0 / 1260.0, S3 = 1.0 / 1680.0, S4 = 1.0 / 1188.0;
-    const double nn = n * n;
-    if (n > 500.0) return (S0 - S1 / nn) / n;
-    if (n > 80.0) return (S0 - (S1 - S2 / nn) / nn) / n;
-    if (n > 35.0) return (S0 - (S1 - (S2 - S3 / nn) / nn) / nn) / n;
-    return (S0 - (S1 - (S2 - (S3 - S4 / nn) / nn) / nn) / nn) / n;
+    const double r = 1.0 / n;  // one division; the series is in powers of 1/n^2
+    const double rr = r * r;
+    if (n > 500.0) return (S0 - S1 * rr) * r;
+    if (n > 80.0) return (S0 - (S1 - S2 * rr) * rr) * r;
+    if (n > 35.0) return (S0 - (S1 - (S2 - S3 * rr) * rr) * rr) * r;
+    return (S0 - (S1 - (S2 - (S3 - S4 * rr) * rr) * rr) * rr) * r;
 }
 
 JL_FHD double bd0(double x, double np)
@@ -53,6 +54,7 @@ JL_FHD double bd0(double x, double np)
         double s = (x - np) * v;
         double ej = 2.0 * x * v;
         v = v * v;
+        // |v| < 0.1: the series gains two digits per term, so it ends within ~10 terms
         for (int j = 1; j < 1000; ++j) {
             ej *= v;
             const double s1 = s + ej / (double)(2 * j + 1);
@@ -76,17 +78,32 @@ JL_FHD double log_binom_half(double x, double n)
     return lc + 0.5 * log(n / (TWO_PI * x * (n - x)));
 }
 
+// ln P(X = x) for X ~ Hypergeometric(2n, K, n): the three Binomial(., 1/2) masses folded into one expression
+// (one log for the sqrt factors, the Binom(n; 2n) deviance terms are exactly zero)
+JL_FHD double jl_log_pmf_equal_rows(double x, double K, double n)
+{
+    const double TWO_PI = 6.283185307179586477;
+    const double M = 2.0 * n, L = M - K;
+    const double c = K - x, nx = n - x, nc = n - c;
+    if (x == 0.0 || c == 0.0 || nx == 0.0 || nc == 0.0)
+        return log_binom_half(x, K) + log_binom_half(nx, L) - log_binom_half(n, M);
+    const double hK = 0.5 * K, hL = 0.5 * L;
+    double s = stirlerr(K) + stirlerr(L) + 2.0 * stirlerr(n) - stirlerr(M);
+    s -= stirlerr(x) + stirlerr(c) + stirlerr(nx) + stirlerr(nc);
+    s -= bd0(x, hK) + bd0(c, hK) + bd0(nx, hL) + bd0(nc, hL);
+    return s + 0.5 * log((K * L * n * n) / (TWO_PI * x * c * nx * nc * M));
+}
+
 // P(X >= a) for the table [[a, n-a], [c, n-c]] (both rows sum to n); returns p, *logp = ln p
 JL_FHD double jl_fisher_greater_equal_rows(uint32_t a_, uint32_t c_, uint32_t n_, double *logp)
 {
     const double a = a_, c = c_, n = n_;
-    const double K = a + c, M = 2.0 * n;
+    const double K = a + c;
     const double hi = K < n ? K : n;
     const double lo = K > n ? K - n : 0.0;
     if (a <= lo) { *logp = 0.0; return 1.0; }
-    const double lden = log_binom_half(n, M);
     if (a > c) {  // above the mean K/2: sum the decreasing upper tail
-        const double l0 = log_binom_half(a, K) + log_binom_half(n - a, M - K) - lden;
+        const double l0 = jl_log_pmf_equal_rows(a, K, n);
         double term = 1.0, sum = 1.0;
         for (double x = a; x < hi; x += 1.0) {
             term *= ((K - x) * (n - x)) / ((x + 1.0) * (n - K + x + 1.0));
@@ -99,7 +116,7 @@ JL_FHD double jl_fisher_greater_equal_rows(uint32_t a_, uint32_t c_, uint32_t n_
     }
     // at or below the mean: 1 - P(X <= a-1), lower tail summed downwards
     const double x0 = a - 1.0;
-    const double l0 = log_binom_half(x0, K) + log_binom_half(n - x0, M - K) - lden;
+    const double l0 = jl_log_pmf_equal_rows(x0, K, n);
     double term = 1.0, sum = 1.0;
     for (double x = x0; x > lo; x -= 1.0) {
         term *= (x * (n - K + x)) / ((K - x + 1.0) * (n - x + 1.0));

@@ -72,10 +72,16 @@ __global__ __launch_bounds__(256) void fisher_kernel(call_args A, const uint32_t
         if (r < 0.0) r = 0.0;
         if (r > (double)cov) r = (double)cov;
         e = (uint32_t)r;
-        const double pv = jl_fisher_greater_equal_rows(h, e, cov, &lp);
-        p_adj = pv * A.n_tests;
-        if (p_adj > 1.0) p_adj = 1.0;
-        is_called = p_adj < A.alpha;
+        // An observed count at or below the expected one has p >= 1/2 (the null is symmetric about K/2
+        // because both rows sum to the coverage), so it cannot be called once min(1, n_tests/2) >= alpha;
+        // uncalled codons are never reported, so their p-value is not needed.
+        const double floor_adj = 0.5 * A.n_tests < 1.0 ? 0.5 * A.n_tests : 1.0;
+        if (h > e || !(floor_adj >= A.alpha)) {
+            const double pv = jl_fisher_greater_equal_rows(h, e, cov, &lp);
+            p_adj = pv * A.n_tests;
+            if (p_adj > 1.0) p_adj = 1.0;
+            is_called = p_adj < A.alpha;
+        }
         const double perc = 100.0 * (double)h / (double)cov;
         if (A.min_perc >= 0.0 && !(perc > A.min_perc)) is_called = false;
         if (A.max_perc >= 0.0 && !(perc < A.max_perc)) is_called = false;

@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256) void phase_keys_kernel(const uint8_t *__restri
                                                           uint64_t *__restrict__ keys, uint32_t *__restrict__ flagw)
 {
     const uint32_t vp = meta->vp;
-    if (vp == 0) return;
+    if (vp == 0 || meta->kwords == 1) return;  // single-word keys take the fused kernel below
     const uint64_t t = (uint64_t)blockIdx.x * 256u + threadIdx.x;  // dword index within a column
     const bool live = t * 4u < col_stride;
     uint32_t gap = 0, het = 0, par = 0;
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256) void phase_group_kernel(uint64_t n_reads, uint
                                                            uint32_t *__restrict__ read_slot)
 {
     const uint32_t kwords = meta->kwords;
-    if (kwords == 0) return;
+    if (kwords <= 1) return;  // 0: nothing to phase; 1: fused kernel
     const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63u;
     bool active = false;
@@ -241,6 +241,197 @@ __global__ __launch_bounds__(256) void phase_group_kernel(uint64_t n_reads, uint
             active = false;
         }
         todo &= ~grp;
+    }
+}
+
+// ---------------------------------------------------------------------------------------- fused keys + group
+// Vp <= 10: the whole pattern is ONE 64-bit word, so the table can be keyed by value (64-bit CAS, no
+// representative lookup) and a block can aggregate before it touches HBM:
+//   1. every lane builds the keys and flags of its 8 reads (30 independent dword loads in flight),
+//   2. the block's dominant key (that of its first clean read — the wild type for all but pathological
+//      inputs) is counted with popcount-style compares and costs ONE global insert per block,
+//   3. the remaining clean reads go through an LDS table (CAS on the 64-bit key), which is then flushed
+//      with one global insert per distinct key per block.
+// Global atomics on the hot slot drop from one per wave to one per 2048 reads.
+constexpr uint32_t kLdsSlots = 1024;
+constexpr uint64_t kNoKey = ~0ull;
+
+__device__ __forceinline__ uint32_t global_insert64(uint64_t key, uint32_t cnt, uint32_t first, uint64_t slots_mask,
+                                                    unsigned long long *__restrict__ slot_key,
+                                                    uint32_t *__restrict__ slot_rep, uint32_t *__restrict__ slot_count,
+                                                    uint32_t *__restrict__ occupied, jl_phase_meta *__restrict__ meta)
+{
+    uint64_t s = mix64(key + 0x9E3779B97F4A7C15ull) & slots_mask;
+    for (;;) {
+        unsigned long long old = __hip_atomic_load(&slot_key[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old == kNoKey) {
+            old = atomicCAS(&slot_key[s], (unsigned long long)kNoKey, (unsigned long long)key);
+            if (old == kNoKey) {
+                slot_rep[s] = first;  // any read carrying the key; select decodes the pattern from it
+                occupied[atomicAdd(&meta->n_occupied, 1u)] = (uint32_t)s;
+                old = key;
+            }
+        }
+        if (old == key) {
+            atomicAdd(&slot_count[s], cnt);
+            return (uint32_t)s;
+        }
+        s = (s + 1u) & slots_mask;
+    }
+}
+
+__global__ __launch_bounds__(256) void phase_fused1_kernel(const uint8_t *__restrict__ msa, uint64_t col_stride,
+                                                            uint64_t n_reads, uint64_t reads_pad,
+                                                            const uint32_t *__restrict__ vpcols,
+                                                            jl_phase_meta *__restrict__ meta,
+                                                            uint64_t *__restrict__ keys, uint32_t *__restrict__ flagw,
+                                                            uint64_t slots_mask,
+                                                            unsigned long long *__restrict__ slot_key,
+                                                            uint32_t *__restrict__ slot_rep,
+                                                            uint32_t *__restrict__ slot_count,
+                                                            uint32_t *__restrict__ occupied,
+                                                            uint32_t *__restrict__ read_slot)
+{
+    const uint32_t vp = meta->vp;
+    if (vp == 0 || meta->kwords != 1) return;
+    __shared__ unsigned long long s_key[kLdsSlots];
+    __shared__ uint32_t s_cnt[kLdsSlots], s_first[kLdsSlots], s_gslot[kLdsSlots];
+    __shared__ unsigned long long s_dom;
+    __shared__ uint32_t s_domcnt, s_domfirst, s_domslot;
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t i = tid; i < kLdsSlots; i += 256u) { s_key[i] = kNoKey; s_cnt[i] = 0; s_first[i] = 0xFFFFFFFFu; }
+    if (tid == 0) { s_dom = kNoKey; s_domcnt = 0; s_domfirst = 0xFFFFFFFFu; s_domslot = 0; }
+    __syncthreads();
+
+    const uint64_t t = (uint64_t)blockIdx.x * 256u + tid;  // dword index within a column = 8 reads
+    const bool live = t * 4u < col_stride;
+    // ---- 1. keys and flags
+    uint32_t w[JL_POS_PER_WORD][3];
+#pragma unroll
+    for (uint32_t p = 0; p < JL_POS_PER_WORD; ++p) {
+        const bool on = live && p < vp;
+        const uint32_t c = p < vp ? vpcols[p] : 0u;
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            w[p][k] = on ? *reinterpret_cast<const uint32_t *>(msa + (uint64_t)(c + k) * col_stride + t * 4u)
+                         : 0x66666666u;
+    }
+    uint32_t gap = 0, het = 0, par = 0;
+    uint64_t key[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (uint32_t p = 0; p < JL_POS_PER_WORD; ++p) {
+        if (p < vp) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const uint32_t b0 = w[p][k] & kM1, b1 = (w[p][k] >> 1) & kM1, b2 = (w[p][k] >> 2) & kM1;
+                gap |= b2 & ~b1 & ~b0;
+                het |= b2 & b0;
+                par |= b2 & b1;
+            }
+            const uint32_t hi2 = w[p][0] & 0x33333333u;
+            const uint32_t lo4 = ((w[p][1] & 0x33333333u) << 2) | (w[p][2] & 0x33333333u);
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+                key[r] = (key[r] << 6) | ((((hi2 >> (4 * r)) & 3u) << 4) | ((lo4 >> (4 * r)) & 15u));
+        }
+    }
+    uint32_t valid = 0;
+    if (live) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+            if (t * 8u + r < n_reads) valid |= 1u << (4 * r);
+    }
+    gap &= valid; het &= valid; par &= valid;
+    const uint32_t dirty = gap | het | par;
+    const uint32_t cleanm = valid & ~dirty;  // bit 4r: read r is clean
+    if (live) {
+        flagw[t] = gap | (het << 1) | (par << 2) | ((valid ^ kM1) << 3);
+        uint64_t *dst = keys + t * 8u;
+#pragma unroll
+        for (int r = 0; r < 8; r += 2) {
+            ulonglong2 v;
+            v.x = key[r];
+            v.y = key[r + 1];
+            *reinterpret_cast<ulonglong2 *>(dst + r) = v;
+        }
+    }
+    {
+        const uint32_t n_gap = wave_sum_all(__popc(gap)), n_het = wave_sum_all(__popc(het));
+        const uint32_t n_par = wave_sum_all(__popc(par)), n_dam = wave_sum_all(__popc(dirty));
+        if ((tid & 63u) == 0) {
+            if (n_dam) atomicAdd(&meta->summary.damaged_reads, n_dam);
+            if (n_gap) atomicAdd(&meta->summary.marginal_gap, n_gap);
+            if (n_het) atomicAdd(&meta->summary.marginal_heteroduplex, n_het);
+            if (n_par) atomicAdd(&meta->summary.marginal_partial, n_par);
+        }
+    }
+    // ---- 2. dominant key of the block = key of its first clean read
+    uint32_t myfirst = 0xFFFFFFFFu;
+    if (cleanm) myfirst = (uint32_t)(t * 8u) + ((uint32_t)__ffs((int)cleanm) - 1u) / 4u;
+    {
+        uint32_t m = myfirst;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = min(m, (uint32_t)__shfl_xor((int)m, o, 64));
+        if ((tid & 63u) == 0 && m != 0xFFFFFFFFu) atomicMin(&s_domfirst, m);
+    }
+    __syncthreads();
+    const uint32_t domfirst = s_domfirst;
+    if (domfirst != 0xFFFFFFFFu && (uint64_t)(domfirst >> 3) == t) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r)  // static indices keep key[] in registers
+            if ((domfirst & 7u) == (uint32_t)r) s_dom = key[r];
+    }
+    __syncthreads();
+    const unsigned long long dom = s_dom;
+    uint32_t isdom = 0;  // bit 4r
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+        if (((cleanm >> (4 * r)) & 1u) && key[r] == dom) isdom |= 1u << (4 * r);
+    {
+        const uint32_t c = wave_sum_all(__popc(isdom));
+        if ((tid & 63u) == 0 && c) atomicAdd(&s_domcnt, c);
+    }
+    // ---- 3. everything else through the LDS table
+    uint32_t rest = cleanm & ~isdom;
+    uint32_t myslot[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) myslot[r] = 0xFFFFFFFFu;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        if ((rest >> (4 * r)) & 1u) {
+            const unsigned long long k = key[r];
+            uint32_t s = (uint32_t)mix64(k) & (kLdsSlots - 1u);
+            for (uint32_t probe = 0; probe < kLdsSlots; ++probe) {
+                const unsigned long long old = atomicCAS(&s_key[s], (unsigned long long)kNoKey, k);
+                if (old == kNoKey || old == k) {
+                    atomicAdd(&s_cnt[s], 1u);
+                    atomicMin(&s_first[s], (uint32_t)(t * 8u + r));
+                    myslot[r] = s;
+                    break;
+                }
+                s = (s + 1u) & (kLdsSlots - 1u);
+            }
+        }
+    }
+    __syncthreads();
+    for (uint32_t s = tid; s < kLdsSlots; s += 256u)
+        if (s_cnt[s])
+            s_gslot[s] = global_insert64(s_key[s], s_cnt[s], s_first[s], slots_mask, slot_key, slot_rep, slot_count,
+                                         occupied, meta);
+    if (tid == 0 && s_domcnt)
+        s_domslot = global_insert64(dom, s_domcnt, s_domfirst, slots_mask, slot_key, slot_rep, slot_count, occupied, meta);
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        if ((cleanm >> (4 * r)) & 1u) {
+            uint32_t g;
+            if ((isdom >> (4 * r)) & 1u) g = s_domslot;
+            else if (myslot[r] != 0xFFFFFFFFu) g = s_gslot[myslot[r]];
+            else  // LDS table full (> 1024 distinct patterns in 2048 reads): straight to the global table
+                g = global_insert64(key[r], 1u, (uint32_t)(t * 8u + r), slots_mask, slot_key, slot_rep, slot_count,
+                                    occupied, meta);
+            read_slot[t * 8u + r] = g;
+        }
     }
 }
 
@@ -390,10 +581,15 @@ void jl_launch_phase(jl_ctx *ctx, uint32_t min_reads)
     // table: representatives empty, counts zero
     hipMemsetAsync(ctx->d_slot_rep, 0xFF, ctx->table_slots * sizeof(uint32_t), st);
     hipMemsetAsync(ctx->d_slot_count, 0, ctx->table_slots * sizeof(uint32_t), st);
+    hipMemsetAsync(ctx->d_slot_key, 0xFF, ctx->table_slots * sizeof(uint64_t), st);
     const uint32_t n_dwords = (uint32_t)(ctx->col_stride / 4u);
     hipLaunchKernelGGL(phase_keys_kernel, dim3((n_dwords + 255u) / 256u), dim3(256), 0, st, ctx->d_msa,
                        ctx->col_stride, ctx->n_reads, reads_pad, ctx->d_vpcols, ctx->d_meta, ctx->d_keys,
                        ctx->d_flagw);
+    hipLaunchKernelGGL(phase_fused1_kernel, dim3((n_dwords + 255u) / 256u), dim3(256), 0, st, ctx->d_msa,
+                       ctx->col_stride, ctx->n_reads, reads_pad, ctx->d_vpcols, ctx->d_meta, ctx->d_keys, ctx->d_flagw,
+                       ctx->table_slots - 1u, (unsigned long long *)ctx->d_slot_key, ctx->d_slot_rep,
+                       ctx->d_slot_count, ctx->d_occupied, ctx->d_read_slot);
     const uint32_t rblocks = (uint32_t)((ctx->n_reads + 255u) / 256u);
     hipLaunchKernelGGL(phase_group_kernel, dim3(rblocks), dim3(256), 0, st, ctx->n_reads, reads_pad, ctx->d_keys,
                        ctx->d_flagw, ctx->d_meta, ctx->table_slots - 1u, ctx->d_slot_rep, ctx->d_slot_count,

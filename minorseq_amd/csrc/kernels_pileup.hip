@@ -6,23 +6,35 @@
 //
 // Shape of the work.  The matrix is n_cols columns of n_reads 4-bit codes; every cell is read exactly
 // once (algorithmic bytes = n_reads * n_cols / 2), so the kernel is an HBM stream and the design goal is
-// to keep the per-nibble VALU work below the ~6 lane-ops the chip has per nibble at full HBM rate:
+// to keep the per-nibble VALU work well below the ~6 lane-ops the chip has per nibble at full HBM rate:
 //   * a lane loads 16 B = 32 reads of one column (a wave = 1 KiB contiguous per load),
-//   * column counts are bit-sliced: six masked popcounts per 8 nibbles give {b0,b1,b2,b0&b1,b1&b2,b0&b2}
-//     plane counts, from which A C G T - N follow by a linear solve once per block,
+//   * column counts are six linear measurements per 8 nibbles, four of them one v_dot8_u32_u4 each
+//     (sum of codes, sum of squares, sum over odd codes, sum over codes >= 4) plus two popcounts; the
+//     counts of A C G T - N follow from an exact integer solve once per lane and flush,
 //   * codon histograms are counted against a per-column seed base: eight reads are compared at once with
 //     xor/or on the three column words; reads equal to the seed codon are counted by popcount (the
 //     contended "major codon" bin never sees an atomic), the rare valid mismatches take an LDS atomic each.
 //     The seed only steers which bin is counted the fast way — any seed gives the same histogram.
 // A block owns W consecutive columns (plus a 2-column halo when a codon straddles its right edge) and a
-// strided set of 8192-read tiles; per-thread counters are reduced once per block and flushed with integer
-// atomics, which commute, so results are bit-exact and order-independent.
+// strided set of 8192-read tiles; per-lane counters are packed two per register, wave-reduced by DPP and
+// flushed to LDS at most every 31 tiles (16-bit fields cannot overflow), then to HBM with integer atomics,
+// which commute, so results are bit-exact and order-independent.
+#include <stdlib.h>
+
 #include "jl_internal.h"
+
+#ifndef JL_PILEUP_W
+#define JL_PILEUP_W 6
+#endif
+#ifndef JL_PILEUP_PIPE
+#define JL_PILEUP_PIPE 0
+#endif
 
 namespace {
 
-constexpr uint32_t kM1 = 0x11111111u, kM2 = 0x22222222u, kM4 = 0x44444444u;
+constexpr uint32_t kM1 = 0x11111111u, kM4 = 0x44444444u;
 constexpr uint32_t kNone = 0x66666666u;
+constexpr uint32_t kFlushTiles = 31;  // 64 lanes x 32 reads x 31 tiles = 63488 < 2^16
 
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
 {
@@ -36,19 +48,58 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
     return v;
 }
 
-// raw plane counts kept per column: 0:b0 1:b1 2:b2 3:b0&b1 (T) 4:b1&b2 (uncovered) 5:b0&b2 (N)
-__device__ __forceinline__ void count_planes(uint32_t w, uint32_t (&a)[6])
+// Six linear measurements of the eight 4-bit codes in w (codes 0..6):
+//   a[0] S1  = sum code            a[1] S2 = sum code^2
+//   a[2] B0  = #odd codes          a[3] B0W = sum of the odd codes
+//   a[4] E   = #codes >= 4         a[5] D  = 4 * sum of the codes >= 4
+__device__ __forceinline__ void measure(uint32_t w, uint32_t (&a)[6])
 {
-    a[0] += __popc(w & kM1);
-    a[1] += __popc(w & kM2);
-    a[2] += __popc(w & kM4);
-    uint32_t t = w & (w >> 1);
-    a[3] += __popc(t & kM1);
-    a[4] += __popc(t & kM2);
-    a[5] += __popc(w & (w >> 2) & kM1);
+    const uint32_t t1 = w & kM1;
+    const uint32_t t2 = w & kM4;
+    a[0] = __builtin_amdgcn_udot8(w, kM1, a[0], false);
+    a[1] = __builtin_amdgcn_udot8(w, w, a[1], false);
+    a[2] += __popc(t1);
+    a[3] = __builtin_amdgcn_udot8(t1, w, a[3], false);
+    a[4] += __popc(t2);
+    a[5] = __builtin_amdgcn_udot8(t2, w, a[5], false);
+}
+
+// Exact integer solve of the measurements for the counts of C G T - N and uncovered.
+__device__ __forceinline__ void solve(const uint32_t (&a)[6], uint32_t &nC, uint32_t &nG, uint32_t &nT, uint32_t &nD,
+                                      uint32_t &nN, uint32_t &nU)
+{
+    const int S1 = (int)a[0], S2 = (int)a[1], B0 = (int)a[2], B0W = (int)a[3], E = (int)a[4], Dq = (int)(a[5] >> 2);
+    const int n = (-3 * B0 + 2 * B0W + 2 * S1 + 8 * Dq - 24 * E - S2) >> 3;
+    const int t = ((B0W - B0) >> 1) - 2 * n;
+    const int c = B0 - t - n;
+    const int u = (Dq - 4 * E - n) >> 1;
+    const int d = E - n - u;
+    const int g = (S1 - B0W - Dq + 5 * n) >> 1;
+    nC = (uint32_t)c; nG = (uint32_t)g; nT = (uint32_t)t; nD = (uint32_t)d; nN = (uint32_t)n; nU = (uint32_t)u;
 }
 
 template <int W>
+struct tile_regs {
+    uint32_t d[W + 2][4];
+};
+
+template <int W>
+__device__ __forceinline__ void load_tile(tile_regs<W> &r, const uint8_t *__restrict__ msa, uint64_t col_stride,
+                                          uint32_t n_cols, uint32_t c0, uint64_t off, bool need_halo)
+{
+#pragma unroll
+    for (int j = 0; j < W + 2; ++j) {
+        const bool live = (c0 + j < n_cols) && (j < W || need_halo);
+        if (live) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(msa + (uint64_t)(c0 + j) * col_stride + off);
+            r.d[j][0] = v.x; r.d[j][1] = v.y; r.d[j][2] = v.z; r.d[j][3] = v.w;
+        } else {
+            r.d[j][0] = r.d[j][1] = r.d[j][2] = r.d[j][3] = kNone;
+        }
+    }
+}
+
+template <int W, bool PIPE>
 __global__ __launch_bounds__(256) void pileup_kernel(const uint8_t *__restrict__ msa, uint64_t col_stride,
                                                       uint32_t n_cols, uint32_t n_tiles,
                                                       const uint8_t *__restrict__ colflag,
@@ -56,17 +107,15 @@ __global__ __launch_bounds__(256) void pileup_kernel(const uint8_t *__restrict__
                                                       uint32_t *__restrict__ counts, uint32_t *__restrict__ hist)
 {
     __shared__ uint32_t s_hist[W][64];
-    __shared__ uint32_t s_raw[W][6];
-    __shared__ uint32_t s_mism[W];
-    __shared__ uint32_t s_words;
+    __shared__ uint32_t s_col[W][6];   // A C G T - N
+    __shared__ uint32_t s_match[W];
 
     const uint32_t tid = threadIdx.x;
     const uint32_t c0 = blockIdx.x * W;
 
     for (uint32_t i = tid; i < W * 64; i += 256) (&s_hist[0][0])[i] = 0;
-    if (tid < W * 6) (&s_raw[0][0])[tid] = 0;
-    if (tid < W) s_mism[tid] = 0;
-    if (tid == 0) s_words = 0;
+    if (tid < W * 6) (&s_col[0][0])[tid] = 0;
+    if (tid < W) s_match[tid] = 0;
     __syncthreads();
 
     // per-column metadata is block-uniform
@@ -74,117 +123,129 @@ __global__ __launch_bounds__(256) void pileup_kernel(const uint8_t *__restrict__
     uint32_t g[W + 2];       // seed base of column c0+j replicated into every nibble
 #pragma unroll
     for (int j = 0; j < W + 2; ++j) {
-        uint32_t c = c0 + j;
-        uint32_t b = c < n_cols ? guess[c] & 3u : 0u;
+        const uint32_t c = c0 + j;
+        const uint32_t b = c < n_cols ? guess[c] & 3u : 0u;
         g[j] = b * kM1;
         if (j < W && c < n_cols && (colflag[c] & 1u)) startf |= 1u << j;
     }
     const bool need_halo = (startf >> (W - 2)) != 0;
+    const bool last_lane = (tid & 63u) == 63u;
+    const uint64_t lane_off = (uint64_t)tid * 16u;
 
-    uint32_t acc[W][6];
-    uint32_t mism[W];
-#pragma unroll
-    for (int j = 0; j < W; ++j) {
-        mism[j] = 0;
-#pragma unroll
-        for (int k = 0; k < 6; ++k) acc[j][k] = 0;
+    uint32_t tile = blockIdx.y;
+    tile_regs<W> nxt;
+    bool nxt_live = false;
+    if (PIPE && tile < n_tiles) {
+        const uint64_t off = (uint64_t)tile * JL_PILEUP_TILE_BYTES + lane_off;
+        nxt_live = off < col_stride;
+        if (nxt_live) load_tile<W>(nxt, msa, col_stride, n_cols, c0, off, need_halo);
     }
-    uint32_t words = 0;
 
-    for (uint32_t tile = blockIdx.y; tile < n_tiles; tile += gridDim.y) {
-        const uint64_t off = (uint64_t)tile * JL_PILEUP_TILE_BYTES + (uint64_t)tid * 16u;
-        if (off >= col_stride) continue;  // col_stride is a multiple of 128: a 16-B chunk is all in or all out
-        uint32_t d[W + 2][4];
-#pragma unroll
-        for (int j = 0; j < W + 2; ++j) {
-            const bool live = (c0 + j < n_cols) && (j < W || need_halo);
-            if (live) {
-                const uint4 v = *reinterpret_cast<const uint4 *>(msa + (uint64_t)(c0 + j) * col_stride + off);
-                d[j][0] = v.x; d[j][1] = v.y; d[j][2] = v.z; d[j][3] = v.w;
-            } else {
-                d[j][0] = d[j][1] = d[j][2] = d[j][3] = kNone;
-            }
-        }
-        words += 4;
+    while (tile < n_tiles) {
+        uint32_t acc[W][6];
+        uint32_t mism[W];
 #pragma unroll
         for (int j = 0; j < W; ++j) {
-            if (c0 + j < n_cols) {
+            mism[j] = 0;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) count_planes(d[j][q], acc[j]);
-            }
+            for (int k = 0; k < 6; ++k) acc[j][k] = 0;
         }
-#pragma unroll
-        for (int j = 0; j < W; ++j) {
-            if (startf & (1u << j)) {
-                uint32_t mm[4];
-                uint32_t any = 0;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const uint32_t w0 = d[j][q], w1 = d[j + 1][q], w2 = d[j + 2][q];
-                    const uint32_t x = (w0 ^ g[j]) | (w1 ^ g[j + 1]) | (w2 ^ g[j + 2]);
-                    const uint32_t m = (x | (x >> 1) | (x >> 2)) & kM1;  // read differs from the seed codon
-                    mism[j] += __popc(m);
-                    const uint32_t inv = ((w0 | w1 | w2) >> 2) & kM1;   // some code >= 4: not in coverage
-                    mm[q] = m & ~inv;                                    // valid codon, not the seed one
-                    any |= mm[q];
+        uint32_t words = 0;
+
+        for (uint32_t it = 0; it < kFlushTiles && tile < n_tiles; ++it, tile += gridDim.y) {
+            tile_regs<W> cur;
+            bool live;
+            if (PIPE) {
+                cur = nxt;
+                live = nxt_live;
+                const uint32_t tn = tile + gridDim.y;
+                nxt_live = false;
+                if (tn < n_tiles) {
+                    const uint64_t off = (uint64_t)tn * JL_PILEUP_TILE_BYTES + lane_off;
+                    nxt_live = off < col_stride;
+                    if (nxt_live) load_tile<W>(nxt, msa, col_stride, n_cols, c0, off, need_halo);
                 }
-                if (any) {
+            } else {
+                const uint64_t off = (uint64_t)tile * JL_PILEUP_TILE_BYTES + lane_off;
+                live = off < col_stride;  // col_stride is a multiple of 128: a 16-B chunk is all in or all out
+                if (live) load_tile<W>(cur, msa, col_stride, n_cols, c0, off, need_halo);
+            }
+            if (!live) continue;
+            words += 4;
+#pragma unroll
+            for (int j = 0; j < W; ++j) {
+                if (c0 + j < n_cols) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) measure(cur.d[j][q], acc[j]);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < W; ++j) {
+                if (startf & (1u << j)) {
+                    uint32_t mm[4];
+                    uint32_t any = 0;
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        uint32_t rest = mm[q];
-                        while (rest) {
-                            const int b = __ffs((int)rest) - 1;
-                            rest &= rest - 1;
-                            const uint32_t idx = (((d[j][q] >> b) & 3u) << 4) | (((d[j + 1][q] >> b) & 3u) << 2) |
-                                                 ((d[j + 2][q] >> b) & 3u);
-                            atomicAdd(&s_hist[j][idx], 1u);
+                        const uint32_t w0 = cur.d[j][q], w1 = cur.d[j + 1][q], w2 = cur.d[j + 2][q];
+                        const uint32_t x = (w0 ^ g[j]) | (w1 ^ g[j + 1]) | (w2 ^ g[j + 2]);
+                        const uint32_t m = (x | (x >> 1) | (x >> 2)) & kM1;  // read differs from the seed codon
+                        mism[j] += __popc(m);
+                        const uint32_t inv = ((w0 | w1 | w2) >> 2) & kM1;   // some code >= 4: not in coverage
+                        mm[q] = m & ~inv;                                    // valid codon, not the seed one
+                        any |= mm[q];
+                    }
+                    if (any) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            uint32_t rest = mm[q];
+                            while (rest) {
+                                const int b = __ffs((int)rest) - 1;
+                                rest &= rest - 1;
+                                const uint32_t idx = (((cur.d[j][q] >> b) & 3u) << 4) |
+                                                     (((cur.d[j + 1][q] >> b) & 3u) << 2) |
+                                                     ((cur.d[j + 2][q] >> b) & 3u);
+                                atomicAdd(&s_hist[j][idx], 1u);
+                            }
                         }
                     }
                 }
             }
         }
-    }
 
-    // ---- block reduction: wave sums by DPP, one LDS atomic per wave and counter
-    const bool last_lane = (tid & 63u) == 63u;
+        // ---- flush this batch: per-lane solve, 16-bit packing, DPP wave sums, one LDS atomic per wave and counter
+        const uint32_t nib = words * 8u;
 #pragma unroll
-    for (int j = 0; j < W; ++j) {
-#pragma unroll
-        for (int k = 0; k < 6; ++k) {
-            const uint32_t s = wave_sum(acc[j][k]);
-            if (last_lane && s) atomicAdd(&s_raw[j][k], s);
+        for (int j = 0; j < W; ++j) {
+            uint32_t nC, nG, nT, nD, nN, nU;
+            solve(acc[j], nC, nG, nT, nD, nN, nU);
+            const uint32_t nA = nib - (nC + nG + nT + nD + nN + nU);
+            const uint32_t p0 = wave_sum(nA | (nC << 16));
+            const uint32_t p1 = wave_sum(nG | (nT << 16));
+            const uint32_t p2 = wave_sum(nD | (nN << 16));
+            const uint32_t p3 = wave_sum((nib - mism[j]) & 0xFFFFu);  // reads equal to the seed codon
+            if (last_lane && c0 + j < n_cols) {
+                if (p0 & 0xFFFFu) atomicAdd(&s_col[j][0], p0 & 0xFFFFu);
+                if (p0 >> 16) atomicAdd(&s_col[j][1], p0 >> 16);
+                if (p1 & 0xFFFFu) atomicAdd(&s_col[j][2], p1 & 0xFFFFu);
+                if (p1 >> 16) atomicAdd(&s_col[j][3], p1 >> 16);
+                if (p2 & 0xFFFFu) atomicAdd(&s_col[j][4], p2 & 0xFFFFu);
+                if (p2 >> 16) atomicAdd(&s_col[j][5], p2 >> 16);
+                if ((startf & (1u << j)) && p3) atomicAdd(&s_match[j], p3);
+            }
         }
-        const uint32_t sm = wave_sum(mism[j]);
-        if (last_lane && sm) atomicAdd(&s_mism[j], sm);
-    }
-    {
-        const uint32_t sw = wave_sum(words);
-        if (last_lane && sw) atomicAdd(&s_words, sw);
     }
     __syncthreads();
 
-    const uint32_t nib = s_words * 8u;  // nibbles this block looked at, per column
-    if (nib == 0) return;
-    if (tid < W && c0 + tid < n_cols) {
+    if (tid < W * 6) {
+        const uint32_t j = tid / 6u, k = tid - j * 6u;
+        const uint32_t v = s_col[j][k];
+        if (v && c0 + j < n_cols) atomicAdd(counts + (uint64_t)(c0 + j) * 6u + k, v);
+    }
+    if (tid < W && (startf & (1u << tid))) {
+        // reads equal to the seed codon were only counted, never binned
         const uint32_t j = tid;
-        const uint32_t b0 = s_raw[j][0], b1 = s_raw[j][1], b2 = s_raw[j][2];
-        const uint32_t nT = s_raw[j][3], nU = s_raw[j][4], nN = s_raw[j][5];
-        const uint32_t nC = b0 - nT - nN;   // 1 = 001 ; b0 set in {1,3,5}
-        const uint32_t nG = b1 - nT - nU;   // 2 = 010 ; b1 set in {2,3,6}
-        const uint32_t nD = b2 - nN - nU;   // 4 = 100 ; b2 set in {4,5,6}
-        const uint32_t nA = nib - (nC + nG + nT + nD + nN + nU);
-        uint32_t *o = counts + (uint64_t)(c0 + j) * 6u;
-        if (nA) atomicAdd(o + 0, nA);
-        if (nC) atomicAdd(o + 1, nC);
-        if (nG) atomicAdd(o + 2, nG);
-        if (nT) atomicAdd(o + 3, nT);
-        if (nD) atomicAdd(o + 4, nD);
-        if (nN) atomicAdd(o + 5, nN);
-        if (startf & (1u << j)) {
-            // reads equal to the seed codon were only counted, never binned
-            const uint32_t seed = ((g[j] & 3u) << 4) | ((g[j + 1] & 3u) << 2) | (g[j + 2] & 3u);
-            s_hist[j][seed] += nib - s_mism[j];
-        }
+        const uint32_t seed = ((g[j] & 3u) << 4) | ((g[j + 1] & 3u) << 2) | (g[j + 2] & 3u);
+        s_hist[j][seed] += s_match[j];
     }
     __syncthreads();
     for (uint32_t i = tid; i < W * 64; i += 256) {
@@ -208,30 +269,43 @@ __global__ __launch_bounds__(64) void guess_kernel(const uint8_t *__restrict__ m
     const uint64_t off = (uint64_t)lane * 16u;
     if (off < col_stride) {
         const uint4 v = *reinterpret_cast<const uint4 *>(msa + (uint64_t)c * col_stride + off);
-        count_planes(v.x, a); count_planes(v.y, a); count_planes(v.z, a); count_planes(v.w, a);
+        measure(v.x, a); measure(v.y, a); measure(v.z, a); measure(v.w, a);
         words = 4;
     }
-    uint32_t s[6];
-#pragma unroll
-    for (int k = 0; k < 6; ++k) s[k] = wave_sum(a[k]);
-    const uint32_t sw = wave_sum(words);
+    uint32_t nC, nG, nT, nD, nN, nU;
+    solve(a, nC, nG, nT, nD, nN, nU);
+    const uint32_t nA = words * 8u - (nC + nG + nT + nD + nN + nU);
+    const uint32_t p0 = wave_sum(nA | (nC << 16));
+    const uint32_t p1 = wave_sum(nG | (nT << 16));
     if (lane == 63) {
-        const uint32_t nT = s[3], nU = s[4], nN = s[5];
-        const uint32_t nC = s[0] - nT - nN, nG = s[1] - nT - nU, nD = s[2] - nN - nU;
-        const uint32_t nA = sw * 8u - (nC + nG + nT + nD + nN + nU);
-        uint32_t best = 0, bv = nA;
-        if (nC > bv) { bv = nC; best = 1; }
-        if (nG > bv) { bv = nG; best = 2; }
-        if (nT > bv) { bv = nT; best = 3; }
+        uint32_t best = 0, bv = p0 & 0xFFFFu;
+        if ((p0 >> 16) > bv) { bv = p0 >> 16; best = 1; }
+        if ((p1 & 0xFFFFu) > bv) { bv = p1 & 0xFFFFu; best = 2; }
+        if ((p1 >> 16) > bv) { bv = p1 >> 16; best = 3; }
         guess[c] = (uint8_t)best;
     }
 }
 
-}  // namespace
+struct variant_t {
+    int w;
+    bool pipe;
+    void (*fn)(const uint8_t *, uint64_t, uint32_t, uint32_t, const uint8_t *, const uint8_t *, uint32_t *, uint32_t *);
+};
 
-#ifndef JL_PILEUP_W
-#define JL_PILEUP_W 12
-#endif
+const variant_t kVariants[] = {
+    {6, false, pileup_kernel<6, false>},
+    {6, true, pileup_kernel<6, true>},
+    {12, false, pileup_kernel<12, false>},
+    {12, true, pileup_kernel<12, true>},
+};
+
+int env_int(const char *name, int dflt)
+{
+    const char *s = getenv(name);
+    return s && *s ? atoi(s) : dflt;
+}
+
+}  // namespace
 
 const char *jl_pileup_kernel_name(void) { return "pileup_kernel"; }
 
@@ -243,15 +317,27 @@ void jl_launch_guess(jl_ctx *ctx)
 
 void jl_launch_pileup(jl_ctx *ctx)
 {
-    constexpr int W = JL_PILEUP_W;
+    // tuning knobs (defaults are the measured best on MI355X)
+    const int want_w = env_int("JL_PILEUP_W", JL_PILEUP_W);
+    const bool want_pipe = env_int("JL_PILEUP_PIPE", JL_PILEUP_PIPE) != 0;
+    const variant_t *var = &kVariants[0];
+    for (const variant_t &v : kVariants)
+        if (v.w == want_w && v.pipe == want_pipe) var = &v;
+    const uint32_t W = (uint32_t)var->w;
     const uint32_t n_chunks = (ctx->n_cols + W - 1) / W;
     const uint32_t n_tiles = (uint32_t)((ctx->col_stride + JL_PILEUP_TILE_BYTES - 1) / JL_PILEUP_TILE_BYTES);
-    // enough blocks to fill 256 CUs a few times over, without splitting the reads finer than one tile
-    uint32_t rsplit = (2048u + n_chunks - 1) / n_chunks;
+    // one resident wave of blocks: (CUs x blocks the kernel's registers admit per CU), reads split no finer than a tile
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)var->fn, 256, 0) != hipSuccess || per_cu < 1)
+        per_cu = 2;
+    if (per_cu > 8) per_cu = 8;
+    const uint32_t target = 256u * (uint32_t)per_cu * (uint32_t)env_int("JL_PILEUP_WAVES", 1);
+    uint32_t rsplit = (target + n_chunks / 2) / n_chunks;
+    const int forced = env_int("JL_PILEUP_RSPLIT", 0);
+    if (forced > 0) rsplit = (uint32_t)forced;
     if (rsplit > n_tiles) rsplit = n_tiles;
     if (rsplit < 1) rsplit = 1;
     if (rsplit > 65535u) rsplit = 65535u;
-    hipLaunchKernelGGL(pileup_kernel<W>, dim3(n_chunks, rsplit), dim3(256), 0, ctx->stream, ctx->d_msa,
-                       ctx->col_stride, ctx->n_cols, n_tiles, ctx->d_colflag, ctx->d_guess, ctx->d_counts,
-                       ctx->d_hist);
+    hipLaunchKernelGGL(var->fn, dim3(n_chunks, rsplit), dim3(256), 0, ctx->stream, ctx->d_msa, ctx->col_stride,
+                       ctx->n_cols, n_tiles, ctx->d_colflag, ctx->d_guess, ctx->d_counts, ctx->d_hist);
 }
