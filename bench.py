@@ -13,6 +13,7 @@ Prints ONE JSON line on rank 0 (see the driver contract in the task brief), incl
   cpu_baseline this repo's CPU restatement (oracle/, kind "port": the reference ships no source) on the host cores.
 """
 import argparse
+import ctypes as C
 import json
 import os
 import sys
@@ -89,7 +90,6 @@ def main():
 
     comm = None
     if distributed:
-        import ctypes as C
         idbuf = np.zeros(128, dtype=np.uint8)
         if rank == 0:
             assert jl.lib.jl_comm_unique_id(idbuf.ctypes.data_as(C.c_void_p)) == 0
@@ -103,17 +103,14 @@ def main():
         all_counts = np.zeros(world, dtype=np.uint32)
 
     def step():
-        jl.pileup_async(genes, refseq)
-        jl.call_async(prm)
+        # the whole path as one captured graph + one pinned result copy; the all-gather (N > 1) is the only
+        # other device work of a step
+        jl.run_async(genes, refseq, prm, None, True, 10, True)
         if comm is not None:
             jl._chk(jl.lib.jl_allgather_variants(jl.h, comm, all_rows.ctypes.data_as(C.c_void_p),
                                                  all_counts.ctypes.data_as(C.c_void_p), capi.VARIANT_CAP))
-            table = None
-        else:
-            table = jl.call_fetch()
-        jl.phase_async(None, 10)
-        ph = jl.phase_fetch(want_reads=True, cap_var=64)
-        return table, ph
+        out = jl.run_fetch(True, True, cap_var=64)
+        return out["variants"], out["phase"]
 
     def fence():
         if distributed:

@@ -180,6 +180,18 @@ int jl_phase_async(jl_ctx *ctx, const jl_variant *variants, uint32_t n_var, uint
 int jl_phase_fetch(jl_ctx *ctx, jl_phase_summary *summary, uint32_t *pos_cols, uint32_t *hap_count,
                    uint8_t *hap_pattern, uint8_t *hit, uint16_t *read_hap, uint32_t *cooc, uint32_t cap_var);
 
+/* ---------------------------------------------------------------- the whole path in one enqueue */
+
+/*
+ * pileup -> call (-> phase) -> one small result copy, enqueued as a captured HIP graph that is replayed
+ * while genes / reference / parameters / buffers are unchanged (what `juliet in.bam out.json` does per
+ * window, J:62-66, 195).  Results are then read with jl_call_fetch / jl_phase_fetch, which decode the
+ * pinned result block without further device traffic.  `want_read_hap` also copies the per-read haplotype
+ * ids (the haplotype block's read lists, J:209-211).  Set the environment variable JL_NO_GRAPH to run eagerly.
+ */
+int jl_run_async(jl_ctx *ctx, const jl_gene *genes, uint32_t n_genes, const uint8_t *refseq, uint32_t ref_len,
+                 const jl_params *prm, const uint64_t *drm_masks, int phasing, uint32_t min_reads, int want_read_hap);
+
 /* ---------------------------------------------------------------- numerics self-check */
 
 /*

@@ -31,7 +31,7 @@ EXPORTS = ("jl_abi_version", "jl_strerror", "jl_device_count", "jl_ctx_create", 
            "jl_sync", "jl_col_stride", "jl_msa_upload", "jl_msa_alloc", "jl_msa_adopt", "jl_msa_pack_rows",
            "jl_msa_download", "jl_synth_fill", "jl_pileup_async", "jl_n_positions", "jl_pileup_fetch",
            "jl_call_async", "jl_call_fetch", "jl_variant_table_device", "jl_phase_async", "jl_phase_fetch",
-           "jl_fisher_eval", "jl_time_pileup", "jl_pileup_kernel_name", "jl_comm_unique_id", "jl_comm_create", "jl_comm_destroy",
+           "jl_run_async", "jl_fisher_eval", "jl_time_pileup", "jl_pileup_kernel_name", "jl_comm_unique_id", "jl_comm_create", "jl_comm_destroy",
            "jl_allgather_variants")
 
 
@@ -104,6 +104,7 @@ def load_library(path=LIB_PATH):
     lib.jl_variant_table_device.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(u32)]
     lib.jl_phase_async.argtypes = [vp, vp, u32, u32]
     lib.jl_phase_fetch.argtypes = [vp] * 8 + [u32]
+    lib.jl_run_async.argtypes = [vp, vp, u32, vp, u32, C.POINTER(Params), vp, C.c_int, u32, C.c_int]
     lib.jl_fisher_eval.argtypes = [vp, vp, vp, vp, u32, vp, vp]
     lib.jl_time_pileup.argtypes = [vp, u32, C.POINTER(C.c_float)]
     lib.jl_comm_unique_id.argtypes = [vp]
@@ -265,21 +266,66 @@ class Juliet:
         self._chk(self.lib.jl_time_pileup(self.h, reps, C.byref(ms)))
         return ms.value
 
-    # ------------------------------------------------------------------ convenience: the whole path
-    def run(self, genes, refseq=None, params=None, drm_masks=None, phasing=True, min_reads=10):
-        self.pileup_async(genes, refseq)
-        self.call_async(params, drm_masks)
+    # ------------------------------------------------------------------ the whole path in one enqueue
+    def run_async(self, genes, refseq=None, params=None, drm_masks=None, phasing=True, min_reads=10,
+                  want_read_hap=True):
+        """pileup -> call (-> phase) as one captured HIP graph + one pinned result copy (jl_run_async)."""
+        genes = np.ascontiguousarray(genes, dtype=GENE)
+        if refseq is not None:
+            refseq = np.ascontiguousarray(refseq, dtype=np.uint8)
+        if drm_masks is not None:
+            drm_masks = np.ascontiguousarray(drm_masks, dtype=np.uint64)
+        prm = params or default_params()
+        self._chk(self.lib.jl_run_async(self.h, _p(genes), len(genes), _p(refseq), 0 if refseq is None else len(refseq),
+                                        C.byref(prm), _p(drm_masks), 1 if phasing else 0, min_reads,
+                                        1 if want_read_hap else 0))
+
+    def _bufs(self, cap_var):
+        b = getattr(self, "_fetch_bufs", None)
+        if b is None or b["cap_var"] != cap_var or len(b["read_hap"]) != self.n_reads:
+            b = dict(cap_var=cap_var, variants=np.zeros(VARIANT_CAP, dtype=VARIANT), n=C.c_uint32(),
+                     summ=np.zeros(1, dtype=SUMMARY), pos_cols=np.zeros(cap_var, dtype=np.uint32),
+                     hap_count=np.zeros(MAX_HAPLOTYPES, dtype=np.uint32),
+                     hap_pattern=np.zeros((MAX_HAPLOTYPES, cap_var), dtype=np.uint8),
+                     hit=np.zeros((cap_var, MAX_HAPLOTYPES), dtype=np.uint8),
+                     read_hap=np.zeros(self.n_reads, dtype=np.uint16),
+                     cooc=np.zeros((cap_var, cap_var), dtype=np.uint32))
+            self._fetch_bufs = b
+        return b
+
+    def run_fetch(self, phasing=True, want_read_hap=True, cap_var=64):
+        """Results of the last run_async.  Returned arrays are views of buffers reused by the next call."""
+        b = self._bufs(cap_var)
+        self._chk(self.lib.jl_call_fetch(self.h, _p(b["variants"]), VARIANT_CAP, C.byref(b["n"])))
+        nv = b["n"].value
+        out = dict(variants=b["variants"][:nv])
         if phasing:
-            self.phase_async(None, min_reads)
-        variants = self.call_fetch()
-        out = dict(variants=variants)
-        if phasing:
-            ph = self.phase_fetch(cap_var=max(1, min(VARIANT_CAP, len(variants))))
-            ph["hit"] = ph["hit"][: len(variants), : ph["summary"]["n_haplotypes"]].copy()
-            if ph["cooc"] is not None:
-                ph["cooc"] = ph["cooc"][: len(variants), : len(variants)].copy()
-            out["phase"] = ph
+            self._chk(self.lib.jl_phase_fetch(self.h, _p(b["summ"]), _p(b["pos_cols"]), _p(b["hap_count"]),
+                                              _p(b["hap_pattern"]), _p(b["hit"]),
+                                              _p(b["read_hap"]) if want_read_hap else None, _p(b["cooc"]), cap_var))
+            s = {k: int(b["summ"][0][k]) for k in SUMMARY_FIELDS}
+            h, vp = s["n_haplotypes"], s["n_positions"]
+            out["phase"] = dict(summary=s, pos_cols=b["pos_cols"][:vp], hap_count=b["hap_count"][:h],
+                                hap_pattern=b["hap_pattern"][:h, :vp], hit=b["hit"][:nv, :h],
+                                read_hap=b["read_hap"] if want_read_hap else None, cooc=b["cooc"][:nv, :nv])
         return out
+
+    def run(self, genes, refseq=None, params=None, drm_masks=None, phasing=True, min_reads=10):
+        """The whole hot path, blocking; arrays are copies."""
+        self.run_async(genes, refseq, params, drm_masks, phasing, min_reads, want_read_hap=True)
+        cap = 64
+        while True:
+            try:
+                out = self.run_fetch(phasing, True, cap_var=cap)
+                break
+            except JulietError as e:
+                if e.status != -5 or cap >= VARIANT_CAP:
+                    raise
+                cap = min(VARIANT_CAP, cap * 8)
+        res = dict(variants=out["variants"].copy())
+        if phasing:
+            res["phase"] = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in out["phase"].items()}
+        return res
 
 
 def haplotype_name(h: int) -> str:

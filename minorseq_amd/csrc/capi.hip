@@ -28,6 +28,7 @@ static int regrow(jl_ctx *ctx, T **p, size_t n)
 {
     if (*p) hipFree(*p);
     *p = nullptr;
+    ctx->alloc_version++;  // pointers captured in a graph are stale now
     JL_HIP(ctx, hipMalloc(p, n * sizeof(T)));
     return JL_OK;
 }
@@ -98,7 +99,9 @@ int jl_ctx_create(int device, void *stream, jl_ctx **out)
               hipMalloc(&ctx->d_hap_count, sizeof(uint32_t) * JL_MAX_HAPLOTYPES) == hipSuccess &&
               hipMalloc(&ctx->d_hap_pattern, (size_t)JL_MAX_HAPLOTYPES * JL_VARIANT_CAP) == hipSuccess &&
               hipMalloc(&ctx->d_hit, (size_t)JL_VARIANT_CAP * JL_MAX_HAPLOTYPES) == hipSuccess &&
-              hipMalloc(&ctx->d_cooc, sizeof(uint32_t) * ctx->cooc_cap * ctx->cooc_cap) == hipSuccess;
+              hipMalloc(&ctx->d_cooc, sizeof(uint32_t) * ctx->cooc_cap * ctx->cooc_cap) == hipSuccess &&
+              hipMalloc(&ctx->d_pack, sizeof(jl_pack)) == hipSuccess &&
+              hipHostMalloc(&ctx->h_pack, sizeof(jl_pack), hipHostMallocDefault) == hipSuccess;
     if (!ok) { jl_ctx_destroy(ctx); return jl_fail(nullptr, JL_ERR_MEMORY, "context allocation failed"); }
     hipMemsetAsync(ctx->d_nvar, 0, 2 * sizeof(uint32_t), ctx->stream);
     hipMemsetAsync(ctx->d_meta, 0, sizeof(jl_phase_meta), ctx->stream);
@@ -108,6 +111,7 @@ int jl_ctx_create(int device, void *stream, jl_ctx **out)
 
 static void free_msa(jl_ctx *ctx)
 {
+    ctx->alloc_version++;
     if (ctx->own_msa && ctx->d_msa) hipFree(ctx->d_msa);
     ctx->d_msa = nullptr;
     ctx->own_msa = false;
@@ -119,13 +123,17 @@ void jl_ctx_destroy(jl_ctx *ctx)
     if (!ctx) return;
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
+    if (ctx->graph_exec) hipGraphExecDestroy(ctx->graph_exec);
+    if (ctx->graph) hipGraphDestroy(ctx->graph);
+    if (ctx->h_pack) hipHostFree(ctx->h_pack);
+    if (ctx->h_read_hap) hipHostFree(ctx->h_read_hap);
     free_msa(ctx);
     void *ptrs[] = {ctx->d_pos_gene, ctx->d_pos_codon, ctx->d_pos_col, ctx->d_pos_refcfg, ctx->d_colflag, ctx->d_guess,
                     ctx->d_counts, ctx->d_called, ctx->d_cand_p, ctx->d_cand_lp, ctx->d_cand_e, ctx->d_pos_cov,
                     ctx->d_pos_ref, ctx->d_drm, ctx->d_variants, ctx->d_nvar, ctx->d_meta, ctx->d_vpcols,
                     ctx->d_col2pos, ctx->d_varcol, ctx->d_keys, ctx->d_flagw, ctx->d_read_slot, ctx->d_read_hap,
                     ctx->d_slot_rep, ctx->d_slot_count, ctx->d_slot_key, ctx->d_slot_hap, ctx->d_occupied, ctx->d_hap_count,
-                    ctx->d_hap_pattern, ctx->d_hit, ctx->d_cooc};
+                    ctx->d_hap_pattern, ctx->d_hit, ctx->d_cooc, ctx->d_pack};
     for (void *p : ptrs)
         if (p) hipFree(p);
     if (ctx->ev0) hipEventDestroy(ctx->ev0);
@@ -157,6 +165,8 @@ static int set_shape(jl_ctx *ctx, uint64_t n_reads, uint32_t n_cols, uint64_t co
     ctx->n_cols = n_cols;
     ctx->col_stride = col_stride;
     ctx->win_begin = win_begin;
+    ctx->alloc_version++;
+    ctx->pack_valid = false;
     ctx->pileup_done = ctx->call_done = ctx->phase_done = false;
     return JL_OK;
 }
@@ -332,6 +342,7 @@ static int build_plan(jl_ctx *ctx, const jl_gene *genes, uint32_t n_genes, const
     // the staging vectors above are pageable: wait before they go out of scope
     JL_HIP(ctx, hipStreamSynchronize(st));
     ctx->plan_valid = true;
+    ctx->plan_version++;
     return JL_OK;
 }
 
@@ -359,6 +370,7 @@ int jl_pileup_async(jl_ctx *ctx, const jl_gene *genes, uint32_t n_genes, const u
     JL_HIP(ctx, hipGetLastError());
     ctx->pileup_done = true;
     ctx->call_done = ctx->phase_done = false;
+    ctx->pack_valid = false;
     return JL_OK;
 }
 
@@ -410,6 +422,7 @@ int jl_call_async(jl_ctx *ctx, const jl_params *prm, const uint64_t *drm_masks)
     JL_HIP(ctx, hipGetLastError());
     ctx->call_done = true;
     ctx->phase_done = false;
+    ctx->pack_valid = false;
     return JL_OK;
 }
 
@@ -417,6 +430,17 @@ int jl_call_fetch(jl_ctx *ctx, jl_variant *out, uint32_t cap, uint32_t *n_out)
 {
     if (!ctx || !n_out || (!out && cap)) return JL_ERR_ARG;
     if (!ctx->call_done) return jl_fail(ctx, JL_ERR_STATE, "jl_call_fetch before jl_call_async");
+    if (ctx->pack_valid) {  // one pinned copy already holds the table
+        JL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        const jl_pack *pk = ctx->h_pack;
+        if (pk->magic == JL_PACK_MAGIC && pk->fits_call) {
+            *n_out = pk->nvar_total;
+            const uint32_t take = pk->nvar_total < cap ? pk->nvar_total : cap;
+            if (take) memcpy(out, pk->variants, (size_t)take * sizeof(jl_variant));
+            if (pk->nvar_total > cap) return jl_fail(ctx, JL_ERR_OVERFLOW, "%u variant rows, capacity %u", pk->nvar_total, cap);
+            return JL_OK;
+        }
+    }
     uint32_t n = 0;
     JL_HIP(ctx, hipMemcpyAsync(&n, ctx->d_nvar, 4, hipMemcpyDeviceToHost, ctx->stream));
     JL_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -497,6 +521,7 @@ int jl_phase_async(jl_ctx *ctx, const jl_variant *variants, uint32_t n_var, uint
     jl_launch_phase(ctx, min_reads);
     JL_HIP(ctx, hipGetLastError());
     ctx->phase_done = true;
+    ctx->pack_valid = false;
     return JL_OK;
 }
 
@@ -506,6 +531,32 @@ int jl_phase_fetch(jl_ctx *ctx, jl_phase_summary *summary, uint32_t *pos_cols, u
     if (!ctx) return JL_ERR_ARG;
     if (!ctx->phase_done) return jl_fail(ctx, JL_ERR_STATE, "jl_phase_fetch before jl_phase_async");
     hipStream_t st = ctx->stream;
+    if (ctx->pack_valid) {
+        JL_HIP(ctx, hipStreamSynchronize(st));
+        const jl_pack *pk = ctx->h_pack;
+        if (pk->magic == JL_PACK_MAGIC && pk->phase_ran && pk->fits_phase && (!cooc || pk->cooc_fits)) {
+            const uint32_t vp = pk->vp, H = pk->H, nv = pk->nv_phase;
+            if ((pos_cols || hap_pattern) && vp > cap_var) return jl_fail(ctx, JL_ERR_OVERFLOW, "%u variant positions, caller capacity %u", vp, cap_var);
+            if ((hit || cooc) && nv > cap_var) return jl_fail(ctx, JL_ERR_OVERFLOW, "%u variants, caller capacity %u", nv, cap_var);
+            if (summary) *summary = pk->summary;
+            if (pos_cols && vp) memcpy(pos_cols, pk->pos_cols, (size_t)vp * 4);
+            if (hap_count && H) memcpy(hap_count, pk->hap_count, (size_t)H * 4);
+            if (hap_pattern)
+                for (uint32_t h = 0; h < H; ++h) memcpy(hap_pattern + (size_t)h * cap_var, pk->hap_pattern + (size_t)h * vp, vp);
+            if (hit)
+                for (uint32_t v = 0; v < nv; ++v) memcpy(hit + (size_t)v * JL_MAX_HAPLOTYPES, pk->hit + (size_t)v * H, H);
+            if (cooc)
+                for (uint32_t v = 0; v < nv; ++v) memcpy(cooc + (size_t)v * cap_var, pk->cooc + (size_t)v * nv, (size_t)nv * 4);
+            if (read_hap) {
+                if (ctx->run_read_hap) memcpy(read_hap, ctx->h_read_hap, (size_t)ctx->n_reads * 2);
+                else {
+                    JL_HIP(ctx, hipMemcpyAsync(read_hap, ctx->d_read_hap, (size_t)ctx->n_reads * 2, hipMemcpyDeviceToHost, st));
+                    JL_HIP(ctx, hipStreamSynchronize(st));
+                }
+            }
+            return JL_OK;
+        }
+    }
     jl_phase_meta meta;
     JL_HIP(ctx, hipMemcpyAsync(&meta, ctx->d_meta, sizeof meta, hipMemcpyDeviceToHost, st));
     if (read_hap) JL_HIP(ctx, hipMemcpyAsync(read_hap, ctx->d_read_hap, (size_t)ctx->n_reads * 2, hipMemcpyDeviceToHost, st));
@@ -536,6 +587,93 @@ int jl_phase_fetch(jl_ctx *ctx, jl_phase_summary *summary, uint32_t *pos_cols, u
     }
     JL_HIP(ctx, hipStreamSynchronize(st));
     if (meta.overflow & 1u) return jl_fail(ctx, JL_ERR_OVERFLOW, "more than %u haplotype candidates", JL_CAND_CAP);
+    return JL_OK;
+}
+
+/* ---------------------------------------------------------------- the whole path as one enqueue */
+
+static void enqueue_path(jl_ctx *ctx, const jl_params *prm, double n_tests, bool use_drm, bool phasing, uint32_t min_reads,
+                         bool want_read_hap)
+{
+    hipStream_t st = ctx->stream;
+    hipMemsetAsync(ctx->d_counts, 0, ctx->counts_words * sizeof(uint32_t), st);
+    if (!ctx->have_ref) jl_launch_guess(ctx);
+    jl_launch_pileup(ctx);
+    jl_launch_call(ctx, prm, n_tests, use_drm);
+    if (phasing) jl_launch_phase(ctx, min_reads);
+    jl_launch_result_pack(ctx, phasing);
+    hipMemcpyAsync(ctx->h_pack, ctx->d_pack, sizeof(jl_pack), hipMemcpyDeviceToHost, st);
+    if (phasing && want_read_hap)
+        hipMemcpyAsync(ctx->h_read_hap, ctx->d_read_hap, (size_t)ctx->n_reads * 2, hipMemcpyDeviceToHost, st);
+}
+
+int jl_run_async(jl_ctx *ctx, const jl_gene *genes, uint32_t n_genes, const uint8_t *refseq, uint32_t ref_len,
+                 const jl_params *prm, const uint64_t *drm_masks, int phasing, uint32_t min_reads, int want_read_hap)
+{
+    if (!ctx || !prm || (!genes && n_genes)) return JL_ERR_ARG;
+    if (!ctx->d_msa) return jl_fail(ctx, JL_ERR_STATE, "no resident matrix: call jl_msa_upload/alloc/adopt first");
+    if (prm->tail != 0) return jl_fail(ctx, JL_ERR_ARG, "only the one-sided (greater) tail is implemented");
+    if (!(prm->alpha > 0.0) || !(prm->err.match > 0.0) || !(prm->err.substitution >= 0.0))
+        return jl_fail(ctx, JL_ERR_ARG, "alpha/match must be > 0 and substitution >= 0");
+    JL_HIP(ctx, hipSetDevice(ctx->device));
+    int rc;
+    // everything that allocates or waits happens before the enqueue (and before any capture)
+    if (!same_plan(ctx, genes, n_genes, refseq, ref_len) && (rc = build_plan(ctx, genes, n_genes, refseq, ref_len))) return rc;
+    if (drm_masks && ctx->P) {
+        JL_HIP(ctx, hipMemcpyAsync(ctx->d_drm, drm_masks, (size_t)ctx->P * 8, hipMemcpyHostToDevice, ctx->stream));
+        JL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    if (phasing) {
+        if ((rc = reserve_phase(ctx, ctx->keys_words > 4 ? ctx->keys_words : 4))) return rc;
+        if (want_read_hap && ctx->h_read_hap_cap < (size_t)ctx->col_stride * 2) {
+            if (ctx->h_read_hap) hipHostFree(ctx->h_read_hap);
+            ctx->h_read_hap = nullptr;
+            ctx->alloc_version++;
+            JL_HIP(ctx, hipHostMalloc(&ctx->h_read_hap, (size_t)ctx->col_stride * 4, hipHostMallocDefault));
+            ctx->h_read_hap_cap = (size_t)ctx->col_stride * 2;
+        }
+    }
+    const double n_tests = prm->n_tests > 0.0 ? prm->n_tests : ctx->default_n_tests;
+    ctx->last_min_reads = min_reads;
+    jl_prepare_pileup(ctx);
+
+    // signature of everything a captured graph bakes in
+    struct { uint64_t alloc, plan; jl_params prm; double n_tests; uint32_t drm, phasing, min_reads, rh; } sig;
+    memset(&sig, 0, sizeof sig);
+    sig.alloc = ctx->alloc_version; sig.plan = ctx->plan_version; sig.prm = *prm; sig.n_tests = n_tests;
+    sig.drm = drm_masks != nullptr; sig.phasing = phasing != 0; sig.min_reads = min_reads; sig.rh = want_read_hap != 0;
+    const bool graphs_on = !getenv("JL_NO_GRAPH");
+    bool launched = false;
+    if (graphs_on) {
+        const bool hit = ctx->graph_exec && ctx->graph_sig.size() == sizeof sig && memcmp(ctx->graph_sig.data(), &sig, sizeof sig) == 0;
+        if (!hit) {
+            if (ctx->graph_exec) { hipGraphExecDestroy(ctx->graph_exec); ctx->graph_exec = nullptr; }
+            if (ctx->graph) { hipGraphDestroy(ctx->graph); ctx->graph = nullptr; }
+            ctx->graph_sig.clear();
+            if (hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+                enqueue_path(ctx, prm, n_tests, drm_masks != nullptr, phasing != 0, min_reads, want_read_hap != 0);
+                hipGraph_t g = nullptr;
+                if (hipStreamEndCapture(ctx->stream, &g) == hipSuccess && g &&
+                    hipGraphInstantiate(&ctx->graph_exec, g, nullptr, nullptr, 0) == hipSuccess) {
+                    ctx->graph = g;
+                    ctx->graph_sig.assign((const uint8_t *)&sig, (const uint8_t *)&sig + sizeof sig);
+                } else {
+                    if (g) hipGraphDestroy(g);
+                    ctx->graph_exec = nullptr;
+                }
+            }
+            (void)hipGetLastError();
+        }
+        if (ctx->graph_exec && hipGraphLaunch(ctx->graph_exec, ctx->stream) == hipSuccess) launched = true;
+    }
+    if (!launched) {
+        enqueue_path(ctx, prm, n_tests, drm_masks != nullptr, phasing != 0, min_reads, want_read_hap != 0);
+        JL_HIP(ctx, hipGetLastError());
+    }
+    ctx->pileup_done = ctx->call_done = true;
+    ctx->phase_done = phasing != 0;
+    ctx->pack_valid = true;
+    ctx->run_read_hap = phasing && want_read_hap;
     return JL_OK;
 }
 

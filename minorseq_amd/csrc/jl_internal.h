@@ -30,6 +30,29 @@ struct jl_phase_meta {  // device-resident scalars of one phasing run
     jl_phase_summary summary;
 };
 
+// Small fixed-size result block: everything a typical run returns except the per-read ids, gathered by one
+// tiny kernel so that ONE device-to-host copy into pinned memory ends the step (results that do not fit set
+// fits_* = 0 and the fetch calls fall back to their piecewise copies).
+#define JL_PACK_MAX_VAR 128u
+#define JL_PACK_MAX_VP 128u
+#define JL_PACK_MAX_HAP 128u
+#define JL_PACK_PATTERN_BYTES 4096u
+#define JL_PACK_HIT_BYTES 4096u
+#define JL_PACK_COOC_N 32u
+#define JL_PACK_MAGIC 0x4A4C504Bu
+struct jl_pack {
+    uint32_t magic, nvar_total, fits_call, fits_phase;
+    uint32_t phase_ran, overflow, vp, H;
+    jl_phase_summary summary;
+    uint32_t nv_phase, cooc_fits, pad_[6];
+    jl_variant variants[JL_PACK_MAX_VAR];
+    uint32_t pos_cols[JL_PACK_MAX_VP];
+    uint32_t hap_count[JL_PACK_MAX_HAP];
+    uint8_t hap_pattern[JL_PACK_PATTERN_BYTES];  // [H][vp]
+    uint8_t hit[JL_PACK_HIT_BYTES];              // [nv][H]
+    uint32_t cooc[JL_PACK_COOC_N * JL_PACK_COOC_N];  // [nv][nv]
+};
+
 struct jl_ctx {
     int device = -1;
     hipStream_t stream = nullptr;
@@ -103,6 +126,20 @@ struct jl_ctx {
     uint32_t cooc_cap = 256;
     bool phase_done = false;
 
+    // ---- whole-path run: result pack, pinned mirrors, captured graph
+    jl_pack *d_pack = nullptr;
+    jl_pack *h_pack = nullptr;        // pinned
+    uint16_t *h_read_hap = nullptr;   // pinned, [reads_pad]
+    size_t h_read_hap_cap = 0;
+    bool pack_valid = false;          // the last stage calls were one jl_run_async
+    bool run_read_hap = false;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t graph_exec = nullptr;
+    std::vector<uint8_t> graph_sig;
+    uint64_t alloc_version = 0;       // bumped by every (re)allocation: captured pointers go stale
+    uint64_t plan_version = 0;
+    int pileup_blocks_per_cu[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // occupancy per kernel variant, queried once
+
     // ---- timing
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
@@ -120,9 +157,11 @@ int jl_fail(jl_ctx *ctx, int status, const char *fmt, ...);
 // kernel launchers (defined in the .hip files) -------------------------------------------------
 void jl_launch_guess(jl_ctx *ctx);
 void jl_launch_pileup(jl_ctx *ctx);
+void jl_prepare_pileup(jl_ctx *ctx);
 void jl_launch_call(jl_ctx *ctx, const jl_params *prm, double n_tests, bool use_drm);
 void jl_launch_phase(jl_ctx *ctx, uint32_t min_reads);
 void jl_launch_synth(jl_ctx *ctx, const jl_synth_plan *plan, const uint8_t *d_ref);
 void jl_launch_pack_rows(jl_ctx *ctx, const uint8_t *d_rows);
+void jl_launch_result_pack(jl_ctx *ctx, bool phasing);
 void jl_launch_fisher_eval(jl_ctx *ctx, uint32_t n, const uint32_t *a, const uint32_t *c, const uint32_t *cov,
                            double *p, double *lp);

@@ -570,7 +570,56 @@ __global__ __launch_bounds__(256) void phase_cooc_kernel(const jl_phase_meta *__
     }
 }
 
+
+// ---------------------------------------------------------------------------------------- result pack
+__global__ __launch_bounds__(256) void result_pack_kernel(const jl_variant *__restrict__ variants,
+                                                           const uint32_t *__restrict__ n_rows,
+                                                           const jl_phase_meta *__restrict__ meta, uint32_t phasing,
+                                                           const uint32_t *__restrict__ vpcols,
+                                                           const uint32_t *__restrict__ hap_count,
+                                                           const uint8_t *__restrict__ hap_pattern,
+                                                           const uint8_t *__restrict__ hit,
+                                                           const uint32_t *__restrict__ cooc, uint32_t cooc_cap,
+                                                           jl_pack *__restrict__ pk)
+{
+    const uint32_t tid = threadIdx.x;
+    const uint32_t n = n_rows[0];
+    const uint32_t fits_call = n <= JL_PACK_MAX_VAR;
+    uint32_t vp = 0, H = 0, nv = 0, ovf = 0, fits_phase = 0, cooc_fits = 0;
+    if (phasing) {
+        vp = meta->vp; H = meta->summary.n_haplotypes; nv = meta->n_var; ovf = meta->overflow;
+        fits_phase = ovf == 0 && fits_call && vp <= JL_PACK_MAX_VP && H <= JL_PACK_MAX_HAP &&
+                     H * vp <= JL_PACK_PATTERN_BYTES && nv * H <= JL_PACK_HIT_BYTES;
+        cooc_fits = nv <= JL_PACK_COOC_N;
+    }
+    if (tid == 0) {
+        pk->magic = JL_PACK_MAGIC; pk->nvar_total = n; pk->fits_call = fits_call; pk->fits_phase = fits_phase;
+        pk->phase_ran = phasing; pk->overflow = ovf; pk->vp = vp; pk->H = H;
+        pk->nv_phase = nv; pk->cooc_fits = cooc_fits;
+        if (phasing) pk->summary = meta->summary;
+    }
+    if (fits_call)
+        for (uint32_t i = tid; i < n * (uint32_t)(sizeof(jl_variant) / 8); i += 256u)
+            reinterpret_cast<uint64_t *>(pk->variants)[i] = reinterpret_cast<const uint64_t *>(variants)[i];
+    if (fits_phase) {
+        for (uint32_t i = tid; i < vp; i += 256u) pk->pos_cols[i] = vpcols[i];
+        for (uint32_t i = tid; i < H; i += 256u) pk->hap_count[i] = hap_count[i];
+        for (uint32_t i = tid; i < H * vp; i += 256u)
+            pk->hap_pattern[i] = hap_pattern[(uint64_t)(i / vp) * JL_VARIANT_CAP + (i % vp)];
+        for (uint32_t i = tid; i < nv * H; i += 256u) pk->hit[i] = hit[(uint64_t)(i / H) * JL_MAX_HAPLOTYPES + (i % H)];
+        if (cooc_fits)
+            for (uint32_t i = tid; i < nv * nv; i += 256u) pk->cooc[i] = cooc[(uint64_t)(i / nv) * cooc_cap + (i % nv)];
+    }
+}
+
 }  // namespace
+
+void jl_launch_result_pack(jl_ctx *ctx, bool phasing)
+{
+    hipLaunchKernelGGL(result_pack_kernel, dim3(1), dim3(256), 0, ctx->stream, ctx->d_variants, ctx->d_nvar, ctx->d_meta,
+                       phasing ? 1u : 0u, ctx->d_vpcols, ctx->d_hap_count, ctx->d_hap_pattern, ctx->d_hit, ctx->d_cooc,
+                       ctx->cooc_cap, ctx->d_pack);
+}
 
 void jl_launch_phase(jl_ctx *ctx, uint32_t min_reads)
 {

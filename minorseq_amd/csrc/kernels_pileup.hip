@@ -315,22 +315,39 @@ void jl_launch_guess(jl_ctx *ctx)
                        ctx->n_cols, ctx->d_guess);
 }
 
-void jl_launch_pileup(jl_ctx *ctx)
+static int pick_variant()
 {
     // tuning knobs (defaults are the measured best on MI355X)
     const int want_w = env_int("JL_PILEUP_W", JL_PILEUP_W);
     const bool want_pipe = env_int("JL_PILEUP_PIPE", JL_PILEUP_PIPE) != 0;
-    const variant_t *var = &kVariants[0];
-    for (const variant_t &v : kVariants)
-        if (v.w == want_w && v.pipe == want_pipe) var = &v;
+    int idx = 0;
+    for (int i = 0; i < (int)(sizeof(kVariants) / sizeof(kVariants[0])); ++i)
+        if (kVariants[i].w == want_w && kVariants[i].pipe == want_pipe) idx = i;
+    return idx;
+}
+
+// occupancy query, once per variant and outside any stream capture
+void jl_prepare_pileup(jl_ctx *ctx)
+{
+    const int idx = pick_variant();
+    if (ctx->pileup_blocks_per_cu[idx] > 0) return;
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)kVariants[idx].fn, 256, 0) != hipSuccess || per_cu < 1)
+        per_cu = 2;
+    if (per_cu > 8) per_cu = 8;
+    ctx->pileup_blocks_per_cu[idx] = per_cu;
+}
+
+void jl_launch_pileup(jl_ctx *ctx)
+{
+    const int idx = pick_variant();
+    const variant_t *var = &kVariants[idx];
+    jl_prepare_pileup(ctx);
     const uint32_t W = (uint32_t)var->w;
     const uint32_t n_chunks = (ctx->n_cols + W - 1) / W;
     const uint32_t n_tiles = (uint32_t)((ctx->col_stride + JL_PILEUP_TILE_BYTES - 1) / JL_PILEUP_TILE_BYTES);
     // one resident wave of blocks: (CUs x blocks the kernel's registers admit per CU), reads split no finer than a tile
-    int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)var->fn, 256, 0) != hipSuccess || per_cu < 1)
-        per_cu = 2;
-    if (per_cu > 8) per_cu = 8;
+    const int per_cu = ctx->pileup_blocks_per_cu[idx];
     const uint32_t target = 256u * (uint32_t)per_cu * (uint32_t)env_int("JL_PILEUP_WAVES", 1);
     uint32_t rsplit = (target + n_chunks / 2) / n_chunks;
     const int forced = env_int("JL_PILEUP_RSPLIT", 0);

@@ -347,3 +347,64 @@ def test_config2_full_size_against_oracle(jl, oracle):
     exp_v = oracle.call(rows, genes, refseq=ref)
     assert_variants_equal(out["variants"], exp_v)
     assert_phase_equal(out["phase"], oracle.phase(rows, exp_v), len(exp_v))
+
+
+# --------------------------------------------------------------------------------------------- graph replay
+def test_run_graph_replay_tracks_new_data_and_parameters(jl, oracle):
+    """jl_run_async replays a captured graph while nothing it bakes in changes: new reads in the same
+    buffers must flow through the replay, and changed parameters / genes / shapes must re-capture."""
+    n, l = 6000, 300
+    genes = np.array([(1, l + 1)], dtype=capi.GENE)
+    j = capi.Juliet(0)
+    j.alloc(n, l)
+    for seed, prm in ((41, capi.default_params()), (42, capi.default_params()), (43, capi.default_params()),
+                      (43, capi.default_params(alpha=0.3, n_tests=1.0)), (44, capi.default_params(min_perc=3.0))):
+        sp = synth.SynthParams(seed=seed, minor_permille=(70, 50, 40, 30), partial_rate=0.1)
+        ref = synth.reference(41, l)          # same reference: the plan (and the graph) stay valid across seeds
+        j.synth_fill(sp, ref)
+        rows = msa.unpack_columns(j.download_columns(), n)
+        out = j.run(genes, ref, prm)
+        o = oracle_params(prm)
+        exp_v = oracle.call(rows, genes, refseq=ref, params=o)
+        if prm.min_perc >= 0:
+            exp_v = exp_v[100.0 * exp_v["count"] / exp_v["coverage"] > prm.min_perc]
+        assert_variants_equal(out["variants"], exp_v)
+        assert_phase_equal(out["phase"], oracle.phase(rows, exp_v), len(exp_v))
+    # different gene set and a different shape on the same context
+    genes2 = np.array([(1, 151), (152, 299)], dtype=capi.GENE)
+    out = j.run(genes2, ref, capi.default_params())
+    assert_variants_equal(out["variants"], oracle.call(rows, genes2, refseq=ref))
+    rows3 = synth.rows(synth.SynthParams(seed=5, minor_permille=(60, 60, 60, 60)), 90, 0, 2000)
+    j.upload_columns(msa.pack_columns(rows3), 2000)
+    g3 = np.array([(1, 91)], dtype=capi.GENE)
+    out = j.run(g3, None, capi.default_params())
+    exp_v = oracle.call(rows3, g3)
+    assert_variants_equal(out["variants"], exp_v)
+    assert_phase_equal(out["phase"], oracle.phase(rows3, exp_v), len(exp_v))
+    # eager path (no graph) gives the same answer
+    os.environ["JL_NO_GRAPH"] = "1"
+    try:
+        out2 = j.run(g3, None, capi.default_params())
+    finally:
+        del os.environ["JL_NO_GRAPH"]
+    assert (out2["variants"] == out["variants"]).all()
+    assert out2["phase"]["summary"] == out["phase"]["summary"]
+    j.close()
+
+
+def test_run_results_larger_than_the_pack(jl, oracle):
+    """More variants / positions than the pinned result block holds: the fetch calls fall back to piecewise copies."""
+    n, l = 6000, 600
+    sp = synth.SynthParams(seed=31, sub_rate=0.01, minor_permille=(50, 50, 50, 50))
+    ref = synth.reference(sp.seed, l)
+    rows = synth.rows(sp, l, 0, n, ref)
+    j = capi.Juliet(0)
+    j.upload_columns(msa.pack_columns(rows), n)
+    genes = np.array([(1, l + 1)], dtype=capi.GENE)
+    loose = capi.default_params(alpha=0.9, n_tests=1.0)
+    out = j.run(genes, None, loose, min_reads=3)
+    exp_v = oracle.call(rows, genes, params=oracle_params(loose))
+    assert len(exp_v) > 128
+    assert_variants_equal(out["variants"], exp_v)
+    assert_phase_equal(out["phase"], oracle.phase(rows, exp_v, min_reads=3), len(exp_v))
+    j.close()
