@@ -270,15 +270,21 @@ class Juliet:
     def run_async(self, genes, refseq=None, params=None, drm_masks=None, phasing=True, min_reads=10,
                   want_read_hap=True):
         """pileup -> call (-> phase) as one captured HIP graph + one pinned result copy (jl_run_async)."""
-        genes = np.ascontiguousarray(genes, dtype=GENE)
-        if refseq is not None:
-            refseq = np.ascontiguousarray(refseq, dtype=np.uint8)
-        if drm_masks is not None:
-            drm_masks = np.ascontiguousarray(drm_masks, dtype=np.uint64)
-        prm = params or default_params()
-        self._chk(self.lib.jl_run_async(self.h, _p(genes), len(genes), _p(refseq), 0 if refseq is None else len(refseq),
-                                        C.byref(prm), _p(drm_masks), 1 if phasing else 0, min_reads,
-                                        1 if want_read_hap else 0))
+        key = (id(genes), id(refseq), id(params), id(drm_masks))
+        c = getattr(self, "_run_args", None)
+        if c is None or c[0] != key:   # argument marshalling is cached: repeated steps pass the same objects
+            g = np.ascontiguousarray(genes, dtype=GENE)
+            r = None if refseq is None else np.ascontiguousarray(refseq, dtype=np.uint8)
+            d = None if drm_masks is None else np.ascontiguousarray(drm_masks, dtype=np.uint64)
+            prm = params or default_params()
+            c = (key, (genes, refseq, params, drm_masks), (g, r, d, prm),
+                 (_p(g), len(g), _p(r), 0 if r is None else len(r), C.byref(prm), _p(d)))
+            self._run_args = c
+        a = c[3]
+        rc = self.lib.jl_run_async(self.h, a[0], a[1], a[2], a[3], a[4], a[5], 1 if phasing else 0, min_reads,
+                                   1 if want_read_hap else 0)
+        if rc:
+            self._chk(rc)
 
     def _bufs(self, cap_var):
         b = getattr(self, "_fetch_bufs", None)
@@ -290,20 +296,26 @@ class Juliet:
                      hit=np.zeros((cap_var, MAX_HAPLOTYPES), dtype=np.uint8),
                      read_hap=np.zeros(self.n_reads, dtype=np.uint16),
                      cooc=np.zeros((cap_var, cap_var), dtype=np.uint32))
+            b["ptr"] = {k: _p(v) for k, v in b.items() if isinstance(v, np.ndarray)}
+            b["n_ref"] = C.byref(b["n"])
             self._fetch_bufs = b
         return b
 
     def run_fetch(self, phasing=True, want_read_hap=True, cap_var=64):
         """Results of the last run_async.  Returned arrays are views of buffers reused by the next call."""
         b = self._bufs(cap_var)
-        self._chk(self.lib.jl_call_fetch(self.h, _p(b["variants"]), VARIANT_CAP, C.byref(b["n"])))
+        q = b["ptr"]
+        rc = self.lib.jl_call_fetch(self.h, q["variants"], VARIANT_CAP, b["n_ref"])
+        if rc:
+            self._chk(rc)
         nv = b["n"].value
         out = dict(variants=b["variants"][:nv])
         if phasing:
-            self._chk(self.lib.jl_phase_fetch(self.h, _p(b["summ"]), _p(b["pos_cols"]), _p(b["hap_count"]),
-                                              _p(b["hap_pattern"]), _p(b["hit"]),
-                                              _p(b["read_hap"]) if want_read_hap else None, _p(b["cooc"]), cap_var))
-            s = {k: int(b["summ"][0][k]) for k in SUMMARY_FIELDS}
+            rc = self.lib.jl_phase_fetch(self.h, q["summ"], q["pos_cols"], q["hap_count"], q["hap_pattern"], q["hit"],
+                                         q["read_hap"] if want_read_hap else None, q["cooc"], cap_var)
+            if rc:
+                self._chk(rc)
+            s = dict(zip(SUMMARY_FIELDS, b["summ"][0].tolist()))
             h, vp = s["n_haplotypes"], s["n_positions"]
             out["phase"] = dict(summary=s, pos_cols=b["pos_cols"][:vp], hap_count=b["hap_count"][:h],
                                 hap_pattern=b["hap_pattern"][:h, :vp], hit=b["hit"][:nv, :h],

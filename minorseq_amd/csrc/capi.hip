@@ -418,7 +418,7 @@ int jl_call_async(jl_ctx *ctx, const jl_params *prm, const uint64_t *drm_masks)
         JL_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
     const double n_tests = prm->n_tests > 0.0 ? prm->n_tests : ctx->default_n_tests;
-    jl_launch_call(ctx, prm, n_tests, drm_masks != nullptr);
+    jl_launch_call(ctx, prm, n_tests, drm_masks != nullptr, false);
     JL_HIP(ctx, hipGetLastError());
     ctx->call_done = true;
     ctx->phase_done = false;
@@ -482,6 +482,11 @@ static int reserve_phase(jl_ctx *ctx, uint32_t kwords_needed)
         if ((rc = regrow(ctx, &ctx->d_slot_count, (size_t)slots))) return rc;
         if ((rc = regrow(ctx, &ctx->d_slot_key, (size_t)slots))) return rc;
         if ((rc = regrow(ctx, &ctx->d_slot_hap, (size_t)slots))) return rc;
+        // the grouping table is initialised once; phase_select_kernel empties the slots a run touched
+        JL_HIP(ctx, hipMemsetAsync(ctx->d_slot_rep, 0xFF, (size_t)slots * 4, ctx->stream));
+        JL_HIP(ctx, hipMemsetAsync(ctx->d_slot_count, 0, (size_t)slots * 4, ctx->stream));
+        JL_HIP(ctx, hipMemsetAsync(ctx->d_slot_key, 0xFF, (size_t)slots * 8, ctx->stream));
+        JL_HIP(ctx, hipStreamSynchronize(ctx->stream));
         ctx->reads_capacity = reads_pad;
         ctx->keys_capacity = 0;
     }
@@ -518,7 +523,7 @@ int jl_phase_async(jl_ctx *ctx, const jl_variant *variants, uint32_t n_var, uint
     int rc = reserve_phase(ctx, kwords);
     if (rc) return rc;
     ctx->last_min_reads = min_reads;
-    jl_launch_phase(ctx, min_reads);
+    jl_launch_phase(ctx, min_reads, false);
     JL_HIP(ctx, hipGetLastError());
     ctx->phase_done = true;
     ctx->pack_valid = false;
@@ -561,11 +566,13 @@ int jl_phase_fetch(jl_ctx *ctx, jl_phase_summary *summary, uint32_t *pos_cols, u
     JL_HIP(ctx, hipMemcpyAsync(&meta, ctx->d_meta, sizeof meta, hipMemcpyDeviceToHost, st));
     if (read_hap) JL_HIP(ctx, hipMemcpyAsync(read_hap, ctx->d_read_hap, (size_t)ctx->n_reads * 2, hipMemcpyDeviceToHost, st));
     JL_HIP(ctx, hipStreamSynchronize(st));
-    if (meta.overflow & 4u) {
-        // more variant positions than the resident key buffer covered: grow it and run phasing again
+    if (meta.overflow & 12u) {
+        // more variant positions than the single-word kernels (bit 3) or the resident key buffer (bit 2) cover:
+        // switch to the generic pipeline / grow the buffer and run phasing again
+        if (meta.vp_true > JL_POS_PER_WORD) ctx->phase_generic = true;
         int rc = reserve_phase(ctx, (meta.vp_true + JL_POS_PER_WORD - 1) / JL_POS_PER_WORD);
         if (rc) return rc;
-        jl_launch_phase(ctx, ctx->last_min_reads);
+        jl_launch_phase(ctx, ctx->last_min_reads, false);
         JL_HIP(ctx, hipGetLastError());
         JL_HIP(ctx, hipMemcpyAsync(&meta, ctx->d_meta, sizeof meta, hipMemcpyDeviceToHost, st));
         if (read_hap) JL_HIP(ctx, hipMemcpyAsync(read_hap, ctx->d_read_hap, (size_t)ctx->n_reads * 2, hipMemcpyDeviceToHost, st));
@@ -599,8 +606,8 @@ static void enqueue_path(jl_ctx *ctx, const jl_params *prm, double n_tests, bool
     hipMemsetAsync(ctx->d_counts, 0, ctx->counts_words * sizeof(uint32_t), st);
     if (!ctx->have_ref) jl_launch_guess(ctx);
     jl_launch_pileup(ctx);
-    jl_launch_call(ctx, prm, n_tests, use_drm);
-    if (phasing) jl_launch_phase(ctx, min_reads);
+    jl_launch_call(ctx, prm, n_tests, use_drm, phasing);
+    if (phasing) jl_launch_phase(ctx, min_reads, true);
     jl_launch_result_pack(ctx, phasing);
     hipMemcpyAsync(ctx->h_pack, ctx->d_pack, sizeof(jl_pack), hipMemcpyDeviceToHost, st);
     if (phasing && want_read_hap)
@@ -638,10 +645,10 @@ int jl_run_async(jl_ctx *ctx, const jl_gene *genes, uint32_t n_genes, const uint
     jl_prepare_pileup(ctx);
 
     // signature of everything a captured graph bakes in
-    struct { uint64_t alloc, plan; jl_params prm; double n_tests; uint32_t drm, phasing, min_reads, rh; } sig;
+    struct { uint64_t alloc, plan; jl_params prm; double n_tests; uint32_t drm, phasing, min_reads, rh, generic, pad; } sig;
     memset(&sig, 0, sizeof sig);
     sig.alloc = ctx->alloc_version; sig.plan = ctx->plan_version; sig.prm = *prm; sig.n_tests = n_tests;
-    sig.drm = drm_masks != nullptr; sig.phasing = phasing != 0; sig.min_reads = min_reads; sig.rh = want_read_hap != 0;
+    sig.drm = drm_masks != nullptr; sig.phasing = phasing != 0; sig.min_reads = min_reads; sig.rh = want_read_hap != 0; sig.generic = ctx->phase_generic;
     const bool graphs_on = !getenv("JL_NO_GRAPH");
     bool launched = false;
     if (graphs_on) {

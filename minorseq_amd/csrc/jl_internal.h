@@ -125,6 +125,7 @@ struct jl_ctx {
     uint32_t *d_cooc = nullptr;        // [cooc_cap][cooc_cap]
     uint32_t cooc_cap = 256;
     bool phase_done = false;
+    bool phase_generic = false;  // multi-word (Vp > 10) pipeline selected
 
     // ---- whole-path run: result pack, pinned mirrors, captured graph
     jl_pack *d_pack = nullptr;
@@ -158,8 +159,8 @@ int jl_fail(jl_ctx *ctx, int status, const char *fmt, ...);
 void jl_launch_guess(jl_ctx *ctx);
 void jl_launch_pileup(jl_ctx *ctx);
 void jl_prepare_pileup(jl_ctx *ctx);
-void jl_launch_call(jl_ctx *ctx, const jl_params *prm, double n_tests, bool use_drm);
-void jl_launch_phase(jl_ctx *ctx, uint32_t min_reads);
+void jl_launch_call(jl_ctx *ctx, const jl_params *prm, double n_tests, bool use_drm, bool with_plan);
+void jl_launch_phase(jl_ctx *ctx, uint32_t min_reads, bool planned);
 void jl_launch_synth(jl_ctx *ctx, const jl_synth_plan *plan, const uint8_t *d_ref);
 void jl_launch_pack_rows(jl_ctx *ctx, const uint8_t *d_rows);
 void jl_launch_result_pack(jl_ctx *ctx, bool phasing);

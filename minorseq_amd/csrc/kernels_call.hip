@@ -11,6 +11,7 @@
 // `expected`+1 terms of a ratio recurrence.
 #include "jl_internal.h"
 #include "jl_fisher.h"
+#include "phase_plan.h"
 
 namespace {
 
@@ -114,7 +115,10 @@ __global__ __launch_bounds__(1024) void compact_kernel(uint32_t P, const uint64_
                                                         const uint32_t *__restrict__ pos_cov,
                                                         const uint8_t *__restrict__ pos_ref,
                                                         jl_variant *__restrict__ rows, uint32_t cap,
-                                                        uint32_t *__restrict__ n_rows)
+                                                        uint32_t *__restrict__ n_rows, uint32_t n_cols,
+                                                        uint8_t *__restrict__ varcol, uint32_t *__restrict__ vpcols,
+                                                        uint32_t *__restrict__ col2pos, uint32_t kwords_cap,
+                                                        uint32_t fast_only, jl_phase_meta *__restrict__ meta)
 {
     __shared__ uint32_t s_wave[16];
     __shared__ uint32_t s_running;
@@ -169,6 +173,12 @@ __global__ __launch_bounds__(1024) void compact_kernel(uint32_t P, const uint64_
         __syncthreads();
     }
     if (tid == 0) n_rows[0] = s_running;
+    if (meta) {  // phasing follows: distinct variant columns now, saving a dependent launch
+        __syncthreads();
+        const uint32_t nv = s_running < cap ? s_running : cap;
+        __syncthreads();
+        jl_phase_plan_block(rows, nv, n_cols, varcol, vpcols, col2pos, kwords_cap, fast_only, meta);
+    }
 }
 
 __global__ __launch_bounds__(256) void fisher_eval_kernel(uint32_t n, const uint32_t *__restrict__ a,
@@ -191,7 +201,7 @@ void jl_launch_fisher_eval(jl_ctx *ctx, uint32_t n, const uint32_t *a, const uin
     hipLaunchKernelGGL(fisher_eval_kernel, dim3((n + 255u) / 256u), dim3(256), 0, ctx->stream, n, a, c, cov, p, lp);
 }
 
-void jl_launch_call(jl_ctx *ctx, const jl_params *prm, double n_tests, bool use_drm)
+void jl_launch_call(jl_ctx *ctx, const jl_params *prm, double n_tests, bool use_drm, bool with_plan)
 {
     call_args A;
     A.alpha = prm->alpha;
@@ -209,5 +219,7 @@ void jl_launch_call(jl_ctx *ctx, const jl_params *prm, double n_tests, bool use_
     }
     hipLaunchKernelGGL(compact_kernel, dim3(1), dim3(1024), 0, ctx->stream, ctx->P, ctx->d_called, ctx->d_pos_gene,
                        ctx->d_pos_codon, ctx->d_pos_col, ctx->d_hist, ctx->d_cand_p, ctx->d_cand_lp, ctx->d_cand_e,
-                       ctx->d_pos_cov, ctx->d_pos_ref, ctx->d_variants, JL_VARIANT_CAP, ctx->d_nvar);
+                       ctx->d_pos_cov, ctx->d_pos_ref, ctx->d_variants, JL_VARIANT_CAP, ctx->d_nvar, ctx->n_cols,
+                       ctx->d_varcol, ctx->d_vpcols, ctx->d_col2pos, ctx->keys_words, ctx->phase_generic ? 0u : 1u,
+                       with_plan ? ctx->d_meta : nullptr);
 }

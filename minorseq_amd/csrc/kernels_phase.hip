@@ -10,9 +10,10 @@
 //   group   exact grouping of clean reads: wave-level match-any collapses equal keys, one leader per group
 //           inserts into an open-addressing table keyed by the FULL key (representative read + compare)
 //   select  groups with >= min_reads ranked by (count desc, pattern asc), haplotype ids, patterns, hit matrix
+//           + variant x variant co-occurrence, the pinned result block, and emptying of the table slots used
 //   assign  per-read haplotype id
-//   cooc    variant x variant co-occurrence over reported haplotypes
 #include "jl_internal.h"
+#include "phase_plan.h"
 
 namespace {
 
@@ -39,65 +40,11 @@ __global__ __launch_bounds__(1024) void phase_plan_kernel(const jl_variant *__re
                                                            uint32_t n_cols, uint8_t *__restrict__ varcol,
                                                            uint32_t *__restrict__ vpcols,
                                                            uint32_t *__restrict__ col2pos, uint32_t kwords_cap,
-                                                           jl_phase_meta *__restrict__ meta)
+                                                           uint32_t fast_only, jl_phase_meta *__restrict__ meta)
 {
-    __shared__ uint32_t s_wave[16];
-    __shared__ uint32_t s_running;
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6;
     uint32_t nv = n_rows[0];
     if (nv > cap) nv = cap;
-    for (uint32_t c = tid; c < n_cols; c += 1024u) varcol[c] = 0;
-    if (tid == 0) s_running = 0;
-    __syncthreads();
-    for (uint32_t v = tid; v < nv; v += 1024u) {
-        const uint32_t c = variants[v].col;
-        if (c + 2u < n_cols) varcol[c] = 1;
-    }
-    __syncthreads();
-    for (uint32_t base = 0; base < n_cols; base += 1024u) {
-        const uint32_t c = base + tid;
-        const uint32_t f = c < n_cols ? varcol[c] : 0u;
-        uint32_t inc = f;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t u = __shfl_up(inc, o, 64);
-            if ((int)lane >= o) inc += u;
-        }
-        if (lane == 63) s_wave[wid] = inc;
-        __syncthreads();
-        uint32_t off = 0, total = 0;
-#pragma unroll
-        for (int w = 0; w < 16; ++w) {
-            const uint32_t x = s_wave[w];
-            if (w < (int)wid) off += x;
-            total += x;
-        }
-        if (f) {
-            const uint32_t p = s_running + off + inc - 1u;
-            vpcols[p] = c;
-            col2pos[c] = p;
-        }
-        __syncthreads();
-        if (tid == 0) s_running += total;
-        __syncthreads();
-    }
-    if (tid == 0) {
-        uint32_t vp = s_running;
-        uint32_t kw = (vp + JL_POS_PER_WORD - 1u) / JL_POS_PER_WORD;
-        meta->n_var = nv;
-        meta->vp_true = vp;
-        meta->overflow = 0;
-        if (kw > kwords_cap) {  // key buffer too small: skip, the host re-runs with the exact size
-            meta->overflow = 4u;
-            vp = 0;
-            kw = 0;
-        }
-        meta->vp = vp;
-        meta->kwords = kw;
-        meta->n_occupied = 0;
-        jl_phase_summary z = {0, 0, 0, 0, 0, 0, vp, 0};
-        meta->summary = z;
-    }
+    jl_phase_plan_block(variants, nv, n_cols, varcol, vpcols, col2pos, kwords_cap, fast_only, meta);
 }
 
 // ---------------------------------------------------------------------------------------- keys
@@ -435,6 +382,54 @@ __global__ __launch_bounds__(256) void phase_fused1_kernel(const uint8_t *__rest
     }
 }
 
+// ---------------------------------------------------------------------------------------- result pack
+// Block-level: gathers the small results into one fixed-size block for a single pinned D2H copy.
+__device__ __forceinline__ void result_pack_block(const jl_variant *__restrict__ variants, uint32_t n,
+                                                  const jl_phase_meta *__restrict__ meta, uint32_t phasing,
+                                                  const uint32_t *__restrict__ vpcols,
+                                                  const uint32_t *__restrict__ hap_count,
+                                                  const uint8_t *__restrict__ hap_pattern,
+                                                  const uint8_t *__restrict__ hit, const uint32_t *__restrict__ cooc,
+                                                  uint32_t cooc_cap, uint32_t cooc_ready, jl_pack *__restrict__ pk)
+{
+    const uint32_t tid = threadIdx.x, nt = blockDim.x;
+    const uint32_t fits_call = n <= JL_PACK_MAX_VAR;
+    uint32_t vp = 0, H = 0, nv = 0, ovf = 0, fits_phase = 0, cooc_fits = 0;
+    if (phasing) {
+        vp = meta->vp; H = meta->summary.n_haplotypes; nv = meta->n_var; ovf = meta->overflow;
+        fits_phase = ovf == 0 && fits_call && vp <= JL_PACK_MAX_VP && H <= JL_PACK_MAX_HAP &&
+                     H * vp <= JL_PACK_PATTERN_BYTES && nv * H <= JL_PACK_HIT_BYTES;
+        cooc_fits = cooc_ready && nv <= JL_PACK_COOC_N;
+    }
+    if (tid == 0) {
+        pk->magic = JL_PACK_MAGIC; pk->nvar_total = n; pk->fits_call = fits_call; pk->fits_phase = fits_phase;
+        pk->phase_ran = phasing; pk->overflow = ovf; pk->vp = vp; pk->H = H;
+        pk->nv_phase = nv; pk->cooc_fits = cooc_fits;
+        if (phasing) pk->summary = meta->summary;
+    }
+    if (fits_call)
+        for (uint32_t i = tid; i < n * (uint32_t)(sizeof(jl_variant) / 8); i += nt)
+            reinterpret_cast<uint64_t *>(pk->variants)[i] = reinterpret_cast<const uint64_t *>(variants)[i];
+    if (fits_phase) {
+        for (uint32_t i = tid; i < vp; i += nt) pk->pos_cols[i] = vpcols[i];
+        for (uint32_t i = tid; i < H; i += nt) pk->hap_count[i] = hap_count[i];
+        for (uint32_t i = tid; i < H * vp; i += nt)
+            pk->hap_pattern[i] = hap_pattern[(uint64_t)(i / vp) * JL_VARIANT_CAP + (i % vp)];
+        for (uint32_t i = tid; i < nv * H; i += nt) pk->hit[i] = hit[(uint64_t)(i / H) * JL_MAX_HAPLOTYPES + (i % H)];
+        if (cooc_fits)
+            for (uint32_t i = tid; i < nv * nv; i += nt) pk->cooc[i] = cooc[(uint64_t)(i / nv) * cooc_cap + (i % nv)];
+    }
+}
+
+__global__ __launch_bounds__(256) void result_pack_kernel(const jl_variant *__restrict__ variants,
+                                                           const uint32_t *__restrict__ n_rows,
+                                                           const jl_phase_meta *__restrict__ meta,
+                                                           jl_pack *__restrict__ pk)
+{
+    // phasing off: only the variant table
+    result_pack_block(variants, n_rows[0], meta, 0u, nullptr, nullptr, nullptr, nullptr, nullptr, 0u, 0u, pk);
+}
+
 // ---------------------------------------------------------------------------------------- select
 __device__ __forceinline__ uint32_t pattern_code(const uint64_t *__restrict__ keys, uint64_t reads_pad, uint32_t vp,
                                                  uint32_t rep, uint32_t p)
@@ -448,25 +443,31 @@ __device__ __forceinline__ uint32_t pattern_code(const uint64_t *__restrict__ ke
 __global__ __launch_bounds__(1024) void phase_select_kernel(uint32_t min_reads, uint64_t reads_pad,
                                                              const uint64_t *__restrict__ keys,
                                                              jl_phase_meta *__restrict__ meta,
-                                                             const uint32_t *__restrict__ slot_rep,
-                                                             const uint32_t *__restrict__ slot_count,
+                                                             const uint32_t *slot_rep, const uint32_t *slot_count,
                                                              const uint32_t *__restrict__ occupied,
                                                              uint16_t *__restrict__ slot_hap,
                                                              const jl_variant *__restrict__ variants,
                                                              const uint32_t *__restrict__ col2pos, uint32_t n_cols,
                                                              uint32_t *__restrict__ hap_count,
                                                              uint8_t *__restrict__ hap_pattern,
-                                                             uint8_t *__restrict__ hit)
+                                                             uint8_t *__restrict__ hit,
+                                                             const uint32_t *__restrict__ n_rows,
+                                                             const uint32_t *__restrict__ vpcols,
+                                                             uint32_t *__restrict__ cooc, uint32_t cooc_cap,
+                                                             jl_pack *__restrict__ pk,
+                                                             unsigned long long *__restrict__ slot_key,
+                                                             uint32_t *__restrict__ slot_rep_w,
+                                                             uint32_t *__restrict__ slot_count_w)
 {
     __shared__ uint32_t s_cand[JL_CAND_CAP];  // slot of each candidate
     __shared__ uint32_t s_hrep[JL_MAX_HAPLOTYPES];
     __shared__ uint32_t s_ncand, s_insufficient, s_reported, s_nhap;
     const uint32_t tid = threadIdx.x;
     const uint32_t vp = meta->vp, kwords = meta->kwords, nv = meta->n_var;
-    if (vp == 0) return;
+    const uint32_t n_occ = meta->n_occupied;
+    if (vp != 0) {  // block-uniform
     if (tid == 0) { s_ncand = 0; s_insufficient = 0; s_reported = 0; s_nhap = 0; }
     __syncthreads();
-    const uint32_t n_occ = meta->n_occupied;
     for (uint32_t q = tid; q < n_occ; q += 1024u) {
         const uint32_t s = occupied[q];
         const uint32_t c = slot_count[s];
@@ -533,6 +534,28 @@ __global__ __launch_bounds__(1024) void phase_select_kernel(uint32_t min_reads, 
         }
         hit[(uint64_t)v * JL_MAX_HAPLOTYPES + h] = x;
     }
+    __syncthreads();
+    // co-occurrence over the reported haplotypes, for the first cooc_cap variants
+    {
+        const uint32_t nvc = nv < cooc_cap ? nv : cooc_cap;
+        for (uint32_t q = tid; q < nvc * nvc; q += 1024u) {
+            const uint32_t v = q / nvc, w = q - v * nvc;
+            uint32_t sum = 0;
+            for (uint32_t h = 0; h < H; ++h)
+                if (hit[(uint64_t)v * JL_MAX_HAPLOTYPES + h] && hit[(uint64_t)w * JL_MAX_HAPLOTYPES + h]) sum += hap_count[h];
+            cooc[(uint64_t)v * cooc_cap + w] = sum;
+        }
+    }
+    }  // vp != 0
+    __syncthreads();
+    result_pack_block(variants, n_rows[0], meta, 1u, vpcols, hap_count, hap_pattern, hit, cooc, cooc_cap, 1u, pk);
+    // leave the table empty for the next run: only the slots this run touched
+    for (uint32_t q = tid; q < n_occ; q += 1024u) {
+        const uint32_t s = occupied[q];
+        slot_key[s] = ~0ull;
+        slot_rep_w[s] = 0xFFFFFFFFu;
+        slot_count_w[s] = 0;
+    }
 }
 
 // ---------------------------------------------------------------------------------------- assign
@@ -552,102 +575,46 @@ __global__ __launch_bounds__(256) void phase_assign_kernel(uint64_t n_reads, con
     read_hap[i] = h;
 }
 
-// ---------------------------------------------------------------------------------------- cooc
-__global__ __launch_bounds__(256) void phase_cooc_kernel(const jl_phase_meta *__restrict__ meta,
-                                                          const uint8_t *__restrict__ hit,
-                                                          const uint32_t *__restrict__ hap_count, uint32_t cooc_cap,
-                                                          uint32_t *__restrict__ cooc)
-{
-    const uint32_t nv = min(meta->n_var, cooc_cap);
-    const uint32_t H = meta->summary.n_haplotypes;
-    const uint32_t total = nv * nv;
-    for (uint32_t q = blockIdx.x * 256u + threadIdx.x; q < total; q += gridDim.x * 256u) {
-        const uint32_t v = q / nv, w = q - v * nv;
-        uint32_t s = 0;
-        for (uint32_t h = 0; h < H; ++h)
-            if (hit[(uint64_t)v * JL_MAX_HAPLOTYPES + h] && hit[(uint64_t)w * JL_MAX_HAPLOTYPES + h]) s += hap_count[h];
-        cooc[(uint64_t)v * cooc_cap + w] = s;
-    }
-}
-
-
-// ---------------------------------------------------------------------------------------- result pack
-__global__ __launch_bounds__(256) void result_pack_kernel(const jl_variant *__restrict__ variants,
-                                                           const uint32_t *__restrict__ n_rows,
-                                                           const jl_phase_meta *__restrict__ meta, uint32_t phasing,
-                                                           const uint32_t *__restrict__ vpcols,
-                                                           const uint32_t *__restrict__ hap_count,
-                                                           const uint8_t *__restrict__ hap_pattern,
-                                                           const uint8_t *__restrict__ hit,
-                                                           const uint32_t *__restrict__ cooc, uint32_t cooc_cap,
-                                                           jl_pack *__restrict__ pk)
-{
-    const uint32_t tid = threadIdx.x;
-    const uint32_t n = n_rows[0];
-    const uint32_t fits_call = n <= JL_PACK_MAX_VAR;
-    uint32_t vp = 0, H = 0, nv = 0, ovf = 0, fits_phase = 0, cooc_fits = 0;
-    if (phasing) {
-        vp = meta->vp; H = meta->summary.n_haplotypes; nv = meta->n_var; ovf = meta->overflow;
-        fits_phase = ovf == 0 && fits_call && vp <= JL_PACK_MAX_VP && H <= JL_PACK_MAX_HAP &&
-                     H * vp <= JL_PACK_PATTERN_BYTES && nv * H <= JL_PACK_HIT_BYTES;
-        cooc_fits = nv <= JL_PACK_COOC_N;
-    }
-    if (tid == 0) {
-        pk->magic = JL_PACK_MAGIC; pk->nvar_total = n; pk->fits_call = fits_call; pk->fits_phase = fits_phase;
-        pk->phase_ran = phasing; pk->overflow = ovf; pk->vp = vp; pk->H = H;
-        pk->nv_phase = nv; pk->cooc_fits = cooc_fits;
-        if (phasing) pk->summary = meta->summary;
-    }
-    if (fits_call)
-        for (uint32_t i = tid; i < n * (uint32_t)(sizeof(jl_variant) / 8); i += 256u)
-            reinterpret_cast<uint64_t *>(pk->variants)[i] = reinterpret_cast<const uint64_t *>(variants)[i];
-    if (fits_phase) {
-        for (uint32_t i = tid; i < vp; i += 256u) pk->pos_cols[i] = vpcols[i];
-        for (uint32_t i = tid; i < H; i += 256u) pk->hap_count[i] = hap_count[i];
-        for (uint32_t i = tid; i < H * vp; i += 256u)
-            pk->hap_pattern[i] = hap_pattern[(uint64_t)(i / vp) * JL_VARIANT_CAP + (i % vp)];
-        for (uint32_t i = tid; i < nv * H; i += 256u) pk->hit[i] = hit[(uint64_t)(i / H) * JL_MAX_HAPLOTYPES + (i % H)];
-        if (cooc_fits)
-            for (uint32_t i = tid; i < nv * nv; i += 256u) pk->cooc[i] = cooc[(uint64_t)(i / nv) * cooc_cap + (i % nv)];
-    }
-}
-
 }  // namespace
 
 void jl_launch_result_pack(jl_ctx *ctx, bool phasing)
 {
+    if (phasing) return;  // phase_select_kernel packs at its end
     hipLaunchKernelGGL(result_pack_kernel, dim3(1), dim3(256), 0, ctx->stream, ctx->d_variants, ctx->d_nvar, ctx->d_meta,
-                       phasing ? 1u : 0u, ctx->d_vpcols, ctx->d_hap_count, ctx->d_hap_pattern, ctx->d_hit, ctx->d_cooc,
-                       ctx->cooc_cap, ctx->d_pack);
+                       ctx->d_pack);
 }
 
-void jl_launch_phase(jl_ctx *ctx, uint32_t min_reads)
+// `planned`: compact_kernel already ran the plan (jl_run_async); otherwise the stand-alone plan kernel runs here.
+// ctx->phase_generic selects the multi-word pipeline; the default runs only the single-word (Vp <= 10) kernels
+// and lets the plan flag inputs that need more (jl_phase_fetch then switches and re-runs).
+void jl_launch_phase(jl_ctx *ctx, uint32_t min_reads, bool planned)
 {
     hipStream_t st = ctx->stream;
     const uint64_t reads_pad = ctx->col_stride * 2u;
-    hipLaunchKernelGGL(phase_plan_kernel, dim3(1), dim3(1024), 0, st, ctx->d_variants, ctx->d_nvar, JL_VARIANT_CAP,
-                       ctx->n_cols, ctx->d_varcol, ctx->d_vpcols, ctx->d_col2pos, ctx->keys_words, ctx->d_meta);
-    // table: representatives empty, counts zero
-    hipMemsetAsync(ctx->d_slot_rep, 0xFF, ctx->table_slots * sizeof(uint32_t), st);
-    hipMemsetAsync(ctx->d_slot_count, 0, ctx->table_slots * sizeof(uint32_t), st);
-    hipMemsetAsync(ctx->d_slot_key, 0xFF, ctx->table_slots * sizeof(uint64_t), st);
+    const bool generic = ctx->phase_generic;
+    if (!planned)
+        hipLaunchKernelGGL(phase_plan_kernel, dim3(1), dim3(1024), 0, st, ctx->d_variants, ctx->d_nvar, JL_VARIANT_CAP,
+                           ctx->n_cols, ctx->d_varcol, ctx->d_vpcols, ctx->d_col2pos, ctx->keys_words,
+                           generic ? 0u : 1u, ctx->d_meta);
     const uint32_t n_dwords = (uint32_t)(ctx->col_stride / 4u);
-    hipLaunchKernelGGL(phase_keys_kernel, dim3((n_dwords + 255u) / 256u), dim3(256), 0, st, ctx->d_msa,
-                       ctx->col_stride, ctx->n_reads, reads_pad, ctx->d_vpcols, ctx->d_meta, ctx->d_keys,
-                       ctx->d_flagw);
+    const uint32_t rblocks = (uint32_t)((ctx->n_reads + 255u) / 256u);
+    if (generic)
+        hipLaunchKernelGGL(phase_keys_kernel, dim3((n_dwords + 255u) / 256u), dim3(256), 0, st, ctx->d_msa,
+                           ctx->col_stride, ctx->n_reads, reads_pad, ctx->d_vpcols, ctx->d_meta, ctx->d_keys,
+                           ctx->d_flagw);
     hipLaunchKernelGGL(phase_fused1_kernel, dim3((n_dwords + 255u) / 256u), dim3(256), 0, st, ctx->d_msa,
                        ctx->col_stride, ctx->n_reads, reads_pad, ctx->d_vpcols, ctx->d_meta, ctx->d_keys, ctx->d_flagw,
                        ctx->table_slots - 1u, (unsigned long long *)ctx->d_slot_key, ctx->d_slot_rep,
                        ctx->d_slot_count, ctx->d_occupied, ctx->d_read_slot);
-    const uint32_t rblocks = (uint32_t)((ctx->n_reads + 255u) / 256u);
-    hipLaunchKernelGGL(phase_group_kernel, dim3(rblocks), dim3(256), 0, st, ctx->n_reads, reads_pad, ctx->d_keys,
-                       ctx->d_flagw, ctx->d_meta, ctx->table_slots - 1u, ctx->d_slot_rep, ctx->d_slot_count,
-                       ctx->d_occupied, ctx->d_read_slot);
+    if (generic)
+        hipLaunchKernelGGL(phase_group_kernel, dim3(rblocks), dim3(256), 0, st, ctx->n_reads, reads_pad, ctx->d_keys,
+                           ctx->d_flagw, ctx->d_meta, ctx->table_slots - 1u, ctx->d_slot_rep, ctx->d_slot_count,
+                           ctx->d_occupied, ctx->d_read_slot);
     hipLaunchKernelGGL(phase_select_kernel, dim3(1), dim3(1024), 0, st, min_reads, reads_pad, ctx->d_keys,
                        ctx->d_meta, ctx->d_slot_rep, ctx->d_slot_count, ctx->d_occupied, ctx->d_slot_hap,
-                       ctx->d_variants, ctx->d_col2pos, ctx->n_cols, ctx->d_hap_count, ctx->d_hap_pattern, ctx->d_hit);
+                       ctx->d_variants, ctx->d_col2pos, ctx->n_cols, ctx->d_hap_count, ctx->d_hap_pattern, ctx->d_hit,
+                       ctx->d_nvar, ctx->d_vpcols, ctx->d_cooc, ctx->cooc_cap, ctx->d_pack,
+                       (unsigned long long *)ctx->d_slot_key, ctx->d_slot_rep, ctx->d_slot_count);
     hipLaunchKernelGGL(phase_assign_kernel, dim3(rblocks), dim3(256), 0, st, ctx->n_reads, ctx->d_flagw, ctx->d_meta,
                        ctx->d_read_slot, ctx->d_slot_hap, ctx->d_read_hap);
-    hipLaunchKernelGGL(phase_cooc_kernel, dim3(64), dim3(256), 0, st, ctx->d_meta, ctx->d_hit, ctx->d_hap_count,
-                       ctx->cooc_cap, ctx->d_cooc);
 }

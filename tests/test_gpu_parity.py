@@ -408,3 +408,32 @@ def test_run_results_larger_than_the_pack(jl, oracle):
     assert_variants_equal(out["variants"], exp_v)
     assert_phase_equal(out["phase"], oracle.phase(rows, exp_v, min_reads=3), len(exp_v))
     j.close()
+
+
+# --------------------------------------------------------------------------------------------- the collective
+def test_allgather_variants_single_rank_communicator(jl, oracle):
+    """jl_allgather_variants over a real RCCL communicator (world = 1 is all one GPU allows here): the payload
+    layout and the host unpacking are the ones the 8-GPU run uses."""
+    import ctypes as C
+    sp = synth.SynthParams(seed=23, minor_permille=(70, 60, 50, 40))
+    ref = synth.reference(sp.seed, 300)
+    rows = synth.rows(sp, 300, 0, 5000, ref)
+    genes = np.array([(1, 301)], dtype=capi.GENE)
+    jl.upload_columns(msa.pack_columns(rows), 5000)
+    idbuf = np.zeros(128, dtype=np.uint8)
+    assert jl.lib.jl_comm_unique_id(idbuf.ctypes.data_as(C.c_void_p)) == 0
+    comm = C.c_void_p()
+    jl._chk(jl.lib.jl_comm_create(jl.h, idbuf.ctypes.data_as(C.c_void_p), 0, 1, C.byref(comm)))
+    try:
+        jl.run_async(genes, ref, capi.default_params(), None, True, 10, True)
+        all_rows = np.zeros(capi.VARIANT_CAP, dtype=capi.VARIANT)
+        counts = np.zeros(1, dtype=np.uint32)
+        jl._chk(jl.lib.jl_allgather_variants(jl.h, comm, all_rows.ctypes.data_as(C.c_void_p),
+                                             counts.ctypes.data_as(C.c_void_p), capi.VARIANT_CAP))
+        exp = oracle.call(rows, genes, refseq=ref)
+        assert counts[0] == len(exp)
+        assert_variants_equal(all_rows[: counts[0]], exp)
+        out = jl.run_fetch(True, True)
+        assert_variants_equal(out["variants"], exp)
+    finally:
+        jl.lib.jl_comm_destroy(comm)
