@@ -1,0 +1,453 @@
+// juliet — command-line front end over libjuliet_hip.so: aligned CCS BAM in, JSON (and a plain HTML
+// rendering of it) out.  Keeps the documented surface of the reference tool:
+//   juliet [--config/-c CFG] [--mode-phasing/-p] [--region/-r B-E] [--min-perc X] [--max-perc X] [--drm-only]
+//          in.align.bam out.{json,html} [out2.{json,html}]
+// (doc/JULIET.md:62-66, 121, 160-163, 195, 270-271, 342-344, 352-354, 370).  Everything the reference text
+// leaves open is an explicit flag with the docs/SPEC.md default.  All compute happens on the GPU through
+// the C ABI; without a gfx950 device the tool exits with status 3.
+#include <chrono>
+#include <cstdlib>
+#include <ctime>
+#include <fstream>
+#include <iostream>
+
+#include "config.hpp"
+#include "msa_builder.hpp"
+
+using namespace jlhost;
+
+namespace {
+
+const char *kVersion = "0.1.0 (minorseq_amd, MI355X)";
+
+struct Options {
+    std::string bam, config;
+    std::vector<std::string> outputs;
+    bool phasing = false, drm_only = false;
+    bool have_region = false;
+    uint32_t region_b = 0, region_e = 0;
+    double min_perc = -1.0, max_perc = -1.0;
+    double alpha = 0.01, n_tests = 0.0;
+    std::string chemistry = "auto";
+    double match = -1.0, substitution = -1.0;
+    int expected_round = 0;
+    uint32_t min_reads = 10, min_qv = 0;
+    double min_rq = 0.0;
+    int device = 0;
+    std::string dump_msa, dump_config;
+};
+
+[[noreturn]] void usage(int code)
+{
+    std::cerr <<
+        "juliet " << kVersion << "\n"
+        "usage: juliet [options] in.align.bam out.json|out.html [second output]\n"
+        "  -c, --config <HIV|ABL1|file.json>   target config (doc/JULIET.md:109-180)\n"
+        "  -p, --mode-phasing                  cluster reads into haplotypes (doc/JULIET.md:192-211)\n"
+        "  -r, --region <begin-end>            1-based [begin,end) window of the config to call\n"
+        "      --min-perc <x> / --max-perc <x> only calls above / below x percent\n"
+        "  -k, --drm-only                      only known DRM positions of the config\n"
+        "  parameters the reference text leaves open (docs/SPEC.md):\n"
+        "      --alpha 0.01  --n-tests <auto>  --chemistry auto|sequel|permissive\n"
+        "      --match-rate <r> --substitution-rate <r> --expected-round ceil|floor|nearest\n"
+        "      --min-reads 10  --min-qv 0  --min-rq 0  --device 0\n"
+        "  diagnostics (no GPU needed): --dump-msa <file>  --dump-config <file>\n";
+    std::exit(code);
+}
+
+Options parse(int argc, char **argv)
+{
+    Options o;
+    auto need = [&](int &i) -> std::string {
+        if (i + 1 >= argc) { std::cerr << "juliet: " << argv[i] << " needs a value\n"; usage(1); }
+        return argv[++i];
+    };
+    std::vector<std::string> pos;
+    for (int i = 1; i < argc; ++i) {
+        const std::string a = argv[i];
+        if (a == "-h" || a == "--help") usage(0);
+        else if (a == "--version") { std::cout << kVersion << "\n"; std::exit(0); }
+        else if (a == "-c" || a == "--config") o.config = need(i);
+        else if (a == "-p" || a == "--mode-phasing") o.phasing = true;
+        else if (a == "-k" || a == "--drm-only") o.drm_only = true;
+        else if (a == "-r" || a == "--region") {
+            const std::string v = need(i);
+            const size_t d = v.find('-');
+            if (d == std::string::npos) { std::cerr << "juliet: --region wants begin-end\n"; usage(1); }
+            o.region_b = (uint32_t)std::stoul(v.substr(0, d));
+            o.region_e = (uint32_t)std::stoul(v.substr(d + 1));
+            o.have_region = true;
+        }
+        else if (a == "--min-perc") o.min_perc = std::stod(need(i));
+        else if (a == "--max-perc") o.max_perc = std::stod(need(i));
+        else if (a == "--alpha") o.alpha = std::stod(need(i));
+        else if (a == "--n-tests") o.n_tests = std::stod(need(i));
+        else if (a == "--chemistry") o.chemistry = need(i);
+        else if (a == "--match-rate") o.match = std::stod(need(i));
+        else if (a == "--substitution-rate") o.substitution = std::stod(need(i));
+        else if (a == "--expected-round") {
+            const std::string v = need(i);
+            o.expected_round = v == "floor" ? 1 : v == "nearest" ? 2 : 0;
+        }
+        else if (a == "--min-reads") o.min_reads = (uint32_t)std::stoul(need(i));
+        else if (a == "--min-qv") o.min_qv = (uint32_t)std::stoul(need(i));
+        else if (a == "--min-rq") o.min_rq = std::stod(need(i));
+        else if (a == "--device") o.device = std::stoi(need(i));
+        else if (a == "--dump-msa") o.dump_msa = need(i);
+        else if (a == "--dump-config") o.dump_config = need(i);
+        else if (!a.empty() && a[0] == '-') { std::cerr << "juliet: unknown option " << a << "\n"; usage(1); }
+        else pos.push_back(a);
+    }
+    if (!o.dump_config.empty() && pos.empty()) return o;
+    if (pos.size() < 2 && o.dump_msa.empty()) { std::cerr << "juliet: need an input BAM and at least one output\n"; usage(1); }
+    if (pos.empty()) usage(1);
+    o.bam = pos[0];
+    o.outputs.assign(pos.begin() + 1, pos.end());
+    for (const std::string &out : o.outputs) {
+        const bool ok = (out.size() > 5 && out.substr(out.size() - 5) == ".json") || (out.size() > 5 && out.substr(out.size() - 5) == ".html");
+        if (!ok) { std::cerr << "juliet: output '" << out << "' must end in .json or .html (doc/JULIET.md:61-66)\n"; usage(1); }
+    }
+    return o;
+}
+
+std::string iso_now()
+{
+    using namespace std::chrono;
+    const auto now = system_clock::now();
+    const std::time_t t = system_clock::to_time_t(now);
+    const int ms = (int)(duration_cast<milliseconds>(now.time_since_epoch()).count() % 1000);
+    std::tm tm;
+    gmtime_r(&t, &tm);
+    char buf[40];
+    snprintf(buf, sizeof buf, "%04d-%02d-%02dT%02d:%02d:%02d.%03dZ", tm.tm_year + 1900, tm.tm_mon + 1, tm.tm_mday,
+             tm.tm_hour, tm.tm_min, tm.tm_sec, ms);
+    return buf;
+}
+
+std::string haplotype_name(uint32_t h)  // [A-Z]{1}[a-z]?  (doc/JULIET.md:198)
+{
+    if (h < 26) return std::string(1, (char)('A' + h));
+    h -= 26;
+    return std::string{(char)('A' + h / 26), (char)('a' + h % 26)};
+}
+
+void die_jl(jl_ctx *ctx, const char *what)
+{
+    std::cerr << "juliet: " << what << ": " << jl_last_error(ctx) << "\n";
+    std::exit(3);
+}
+
+std::string html_escape(const std::string &s)
+{
+    std::string o;
+    for (char c : s) {
+        if (c == '<') o += "&lt;"; else if (c == '>') o += "&gt;"; else if (c == '&') o += "&amp;"; else o += c;
+    }
+    return o;
+}
+
+// Plain rendering of the JSON (doc/JULIET.md:68-69: "The HTML page is a 1:1 conversion of the JSON file").
+std::string render_html(const Json &root, const std::string &json_text)
+{
+    std::string h = "<!DOCTYPE html><html><head><meta charset=\"utf-8\"><title>juliet</title>"
+                    "<style>body{font-family:sans-serif}table{border-collapse:collapse}td,th{border:1px solid #999;padding:2px 8px}</style>"
+                    "</head><body>\n<h1>juliet</h1>\n";
+    if (const Json *in = root.get("input")) {
+        h += "<h2>Input data</h2><table>";
+        for (auto &kv : in->obj) h += "<tr><th>" + html_escape(kv.first) + "</th><td>" + html_escape(kv.second.str) + "</td></tr>";
+        h += "</table>\n";
+    }
+    if (const Json *genes = root.get("genes")) {
+        h += "<h2>Variant Discovery</h2>\n";
+        for (const Json &g : genes->arr) {
+            h += "<h3>" + html_escape(g.get_str("name")) + "</h3><table><tr><th>Codon</th><th>AA</th><th>Pos</th><th>AA</th><th>Codon</th><th>%</th><th>Coverage</th><th>Affected Drugs</th></tr>\n";
+            if (const Json *vps = g.get("variant_positions"))
+                for (const Json &vp : vps->arr)
+                    for (const Json &aa : vp.get("variant_amino_acids")->arr)
+                        for (const Json &vc : aa.get("variant_codons")->arr) {
+                            char pc[32];
+                            snprintf(pc, sizeof pc, "%.2g", 100.0 * vc.get("frequency")->num);
+                            h += "<tr><td>" + vp.get_str("ref_codon") + "</td><td>" + vp.get_str("ref_amino_acid") + "</td><td>" +
+                                 std::to_string((long)vp.get("ref_position")->num) + "</td><td>" + aa.get_str("amino_acid") + "</td><td>" +
+                                 vc.get_str("codon") + "</td><td>" + pc + "</td><td>" + std::to_string((long)vp.get("coverage")->num) +
+                                 "</td><td>" + html_escape(vc.get_str("known_drm")) + "</td></tr>\n";
+                        }
+            h += "</table>\n";
+        }
+    }
+    h += "<h2>JSON</h2><pre>" + html_escape(json_text) + "</pre></body></html>\n";
+    return h;
+}
+
+}  // namespace
+
+int main(int argc, char **argv)
+{
+    Options opt;
+    std::string cmdline;
+    for (int i = 0; i < argc; ++i) cmdline += (i ? " " : "") + std::string(argv[i]);
+    try {
+        opt = parse(argc, argv);
+        // ---------------------------------------------------------------- target config
+        TargetConfig cfg;
+        if (!opt.config.empty()) cfg = TargetConfig::load(opt.config);
+        if (!opt.dump_config.empty() && opt.bam.empty()) {
+            if (opt.have_region) cfg.apply_region(opt.region_b, opt.region_e);
+            Json j = cfg.echo();
+            Json eff = Json::array();
+            for (const GeneCfg &g : cfg.genes)
+                eff.push(Json::object().set("name", Json::of(g.name)).set("begin", Json::of(g.begin_eff)).set("end", Json::of(g.end_eff)).set("first_codon", Json::of(g.first_codon)));
+            j.set("effective_genes", eff);
+            std::string s;
+            j.write(s);
+            std::ofstream(opt.dump_config) << s << "\n";
+            return 0;
+        }
+        // ---------------------------------------------------------------- ingest
+        IngestOptions io;
+        io.min_qv = opt.min_qv;
+        io.min_rq = opt.min_rq;
+        const ReadExtent ext = scan_extent(opt.bam, io);
+        if (ext.n_reads == 0) { std::cerr << "juliet: no primary or supplementary alignments in " << opt.bam << "\n"; return 2; }
+        std::string header_text;
+        int64_t ref_len = std::numeric_limits<int64_t>::max();
+        {
+            BamReader hdr(opt.bam);
+            header_text = hdr.header_text();
+            if (ext.ref_id >= 0 && (size_t)ext.ref_id < hdr.refs().size()) ref_len = hdr.refs()[(size_t)ext.ref_id].length;
+        }
+
+        const bool have_cfg = !cfg.genes.empty();
+        if (!have_cfg) {
+            // no target config: one ORF over the covered window, labelled "unknown" (doc/JULIET.md:182-188);
+            // --region marks the reading frame
+            GeneCfg g;
+            g.name = "unknown";
+            g.begin = g.begin_eff = opt.have_region ? opt.region_b : (uint32_t)ext.min_pos + 1;
+            g.end = g.end_eff = opt.have_region ? opt.region_e : (uint32_t)ext.max_end + 1;
+            cfg.genes.push_back(g);
+        } else if (opt.have_region) {
+            cfg.apply_region(opt.region_b, opt.region_e);
+            if (cfg.genes.empty()) { std::cerr << "juliet: --region leaves no gene of the config\n"; return 1; }
+        }
+        // window: the called genes plus the -3..+5 context columns (doc/JULIET.md:99-100), inside the reference
+        int64_t gb = std::numeric_limits<int64_t>::max(), ge = 0;
+        for (const GeneCfg &g : cfg.genes) { gb = std::min<int64_t>(gb, (int64_t)g.begin_eff - 1); ge = std::max<int64_t>(ge, (int64_t)g.end_eff - 1); }
+        const int64_t wb = std::max<int64_t>(0, gb - 3);
+        const int64_t we = std::max<int64_t>(wb + 1, std::min<int64_t>(ref_len, ge + 5));
+        const uint32_t win_begin = (uint32_t)wb, n_cols = (uint32_t)(we - wb);
+
+        std::vector<uint8_t> rows;
+        std::vector<std::string> names;
+        const uint64_t n_reads = build_rows(opt.bam, io, ext.ref_id, win_begin, n_cols, ext.n_reads, rows, &names);
+        if (!opt.dump_msa.empty()) {  // host-side ingest check, no GPU involved
+            std::ofstream f(opt.dump_msa, std::ios::binary);
+            const uint64_t hdr[3] = {n_reads, n_cols, win_begin};
+            f.write((const char *)hdr, sizeof hdr);
+            f.write((const char *)rows.data(), (std::streamsize)((size_t)n_reads * n_cols));
+            if (opt.outputs.empty()) return 0;
+        }
+
+        // ---------------------------------------------------------------- parameters
+        std::string chem = opt.chemistry;
+        if (chem == "auto") {
+            // chemistry-keyed rates with a permissive fallback (doc/JULIET.md:221-225); the key here is the
+            // platform model in the @RG line
+            chem = (header_text.find("SEQUEL") != std::string::npos || header_text.find("S/P") != std::string::npos) ? "sequel" : "permissive";
+            if (chem == "permissive") std::cerr << "juliet: chemistry not recognised, permissive mode is active (doc/JULIET.md:221-225)\n";
+        }
+        jl_params prm;
+        prm.alpha = opt.alpha;
+        prm.n_tests = opt.n_tests;
+        if (chem == "sequel") prm.err = {0.998826, 5.8e-5, 1.0e-3};
+        else prm.err = {0.99764, 1.2e-4, 2.0e-3};
+        if (opt.match > 0) prm.err.match = opt.match;
+        if (opt.substitution >= 0) prm.err.substitution = opt.substitution;
+        prm.expected_round = opt.expected_round;
+        prm.tail = 0;
+        prm.min_perc = opt.min_perc;
+        prm.max_perc = opt.max_perc;
+
+        std::vector<jl_gene> genes;
+        for (const GeneCfg &g : cfg.genes) genes.push_back({g.begin_eff, g.end_eff});
+        std::vector<uint8_t> refcodes;
+        if (!cfg.reference_sequence.empty())
+            for (char ch : cfg.reference_sequence) refcodes.push_back(base_code(ch));
+
+        // ---------------------------------------------------------------- device
+        jl_ctx *ctx = nullptr;
+        if (jl_ctx_create(opt.device, nullptr, &ctx) != JL_OK) die_jl(nullptr, "no usable GPU (this tool has no CPU fallback)");
+        if (jl_msa_pack_rows(ctx, rows.data(), n_reads, n_cols, win_begin) != JL_OK) die_jl(ctx, "upload");
+        std::vector<uint8_t>().swap(rows);
+
+        // --drm-only needs the position list, which the plan of a first pileup provides
+        std::vector<uint64_t> drm_masks;
+        const uint8_t *refp = refcodes.empty() ? nullptr : refcodes.data();
+        if (opt.drm_only) {
+            if (jl_pileup_async(ctx, genes.data(), (uint32_t)genes.size(), refp, (uint32_t)refcodes.size()) != JL_OK) die_jl(ctx, "pileup");
+            const uint32_t P = jl_n_positions(ctx);
+            std::vector<uint32_t> pg(P), pk(P);
+            if (jl_pileup_fetch(ctx, nullptr, pg.data(), pk.data(), nullptr, nullptr, nullptr) != JL_OK) die_jl(ctx, "pileup fetch");
+            drm_masks.assign(P, 0);
+            for (uint32_t p = 0; p < P; ++p) {
+                const GeneCfg &g = cfg.genes[pg[p]];
+                for (unsigned cod = 0; cod < 64; ++cod)
+                    if (!cfg.known_drms(pg[p], pk[p] + g.first_codon, translate(cod)).empty()) drm_masks[p] |= 1ull << cod;
+            }
+        }
+        if (jl_run_async(ctx, genes.data(), (uint32_t)genes.size(), refp, (uint32_t)refcodes.size(), &prm,
+                         opt.drm_only ? drm_masks.data() : nullptr, opt.phasing, opt.min_reads, opt.phasing) != JL_OK)
+            die_jl(ctx, "run");
+
+        std::vector<jl_variant> var(4096);
+        uint32_t nv = 0;
+        if (jl_call_fetch(ctx, var.data(), 4096, &nv) != JL_OK) die_jl(ctx, "call fetch");
+        var.resize(nv);
+        std::vector<uint32_t> col_counts((size_t)n_cols * 6);
+        if (jl_pileup_fetch(ctx, col_counts.data(), nullptr, nullptr, nullptr, nullptr, nullptr) != JL_OK) die_jl(ctx, "pileup fetch");
+
+        jl_phase_summary ps = {};
+        std::vector<uint32_t> pos_cols, hap_count;
+        std::vector<uint8_t> hap_pattern, hit;
+        std::vector<uint16_t> read_hap;
+        const uint32_t cap_var = std::max<uint32_t>(1, nv);
+        if (opt.phasing) {
+            pos_cols.resize(cap_var);
+            hap_count.resize(JL_MAX_HAPLOTYPES);
+            hap_pattern.resize((size_t)JL_MAX_HAPLOTYPES * cap_var);
+            hit.resize((size_t)cap_var * JL_MAX_HAPLOTYPES);
+            read_hap.resize(n_reads);
+            if (jl_phase_fetch(ctx, &ps, pos_cols.data(), hap_count.data(), hap_pattern.data(), hit.data(), read_hap.data(), nullptr, cap_var) != JL_OK)
+                die_jl(ctx, "phase fetch");
+        }
+        jl_ctx_destroy(ctx);
+
+        // ---------------------------------------------------------------- JSON (doc/JULIET.md:61-107, 207-211)
+        Json root = Json::object();
+        root.set("input", Json::object()
+                              .set("timestamp", Json::of(iso_now()))
+                              .set("input_file", Json::of(opt.bam))
+                              .set("command_line", Json::of(cmdline))
+                              .set("juliet_version", Json::of(kVersion)));
+        Json tc = cfg.echo();
+        tc.set("n_reads", Json::of((int64_t)n_reads));
+        tc.set("window_begin", Json::of(win_begin + 1)).set("window_end", Json::of(win_begin + n_cols + 1));
+        tc.set("chemistry_model", Json::of(chem));
+        root.set("target_config", tc);
+
+        Json genes_json = Json::array();
+        const uint32_t H = ps.n_haplotypes;
+        for (size_t g = 0; g < cfg.genes.size(); ++g) {
+            Json gj = Json::object();
+            gj.set("name", Json::of(cfg.genes[g].name));
+            Json vps = Json::array();
+            size_t v = 0;
+            while (v < var.size()) {
+                if (var[v].gene != g) { ++v; continue; }
+                size_t e = v;
+                while (e < var.size() && var[e].gene == g && var[e].codon_pos == var[v].codon_pos) ++e;
+                const jl_variant &f = var[v];
+                Json vp = Json::object();
+                vp.set("ref_codon", Json::of(codon_string(f.ref_codon)));
+                vp.set("ref_amino_acid", Json::of(std::string(1, translate(f.ref_codon))));
+                const uint32_t aa_pos = f.codon_pos + cfg.genes[g].first_codon;
+                vp.set("ref_position", Json::of(aa_pos));
+                vp.set("coverage", Json::of(f.coverage));
+                // variant codons grouped by amino acid (position 223 with two rows)
+                Json aas = Json::array();
+                std::vector<char> order;
+                for (size_t k = v; k < e; ++k) {
+                    const char aa = translate(var[k].codon);
+                    if (std::find(order.begin(), order.end(), aa) == order.end()) order.push_back(aa);
+                }
+                for (char aa : order) {
+                    Json aj = Json::object();
+                    aj.set("amino_acid", Json::of(std::string(1, aa)));
+                    Json cods = Json::array();
+                    for (size_t k = v; k < e; ++k) {
+                        if (translate(var[k].codon) != aa) continue;
+                        Json cj = Json::object();
+                        cj.set("codon", Json::of(codon_string(var[k].codon)));
+                        cj.set("frequency", Json::of((double)var[k].count / (double)var[k].coverage));
+                        cj.set("count", Json::of(var[k].count));
+                        cj.set("expected", Json::of(var[k].expected));
+                        cj.set("pValue", Json::of(var[k].p_value));
+                        cj.set("log_pValue", Json::of(var[k].log_p));
+                        cj.set("known_drm", Json::of(cfg.known_drms(g, aa_pos, aa)));
+                        if (opt.phasing) {
+                            Json hh = Json::array();
+                            for (uint32_t h = 0; h < H; ++h) hh.push(Json::of(hit[(size_t)k * JL_MAX_HAPLOTYPES + h] != 0));
+                            cj.set("haplotype_hit", hh);  // doc/JULIET.md:207-209
+                        }
+                        cods.push(cj);
+                    }
+                    aj.set("variant_codons", cods);
+                    aas.push(aj);
+                }
+                vp.set("variant_amino_acids", aas);
+                // MSA context: -3 .. +5 around the codon's first base (doc/JULIET.md:99-100)
+                Json msa = Json::array();
+                for (int rel = -3; rel <= 5; ++rel) {
+                    const int64_t c = (int64_t)f.col + rel;
+                    if (c < 0 || c >= (int64_t)n_cols) continue;
+                    const uint32_t *cc = &col_counts[(size_t)c * 6];
+                    Json mj = Json::object();
+                    mj.set("rel_pos", Json::of((int64_t)rel)).set("abs_pos", Json::of((int64_t)(win_begin + c + 1)));
+                    static const char *sym[6] = {"A", "C", "G", "T", "-", "N"};
+                    for (int s = 0; s < 6; ++s) mj.set(sym[s], Json::of(cc[s]));
+                    const size_t r = (size_t)win_begin + (size_t)c;
+                    if (r < cfg.reference_sequence.size()) mj.set("wt", Json::of(std::string(1, (char)std::toupper((unsigned char)cfg.reference_sequence[r]))));
+                    msa.push(mj);
+                }
+                vp.set("msa", msa);
+                vps.push(vp);
+                v = e;
+            }
+            gj.set("variant_positions", vps);
+            genes_json.push(gj);
+        }
+        root.set("genes", genes_json);
+
+        if (opt.phasing) {  // root `haplotype` block: counts and read names, same order as haplotype_hit (doc/JULIET.md:209-211)
+            Json hb = Json::object();
+            hb.set("reported_reads", Json::of(ps.reported_reads)).set("insufficient_coverage_reads", Json::of(ps.insufficient_reads));
+            hb.set("damaged_reads", Json::of(ps.damaged_reads)).set("marginal_gaps", Json::of(ps.marginal_gap));
+            hb.set("marginal_heteroduplexes", Json::of(ps.marginal_heteroduplex)).set("marginal_partial", Json::of(ps.marginal_partial));
+            std::vector<std::vector<uint32_t>> members(H);
+            for (uint64_t i = 0; i < n_reads; ++i)
+                if (read_hap[i] < H) members[read_hap[i]].push_back((uint32_t)i);
+            Json hs = Json::array();
+            for (uint32_t h = 0; h < H; ++h) {
+                Json hj = Json::object();
+                hj.set("name", Json::of(haplotype_name(h))).set("reads", Json::of(hap_count[h]));
+                hj.set("frequency", Json::of(ps.reported_reads ? (double)hap_count[h] / (double)ps.reported_reads : 0.0));
+                Json cods = Json::array();
+                for (uint32_t p = 0; p < ps.n_positions; ++p) cods.push(Json::of(codon_string(hap_pattern[(size_t)h * cap_var + p])));
+                hj.set("codons", cods);
+                Json rn = Json::array();
+                for (uint32_t i : members[h]) rn.push(Json::of(names[i]));
+                hj.set("read_names", rn);
+                hs.push(hj);
+            }
+            hb.set("haplotypes", hs);
+            Json pc = Json::array();
+            for (uint32_t p = 0; p < ps.n_positions; ++p) pc.push(Json::of(win_begin + pos_cols[p] + 1));
+            hb.set("variant_positions_abs", pc);
+            root.set("haplotype", hb);
+        }
+
+        std::string text;
+        root.write(text);
+        text += "\n";
+        for (const std::string &out : opt.outputs) {
+            std::ofstream f(out);
+            if (!f) { std::cerr << "juliet: cannot write " << out << "\n"; return 2; }
+            if (out.substr(out.size() - 5) == ".json") f << text;
+            else f << render_html(root, text);
+        }
+        return 0;
+    } catch (const std::exception &e) {
+        std::cerr << "juliet: " << e.what() << "\n";
+        return 2;
+    }
+}

@@ -1,0 +1,102 @@
+// msa_builder.hpp — aligned BAM records -> by-row symbol matrix of one reference window
+// (doc/JULIET.md:50-58 input contract; :26-27 insertions ignored, deletions are '-'; :256-259 filtered base = N).
+#pragma once
+#include <limits>
+
+#include "bam.hpp"
+
+namespace jlhost {
+
+struct IngestOptions {
+    int ref_id = -1;        // -1: the reference of the first kept record
+    uint32_t min_qv = 0;    // bases below become N (UNPINNED threshold, SPEC / SURVEY C6); 0 = off
+    double min_rq = 0.0;    // skip reads with a lower rq tag; 0 = off (doc/JULIET.md:56 leaves this to the user)
+};
+
+inline bool keep_record(const BamRecord &r)
+{
+    // "Reads that are not primary or supplementary alignments, get ignored" (doc/JULIET.md:58)
+    return !(r.flag & 0x4) && !(r.flag & 0x100) && r.ref_id >= 0 && r.pos >= 0;
+}
+
+inline uint32_t ref_span(const BamRecord &r)
+{
+    uint32_t n = 0;
+    for (uint32_t c : r.cigar) {
+        const uint32_t op = c & 15;
+        if (op == CIG_D || op == CIG_N || op == CIG_EQ || op == CIG_X || op == CIG_M) n += c >> 4;
+    }
+    return n;
+}
+
+struct ReadExtent {
+    uint64_t n_reads = 0;
+    int64_t min_pos = std::numeric_limits<int64_t>::max(), max_end = 0;
+    int ref_id = -1;
+};
+
+inline ReadExtent scan_extent(const std::string &bam, const IngestOptions &opt)
+{
+    BamReader in(bam);
+    BamRecord r;
+    ReadExtent e;
+    e.ref_id = opt.ref_id;
+    while (in.next(r)) {
+        if (!keep_record(r)) continue;
+        if (opt.min_rq > 0.0 && r.rq >= 0.f && r.rq < opt.min_rq) continue;
+        if (e.ref_id < 0) e.ref_id = r.ref_id;
+        if (r.ref_id != e.ref_id) continue;
+        ++e.n_reads;
+        e.min_pos = std::min<int64_t>(e.min_pos, r.pos);
+        e.max_end = std::max<int64_t>(e.max_end, (int64_t)r.pos + ref_span(r));
+    }
+    return e;
+}
+
+// rows: uint8[n_reads][n_cols] (codes 0..6), names in record order.  Returns the number of rows filled.
+inline uint64_t build_rows(const std::string &bam, const IngestOptions &opt, int ref_id, uint32_t win_begin,
+                           uint32_t n_cols, uint64_t cap_reads, std::vector<uint8_t> &rows,
+                           std::vector<std::string> *names)
+{
+    rows.assign((size_t)cap_reads * n_cols, JL_SYM_NONE);
+    BamReader in(bam);
+    BamRecord r;
+    uint64_t n = 0;
+    const int64_t wb = win_begin, we = (int64_t)win_begin + n_cols;
+    while (in.next(r)) {
+        if (!keep_record(r) || r.ref_id != ref_id) continue;
+        if (opt.min_rq > 0.0 && r.rq >= 0.f && r.rq < opt.min_rq) continue;
+        if (n >= cap_reads) throw std::runtime_error("BAM changed between passes");
+        uint8_t *row = rows.data() + (size_t)n * n_cols;
+        int64_t rp = r.pos;  // reference cursor
+        size_t qp = 0;       // read cursor
+        for (uint32_t c : r.cigar) {
+            const uint32_t op = c & 15, len = c >> 4;
+            switch (op) {
+            case CIG_M:
+                throw std::runtime_error("read " + r.name + ": cigar M is forbidden in PacBio-compliant BAM (doc/JULIET.md:53)");
+            case CIG_EQ:
+            case CIG_X:
+                for (uint32_t k = 0; k < len; ++k, ++rp, ++qp) {
+                    if (rp < wb || rp >= we || qp >= r.seq.size()) continue;
+                    uint8_t s = r.seq[qp] < 4 ? r.seq[qp] : (uint8_t)JL_SYM_MASK;
+                    if (opt.min_qv && qp < r.qual.size() && r.qual[qp] != 0xFF && r.qual[qp] < opt.min_qv) s = JL_SYM_MASK;
+                    row[rp - wb] = s;
+                }
+                break;
+            case CIG_D:
+                for (uint32_t k = 0; k < len; ++k, ++rp)
+                    if (rp >= wb && rp < we) row[rp - wb] = JL_SYM_GAP;
+                break;
+            case CIG_N: rp += len; break;            // reference skip: stays uncovered
+            case CIG_I: case CIG_S: qp += len; break;  // insertions and clips carry no reference column
+            default: break;                           // H, P
+            }
+        }
+        if (names) names->push_back(r.name);
+        ++n;
+    }
+    return n;
+}
+
+}  // namespace jlhost

@@ -1,0 +1,109 @@
+// juliet-synth — writes the synthetic aligned-CCS mixture of csrc/jl_synth.h as a PacBio-style BAM
+// (cigar = X D only, no M: doc/JULIET.md:53) plus a matching target config, so the BAM-in / JSON-out
+// surface can be exercised end to end.  Mixture semantics: doc/MIXDATA.md:9-22.
+#include <cstdlib>
+#include <fstream>
+#include <iostream>
+
+#include "../csrc/jl_synth.h"
+#include "bam.hpp"
+#include "config.hpp"
+
+using namespace jlhost;
+
+int main(int argc, char **argv)
+{
+    uint64_t n_reads = 1000, seed = 1;
+    uint32_t n_cols = 3000, ref_offset = 0;
+    double sub = 1.75e-4, del = 1.3e-3, mask = 2.0e-2, partial = 0.0;
+    uint32_t minor[4] = {10, 10, 10, 10};
+    std::string out, cfg_out;
+    for (int i = 1; i < argc; ++i) {
+        const std::string a = argv[i];
+        auto need = [&]() -> std::string { if (i + 1 >= argc) { std::cerr << a << " needs a value\n"; std::exit(1); } return argv[++i]; };
+        if (a == "--reads") n_reads = std::stoull(need());
+        else if (a == "--cols") n_cols = (uint32_t)std::stoul(need());
+        else if (a == "--seed") seed = std::stoull(need());
+        else if (a == "--sub") sub = std::stod(need());
+        else if (a == "--del") del = std::stod(need());
+        else if (a == "--mask") mask = std::stod(need());
+        else if (a == "--partial") partial = std::stod(need());
+        else if (a == "--minor-permille") { for (int k = 0; k < 4; ++k) minor[k] = (uint32_t)std::stoul(need()); }
+        else if (a == "--ref-offset") ref_offset = (uint32_t)std::stoul(need());  // window starts here in a longer reference
+        else if (a == "-o") out = need();
+        else if (a == "--config-out") cfg_out = need();
+        else { std::cerr << "usage: juliet-synth --reads N --cols L --seed S [--partial p] [--minor-permille a b c d] [--ref-offset k] -o out.bam [--config-out cfg.json]\n"; return 1; }
+    }
+    if (out.empty()) { std::cerr << "juliet-synth: -o out.bam is required\n"; return 1; }
+    std::vector<uint8_t> ref(n_cols);
+    jl_synth_reference(seed, n_cols, ref.data());
+    jl_synth_plan pl;
+    jl_synth_make_plan(&pl, seed, n_cols, sub, del, mask, partial, minor, ref.data());
+
+    const uint32_t ref_len = ref_offset + n_cols;
+    const std::string header = "@HD\tVN:1.5\tSO:unknown\tpb:3.0.1\n@SQ\tSN:synthetic_ref\tLN:" + std::to_string(ref_len) +
+                               "\n@RG\tID:synth\tPL:PACBIO\tPM:SEQUEL\tDS:READTYPE=CCS\n";
+    BamWriter bw(out, header, {{"synthetic_ref", ref_len}});
+    BamRecord r;
+    for (uint64_t i = 0; i < n_reads; ++i) {
+        uint32_t hap, st, en;
+        jl_synth_read(&pl, i, &hap, &st, &en);
+        r = BamRecord();
+        r.ref_id = 0;
+        r.pos = (int32_t)(ref_offset + st);
+        r.flag = 0;
+        r.mapq = 254;
+        r.name = "synth/" + std::to_string(i) + "/ccs";
+        r.rq = 0.999f;
+        uint32_t run_op = 99, run_len = 0;
+        auto flush = [&]() { if (run_len) r.cigar.push_back(run_len << 4 | run_op); run_len = 0; };
+        for (uint32_t c = st; c < en; ++c) {
+            const uint32_t s = jl_synth_cell(&pl, i, c, hap, st, en, ref[c]);
+            uint32_t op;
+            if (s == 4) op = CIG_D;
+            else {
+                op = (s < 4 && s == ref[c]) ? CIG_EQ : CIG_X;
+                r.seq.push_back(s < 4 ? (uint8_t)s : (uint8_t)4);  // filtered base travels as 'N'
+                r.qual.push_back(93);
+            }
+            if (op != run_op) { flush(); run_op = op; }
+            ++run_len;
+        }
+        flush();
+        bw.write(r);
+    }
+    bw.close();
+
+    if (!cfg_out.empty()) {
+        static const char *b = "ACGT";
+        std::string seq(ref_offset, 'A');
+        for (uint32_t c = 0; c < n_cols; ++c) seq += b[ref[c]];
+        Json cfg = Json::object();
+        Json g = Json::object();
+        g.set("name", Json::of("Synthetic ORF")).set("begin", Json::of(ref_offset + 1)).set("end", Json::of(ref_offset + 3 * (n_cols / 3) + 1));
+        Json drms = Json::array();
+        // the planted codon edits double as the "known" resistance mutations of a made-up drug
+        Json d = Json::object();
+        d.set("name", Json::of("synthetic drug"));
+        Json ps = Json::array();
+        for (int k = 0; k < JL_SYNTH_N_EDITS; ++k) {
+            const uint32_t col = pl.edit_col[k], cs = col - col % 3;
+            unsigned cod[3] = {ref[cs], ref[cs + 1], ref[cs + 2]};
+            const char ra = translate(16 * cod[0] + 4 * cod[1] + cod[2]);
+            cod[col % 3] = pl.edit_base[k];
+            const char ma = translate(16 * cod[0] + 4 * cod[1] + cod[2]);
+            ps.push(Json::of(std::string(1, ra) + std::to_string(cs / 3 + 1) + std::string(1, ma)));
+        }
+        d.set("positions", ps);
+        drms.push(d);
+        g.set("drms", drms);
+        cfg.set("genes", Json::array().push(g));
+        cfg.set("referenceName", Json::of("synthetic_ref")).set("referenceSequence", Json::of(seq));
+        cfg.set("version", Json::of("juliet-synth seed " + std::to_string(seed)));
+        cfg.set("databaseVersion", Json::of("synthetic DRM list"));
+        std::string s;
+        cfg.write(s);
+        std::ofstream(cfg_out) << s << "\n";
+    }
+    return 0;
+}

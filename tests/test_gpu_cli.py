@@ -1,0 +1,144 @@
+"""End to end on the GPU: synthetic PacBio-style BAM -> `juliet` (C++ front end over the C ABI) -> JSON,
+checked against the oracle run on the same reads.  Exercises the documented command-line surface
+(doc/JULIET.md:62-66, 121, 195, 270-271, 342-370)."""
+import json
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle_lib
+from minorseq_amd import capi, msa, synth
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+JULIET = os.path.join(ROOT, "minorseq_amd", "bin", "juliet")
+SYNTH = os.path.join(ROOT, "minorseq_amd", "bin", "juliet-synth")
+N, L, SEED = 6000, 900, 4
+MINOR = (60, 50, 40, 30)
+
+
+@pytest.fixture(scope="module")
+def sample(tmp_path_factory):
+    d = tmp_path_factory.mktemp("cli")
+    bam, cfg = str(d / "s.align.bam"), str(d / "cfg.json")
+    subprocess.check_call([SYNTH, "--reads", str(N), "--cols", str(L), "--seed", str(SEED), "--partial", "0.1",
+                           "--minor-permille", *map(str, MINOR), "-o", bam, "--config-out", cfg])
+    sp = synth.SynthParams(seed=SEED, partial_rate=0.1, minor_permille=MINOR)
+    ref = synth.reference(SEED, L)
+    return d, bam, cfg, synth.rows(sp, L, 0, N, ref), ref
+
+
+def run_juliet(d, bam, *args, out="o.json"):
+    o = str(d / out)
+    subprocess.check_call([JULIET, *args, bam, o])
+    return json.load(open(o)) if o.endswith(".json") else open(o).read()
+
+
+def flat_variants(j):
+    rows = []
+    for gi, g in enumerate(j["genes"]):
+        for vp in g["variant_positions"]:
+            for aa in vp["variant_amino_acids"]:
+                for vc in aa["variant_codons"]:
+                    rows.append((gi, vp["ref_position"], msa.codon_index(vc["codon"]), vc, vp, aa))
+    return sorted(rows, key=lambda r: r[:3])
+
+
+def test_json_matches_oracle_with_phasing(sample, oracle):
+    d, bam, cfg, rows, ref = sample
+    j = run_juliet(d, bam, "-c", cfg, "--mode-phasing")
+    genes = np.array([(1, L + 1)], dtype=capi.GENE)
+    exp = oracle.call(rows, genes, refseq=ref)
+    got = flat_variants(j)
+    assert len(got) == len(exp) >= 4
+    for (gi, pos, cod, vc, vp, aa), e in zip(got, exp):
+        assert (gi, pos, cod) == (e["gene"], e["codon_pos"], e["codon"])
+        assert vc["count"] == e["count"] and vp["coverage"] == e["coverage"] and vc["expected"] == e["expected"]
+        assert vc["frequency"] == e["count"] / e["coverage"]
+        assert abs(vc["pValue"] - e["p_value"]) <= 1e-10
+        assert vp["ref_codon"] == msa.codon_string(e["ref_codon"])
+        assert vc["known_drm"] == "synthetic drug"        # the planted edits are the config's DRMs
+        # MSA context rows are the column pileup (doc/JULIET.md:99-100)
+        col = oracle.pileup(rows)
+        for m in vp["msa"]:
+            c = m["abs_pos"] - 1
+            assert [m[s] for s in "ACGT-N"] == col[c].tolist() and m["wt"] == "ACGT"[ref[c]]
+        assert [m["rel_pos"] for m in vp["msa"]] == list(range(max(-3, -int(e["col"])), 6))
+    ph = oracle.phase(rows, exp)
+    hb = j["haplotype"]
+    s = ph["summary"]
+    assert (hb["reported_reads"], hb["insufficient_coverage_reads"], hb["damaged_reads"]) == \
+        (s["reported_reads"], s["insufficient_reads"], s["damaged_reads"])
+    assert hb["reported_reads"] + hb["insufficient_coverage_reads"] + hb["damaged_reads"] == N   # doc/JULIET.md:378-379
+    assert (hb["marginal_gaps"], hb["marginal_heteroduplexes"], hb["marginal_partial"]) == \
+        (s["marginal_gap"], s["marginal_heteroduplex"], s["marginal_partial"])
+    assert [h["reads"] for h in hb["haplotypes"]] == ph["hap_count"].tolist()
+    assert all(re.fullmatch(r"[A-Z][a-z]?", h["name"]) for h in hb["haplotypes"])             # doc/JULIET.md:198
+    assert [h["name"] for h in hb["haplotypes"]] == [capi.haplotype_name(i) for i in range(len(hb["haplotypes"]))]
+    assert abs(sum(h["frequency"] for h in hb["haplotypes"]) - 1.0) < 1e-12
+    for hi, h in enumerate(hb["haplotypes"]):
+        assert [msa.codon_index(c) for c in h["codons"]] == ph["hap_pattern"][hi].tolist()
+        idx = sorted(int(n.split("/")[1]) for n in h["read_names"])
+        assert idx == np.nonzero(ph["read_hap"] == hi)[0].tolist()
+    for k, (gi, pos, cod, vc, vp, aa) in enumerate(got):
+        assert vc["haplotype_hit"] == [bool(x) for x in ph["hit"][k]]                           # doc/JULIET.md:207-211
+    # traceability block (doc/JULIET.md:75-79)
+    assert j["input"]["input_file"] == bam and "--mode-phasing" in j["input"]["command_line"]
+    assert re.fullmatch(r"\d{4}-\d\d-\d\dT\d\d:\d\d:\d\d\.\d{3}Z", j["input"]["timestamp"])
+    assert j["target_config"]["referenceName"] == "synthetic_ref" and j["target_config"]["chemistry_model"] == "sequel"
+
+
+def test_filters_and_region(sample, oracle):
+    d, bam, cfg, rows, ref = sample
+    genes = np.array([(1, L + 1)], dtype=capi.GENE)
+    exp = oracle.call(rows, genes, refseq=ref)
+    perc = 100.0 * exp["count"] / exp["coverage"]
+    j = run_juliet(d, bam, "-c", cfg, "--min-perc", "4.5")
+    assert [(r[1], r[2]) for r in flat_variants(j)] == [(e["codon_pos"], e["codon"]) for e in exp[perc > 4.5]]
+    j = run_juliet(d, bam, "-c", cfg, "--max-perc", "4.5")
+    assert [(r[1], r[2]) for r in flat_variants(j)] == [(e["codon_pos"], e["codon"]) for e in exp[perc < 4.5]]
+    assert "haplotype" not in j                                   # phasing is opt-in (doc/JULIET.md:194-195)
+    # --region: AA numbering stays relative to the gene (first_codon offset)
+    b, e_ = 31, 400
+    j = run_juliet(d, bam, "-c", cfg, "--region", f"{b}-{e_}", "--n-tests", "300")
+    sub = oracle.call(rows, np.array([(b, e_)], dtype=capi.GENE), refseq=ref, params=oracle_lib.default_params(n_tests=300))
+    assert [(r[1], r[2]) for r in flat_variants(j)] == [(x["codon_pos"] + (b - 1) // 3, x["codon"]) for x in sub]
+    assert len(sub) >= 1
+
+
+def test_drm_only_keeps_only_config_mutations(tmp_path, oracle):
+    """--drm-only (doc/JULIET.md:370) on a noisy sample where plenty of non-DRM codons are significant too."""
+    n, l, seed = 3000, 300, 8
+    bam, cfg = str(tmp_path / "noisy.bam"), str(tmp_path / "noisy.json")
+    subprocess.check_call([SYNTH, "--reads", str(n), "--cols", str(l), "--seed", str(seed), "--sub", "0.012",
+                           "--minor-permille", "60", "50", "40", "30", "-o", bam, "--config-out", cfg])
+    sp = synth.SynthParams(seed=seed, sub_rate=0.012, minor_permille=(60, 50, 40, 30))
+    ref = synth.reference(seed, l)
+    rows = synth.rows(sp, l, 0, n, ref)
+    genes = np.array([(1, l + 1)], dtype=capi.GENE)
+    every = flat_variants(run_juliet(tmp_path, bam, "-c", cfg))
+    only = flat_variants(run_juliet(tmp_path, bam, "-c", cfg, "--drm-only"))
+    assert len(every) > len(only) >= 4
+    assert all(r[3]["known_drm"] == "synthetic drug" for r in only)
+    assert [(r[1], r[2]) for r in only] == [(r[1], r[2]) for r in every if r[3]["known_drm"]]
+    exp = oracle.call(rows, genes, refseq=ref)
+    assert [(r[1], r[2]) for r in every] == [(e["codon_pos"], e["codon"]) for e in exp]
+
+
+def test_no_config_majority_mode_and_html(sample, oracle):
+    d, bam, cfg, rows, ref = sample
+    j = run_juliet(d, bam)                                        # doc/JULIET.md:182-188
+    assert [g["name"] for g in j["genes"]] == ["unknown"]
+    lo = int((rows != 6).any(axis=0).argmax())
+    hi = L - int((rows[:, ::-1] != 6).any(axis=0).argmax())
+    exp = oracle.call(rows[:, lo:hi], np.array([(lo + 1, hi + 1)], dtype=capi.GENE), win_begin=lo)
+    assert [(r[1], r[2]) for r in flat_variants(j)] == [(e["codon_pos"], e["codon"]) for e in exp]
+    html = run_juliet(d, bam, "-c", cfg, out="o.html")
+    assert html.startswith("<!DOCTYPE html>") and "Variant Discovery" in html and "synthetic drug" in html
+    # two outputs at once (doc/JULIET.md:65)
+    subprocess.check_call([JULIET, "-c", cfg, bam, str(d / "both.html"), str(d / "both.json")])
+    assert os.path.getsize(d / "both.html") > 0 and json.load(open(d / "both.json"))["genes"]

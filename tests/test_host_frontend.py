@@ -1,0 +1,91 @@
+"""Host-side front end (minorseq_amd/host/): BAM writer + BGZF/BAM reader + CIGAR walk, target-config parsing,
+DRM grammar, --region.  CPU only: uses the tool's --dump-msa / --dump-config diagnostics, which never touch a GPU."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from minorseq_amd import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "minorseq_amd", "bin")
+JULIET = os.path.join(BIN, "juliet")
+SYNTH = os.path.join(BIN, "juliet-synth")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def built():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "minorseq_amd", "csrc")])
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "minorseq_amd", "host")])
+
+
+def read_msa(path):
+    raw = open(path, "rb").read()
+    n, l, wb = (int(x) for x in np.frombuffer(raw[:24], dtype=np.uint64))
+    return np.frombuffer(raw[24:], dtype=np.uint8).reshape(n, l), wb
+
+
+@pytest.mark.parametrize("n,l,seed,partial,offset", [(300, 90, 3, 0.0, 0), (700, 300, 5, 0.3, 0), (200, 120, 9, 0.5, 250)])
+def test_bam_roundtrip_equals_generator(tmp_path, n, l, seed, partial, offset):
+    bam, cfg, msa = (str(tmp_path / x) for x in ("s.bam", "s.json", "s.msa"))
+    subprocess.check_call([SYNTH, "--reads", str(n), "--cols", str(l), "--seed", str(seed), "--partial", str(partial),
+                           "--ref-offset", str(offset), "-o", bam, "--config-out", cfg])
+    subprocess.check_call([JULIET, "-c", cfg, "--dump-msa", msa, bam])
+    rows, wb = read_msa(msa)
+    exp = synth.rows(synth.SynthParams(seed=seed, partial_rate=partial), l, 0, n)
+    # the window is the gene plus the -3..+5 context, clipped to the reference
+    assert wb == max(0, offset - 3)
+    assert (rows[:, offset - wb: offset - wb + l] == exp).all()
+    assert (rows[:, : offset - wb] == 6).all()          # nothing aligned before the window start
+    # without a config the window is the covered range and the gene is "unknown"
+    subprocess.check_call([JULIET, "--dump-msa", msa, bam])
+    rows2, wb2 = read_msa(msa)
+    assert rows2.shape[0] == n and wb2 <= offset + l
+
+
+def test_bgzf_multi_block(tmp_path):
+    """> 64 KiB of records => several BGZF blocks; the reader must cross member boundaries."""
+    bam, msa = str(tmp_path / "big.bam"), str(tmp_path / "big.msa")
+    subprocess.check_call([SYNTH, "--reads", "400", "--cols", "3000", "--seed", "2", "-o", bam])
+    assert os.path.getsize(bam) > 100_000
+    subprocess.check_call([JULIET, "--dump-msa", msa, bam])
+    rows, _ = read_msa(msa)
+    assert (rows[:, :3000] == synth.rows(synth.SynthParams(seed=2), 3000, 0, 400)).all()
+
+
+def test_target_config_grammar_and_region(tmp_path):
+    cfg = {"genes": [{"begin": 2550, "end": 2700, "name": "Reverse Transcriptase",
+                      "drms": [{"name": "fancy drug", "positions": ["M41L"]},
+                               {"name": "ATV/r", "positions": ["V32I", "L33", "46IL", "I54VTALM", "V82ATFS", "84"]}]}],
+           "referenceName": "my seq", "referenceSequence": "TGGAAGGGCT", "version": "v", "databaseVersion": "DrugDB"}
+    p, out = str(tmp_path / "hiv.json"), str(tmp_path / "out.json")
+    json.dump(cfg, open(p, "w"))
+    subprocess.check_call([JULIET, "-c", p, "--dump-config", out])
+    got = json.load(open(out))
+    assert got["referenceName"] == "my seq" and got["referenceLength"] == 10 and got["databaseVersion"] == "DrugDB"
+    assert got["genes"][0]["drms"][1]["positions"] == ["V32I", "L33", "46IL", "I54VTALM", "V82ATFS", "84"]
+    assert got["effective_genes"] == [{"name": "Reverse Transcriptase", "begin": 2550, "end": 2700, "first_codon": 0}]
+    # --region snaps inward to the gene's own frame (doc/JULIET.md:270-271)
+    subprocess.check_call([JULIET, "-c", p, "-r", "2560-2650", "--dump-config", out])
+    eff = json.load(open(out))["effective_genes"][0]
+    assert eff == {"name": "Reverse Transcriptase", "begin": 2562, "end": 2650, "first_codon": 4}
+    # predefined configs (doc/JULIET.md:118-126)
+    subprocess.check_call([JULIET, "-c", "ABL1", "--dump-config", out])
+    abl = json.load(open(out))
+    assert abl["genes"][0]["begin"] == 193 and abl["genes"][0]["end"] == 3585 and len(abl["genes"][0]["drms"]) == 4
+    r = subprocess.run([JULIET, "-c", "HIV", "--dump-config", out], capture_output=True, text=True)
+    assert r.returncode == 2 and "not bundled" in r.stderr
+    bad = str(tmp_path / "bad.json")
+    json.dump({"genes": [{"begin": 1, "end": 10, "name": "g", "drms": [{"name": "d", "positions": ["M4!"]}]}]}, open(bad, "w"))
+    assert subprocess.run([JULIET, "-c", bad, "--dump-config", out], capture_output=True).returncode == 2
+
+
+def test_cli_usage_errors(tmp_path):
+    assert subprocess.run([JULIET], capture_output=True).returncode == 1
+    assert subprocess.run([JULIET, "--frobnicate", "a.bam", "o.json"], capture_output=True).returncode == 1
+    assert subprocess.run([JULIET, "a.bam", "o.txt"], capture_output=True).returncode == 1       # suffix selects the format
+    r = subprocess.run([JULIET, str(tmp_path / "missing.bam"), str(tmp_path / "o.json")], capture_output=True, text=True)
+    assert r.returncode == 2 and "cannot open" in r.stderr
+    assert subprocess.run([JULIET, "--version"], capture_output=True).returncode == 0
