@@ -297,6 +297,13 @@ static int build_plan(jl_ctx *ctx, const jl_gene *genes, uint32_t n_genes, const
     }
     ctx->default_n_tests = n_tests;
     ctx->P = (uint32_t)ctx->h_pos_col.size();
+    {   // which reading frames occur: decides the pileup kernel's chunk width and alignment
+        bool seen[3] = {false, false, false};
+        for (uint32_t c : ctx->h_pos_col) seen[c % 3] = true;
+        const int nf = (int)seen[0] + (int)seen[1] + (int)seen[2];
+        ctx->pileup_multi_frame = nf > 1;
+        ctx->pileup_frame = seen[1] ? 1u : seen[2] ? 2u : 0u;
+    }
     if (refseq)
         for (uint32_t c = 0; c < ctx->n_cols; ++c) {
             const uint64_t r = (uint64_t)c + ctx->win_begin;

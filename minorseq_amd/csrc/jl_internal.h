@@ -88,6 +88,8 @@ struct jl_ctx {
     uint32_t *d_hist = nullptr;
     size_t counts_words = 0;
     bool pileup_done = false;
+    bool pileup_multi_frame = false;  // codon starts fall in more than one frame (halo columns needed)
+    uint32_t pileup_frame = 0;        // the frame (start column mod 3) of a single-frame plan
 
     // ---- call
     uint64_t *d_called = nullptr;  // [P] mask of called codons
@@ -139,7 +141,7 @@ struct jl_ctx {
     std::vector<uint8_t> graph_sig;
     uint64_t alloc_version = 0;       // bumped by every (re)allocation: captured pointers go stale
     uint64_t plan_version = 0;
-    int pileup_blocks_per_cu[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // occupancy per kernel variant, queried once
+    int pileup_blocks_per_cu[16] = {0};  // occupancy per kernel variant, queried once
 
     // ---- timing
     hipEvent_t ev0 = nullptr, ev1 = nullptr;

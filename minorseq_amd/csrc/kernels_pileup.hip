@@ -23,9 +23,6 @@
 
 #include "jl_internal.h"
 
-#ifndef JL_PILEUP_W
-#define JL_PILEUP_W 6
-#endif
 #ifndef JL_PILEUP_PIPE
 #define JL_PILEUP_PIPE 0
 #endif
@@ -64,6 +61,22 @@ __device__ __forceinline__ void measure(uint32_t w, uint32_t (&a)[6])
     a[5] = __builtin_amdgcn_udot8(t2, w, a[5], false);
 }
 
+// the same six measurements without v_dot8 (tuning comparison): S1, S2 from bit-plane popcounts
+__device__ __forceinline__ void measure_popc(uint32_t w, uint32_t (&a)[6])
+{
+    const uint32_t p0 = __popc(w & kM1), p1 = __popc(w & 0x22222222u), p2 = __popc(w & kM4);
+    const uint32_t t = w & (w >> 1);
+    const uint32_t n01 = __popc(t & kM1), n12 = __popc(t & 0x22222222u), n02 = __popc(w & (w >> 2) & kM1);
+    // codes: C=1 G=2 T=3 D=4 N=5 U=6 ; nT=n01, nU=n12, nN=n02
+    const uint32_t nC = p0 - n01 - n02, nG = p1 - n01 - n12, nD = p2 - n02 - n12;
+    a[0] += nC + 2 * nG + 3 * n01 + 4 * nD + 5 * n02 + 6 * n12;
+    a[1] += nC + 4 * nG + 9 * n01 + 16 * nD + 25 * n02 + 36 * n12;
+    a[2] += p0;
+    a[3] += nC + 3 * n01 + 5 * n02;
+    a[4] += p2;
+    a[5] += 4 * (4 * nD + 5 * n02 + 6 * n12);
+}
+
 // Exact integer solve of the measurements for the counts of C G T - N and uncovered.
 __device__ __forceinline__ void solve(const uint32_t (&a)[6], uint32_t &nC, uint32_t &nG, uint32_t &nT, uint32_t &nD,
                                       uint32_t &nN, uint32_t &nU)
@@ -99,9 +112,9 @@ __device__ __forceinline__ void load_tile(tile_regs<W> &r, const uint8_t *__rest
     }
 }
 
-template <int W, bool PIPE>
+template <int W, bool PIPE, int MODE>
 __global__ __launch_bounds__(256) void pileup_kernel(const uint8_t *__restrict__ msa, uint64_t col_stride,
-                                                      uint32_t n_cols, uint32_t n_tiles,
+                                                      uint32_t n_cols, uint32_t n_tiles, uint32_t shift,
                                                       const uint8_t *__restrict__ colflag,
                                                       const uint8_t *__restrict__ guess,
                                                       uint32_t *__restrict__ counts, uint32_t *__restrict__ hist)
@@ -111,7 +124,9 @@ __global__ __launch_bounds__(256) void pileup_kernel(const uint8_t *__restrict__
     __shared__ uint32_t s_match[W];
 
     const uint32_t tid = threadIdx.x;
-    const uint32_t c0 = blockIdx.x * W;
+    // chunk grid shifted so that chunk boundaries coincide with codon boundaries of a single-frame plan;
+    // columns "before 0" wrap to huge unsigned values and fail every `< n_cols` test
+    const uint32_t c0 = blockIdx.x * W - shift;
 
     for (uint32_t i = tid; i < W * 64; i += 256) (&s_hist[0][0])[i] = 0;
     if (tid < W * 6) (&s_col[0][0])[tid] = 0;
@@ -172,11 +187,21 @@ __global__ __launch_bounds__(256) void pileup_kernel(const uint8_t *__restrict__
             }
             if (!live) continue;
             words += 4;
+            if (MODE == 1) {  // tuning probe: the loads alone (results are wrong by design)
+#pragma unroll
+                for (int j = 0; j < W; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc[j][q] ^= cur.d[j][q];
+                continue;
+            }
 #pragma unroll
             for (int j = 0; j < W; ++j) {
                 if (c0 + j < n_cols) {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) measure(cur.d[j][q], acc[j]);
+                    for (int q = 0; q < 4; ++q) {
+                        if (MODE == 2) measure_popc(cur.d[j][q], acc[j]);
+                        else measure(cur.d[j][q], acc[j]);
+                    }
                 }
             }
 #pragma unroll
@@ -289,14 +314,22 @@ __global__ __launch_bounds__(64) void guess_kernel(const uint8_t *__restrict__ m
 struct variant_t {
     int w;
     bool pipe;
-    void (*fn)(const uint8_t *, uint64_t, uint32_t, uint32_t, const uint8_t *, const uint8_t *, uint32_t *, uint32_t *);
+    void (*fn)(const uint8_t *, uint64_t, uint32_t, uint32_t, uint32_t, const uint8_t *, const uint8_t *, uint32_t *,
+               uint32_t *);
 };
 
 const variant_t kVariants[] = {
-    {6, false, pileup_kernel<6, false>},
-    {6, true, pileup_kernel<6, true>},
-    {12, false, pileup_kernel<12, false>},
-    {12, true, pileup_kernel<12, true>},
+    {6, false, pileup_kernel<6, false, 0>},
+    {6, true, pileup_kernel<6, true, 0>},
+    {12, false, pileup_kernel<12, false, 0>},
+    {12, true, pileup_kernel<12, true, 0>},
+#ifdef JL_PILEUP_TUNING
+    {106, false, pileup_kernel<6, false, 1>},   // W = 100 + w: load-only probe
+    {206, false, pileup_kernel<6, false, 2>},   // W = 200 + w: popcount measurements
+    {9, false, pileup_kernel<9, false, 0>},
+#endif
+    {3, false, pileup_kernel<3, false, 0>},
+    {3, true, pileup_kernel<3, true, 0>},
 };
 
 int env_int(const char *name, int dflt)
@@ -315,10 +348,12 @@ void jl_launch_guess(jl_ctx *ctx)
                        ctx->n_cols, ctx->d_guess);
 }
 
-static int pick_variant()
+static int pick_variant(const jl_ctx *ctx)
 {
-    // tuning knobs (defaults are the measured best on MI355X)
-    const int want_w = env_int("JL_PILEUP_W", JL_PILEUP_W);
+    // Measured on MI355X: 3-column chunks aligned to the codon frame when every codon of the plan
+    // is in one frame (no halo columns); 6-column chunks when frames mix (halo re-reads amortised).
+    // Environment variables override for tuning.
+    const int want_w = env_int("JL_PILEUP_W", ctx->pileup_multi_frame ? 6 : 3);
     const bool want_pipe = env_int("JL_PILEUP_PIPE", JL_PILEUP_PIPE) != 0;
     int idx = 0;
     for (int i = 0; i < (int)(sizeof(kVariants) / sizeof(kVariants[0])); ++i)
@@ -329,7 +364,7 @@ static int pick_variant()
 // occupancy query, once per variant and outside any stream capture
 void jl_prepare_pileup(jl_ctx *ctx)
 {
-    const int idx = pick_variant();
+    const int idx = pick_variant(ctx);
     if (ctx->pileup_blocks_per_cu[idx] > 0) return;
     int per_cu = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)kVariants[idx].fn, 256, 0) != hipSuccess || per_cu < 1)
@@ -340,21 +375,23 @@ void jl_prepare_pileup(jl_ctx *ctx)
 
 void jl_launch_pileup(jl_ctx *ctx)
 {
-    const int idx = pick_variant();
+    const int idx = pick_variant(ctx);
     const variant_t *var = &kVariants[idx];
     jl_prepare_pileup(ctx);
-    const uint32_t W = (uint32_t)var->w;
-    const uint32_t n_chunks = (ctx->n_cols + W - 1) / W;
+    const uint32_t W = (uint32_t)(var->w % 100);
+    const uint32_t shift = ctx->pileup_multi_frame ? 0u : (W - ctx->pileup_frame % W) % W;
+    const uint32_t n_chunks = (ctx->n_cols + shift + W - 1) / W;
     const uint32_t n_tiles = (uint32_t)((ctx->col_stride + JL_PILEUP_TILE_BYTES - 1) / JL_PILEUP_TILE_BYTES);
     // one resident wave of blocks: (CUs x blocks the kernel's registers admit per CU), reads split no finer than a tile
     const int per_cu = ctx->pileup_blocks_per_cu[idx];
-    const uint32_t target = 256u * (uint32_t)per_cu * (uint32_t)env_int("JL_PILEUP_WAVES", 1);
-    uint32_t rsplit = (target + n_chunks / 2) / n_chunks;
+    // long columns: several blocks per slot smooth the tail; short ones: exactly one resident wave of blocks
+    const uint32_t target = 256u * (uint32_t)per_cu * (uint32_t)env_int("JL_PILEUP_WAVES", n_tiles >= 64 ? 4 : 1);
+    uint32_t rsplit = target / n_chunks;  // never more blocks than resident slots: a second wave costs more than it balances
     const int forced = env_int("JL_PILEUP_RSPLIT", 0);
     if (forced > 0) rsplit = (uint32_t)forced;
     if (rsplit > n_tiles) rsplit = n_tiles;
     if (rsplit < 1) rsplit = 1;
     if (rsplit > 65535u) rsplit = 65535u;
     hipLaunchKernelGGL(var->fn, dim3(n_chunks, rsplit), dim3(256), 0, ctx->stream, ctx->d_msa, ctx->col_stride,
-                       ctx->n_cols, n_tiles, ctx->d_colflag, ctx->d_guess, ctx->d_counts, ctx->d_hist);
+                       ctx->n_cols, n_tiles, shift, ctx->d_colflag, ctx->d_guess, ctx->d_counts, ctx->d_hist);
 }
