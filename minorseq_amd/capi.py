@@ -32,7 +32,7 @@ EXPORTS = ("jl_abi_version", "jl_strerror", "jl_device_count", "jl_ctx_create", 
            "jl_msa_download", "jl_synth_fill", "jl_pileup_async", "jl_n_positions", "jl_pileup_fetch",
            "jl_call_async", "jl_call_fetch", "jl_variant_table_device", "jl_phase_async", "jl_phase_fetch",
            "jl_run_async", "jl_fisher_eval", "jl_time_pileup", "jl_pileup_kernel_name", "jl_comm_unique_id", "jl_comm_create", "jl_comm_destroy",
-           "jl_allgather_variants")
+           "jl_allgather_variants", "jl_allgather_variants_async")
 
 
 class ErrorModel(C.Structure):
@@ -112,6 +112,7 @@ def load_library(path=LIB_PATH):
     lib.jl_comm_destroy.argtypes = [vp]
     lib.jl_comm_destroy.restype = None
     lib.jl_allgather_variants.argtypes = [vp, vp, vp, vp, u32]
+    lib.jl_allgather_variants_async.argtypes = [vp, vp]
     if lib.jl_abi_version() != 1:
         raise ImportError("libjuliet_hip.so ABI version mismatch")
     _lib = lib

@@ -2,12 +2,84 @@
 // No compute happens on the host here and there is no CPU fallback: every entry point needs a gfx950 device.
 #include <rccl/rccl.h>
 #include <stdarg.h>
+#include <stddef.h>
 #include <stdio.h>
 #include <string.h>
 
+#include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
 #include <new>
+#include <thread>
 
 #include "jl_internal.h"
+
+// bytes of jl_pack up to and including variants[]: what one rank contributes to the compact all-gather
+#define JL_PACK_HEAD_BYTES (offsetof(jl_pack, pos_cols))
+#define JL_COMM_SLOTS 16
+
+// One communicator per (rank, device).  Collectives run on the communicator's OWN stream, ordered behind the
+// producing context by an event, so that several contexts (batches in flight) never have an RCCL launch — and
+// whatever host-side work it implies — sitting in their compute streams.
+struct jl_comm_slot {
+    jl_ctx *ctx = nullptr;
+    const void *src = nullptr;   // the context's d_pack
+    uint8_t *d_heads = nullptr;  // [world][JL_PACK_HEAD_BYTES]
+    uint8_t *h_heads = nullptr;  // pinned mirror
+    hipEvent_t produced = nullptr, done = nullptr;
+    bool pending = false;        // an exchange was requested and not yet collected (host thread only)
+    bool enqueued = false;       // the worker has issued it and recorded `done` (guarded by jl_comm::mu)
+    int status = 0;              // ncclResult_t / hip error of the enqueue, as jl_status
+};
+
+struct jl_comm {
+    ncclComm_t comm = nullptr;
+    int rank = 0, world = 1, device = 0;
+    hipStream_t stream = nullptr;
+    jl_variant *d_all = nullptr;   // [world][JL_VARIANT_CAP]   (full-stride fallback)
+    uint32_t *d_counts = nullptr;  // [world][2]
+    jl_comm_slot slots[JL_COMM_SLOTS];
+    // RCCL enqueues cost the host ~20 us each; a worker thread issues them (FIFO, so every rank keeps the
+    // same collective order) while the caller's thread goes on launching the next batch
+    std::thread worker;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<jl_comm_slot *> queue;
+    bool stop = false;
+};
+
+static void comm_worker(jl_comm *c)
+{
+    hipSetDevice(c->device);
+    for (;;) {
+        jl_comm_slot *s = nullptr;
+        {
+            std::unique_lock<std::mutex> lk(c->mu);
+            c->cv.wait(lk, [&] { return c->stop || !c->queue.empty(); });
+            if (c->queue.empty()) return;  // stop requested and nothing left
+            s = c->queue.front();
+            c->queue.pop_front();
+        }
+        int st = JL_OK;
+        if (hipStreamWaitEvent(c->stream, s->produced, 0) != hipSuccess) st = JL_ERR_DEVICE;
+        if (st == JL_OK && ncclAllGather(s->src, s->d_heads, JL_PACK_HEAD_BYTES, ncclUint8, c->comm, c->stream) != ncclSuccess) st = JL_ERR_COMM;
+        if (st == JL_OK && hipMemcpyAsync(s->h_heads, s->d_heads, JL_PACK_HEAD_BYTES * (size_t)c->world, hipMemcpyDeviceToHost, c->stream) != hipSuccess) st = JL_ERR_DEVICE;
+        if (hipEventRecord(s->done, c->stream) != hipSuccess && st == JL_OK) st = JL_ERR_DEVICE;
+        {
+            std::lock_guard<std::mutex> lk(c->mu);
+            s->status = st;
+            s->enqueued = true;
+        }
+        c->cv.notify_all();
+    }
+}
+
+static void comm_wait_enqueued(jl_comm *c, jl_comm_slot *s)
+{
+    std::unique_lock<std::mutex> lk(c->mu);
+    c->cv.wait(lk, [&] { return s->enqueued; });
+}
 
 static thread_local std::string g_create_error;
 
@@ -650,6 +722,11 @@ int jl_run_async(jl_ctx *ctx, const jl_gene *genes, uint32_t n_genes, const uint
     const double n_tests = prm->n_tests > 0.0 ? prm->n_tests : ctx->default_n_tests;
     ctx->last_min_reads = min_reads;
     jl_prepare_pileup(ctx);
+    if (ctx->exchange_slot) {  // an uncollected all-gather may still be reading the previous result block
+        jl_comm_slot *s = static_cast<jl_comm_slot *>(ctx->exchange_slot);
+        comm_wait_enqueued(static_cast<jl_comm *>(ctx->exchange_comm), s);
+        JL_HIP(ctx, hipStreamWaitEvent(ctx->stream, s->done, 0));
+    }
 
     // signature of everything a captured graph bakes in
     struct { uint64_t alloc, plan; jl_params prm; double n_tests; uint32_t drm, phasing, min_reads, rh, generic, pad; } sig;
@@ -748,12 +825,7 @@ int jl_time_pileup(jl_ctx *ctx, uint32_t reps, float *ms_avg)
 
 /* ---------------------------------------------------------------- multi-GPU */
 
-struct jl_comm {
-    ncclComm_t comm = nullptr;
-    int rank = 0, world = 1;
-    jl_variant *d_all = nullptr;   // [world][JL_VARIANT_CAP]
-    uint32_t *d_counts = nullptr;  // [world][2]
-};
+
 
 int jl_comm_unique_id(uint8_t id[128])
 {
@@ -772,6 +844,7 @@ int jl_comm_create(jl_ctx *ctx, const uint8_t id[128], int rank, int world, jl_c
     if (!c) return JL_ERR_MEMORY;
     c->rank = rank;
     c->world = world;
+    c->device = ctx->device;
     ncclUniqueId u;
     memcpy(&u, id, 128);
     ncclResult_t r = ncclCommInitRank(&c->comm, world, u, rank);
@@ -779,11 +852,13 @@ int jl_comm_create(jl_ctx *ctx, const uint8_t id[128], int rank, int world, jl_c
         delete c;
         return jl_fail(ctx, JL_ERR_COMM, "ncclCommInitRank: %s", ncclGetErrorString(r));
     }
-    if (hipMalloc(&c->d_all, sizeof(jl_variant) * JL_VARIANT_CAP * world) != hipSuccess ||
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipMalloc(&c->d_all, sizeof(jl_variant) * JL_VARIANT_CAP * world) != hipSuccess ||
         hipMalloc(&c->d_counts, 8 * world) != hipSuccess) {
         jl_comm_destroy(c);
         return jl_fail(ctx, JL_ERR_MEMORY, "comm buffers");
     }
+    c->worker = std::thread(comm_worker, c);
     *out = c;
     return JL_OK;
 }
@@ -791,19 +866,77 @@ int jl_comm_create(jl_ctx *ctx, const uint8_t id[128], int rank, int world, jl_c
 void jl_comm_destroy(jl_comm *c)
 {
     if (!c) return;
+    hipSetDevice(c->device);
+    if (c->worker.joinable()) {
+        {
+            std::lock_guard<std::mutex> lk(c->mu);
+            c->stop = true;
+        }
+        c->cv.notify_all();
+        c->worker.join();
+    }
+    if (c->stream) hipStreamSynchronize(c->stream);
+    for (jl_comm_slot &s : c->slots) {
+        if (s.ctx && s.ctx->exchange_slot == (void *)&s) s.ctx->exchange_slot = nullptr;
+        if (s.d_heads) hipFree(s.d_heads);
+        if (s.h_heads) hipHostFree(s.h_heads);
+        if (s.produced) hipEventDestroy(s.produced);
+        if (s.done) hipEventDestroy(s.done);
+    }
     if (c->comm) ncclCommDestroy(c->comm);
     if (c->d_all) hipFree(c->d_all);
     if (c->d_counts) hipFree(c->d_counts);
+    if (c->stream) hipStreamDestroy(c->stream);
     delete c;
 }
 
-int jl_allgather_variants(jl_ctx *ctx, jl_comm *c, jl_variant *all_rows, uint32_t *all_counts, uint32_t cap_rows)
+static jl_comm_slot *comm_slot(jl_ctx *ctx, jl_comm *c, bool create)
 {
-    if (!ctx || !c || !all_rows || !all_counts) return JL_ERR_ARG;
-    if (!ctx->call_done) return jl_fail(ctx, JL_ERR_STATE, "jl_allgather_variants before jl_call_async");
-    if (cap_rows == 0 || cap_rows > JL_VARIANT_CAP) return jl_fail(ctx, JL_ERR_ARG, "cap_rows must be 1..%u", JL_VARIANT_CAP);
+    for (jl_comm_slot &s : c->slots)
+        if (s.ctx == ctx) return &s;
+    if (!create) return nullptr;
+    for (jl_comm_slot &s : c->slots) {
+        if (s.ctx) continue;
+        const size_t bytes = JL_PACK_HEAD_BYTES * (size_t)c->world;
+        if (hipMalloc(&s.d_heads, bytes) != hipSuccess || hipHostMalloc(&s.h_heads, bytes, hipHostMallocDefault) != hipSuccess ||
+            hipEventCreateWithFlags(&s.produced, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&s.done, hipEventDisableTiming) != hipSuccess)
+            return nullptr;
+        s.ctx = ctx;
+        return &s;
+    }
+    return nullptr;
+}
+
+// Enqueue-only half: after jl_run_async, all-gather the head of the result block (header + up to 128 rows =
+// 6.2 KB per rank) on the communicator's stream, ordered behind the context by an event, into pinned memory.
+int jl_allgather_variants_async(jl_ctx *ctx, jl_comm *c)
+{
+    if (!ctx || !c) return JL_ERR_ARG;
+    if (!ctx->pack_valid) return jl_fail(ctx, JL_ERR_STATE, "jl_allgather_variants_async needs jl_run_async first");
+    if (ctx->device != c->device) return jl_fail(ctx, JL_ERR_ARG, "context and communicator are on different devices");
     JL_HIP(ctx, hipSetDevice(ctx->device));
-    // the one collective of the path: fixed-stride table (+ row counts) over RCCL/xGMI, on the ctx stream
+    jl_comm_slot *s = comm_slot(ctx, c, true);
+    if (!s) return jl_fail(ctx, JL_ERR_MEMORY, "no free exchange slot (at most %d contexts per communicator)", JL_COMM_SLOTS);
+    if (s->pending) return jl_fail(ctx, JL_ERR_STATE, "previous exchange of this context not collected yet");
+    JL_HIP(ctx, hipEventRecord(s->produced, ctx->stream));
+    s->src = ctx->d_pack;
+    {
+        std::lock_guard<std::mutex> lk(c->mu);
+        s->enqueued = false;
+        s->status = JL_OK;
+        c->queue.push_back(s);
+    }
+    c->cv.notify_all();
+    s->pending = true;
+    ctx->exchange_slot = s;
+    ctx->exchange_comm = c;
+    return JL_OK;
+}
+
+static int allgather_full(jl_ctx *ctx, jl_comm *c, jl_variant *all_rows, uint32_t *all_counts, uint32_t cap_rows)
+{
+    // fixed-stride table (+ row counts) over RCCL/xGMI; blocking, so it can simply use the ctx stream
     ncclResult_t r = ncclGroupStart();
     if (r == ncclSuccess) r = ncclAllGather(ctx->d_variants, c->d_all, sizeof(jl_variant) * (size_t)cap_rows, ncclUint8, c->comm, ctx->stream);
     if (r == ncclSuccess) r = ncclAllGather(ctx->d_nvar, c->d_counts, 8, ncclUint8, c->comm, ctx->stream);
@@ -820,6 +953,52 @@ int jl_allgather_variants(jl_ctx *ctx, jl_comm *c, jl_variant *all_rows, uint32_
     }
     if (rc) return jl_fail(ctx, rc, "a rank produced more than %u variant rows", cap_rows);
     return JL_OK;
+}
+
+// The one collective of the path.  After jl_run_async the exchange is the 6.2 KB head of each rank's result
+// block (enqueued here unless jl_allgather_variants_async already did); tables with more than 128 rows on any
+// rank, or stage-by-stage callers, use the full fixed stride.  The decision is made from the gathered headers,
+// so every rank takes the same branch.
+int jl_allgather_variants(jl_ctx *ctx, jl_comm *c, jl_variant *all_rows, uint32_t *all_counts, uint32_t cap_rows)
+{
+    if (!ctx || !c || !all_rows || !all_counts) return JL_ERR_ARG;
+    if (!ctx->call_done) return jl_fail(ctx, JL_ERR_STATE, "jl_allgather_variants before jl_call_async");
+    if (cap_rows == 0 || cap_rows > JL_VARIANT_CAP) return jl_fail(ctx, JL_ERR_ARG, "cap_rows must be 1..%u", JL_VARIANT_CAP);
+    JL_HIP(ctx, hipSetDevice(ctx->device));
+    if (ctx->pack_valid) {
+        jl_comm_slot *s = comm_slot(ctx, c, false);
+        if (!s || !s->pending) {
+            int rc = jl_allgather_variants_async(ctx, c);
+            if (rc) return rc;
+            s = comm_slot(ctx, c, false);
+        }
+        s->pending = false;
+        comm_wait_enqueued(c, s);
+        ctx->exchange_slot = nullptr;
+        if (s->status != JL_OK) return jl_fail(ctx, s->status, "all-gather enqueue failed on the communicator thread");
+        {   // spin on the event: a blocking hipEventSynchronize costs ~15 us of wake-up latency per step
+            hipError_t q;
+            while ((q = hipEventQuery(s->done)) == hipErrorNotReady) {}
+            if (q != hipSuccess) return jl_fail(ctx, JL_ERR_DEVICE, "all-gather: %s", hipGetErrorString(q));
+        }
+        bool compact = true;
+        for (int k = 0; k < c->world; ++k) {
+            const jl_pack *pk = reinterpret_cast<const jl_pack *>(s->h_heads + (size_t)k * JL_PACK_HEAD_BYTES);
+            if (pk->magic != JL_PACK_MAGIC || !pk->fits_call) compact = false;
+        }
+        if (compact) {
+            int rc = JL_OK;
+            for (int k = 0; k < c->world; ++k) {
+                const jl_pack *pk = reinterpret_cast<const jl_pack *>(s->h_heads + (size_t)k * JL_PACK_HEAD_BYTES);
+                all_counts[k] = pk->nvar_total;
+                if (pk->nvar_total > cap_rows) { rc = JL_ERR_OVERFLOW; continue; }
+                memcpy(all_rows + (size_t)k * cap_rows, pk->variants, (size_t)pk->nvar_total * sizeof(jl_variant));
+            }
+            if (rc) return jl_fail(ctx, rc, "a rank produced more than %u variant rows", cap_rows);
+            return JL_OK;
+        }
+    }
+    return allgather_full(ctx, c, all_rows, all_counts, cap_rows);
 }
 
 }  // extern "C"

@@ -53,8 +53,12 @@ struct jl_pack {
     uint32_t cooc[JL_PACK_COOC_N * JL_PACK_COOC_N];  // [nv][nv]
 };
 
+struct jl_comm;
+
 struct jl_ctx {
     int device = -1;
+    void *exchange_slot = nullptr;  // jl_comm_slot of an uncollected all-gather that reads d_pack
+    void *exchange_comm = nullptr;
     hipStream_t stream = nullptr;
     bool own_stream = false;
     std::string err;
