@@ -132,6 +132,16 @@ int jl_msa_adopt(jl_ctx *ctx, void *d_colpacked, uint64_t n_reads, uint32_t n_co
                  uint32_t win_begin);
 /* Device-side transpose of a host by-row matrix uint8[n_reads][n_cols] (codes 0..6) into the resident layout. */
 int jl_msa_pack_rows(jl_ctx *ctx, const uint8_t *rows, uint64_t n_reads, uint32_t n_cols, uint32_t win_begin);
+/*
+ * Aligned records -> resident matrix entirely on the device: cigar expansion (= X I D S H N; M is rejected,
+ * J:53), insertions dropped and deletions '-' (J:26-27), optional QV masking to N (J:256-259), transpose.
+ * pos[r]: 0-based leftmost reference position; cigar words are BAM's (len << 4 | op), read r owns
+ * cigar[cig_off[r] .. cig_off[r+1]); seq4 holds BAM's 4-bit bases, read r starting at byte seq_off[r];
+ * qual (optional, with qual_off) one byte per base, 0xFF = absent; bases with qual < min_qv become N.
+ */
+int jl_msa_ingest_records(jl_ctx *ctx, uint64_t n_reads, uint32_t n_cols, uint32_t win_begin, const int32_t *pos,
+                          const uint32_t *cigar, const uint64_t *cig_off, const uint8_t *seq4, const uint64_t *seq_off,
+                          const uint8_t *qual, const uint64_t *qual_off, uint32_t min_qv);
 /* Copy the resident matrix back to the host (tests). */
 int jl_msa_download(jl_ctx *ctx, uint8_t *colpacked, uint64_t bytes);
 /* Fill the resident matrix with synthetic reads, on the device. `ref` = n_cols base codes (host). */

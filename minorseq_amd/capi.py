@@ -29,7 +29,7 @@ SUMMARY = np.dtype([(n, "<u4") for n in SUMMARY_FIELDS])
 # every symbol include/juliet_hip.h declares (checked by tests/test_capi_exports.py)
 EXPORTS = ("jl_abi_version", "jl_strerror", "jl_device_count", "jl_ctx_create", "jl_ctx_destroy", "jl_last_error",
            "jl_sync", "jl_col_stride", "jl_msa_upload", "jl_msa_alloc", "jl_msa_adopt", "jl_msa_pack_rows",
-           "jl_msa_download", "jl_synth_fill", "jl_pileup_async", "jl_n_positions", "jl_pileup_fetch",
+           "jl_msa_ingest_records", "jl_msa_download", "jl_synth_fill", "jl_pileup_async", "jl_n_positions", "jl_pileup_fetch",
            "jl_call_async", "jl_call_fetch", "jl_variant_table_device", "jl_phase_async", "jl_phase_fetch",
            "jl_run_async", "jl_fisher_eval", "jl_time_pileup", "jl_pileup_kernel_name", "jl_comm_unique_id", "jl_comm_create", "jl_comm_destroy",
            "jl_allgather_variants", "jl_allgather_variants_async")
@@ -93,6 +93,7 @@ def load_library(path=LIB_PATH):
     lib.jl_msa_alloc.argtypes = [vp, u64, u32, u32]
     lib.jl_msa_adopt.argtypes = [vp, vp, u64, u32, u64, u32]
     lib.jl_msa_pack_rows.argtypes = [vp, vp, u64, u32, u32]
+    lib.jl_msa_ingest_records.argtypes = [vp, u64, u32, u32] + [vp] * 7 + [u32]
     lib.jl_msa_download.argtypes = [vp, vp, u64]
     lib.jl_synth_fill.argtypes = [vp, C.POINTER(SynthParams), vp]
     lib.jl_pileup_async.argtypes = [vp, vp, u32, vp, u32]
@@ -170,6 +171,21 @@ class Juliet:
         n, l = rows.shape
         self._chk(self.lib.jl_msa_pack_rows(self.h, _p(rows), n, l, win_begin))
         self._shape(n, l, self.lib.jl_col_stride(n))
+
+    def ingest_records(self, n_cols, win_begin, pos, cigar, cig_off, seq4, seq_off, qual=None, qual_off=None, min_qv=0):
+        """Aligned records (BAM-decoded arrays) -> resident matrix, cigar expansion on the device."""
+        pos = np.ascontiguousarray(pos, dtype=np.int32)
+        cigar = np.ascontiguousarray(cigar, dtype=np.uint32)
+        cig_off = np.ascontiguousarray(cig_off, dtype=np.uint64)
+        seq4 = np.ascontiguousarray(seq4, dtype=np.uint8)
+        seq_off = np.ascontiguousarray(seq_off, dtype=np.uint64)
+        if qual is not None:
+            qual = np.ascontiguousarray(qual, dtype=np.uint8)
+            qual_off = np.ascontiguousarray(qual_off, dtype=np.uint64)
+        n = len(pos)
+        self._chk(self.lib.jl_msa_ingest_records(self.h, n, n_cols, win_begin, _p(pos), _p(cigar), _p(cig_off), _p(seq4),
+                                                 _p(seq_off), _p(qual), _p(qual_off), min_qv))
+        self._shape(n, n_cols, self.lib.jl_col_stride(n))
 
     def alloc(self, n_reads, n_cols, win_begin=0):
         self._chk(self.lib.jl_msa_alloc(self.h, n_reads, n_cols, win_begin))

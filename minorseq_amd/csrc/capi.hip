@@ -272,7 +272,16 @@ int jl_msa_upload(jl_ctx *ctx, const uint8_t *colpacked, uint64_t n_reads, uint3
     rc = reserve_msa(ctx, (size_t)col_stride * n_cols);
     if (rc) return rc;
     JL_HIP(ctx, hipMemcpyAsync(ctx->d_msa, colpacked, (size_t)col_stride * n_cols, hipMemcpyHostToDevice, ctx->stream));
+    // symbol codes are 0..6 (SPEC §1); anything else would corrupt the linear solve of the pileup counters
+    uint32_t bad[2] = {0, 0};
+    JL_HIP(ctx, hipMemsetAsync(ctx->d_nvar + 1, 0, 4, ctx->stream));
+    jl_launch_validate(ctx, ctx->d_nvar + 1);
+    JL_HIP(ctx, hipMemcpyAsync(bad, ctx->d_nvar + 1, 4, hipMemcpyDeviceToHost, ctx->stream));
     JL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (bad[0]) {
+        free_msa(ctx);
+        return jl_fail(ctx, JL_ERR_ARG, "matrix holds a symbol code outside 0..6");
+    }
     return JL_OK;
 }
 
@@ -302,6 +311,54 @@ int jl_msa_pack_rows(jl_ctx *ctx, const uint8_t *rows, uint64_t n_reads, uint32_
     }
     hipFree(d_rows);
     if (e != hipSuccess) return jl_fail(ctx, JL_ERR_DEVICE, "pack_rows: %s", hipGetErrorString(e));
+    return JL_OK;
+}
+
+// Aligned records straight to the resident layout: cigar expansion, QV masking and the transpose all run
+// on the device.  Arrays are what a BAM decoder holds: per read its leftmost position, its
+// cigar words (len << 4 | op), its 4-bit packed bases exactly as stored in BAM, optionally its qualities.
+int jl_msa_ingest_records(jl_ctx *ctx, uint64_t n_reads, uint32_t n_cols, uint32_t win_begin, const int32_t *pos,
+                          const uint32_t *cigar, const uint64_t *cig_off, const uint8_t *seq4, const uint64_t *seq_off,
+                          const uint8_t *qual, const uint64_t *qual_off, uint32_t min_qv)
+{
+    if (!ctx || !pos || !cigar || !cig_off || !seq4 || !seq_off || (qual && !qual_off)) return JL_ERR_ARG;
+    for (uint64_t k = cig_off[0]; k < cig_off[n_reads]; ++k)
+        if ((cigar[k] & 15u) == 0u)
+            return jl_fail(ctx, JL_ERR_ARG, "cigar M is forbidden in PacBio-compliant BAM (doc/JULIET.md:53)");
+    int rc = jl_msa_alloc(ctx, n_reads, n_cols, win_begin);
+    if (rc) return rc;
+    const size_t n_cig = (size_t)cig_off[n_reads], n_seq = (size_t)seq_off[n_reads], n_q = qual ? (size_t)qual_off[n_reads] : 0;
+    const size_t off_bytes = (size_t)(n_reads + 1) * 8;
+    uint8_t *d_rows = nullptr, *d_seq = nullptr, *d_qual = nullptr;
+    uint32_t *d_cig = nullptr;
+    uint64_t *d_co = nullptr, *d_so = nullptr, *d_qo = nullptr;
+    int32_t *d_pos = nullptr;
+    hipStream_t st = ctx->stream;
+    hipError_t e = hipMalloc(&d_rows, (size_t)n_reads * n_cols);
+    if (e == hipSuccess) e = hipMalloc(&d_seq, n_seq ? n_seq : 1);
+    if (e == hipSuccess) e = hipMalloc(&d_cig, (n_cig ? n_cig : 1) * 4);
+    if (e == hipSuccess) e = hipMalloc(&d_co, off_bytes);
+    if (e == hipSuccess) e = hipMalloc(&d_so, off_bytes);
+    if (e == hipSuccess) e = hipMalloc(&d_pos, (size_t)n_reads * 4);
+    if (e == hipSuccess && qual) e = hipMalloc(&d_qual, n_q ? n_q : 1);
+    if (e == hipSuccess && qual) e = hipMalloc(&d_qo, off_bytes);
+    if (e == hipSuccess) e = hipMemsetAsync(d_rows, JL_SYM_NONE, (size_t)n_reads * n_cols, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_seq, seq4, n_seq, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_cig, cigar, n_cig * 4, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_co, cig_off, off_bytes, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_so, seq_off, off_bytes, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_pos, pos, (size_t)n_reads * 4, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess && qual) e = hipMemcpyAsync(d_qual, qual, n_q, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess && qual) e = hipMemcpyAsync(d_qo, qual_off, off_bytes, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) {
+        jl_launch_ingest(ctx, d_pos, d_cig, d_co, d_seq, d_so, d_qual, d_qo, min_qv, d_rows);
+        jl_launch_pack_rows(ctx, d_rows);
+        e = hipStreamSynchronize(st);
+    }
+    void *tmp[] = {d_rows, d_seq, d_cig, d_co, d_so, d_pos, d_qual, d_qo};
+    for (void *p : tmp)
+        if (p) hipFree(p);
+    if (e != hipSuccess) return jl_fail(ctx, e == hipErrorOutOfMemory ? JL_ERR_MEMORY : JL_ERR_DEVICE, "ingest: %s", hipGetErrorString(e));
     return JL_OK;
 }
 

@@ -1,6 +1,8 @@
 // kernels_util.hip — device-side producers of the resident column-packed matrix:
 //   synth_kernel      synthetic aligned CCS reads (jl_synth.h), one dword (8 reads) of one column per step
 //   pack_rows_kernel  by-row uint8 codes -> column-packed nibbles (the first step of SURVEY §8 f1)
+#include <algorithm>
+
 #include "jl_internal.h"
 
 namespace {
@@ -49,7 +51,125 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(const uint8_t *__restric
     *reinterpret_cast<uint32_t *>(msa + (uint64_t)c * col_stride + t * 4u) = w;
 }
 
+
+// ---------------------------------------------------------------------------------------- record ingest
+// Aligned records -> by-row symbols, one wave per read: doc/JULIET.md:26-27 (insertions dropped, deletions '-'),
+// :53 (PacBio cigars = X I D S H N; M rejected on the host), :256-259 (filtered base = N).
+// Lanes walk REFERENCE positions; the operation covering a position is found by binary search in the read's
+// scanned cigar (reference and query offsets per op, kept in LDS).
+constexpr int kIngestMaxOps = 1024;  // ops staged per pass; longer cigars are processed in several passes
+
+__global__ __launch_bounds__(256) void ingest_kernel(uint64_t n_reads, uint32_t n_cols, uint32_t win_begin,
+                                                      const int32_t *__restrict__ pos,
+                                                      const uint32_t *__restrict__ cigar,
+                                                      const uint64_t *__restrict__ cig_off,
+                                                      const uint8_t *__restrict__ seq4,
+                                                      const uint64_t *__restrict__ seq_off,
+                                                      const uint8_t *__restrict__ qual,
+                                                      const uint64_t *__restrict__ qual_off, uint32_t min_qv,
+                                                      uint8_t *__restrict__ rows)
+{
+    __shared__ uint32_t s_rend[4][kIngestMaxOps];  // reference offset AFTER op k (relative to the pass start)
+    __shared__ uint32_t s_qbeg[4][kIngestMaxOps];  // query offset BEFORE op k
+    __shared__ uint8_t s_op[4][kIngestMaxOps];
+    const uint32_t wid = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint64_t r = (uint64_t)blockIdx.x * 4u + wid;
+    if (r >= n_reads) return;
+    const uint64_t c0 = cig_off[r], c1 = cig_off[r + 1];
+    const uint8_t *sq = seq4 + seq_off[r];
+    const uint8_t *ql = qual ? qual + qual_off[r] : nullptr;
+    uint8_t *row = rows + r * (uint64_t)n_cols;
+    int64_t ref_cur = pos[r];
+    uint32_t q_cur = 0;
+    for (uint64_t base = c0; base < c1; base += kIngestMaxOps) {
+        const uint32_t nops = (uint32_t)min((uint64_t)kIngestMaxOps, c1 - base);
+        // scan the ops of this pass (64 at a time) into LDS
+        uint32_t racc = 0, qacc = q_cur;
+        for (uint32_t k0 = 0; k0 < nops; k0 += 64u) {
+            const uint32_t k = k0 + lane;
+            uint32_t op = 15u, len = 0;
+            if (k < nops) { const uint32_t c = cigar[base + k]; op = c & 15u; len = c >> 4; }
+            const uint32_t rl = (op == 2u || op == 3u || op == 7u || op == 8u) ? len : 0u;   // D N = X consume reference
+            const uint32_t qn = (op == 1u || op == 4u || op == 7u || op == 8u) ? len : 0u;   // I S = X consume query
+            uint32_t ri = rl, qi = qn;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t a = __shfl_up(ri, o, 64), b = __shfl_up(qi, o, 64);
+                if ((int)lane >= o) { ri += a; qi += b; }
+            }
+            if (k < nops) {
+                s_rend[wid][k] = racc + ri;
+                s_qbeg[wid][k] = qacc + qi - qn;
+                s_op[wid][k] = (uint8_t)op;
+            }
+            racc += __shfl(ri, 63, 64);
+            qacc += __shfl(qi, 63, 64);
+        }
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t rtot = racc;
+        // reference positions of this pass, 64 at a time
+        for (uint32_t p0 = 0; p0 < rtot; p0 += 64u) {
+            const uint32_t p = p0 + lane;
+            const int64_t col = ref_cur + p - (int64_t)win_begin;
+            if (p < rtot && col >= 0 && col < (int64_t)n_cols) {
+                uint32_t lo = 0, hi = nops - 1u;  // first op with rend > p
+                while (lo < hi) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (s_rend[wid][mid] > p) hi = mid; else lo = mid + 1u;
+                }
+                const uint32_t op = s_op[wid][lo];
+                const uint32_t rbeg = lo ? s_rend[wid][lo - 1u] : 0u;
+                uint8_t sym;
+                if (op == 2u) sym = JL_SYM_GAP;
+                else if (op == 3u) sym = JL_SYM_NONE;
+                else {
+                    const uint32_t q = s_qbeg[wid][lo] + (p - rbeg);
+                    const uint8_t b16 = (q & 1u) ? (sq[q >> 1] & 15u) : (sq[q >> 1] >> 4);
+                    // BAM nibble codes: A=1 C=2 G=4 T=8; anything else is an ambiguous base
+                    sym = b16 == 1u ? 0 : b16 == 2u ? 1 : b16 == 4u ? 2 : b16 == 8u ? 3 : (uint8_t)JL_SYM_MASK;
+                    if (ql && min_qv) { const uint8_t qv = ql[q]; if (qv != 0xFFu && qv < min_qv) sym = JL_SYM_MASK; }
+                }
+                row[col] = sym;
+            }
+        }
+        ref_cur += rtot;
+        q_cur = qacc;
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// any nibble outside 0..6 (code 7 or bit 3 set) is rejected at upload (SPEC §1)
+__global__ __launch_bounds__(256) void validate_kernel(const uint8_t *__restrict__ msa, uint64_t n_bytes,
+                                                        uint32_t *__restrict__ bad)
+{
+    uint32_t any = 0;
+    for (uint64_t i = ((uint64_t)blockIdx.x * 256u + threadIdx.x) * 16u; i < n_bytes; i += (uint64_t)gridDim.x * 256u * 16u) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(msa + i);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) any |= (w[q] & 0x88888888u) | (w[q] & (w[q] >> 1) & (w[q] >> 2) & 0x11111111u);
+    }
+    if (any) atomicOr(bad, 1u);
+}
+
 }  // namespace
+
+void jl_launch_validate(jl_ctx *ctx, uint32_t *d_flag)
+{
+    const uint64_t n_bytes = (uint64_t)ctx->col_stride * ctx->n_cols;  // multiple of 128
+    uint32_t blocks = (uint32_t)std::min<uint64_t>(2048, (n_bytes / 16 + 255) / 256);
+    if (blocks == 0) blocks = 1;
+    hipLaunchKernelGGL(validate_kernel, dim3(blocks), dim3(256), 0, ctx->stream, ctx->d_msa, n_bytes, d_flag);
+}
+
+void jl_launch_ingest(jl_ctx *ctx, const int32_t *d_pos, const uint32_t *d_cigar, const uint64_t *d_cig_off,
+                      const uint8_t *d_seq4, const uint64_t *d_seq_off, const uint8_t *d_qual,
+                      const uint64_t *d_qual_off, uint32_t min_qv, uint8_t *d_rows)
+{
+    const uint32_t blocks = (uint32_t)((ctx->n_reads + 3u) / 4u);
+    hipLaunchKernelGGL(ingest_kernel, dim3(blocks), dim3(256), 0, ctx->stream, ctx->n_reads, ctx->n_cols,
+                       ctx->win_begin, d_pos, d_cigar, d_cig_off, d_seq4, d_seq_off, d_qual, d_qual_off, min_qv, d_rows);
+}
 
 void jl_launch_synth(jl_ctx *ctx, const jl_synth_plan *plan, const uint8_t *d_ref)
 {

@@ -25,6 +25,7 @@ struct BamRecord {
     std::string name;
     std::vector<uint32_t> cigar;  // len << 4 | op
     std::vector<uint8_t> seq;     // base codes 0..3 = ACGT, 4 = N/other
+    std::vector<uint8_t> seq4;    // the same bases as stored in BAM (two 4-bit codes per byte, high nibble first)
     std::vector<uint8_t> qual;    // phred, 0xFF when absent
     float rq = -1.f;              // predicted accuracy tag (doc/JULIET.md:56), -1 when absent
 };
@@ -79,6 +80,7 @@ public:
             const uint8_t b = p[o + i / 2];
             r.seq[i] = nt16[(i & 1) ? (b & 15) : (b >> 4)];
         }
+        r.seq4.assign(p + o, p + o + (l_seq + 1) / 2);
         o += (l_seq + 1) / 2;
         r.qual.assign(p + o, p + o + l_seq);
         o += l_seq;

@@ -237,16 +237,22 @@ int main(int argc, char **argv)
         const int64_t we = std::max<int64_t>(wb + 1, std::min<int64_t>(ref_len, ge + 5));
         const uint32_t win_begin = (uint32_t)wb, n_cols = (uint32_t)(we - wb);
 
-        std::vector<uint8_t> rows;
         std::vector<std::string> names;
-        const uint64_t n_reads = build_rows(opt.bam, io, ext.ref_id, win_begin, n_cols, ext.n_reads, rows, &names);
+        uint64_t n_reads = 0;
         if (!opt.dump_msa.empty()) {  // host-side ingest check, no GPU involved
+            std::vector<uint8_t> rows;
+            n_reads = build_rows(opt.bam, io, ext.ref_id, win_begin, n_cols, ext.n_reads, rows, nullptr);
             std::ofstream f(opt.dump_msa, std::ios::binary);
             const uint64_t hdr[3] = {n_reads, n_cols, win_begin};
             f.write((const char *)hdr, sizeof hdr);
             f.write((const char *)rows.data(), (std::streamsize)((size_t)n_reads * n_cols));
             if (opt.outputs.empty()) return 0;
         }
+        // records as decoded from BAM; cigar expansion, QV masking and the transpose run on the device
+        RecordArrays rec;
+        collect_records(opt.bam, io, ext.ref_id, opt.min_qv > 0, rec);
+        n_reads = rec.pos.size();
+        names.swap(rec.names);
 
         // ---------------------------------------------------------------- parameters
         std::string chem = opt.chemistry;
@@ -277,8 +283,11 @@ int main(int argc, char **argv)
         // ---------------------------------------------------------------- device
         jl_ctx *ctx = nullptr;
         if (jl_ctx_create(opt.device, nullptr, &ctx) != JL_OK) die_jl(nullptr, "no usable GPU (this tool has no CPU fallback)");
-        if (jl_msa_pack_rows(ctx, rows.data(), n_reads, n_cols, win_begin) != JL_OK) die_jl(ctx, "upload");
-        std::vector<uint8_t>().swap(rows);
+        if (jl_msa_ingest_records(ctx, n_reads, n_cols, win_begin, rec.pos.data(), rec.cigar.data(), rec.cig_off.data(),
+                                  rec.seq4.data(), rec.seq_off.data(), opt.min_qv ? rec.qual.data() : nullptr,
+                                  opt.min_qv ? rec.qual_off.data() : nullptr, opt.min_qv) != JL_OK)
+            die_jl(ctx, "ingest");
+        rec = RecordArrays();
 
         // --drm-only needs the position list, which the plan of a first pileup provides
         std::vector<uint64_t> drm_masks;

@@ -99,4 +99,36 @@ inline uint64_t build_rows(const std::string &bam, const IngestOptions &opt, int
     return n;
 }
 
+// Raw record arrays for jl_msa_ingest_records (cigar expansion happens on the device).
+struct RecordArrays {
+    std::vector<int32_t> pos;
+    std::vector<uint32_t> cigar;
+    std::vector<uint64_t> cig_off{0}, seq_off{0}, qual_off{0};
+    std::vector<uint8_t> seq4, qual;
+    std::vector<std::string> names;
+};
+
+inline void collect_records(const std::string &bam, const IngestOptions &opt, int ref_id, bool want_qual, RecordArrays &out)
+{
+    BamReader in(bam);
+    BamRecord r;
+    while (in.next(r)) {
+        if (!keep_record(r) || r.ref_id != ref_id) continue;
+        if (opt.min_rq > 0.0 && r.rq >= 0.f && r.rq < opt.min_rq) continue;
+        for (uint32_t c : r.cigar)
+            if ((c & 15) == CIG_M)
+                throw std::runtime_error("read " + r.name + ": cigar M is forbidden in PacBio-compliant BAM (doc/JULIET.md:53)");
+        out.pos.push_back(r.pos);
+        out.cigar.insert(out.cigar.end(), r.cigar.begin(), r.cigar.end());
+        out.cig_off.push_back(out.cigar.size());
+        out.seq4.insert(out.seq4.end(), r.seq4.begin(), r.seq4.end());
+        out.seq_off.push_back(out.seq4.size());
+        if (want_qual) {
+            out.qual.insert(out.qual.end(), r.qual.begin(), r.qual.end());
+            out.qual_off.push_back(out.qual.size());
+        }
+        out.names.push_back(r.name);
+    }
+}
+
 }  // namespace jlhost

@@ -150,6 +150,15 @@ def test_pileup_empty_and_degenerate(jl, oracle):
     assert len(got["pos_col"]) == 0 and got["col_counts"][0, 0] == 10
     with pytest.raises(capi.JulietError):
         jl.upload_columns(np.zeros((0, 128), dtype=np.uint8), 10)
+    # symbol codes outside 0..6 are rejected at upload (SPEC §1)
+    for bad in (0x07, 0x70, 0x08, 0xF0):
+        packed = msa.pack_columns(np.zeros((300, 4), dtype=np.uint8))
+        packed[2, 77] = bad
+        with pytest.raises(capi.JulietError) as e:
+            jl.upload_columns(packed, 300)
+        assert e.value.status == -1 and "0..6" in str(e.value)
+    with pytest.raises(ValueError):
+        msa.pack_columns(np.full((3, 3), 7, dtype=np.uint8))
 
 
 def test_seed_never_changes_results(jl, oracle):
@@ -437,3 +446,102 @@ def test_allgather_variants_single_rank_communicator(jl, oracle):
         assert_variants_equal(out["variants"], exp)
     finally:
         jl.lib.jl_comm_destroy(comm)
+
+
+# --------------------------------------------------------------------------------------------- device ingest
+def rows_to_records(rows, ref, rng, with_noise_ops=True):
+    """Re-express by-row symbols as BAM-style records (pos, cigar words, 4-bit packed bases, qualities):
+    '='/'X' for bases, 'D' for '-', 'N' bases for filtered ones, plus insertions / soft clips / hard clips that
+    an ingest must ignore (doc/JULIET.md:26-27, 53)."""
+    OPS = {"M": 0, "I": 1, "D": 2, "N": 3, "S": 4, "H": 5, "P": 6, "=": 7, "X": 8}
+    nt16 = {0: 1, 1: 2, 2: 4, 3: 8, 4: 15}
+    pos, cigar, cig_off, seq4, seq_off, qual, qual_off = [], [], [0], [], [0], [], [0]
+    for row in rows:
+        cov = np.nonzero(row != 6)[0]
+        ops, bases, quals = [], [], []
+        if len(cov) == 0:
+            pos.append(0)
+            ops.append((OPS["S"], 1)); bases.append(0); quals.append(30)
+        else:
+            a, b = int(cov[0]), int(cov[-1]) + 1
+            pos.append(a)
+            if with_noise_ops and rng.random() < 0.5:
+                ops.append((OPS["H"], 3))
+            if with_noise_ops and rng.random() < 0.5:
+                k = int(rng.integers(1, 4)); ops.append((OPS["S"], k)); bases += [int(x) for x in rng.integers(0, 4, k)]; quals += [20] * k
+            for c in range(a, b):
+                s = int(row[c])
+                if s == 4:
+                    ops.append((OPS["D"], 1))
+                elif s == 6:
+                    ops.append((OPS["N"], 1))
+                else:
+                    base = 4 if s == 5 else s
+                    ops.append((OPS["="] if s == ref[c] else OPS["X"], 1)); bases.append(base); quals.append(93)
+                    if with_noise_ops and rng.random() < 0.01:
+                        k = int(rng.integers(1, 3)); ops.append((OPS["I"], k)); bases += [int(x) for x in rng.integers(0, 4, k)]; quals += [10] * k
+            if with_noise_ops and rng.random() < 0.3:
+                ops.append((OPS["S"], 2)); bases += [1, 2]; quals += [5, 5]
+        merged = []
+        for op, ln in ops:
+            if merged and merged[-1][0] == op:
+                merged[-1][1] += ln
+            else:
+                merged.append([op, ln])
+        cigar += [(ln << 4) | op for op, ln in merged]
+        cig_off.append(len(cigar))
+        packed = []
+        for i in range(0, len(bases), 2):
+            hi = nt16[bases[i]]
+            lo = nt16[bases[i + 1]] if i + 1 < len(bases) else 0
+            packed.append((hi << 4) | lo)
+        seq4 += packed
+        seq_off.append(len(seq4))
+        qual += quals
+        qual_off.append(len(qual))
+    return (np.array(pos, dtype=np.int32), np.array(cigar, dtype=np.uint32), np.array(cig_off, dtype=np.uint64),
+            np.array(seq4, dtype=np.uint8), np.array(seq_off, dtype=np.uint64), np.array(qual, dtype=np.uint8),
+            np.array(qual_off, dtype=np.uint64))
+
+
+@pytest.mark.parametrize("n,l,partial,win", [(300, 120, 0.3, (0, 120)), (1000, 400, 0.2, (37, 351)), (70, 3000, 0.1, (0, 3000))])
+def test_device_ingest_matches_rows(jl, n, l, partial, win):
+    rng = np.random.default_rng(n + l)
+    sp = synth.SynthParams(seed=n + l, partial_rate=partial, del_rate=0.02, mask_rate=0.03, sub_rate=0.01)
+    ref = synth.reference(sp.seed, l)
+    rows = synth.rows(sp, l, 0, n, ref)
+    rows[5, 40:60] = 6            # a reference skip inside a read (cigar N): stays uncovered
+    rows[7] = 6                   # a read with no aligned base at all
+    pos, cigar, cig_off, seq4, seq_off, qual, qual_off = rows_to_records(rows, ref, rng)
+    b, e = win
+    jl.ingest_records(e - b, b, pos, cigar, cig_off, seq4, seq_off)
+    got = msa.unpack_columns(jl.download_columns(), n)
+    assert (got == rows[:, b:e]).all()
+    # QV masking: soft-clip / insertion qualities never matter; masking the '=' / 'X' bases turns them all into N
+    jl.ingest_records(e - b, b, pos, cigar, cig_off, seq4, seq_off, qual, qual_off, min_qv=94)
+    got = msa.unpack_columns(jl.download_columns(), n)
+    exp = rows[:, b:e].copy()
+    exp[exp < 4] = 5
+    assert (got == exp).all()
+    jl.ingest_records(e - b, b, pos, cigar, cig_off, seq4, seq_off, qual, qual_off, min_qv=50)
+    assert (msa.unpack_columns(jl.download_columns(), n) == rows[:, b:e]).all()
+    # cigar M is rejected (doc/JULIET.md:53)
+    bad = cigar.copy()
+    bad[0] = (bad[0] >> 4 << 4) | 0
+    with pytest.raises(capi.JulietError) as err:
+        jl.ingest_records(e - b, b, pos, bad, cig_off, seq4, seq_off)
+    assert "cigar M" in str(err.value)
+
+
+def test_device_ingest_long_cigar(jl):
+    """A cigar longer than the kernel's staging pass (1024 ops) is processed in several passes."""
+    l = 5000
+    rng = np.random.default_rng(1)
+    ref = synth.reference(3, l)
+    rows = np.tile(ref, (3, 1)).astype(np.uint8)
+    rows[:, ::2] = (rows[:, ::2] + 1) % 4       # alternate match / mismatch: one op per base => 5000 ops
+    rows[1, 1000:1100] = 4
+    pos, cigar, cig_off, seq4, seq_off, _, _ = rows_to_records(rows, ref, rng, with_noise_ops=False)
+    assert cig_off[1] - cig_off[0] > 4000
+    jl.ingest_records(l, 0, pos, cigar, cig_off, seq4, seq_off)
+    assert (msa.unpack_columns(jl.download_columns(), 3) == rows).all()
