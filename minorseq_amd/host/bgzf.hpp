@@ -3,32 +3,132 @@
 #pragma once
 #include <zlib.h>
 
+#include <algorithm>
+#include <atomic>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace jlhost {
 
-// Sequential reader: BGZF is a series of gzip members, so plain inflate with member restart reads it.
+// Reader.  BGZF is a series of independent gzip members of at most 64 KiB, each announcing its compressed
+// size in a 'BC' extra field, so batches of blocks are inflated in parallel; files whose first
+// member lacks the field are read as a plain concatenated-gzip stream.
 class BgzfReader {
 public:
-    explicit BgzfReader(const std::string &path) : f_(fopen(path.c_str(), "rb"))
+    explicit BgzfReader(const std::string &path, unsigned threads = 0) : f_(fopen(path.c_str(), "rb"))
     {
         if (!f_) throw std::runtime_error("cannot open " + path);
-        memset(&z_, 0, sizeof z_);
-        if (inflateInit2(&z_, 15 + 32) != Z_OK) throw std::runtime_error("inflateInit2 failed");
-        in_.resize(1 << 16);
+        unsigned hw = std::thread::hardware_concurrency();
+        n_threads_ = threads ? threads : std::min(8u, hw ? hw : 1u);
+        uint8_t hdr[18];
+        const size_t got = fread(hdr, 1, sizeof hdr, f_);
+        block_mode_ = got == sizeof hdr && is_bgzf_header(hdr);
+        fseek(f_, 0, SEEK_SET);
+        if (!block_mode_) {
+            memset(&z_, 0, sizeof z_);
+            if (inflateInit2(&z_, 15 + 32) != Z_OK) throw std::runtime_error("inflateInit2 failed");
+            in_.resize(1 << 16);
+        }
     }
     ~BgzfReader()
     {
-        inflateEnd(&z_);
+        if (!block_mode_) inflateEnd(&z_);
         if (f_) fclose(f_);
     }
     // read exactly n bytes; returns false on clean EOF at a record boundary (n bytes not started)
-    bool read(void *dst, size_t n)
+    bool read(void *dst, size_t n) { return block_mode_ ? read_blocks(dst, n) : read_stream(dst, n); }
+
+private:
+    static bool is_bgzf_header(const uint8_t *h)
+    {
+        return h[0] == 0x1f && h[1] == 0x8b && h[2] == 8 && (h[3] & 4) && h[10] == 6 && h[11] == 0 && h[12] == 'B' && h[13] == 'C';
+    }
+
+    // ---- block mode: read a batch of raw blocks, inflate them on n_threads_ threads, serve in order
+    bool refill()
+    {
+        struct Blk { size_t in_off, in_len, out_off; uint32_t isize; };
+        std::vector<Blk> blks;
+        comp_.clear();
+        size_t out_total = 0;
+        const size_t kBatch = 256;
+        while (blks.size() < kBatch) {
+            uint8_t hdr[18];
+            const size_t got = fread(hdr, 1, sizeof hdr, f_);
+            if (got == 0) break;
+            if (got != sizeof hdr || !is_bgzf_header(hdr)) throw std::runtime_error("corrupt BGZF block header");
+            const size_t bsize = (size_t)hdr[16] + ((size_t)hdr[17] << 8) + 1;  // whole block
+            if (bsize < 26) throw std::runtime_error("corrupt BGZF block size");
+            const size_t body = bsize - 18;  // deflate data + crc32 + isize
+            const size_t off = comp_.size();
+            comp_.resize(off + body);
+            if (fread(comp_.data() + off, 1, body, f_) != body) throw std::runtime_error("truncated BGZF block");
+            uint32_t isize;
+            memcpy(&isize, comp_.data() + off + body - 4, 4);
+            if (isize > (1u << 16)) throw std::runtime_error("BGZF block larger than 64 KiB");
+            blks.push_back({off, body - 8, out_total, isize});
+            out_total += isize;
+        }
+        if (blks.empty()) return false;
+        out_.resize(out_total);
+        out_pos_ = 0;
+        std::atomic<size_t> next{0};
+        std::atomic<bool> bad{false};
+        auto work = [&]() {
+            z_stream z;
+            for (;;) {
+                const size_t i = next.fetch_add(1);
+                if (i >= blks.size()) return;
+                const Blk &b = blks[i];
+                if (b.isize == 0) continue;
+                memset(&z, 0, sizeof z);
+                if (inflateInit2(&z, -15) != Z_OK) { bad = true; return; }
+                z.next_in = comp_.data() + b.in_off;
+                z.avail_in = (uInt)b.in_len;
+                z.next_out = out_.data() + b.out_off;
+                z.avail_out = b.isize;
+                const int rc = inflate(&z, Z_FINISH);
+                inflateEnd(&z);
+                if (rc != Z_STREAM_END || z.avail_out != 0) { bad = true; return; }
+            }
+        };
+        const unsigned nt = (unsigned)std::min<size_t>(n_threads_, blks.size());
+        if (nt <= 1) work();
+        else {
+            std::vector<std::thread> th;
+            for (unsigned t = 0; t < nt; ++t) th.emplace_back(work);
+            for (auto &t : th) t.join();
+        }
+        if (bad) throw std::runtime_error("BGZF block failed to inflate");
+        return true;
+    }
+    bool read_blocks(void *dst, size_t n)
+    {
+        uint8_t *out = static_cast<uint8_t *>(dst);
+        size_t got = 0;
+        while (got < n) {
+            if (out_pos_ == out_.size()) {
+                if (!refill()) {
+                    if (got == 0) return false;
+                    throw std::runtime_error("truncated BGZF stream");
+                }
+                continue;
+            }
+            const size_t take = std::min(n - got, out_.size() - out_pos_);
+            memcpy(out + got, out_.data() + out_pos_, take);
+            out_pos_ += take;
+            got += take;
+        }
+        return true;
+    }
+
+    // ---- stream mode: plain inflate with member restart
+    bool read_stream(void *dst, size_t n)
     {
         uint8_t *out = static_cast<uint8_t *>(dst);
         size_t got = 0;
@@ -56,8 +156,11 @@ public:
         return true;
     }
 
-private:
     FILE *f_;
+    bool block_mode_ = false;
+    unsigned n_threads_ = 1;
+    std::vector<uint8_t> comp_, out_;
+    size_t out_pos_ = 0;
     z_stream z_;
     std::vector<uint8_t> in_;
     bool eof_ = false;

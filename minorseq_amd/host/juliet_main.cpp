@@ -175,6 +175,17 @@ std::string render_html(const Json &root, const std::string &json_text)
             h += "</table>\n";
         }
     }
+    if (const Json *ds = root.get("drug_summaries")) {
+        h += "<h2>Drug Summaries</h2><table><tr><th>Drug</th><th>Gene</th><th>Mutation</th><th>%</th></tr>\n";
+        for (const Json &d : ds->arr)
+            for (const Json &v : d.get("variants")->arr) {
+                char pc[32];
+                snprintf(pc, sizeof pc, "%.2g", 100.0 * v.get("frequency")->num);
+                h += "<tr><td>" + html_escape(d.get_str("drug")) + "</td><td>" + html_escape(v.get_str("gene")) + "</td><td>" +
+                     v.get_str("mutation") + "</td><td>" + pc + "</td></tr>\n";
+            }
+        h += "</table>\n";
+    }
     h += "<h2>JSON</h2><pre>" + html_escape(json_text) + "</pre></body></html>\n";
     return h;
 }
@@ -416,6 +427,32 @@ int main(int argc, char **argv)
             genes_json.push(gj);
         }
         root.set("genes", genes_json);
+
+        // Section 4, drug summaries: variants grouped by annotated drug (doc/JULIET.md:104-107)
+        {
+            std::vector<std::pair<std::string, Json>> by_drug;
+            for (const jl_variant &f : var) {
+                const GeneCfg &g = cfg.genes[f.gene];
+                const uint32_t aa_pos = f.codon_pos + g.first_codon;
+                const char aa = translate(f.codon);
+                for (const Drm &d : g.drms) {
+                    bool hit_drm = false;
+                    for (const DrmPosition &dp : d.positions) hit_drm = hit_drm || dp.matches(aa_pos, aa);
+                    if (!hit_drm) continue;
+                    Json e = Json::object();
+                    e.set("gene", Json::of(g.name));
+                    e.set("mutation", Json::of(std::string(1, translate(f.ref_codon)) + std::to_string(aa_pos) + std::string(1, aa)));
+                    e.set("codon", Json::of(codon_string(f.codon)));
+                    e.set("frequency", Json::of((double)f.count / (double)f.coverage));
+                    auto it = std::find_if(by_drug.begin(), by_drug.end(), [&](const std::pair<std::string, Json> &kv) { return kv.first == d.name; });
+                    if (it == by_drug.end()) { by_drug.emplace_back(d.name, Json::array()); it = by_drug.end() - 1; }
+                    it->second.push(e);
+                }
+            }
+            Json ds = Json::array();
+            for (auto &kv : by_drug) ds.push(Json::object().set("drug", Json::of(kv.first)).set("variants", kv.second));
+            root.set("drug_summaries", ds);
+        }
 
         if (opt.phasing) {  // root `haplotype` block: counts and read names, same order as haplotype_hit (doc/JULIET.md:209-211)
             Json hb = Json::object();

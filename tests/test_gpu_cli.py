@@ -86,6 +86,11 @@ def test_json_matches_oracle_with_phasing(sample, oracle):
         assert idx == np.nonzero(ph["read_hap"] == hi)[0].tolist()
     for k, (gi, pos, cod, vc, vp, aa) in enumerate(got):
         assert vc["haplotype_hit"] == [bool(x) for x in ph["hit"][k]]                           # doc/JULIET.md:207-211
+    # drug summaries (doc/JULIET.md:104-107): the made-up drug lists all five planted mutations
+    assert [d["drug"] for d in j["drug_summaries"]] == ["synthetic drug"]
+    muts = j["drug_summaries"][0]["variants"]
+    assert len(muts) == len(exp) and all(re.fullmatch(r"[A-Z]\d+[A-Z]", m["mutation"]) for m in muts)
+    assert [m["frequency"] for m in muts] == [e["count"] / e["coverage"] for e in exp]
     # traceability block (doc/JULIET.md:75-79)
     assert j["input"]["input_file"] == bam and "--mode-phasing" in j["input"]["command_line"]
     assert re.fullmatch(r"\d{4}-\d\d-\d\dT\d\d:\d\d:\d\d\.\d{3}Z", j["input"]["timestamp"])
