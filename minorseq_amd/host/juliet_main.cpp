@@ -118,7 +118,7 @@ std::string iso_now()
     const int ms = (int)(duration_cast<milliseconds>(now.time_since_epoch()).count() % 1000);
     std::tm tm;
     gmtime_r(&t, &tm);
-    char buf[40];
+    char buf[80];
     snprintf(buf, sizeof buf, "%04d-%02d-%02dT%02d:%02d:%02d.%03dZ", tm.tm_year + 1900, tm.tm_mon + 1, tm.tm_mday,
              tm.tm_hour, tm.tm_min, tm.tm_sec, ms);
     return buf;
