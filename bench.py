@@ -170,7 +170,7 @@ def main():
     achieved = alg_bytes / (t_pileup_ms * 1e-3) / 1e9
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(tpath):
+    if os.path.exists(tpath) and (n, l) == (N_READS, N_COLS):   # the PMC passes were taken on the default workload
         try:
             traffic = json.load(open(tpath)).get("pileup_kernel_hbm_bytes_per_launch")
         except Exception:
