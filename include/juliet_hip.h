@@ -239,6 +239,24 @@ int jl_allgather_variants(jl_ctx *ctx, jl_comm *comm, jl_variant *all_rows, uint
  */
 int jl_allgather_variants_async(jl_ctx *ctx, jl_comm *comm);
 
+/* ---------------------------------------------------------------- cross-window phasing */
+
+/*
+ * Reads that span several windows are phased on a compact matrix made of only the variant columns of ALL
+ * windows: position k (ascending global column) occupies columns 3k..3k+2 of `pc`'s resident matrix.
+ * `merged`: every window's called rows with GLOBAL (reference) columns, e.g. the all-gathered table.
+ * Outputs: `remapped` (same rows, col = 3k) to pass to jl_phase_async(pc, remapped, ...), `pos_global[vp]`.
+ * All windows must hold the same reads in the same order.  Phasing itself then runs replicated on the
+ * compact matrix (3*Vp columns: a few MB even at 1e7 reads).
+ */
+/* every window resident on this device: device-to-device copies */
+int jl_xwin_assemble_local(jl_ctx *pc, jl_ctx *const *windows, uint32_t n_windows, const jl_variant *merged,
+                           uint32_t n_var, jl_variant *remapped, uint32_t *pos_global, uint32_t *vp_total);
+/* one window per rank: each position's owner broadcasts its 3 columns over RCCL (second exchange of the run) */
+int jl_xwin_assemble_rccl(jl_ctx *pc, jl_ctx *window, jl_comm *comm, const uint32_t *win_begin,
+                          const uint32_t *win_ncols, const jl_variant *merged, uint32_t n_var, jl_variant *remapped,
+                          uint32_t *pos_global, uint32_t *vp_total);
+
 #ifdef __cplusplus
 }
 #endif

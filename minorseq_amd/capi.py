@@ -32,7 +32,8 @@ EXPORTS = ("jl_abi_version", "jl_strerror", "jl_device_count", "jl_ctx_create", 
            "jl_msa_ingest_records", "jl_msa_download", "jl_synth_fill", "jl_pileup_async", "jl_n_positions", "jl_pileup_fetch",
            "jl_call_async", "jl_call_fetch", "jl_variant_table_device", "jl_phase_async", "jl_phase_fetch",
            "jl_run_async", "jl_fisher_eval", "jl_time_pileup", "jl_pileup_kernel_name", "jl_comm_unique_id", "jl_comm_create", "jl_comm_destroy",
-           "jl_allgather_variants", "jl_allgather_variants_async")
+           "jl_allgather_variants", "jl_allgather_variants_async", "jl_xwin_assemble_local",
+           "jl_xwin_assemble_rccl")
 
 
 class ErrorModel(C.Structure):
@@ -114,6 +115,8 @@ def load_library(path=LIB_PATH):
     lib.jl_comm_destroy.restype = None
     lib.jl_allgather_variants.argtypes = [vp, vp, vp, vp, u32]
     lib.jl_allgather_variants_async.argtypes = [vp, vp]
+    lib.jl_xwin_assemble_local.argtypes = [vp, vp, u32, vp, u32, vp, vp, C.POINTER(u32)]
+    lib.jl_xwin_assemble_rccl.argtypes = [vp, vp, vp, vp, vp, vp, u32, vp, vp, C.POINTER(u32)]
     if lib.jl_abi_version() != 1:
         raise ImportError("libjuliet_hip.so ABI version mismatch")
     _lib = lib
@@ -355,6 +358,37 @@ class Juliet:
         if phasing:
             res["phase"] = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in out["phase"].items()}
         return res
+
+
+def phase_across_windows(windows, merged, min_reads=10, comm=None, win_begins=None, win_ncols=None, device=0):
+    """Cross-window phasing: `windows` = contexts holding the SAME reads over different column
+    windows (all on this device), or a single context plus an RCCL `comm` when every rank owns one window.
+    `merged`: all windows' variant rows with GLOBAL columns.  Returns (phase result, global columns of the positions)."""
+    merged = np.ascontiguousarray(merged, dtype=VARIANT)
+    pc = Juliet(device)
+    remapped = np.zeros(max(1, len(merged)), dtype=VARIANT)
+    pos_global = np.zeros(max(1, len(merged)), dtype=np.uint32)
+    vp = C.c_uint32()
+    if comm is None:
+        arr = (C.c_void_p * len(windows))(*[w.h for w in windows])
+        pc._chk(pc.lib.jl_xwin_assemble_local(pc.h, arr, len(windows), _p(merged), len(merged), _p(remapped), _p(pos_global),
+                                              C.byref(vp)))
+    else:
+        wb = np.ascontiguousarray(win_begins, dtype=np.uint32)
+        wn = np.ascontiguousarray(win_ncols, dtype=np.uint32)
+        pc._chk(pc.lib.jl_xwin_assemble_rccl(pc.h, windows[0].h, comm, _p(wb), _p(wn), _p(merged), len(merged), _p(remapped),
+                                             _p(pos_global), C.byref(vp)))
+    if vp.value == 0:
+        pc.close()
+        return None, pos_global[:0]
+    pc._shape(windows[0].n_reads, 3 * vp.value, windows[0].col_stride)
+    pc.phase_async(remapped[: len(merged)], min_reads)
+    ph = pc.phase_fetch(want_reads=True, cap_var=max(1, len(merged)))
+    ph["hit"] = ph["hit"][: len(merged), : ph["summary"]["n_haplotypes"]].copy()
+    if ph["cooc"] is not None:
+        ph["cooc"] = ph["cooc"][: len(merged), : len(merged)].copy()
+    pc.close()
+    return ph, pos_global[: vp.value].copy()
 
 
 def haplotype_name(h: int) -> str:

@@ -10,6 +10,7 @@
 #include <condition_variable>
 #include <deque>
 #include <mutex>
+#include <algorithm>
 #include <new>
 #include <thread>
 
@@ -392,6 +393,24 @@ int jl_synth_fill(jl_ctx *ctx, const jl_synth_params *sp, const uint8_t *ref)
 
 /* ---------------------------------------------------------------- call */
 
+// per-column device arrays (pileup outputs, plan flags, phasing maps)
+static int reserve_columns(jl_ctx *ctx)
+{
+    int rc;
+    if (ctx->col_capacity < ctx->n_cols) {
+        if ((rc = regrow(ctx, &ctx->d_colflag, ctx->n_cols))) return rc;
+        if ((rc = regrow(ctx, &ctx->d_guess, ctx->n_cols))) return rc;
+        if ((rc = regrow(ctx, &ctx->d_col2pos, ctx->n_cols))) return rc;
+        if ((rc = regrow(ctx, &ctx->d_varcol, ctx->n_cols))) return rc;
+        ctx->counts_words = (size_t)ctx->n_cols * (6 + 64);
+        if ((rc = regrow(ctx, &ctx->d_counts, ctx->counts_words))) return rc;
+        ctx->col_capacity = ctx->n_cols;
+    }
+    ctx->counts_words = (size_t)ctx->n_cols * (6 + 64);
+    ctx->d_hist = ctx->d_counts + (size_t)ctx->n_cols * 6;
+    return JL_OK;
+}
+
 // SPEC §3: evaluated positions of every gene, in (gene, k) order
 static int build_plan(jl_ctx *ctx, const jl_gene *genes, uint32_t n_genes, const uint8_t *refseq, uint32_t ref_len)
 {
@@ -440,17 +459,7 @@ static int build_plan(jl_ctx *ctx, const jl_gene *genes, uint32_t n_genes, const
         }
 
     int rc;
-    if (ctx->col_capacity < ctx->n_cols) {
-        if ((rc = regrow(ctx, &ctx->d_colflag, ctx->n_cols))) return rc;
-        if ((rc = regrow(ctx, &ctx->d_guess, ctx->n_cols))) return rc;
-        if ((rc = regrow(ctx, &ctx->d_col2pos, ctx->n_cols))) return rc;
-        if ((rc = regrow(ctx, &ctx->d_varcol, ctx->n_cols))) return rc;
-        ctx->counts_words = (size_t)ctx->n_cols * (6 + 64);
-        if ((rc = regrow(ctx, &ctx->d_counts, ctx->counts_words))) return rc;
-        ctx->col_capacity = ctx->n_cols;
-    }
-    ctx->counts_words = (size_t)ctx->n_cols * (6 + 64);
-    ctx->d_hist = ctx->d_counts + (size_t)ctx->n_cols * 6;
+    if ((rc = reserve_columns(ctx))) return rc;
     const size_t P = ctx->P ? ctx->P : 1;
     if (ctx->pos_capacity < P) {
         if ((rc = regrow(ctx, &ctx->d_pos_gene, P))) return rc;
@@ -639,8 +648,12 @@ int jl_phase_async(jl_ctx *ctx, const jl_variant *variants, uint32_t n_var, uint
 {
     if (!ctx) return JL_ERR_ARG;
     if (!ctx->d_msa) return jl_fail(ctx, JL_ERR_STATE, "no resident matrix");
-    if (!ctx->d_col2pos) return jl_fail(ctx, JL_ERR_STATE, "jl_phase_async before jl_pileup_async");
     JL_HIP(ctx, hipSetDevice(ctx->device));
+    if (!variants && !ctx->call_done) return jl_fail(ctx, JL_ERR_STATE, "jl_phase_async(NULL) needs jl_call_async first");
+    {
+        int rcc = reserve_columns(ctx);  // a context that only phases (cross-window matrix) never ran a pileup plan
+        if (rcc) return rcc;
+    }
     uint32_t kwords;
     if (variants) {
         if (n_var > JL_VARIANT_CAP) return jl_fail(ctx, JL_ERR_OVERFLOW, "%u variants, table holds %u", n_var, JL_VARIANT_CAP);
@@ -1056,6 +1069,100 @@ int jl_allgather_variants(jl_ctx *ctx, jl_comm *c, jl_variant *all_rows, uint32_
         }
     }
     return allgather_full(ctx, c, all_rows, all_counts, cap_rows);
+}
+
+
+/* ---------------------------------------------------------------- cross-window phasing */
+
+// Distinct variant positions of the merged (global-column) table, ascending, and the remapped table whose
+// columns index the compact matrix: position k lives in compact columns 3k..3k+2.
+static uint32_t xwin_remap(const jl_variant *merged, uint32_t n_var, jl_variant *remapped, uint32_t *pos_global)
+{
+    std::vector<uint32_t> cols;
+    cols.reserve(n_var);
+    for (uint32_t v = 0; v < n_var; ++v) cols.push_back(merged[v].col);
+    std::sort(cols.begin(), cols.end());
+    cols.erase(std::unique(cols.begin(), cols.end()), cols.end());
+    for (uint32_t v = 0; v < n_var; ++v) {
+        const uint32_t k = (uint32_t)(std::lower_bound(cols.begin(), cols.end(), merged[v].col) - cols.begin());
+        if (remapped) {
+            remapped[v] = merged[v];
+            remapped[v].col = 3u * k;
+        }
+    }
+    if (pos_global) std::copy(cols.begin(), cols.end(), pos_global);
+    return (uint32_t)cols.size();
+}
+
+static int xwin_owner(const uint32_t *win_begin, const uint32_t *win_ncols, uint32_t n_windows, uint32_t col)
+{
+    for (uint32_t w = 0; w < n_windows; ++w)
+        if (col >= win_begin[w] && (uint64_t)col + 3 <= (uint64_t)win_begin[w] + win_ncols[w]) return (int)w;
+    return -1;
+}
+
+// All windows on THIS device (a 288 GB GPU holds many): device-to-device copies of 3 columns per position.
+int jl_xwin_assemble_local(jl_ctx *pc, jl_ctx *const *windows, uint32_t n_windows, const jl_variant *merged, uint32_t n_var,
+                           jl_variant *remapped, uint32_t *pos_global, uint32_t *vp_total)
+{
+    if (!pc || !windows || n_windows == 0 || (!merged && n_var) || !vp_total) return JL_ERR_ARG;
+    if (n_var > JL_VARIANT_CAP) return jl_fail(pc, JL_ERR_OVERFLOW, "%u variants, table holds %u", n_var, JL_VARIANT_CAP);
+    std::vector<uint32_t> wb(n_windows), wn(n_windows);
+    for (uint32_t w = 0; w < n_windows; ++w) {
+        if (!windows[w] || !windows[w]->d_msa) return jl_fail(pc, JL_ERR_ARG, "window %u has no resident matrix", w);
+        if (windows[w]->n_reads != windows[0]->n_reads || windows[w]->col_stride != windows[0]->col_stride)
+            return jl_fail(pc, JL_ERR_ARG, "windows must hold the same reads (window %u differs)", w);
+        wb[w] = windows[w]->win_begin;
+        wn[w] = windows[w]->n_cols;
+    }
+    std::vector<uint32_t> pos(n_var ? n_var : 1);
+    const uint32_t vp = xwin_remap(merged, n_var, remapped, pos.data());
+    *vp_total = vp;
+    if (pos_global) std::copy(pos.begin(), pos.begin() + vp, pos_global);
+    if (vp == 0) return JL_OK;
+    int rc = jl_msa_alloc(pc, windows[0]->n_reads, 3u * vp, 0);
+    if (rc) return rc;
+    const uint64_t stride = windows[0]->col_stride;
+    for (uint32_t k = 0; k < vp; ++k) {
+        const int w = xwin_owner(wb.data(), wn.data(), n_windows, pos[k]);
+        if (w < 0) return jl_fail(pc, JL_ERR_ARG, "variant column %u is not fully inside any window", pos[k]);
+        JL_HIP(pc, hipStreamSynchronize(windows[w]->stream));
+        JL_HIP(pc, hipMemcpyAsync(pc->d_msa + (uint64_t)3 * k * stride, windows[w]->d_msa + (uint64_t)(pos[k] - wb[w]) * stride,
+                                  3 * stride, hipMemcpyDeviceToDevice, pc->stream));
+    }
+    JL_HIP(pc, hipStreamSynchronize(pc->stream));
+    return JL_OK;
+}
+
+// One window per rank: the owner of each position broadcasts its 3 columns over RCCL/xGMI into every rank's
+// compact matrix (the second exchange of a cross-window run; 3*Vp*col_stride bytes in total).
+int jl_xwin_assemble_rccl(jl_ctx *pc, jl_ctx *window, jl_comm *c, const uint32_t *win_begin, const uint32_t *win_ncols,
+                          const jl_variant *merged, uint32_t n_var, jl_variant *remapped, uint32_t *pos_global,
+                          uint32_t *vp_total)
+{
+    if (!pc || !window || !c || !win_begin || !win_ncols || (!merged && n_var) || !vp_total) return JL_ERR_ARG;
+    if (!window->d_msa) return jl_fail(pc, JL_ERR_ARG, "window has no resident matrix");
+    if (n_var > JL_VARIANT_CAP) return jl_fail(pc, JL_ERR_OVERFLOW, "%u variants, table holds %u", n_var, JL_VARIANT_CAP);
+    std::vector<uint32_t> pos(n_var ? n_var : 1);
+    const uint32_t vp = xwin_remap(merged, n_var, remapped, pos.data());
+    *vp_total = vp;
+    if (pos_global) std::copy(pos.begin(), pos.begin() + vp, pos_global);
+    if (vp == 0) return JL_OK;
+    int rc = jl_msa_alloc(pc, window->n_reads, 3u * vp, 0);
+    if (rc) return rc;
+    const uint64_t stride = window->col_stride;
+    JL_HIP(pc, hipStreamSynchronize(window->stream));
+    ncclResult_t r = ncclGroupStart();
+    for (uint32_t k = 0; k < vp && r == ncclSuccess; ++k) {
+        const int w = xwin_owner(win_begin, win_ncols, (uint32_t)c->world, pos[k]);
+        if (w < 0) { ncclGroupEnd(); return jl_fail(pc, JL_ERR_ARG, "variant column %u is not fully inside any window", pos[k]); }
+        const uint8_t *src = (w == c->rank) ? window->d_msa + (uint64_t)(pos[k] - win_begin[w]) * stride : pc->d_msa;
+        r = ncclBroadcast(src, pc->d_msa + (uint64_t)3 * k * stride, 3 * stride, ncclUint8, w, c->comm, pc->stream);
+    }
+    if (r == ncclSuccess) r = ncclGroupEnd();
+    if (r != ncclSuccess) return jl_fail(pc, JL_ERR_COMM, "ncclBroadcast: %s", ncclGetErrorString(r));
+    JL_HIP(pc, hipStreamSynchronize(pc->stream));
+    return JL_OK;
 }
 
 }  // extern "C"

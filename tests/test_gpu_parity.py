@@ -545,3 +545,66 @@ def test_device_ingest_long_cigar(jl):
     assert cig_off[1] - cig_off[0] > 4000
     jl.ingest_records(l, 0, pos, cigar, cig_off, seq4, seq_off)
     assert (msa.unpack_columns(jl.download_columns(), 3) == rows).all()
+
+
+# --------------------------------------------------------------------------------------------- cross-window phasing
+def test_phase_across_windows_equals_unsharded(oracle):
+    """the same reads span several windows (config 4/5 as one long reference).  Each window is called
+    on its own context with the global Bonferroni factor; phasing then runs on the compact matrix of all variant
+    columns and must equal the oracle's phasing of the unsharded matrix."""
+    from minorseq_amd import sharding
+    n, l = 7000, 900
+    sp = synth.SynthParams(seed=29, minor_permille=(70, 60, 50, 40), partial_rate=0.15)
+    ref = synth.reference(sp.seed, l)
+    rows = synth.rows(sp, l, 0, n, ref)
+    # move two of the planted edits into the last third so that haplotypes really span windows
+    genes = np.array([(1, l + 1)], dtype=capi.GENE)
+    rows[: n // 20, 700:703] = (rows[: n // 20, 700:703] + 1) % 4
+    rows[n // 40: n // 16, 820:823] = (rows[n // 40: n // 16, 820:823] + 2) % 4
+    full_v = oracle.call(rows, genes, refseq=ref)
+    assert len(np.unique(full_v["col"] // 300)) >= 2                         # variants in more than one window
+    exp = oracle.phase(rows, full_v)
+    for world in (2, 3):
+        wb = sharding.window_bounds(l, world)
+        ctxs, tables = [], []
+        prm = capi.default_params(n_tests=sharding.default_n_tests(genes))
+        for b, e in wb:
+            c = capi.Juliet(0)
+            c.upload_columns(msa.pack_columns(rows[:, b:e]), n, win_begin=b)
+            c.pileup_async(genes, ref)
+            c.call_async(prm)
+            tables.append(c.call_fetch())
+            ctxs.append(c)
+        merged = sharding.merge_tables(tables, [b for b, _ in wb])
+        assert_variants_equal(merged, full_v)
+        ph, pos_global = capi.phase_across_windows(ctxs, merged)
+        assert (pos_global == exp["pos_cols"]).all()
+        got = dict(ph, pos_cols=pos_global)
+        assert_phase_equal(got, exp, len(full_v))
+        for c in ctxs:
+            c.close()
+
+
+def test_phase_across_windows_rccl_single_rank(jl, oracle):
+    """The RCCL form of the column exchange (owner broadcasts 3 columns per position) with world = 1."""
+    import ctypes as C
+    n, l = 4000, 300
+    sp = synth.SynthParams(seed=37, minor_permille=(70, 60, 50, 40))
+    ref = synth.reference(sp.seed, l)
+    rows = synth.rows(sp, l, 0, n, ref)
+    genes = np.array([(1, l + 1)], dtype=capi.GENE)
+    jl.upload_columns(msa.pack_columns(rows), n)
+    jl.pileup_async(genes, ref)
+    jl.call_async(capi.default_params())
+    table = jl.call_fetch()
+    idbuf = np.zeros(128, dtype=np.uint8)
+    assert jl.lib.jl_comm_unique_id(idbuf.ctypes.data_as(C.c_void_p)) == 0
+    comm = C.c_void_p()
+    jl._chk(jl.lib.jl_comm_create(jl.h, idbuf.ctypes.data_as(C.c_void_p), 0, 1, C.byref(comm)))
+    try:
+        ph, pos_global = capi.phase_across_windows([jl], table, comm=comm, win_begins=[0], win_ncols=[l])
+    finally:
+        jl.lib.jl_comm_destroy(comm)
+    exp = oracle.phase(rows, table)
+    assert (pos_global == exp["pos_cols"]).all()
+    assert_phase_equal(dict(ph, pos_cols=pos_global), exp, len(table))
