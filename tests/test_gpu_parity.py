@@ -608,3 +608,32 @@ def test_phase_across_windows_rccl_single_rank(jl, oracle):
     exp = oracle.phase(rows, table)
     assert (pos_global == exp["pos_cols"]).all()
     assert_phase_equal(dict(ph, pos_cols=pos_global), exp, len(table))
+
+
+# --------------------------------------------------------------------------------------------- deep coverage
+def test_ten_million_reads_against_oracle(oracle):
+    """Config-5 depth (1e7 reads) on a narrow window: exercises the multi-flush path of the pileup kernel
+    (611 tiles per column), 2^25-slot grouping table, p-values that underflow, u32 counts near 1e7."""
+    n, l = 10_000_000, 60
+    sp = synth.SynthParams(seed=5, minor_permille=(10, 10, 10, 10))
+    ref = synth.reference(sp.seed, l)
+    genes = np.array([(1, l + 1), (2, l)], dtype=capi.GENE)
+    j = capi.Juliet(0)
+    j.alloc(n, l)
+    j.synth_fill(sp, ref)
+    out = j.run(genes, ref)
+    pf = j.pileup_fetch()
+    rows = msa.unpack_columns(j.download_columns(), n)
+    j.close()
+    assert (pf["col_counts"].sum(axis=1) == n).all()
+    assert (pf["col_counts"] == oracle.pileup(rows)).all()
+    hist, cov = oracle.codon_hist(rows, pf["pos_col"])
+    assert (pf["hist"] == hist).all() and (pf["coverage"] == cov).all()
+    exp_v = oracle.call(rows, genes, refseq=ref)
+    assert len(exp_v) >= 4
+    assert_variants_equal(out["variants"], exp_v)
+    assert (exp_v["p_value"] == 0.0).any() and np.isfinite(exp_v["log_p"]).all()     # underflow carried as log-p
+    ph = oracle.phase(rows, exp_v)
+    assert_phase_equal(out["phase"], ph, len(exp_v))
+    s = out["phase"]["summary"]
+    assert s["reported_reads"] + s["insufficient_reads"] + s["damaged_reads"] == n
