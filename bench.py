@@ -38,7 +38,7 @@ def cpu_baseline(jl, genes, ref, budget_s=12.0):
     orc = oracle_lib.load()
     rows = msa.unpack_columns(jl.download_columns(), jl.n_reads)
     reps, t_total = 0, 0.0
-    while reps < 1 or (t_total < budget_s and reps < 20):
+    while reps < 1 or (t_total < budget_s and reps < 100):
         t0 = time.perf_counter()
         v = orc.call(rows, genes, refseq=ref)
         orc.pileup(rows)
@@ -164,6 +164,19 @@ def main():
         elapsed = float(tt.item())
     ms_per_step = 1000.0 * elapsed / args.steps
 
+    # latency of ONE batch through the path (no overlap with other batches), for the record
+    def one_batch():
+        launch(0)
+        return collect(0)
+    for _ in range(3):
+        one_batch()
+    fence()
+    t1 = time.perf_counter()
+    for _ in range(20):
+        one_batch()
+    fence()
+    latency_ms = 1000.0 * (time.perf_counter() - t1) / 20
+
     # dominant kernel alone, HIP events on the stream it is launched on
     t_pileup_ms = jl.time_pileup(reps=max(10, args.steps))
     alg_bytes = n * l / 2.0
@@ -195,7 +208,7 @@ def main():
                    "reads_per_gpu": n, "ref_columns_per_gpu": l,
                    "parallelism": f"window-sharded x{world}, one all-gather of the variant table" if distributed
                    else "single GPU",
-                   "batches_in_flight": len(ctxs),
+                   "batches_in_flight": len(ctxs), "one_batch_latency_ms": latency_ms,
                    "variants_called": n_var, "haplotypes": ph["summary"]["n_haplotypes"]},
         "roofline": {"bound": "hbm", "kernel": jl.lib.jl_pileup_kernel_name().decode(), "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

@@ -637,3 +637,39 @@ def test_ten_million_reads_against_oracle(oracle):
     assert_phase_equal(out["phase"], ph, len(exp_v))
     s = out["phase"]["summary"]
     assert s["reported_reads"] + s["insufficient_reads"] + s["damaged_reads"] == n
+
+
+# --------------------------------------------------------------------------------------------- randomized sweep
+def test_random_shapes_and_plans_against_oracle(oracle):
+    """Forty random (reads, columns, gene layout, parameter) combinations through jl_run_async vs the oracle."""
+    rng = np.random.default_rng(20260101)
+    j = capi.Juliet(0)
+    for case in range(40):
+        n = int(rng.integers(1, 4000))
+        l = int(rng.integers(3, 260))
+        sp = synth.SynthParams(seed=int(rng.integers(1, 1 << 30)), partial_rate=float(rng.choice([0.0, 0.3])),
+                               mask_rate=float(rng.choice([0.0, 0.02, 0.1])), del_rate=float(rng.choice([0.0, 0.01])),
+                               sub_rate=float(rng.choice([1e-4, 0.01])),
+                               minor_permille=tuple(int(x) for x in rng.integers(0, 120, 4)))
+        ref = synth.reference(sp.seed, l)
+        rows = synth.rows(sp, l, 0, n, ref)
+        ng = int(rng.integers(1, 4))
+        genes = []
+        for _ in range(ng):
+            b = int(rng.integers(1, max(2, l - 2)))
+            e = int(rng.integers(b + 1, l + 8))
+            genes.append((b, e))
+        genes = np.array(genes, dtype=capi.GENE)
+        use_ref = bool(rng.integers(0, 2))
+        win_b = int(rng.integers(0, max(1, l // 4)))
+        win = rows[:, win_b:]
+        prm = capi.default_params(alpha=float(rng.choice([0.01, 0.2])), n_tests=float(rng.choice([0.0, 1.0, 50.0])),
+                                  chemistry=str(rng.choice(["sequel", "permissive"])),
+                                  expected_round=int(rng.integers(0, 3)))
+        min_reads = int(rng.choice([1, 3, 10]))
+        j.upload_columns(msa.pack_columns(win), n, win_begin=win_b)
+        out = j.run(genes, ref if use_ref else None, prm, phasing=True, min_reads=min_reads)
+        exp_v = oracle.call(win, genes, win_begin=win_b, refseq=ref if use_ref else None, params=oracle_params(prm))
+        assert_variants_equal(out["variants"], exp_v)
+        assert_phase_equal(out["phase"], oracle.phase(win, exp_v, min_reads=min_reads), len(exp_v))
+    j.close()
