@@ -673,3 +673,31 @@ def test_random_shapes_and_plans_against_oracle(oracle):
         assert_variants_equal(out["variants"], exp_v)
         assert_phase_equal(out["phase"], oracle.phase(win, exp_v, min_reads=min_reads), len(exp_v))
     j.close()
+
+
+def test_variant_table_overflow_is_reported(oracle):
+    """More called codons than the fixed-stride table (4096 rows): JL_ERR_OVERFLOW, the rows that fit are the
+    first rows of the ordered table."""
+    n, l = 2000, 3000
+    sp = synth.SynthParams(seed=3, sub_rate=0.05, minor_permille=(10, 10, 10, 10))
+    ref = synth.reference(sp.seed, l)
+    rows = synth.rows(sp, l, 0, n, ref)
+    genes = np.array([(1, l + 1)], dtype=capi.GENE)
+    loose = capi.default_params(alpha=0.9, n_tests=1.0)
+    exp = oracle.call(rows, genes, refseq=ref, params=oracle_params(loose))
+    assert len(exp) > capi.VARIANT_CAP
+    j = capi.Juliet(0)
+    j.upload_columns(msa.pack_columns(rows), n)
+    j.pileup_async(genes, ref)
+    j.call_async(loose)
+    out = np.zeros(capi.VARIANT_CAP, dtype=capi.VARIANT)
+    import ctypes as C
+    cnt = C.c_uint32()
+    rc = j.lib.jl_call_fetch(j.h, out.ctypes.data_as(C.c_void_p), capi.VARIANT_CAP, C.byref(cnt))
+    assert rc == -5 and cnt.value == len(exp)
+    assert_variants_equal(out, exp[: capi.VARIANT_CAP])
+    # the whole-path entry point reports the same condition
+    with pytest.raises(capi.JulietError) as e:
+        j.run(genes, ref, loose, phasing=False)
+    assert e.value.status == -5
+    j.close()
