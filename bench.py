@@ -29,14 +29,18 @@ N_COLS = 3000
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 
 
-def cpu_baseline(jl, genes, ref, budget_s=12.0):
-    """Oracle (CPU restatement) call+phase on the same reads, single thread, bounded to ~budget_s of CPU work."""
+def cpu_baseline(jl, genes, ref, budget_s=12.0, threads=1, rows=None):
+    """Oracle (CPU restatement) call+phase on the same reads, bounded to ~budget_s of wall time.
+    threads = 1: the plain restatement (no thread option is documented for juliet, so this is the faithful stand-in);
+    threads > 1: its two counting sweeps split over reads with OpenMP (SURVEY.md §8d "all host cores")."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib
     from minorseq_amd import msa
 
     orc = oracle_lib.load()
-    rows = msa.unpack_columns(jl.download_columns(), jl.n_reads)
+    if rows is None:
+        rows = msa.unpack_columns(jl.download_columns(), jl.n_reads)
+    orc.set_threads(threads)
     reps, t_total = 0, 0.0
     while reps < 1 or (t_total < budget_s and reps < 100):
         t0 = time.perf_counter()
@@ -45,9 +49,10 @@ def cpu_baseline(jl, genes, ref, budget_s=12.0):
         orc.phase(rows, v)
         t_total += time.perf_counter() - t0
         reps += 1
-    return {"value": jl.n_reads * reps / t_total, "unit": "reads/s", "cores": 1, "kind": "port",
+    orc.set_threads(1)
+    return {"value": jl.n_reads * reps / t_total, "unit": "reads/s", "cores": threads, "kind": "port",
             "sample": f"{reps} x the full workload ({jl.n_reads} reads x {jl.n_cols} columns), call+phase, "
-                      f"oracle/juliet_oracle.c single thread, {t_total:.1f} s"}
+                      f"oracle/juliet_oracle.c, {threads} thread(s), {t_total:.1f} s"}, rows
 
 
 def main():
@@ -215,7 +220,10 @@ def main():
                      "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": t_pileup_ms},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(jl, genes, refseq)
+        out["cpu_baseline"], rows_host = cpu_baseline(jl, genes, refseq)
+        ncores = min(os.cpu_count() or 1, 64)
+        if ncores > 1:
+            out["cpu_baseline_all_cores"], _ = cpu_baseline(jl, genes, refseq, budget_s=6.0, threads=ncores, rows=rows_host)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if comm is not None:

@@ -672,6 +672,8 @@ int jl_phase_async(jl_ctx *ctx, const jl_variant *variants, uint32_t n_var, uint
     int rc = reserve_phase(ctx, kwords);
     if (rc) return rc;
     ctx->last_min_reads = min_reads;
+    ctx->pack_mirror = nullptr;
+    ctx->read_hap_out = nullptr;
     jl_launch_phase(ctx, min_reads, false);
     JL_HIP(ctx, hipGetLastError());
     ctx->phase_done = true;
@@ -702,7 +704,7 @@ int jl_phase_fetch(jl_ctx *ctx, jl_phase_summary *summary, uint32_t *pos_cols, u
             if (cooc)
                 for (uint32_t v = 0; v < nv; ++v) memcpy(cooc + (size_t)v * cap_var, pk->cooc + (size_t)v * nv, (size_t)nv * 4);
             if (read_hap) {
-                if (ctx->run_read_hap) memcpy(read_hap, ctx->h_read_hap, (size_t)ctx->n_reads * 2);
+                if (ctx->read_hap_out) memcpy(read_hap, ctx->h_read_hap, (size_t)ctx->n_reads * 2);
                 else {
                     JL_HIP(ctx, hipMemcpyAsync(read_hap, ctx->d_read_hap, (size_t)ctx->n_reads * 2, hipMemcpyDeviceToHost, st));
                     JL_HIP(ctx, hipStreamSynchronize(st));
@@ -712,8 +714,9 @@ int jl_phase_fetch(jl_ctx *ctx, jl_phase_summary *summary, uint32_t *pos_cols, u
         }
     }
     jl_phase_meta meta;
+    const bool ids_pinned = ctx->read_hap_out != nullptr;  // the last phase launch stored them in h_read_hap
     JL_HIP(ctx, hipMemcpyAsync(&meta, ctx->d_meta, sizeof meta, hipMemcpyDeviceToHost, st));
-    if (read_hap) JL_HIP(ctx, hipMemcpyAsync(read_hap, ctx->d_read_hap, (size_t)ctx->n_reads * 2, hipMemcpyDeviceToHost, st));
+    if (read_hap && !ids_pinned) JL_HIP(ctx, hipMemcpyAsync(read_hap, ctx->d_read_hap, (size_t)ctx->n_reads * 2, hipMemcpyDeviceToHost, st));
     JL_HIP(ctx, hipStreamSynchronize(st));
     if (meta.overflow & 12u) {
         // more variant positions than the single-word kernels (bit 3) or the resident key buffer (bit 2) cover:
@@ -724,9 +727,10 @@ int jl_phase_fetch(jl_ctx *ctx, jl_phase_summary *summary, uint32_t *pos_cols, u
         jl_launch_phase(ctx, ctx->last_min_reads, false);
         JL_HIP(ctx, hipGetLastError());
         JL_HIP(ctx, hipMemcpyAsync(&meta, ctx->d_meta, sizeof meta, hipMemcpyDeviceToHost, st));
-        if (read_hap) JL_HIP(ctx, hipMemcpyAsync(read_hap, ctx->d_read_hap, (size_t)ctx->n_reads * 2, hipMemcpyDeviceToHost, st));
+        if (read_hap && !ids_pinned) JL_HIP(ctx, hipMemcpyAsync(read_hap, ctx->d_read_hap, (size_t)ctx->n_reads * 2, hipMemcpyDeviceToHost, st));
         JL_HIP(ctx, hipStreamSynchronize(st));
     }
+    if (read_hap && ids_pinned) memcpy(read_hap, ctx->h_read_hap, (size_t)ctx->n_reads * 2);
     if (summary) *summary = meta.summary;
     const uint32_t vp = meta.vp, H = meta.summary.n_haplotypes, nv = meta.n_var;
     if ((pos_cols || hap_pattern) && vp > cap_var) return jl_fail(ctx, JL_ERR_OVERFLOW, "%u variant positions, caller capacity %u", vp, cap_var);
@@ -758,9 +762,9 @@ static void enqueue_path(jl_ctx *ctx, const jl_params *prm, double n_tests, bool
     jl_launch_call(ctx, prm, n_tests, use_drm, phasing);
     if (phasing) jl_launch_phase(ctx, min_reads, true);
     jl_launch_result_pack(ctx, phasing);
-    hipMemcpyAsync(ctx->h_pack, ctx->d_pack, sizeof(jl_pack), hipMemcpyDeviceToHost, st);
-    if (phasing && want_read_hap)
-        hipMemcpyAsync(ctx->h_read_hap, ctx->d_read_hap, (size_t)ctx->n_reads * 2, hipMemcpyDeviceToHost, st);
+    // no copy nodes: the result block and the per-read ids are stored straight into pinned host memory by the
+    // kernels that produce them (ctx->pack_mirror / ctx->read_hap_out, set by jl_run_async)
+    (void)want_read_hap;
 }
 
 int jl_run_async(jl_ctx *ctx, const jl_gene *genes, uint32_t n_genes, const uint8_t *refseq, uint32_t ref_len,
@@ -792,6 +796,8 @@ int jl_run_async(jl_ctx *ctx, const jl_gene *genes, uint32_t n_genes, const uint
     const double n_tests = prm->n_tests > 0.0 ? prm->n_tests : ctx->default_n_tests;
     ctx->last_min_reads = min_reads;
     jl_prepare_pileup(ctx);
+    ctx->pack_mirror = ctx->h_pack;
+    ctx->read_hap_out = (phasing && want_read_hap) ? ctx->h_read_hap : nullptr;
     if (ctx->exchange_slot) {  // an uncollected all-gather may still be reading the previous result block
         jl_comm_slot *s = static_cast<jl_comm_slot *>(ctx->exchange_slot);
         comm_wait_enqueued(static_cast<jl_comm *>(ctx->exchange_comm), s);
@@ -802,7 +808,7 @@ int jl_run_async(jl_ctx *ctx, const jl_gene *genes, uint32_t n_genes, const uint
     struct { uint64_t alloc, plan; jl_params prm; double n_tests; uint32_t drm, phasing, min_reads, rh, generic, pad; } sig;
     memset(&sig, 0, sizeof sig);
     sig.alloc = ctx->alloc_version; sig.plan = ctx->plan_version; sig.prm = *prm; sig.n_tests = n_tests;
-    sig.drm = drm_masks != nullptr; sig.phasing = phasing != 0; sig.min_reads = min_reads; sig.rh = want_read_hap != 0; sig.generic = ctx->phase_generic;
+    sig.drm = drm_masks != nullptr; sig.phasing = phasing != 0; sig.min_reads = min_reads; sig.rh = want_read_hap != 0; sig.generic = ctx->phase_generic; sig.pad = (uint32_t)(uintptr_t)ctx->read_hap_out;
     const bool graphs_on = !getenv("JL_NO_GRAPH");
     bool launched = false;
     if (graphs_on) {

@@ -138,6 +138,8 @@ struct jl_ctx {
     jl_pack *h_pack = nullptr;        // pinned
     uint16_t *h_read_hap = nullptr;   // pinned, [reads_pad]
     size_t h_read_hap_cap = 0;
+    jl_pack *pack_mirror = nullptr;     // where kernels mirror the result block (h_pack during jl_run_async)
+    uint16_t *read_hap_out = nullptr;   // where phase_assign_kernel writes (h_read_hap when the host wants the ids)
     bool pack_valid = false;          // the last stage calls were one jl_run_async
     bool run_read_hap = false;
     hipGraph_t graph = nullptr;

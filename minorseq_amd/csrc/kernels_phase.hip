@@ -421,13 +421,24 @@ __device__ __forceinline__ void result_pack_block(const jl_variant *__restrict__
     }
 }
 
+// The finished block also goes straight to pinned host memory (zero-copy store over PCIe, 20 KB): no copy node.
+__device__ __forceinline__ void result_pack_mirror(const jl_pack *__restrict__ pk, jl_pack *__restrict__ mirror)
+{
+    if (!mirror) return;
+    __syncthreads();
+    const uint64_t *src = reinterpret_cast<const uint64_t *>(pk);
+    uint64_t *dst = reinterpret_cast<uint64_t *>(mirror);
+    for (uint32_t i = threadIdx.x; i < (uint32_t)(sizeof(jl_pack) / 8); i += blockDim.x) dst[i] = src[i];
+}
+
 __global__ __launch_bounds__(256) void result_pack_kernel(const jl_variant *__restrict__ variants,
                                                            const uint32_t *__restrict__ n_rows,
                                                            const jl_phase_meta *__restrict__ meta,
-                                                           jl_pack *__restrict__ pk)
+                                                           jl_pack *__restrict__ pk, jl_pack *__restrict__ mirror)
 {
     // phasing off: only the variant table
     result_pack_block(variants, n_rows[0], meta, 0u, nullptr, nullptr, nullptr, nullptr, nullptr, 0u, 0u, pk);
+    result_pack_mirror(pk, mirror);
 }
 
 // ---------------------------------------------------------------------------------------- select
@@ -454,7 +465,7 @@ __global__ __launch_bounds__(1024) void phase_select_kernel(uint32_t min_reads, 
                                                              const uint32_t *__restrict__ n_rows,
                                                              const uint32_t *__restrict__ vpcols,
                                                              uint32_t *__restrict__ cooc, uint32_t cooc_cap,
-                                                             jl_pack *__restrict__ pk,
+                                                             jl_pack *__restrict__ pk, jl_pack *__restrict__ mirror,
                                                              unsigned long long *__restrict__ slot_key,
                                                              uint32_t *__restrict__ slot_rep_w,
                                                              uint32_t *__restrict__ slot_count_w)
@@ -549,6 +560,7 @@ __global__ __launch_bounds__(1024) void phase_select_kernel(uint32_t min_reads, 
     }  // vp != 0
     __syncthreads();
     result_pack_block(variants, n_rows[0], meta, 1u, vpcols, hap_count, hap_pattern, hit, cooc, cooc_cap, 1u, pk);
+    result_pack_mirror(pk, mirror);
     // leave the table empty for the next run: only the slots this run touched
     for (uint32_t q = tid; q < n_occ; q += 1024u) {
         const uint32_t s = occupied[q];
@@ -581,7 +593,7 @@ void jl_launch_result_pack(jl_ctx *ctx, bool phasing)
 {
     if (phasing) return;  // phase_select_kernel packs at its end
     hipLaunchKernelGGL(result_pack_kernel, dim3(1), dim3(256), 0, ctx->stream, ctx->d_variants, ctx->d_nvar, ctx->d_meta,
-                       ctx->d_pack);
+                       ctx->d_pack, ctx->pack_mirror);
 }
 
 // `planned`: compact_kernel already ran the plan (jl_run_async); otherwise the stand-alone plan kernel runs here.
@@ -613,8 +625,8 @@ void jl_launch_phase(jl_ctx *ctx, uint32_t min_reads, bool planned)
     hipLaunchKernelGGL(phase_select_kernel, dim3(1), dim3(1024), 0, st, min_reads, reads_pad, ctx->d_keys,
                        ctx->d_meta, ctx->d_slot_rep, ctx->d_slot_count, ctx->d_occupied, ctx->d_slot_hap,
                        ctx->d_variants, ctx->d_col2pos, ctx->n_cols, ctx->d_hap_count, ctx->d_hap_pattern, ctx->d_hit,
-                       ctx->d_nvar, ctx->d_vpcols, ctx->d_cooc, ctx->cooc_cap, ctx->d_pack,
+                       ctx->d_nvar, ctx->d_vpcols, ctx->d_cooc, ctx->cooc_cap, ctx->d_pack, ctx->pack_mirror,
                        (unsigned long long *)ctx->d_slot_key, ctx->d_slot_rep, ctx->d_slot_count);
     hipLaunchKernelGGL(phase_assign_kernel, dim3(rblocks), dim3(256), 0, st, ctx->n_reads, ctx->d_flagw, ctx->d_meta,
-                       ctx->d_read_slot, ctx->d_slot_hap, ctx->d_read_hap);
+                       ctx->d_read_slot, ctx->d_slot_hap, ctx->read_hap_out ? ctx->read_hap_out : ctx->d_read_hap);
 }

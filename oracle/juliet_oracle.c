@@ -20,6 +20,23 @@
 #include <stdlib.h>
 #include <string.h>
 
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* 1 = the plain single-threaded restatement (default).  > 1 = the same loops split over reads with OpenMP and
+ * per-thread counters summed afterwards — the "all host cores" CPU baseline of SURVEY.md §8d. */
+static int g_threads = 1;
+void orc_set_threads(int n) { g_threads = n < 1 ? 1 : n; }
+int orc_max_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
 enum { SYM_A = 0, SYM_C = 1, SYM_G = 2, SYM_T = 3, SYM_GAP = 4, SYM_MASK = 5, SYM_NONE = 6 };
 
 typedef struct {
@@ -63,6 +80,26 @@ typedef struct {
 int orc_pileup(const uint8_t *msa, uint64_t n_reads, uint32_t n_cols, uint32_t *col_counts)
 {
     memset(col_counts, 0, (size_t)n_cols * 6 * sizeof(uint32_t));
+#ifdef _OPENMP
+    if (g_threads > 1) {
+#pragma omp parallel num_threads(g_threads)
+        {
+            uint32_t *loc = (uint32_t *)calloc((size_t)n_cols * 6, sizeof(uint32_t));
+#pragma omp for schedule(static)
+            for (int64_t i = 0; i < (int64_t)n_reads; ++i) {
+                const uint8_t *row = msa + (uint64_t)i * n_cols;
+                for (uint32_t c = 0; c < n_cols; ++c) {
+                    uint8_t s = row[c];
+                    if (s < 6) loc[(size_t)c * 6 + s]++;
+                }
+            }
+#pragma omp critical
+            for (size_t k = 0; k < (size_t)n_cols * 6; ++k) col_counts[k] += loc[k];
+            free(loc);
+        }
+        return 0;
+    }
+#endif
     for (uint64_t i = 0; i < n_reads; ++i) {
         const uint8_t *row = msa + i * n_cols;
         for (uint32_t c = 0; c < n_cols; ++c) {
@@ -79,6 +116,35 @@ int orc_codon_hist(const uint8_t *msa, uint64_t n_reads, uint32_t n_cols, const 
 {
     memset(hist, 0, (size_t)n_pos * 64 * sizeof(uint32_t));
     memset(coverage, 0, (size_t)n_pos * sizeof(uint32_t));
+#ifdef _OPENMP
+    if (g_threads > 1) {
+#pragma omp parallel num_threads(g_threads)
+        {
+            uint32_t *lh = (uint32_t *)calloc((size_t)n_pos * 64 + 1, sizeof(uint32_t));
+            uint32_t *lc = (uint32_t *)calloc((size_t)n_pos + 1, sizeof(uint32_t));
+#pragma omp for schedule(static)
+            for (int64_t i = 0; i < (int64_t)n_reads; ++i) {
+                const uint8_t *row = msa + (uint64_t)i * n_cols;
+                for (uint32_t p = 0; p < n_pos; ++p) {
+                    uint32_t c = start_cols[p];
+                    if ((uint64_t)c + 2 >= n_cols) continue;
+                    uint8_t s0 = row[c], s1 = row[c + 1], s2 = row[c + 2];
+                    if (s0 > 3 || s1 > 3 || s2 > 3) continue;
+                    lh[(size_t)p * 64 + 16 * s0 + 4 * s1 + s2]++;
+                    lc[p]++;
+                }
+            }
+#pragma omp critical
+            {
+                for (size_t k = 0; k < (size_t)n_pos * 64; ++k) hist[k] += lh[k];
+                for (size_t k = 0; k < n_pos; ++k) coverage[k] += lc[k];
+            }
+            free(lh);
+            free(lc);
+        }
+        return 0;
+    }
+#endif
     /* reads outermost: one sequential sweep of the by-row matrix */
     for (uint64_t i = 0; i < n_reads; ++i) {
         const uint8_t *row = msa + i * n_cols;

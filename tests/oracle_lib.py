@@ -50,8 +50,17 @@ class Oracle:
         lib.orc_default_n_tests.restype = C.c_double
         lib.orc_expected.restype = C.c_uint32
         lib.orc_expected.argtypes = [C.POINTER(Params), C.c_uint32, C.c_int, C.c_int]
+        lib.orc_set_threads.argtypes = [C.c_int]
+        lib.orc_set_threads.restype = None
         assert lib.orc_sizeof_variant() == VARIANT.itemsize
         assert lib.orc_sizeof_params() == C.sizeof(Params)
+
+    def set_threads(self, n):
+        """1 = the plain restatement; more = OpenMP over reads in the two counting sweeps (same results)."""
+        self.lib.orc_set_threads(int(n))
+
+    def max_threads(self):
+        return int(self.lib.orc_max_threads())
 
     def pileup(self, msa):
         msa = np.ascontiguousarray(msa, dtype=np.uint8)

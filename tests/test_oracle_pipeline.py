@@ -195,3 +195,18 @@ def test_pack_roundtrip():
         # pad nibbles are 6 (uncovered)
         full = msa.unpack_columns(p, p.shape[1] * 2)
         assert (full[n:] == 6).all()
+
+
+def test_openmp_sweeps_give_identical_results(oracle, c1):
+    """The all-cores CPU baseline (OpenMP over reads) is the same restatement: identical counts and calls."""
+    sp, ref, rows = c1
+    genes = np.array([(1, 3001), (2, 2999)], dtype=oracle_lib.GENE)
+    a = oracle.call(rows, genes, refseq=ref, params=oracle_lib.default_params(alpha=0.3, n_tests=1))
+    col_a = oracle.pileup(rows)
+    oracle.set_threads(min(4, oracle.max_threads()))
+    try:
+        b = oracle.call(rows, genes, refseq=ref, params=oracle_lib.default_params(alpha=0.3, n_tests=1))
+        col_b = oracle.pileup(rows)
+    finally:
+        oracle.set_threads(1)
+    assert (a == b).all() and (col_a == col_b).all() and len(a) > 0
