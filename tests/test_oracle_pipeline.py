@@ -210,3 +210,22 @@ def test_openmp_sweeps_give_identical_results(oracle, c1):
     finally:
         oracle.set_threads(1)
     assert (a == b).all() and (col_a == col_b).all() and len(a) > 0
+
+
+def test_appendix_a_fixture_relationships():
+    """The transcribed screenshot numbers themselves satisfy the relationships the SPEC is built on."""
+    import json
+    import os
+    a = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "appendix_a.json")))
+    rows = a["a1_context_k65"]["rows"]
+    assert all(sum(r) == 2998 for r in rows.values())                       # one symbol per read and column
+    real = [sum(rows[k][:4]) for k in ("0", "1", "2")]
+    bad = [sum(rows[k][4:]) for k in ("0", "1", "2")]
+    assert 2998 - sum(bad) <= a["a1_context_k65"]["coverage"] <= min(real)  # coverage = reads with three real bases
+    assert f"{100.0 * rows['1'][2] / a['a1_context_k65']['coverage']:.2g}" == a["a1_context_k65"]["percent_shown"]
+    assert abs(sum(a["a3_phasing_percent"]) - 100.0) < 1e-9                 # haplotype percentages sum to 100
+    w = a["a3_weakest_variant"]
+    assert round(w["percent"] / 100 * w["coverage"]) == 21                   # the SPEC §5 threshold anchor
+    c = a["a4_categories"]
+    assert c["reported"] + c["insufficient"] + c["damaged"] == c["total"]   # doc/JULIET.md:378-379
+    assert c["marginal_gaps"] + c["marginal_heteroduplexes"] + c["marginal_partial"] > c["damaged"]   # marginals overlap
