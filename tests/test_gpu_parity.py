@@ -701,3 +701,38 @@ def test_variant_table_overflow_is_reported(oracle):
         j.run(genes, ref, loose, phasing=False)
     assert e.value.status == -5
     j.close()
+
+
+def test_fused_grouping_with_thousands_of_distinct_patterns(jl, oracle):
+    """Vp = 10 (single-word keys, fused kernel) on reads so noisy that a 2048-read block holds more distinct
+    patterns than its 1024-slot LDS table: the overflow path inserts straight into the global table, and the
+    global table itself sees long probe sequences.  Grouping must stay exact."""
+    n, l = 9000, 60
+    sp = synth.SynthParams(seed=77, sub_rate=0.12, del_rate=0.0, mask_rate=0.0, minor_permille=(100, 100, 100, 100))
+    ref = synth.reference(sp.seed, l)
+    rows = synth.rows(sp, l, 0, n, ref)
+    genes = np.array([(1, l + 1)], dtype=capi.GENE)
+    loose = capi.default_params(alpha=0.9, n_tests=1.0)
+    jl.upload_columns(msa.pack_columns(rows), n)
+    jl.pileup_async(genes, ref)
+    jl.call_async(loose)
+    table = jl.call_fetch()
+    cols = np.unique(table["col"])[:10]
+    sub = table[np.isin(table["col"], cols)]
+    assert len(cols) == 10
+    for min_reads in (1, 2, 10):
+        jl.phase_async(sub, min_reads=min_reads)
+        try:
+            got = jl.phase_fetch(cap_var=len(sub))
+        except capi.JulietError as e:
+            # more than 4096 groups reach min_reads = 1: documented capacity of the selector
+            assert e.status == -5 and min_reads == 1
+            continue
+        exp = oracle.phase(rows, sub, min_reads=min_reads)
+        assert exp["summary"]["n_positions"] == 10
+        assert_phase_equal(got, exp, len(sub))
+    exp1 = oracle.phase(rows, sub, min_reads=1)
+    assert exp1["summary"]["reported_reads"] + exp1["summary"]["insufficient_reads"] == n   # no damaged reads here
+    # distinct patterns per 2048-read block exceed the LDS table
+    pat = np.stack([rows[:2048, c] * 16 + rows[:2048, c + 1] * 4 + rows[:2048, c + 2] for c in cols], axis=1)
+    assert len(np.unique(pat, axis=0)) > 1024
