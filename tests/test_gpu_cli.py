@@ -21,6 +21,13 @@ N, L, SEED = 6000, 900, 4
 MINOR = (60, 50, 40, 30)
 
 
+@pytest.fixture(scope="module", autouse=True)
+def built():
+    """The binaries normally travel with the tree; rebuild them if they are missing or stale."""
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "minorseq_amd", "csrc")])
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "minorseq_amd", "host")])
+
+
 @pytest.fixture(scope="module")
 def sample(tmp_path_factory):
     d = tmp_path_factory.mktemp("cli")
