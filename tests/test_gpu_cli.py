@@ -23,9 +23,11 @@ MINOR = (60, 50, 40, 30)
 
 @pytest.fixture(scope="module", autouse=True)
 def built():
-    """The binaries normally travel with the tree; rebuild them if they are missing or stale."""
-    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "minorseq_amd", "csrc")])
-    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "minorseq_amd", "host")])
+    """The binaries normally travel with the tree; build them only if they are missing (never under a loaded .so)."""
+    if not os.path.exists(os.path.join(ROOT, "minorseq_amd", "libjuliet_hip.so")):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "minorseq_amd", "csrc")])
+    if not (os.path.exists(JULIET) and os.path.exists(SYNTH)):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "minorseq_amd", "host")])
 
 
 @pytest.fixture(scope="module")
