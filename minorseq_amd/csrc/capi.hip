@@ -201,7 +201,7 @@ void jl_ctx_destroy(jl_ctx *ctx)
     if (ctx->h_pack) hipHostFree(ctx->h_pack);
     if (ctx->h_read_hap) hipHostFree(ctx->h_read_hap);
     free_msa(ctx);
-    void *ptrs[] = {ctx->d_pos_gene, ctx->d_pos_codon, ctx->d_pos_col, ctx->d_pos_refcfg, ctx->d_colflag, ctx->d_guess,
+    void *ptrs[] = {ctx->d_pos_gene, ctx->d_pos_codon, ctx->d_pos_col, ctx->d_pos_refcfg, ctx->d_colflag, ctx->d_guess, ctx->d_chunk_c0, ctx->d_chunk_n,
                     ctx->d_counts, ctx->d_called, ctx->d_cand_p, ctx->d_cand_lp, ctx->d_cand_e, ctx->d_pos_cov,
                     ctx->d_pos_ref, ctx->d_drm, ctx->d_variants, ctx->d_nvar, ctx->d_meta, ctx->d_vpcols,
                     ctx->d_col2pos, ctx->d_varcol, ctx->d_keys, ctx->d_flagw, ctx->d_read_slot, ctx->d_read_hap,
@@ -411,6 +411,52 @@ static int reserve_columns(jl_ctx *ctx)
     return JL_OK;
 }
 
+// Column chunks of the pileup kernel.  Measured on MI355X: 3-column chunks that START ON A CODON
+// need no halo columns and run fastest; where reading frames mix densely, 6-column chunks amortise the
+// two halo columns.  The walk below starts a chunk at every codon start it meets, so stretches that are
+// locally single-frame (different genes in different frames, as in HIV) stay halo-free.
+static void build_chunks(jl_ctx *ctx, const std::vector<uint8_t> &colflag, std::vector<uint32_t> &c0s,
+                         std::vector<uint8_t> &ns)
+{
+    const uint32_t L = ctx->n_cols;
+    size_t per_frame[3] = {0, 0, 0}, total = 0;
+    for (uint32_t c = 0; c < L; ++c)
+        if (colflag[c] & 1) { per_frame[c % 3]++; ++total; }
+    const size_t major = std::max(per_frame[0], std::max(per_frame[1], per_frame[2]));
+    // dense mixing = more than a quarter of the codon starts fall outside their neighbourhood's frame; estimated
+    // globally by counting starts that have another start within the two following columns
+    size_t crowded = 0;
+    for (uint32_t c = 0; c + 2 < L; ++c)
+        if ((colflag[c] & 1) && ((colflag[c + 1] & 1) || (colflag[c + 2] & 1))) ++crowded;
+    const char *env_w = getenv("JL_PILEUP_W");
+    uint32_t W = (total && crowded * 4 > total) ? 6u : 3u;
+    if (env_w && *env_w) W = (uint32_t)atoi(env_w) % 100u;
+    if (W != 3 && W != 6 && W != 9 && W != 12) W = 3;
+    (void)major;
+    ctx->pileup_w = W;
+    c0s.clear();
+    ns.clear();
+    if (W != 3) {  // uniform grid
+        for (uint32_t c = 0; c < L; c += W) { c0s.push_back(c); ns.push_back((uint8_t)std::min(W, L - c)); }
+        return;
+    }
+    uint32_t c = 0;
+    while (c < L) {
+        if (colflag[c] & 1) {  // chunk = this codon's three columns
+            const uint32_t n = std::min(3u, L - c);
+            c0s.push_back(c);
+            ns.push_back((uint8_t)n);
+            c += n;
+        } else {  // filler up to the next codon start (or three columns)
+            uint32_t n = 1;
+            while (n < 3 && c + n < L && !(colflag[c + n] & 1)) ++n;
+            c0s.push_back(c);
+            ns.push_back((uint8_t)n);
+            c += n;
+        }
+    }
+}
+
 // SPEC §3: evaluated positions of every gene, in (gene, k) order
 static int build_plan(jl_ctx *ctx, const jl_gene *genes, uint32_t n_genes, const uint8_t *refseq, uint32_t ref_len)
 {
@@ -445,13 +491,9 @@ static int build_plan(jl_ctx *ctx, const jl_gene *genes, uint32_t n_genes, const
     }
     ctx->default_n_tests = n_tests;
     ctx->P = (uint32_t)ctx->h_pos_col.size();
-    {   // which reading frames occur: decides the pileup kernel's chunk width and alignment
-        bool seen[3] = {false, false, false};
-        for (uint32_t c : ctx->h_pos_col) seen[c % 3] = true;
-        const int nf = (int)seen[0] + (int)seen[1] + (int)seen[2];
-        ctx->pileup_multi_frame = nf > 1;
-        ctx->pileup_frame = seen[1] ? 1u : seen[2] ? 2u : 0u;
-    }
+    std::vector<uint32_t> chunk_c0;
+    std::vector<uint8_t> chunk_n;
+    build_chunks(ctx, colflag, chunk_c0, chunk_n);
     if (refseq)
         for (uint32_t c = 0; c < ctx->n_cols; ++c) {
             const uint64_t r = (uint64_t)c + ctx->win_begin;
@@ -475,7 +517,15 @@ static int build_plan(jl_ctx *ctx, const jl_gene *genes, uint32_t n_genes, const
         if ((rc = regrow(ctx, &ctx->d_drm, P))) return rc;
         ctx->pos_capacity = P;
     }
+    ctx->n_chunks = (uint32_t)chunk_c0.size();
+    if (ctx->chunk_capacity < chunk_c0.size()) {
+        if ((rc = regrow(ctx, &ctx->d_chunk_c0, chunk_c0.size()))) return rc;
+        if ((rc = regrow(ctx, &ctx->d_chunk_n, chunk_c0.size()))) return rc;
+        ctx->chunk_capacity = chunk_c0.size();
+    }
     hipStream_t st = ctx->stream;
+    JL_HIP(ctx, hipMemcpyAsync(ctx->d_chunk_c0, chunk_c0.data(), chunk_c0.size() * 4, hipMemcpyHostToDevice, st));
+    JL_HIP(ctx, hipMemcpyAsync(ctx->d_chunk_n, chunk_n.data(), chunk_n.size(), hipMemcpyHostToDevice, st));
     JL_HIP(ctx, hipMemcpyAsync(ctx->d_colflag, colflag.data(), ctx->n_cols, hipMemcpyHostToDevice, st));
     JL_HIP(ctx, hipMemcpyAsync(ctx->d_guess, guess.data(), ctx->n_cols, hipMemcpyHostToDevice, st));
     if (ctx->P) {

@@ -92,8 +92,12 @@ struct jl_ctx {
     uint32_t *d_hist = nullptr;
     size_t counts_words = 0;
     bool pileup_done = false;
-    bool pileup_multi_frame = false;  // codon starts fall in more than one frame (halo columns needed)
-    uint32_t pileup_frame = 0;        // the frame (start column mod 3) of a single-frame plan
+    // pileup chunk table (host-built, see build_chunks): chunk k owns columns [c0, c0 + n), n <= pileup_w
+    uint32_t pileup_w = 3;
+    uint32_t n_chunks = 0;
+    uint32_t *d_chunk_c0 = nullptr;
+    uint8_t *d_chunk_n = nullptr;
+    size_t chunk_capacity = 0;
 
     // ---- call
     uint64_t *d_called = nullptr;  // [P] mask of called codons

@@ -100,11 +100,12 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 template <int W, bool NT>
 __device__ __forceinline__ void load_tile(tile_regs<W> &r, const uint8_t *__restrict__ msa, uint64_t col_stride,
-                                          uint32_t n_cols, uint32_t c0, uint64_t off, bool need_halo)
+                                          uint32_t n_cols, uint32_t c0, uint32_t ncols, uint64_t off, bool need_halo)
 {
 #pragma unroll
     for (int j = 0; j < W + 2; ++j) {
-        const bool live = (c0 + j < n_cols) && (j < W || need_halo);
+        // own columns j < ncols; the two columns after them only when a codon of this chunk reaches into them
+        const bool live = (c0 + j < n_cols) && ((uint32_t)j < ncols || (need_halo && (uint32_t)j < ncols + 2u));
         if (live) {
             const u32x4 *src = reinterpret_cast<const u32x4 *>(msa + (uint64_t)(c0 + j) * col_stride + off);
             // every cell is read exactly once: a non-temporal load keeps the stream from displacing L2 lines
@@ -118,7 +119,9 @@ __device__ __forceinline__ void load_tile(tile_regs<W> &r, const uint8_t *__rest
 
 template <int W, bool PIPE, int MODE>
 __global__ __launch_bounds__(256) void pileup_kernel(const uint8_t *__restrict__ msa, uint64_t col_stride,
-                                                      uint32_t n_cols, uint32_t n_tiles, uint32_t shift,
+                                                      uint32_t n_cols, uint32_t n_tiles,
+                                                      const uint32_t *__restrict__ chunk_c0,
+                                                      const uint8_t *__restrict__ chunk_n,
                                                       const uint8_t *__restrict__ colflag,
                                                       const uint8_t *__restrict__ guess,
                                                       uint32_t *__restrict__ counts, uint32_t *__restrict__ hist)
@@ -128,9 +131,10 @@ __global__ __launch_bounds__(256) void pileup_kernel(const uint8_t *__restrict__
     __shared__ uint32_t s_match[W];
 
     const uint32_t tid = threadIdx.x;
-    // chunk grid shifted so that chunk boundaries coincide with codon boundaries of a single-frame plan;
-    // columns "before 0" wrap to huge unsigned values and fail every `< n_cols` test
-    const uint32_t c0 = blockIdx.x * W - shift;
+    // chunks come from a host-built table: each starts on a codon boundary of the locally dominant frame, so
+    // single-frame stretches never need halo columns even when different genes use different frames
+    const uint32_t c0 = chunk_c0[blockIdx.x];
+    const uint32_t ncols = chunk_n[blockIdx.x];   // own columns, 1..W
 
     for (uint32_t i = tid; i < W * 64; i += 256) (&s_hist[0][0])[i] = 0;
     if (tid < W * 6) (&s_col[0][0])[tid] = 0;
@@ -145,9 +149,9 @@ __global__ __launch_bounds__(256) void pileup_kernel(const uint8_t *__restrict__
         const uint32_t c = c0 + j;
         const uint32_t b = c < n_cols ? guess[c] & 3u : 0u;
         g[j] = b * kM1;
-        if (j < W && c < n_cols && (colflag[c] & 1u)) startf |= 1u << j;
+        if ((uint32_t)j < ncols && c < n_cols && (colflag[c] & 1u)) startf |= 1u << j;
     }
-    const bool need_halo = (startf >> (W - 2)) != 0;
+    const bool need_halo = ncols >= 2u ? (startf >> (ncols - 2u)) != 0 : startf != 0;
     const bool last_lane = (tid & 63u) == 63u;
     const uint64_t lane_off = (uint64_t)tid * 16u;
 
@@ -157,7 +161,7 @@ __global__ __launch_bounds__(256) void pileup_kernel(const uint8_t *__restrict__
     if (PIPE && tile < n_tiles) {
         const uint64_t off = (uint64_t)tile * JL_PILEUP_TILE_BYTES + lane_off;
         nxt_live = off < col_stride;
-        if (nxt_live) load_tile<W, (MODE & 4) != 0>(nxt, msa, col_stride, n_cols, c0, off, need_halo);
+        if (nxt_live) load_tile<W, (MODE & 4) != 0>(nxt, msa, col_stride, n_cols, c0, ncols, off, need_halo);
     }
 
     while (tile < n_tiles) {
@@ -182,12 +186,12 @@ __global__ __launch_bounds__(256) void pileup_kernel(const uint8_t *__restrict__
                 if (tn < n_tiles) {
                     const uint64_t off = (uint64_t)tn * JL_PILEUP_TILE_BYTES + lane_off;
                     nxt_live = off < col_stride;
-                    if (nxt_live) load_tile<W, (MODE & 4) != 0>(nxt, msa, col_stride, n_cols, c0, off, need_halo);
+                    if (nxt_live) load_tile<W, (MODE & 4) != 0>(nxt, msa, col_stride, n_cols, c0, ncols, off, need_halo);
                 }
             } else {
                 const uint64_t off = (uint64_t)tile * JL_PILEUP_TILE_BYTES + lane_off;
                 live = off < col_stride;  // col_stride is a multiple of 128: a 16-B chunk is all in or all out
-                if (live) load_tile<W, (MODE & 4) != 0>(cur, msa, col_stride, n_cols, c0, off, need_halo);
+                if (live) load_tile<W, (MODE & 4) != 0>(cur, msa, col_stride, n_cols, c0, ncols, off, need_halo);
             }
             if (!live) continue;
             words += 4;
@@ -200,7 +204,7 @@ __global__ __launch_bounds__(256) void pileup_kernel(const uint8_t *__restrict__
             }
 #pragma unroll
             for (int j = 0; j < W; ++j) {
-                if (c0 + j < n_cols) {
+                if ((uint32_t)j < ncols) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         if (MODE & 2) measure_popc(cur.d[j][q], acc[j]);
@@ -252,7 +256,7 @@ __global__ __launch_bounds__(256) void pileup_kernel(const uint8_t *__restrict__
             const uint32_t p1 = wave_sum(nG | (nT << 16));
             const uint32_t p2 = wave_sum(nD | (nN << 16));
             const uint32_t p3 = wave_sum((nib - mism[j]) & 0xFFFFu);  // reads equal to the seed codon
-            if (last_lane && c0 + j < n_cols) {
+            if (last_lane && (uint32_t)j < ncols) {
                 if (p0 & 0xFFFFu) atomicAdd(&s_col[j][0], p0 & 0xFFFFu);
                 if (p0 >> 16) atomicAdd(&s_col[j][1], p0 >> 16);
                 if (p1 & 0xFFFFu) atomicAdd(&s_col[j][2], p1 & 0xFFFFu);
@@ -268,7 +272,7 @@ __global__ __launch_bounds__(256) void pileup_kernel(const uint8_t *__restrict__
     if (tid < W * 6) {
         const uint32_t j = tid / 6u, k = tid - j * 6u;
         const uint32_t v = s_col[j][k];
-        if (v && c0 + j < n_cols) atomicAdd(counts + (uint64_t)(c0 + j) * 6u + k, v);
+        if (v && j < ncols) atomicAdd(counts + (uint64_t)(c0 + j) * 6u + k, v);
     }
     if (tid < W && (startf & (1u << tid))) {
         // reads equal to the seed codon were only counted, never binned
@@ -318,8 +322,8 @@ __global__ __launch_bounds__(64) void guess_kernel(const uint8_t *__restrict__ m
 struct variant_t {
     int w;
     bool pipe;
-    void (*fn)(const uint8_t *, uint64_t, uint32_t, uint32_t, uint32_t, const uint8_t *, const uint8_t *, uint32_t *,
-               uint32_t *);
+    void (*fn)(const uint8_t *, uint64_t, uint32_t, uint32_t, const uint32_t *, const uint8_t *, const uint8_t *,
+               const uint8_t *, uint32_t *, uint32_t *);
 };
 
 // Default builds use non-temporal loads: every cell is read once, and at 2.4 GB they lift the stream from 5.6 to
@@ -357,15 +361,17 @@ void jl_launch_guess(jl_ctx *ctx)
 
 static int pick_variant(const jl_ctx *ctx)
 {
-    // Measured on MI355X: 3-column chunks aligned to the codon frame when every codon of the plan
-    // is in one frame (no halo columns); 6-column chunks when frames mix (halo re-reads amortised).
-    // Environment variables override for tuning.
-    const int want_w = env_int("JL_PILEUP_W", ctx->pileup_multi_frame ? 6 : 3);
+    // The chunk table was built for ctx->pileup_w columns per chunk (capi.hip: build_chunks); the kernel
+    // variant must match it.  JL_PILEUP_PIPE selects the register-prefetching build (tuning).
+    const int want_w = (int)ctx->pileup_w;
     const bool want_pipe = env_int("JL_PILEUP_PIPE", JL_PILEUP_PIPE) != 0;
-    int idx = 0;
+    int idx = -1;
     for (int i = 0; i < (int)(sizeof(kVariants) / sizeof(kVariants[0])); ++i)
         if (kVariants[i].w == want_w && kVariants[i].pipe == want_pipe) idx = i;
-    return idx;
+    if (idx < 0)
+        for (int i = 0; i < (int)(sizeof(kVariants) / sizeof(kVariants[0])); ++i)
+            if (kVariants[i].w == want_w && !kVariants[i].pipe) idx = i;
+    return idx < 0 ? 0 : idx;
 }
 
 // occupancy query, once per variant and outside any stream capture
@@ -385,9 +391,7 @@ void jl_launch_pileup(jl_ctx *ctx)
     const int idx = pick_variant(ctx);
     const variant_t *var = &kVariants[idx];
     jl_prepare_pileup(ctx);
-    const uint32_t W = (uint32_t)(var->w % 100);
-    const uint32_t shift = ctx->pileup_multi_frame ? 0u : (W - ctx->pileup_frame % W) % W;
-    const uint32_t n_chunks = (ctx->n_cols + shift + W - 1) / W;
+    const uint32_t n_chunks = ctx->n_chunks;
     const uint32_t n_tiles = (uint32_t)((ctx->col_stride + JL_PILEUP_TILE_BYTES - 1) / JL_PILEUP_TILE_BYTES);
     // one resident wave of blocks: (CUs x blocks the kernel's registers admit per CU), reads split no finer than a tile
     const int per_cu = ctx->pileup_blocks_per_cu[idx];
@@ -400,5 +404,5 @@ void jl_launch_pileup(jl_ctx *ctx)
     if (rsplit < 1) rsplit = 1;
     if (rsplit > 65535u) rsplit = 65535u;
     hipLaunchKernelGGL(var->fn, dim3(n_chunks, rsplit), dim3(256), 0, ctx->stream, ctx->d_msa, ctx->col_stride,
-                       ctx->n_cols, n_tiles, shift, ctx->d_colflag, ctx->d_guess, ctx->d_counts, ctx->d_hist);
+                       ctx->n_cols, n_tiles, ctx->d_chunk_c0, ctx->d_chunk_n, ctx->d_colflag, ctx->d_guess, ctx->d_counts, ctx->d_hist);
 }

@@ -736,3 +736,34 @@ def test_fused_grouping_with_thousands_of_distinct_patterns(jl, oracle):
     # distinct patterns per 2048-read block exceed the LDS table
     pat = np.stack([rows[:2048, c] * 16 + rows[:2048, c + 1] * 4 + rows[:2048, c + 2] for c in cols], axis=1)
     assert len(np.unique(pat, axis=0)) > 1024
+
+
+# --------------------------------------------------------------------------------------------- chunk table
+@pytest.mark.parametrize("n,l", [(5000, 700), (8200, 301), (300, 40)])
+def test_pileup_genes_in_different_frames(jl, oracle, n, l):
+    """HIV-like layout: consecutive genes in different reading frames plus a short overlap (p6/protease style,
+    SURVEY A.5).  The chunk table keeps every single-frame stretch halo-free; results must not depend on it."""
+    sp = synth.SynthParams(seed=n + l, partial_rate=0.2, mask_rate=0.03, del_rate=0.01, sub_rate=0.01,
+                           minor_permille=(60, 50, 40, 30))
+    ref = synth.reference(sp.seed, l)
+    rows = synth.rows(sp, l, 0, n, ref)
+    third = l // 3
+    def begin_in_frame(near, frame):          # smallest 1-based begin >= near whose 0-based start is in `frame`
+        b = near
+        while (b - 1) % 3 != frame:
+            b += 1
+        return b
+    genes = np.array([(begin_in_frame(2, 1), third + 1), (begin_in_frame(third + 2, 2), 2 * third + 2),
+                      (begin_in_frame(max(1, 2 * third - 20), 0), l - 1), (5, 9), (l - 4, l + 5)], dtype=capi.GENE)
+    assert len({(int(g["begin"]) - 1) % 3 for g in genes[:3]}) >= 2          # really different frames
+    jl.upload_columns(msa.pack_columns(rows), n)
+    for refseq in (ref, None):
+        jl.pileup_async(genes, refseq)
+        got = jl.pileup_fetch()
+        assert (got["col_counts"] == oracle.pileup(rows)).all()
+        hist, cov = oracle.codon_hist(rows, got["pos_col"])
+        assert (got["hist"] == hist).all() and (got["coverage"] == cov).all()
+    out = jl.run(genes, ref, capi.default_params(alpha=0.3, n_tests=1.0))
+    exp_v = oracle.call(rows, genes, refseq=ref, params=oracle_lib.default_params(alpha=0.3, n_tests=1.0))
+    assert_variants_equal(out["variants"], exp_v)
+    assert_phase_equal(out["phase"], oracle.phase(rows, exp_v), len(exp_v))
