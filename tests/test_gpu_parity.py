@@ -767,3 +767,33 @@ def test_pileup_genes_in_different_frames(jl, oracle, n, l):
     exp_v = oracle.call(rows, genes, refseq=ref, params=oracle_lib.default_params(alpha=0.3, n_tests=1.0))
     assert_variants_equal(out["variants"], exp_v)
     assert_phase_equal(out["phase"], oracle.phase(rows, exp_v), len(exp_v))
+
+
+# --------------------------------------------------------------------------------------------- torch plumbing
+def test_adopted_torch_tensor_and_caller_stream(oracle):
+    """PyTorch as plumbing only: the resident matrix lives in a torch tensor (jl_msa_adopt) and all work of the
+    context is enqueued on a torch stream the caller owns."""
+    import torch
+    n, l = 5000, 300
+    sp = synth.SynthParams(seed=19, minor_permille=(70, 60, 50, 40), partial_rate=0.1)
+    ref = synth.reference(sp.seed, l)
+    rows = synth.rows(sp, l, 0, n, ref)
+    packed = msa.pack_columns(rows)
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        t = torch.from_numpy(packed).cuda(non_blocking=False)
+    stream.synchronize()
+    j = capi.Juliet(0, stream=stream.cuda_stream)
+    j.adopt(t.data_ptr(), n, l, packed.shape[1], keep_alive=t)
+    genes = np.array([(1, l + 1)], dtype=capi.GENE)
+    out = j.run(genes, ref)
+    exp_v = oracle.call(rows, genes, refseq=ref)
+    assert_variants_equal(out["variants"], exp_v)
+    assert_phase_equal(out["phase"], oracle.phase(rows, exp_v), len(exp_v))
+    # work really was ordered on the caller's stream: a torch op enqueued behind it sees the finished table
+    j.run_async(genes, ref)
+    rows_ptr, cnt_ptr, cap = j.variant_table_device()
+    assert cap == capi.VARIANT_CAP and rows_ptr and cnt_ptr
+    stream.synchronize()
+    j.close()
+    del t
