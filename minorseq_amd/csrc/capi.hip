@@ -815,6 +815,8 @@ static void enqueue_path(jl_ctx *ctx, const jl_params *prm, double n_tests, bool
     // no copy nodes: the result block and the per-read ids are stored straight into pinned host memory by the
     // kernels that produce them (ctx->pack_mirror / ctx->read_hap_out, set by jl_run_async)
     (void)want_read_hap;
+    if (const char *e = getenv("JL_DUMMY_NODES"))   // tuning probe (tools_tuning/): cost of extra dependent nodes
+        for (int k = atoi(e); k > 0; --k) jl_launch_noop(ctx);
 }
 
 int jl_run_async(jl_ctx *ctx, const jl_gene *genes, uint32_t n_genes, const uint8_t *refseq, uint32_t ref_len,

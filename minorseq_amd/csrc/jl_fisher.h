@@ -94,6 +94,27 @@ JL_FHD double jl_log_pmf_equal_rows(double x, double K, double n)
     return s + 0.5 * log((K * L * n * n) / (TWO_PI * x * c * nx * nc * M));
 }
 
+// P(X = x) for K = (row sums' first column total) <= 64 by direct products — the common case (a noise codon
+// seen a few dozen times against an expected count of a few): ~2K multiplications and K/16 + 1 divisions
+// instead of the logs, divisions and series of the saddle-point form.  Relative error <= ~K * 1e-16.
+//   P = C(K, x) * prod_{i<x} (n - i) * prod_{i<K-x} (n - i) / prod_{i<K} (2n - i)
+JL_FHD double jl_pmf_equal_rows_small(double x, double K, double n)
+{
+    const double c = K - x;
+    const double M = 2.0 * n;
+    double num = 1.0, den = 1.0, p = 1.0;
+    int pending = 0;
+    for (double i = 0.0; i < K; i += 1.0) {
+        num *= i < x ? n - i : n - (i - x);
+        den *= M - i;
+        if (++pending == 16) { p *= num / den; num = 1.0; den = 1.0; pending = 0; }  // keep both below 1e160
+    }
+    // binomial coefficient C(K, min(x, c)): at most 32 factors, value < 2^64
+    const double m = x < c ? x : c;
+    for (double i = 0.0; i < m; i += 1.0) { num *= K - i; den *= i + 1.0; }
+    return p * (num / den);
+}
+
 // P(X >= a) for the table [[a, n-a], [c, n-c]] (both rows sum to n); returns p, *logp = ln p
 JL_FHD double jl_fisher_greater_equal_rows(uint32_t a_, uint32_t c_, uint32_t n_, double *logp)
 {
@@ -102,6 +123,29 @@ JL_FHD double jl_fisher_greater_equal_rows(uint32_t a_, uint32_t c_, uint32_t n_
     const double hi = K < n ? K : n;
     const double lo = K > n ? K - n : 0.0;
     if (a <= lo) { *logp = 0.0; return 1.0; }
+    if (K <= 64.0) {  // direct products (no log/exp until the very end)
+        if (a > c) {
+            double term = 1.0, sum = 1.0;
+            for (double x = a; x < hi; x += 1.0) {
+                term *= ((K - x) * (n - x)) / ((x + 1.0) * (n - K + x + 1.0));
+                sum += term;
+            }
+            double pv = jl_pmf_equal_rows_small(a, K, n) * sum;
+            if (pv > 1.0) pv = 1.0;
+            *logp = log(pv);
+            return pv;
+        }
+        const double x0 = a - 1.0;
+        double term = 1.0, sum = 1.0;
+        for (double x = x0; x > lo; x -= 1.0) {
+            term *= (x * (n - K + x)) / ((K - x + 1.0) * (n - x + 1.0));
+            sum += term;
+        }
+        double lower = jl_pmf_equal_rows_small(x0, K, n) * sum;
+        if (lower > 1.0) lower = 1.0;
+        *logp = lower < 1.0 ? log1p(-lower) : -HUGE_VAL;
+        return 1.0 - lower;
+    }
     if (a > c) {  // above the mean K/2: sum the decreasing upper tail
         const double l0 = jl_log_pmf_equal_rows(a, K, n);
         double term = 1.0, sum = 1.0;
