@@ -210,14 +210,13 @@ __device__ __forceinline__ uint32_t global_insert64(uint64_t key, uint32_t cnt, 
 {
     uint64_t s = mix64(key + 0x9E3779B97F4A7C15ull) & slots_mask;
     for (;;) {
-        unsigned long long old = __hip_atomic_load(&slot_key[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // one round trip: the CAS returns the resident key whether or not it installs ours (a block calls
+        // this once per distinct key, so the hot slot sees one CAS per 2048 reads)
+        unsigned long long old = atomicCAS(&slot_key[s], (unsigned long long)kNoKey, (unsigned long long)key);
         if (old == kNoKey) {
-            old = atomicCAS(&slot_key[s], (unsigned long long)kNoKey, (unsigned long long)key);
-            if (old == kNoKey) {
-                slot_rep[s] = first;  // any read carrying the key; select decodes the pattern from it
-                occupied[atomicAdd(&meta->n_occupied, 1u)] = (uint32_t)s;
-                old = key;
-            }
+            slot_rep[s] = first;  // any read carrying the key; select decodes the pattern from it
+            occupied[atomicAdd(&meta->n_occupied, 1u)] = (uint32_t)s;
+            old = key;
         }
         if (old == key) {
             atomicAdd(&slot_count[s], cnt);
@@ -390,8 +389,10 @@ __device__ __forceinline__ void result_pack_block(const jl_variant *__restrict__
                                                   const uint32_t *__restrict__ hap_count,
                                                   const uint8_t *__restrict__ hap_pattern,
                                                   const uint8_t *__restrict__ hit, const uint32_t *__restrict__ cooc,
-                                                  uint32_t cooc_cap, uint32_t cooc_ready, jl_pack *__restrict__ pk)
+                                                  uint32_t cooc_cap, uint32_t cooc_ready, jl_pack *__restrict__ pk,
+                                                  jl_pack *__restrict__ pk2)
 {
+    // pk: device copy (all-gather source); pk2: pinned host mirror (may be null) — both written directly
     const uint32_t tid = threadIdx.x, nt = blockDim.x;
     const uint32_t fits_call = n <= JL_PACK_MAX_VAR;
     uint32_t vp = 0, H = 0, nv = 0, ovf = 0, fits_phase = 0, cooc_fits = 0;
@@ -401,34 +402,30 @@ __device__ __forceinline__ void result_pack_block(const jl_variant *__restrict__
                      H * vp <= JL_PACK_PATTERN_BYTES && nv * H <= JL_PACK_HIT_BYTES;
         cooc_fits = cooc_ready && nv <= JL_PACK_COOC_N;
     }
-    if (tid == 0) {
-        pk->magic = JL_PACK_MAGIC; pk->nvar_total = n; pk->fits_call = fits_call; pk->fits_phase = fits_phase;
-        pk->phase_ran = phasing; pk->overflow = ovf; pk->vp = vp; pk->H = H;
-        pk->nv_phase = nv; pk->cooc_fits = cooc_fits;
-        if (phasing) pk->summary = meta->summary;
+    jl_pack *dsts[2] = {pk, pk2};
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        jl_pack *o = dsts[t];
+        if (!o) continue;
+        if (tid == 0) {
+            o->magic = JL_PACK_MAGIC; o->nvar_total = n; o->fits_call = fits_call; o->fits_phase = fits_phase;
+            o->phase_ran = phasing; o->overflow = ovf; o->vp = vp; o->H = H;
+            o->nv_phase = nv; o->cooc_fits = cooc_fits;
+            if (phasing) o->summary = meta->summary;
+        }
+        if (fits_call)
+            for (uint32_t i = tid; i < n * (uint32_t)(sizeof(jl_variant) / 8); i += nt)
+                reinterpret_cast<uint64_t *>(o->variants)[i] = reinterpret_cast<const uint64_t *>(variants)[i];
+        if (fits_phase) {
+            for (uint32_t i = tid; i < vp; i += nt) o->pos_cols[i] = vpcols[i];
+            for (uint32_t i = tid; i < H; i += nt) o->hap_count[i] = hap_count[i];
+            for (uint32_t i = tid; i < H * vp; i += nt)
+                o->hap_pattern[i] = hap_pattern[(uint64_t)(i / vp) * JL_VARIANT_CAP + (i % vp)];
+            for (uint32_t i = tid; i < nv * H; i += nt) o->hit[i] = hit[(uint64_t)(i / H) * JL_MAX_HAPLOTYPES + (i % H)];
+            if (cooc_fits)
+                for (uint32_t i = tid; i < nv * nv; i += nt) o->cooc[i] = cooc[(uint64_t)(i / nv) * cooc_cap + (i % nv)];
+        }
     }
-    if (fits_call)
-        for (uint32_t i = tid; i < n * (uint32_t)(sizeof(jl_variant) / 8); i += nt)
-            reinterpret_cast<uint64_t *>(pk->variants)[i] = reinterpret_cast<const uint64_t *>(variants)[i];
-    if (fits_phase) {
-        for (uint32_t i = tid; i < vp; i += nt) pk->pos_cols[i] = vpcols[i];
-        for (uint32_t i = tid; i < H; i += nt) pk->hap_count[i] = hap_count[i];
-        for (uint32_t i = tid; i < H * vp; i += nt)
-            pk->hap_pattern[i] = hap_pattern[(uint64_t)(i / vp) * JL_VARIANT_CAP + (i % vp)];
-        for (uint32_t i = tid; i < nv * H; i += nt) pk->hit[i] = hit[(uint64_t)(i / H) * JL_MAX_HAPLOTYPES + (i % H)];
-        if (cooc_fits)
-            for (uint32_t i = tid; i < nv * nv; i += nt) pk->cooc[i] = cooc[(uint64_t)(i / nv) * cooc_cap + (i % nv)];
-    }
-}
-
-// The finished block also goes straight to pinned host memory (zero-copy store over PCIe, 20 KB): no copy node.
-__device__ __forceinline__ void result_pack_mirror(const jl_pack *__restrict__ pk, jl_pack *__restrict__ mirror)
-{
-    if (!mirror) return;
-    __syncthreads();
-    const uint64_t *src = reinterpret_cast<const uint64_t *>(pk);
-    uint64_t *dst = reinterpret_cast<uint64_t *>(mirror);
-    for (uint32_t i = threadIdx.x; i < (uint32_t)(sizeof(jl_pack) / 8); i += blockDim.x) dst[i] = src[i];
 }
 
 __global__ __launch_bounds__(256) void result_pack_kernel(const jl_variant *__restrict__ variants,
@@ -437,8 +434,7 @@ __global__ __launch_bounds__(256) void result_pack_kernel(const jl_variant *__re
                                                            jl_pack *__restrict__ pk, jl_pack *__restrict__ mirror)
 {
     // phasing off: only the variant table
-    result_pack_block(variants, n_rows[0], meta, 0u, nullptr, nullptr, nullptr, nullptr, nullptr, 0u, 0u, pk);
-    result_pack_mirror(pk, mirror);
+    result_pack_block(variants, n_rows[0], meta, 0u, nullptr, nullptr, nullptr, nullptr, nullptr, 0u, 0u, pk, mirror);
 }
 
 // ---------------------------------------------------------------------------------------- select
@@ -559,8 +555,7 @@ __global__ __launch_bounds__(1024) void phase_select_kernel(uint32_t min_reads, 
     }
     }  // vp != 0
     __syncthreads();
-    result_pack_block(variants, n_rows[0], meta, 1u, vpcols, hap_count, hap_pattern, hit, cooc, cooc_cap, 1u, pk);
-    result_pack_mirror(pk, mirror);
+    result_pack_block(variants, n_rows[0], meta, 1u, vpcols, hap_count, hap_pattern, hit, cooc, cooc_cap, 1u, pk, mirror);
     // leave the table empty for the next run: only the slots this run touched
     for (uint32_t q = tid; q < n_occ; q += 1024u) {
         const uint32_t s = occupied[q];
