@@ -164,6 +164,12 @@ uint32_t jl_n_positions(const jl_ctx *ctx);
 int jl_pileup_fetch(jl_ctx *ctx, uint32_t *col_counts, uint32_t *pos_gene, uint32_t *pos_codon, uint32_t *pos_col,
                     uint32_t *hist, uint32_t *coverage);
 /*
+ * By-product of the pileup: per-column consensus (majority of A C G T -), the part of `fuse`
+ * (doc/FUSE.md:17-20) that needs no insertion tracking.  out[n_cols]: 0..3 base, 4 = majority deletion
+ * ("major deletions are being removed"), 5 = column without coverage.  Blocking.
+ */
+int jl_consensus_fetch(jl_ctx *ctx, uint8_t *out);
+/*
  * Reference/majority codon, error model, Fisher's exact x Bonferroni, filters, variant table
  * (SPEC §4-7; J:38-42).  `drm_masks`: optional [P] 64-bit codon masks; with --drm-only a codon is kept
  * only if its bit is set (J:370); NULL disables.  Table stays on the device; enqueues only.

@@ -30,7 +30,7 @@ SUMMARY = np.dtype([(n, "<u4") for n in SUMMARY_FIELDS])
 EXPORTS = ("jl_abi_version", "jl_strerror", "jl_device_count", "jl_ctx_create", "jl_ctx_destroy", "jl_last_error",
            "jl_sync", "jl_col_stride", "jl_msa_upload", "jl_msa_alloc", "jl_msa_adopt", "jl_msa_pack_rows",
            "jl_msa_ingest_records", "jl_msa_download", "jl_synth_fill", "jl_pileup_async", "jl_n_positions", "jl_pileup_fetch",
-           "jl_call_async", "jl_call_fetch", "jl_variant_table_device", "jl_phase_async", "jl_phase_fetch",
+           "jl_consensus_fetch", "jl_call_async", "jl_call_fetch", "jl_variant_table_device", "jl_phase_async", "jl_phase_fetch",
            "jl_run_async", "jl_fisher_eval", "jl_time_pileup", "jl_pileup_kernel_name", "jl_comm_unique_id", "jl_comm_create", "jl_comm_destroy",
            "jl_allgather_variants", "jl_allgather_variants_async", "jl_xwin_assemble_local",
            "jl_xwin_assemble_rccl")
@@ -101,6 +101,7 @@ def load_library(path=LIB_PATH):
     lib.jl_n_positions.argtypes = [vp]
     lib.jl_n_positions.restype = u32
     lib.jl_pileup_fetch.argtypes = [vp] * 7
+    lib.jl_consensus_fetch.argtypes = [vp, vp]
     lib.jl_call_async.argtypes = [vp, C.POINTER(Params), vp]
     lib.jl_call_fetch.argtypes = [vp, vp, u32, C.POINTER(u32)]
     lib.jl_variant_table_device.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(u32)]
@@ -228,6 +229,12 @@ class Juliet:
         cov = np.zeros(p, dtype=np.uint32)
         self._chk(self.lib.jl_pileup_fetch(self.h, _p(col), _p(pg), _p(pk), _p(pc), _p(hist), _p(cov)))
         return dict(col_counts=col, pos_gene=pg, pos_codon=pk, pos_col=pc, hist=hist, coverage=cov)
+
+    def consensus(self):
+        """Majority symbol per column of the last pileup: 0..3 base, 4 majority deletion, 5 uncovered."""
+        out = np.zeros(self.n_cols, dtype=np.uint8)
+        self._chk(self.lib.jl_consensus_fetch(self.h, _p(out)))
+        return out
 
     def call_async(self, params=None, drm_masks=None):
         prm = params or default_params()

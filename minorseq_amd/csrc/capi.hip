@@ -600,6 +600,19 @@ int jl_pileup_fetch(jl_ctx *ctx, uint32_t *col_counts, uint32_t *pos_gene, uint3
     return JL_OK;
 }
 
+// Column consensus of the last pileup (the `fuse` by-product): out[c] = 0..3 majority base,
+// 4 = majority deletion (column dropped from a consensus sequence), 5 = no covering read.
+int jl_consensus_fetch(jl_ctx *ctx, uint8_t *out)
+{
+    if (!ctx || !out) return JL_ERR_ARG;
+    if (!ctx->pileup_done) return jl_fail(ctx, JL_ERR_STATE, "jl_consensus_fetch before a pileup");
+    JL_HIP(ctx, hipSetDevice(ctx->device));
+    jl_launch_consensus(ctx, ctx->d_varcol);  // [n_cols] byte scratch, rewritten by every phase plan
+    JL_HIP(ctx, hipMemcpyAsync(out, ctx->d_varcol, ctx->n_cols, hipMemcpyDeviceToHost, ctx->stream));
+    JL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return JL_OK;
+}
+
 int jl_call_async(jl_ctx *ctx, const jl_params *prm, const uint64_t *drm_masks)
 {
     if (!ctx || !prm) return JL_ERR_ARG;

@@ -178,6 +178,7 @@ void jl_launch_pack_rows(jl_ctx *ctx, const uint8_t *d_rows);
 void jl_launch_result_pack(jl_ctx *ctx, bool phasing);
 void jl_launch_validate(jl_ctx *ctx, uint32_t *d_flag);
 void jl_launch_noop(jl_ctx *ctx);
+void jl_launch_consensus(jl_ctx *ctx, uint8_t *d_out);
 void jl_launch_ingest(jl_ctx *ctx, const int32_t *d_pos, const uint32_t *d_cigar, const uint64_t *d_cig_off,
                       const uint8_t *d_seq4, const uint64_t *d_seq_off, const uint8_t *d_qual,
                       const uint64_t *d_qual_off, uint32_t min_qv, uint8_t *d_rows);

@@ -138,6 +138,21 @@ __global__ __launch_bounds__(256) void ingest_kernel(uint64_t n_reads, uint32_t 
     }
 }
 
+// Per-column consensus from the pileup (doc/FUSE.md:17-20, the part that needs no insertion tracking):
+// majority among A C G T -; a column whose majority is '-' is marked removed (4); no covering read => 5.
+__global__ __launch_bounds__(256) void consensus_kernel(const uint32_t *__restrict__ counts, uint32_t n_cols,
+                                                         uint8_t *__restrict__ out)
+{
+    const uint32_t c = blockIdx.x * 256u + threadIdx.x;
+    if (c >= n_cols) return;
+    const uint32_t *k = counts + (uint64_t)c * 6u;
+    uint32_t best = 0, bv = k[0];
+#pragma unroll
+    for (uint32_t s = 1; s < 5; ++s)
+        if (k[s] > bv) { bv = k[s]; best = s; }
+    out[c] = bv == 0 ? (uint8_t)5 : (uint8_t)best;
+}
+
 // any nibble outside 0..6 (code 7 or bit 3 set) is rejected at upload (SPEC §1)
 __global__ __launch_bounds__(256) void validate_kernel(const uint8_t *__restrict__ msa, uint64_t n_bytes,
                                                         uint32_t *__restrict__ bad)
@@ -157,6 +172,12 @@ __global__ __launch_bounds__(256) void validate_kernel(const uint8_t *__restrict
 // tuning probe: what does one more (empty) dependent node cost a pipelined step?
 __global__ void noop_kernel(uint32_t *p) { if (p == nullptr && threadIdx.x == 12345u) *p = 0; }
 void jl_launch_noop(jl_ctx *ctx) { hipLaunchKernelGGL(noop_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->d_nvar); }
+
+void jl_launch_consensus(jl_ctx *ctx, uint8_t *d_out)
+{
+    hipLaunchKernelGGL(consensus_kernel, dim3((ctx->n_cols + 255u) / 256u), dim3(256), 0, ctx->stream, ctx->d_counts,
+                       ctx->n_cols, d_out);
+}
 
 void jl_launch_validate(jl_ctx *ctx, uint32_t *d_flag)
 {

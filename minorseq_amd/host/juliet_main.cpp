@@ -34,7 +34,7 @@ struct Options {
     uint32_t min_reads = 10, min_qv = 0;
     double min_rq = 0.0;
     int device = 0;
-    std::string dump_msa, dump_config;
+    std::string dump_msa, dump_config, consensus;
 };
 
 [[noreturn]] void usage(int code)
@@ -51,6 +51,7 @@ struct Options {
         "      --alpha 0.01  --n-tests <auto>  --chemistry auto|sequel|permissive\n"
         "      --match-rate <r> --substitution-rate <r> --expected-round ceil|floor|nearest\n"
         "      --min-reads 10  --min-qv 0  --min-rq 0  --device 0\n"
+        "      --consensus <out.fasta>         also write the window's majority consensus (fuse-style, no insertions)\n"
         "  diagnostics (no GPU needed): --dump-msa <file>  --dump-config <file>\n";
     std::exit(code);
 }
@@ -93,6 +94,7 @@ Options parse(int argc, char **argv)
         else if (a == "--min-qv") o.min_qv = (uint32_t)std::stoul(need(i));
         else if (a == "--min-rq") o.min_rq = std::stod(need(i));
         else if (a == "--device") o.device = std::stoi(need(i));
+        else if (a == "--consensus") o.consensus = need(i);
         else if (a == "--dump-msa") o.dump_msa = need(i);
         else if (a == "--dump-config") o.dump_config = need(i);
         else if (!a.empty() && a[0] == '-') { std::cerr << "juliet: unknown option " << a << "\n"; usage(1); }
@@ -326,6 +328,18 @@ int main(int argc, char **argv)
         std::vector<uint32_t> col_counts((size_t)n_cols * 6);
         if (jl_pileup_fetch(ctx, col_counts.data(), nullptr, nullptr, nullptr, nullptr, nullptr) != JL_OK) die_jl(ctx, "pileup fetch");
 
+        if (!opt.consensus.empty()) {  // by-product of the pileup (doc/FUSE.md:17-24): majority base, major deletions removed
+            std::vector<uint8_t> cons(n_cols);
+            if (jl_consensus_fetch(ctx, cons.data()) != JL_OK) die_jl(ctx, "consensus");
+            std::ofstream f(opt.consensus);
+            if (!f) { std::cerr << "juliet: cannot write " << opt.consensus << "\n"; return 2; }
+            f << ">consensus window=" << (win_begin + 1) << "-" << (win_begin + n_cols) << " source=" << opt.bam << "\n";
+            std::string seq;
+            for (uint8_t s : cons)
+                if (s < 4) seq += "ACGT"[s];
+                else if (s == 5) seq += 'N';      // uncovered; majority-deletion columns (4) are dropped
+            for (size_t i = 0; i < seq.size(); i += 70) f << seq.substr(i, 70) << "\n";
+        }
         jl_phase_summary ps = {};
         std::vector<uint32_t> pos_cols, hap_count;
         std::vector<uint8_t> hap_pattern, hit;

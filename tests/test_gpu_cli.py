@@ -156,3 +156,23 @@ def test_no_config_majority_mode_and_html(sample, oracle):
     # two outputs at once (doc/JULIET.md:65)
     subprocess.check_call([JULIET, "-c", cfg, bam, str(d / "both.html"), str(d / "both.json")])
     assert os.path.getsize(d / "both.html") > 0 and json.load(open(d / "both.json"))["genes"]
+
+
+def test_consensus_by_product(sample, oracle):
+    """--consensus: majority base per column, majority-deletion columns dropped (doc/FUSE.md:17-24, without insertions)."""
+    d, bam, cfg, rows, ref = sample
+    fa = str(d / "cons.fasta")
+    subprocess.check_call([JULIET, "-c", cfg, "--consensus", fa, bam, str(d / "c.json")])
+    lines = open(fa).read().splitlines()
+    assert lines[0].startswith(">consensus window=1-")
+    seq = "".join(lines[1:])
+    col = oracle.pileup(rows)
+    exp = ""
+    for c in range(L):
+        k = col[c, :5]
+        if k.max() == 0:
+            exp += "N"
+        elif int(k.argmax()) < 4:
+            exp += "ACGT"[int(k.argmax())]
+    assert seq[: len(exp)] == exp[: len(seq)] and abs(len(seq) - len(exp)) <= 5   # window may carry context columns
+    assert seq.startswith("".join("ACGT"[b] for b in ref[:50]))                 # the 96 % major clone is the reference

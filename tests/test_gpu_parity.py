@@ -161,6 +161,19 @@ def test_pileup_empty_and_degenerate(jl, oracle):
         msa.pack_columns(np.full((3, 3), 7, dtype=np.uint8))
 
 
+def test_consensus_of_pileup(jl, oracle):
+    rows = synth.rows(synth.SynthParams(seed=61, del_rate=0.02, partial_rate=0.3), 200, 0, 3000)
+    rows[:, 17] = msa.SYM_GAP          # a column whose majority is a deletion
+    rows[:, 50] = msa.SYM_NONE         # a column nobody covers
+    rows[:, 51] = msa.SYM_MASK         # only filtered bases: no A C G T - at all
+    jl.upload_columns(msa.pack_columns(rows), 3000)
+    jl.pileup_async(np.array([(1, 201)], dtype=capi.GENE))
+    got = jl.consensus()
+    col = oracle.pileup(rows)[:, :5]
+    exp = np.where(col.max(axis=1) == 0, 5, col.argmax(axis=1)).astype(np.uint8)
+    assert (got == exp).all() and got[17] == 4 and got[50] == 5 and got[51] == 5
+
+
 def test_seed_never_changes_results(jl, oracle):
     """A wrong reference (bad seed for the codon fast path) must give the same histograms."""
     sp = synth.SynthParams(seed=77, minor_permille=(200, 100, 100, 100))
