@@ -28,6 +28,8 @@ struct BamRecord {
     std::vector<uint8_t> seq4;    // the same bases as stored in BAM (two 4-bit codes per byte, high nibble first)
     std::vector<uint8_t> qual;    // phred, 0xFF when absent
     float rq = -1.f;              // predicted accuracy tag (doc/JULIET.md:56), -1 when absent
+    // rich QV tracks of `ccs --richQVs` (doc/JULIET.md:51-52, 256-259): per-base phred+33 strings, empty when absent
+    std::string dq, iq, sq;
 };
 
 class BamReader {
@@ -85,7 +87,8 @@ public:
         r.qual.assign(p + o, p + o + l_seq);
         o += l_seq;
         r.rq = -1.f;
-        // aux: only `rq` (float) is interpreted; everything else is skipped by type
+        r.dq.clear(); r.iq.clear(); r.sq.clear();
+        // aux: `rq` (float) and the rich-QV strings dq / iq / sq are interpreted; everything else is skipped by type
         while (o + 3 <= (size_t)block) {
             const char t0 = (char)p[o], t1 = (char)p[o + 1], ty = (char)p[o + 2];
             o += 3;
@@ -105,6 +108,10 @@ public:
             default: throw std::runtime_error("unknown BAM aux type");
             }
             if (t0 == 'r' && t1 == 'q' && ty == 'f') memcpy(&r.rq, p + o, 4);
+            if (ty == 'Z' && t1 == 'q' && (t0 == 'd' || t0 == 'i' || t0 == 's')) {
+                std::string &dst = t0 == 'd' ? r.dq : t0 == 'i' ? r.iq : r.sq;
+                dst.assign((const char *)p + o, len - 1);
+            }
             o += len;
         }
         return true;
@@ -168,6 +175,15 @@ public:
             put("rqf", 3);
             put(&r.rq, 4);
         }
+        auto put_z = [&](const char *tag, const std::string &v) {
+            if (v.empty()) return;
+            put(tag, 2);
+            b.push_back('Z');
+            put(v.c_str(), v.size() + 1);
+        };
+        put_z("dq", r.dq);
+        put_z("iq", r.iq);
+        put_z("sq", r.sq);
         (void)ref_len;
         wr<int32_t>((int32_t)b.size());
         out_.write(b.data(), b.size());

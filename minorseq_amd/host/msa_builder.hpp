@@ -9,9 +9,25 @@ namespace jlhost {
 
 struct IngestOptions {
     int ref_id = -1;        // -1: the reference of the first kept record
-    uint32_t min_qv = 0;    // bases below become N (UNPINNED threshold, SPEC / SURVEY C6); 0 = off
+    uint32_t min_qv = 0;    // bases whose lowest QV (QUAL and the rich-QV tracks dq/iq/sq when present) is below this
+                            // become N (doc/JULIET.md:256-259; threshold UNPINNED); 0 = off
     double min_rq = 0.0;    // skip reads with a lower rq tag; 0 = off (doc/JULIET.md:56 leaves this to the user)
 };
+
+// lowest phred over QUAL and whichever rich-QV tracks the record carries, per base (0xFF = nothing known)
+inline void effective_quals(const BamRecord &r, std::vector<uint8_t> &out)
+{
+    out.assign(r.seq.size(), 0xFF);
+    for (size_t i = 0; i < out.size(); ++i) {
+        uint8_t q = i < r.qual.size() ? r.qual[i] : 0xFF;
+        for (const std::string *t : {&r.dq, &r.iq, &r.sq})
+            if (i < t->size()) {
+                const uint8_t v = (uint8_t)((*t)[i] - 33);
+                if (q == 0xFF || v < q) q = v;
+            }
+        out[i] = q;
+    }
+}
 
 inline bool keep_record(const BamRecord &r)
 {
@@ -68,6 +84,8 @@ inline uint64_t build_rows(const std::string &bam, const IngestOptions &opt, int
         if (opt.min_rq > 0.0 && r.rq >= 0.f && r.rq < opt.min_rq) continue;
         if (n >= cap_reads) throw std::runtime_error("BAM changed between passes");
         uint8_t *row = rows.data() + (size_t)n * n_cols;
+        std::vector<uint8_t> eq;
+        if (opt.min_qv) effective_quals(r, eq);
         int64_t rp = r.pos;  // reference cursor
         size_t qp = 0;       // read cursor
         for (uint32_t c : r.cigar) {
@@ -80,7 +98,7 @@ inline uint64_t build_rows(const std::string &bam, const IngestOptions &opt, int
                 for (uint32_t k = 0; k < len; ++k, ++rp, ++qp) {
                     if (rp < wb || rp >= we || qp >= r.seq.size()) continue;
                     uint8_t s = r.seq[qp] < 4 ? r.seq[qp] : (uint8_t)JL_SYM_MASK;
-                    if (opt.min_qv && qp < r.qual.size() && r.qual[qp] != 0xFF && r.qual[qp] < opt.min_qv) s = JL_SYM_MASK;
+                    if (opt.min_qv && qp < eq.size() && eq[qp] != 0xFF && eq[qp] < opt.min_qv) s = JL_SYM_MASK;
                     row[rp - wb] = s;
                 }
                 break;
@@ -124,7 +142,9 @@ inline void collect_records(const std::string &bam, const IngestOptions &opt, in
         out.seq4.insert(out.seq4.end(), r.seq4.begin(), r.seq4.end());
         out.seq_off.push_back(out.seq4.size());
         if (want_qual) {
-            out.qual.insert(out.qual.end(), r.qual.begin(), r.qual.end());
+            std::vector<uint8_t> eq;
+            effective_quals(r, eq);
+            out.qual.insert(out.qual.end(), eq.begin(), eq.end());
             out.qual_off.push_back(out.qual.size());
         }
         out.names.push_back(r.name);

@@ -18,6 +18,7 @@ int main(int argc, char **argv)
     double sub = 1.75e-4, del = 1.3e-3, mask = 2.0e-2, partial = 0.0;
     uint32_t minor[4] = {10, 10, 10, 10};
     std::string out, cfg_out;
+    bool rich_qv = false;  // filtered bases keep their letter and get a low substitution QV (sq tag) instead of 'N'
     for (int i = 1; i < argc; ++i) {
         const std::string a = argv[i];
         auto need = [&]() -> std::string { if (i + 1 >= argc) { std::cerr << a << " needs a value\n"; std::exit(1); } return argv[++i]; };
@@ -30,6 +31,7 @@ int main(int argc, char **argv)
         else if (a == "--partial") partial = std::stod(need());
         else if (a == "--minor-permille") { for (int k = 0; k < 4; ++k) minor[k] = (uint32_t)std::stoul(need()); }
         else if (a == "--ref-offset") ref_offset = (uint32_t)std::stoul(need());  // window starts here in a longer reference
+        else if (a == "--rich-qv") rich_qv = true;
         else if (a == "-o") out = need();
         else if (a == "--config-out") cfg_out = need();
         else { std::cerr << "usage: juliet-synth --reads N --cols L --seed S [--partial p] [--minor-permille a b c d] [--ref-offset k] -o out.bam [--config-out cfg.json]\n"; return 1; }
@@ -62,8 +64,16 @@ int main(int argc, char **argv)
             uint32_t op;
             if (s == 4) op = CIG_D;
             else {
-                op = (s < 4 && s == ref[c]) ? CIG_EQ : CIG_X;
-                r.seq.push_back(s < 4 ? (uint8_t)s : (uint8_t)4);  // filtered base travels as 'N'
+                op = ((s < 4 && s == ref[c]) || (rich_qv && s == 5)) ? CIG_EQ : CIG_X;
+                if (rich_qv) {
+                    // as `ccs --richQVs` output would look: a real base letter with a poor per-base QV track
+                    r.seq.push_back(s < 4 ? (uint8_t)s : ref[c]);
+                    r.sq.push_back(s < 4 ? (char)(33 + 60) : (char)(33 + 3));
+                    r.dq.push_back((char)(33 + 60));
+                    r.iq.push_back((char)(33 + 60));
+                } else {
+                    r.seq.push_back(s < 4 ? (uint8_t)s : (uint8_t)4);  // filtered base travels as 'N'
+                }
                 r.qual.push_back(93);
             }
             if (op != run_op) { flush(); run_op = op; }

@@ -176,3 +176,23 @@ def test_consensus_by_product(sample, oracle):
             exp += "ACGT"[int(k.argmax())]
     assert seq[: len(exp)] == exp[: len(seq)] and abs(len(seq) - len(exp)) <= 5   # window may carry context columns
     assert seq.startswith("".join("ACGT"[b] for b in ref[:50]))                 # the 96 % major clone is the reference
+
+
+def test_rich_qv_filter_end_to_end(tmp_path, oracle):
+    """Filtered bases arrive as letters + a poor sq track (ccs --richQVs); `--min-qv` masks them on the device
+    and the calls equal those on the N-encoded reads."""
+    n, l, seed = 4000, 300, 12
+    bam, cfg = str(tmp_path / "rich.bam"), str(tmp_path / "rich.json")
+    subprocess.check_call([SYNTH, "--reads", str(n), "--cols", str(l), "--seed", str(seed), "--rich-qv",
+                           "--minor-permille", "60", "50", "40", "30", "-o", bam, "--config-out", cfg])
+    sp = synth.SynthParams(seed=seed, minor_permille=(60, 50, 40, 30))
+    ref = synth.reference(seed, l)
+    rows = synth.rows(sp, l, 0, n, ref)
+    j = run_juliet(tmp_path, bam, "-c", cfg, "--min-qv", "10")
+    exp = oracle.call(rows, np.array([(1, l + 1)], dtype=capi.GENE), refseq=ref)
+    got = flat_variants(j)
+    assert [(r[1], r[2], r[3]["count"], r[4]["coverage"]) for r in got] == \
+        [(e["codon_pos"], e["codon"], e["count"], e["coverage"]) for e in exp]
+    # unfiltered: coverage is higher because nothing is masked
+    j0 = run_juliet(tmp_path, bam, "-c", cfg)
+    assert all(a[4]["coverage"] > b[4]["coverage"] for a, b in zip(flat_variants(j0), got))

@@ -89,3 +89,21 @@ def test_cli_usage_errors(tmp_path):
     r = subprocess.run([JULIET, str(tmp_path / "missing.bam"), str(tmp_path / "o.json")], capture_output=True, text=True)
     assert r.returncode == 2 and "cannot open" in r.stderr
     assert subprocess.run([JULIET, "--version"], capture_output=True).returncode == 0
+
+
+def test_rich_qv_tracks_mask_bases(tmp_path):
+    """doc/JULIET.md:256-259: bases are filtered on the individual QV tracks (ccs --richQVs) and show up as N.
+    The generator writes filtered bases as ordinary letters with a poor `sq` track; --min-qv turns them into N."""
+    n, l, seed = 400, 150, 21
+    bam, msa_out = str(tmp_path / "rich.bam"), str(tmp_path / "rich.msa")
+    subprocess.check_call([SYNTH, "--reads", str(n), "--cols", str(l), "--seed", str(seed), "--rich-qv", "-o", bam])
+    exp = synth.rows(synth.SynthParams(seed=seed), l, 0, n)
+    subprocess.check_call([JULIET, "--min-qv", "10", "--dump-msa", msa_out, bam])
+    rows, _ = read_msa(msa_out)
+    assert (rows[:, :l] == exp).all() and (exp == 5).sum() > 100
+    # without the filter the masked bases read as the reference base (more false positives: doc/JULIET.md:273-276)
+    subprocess.check_call([JULIET, "--dump-msa", msa_out, bam])
+    rows0, _ = read_msa(msa_out)
+    ref = synth.reference(seed, l)
+    assert (rows0[:, :l][exp == 5] == np.broadcast_to(ref, exp.shape)[exp == 5]).all()
+    assert (rows0[:, :l][exp != 5] == exp[exp != 5]).all()
