@@ -56,6 +56,12 @@ def cpu_baseline(jl, genes, ref, budget_s=12.0, threads=1, rows=None):
 
 
 def main():
+    # The contract is ONE JSON line on stdout.  Libraries print banners there (RCCL with NCCL_DEBUG=VERSION, gloo's
+    # connection notice), so stdout is pointed at stderr for the duration and the line is written to the real one.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -243,7 +249,8 @@ def main():
         if ncores > 1:
             out["cpu_baseline_all_cores"], _ = cpu_baseline(jl, genes, refseq, budget_s=6.0, threads=ncores, rows=rows_host)
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if comm is not None:
         jl.lib.jl_comm_destroy(comm)
     for c in ctxs:
