@@ -15,10 +15,13 @@
 //     xor/or on the three column words; reads equal to the seed codon are counted by popcount (the
 //     contended "major codon" bin never sees an atomic), the rare valid mismatches take an LDS atomic each.
 //     The seed only steers which bin is counted the fast way — any seed gives the same histogram.
-// A block owns W consecutive columns (plus a 2-column halo when a codon straddles its right edge) and a
-// strided set of 8192-read tiles; per-lane counters are packed two per register, wave-reduced by DPP and
-// flushed to LDS at most every 31 tiles (16-bit fields cannot overflow), then to HBM with integer atomics,
-// which commute, so results are bit-exact and order-independent.
+// A block owns one chunk of <= W consecutive columns from a host-built table (capi.hip: build_chunks) and a
+// strided set of 8192-read tiles.  Chunks start on codon boundaries, so stretches that are locally single-frame
+// need no halo; only where a codon of the chunk reaches past its last column are the next two columns loaded
+// as well.  Loads are non-temporal (every cell is read once).  Per-lane counters are packed two per register,
+// wave-reduced by DPP and flushed to LDS at most every 31 tiles (16-bit fields cannot overflow), then to HBM
+// with integer atomics, which commute, so results are bit-exact and order-independent.  There is no reuse
+// between blocks (halo columns aside), so the block -> XCD mapping does not matter here.
 #include <stdlib.h>
 
 #include "jl_internal.h"
