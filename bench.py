@@ -142,6 +142,8 @@ def main():
         all_counts = np.zeros(world, dtype=np.uint32)
         p_rows, p_counts = all_rows.ctypes.data_as(C.c_void_p), all_counts.ctypes.data_as(C.c_void_p)
 
+    pending = [0] * len(ctxs)   # exchanges enqueued and not yet collected, per context
+
     def launch(i):
         # the whole path as one captured graph + one pinned result copy; the all-gather (N > 1) is the only
         # other device work of a step and is enqueued right behind it
@@ -151,14 +153,23 @@ def main():
             rc = c.lib.jl_allgather_variants_async(c.h, comm)
             if rc:
                 c._chk(rc)
+            pending[i] += 1
 
-    def collect(i):
+    def drain(i, k):
         c = ctxs[i]
-        if comm is not None:
+        for _ in range(k):
             rc = c.lib.jl_allgather_variants(c.h, comm, p_rows, p_counts, capi.VARIANT_CAP)
             if rc:
                 c._chk(rc)
+            pending[i] -= 1
+
+    def collect(i, final=False):
+        c = ctxs[i]
         out = c.run_fetch(True, True, cap_var=64)
+        # the exchange of this context's PREVIOUS step is collected now (its own is still crossing xGMI): every
+        # step's all-gather is consumed, one cycle late, and its latency never stalls the launching thread
+        if comm is not None and pending[i] > (0 if final else 1):
+            drain(i, 1)
         if distributed and comm is None and os.environ.get('JL_BENCH_NO_COMM') != '1':
             from minorseq_amd import sharding
             tabs = sharding.allgather_tables(out["variants"])
@@ -173,7 +184,10 @@ def main():
                 last = collect(i % len(ctxs))
             launch(i % len(ctxs))
         for i in range(max(0, k - len(ctxs)), k):
-            last = collect(i % len(ctxs))
+            last = collect(i % len(ctxs), final=True)
+        if comm is not None:
+            for i in range(len(ctxs)):
+                drain(i, pending[i])
         return last
 
     def fence():

@@ -241,7 +241,9 @@ int jl_allgather_variants(jl_ctx *ctx, jl_comm *comm, jl_variant *all_rows, uint
 /*
  * Enqueue-only half for hosts that keep several batches in flight: call right after jl_run_async; the
  * exchange (6.2 KB per rank: result header + up to 128 rows) then overlaps other work and the following
- * jl_allgather_variants on the same ctx/comm only waits and unpacks.  Up to 16 contexts per communicator.
+ * jl_allgather_variants on the same ctx/comm only waits and unpacks.  A context may have several exchanges in
+ * flight (its contribution is copied at enqueue time); jl_allgather_variants then returns the OLDEST pending one.
+ * At most 64 exchanges in flight per communicator.
  */
 int jl_allgather_variants_async(jl_ctx *ctx, jl_comm *comm);
 

@@ -18,14 +18,15 @@
 
 // bytes of jl_pack up to and including variants[]: what one rank contributes to the compact all-gather
 #define JL_PACK_HEAD_BYTES (offsetof(jl_pack, pos_cols))
-#define JL_COMM_SLOTS 16
+#define JL_COMM_SLOTS 64
 
 // One communicator per (rank, device).  Collectives run on the communicator's OWN stream, ordered behind the
 // producing context by an event, so that several contexts (batches in flight) never have an RCCL launch — and
 // whatever host-side work it implies — sitting in their compute streams.
 struct jl_comm_slot {
     jl_ctx *ctx = nullptr;
-    const void *src = nullptr;   // the context's d_pack
+    uint8_t *d_src = nullptr;    // this rank's contribution, copied out of the context's result block at enqueue time
+    uint64_t seq = 0;            // enqueue order: jl_allgather_variants collects a context's OLDEST pending exchange
     uint8_t *d_heads = nullptr;  // [world][JL_PACK_HEAD_BYTES]
     uint8_t *h_heads = nullptr;  // pinned mirror
     hipEvent_t produced = nullptr, done = nullptr;
@@ -41,6 +42,7 @@ struct jl_comm {
     jl_variant *d_all = nullptr;   // [world][JL_VARIANT_CAP]   (full-stride fallback)
     uint32_t *d_counts = nullptr;  // [world][2]
     jl_comm_slot slots[JL_COMM_SLOTS];
+    uint64_t next_seq = 1;
     // RCCL enqueues cost the host ~20 us each; a worker thread issues them (FIFO, so every rank keeps the
     // same collective order) while the caller's thread goes on launching the next batch
     std::thread worker;
@@ -64,7 +66,7 @@ static void comm_worker(jl_comm *c)
         }
         int st = JL_OK;
         if (hipStreamWaitEvent(c->stream, s->produced, 0) != hipSuccess) st = JL_ERR_DEVICE;
-        if (st == JL_OK && ncclAllGather(s->src, s->d_heads, JL_PACK_HEAD_BYTES, ncclUint8, c->comm, c->stream) != ncclSuccess) st = JL_ERR_COMM;
+        if (st == JL_OK && ncclAllGather(s->d_src, s->d_heads, JL_PACK_HEAD_BYTES, ncclUint8, c->comm, c->stream) != ncclSuccess) st = JL_ERR_COMM;
         if (st == JL_OK && hipMemcpyAsync(s->h_heads, s->d_heads, JL_PACK_HEAD_BYTES * (size_t)c->world, hipMemcpyDeviceToHost, c->stream) != hipSuccess) st = JL_ERR_DEVICE;
         if (hipEventRecord(s->done, c->stream) != hipSuccess && st == JL_OK) st = JL_ERR_DEVICE;
         {
@@ -863,11 +865,6 @@ int jl_run_async(jl_ctx *ctx, const jl_gene *genes, uint32_t n_genes, const uint
     jl_prepare_pileup(ctx);
     ctx->pack_mirror = ctx->h_pack;
     ctx->read_hap_out = (phasing && want_read_hap) ? ctx->h_read_hap : nullptr;
-    if (ctx->exchange_slot) {  // an uncollected all-gather may still be reading the previous result block
-        jl_comm_slot *s = static_cast<jl_comm_slot *>(ctx->exchange_slot);
-        comm_wait_enqueued(static_cast<jl_comm *>(ctx->exchange_comm), s);
-        JL_HIP(ctx, hipStreamWaitEvent(ctx->stream, s->done, 0));
-    }
 
     // signature of everything a captured graph bakes in
     struct { uint64_t alloc, plan; jl_params prm; double n_tests; uint32_t drm, phasing, min_reads, rh, generic, pad; } sig;
@@ -1018,7 +1015,7 @@ void jl_comm_destroy(jl_comm *c)
     }
     if (c->stream) hipStreamSynchronize(c->stream);
     for (jl_comm_slot &s : c->slots) {
-        if (s.ctx && s.ctx->exchange_slot == (void *)&s) s.ctx->exchange_slot = nullptr;
+        if (s.d_src) hipFree(s.d_src);
         if (s.d_heads) hipFree(s.d_heads);
         if (s.h_heads) hipHostFree(s.h_heads);
         if (s.produced) hipEventDestroy(s.produced);
@@ -1031,15 +1028,17 @@ void jl_comm_destroy(jl_comm *c)
     delete c;
 }
 
-static jl_comm_slot *comm_slot(jl_ctx *ctx, jl_comm *c, bool create)
+// A context may have several exchanges in flight (each in its own slot): `free` = a slot of this context that is
+// not pending, created on demand; `oldest` = its pending slot with the smallest sequence number.
+static jl_comm_slot *comm_slot_free(jl_ctx *ctx, jl_comm *c)
 {
     for (jl_comm_slot &s : c->slots)
-        if (s.ctx == ctx) return &s;
-    if (!create) return nullptr;
+        if (s.ctx == ctx && !s.pending) return &s;
     for (jl_comm_slot &s : c->slots) {
         if (s.ctx) continue;
         const size_t bytes = JL_PACK_HEAD_BYTES * (size_t)c->world;
         if (hipMalloc(&s.d_heads, bytes) != hipSuccess || hipHostMalloc(&s.h_heads, bytes, hipHostMallocDefault) != hipSuccess ||
+            hipMalloc(&s.d_src, JL_PACK_HEAD_BYTES) != hipSuccess ||
             hipEventCreateWithFlags(&s.produced, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&s.done, hipEventDisableTiming) != hipSuccess)
             return nullptr;
@@ -1047,6 +1046,14 @@ static jl_comm_slot *comm_slot(jl_ctx *ctx, jl_comm *c, bool create)
         return &s;
     }
     return nullptr;
+}
+
+static jl_comm_slot *comm_slot_oldest(jl_ctx *ctx, jl_comm *c)
+{
+    jl_comm_slot *best = nullptr;
+    for (jl_comm_slot &s : c->slots)
+        if (s.ctx == ctx && s.pending && (!best || s.seq < best->seq)) best = &s;
+    return best;
 }
 
 // Enqueue-only half: after jl_run_async, all-gather the head of the result block (header + up to 128 rows =
@@ -1057,11 +1064,13 @@ int jl_allgather_variants_async(jl_ctx *ctx, jl_comm *c)
     if (!ctx->pack_valid) return jl_fail(ctx, JL_ERR_STATE, "jl_allgather_variants_async needs jl_run_async first");
     if (ctx->device != c->device) return jl_fail(ctx, JL_ERR_ARG, "context and communicator are on different devices");
     JL_HIP(ctx, hipSetDevice(ctx->device));
-    jl_comm_slot *s = comm_slot(ctx, c, true);
-    if (!s) return jl_fail(ctx, JL_ERR_MEMORY, "no free exchange slot (at most %d contexts per communicator)", JL_COMM_SLOTS);
-    if (s->pending) return jl_fail(ctx, JL_ERR_STATE, "previous exchange of this context not collected yet");
+    jl_comm_slot *s = comm_slot_free(ctx, c);
+    if (!s) return jl_fail(ctx, JL_ERR_MEMORY, "no free exchange slot (%d per communicator): collect pending exchanges first", JL_COMM_SLOTS);
+    // the contribution is copied out of the result block on the context's stream, so the next run of this
+    // context may overwrite the block while the collective is still in flight
+    JL_HIP(ctx, hipMemcpyAsync(s->d_src, ctx->d_pack, JL_PACK_HEAD_BYTES, hipMemcpyDeviceToDevice, ctx->stream));
     JL_HIP(ctx, hipEventRecord(s->produced, ctx->stream));
-    s->src = ctx->d_pack;
+    s->seq = c->next_seq++;
     {
         std::lock_guard<std::mutex> lk(c->mu);
         s->enqueued = false;
@@ -1070,8 +1079,6 @@ int jl_allgather_variants_async(jl_ctx *ctx, jl_comm *c)
     }
     c->cv.notify_all();
     s->pending = true;
-    ctx->exchange_slot = s;
-    ctx->exchange_comm = c;
     return JL_OK;
 }
 
@@ -1107,15 +1114,14 @@ int jl_allgather_variants(jl_ctx *ctx, jl_comm *c, jl_variant *all_rows, uint32_
     if (cap_rows == 0 || cap_rows > JL_VARIANT_CAP) return jl_fail(ctx, JL_ERR_ARG, "cap_rows must be 1..%u", JL_VARIANT_CAP);
     JL_HIP(ctx, hipSetDevice(ctx->device));
     if (ctx->pack_valid) {
-        jl_comm_slot *s = comm_slot(ctx, c, false);
-        if (!s || !s->pending) {
+        jl_comm_slot *s = comm_slot_oldest(ctx, c);
+        if (!s) {
             int rc = jl_allgather_variants_async(ctx, c);
             if (rc) return rc;
-            s = comm_slot(ctx, c, false);
+            s = comm_slot_oldest(ctx, c);
         }
         s->pending = false;
         comm_wait_enqueued(c, s);
-        ctx->exchange_slot = nullptr;
         if (s->status != JL_OK) return jl_fail(ctx, s->status, "all-gather enqueue failed on the communicator thread");
         {   // spin on the event: a blocking hipEventSynchronize costs ~15 us of wake-up latency per step
             hipError_t q;

@@ -57,8 +57,6 @@ struct jl_comm;
 
 struct jl_ctx {
     int device = -1;
-    void *exchange_slot = nullptr;  // jl_comm_slot of an uncollected all-gather that reads d_pack
-    void *exchange_comm = nullptr;
     hipStream_t stream = nullptr;
     bool own_stream = false;
     std::string err;
