@@ -1,0 +1,371 @@
+// capi_comm.hip — the multi-GPU part of the C ABI: RCCL communicator, the all-gather of the variant
+// table, and the cross-window column exchange.  One communicator per (rank, device); collectives run on the
+// communicator's own stream and are issued by a worker thread.
+#include <rccl/rccl.h>
+#include <stddef.h>
+#include <string.h>
+
+#include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
+#include <new>
+#include <thread>
+#include <vector>
+
+#include "jl_internal.h"
+
+// bytes of jl_pack up to and including variants[]: what one rank contributes to the compact all-gather
+#define JL_PACK_HEAD_BYTES (offsetof(jl_pack, pos_cols))
+#define JL_COMM_SLOTS 64
+
+// One communicator per (rank, device).  Collectives run on the communicator's OWN stream, ordered behind the
+// producing context by an event, so that several contexts (batches in flight) never have an RCCL launch — and
+// whatever host-side work it implies — sitting in their compute streams.
+struct jl_comm_slot {
+    jl_ctx *ctx = nullptr;
+    uint8_t *d_src = nullptr;    // this rank's contribution, copied out of the context's result block at enqueue time
+    uint64_t seq = 0;            // enqueue order: jl_allgather_variants collects a context's OLDEST pending exchange
+    uint8_t *d_heads = nullptr;  // [world][JL_PACK_HEAD_BYTES]
+    uint8_t *h_heads = nullptr;  // pinned mirror
+    hipEvent_t produced = nullptr, done = nullptr;
+    bool pending = false;        // an exchange was requested and not yet collected (host thread only)
+    bool enqueued = false;       // the worker has issued it and recorded `done` (guarded by jl_comm::mu)
+    int status = 0;              // ncclResult_t / hip error of the enqueue, as jl_status
+};
+
+struct jl_comm {
+    ncclComm_t comm = nullptr;
+    int rank = 0, world = 1, device = 0;
+    hipStream_t stream = nullptr;
+    jl_variant *d_all = nullptr;   // [world][JL_VARIANT_CAP]   (full-stride fallback)
+    uint32_t *d_counts = nullptr;  // [world][2]
+    jl_comm_slot slots[JL_COMM_SLOTS];
+    uint64_t next_seq = 1;
+    // RCCL enqueues cost the host ~20 us each; a worker thread issues them (FIFO, so every rank keeps the
+    // same collective order) while the caller's thread goes on launching the next batch
+    std::thread worker;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<jl_comm_slot *> queue;
+    bool stop = false;
+};
+
+static void comm_worker(jl_comm *c)
+{
+    hipSetDevice(c->device);
+    for (;;) {
+        jl_comm_slot *s = nullptr;
+        {
+            std::unique_lock<std::mutex> lk(c->mu);
+            c->cv.wait(lk, [&] { return c->stop || !c->queue.empty(); });
+            if (c->queue.empty()) return;  // stop requested and nothing left
+            s = c->queue.front();
+            c->queue.pop_front();
+        }
+        int st = JL_OK;
+        if (hipStreamWaitEvent(c->stream, s->produced, 0) != hipSuccess) st = JL_ERR_DEVICE;
+        if (st == JL_OK && ncclAllGather(s->d_src, s->d_heads, JL_PACK_HEAD_BYTES, ncclUint8, c->comm, c->stream) != ncclSuccess) st = JL_ERR_COMM;
+        if (st == JL_OK && hipMemcpyAsync(s->h_heads, s->d_heads, JL_PACK_HEAD_BYTES * (size_t)c->world, hipMemcpyDeviceToHost, c->stream) != hipSuccess) st = JL_ERR_DEVICE;
+        if (hipEventRecord(s->done, c->stream) != hipSuccess && st == JL_OK) st = JL_ERR_DEVICE;
+        {
+            std::lock_guard<std::mutex> lk(c->mu);
+            s->status = st;
+            s->enqueued = true;
+        }
+        c->cv.notify_all();
+    }
+}
+
+static void comm_wait_enqueued(jl_comm *c, jl_comm_slot *s)
+{
+    std::unique_lock<std::mutex> lk(c->mu);
+    c->cv.wait(lk, [&] { return s->enqueued; });
+}
+
+
+extern "C" {
+
+/* ---------------------------------------------------------------- multi-GPU */
+
+
+
+int jl_comm_unique_id(uint8_t id[128])
+{
+    static_assert(sizeof(ncclUniqueId) == 128, "RCCL unique id is 128 bytes");
+    ncclUniqueId u;
+    if (ncclGetUniqueId(&u) != ncclSuccess) return JL_ERR_COMM;
+    memcpy(id, &u, 128);
+    return JL_OK;
+}
+
+int jl_comm_create(jl_ctx *ctx, const uint8_t id[128], int rank, int world, jl_comm **out)
+{
+    if (!ctx || !id || !out || world < 1 || rank < 0 || rank >= world) return JL_ERR_ARG;
+    JL_HIP(ctx, hipSetDevice(ctx->device));
+    jl_comm *c = new (std::nothrow) jl_comm();
+    if (!c) return JL_ERR_MEMORY;
+    c->rank = rank;
+    c->world = world;
+    c->device = ctx->device;
+    ncclUniqueId u;
+    memcpy(&u, id, 128);
+    ncclResult_t r = ncclCommInitRank(&c->comm, world, u, rank);
+    if (r != ncclSuccess) {
+        delete c;
+        return jl_fail(ctx, JL_ERR_COMM, "ncclCommInitRank: %s", ncclGetErrorString(r));
+    }
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipMalloc(&c->d_all, sizeof(jl_variant) * JL_VARIANT_CAP * world) != hipSuccess ||
+        hipMalloc(&c->d_counts, 8 * world) != hipSuccess) {
+        jl_comm_destroy(c);
+        return jl_fail(ctx, JL_ERR_MEMORY, "comm buffers");
+    }
+    c->worker = std::thread(comm_worker, c);
+    *out = c;
+    return JL_OK;
+}
+
+void jl_comm_destroy(jl_comm *c)
+{
+    if (!c) return;
+    hipSetDevice(c->device);
+    if (c->worker.joinable()) {
+        {
+            std::lock_guard<std::mutex> lk(c->mu);
+            c->stop = true;
+        }
+        c->cv.notify_all();
+        c->worker.join();
+    }
+    if (c->stream) hipStreamSynchronize(c->stream);
+    for (jl_comm_slot &s : c->slots) {
+        if (s.d_src) hipFree(s.d_src);
+        if (s.d_heads) hipFree(s.d_heads);
+        if (s.h_heads) hipHostFree(s.h_heads);
+        if (s.produced) hipEventDestroy(s.produced);
+        if (s.done) hipEventDestroy(s.done);
+    }
+    if (c->comm) ncclCommDestroy(c->comm);
+    if (c->d_all) hipFree(c->d_all);
+    if (c->d_counts) hipFree(c->d_counts);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+// A context may have several exchanges in flight (each in its own slot): `free` = a slot of this context that is
+// not pending, created on demand; `oldest` = its pending slot with the smallest sequence number.
+static jl_comm_slot *comm_slot_free(jl_ctx *ctx, jl_comm *c)
+{
+    for (jl_comm_slot &s : c->slots)
+        if (s.ctx == ctx && !s.pending) return &s;
+    for (jl_comm_slot &s : c->slots) {
+        if (s.ctx) continue;
+        const size_t bytes = JL_PACK_HEAD_BYTES * (size_t)c->world;
+        if (hipMalloc(&s.d_heads, bytes) != hipSuccess || hipHostMalloc(&s.h_heads, bytes, hipHostMallocDefault) != hipSuccess ||
+            hipMalloc(&s.d_src, JL_PACK_HEAD_BYTES) != hipSuccess ||
+            hipEventCreateWithFlags(&s.produced, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&s.done, hipEventDisableTiming) != hipSuccess)
+            return nullptr;
+        s.ctx = ctx;
+        return &s;
+    }
+    return nullptr;
+}
+
+static jl_comm_slot *comm_slot_oldest(jl_ctx *ctx, jl_comm *c)
+{
+    jl_comm_slot *best = nullptr;
+    for (jl_comm_slot &s : c->slots)
+        if (s.ctx == ctx && s.pending && (!best || s.seq < best->seq)) best = &s;
+    return best;
+}
+
+// Enqueue-only half: after jl_run_async, all-gather the head of the result block (header + up to 128 rows =
+// 6.2 KB per rank) on the communicator's stream, ordered behind the context by an event, into pinned memory.
+int jl_allgather_variants_async(jl_ctx *ctx, jl_comm *c)
+{
+    if (!ctx || !c) return JL_ERR_ARG;
+    if (!ctx->pack_valid) return jl_fail(ctx, JL_ERR_STATE, "jl_allgather_variants_async needs jl_run_async first");
+    if (ctx->device != c->device) return jl_fail(ctx, JL_ERR_ARG, "context and communicator are on different devices");
+    JL_HIP(ctx, hipSetDevice(ctx->device));
+    jl_comm_slot *s = comm_slot_free(ctx, c);
+    if (!s) return jl_fail(ctx, JL_ERR_MEMORY, "no free exchange slot (%d per communicator): collect pending exchanges first", JL_COMM_SLOTS);
+    // the contribution is copied out of the result block on the context's stream, so the next run of this
+    // context may overwrite the block while the collective is still in flight
+    JL_HIP(ctx, hipMemcpyAsync(s->d_src, ctx->d_pack, JL_PACK_HEAD_BYTES, hipMemcpyDeviceToDevice, ctx->stream));
+    JL_HIP(ctx, hipEventRecord(s->produced, ctx->stream));
+    s->seq = c->next_seq++;
+    {
+        std::lock_guard<std::mutex> lk(c->mu);
+        s->enqueued = false;
+        s->status = JL_OK;
+        c->queue.push_back(s);
+    }
+    c->cv.notify_all();
+    s->pending = true;
+    return JL_OK;
+}
+
+static int allgather_full(jl_ctx *ctx, jl_comm *c, jl_variant *all_rows, uint32_t *all_counts, uint32_t cap_rows)
+{
+    // fixed-stride table (+ row counts) over RCCL/xGMI; blocking, so it can simply use the ctx stream
+    ncclResult_t r = ncclGroupStart();
+    if (r == ncclSuccess) r = ncclAllGather(ctx->d_variants, c->d_all, sizeof(jl_variant) * (size_t)cap_rows, ncclUint8, c->comm, ctx->stream);
+    if (r == ncclSuccess) r = ncclAllGather(ctx->d_nvar, c->d_counts, 8, ncclUint8, c->comm, ctx->stream);
+    if (r == ncclSuccess) r = ncclGroupEnd();
+    if (r != ncclSuccess) return jl_fail(ctx, JL_ERR_COMM, "ncclAllGather: %s", ncclGetErrorString(r));
+    std::vector<uint32_t> cnt(2 * (size_t)c->world);
+    JL_HIP(ctx, hipMemcpyAsync(all_rows, c->d_all, sizeof(jl_variant) * (size_t)cap_rows * c->world, hipMemcpyDeviceToHost, ctx->stream));
+    JL_HIP(ctx, hipMemcpyAsync(cnt.data(), c->d_counts, 8 * (size_t)c->world, hipMemcpyDeviceToHost, ctx->stream));
+    JL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    int rc = JL_OK;
+    for (int k = 0; k < c->world; ++k) {
+        all_counts[k] = cnt[2 * k];
+        if (cnt[2 * k] > cap_rows) rc = JL_ERR_OVERFLOW;
+    }
+    if (rc) return jl_fail(ctx, rc, "a rank produced more than %u variant rows", cap_rows);
+    return JL_OK;
+}
+
+// The one collective of the path.  After jl_run_async the exchange is the 6.2 KB head of each rank's result
+// block (enqueued here unless jl_allgather_variants_async already did); tables with more than 128 rows on any
+// rank, or stage-by-stage callers, use the full fixed stride.  The decision is made from the gathered headers,
+// so every rank takes the same branch.
+int jl_allgather_variants(jl_ctx *ctx, jl_comm *c, jl_variant *all_rows, uint32_t *all_counts, uint32_t cap_rows)
+{
+    if (!ctx || !c || !all_rows || !all_counts) return JL_ERR_ARG;
+    if (!ctx->call_done) return jl_fail(ctx, JL_ERR_STATE, "jl_allgather_variants before jl_call_async");
+    if (cap_rows == 0 || cap_rows > JL_VARIANT_CAP) return jl_fail(ctx, JL_ERR_ARG, "cap_rows must be 1..%u", JL_VARIANT_CAP);
+    JL_HIP(ctx, hipSetDevice(ctx->device));
+    if (ctx->pack_valid) {
+        jl_comm_slot *s = comm_slot_oldest(ctx, c);
+        if (!s) {
+            int rc = jl_allgather_variants_async(ctx, c);
+            if (rc) return rc;
+            s = comm_slot_oldest(ctx, c);
+        }
+        s->pending = false;
+        comm_wait_enqueued(c, s);
+        if (s->status != JL_OK) return jl_fail(ctx, s->status, "all-gather enqueue failed on the communicator thread");
+        {   // spin on the event: a blocking hipEventSynchronize costs ~15 us of wake-up latency per step
+            hipError_t q;
+            while ((q = hipEventQuery(s->done)) == hipErrorNotReady) {}
+            if (q != hipSuccess) return jl_fail(ctx, JL_ERR_DEVICE, "all-gather: %s", hipGetErrorString(q));
+        }
+        bool compact = true;
+        for (int k = 0; k < c->world; ++k) {
+            const jl_pack *pk = reinterpret_cast<const jl_pack *>(s->h_heads + (size_t)k * JL_PACK_HEAD_BYTES);
+            if (pk->magic != JL_PACK_MAGIC || !pk->fits_call) compact = false;
+        }
+        if (compact) {
+            int rc = JL_OK;
+            for (int k = 0; k < c->world; ++k) {
+                const jl_pack *pk = reinterpret_cast<const jl_pack *>(s->h_heads + (size_t)k * JL_PACK_HEAD_BYTES);
+                all_counts[k] = pk->nvar_total;
+                if (pk->nvar_total > cap_rows) { rc = JL_ERR_OVERFLOW; continue; }
+                memcpy(all_rows + (size_t)k * cap_rows, pk->variants, (size_t)pk->nvar_total * sizeof(jl_variant));
+            }
+            if (rc) return jl_fail(ctx, rc, "a rank produced more than %u variant rows", cap_rows);
+            return JL_OK;
+        }
+    }
+    return allgather_full(ctx, c, all_rows, all_counts, cap_rows);
+}
+
+
+/* ---------------------------------------------------------------- cross-window phasing */
+
+// Distinct variant positions of the merged (global-column) table, ascending, and the remapped table whose
+// columns index the compact matrix: position k lives in compact columns 3k..3k+2.
+static uint32_t xwin_remap(const jl_variant *merged, uint32_t n_var, jl_variant *remapped, uint32_t *pos_global)
+{
+    std::vector<uint32_t> cols;
+    cols.reserve(n_var);
+    for (uint32_t v = 0; v < n_var; ++v) cols.push_back(merged[v].col);
+    std::sort(cols.begin(), cols.end());
+    cols.erase(std::unique(cols.begin(), cols.end()), cols.end());
+    for (uint32_t v = 0; v < n_var; ++v) {
+        const uint32_t k = (uint32_t)(std::lower_bound(cols.begin(), cols.end(), merged[v].col) - cols.begin());
+        if (remapped) {
+            remapped[v] = merged[v];
+            remapped[v].col = 3u * k;
+        }
+    }
+    if (pos_global) std::copy(cols.begin(), cols.end(), pos_global);
+    return (uint32_t)cols.size();
+}
+
+static int xwin_owner(const uint32_t *win_begin, const uint32_t *win_ncols, uint32_t n_windows, uint32_t col)
+{
+    for (uint32_t w = 0; w < n_windows; ++w)
+        if (col >= win_begin[w] && (uint64_t)col + 3 <= (uint64_t)win_begin[w] + win_ncols[w]) return (int)w;
+    return -1;
+}
+
+// All windows on THIS device (a 288 GB GPU holds many): device-to-device copies of 3 columns per position.
+int jl_xwin_assemble_local(jl_ctx *pc, jl_ctx *const *windows, uint32_t n_windows, const jl_variant *merged, uint32_t n_var,
+                           jl_variant *remapped, uint32_t *pos_global, uint32_t *vp_total)
+{
+    if (!pc || !windows || n_windows == 0 || (!merged && n_var) || !vp_total) return JL_ERR_ARG;
+    if (n_var > JL_VARIANT_CAP) return jl_fail(pc, JL_ERR_OVERFLOW, "%u variants, table holds %u", n_var, JL_VARIANT_CAP);
+    std::vector<uint32_t> wb(n_windows), wn(n_windows);
+    for (uint32_t w = 0; w < n_windows; ++w) {
+        if (!windows[w] || !windows[w]->d_msa) return jl_fail(pc, JL_ERR_ARG, "window %u has no resident matrix", w);
+        if (windows[w]->n_reads != windows[0]->n_reads || windows[w]->col_stride != windows[0]->col_stride)
+            return jl_fail(pc, JL_ERR_ARG, "windows must hold the same reads (window %u differs)", w);
+        wb[w] = windows[w]->win_begin;
+        wn[w] = windows[w]->n_cols;
+    }
+    std::vector<uint32_t> pos(n_var ? n_var : 1);
+    const uint32_t vp = xwin_remap(merged, n_var, remapped, pos.data());
+    *vp_total = vp;
+    if (pos_global) std::copy(pos.begin(), pos.begin() + vp, pos_global);
+    if (vp == 0) return JL_OK;
+    int rc = jl_msa_alloc(pc, windows[0]->n_reads, 3u * vp, 0);
+    if (rc) return rc;
+    const uint64_t stride = windows[0]->col_stride;
+    for (uint32_t k = 0; k < vp; ++k) {
+        const int w = xwin_owner(wb.data(), wn.data(), n_windows, pos[k]);
+        if (w < 0) return jl_fail(pc, JL_ERR_ARG, "variant column %u is not fully inside any window", pos[k]);
+        JL_HIP(pc, hipStreamSynchronize(windows[w]->stream));
+        JL_HIP(pc, hipMemcpyAsync(pc->d_msa + (uint64_t)3 * k * stride, windows[w]->d_msa + (uint64_t)(pos[k] - wb[w]) * stride,
+                                  3 * stride, hipMemcpyDeviceToDevice, pc->stream));
+    }
+    JL_HIP(pc, hipStreamSynchronize(pc->stream));
+    return JL_OK;
+}
+
+// One window per rank: the owner of each position broadcasts its 3 columns over RCCL/xGMI into every rank's
+// compact matrix (the second exchange of a cross-window run; 3*Vp*col_stride bytes in total).
+int jl_xwin_assemble_rccl(jl_ctx *pc, jl_ctx *window, jl_comm *c, const uint32_t *win_begin, const uint32_t *win_ncols,
+                          const jl_variant *merged, uint32_t n_var, jl_variant *remapped, uint32_t *pos_global,
+                          uint32_t *vp_total)
+{
+    if (!pc || !window || !c || !win_begin || !win_ncols || (!merged && n_var) || !vp_total) return JL_ERR_ARG;
+    if (!window->d_msa) return jl_fail(pc, JL_ERR_ARG, "window has no resident matrix");
+    if (n_var > JL_VARIANT_CAP) return jl_fail(pc, JL_ERR_OVERFLOW, "%u variants, table holds %u", n_var, JL_VARIANT_CAP);
+    std::vector<uint32_t> pos(n_var ? n_var : 1);
+    const uint32_t vp = xwin_remap(merged, n_var, remapped, pos.data());
+    *vp_total = vp;
+    if (pos_global) std::copy(pos.begin(), pos.begin() + vp, pos_global);
+    if (vp == 0) return JL_OK;
+    int rc = jl_msa_alloc(pc, window->n_reads, 3u * vp, 0);
+    if (rc) return rc;
+    const uint64_t stride = window->col_stride;
+    JL_HIP(pc, hipStreamSynchronize(window->stream));
+    ncclResult_t r = ncclGroupStart();
+    for (uint32_t k = 0; k < vp && r == ncclSuccess; ++k) {
+        const int w = xwin_owner(win_begin, win_ncols, (uint32_t)c->world, pos[k]);
+        if (w < 0) { ncclGroupEnd(); return jl_fail(pc, JL_ERR_ARG, "variant column %u is not fully inside any window", pos[k]); }
+        const uint8_t *src = (w == c->rank) ? window->d_msa + (uint64_t)(pos[k] - win_begin[w]) * stride : pc->d_msa;
+        r = ncclBroadcast(src, pc->d_msa + (uint64_t)3 * k * stride, 3 * stride, ncclUint8, w, c->comm, pc->stream);
+    }
+    if (r == ncclSuccess) r = ncclGroupEnd();
+    if (r != ncclSuccess) return jl_fail(pc, JL_ERR_COMM, "ncclBroadcast: %s", ncclGetErrorString(r));
+    JL_HIP(pc, hipStreamSynchronize(pc->stream));
+    return JL_OK;
+}
+
+}  // extern "C"
