@@ -53,3 +53,29 @@ def test_haplotype_names():
     assert names[0] == "A" and names[25] == "Z" and names[26] == "Aa" and names[51] == "Az" and names[52] == "Ba"
     assert names[-1] == "Zz" and len(set(names)) == 702
     assert all(re.fullmatch(r"[A-Z][a-z]?", n) for n in names)
+
+
+def test_header_is_plain_c_and_links(tmp_path):
+    """include/juliet_hip.h is a C header (no C++/torch types): a C99 program compiles against it, links the
+    library and runs without a GPU (it only asks for the ABI version and the device count)."""
+    import subprocess
+    src = tmp_path / "use.c"
+    src.write_text('#include <stdio.h>\n#include "juliet_hip.h"\n'
+                   'int main(void) {\n'
+                   '    jl_params p = {0.01, 0.0, {0.998826, 5.8e-5, 1.0e-3}, 0, 0, -1.0, -1.0};\n'
+                   '    jl_ctx *ctx = 0;\n'
+                   '    int n = jl_device_count();\n'
+                   '    int rc = n ? 0 : jl_ctx_create(0, 0, &ctx);\n'
+                   '    printf("%d %d %d %s|%s\\n", jl_abi_version(), n, rc, jl_strerror(rc), jl_last_error(0));\n'
+                   '    return (int)(p.alpha > 1.0);\n}\n')
+    exe = tmp_path / "use"
+    lib_dir = os.path.join(ROOT, "minorseq_amd")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                           "-o", str(exe), str(src), "-L" + lib_dir, "-ljuliet_hip", "-Wl,-rpath," + lib_dir,
+                           "-Wl,-rpath-link,/opt/rocm/lib"])
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    ver, n, rc, msg = out.stdout.strip().split(" ", 3)
+    assert ver == "1"
+    if n == "0":
+        assert rc == "-2" and "no CPU fallback" in msg      # loud failure without a device
