@@ -165,7 +165,9 @@ def main():
 
     def collect(i, final=False):
         c = ctxs[i]
-        out = c.run_fetch(True, True, cap_var=64)
+        # results are read in place: the kernels stored them into pinned host memory, completion is a sequence
+        # word behind a system-scope fence (jl_run_view_get); results too large for that block use the copying fetch
+        out = c.run_view() or c.run_fetch(True, True, cap_var=64)
         # the exchange of this context's PREVIOUS step is collected now (its own is still crossing xGMI): every
         # step's all-gather is consumed, one cycle late, and its latency never stalls the launching thread
         if comm is not None and pending[i] > (0 if final else 1):

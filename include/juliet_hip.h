@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define JL_ABI_VERSION 1
+#define JL_ABI_VERSION 2
 
 /* symbol codes of the MSA (SPEC §1; J:99-100, 256-259, 372-381) */
 enum { JL_SYM_A = 0, JL_SYM_C = 1, JL_SYM_G = 2, JL_SYM_T = 3, JL_SYM_GAP = 4, JL_SYM_MASK = 5, JL_SYM_NONE = 6 };
@@ -207,6 +207,41 @@ int jl_phase_fetch(jl_ctx *ctx, jl_phase_summary *summary, uint32_t *pos_cols, u
  */
 int jl_run_async(jl_ctx *ctx, const jl_gene *genes, uint32_t n_genes, const uint8_t *refseq, uint32_t ref_len,
                  const jl_params *prm, const uint64_t *drm_masks, int phasing, uint32_t min_reads, int want_read_hap);
+
+/*
+ * Completion of the last jl_run_async without a HIP synchronisation call: the run's last kernel stores a
+ * sequence word into pinned host memory behind a system-scope fence and these calls read it (a
+ * hipStreamSynchronize after a graph launch costs 10-18 us of host time on ROCm 7.2 even when the work has
+ * long finished).  jl_run_wait spins until the results are on the host; jl_run_done never blocks (1 done, 0 not).
+ * jl_call_fetch / jl_phase_fetch wait the same way, so calling these first is optional.
+ */
+int jl_run_wait(jl_ctx *ctx);
+int jl_run_done(jl_ctx *ctx);
+
+/*
+ * Zero-copy view of the results of the last jl_run_async: pointers into the context's pinned result block
+ * (host memory the kernels stored into directly), valid until the next jl_run_async / stage call on this
+ * context.  `complete` = 0 means some part did not fit the fixed-size block (more than 128 variants /
+ * positions / haplotypes): use jl_call_fetch / jl_phase_fetch then.  Waits like jl_run_wait.
+ */
+typedef struct {
+    uint32_t complete;      /* 1: every field below is valid */
+    uint32_t n_variants;    /* rows of `variants` (total called; J:94-98) */
+    uint32_t phased;        /* 1 if the run included phasing */
+    uint32_t n_positions;   /* Vp */
+    uint32_t n_haplotypes;  /* H */
+    uint32_t n_var_phase;   /* rows the hit / co-occurrence matrices cover */
+    uint64_t n_reads;
+    jl_phase_summary summary;
+    const jl_variant *variants;
+    const uint32_t *pos_cols;     /* [Vp] */
+    const uint32_t *hap_count;    /* [H] */
+    const uint8_t *hap_pattern;   /* [H][Vp] */
+    const uint8_t *hit;           /* [n_var_phase][H] (haplotype_hit, J:207-209) */
+    const uint32_t *cooc;         /* [n_var_phase][n_var_phase], NULL if it did not fit */
+    const uint16_t *read_hap;     /* [n_reads], NULL unless the run asked for the per-read ids */
+} jl_run_view;
+int jl_run_view_get(jl_ctx *ctx, jl_run_view *out);
 
 /* ---------------------------------------------------------------- numerics self-check */
 

@@ -31,7 +31,7 @@ EXPORTS = ("jl_abi_version", "jl_strerror", "jl_device_count", "jl_ctx_create", 
            "jl_sync", "jl_col_stride", "jl_msa_upload", "jl_msa_alloc", "jl_msa_adopt", "jl_msa_pack_rows",
            "jl_msa_ingest_records", "jl_msa_download", "jl_synth_fill", "jl_pileup_async", "jl_n_positions", "jl_pileup_fetch",
            "jl_consensus_fetch", "jl_call_async", "jl_call_fetch", "jl_variant_table_device", "jl_phase_async", "jl_phase_fetch",
-           "jl_run_async", "jl_fisher_eval", "jl_time_pileup", "jl_pileup_kernel_name", "jl_comm_unique_id", "jl_comm_create", "jl_comm_destroy",
+           "jl_run_async", "jl_run_wait", "jl_run_done", "jl_run_view_get", "jl_fisher_eval", "jl_time_pileup", "jl_pileup_kernel_name", "jl_comm_unique_id", "jl_comm_create", "jl_comm_destroy",
            "jl_allgather_variants", "jl_allgather_variants_async", "jl_xwin_assemble_local",
            "jl_xwin_assemble_rccl")
 
@@ -48,6 +48,25 @@ class Params(C.Structure):
 class SynthParams(C.Structure):
     _fields_ = [("seed", C.c_uint64), ("sub_rate", C.c_double), ("del_rate", C.c_double), ("mask_rate", C.c_double),
                 ("partial_rate", C.c_double), ("minor_permille", C.c_uint32 * 4), ("reserved", C.c_uint32)]
+
+
+class PhaseSummary(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in SUMMARY_FIELDS]
+
+
+class RunView(C.Structure):
+    """jl_run_view: pointers into the context's pinned result block (include/juliet_hip.h)."""
+    _fields_ = [("complete", C.c_uint32), ("n_variants", C.c_uint32), ("phased", C.c_uint32),
+                ("n_positions", C.c_uint32), ("n_haplotypes", C.c_uint32), ("n_var_phase", C.c_uint32),
+                ("n_reads", C.c_uint64), ("summary", PhaseSummary), ("variants", C.c_void_p),
+                ("pos_cols", C.c_void_p), ("hap_count", C.c_void_p), ("hap_pattern", C.c_void_p),
+                ("hit", C.c_void_p), ("cooc", C.c_void_p), ("read_hap", C.c_void_p)]
+
+
+def _view(addr, dtype, count):
+    """numpy array over `count` items of host memory at `addr` (no copy; the owner must outlive the array)."""
+    buf = (C.c_char * (int(count) * np.dtype(dtype).itemsize)).from_address(addr)
+    return np.frombuffer(buf, dtype=dtype, count=int(count))
 
 
 ERROR_MODELS = {  # docs/SPEC.md §5 (values UNPINNED)
@@ -108,6 +127,9 @@ def load_library(path=LIB_PATH):
     lib.jl_phase_async.argtypes = [vp, vp, u32, u32]
     lib.jl_phase_fetch.argtypes = [vp] * 8 + [u32]
     lib.jl_run_async.argtypes = [vp, vp, u32, vp, u32, C.POINTER(Params), vp, C.c_int, u32, C.c_int]
+    lib.jl_run_wait.argtypes = [vp]
+    lib.jl_run_done.argtypes = [vp]
+    lib.jl_run_view_get.argtypes = [vp, C.POINTER(RunView)]
     lib.jl_fisher_eval.argtypes = [vp, vp, vp, vp, u32, vp, vp]
     lib.jl_time_pileup.argtypes = [vp, u32, C.POINTER(C.c_float)]
     lib.jl_comm_unique_id.argtypes = [vp]
@@ -118,7 +140,7 @@ def load_library(path=LIB_PATH):
     lib.jl_allgather_variants_async.argtypes = [vp, vp]
     lib.jl_xwin_assemble_local.argtypes = [vp, vp, u32, vp, u32, vp, vp, C.POINTER(u32)]
     lib.jl_xwin_assemble_rccl.argtypes = [vp, vp, vp, vp, vp, vp, u32, vp, vp, C.POINTER(u32)]
-    if lib.jl_abi_version() != 1:
+    if lib.jl_abi_version() != 2:
         raise ImportError("libjuliet_hip.so ABI version mismatch")
     _lib = lib
     return lib
@@ -347,6 +369,50 @@ class Juliet:
             out["phase"] = dict(summary=s, pos_cols=b["pos_cols"][:vp], hap_count=b["hap_count"][:h],
                                 hap_pattern=b["hap_pattern"][:h, :vp], hit=b["hit"][:nv, :h],
                                 read_hap=b["read_hap"] if want_read_hap else None, cooc=b["cooc"][:nv, :nv])
+        return out
+
+    def run_wait(self):
+        """Block until the last run_async's results are on the host (pinned sequence word, no HIP sync)."""
+        rc = self.lib.jl_run_wait(self.h)
+        if rc:
+            self._chk(rc)
+
+    def run_done(self):
+        return bool(self.lib.jl_run_done(self.h))
+
+    def run_view(self):
+        """Zero-copy results of the last run_async: numpy views of the pinned block the kernels stored into
+        (valid until the next run on this context).  Returns None when the results do not fit that block
+        (more than 128 variants / positions / haplotypes) — use run_fetch then."""
+        v = getattr(self, "_rv", None)
+        if v is None:
+            v = self._rv = RunView()
+            self._rv_ref = C.byref(v)
+            self._rv_cache = {}
+        rc = self.lib.jl_run_view_get(self.h, self._rv_ref)
+        if rc:
+            self._chk(rc)
+        if not v.complete:
+            return None
+        key = (v.variants, v.read_hap, v.n_reads, v.phased)
+        c = self._rv_cache.get(key)
+        if c is None:   # base arrays over the whole block, built once per allocation
+            c = dict(variants=_view(v.variants, VARIANT, 128))
+            if v.phased:
+                c.update(pos_cols=_view(v.pos_cols, np.uint32, 128), hap_count=_view(v.hap_count, np.uint32, 128),
+                         hap_pattern=_view(v.hap_pattern, np.uint8, 4096), hit=_view(v.hit, np.uint8, 4096),
+                         cooc=_view(v.cooc, np.uint32, 1024) if v.cooc else None,
+                         read_hap=_view(v.read_hap, np.uint16, v.n_reads) if v.read_hap else None)
+            self._rv_cache = {key: c}
+        nv = v.n_variants
+        out = dict(variants=c["variants"][:nv])
+        if v.phased:
+            h, vp, nvp = v.n_haplotypes, v.n_positions, v.n_var_phase
+            s = {n: getattr(v.summary, n) for n in SUMMARY_FIELDS}
+            out["phase"] = dict(summary=s, pos_cols=c["pos_cols"][:vp], hap_count=c["hap_count"][:h],
+                                hap_pattern=c["hap_pattern"][:h * vp].reshape(h, vp),
+                                hit=c["hit"][:nvp * h].reshape(nvp, h), read_hap=c["read_hap"],
+                                cooc=None if c["cooc"] is None or not v.cooc else c["cooc"][:nvp * nvp].reshape(nvp, nvp))
         return out
 
     def run(self, genes, refseq=None, params=None, drm_masks=None, phasing=True, min_reads=10):

@@ -102,10 +102,14 @@ int jl_ctx_create(int device, void *stream, jl_ctx **out)
               hipMalloc(&ctx->d_hit, (size_t)JL_VARIANT_CAP * JL_MAX_HAPLOTYPES) == hipSuccess &&
               hipMalloc(&ctx->d_cooc, sizeof(uint32_t) * ctx->cooc_cap * ctx->cooc_cap) == hipSuccess &&
               hipMalloc(&ctx->d_pack, sizeof(jl_pack)) == hipSuccess &&
-              hipHostMalloc(&ctx->h_pack, sizeof(jl_pack), hipHostMallocDefault) == hipSuccess;
+              hipMalloc(&ctx->d_sync, 16 * sizeof(uint32_t)) == hipSuccess &&
+              hipHostMalloc(&ctx->h_pack, sizeof(jl_pack), hipHostMallocDefault) == hipSuccess &&
+              hipHostMalloc((void **)&ctx->h_seq, 64, hipHostMallocDefault) == hipSuccess;
     if (!ok) { jl_ctx_destroy(ctx); return jl_fail(nullptr, JL_ERR_MEMORY, "context allocation failed"); }
     hipMemsetAsync(ctx->d_nvar, 0, 2 * sizeof(uint32_t), ctx->stream);
     hipMemsetAsync(ctx->d_meta, 0, sizeof(jl_phase_meta), ctx->stream);
+    hipMemsetAsync(ctx->d_sync, 0, 16 * sizeof(uint32_t), ctx->stream);
+    *ctx->h_seq = 0;
     *out = ctx;
     return JL_OK;
 }
@@ -127,14 +131,15 @@ void jl_ctx_destroy(jl_ctx *ctx)
     if (ctx->graph_exec) hipGraphExecDestroy(ctx->graph_exec);
     if (ctx->graph) hipGraphDestroy(ctx->graph);
     if (ctx->h_pack) hipHostFree(ctx->h_pack);
+    if (ctx->h_seq) hipHostFree((void *)ctx->h_seq);
     if (ctx->h_read_hap) hipHostFree(ctx->h_read_hap);
     free_msa(ctx);
-    void *ptrs[] = {ctx->d_pos_gene, ctx->d_pos_codon, ctx->d_pos_col, ctx->d_pos_refcfg, ctx->d_colflag, ctx->d_guess, ctx->d_chunk_c0, ctx->d_chunk_n,
+    void *ptrs[] = {ctx->d_pos_gene, ctx->d_pos_codon, ctx->d_pos_col, ctx->d_pos_refcfg, ctx->d_guess, ctx->d_chunks,
                     ctx->d_counts, ctx->d_called, ctx->d_cand_p, ctx->d_cand_lp, ctx->d_cand_e, ctx->d_pos_cov,
                     ctx->d_pos_ref, ctx->d_drm, ctx->d_variants, ctx->d_nvar, ctx->d_meta, ctx->d_vpcols,
                     ctx->d_col2pos, ctx->d_varcol, ctx->d_keys, ctx->d_flagw, ctx->d_read_slot, ctx->d_read_hap,
                     ctx->d_slot_rep, ctx->d_slot_count, ctx->d_slot_key, ctx->d_slot_hap, ctx->d_occupied, ctx->d_hap_count,
-                    ctx->d_hap_pattern, ctx->d_hit, ctx->d_cooc, ctx->d_pack};
+                    ctx->d_hap_pattern, ctx->d_hit, ctx->d_cooc, ctx->d_pack, ctx->d_sync, ctx->d_timeline};
     for (void *p : ptrs)
         if (p) hipFree(p);
     if (ctx->ev0) hipEventDestroy(ctx->ev0);
@@ -326,8 +331,7 @@ static int reserve_columns(jl_ctx *ctx)
 {
     int rc;
     if (ctx->col_capacity < ctx->n_cols) {
-        if ((rc = regrow(ctx, &ctx->d_colflag, ctx->n_cols))) return rc;
-        if ((rc = regrow(ctx, &ctx->d_guess, ctx->n_cols))) return rc;
+        if ((rc = regrow(ctx, &ctx->d_guess, (size_t)ctx->n_cols + JL_GUESS_PAD))) return rc;
         if ((rc = regrow(ctx, &ctx->d_col2pos, ctx->n_cols))) return rc;
         if ((rc = regrow(ctx, &ctx->d_varcol, ctx->n_cols))) return rc;
         ctx->counts_words = (size_t)ctx->n_cols * (6 + 64);
@@ -395,7 +399,7 @@ static int build_plan(jl_ctx *ctx, const jl_gene *genes, uint32_t n_genes, const
     ctx->h_pos_gene.clear();
     ctx->h_pos_codon.clear();
     ctx->h_pos_col.clear();
-    std::vector<uint8_t> refcfg, colflag(ctx->n_cols, 0), guess(ctx->n_cols, 0);
+    std::vector<uint8_t> refcfg, colflag(ctx->n_cols, 0), guess((size_t)ctx->n_cols + JL_GUESS_PAD, 0);
     double n_tests = 0.0;
     for (uint32_t g = 0; g < n_genes; ++g) {
         if (genes[g].begin == 0 || genes[g].end <= genes[g].begin) continue;
@@ -447,15 +451,24 @@ static int build_plan(jl_ctx *ctx, const jl_gene *genes, uint32_t n_genes, const
     }
     ctx->n_chunks = (uint32_t)chunk_c0.size();
     if (ctx->chunk_capacity < chunk_c0.size()) {
-        if ((rc = regrow(ctx, &ctx->d_chunk_c0, chunk_c0.size()))) return rc;
-        if ((rc = regrow(ctx, &ctx->d_chunk_n, chunk_c0.size()))) return rc;
+        if ((rc = regrow(ctx, &ctx->d_chunks, chunk_c0.size()))) return rc;
         ctx->chunk_capacity = chunk_c0.size();
     }
+    // chunk records: first column | own columns, codon-start flags of the own columns, "needs the two halo columns"
+    std::vector<uint64_t> recs(chunk_c0.size());
+    for (size_t k = 0; k < chunk_c0.size(); ++k) {
+        const uint32_t c0 = chunk_c0[k], n = chunk_n[k];
+        uint32_t startf = 0;
+        for (uint32_t j = 0; j < n; ++j)
+            if (colflag[c0 + j] & 1) startf |= 1u << j;
+        const uint32_t halo = n >= 2u ? (startf >> (n - 2u)) != 0 : startf != 0;
+        const uint32_t meta = n | (startf << 4) | (halo << 16);
+        recs[k] = (uint64_t)c0 | ((uint64_t)meta << 32);
+    }
     hipStream_t st = ctx->stream;
-    JL_HIP(ctx, hipMemcpyAsync(ctx->d_chunk_c0, chunk_c0.data(), chunk_c0.size() * 4, hipMemcpyHostToDevice, st));
-    JL_HIP(ctx, hipMemcpyAsync(ctx->d_chunk_n, chunk_n.data(), chunk_n.size(), hipMemcpyHostToDevice, st));
-    JL_HIP(ctx, hipMemcpyAsync(ctx->d_colflag, colflag.data(), ctx->n_cols, hipMemcpyHostToDevice, st));
-    JL_HIP(ctx, hipMemcpyAsync(ctx->d_guess, guess.data(), ctx->n_cols, hipMemcpyHostToDevice, st));
+    JL_HIP(ctx, hipMemcpyAsync(ctx->d_chunks, recs.data(), recs.size() * 8, hipMemcpyHostToDevice, st));
+    // the pad behind the last column is zero; in majority mode guess_kernel overwrites [0, n_cols) only
+    JL_HIP(ctx, hipMemcpyAsync(ctx->d_guess, guess.data(), guess.size(), hipMemcpyHostToDevice, st));
     if (ctx->P) {
         JL_HIP(ctx, hipMemcpyAsync(ctx->d_pos_gene, ctx->h_pos_gene.data(), P * 4, hipMemcpyHostToDevice, st));
         JL_HIP(ctx, hipMemcpyAsync(ctx->d_pos_codon, ctx->h_pos_codon.data(), P * 4, hipMemcpyHostToDevice, st));
@@ -487,7 +500,8 @@ int jl_pileup_async(jl_ctx *ctx, const jl_gene *genes, uint32_t n_genes, const u
         int rc = build_plan(ctx, genes, n_genes, refseq, ref_len);
         if (rc) return rc;
     }
-    JL_HIP(ctx, hipMemsetAsync(ctx->d_counts, 0, ctx->counts_words * sizeof(uint32_t), ctx->stream));
+    if (jl_pileup_needs_zero(ctx))
+        JL_HIP(ctx, hipMemsetAsync(ctx->d_counts, 0, ctx->counts_words * sizeof(uint32_t), ctx->stream));
     if (!ctx->have_ref) jl_launch_guess(ctx);
     jl_launch_pileup(ctx);
     JL_HIP(ctx, hipGetLastError());
@@ -567,7 +581,7 @@ int jl_call_fetch(jl_ctx *ctx, jl_variant *out, uint32_t cap, uint32_t *n_out)
     if (!ctx || !n_out || (!out && cap)) return JL_ERR_ARG;
     if (!ctx->call_done) return jl_fail(ctx, JL_ERR_STATE, "jl_call_fetch before jl_call_async");
     if (ctx->pack_valid) {  // one pinned copy already holds the table
-        JL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (int rc = jl_run_wait_impl(ctx)) return rc;
         const jl_pack *pk = ctx->h_pack;
         if (pk->magic == JL_PACK_MAGIC && pk->fits_call) {
             *n_out = pk->nvar_total;
@@ -679,7 +693,7 @@ int jl_phase_fetch(jl_ctx *ctx, jl_phase_summary *summary, uint32_t *pos_cols, u
     if (!ctx->phase_done) return jl_fail(ctx, JL_ERR_STATE, "jl_phase_fetch before jl_phase_async");
     hipStream_t st = ctx->stream;
     if (ctx->pack_valid) {
-        JL_HIP(ctx, hipStreamSynchronize(st));
+        if (int rc = jl_run_wait_impl(ctx)) return rc;
         const jl_pack *pk = ctx->h_pack;
         if (pk->magic == JL_PACK_MAGIC && pk->phase_ran && pk->fits_phase && (!cooc || pk->cooc_fits)) {
             const uint32_t vp = pk->vp, H = pk->H, nv = pk->nv_phase;
@@ -747,17 +761,24 @@ static void enqueue_path(jl_ctx *ctx, const jl_params *prm, double n_tests, bool
                          bool want_read_hap)
 {
     hipStream_t st = ctx->stream;
-    hipMemsetAsync(ctx->d_counts, 0, ctx->counts_words * sizeof(uint32_t), st);
+    if (jl_pileup_needs_zero(ctx)) hipMemsetAsync(ctx->d_counts, 0, ctx->counts_words * sizeof(uint32_t), st);
     if (!ctx->have_ref) jl_launch_guess(ctx);
+    jl_launch_stamp(ctx, 0);
     jl_launch_pileup(ctx);
-    jl_launch_call(ctx, prm, n_tests, use_drm, phasing);
-    if (phasing) jl_launch_phase(ctx, min_reads, true);
-    jl_launch_result_pack(ctx, phasing);
+    jl_launch_stamp(ctx, 1);
+    // tuning probe: leave stages out (bit 0 call, bit 1 phase) to see what each costs the pipelined step
+    const int skip = getenv("JL_SKIP_TAIL") ? atoi(getenv("JL_SKIP_TAIL")) : 0;
+    if (!(skip & 1)) jl_launch_call(ctx, prm, n_tests, use_drm, phasing);
+    jl_launch_stamp(ctx, 2);
+    if (phasing && !(skip & 2)) jl_launch_phase(ctx, min_reads, true);
+    if (!(skip & 2)) jl_launch_result_pack(ctx, phasing);
+    jl_launch_stamp(ctx, 3);
     // no copy nodes: the result block and the per-read ids are stored straight into pinned host memory by the
     // kernels that produce them (ctx->pack_mirror / ctx->read_hap_out, set by jl_run_async)
     (void)want_read_hap;
     if (const char *e = getenv("JL_DUMMY_NODES"))   // tuning probe (tools_tuning/): cost of extra dependent nodes
         for (int k = atoi(e); k > 0; --k) jl_launch_noop(ctx);
+    jl_launch_done(ctx);   // sequence word into pinned memory: completion without a HIP sync (jl_run_wait)
 }
 
 int jl_run_async(jl_ctx *ctx, const jl_gene *genes, uint32_t n_genes, const uint8_t *refseq, uint32_t ref_len,
@@ -785,6 +806,11 @@ int jl_run_async(jl_ctx *ctx, const jl_gene *genes, uint32_t n_genes, const uint
             JL_HIP(ctx, hipHostMalloc(&ctx->h_read_hap, (size_t)ctx->col_stride * 4, hipHostMallocDefault));
             ctx->h_read_hap_cap = (size_t)ctx->col_stride * 2;
         }
+    }
+    if (!ctx->d_timeline && getenv("JL_TIMELINE")) {   // tuning aid, see stamp_kernel
+        JL_HIP(ctx, hipMalloc(&ctx->d_timeline, (size_t)JL_TIMELINE_ROWS * JL_TIMELINE_SLOTS * 8));
+        JL_HIP(ctx, hipMemset(ctx->d_timeline, 0, (size_t)JL_TIMELINE_ROWS * JL_TIMELINE_SLOTS * 8));
+        ctx->alloc_version++;
     }
     const double n_tests = prm->n_tests > 0.0 ? prm->n_tests : ctx->default_n_tests;
     ctx->last_min_reads = min_reads;
@@ -825,10 +851,89 @@ int jl_run_async(jl_ctx *ctx, const jl_gene *genes, uint32_t n_genes, const uint
         enqueue_path(ctx, prm, n_tests, drm_masks != nullptr, phasing != 0, min_reads, want_read_hap != 0);
         JL_HIP(ctx, hipGetLastError());
     }
+    ctx->runs_launched++;
     ctx->pileup_done = ctx->call_done = true;
     ctx->phase_done = phasing != 0;
     ctx->pack_valid = true;
     ctx->run_read_hap = phasing && want_read_hap;
+    return JL_OK;
+}
+
+// Spin on the pinned sequence word of the last run (see done_kernel).  A device fault would leave it unset for
+// ever, so after a long wait the stream is asked directly.
+int jl_run_wait_impl(jl_ctx *ctx)
+{
+    const uint32_t want = ctx->runs_launched;
+    volatile uint32_t *p = ctx->h_seq;
+    uint64_t spins = 0;
+    while ((int32_t)(*p - want) < 0) {
+        __builtin_ia32_pause();
+        if ((++spins & 0xFFFFFu) == 0) {   // every ~1M polls: has the stream failed or finished without the word?
+            const hipError_t q = hipStreamQuery(ctx->stream);
+            if (q == hipSuccess) {
+                if ((int32_t)(*p - want) >= 0) break;
+                return jl_fail(ctx, JL_ERR_DEVICE, "run finished without its completion word (%u of %u)", *p, want);
+            }
+            if (q != hipErrorNotReady) return jl_fail(ctx, JL_ERR_DEVICE, "run failed: %s", hipGetErrorString(q));
+        }
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    return JL_OK;
+}
+
+// tuning aid: the device-clock stamps of the last JL_TIMELINE_ROWS runs (JL_TIMELINE=1), 100 MHz ticks
+int jl_debug_timeline(jl_ctx *ctx, uint64_t *out)
+{
+    if (!ctx || !out) return JL_ERR_ARG;
+    if (!ctx->d_timeline) return jl_fail(ctx, JL_ERR_STATE, "run with JL_TIMELINE=1");
+    JL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    JL_HIP(ctx, hipMemcpy(out, ctx->d_timeline, (size_t)JL_TIMELINE_ROWS * JL_TIMELINE_SLOTS * 8, hipMemcpyDeviceToHost));
+    return JL_OK;
+}
+
+int jl_run_wait(jl_ctx *ctx)
+{
+    if (!ctx) return JL_ERR_ARG;
+    if (!ctx->pack_valid) return jl_fail(ctx, JL_ERR_STATE, "jl_run_wait needs jl_run_async first");
+    return jl_run_wait_impl(ctx);
+}
+
+int jl_run_done(jl_ctx *ctx)
+{
+    if (!ctx || !ctx->pack_valid) return 0;
+    if ((int32_t)(*ctx->h_seq - ctx->runs_launched) < 0) return 0;
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    return 1;
+}
+
+int jl_run_view_get(jl_ctx *ctx, jl_run_view *out)
+{
+    if (!ctx || !out) return JL_ERR_ARG;
+    if (!ctx->pack_valid) return jl_fail(ctx, JL_ERR_STATE, "jl_run_view_get needs jl_run_async first");
+    int rc = jl_run_wait_impl(ctx);
+    if (rc) return rc;
+    const jl_pack *pk = ctx->h_pack;
+    memset(out, 0, sizeof *out);
+    if (pk->magic != JL_PACK_MAGIC) return jl_fail(ctx, JL_ERR_STATE, "result block not written");
+    out->n_variants = pk->nvar_total;
+    out->phased = pk->phase_ran;
+    out->n_reads = ctx->n_reads;
+    out->variants = pk->variants;
+    bool ok = pk->fits_call != 0;
+    if (pk->phase_ran) {
+        ok = ok && pk->fits_phase;
+        out->n_positions = pk->vp;
+        out->n_haplotypes = pk->H;
+        out->n_var_phase = pk->nv_phase;
+        out->summary = pk->summary;
+        out->pos_cols = pk->pos_cols;
+        out->hap_count = pk->hap_count;
+        out->hap_pattern = pk->hap_pattern;
+        out->hit = pk->hit;
+        out->cooc = pk->cooc_fits ? pk->cooc : nullptr;
+        out->read_hap = ctx->run_read_hap ? ctx->h_read_hap : nullptr;
+    }
+    out->complete = ok ? 1u : 0u;
     return JL_OK;
 }
 
@@ -871,8 +976,9 @@ int jl_time_pileup(jl_ctx *ctx, uint32_t reps, float *ms_avg)
     JL_HIP(ctx, hipSetDevice(ctx->device));
     float total = 0.f;
     for (uint32_t r = 0; r < reps; ++r) {
-        // the counters are zeroed outside the timed interval; only the kernel sits between the events
-        JL_HIP(ctx, hipMemsetAsync(ctx->d_counts, 0, ctx->counts_words * sizeof(uint32_t), ctx->stream));
+        // the counters (where the launch shape needs them zeroed) are cleared outside the timed interval
+        if (jl_pileup_needs_zero(ctx))
+            JL_HIP(ctx, hipMemsetAsync(ctx->d_counts, 0, ctx->counts_words * sizeof(uint32_t), ctx->stream));
         JL_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
         jl_launch_pileup(ctx);
         JL_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));

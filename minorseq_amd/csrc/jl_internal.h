@@ -12,6 +12,9 @@
 #define JL_VARIANT_CAP 4096u      // rows of the resident variant table (all-gather stride)
 #define JL_CAND_CAP 4096u         // haplotype candidates (groups with >= min_reads) the selector can rank
 #define JL_POS_PER_WORD 10u       // variant positions per 64-bit key word (6 bits each)
+#define JL_TIMELINE_ROWS 4096u
+#define JL_TIMELINE_SLOTS 8u
+#define JL_GUESS_PAD 32u           // zero bytes after the last column's seed base
 #define JL_PILEUP_TILE_BYTES 4096u  // bytes of one column a 256-thread block reads per iteration (16 B / lane)
 
 // resolved reference codon per position
@@ -81,8 +84,8 @@ struct jl_ctx {
     uint32_t *d_pos_gene = nullptr, *d_pos_codon = nullptr, *d_pos_col = nullptr;
     uint8_t *d_pos_refcfg = nullptr;
     size_t pos_capacity = 0;
-    uint8_t *d_colflag = nullptr;  // [n_cols] bit0: a codon starts here
-    uint8_t *d_guess = nullptr;    // [n_cols] base the codon compare is seeded with (never affects results)
+    uint8_t *d_guess = nullptr;    // [n_cols + JL_GUESS_PAD] base the codon compare is seeded with (never affects
+                                   // results); the zeroed pad lets the kernel fetch it as aligned dwords
     size_t col_capacity = 0;
 
     // ---- pileup outputs: one zeroed region = col counts [n_cols][6] then hist [n_cols][64]
@@ -93,8 +96,7 @@ struct jl_ctx {
     // pileup chunk table (host-built, see build_chunks): chunk k owns columns [c0, c0 + n), n <= pileup_w
     uint32_t pileup_w = 3;
     uint32_t n_chunks = 0;
-    uint32_t *d_chunk_c0 = nullptr;
-    uint8_t *d_chunk_n = nullptr;
+    uint64_t *d_chunks = nullptr;  // [n_chunks] records {first column, JL_CHUNK_META}: see kernels_pileup.hip
     size_t chunk_capacity = 0;
 
     // ---- call
@@ -144,6 +146,11 @@ struct jl_ctx {
     uint16_t *read_hap_out = nullptr;   // where phase_assign_kernel writes (h_read_hap when the host wants the ids)
     bool pack_valid = false;          // the last stage calls were one jl_run_async
     bool run_read_hap = false;
+    // completion without a HIP sync: the last kernel of a run bumps d_sync[0] and stores it to *h_seq (pinned)
+    uint32_t *d_sync = nullptr;       // [16] zeroed once: [0] runs completed, [1..] arrival counters of fused kernels
+    volatile uint32_t *h_seq = nullptr;  // pinned
+    uint32_t runs_launched = 0;
+    uint64_t *d_timeline = nullptr;   // JL_TIMELINE=1 only: [JL_TIMELINE_ROWS][JL_TIMELINE_SLOTS] device clock stamps
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
     std::vector<uint8_t> graph_sig;
@@ -168,6 +175,8 @@ int jl_fail(jl_ctx *ctx, int status, const char *fmt, ...);
 // kernel launchers (defined in the .hip files) -------------------------------------------------
 void jl_launch_guess(jl_ctx *ctx);
 void jl_launch_pileup(jl_ctx *ctx);
+uint32_t jl_pileup_rsplit(jl_ctx *ctx);
+bool jl_pileup_needs_zero(jl_ctx *ctx);
 void jl_prepare_pileup(jl_ctx *ctx);
 void jl_launch_call(jl_ctx *ctx, const jl_params *prm, double n_tests, bool use_drm, bool with_plan);
 void jl_launch_phase(jl_ctx *ctx, uint32_t min_reads, bool planned);
@@ -176,6 +185,9 @@ void jl_launch_pack_rows(jl_ctx *ctx, const uint8_t *d_rows);
 void jl_launch_result_pack(jl_ctx *ctx, bool phasing);
 void jl_launch_validate(jl_ctx *ctx, uint32_t *d_flag);
 void jl_launch_noop(jl_ctx *ctx);
+void jl_launch_done(jl_ctx *ctx);
+void jl_launch_stamp(jl_ctx *ctx, uint32_t slot);
+extern "C" int jl_run_wait_impl(jl_ctx *ctx);
 void jl_launch_consensus(jl_ctx *ctx, uint8_t *d_out);
 void jl_launch_ingest(jl_ctx *ctx, const int32_t *d_pos, const uint32_t *d_cigar, const uint64_t *d_cig_off,
                       const uint8_t *d_seq4, const uint64_t *d_seq_off, const uint8_t *d_qual,

@@ -101,14 +101,22 @@ struct tile_regs {
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-template <int W, bool NT>
+// chunk record (host-built, capi.hip: build_chunks): x = first column, y = own columns (bits 0-3) | codon-start
+// flags of the own columns (bits 4-15) | "a codon reaches into the next two columns" (bit 16)
+#define JL_CHUNK_META(ncols, startf, halo) ((uint32_t)(ncols) | ((uint32_t)(startf) << 4) | ((uint32_t)(halo) << 16))
+
+// FAST = the common chunk of a single-frame stretch: exactly three own columns that are one codon (no halo).
+// Everything the generic path decides per column at run time is a compile-time constant then.
+template <int W, bool NT, bool FAST>
 __device__ __forceinline__ void load_tile(tile_regs<W> &r, const uint8_t *__restrict__ msa, uint64_t col_stride,
                                           uint32_t n_cols, uint32_t c0, uint32_t ncols, uint64_t off, bool need_halo)
 {
 #pragma unroll
     for (int j = 0; j < W + 2; ++j) {
+        if (FAST && j >= 3) continue;  // never touched
         // own columns j < ncols; the two columns after them only when a codon of this chunk reaches into them
-        const bool live = (c0 + j < n_cols) && ((uint32_t)j < ncols || (need_halo && (uint32_t)j < ncols + 2u));
+        const bool live = FAST ? true
+                               : (c0 + j < n_cols) && ((uint32_t)j < ncols || (need_halo && (uint32_t)j < ncols + 2u));
         if (live) {
             const u32x4 *src = reinterpret_cast<const u32x4 *>(msa + (uint64_t)(c0 + j) * col_stride + off);
             // every cell is read exactly once: a non-temporal load keeps the stream from displacing L2 lines
@@ -120,41 +128,14 @@ __device__ __forceinline__ void load_tile(tile_regs<W> &r, const uint8_t *__rest
     }
 }
 
-template <int W, bool PIPE, int MODE>
-__global__ __launch_bounds__(256) void pileup_kernel(const uint8_t *__restrict__ msa, uint64_t col_stride,
-                                                      uint32_t n_cols, uint32_t n_tiles,
-                                                      const uint32_t *__restrict__ chunk_c0,
-                                                      const uint8_t *__restrict__ chunk_n,
-                                                      const uint8_t *__restrict__ colflag,
-                                                      const uint8_t *__restrict__ guess,
-                                                      uint32_t *__restrict__ counts, uint32_t *__restrict__ hist)
+template <int W, bool PIPE, int MODE, bool FAST>
+__device__ __forceinline__ void pileup_stream(const uint8_t *__restrict__ msa, uint64_t col_stride, uint32_t n_cols,
+                                              uint32_t n_tiles, uint32_t c0, uint32_t ncols, uint32_t startf,
+                                              bool need_halo, const uint32_t (&g)[W + 2], uint32_t (*s_hist)[64],
+                                              uint32_t (*s_col)[6], uint32_t *s_match)
 {
-    __shared__ uint32_t s_hist[W][64];
-    __shared__ uint32_t s_col[W][6];   // A C G T - N
-    __shared__ uint32_t s_match[W];
-
+    constexpr bool NT = (MODE & 4) != 0;
     const uint32_t tid = threadIdx.x;
-    // chunks come from a host-built table: each starts on a codon boundary of the locally dominant frame, so
-    // single-frame stretches never need halo columns even when different genes use different frames
-    const uint32_t c0 = chunk_c0[blockIdx.x];
-    const uint32_t ncols = chunk_n[blockIdx.x];   // own columns, 1..W
-
-    for (uint32_t i = tid; i < W * 64; i += 256) (&s_hist[0][0])[i] = 0;
-    if (tid < W * 6) (&s_col[0][0])[tid] = 0;
-    if (tid < W) s_match[tid] = 0;
-    __syncthreads();
-
-    // per-column metadata is block-uniform
-    uint32_t startf = 0;     // bit j: a codon starts at column c0+j
-    uint32_t g[W + 2];       // seed base of column c0+j replicated into every nibble
-#pragma unroll
-    for (int j = 0; j < W + 2; ++j) {
-        const uint32_t c = c0 + j;
-        const uint32_t b = c < n_cols ? guess[c] & 3u : 0u;
-        g[j] = b * kM1;
-        if ((uint32_t)j < ncols && c < n_cols && (colflag[c] & 1u)) startf |= 1u << j;
-    }
-    const bool need_halo = ncols >= 2u ? (startf >> (ncols - 2u)) != 0 : startf != 0;
     const bool last_lane = (tid & 63u) == 63u;
     const uint64_t lane_off = (uint64_t)tid * 16u;
 
@@ -164,7 +145,7 @@ __global__ __launch_bounds__(256) void pileup_kernel(const uint8_t *__restrict__
     if (PIPE && tile < n_tiles) {
         const uint64_t off = (uint64_t)tile * JL_PILEUP_TILE_BYTES + lane_off;
         nxt_live = off < col_stride;
-        if (nxt_live) load_tile<W, (MODE & 4) != 0>(nxt, msa, col_stride, n_cols, c0, ncols, off, need_halo);
+        if (nxt_live) load_tile<W, NT, FAST>(nxt, msa, col_stride, n_cols, c0, ncols, off, need_halo);
     }
 
     while (tile < n_tiles) {
@@ -189,12 +170,12 @@ __global__ __launch_bounds__(256) void pileup_kernel(const uint8_t *__restrict__
                 if (tn < n_tiles) {
                     const uint64_t off = (uint64_t)tn * JL_PILEUP_TILE_BYTES + lane_off;
                     nxt_live = off < col_stride;
-                    if (nxt_live) load_tile<W, (MODE & 4) != 0>(nxt, msa, col_stride, n_cols, c0, ncols, off, need_halo);
+                    if (nxt_live) load_tile<W, NT, FAST>(nxt, msa, col_stride, n_cols, c0, ncols, off, need_halo);
                 }
             } else {
                 const uint64_t off = (uint64_t)tile * JL_PILEUP_TILE_BYTES + lane_off;
                 live = off < col_stride;  // col_stride is a multiple of 128: a 16-B chunk is all in or all out
-                if (live) load_tile<W, (MODE & 4) != 0>(cur, msa, col_stride, n_cols, c0, ncols, off, need_halo);
+                if (live) load_tile<W, NT, FAST>(cur, msa, col_stride, n_cols, c0, ncols, off, need_halo);
             }
             if (!live) continue;
             words += 4;
@@ -207,7 +188,7 @@ __global__ __launch_bounds__(256) void pileup_kernel(const uint8_t *__restrict__
             }
 #pragma unroll
             for (int j = 0; j < W; ++j) {
-                if ((uint32_t)j < ncols) {
+                if (FAST ? j < 3 : (uint32_t)j < ncols) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         if (MODE & 2) measure_popc(cur.d[j][q], acc[j]);
@@ -217,7 +198,7 @@ __global__ __launch_bounds__(256) void pileup_kernel(const uint8_t *__restrict__
             }
 #pragma unroll
             for (int j = 0; j < W; ++j) {
-                if (startf & (1u << j)) {
+                if (FAST ? j == 0 : (startf & (1u << j)) != 0) {
                     uint32_t mm[4];
                     uint32_t any = 0;
 #pragma unroll
@@ -252,13 +233,16 @@ __global__ __launch_bounds__(256) void pileup_kernel(const uint8_t *__restrict__
         const uint32_t nib = words * 8u;
 #pragma unroll
         for (int j = 0; j < W; ++j) {
+            if (FAST && j >= 3) continue;
             uint32_t nC, nG, nT, nD, nN, nU;
             solve(acc[j], nC, nG, nT, nD, nN, nU);
             const uint32_t nA = nib - (nC + nG + nT + nD + nN + nU);
             const uint32_t p0 = wave_sum(nA | (nC << 16));
             const uint32_t p1 = wave_sum(nG | (nT << 16));
             const uint32_t p2 = wave_sum(nD | (nN << 16));
-            const uint32_t p3 = wave_sum((nib - mism[j]) & 0xFFFFu);  // reads equal to the seed codon
+            const bool starts = FAST ? j == 0 : (startf & (1u << j)) != 0;
+            uint32_t p3 = 0;
+            if (starts) p3 = wave_sum((nib - mism[j]) & 0xFFFFu);  // reads equal to the seed codon (block-uniform branch)
             if (last_lane && (uint32_t)j < ncols) {
                 if (p0 & 0xFFFFu) atomicAdd(&s_col[j][0], p0 & 0xFFFFu);
                 if (p0 >> 16) atomicAdd(&s_col[j][1], p0 >> 16);
@@ -266,16 +250,72 @@ __global__ __launch_bounds__(256) void pileup_kernel(const uint8_t *__restrict__
                 if (p1 >> 16) atomicAdd(&s_col[j][3], p1 >> 16);
                 if (p2 & 0xFFFFu) atomicAdd(&s_col[j][4], p2 & 0xFFFFu);
                 if (p2 >> 16) atomicAdd(&s_col[j][5], p2 >> 16);
-                if ((startf & (1u << j)) && p3) atomicAdd(&s_match[j], p3);
+                if (starts && p3) atomicAdd(&s_match[j], p3);
             }
         }
     }
+}
+
+template <int W, bool PIPE, int MODE>
+__global__ __launch_bounds__(256) void pileup_kernel(const uint8_t *__restrict__ msa, uint64_t col_stride,
+                                                      uint32_t n_cols, uint32_t n_tiles,
+                                                      const uint2 *__restrict__ chunks,
+                                                      const uint32_t *__restrict__ guess32,
+                                                      uint32_t *__restrict__ counts, uint32_t *__restrict__ hist)
+{
+    __shared__ uint32_t s_hist[W][64];
+    __shared__ uint32_t s_col[W][6];   // A C G T - N
+    __shared__ uint32_t s_match[W];
+
+    const uint32_t tid = threadIdx.x;
+    // chunks come from a host-built table: each starts on a codon boundary of the locally dominant frame, so
+    // single-frame stretches never need halo columns even when different genes use different frames.  The record
+    // and the seed bases are block-uniform: scalar loads, all issued before the first wait.
+    const uint2 rec = chunks[blockIdx.x];
+    const uint32_t c0 = rec.x;
+    const uint32_t ncols = rec.y & 15u;               // own columns, 1..W
+    const uint32_t startf = (rec.y >> 4) & 0xFFFu;    // bit j: a codon starts at column c0+j
+    const bool need_halo = ((rec.y >> 16) & 1u) != 0;
+
+    // seed base of column c0+j replicated into every nibble; the byte array is padded, so the aligned dwords
+    // covering bytes c0 .. c0+W+1 are always in bounds
+    constexpr int NG = (W + 2 + 3 + 3) / 4;
+    uint32_t gw[NG];
+#pragma unroll
+    for (int k = 0; k < NG; ++k) gw[k] = guess32[(c0 >> 2) + k];
+    uint32_t g[W + 2];
+#pragma unroll
+    for (int j = 0; j < W + 2; ++j) {
+        const uint32_t b = (c0 & 3u) + (uint32_t)j;
+        uint32_t word = gw[0];
+#pragma unroll
+        for (int k = 1; k < NG; ++k)
+            if ((b >> 2) == (uint32_t)k) word = gw[k];
+        g[j] = ((word >> (8u * (b & 3u))) & 3u) * kM1;
+    }
+
+    for (uint32_t i = tid; i < W * 64; i += 256) (&s_hist[0][0])[i] = 0;
+    if (tid < W * 6) (&s_col[0][0])[tid] = 0;
+    if (tid < W) s_match[tid] = 0;
     __syncthreads();
 
+    if (MODE & 8) {  // tuning probe: fixed costs only
+    } else if (W == 3 && rec.y == JL_CHUNK_META(3, 1, 0))
+        pileup_stream<W, PIPE, MODE, true>(msa, col_stride, n_cols, n_tiles, c0, ncols, startf, need_halo, g, s_hist, s_col, s_match);
+    else
+        pileup_stream<W, PIPE, MODE, false>(msa, col_stride, n_cols, n_tiles, c0, ncols, startf, need_halo, g, s_hist, s_col, s_match);
+    __syncthreads();
+
+    // gridDim.y == 1: this block is the only one that counts its chunk, so the totals are plain stores and the
+    // output needs no zeroing pass; otherwise integer atomics into the zeroed region (they commute: bit-exact)
+    const bool excl = gridDim.y == 1;
     if (tid < W * 6) {
         const uint32_t j = tid / 6u, k = tid - j * 6u;
         const uint32_t v = s_col[j][k];
-        if (v && j < ncols) atomicAdd(counts + (uint64_t)(c0 + j) * 6u + k, v);
+        if (j < ncols) {
+            if (excl) counts[(uint64_t)(c0 + j) * 6u + k] = v;
+            else if (v) atomicAdd(counts + (uint64_t)(c0 + j) * 6u + k, v);
+        }
     }
     if (tid < W && (startf & (1u << tid))) {
         // reads equal to the seed codon were only counted, never binned
@@ -287,7 +327,10 @@ __global__ __launch_bounds__(256) void pileup_kernel(const uint8_t *__restrict__
     for (uint32_t i = tid; i < W * 64; i += 256) {
         const uint32_t j = i >> 6;
         const uint32_t v = s_hist[j][i & 63u];
-        if (v && (startf & (1u << j))) atomicAdd(hist + (uint64_t)(c0 + j) * 64u + (i & 63u), v);
+        if (startf & (1u << j)) {
+            if (excl) hist[(uint64_t)(c0 + j) * 64u + (i & 63u)] = v;
+            else if (v) atomicAdd(hist + (uint64_t)(c0 + j) * 64u + (i & 63u), v);
+        }
     }
 }
 
@@ -325,24 +368,18 @@ __global__ __launch_bounds__(64) void guess_kernel(const uint8_t *__restrict__ m
 struct variant_t {
     int w;
     bool pipe;
-    void (*fn)(const uint8_t *, uint64_t, uint32_t, uint32_t, const uint32_t *, const uint8_t *, const uint8_t *,
-               const uint8_t *, uint32_t *, uint32_t *);
+    int mode;  // bit 0: loads only (probe), bit 1: popcount measurements (probe), bit 2: non-temporal loads, bit 3: no stream (probe)
+    void (*fn)(const uint8_t *, uint64_t, uint32_t, uint32_t, const uint2 *, const uint32_t *, uint32_t *, uint32_t *);
 };
 
 // Default builds use non-temporal loads: every cell is read once, and at 2.4 GB they lift the stream from 5.6 to
 // 6.3 TB/s (no difference at 150 MB).
+#define JL_V(W, P, M) {W, P, M, pileup_kernel<W, P, M>}
 const variant_t kVariants[] = {
-    {6, false, pileup_kernel<6, false, 4>},
-    {6, true, pileup_kernel<6, true, 4>},
-    {12, false, pileup_kernel<12, false, 4>},
-    {3, false, pileup_kernel<3, false, 4>},
-    {3, true, pileup_kernel<3, true, 4>},
-#ifdef JL_PILEUP_TUNING
-    {106, false, pileup_kernel<6, false, 5>},   // W = 100 + w: load-only probe
-    {206, false, pileup_kernel<6, false, 6>},   // W = 200 + w: popcount measurements
-    {403, false, pileup_kernel<3, false, 0>},   // W = 400 + w: plain (temporal) loads
-    {406, false, pileup_kernel<6, false, 0>},
-    {9, false, pileup_kernel<9, false, 4>},
+    JL_V(6, false, 4), JL_V(6, true, 4), JL_V(12, false, 4), JL_V(3, false, 4), JL_V(3, true, 4),
+#ifdef JL_PILEUP_TUNING   // probes (results wrong by design except mode 0/6): JL_PILEUP_MODE selects
+    JL_V(3, false, 5), JL_V(3, true, 5), JL_V(3, false, 12), JL_V(3, false, 0), JL_V(3, true, 0), JL_V(3, false, 6),
+    JL_V(6, false, 5), JL_V(6, false, 0), JL_V(9, false, 4),
 #endif
 };
 
@@ -368,13 +405,15 @@ static int pick_variant(const jl_ctx *ctx)
     // variant must match it.  JL_PILEUP_PIPE selects the register-prefetching build (tuning).
     const int want_w = (int)ctx->pileup_w;
     const bool want_pipe = env_int("JL_PILEUP_PIPE", JL_PILEUP_PIPE) != 0;
-    int idx = -1;
-    for (int i = 0; i < (int)(sizeof(kVariants) / sizeof(kVariants[0])); ++i)
-        if (kVariants[i].w == want_w && kVariants[i].pipe == want_pipe) idx = i;
-    if (idx < 0)
-        for (int i = 0; i < (int)(sizeof(kVariants) / sizeof(kVariants[0])); ++i)
-            if (kVariants[i].w == want_w && !kVariants[i].pipe) idx = i;
-    return idx < 0 ? 0 : idx;
+    const int want_mode = env_int("JL_PILEUP_MODE", 4);
+    const int n = (int)(sizeof(kVariants) / sizeof(kVariants[0]));
+    for (int i = 0; i < n; ++i)
+        if (kVariants[i].w == want_w && kVariants[i].pipe == want_pipe && kVariants[i].mode == want_mode) return i;
+    for (int i = 0; i < n; ++i)
+        if (kVariants[i].w == want_w && kVariants[i].pipe == want_pipe && kVariants[i].mode == 4) return i;
+    for (int i = 0; i < n; ++i)
+        if (kVariants[i].w == want_w && !kVariants[i].pipe && kVariants[i].mode == 4) return i;
+    return 0;
 }
 
 // occupancy query, once per variant and outside any stream capture
@@ -389,14 +428,14 @@ void jl_prepare_pileup(jl_ctx *ctx)
     ctx->pileup_blocks_per_cu[idx] = per_cu;
 }
 
-void jl_launch_pileup(jl_ctx *ctx)
+// Launch shape: chunks x read splits.  One resident wave of blocks (CUs x the blocks the kernel's registers admit
+// per CU) for short columns, four per slot for long ones; reads are split no finer than a tile.
+uint32_t jl_pileup_rsplit(jl_ctx *ctx)
 {
     const int idx = pick_variant(ctx);
-    const variant_t *var = &kVariants[idx];
     jl_prepare_pileup(ctx);
-    const uint32_t n_chunks = ctx->n_chunks;
+    const uint32_t n_chunks = ctx->n_chunks ? ctx->n_chunks : 1u;
     const uint32_t n_tiles = (uint32_t)((ctx->col_stride + JL_PILEUP_TILE_BYTES - 1) / JL_PILEUP_TILE_BYTES);
-    // one resident wave of blocks: (CUs x blocks the kernel's registers admit per CU), reads split no finer than a tile
     const int per_cu = ctx->pileup_blocks_per_cu[idx];
     // long columns: several blocks per slot smooth the tail; short ones: exactly one resident wave of blocks
     const uint32_t target = 256u * (uint32_t)per_cu * (uint32_t)env_int("JL_PILEUP_WAVES", n_tiles >= 64 ? 4 : 1);
@@ -406,6 +445,23 @@ void jl_launch_pileup(jl_ctx *ctx)
     if (rsplit > n_tiles) rsplit = n_tiles;
     if (rsplit < 1) rsplit = 1;
     if (rsplit > 65535u) rsplit = 65535u;
-    hipLaunchKernelGGL(var->fn, dim3(n_chunks, rsplit), dim3(256), 0, ctx->stream, ctx->d_msa, ctx->col_stride,
-                       ctx->n_cols, n_tiles, ctx->d_chunk_c0, ctx->d_chunk_n, ctx->d_colflag, ctx->d_guess, ctx->d_counts, ctx->d_hist);
+    return rsplit;
+}
+
+// With one read split every chunk is counted by exactly one block, which stores its totals: no zeroing needed.
+bool jl_pileup_needs_zero(jl_ctx *ctx) { return jl_pileup_rsplit(ctx) != 1u; }
+
+void jl_launch_pileup(jl_ctx *ctx)
+{
+    const int idx = pick_variant(ctx);
+    const variant_t *var = &kVariants[idx];
+    const uint32_t n_tiles = (uint32_t)((ctx->col_stride + JL_PILEUP_TILE_BYTES - 1) / JL_PILEUP_TILE_BYTES);
+    const uint32_t rsplit = jl_pileup_rsplit(ctx);
+    // Unused dynamic LDS caps the blocks per CU: one pileup launch then fills the chip's block slots by itself, so
+    // a second batch's pileup (another stream) starts as this one's blocks retire instead of running beside it —
+    // two 150 MB streams side by side reach 3.6 TB/s together, one alone 5.5 (tools_tuning/timeline.py).
+    const uint32_t lds_pad = (uint32_t)env_int("JL_PILEUP_LDS_KB", 0) * 1024u;
+    hipLaunchKernelGGL(var->fn, dim3(ctx->n_chunks, rsplit), dim3(256), lds_pad, ctx->stream, ctx->d_msa, ctx->col_stride,
+                       ctx->n_cols, n_tiles, (const uint2 *)ctx->d_chunks, (const uint32_t *)ctx->d_guess, ctx->d_counts,
+                       ctx->d_hist);
 }

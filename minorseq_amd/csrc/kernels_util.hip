@@ -169,6 +169,33 @@ __global__ __launch_bounds__(256) void validate_kernel(const uint8_t *__restrict
 
 }  // namespace
 
+// Last node of a run: everything before it on the stream has completed (including the stores the result
+// kernels made into pinned host memory), so a sequence word stored behind a system-scope fence tells a
+// polling host that the results are there — no hipStreamSynchronize on the hot path.
+__global__ void done_kernel(uint32_t *__restrict__ seq_dev, volatile uint32_t *__restrict__ seq_host)
+{
+    const uint32_t v = *seq_dev + 1u;
+    *seq_dev = v;
+    __threadfence_system();
+    __hip_atomic_store(const_cast<uint32_t *>(seq_host), v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+void jl_launch_done(jl_ctx *ctx)
+{
+    hipLaunchKernelGGL(done_kernel, dim3(1), dim3(1), 0, ctx->stream, ctx->d_sync, ctx->h_seq);
+}
+
+// tuning aid (JL_TIMELINE=1): a one-thread node that records the device's constant-rate clock between the stages of
+// a run, row = runs completed so far; read back with jl_debug_timeline (tools_tuning/timeline.py)
+__global__ void stamp_kernel(const uint32_t *__restrict__ seq_dev, uint64_t *__restrict__ tl, uint32_t slot)
+{
+    tl[(uint64_t)(*seq_dev % JL_TIMELINE_ROWS) * JL_TIMELINE_SLOTS + slot] = wall_clock64();
+}
+void jl_launch_stamp(jl_ctx *ctx, uint32_t slot)
+{
+    if (!ctx->d_timeline) return;
+    hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(1), 0, ctx->stream, ctx->d_sync, ctx->d_timeline, slot);
+}
+
 // tuning probe: what does one more (empty) dependent node cost a pipelined step?
 __global__ void noop_kernel(uint32_t *p) { if (p == nullptr && threadIdx.x == 12345u) *p = 0; }
 void jl_launch_noop(jl_ctx *ctx) { hipLaunchKernelGGL(noop_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->d_nvar); }

@@ -432,6 +432,51 @@ def test_run_results_larger_than_the_pack(jl, oracle):
     j.close()
 
 
+def test_run_view_and_completion_word(jl, oracle):
+    """jl_run_wait / jl_run_view_get: completion through the pinned sequence word (no HIP sync) and results read
+    in place must equal the copying fetch and the oracle, over many replays and with several contexts in flight;
+    a result too large for the pinned block yields no view."""
+    n, l = 9000, 300
+    genes = np.array([(1, l + 1)], dtype=capi.GENE)
+    ctxs, exps = [], []
+    for k in range(3):
+        sp = synth.SynthParams(seed=70 + k, minor_permille=(70, 50, 40, 30), partial_rate=0.05)
+        ref = synth.reference(70, l)
+        j = capi.Juliet(0)
+        j.alloc(n, l)
+        j.synth_fill(sp, ref)
+        rows = msa.unpack_columns(j.download_columns(), n)
+        exp_v = oracle.call(rows, genes, refseq=ref)
+        ctxs.append((j, ref))
+        exps.append((exp_v, oracle.phase(rows, exp_v)))
+    prm = capi.default_params()
+    for rep in range(12):
+        for j, ref in ctxs:
+            j.run_async(genes, ref, prm, None, True, 10, True)
+        for (j, ref), (exp_v, exp_p) in zip(ctxs, exps):
+            j.run_wait()
+            assert j.run_done()
+            v = j.run_view()
+            assert v is not None
+            assert_variants_equal(v["variants"], exp_v)
+            assert_phase_equal(v["phase"], exp_p, len(exp_v))
+            f = j.run_fetch(True, True, cap_var=64)
+            assert (f["variants"] == v["variants"]).all()
+            assert (f["phase"]["read_hap"] == v["phase"]["read_hap"]).all()
+    # phasing off: the view carries only the table
+    j, ref = ctxs[0]
+    j.run_async(genes, ref, prm, None, False, 10, False)
+    v = j.run_view()
+    assert v is not None and "phase" not in v
+    assert_variants_equal(v["variants"], exps[0][0])
+    # too many rows for the block: no view, the fetch calls still work
+    loose = capi.default_params(alpha=0.9, n_tests=1.0)
+    j.run_async(genes, None, loose, None, True, 3, True)
+    assert j.run_view() is None
+    for j, _ in ctxs:
+        j.close()
+
+
 # --------------------------------------------------------------------------------------------- the collective
 def test_allgather_variants_single_rank_communicator(jl, oracle):
     """jl_allgather_variants over a real RCCL communicator (world = 1 is all one GPU allows here): the payload
