@@ -222,8 +222,12 @@ def main():
     fence()
     latency_ms = 1000.0 * (time.perf_counter() - t1) / 20
 
-    # dominant kernel alone, HIP events on the stream it is launched on
-    t_pileup_ms = jl.time_pileup(reps=max(10, args.steps))
+    # dominant kernel alone: HIP events on the stream it is launched on, around back-to-back launches that rotate
+    # over the resident batches (with 4 x 150 MB no launch finds its window in the 256 MiB Infinity Cache)
+    try:
+        t_pileup_ms = capi.time_pileup_set(ctxs, reps=max(20, args.steps))
+    except capi.JulietError:   # launch shapes that need zeroed counters (long columns): one launch per event pair
+        t_pileup_ms = jl.time_pileup(reps=max(10, args.steps))
     alg_bytes = n * l / 2.0
     achieved = alg_bytes / (t_pileup_ms * 1e-3) / 1e9
     traffic = None

@@ -257,6 +257,9 @@ int jl_fisher_eval(jl_ctx *ctx, const uint32_t *a, const uint32_t *c, const uint
 
 /* Average device time in ms of `reps` back-to-back launches of the pileup kernel alone, by HIP events on the ctx stream. */
 int jl_time_pileup(jl_ctx *ctx, uint32_t reps, float *ms_avg);
+/* The same over several contexts' resident windows in rotation, all on the first context's stream: no launch finds
+ * its input in the Infinity Cache (4 x 150 MB > 256 MiB), as in a pipelined loop over several batches. */
+int jl_time_pileup_set(jl_ctx *const *ctxs, uint32_t n_ctx, uint32_t reps, float *ms_avg);
 /* Name of the dominant kernel as rocprofv3 reports it. */
 const char *jl_pileup_kernel_name(void);
 

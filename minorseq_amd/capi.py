@@ -31,7 +31,7 @@ EXPORTS = ("jl_abi_version", "jl_strerror", "jl_device_count", "jl_ctx_create", 
            "jl_sync", "jl_col_stride", "jl_msa_upload", "jl_msa_alloc", "jl_msa_adopt", "jl_msa_pack_rows",
            "jl_msa_ingest_records", "jl_msa_download", "jl_synth_fill", "jl_pileup_async", "jl_n_positions", "jl_pileup_fetch",
            "jl_consensus_fetch", "jl_call_async", "jl_call_fetch", "jl_variant_table_device", "jl_phase_async", "jl_phase_fetch",
-           "jl_run_async", "jl_run_wait", "jl_run_done", "jl_run_view_get", "jl_fisher_eval", "jl_time_pileup", "jl_pileup_kernel_name", "jl_comm_unique_id", "jl_comm_create", "jl_comm_destroy",
+           "jl_run_async", "jl_run_wait", "jl_run_done", "jl_run_view_get", "jl_fisher_eval", "jl_time_pileup", "jl_time_pileup_set", "jl_pileup_kernel_name", "jl_comm_unique_id", "jl_comm_create", "jl_comm_destroy",
            "jl_allgather_variants", "jl_allgather_variants_async", "jl_xwin_assemble_local",
            "jl_xwin_assemble_rccl")
 
@@ -132,6 +132,7 @@ def load_library(path=LIB_PATH):
     lib.jl_run_view_get.argtypes = [vp, C.POINTER(RunView)]
     lib.jl_fisher_eval.argtypes = [vp, vp, vp, vp, u32, vp, vp]
     lib.jl_time_pileup.argtypes = [vp, u32, C.POINTER(C.c_float)]
+    lib.jl_time_pileup_set.argtypes = [vp, u32, u32, C.POINTER(C.c_float)]
     lib.jl_comm_unique_id.argtypes = [vp]
     lib.jl_comm_create.argtypes = [vp, vp, C.c_int, C.c_int, C.POINTER(vp)]
     lib.jl_comm_destroy.argtypes = [vp]
@@ -462,6 +463,14 @@ def phase_across_windows(windows, merged, min_reads=10, comm=None, win_begins=No
         ph["cooc"] = ph["cooc"][: len(merged), : len(merged)].copy()
     pc.close()
     return ph, pos_global[: vp.value].copy()
+
+
+def time_pileup_set(ctxs, reps=20):
+    """Average ms per pileup launch over the contexts' windows in rotation (jl_time_pileup_set)."""
+    arr = (C.c_void_p * len(ctxs))(*[c.h for c in ctxs])
+    ms = C.c_float()
+    ctxs[0]._chk(ctxs[0].lib.jl_time_pileup_set(arr, len(ctxs), reps, C.byref(ms)))
+    return float(ms.value)
 
 
 def haplotype_name(h: int) -> str:

@@ -93,6 +93,7 @@ int jl_ctx_create(int device, void *stream, jl_ctx **out)
     }
     hipEventCreate(&ctx->ev0);
     hipEventCreate(&ctx->ev1);
+
     bool ok = hipMalloc(&ctx->d_variants, sizeof(jl_variant) * JL_VARIANT_CAP) == hipSuccess &&
               hipMalloc(&ctx->d_nvar, 2 * sizeof(uint32_t)) == hipSuccess &&
               hipMalloc(&ctx->d_meta, sizeof(jl_phase_meta)) == hipSuccess &&
@@ -135,8 +136,7 @@ void jl_ctx_destroy(jl_ctx *ctx)
     if (ctx->h_read_hap) hipHostFree(ctx->h_read_hap);
     free_msa(ctx);
     void *ptrs[] = {ctx->d_pos_gene, ctx->d_pos_codon, ctx->d_pos_col, ctx->d_pos_refcfg, ctx->d_guess, ctx->d_chunks,
-                    ctx->d_counts, ctx->d_called, ctx->d_cand_p, ctx->d_cand_lp, ctx->d_cand_e, ctx->d_pos_cov,
-                    ctx->d_pos_ref, ctx->d_drm, ctx->d_variants, ctx->d_nvar, ctx->d_meta, ctx->d_vpcols,
+                    ctx->d_counts, ctx->d_called, ctx->d_staged, ctx->d_drm, ctx->d_variants, ctx->d_nvar, ctx->d_meta, ctx->d_vpcols,
                     ctx->d_col2pos, ctx->d_varcol, ctx->d_keys, ctx->d_flagw, ctx->d_read_slot, ctx->d_read_hap,
                     ctx->d_slot_rep, ctx->d_slot_count, ctx->d_slot_key, ctx->d_slot_hap, ctx->d_occupied, ctx->d_hap_count,
                     ctx->d_hap_pattern, ctx->d_hit, ctx->d_cooc, ctx->d_pack, ctx->d_sync, ctx->d_timeline};
@@ -144,6 +144,7 @@ void jl_ctx_destroy(jl_ctx *ctx)
         if (p) hipFree(p);
     if (ctx->ev0) hipEventDestroy(ctx->ev0);
     if (ctx->ev1) hipEventDestroy(ctx->ev1);
+
     if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -441,11 +442,7 @@ static int build_plan(jl_ctx *ctx, const jl_gene *genes, uint32_t n_genes, const
         if ((rc = regrow(ctx, &ctx->d_pos_col, P))) return rc;
         if ((rc = regrow(ctx, &ctx->d_pos_refcfg, P))) return rc;
         if ((rc = regrow(ctx, &ctx->d_called, P))) return rc;
-        if ((rc = regrow(ctx, &ctx->d_cand_p, P * 64))) return rc;
-        if ((rc = regrow(ctx, &ctx->d_cand_lp, P * 64))) return rc;
-        if ((rc = regrow(ctx, &ctx->d_cand_e, P * 64))) return rc;
-        if ((rc = regrow(ctx, &ctx->d_pos_cov, P))) return rc;
-        if ((rc = regrow(ctx, &ctx->d_pos_ref, P))) return rc;
+        if ((rc = regrow(ctx, &ctx->d_staged, P * 64))) return rc;
         if ((rc = regrow(ctx, &ctx->d_drm, P))) return rc;
         ctx->pos_capacity = P;
     }
@@ -502,8 +499,8 @@ int jl_pileup_async(jl_ctx *ctx, const jl_gene *genes, uint32_t n_genes, const u
     }
     if (jl_pileup_needs_zero(ctx))
         JL_HIP(ctx, hipMemsetAsync(ctx->d_counts, 0, ctx->counts_words * sizeof(uint32_t), ctx->stream));
-    if (!ctx->have_ref) jl_launch_guess(ctx);
-    jl_launch_pileup(ctx);
+    if (!ctx->have_ref) jl_launch_guess(ctx, ctx->stream);
+    jl_launch_pileup(ctx, ctx->stream);
     JL_HIP(ctx, hipGetLastError());
     ctx->pileup_done = true;
     ctx->call_done = ctx->phase_done = false;
@@ -679,7 +676,7 @@ int jl_phase_async(jl_ctx *ctx, const jl_variant *variants, uint32_t n_var, uint
     ctx->last_min_reads = min_reads;
     ctx->pack_mirror = nullptr;
     ctx->read_hap_out = nullptr;
-    jl_launch_phase(ctx, min_reads, false);
+    jl_launch_phase(ctx, min_reads, false, false);
     JL_HIP(ctx, hipGetLastError());
     ctx->phase_done = true;
     ctx->pack_valid = false;
@@ -729,7 +726,7 @@ int jl_phase_fetch(jl_ctx *ctx, jl_phase_summary *summary, uint32_t *pos_cols, u
         if (meta.vp_true > JL_POS_PER_WORD) ctx->phase_generic = true;
         int rc = reserve_phase(ctx, (meta.vp_true + JL_POS_PER_WORD - 1) / JL_POS_PER_WORD);
         if (rc) return rc;
-        jl_launch_phase(ctx, ctx->last_min_reads, false);
+        jl_launch_phase(ctx, ctx->last_min_reads, false, false);
         JL_HIP(ctx, hipGetLastError());
         JL_HIP(ctx, hipMemcpyAsync(&meta, ctx->d_meta, sizeof meta, hipMemcpyDeviceToHost, st));
         if (read_hap && !ids_pinned) JL_HIP(ctx, hipMemcpyAsync(read_hap, ctx->d_read_hap, (size_t)ctx->n_reads * 2, hipMemcpyDeviceToHost, st));
@@ -762,23 +759,26 @@ static void enqueue_path(jl_ctx *ctx, const jl_params *prm, double n_tests, bool
 {
     hipStream_t st = ctx->stream;
     if (jl_pileup_needs_zero(ctx)) hipMemsetAsync(ctx->d_counts, 0, ctx->counts_words * sizeof(uint32_t), st);
-    if (!ctx->have_ref) jl_launch_guess(ctx);
+    if (!ctx->have_ref) jl_launch_guess(ctx, st);
     jl_launch_stamp(ctx, 0);
-    jl_launch_pileup(ctx);
+    jl_launch_pileup(ctx, st);
     jl_launch_stamp(ctx, 1);
     // tuning probe: leave stages out (bit 0 call, bit 1 phase) to see what each costs the pipelined step
     const int skip = getenv("JL_SKIP_TAIL") ? atoi(getenv("JL_SKIP_TAIL")) : 0;
     if (!(skip & 1)) jl_launch_call(ctx, prm, n_tests, use_drm, phasing);
     jl_launch_stamp(ctx, 2);
-    if (phasing && !(skip & 2)) jl_launch_phase(ctx, min_reads, true);
-    if (!(skip & 2)) jl_launch_result_pack(ctx, phasing);
+    // the last kernel of the run stores the completion word (jl_run_wait); probes that leave it out, and the
+    // timeline stamps behind it, need the stand-alone node instead
+    const bool own_done = skip != 0 || ctx->d_timeline != nullptr || getenv("JL_DUMMY_NODES") != nullptr;
+    if (phasing && !(skip & 2)) jl_launch_phase(ctx, min_reads, true, !own_done);
+    if (!(skip & 2)) jl_launch_result_pack(ctx, phasing, !own_done);
     jl_launch_stamp(ctx, 3);
     // no copy nodes: the result block and the per-read ids are stored straight into pinned host memory by the
     // kernels that produce them (ctx->pack_mirror / ctx->read_hap_out, set by jl_run_async)
     (void)want_read_hap;
     if (const char *e = getenv("JL_DUMMY_NODES"))   // tuning probe (tools_tuning/): cost of extra dependent nodes
         for (int k = atoi(e); k > 0; --k) jl_launch_noop(ctx);
-    jl_launch_done(ctx);   // sequence word into pinned memory: completion without a HIP sync (jl_run_wait)
+    if (own_done) jl_launch_done(ctx);
 }
 
 int jl_run_async(jl_ctx *ctx, const jl_gene *genes, uint32_t n_genes, const uint8_t *refseq, uint32_t ref_len,
@@ -825,6 +825,7 @@ int jl_run_async(jl_ctx *ctx, const jl_gene *genes, uint32_t n_genes, const uint
     sig.drm = drm_masks != nullptr; sig.phasing = phasing != 0; sig.min_reads = min_reads; sig.rh = want_read_hap != 0; sig.generic = ctx->phase_generic; sig.pad = (uint32_t)(uintptr_t)ctx->read_hap_out;
     const bool graphs_on = !getenv("JL_NO_GRAPH");
     bool launched = false;
+
     if (graphs_on) {
         const bool hit = ctx->graph_exec && ctx->graph_sig.size() == sizeof sig && memcmp(ctx->graph_sig.data(), &sig, sizeof sig) == 0;
         if (!hit) {
@@ -975,21 +976,61 @@ int jl_time_pileup(jl_ctx *ctx, uint32_t reps, float *ms_avg)
     if (!ctx->plan_valid) return jl_fail(ctx, JL_ERR_STATE, "jl_time_pileup needs a plan: call jl_pileup_async once first");
     JL_HIP(ctx, hipSetDevice(ctx->device));
     float total = 0.f;
-    for (uint32_t r = 0; r < reps; ++r) {
-        // the counters (where the launch shape needs them zeroed) are cleared outside the timed interval
-        if (jl_pileup_needs_zero(ctx))
-            JL_HIP(ctx, hipMemsetAsync(ctx->d_counts, 0, ctx->counts_words * sizeof(uint32_t), ctx->stream));
+    if (!jl_pileup_needs_zero(ctx)) {
+        // nothing but the kernel goes on the stream: one pair of events around `reps` back-to-back launches, so the
+        // events' own latency (~3 us around a single launch) is not charged to the kernel; the figure includes the
+        // gaps between consecutive launches and agrees with rocprofv3's per-dispatch average to ~1 us
         JL_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-        jl_launch_pileup(ctx);
+        for (uint32_t r = 0; r < reps; ++r) jl_launch_pileup(ctx, ctx->stream);
         JL_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
         JL_HIP(ctx, hipEventSynchronize(ctx->ev1));
-        float ms = 0.f;
-        JL_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
-        total += ms;
+        JL_HIP(ctx, hipEventElapsedTime(&total, ctx->ev0, ctx->ev1));
+    } else {
+        for (uint32_t r = 0; r < reps; ++r) {
+            // the counters are cleared outside the timed interval; only the kernel sits between the events
+            JL_HIP(ctx, hipMemsetAsync(ctx->d_counts, 0, ctx->counts_words * sizeof(uint32_t), ctx->stream));
+            JL_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+            jl_launch_pileup(ctx, ctx->stream);
+            JL_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+            JL_HIP(ctx, hipEventSynchronize(ctx->ev1));
+            float ms = 0.f;
+            JL_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+            total += ms;
+        }
     }
     *ms_avg = total / (float)reps;
     ctx->pileup_done = true;
     ctx->call_done = ctx->phase_done = false;
+    return JL_OK;
+}
+
+// The same measurement over several resident windows in rotation (all launches on the first context's stream): with
+// four 150 MB windows no launch finds its input in the 256 MiB Infinity Cache, as in the pipelined bench loop.
+int jl_time_pileup_set(jl_ctx *const *ctxs, uint32_t n_ctx, uint32_t reps, float *ms_avg)
+{
+    if (!ctxs || n_ctx == 0 || !ms_avg || reps == 0) return JL_ERR_ARG;
+    jl_ctx *c0 = ctxs[0];
+    if (!c0) return JL_ERR_ARG;
+    for (uint32_t k = 0; k < n_ctx; ++k) {
+        if (!ctxs[k] || ctxs[k]->device != c0->device) return jl_fail(c0, JL_ERR_ARG, "contexts must share a device");
+        if (!ctxs[k]->plan_valid) return jl_fail(c0, JL_ERR_STATE, "jl_time_pileup_set needs a plan on every context");
+        if (jl_pileup_needs_zero(ctxs[k])) return jl_fail(c0, JL_ERR_STATE, "this launch shape needs zeroed counters: use jl_time_pileup");
+    }
+    JL_HIP(c0, hipSetDevice(c0->device));
+    for (uint32_t k = 0; k < n_ctx; ++k) JL_HIP(c0, hipStreamSynchronize(ctxs[k]->stream));
+    for (uint32_t k = 0; k < n_ctx; ++k) jl_launch_pileup(ctxs[k], c0->stream);   // warm-up, one per window
+    JL_HIP(c0, hipEventRecord(c0->ev0, c0->stream));
+    for (uint32_t r = 0; r < reps; ++r) jl_launch_pileup(ctxs[r % n_ctx], c0->stream);
+    JL_HIP(c0, hipEventRecord(c0->ev1, c0->stream));
+    JL_HIP(c0, hipEventSynchronize(c0->ev1));
+    float total = 0.f;
+    JL_HIP(c0, hipEventElapsedTime(&total, c0->ev0, c0->ev1));
+    *ms_avg = total / (float)reps;
+    for (uint32_t k = 0; k < n_ctx; ++k) {
+        ctxs[k]->pileup_done = true;
+        ctxs[k]->call_done = ctxs[k]->phase_done = false;
+        ctxs[k]->pack_valid = false;
+    }
     return JL_OK;
 }
 

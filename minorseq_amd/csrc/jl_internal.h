@@ -101,11 +101,7 @@ struct jl_ctx {
 
     // ---- call
     uint64_t *d_called = nullptr;  // [P] mask of called codons
-    double *d_cand_p = nullptr;    // [P][64]
-    double *d_cand_lp = nullptr;   // [P][64]
-    uint32_t *d_cand_e = nullptr;  // [P][64]
-    uint32_t *d_pos_cov = nullptr; // [P]
-    uint8_t *d_pos_ref = nullptr;  // [P] resolved reference codon or JL_REF_SKIP
+    jl_variant *d_staged = nullptr;  // [P][64] finished rows of the called codons, before the ordered compaction
     uint64_t *d_drm = nullptr;     // [P] optional
     jl_variant *d_variants = nullptr;  // [JL_VARIANT_CAP]
     uint32_t *d_nvar = nullptr;        // [0] rows needed, [1] spare
@@ -173,16 +169,16 @@ int jl_fail(jl_ctx *ctx, int status, const char *fmt, ...);
     } while (0)
 
 // kernel launchers (defined in the .hip files) -------------------------------------------------
-void jl_launch_guess(jl_ctx *ctx);
-void jl_launch_pileup(jl_ctx *ctx);
+void jl_launch_guess(jl_ctx *ctx, hipStream_t st);
+void jl_launch_pileup(jl_ctx *ctx, hipStream_t st);
 uint32_t jl_pileup_rsplit(jl_ctx *ctx);
 bool jl_pileup_needs_zero(jl_ctx *ctx);
 void jl_prepare_pileup(jl_ctx *ctx);
 void jl_launch_call(jl_ctx *ctx, const jl_params *prm, double n_tests, bool use_drm, bool with_plan);
-void jl_launch_phase(jl_ctx *ctx, uint32_t min_reads, bool planned);
+void jl_launch_phase(jl_ctx *ctx, uint32_t min_reads, bool planned, bool signal);
 void jl_launch_synth(jl_ctx *ctx, const jl_synth_plan *plan, const uint8_t *d_ref);
 void jl_launch_pack_rows(jl_ctx *ctx, const uint8_t *d_rows);
-void jl_launch_result_pack(jl_ctx *ctx, bool phasing);
+void jl_launch_result_pack(jl_ctx *ctx, bool phasing, bool signal);
 void jl_launch_validate(jl_ctx *ctx, uint32_t *d_flag);
 void jl_launch_noop(jl_ctx *ctx);
 void jl_launch_done(jl_ctx *ctx);

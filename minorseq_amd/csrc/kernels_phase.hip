@@ -191,6 +191,251 @@ __global__ __launch_bounds__(256) void phase_group_kernel(uint64_t n_reads, uint
     }
 }
 
+// Completion word of a run (see jl_run_wait): stored by ONE thread after everything the run wrote for the host
+// has been drained by its writers and a block barrier; `seq_host` is pinned host memory.
+__device__ __forceinline__ void signal_done(uint32_t *seq_dev, volatile uint32_t *seq_host)
+{
+    const uint32_t v = __hip_atomic_load(seq_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+    __hip_atomic_store(seq_dev, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence_system();
+    __hip_atomic_store(const_cast<uint32_t *>(seq_host), v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// ---------------------------------------------------------------------------------------- result pack
+// Block-level: gathers the small results into one fixed-size block for a single pinned D2H copy.
+__device__ __forceinline__ void result_pack_block(const jl_variant *__restrict__ variants, uint32_t n,
+                                                  const jl_phase_meta *meta, uint32_t phasing,
+                                                  const uint32_t *__restrict__ vpcols,
+                                                  const uint32_t *__restrict__ hap_count,
+                                                  const uint8_t *__restrict__ hap_pattern,
+                                                  const uint8_t *__restrict__ hit, const uint32_t *__restrict__ cooc,
+                                                  uint32_t cooc_cap, uint32_t cooc_ready, jl_pack *__restrict__ pk,
+                                                  jl_pack *__restrict__ pk2)
+{
+    // pk: device copy (all-gather source); pk2: pinned host mirror (may be null) — both written directly
+    const uint32_t tid = threadIdx.x, nt = blockDim.x;
+    const uint32_t fits_call = n <= JL_PACK_MAX_VAR;
+    uint32_t vp = 0, H = 0, nv = 0, ovf = 0, fits_phase = 0, cooc_fits = 0;
+    if (phasing) {
+        vp = meta->vp; H = meta->summary.n_haplotypes; nv = meta->n_var; ovf = meta->overflow;
+        fits_phase = ovf == 0 && fits_call && vp <= JL_PACK_MAX_VP && H <= JL_PACK_MAX_HAP &&
+                     H * vp <= JL_PACK_PATTERN_BYTES && nv * H <= JL_PACK_HIT_BYTES;
+        cooc_fits = cooc_ready && nv <= JL_PACK_COOC_N;
+    }
+    jl_pack *dsts[2] = {pk, pk2};
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        jl_pack *o = dsts[t];
+        if (!o) continue;
+        if (tid == 0) {
+            o->magic = JL_PACK_MAGIC; o->nvar_total = n; o->fits_call = fits_call; o->fits_phase = fits_phase;
+            o->phase_ran = phasing; o->overflow = ovf; o->vp = vp; o->H = H;
+            o->nv_phase = nv; o->cooc_fits = cooc_fits;
+            if (phasing) o->summary = meta->summary;
+        }
+        if (fits_call)
+            for (uint32_t i = tid; i < n * (uint32_t)(sizeof(jl_variant) / 8); i += nt)
+                reinterpret_cast<uint64_t *>(o->variants)[i] = reinterpret_cast<const uint64_t *>(variants)[i];
+        if (fits_phase) {
+            for (uint32_t i = tid; i < vp; i += nt) o->pos_cols[i] = vpcols[i];
+            for (uint32_t i = tid; i < H; i += nt) o->hap_count[i] = hap_count[i];
+            for (uint32_t i = tid; i < H * vp; i += nt)
+                o->hap_pattern[i] = hap_pattern[(uint64_t)(i / vp) * JL_VARIANT_CAP + (i % vp)];
+            for (uint32_t i = tid; i < nv * H; i += nt) o->hit[i] = hit[(uint64_t)(i / H) * JL_MAX_HAPLOTYPES + (i % H)];
+            if (cooc_fits)
+                for (uint32_t i = tid; i < nv * nv; i += nt) o->cooc[i] = cooc[(uint64_t)(i / nv) * cooc_cap + (i % nv)];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void result_pack_kernel(const jl_variant *__restrict__ variants,
+                                                           const uint32_t *__restrict__ n_rows,
+                                                           const jl_phase_meta *__restrict__ meta,
+                                                           jl_pack *__restrict__ pk, jl_pack *__restrict__ mirror,
+                                                           uint32_t *seq_dev, volatile uint32_t *seq_host)
+{
+    // phasing off: only the variant table
+    result_pack_block(variants, n_rows[0], meta, 0u, nullptr, nullptr, nullptr, nullptr, nullptr, 0u, 0u, pk, mirror);
+    if (seq_host) {  // last kernel of the run
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) signal_done(seq_dev, seq_host);
+    }
+}
+
+// ---------------------------------------------------------------------------------------- select
+template <bool BYKEY>
+__device__ __forceinline__ uint32_t pattern_code(const uint64_t *keys, unsigned long long *slot_key, uint64_t reads_pad,
+                                                 uint32_t vp, uint32_t id, uint32_t p)
+{
+    const uint32_t g = p / JL_POS_PER_WORD;
+    const uint32_t in_word = min(JL_POS_PER_WORD, vp - g * JL_POS_PER_WORD);
+    const uint32_t sh = 6u * (in_word - 1u - (p - g * JL_POS_PER_WORD));
+    const uint64_t k = BYKEY ? (uint64_t)__hip_atomic_load(&slot_key[id], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                             : keys[(uint64_t)g * reads_pad + id];
+    return (uint32_t)(k >> sh) & 63u;
+}
+
+// Block-level (any block size that is a multiple of 64): groups with >= min_reads ranked by (count desc, pattern asc),
+// haplotype ids, patterns, hit matrix, co-occurrence, the result block, and emptying of the table slots the run used.
+// Every table / key / meta word it reads was written by other workgroups: the caller has acquired them.
+// BYKEY: single-word pipeline — a group's pattern is its 64-bit table key (coherent: written by CAS), so no
+// representative read has to be looked up in the key buffer another workgroup may have written in this launch.
+template <bool BYKEY>
+__device__ __forceinline__ void phase_select_block(uint32_t min_reads, uint64_t reads_pad, const uint64_t *keys,
+                                                   jl_phase_meta *meta, uint32_t *slot_rep, uint32_t *slot_count,
+                                                   const uint32_t *occupied, uint16_t *slot_hap,
+                                                   const jl_variant *variants, const uint32_t *col2pos, uint32_t n_cols,
+                                                   uint32_t *hap_count, uint8_t *hap_pattern, uint8_t *hit,
+                                                   const uint32_t *n_rows, const uint32_t *vpcols, uint32_t *cooc,
+                                                   uint32_t cooc_cap, jl_pack *pk, jl_pack *mirror,
+                                                   unsigned long long *slot_key)
+{
+    __shared__ uint32_t s_cand[JL_CAND_CAP];  // slot of each candidate
+    __shared__ uint32_t s_hrep[JL_MAX_HAPLOTYPES];
+    __shared__ uint32_t s_ncand, s_insufficient, s_reported, s_nhap;
+    const uint32_t tid = threadIdx.x, nt = blockDim.x;
+    const uint32_t vp = __hip_atomic_load(&meta->vp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t kwords = __hip_atomic_load(&meta->kwords, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t nv = __hip_atomic_load(&meta->n_var, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t n_occ = __hip_atomic_load(&meta->n_occupied, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (vp != 0) {  // block-uniform
+    if (tid == 0) { s_ncand = 0; s_insufficient = 0; s_reported = 0; s_nhap = 0; }
+    __syncthreads();
+    for (uint32_t q = tid; q < n_occ; q += nt) {
+        const uint32_t s = occupied[q];
+        const uint32_t c = slot_count[s];
+        if (c >= min_reads) {
+            const uint32_t k = atomicAdd(&s_ncand, 1u);
+            if (k < JL_CAND_CAP) s_cand[k] = s;
+            else { atomicAdd(&s_insufficient, c); slot_hap[s] = JL_HAP_INSUFFICIENT; }
+        } else {
+            atomicAdd(&s_insufficient, c);
+            slot_hap[s] = JL_HAP_INSUFFICIENT;
+        }
+    }
+    __syncthreads();
+    uint32_t ncand = s_ncand;
+    if (ncand > JL_CAND_CAP) {
+        if (tid == 0) meta->overflow |= 1u;
+        ncand = JL_CAND_CAP;
+    }
+    // rank sort: (count desc, pattern asc); patterns are unique so ranks are a permutation
+    for (uint32_t a = tid; a < ncand; a += nt) {
+        const uint32_t sa = s_cand[a], ca = slot_count[sa], ra = BYKEY ? sa : slot_rep[sa];
+        uint32_t rank = 0;
+        for (uint32_t b = 0; b < ncand; ++b) {
+            if (b == a) continue;
+            const uint32_t sb = s_cand[b], cb = slot_count[sb];
+            if (cb > ca) { ++rank; continue; }
+            if (cb < ca) continue;
+            if (BYKEY) {
+                const uint64_t ka = __hip_atomic_load(&slot_key[sa], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint64_t kb = __hip_atomic_load(&slot_key[sb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (kb < ka) ++rank;
+                continue;
+            }
+            const uint32_t rb = slot_rep[sb];
+            for (uint32_t g = 0; g < kwords; ++g) {
+                const uint64_t ka = keys[(uint64_t)g * reads_pad + ra], kb = keys[(uint64_t)g * reads_pad + rb];
+                if (kb != ka) { if (kb < ka) ++rank; break; }
+            }
+        }
+        if (rank < JL_MAX_HAPLOTYPES) {
+            hap_count[rank] = ca;
+            s_hrep[rank] = ra;  // BYKEY: the slot, else a read carrying the pattern
+            slot_hap[sa] = (uint16_t)rank;
+            atomicAdd(&s_reported, ca);
+            atomicAdd(&s_nhap, 1u);
+        } else {
+            slot_hap[sa] = JL_HAP_INSUFFICIENT;
+            atomicAdd(&s_insufficient, ca);
+        }
+    }
+    __syncthreads();
+    const uint32_t H = s_nhap;
+    if (tid == 0) {
+        if (ncand > JL_MAX_HAPLOTYPES) meta->overflow |= 2u;
+        meta->summary.reported_reads = s_reported;
+        meta->summary.insufficient_reads = s_insufficient;
+        meta->summary.n_haplotypes = H;
+    }
+    for (uint32_t q = tid; q < H * vp; q += nt) {
+        const uint32_t h = q / vp, p = q - h * vp;
+        hap_pattern[(uint64_t)h * JL_VARIANT_CAP + p] = (uint8_t)pattern_code<BYKEY>(keys, slot_key, reads_pad, vp, s_hrep[h], p);
+    }
+    for (uint32_t q = tid; q < nv * H; q += nt) {
+        const uint32_t v = q / H, h = q - v * H;
+        const uint32_t c = variants[v].col;
+        uint8_t x = 0;
+        if (c + 2u < n_cols) {  // rows outside this window never hit
+            const uint32_t p = col2pos[c];
+            x = pattern_code<BYKEY>(keys, slot_key, reads_pad, vp, s_hrep[h], p) == variants[v].codon;
+        }
+        hit[(uint64_t)v * JL_MAX_HAPLOTYPES + h] = x;
+    }
+    __syncthreads();
+    // co-occurrence over the reported haplotypes, for the first cooc_cap variants
+    {
+        const uint32_t nvc = nv < cooc_cap ? nv : cooc_cap;
+        for (uint32_t q = tid; q < nvc * nvc; q += nt) {
+            const uint32_t v = q / nvc, w = q - v * nvc;
+            uint32_t sum = 0;
+            for (uint32_t h = 0; h < H; ++h)
+                if (hit[(uint64_t)v * JL_MAX_HAPLOTYPES + h] && hit[(uint64_t)w * JL_MAX_HAPLOTYPES + h]) sum += hap_count[h];
+            cooc[(uint64_t)v * cooc_cap + w] = sum;
+        }
+    }
+    }  // vp != 0
+    __syncthreads();
+    result_pack_block(variants, n_rows[0], meta, 1u, vpcols, hap_count, hap_pattern, hit, cooc, cooc_cap, 1u, pk, mirror);
+    // leave the table empty for the next run: only the slots this run touched
+    for (uint32_t q = tid; q < n_occ; q += nt) {
+        const uint32_t s = occupied[q];
+        slot_key[s] = ~0ull;
+        slot_rep[s] = 0xFFFFFFFFu;
+        slot_count[s] = 0;
+    }
+}
+
+__global__ __launch_bounds__(1024) void phase_select_kernel(uint32_t min_reads, uint64_t reads_pad, const uint64_t *keys,
+                                                             jl_phase_meta *meta, uint32_t *slot_rep,
+                                                             uint32_t *slot_count, const uint32_t *occupied,
+                                                             uint16_t *slot_hap, const jl_variant *variants,
+                                                             const uint32_t *col2pos, uint32_t n_cols,
+                                                             uint32_t *hap_count, uint8_t *hap_pattern, uint8_t *hit,
+                                                             const uint32_t *n_rows, const uint32_t *vpcols,
+                                                             uint32_t *cooc, uint32_t cooc_cap, jl_pack *pk,
+                                                             jl_pack *mirror, unsigned long long *slot_key,
+                                                             uint32_t *seq_dev, volatile uint32_t *seq_host)
+{
+    phase_select_block<false>(min_reads, reads_pad, keys, meta, slot_rep, slot_count, occupied, slot_hap, variants, col2pos,
+                              n_cols, hap_count, hap_pattern, hit, n_rows, vpcols, cooc, cooc_cap, pk, mirror, slot_key);
+    if (seq_host) {  // last kernel of the run: the result block is on its way to the host
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) signal_done(seq_dev, seq_host);
+    }
+}
+
+// what the last block of phase_fused1_kernel needs to run the selection (and to end the run)
+struct select_args {
+    uint32_t run;  // 0: the generic (multi-word) pipeline follows with its own select launch
+    uint32_t min_reads, n_cols, cooc_cap;
+    uint16_t *slot_hap;
+    const jl_variant *variants;
+    const uint32_t *col2pos;
+    uint32_t *hap_count;
+    uint8_t *hap_pattern;
+    uint8_t *hit;
+    const uint32_t *n_rows;
+    uint32_t *cooc;
+    jl_pack *pk, *mirror;
+    uint32_t *arrive;
+    uint32_t *seq_dev;
+    volatile uint32_t *seq_host;
+};
+
 // ---------------------------------------------------------------------------------------- fused keys + group
 // Vp <= 10: the whole pattern is ONE 64-bit word, so the table can be keyed by value (64-bit CAS, no
 // representative lookup) and a block can aggregate before it touches HBM:
@@ -214,8 +459,9 @@ __device__ __forceinline__ uint32_t global_insert64(uint64_t key, uint32_t cnt, 
         // this once per distinct key, so the hot slot sees one CAS per 2048 reads)
         unsigned long long old = atomicCAS(&slot_key[s], (unsigned long long)kNoKey, (unsigned long long)key);
         if (old == kNoKey) {
-            slot_rep[s] = first;  // any read carrying the key; select decodes the pattern from it
-            occupied[atomicAdd(&meta->n_occupied, 1u)] = (uint32_t)s;
+            // write-through stores: the selection may run in another workgroup of this launch
+            __hip_atomic_store(&slot_rep[s], first, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // any read carrying the key
+            __hip_atomic_store(&occupied[atomicAdd(&meta->n_occupied, 1u)], (uint32_t)s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             old = key;
         }
         if (old == key) {
@@ -236,31 +482,49 @@ __global__ __launch_bounds__(256) void phase_fused1_kernel(const uint8_t *__rest
                                                             uint32_t *__restrict__ slot_rep,
                                                             uint32_t *__restrict__ slot_count,
                                                             uint32_t *__restrict__ occupied,
-                                                            uint32_t *__restrict__ read_slot)
+                                                            uint32_t *__restrict__ read_slot, select_args S)
 {
-    const uint32_t vp = meta->vp;
-    if (vp == 0 || meta->kwords != 1) return;
+    const uint32_t vp = meta->vp, kw = meta->kwords;  // one scalar round trip for both; the plan wrote them
+    const bool work = (vp != 0) & (kw == 1);           // block-uniform
     __shared__ unsigned long long s_key[kLdsSlots];
     __shared__ uint32_t s_cnt[kLdsSlots], s_first[kLdsSlots], s_gslot[kLdsSlots];
     __shared__ unsigned long long s_dom;
     __shared__ uint32_t s_domcnt, s_domfirst, s_domslot;
+    __shared__ uint32_t s_last, s_cat[4];
     const uint32_t tid = threadIdx.x;
+    if (work) {
     for (uint32_t i = tid; i < kLdsSlots; i += 256u) { s_key[i] = kNoKey; s_cnt[i] = 0; s_first[i] = 0xFFFFFFFFu; }
     if (tid == 0) { s_dom = kNoKey; s_domcnt = 0; s_domfirst = 0xFFFFFFFFu; s_domslot = 0; }
+    if (tid < 4) s_cat[tid] = 0;
     __syncthreads();
 
     const uint64_t t = (uint64_t)blockIdx.x * 256u + tid;  // dword index within a column = 8 reads
     const bool live = t * 4u < col_stride;
     // ---- 1. keys and flags
+    // All ten column indices in one go (the array always holds JL_VARIANT_CAP words; entries past vp are never
+    // used): a load per position behind `p < vp` makes each wait for its own scalar round trip.  Lanes past the
+    // end of the columns load from a clamped address and drop the value, so the loads need no per-lane branch.
+    uint32_t cols[JL_POS_PER_WORD];
+#pragma unroll
+    for (uint32_t p = 0; p < JL_POS_PER_WORD; ++p) cols[p] = vpcols[p];
+    const uint64_t t_ld = live ? t : 0u;
     uint32_t w[JL_POS_PER_WORD][3];
 #pragma unroll
     for (uint32_t p = 0; p < JL_POS_PER_WORD; ++p) {
-        const bool on = live && p < vp;
-        const uint32_t c = p < vp ? vpcols[p] : 0u;
+        if (p < vp) {  // block-uniform
 #pragma unroll
-        for (int k = 0; k < 3; ++k)
-            w[p][k] = on ? *reinterpret_cast<const uint32_t *>(msa + (uint64_t)(c + k) * col_stride + t * 4u)
-                         : 0x66666666u;
+            for (int k = 0; k < 3; ++k)
+                w[p][k] = *reinterpret_cast<const uint32_t *>(msa + (uint64_t)(cols[p] + k) * col_stride + t_ld * 4u);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) w[p][k] = 0x66666666u;
+        }
+    }
+    if (!live) {
+#pragma unroll
+        for (uint32_t p = 0; p < JL_POS_PER_WORD; ++p)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) w[p][k] = 0x66666666u;
     }
     uint32_t gap = 0, het = 0, par = 0;
     uint64_t key[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -302,13 +566,15 @@ __global__ __launch_bounds__(256) void phase_fused1_kernel(const uint8_t *__rest
         }
     }
     {
+        // read categories: wave sums into LDS here, ONE global atomic per block and counter further down (the four
+        // counters share a cache line: 1564 waves adding to it serialise at the memory side)
         const uint32_t n_gap = wave_sum_all(__popc(gap)), n_het = wave_sum_all(__popc(het));
         const uint32_t n_par = wave_sum_all(__popc(par)), n_dam = wave_sum_all(__popc(dirty));
         if ((tid & 63u) == 0) {
-            if (n_dam) atomicAdd(&meta->summary.damaged_reads, n_dam);
-            if (n_gap) atomicAdd(&meta->summary.marginal_gap, n_gap);
-            if (n_het) atomicAdd(&meta->summary.marginal_heteroduplex, n_het);
-            if (n_par) atomicAdd(&meta->summary.marginal_partial, n_par);
+            if (n_dam) atomicAdd(&s_cat[0], n_dam);
+            if (n_gap) atomicAdd(&s_cat[1], n_gap);
+            if (n_het) atomicAdd(&s_cat[2], n_het);
+            if (n_par) atomicAdd(&s_cat[3], n_par);
         }
     }
     // ---- 2. dominant key of the block = key of its first clean read
@@ -366,6 +632,11 @@ __global__ __launch_bounds__(256) void phase_fused1_kernel(const uint8_t *__rest
                                          occupied, meta);
     if (tid == 0 && s_domcnt)
         s_domslot = global_insert64(dom, s_domcnt, s_domfirst, slots_mask, slot_key, slot_rep, slot_count, occupied, meta);
+    if (tid >= 64u && tid < 68u && s_cat[tid - 64u]) {  // a lane of another wave than the inserting one
+        uint32_t *dst = tid == 64u ? &meta->summary.damaged_reads : tid == 65u ? &meta->summary.marginal_gap
+                      : tid == 66u ? &meta->summary.marginal_heteroduplex : &meta->summary.marginal_partial;
+        atomicAdd(dst, s_cat[tid - 64u]);
+    }
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
@@ -379,189 +650,33 @@ __global__ __launch_bounds__(256) void phase_fused1_kernel(const uint8_t *__rest
             read_slot[t * 8u + r] = g;
         }
     }
-}
-
-// ---------------------------------------------------------------------------------------- result pack
-// Block-level: gathers the small results into one fixed-size block for a single pinned D2H copy.
-__device__ __forceinline__ void result_pack_block(const jl_variant *__restrict__ variants, uint32_t n,
-                                                  const jl_phase_meta *__restrict__ meta, uint32_t phasing,
-                                                  const uint32_t *__restrict__ vpcols,
-                                                  const uint32_t *__restrict__ hap_count,
-                                                  const uint8_t *__restrict__ hap_pattern,
-                                                  const uint8_t *__restrict__ hit, const uint32_t *__restrict__ cooc,
-                                                  uint32_t cooc_cap, uint32_t cooc_ready, jl_pack *__restrict__ pk,
-                                                  jl_pack *__restrict__ pk2)
-{
-    // pk: device copy (all-gather source); pk2: pinned host mirror (may be null) — both written directly
-    const uint32_t tid = threadIdx.x, nt = blockDim.x;
-    const uint32_t fits_call = n <= JL_PACK_MAX_VAR;
-    uint32_t vp = 0, H = 0, nv = 0, ovf = 0, fits_phase = 0, cooc_fits = 0;
-    if (phasing) {
-        vp = meta->vp; H = meta->summary.n_haplotypes; nv = meta->n_var; ovf = meta->overflow;
-        fits_phase = ovf == 0 && fits_call && vp <= JL_PACK_MAX_VP && H <= JL_PACK_MAX_HAP &&
-                     H * vp <= JL_PACK_PATTERN_BYTES && nv * H <= JL_PACK_HIT_BYTES;
-        cooc_fits = cooc_ready && nv <= JL_PACK_COOC_N;
-    }
-    jl_pack *dsts[2] = {pk, pk2};
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        jl_pack *o = dsts[t];
-        if (!o) continue;
-        if (tid == 0) {
-            o->magic = JL_PACK_MAGIC; o->nvar_total = n; o->fits_call = fits_call; o->fits_phase = fits_phase;
-            o->phase_ran = phasing; o->overflow = ovf; o->vp = vp; o->H = H;
-            o->nv_phase = nv; o->cooc_fits = cooc_fits;
-            if (phasing) o->summary = meta->summary;
-        }
-        if (fits_call)
-            for (uint32_t i = tid; i < n * (uint32_t)(sizeof(jl_variant) / 8); i += nt)
-                reinterpret_cast<uint64_t *>(o->variants)[i] = reinterpret_cast<const uint64_t *>(variants)[i];
-        if (fits_phase) {
-            for (uint32_t i = tid; i < vp; i += nt) o->pos_cols[i] = vpcols[i];
-            for (uint32_t i = tid; i < H; i += nt) o->hap_count[i] = hap_count[i];
-            for (uint32_t i = tid; i < H * vp; i += nt)
-                o->hap_pattern[i] = hap_pattern[(uint64_t)(i / vp) * JL_VARIANT_CAP + (i % vp)];
-            for (uint32_t i = tid; i < nv * H; i += nt) o->hit[i] = hit[(uint64_t)(i / H) * JL_MAX_HAPLOTYPES + (i % H)];
-            if (cooc_fits)
-                for (uint32_t i = tid; i < nv * nv; i += nt) o->cooc[i] = cooc[(uint64_t)(i / nv) * cooc_cap + (i % nv)];
-        }
-    }
-}
-
-__global__ __launch_bounds__(256) void result_pack_kernel(const jl_variant *__restrict__ variants,
-                                                           const uint32_t *__restrict__ n_rows,
-                                                           const jl_phase_meta *__restrict__ meta,
-                                                           jl_pack *__restrict__ pk, jl_pack *__restrict__ mirror)
-{
-    // phasing off: only the variant table
-    result_pack_block(variants, n_rows[0], meta, 0u, nullptr, nullptr, nullptr, nullptr, nullptr, 0u, 0u, pk, mirror);
-}
-
-// ---------------------------------------------------------------------------------------- select
-__device__ __forceinline__ uint32_t pattern_code(const uint64_t *__restrict__ keys, uint64_t reads_pad, uint32_t vp,
-                                                 uint32_t rep, uint32_t p)
-{
-    const uint32_t g = p / JL_POS_PER_WORD;
-    const uint32_t in_word = min(JL_POS_PER_WORD, vp - g * JL_POS_PER_WORD);
-    const uint32_t sh = 6u * (in_word - 1u - (p - g * JL_POS_PER_WORD));
-    return (uint32_t)(keys[(uint64_t)g * reads_pad + rep] >> sh) & 63u;
-}
-
-__global__ __launch_bounds__(1024) void phase_select_kernel(uint32_t min_reads, uint64_t reads_pad,
-                                                             const uint64_t *__restrict__ keys,
-                                                             jl_phase_meta *__restrict__ meta,
-                                                             const uint32_t *slot_rep, const uint32_t *slot_count,
-                                                             const uint32_t *__restrict__ occupied,
-                                                             uint16_t *__restrict__ slot_hap,
-                                                             const jl_variant *__restrict__ variants,
-                                                             const uint32_t *__restrict__ col2pos, uint32_t n_cols,
-                                                             uint32_t *__restrict__ hap_count,
-                                                             uint8_t *__restrict__ hap_pattern,
-                                                             uint8_t *__restrict__ hit,
-                                                             const uint32_t *__restrict__ n_rows,
-                                                             const uint32_t *__restrict__ vpcols,
-                                                             uint32_t *__restrict__ cooc, uint32_t cooc_cap,
-                                                             jl_pack *__restrict__ pk, jl_pack *__restrict__ mirror,
-                                                             unsigned long long *__restrict__ slot_key,
-                                                             uint32_t *__restrict__ slot_rep_w,
-                                                             uint32_t *__restrict__ slot_count_w)
-{
-    __shared__ uint32_t s_cand[JL_CAND_CAP];  // slot of each candidate
-    __shared__ uint32_t s_hrep[JL_MAX_HAPLOTYPES];
-    __shared__ uint32_t s_ncand, s_insufficient, s_reported, s_nhap;
-    const uint32_t tid = threadIdx.x;
-    const uint32_t vp = meta->vp, kwords = meta->kwords, nv = meta->n_var;
-    const uint32_t n_occ = meta->n_occupied;
-    if (vp != 0) {  // block-uniform
-    if (tid == 0) { s_ncand = 0; s_insufficient = 0; s_reported = 0; s_nhap = 0; }
+    }  // work
+    if (!S.run) return;  // the generic pipeline has its own select launch
+    // ---- hand-off: the block that arrives last ranks the groups and writes the result block (see call_kernel).
+    // Everything the selection reads was written by agent-scope atomics or write-through stores (slot keys and
+    // counts, the occupied list, the read-category counters): no release fence.  The bulk outputs (keys, flags,
+    // per-read slots) are for the NEXT kernel.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    for (uint32_t q = tid; q < n_occ; q += 1024u) {
-        const uint32_t s = occupied[q];
-        const uint32_t c = slot_count[s];
-        if (c >= min_reads) {
-            const uint32_t k = atomicAdd(&s_ncand, 1u);
-            if (k < JL_CAND_CAP) s_cand[k] = s;
-            else { atomicAdd(&s_insufficient, c); slot_hap[s] = JL_HAP_INSUFFICIENT; }
-        } else {
-            atomicAdd(&s_insufficient, c);
-            slot_hap[s] = JL_HAP_INSUFFICIENT;
-        }
-    }
-    __syncthreads();
-    uint32_t ncand = s_ncand;
-    if (ncand > JL_CAND_CAP) {
-        if (tid == 0) meta->overflow |= 1u;
-        ncand = JL_CAND_CAP;
-    }
-    // rank sort: (count desc, pattern asc); patterns are unique so ranks are a permutation
-    for (uint32_t a = tid; a < ncand; a += 1024u) {
-        const uint32_t sa = s_cand[a], ca = slot_count[sa], ra = slot_rep[sa];
-        uint32_t rank = 0;
-        for (uint32_t b = 0; b < ncand; ++b) {
-            if (b == a) continue;
-            const uint32_t sb = s_cand[b], cb = slot_count[sb];
-            if (cb > ca) { ++rank; continue; }
-            if (cb < ca) continue;
-            const uint32_t rb = slot_rep[sb];
-            for (uint32_t g = 0; g < kwords; ++g) {
-                const uint64_t ka = keys[(uint64_t)g * reads_pad + ra], kb = keys[(uint64_t)g * reads_pad + rb];
-                if (kb != ka) { if (kb < ka) ++rank; break; }
-            }
-        }
-        if (rank < JL_MAX_HAPLOTYPES) {
-            hap_count[rank] = ca;
-            s_hrep[rank] = ra;
-            slot_hap[sa] = (uint16_t)rank;
-            atomicAdd(&s_reported, ca);
-            atomicAdd(&s_nhap, 1u);
-        } else {
-            slot_hap[sa] = JL_HAP_INSUFFICIENT;
-            atomicAdd(&s_insufficient, ca);
-        }
-    }
-    __syncthreads();
-    const uint32_t H = s_nhap;
     if (tid == 0) {
-        if (ncand > JL_MAX_HAPLOTYPES) meta->overflow |= 2u;
-        meta->summary.reported_reads = s_reported;
-        meta->summary.insufficient_reads = s_insufficient;
-        meta->summary.n_haplotypes = H;
-    }
-    for (uint32_t q = tid; q < H * vp; q += 1024u) {
-        const uint32_t h = q / vp, p = q - h * vp;
-        hap_pattern[(uint64_t)h * JL_VARIANT_CAP + p] = (uint8_t)pattern_code(keys, reads_pad, vp, s_hrep[h], p);
-    }
-    for (uint32_t q = tid; q < nv * H; q += 1024u) {
-        const uint32_t v = q / H, h = q - v * H;
-        const uint32_t c = variants[v].col;
-        uint8_t x = 0;
-        if (c + 2u < n_cols) {  // rows outside this window never hit
-            const uint32_t p = col2pos[c];
-            x = pattern_code(keys, reads_pad, vp, s_hrep[h], p) == variants[v].codon;
+        const uint32_t prev = __hip_atomic_fetch_add(S.arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t last = prev == gridDim.x - 1u;
+        if (last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(S.arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        hit[(uint64_t)v * JL_MAX_HAPLOTYPES + h] = x;
+        s_last = last;
     }
     __syncthreads();
-    // co-occurrence over the reported haplotypes, for the first cooc_cap variants
-    {
-        const uint32_t nvc = nv < cooc_cap ? nv : cooc_cap;
-        for (uint32_t q = tid; q < nvc * nvc; q += 1024u) {
-            const uint32_t v = q / nvc, w = q - v * nvc;
-            uint32_t sum = 0;
-            for (uint32_t h = 0; h < H; ++h)
-                if (hit[(uint64_t)v * JL_MAX_HAPLOTYPES + h] && hit[(uint64_t)w * JL_MAX_HAPLOTYPES + h]) sum += hap_count[h];
-            cooc[(uint64_t)v * cooc_cap + w] = sum;
-        }
-    }
-    }  // vp != 0
-    __syncthreads();
-    result_pack_block(variants, n_rows[0], meta, 1u, vpcols, hap_count, hap_pattern, hit, cooc, cooc_cap, 1u, pk, mirror);
-    // leave the table empty for the next run: only the slots this run touched
-    for (uint32_t q = tid; q < n_occ; q += 1024u) {
-        const uint32_t s = occupied[q];
-        slot_key[s] = ~0ull;
-        slot_rep_w[s] = 0xFFFFFFFFu;
-        slot_count_w[s] = 0;
+    if (!s_last) return;
+    phase_select_block<true>(S.min_reads, reads_pad, keys, meta, slot_rep, slot_count, occupied, S.slot_hap, S.variants,
+                             S.col2pos, S.n_cols, S.hap_count, S.hap_pattern, S.hit, S.n_rows, vpcols, S.cooc, S.cooc_cap,
+                             S.pk, S.mirror, slot_key);
+    if (S.seq_host) {  // no per-read ids wanted: this is the last kernel of the run
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) signal_done(S.seq_dev, S.seq_host);
     }
 }
 
@@ -570,35 +685,55 @@ __global__ __launch_bounds__(256) void phase_assign_kernel(uint64_t n_reads, con
                                                             const jl_phase_meta *__restrict__ meta,
                                                             const uint32_t *__restrict__ read_slot,
                                                             const uint16_t *__restrict__ slot_hap,
-                                                            uint16_t *__restrict__ read_hap)
+                                                            uint16_t *__restrict__ read_hap, uint32_t *arrive,
+                                                            uint32_t *seq_dev, volatile uint32_t *seq_host)
 {
     const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
-    if (i >= n_reads) return;
-    uint16_t h = JL_HAP_DAMAGED;
-    if (meta->vp != 0) {
-        const uint32_t f = (flagw[i >> 3] >> (4u * (uint32_t)(i & 7u))) & 15u;
-        if (f == 0) h = slot_hap[read_slot[i]];
+    if (i < n_reads) {
+        uint16_t h = JL_HAP_DAMAGED;
+        if (meta->vp != 0) {
+            const uint32_t f = (flagw[i >> 3] >> (4u * (uint32_t)(i & 7u))) & 15u;
+            if (f == 0) h = slot_hap[read_slot[i]];
+        }
+        read_hap[i] = h;
     }
-    read_hap[i] = h;
+    if (seq_host) {
+        // last kernel of the run: the block that arrives last stores the completion word behind everybody's ids.
+        // The ids go to fine-grained (uncached) pinned memory, so draining the stores is all a block has to do
+        // before it arrives — a system-scope fence per block would write back the L2 391 times.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const uint32_t prev = __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (prev == gridDim.x - 1u) {
+                __hip_atomic_store(arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                signal_done(seq_dev, seq_host);
+            }
+        }
+    }
 }
 
 }  // namespace
 
-void jl_launch_result_pack(jl_ctx *ctx, bool phasing)
+// `signal`: this launch ends a jl_run_async — its last kernel stores the completion word (jl_run_wait)
+void jl_launch_result_pack(jl_ctx *ctx, bool phasing, bool signal)
 {
-    if (phasing) return;  // phase_select_kernel packs at its end
+    if (phasing) return;  // the selection packs at its end
     hipLaunchKernelGGL(result_pack_kernel, dim3(1), dim3(256), 0, ctx->stream, ctx->d_variants, ctx->d_nvar, ctx->d_meta,
-                       ctx->d_pack, ctx->pack_mirror);
+                       ctx->d_pack, ctx->pack_mirror, ctx->d_sync, signal ? ctx->h_seq : nullptr);
 }
 
-// `planned`: compact_kernel already ran the plan (jl_run_async); otherwise the stand-alone plan kernel runs here.
-// ctx->phase_generic selects the multi-word pipeline; the default runs only the single-word (Vp <= 10) kernels
-// and lets the plan flag inputs that need more (jl_phase_fetch then switches and re-runs).
-void jl_launch_phase(jl_ctx *ctx, uint32_t min_reads, bool planned)
+// `planned`: call_kernel already ran the plan (jl_run_async); otherwise the stand-alone plan kernel runs here.
+// ctx->phase_generic selects the multi-word pipeline; the default runs only the single-word (Vp <= 10) kernel,
+// whose last block also does the selection, and lets the plan flag inputs that need more (jl_phase_fetch then
+// switches and re-runs).  `signal` as above; the per-read ids are the last thing a run produces.
+void jl_launch_phase(jl_ctx *ctx, uint32_t min_reads, bool planned, bool signal)
 {
     hipStream_t st = ctx->stream;
     const uint64_t reads_pad = ctx->col_stride * 2u;
     const bool generic = ctx->phase_generic;
+    const bool ids_to_host = ctx->read_hap_out != nullptr;
+    const bool signal_select = signal && !ids_to_host;   // no ids wanted on the host: the selection ends the run
     if (!planned)
         hipLaunchKernelGGL(phase_plan_kernel, dim3(1), dim3(1024), 0, st, ctx->d_variants, ctx->d_nvar, JL_VARIANT_CAP,
                            ctx->n_cols, ctx->d_varcol, ctx->d_vpcols, ctx->d_col2pos, ctx->keys_words,
@@ -609,19 +744,28 @@ void jl_launch_phase(jl_ctx *ctx, uint32_t min_reads, bool planned)
         hipLaunchKernelGGL(phase_keys_kernel, dim3((n_dwords + 255u) / 256u), dim3(256), 0, st, ctx->d_msa,
                            ctx->col_stride, ctx->n_reads, reads_pad, ctx->d_vpcols, ctx->d_meta, ctx->d_keys,
                            ctx->d_flagw);
+    select_args S;
+    S.run = generic ? 0u : 1u;
+    S.min_reads = min_reads; S.n_cols = ctx->n_cols; S.cooc_cap = ctx->cooc_cap;
+    S.slot_hap = ctx->d_slot_hap; S.variants = ctx->d_variants; S.col2pos = ctx->d_col2pos;
+    S.hap_count = ctx->d_hap_count; S.hap_pattern = ctx->d_hap_pattern; S.hit = ctx->d_hit; S.n_rows = ctx->d_nvar;
+    S.cooc = ctx->d_cooc; S.pk = ctx->d_pack; S.mirror = ctx->pack_mirror;
+    S.arrive = ctx->d_sync + 2; S.seq_dev = ctx->d_sync; S.seq_host = signal_select ? ctx->h_seq : nullptr;
     hipLaunchKernelGGL(phase_fused1_kernel, dim3((n_dwords + 255u) / 256u), dim3(256), 0, st, ctx->d_msa,
                        ctx->col_stride, ctx->n_reads, reads_pad, ctx->d_vpcols, ctx->d_meta, ctx->d_keys, ctx->d_flagw,
                        ctx->table_slots - 1u, (unsigned long long *)ctx->d_slot_key, ctx->d_slot_rep,
-                       ctx->d_slot_count, ctx->d_occupied, ctx->d_read_slot);
-    if (generic)
+                       ctx->d_slot_count, ctx->d_occupied, ctx->d_read_slot, S);
+    if (generic) {
         hipLaunchKernelGGL(phase_group_kernel, dim3(rblocks), dim3(256), 0, st, ctx->n_reads, reads_pad, ctx->d_keys,
                            ctx->d_flagw, ctx->d_meta, ctx->table_slots - 1u, ctx->d_slot_rep, ctx->d_slot_count,
                            ctx->d_occupied, ctx->d_read_slot);
-    hipLaunchKernelGGL(phase_select_kernel, dim3(1), dim3(1024), 0, st, min_reads, reads_pad, ctx->d_keys,
-                       ctx->d_meta, ctx->d_slot_rep, ctx->d_slot_count, ctx->d_occupied, ctx->d_slot_hap,
-                       ctx->d_variants, ctx->d_col2pos, ctx->n_cols, ctx->d_hap_count, ctx->d_hap_pattern, ctx->d_hit,
-                       ctx->d_nvar, ctx->d_vpcols, ctx->d_cooc, ctx->cooc_cap, ctx->d_pack, ctx->pack_mirror,
-                       (unsigned long long *)ctx->d_slot_key, ctx->d_slot_rep, ctx->d_slot_count);
+        hipLaunchKernelGGL(phase_select_kernel, dim3(1), dim3(1024), 0, st, min_reads, reads_pad, ctx->d_keys,
+                           ctx->d_meta, ctx->d_slot_rep, ctx->d_slot_count, ctx->d_occupied, ctx->d_slot_hap,
+                           ctx->d_variants, ctx->d_col2pos, ctx->n_cols, ctx->d_hap_count, ctx->d_hap_pattern, ctx->d_hit,
+                           ctx->d_nvar, ctx->d_vpcols, ctx->d_cooc, ctx->cooc_cap, ctx->d_pack, ctx->pack_mirror,
+                           (unsigned long long *)ctx->d_slot_key, ctx->d_sync, signal_select ? ctx->h_seq : nullptr);
+    }
     hipLaunchKernelGGL(phase_assign_kernel, dim3(rblocks), dim3(256), 0, st, ctx->n_reads, ctx->d_flagw, ctx->d_meta,
-                       ctx->d_read_slot, ctx->d_slot_hap, ctx->read_hap_out ? ctx->read_hap_out : ctx->d_read_hap);
+                       ctx->d_read_slot, ctx->d_slot_hap, ctx->read_hap_out ? ctx->read_hap_out : ctx->d_read_hap,
+                       ctx->d_sync + 3, ctx->d_sync, (signal && ids_to_host) ? ctx->h_seq : nullptr);
 }
