@@ -279,8 +279,11 @@ int jl_allgather_variants(jl_ctx *ctx, jl_comm *comm, jl_variant *all_rows, uint
 /*
  * Enqueue-only half for hosts that keep several batches in flight: call right after jl_run_async; the
  * exchange (6.2 KB per rank: result header + up to 128 rows) then overlaps other work and the following
- * jl_allgather_variants on the same ctx/comm only waits and unpacks.  A context may have several exchanges in
- * flight (its contribution is copied at enqueue time); jl_allgather_variants then returns the OLDEST pending one.
+ * jl_allgather_variants on the same ctx/comm only waits and unpacks.  The call itself makes no HIP call: a worker
+ * thread of the communicator waits for the run's completion word and then issues the collective on the
+ * communicator's stream.  The device result block is double-buffered by run parity, so a context may launch its
+ * next run — and request that run's exchange — before collecting this one: at most TWO exchanges pending per
+ * context (a third is refused with JL_ERR_STATE); jl_allgather_variants returns the OLDEST pending one.
  * At most 64 exchanges in flight per communicator.
  */
 int jl_allgather_variants_async(jl_ctx *ctx, jl_comm *comm);

@@ -102,7 +102,7 @@ int jl_ctx_create(int device, void *stream, jl_ctx **out)
               hipMalloc(&ctx->d_hap_pattern, (size_t)JL_MAX_HAPLOTYPES * JL_VARIANT_CAP) == hipSuccess &&
               hipMalloc(&ctx->d_hit, (size_t)JL_VARIANT_CAP * JL_MAX_HAPLOTYPES) == hipSuccess &&
               hipMalloc(&ctx->d_cooc, sizeof(uint32_t) * ctx->cooc_cap * ctx->cooc_cap) == hipSuccess &&
-              hipMalloc(&ctx->d_pack, sizeof(jl_pack)) == hipSuccess &&
+              hipMalloc(&ctx->d_pack, 2 * sizeof(jl_pack)) == hipSuccess &&
               hipMalloc(&ctx->d_sync, 16 * sizeof(uint32_t)) == hipSuccess &&
               hipHostMalloc(&ctx->h_pack, sizeof(jl_pack), hipHostMallocDefault) == hipSuccess &&
               hipHostMalloc((void **)&ctx->h_seq, 64, hipHostMallocDefault) == hipSuccess;
@@ -862,9 +862,11 @@ int jl_run_async(jl_ctx *ctx, const jl_gene *genes, uint32_t n_genes, const uint
 
 // Spin on the pinned sequence word of the last run (see done_kernel).  A device fault would leave it unset for
 // ever, so after a long wait the stream is asked directly.
-int jl_run_wait_impl(jl_ctx *ctx)
+int jl_run_wait_impl(jl_ctx *ctx) { return jl_run_wait_seq(ctx, ctx->runs_launched); }
+
+// `want`: the value of runs_launched right after the run of interest was launched (any thread may wait)
+int jl_run_wait_seq(jl_ctx *ctx, uint32_t want)
 {
-    const uint32_t want = ctx->runs_launched;
     volatile uint32_t *p = ctx->h_seq;
     uint64_t spins = 0;
     while ((int32_t)(*p - want) < 0) {

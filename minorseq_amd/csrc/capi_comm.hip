@@ -16,20 +16,19 @@
 
 #include "jl_internal.h"
 
-// bytes of jl_pack up to and including variants[]: what one rank contributes to the compact all-gather
-#define JL_PACK_HEAD_BYTES (offsetof(jl_pack, pos_cols))
 #define JL_COMM_SLOTS 64
 
-// One communicator per (rank, device).  Collectives run on the communicator's OWN stream, ordered behind the
-// producing context by an event, so that several contexts (batches in flight) never have an RCCL launch — and
-// whatever host-side work it implies — sitting in their compute streams.
+// One communicator per (rank, device).  Collectives run on the communicator's OWN stream, issued by a worker
+// thread once the producing run's completion word has arrived in pinned memory, so that several contexts (batches
+// in flight) never have an RCCL launch — nor any HIP call it would imply — on the thread that launches batches.
 struct jl_comm_slot {
     jl_ctx *ctx = nullptr;
-    uint8_t *d_src = nullptr;    // this rank's contribution, copied out of the context's result block at enqueue time
+    const uint8_t *d_src = nullptr;  // this rank's contribution: the run's device result block (double-buffered by run parity)
+    uint32_t run_seq = 0;        // the run whose results are exchanged: the worker waits for its completion word
     uint64_t seq = 0;            // enqueue order: jl_allgather_variants collects a context's OLDEST pending exchange
     uint8_t *d_heads = nullptr;  // [world][JL_PACK_HEAD_BYTES]
     uint8_t *h_heads = nullptr;  // pinned mirror
-    hipEvent_t produced = nullptr, done = nullptr;
+    hipEvent_t done = nullptr;
     bool pending = false;        // an exchange was requested and not yet collected (host thread only)
     bool enqueued = false;       // the worker has issued it and recorded `done` (guarded by jl_comm::mu)
     int status = 0;              // ncclResult_t / hip error of the enqueue, as jl_status
@@ -65,7 +64,8 @@ static void comm_worker(jl_comm *c)
             c->queue.pop_front();
         }
         int st = JL_OK;
-        if (hipStreamWaitEvent(c->stream, s->produced, 0) != hipSuccess) st = JL_ERR_DEVICE;
+        // the producing run is complete when its sequence word is in pinned memory (jl_run_wait): no event needed
+        if (jl_run_wait_seq(s->ctx, s->run_seq) != JL_OK) st = JL_ERR_DEVICE;
         if (st == JL_OK && ncclAllGather(s->d_src, s->d_heads, JL_PACK_HEAD_BYTES, ncclUint8, c->comm, c->stream) != ncclSuccess) st = JL_ERR_COMM;
         if (st == JL_OK && hipMemcpyAsync(s->h_heads, s->d_heads, JL_PACK_HEAD_BYTES * (size_t)c->world, hipMemcpyDeviceToHost, c->stream) != hipSuccess) st = JL_ERR_DEVICE;
         if (hipEventRecord(s->done, c->stream) != hipSuccess && st == JL_OK) st = JL_ERR_DEVICE;
@@ -141,10 +141,8 @@ void jl_comm_destroy(jl_comm *c)
     }
     if (c->stream) hipStreamSynchronize(c->stream);
     for (jl_comm_slot &s : c->slots) {
-        if (s.d_src) hipFree(s.d_src);
         if (s.d_heads) hipFree(s.d_heads);
         if (s.h_heads) hipHostFree(s.h_heads);
-        if (s.produced) hipEventDestroy(s.produced);
         if (s.done) hipEventDestroy(s.done);
     }
     if (c->comm) ncclCommDestroy(c->comm);
@@ -164,8 +162,6 @@ static jl_comm_slot *comm_slot_free(jl_ctx *ctx, jl_comm *c)
         if (s.ctx) continue;
         const size_t bytes = JL_PACK_HEAD_BYTES * (size_t)c->world;
         if (hipMalloc(&s.d_heads, bytes) != hipSuccess || hipHostMalloc(&s.h_heads, bytes, hipHostMallocDefault) != hipSuccess ||
-            hipMalloc(&s.d_src, JL_PACK_HEAD_BYTES) != hipSuccess ||
-            hipEventCreateWithFlags(&s.produced, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&s.done, hipEventDisableTiming) != hipSuccess)
             return nullptr;
         s.ctx = ctx;
@@ -182,20 +178,24 @@ static jl_comm_slot *comm_slot_oldest(jl_ctx *ctx, jl_comm *c)
     return best;
 }
 
-// Enqueue-only half: after jl_run_async, all-gather the head of the result block (header + up to 128 rows =
-// 6.2 KB per rank) on the communicator's stream, ordered behind the context by an event, into pinned memory.
+// Enqueue-only half: after jl_run_async, all-gather the head of the run's device result block (header + up to 128
+// rows = 6.2 KB per rank) on the communicator's stream.  No HIP call here: the request goes to the worker thread,
+// which waits for the run's completion word and then issues the collective.  The result block is double-buffered
+// by run parity, so the run that follows on this context does not disturb the exchange; a context can therefore
+// have TWO exchanges pending, a third is refused.
 int jl_allgather_variants_async(jl_ctx *ctx, jl_comm *c)
 {
     if (!ctx || !c) return JL_ERR_ARG;
     if (!ctx->pack_valid) return jl_fail(ctx, JL_ERR_STATE, "jl_allgather_variants_async needs jl_run_async first");
     if (ctx->device != c->device) return jl_fail(ctx, JL_ERR_ARG, "context and communicator are on different devices");
-    JL_HIP(ctx, hipSetDevice(ctx->device));
+    int n_pending = 0;
+    for (jl_comm_slot &q : c->slots)
+        if (q.ctx == ctx && q.pending) ++n_pending;
+    if (n_pending >= 2) return jl_fail(ctx, JL_ERR_STATE, "two exchanges of this context are pending: collect one first");
     jl_comm_slot *s = comm_slot_free(ctx, c);
     if (!s) return jl_fail(ctx, JL_ERR_MEMORY, "no free exchange slot (%d per communicator): collect pending exchanges first", JL_COMM_SLOTS);
-    // the contribution is copied out of the result block on the context's stream, so the next run of this
-    // context may overwrite the block while the collective is still in flight
-    JL_HIP(ctx, hipMemcpyAsync(s->d_src, ctx->d_pack, JL_PACK_HEAD_BYTES, hipMemcpyDeviceToDevice, ctx->stream));
-    JL_HIP(ctx, hipEventRecord(s->produced, ctx->stream));
+    s->run_seq = ctx->runs_launched;
+    s->d_src = reinterpret_cast<const uint8_t *>(ctx->d_pack + ((ctx->runs_launched - 1u) & 1u));
     s->seq = c->next_seq++;
     {
         std::lock_guard<std::mutex> lk(c->mu);

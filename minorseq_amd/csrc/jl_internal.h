@@ -1,6 +1,7 @@
 // jl_internal.h — private to libjuliet_hip.so: context layout, launch helpers, kernel entry points.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <stddef.h>
 #include <stdint.h>
 
 #include <string>
@@ -55,6 +56,9 @@ struct jl_pack {
     uint8_t hit[JL_PACK_HIT_BYTES];              // [nv][H]
     uint32_t cooc[JL_PACK_COOC_N * JL_PACK_COOC_N];  // [nv][nv]
 };
+
+// bytes of jl_pack up to and including variants[]: what one rank contributes to the compact all-gather
+#define JL_PACK_HEAD_BYTES (offsetof(jl_pack, pos_cols))
 
 struct jl_comm;
 
@@ -134,7 +138,7 @@ struct jl_ctx {
     bool phase_generic = false;  // multi-word (Vp > 10) pipeline selected
 
     // ---- whole-path run: result pack, pinned mirrors, captured graph
-    jl_pack *d_pack = nullptr;
+    jl_pack *d_pack = nullptr;        // [2]: run n writes block n & 1 (an exchange may still read the other one)
     jl_pack *h_pack = nullptr;        // pinned
     uint16_t *h_read_hap = nullptr;   // pinned, [reads_pad]
     size_t h_read_hap_cap = 0;
@@ -184,6 +188,7 @@ void jl_launch_noop(jl_ctx *ctx);
 void jl_launch_done(jl_ctx *ctx);
 void jl_launch_stamp(jl_ctx *ctx, uint32_t slot);
 extern "C" int jl_run_wait_impl(jl_ctx *ctx);
+extern "C" int jl_run_wait_seq(jl_ctx *ctx, uint32_t want);
 void jl_launch_consensus(jl_ctx *ctx, uint8_t *d_out);
 void jl_launch_ingest(jl_ctx *ctx, const int32_t *d_pos, const uint32_t *d_cigar, const uint64_t *d_cig_off,
                       const uint8_t *d_seq4, const uint64_t *d_seq_off, const uint8_t *d_qual,

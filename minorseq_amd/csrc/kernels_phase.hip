@@ -254,7 +254,9 @@ __global__ __launch_bounds__(256) void result_pack_kernel(const jl_variant *__re
                                                            jl_pack *__restrict__ pk, jl_pack *__restrict__ mirror,
                                                            uint32_t *seq_dev, volatile uint32_t *seq_host)
 {
-    // phasing off: only the variant table
+    // phasing off: only the variant table.  The device copy (the all-gather source) is double-buffered by the
+    // parity of the run index, so an exchange may still read run n's block while run n+1 writes its own.
+    pk += __hip_atomic_load(seq_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 1u;
     result_pack_block(variants, n_rows[0], meta, 0u, nullptr, nullptr, nullptr, nullptr, nullptr, 0u, 0u, pk, mirror);
     if (seq_host) {  // last kernel of the run
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -289,7 +291,7 @@ __device__ __forceinline__ void phase_select_block(uint32_t min_reads, uint64_t 
                                                    uint32_t *hap_count, uint8_t *hap_pattern, uint8_t *hit,
                                                    const uint32_t *n_rows, const uint32_t *vpcols, uint32_t *cooc,
                                                    uint32_t cooc_cap, jl_pack *pk, jl_pack *mirror,
-                                                   unsigned long long *slot_key)
+                                                   unsigned long long *slot_key, uint32_t *seq_dev)
 {
     __shared__ uint32_t s_cand[JL_CAND_CAP];  // slot of each candidate
     __shared__ uint32_t s_hrep[JL_MAX_HAPLOTYPES];
@@ -388,6 +390,8 @@ __device__ __forceinline__ void phase_select_block(uint32_t min_reads, uint64_t 
     }
     }  // vp != 0
     __syncthreads();
+    // device copy double-buffered by the parity of the run index (see result_pack_kernel)
+    pk += __hip_atomic_load(seq_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 1u;
     result_pack_block(variants, n_rows[0], meta, 1u, vpcols, hap_count, hap_pattern, hit, cooc, cooc_cap, 1u, pk, mirror);
     // leave the table empty for the next run: only the slots this run touched
     for (uint32_t q = tid; q < n_occ; q += nt) {
@@ -410,7 +414,7 @@ __global__ __launch_bounds__(1024) void phase_select_kernel(uint32_t min_reads, 
                                                              uint32_t *seq_dev, volatile uint32_t *seq_host)
 {
     phase_select_block<false>(min_reads, reads_pad, keys, meta, slot_rep, slot_count, occupied, slot_hap, variants, col2pos,
-                              n_cols, hap_count, hap_pattern, hit, n_rows, vpcols, cooc, cooc_cap, pk, mirror, slot_key);
+                              n_cols, hap_count, hap_pattern, hit, n_rows, vpcols, cooc, cooc_cap, pk, mirror, slot_key, seq_dev);
     if (seq_host) {  // last kernel of the run: the result block is on its way to the host
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -672,7 +676,7 @@ __global__ __launch_bounds__(256) void phase_fused1_kernel(const uint8_t *__rest
     if (!s_last) return;
     phase_select_block<true>(S.min_reads, reads_pad, keys, meta, slot_rep, slot_count, occupied, S.slot_hap, S.variants,
                              S.col2pos, S.n_cols, S.hap_count, S.hap_pattern, S.hit, S.n_rows, vpcols, S.cooc, S.cooc_cap,
-                             S.pk, S.mirror, slot_key);
+                             S.pk, S.mirror, slot_key, S.seq_dev);
     if (S.seq_host) {  // no per-read ids wanted: this is the last kernel of the run
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
