@@ -125,7 +125,7 @@ struct jl_ctx {
     uint16_t *d_read_hap = nullptr;   // [reads_pad]
     uint32_t *d_slot_rep = nullptr, *d_slot_count = nullptr;  // [M]
     uint64_t *d_slot_key = nullptr;                           // [M] single-word keys (fused path)
-    uint16_t *d_slot_hap = nullptr;                           // [M]
+    uint32_t *d_slot_hap = nullptr;                           // [M] haplotype id of a table slot (32-bit: write-through stores)
     uint32_t *d_occupied = nullptr;                           // [reads_pad]
     uint64_t table_slots = 0;
     size_t reads_capacity = 0;

@@ -286,7 +286,7 @@ __device__ __forceinline__ uint32_t pattern_code(const uint64_t *keys, unsigned 
 template <bool BYKEY>
 __device__ __forceinline__ void phase_select_block(uint32_t min_reads, uint64_t reads_pad, const uint64_t *keys,
                                                    jl_phase_meta *meta, uint32_t *slot_rep, uint32_t *slot_count,
-                                                   const uint32_t *occupied, uint16_t *slot_hap,
+                                                   const uint32_t *occupied, uint32_t *slot_hap,
                                                    const jl_variant *variants, const uint32_t *col2pos, uint32_t n_cols,
                                                    uint32_t *hap_count, uint8_t *hap_pattern, uint8_t *hit,
                                                    const uint32_t *n_rows, const uint32_t *vpcols, uint32_t *cooc,
@@ -310,10 +310,10 @@ __device__ __forceinline__ void phase_select_block(uint32_t min_reads, uint64_t 
         if (c >= min_reads) {
             const uint32_t k = atomicAdd(&s_ncand, 1u);
             if (k < JL_CAND_CAP) s_cand[k] = s;
-            else { atomicAdd(&s_insufficient, c); slot_hap[s] = JL_HAP_INSUFFICIENT; }
+            else { atomicAdd(&s_insufficient, c); __hip_atomic_store(&slot_hap[s], (uint32_t)JL_HAP_INSUFFICIENT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
         } else {
             atomicAdd(&s_insufficient, c);
-            slot_hap[s] = JL_HAP_INSUFFICIENT;
+            __hip_atomic_store(&slot_hap[s], (uint32_t)JL_HAP_INSUFFICIENT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     __syncthreads();
@@ -346,11 +346,11 @@ __device__ __forceinline__ void phase_select_block(uint32_t min_reads, uint64_t 
         if (rank < JL_MAX_HAPLOTYPES) {
             hap_count[rank] = ca;
             s_hrep[rank] = ra;  // BYKEY: the slot, else a read carrying the pattern
-            slot_hap[sa] = (uint16_t)rank;
+            __hip_atomic_store(&slot_hap[sa], rank, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // write-through: read by other workgroups
             atomicAdd(&s_reported, ca);
             atomicAdd(&s_nhap, 1u);
         } else {
-            slot_hap[sa] = JL_HAP_INSUFFICIENT;
+            __hip_atomic_store(&slot_hap[sa], (uint32_t)JL_HAP_INSUFFICIENT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             atomicAdd(&s_insufficient, ca);
         }
     }
@@ -405,7 +405,7 @@ __device__ __forceinline__ void phase_select_block(uint32_t min_reads, uint64_t 
 __global__ __launch_bounds__(1024) void phase_select_kernel(uint32_t min_reads, uint64_t reads_pad, const uint64_t *keys,
                                                              jl_phase_meta *meta, uint32_t *slot_rep,
                                                              uint32_t *slot_count, const uint32_t *occupied,
-                                                             uint16_t *slot_hap, const jl_variant *variants,
+                                                             uint32_t *slot_hap, const jl_variant *variants,
                                                              const uint32_t *col2pos, uint32_t n_cols,
                                                              uint32_t *hap_count, uint8_t *hap_pattern, uint8_t *hit,
                                                              const uint32_t *n_rows, const uint32_t *vpcols,
@@ -426,7 +426,7 @@ __global__ __launch_bounds__(1024) void phase_select_kernel(uint32_t min_reads, 
 struct select_args {
     uint32_t run;  // 0: the generic (multi-word) pipeline follows with its own select launch
     uint32_t min_reads, n_cols, cooc_cap;
-    uint16_t *slot_hap;
+    uint32_t *slot_hap;
     const jl_variant *variants;
     const uint32_t *col2pos;
     uint32_t *hap_count;
@@ -438,6 +438,11 @@ struct select_args {
     uint32_t *arrive;
     uint32_t *seq_dev;
     volatile uint32_t *seq_host;
+    // fold != 0: the per-read ids are written by this launch too (grids of at most 256 workgroups, which are all
+    // resident together): the other workgroups wait for the selection on `flag`, then map their own reads
+    uint32_t fold;
+    uint32_t *flag, *arrive2;
+    uint16_t *read_hap;
 };
 
 // ---------------------------------------------------------------------------------------- fused keys + group
@@ -496,14 +501,18 @@ __global__ __launch_bounds__(256) void phase_fused1_kernel(const uint8_t *__rest
     __shared__ uint32_t s_domcnt, s_domfirst, s_domslot;
     __shared__ uint32_t s_last, s_cat[4];
     const uint32_t tid = threadIdx.x;
+    const uint64_t t = (uint64_t)blockIdx.x * 256u + tid;  // dword index within a column = 8 reads
+    const bool live = t * 4u < col_stride;
+    uint32_t clean_keep = 0;   // bit 4r: read r of this lane is clean
+    uint32_t gslot[8];         // global table slot of each clean read
+#pragma unroll
+    for (int r = 0; r < 8; ++r) gslot[r] = 0;
     if (work) {
     for (uint32_t i = tid; i < kLdsSlots; i += 256u) { s_key[i] = kNoKey; s_cnt[i] = 0; s_first[i] = 0xFFFFFFFFu; }
     if (tid == 0) { s_dom = kNoKey; s_domcnt = 0; s_domfirst = 0xFFFFFFFFu; s_domslot = 0; }
     if (tid < 4) s_cat[tid] = 0;
     __syncthreads();
 
-    const uint64_t t = (uint64_t)blockIdx.x * 256u + tid;  // dword index within a column = 8 reads
-    const bool live = t * 4u < col_stride;
     // ---- 1. keys and flags
     // All ten column indices in one go (the array always holds JL_VARIANT_CAP words; entries past vp are never
     // used): a load per position behind `p < vp` makes each wait for its own scalar round trip.  Lanes past the
@@ -652,8 +661,10 @@ __global__ __launch_bounds__(256) void phase_fused1_kernel(const uint8_t *__rest
                 g = global_insert64(key[r], 1u, (uint32_t)(t * 8u + r), slots_mask, slot_key, slot_rep, slot_count,
                                     occupied, meta);
             read_slot[t * 8u + r] = g;
+            gslot[r] = g;
         }
     }
+    clean_keep = cleanm;
     }  // work
     if (!S.run) return;  // the generic pipeline has its own select launch
     // ---- hand-off: the block that arrives last ranks the groups and writes the result block (see call_kernel).
@@ -673,14 +684,58 @@ __global__ __launch_bounds__(256) void phase_fused1_kernel(const uint8_t *__rest
         s_last = last;
     }
     __syncthreads();
-    if (!s_last) return;
-    phase_select_block<true>(S.min_reads, reads_pad, keys, meta, slot_rep, slot_count, occupied, S.slot_hap, S.variants,
-                             S.col2pos, S.n_cols, S.hap_count, S.hap_pattern, S.hit, S.n_rows, vpcols, S.cooc, S.cooc_cap,
-                             S.pk, S.mirror, slot_key, S.seq_dev);
-    if (S.seq_host) {  // no per-read ids wanted: this is the last kernel of the run
+    const bool last = s_last != 0;
+    if (!last && !S.fold) return;
+    if (last) {
+        phase_select_block<true>(S.min_reads, reads_pad, keys, meta, slot_rep, slot_count, occupied, S.slot_hap, S.variants,
+                                 S.col2pos, S.n_cols, S.hap_count, S.hap_pattern, S.hit, S.n_rows, vpcols, S.cooc, S.cooc_cap,
+                                 S.pk, S.mirror, slot_key, S.seq_dev);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (tid == 0) signal_done(S.seq_dev, S.seq_host);
+        if (!S.fold) {
+            if (S.seq_host && tid == 0) signal_done(S.seq_dev, S.seq_host);  // no per-read ids wanted: the run ends here
+            return;
+        }
+        // the slot -> haplotype table is complete (write-through stores, drained above): release the waiting workgroups
+        if (tid == 0) __hip_atomic_store(S.flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        // wait for the selection.  Every workgroup of this launch is resident (the host folds only grids of at
+        // most 256), so the flag does arrive; the bound turns a broken invariant into a loud failure, not a hang.
+        if (tid == 0) {
+            uint32_t spins = 0;
+            while (__hip_atomic_load(S.flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+                __builtin_amdgcn_s_sleep(4);
+                if (++spins > (1u << 23)) __builtin_trap();
+            }
+        }
+        __syncthreads();
+    }
+    // ---- per-read haplotype ids of this workgroup's own reads, straight from the slots still in registers
+    if (live) {
+        uint16_t h[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            h[r] = JL_HAP_DAMAGED;
+            if ((clean_keep >> (4 * r)) & 1u)
+                h[r] = (uint16_t)__hip_atomic_load(&S.slot_hap[gslot[r]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        uint4 v;
+        v.x = h[0] | ((uint32_t)h[1] << 16); v.y = h[2] | ((uint32_t)h[3] << 16);
+        v.z = h[4] | ((uint32_t)h[5] << 16); v.w = h[6] | ((uint32_t)h[7] << 16);
+        // reads_pad = 2 * col_stride entries: the 16-byte store of a live lane is always inside the buffer
+        *reinterpret_cast<uint4 *>(S.read_hap + t * 8u) = v;
+    }
+    // Second arrival: every workgroup is past the flag by now, so the one that arrives last resets it (and the
+    // counter) for the next launch and, when this launch ends a run, stores the completion word behind all the ids.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        const uint32_t prev = __hip_atomic_fetch_add(S.arrive2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (prev == gridDim.x - 1u) {
+            __hip_atomic_store(S.arrive2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(S.flag, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (S.seq_host) signal_done(S.seq_dev, S.seq_host);
+        }
     }
 }
 
@@ -688,7 +743,7 @@ __global__ __launch_bounds__(256) void phase_fused1_kernel(const uint8_t *__rest
 __global__ __launch_bounds__(256) void phase_assign_kernel(uint64_t n_reads, const uint32_t *__restrict__ flagw,
                                                             const jl_phase_meta *__restrict__ meta,
                                                             const uint32_t *__restrict__ read_slot,
-                                                            const uint16_t *__restrict__ slot_hap,
+                                                            const uint32_t *__restrict__ slot_hap,
                                                             uint16_t *__restrict__ read_hap, uint32_t *arrive,
                                                             uint32_t *seq_dev, volatile uint32_t *seq_host)
 {
@@ -697,7 +752,7 @@ __global__ __launch_bounds__(256) void phase_assign_kernel(uint64_t n_reads, con
         uint16_t h = JL_HAP_DAMAGED;
         if (meta->vp != 0) {
             const uint32_t f = (flagw[i >> 3] >> (4u * (uint32_t)(i & 7u))) & 15u;
-            if (f == 0) h = slot_hap[read_slot[i]];
+            if (f == 0) h = (uint16_t)slot_hap[read_slot[i]];
         }
         read_hap[i] = h;
     }
@@ -754,7 +809,14 @@ void jl_launch_phase(jl_ctx *ctx, uint32_t min_reads, bool planned, bool signal)
     S.slot_hap = ctx->d_slot_hap; S.variants = ctx->d_variants; S.col2pos = ctx->d_col2pos;
     S.hap_count = ctx->d_hap_count; S.hap_pattern = ctx->d_hap_pattern; S.hit = ctx->d_hit; S.n_rows = ctx->d_nvar;
     S.cooc = ctx->d_cooc; S.pk = ctx->d_pack; S.mirror = ctx->pack_mirror;
-    S.arrive = ctx->d_sync + 2; S.seq_dev = ctx->d_sync; S.seq_host = signal_select ? ctx->h_seq : nullptr;
+    S.arrive = ctx->d_sync + 2; S.seq_dev = ctx->d_sync;
+    // grids of at most 256 workgroups (<= 524288 reads) also write the per-read ids: one launch less
+    const uint32_t fblocks = (n_dwords + 255u) / 256u;
+    const bool fold = !generic && fblocks <= 256u && !getenv("JL_NO_FOLD");
+    S.fold = fold ? 1u : 0u;
+    S.flag = ctx->d_sync + 4; S.arrive2 = ctx->d_sync + 3;
+    S.read_hap = ctx->read_hap_out ? ctx->read_hap_out : ctx->d_read_hap;
+    S.seq_host = (fold ? signal : signal_select) ? ctx->h_seq : nullptr;
     hipLaunchKernelGGL(phase_fused1_kernel, dim3((n_dwords + 255u) / 256u), dim3(256), 0, st, ctx->d_msa,
                        ctx->col_stride, ctx->n_reads, reads_pad, ctx->d_vpcols, ctx->d_meta, ctx->d_keys, ctx->d_flagw,
                        ctx->table_slots - 1u, (unsigned long long *)ctx->d_slot_key, ctx->d_slot_rep,
@@ -769,6 +831,7 @@ void jl_launch_phase(jl_ctx *ctx, uint32_t min_reads, bool planned, bool signal)
                            ctx->d_nvar, ctx->d_vpcols, ctx->d_cooc, ctx->cooc_cap, ctx->d_pack, ctx->pack_mirror,
                            (unsigned long long *)ctx->d_slot_key, ctx->d_sync, signal_select ? ctx->h_seq : nullptr);
     }
+    if (fold) return;
     hipLaunchKernelGGL(phase_assign_kernel, dim3(rblocks), dim3(256), 0, st, ctx->n_reads, ctx->d_flagw, ctx->d_meta,
                        ctx->d_read_slot, ctx->d_slot_hap, ctx->read_hap_out ? ctx->read_hap_out : ctx->d_read_hap,
                        ctx->d_sync + 3, ctx->d_sync, (signal && ids_to_host) ? ctx->h_seq : nullptr);
