@@ -4,6 +4,9 @@
 A "step" is one pass of the hot path over one resident batch of synthetic aligned CCS reads:
   column pileup + per-codon histograms -> Fisher's exact x Bonferroni -> variant table
   (-> the one RCCL all-gather of the variant table when N > 1) -> read x variant phasing -> results on the host.
+Batches are independent windows; `--group G` of them (default 4) go through the path in ONE launch per stage
+(jl_group_run_async: blockIdx.z = window), so a launch is G steps, and `--inflight` launches are kept in flight.
+Every batch's results (variant table, haplotypes, per-read ids) land in pinned host memory and are read each step.
 Workload at N=1: BASELINE.json configs[2] (= configs[1] with phasing on): 100k CCS reads x 3 kb reference.
 N > 1: reference windows shard independently (one 3 kb window x 100k reads per rank, weak scaling), the only
 exchange is the all-gather of the fixed-stride variant table.
@@ -70,7 +73,10 @@ def main():
     ap.add_argument("--cols", type=int, default=N_COLS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--inflight", type=int, default=4,
-                    help="independent batches in flight per GPU (one context + stream + captured graph each)")
+                    help="launches in flight per GPU (each on its own stream, with its own captured graph)")
+    ap.add_argument("--group", type=int, default=4,
+                    help="batches (windows) per launch: 1 = one graph per batch (jl_run_async), G > 1 = group runs "
+                         "(jl_group_run_async: one pileup / call / phase launch for G windows)")
     args = ap.parse_args()
 
     import torch
@@ -99,13 +105,21 @@ def main():
     sp = synth.SynthParams(seed=2 + rank)
     ref_local = synth.reference(sp.seed, l)
     win_begin = rank * l
+    G = max(1, args.group)
+    n_units = max(1, args.inflight)
     ctxs = []
-    for _ in range(max(1, args.inflight)):
+    for _ in range(n_units * G):
         c = capi.Juliet(local_rank)
         c.alloc(n, l, win_begin=win_begin)
         c.synth_fill(sp, ref_local)
+        c.sync()
         ctxs.append(c)
     jl = ctxs[0]
+    # launch unit u = contexts [u*G, (u+1)*G): one group object per unit (and, for a step count that is not a
+    # multiple of G, one smaller group over the unit's first contexts, made on demand)
+    units = [ctxs[u * G:(u + 1) * G] for u in range(n_units)]
+    groups = [capi.Group(u) for u in units] if G > 1 else None
+    partial_groups = {}
     genes = np.array([(1, world * l + 1)], dtype=capi.GENE)
     refseq = np.full(world * l, 4, dtype=np.uint8)
     refseq[win_begin:win_begin + l] = ref_local
@@ -142,54 +156,80 @@ def main():
         all_counts = np.zeros(world, dtype=np.uint32)
         p_rows, p_counts = all_rows.ctypes.data_as(C.c_void_p), all_counts.ctypes.data_as(C.c_void_p)
 
-    pending = [0] * len(ctxs)   # exchanges enqueued and not yet collected, per context
+    pending = {id(c): 0 for c in ctxs}   # exchanges enqueued and not yet collected, per context
 
-    def launch(i):
-        # the whole path as one captured graph + one pinned result copy; the all-gather (N > 1) is the only
-        # other device work of a step and is enqueued right behind it
-        c = ctxs[i]
-        c.run_async(genes, refseq, prm, None, True, 10, True)
+    def launch(u, count=G):
+        """Enqueue `count` steps (batches) of unit u: the whole path, results stored into pinned memory by the
+        kernels; the all-gather (N > 1) is the only other device work of a step and is requested right behind it."""
+        members = units[u][:count]
+        if G == 1:
+            members[0].run_async(genes, refseq, prm, None, True, 10, True)
+        else:
+            if count == G:
+                grp = groups[u]
+            else:
+                grp = partial_groups.get((u, count))
+                if grp is None:
+                    grp = partial_groups[(u, count)] = capi.Group(members)
+            grp.run_async(genes, refseq, prm, True, 10, True)
         if comm is not None:
-            rc = c.lib.jl_allgather_variants_async(c.h, comm)
-            if rc:
-                c._chk(rc)
-            pending[i] += 1
+            for c in members:
+                rc = c.lib.jl_allgather_variants_async(c.h, comm)
+                if rc:
+                    c._chk(rc)
+                pending[id(c)] += 1
+        return members
 
-    def drain(i, k):
-        c = ctxs[i]
+    def drain(c, k):
         for _ in range(k):
             rc = c.lib.jl_allgather_variants(c.h, comm, p_rows, p_counts, capi.VARIANT_CAP)
             if rc:
                 c._chk(rc)
-            pending[i] -= 1
+            pending[id(c)] -= 1
 
-    def collect(i, final=False):
-        c = ctxs[i]
-        # results are read in place: the kernels stored them into pinned host memory, completion is a sequence
-        # word behind a system-scope fence (jl_run_view_get); results too large for that block use the copying fetch
-        out = c.run_view() or c.run_fetch(True, True, cap_var=64)
-        # the exchange of this context's PREVIOUS step is collected now (its own is still crossing xGMI): every
-        # step's all-gather is consumed, one cycle late, and its latency never stalls the launching thread
-        if comm is not None and pending[i] > (0 if final else 1):
-            drain(i, 1)
-        if distributed and comm is None and os.environ.get('JL_BENCH_NO_COMM') != '1':
-            from minorseq_amd import sharding
-            tabs = sharding.allgather_tables(out["variants"])
-            all_counts[:] = [len(t) for t in tabs]
-        return out["variants"], out["phase"]
+    def collect(members, final=False):
+        last = None
+        for c in members:
+            # results are read in place: the kernels stored them into pinned host memory, completion is a sequence
+            # word behind a system-scope fence (jl_run_view_get); results too large for that block use the copying fetch
+            out = c.run_view() or c.run_fetch(True, True, cap_var=64)
+            # the exchange of this context's PREVIOUS step is collected now (its own is still crossing xGMI): every
+            # step's all-gather is consumed, one cycle late, and its latency never stalls the launching thread
+            if comm is not None and pending[id(c)] > (0 if final else 1):
+                drain(c, 1)
+            if distributed and comm is None and os.environ.get('JL_BENCH_NO_COMM') != '1':
+                from minorseq_amd import sharding
+                tabs = sharding.allgather_tables(out["variants"])
+                all_counts[:] = [len(t) for t in tabs]
+            last = (out["variants"], out["phase"])
+        return last
 
     def run_steps(k):
-        """k steps; at most len(ctxs) in flight; every step's results are fetched to the host."""
+        """k steps; at most n_units launches (G steps each) in flight; every step's results are read on the host."""
         last = None
-        for i in range(k):
-            if i >= len(ctxs):
-                last = collect(i % len(ctxs))
-            launch(i % len(ctxs))
-        for i in range(max(0, k - len(ctxs)), k):
-            last = collect(i % len(ctxs), final=True)
+        inflight = []   # (unit, members) in launch order
+        done = 0
+        u = 0
+        dbg = os.environ.get("JL_BENCH_DEBUG")
+        tl = tc = 0
+        while done < k:
+            if len(inflight) == n_units:
+                t_ = time.perf_counter_ns()
+                last = collect(inflight.pop(0)[1])
+                tc += time.perf_counter_ns() - t_
+            count = min(G, k - done)
+            t_ = time.perf_counter_ns()
+            inflight.append((u, launch(u, count)))
+            tl += time.perf_counter_ns() - t_
+            done += count
+            u = (u + 1) % n_units
+        if dbg:
+            print(f"[bench debug] {k} steps: launch {tl / 1e3:.0f} us, collect {tc / 1e3:.0f} us", file=sys.stderr)
+        while inflight:
+            last = collect(inflight.pop(0)[1], final=True)
         if comm is not None:
-            for i in range(len(ctxs)):
-                drain(i, pending[i])
+            for c in ctxs:
+                drain(c, pending[id(c)])
         return last
 
     def fence():
@@ -197,6 +237,17 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # set-up, before the warm-up steps: every launch unit (and the smaller groups that step counts which are not a
+    # multiple of G will need) runs once, so that no graph capture or table upload falls into the timed steps
+    for u in range(n_units):
+        collect(launch(u, G), final=True)
+        for k in (args.warmup, args.steps):
+            if G > 1 and k % G:
+                collect(launch(u, k % G), final=True)
+    if comm is not None:
+        for c in ctxs:
+            drain(c, pending[id(c)])
+    fence()
     run_steps(args.warmup)
     fence()
     t0 = time.perf_counter()
@@ -209,10 +260,10 @@ def main():
         elapsed = float(tt.item())
     ms_per_step = 1000.0 * elapsed / args.steps
 
-    # latency of ONE batch through the path (no overlap with other batches), for the record
+    # latency of ONE batch through the path (its own graph, nothing else on the GPU), for the record
     def one_batch():
-        launch(0)
-        return collect(0)
+        jl.run_async(genes, refseq, prm, None, True, 10, True)
+        return jl.run_view()
     for _ in range(3):
         one_batch()
     fence()
@@ -223,18 +274,27 @@ def main():
     latency_ms = 1000.0 * (time.perf_counter() - t1) / 20
 
     # dominant kernel alone: HIP events on the stream it is launched on, around back-to-back launches that rotate
-    # over the resident batches (with 4 x 150 MB no launch finds its window in the 256 MiB Infinity Cache)
-    try:
-        t_pileup_ms = capi.time_pileup_set(ctxs, reps=max(20, args.steps))
-    except capi.JulietError:   # launch shapes that need zeroed counters (long columns): one launch per event pair
-        t_pileup_ms = jl.time_pileup(reps=max(10, args.steps))
-    alg_bytes = n * l / 2.0
+    # over the resident batches (no launch finds its windows in the 256 MiB Infinity Cache)
+    if G > 1:
+        run_steps(n_units * G)   # the timing hook reads each group's argument table: every group has run
+        fence()
+        t_pileup_ms, alg_bytes = capi.time_pileup_groups(groups, reps=max(20, args.steps // G))
+        kernel_name = "pileup_group_kernel"
+    else:
+        alg_bytes = n * l / 2.0
+        kernel_name = jl.lib.jl_pileup_kernel_name().decode()
+        try:
+            t_pileup_ms = capi.time_pileup_set(ctxs, reps=max(20, args.steps))
+        except capi.JulietError:   # launch shapes that need zeroed counters (long columns): one launch per event pair
+            t_pileup_ms = jl.time_pileup(reps=max(10, args.steps))
     achieved = alg_bytes / (t_pileup_ms * 1e-3) / 1e9
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(tpath) and (n, l) == (N_READS, N_COLS):   # the PMC passes were taken on the default workload
         try:
-            traffic = json.load(open(tpath)).get("pileup_kernel_hbm_bytes_per_launch")
+            tj = json.load(open(tpath))
+            if tj.get("windows_per_launch", 1) == G:
+                traffic = tj.get("pileup_kernel_hbm_bytes_per_launch")
         except Exception:
             traffic = None
 
@@ -257,9 +317,10 @@ def main():
                    "reads_per_gpu": n, "ref_columns_per_gpu": l,
                    "parallelism": f"window-sharded x{world}, {exchange}" if distributed
                    else "single GPU",
-                   "batches_in_flight": len(ctxs), "one_batch_latency_ms": latency_ms,
+                   "batches_per_launch": G, "launches_in_flight": n_units, "resident_batches": len(ctxs),
+                   "one_batch_latency_ms": latency_ms,
                    "variants_called": n_var, "haplotypes": ph["summary"]["n_haplotypes"]},
-        "roofline": {"bound": "hbm", "kernel": jl.lib.jl_pileup_kernel_name().decode(), "achieved": achieved,
+        "roofline": {"bound": "hbm", "kernel": kernel_name, "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": t_pileup_ms},
     }
@@ -273,6 +334,8 @@ def main():
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if comm is not None:
         jl.lib.jl_comm_destroy(comm)
+    for g in (groups or []) + list(partial_groups.values()):
+        g.close()
     for c in ctxs:
         c.close()
     if distributed:

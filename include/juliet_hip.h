@@ -243,6 +243,30 @@ typedef struct {
 } jl_run_view;
 int jl_run_view_get(jl_ctx *ctx, jl_run_view *out);
 
+/*
+ * Group runs: the whole path for SEVERAL resident windows (one context each, same device) in three launches —
+ * one pileup stream over all windows, one Fisher/compaction launch, one phasing launch (blockIdx.z = window).
+ * A 150 MB window is too short a stream to hide a launch's ramp and drain, and its Fisher and phasing stages are
+ * latency chains that occupy a hardware queue while doing little; grouped, the pileup runs at the rate of one long
+ * stream and the latency chains of all windows overlap.  Results are per window and identical to jl_run_async on
+ * each context: every context keeps its own result block, per-read ids and completion word, so jl_run_wait,
+ * jl_run_done, jl_run_view_get, jl_call_fetch, jl_phase_fetch and jl_allgather_variants_async apply unchanged.
+ * All windows get the same genes / reference / parameters (they are windows of one reference, or samples of one
+ * amplicon).  Limits: call + phase only; at most 524288 reads over the whole group; a window with more than 10
+ * variant positions is flagged as in jl_run_async (its fetch calls then re-run the multi-word pipeline).  Every
+ * window is counted by one block per column chunk, so windows of millions of reads are better run one by one.
+ * The contexts' own streams must be idle (uploads finished).
+ */
+typedef struct jl_group jl_group;
+int jl_group_create(jl_ctx *const *ctxs, uint32_t n_ctx, jl_group **out);
+void jl_group_destroy(jl_group *group);
+const char *jl_group_last_error(const jl_group *group);
+int jl_group_run_async(jl_group *group, const jl_gene *genes, uint32_t n_genes, const uint8_t *refseq, uint32_t ref_len,
+                       const jl_params *prm, int phasing, uint32_t min_reads, int want_read_hap);
+/* Timing hook (bench): average device time in ms of the grouped pileup launch alone, `reps` back-to-back launches
+ * rotating over `groups` (each must have run once); `bytes_per_launch` = algorithmic bytes of one launch of groups[0]. */
+int jl_group_time_pileup(jl_group *const *groups, uint32_t n_groups, uint32_t reps, float *ms_avg, uint64_t *bytes_per_launch);
+
 /* ---------------------------------------------------------------- numerics self-check */
 
 /*

@@ -31,7 +31,8 @@ EXPORTS = ("jl_abi_version", "jl_strerror", "jl_device_count", "jl_ctx_create", 
            "jl_sync", "jl_col_stride", "jl_msa_upload", "jl_msa_alloc", "jl_msa_adopt", "jl_msa_pack_rows",
            "jl_msa_ingest_records", "jl_msa_download", "jl_synth_fill", "jl_pileup_async", "jl_n_positions", "jl_pileup_fetch",
            "jl_consensus_fetch", "jl_call_async", "jl_call_fetch", "jl_variant_table_device", "jl_phase_async", "jl_phase_fetch",
-           "jl_run_async", "jl_run_wait", "jl_run_done", "jl_run_view_get", "jl_fisher_eval", "jl_time_pileup", "jl_time_pileup_set", "jl_pileup_kernel_name", "jl_comm_unique_id", "jl_comm_create", "jl_comm_destroy",
+           "jl_run_async", "jl_run_wait", "jl_run_done", "jl_run_view_get", "jl_group_create", "jl_group_destroy",
+           "jl_group_last_error", "jl_group_run_async", "jl_group_time_pileup", "jl_fisher_eval", "jl_time_pileup", "jl_time_pileup_set", "jl_pileup_kernel_name", "jl_comm_unique_id", "jl_comm_create", "jl_comm_destroy",
            "jl_allgather_variants", "jl_allgather_variants_async", "jl_xwin_assemble_local",
            "jl_xwin_assemble_rccl")
 
@@ -127,6 +128,13 @@ def load_library(path=LIB_PATH):
     lib.jl_phase_async.argtypes = [vp, vp, u32, u32]
     lib.jl_phase_fetch.argtypes = [vp] * 8 + [u32]
     lib.jl_run_async.argtypes = [vp, vp, u32, vp, u32, C.POINTER(Params), vp, C.c_int, u32, C.c_int]
+    lib.jl_group_create.argtypes = [vp, u32, C.POINTER(vp)]
+    lib.jl_group_destroy.argtypes = [vp]
+    lib.jl_group_destroy.restype = None
+    lib.jl_group_last_error.argtypes = [vp]
+    lib.jl_group_last_error.restype = C.c_char_p
+    lib.jl_group_run_async.argtypes = [vp, vp, u32, vp, u32, C.POINTER(Params), C.c_int, u32, C.c_int]
+    lib.jl_group_time_pileup.argtypes = [vp, u32, u32, C.POINTER(C.c_float), C.POINTER(u64)]
     lib.jl_run_wait.argtypes = [vp]
     lib.jl_run_done.argtypes = [vp]
     lib.jl_run_view_get.argtypes = [vp, C.POINTER(RunView)]
@@ -463,6 +471,53 @@ def phase_across_windows(windows, merged, min_reads=10, comm=None, win_begins=No
         ph["cooc"] = ph["cooc"][: len(merged), : len(merged)].copy()
     pc.close()
     return ph, pos_global[: vp.value].copy()
+
+
+class Group:
+    """Several resident windows (Juliet contexts of one device) run through the path in three launches
+    (jl_group_run_async); results are read from each context as after run_async (run_view / run_fetch)."""
+
+    def __init__(self, ctxs):
+        self.lib = load_library()
+        self.ctxs = list(ctxs)
+        arr = (C.c_void_p * len(self.ctxs))(*[c.h for c in self.ctxs])
+        h = C.c_void_p()
+        rc = self.lib.jl_group_create(arr, len(self.ctxs), C.byref(h))
+        if rc != 0:
+            raise JulietError(rc, "jl_group_create failed")
+        self.h = h
+        self._args = None
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.jl_group_destroy(self.h)
+            self.h = None
+
+    def run_async(self, genes, refseq=None, params=None, phasing=True, min_reads=10, want_read_hap=True):
+        key = (id(genes), id(refseq), id(params))
+        c = self._args
+        if c is None or c[0] != key:   # marshalling cached: repeated steps pass the same objects
+            g = np.ascontiguousarray(genes, dtype=GENE)
+            r = None if refseq is None else np.ascontiguousarray(refseq, dtype=np.uint8)
+            prm = params or default_params()
+            c = self._args = (key, (genes, refseq, params), (g, r, prm),
+                              (_p(g), len(g), _p(r), 0 if r is None else len(r), C.byref(prm)))
+        a = c[3]
+        rc = self.lib.jl_group_run_async(self.h, a[0], a[1], a[2], a[3], a[4], 1 if phasing else 0, min_reads,
+                                         1 if want_read_hap else 0)
+        if rc:
+            raise JulietError(rc, self.lib.jl_group_last_error(self.h).decode())
+
+
+def time_pileup_groups(groups, reps=20):
+    """(average ms per grouped pileup launch, algorithmic bytes per launch), rotating over the groups
+    (jl_group_time_pileup)."""
+    arr = (C.c_void_p * len(groups))(*[g.h for g in groups])
+    ms, nbytes = C.c_float(), C.c_uint64()
+    rc = groups[0].lib.jl_group_time_pileup(arr, len(groups), reps, C.byref(ms), C.byref(nbytes))
+    if rc:
+        raise JulietError(rc, groups[0].lib.jl_group_last_error(groups[0].h).decode())
+    return float(ms.value), int(nbytes.value)
 
 
 def time_pileup_set(ctxs, reps=20):

@@ -781,8 +781,11 @@ static void enqueue_path(jl_ctx *ctx, const jl_params *prm, double n_tests, bool
     if (own_done) jl_launch_done(ctx);
 }
 
-int jl_run_async(jl_ctx *ctx, const jl_gene *genes, uint32_t n_genes, const uint8_t *refseq, uint32_t ref_len,
-                 const jl_params *prm, const uint64_t *drm_masks, int phasing, uint32_t min_reads, int want_read_hap)
+// Everything of a run that allocates, uploads or waits: done before the enqueue (and before any capture).  Shared by
+// jl_run_async and jl_group_run_async.
+int jl_run_prepare(jl_ctx *ctx, const jl_gene *genes, uint32_t n_genes, const uint8_t *refseq, uint32_t ref_len,
+                   const jl_params *prm, const uint64_t *drm_masks, int phasing, uint32_t min_reads, int want_read_hap,
+                   double *n_tests_out)
 {
     if (!ctx || !prm || (!genes && n_genes)) return JL_ERR_ARG;
     if (!ctx->d_msa) return jl_fail(ctx, JL_ERR_STATE, "no resident matrix: call jl_msa_upload/alloc/adopt first");
@@ -791,7 +794,6 @@ int jl_run_async(jl_ctx *ctx, const jl_gene *genes, uint32_t n_genes, const uint
         return jl_fail(ctx, JL_ERR_ARG, "alpha/match must be > 0 and substitution >= 0");
     JL_HIP(ctx, hipSetDevice(ctx->device));
     int rc;
-    // everything that allocates or waits happens before the enqueue (and before any capture)
     if (!same_plan(ctx, genes, n_genes, refseq, ref_len) && (rc = build_plan(ctx, genes, n_genes, refseq, ref_len))) return rc;
     if (drm_masks && ctx->P) {
         JL_HIP(ctx, hipMemcpyAsync(ctx->d_drm, drm_masks, (size_t)ctx->P * 8, hipMemcpyHostToDevice, ctx->stream));
@@ -812,11 +814,29 @@ int jl_run_async(jl_ctx *ctx, const jl_gene *genes, uint32_t n_genes, const uint
         JL_HIP(ctx, hipMemset(ctx->d_timeline, 0, (size_t)JL_TIMELINE_ROWS * JL_TIMELINE_SLOTS * 8));
         ctx->alloc_version++;
     }
-    const double n_tests = prm->n_tests > 0.0 ? prm->n_tests : ctx->default_n_tests;
+    *n_tests_out = prm->n_tests > 0.0 ? prm->n_tests : ctx->default_n_tests;
     ctx->last_min_reads = min_reads;
     jl_prepare_pileup(ctx);
     ctx->pack_mirror = ctx->h_pack;
     ctx->read_hap_out = (phasing && want_read_hap) ? ctx->h_read_hap : nullptr;
+    return JL_OK;
+}
+
+void jl_run_finish(jl_ctx *ctx, int phasing, int want_read_hap)
+{
+    ctx->runs_launched++;
+    ctx->pileup_done = ctx->call_done = true;
+    ctx->phase_done = phasing != 0;
+    ctx->pack_valid = true;
+    ctx->run_read_hap = phasing && want_read_hap;
+}
+
+int jl_run_async(jl_ctx *ctx, const jl_gene *genes, uint32_t n_genes, const uint8_t *refseq, uint32_t ref_len,
+                 const jl_params *prm, const uint64_t *drm_masks, int phasing, uint32_t min_reads, int want_read_hap)
+{
+    double n_tests = 0.0;
+    int rc = jl_run_prepare(ctx, genes, n_genes, refseq, ref_len, prm, drm_masks, phasing, min_reads, want_read_hap, &n_tests);
+    if (rc) return rc;
 
     // signature of everything a captured graph bakes in
     struct { uint64_t alloc, plan; jl_params prm; double n_tests; uint32_t drm, phasing, min_reads, rh, generic, pad; } sig;
@@ -871,26 +891,19 @@ int jl_run_wait_seq(jl_ctx *ctx, uint32_t want)
     uint64_t spins = 0;
     while ((int32_t)(*p - want) < 0) {
         __builtin_ia32_pause();
-        if ((++spins & 0xFFFFFu) == 0) {   // every ~1M polls: has the stream failed or finished without the word?
-            const hipError_t q = hipStreamQuery(ctx->stream);
-            if (q == hipSuccess) {
-                if ((int32_t)(*p - want) >= 0) break;
+        if ((++spins & 0x3FFFFFu) == 0) {
+            // A long wait (tens of ms): a device fault would leave the word unset for ever, so ask the stream.  A
+            // blocking synchronize, not a query: the first launch of a freshly instantiated graph can sit in the
+            // runtime for milliseconds before it reaches the queue, during which a query calls the stream idle.
+            const hipError_t q = hipStreamSynchronize(ctx->run_stream ? ctx->run_stream : ctx->stream);
+            if (q != hipSuccess) return jl_fail(ctx, JL_ERR_DEVICE, "run failed: %s", hipGetErrorString(q));
+            for (int k = 0; k < 1000000 && (int32_t)(*p - want) < 0; ++k) __builtin_ia32_pause();
+            if ((int32_t)(*p - want) < 0)
                 return jl_fail(ctx, JL_ERR_DEVICE, "run finished without its completion word (%u of %u)", *p, want);
-            }
-            if (q != hipErrorNotReady) return jl_fail(ctx, JL_ERR_DEVICE, "run failed: %s", hipGetErrorString(q));
+            break;
         }
     }
     __atomic_thread_fence(__ATOMIC_ACQUIRE);
-    return JL_OK;
-}
-
-// tuning aid: the device-clock stamps of the last JL_TIMELINE_ROWS runs (JL_TIMELINE=1), 100 MHz ticks
-int jl_debug_timeline(jl_ctx *ctx, uint64_t *out)
-{
-    if (!ctx || !out) return JL_ERR_ARG;
-    if (!ctx->d_timeline) return jl_fail(ctx, JL_ERR_STATE, "run with JL_TIMELINE=1");
-    JL_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    JL_HIP(ctx, hipMemcpy(out, ctx->d_timeline, (size_t)JL_TIMELINE_ROWS * JL_TIMELINE_SLOTS * 8, hipMemcpyDeviceToHost));
     return JL_OK;
 }
 

@@ -60,6 +60,79 @@ struct jl_pack {
 // bytes of jl_pack up to and including variants[]: what one rank contributes to the compact all-gather
 #define JL_PACK_HEAD_BYTES (offsetof(jl_pack, pos_cols))
 
+// ---- per-window argument blocks of the three stage kernels.  A single run passes one by value; a group run
+// (jl_group_run_async) keeps an array of them in device memory and launches each stage ONCE for all windows
+// (blockIdx.z = window).  `n_blocks` = workgroups of the window's own grid (the arrival counters count to it).
+struct jl_call_args {
+    double alpha, n_tests, match, substitution, min_perc, max_perc;
+    int32_t expected_round;
+    uint32_t P;
+};
+
+struct jl_win_pileup {
+    const uint8_t *msa;
+    uint64_t col_stride;
+    uint32_t n_cols, n_tiles, n_chunks, pad_;
+    const uint2 *chunks;
+    const uint32_t *guess32;
+    uint32_t *counts, *hist;
+};
+
+struct jl_win_call {
+    jl_call_args A;
+    const uint32_t *pos_gene, *pos_codon, *pos_col;
+    const uint8_t *pos_refcfg;
+    const uint32_t *hist;
+    const uint64_t *drm;
+    uint64_t *called;
+    jl_variant *staged, *rows;
+    uint32_t cap, n_cols;
+    uint32_t *n_rows;
+    uint8_t *varcol;
+    uint32_t *vpcols, *col2pos;
+    uint32_t kwords_cap, fast_only;
+    jl_phase_meta *meta;   // null: no plan (phasing off)
+    uint32_t *arrive;
+    uint32_t n_blocks, pad_;
+};
+
+// what the last block of the fused phase launch needs to run the selection (and to end the run)
+struct jl_select_args {
+    uint32_t run;  // 0: the generic (multi-word) pipeline follows with its own select launch
+    uint32_t min_reads, n_cols, cooc_cap;
+    uint32_t *slot_hap;
+    const jl_variant *variants;
+    const uint32_t *col2pos;
+    uint32_t *hap_count;
+    uint8_t *hap_pattern;
+    uint8_t *hit;
+    const uint32_t *n_rows;
+    uint32_t *cooc;
+    jl_pack *pk, *mirror;
+    uint32_t *arrive;
+    uint32_t *seq_dev;
+    volatile uint32_t *seq_host;
+    // fold != 0: the per-read ids are written by this launch too (all its workgroups are resident together): the
+    // other workgroups wait for the selection on `flag`, then map their own reads
+    uint32_t fold, pad_;
+    uint32_t *flag, *arrive2;
+    uint16_t *read_hap;
+};
+
+struct jl_win_phase {
+    const uint8_t *msa;
+    uint64_t col_stride, n_reads, reads_pad;
+    const uint32_t *vpcols;
+    jl_phase_meta *meta;
+    uint64_t *keys;
+    uint32_t *flagw;
+    uint64_t slots_mask;
+    unsigned long long *slot_key;
+    uint32_t *slot_rep, *slot_count, *occupied, *read_slot;
+    jl_select_args S;
+    uint32_t n_blocks, pad_;
+};
+
 struct jl_comm;
 
 struct jl_ctx {
@@ -150,6 +223,7 @@ struct jl_ctx {
     uint32_t *d_sync = nullptr;       // [16] zeroed once: [0] runs completed, [1..] arrival counters of fused kernels
     volatile uint32_t *h_seq = nullptr;  // pinned
     uint32_t runs_launched = 0;
+    hipStream_t run_stream = nullptr;  // where the last run was enqueued (the ctx stream, or a group's)
     uint64_t *d_timeline = nullptr;   // JL_TIMELINE=1 only: [JL_TIMELINE_ROWS][JL_TIMELINE_SLOTS] device clock stamps
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
@@ -180,6 +254,13 @@ bool jl_pileup_needs_zero(jl_ctx *ctx);
 void jl_prepare_pileup(jl_ctx *ctx);
 void jl_launch_call(jl_ctx *ctx, const jl_params *prm, double n_tests, bool use_drm, bool with_plan);
 void jl_launch_phase(jl_ctx *ctx, uint32_t min_reads, bool planned, bool signal);
+// group runs: fill one window's argument block / launch a stage once for `n_win` windows (tables in device memory)
+void jl_fill_win_pileup(jl_ctx *ctx, jl_win_pileup *w);
+void jl_fill_win_call(jl_ctx *ctx, const jl_params *prm, double n_tests, bool use_drm, bool with_plan, jl_win_call *w);
+bool jl_fill_win_phase(jl_ctx *ctx, uint32_t min_reads, bool signal, uint32_t fold_budget, jl_win_phase *w);
+int jl_launch_pileup_group(jl_ctx *const *ctxs, uint32_t n_win, const jl_win_pileup *d_wins, uint32_t max_chunks, hipStream_t st);
+void jl_launch_call_group(const jl_win_call *d_wins, uint32_t n_win, uint32_t max_blocks, hipStream_t st);
+void jl_launch_phase_group(const jl_win_phase *d_wins, uint32_t n_win, uint32_t max_blocks, hipStream_t st);
 void jl_launch_synth(jl_ctx *ctx, const jl_synth_plan *plan, const uint8_t *d_ref);
 void jl_launch_pack_rows(jl_ctx *ctx, const uint8_t *d_rows);
 void jl_launch_result_pack(jl_ctx *ctx, bool phasing, bool signal);
@@ -187,6 +268,10 @@ void jl_launch_validate(jl_ctx *ctx, uint32_t *d_flag);
 void jl_launch_noop(jl_ctx *ctx);
 void jl_launch_done(jl_ctx *ctx);
 void jl_launch_stamp(jl_ctx *ctx, uint32_t slot);
+extern "C" int jl_run_prepare(jl_ctx *ctx, const jl_gene *genes, uint32_t n_genes, const uint8_t *refseq, uint32_t ref_len,
+                              const jl_params *prm, const uint64_t *drm_masks, int phasing, uint32_t min_reads,
+                              int want_read_hap, double *n_tests_out);
+extern "C" void jl_run_finish(jl_ctx *ctx, int phasing, int want_read_hap);
 extern "C" int jl_run_wait_impl(jl_ctx *ctx);
 extern "C" int jl_run_wait_seq(jl_ctx *ctx, uint32_t want);
 void jl_launch_consensus(jl_ctx *ctx, uint8_t *d_out);

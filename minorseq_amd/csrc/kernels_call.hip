@@ -9,6 +9,8 @@
 // to the coverage, so the hypergeometric is a ratio of three Binomial(.,1/2) masses — which keeps ~1e-14
 // relative accuracy at 1e7 coverage where a plain lgamma difference loses 7 digits; the tail is at most
 // `expected`+1 terms of a ratio recurrence.
+#include <string.h>
+
 #include "jl_internal.h"
 #include "jl_fisher.h"
 #include "phase_plan.h"
@@ -32,11 +34,7 @@ __device__ __forceinline__ uint64_t wave_max_all(uint64_t v)
     return v;
 }
 
-struct call_args {
-    double alpha, n_tests, match, substitution, min_perc, max_perc;
-    int32_t expected_round;
-    uint32_t P;
-};
+typedef jl_call_args call_args;
 
 // One launch for the whole call stage.  Every wave evaluates one codon position and its called lanes write their
 // finished variant rows into a staging slot [p][codon]; the block that arrives last at the launch's counter then
@@ -48,14 +46,19 @@ struct call_args {
 // drains its stores -> block barrier -> one lane: the arrival add; the last arriver reads every handed-over byte
 // with agent-scope relaxed loads (`sc1`, past its L1), which takes the place of an acquire fence (an L1
 // invalidate costs ~1.7 us).  The counter is zero before the first launch and the last arriver leaves it zero.
-__global__ __launch_bounds__(256) void call_kernel(call_args A, const uint32_t *pos_gene, const uint32_t *pos_codon,
-                                                    const uint32_t *pos_col, const uint8_t *pos_refcfg,
-                                                    const uint32_t *hist, const uint64_t *drm, uint64_t *called,
-                                                    jl_variant *staged, jl_variant *rows, uint32_t cap,
-                                                    uint32_t *n_rows, uint32_t n_cols, uint8_t *varcol,
-                                                    uint32_t *vpcols, uint32_t *col2pos, uint32_t kwords_cap,
-                                                    uint32_t fast_only, jl_phase_meta *meta, uint32_t *arrive)
+__device__ __forceinline__ void call_body(const jl_win_call &w)
 {
+    const call_args A = w.A;
+    const uint32_t *pos_gene = w.pos_gene, *pos_codon = w.pos_codon, *pos_col = w.pos_col;
+    const uint8_t *pos_refcfg = w.pos_refcfg;
+    const uint32_t *hist = w.hist;
+    const uint64_t *drm = w.drm;
+    uint64_t *called = w.called;
+    jl_variant *staged = w.staged, *rows = w.rows;
+    const uint32_t cap = w.cap, n_cols = w.n_cols, kwords_cap = w.kwords_cap, fast_only = w.fast_only;
+    uint32_t *n_rows = w.n_rows, *vpcols = w.vpcols, *col2pos = w.col2pos, *arrive = w.arrive;
+    uint8_t *varcol = w.varcol;
+    jl_phase_meta *meta = w.meta;
     constexpr uint32_t kPlanCols = 1024;   // columns of the first rows kept in LDS for the plan
     __shared__ uint32_t s_scan[16];
     __shared__ uint32_t s_running, s_last;
@@ -132,7 +135,7 @@ __global__ __launch_bounds__(256) void call_kernel(call_args A, const uint32_t *
     __syncthreads();
     if (tid == 0) {
         const uint32_t prev = __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const uint32_t last = prev == gridDim.x - 1u;
+        const uint32_t last = prev == w.n_blocks - 1u;
         if (last) __hip_atomic_store(arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s_last = last;
         s_running = 0;
@@ -206,6 +209,16 @@ __global__ __launch_bounds__(256) void call_kernel(call_args A, const uint32_t *
     }
 }
 
+__global__ __launch_bounds__(256) void call_kernel(jl_win_call w) { call_body(w); }
+
+// one launch for several windows: blockIdx.z = window, argument blocks in device memory
+__global__ __launch_bounds__(256) void call_group_kernel(const jl_win_call *__restrict__ wins)
+{
+    const jl_win_call w = wins[blockIdx.z];
+    if (blockIdx.x >= w.n_blocks) return;
+    call_body(w);
+}
+
 __global__ __launch_bounds__(256) void fisher_eval_kernel(uint32_t n, const uint32_t *__restrict__ a,
                                                            const uint32_t *__restrict__ c,
                                                            const uint32_t *__restrict__ cov, double *__restrict__ p,
@@ -226,22 +239,41 @@ void jl_launch_fisher_eval(jl_ctx *ctx, uint32_t n, const uint32_t *a, const uin
     hipLaunchKernelGGL(fisher_eval_kernel, dim3((n + 255u) / 256u), dim3(256), 0, ctx->stream, n, a, c, cov, p, lp);
 }
 
+void jl_fill_win_call(jl_ctx *ctx, const jl_params *prm, double n_tests, bool use_drm, bool with_plan, jl_win_call *w)
+{
+    memset(w, 0, sizeof *w);
+    w->A.alpha = prm->alpha;
+    w->A.n_tests = n_tests;
+    w->A.match = prm->err.match;
+    w->A.substitution = prm->err.substitution;
+    w->A.min_perc = prm->min_perc;
+    w->A.max_perc = prm->max_perc;
+    w->A.expected_round = prm->expected_round;
+    w->A.P = ctx->P;
+    w->pos_gene = ctx->d_pos_gene; w->pos_codon = ctx->d_pos_codon; w->pos_col = ctx->d_pos_col;
+    w->pos_refcfg = ctx->d_pos_refcfg;
+    w->hist = ctx->d_hist;
+    w->drm = use_drm ? ctx->d_drm : nullptr;
+    w->called = ctx->d_called;
+    w->staged = ctx->d_staged; w->rows = ctx->d_variants;
+    w->cap = JL_VARIANT_CAP; w->n_cols = ctx->n_cols;
+    w->n_rows = ctx->d_nvar;
+    w->varcol = ctx->d_varcol; w->vpcols = ctx->d_vpcols; w->col2pos = ctx->d_col2pos;
+    w->kwords_cap = ctx->keys_words; w->fast_only = ctx->phase_generic ? 0u : 1u;
+    w->meta = with_plan ? ctx->d_meta : nullptr;
+    w->arrive = ctx->d_sync + 1;
+    // at least one block even without positions: the last (only) block still writes the row count and the plan
+    w->n_blocks = ctx->P ? (ctx->P + 3u) / 4u : 1u;
+}
+
 void jl_launch_call(jl_ctx *ctx, const jl_params *prm, double n_tests, bool use_drm, bool with_plan)
 {
-    call_args A;
-    A.alpha = prm->alpha;
-    A.n_tests = n_tests;
-    A.match = prm->err.match;
-    A.substitution = prm->err.substitution;
-    A.min_perc = prm->min_perc;
-    A.max_perc = prm->max_perc;
-    A.expected_round = prm->expected_round;
-    A.P = ctx->P;
-    // at least one block even without positions: the last (only) block still writes the row count and the plan
-    const uint32_t blocks = ctx->P ? (ctx->P + 3u) / 4u : 1u;
-    hipLaunchKernelGGL(call_kernel, dim3(blocks), dim3(256), 0, ctx->stream, A, ctx->d_pos_gene, ctx->d_pos_codon,
-                       ctx->d_pos_col, ctx->d_pos_refcfg, ctx->d_hist, use_drm ? ctx->d_drm : nullptr, ctx->d_called,
-                       ctx->d_staged, ctx->d_variants, JL_VARIANT_CAP, ctx->d_nvar, ctx->n_cols, ctx->d_varcol,
-                       ctx->d_vpcols, ctx->d_col2pos, ctx->keys_words, ctx->phase_generic ? 0u : 1u,
-                       with_plan ? ctx->d_meta : nullptr, ctx->d_sync + 1);
+    jl_win_call w;
+    jl_fill_win_call(ctx, prm, n_tests, use_drm, with_plan, &w);
+    hipLaunchKernelGGL(call_kernel, dim3(w.n_blocks), dim3(256), 0, ctx->stream, w);
+}
+
+void jl_launch_call_group(const jl_win_call *d_wins, uint32_t n_win, uint32_t max_blocks, hipStream_t st)
+{
+    hipLaunchKernelGGL(call_group_kernel, dim3(max_blocks, 1, n_win), dim3(256), 0, st, d_wins);
 }

@@ -12,6 +12,8 @@
 //   select  groups with >= min_reads ranked by (count desc, pattern asc), haplotype ids, patterns, hit matrix
 //           + variant x variant co-occurrence, the pinned result block, and emptying of the table slots used
 //   assign  per-read haplotype id
+#include <string.h>
+
 #include "jl_internal.h"
 #include "phase_plan.h"
 
@@ -191,6 +193,21 @@ __global__ __launch_bounds__(256) void phase_group_kernel(uint64_t n_reads, uint
     }
 }
 
+// Words that other workgroups of the SAME launch update with atomics (group counts, the read-category counters)
+// are read past the caches: memory-side atomics do not refresh a copy another XCD's L2 may still hold.
+// A write-through-scope load is still served by this XCD's L2, which may hold the word as an earlier launch left
+// it: observed as a selection that ranked the PREVIOUS run's group counts (one in five group runs after new reads
+// had been generated into the same buffers).  An atomic read-modify-write executes where the other workgroups'
+// atomics did, so it returns the value they left.
+__device__ __forceinline__ uint32_t ld_coherent(const uint32_t *p)
+{
+    return __hip_atomic_fetch_add(const_cast<uint32_t *>(p), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long ld_coherent64(const unsigned long long *p)
+{
+    return __hip_atomic_fetch_add(const_cast<unsigned long long *>(p), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // Completion word of a run (see jl_run_wait): stored by ONE thread after everything the run wrote for the host
 // has been drained by its writers and a block barrier; `seq_host` is pinned host memory.
 __device__ __forceinline__ void signal_done(uint32_t *seq_dev, volatile uint32_t *seq_host)
@@ -217,7 +234,8 @@ __device__ __forceinline__ void result_pack_block(const jl_variant *__restrict__
     const uint32_t fits_call = n <= JL_PACK_MAX_VAR;
     uint32_t vp = 0, H = 0, nv = 0, ovf = 0, fits_phase = 0, cooc_fits = 0;
     if (phasing) {
-        vp = meta->vp; H = meta->summary.n_haplotypes; nv = meta->n_var; ovf = meta->overflow;
+        vp = ld_coherent(&meta->vp); H = ld_coherent(&meta->summary.n_haplotypes); nv = ld_coherent(&meta->n_var);
+        ovf = ld_coherent(&meta->overflow);
         fits_phase = ovf == 0 && fits_call && vp <= JL_PACK_MAX_VP && H <= JL_PACK_MAX_HAP &&
                      H * vp <= JL_PACK_PATTERN_BYTES && nv * H <= JL_PACK_HIT_BYTES;
         cooc_fits = cooc_ready && nv <= JL_PACK_COOC_N;
@@ -231,7 +249,18 @@ __device__ __forceinline__ void result_pack_block(const jl_variant *__restrict__
             o->magic = JL_PACK_MAGIC; o->nvar_total = n; o->fits_call = fits_call; o->fits_phase = fits_phase;
             o->phase_ran = phasing; o->overflow = ovf; o->vp = vp; o->H = H;
             o->nv_phase = nv; o->cooc_fits = cooc_fits;
-            if (phasing) o->summary = meta->summary;
+            if (phasing) {   // the category counters were added to by other workgroups of this launch
+                jl_phase_summary sm;
+                sm.reported_reads = ld_coherent(&meta->summary.reported_reads);
+                sm.insufficient_reads = ld_coherent(&meta->summary.insufficient_reads);
+                sm.damaged_reads = ld_coherent(&meta->summary.damaged_reads);
+                sm.marginal_gap = ld_coherent(&meta->summary.marginal_gap);
+                sm.marginal_heteroduplex = ld_coherent(&meta->summary.marginal_heteroduplex);
+                sm.marginal_partial = ld_coherent(&meta->summary.marginal_partial);
+                sm.n_positions = ld_coherent(&meta->summary.n_positions);
+                sm.n_haplotypes = ld_coherent(&meta->summary.n_haplotypes);
+                o->summary = sm;
+            }
         }
         if (fits_call)
             for (uint32_t i = tid; i < n * (uint32_t)(sizeof(jl_variant) / 8); i += nt)
@@ -273,7 +302,7 @@ __device__ __forceinline__ uint32_t pattern_code(const uint64_t *keys, unsigned 
     const uint32_t g = p / JL_POS_PER_WORD;
     const uint32_t in_word = min(JL_POS_PER_WORD, vp - g * JL_POS_PER_WORD);
     const uint32_t sh = 6u * (in_word - 1u - (p - g * JL_POS_PER_WORD));
-    const uint64_t k = BYKEY ? (uint64_t)__hip_atomic_load(&slot_key[id], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+    const uint64_t k = BYKEY ? (uint64_t)ld_coherent64(&slot_key[id])
                              : keys[(uint64_t)g * reads_pad + id];
     return (uint32_t)(k >> sh) & 63u;
 }
@@ -297,16 +326,16 @@ __device__ __forceinline__ void phase_select_block(uint32_t min_reads, uint64_t 
     __shared__ uint32_t s_hrep[JL_MAX_HAPLOTYPES];
     __shared__ uint32_t s_ncand, s_insufficient, s_reported, s_nhap;
     const uint32_t tid = threadIdx.x, nt = blockDim.x;
-    const uint32_t vp = __hip_atomic_load(&meta->vp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const uint32_t kwords = __hip_atomic_load(&meta->kwords, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const uint32_t nv = __hip_atomic_load(&meta->n_var, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const uint32_t n_occ = __hip_atomic_load(&meta->n_occupied, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t vp = ld_coherent(&meta->vp);
+    const uint32_t kwords = ld_coherent(&meta->kwords);
+    const uint32_t nv = ld_coherent(&meta->n_var);
+    const uint32_t n_occ = ld_coherent(&meta->n_occupied);
     if (vp != 0) {  // block-uniform
     if (tid == 0) { s_ncand = 0; s_insufficient = 0; s_reported = 0; s_nhap = 0; }
     __syncthreads();
     for (uint32_t q = tid; q < n_occ; q += nt) {
-        const uint32_t s = occupied[q];
-        const uint32_t c = slot_count[s];
+        const uint32_t s = ld_coherent(&occupied[q]);
+        const uint32_t c = ld_coherent(&slot_count[s]);
         if (c >= min_reads) {
             const uint32_t k = atomicAdd(&s_ncand, 1u);
             if (k < JL_CAND_CAP) s_cand[k] = s;
@@ -324,20 +353,20 @@ __device__ __forceinline__ void phase_select_block(uint32_t min_reads, uint64_t 
     }
     // rank sort: (count desc, pattern asc); patterns are unique so ranks are a permutation
     for (uint32_t a = tid; a < ncand; a += nt) {
-        const uint32_t sa = s_cand[a], ca = slot_count[sa], ra = BYKEY ? sa : slot_rep[sa];
+        const uint32_t sa = s_cand[a], ca = ld_coherent(&slot_count[sa]), ra = BYKEY ? sa : ld_coherent(&slot_rep[sa]);
         uint32_t rank = 0;
         for (uint32_t b = 0; b < ncand; ++b) {
             if (b == a) continue;
-            const uint32_t sb = s_cand[b], cb = slot_count[sb];
+            const uint32_t sb = s_cand[b], cb = ld_coherent(&slot_count[sb]);
             if (cb > ca) { ++rank; continue; }
             if (cb < ca) continue;
             if (BYKEY) {
-                const uint64_t ka = __hip_atomic_load(&slot_key[sa], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const uint64_t kb = __hip_atomic_load(&slot_key[sb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint64_t ka = ld_coherent64(&slot_key[sa]);
+                const uint64_t kb = ld_coherent64(&slot_key[sb]);
                 if (kb < ka) ++rank;
                 continue;
             }
-            const uint32_t rb = slot_rep[sb];
+            const uint32_t rb = ld_coherent(&slot_rep[sb]);
             for (uint32_t g = 0; g < kwords; ++g) {
                 const uint64_t ka = keys[(uint64_t)g * reads_pad + ra], kb = keys[(uint64_t)g * reads_pad + rb];
                 if (kb != ka) { if (kb < ka) ++rank; break; }
@@ -395,7 +424,7 @@ __device__ __forceinline__ void phase_select_block(uint32_t min_reads, uint64_t 
     result_pack_block(variants, n_rows[0], meta, 1u, vpcols, hap_count, hap_pattern, hit, cooc, cooc_cap, 1u, pk, mirror);
     // leave the table empty for the next run: only the slots this run touched
     for (uint32_t q = tid; q < n_occ; q += nt) {
-        const uint32_t s = occupied[q];
+        const uint32_t s = ld_coherent(&occupied[q]);
         slot_key[s] = ~0ull;
         slot_rep[s] = 0xFFFFFFFFu;
         slot_count[s] = 0;
@@ -422,28 +451,7 @@ __global__ __launch_bounds__(1024) void phase_select_kernel(uint32_t min_reads, 
     }
 }
 
-// what the last block of phase_fused1_kernel needs to run the selection (and to end the run)
-struct select_args {
-    uint32_t run;  // 0: the generic (multi-word) pipeline follows with its own select launch
-    uint32_t min_reads, n_cols, cooc_cap;
-    uint32_t *slot_hap;
-    const jl_variant *variants;
-    const uint32_t *col2pos;
-    uint32_t *hap_count;
-    uint8_t *hap_pattern;
-    uint8_t *hit;
-    const uint32_t *n_rows;
-    uint32_t *cooc;
-    jl_pack *pk, *mirror;
-    uint32_t *arrive;
-    uint32_t *seq_dev;
-    volatile uint32_t *seq_host;
-    // fold != 0: the per-read ids are written by this launch too (grids of at most 256 workgroups, which are all
-    // resident together): the other workgroups wait for the selection on `flag`, then map their own reads
-    uint32_t fold;
-    uint32_t *flag, *arrive2;
-    uint16_t *read_hap;
-};
+typedef jl_select_args select_args;
 
 // ---------------------------------------------------------------------------------------- fused keys + group
 // Vp <= 10: the whole pattern is ONE 64-bit word, so the table can be keyed by value (64-bit CAS, no
@@ -481,18 +489,18 @@ __device__ __forceinline__ uint32_t global_insert64(uint64_t key, uint32_t cnt, 
     }
 }
 
-__global__ __launch_bounds__(256) void phase_fused1_kernel(const uint8_t *__restrict__ msa, uint64_t col_stride,
-                                                            uint64_t n_reads, uint64_t reads_pad,
-                                                            const uint32_t *__restrict__ vpcols,
-                                                            jl_phase_meta *__restrict__ meta,
-                                                            uint64_t *__restrict__ keys, uint32_t *__restrict__ flagw,
-                                                            uint64_t slots_mask,
-                                                            unsigned long long *__restrict__ slot_key,
-                                                            uint32_t *__restrict__ slot_rep,
-                                                            uint32_t *__restrict__ slot_count,
-                                                            uint32_t *__restrict__ occupied,
-                                                            uint32_t *__restrict__ read_slot, select_args S)
+__device__ __forceinline__ void phase_fused1_body(const jl_win_phase &w)
 {
+    const uint8_t *__restrict__ msa = w.msa;
+    const uint64_t col_stride = w.col_stride, n_reads = w.n_reads, reads_pad = w.reads_pad;
+    const uint32_t *__restrict__ vpcols = w.vpcols;
+    jl_phase_meta *meta = w.meta;
+    uint64_t *keys = w.keys;
+    uint32_t *flagw = w.flagw;
+    const uint64_t slots_mask = w.slots_mask;
+    unsigned long long *slot_key = w.slot_key;
+    uint32_t *slot_rep = w.slot_rep, *slot_count = w.slot_count, *occupied = w.occupied, *read_slot = w.read_slot;
+    const select_args &S = w.S;
     const uint32_t vp = meta->vp, kw = meta->kwords;  // one scalar round trip for both; the plan wrote them
     const bool work = (vp != 0) & (kw == 1);           // block-uniform
     __shared__ unsigned long long s_key[kLdsSlots];
@@ -675,7 +683,7 @@ __global__ __launch_bounds__(256) void phase_fused1_kernel(const uint8_t *__rest
     __syncthreads();
     if (tid == 0) {
         const uint32_t prev = __hip_atomic_fetch_add(S.arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const uint32_t last = prev == gridDim.x - 1u;
+        const uint32_t last = prev == w.n_blocks - 1u;
         if (last) {
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -692,6 +700,11 @@ __global__ __launch_bounds__(256) void phase_fused1_kernel(const uint8_t *__rest
                                  S.pk, S.mirror, slot_key, S.seq_dev);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        // The result block went to pinned host memory from THIS compute die; the completion word will be stored by
+        // whichever workgroup arrives last, possibly on another die.  A system-scope release here pushes the block
+        // out of this die's L2 first — without it the host now and then saw the word before the block's header
+        // (new per-read ids and variant rows beside the previous run's read categories: one group run in ten).
+        if (tid == 0) __threadfence_system();
         if (!S.fold) {
             if (S.seq_host && tid == 0) signal_done(S.seq_dev, S.seq_host);  // no per-read ids wanted: the run ends here
             return;
@@ -730,13 +743,24 @@ __global__ __launch_bounds__(256) void phase_fused1_kernel(const uint8_t *__rest
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
+        if (S.seq_host) __threadfence_system();   // this workgroup's ids leave its die's L2 before it arrives (see above)
         const uint32_t prev = __hip_atomic_fetch_add(S.arrive2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (prev == gridDim.x - 1u) {
+        if (prev == w.n_blocks - 1u) {
             __hip_atomic_store(S.arrive2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(S.flag, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (S.seq_host) signal_done(S.seq_dev, S.seq_host);
         }
     }
+}
+
+__global__ __launch_bounds__(256) void phase_fused1_kernel(jl_win_phase w) { phase_fused1_body(w); }
+
+// one launch for several windows: blockIdx.z = window, argument blocks in device memory
+__global__ __launch_bounds__(256) void phase_group_run_kernel(const jl_win_phase *__restrict__ wins)
+{
+    const jl_win_phase w = wins[blockIdx.z];
+    if (blockIdx.x >= w.n_blocks) return;
+    phase_fused1_body(w);
 }
 
 // ---------------------------------------------------------------------------------------- assign
@@ -782,17 +806,50 @@ void jl_launch_result_pack(jl_ctx *ctx, bool phasing, bool signal)
                        ctx->d_pack, ctx->pack_mirror, ctx->d_sync, signal ? ctx->h_seq : nullptr);
 }
 
+// Argument block of the fused phase launch for one window.  `fold_budget`: workgroups that may still be added to a
+// launch whose members all wait for each other (the per-read ids are then written by the same launch); returns
+// whether this window folds.
+bool jl_fill_win_phase(jl_ctx *ctx, uint32_t min_reads, bool signal, uint32_t fold_budget, jl_win_phase *w)
+{
+    memset(w, 0, sizeof *w);
+    const bool generic = ctx->phase_generic;
+    const bool ids_to_host = ctx->read_hap_out != nullptr;
+    const bool signal_select = signal && !ids_to_host;   // no ids wanted on the host: the selection ends the run
+    const uint32_t n_dwords = (uint32_t)(ctx->col_stride / 4u);
+    const uint32_t fblocks = (n_dwords + 255u) / 256u;
+    w->msa = ctx->d_msa; w->col_stride = ctx->col_stride; w->n_reads = ctx->n_reads; w->reads_pad = ctx->col_stride * 2u;
+    w->vpcols = ctx->d_vpcols; w->meta = ctx->d_meta; w->keys = ctx->d_keys; w->flagw = ctx->d_flagw;
+    w->slots_mask = ctx->table_slots - 1u; w->slot_key = (unsigned long long *)ctx->d_slot_key;
+    w->slot_rep = ctx->d_slot_rep; w->slot_count = ctx->d_slot_count; w->occupied = ctx->d_occupied;
+    w->read_slot = ctx->d_read_slot;
+    w->n_blocks = fblocks;
+    select_args &S = w->S;
+    S.run = generic ? 0u : 1u;
+    S.min_reads = min_reads; S.n_cols = ctx->n_cols; S.cooc_cap = ctx->cooc_cap;
+    S.slot_hap = ctx->d_slot_hap; S.variants = ctx->d_variants; S.col2pos = ctx->d_col2pos;
+    S.hap_count = ctx->d_hap_count; S.hap_pattern = ctx->d_hap_pattern; S.hit = ctx->d_hit; S.n_rows = ctx->d_nvar;
+    S.cooc = ctx->d_cooc; S.pk = ctx->d_pack; S.mirror = ctx->pack_mirror;
+    S.arrive = ctx->d_sync + 2; S.seq_dev = ctx->d_sync;
+    // a launch of at most 256 workgroups in all (<= 524288 reads) also writes the per-read ids: one launch less
+    const bool fold = !generic && fblocks <= fold_budget && !getenv("JL_NO_FOLD");
+    S.fold = fold ? 1u : 0u;
+    S.flag = ctx->d_sync + 4; S.arrive2 = ctx->d_sync + 3;
+    S.read_hap = ctx->read_hap_out ? ctx->read_hap_out : ctx->d_read_hap;
+    S.seq_host = (fold ? signal : signal_select) ? ctx->h_seq : nullptr;
+    return fold;
+}
+
 // `planned`: call_kernel already ran the plan (jl_run_async); otherwise the stand-alone plan kernel runs here.
 // ctx->phase_generic selects the multi-word pipeline; the default runs only the single-word (Vp <= 10) kernel,
 // whose last block also does the selection, and lets the plan flag inputs that need more (jl_phase_fetch then
-// switches and re-runs).  `signal` as above; the per-read ids are the last thing a run produces.
+// switches and re-runs).  `signal`: this launch ends a jl_run_async — its last kernel stores the completion word.
 void jl_launch_phase(jl_ctx *ctx, uint32_t min_reads, bool planned, bool signal)
 {
     hipStream_t st = ctx->stream;
     const uint64_t reads_pad = ctx->col_stride * 2u;
     const bool generic = ctx->phase_generic;
     const bool ids_to_host = ctx->read_hap_out != nullptr;
-    const bool signal_select = signal && !ids_to_host;   // no ids wanted on the host: the selection ends the run
+    const bool signal_select = signal && !ids_to_host;
     if (!planned)
         hipLaunchKernelGGL(phase_plan_kernel, dim3(1), dim3(1024), 0, st, ctx->d_variants, ctx->d_nvar, JL_VARIANT_CAP,
                            ctx->n_cols, ctx->d_varcol, ctx->d_vpcols, ctx->d_col2pos, ctx->keys_words,
@@ -803,24 +860,9 @@ void jl_launch_phase(jl_ctx *ctx, uint32_t min_reads, bool planned, bool signal)
         hipLaunchKernelGGL(phase_keys_kernel, dim3((n_dwords + 255u) / 256u), dim3(256), 0, st, ctx->d_msa,
                            ctx->col_stride, ctx->n_reads, reads_pad, ctx->d_vpcols, ctx->d_meta, ctx->d_keys,
                            ctx->d_flagw);
-    select_args S;
-    S.run = generic ? 0u : 1u;
-    S.min_reads = min_reads; S.n_cols = ctx->n_cols; S.cooc_cap = ctx->cooc_cap;
-    S.slot_hap = ctx->d_slot_hap; S.variants = ctx->d_variants; S.col2pos = ctx->d_col2pos;
-    S.hap_count = ctx->d_hap_count; S.hap_pattern = ctx->d_hap_pattern; S.hit = ctx->d_hit; S.n_rows = ctx->d_nvar;
-    S.cooc = ctx->d_cooc; S.pk = ctx->d_pack; S.mirror = ctx->pack_mirror;
-    S.arrive = ctx->d_sync + 2; S.seq_dev = ctx->d_sync;
-    // grids of at most 256 workgroups (<= 524288 reads) also write the per-read ids: one launch less
-    const uint32_t fblocks = (n_dwords + 255u) / 256u;
-    const bool fold = !generic && fblocks <= 256u && !getenv("JL_NO_FOLD");
-    S.fold = fold ? 1u : 0u;
-    S.flag = ctx->d_sync + 4; S.arrive2 = ctx->d_sync + 3;
-    S.read_hap = ctx->read_hap_out ? ctx->read_hap_out : ctx->d_read_hap;
-    S.seq_host = (fold ? signal : signal_select) ? ctx->h_seq : nullptr;
-    hipLaunchKernelGGL(phase_fused1_kernel, dim3((n_dwords + 255u) / 256u), dim3(256), 0, st, ctx->d_msa,
-                       ctx->col_stride, ctx->n_reads, reads_pad, ctx->d_vpcols, ctx->d_meta, ctx->d_keys, ctx->d_flagw,
-                       ctx->table_slots - 1u, (unsigned long long *)ctx->d_slot_key, ctx->d_slot_rep,
-                       ctx->d_slot_count, ctx->d_occupied, ctx->d_read_slot, S);
+    jl_win_phase w;
+    const bool fold = jl_fill_win_phase(ctx, min_reads, signal, 256u, &w);
+    hipLaunchKernelGGL(phase_fused1_kernel, dim3(w.n_blocks), dim3(256), 0, st, w);
     if (generic) {
         hipLaunchKernelGGL(phase_group_kernel, dim3(rblocks), dim3(256), 0, st, ctx->n_reads, reads_pad, ctx->d_keys,
                            ctx->d_flagw, ctx->d_meta, ctx->table_slots - 1u, ctx->d_slot_rep, ctx->d_slot_count,
@@ -835,4 +877,9 @@ void jl_launch_phase(jl_ctx *ctx, uint32_t min_reads, bool planned, bool signal)
     hipLaunchKernelGGL(phase_assign_kernel, dim3(rblocks), dim3(256), 0, st, ctx->n_reads, ctx->d_flagw, ctx->d_meta,
                        ctx->d_read_slot, ctx->d_slot_hap, ctx->read_hap_out ? ctx->read_hap_out : ctx->d_read_hap,
                        ctx->d_sync + 3, ctx->d_sync, (signal && ids_to_host) ? ctx->h_seq : nullptr);
+}
+
+void jl_launch_phase_group(const jl_win_phase *d_wins, uint32_t n_win, uint32_t max_blocks, hipStream_t st)
+{
+    hipLaunchKernelGGL(phase_group_run_kernel, dim3(max_blocks, 1, n_win), dim3(256), 0, st, d_wins);
 }

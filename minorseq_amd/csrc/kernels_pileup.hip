@@ -259,11 +259,10 @@ __device__ __forceinline__ void pileup_stream(const uint8_t *__restrict__ msa, u
 }
 
 template <int W, bool PIPE, int MODE>
-__global__ __launch_bounds__(256) void pileup_kernel(const uint8_t *__restrict__ msa, uint64_t col_stride,
-                                                      uint32_t n_cols, uint32_t n_tiles,
-                                                      const uint2 *__restrict__ chunks,
-                                                      const uint32_t *__restrict__ guess32,
-                                                      uint32_t *__restrict__ counts, uint32_t *__restrict__ hist)
+__device__ __forceinline__ void pileup_body(const uint8_t *__restrict__ msa, uint64_t col_stride, uint32_t n_cols,
+                                            uint32_t n_tiles, const uint2 *__restrict__ chunks,
+                                            const uint32_t *__restrict__ guess32, uint32_t *__restrict__ counts,
+                                            uint32_t *__restrict__ hist)
 {
     __shared__ uint32_t s_hist[W][64];
     __shared__ uint32_t s_col[W][6];   // A C G T - N
@@ -336,6 +335,27 @@ __global__ __launch_bounds__(256) void pileup_kernel(const uint8_t *__restrict__
     }
 }
 
+template <int W, bool PIPE, int MODE>
+__global__ __launch_bounds__(256) void pileup_kernel(const uint8_t *__restrict__ msa, uint64_t col_stride,
+                                                      uint32_t n_cols, uint32_t n_tiles,
+                                                      const uint2 *__restrict__ chunks,
+                                                      const uint32_t *__restrict__ guess32,
+                                                      uint32_t *__restrict__ counts, uint32_t *__restrict__ hist)
+{
+    pileup_body<W, PIPE, MODE>(msa, col_stride, n_cols, n_tiles, chunks, guess32, counts, hist);
+}
+
+// One launch over several resident windows (blockIdx.z = window, argument blocks in device memory): the stream of a
+// 150 MB window is too short to hide a launch's ramp and drain, four of them in one grid run at the rate of a
+// 600 MB stream.  Every window is counted by one block per chunk (gridDim.y = 1: plain stores, no zeroing pass).
+template <int W, bool PIPE, int MODE>
+__global__ __launch_bounds__(256) void pileup_group_kernel(const jl_win_pileup *__restrict__ wins)
+{
+    const jl_win_pileup w = wins[blockIdx.z];
+    if (blockIdx.x >= w.n_chunks) return;
+    pileup_body<W, PIPE, MODE>(w.msa, w.col_stride, w.n_cols, w.n_tiles, w.chunks, w.guess32, w.counts, w.hist);
+}
+
 // Seed base per column for majority-codon mode: majority base among the first reads of the column.
 // (Any value is correct; a good seed keeps the codon compare on its fast path.)
 __global__ __launch_bounds__(64) void guess_kernel(const uint8_t *__restrict__ msa, uint64_t col_stride,
@@ -372,11 +392,12 @@ struct variant_t {
     bool pipe;
     int mode;  // bit 0: loads only (probe), bit 1: popcount measurements (probe), bit 2: non-temporal loads, bit 3: no stream (probe)
     void (*fn)(const uint8_t *, uint64_t, uint32_t, uint32_t, const uint2 *, const uint32_t *, uint32_t *, uint32_t *);
+    void (*gfn)(const jl_win_pileup *);
 };
 
 // Default builds use non-temporal loads: every cell is read once, and at 2.4 GB they lift the stream from 5.6 to
 // 6.3 TB/s (no difference at 150 MB).
-#define JL_V(W, P, M) {W, P, M, pileup_kernel<W, P, M>}
+#define JL_V(W, P, M) {W, P, M, pileup_kernel<W, P, M>, pileup_group_kernel<W, P, M>}
 const variant_t kVariants[] = {
     JL_V(6, false, 4), JL_V(6, true, 4), JL_V(12, false, 4), JL_V(3, false, 4), JL_V(3, true, 4),
 #ifdef JL_PILEUP_TUNING   // probes (results wrong by design except mode 0/6): JL_PILEUP_MODE selects
@@ -466,4 +487,29 @@ void jl_launch_pileup(jl_ctx *ctx, hipStream_t st)
     hipLaunchKernelGGL(var->fn, dim3(ctx->n_chunks, rsplit), dim3(256), lds_pad, st, ctx->d_msa, ctx->col_stride,
                        ctx->n_cols, n_tiles, (const uint2 *)ctx->d_chunks, (const uint32_t *)ctx->d_guess, ctx->d_counts,
                        ctx->d_hist);
+}
+
+void jl_fill_win_pileup(jl_ctx *ctx, jl_win_pileup *w)
+{
+    w->msa = ctx->d_msa;
+    w->col_stride = ctx->col_stride;
+    w->n_cols = ctx->n_cols;
+    w->n_tiles = (uint32_t)((ctx->col_stride + JL_PILEUP_TILE_BYTES - 1) / JL_PILEUP_TILE_BYTES);
+    w->n_chunks = ctx->n_chunks;
+    w->pad_ = 0;
+    w->chunks = (const uint2 *)ctx->d_chunks;
+    w->guess32 = (const uint32_t *)ctx->d_guess;
+    w->counts = ctx->d_counts;
+    w->hist = ctx->d_hist;
+}
+
+// Every window of a group must use the same kernel variant; each is counted by ONE block per chunk whatever its
+// depth (a single run would split very long columns over several blocks).
+int jl_launch_pileup_group(jl_ctx *const *ctxs, uint32_t n_win, const jl_win_pileup *d_wins, uint32_t max_chunks, hipStream_t st)
+{
+    const int idx = pick_variant(ctxs[0]);
+    for (uint32_t k = 0; k < n_win; ++k)
+        if (pick_variant(ctxs[k]) != idx) return JL_ERR_ARG;
+    hipLaunchKernelGGL(kVariants[idx].gfn, dim3(max_chunks, 1, n_win), dim3(256), 0, st, d_wins);
+    return JL_OK;
 }

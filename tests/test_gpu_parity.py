@@ -477,6 +477,56 @@ def test_run_view_and_completion_word(jl, oracle):
         j.close()
 
 
+def test_group_run_equals_single_runs_and_oracle(jl, oracle):
+    """jl_group_run_async: several windows through the path in three launches (blockIdx.z = window).  Windows of
+    different depth and noise, the same genes: every window's results must equal the oracle's (and so a single
+    run's), over graph replays, after new reads were generated into the same buffers, and in majority-codon mode."""
+    l = 300
+    genes = np.array([(1, l + 1)], dtype=capi.GENE)
+    shapes = [(9000, 0.05), (5000, 0.0), (12345, 0.2), (2048, 0.1)]
+    ref = synth.reference(90, l)
+    ctxs = []
+    for k, (n, partial) in enumerate(shapes):
+        j = capi.Juliet(0)
+        j.alloc(n, l)
+        ctxs.append(j)
+    grp = capi.Group(ctxs)
+    prm = capi.default_params()
+
+    def fill_and_expect(seed0, use_ref):
+        exp = []
+        for k, ((n, partial), j) in enumerate(zip(shapes, ctxs)):
+            sp = synth.SynthParams(seed=seed0 + k, minor_permille=(70, 50, 40, 30), partial_rate=partial)
+            j.synth_fill(sp, ref)
+            j.sync()
+            rows = msa.unpack_columns(j.download_columns(), n)
+            exp_v = oracle.call(rows, genes, refseq=ref if use_ref else None)
+            exp.append((exp_v, oracle.phase(rows, exp_v)))
+        return exp
+
+    for seed0, use_ref in ((90, True), (130, True), (170, False), (250, True)):
+        exp = fill_and_expect(seed0, use_ref)
+        for rep in range(4):
+            grp.run_async(genes, ref if use_ref else None, prm, True, 10, True)
+            for j, (exp_v, exp_p) in zip(ctxs, exp):
+                v = j.run_view()
+                assert v is not None
+                assert_variants_equal(v["variants"], exp_v)
+                assert_phase_equal(v["phase"], exp_p, len(exp_v))
+        # the copying fetches read the same blocks
+        f = ctxs[2].run_fetch(True, True, cap_var=64)
+        assert_variants_equal(f["variants"], exp[2][0])
+        assert_phase_equal(f["phase"], exp[2][1], len(exp[2][0]))
+    # a single run on a member context still works afterwards (its own stream and graph)
+    exp = fill_and_expect(210, True)
+    out = ctxs[1].run(genes, ref, prm)
+    assert_variants_equal(out["variants"], exp[1][0])
+    assert_phase_equal(out["phase"], exp[1][1], len(exp[1][0]))
+    grp.close()
+    for j in ctxs:
+        j.close()
+
+
 # --------------------------------------------------------------------------------------------- the collective
 def test_allgather_variants_single_rank_communicator(jl, oracle):
     """jl_allgather_variants over a real RCCL communicator (world = 1 is all one GPU allows here): the payload
