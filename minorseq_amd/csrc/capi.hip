@@ -767,9 +767,12 @@ static void enqueue_path(jl_ctx *ctx, const jl_params *prm, double n_tests, bool
     const int skip = getenv("JL_SKIP_TAIL") ? atoi(getenv("JL_SKIP_TAIL")) : 0;
     if (!(skip & 1)) jl_launch_call(ctx, prm, n_tests, use_drm, phasing);
     jl_launch_stamp(ctx, 2);
-    // the last kernel of the run stores the completion word (jl_run_wait); probes that leave it out, and the
-    // timeline stamps behind it, need the stand-alone node instead
-    const bool own_done = skip != 0 || ctx->d_timeline != nullptr || getenv("JL_DUMMY_NODES") != nullptr;
+    // The completion word (jl_run_wait) is stored by a one-thread node of its own behind the last stage: the end of
+    // that stage's kernel is what pushes the results every compute die wrote for the host out of the dies' L2s.
+    // (Folding the word into the last kernel needs a system-scope release from every workgroup that wrote host
+    // memory — an L2 write-back each — and measured no faster: JL_SIGNAL_IN_KERNEL=1 keeps that variant.)
+    const bool own_done = skip != 0 || ctx->d_timeline != nullptr || getenv("JL_DUMMY_NODES") != nullptr ||
+                          getenv("JL_SIGNAL_IN_KERNEL") == nullptr;
     if (phasing && !(skip & 2)) jl_launch_phase(ctx, min_reads, true, !own_done);
     if (!(skip & 2)) jl_launch_result_pack(ctx, phasing, !own_done);
     jl_launch_stamp(ctx, 3);

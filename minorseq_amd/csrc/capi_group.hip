@@ -26,6 +26,7 @@ struct jl_group {
     jl_win_pileup *d_pile = nullptr;
     jl_win_call *d_call = nullptr;
     jl_win_phase *d_phase = nullptr;
+    jl_done_ent *d_done = nullptr;
     std::vector<jl_win_pileup> h_pile;
     std::vector<jl_win_call> h_call;
     std::vector<jl_win_phase> h_phase;
@@ -50,6 +51,8 @@ static void group_enqueue(jl_group *g, bool phasing)
     jl_launch_pileup_group(g->ctxs.data(), n, g->d_pile, g->max_chunks, g->stream);
     jl_launch_call_group(g->d_call, n, g->max_call_blocks, g->stream);
     if (phasing) jl_launch_phase_group(g->d_phase, n, g->max_phase_blocks, g->stream);
+    // completion words of all windows, behind the end of the last stage (see enqueue_path in capi.hip)
+    jl_launch_done_group(g->d_done, n, g->stream);
 }
 
 extern "C" {
@@ -74,7 +77,8 @@ int jl_group_create(jl_ctx *const *ctxs, uint32_t n_ctx, jl_group **out)
               hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking) == hipSuccess &&
               hipMalloc(&g->d_pile, sizeof(jl_win_pileup) * n_ctx) == hipSuccess &&
               hipMalloc(&g->d_call, sizeof(jl_win_call) * n_ctx) == hipSuccess &&
-              hipMalloc(&g->d_phase, sizeof(jl_win_phase) * n_ctx) == hipSuccess;
+              hipMalloc(&g->d_phase, sizeof(jl_win_phase) * n_ctx) == hipSuccess &&
+              hipMalloc(&g->d_done, sizeof(jl_done_ent) * n_ctx) == hipSuccess;
     if (!ok) {
         jl_group_destroy(g);
         return JL_ERR_MEMORY;
@@ -93,6 +97,7 @@ void jl_group_destroy(jl_group *g)
     if (g->d_pile) hipFree(g->d_pile);
     if (g->d_call) hipFree(g->d_call);
     if (g->d_phase) hipFree(g->d_phase);
+    if (g->d_done) hipFree(g->d_done);
     if (g->stream) hipStreamDestroy(g->stream);
     delete g;
 }
@@ -142,7 +147,7 @@ int jl_group_run_async(jl_group *g, const jl_gene *genes, uint32_t n_genes, cons
             jl_ctx *c = g->ctxs[k];
             jl_fill_win_pileup(c, &g->h_pile[k]);
             jl_fill_win_call(c, prm, n_tests[k], false, phasing != 0, &g->h_call[k]);
-            const bool fold = jl_fill_win_phase(c, min_reads, true, fold_budget, &g->h_phase[k]);
+            const bool fold = jl_fill_win_phase(c, min_reads, false, fold_budget, &g->h_phase[k]);
             if (fold) fold_budget -= g->h_phase[k].n_blocks;
             else all_fold = false;
             if (!phasing) g->h_call[k].meta = nullptr;
@@ -158,6 +163,12 @@ int jl_group_run_async(jl_group *g, const jl_gene *genes, uint32_t n_genes, cons
             hipMemcpy(g->d_call, g->h_call.data(), sizeof(jl_win_call) * n, hipMemcpyHostToDevice) != hipSuccess ||
             hipMemcpy(g->d_phase, g->h_phase.data(), sizeof(jl_win_phase) * n, hipMemcpyHostToDevice) != hipSuccess)
             return group_fail(g, JL_ERR_DEVICE, "argument tables");
+        {
+            std::vector<jl_done_ent> ents(n);
+            for (uint32_t k = 0; k < n; ++k) { ents[k].seq_dev = g->ctxs[k]->d_sync; ents[k].seq_host = g->ctxs[k]->h_seq; }
+            if (hipMemcpy(g->d_done, ents.data(), sizeof(jl_done_ent) * n, hipMemcpyHostToDevice) != hipSuccess)
+                return group_fail(g, JL_ERR_DEVICE, "argument tables");
+        }
         // same variant / launch shape everywhere?  (checked by the launcher; probe it outside the capture)
         for (uint32_t k = 1; k < n; ++k)
             if (g->ctxs[k]->pileup_w != g->ctxs[0]->pileup_w)

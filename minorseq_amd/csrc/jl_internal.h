@@ -119,6 +119,11 @@ struct jl_select_args {
     uint16_t *read_hap;
 };
 
+struct jl_done_ent {   // completion word of one window (see done_kernel)
+    uint32_t *seq_dev;
+    volatile uint32_t *seq_host;
+};
+
 struct jl_win_phase {
     const uint8_t *msa;
     uint64_t col_stride, n_reads, reads_pad;
@@ -267,6 +272,7 @@ void jl_launch_result_pack(jl_ctx *ctx, bool phasing, bool signal);
 void jl_launch_validate(jl_ctx *ctx, uint32_t *d_flag);
 void jl_launch_noop(jl_ctx *ctx);
 void jl_launch_done(jl_ctx *ctx);
+void jl_launch_done_group(const jl_done_ent *d_ents, uint32_t n, hipStream_t st);
 void jl_launch_stamp(jl_ctx *ctx, uint32_t slot);
 extern "C" int jl_run_prepare(jl_ctx *ctx, const jl_gene *genes, uint32_t n_genes, const uint8_t *refseq, uint32_t ref_len,
                               const jl_params *prm, const uint64_t *drm_masks, int phasing, uint32_t min_reads,

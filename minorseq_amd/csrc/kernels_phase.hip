@@ -195,17 +195,15 @@ __global__ __launch_bounds__(256) void phase_group_kernel(uint64_t n_reads, uint
 
 // Words that other workgroups of the SAME launch update with atomics (group counts, the read-category counters)
 // are read past the caches: memory-side atomics do not refresh a copy another XCD's L2 may still hold.
-// A write-through-scope load is still served by this XCD's L2, which may hold the word as an earlier launch left
-// it: observed as a selection that ranked the PREVIOUS run's group counts (one in five group runs after new reads
-// had been generated into the same buffers).  An atomic read-modify-write executes where the other workgroups'
-// atomics did, so it returns the value they left.
+// Words that other workgroups of the SAME launch update (group counts and keys, the occupied list, the read-category
+// counters) are read past this CU's L1 with agent-scope loads.
 __device__ __forceinline__ uint32_t ld_coherent(const uint32_t *p)
 {
-    return __hip_atomic_fetch_add(const_cast<uint32_t *>(p), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ unsigned long long ld_coherent64(const unsigned long long *p)
 {
-    return __hip_atomic_fetch_add(const_cast<unsigned long long *>(p), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // Completion word of a run (see jl_run_wait): stored by ONE thread after everything the run wrote for the host
@@ -717,8 +715,8 @@ __device__ __forceinline__ void phase_fused1_body(const jl_win_phase &w)
         if (tid == 0) {
             uint32_t spins = 0;
             while (__hip_atomic_load(S.flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
-                __builtin_amdgcn_s_sleep(4);
-                if (++spins > (1u << 23)) __builtin_trap();
+                __builtin_amdgcn_s_sleep(32);   // ~1 us between polls
+                if (++spins > (1u << 21)) __builtin_trap();
             }
         }
         __syncthreads();

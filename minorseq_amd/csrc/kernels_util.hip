@@ -179,6 +179,22 @@ __global__ void done_kernel(uint32_t *__restrict__ seq_dev, volatile uint32_t *_
     __threadfence_system();
     __hip_atomic_store(const_cast<uint32_t *>(seq_host), v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
+// the same for every window of a group launch: thread k ends window k's run
+__global__ void done_group_kernel(const jl_done_ent *__restrict__ ents, uint32_t n)
+{
+    const uint32_t k = threadIdx.x;
+    if (k >= n) return;
+    uint32_t *seq_dev = ents[k].seq_dev;
+    const uint32_t v = *seq_dev + 1u;
+    *seq_dev = v;
+    __threadfence_system();
+    __hip_atomic_store(const_cast<uint32_t *>(ents[k].seq_host), v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+void jl_launch_done_group(const jl_done_ent *d_ents, uint32_t n, hipStream_t st)
+{
+    hipLaunchKernelGGL(done_group_kernel, dim3(1), dim3(64), 0, st, d_ents, n);
+}
+
 void jl_launch_done(jl_ctx *ctx)
 {
     hipLaunchKernelGGL(done_kernel, dim3(1), dim3(1), 0, ctx->stream, ctx->d_sync, ctx->h_seq);
