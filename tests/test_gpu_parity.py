@@ -527,6 +527,50 @@ def test_group_run_equals_single_runs_and_oracle(jl, oracle):
         j.close()
 
 
+def test_group_run_window_with_many_positions_falls_back(jl, oracle):
+    """A window of a group with more than 10 variant positions: the grouped launch flags it (no view), its fetch calls
+    re-run the multi-word pipeline and return the oracle's answer; the other window of the same launch is unaffected;
+    afterwards that context is refused by group runs and served by jl_run_async."""
+    l, n = 300, 6000
+    genes = np.array([(1, l + 1)], dtype=capi.GENE)
+    ref = synth.reference(77, l)
+    loose = capi.default_params(alpha=0.9, n_tests=1.0)
+    ctxs, rows_all = [], []
+    for k, sub in enumerate((1.75e-4, 0.01)):   # the second window is noisy: dozens of called positions
+        sp = synth.SynthParams(seed=77 + k, sub_rate=sub, minor_permille=(50, 50, 50, 50))
+        rows = synth.rows(sp, l, 0, n, ref)
+        j = capi.Juliet(0)
+        j.upload_columns(msa.pack_columns(rows), n)
+        j.sync()
+        ctxs.append(j)
+        rows_all.append(rows)
+    grp = capi.Group(ctxs)
+    grp.run_async(genes, ref, loose, True, 3, True)
+    exp = []
+    for rows in rows_all:
+        ev = oracle.call(rows, genes, refseq=ref, params=oracle_params(loose))
+        exp.append((ev, oracle.phase(rows, ev, min_reads=3)))
+    assert len(np.unique(exp[1][0]["col"])) > 10
+    v0 = ctxs[0].run_view()
+    if len(np.unique(exp[0][0]["col"])) <= 10:
+        assert v0 is not None
+        assert_variants_equal(v0["variants"], exp[0][0])
+        assert_phase_equal(v0["phase"], exp[0][1], len(exp[0][0]))
+    assert ctxs[1].run_view() is None
+    cap = capi.VARIANT_CAP
+    f = ctxs[1].run_fetch(True, True, cap_var=cap)
+    assert_variants_equal(f["variants"], exp[1][0])
+    assert_phase_equal(f["phase"], exp[1][1], len(exp[1][0]))
+    with pytest.raises(capi.JulietError):
+        grp.run_async(genes, ref, loose, True, 3, True)   # that context now needs the multi-word pipeline
+    out = ctxs[1].run(genes, ref, loose, min_reads=3)
+    assert_variants_equal(out["variants"], exp[1][0])
+    assert_phase_equal(out["phase"], exp[1][1], len(exp[1][0]))
+    grp.close()
+    for j in ctxs:
+        j.close()
+
+
 # --------------------------------------------------------------------------------------------- the collective
 def test_allgather_variants_single_rank_communicator(jl, oracle):
     """jl_allgather_variants over a real RCCL communicator (world = 1 is all one GPU allows here): the payload
