@@ -120,6 +120,7 @@ def main():
     units = [ctxs[u * G:(u + 1) * G] for u in range(n_units)]
     groups = [capi.Group(u) for u in units] if G > 1 else None
     partial_groups = {}
+    handle_arrays = {}
     genes = np.array([(1, world * l + 1)], dtype=capi.GENE)
     refseq = np.full(world * l, 4, dtype=np.uint8)
     refseq[win_begin:win_begin + l] = ref_local
@@ -173,10 +174,14 @@ def main():
                     grp = partial_groups[(u, count)] = capi.Group(members)
             grp.run_async(genes, refseq, prm, True, 10, True)
         if comm is not None:
+            # the all-gathers of the launch's windows go out as one RCCL group (one collective launch)
+            arr = handle_arrays.get((u, count))
+            if arr is None:
+                arr = handle_arrays[(u, count)] = (C.c_void_p * count)(*[c.h for c in members])
+            rc = jl.lib.jl_allgather_variants_async_many(arr, count, comm)
+            if rc:
+                members[0]._chk(rc)
             for c in members:
-                rc = c.lib.jl_allgather_variants_async(c.h, comm)
-                if rc:
-                    c._chk(rc)
                 pending[id(c)] += 1
         return members
 

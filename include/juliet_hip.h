@@ -307,10 +307,15 @@ int jl_allgather_variants(jl_ctx *ctx, jl_comm *comm, jl_variant *all_rows, uint
  * thread of the communicator waits for the run's completion word and then issues the collective on the
  * communicator's stream.  The device result block is double-buffered by run parity, so a context may launch its
  * next run — and request that run's exchange — before collecting this one: at most TWO exchanges pending per
- * context (a third is refused with JL_ERR_STATE); jl_allgather_variants returns the OLDEST pending one.
+ * context (a third, and a run started while two are pending, are refused with JL_ERR_STATE);
+ * jl_allgather_variants returns the OLDEST pending one.
  * At most 64 exchanges in flight per communicator.
  */
 int jl_allgather_variants_async(jl_ctx *ctx, jl_comm *comm);
+/* The same for several contexts at once (the windows of a group run): their all-gathers are issued as ONE RCCL group,
+ * i.e. one collective launch.  Every rank must pass the same number of contexts in the same call order.  Collect
+ * each context's exchange with jl_allgather_variants as usual. */
+int jl_allgather_variants_async_many(jl_ctx *const *ctxs, uint32_t n, jl_comm *comm);
 
 /* ---------------------------------------------------------------- cross-window phasing */
 

@@ -795,6 +795,9 @@ int jl_run_prepare(jl_ctx *ctx, const jl_gene *genes, uint32_t n_genes, const ui
     if (prm->tail != 0) return jl_fail(ctx, JL_ERR_ARG, "only the one-sided (greater) tail is implemented");
     if (!(prm->alpha > 0.0) || !(prm->err.match > 0.0) || !(prm->err.substitution >= 0.0))
         return jl_fail(ctx, JL_ERR_ARG, "alpha/match must be > 0 and substitution >= 0");
+    if (ctx->exch_pending >= 2)
+        return jl_fail(ctx, JL_ERR_STATE, "two exchanges of this context are pending and each reads one of its two result "
+                                          "blocks: collect one (jl_allgather_variants) before the next run");
     JL_HIP(ctx, hipSetDevice(ctx->device));
     int rc;
     if (!same_plan(ctx, genes, n_genes, refseq, ref_len) && (rc = build_plan(ctx, genes, n_genes, refseq, ref_len))) return rc;

@@ -47,7 +47,7 @@ struct jl_comm {
     std::thread worker;
     std::mutex mu;
     std::condition_variable cv;
-    std::deque<jl_comm_slot *> queue;
+    std::deque<std::vector<jl_comm_slot *>> queue;   // batches: the exchanges of one batch go out as ONE RCCL group
     bool stop = false;
 };
 
@@ -55,24 +55,34 @@ static void comm_worker(jl_comm *c)
 {
     hipSetDevice(c->device);
     for (;;) {
-        jl_comm_slot *s = nullptr;
+        std::vector<jl_comm_slot *> batch;
         {
             std::unique_lock<std::mutex> lk(c->mu);
             c->cv.wait(lk, [&] { return c->stop || !c->queue.empty(); });
             if (c->queue.empty()) return;  // stop requested and nothing left
-            s = c->queue.front();
+            batch.swap(c->queue.front());
             c->queue.pop_front();
         }
         int st = JL_OK;
-        // the producing run is complete when its sequence word is in pinned memory (jl_run_wait): no event needed
-        if (jl_run_wait_seq(s->ctx, s->run_seq) != JL_OK) st = JL_ERR_DEVICE;
-        if (st == JL_OK && ncclAllGather(s->d_src, s->d_heads, JL_PACK_HEAD_BYTES, ncclUint8, c->comm, c->stream) != ncclSuccess) st = JL_ERR_COMM;
-        if (st == JL_OK && hipMemcpyAsync(s->h_heads, s->d_heads, JL_PACK_HEAD_BYTES * (size_t)c->world, hipMemcpyDeviceToHost, c->stream) != hipSuccess) st = JL_ERR_DEVICE;
-        if (hipEventRecord(s->done, c->stream) != hipSuccess && st == JL_OK) st = JL_ERR_DEVICE;
+        // the producing runs are complete when their sequence words are in pinned memory (jl_run_wait): no events
+        for (jl_comm_slot *s : batch)
+            if (jl_run_wait_seq(s->ctx, s->run_seq) != JL_OK) st = JL_ERR_DEVICE;
+        // one RCCL group for the whole batch: the all-gathers of the windows of a group run share one launch
+        const bool grouped = batch.size() > 1;
+        if (st == JL_OK && grouped && ncclGroupStart() != ncclSuccess) st = JL_ERR_COMM;
+        for (jl_comm_slot *s : batch)
+            if (st == JL_OK && ncclAllGather(s->d_src, s->d_heads, JL_PACK_HEAD_BYTES, ncclUint8, c->comm, c->stream) != ncclSuccess) st = JL_ERR_COMM;
+        if (grouped && ncclGroupEnd() != ncclSuccess && st == JL_OK) st = JL_ERR_COMM;
+        for (jl_comm_slot *s : batch) {
+            if (st == JL_OK && hipMemcpyAsync(s->h_heads, s->d_heads, JL_PACK_HEAD_BYTES * (size_t)c->world, hipMemcpyDeviceToHost, c->stream) != hipSuccess) st = JL_ERR_DEVICE;
+            if (hipEventRecord(s->done, c->stream) != hipSuccess && st == JL_OK) st = JL_ERR_DEVICE;
+        }
         {
             std::lock_guard<std::mutex> lk(c->mu);
-            s->status = st;
-            s->enqueued = true;
+            for (jl_comm_slot *s : batch) {
+                s->status = st;
+                s->enqueued = true;
+            }
         }
         c->cv.notify_all();
     }
@@ -183,9 +193,8 @@ static jl_comm_slot *comm_slot_oldest(jl_ctx *ctx, jl_comm *c)
 // which waits for the run's completion word and then issues the collective.  The result block is double-buffered
 // by run parity, so the run that follows on this context does not disturb the exchange; a context can therefore
 // have TWO exchanges pending, a third is refused.
-int jl_allgather_variants_async(jl_ctx *ctx, jl_comm *c)
+static int comm_request(jl_ctx *ctx, jl_comm *c, jl_comm_slot **out)
 {
-    if (!ctx || !c) return JL_ERR_ARG;
     if (!ctx->pack_valid) return jl_fail(ctx, JL_ERR_STATE, "jl_allgather_variants_async needs jl_run_async first");
     if (ctx->device != c->device) return jl_fail(ctx, JL_ERR_ARG, "context and communicator are on different devices");
     int n_pending = 0;
@@ -197,14 +206,50 @@ int jl_allgather_variants_async(jl_ctx *ctx, jl_comm *c)
     s->run_seq = ctx->runs_launched;
     s->d_src = reinterpret_cast<const uint8_t *>(ctx->d_pack + ((ctx->runs_launched - 1u) & 1u));
     s->seq = c->next_seq++;
+    s->enqueued = false;   // not yet visible to the worker: no lock needed
+    s->status = JL_OK;
+    ctx->exch_pending++;
+    *out = s;
+    return JL_OK;
+}
+
+int jl_allgather_variants_async(jl_ctx *ctx, jl_comm *c)
+{
+    if (!ctx || !c) return JL_ERR_ARG;
+    jl_comm_slot *s = nullptr;
+    int rc = comm_request(ctx, c, &s);
+    if (rc) return rc;
     {
         std::lock_guard<std::mutex> lk(c->mu);
-        s->enqueued = false;
-        s->status = JL_OK;
-        c->queue.push_back(s);
+        c->queue.emplace_back(1, s);
     }
     c->cv.notify_all();
     s->pending = true;
+    return JL_OK;
+}
+
+// The exchanges of several contexts (the windows of one group run) as ONE RCCL group: one collective launch instead
+// of n.  Every rank must pass the same number of contexts in the same call order.
+int jl_allgather_variants_async_many(jl_ctx *const *ctxs, uint32_t n, jl_comm *c)
+{
+    if (!ctxs || !c || n == 0 || n > JL_COMM_SLOTS / 2) return JL_ERR_ARG;
+    std::vector<jl_comm_slot *> batch;
+    for (uint32_t k = 0; k < n; ++k) {
+        if (!ctxs[k]) return JL_ERR_ARG;
+        jl_comm_slot *s = nullptr;
+        int rc = comm_request(ctxs[k], c, &s);
+        if (rc) {
+            for (jl_comm_slot *b : batch) { b->pending = false; b->ctx->exch_pending--; }
+            return rc;
+        }
+        s->pending = true;   // reserves the slot for the following comm_slot_free calls
+        batch.push_back(s);
+    }
+    {
+        std::lock_guard<std::mutex> lk(c->mu);
+        c->queue.push_back(batch);
+    }
+    c->cv.notify_all();
     return JL_OK;
 }
 
@@ -247,6 +292,7 @@ int jl_allgather_variants(jl_ctx *ctx, jl_comm *c, jl_variant *all_rows, uint32_
             s = comm_slot_oldest(ctx, c);
         }
         s->pending = false;
+        if (ctx->exch_pending) ctx->exch_pending--;
         comm_wait_enqueued(c, s);
         if (s->status != JL_OK) return jl_fail(ctx, s->status, "all-gather enqueue failed on the communicator thread");
         {   // spin on the event: a blocking hipEventSynchronize costs ~15 us of wake-up latency per step

@@ -228,6 +228,7 @@ struct jl_ctx {
     uint32_t *d_sync = nullptr;       // [16] zeroed once: [0] runs completed, [1..] arrival counters of fused kernels
     volatile uint32_t *h_seq = nullptr;  // pinned
     uint32_t runs_launched = 0;
+    uint32_t exch_pending = 0;        // exchanges requested and not yet collected: each still reads one of the two result blocks
     hipStream_t run_stream = nullptr;  // where the last run was enqueued (the ctx stream, or a group's)
     uint64_t *d_timeline = nullptr;   // JL_TIMELINE=1 only: [JL_TIMELINE_ROWS][JL_TIMELINE_SLOTS] device clock stamps
     hipGraph_t graph = nullptr;

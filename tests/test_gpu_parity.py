@@ -600,6 +600,53 @@ def test_allgather_variants_single_rank_communicator(jl, oracle):
         jl.lib.jl_comm_destroy(comm)
 
 
+def test_allgather_of_a_group_run_in_one_rccl_group(jl, oracle):
+    """jl_allgather_variants_async_many: the exchanges of the windows of a group run issued as one RCCL group by the
+    worker thread (no HIP call on the launching thread), two rounds pending per context, collected oldest first."""
+    import ctypes as C
+    l = 300
+    genes = np.array([(1, l + 1)], dtype=capi.GENE)
+    ref = synth.reference(51, l)
+    ctxs, exp = [], []
+    for k, n in enumerate((4000, 7000, 2500)):
+        sp = synth.SynthParams(seed=51 + k, minor_permille=(70, 60, 50, 40))
+        rows = synth.rows(sp, l, 0, n, ref)
+        j = capi.Juliet(0)
+        j.upload_columns(msa.pack_columns(rows), n)
+        j.sync()
+        ctxs.append(j)
+        exp.append(oracle.call(rows, genes, refseq=ref))
+    grp = capi.Group(ctxs)
+    idbuf = np.zeros(128, dtype=np.uint8)
+    assert jl.lib.jl_comm_unique_id(idbuf.ctypes.data_as(C.c_void_p)) == 0
+    comm = C.c_void_p()
+    ctxs[0]._chk(jl.lib.jl_comm_create(ctxs[0].h, idbuf.ctypes.data_as(C.c_void_p), 0, 1, C.byref(comm)))
+    arr = (C.c_void_p * len(ctxs))(*[c.h for c in ctxs])
+    all_rows = np.zeros(capi.VARIANT_CAP, dtype=capi.VARIANT)
+    counts = np.zeros(1, dtype=np.uint32)
+    try:
+        prm = capi.default_params()
+        for rnd in range(2):   # two exchanges pending per context before the first is collected
+            grp.run_async(genes, ref, prm, True, 10, True)
+            assert jl.lib.jl_allgather_variants_async_many(arr, len(ctxs), comm) == 0
+        with pytest.raises(capi.JulietError):   # a third run would overwrite a result block an exchange still reads
+            grp.run_async(genes, ref, prm, True, 10, True)
+        assert jl.lib.jl_allgather_variants_async_many(arr, len(ctxs), comm) == -4   # and so is a third exchange
+        for rnd in range(2):
+            for c, e in zip(ctxs, exp):
+                c._chk(jl.lib.jl_allgather_variants(c.h, comm, all_rows.ctypes.data_as(C.c_void_p),
+                                                    counts.ctypes.data_as(C.c_void_p), capi.VARIANT_CAP))
+                assert counts[0] == len(e)
+                assert_variants_equal(all_rows[: counts[0]], e)
+        for c, e in zip(ctxs, exp):
+            assert_variants_equal(c.run_view()["variants"], e)
+    finally:
+        jl.lib.jl_comm_destroy(comm)
+        grp.close()
+        for c in ctxs:
+            c.close()
+
+
 # --------------------------------------------------------------------------------------------- device ingest
 def rows_to_records(rows, ref, rng, with_noise_ops=True):
     """Re-express by-row symbols as BAM-style records (pos, cigar words, 4-bit packed bases, qualities):
