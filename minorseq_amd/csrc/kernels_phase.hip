@@ -310,6 +310,8 @@ __device__ __forceinline__ uint32_t pattern_code(const uint64_t *keys, unsigned 
 // Every table / key / meta word it reads was written by other workgroups: the caller has acquired them.
 // BYKEY: single-word pipeline — a group's pattern is its 64-bit table key (coherent: written by CAS), so no
 // representative read has to be looked up in the key buffer another workgroup may have written in this launch.
+#define JL_SELECT_LDS_WORDS (JL_CAND_CAP + 704u)
+
 template <bool BYKEY>
 __device__ __forceinline__ void phase_select_block(uint32_t min_reads, uint64_t reads_pad, const uint64_t *keys,
                                                    jl_phase_meta *meta, uint32_t *slot_rep, uint32_t *slot_count,
@@ -318,10 +320,11 @@ __device__ __forceinline__ void phase_select_block(uint32_t min_reads, uint64_t 
                                                    uint32_t *hap_count, uint8_t *hap_pattern, uint8_t *hit,
                                                    const uint32_t *n_rows, const uint32_t *vpcols, uint32_t *cooc,
                                                    uint32_t cooc_cap, jl_pack *pk, jl_pack *mirror,
-                                                   unsigned long long *slot_key, uint32_t *seq_dev)
+                                                   unsigned long long *slot_key, uint32_t *seq_dev, uint32_t *lds)
 {
-    __shared__ uint32_t s_cand[JL_CAND_CAP];  // slot of each candidate
-    __shared__ uint32_t s_hrep[JL_MAX_HAPLOTYPES];
+    // `lds`: JL_SELECT_LDS_WORDS words of LDS of the caller (the fused launch lends the tables its grouping is done with)
+    uint32_t *s_cand = lds;                               // [JL_CAND_CAP] slot of each candidate
+    uint32_t *s_hrep = lds + JL_CAND_CAP;                 // [JL_MAX_HAPLOTYPES]
     __shared__ uint32_t s_ncand, s_insufficient, s_reported, s_nhap;
     const uint32_t tid = threadIdx.x, nt = blockDim.x;
     const uint32_t vp = ld_coherent(&meta->vp);
@@ -440,8 +443,10 @@ __global__ __launch_bounds__(1024) void phase_select_kernel(uint32_t min_reads, 
                                                              jl_pack *mirror, unsigned long long *slot_key,
                                                              uint32_t *seq_dev, volatile uint32_t *seq_host)
 {
+    __shared__ uint32_t s_select[JL_SELECT_LDS_WORDS];
     phase_select_block<false>(min_reads, reads_pad, keys, meta, slot_rep, slot_count, occupied, slot_hap, variants, col2pos,
-                              n_cols, hap_count, hap_pattern, hit, n_rows, vpcols, cooc, cooc_cap, pk, mirror, slot_key, seq_dev);
+                              n_cols, hap_count, hap_pattern, hit, n_rows, vpcols, cooc, cooc_cap, pk, mirror, slot_key, seq_dev,
+                              s_select);
     if (seq_host) {  // last kernel of the run: the result block is on its way to the host
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -501,8 +506,12 @@ __device__ __forceinline__ void phase_fused1_body(const jl_win_phase &w)
     const select_args &S = w.S;
     const uint32_t vp = meta->vp, kw = meta->kwords;  // one scalar round trip for both; the plan wrote them
     const bool work = (vp != 0) & (kw == 1);           // block-uniform
-    __shared__ unsigned long long s_key[kLdsSlots];
-    __shared__ uint32_t s_cnt[kLdsSlots], s_first[kLdsSlots], s_gslot[kLdsSlots];
+    // one LDS block: the grouping tables (8 + 3 x 4 KB), lent to the selection once the grouping is done
+    static_assert(kLdsSlots * 5u >= JL_SELECT_LDS_WORDS, "the selection's scratch must fit the grouping tables");
+    __shared__ unsigned long long s_tables[kLdsSlots * 5u / 2u];
+    unsigned long long *s_key = s_tables;                                          // [kLdsSlots]
+    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_tables + kLdsSlots);          // [kLdsSlots]
+    uint32_t *s_first = s_cnt + kLdsSlots, *s_gslot = s_first + kLdsSlots;         // [kLdsSlots] each
     __shared__ unsigned long long s_dom;
     __shared__ uint32_t s_domcnt, s_domfirst, s_domslot;
     __shared__ uint32_t s_last, s_cat[4];
@@ -695,7 +704,7 @@ __device__ __forceinline__ void phase_fused1_body(const jl_win_phase &w)
     if (last) {
         phase_select_block<true>(S.min_reads, reads_pad, keys, meta, slot_rep, slot_count, occupied, S.slot_hap, S.variants,
                                  S.col2pos, S.n_cols, S.hap_count, S.hap_pattern, S.hit, S.n_rows, vpcols, S.cooc, S.cooc_cap,
-                                 S.pk, S.mirror, slot_key, S.seq_dev);
+                                 S.pk, S.mirror, slot_key, S.seq_dev, reinterpret_cast<uint32_t *>(s_tables));
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         // The result block went to pinned host memory from THIS compute die; the completion word will be stored by
