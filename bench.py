@@ -4,7 +4,7 @@
 A "step" is one pass of the hot path over one resident batch of synthetic aligned CCS reads:
   column pileup + per-codon histograms -> Fisher's exact x Bonferroni -> variant table
   (-> the one RCCL all-gather of the variant table when N > 1) -> read x variant phasing -> results on the host.
-Batches are independent windows; `--group G` of them (default 4) go through the path in ONE launch per stage
+Batches are independent windows; `--group G` of them (default 8) go through the path in ONE launch per stage
 (jl_group_run_async: blockIdx.z = window), so a launch is G steps, and `--inflight` launches are kept in flight.
 Every batch's results (variant table, haplotypes, per-read ids) land in pinned host memory and are read each step.
 Workload at N=1: BASELINE.json configs[2] (= configs[1] with phasing on): 100k CCS reads x 3 kb reference.
@@ -74,7 +74,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--inflight", type=int, default=4,
                     help="launches in flight per GPU (each on its own stream, with its own captured graph)")
-    ap.add_argument("--group", type=int, default=4,
+    ap.add_argument("--group", type=int, default=8,
                     help="batches (windows) per launch: 1 = one graph per batch (jl_run_async), G > 1 = group runs "
                          "(jl_group_run_async: one pileup / call / phase launch for G windows)")
     args = ap.parse_args()

@@ -141,7 +141,7 @@ int jl_group_run_async(jl_group *g, const jl_gene *genes, uint32_t n_genes, cons
         g->sig.clear();
         if (hipStreamSynchronize(g->stream) != hipSuccess) return group_fail(g, JL_ERR_DEVICE, "group stream failed");
         g->max_chunks = g->max_call_blocks = g->max_phase_blocks = 0;
-        uint32_t fold_budget = 256;   // workgroups of the phase launch that wait for each other: all resident at once
+        uint32_t fold_budget = 448;   // workgroups of the phase launch that wait for each other: all resident at once (7 per CU fit; 4 launches run at a time)
         bool all_fold = true;
         for (uint32_t k = 0; k < n; ++k) {
             jl_ctx *c = g->ctxs[k];
