@@ -30,7 +30,8 @@ struct jl_group {
     std::vector<jl_win_pileup> h_pile;
     std::vector<jl_win_call> h_call;
     std::vector<jl_win_phase> h_phase;
-    uint32_t max_chunks = 0, max_call_blocks = 0, max_phase_blocks = 0;
+    uint32_t max_chunks = 0, max_call_blocks = 0, max_phase_blocks = 0, max_read_blocks = 0;
+    bool fold = true;   // the phase launch also writes the per-read ids (its workgroups wait for each other)
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
     std::vector<uint8_t> sig;   // everything the captured graph and the tables bake in
@@ -50,7 +51,10 @@ static void group_enqueue(jl_group *g, bool phasing)
         if (!c->have_ref) jl_launch_guess(c, g->stream);   // majority-codon mode: seed bases per window
     jl_launch_pileup_group(g->ctxs.data(), n, g->d_pile, g->max_chunks, g->stream);
     jl_launch_call_group(g->d_call, n, g->max_call_blocks, g->stream);
-    if (phasing) jl_launch_phase_group(g->d_phase, n, g->max_phase_blocks, g->stream);
+    if (phasing) {
+        jl_launch_phase_group(g->d_phase, n, g->max_phase_blocks, g->stream);
+        if (!g->fold) jl_launch_assign_group(g->d_phase, n, g->max_read_blocks, g->stream);
+    }
     // completion words of all windows, behind the end of the last stage (see enqueue_path in capi.hip)
     jl_launch_done_group(g->d_done, n, g->stream);
 }
@@ -141,22 +145,25 @@ int jl_group_run_async(jl_group *g, const jl_gene *genes, uint32_t n_genes, cons
         g->sig.clear();
         if (hipStreamSynchronize(g->stream) != hipSuccess) return group_fail(g, JL_ERR_DEVICE, "group stream failed");
         g->max_chunks = g->max_call_blocks = g->max_phase_blocks = 0;
-        uint32_t fold_budget = 448;   // workgroups of the phase launch that wait for each other: all resident at once (7 per CU fit; 4 launches run at a time)
-        bool all_fold = true;
+        // The phase launch writes the per-read ids itself when ALL its workgroups can wait for each other, i.e. are
+        // resident at once — also while three more such launches run (the chip runs four queues): at most 256 per
+        // launch against 1536 places (six 75-register blocks per CU).  Larger groups take a separate launch for the
+        // ids: nothing waits for anything then.
+        uint32_t total_blocks = 0;
+        for (uint32_t k = 0; k < n; ++k) total_blocks += (uint32_t)((g->ctxs[k]->col_stride / 4u + 255u) / 256u);
+        g->fold = total_blocks <= 256u && !getenv("JL_NO_FOLD");
+        g->max_read_blocks = 0;
         for (uint32_t k = 0; k < n; ++k) {
             jl_ctx *c = g->ctxs[k];
             jl_fill_win_pileup(c, &g->h_pile[k]);
             jl_fill_win_call(c, prm, n_tests[k], false, phasing != 0, &g->h_call[k]);
-            const bool fold = jl_fill_win_phase(c, min_reads, false, fold_budget, &g->h_phase[k]);
-            if (fold) fold_budget -= g->h_phase[k].n_blocks;
-            else all_fold = false;
+            jl_fill_win_phase(c, min_reads, false, g->fold ? 0xFFFFFFFFu : 0u, &g->h_phase[k]);
             if (!phasing) g->h_call[k].meta = nullptr;
             g->max_chunks = std::max(g->max_chunks, g->h_pile[k].n_chunks);
             g->max_call_blocks = std::max(g->max_call_blocks, g->h_call[k].n_blocks);
             g->max_phase_blocks = std::max(g->max_phase_blocks, g->h_phase[k].n_blocks);
+            g->max_read_blocks = std::max(g->max_read_blocks, (uint32_t)((c->n_reads + 255u) / 256u));
         }
-        if (phasing && !all_fold)
-            return group_fail(g, JL_ERR_ARG, "the windows of a group hold more than 524288 reads in all: split the group");
         if (!phasing)
             return group_fail(g, JL_ERR_ARG, "group runs are built for call + phase; run call-only windows with jl_run_async");
         if (hipMemcpy(g->d_pile, g->h_pile.data(), sizeof(jl_win_pileup) * n, hipMemcpyHostToDevice) != hipSuccess ||

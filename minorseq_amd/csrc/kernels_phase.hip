@@ -803,6 +803,21 @@ __global__ __launch_bounds__(256) void phase_assign_kernel(uint64_t n_reads, con
     }
 }
 
+// the same for the windows of a group launch (blockIdx.z = window) — used when the group is too large for the
+// launch that groups the reads to write the ids itself (its workgroups would have to be resident all at once)
+__global__ __launch_bounds__(256) void phase_assign_group_kernel(const jl_win_phase *__restrict__ wins)
+{
+    const jl_win_phase w = wins[blockIdx.z];
+    const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (i >= w.n_reads) return;
+    uint16_t h = JL_HAP_DAMAGED;
+    if (w.meta->vp != 0) {
+        const uint32_t f = (w.flagw[i >> 3] >> (4u * (uint32_t)(i & 7u))) & 15u;
+        if (f == 0) h = (uint16_t)w.S.slot_hap[w.read_slot[i]];
+    }
+    w.S.read_hap[i] = h;
+}
+
 }  // namespace
 
 // `signal`: this launch ends a jl_run_async — its last kernel stores the completion word (jl_run_wait)
@@ -889,4 +904,9 @@ void jl_launch_phase(jl_ctx *ctx, uint32_t min_reads, bool planned, bool signal)
 void jl_launch_phase_group(const jl_win_phase *d_wins, uint32_t n_win, uint32_t max_blocks, hipStream_t st)
 {
     hipLaunchKernelGGL(phase_group_run_kernel, dim3(max_blocks, 1, n_win), dim3(256), 0, st, d_wins);
+}
+
+void jl_launch_assign_group(const jl_win_phase *d_wins, uint32_t n_win, uint32_t max_read_blocks, hipStream_t st)
+{
+    hipLaunchKernelGGL(phase_assign_group_kernel, dim3(max_read_blocks, 1, n_win), dim3(256), 0, st, d_wins);
 }

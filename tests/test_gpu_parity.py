@@ -477,10 +477,14 @@ def test_run_view_and_completion_word(jl, oracle):
         j.close()
 
 
-def test_group_run_equals_single_runs_and_oracle(jl, oracle):
+@pytest.mark.parametrize("fold", [True, False])
+def test_group_run_equals_single_runs_and_oracle(jl, oracle, fold, monkeypatch):
     """jl_group_run_async: several windows through the path in three launches (blockIdx.z = window).  Windows of
     different depth and noise, the same genes: every window's results must equal the oracle's (and so a single
-    run's), over graph replays, after new reads were generated into the same buffers, and in majority-codon mode."""
+    run's), over graph replays, after new reads were generated into the same buffers, and in majority-codon mode.
+    fold = False: the layout large groups use (per-read ids from a launch of their own, nothing waits in a launch)."""
+    if not fold:
+        monkeypatch.setenv("JL_NO_FOLD", "1")
     l = 300
     genes = np.array([(1, l + 1)], dtype=capi.GENE)
     shapes = [(9000, 0.05), (5000, 0.0), (12345, 0.2), (2048, 0.1)]
