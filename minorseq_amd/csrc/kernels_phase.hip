@@ -2,16 +2,21 @@
 // Behaviour: doc/JULIET.md:192-211 (--mode-phasing, haplotype_hit, haplotype block), :253-254 (>= 10 reads),
 // :372-381 (reported / insufficient / damaged, overlapping marginals); docs/SPEC.md §8.
 //
-// Pipeline (all on the ctx stream, no host round trip):
-//   plan    distinct variant columns, ascending, from the resident variant table
+// Stages (no host round trip):
+//   plan    distinct variant columns, ascending, from the resident variant table (done by call_kernel's last block
+//           in a whole-path run; phase_plan_kernel for a host-supplied table)
 //   keys    per read: flags (gap / heteroduplex / partial) and the pattern of codon indices at the Vp
 //           positions, 6 bits each, 10 positions per 64-bit word, first position most significant so that
 //           word-wise unsigned comparison is the lexicographic order of patterns
-//   group   exact grouping of clean reads: wave-level match-any collapses equal keys, one leader per group
-//           inserts into an open-addressing table keyed by the FULL key (representative read + compare)
+//   group   exact grouping of clean reads into an open-addressing table
 //   select  groups with >= min_reads ranked by (count desc, pattern asc), haplotype ids, patterns, hit matrix
-//           + variant x variant co-occurrence, the pinned result block, and emptying of the table slots used
+//           + variant x variant co-occurrence, the result block, and emptying of the table slots used
 //   assign  per-read haplotype id
+// Vp <= 10 (one key word): ONE launch — phase_fused1_kernel (a window) / phase_group_run_kernel (several windows,
+// blockIdx.z): keys + grouping in every block, the selection by the block that arrives last, and — when all
+// workgroups of the launch are resident together (<= 256) — the per-read ids by every block from the slots still
+// in its registers (the others wait on a flag); larger launches leave the ids to phase_assign(_group)_kernel.
+// Vp > 10: phase_keys_kernel, phase_group_kernel, phase_select_kernel, phase_assign_kernel.
 #include <string.h>
 
 #include "jl_internal.h"

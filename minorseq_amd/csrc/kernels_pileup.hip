@@ -18,10 +18,13 @@
 // A block owns one chunk of <= W consecutive columns from a host-built table (capi.hip: build_chunks) and a
 // strided set of 8192-read tiles.  Chunks start on codon boundaries, so stretches that are locally single-frame
 // need no halo; only where a codon of the chunk reaches past its last column are the next two columns loaded
-// as well.  Loads are non-temporal (every cell is read once).  Per-lane counters are packed two per register,
-// wave-reduced by DPP and flushed to LDS at most every 31 tiles (16-bit fields cannot overflow), then to HBM
-// with integer atomics, which commute, so results are bit-exact and order-independent.  There is no reuse
-// between blocks (halo columns aside), so the block -> XCD mapping does not matter here.
+// as well.  Loads are non-temporal (every cell is read once) and the next tile is prefetched into a second register
+// set while the current one is counted.  Per-lane counters are packed two per register, wave-reduced by DPP and
+// flushed to LDS at most every 31 tiles (16-bit fields cannot overflow).  A block that counts its chunk alone
+// (gridDim.y = 1) stores the totals; when the reads of a long column are split over several blocks they go to HBM
+// with integer atomics, which commute, so results are bit-exact and order-independent either way.  There is no
+// reuse between blocks (halo columns aside), so the block -> XCD mapping does not matter here.
+// pileup_group_kernel runs the same body for several windows in one launch (blockIdx.z = window).
 #include <stdlib.h>
 
 #include "jl_internal.h"
