@@ -162,7 +162,7 @@ int jl_group_run_async(jl_group *g, const jl_gene *genes, uint32_t n_genes, cons
             g->max_chunks = std::max(g->max_chunks, g->h_pile[k].n_chunks);
             g->max_call_blocks = std::max(g->max_call_blocks, g->h_call[k].n_blocks);
             g->max_phase_blocks = std::max(g->max_phase_blocks, g->h_phase[k].n_blocks);
-            g->max_read_blocks = std::max(g->max_read_blocks, (uint32_t)((c->n_reads + 255u) / 256u));
+            g->max_read_blocks = std::max(g->max_read_blocks, g->h_phase[k].n_blocks);   // 8 reads per lane there too
         }
         if (!phasing)
             return group_fail(g, JL_ERR_ARG, "group runs are built for call + phase; run call-only windows with jl_run_async");

@@ -783,22 +783,35 @@ __global__ __launch_bounds__(256) void phase_assign_kernel(uint64_t n_reads, con
                                                             uint16_t *__restrict__ read_hap, uint32_t *arrive,
                                                             uint32_t *seq_dev, volatile uint32_t *seq_host)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
-    if (i < n_reads) {
-        uint16_t h = JL_HAP_DAMAGED;
+    // eight reads per lane: one flag word, two 16-byte loads of slots, one 16-byte store of ids (the id buffer holds
+    // 2 * col_stride entries, so the store of a live lane is always inside it)
+    const uint64_t t = (uint64_t)blockIdx.x * 256u + threadIdx.x;   // dword index within a column
+    if (t * 8u < n_reads) {
+        uint16_t h[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) h[r] = JL_HAP_DAMAGED;
         if (meta->vp != 0) {
-            const uint32_t f = (flagw[i >> 3] >> (4u * (uint32_t)(i & 7u))) & 15u;
-            if (f == 0) h = (uint16_t)slot_hap[read_slot[i]];
+            const uint32_t f = flagw[t];
+            const uint4 s0 = *reinterpret_cast<const uint4 *>(read_slot + t * 8u);
+            const uint4 s1 = *reinterpret_cast<const uint4 *>(read_slot + t * 8u + 4u);
+            const uint32_t slot[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+                if (((f >> (4 * r)) & 15u) == 0) h[r] = (uint16_t)slot_hap[slot[r]];   // clean reads only: their slot is valid
         }
-        read_hap[i] = h;
+        uint4 v;
+        v.x = h[0] | ((uint32_t)h[1] << 16); v.y = h[2] | ((uint32_t)h[3] << 16);
+        v.z = h[4] | ((uint32_t)h[5] << 16); v.w = h[6] | ((uint32_t)h[7] << 16);
+        *reinterpret_cast<uint4 *>(read_hap + t * 8u) = v;
     }
     if (seq_host) {
-        // last kernel of the run: the block that arrives last stores the completion word behind everybody's ids.
-        // The ids go to fine-grained (uncached) pinned memory, so draining the stores is all a block has to do
-        // before it arrives — a system-scope fence per block would write back the L2 391 times.
+        // JL_SIGNAL_IN_KERNEL=1 only (comparison variant): the block that arrives last stores the completion word
+        // behind everybody's ids.  Every block releases its ids at system scope first — they may still sit in its
+        // die's L2 otherwise (see done_kernel) — which is what makes this variant slower than a node of its own.
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (threadIdx.x == 0) {
+            __threadfence_system();
             const uint32_t prev = __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (prev == gridDim.x - 1u) {
                 __hip_atomic_store(arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -812,15 +825,27 @@ __global__ __launch_bounds__(256) void phase_assign_kernel(uint64_t n_reads, con
 // launch that groups the reads to write the ids itself (its workgroups would have to be resident all at once)
 __global__ __launch_bounds__(256) void phase_assign_group_kernel(const jl_win_phase *__restrict__ wins)
 {
+    // eight reads per lane: one flag word, two 16-byte loads of slots, one 16-byte store of ids (a wave writes 1 KiB
+    // contiguous — the ids usually go to pinned host memory, and PCIe likes long writes)
     const jl_win_phase w = wins[blockIdx.z];
-    const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
-    if (i >= w.n_reads) return;
-    uint16_t h = JL_HAP_DAMAGED;
+    const uint64_t t = (uint64_t)blockIdx.x * 256u + threadIdx.x;   // dword index within a column = 8 reads
+    if (t * 4u >= w.col_stride) return;
+    uint16_t h[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) h[r] = JL_HAP_DAMAGED;
     if (w.meta->vp != 0) {
-        const uint32_t f = (w.flagw[i >> 3] >> (4u * (uint32_t)(i & 7u))) & 15u;
-        if (f == 0) h = (uint16_t)w.S.slot_hap[w.read_slot[i]];
+        const uint32_t f = w.flagw[t];
+        const uint4 s0 = *reinterpret_cast<const uint4 *>(w.read_slot + t * 8u);
+        const uint4 s1 = *reinterpret_cast<const uint4 *>(w.read_slot + t * 8u + 4u);
+        const uint32_t slot[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+            if (((f >> (4 * r)) & 15u) == 0) h[r] = (uint16_t)w.S.slot_hap[slot[r]];   // clean reads only: their slot is valid
     }
-    w.S.read_hap[i] = h;
+    uint4 v;
+    v.x = h[0] | ((uint32_t)h[1] << 16); v.y = h[2] | ((uint32_t)h[3] << 16);
+    v.z = h[4] | ((uint32_t)h[5] << 16); v.w = h[6] | ((uint32_t)h[7] << 16);
+    *reinterpret_cast<uint4 *>(w.S.read_hap + t * 8u) = v;   // the buffer holds 2 * col_stride entries
 }
 
 }  // namespace
@@ -901,7 +926,7 @@ void jl_launch_phase(jl_ctx *ctx, uint32_t min_reads, bool planned, bool signal)
                            (unsigned long long *)ctx->d_slot_key, ctx->d_sync, signal_select ? ctx->h_seq : nullptr);
     }
     if (fold) return;
-    hipLaunchKernelGGL(phase_assign_kernel, dim3(rblocks), dim3(256), 0, st, ctx->n_reads, ctx->d_flagw, ctx->d_meta,
+    hipLaunchKernelGGL(phase_assign_kernel, dim3(w.n_blocks), dim3(256), 0, st, ctx->n_reads, ctx->d_flagw, ctx->d_meta,
                        ctx->d_read_slot, ctx->d_slot_hap, ctx->read_hap_out ? ctx->read_hap_out : ctx->d_read_hap,
                        ctx->d_sync + 3, ctx->d_sync, (signal && ids_to_host) ? ctx->h_seq : nullptr);
 }
