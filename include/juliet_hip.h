@@ -252,7 +252,7 @@ int jl_run_view_get(jl_ctx *ctx, jl_run_view *out);
  * each context: every context keeps its own result block, per-read ids and completion word, so jl_run_wait,
  * jl_run_done, jl_run_view_get, jl_call_fetch, jl_phase_fetch and jl_allgather_variants_async apply unchanged.
  * All windows get the same genes / reference / parameters (they are windows of one reference, or samples of one
- * amplicon).  Limits: call + phase only; a window with more than 10
+ * amplicon).  Limits: call + phase only, no --drm-only masks (they are per window: use jl_run_async); a window with more than 10
  * variant positions is flagged as in jl_run_async (its fetch calls then re-run the multi-word pipeline).  Every
  * window is counted by one block per column chunk, so windows of millions of reads are better run one by one.
  * The contexts' own streams must be idle (uploads finished).
