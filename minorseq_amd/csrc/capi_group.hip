@@ -146,12 +146,12 @@ int jl_group_run_async(jl_group *g, const jl_gene *genes, uint32_t n_genes, cons
         if (hipStreamSynchronize(g->stream) != hipSuccess) return group_fail(g, JL_ERR_DEVICE, "group stream failed");
         g->max_chunks = g->max_call_blocks = g->max_phase_blocks = 0;
         // The phase launch writes the per-read ids itself when ALL its workgroups can wait for each other, i.e. are
-        // resident at once — also while three more such launches run (the chip runs four queues): at most 256 per
-        // launch against 1536 places (six 75-register blocks per CU).  Larger groups take a separate launch for the
-        // ids: nothing waits for anything then.
+        // resident at once — also while more such launches run: at most JL_FOLD_MAX_BLOCKS per launch against 1536
+        // places (six 75-register blocks per CU).  Larger groups take a separate launch for the ids: nothing waits
+        // for anything then.
         uint32_t total_blocks = 0;
         for (uint32_t k = 0; k < n; ++k) total_blocks += (uint32_t)((g->ctxs[k]->col_stride / 4u + 255u) / 256u);
-        g->fold = total_blocks <= 256u && !getenv("JL_NO_FOLD");
+        g->fold = total_blocks <= JL_FOLD_MAX_BLOCKS && !getenv("JL_NO_FOLD");
         g->max_read_blocks = 0;
         for (uint32_t k = 0; k < n; ++k) {
             jl_ctx *c = g->ctxs[k];

@@ -13,6 +13,10 @@
 #define JL_VARIANT_CAP 4096u      // rows of the resident variant table (all-gather stride)
 #define JL_CAND_CAP 4096u         // haplotype candidates (groups with >= min_reads) the selector can rank
 #define JL_POS_PER_WORD 10u       // variant positions per 64-bit key word (6 bits each)
+// Largest phase launch whose workgroups may wait for each other inside the launch (the per-read ids are then written by
+// the same launch): all of them must be resident at once, next to as many more such launches as queues run at a time.
+// 1536 places on the chip (75 VGPRs, 20.5 KB LDS per block); 128 leaves room for eight concurrent launches and more.
+#define JL_FOLD_MAX_BLOCKS 128u
 #define JL_TIMELINE_ROWS 4096u
 #define JL_TIMELINE_SLOTS 8u
 #define JL_GUESS_PAD 32u           // zero bytes after the last column's seed base

@@ -14,7 +14,7 @@
 //   assign  per-read haplotype id
 // Vp <= 10 (one key word): ONE launch — phase_fused1_kernel (a window) / phase_group_run_kernel (several windows,
 // blockIdx.z): keys + grouping in every block, the selection by the block that arrives last, and — when all
-// workgroups of the launch are resident together (<= 256) — the per-read ids by every block from the slots still
+// workgroups of the launch are resident together (<= JL_FOLD_MAX_BLOCKS) — the per-read ids by every block from the slots still
 // in its registers (the others wait on a flag); larger launches leave the ids to phase_assign(_group)_kernel.
 // Vp > 10: phase_keys_kernel, phase_group_kernel, phase_select_kernel, phase_assign_kernel.
 #include <string.h>
@@ -882,7 +882,7 @@ bool jl_fill_win_phase(jl_ctx *ctx, uint32_t min_reads, bool signal, uint32_t fo
     S.hap_count = ctx->d_hap_count; S.hap_pattern = ctx->d_hap_pattern; S.hit = ctx->d_hit; S.n_rows = ctx->d_nvar;
     S.cooc = ctx->d_cooc; S.pk = ctx->d_pack; S.mirror = ctx->pack_mirror;
     S.arrive = ctx->d_sync + 2; S.seq_dev = ctx->d_sync;
-    // a launch of at most 256 workgroups in all (<= 524288 reads) also writes the per-read ids: one launch less
+    // a launch of at most JL_FOLD_MAX_BLOCKS workgroups in all also writes the per-read ids: one launch less
     const bool fold = !generic && fblocks <= fold_budget && !getenv("JL_NO_FOLD");
     S.fold = fold ? 1u : 0u;
     S.flag = ctx->d_sync + 4; S.arrive2 = ctx->d_sync + 3;
@@ -913,7 +913,7 @@ void jl_launch_phase(jl_ctx *ctx, uint32_t min_reads, bool planned, bool signal)
                            ctx->col_stride, ctx->n_reads, reads_pad, ctx->d_vpcols, ctx->d_meta, ctx->d_keys,
                            ctx->d_flagw);
     jl_win_phase w;
-    const bool fold = jl_fill_win_phase(ctx, min_reads, signal, 256u, &w);
+    const bool fold = jl_fill_win_phase(ctx, min_reads, signal, JL_FOLD_MAX_BLOCKS, &w);
     hipLaunchKernelGGL(phase_fused1_kernel, dim3(w.n_blocks), dim3(256), 0, st, w);
     if (generic) {
         hipLaunchKernelGGL(phase_group_kernel, dim3(rblocks), dim3(256), 0, st, ctx->n_reads, reads_pad, ctx->d_keys,
