@@ -67,6 +67,15 @@ struct jl_pack {
 // ---- per-window argument blocks of the three stage kernels.  A single run passes one by value; a group run
 // (jl_group_run_async) keeps an array of them in device memory and launches each stage ONCE for all windows
 // (blockIdx.z = window).  `n_blocks` = workgroups of the window's own grid (the arrival counters count to it).
+// Pointers that a kernel loads from an argument block in memory are "generic" to the compiler, which then emits flat
+// loads (they count on two wait counters at once, so no wait on them can be an exact count and a register prefetch
+// overlaps nothing).  The streaming code therefore takes pointers typed as global memory (address space 1).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define JL_AS1 __attribute__((address_space(1)))
+#else
+#define JL_AS1
+#endif
+
 struct jl_call_args {
     double alpha, n_tests, match, substitution, min_perc, max_perc;
     int32_t expected_round;

@@ -113,7 +113,7 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 // FAST = the common chunk of a single-frame stretch: exactly three own columns that are one codon (no halo).
 // Everything the generic path decides per column at run time is a compile-time constant then.
 template <int W, bool NT, bool FAST>
-__device__ __forceinline__ void load_tile(tile_regs<W> &r, const uint8_t *__restrict__ msa, uint64_t col_stride,
+__device__ __forceinline__ void load_tile(tile_regs<W> &r, const uint8_t JL_AS1 *msa, uint64_t col_stride,
                                           uint32_t n_cols, uint32_t c0, uint32_t ncols, uint64_t off, bool need_halo)
 {
 #pragma unroll
@@ -123,7 +123,7 @@ __device__ __forceinline__ void load_tile(tile_regs<W> &r, const uint8_t *__rest
         const bool live = FAST ? true
                                : (c0 + j < n_cols) && ((uint32_t)j < ncols || (need_halo && (uint32_t)j < ncols + 2u));
         if (live) {
-            const u32x4 *src = reinterpret_cast<const u32x4 *>(msa + (uint64_t)(c0 + j) * col_stride + off);
+            const u32x4 JL_AS1 *src = (const u32x4 JL_AS1 *)(msa + (uint64_t)(c0 + j) * col_stride + off);
             // every cell is read exactly once: a non-temporal load keeps the stream from displacing L2 lines
             const u32x4 v = NT ? __builtin_nontemporal_load(src) : *src;
             r.d[j][0] = v.x; r.d[j][1] = v.y; r.d[j][2] = v.z; r.d[j][3] = v.w;
@@ -134,7 +134,7 @@ __device__ __forceinline__ void load_tile(tile_regs<W> &r, const uint8_t *__rest
 }
 
 template <int W, bool PIPE, int MODE, bool FAST>
-__device__ __forceinline__ void pileup_stream(const uint8_t *__restrict__ msa, uint64_t col_stride, uint32_t n_cols,
+__device__ __forceinline__ void pileup_stream(const uint8_t JL_AS1 *msa, uint64_t col_stride, uint32_t n_cols,
                                               uint32_t n_tiles, uint32_t c0, uint32_t ncols, uint32_t startf,
                                               bool need_halo, const uint32_t (&g)[W + 2], uint32_t (*s_hist)[64],
                                               uint32_t (*s_col)[6], uint32_t *s_match)
@@ -262,10 +262,9 @@ __device__ __forceinline__ void pileup_stream(const uint8_t *__restrict__ msa, u
 }
 
 template <int W, bool PIPE, int MODE>
-__device__ __forceinline__ void pileup_body(const uint8_t *__restrict__ msa, uint64_t col_stride, uint32_t n_cols,
-                                            uint32_t n_tiles, const uint2 *__restrict__ chunks,
-                                            const uint32_t *__restrict__ guess32, uint32_t *__restrict__ counts,
-                                            uint32_t *__restrict__ hist)
+__device__ __forceinline__ void pileup_body(const uint8_t JL_AS1 *msa, uint64_t col_stride, uint32_t n_cols,
+                                            uint32_t n_tiles, const uint2 JL_AS1 *chunks, const uint32_t JL_AS1 *guess32,
+                                            uint32_t JL_AS1 *counts, uint32_t JL_AS1 *hist)
 {
     __shared__ uint32_t s_hist[W][64];
     __shared__ uint32_t s_col[W][6];   // A C G T - N
@@ -318,7 +317,7 @@ __device__ __forceinline__ void pileup_body(const uint8_t *__restrict__ msa, uin
         const uint32_t v = s_col[j][k];
         if (j < ncols) {
             if (excl) counts[(uint64_t)(c0 + j) * 6u + k] = v;
-            else if (v) atomicAdd(counts + (uint64_t)(c0 + j) * 6u + k, v);
+            else if (v) atomicAdd((uint32_t *)(counts + (uint64_t)(c0 + j) * 6u + k), v);
         }
     }
     if (tid < W && (startf & (1u << tid))) {
@@ -333,7 +332,7 @@ __device__ __forceinline__ void pileup_body(const uint8_t *__restrict__ msa, uin
         const uint32_t v = s_hist[j][i & 63u];
         if (startf & (1u << j)) {
             if (excl) hist[(uint64_t)(c0 + j) * 64u + (i & 63u)] = v;
-            else if (v) atomicAdd(hist + (uint64_t)(c0 + j) * 64u + (i & 63u), v);
+            else if (v) atomicAdd((uint32_t *)(hist + (uint64_t)(c0 + j) * 64u + (i & 63u)), v);
         }
     }
 }
@@ -345,7 +344,8 @@ __global__ __launch_bounds__(256) void pileup_kernel(const uint8_t *__restrict__
                                                       const uint32_t *__restrict__ guess32,
                                                       uint32_t *__restrict__ counts, uint32_t *__restrict__ hist)
 {
-    pileup_body<W, PIPE, MODE>(msa, col_stride, n_cols, n_tiles, chunks, guess32, counts, hist);
+    pileup_body<W, PIPE, MODE>((const uint8_t JL_AS1 *)msa, col_stride, n_cols, n_tiles, (const uint2 JL_AS1 *)chunks,
+                               (const uint32_t JL_AS1 *)guess32, (uint32_t JL_AS1 *)counts, (uint32_t JL_AS1 *)hist);
 }
 
 // One launch over several resident windows (blockIdx.z = window, argument blocks in device memory): the stream of a
@@ -356,7 +356,9 @@ __global__ __launch_bounds__(256) void pileup_group_kernel(const jl_win_pileup *
 {
     const jl_win_pileup w = wins[blockIdx.z];
     if (blockIdx.x >= w.n_chunks) return;
-    pileup_body<W, PIPE, MODE>(w.msa, w.col_stride, w.n_cols, w.n_tiles, w.chunks, w.guess32, w.counts, w.hist);
+    // the pointers come out of memory: say that they are global ones, or the loads become flat loads (JL_AS1)
+    pileup_body<W, PIPE, MODE>((const uint8_t JL_AS1 *)w.msa, w.col_stride, w.n_cols, w.n_tiles, (const uint2 JL_AS1 *)w.chunks,
+                               (const uint32_t JL_AS1 *)w.guess32, (uint32_t JL_AS1 *)w.counts, (uint32_t JL_AS1 *)w.hist);
 }
 
 // Seed base per column for majority-codon mode: majority base among the first reads of the column.
