@@ -23,9 +23,6 @@ struct jl_group {
     int device = -1;
     hipStream_t stream = nullptr;
     std::vector<jl_ctx *> ctxs;
-    jl_win_pileup *d_pile = nullptr;
-    jl_win_call *d_call = nullptr;
-    jl_win_phase *d_phase = nullptr;
     jl_done_ent *d_done = nullptr;
     std::vector<jl_win_pileup> h_pile;
     std::vector<jl_win_call> h_call;
@@ -49,11 +46,11 @@ static void group_enqueue(jl_group *g, bool phasing)
     const uint32_t n = (uint32_t)g->ctxs.size();
     for (jl_ctx *c : g->ctxs)
         if (!c->have_ref) jl_launch_guess(c, g->stream);   // majority-codon mode: seed bases per window
-    jl_launch_pileup_group(g->ctxs.data(), n, g->d_pile, g->max_chunks, g->stream);
-    jl_launch_call_group(g->d_call, n, g->max_call_blocks, g->stream);
+    jl_launch_pileup_group(g->ctxs.data(), n, g->h_pile.data(), g->max_chunks, g->stream);
+    jl_launch_call_group(g->h_call.data(), n, g->max_call_blocks, g->stream);
     if (phasing) {
-        jl_launch_phase_group(g->d_phase, n, g->max_phase_blocks, g->stream);
-        if (!g->fold) jl_launch_assign_group(g->d_phase, n, g->max_read_blocks, g->stream);
+        jl_launch_phase_group(g->h_phase.data(), n, g->max_phase_blocks, g->stream);
+        if (!g->fold) jl_launch_assign_group(g->h_phase.data(), n, g->max_read_blocks, g->stream);
     }
     // completion words of all windows, behind the end of the last stage (see enqueue_path in capi.hip)
     jl_launch_done_group(g->d_done, n, g->stream);
@@ -63,7 +60,7 @@ extern "C" {
 
 int jl_group_create(jl_ctx *const *ctxs, uint32_t n_ctx, jl_group **out)
 {
-    if (!ctxs || !out || n_ctx == 0 || n_ctx > 64) return JL_ERR_ARG;
+    if (!ctxs || !out || n_ctx == 0 || n_ctx > JL_GROUP_MAX) return JL_ERR_ARG;   // the argument blocks travel by value
     *out = nullptr;
     for (uint32_t k = 0; k < n_ctx; ++k) {
         if (!ctxs[k] || ctxs[k]->device != ctxs[0]->device) return JL_ERR_ARG;
@@ -79,9 +76,6 @@ int jl_group_create(jl_ctx *const *ctxs, uint32_t n_ctx, jl_group **out)
     g->h_phase.resize(n_ctx);
     bool ok = hipSetDevice(g->device) == hipSuccess &&
               hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking) == hipSuccess &&
-              hipMalloc(&g->d_pile, sizeof(jl_win_pileup) * n_ctx) == hipSuccess &&
-              hipMalloc(&g->d_call, sizeof(jl_win_call) * n_ctx) == hipSuccess &&
-              hipMalloc(&g->d_phase, sizeof(jl_win_phase) * n_ctx) == hipSuccess &&
               hipMalloc(&g->d_done, sizeof(jl_done_ent) * n_ctx) == hipSuccess;
     if (!ok) {
         jl_group_destroy(g);
@@ -98,9 +92,6 @@ void jl_group_destroy(jl_group *g)
     if (g->stream) hipStreamSynchronize(g->stream);
     if (g->graph_exec) hipGraphExecDestroy(g->graph_exec);
     if (g->graph) hipGraphDestroy(g->graph);
-    if (g->d_pile) hipFree(g->d_pile);
-    if (g->d_call) hipFree(g->d_call);
-    if (g->d_phase) hipFree(g->d_phase);
     if (g->d_done) hipFree(g->d_done);
     if (g->stream) hipStreamDestroy(g->stream);
     delete g;
@@ -166,10 +157,6 @@ int jl_group_run_async(jl_group *g, const jl_gene *genes, uint32_t n_genes, cons
         }
         if (!phasing)
             return group_fail(g, JL_ERR_ARG, "group runs are built for call + phase; run call-only windows with jl_run_async");
-        if (hipMemcpy(g->d_pile, g->h_pile.data(), sizeof(jl_win_pileup) * n, hipMemcpyHostToDevice) != hipSuccess ||
-            hipMemcpy(g->d_call, g->h_call.data(), sizeof(jl_win_call) * n, hipMemcpyHostToDevice) != hipSuccess ||
-            hipMemcpy(g->d_phase, g->h_phase.data(), sizeof(jl_win_phase) * n, hipMemcpyHostToDevice) != hipSuccess)
-            return group_fail(g, JL_ERR_DEVICE, "argument tables");
         {
             std::vector<jl_done_ent> ents(n);
             for (uint32_t k = 0; k < n; ++k) { ents[k].seq_dev = g->ctxs[k]->d_sync; ents[k].seq_host = g->ctxs[k]->h_seq; }
@@ -222,7 +209,7 @@ int jl_group_time_pileup(jl_group *const *groups, uint32_t n_groups, uint32_t re
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return group_fail(g0, JL_ERR_DEVICE, "events");
     auto launch = [&](jl_group *g) {
-        return jl_launch_pileup_group(g->ctxs.data(), (uint32_t)g->ctxs.size(), g->d_pile, g->max_chunks, g0->stream);
+        return jl_launch_pileup_group(g->ctxs.data(), (uint32_t)g->ctxs.size(), g->h_pile.data(), g->max_chunks, g0->stream);
     };
     int rc = JL_OK;
     for (uint32_t k = 0; k < n_groups && rc == JL_OK; ++k) rc = launch(groups[k]);   // warm-up, once per group

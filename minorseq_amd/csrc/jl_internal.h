@@ -151,6 +151,15 @@ struct jl_win_phase {
     uint32_t n_blocks, pad_;
 };
 
+// Group launches take the argument blocks of their (at most JL_GROUP_MAX) windows BY VALUE, i.e. in the kernel-argument
+// segment: pointers loaded from there are known to be global ones, while pointers loaded from a table in device memory
+// are generic to the compiler and every access through them becomes a flat access (slower, and never waited for with
+// an exact count).
+#define JL_GROUP_MAX 8
+struct jl_call_group_args { jl_win_call w[JL_GROUP_MAX]; };
+struct jl_phase_group_args { jl_win_phase w[JL_GROUP_MAX]; };
+struct jl_pileup_group_args { jl_win_pileup w[JL_GROUP_MAX]; };
+
 struct jl_comm;
 
 struct jl_ctx {
@@ -273,14 +282,15 @@ bool jl_pileup_needs_zero(jl_ctx *ctx);
 void jl_prepare_pileup(jl_ctx *ctx);
 void jl_launch_call(jl_ctx *ctx, const jl_params *prm, double n_tests, bool use_drm, bool with_plan);
 void jl_launch_phase(jl_ctx *ctx, uint32_t min_reads, bool planned, bool signal);
-// group runs: fill one window's argument block / launch a stage once for `n_win` windows (tables in device memory)
+// group runs: fill one window's argument block / launch a stage once for `n_win` <= JL_GROUP_MAX windows (the blocks
+// travel by value in the kernel arguments)
 void jl_fill_win_pileup(jl_ctx *ctx, jl_win_pileup *w);
 void jl_fill_win_call(jl_ctx *ctx, const jl_params *prm, double n_tests, bool use_drm, bool with_plan, jl_win_call *w);
 bool jl_fill_win_phase(jl_ctx *ctx, uint32_t min_reads, bool signal, uint32_t fold_budget, jl_win_phase *w);
-int jl_launch_pileup_group(jl_ctx *const *ctxs, uint32_t n_win, const jl_win_pileup *d_wins, uint32_t max_chunks, hipStream_t st);
-void jl_launch_call_group(const jl_win_call *d_wins, uint32_t n_win, uint32_t max_blocks, hipStream_t st);
-void jl_launch_phase_group(const jl_win_phase *d_wins, uint32_t n_win, uint32_t max_blocks, hipStream_t st);
-void jl_launch_assign_group(const jl_win_phase *d_wins, uint32_t n_win, uint32_t max_read_blocks, hipStream_t st);
+int jl_launch_pileup_group(jl_ctx *const *ctxs, uint32_t n_win, const jl_win_pileup *h_wins, uint32_t max_chunks, hipStream_t st);
+void jl_launch_call_group(const jl_win_call *h_wins, uint32_t n_win, uint32_t max_blocks, hipStream_t st);
+void jl_launch_phase_group(const jl_win_phase *h_wins, uint32_t n_win, uint32_t max_blocks, hipStream_t st);
+void jl_launch_assign_group(const jl_win_phase *h_wins, uint32_t n_win, uint32_t max_read_blocks, hipStream_t st);
 void jl_launch_synth(jl_ctx *ctx, const jl_synth_plan *plan, const uint8_t *d_ref);
 void jl_launch_pack_rows(jl_ctx *ctx, const uint8_t *d_rows);
 void jl_launch_result_pack(jl_ctx *ctx, bool phasing, bool signal);

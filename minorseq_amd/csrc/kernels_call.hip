@@ -212,9 +212,9 @@ __device__ __forceinline__ void call_body(const jl_win_call &w)
 __global__ __launch_bounds__(256) void call_kernel(jl_win_call w) { call_body(w); }
 
 // one launch for several windows: blockIdx.z = window, argument blocks in device memory
-__global__ __launch_bounds__(256) void call_group_kernel(const jl_win_call *__restrict__ wins)
+__global__ __launch_bounds__(256) void call_group_kernel(jl_call_group_args args)
 {
-    const jl_win_call w = wins[blockIdx.z];
+    const jl_win_call &w = args.w[blockIdx.z];
     if (blockIdx.x >= w.n_blocks) return;
     call_body(w);
 }
@@ -273,7 +273,10 @@ void jl_launch_call(jl_ctx *ctx, const jl_params *prm, double n_tests, bool use_
     hipLaunchKernelGGL(call_kernel, dim3(w.n_blocks), dim3(256), 0, ctx->stream, w);
 }
 
-void jl_launch_call_group(const jl_win_call *d_wins, uint32_t n_win, uint32_t max_blocks, hipStream_t st)
+void jl_launch_call_group(const jl_win_call *h_wins, uint32_t n_win, uint32_t max_blocks, hipStream_t st)
 {
-    hipLaunchKernelGGL(call_group_kernel, dim3(max_blocks, 1, n_win), dim3(256), 0, st, d_wins);
+    jl_call_group_args args;
+    memset(&args, 0, sizeof args);
+    memcpy(args.w, h_wins, sizeof(jl_win_call) * (n_win < JL_GROUP_MAX ? n_win : JL_GROUP_MAX));
+    hipLaunchKernelGGL(call_group_kernel, dim3(max_blocks, 1, n_win), dim3(256), 0, st, args);
 }

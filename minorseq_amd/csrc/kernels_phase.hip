@@ -768,9 +768,9 @@ __device__ __forceinline__ void phase_fused1_body(const jl_win_phase &w)
 __global__ __launch_bounds__(256) void phase_fused1_kernel(jl_win_phase w) { phase_fused1_body(w); }
 
 // one launch for several windows: blockIdx.z = window, argument blocks in device memory
-__global__ __launch_bounds__(256) void phase_group_run_kernel(const jl_win_phase *__restrict__ wins)
+__global__ __launch_bounds__(256) void phase_group_run_kernel(jl_phase_group_args args)
 {
-    const jl_win_phase w = wins[blockIdx.z];
+    const jl_win_phase &w = args.w[blockIdx.z];
     if (blockIdx.x >= w.n_blocks) return;
     phase_fused1_body(w);
 }
@@ -823,11 +823,11 @@ __global__ __launch_bounds__(256) void phase_assign_kernel(uint64_t n_reads, con
 
 // the same for the windows of a group launch (blockIdx.z = window) — used when the group is too large for the
 // launch that groups the reads to write the ids itself (its workgroups would have to be resident all at once)
-__global__ __launch_bounds__(256) void phase_assign_group_kernel(const jl_win_phase *__restrict__ wins)
+__global__ __launch_bounds__(256) void phase_assign_group_kernel(jl_phase_group_args args)
 {
     // eight reads per lane: one flag word, two 16-byte loads of slots, one 16-byte store of ids (a wave writes 1 KiB
     // contiguous — the ids usually go to pinned host memory, and PCIe likes long writes)
-    const jl_win_phase w = wins[blockIdx.z];
+    const jl_win_phase &w = args.w[blockIdx.z];
     const uint64_t t = (uint64_t)blockIdx.x * 256u + threadIdx.x;   // dword index within a column = 8 reads
     if (t * 4u >= w.col_stride) return;
     uint16_t h[8];
@@ -931,12 +931,22 @@ void jl_launch_phase(jl_ctx *ctx, uint32_t min_reads, bool planned, bool signal)
                        ctx->d_sync + 3, ctx->d_sync, (signal && ids_to_host) ? ctx->h_seq : nullptr);
 }
 
-void jl_launch_phase_group(const jl_win_phase *d_wins, uint32_t n_win, uint32_t max_blocks, hipStream_t st)
+static void fill_phase_group_args(jl_phase_group_args *args, const jl_win_phase *h_wins, uint32_t n_win)
 {
-    hipLaunchKernelGGL(phase_group_run_kernel, dim3(max_blocks, 1, n_win), dim3(256), 0, st, d_wins);
+    memset(args, 0, sizeof *args);
+    memcpy(args->w, h_wins, sizeof(jl_win_phase) * (n_win < JL_GROUP_MAX ? n_win : JL_GROUP_MAX));
 }
 
-void jl_launch_assign_group(const jl_win_phase *d_wins, uint32_t n_win, uint32_t max_read_blocks, hipStream_t st)
+void jl_launch_phase_group(const jl_win_phase *h_wins, uint32_t n_win, uint32_t max_blocks, hipStream_t st)
 {
-    hipLaunchKernelGGL(phase_assign_group_kernel, dim3(max_read_blocks, 1, n_win), dim3(256), 0, st, d_wins);
+    jl_phase_group_args args;
+    fill_phase_group_args(&args, h_wins, n_win);
+    hipLaunchKernelGGL(phase_group_run_kernel, dim3(max_blocks, 1, n_win), dim3(256), 0, st, args);
+}
+
+void jl_launch_assign_group(const jl_win_phase *h_wins, uint32_t n_win, uint32_t max_read_blocks, hipStream_t st)
+{
+    jl_phase_group_args args;
+    fill_phase_group_args(&args, h_wins, n_win);
+    hipLaunchKernelGGL(phase_assign_group_kernel, dim3(max_read_blocks, 1, n_win), dim3(256), 0, st, args);
 }

@@ -26,6 +26,7 @@
 // reuse between blocks (halo columns aside), so the block -> XCD mapping does not matter here.
 // pileup_group_kernel runs the same body for several windows in one launch (blockIdx.z = window).
 #include <stdlib.h>
+#include <string.h>
 
 #include "jl_internal.h"
 
@@ -352,9 +353,9 @@ __global__ __launch_bounds__(256) void pileup_kernel(const uint8_t *__restrict__
 // 150 MB window is too short to hide a launch's ramp and drain, four of them in one grid run at the rate of a
 // 600 MB stream.  Every window is counted by one block per chunk (gridDim.y = 1: plain stores, no zeroing pass).
 template <int W, bool PIPE, int MODE>
-__global__ __launch_bounds__(256) void pileup_group_kernel(const jl_win_pileup *__restrict__ wins)
+__global__ __launch_bounds__(256) void pileup_group_kernel(jl_pileup_group_args args)
 {
-    const jl_win_pileup w = wins[blockIdx.z];
+    const jl_win_pileup &w = args.w[blockIdx.z];
     if (blockIdx.x >= w.n_chunks) return;
     // the pointers come out of memory: say that they are global ones, or the loads become flat loads (JL_AS1)
     pileup_body<W, PIPE, MODE>((const uint8_t JL_AS1 *)w.msa, w.col_stride, w.n_cols, w.n_tiles, (const uint2 JL_AS1 *)w.chunks,
@@ -397,7 +398,7 @@ struct variant_t {
     bool pipe;
     int mode;  // bit 0: loads only (probe), bit 1: popcount measurements (probe), bit 2: non-temporal loads, bit 3: no stream (probe)
     void (*fn)(const uint8_t *, uint64_t, uint32_t, uint32_t, const uint2 *, const uint32_t *, uint32_t *, uint32_t *);
-    void (*gfn)(const jl_win_pileup *);
+    void (*gfn)(jl_pileup_group_args);
 };
 
 // Default builds use non-temporal loads: every cell is read once, and at 2.4 GB they lift the stream from 5.6 to
@@ -510,11 +511,15 @@ void jl_fill_win_pileup(jl_ctx *ctx, jl_win_pileup *w)
 
 // Every window of a group must use the same kernel variant; each is counted by ONE block per chunk whatever its
 // depth (a single run would split very long columns over several blocks).
-int jl_launch_pileup_group(jl_ctx *const *ctxs, uint32_t n_win, const jl_win_pileup *d_wins, uint32_t max_chunks, hipStream_t st)
+int jl_launch_pileup_group(jl_ctx *const *ctxs, uint32_t n_win, const jl_win_pileup *h_wins, uint32_t max_chunks, hipStream_t st)
 {
     const int idx = pick_variant(ctxs[0]);
+    if (n_win > JL_GROUP_MAX) return JL_ERR_ARG;
     for (uint32_t k = 0; k < n_win; ++k)
         if (pick_variant(ctxs[k]) != idx) return JL_ERR_ARG;
-    hipLaunchKernelGGL(kVariants[idx].gfn, dim3(max_chunks, 1, n_win), dim3(256), 0, st, d_wins);
+    jl_pileup_group_args args;
+    memset(&args, 0, sizeof args);
+    memcpy(args.w, h_wins, sizeof(jl_win_pileup) * n_win);
+    hipLaunchKernelGGL(kVariants[idx].gfn, dim3(max_chunks, 1, n_win), dim3(256), 0, st, args);
     return JL_OK;
 }
