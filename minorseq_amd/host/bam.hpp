@@ -54,7 +54,8 @@ public:
     const std::string &header_text() const { return text_; }
     const std::vector<BamRef> &refs() const { return refs_; }
 
-    bool next(BamRecord &r)
+    // unpack_seq = false leaves r.seq empty (callers that hand BAM's packed bases to the device need only seq4)
+    bool next(BamRecord &r, bool unpack_seq = true)
     {
         int32_t block = 0;
         if (!in_.read(&block, 4)) return false;
@@ -77,11 +78,12 @@ public:
         memcpy(r.cigar.data(), p + o, (size_t)n_cigar * 4);
         o += (size_t)n_cigar * 4;
         static const uint8_t nt16[16] = {4, 0, 1, 4, 2, 4, 4, 4, 3, 4, 4, 4, 4, 4, 4, 4};  // =ACMGRSVTWYHKDBN
-        r.seq.resize(l_seq);
-        for (uint32_t i = 0; i < l_seq; ++i) {
-            const uint8_t b = p[o + i / 2];
-            r.seq[i] = nt16[(i & 1) ? (b & 15) : (b >> 4)];
-        }
+        r.seq.resize(unpack_seq ? l_seq : 0);
+        if (unpack_seq)
+            for (uint32_t i = 0; i < l_seq; ++i) {
+                const uint8_t b = p[o + i / 2];
+                r.seq[i] = nt16[(i & 1) ? (b & 15) : (b >> 4)];
+            }
         r.seq4.assign(p + o, p + o + (l_seq + 1) / 2);
         o += (l_seq + 1) / 2;
         r.qual.assign(p + o, p + o + l_seq);

@@ -8,6 +8,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <future>
 #include <stdexcept>
 #include <string>
 #include <thread>
@@ -37,6 +38,7 @@ public:
     }
     ~BgzfReader()
     {
+        if (ahead_.valid()) { try { ahead_.get(); } catch (...) {} }   // the background task uses f_
         if (!block_mode_) inflateEnd(&z_);
         if (f_) fclose(f_);
     }
@@ -49,12 +51,18 @@ private:
         return h[0] == 0x1f && h[1] == 0x8b && h[2] == 8 && (h[3] & 4) && h[10] == 6 && h[11] == 0 && h[12] == 'B' && h[13] == 'C';
     }
 
-    // ---- block mode: read a batch of raw blocks, inflate them on n_threads_ threads, serve in order
-    bool refill()
+    // ---- block mode: read a batch of raw blocks, inflate them on n_threads_ threads, serve in order; the NEXT batch is
+    // read and inflated by a background task while the caller consumes the current one
+    struct Batch {
+        std::vector<uint8_t> comp, out;
+        bool any = false;
+    };
+    void load_batch(Batch &b)
     {
         struct Blk { size_t in_off, in_len, out_off; uint32_t isize; };
         std::vector<Blk> blks;
-        comp_.clear();
+        b.comp.clear();
+        b.any = false;
         size_t out_total = 0;
         const size_t kBatch = 256;
         while (blks.size() < kBatch) {
@@ -65,18 +73,18 @@ private:
             const size_t bsize = (size_t)hdr[16] + ((size_t)hdr[17] << 8) + 1;  // whole block
             if (bsize < 26) throw std::runtime_error("corrupt BGZF block size");
             const size_t body = bsize - 18;  // deflate data + crc32 + isize
-            const size_t off = comp_.size();
-            comp_.resize(off + body);
-            if (fread(comp_.data() + off, 1, body, f_) != body) throw std::runtime_error("truncated BGZF block");
+            const size_t off = b.comp.size();
+            b.comp.resize(off + body);
+            if (fread(b.comp.data() + off, 1, body, f_) != body) throw std::runtime_error("truncated BGZF block");
             uint32_t isize;
-            memcpy(&isize, comp_.data() + off + body - 4, 4);
+            memcpy(&isize, b.comp.data() + off + body - 4, 4);
             if (isize > (1u << 16)) throw std::runtime_error("BGZF block larger than 64 KiB");
             blks.push_back({off, body - 8, out_total, isize});
             out_total += isize;
         }
-        if (blks.empty()) return false;
-        out_.resize(out_total);
-        out_pos_ = 0;
+        if (blks.empty()) return;
+        b.any = true;
+        b.out.resize(out_total);
         std::atomic<size_t> next{0};
         std::atomic<bool> bad{false};
         auto work = [&]() {
@@ -84,14 +92,14 @@ private:
             for (;;) {
                 const size_t i = next.fetch_add(1);
                 if (i >= blks.size()) return;
-                const Blk &b = blks[i];
-                if (b.isize == 0) continue;
+                const Blk &k = blks[i];
+                if (k.isize == 0) continue;
                 memset(&z, 0, sizeof z);
                 if (inflateInit2(&z, -15) != Z_OK) { bad = true; return; }
-                z.next_in = comp_.data() + b.in_off;
-                z.avail_in = (uInt)b.in_len;
-                z.next_out = out_.data() + b.out_off;
-                z.avail_out = b.isize;
+                z.next_in = b.comp.data() + k.in_off;
+                z.avail_in = (uInt)k.in_len;
+                z.next_out = b.out.data() + k.out_off;
+                z.avail_out = k.isize;
                 const int rc = inflate(&z, Z_FINISH);
                 inflateEnd(&z);
                 if (rc != Z_STREAM_END || z.avail_out != 0) { bad = true; return; }
@@ -105,6 +113,20 @@ private:
             for (auto &t : th) t.join();
         }
         if (bad) throw std::runtime_error("BGZF block failed to inflate");
+    }
+    bool refill()
+    {
+        if (!ahead_.valid()) {   // first call: nothing in flight yet
+            load_batch(batch_[cur_]);
+        } else {
+            ahead_.get();        // rethrows what the background task threw
+            cur_ ^= 1;
+        }
+        if (!batch_[cur_].any) return false;
+        out_.swap(batch_[cur_].out);
+        out_pos_ = 0;
+        Batch *nxt = &batch_[cur_ ^ 1];
+        ahead_ = std::async(std::launch::async, [this, nxt]() { load_batch(*nxt); });
         return true;
     }
     bool read_blocks(void *dst, size_t n)
@@ -159,8 +181,11 @@ private:
     FILE *f_;
     bool block_mode_ = false;
     unsigned n_threads_ = 1;
-    std::vector<uint8_t> comp_, out_;
+    std::vector<uint8_t> out_;
     size_t out_pos_ = 0;
+    Batch batch_[2];
+    int cur_ = 0;
+    std::future<void> ahead_;
     z_stream z_;
     std::vector<uint8_t> in_;
     bool eof_ = false;

@@ -6,6 +6,7 @@
 // leaves open is an explicit flag with the docs/SPEC.md default.  All compute happens on the GPU through
 // the C ABI; without a gfx950 device the tool exits with status 3.
 #include <chrono>
+#include <future>
 #include <cstdlib>
 #include <ctime>
 #include <fstream>
@@ -35,6 +36,7 @@ struct Options {
     double min_rq = 0.0;
     int device = 0;
     std::string dump_msa, dump_config, consensus;
+    bool timing = false;
 };
 
 [[noreturn]] void usage(int code)
@@ -52,6 +54,7 @@ struct Options {
         "      --match-rate <r> --substitution-rate <r> --expected-round ceil|floor|nearest\n"
         "      --min-reads 10  --min-qv 0  --min-rq 0  --device 0\n"
         "      --consensus <out.fasta>         also write the window's majority consensus (fuse-style, no insertions)\n"
+        "      --timing                        wall time of each stage on stderr\n"
         "  diagnostics (no GPU needed): --dump-msa <file>  --dump-config <file>\n";
     std::exit(code);
 }
@@ -97,6 +100,7 @@ Options parse(int argc, char **argv)
         else if (a == "--consensus") o.consensus = need(i);
         else if (a == "--dump-msa") o.dump_msa = need(i);
         else if (a == "--dump-config") o.dump_config = need(i);
+        else if (a == "--timing") o.timing = true;
         else if (!a.empty() && a[0] == '-') { std::cerr << "juliet: unknown option " << a << "\n"; usage(1); }
         else pos.push_back(a);
     }
@@ -201,6 +205,16 @@ int main(int argc, char **argv)
     for (int i = 0; i < argc; ++i) cmdline += (i ? " " : "") + std::string(argv[i]);
     try {
         opt = parse(argc, argv);
+        const auto t_start = std::chrono::steady_clock::now();
+        auto t_last = t_start;
+        auto tick = [&](const char *what) {
+            if (!opt.timing) return;
+            const auto now = std::chrono::steady_clock::now();
+            fprintf(stderr, "juliet: timing %-26s %9.1f ms  (at %9.1f ms)\n", what,
+                    std::chrono::duration<double, std::milli>(now - t_last).count(),
+                    std::chrono::duration<double, std::milli>(now - t_start).count());
+            t_last = now;
+        };
         // ---------------------------------------------------------------- target config
         TargetConfig cfg;
         if (!opt.config.empty()) cfg = TargetConfig::load(opt.config);
@@ -220,15 +234,25 @@ int main(int argc, char **argv)
         IngestOptions io;
         io.min_qv = opt.min_qv;
         io.min_rq = opt.min_rq;
-        const ReadExtent ext = scan_extent(opt.bam, io);
-        if (ext.n_reads == 0) { std::cerr << "juliet: no primary or supplementary alignments in " << opt.bam << "\n"; return 2; }
+        // the GPU context comes up (runtime start, stream, pinned blocks) while the host reads the BAM
+        const bool need_gpu = !opt.outputs.empty();
+        std::future<std::pair<int, jl_ctx *>> ctx_up;
+        if (need_gpu)
+            ctx_up = std::async(std::launch::async, [dev = opt.device]() {
+                jl_ctx *c = nullptr;
+                const int rc = jl_ctx_create(dev, nullptr, &c);
+                return std::make_pair(rc, c);
+            });
+        // ONE pass over the file: records as decoded from BAM (cigar expansion, QV masking and the transpose run on
+        // the device) and the extent they cover
+        RecordArrays rec;
+        std::vector<BamRef> bam_refs;
         std::string header_text;
+        const ReadExtent ext = collect_records(opt.bam, io, io.ref_id, opt.min_qv > 0, rec, &bam_refs, &header_text);
+        tick("bam decode");
+        if (ext.n_reads == 0) { std::cerr << "juliet: no primary or supplementary alignments in " << opt.bam << "\n"; return 2; }
         int64_t ref_len = std::numeric_limits<int64_t>::max();
-        {
-            BamReader hdr(opt.bam);
-            header_text = hdr.header_text();
-            if (ext.ref_id >= 0 && (size_t)ext.ref_id < hdr.refs().size()) ref_len = hdr.refs()[(size_t)ext.ref_id].length;
-        }
+        if (ext.ref_id >= 0 && (size_t)ext.ref_id < bam_refs.size()) ref_len = bam_refs[(size_t)ext.ref_id].length;
 
         const bool have_cfg = !cfg.genes.empty();
         if (!have_cfg) {
@@ -261,9 +285,6 @@ int main(int argc, char **argv)
             f.write((const char *)rows.data(), (std::streamsize)((size_t)n_reads * n_cols));
             if (opt.outputs.empty()) return 0;
         }
-        // records as decoded from BAM; cigar expansion, QV masking and the transpose run on the device
-        RecordArrays rec;
-        collect_records(opt.bam, io, ext.ref_id, opt.min_qv > 0, rec);
         n_reads = rec.pos.size();
         names.swap(rec.names);
 
@@ -294,13 +315,16 @@ int main(int argc, char **argv)
             for (char ch : cfg.reference_sequence) refcodes.push_back(base_code(ch));
 
         // ---------------------------------------------------------------- device
-        jl_ctx *ctx = nullptr;
-        if (jl_ctx_create(opt.device, nullptr, &ctx) != JL_OK) die_jl(nullptr, "no usable GPU (this tool has no CPU fallback)");
+        const auto up = ctx_up.get();
+        jl_ctx *ctx = up.second;
+        if (up.first != JL_OK) die_jl(nullptr, "no usable GPU (this tool has no CPU fallback)");
+        tick("context ready");
         if (jl_msa_ingest_records(ctx, n_reads, n_cols, win_begin, rec.pos.data(), rec.cigar.data(), rec.cig_off.data(),
                                   rec.seq4.data(), rec.seq_off.data(), opt.min_qv ? rec.qual.data() : nullptr,
                                   opt.min_qv ? rec.qual_off.data() : nullptr, opt.min_qv) != JL_OK)
             die_jl(ctx, "ingest");
         rec = RecordArrays();
+        tick("upload + device ingest");
 
         // --drm-only needs the position list, which the plan of a first pileup provides
         std::vector<uint64_t> drm_masks;
@@ -354,6 +378,7 @@ int main(int argc, char **argv)
             if (jl_phase_fetch(ctx, &ps, pos_cols.data(), hap_count.data(), hap_pattern.data(), hit.data(), read_hap.data(), nullptr, cap_var) != JL_OK)
                 die_jl(ctx, "phase fetch");
         }
+        tick("call + phase + fetch");
         jl_ctx_destroy(ctx);
 
         // ---------------------------------------------------------------- JSON (doc/JULIET.md:61-107, 207-211)
@@ -505,6 +530,7 @@ int main(int argc, char **argv)
             if (out.substr(out.size() - 5) == ".json") f << text;
             else f << render_html(root, text);
         }
+        tick("json / html");
         return 0;
     } catch (const std::exception &e) {
         std::cerr << "juliet: " << e.what() << "\n";

@@ -17,7 +17,7 @@ struct IngestOptions {
 // lowest phred over QUAL and whichever rich-QV tracks the record carries, per base (0xFF = nothing known)
 inline void effective_quals(const BamRecord &r, std::vector<uint8_t> &out)
 {
-    out.assign(r.seq.size(), 0xFF);
+    out.assign(r.qual.size(), 0xFF);   // QUAL always holds l_seq entries (0xFF = absent)
     for (size_t i = 0; i < out.size(); ++i) {
         uint8_t q = i < r.qual.size() ? r.qual[i] : 0xFF;
         for (const std::string *t : {&r.dq, &r.iq, &r.sq})
@@ -126,29 +126,42 @@ struct RecordArrays {
     std::vector<std::string> names;
 };
 
-inline void collect_records(const std::string &bam, const IngestOptions &opt, int ref_id, bool want_qual, RecordArrays &out)
+// One pass over the file: every kept record of reference `ref_id` (-1: the reference of the first kept record), plus
+// the extent those records cover.  `refs` / `header_text` receive the BAM header when given.
+inline ReadExtent collect_records(const std::string &bam, const IngestOptions &opt, int ref_id, bool want_qual, RecordArrays &out,
+                                  std::vector<BamRef> *refs = nullptr, std::string *header_text = nullptr)
 {
     BamReader in(bam);
+    if (refs) *refs = in.refs();
+    if (header_text) *header_text = in.header_text();
     BamRecord r;
-    while (in.next(r)) {
-        if (!keep_record(r) || r.ref_id != ref_id) continue;
+    ReadExtent e;
+    e.ref_id = ref_id;
+    std::vector<uint8_t> eq;
+    while (in.next(r, /*unpack_seq=*/false)) {
+        if (!keep_record(r)) continue;
         if (opt.min_rq > 0.0 && r.rq >= 0.f && r.rq < opt.min_rq) continue;
+        if (e.ref_id < 0) e.ref_id = r.ref_id;
+        if (r.ref_id != e.ref_id) continue;
         for (uint32_t c : r.cigar)
             if ((c & 15) == CIG_M)
                 throw std::runtime_error("read " + r.name + ": cigar M is forbidden in PacBio-compliant BAM (doc/JULIET.md:53)");
+        ++e.n_reads;
+        e.min_pos = std::min<int64_t>(e.min_pos, r.pos);
+        e.max_end = std::max<int64_t>(e.max_end, (int64_t)r.pos + ref_span(r));
         out.pos.push_back(r.pos);
         out.cigar.insert(out.cigar.end(), r.cigar.begin(), r.cigar.end());
         out.cig_off.push_back(out.cigar.size());
         out.seq4.insert(out.seq4.end(), r.seq4.begin(), r.seq4.end());
         out.seq_off.push_back(out.seq4.size());
         if (want_qual) {
-            std::vector<uint8_t> eq;
             effective_quals(r, eq);
             out.qual.insert(out.qual.end(), eq.begin(), eq.end());
             out.qual_off.push_back(out.qual.size());
         }
         out.names.push_back(r.name);
     }
+    return e;
 }
 
 }  // namespace jlhost

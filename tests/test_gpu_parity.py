@@ -531,6 +531,18 @@ def test_group_run_equals_single_runs_and_oracle(jl, oracle, fold, monkeypatch):
         j.close()
 
 
+def test_group_of_more_than_eight_windows_is_refused():
+    """The per-window argument blocks travel by value in the kernel arguments: a group holds at most 8 windows."""
+    ctxs = [capi.Juliet(0) for _ in range(9)]
+    try:
+        with pytest.raises(capi.JulietError):
+            capi.Group(ctxs)
+        capi.Group(ctxs[:8]).close()
+    finally:
+        for j in ctxs:
+            j.close()
+
+
 def test_group_run_window_with_many_positions_falls_back(jl, oracle):
     """A window of a group with more than 10 variant positions: the grouped launch flags it (no view), its fetch calls
     re-run the multi-word pipeline and return the oracle's answer; the other window of the same launch is unaffected;
