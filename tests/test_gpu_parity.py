@@ -531,6 +531,49 @@ def test_group_run_equals_single_runs_and_oracle(jl, oracle, fold, monkeypatch):
         j.close()
 
 
+def test_bench_configuration_group_of_eight_full_size_windows(oracle):
+    """What bench.py times: ONE jl_group_run_async over 8 resident windows of 100k reads x 3 kb (BASELINE.json
+    configs[2]), per-read ids from their own launch.  Every window against the oracle on the very same reads, twice
+    (the second launch replays the captured graph), plus the size-independent properties."""
+    n, l, g = 100_000, 3000, 8
+    genes = np.array([(1, l + 1)], dtype=capi.GENE)
+    ref = synth.reference(2, l)
+    ctxs = []
+    for k in range(g):
+        j = capi.Juliet(0)
+        j.alloc(n, l)
+        j.synth_fill(synth.SynthParams(seed=2 + 1000 * k), ref)
+        j.sync()
+        ctxs.append(j)
+    grp = capi.Group(ctxs)
+    prm = capi.default_params()
+    try:
+        grp.run_async(genes, ref, prm, True, 10, True)
+        first = []
+        for j in ctxs:
+            v = j.run_view()
+            assert v is not None
+            first.append((v["variants"].copy(), {k: (x.copy() if hasattr(x, "copy") else x) for k, x in v["phase"].items()}))
+        grp.run_async(genes, ref, prm, True, 10, True)
+        for k, j in enumerate(ctxs):
+            v = j.run_view()
+            rows = msa.unpack_columns(j.download_columns(), n)
+            exp_v = oracle.call(rows, genes, refseq=ref)
+            exp_p = oracle.phase(rows, exp_v)
+            for got_v, got_p in ((v["variants"], v["phase"]), first[k]):
+                assert_variants_equal(got_v, exp_v)
+                assert_phase_equal(got_p, exp_p, len(exp_v))
+            sm = v["phase"]["summary"]
+            assert sm["reported_reads"] + sm["insufficient_reads"] + sm["damaged_reads"] == n
+            assert int(v["phase"]["hap_count"].sum()) == sm["reported_reads"]
+            assert len(exp_v) == 5 and sm["n_haplotypes"] >= 5   # a sixth: an error pattern seen in >= 10 reads
+            del rows
+    finally:
+        grp.close()
+        for j in ctxs:
+            j.close()
+
+
 def test_group_of_more_than_eight_windows_is_refused():
     """The per-window argument blocks travel by value in the kernel arguments: a group holds at most 8 windows."""
     ctxs = [capi.Juliet(0) for _ in range(9)]
