@@ -264,33 +264,33 @@ int jl_msa_ingest_records(jl_ctx *ctx, uint64_t n_reads, uint32_t n_cols, uint32
     if (rc) return rc;
     const size_t n_cig = (size_t)cig_off[n_reads], n_seq = (size_t)seq_off[n_reads], n_q = qual ? (size_t)qual_off[n_reads] : 0;
     const size_t off_bytes = (size_t)(n_reads + 1) * 8;
-    uint8_t *d_rows = nullptr, *d_seq = nullptr, *d_qual = nullptr;
+    uint8_t *d_seq = nullptr, *d_qual = nullptr;
     uint32_t *d_cig = nullptr;
     uint64_t *d_co = nullptr, *d_so = nullptr, *d_qo = nullptr;
     int32_t *d_pos = nullptr;
     hipStream_t st = ctx->stream;
-    hipError_t e = hipMalloc(&d_rows, (size_t)n_reads * n_cols);
-    if (e == hipSuccess) e = hipMalloc(&d_seq, n_seq ? n_seq : 1);
+    // the kernel reads the bases a dword at a time and one dword ahead: 16 bytes of padding behind them
+    hipError_t e = hipMalloc(&d_seq, n_seq + 16);
     if (e == hipSuccess) e = hipMalloc(&d_cig, (n_cig ? n_cig : 1) * 4);
     if (e == hipSuccess) e = hipMalloc(&d_co, off_bytes);
     if (e == hipSuccess) e = hipMalloc(&d_so, off_bytes);
-    if (e == hipSuccess) e = hipMalloc(&d_pos, (size_t)n_reads * 4);
+    if (e == hipSuccess) e = hipMalloc(&d_pos, (size_t)(n_reads ? n_reads : 1) * 4);
     if (e == hipSuccess && qual) e = hipMalloc(&d_qual, n_q ? n_q : 1);
     if (e == hipSuccess && qual) e = hipMalloc(&d_qo, off_bytes);
-    if (e == hipSuccess) e = hipMemsetAsync(d_rows, JL_SYM_NONE, (size_t)n_reads * n_cols, st);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_seq, seq4, n_seq, hipMemcpyHostToDevice, st);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_cig, cigar, n_cig * 4, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemsetAsync(d_seq + n_seq, 0, 16, st);
+    if (e == hipSuccess && n_seq) e = hipMemcpyAsync(d_seq, seq4, n_seq, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess && n_cig) e = hipMemcpyAsync(d_cig, cigar, n_cig * 4, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipMemcpyAsync(d_co, cig_off, off_bytes, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipMemcpyAsync(d_so, seq_off, off_bytes, hipMemcpyHostToDevice, st);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_pos, pos, (size_t)n_reads * 4, hipMemcpyHostToDevice, st);
-    if (e == hipSuccess && qual) e = hipMemcpyAsync(d_qual, qual, n_q, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess && n_reads) e = hipMemcpyAsync(d_pos, pos, (size_t)n_reads * 4, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess && qual && n_q) e = hipMemcpyAsync(d_qual, qual, n_q, hipMemcpyHostToDevice, st);
     if (e == hipSuccess && qual) e = hipMemcpyAsync(d_qo, qual_off, off_bytes, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) {
-        jl_launch_ingest(ctx, d_pos, d_cig, d_co, d_seq, d_so, d_qual, d_qo, min_qv, d_rows);
-        jl_launch_pack_rows(ctx, d_rows);
-        e = hipStreamSynchronize(st);
+        jl_launch_ingest(ctx, d_pos, d_cig, d_co, d_seq, d_so, d_qual, d_qo, min_qv);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
     }
-    void *tmp[] = {d_rows, d_seq, d_cig, d_co, d_so, d_pos, d_qual, d_qo};
+    void *tmp[] = {d_seq, d_cig, d_co, d_so, d_pos, d_qual, d_qo};
     for (void *p : tmp)
         if (p) hipFree(p);
     if (e != hipSuccess) return jl_fail(ctx, e == hipErrorOutOfMemory ? JL_ERR_MEMORY : JL_ERR_DEVICE, "ingest: %s", hipGetErrorString(e));

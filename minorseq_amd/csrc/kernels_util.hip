@@ -1,6 +1,7 @@
 // kernels_util.hip — device-side producers of the resident column-packed matrix:
 //   synth_kernel      synthetic aligned CCS reads (jl_synth.h), one dword (8 reads) of one column per step
-//   pack_rows_kernel  by-row uint8 codes -> column-packed nibbles (the first step of SURVEY §8 f1)
+//   pack_rows_kernel  by-row uint8 codes -> column-packed nibbles (jl_msa_pack_rows)
+//   ingest_cols_kernel  aligned BAM records -> column-packed nibbles
 #include <algorithm>
 
 #include "jl_internal.h"
@@ -53,87 +54,135 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(const uint8_t *__restric
 
 
 // ---------------------------------------------------------------------------------------- record ingest
-// Aligned records -> by-row symbols, one wave per read: doc/JULIET.md:26-27 (insertions dropped, deletions '-'),
+// Aligned records -> column-packed nibbles in ONE pass: doc/JULIET.md:26-27 (insertions dropped, deletions '-'),
 // :53 (PacBio cigars = X I D S H N; M rejected on the host), :256-259 (filtered base = N).
-// Lanes walk REFERENCE positions; the operation covering a position is found by binary search in the read's
-// scanned cigar (reference and query offsets per op, kept in LDS).
-constexpr int kIngestMaxOps = 1024;  // ops staged per pass; longer cigars are processed in several passes
+// One LANE per read: the lane walks its own cigar while the wave walks the columns of a segment of the window, so at
+// every column the wave holds the 64 symbols of 64 consecutive reads — the 32 bytes that are contiguous in the
+// column-packed matrix.  Four columns are gathered per lane into one dword, eight such dwords are transposed through a
+// 2 KiB LDS tile per wave, and every lane then stores the packed nibbles of 8 reads for 4 columns.  The next cigar word
+// and the next eight bases of every lane are loaded ahead of their use.  (Loading a tile's worth of cigar words and
+// bases per lane up front was measured and is slower: the kernel is bound by the instructions of the per-lane cursor
+// under divergence — some lane of 64 changes its op at nearly every column — not by load latency.)  Reads past n_reads (the padding of a column up
+// to its 128-byte stride) and columns outside a read's span are 'not covered'.
+constexpr uint32_t kIngestSegAlign = 32;   // columns per transposed tile
 
-__global__ __launch_bounds__(256) void ingest_kernel(uint64_t n_reads, uint32_t n_cols, uint32_t win_begin,
-                                                      const int32_t *__restrict__ pos,
-                                                      const uint32_t *__restrict__ cigar,
-                                                      const uint64_t *__restrict__ cig_off,
-                                                      const uint8_t *__restrict__ seq4,
-                                                      const uint64_t *__restrict__ seq_off,
-                                                      const uint8_t *__restrict__ qual,
-                                                      const uint64_t *__restrict__ qual_off, uint32_t min_qv,
-                                                      uint8_t *__restrict__ rows)
+__device__ __forceinline__ bool cig_ref(uint32_t op) { return op == 2u || op == 3u || op == 7u || op == 8u; }    // D N = X
+__device__ __forceinline__ bool cig_query(uint32_t op) { return op == 1u || op == 4u || op == 7u || op == 8u; }  // I S = X
+
+__global__ __launch_bounds__(256) void ingest_cols_kernel(uint64_t n_reads, uint32_t n_cols, uint32_t win_begin, uint32_t seg_cols,
+                                                           const int32_t *__restrict__ pos,
+                                                           const uint32_t *__restrict__ cigar,
+                                                           const uint64_t *__restrict__ cig_off,
+                                                           const uint8_t *__restrict__ seq4,
+                                                           const uint64_t *__restrict__ seq_off,
+                                                           const uint8_t *__restrict__ qual,
+                                                           const uint64_t *__restrict__ qual_off, uint32_t min_qv,
+                                                           uint8_t *__restrict__ msa, uint64_t col_stride)
 {
-    __shared__ uint32_t s_rend[4][kIngestMaxOps];  // reference offset AFTER op k (relative to the pass start)
-    __shared__ uint32_t s_qbeg[4][kIngestMaxOps];  // query offset BEFORE op k
-    __shared__ uint8_t s_op[4][kIngestMaxOps];
+    __shared__ uint32_t s_t[4][8][64];   // per wave: 8 groups of 4 columns x 64 reads
     const uint32_t wid = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    const uint64_t r = (uint64_t)blockIdx.x * 4u + wid;
-    if (r >= n_reads) return;
-    const uint64_t c0 = cig_off[r], c1 = cig_off[r + 1];
-    const uint8_t *sq = seq4 + seq_off[r];
-    const uint8_t *ql = qual ? qual + qual_off[r] : nullptr;
-    uint8_t *row = rows + r * (uint64_t)n_cols;
-    int64_t ref_cur = pos[r];
-    uint32_t q_cur = 0;
-    for (uint64_t base = c0; base < c1; base += kIngestMaxOps) {
-        const uint32_t nops = (uint32_t)min((uint64_t)kIngestMaxOps, c1 - base);
-        // scan the ops of this pass (64 at a time) into LDS
-        uint32_t racc = 0, qacc = q_cur;
-        for (uint32_t k0 = 0; k0 < nops; k0 += 64u) {
-            const uint32_t k = k0 + lane;
-            uint32_t op = 15u, len = 0;
-            if (k < nops) { const uint32_t c = cigar[base + k]; op = c & 15u; len = c >> 4; }
-            const uint32_t rl = (op == 2u || op == 3u || op == 7u || op == 8u) ? len : 0u;   // D N = X consume reference
-            const uint32_t qn = (op == 1u || op == 4u || op == 7u || op == 8u) ? len : 0u;   // I S = X consume query
-            uint32_t ri = rl, qi = qn;
+    const uint64_t wave_r0 = ((uint64_t)blockIdx.x * 4u + wid) * 64u;
+    if (wave_r0 * 4u >= col_stride * 8u) return;   // col_stride * 2 reads per column (wave-uniform)
+    const uint64_t r = wave_r0 + lane;
+    const bool have = r < n_reads;
+    const uint32_t cs = blockIdx.y * seg_cols, ce = min(n_cols, cs + seg_cols);
+
+    uint64_t ci = 0, cend = 0;
+    const uint32_t *sqw = nullptr;
+    uint32_t q_adj = 0, sq_last = 0;
+    const uint8_t *ql = nullptr;
+    int64_t rel = 0;   // reference offset, relative to the read's first base, of column cs
+    if (have) {
+        ci = cig_off[r];
+        cend = cig_off[r + 1];
+        const uint64_t so = seq_off[r];
+        sqw = reinterpret_cast<const uint32_t *>(seq4 + (so & ~(uint64_t)3));
+        q_adj = (uint32_t)(so & 3u) * 2u;
+        sq_last = (uint32_t)((seq_off[r + 1] - (so & ~(uint64_t)3) + 3u) >> 2);   // the arrays are padded by 16 bytes
+        if (qual && min_qv) ql = qual + qual_off[r];
+        rel = (int64_t)win_begin + cs - (int64_t)pos[r];
+    }
+    // cursor: the op covering reference offsets [r_beg, r_end), which starts at query offset q_beg
+    int64_t r_beg = 0, r_end = 0;
+    uint32_t q_beg = 0, q_next = 0, op = 15u;
+    bool done = !have;
+    // ---- skip to the segment: four cigar words per step
+    if (have && rel > 0) {
+        while (ci < cend && r_end <= rel) {
+            uint32_t cw[4];
 #pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const uint32_t a = __shfl_up(ri, o, 64), b = __shfl_up(qi, o, 64);
-                if ((int)lane >= o) { ri += a; qi += b; }
+            for (int k = 0; k < 4; ++k) cw[k] = cigar[min(ci + k, cend - 1)];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (ci < cend && r_end <= rel) {
+                    const uint32_t o = cw[k] & 15u, len = cw[k] >> 4;
+                    op = o; r_beg = r_end; q_beg = q_next;
+                    if (cig_ref(o)) r_end += len;
+                    if (cig_query(o)) q_next += len;
+                    ++ci;
+                }
             }
-            if (k < nops) {
-                s_rend[wid][k] = racc + ri;
-                s_qbeg[wid][k] = qacc + qi - qn;
-                s_op[wid][k] = (uint8_t)op;
+        }
+    }
+    uint32_t cw_next = (have && ci < cend) ? cigar[ci] : 0u;
+    uint32_t seq_idx = 0xFFFFFFFEu, seq_w = 0, seq_wn = 0;   // dword seq_idx of the read's bases, and the one after it
+
+    for (uint32_t c0 = cs; c0 < ce; c0 += kIngestSegAlign) {
+#pragma unroll 1
+        for (uint32_t g = 0; g < 8u; ++g) {
+            uint32_t pk = 0;
+#pragma unroll
+            for (uint32_t j = 0; j < 4u; ++j) {
+                const int64_t x = rel + (int64_t)(c0 - cs + 4u * g + j);
+                uint32_t sym = JL_SYM_NONE;
+                if (!done && x >= 0) {
+                    while (x >= r_end) {   // next op (those that consume no reference leave r_end where it is)
+                        if (ci >= cend) { done = true; break; }
+                        const uint32_t o = cw_next & 15u, len = cw_next >> 4;
+                        ++ci;
+                        if (ci < cend) cw_next = cigar[ci];
+                        op = o; r_beg = r_end; q_beg = q_next;
+                        if (cig_ref(o)) r_end += len;
+                        if (cig_query(o)) q_next += len;
+                    }
+                    if (!done) {
+                        if (op == 2u) sym = JL_SYM_GAP;
+                        else if (op == 3u) sym = JL_SYM_NONE;
+                        else {
+                            const uint32_t q = q_beg + (uint32_t)(x - r_beg);
+                            const uint32_t qa = q + q_adj, idx = qa >> 3;
+                            if (idx != seq_idx) {
+                                if (idx == seq_idx + 1u) seq_w = seq_wn;
+                                else seq_w = sqw[min(idx, sq_last)];
+                                seq_wn = sqw[min(idx + 1u, sq_last)];
+                                seq_idx = idx;
+                            }
+                            // BAM: two bases per byte, the first in the high nibble
+                            const uint32_t b16 = (seq_w >> (8u * ((qa >> 1) & 3u) + ((qa & 1u) ? 0u : 4u))) & 15u;
+                            // A=1 C=2 G=4 T=8 -> 0..3; anything else is an ambiguous base (N)
+                            sym = (uint32_t)((0x5555555355525105ull >> (4u * b16)) & 15ull);
+                            if (ql) { const uint8_t qv = ql[q]; if (qv != 0xFFu && qv < min_qv) sym = JL_SYM_MASK; }
+                        }
+                    }
+                }
+                pk |= sym << (8u * j);
             }
-            racc += __shfl(ri, 63, 64);
-            qacc += __shfl(qi, 63, 64);
+            s_t[wid][g][lane] = pk;
         }
         __builtin_amdgcn_wave_barrier();
-        const uint32_t rtot = racc;
-        // reference positions of this pass, 64 at a time
-        for (uint32_t p0 = 0; p0 < rtot; p0 += 64u) {
-            const uint32_t p = p0 + lane;
-            const int64_t col = ref_cur + p - (int64_t)win_begin;
-            if (p < rtot && col >= 0 && col < (int64_t)n_cols) {
-                uint32_t lo = 0, hi = nops - 1u;  // first op with rend > p
-                while (lo < hi) {
-                    const uint32_t mid = (lo + hi) >> 1;
-                    if (s_rend[wid][mid] > p) hi = mid; else lo = mid + 1u;
-                }
-                const uint32_t op = s_op[wid][lo];
-                const uint32_t rbeg = lo ? s_rend[wid][lo - 1u] : 0u;
-                uint8_t sym;
-                if (op == 2u) sym = JL_SYM_GAP;
-                else if (op == 3u) sym = JL_SYM_NONE;
-                else {
-                    const uint32_t q = s_qbeg[wid][lo] + (p - rbeg);
-                    const uint8_t b16 = (q & 1u) ? (sq[q >> 1] & 15u) : (sq[q >> 1] >> 4);
-                    // BAM nibble codes: A=1 C=2 G=4 T=8; anything else is an ambiguous base
-                    sym = b16 == 1u ? 0 : b16 == 2u ? 1 : b16 == 4u ? 2 : b16 == 8u ? 3 : (uint8_t)JL_SYM_MASK;
-                    if (ql && min_qv) { const uint8_t qv = ql[q]; if (qv != 0xFFu && qv < min_qv) sym = JL_SYM_MASK; }
-                }
-                row[col] = sym;
-            }
+        // transposed: lane = (group of 4 columns, group of 8 reads)
+        const uint32_t tg = lane >> 3, tk = lane & 7u;
+        uint32_t w[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) w[j] = s_t[wid][tg][8u * tk + j];
+#pragma unroll
+        for (uint32_t cc = 0; cc < 4u; ++cc) {
+            const uint32_t c = c0 + 4u * tg + cc;
+            uint32_t o = 0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o |= ((w[j] >> (8u * cc)) & 15u) << (4 * j);
+            if (c < ce) *reinterpret_cast<uint32_t *>(msa + (uint64_t)c * col_stride + wave_r0 / 2u + 4u * tk) = o;
         }
-        ref_cur += rtot;
-        q_cur = qacc;
         __builtin_amdgcn_wave_barrier();
     }
 }
@@ -232,11 +281,19 @@ void jl_launch_validate(jl_ctx *ctx, uint32_t *d_flag)
 
 void jl_launch_ingest(jl_ctx *ctx, const int32_t *d_pos, const uint32_t *d_cigar, const uint64_t *d_cig_off,
                       const uint8_t *d_seq4, const uint64_t *d_seq_off, const uint8_t *d_qual,
-                      const uint64_t *d_qual_off, uint32_t min_qv, uint8_t *d_rows)
+                      const uint64_t *d_qual_off, uint32_t min_qv)
 {
-    const uint32_t blocks = (uint32_t)((ctx->n_reads + 3u) / 4u);
-    hipLaunchKernelGGL(ingest_kernel, dim3(blocks), dim3(256), 0, ctx->stream, ctx->n_reads, ctx->n_cols,
-                       ctx->win_begin, d_pos, d_cigar, d_cig_off, d_seq4, d_seq_off, d_qual, d_qual_off, min_qv, d_rows);
+    // waves = 64-read groups x column segments; enough segments for some thousands of waves
+    const uint64_t waves_x = (ctx->col_stride * 2u + 63u) / 64u;
+    const uint32_t max_seg = (ctx->n_cols + kIngestSegAlign - 1u) / kIngestSegAlign;
+    uint32_t nseg = (uint32_t)std::min<uint64_t>(max_seg, std::max<uint64_t>(1, (8192u + waves_x - 1u) / waves_x));
+    uint32_t seg_cols = (ctx->n_cols + nseg - 1u) / nseg;
+    seg_cols = (seg_cols + kIngestSegAlign - 1u) / kIngestSegAlign * kIngestSegAlign;
+    nseg = (ctx->n_cols + seg_cols - 1u) / seg_cols;
+    dim3 grid((uint32_t)((waves_x + 3u) / 4u), nseg);
+    hipLaunchKernelGGL(ingest_cols_kernel, grid, dim3(256), 0, ctx->stream, ctx->n_reads, ctx->n_cols, ctx->win_begin,
+                       seg_cols, d_pos, d_cigar, d_cig_off, d_seq4, d_seq_off, d_qual, d_qual_off, min_qv, ctx->d_msa,
+                       ctx->col_stride);
 }
 
 void jl_launch_synth(jl_ctx *ctx, const jl_synth_plan *plan, const uint8_t *d_ref)

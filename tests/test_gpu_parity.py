@@ -762,7 +762,8 @@ def rows_to_records(rows, ref, rng, with_noise_ops=True):
             np.array(qual_off, dtype=np.uint64))
 
 
-@pytest.mark.parametrize("n,l,partial,win", [(300, 120, 0.3, (0, 120)), (1000, 400, 0.2, (37, 351)), (70, 3000, 0.1, (0, 3000))])
+@pytest.mark.parametrize("n,l,partial,win", [(300, 120, 0.3, (0, 120)), (1000, 400, 0.2, (37, 351)), (70, 3000, 0.1, (0, 3000)),
+                                              (4000, 500, 0.3, (64, 500))])
 def test_device_ingest_matches_rows(jl, n, l, partial, win):
     rng = np.random.default_rng(n + l)
     sp = synth.SynthParams(seed=n + l, partial_rate=partial, del_rate=0.02, mask_rate=0.03, sub_rate=0.01)
@@ -792,7 +793,7 @@ def test_device_ingest_matches_rows(jl, n, l, partial, win):
 
 
 def test_device_ingest_long_cigar(jl):
-    """A cigar longer than the kernel's staging pass (1024 ops) is processed in several passes."""
+    """One op per base: 5000 ops per read, every lane fetches a cigar word at every column."""
     l = 5000
     rng = np.random.default_rng(1)
     ref = synth.reference(3, l)
