@@ -54,14 +54,64 @@ public:
     const std::string &header_text() const { return text_; }
     const std::vector<BamRef> &refs() const { return refs_; }
 
+    // aux fields from offset o: `rq` (float) and the rich-QV strings dq / iq / sq are interpreted; everything else is
+    // skipped by type
+    static void parse_aux(const uint8_t *p, size_t o, size_t block, BamRecord &r)
+    {
+        r.rq = -1.f;
+        r.dq.clear(); r.iq.clear(); r.sq.clear();
+        while (o + 3 <= block) {
+            const char t0 = (char)p[o], t1 = (char)p[o + 1], ty = (char)p[o + 2];
+            o += 3;
+            size_t len = 0;
+            switch (ty) {
+            case 'A': case 'c': case 'C': len = 1; break;
+            case 's': case 'S': len = 2; break;
+            case 'i': case 'I': case 'f': len = 4; break;
+            case 'Z': case 'H': while (o + len < block && p[o + len]) ++len; ++len; break;
+            case 'B': {
+                const char sub = (char)p[o];
+                uint32_t cnt; memcpy(&cnt, p + o + 1, 4);
+                const size_t es = (sub == 'c' || sub == 'C') ? 1 : (sub == 's' || sub == 'S') ? 2 : 4;
+                len = 5 + es * cnt;
+                break;
+            }
+            default: throw std::runtime_error("unknown BAM aux type");
+            }
+            if (t0 == 'r' && t1 == 'q' && ty == 'f') memcpy(&r.rq, p + o, 4);
+            if (ty == 'Z' && t1 == 'q' && (t0 == 'd' || t0 == 'i' || t0 == 's')) {
+                std::string &dst = t0 == 'd' ? r.dq : t0 == 'i' ? r.iq : r.sq;
+                dst.assign((const char *)p + o, len - 1);
+            }
+            o += len;
+        }
+    }
+
+    // the bytes of the next record (after its block_size word), in place when they lie inside the reader's inflated
+    // batch; valid until the next call
+    bool next_raw(const uint8_t *&p, size_t &len)
+    {
+        int32_t block = 0;
+        if (const uint8_t *q = in_.peek(4)) memcpy(&block, q, 4);
+        else if (!in_.read(&block, 4)) return false;
+        if (block < 32) throw std::runtime_error("corrupt BAM record");
+        len = (size_t)block;
+        p = in_.peek(len);
+        if (!p) {
+            buf_.resize(len);
+            if (!in_.read(buf_.data(), len)) throw std::runtime_error("truncated BAM record");
+            p = buf_.data();
+        }
+        return true;
+    }
+
     // unpack_seq = false leaves r.seq empty (callers that hand BAM's packed bases to the device need only seq4)
     bool next(BamRecord &r, bool unpack_seq = true)
     {
-        int32_t block = 0;
-        if (!in_.read(&block, 4)) return false;
-        buf_.resize((size_t)block);
-        in_.read(buf_.data(), (size_t)block);
-        const uint8_t *p = buf_.data();
+        const uint8_t *p;
+        size_t blen;
+        if (!next_raw(p, blen)) return false;
+        const int32_t block = (int32_t)blen;
         auto u32 = [&](size_t o) { uint32_t v; memcpy(&v, p + o, 4); return v; };
         auto u16 = [&](size_t o) { uint16_t v; memcpy(&v, p + o, 2); return v; };
         r.ref_id = (int32_t)u32(0);
@@ -88,34 +138,7 @@ public:
         o += (l_seq + 1) / 2;
         r.qual.assign(p + o, p + o + l_seq);
         o += l_seq;
-        r.rq = -1.f;
-        r.dq.clear(); r.iq.clear(); r.sq.clear();
-        // aux: `rq` (float) and the rich-QV strings dq / iq / sq are interpreted; everything else is skipped by type
-        while (o + 3 <= (size_t)block) {
-            const char t0 = (char)p[o], t1 = (char)p[o + 1], ty = (char)p[o + 2];
-            o += 3;
-            size_t len = 0;
-            switch (ty) {
-            case 'A': case 'c': case 'C': len = 1; break;
-            case 's': case 'S': len = 2; break;
-            case 'i': case 'I': case 'f': len = 4; break;
-            case 'Z': case 'H': while (o + len < (size_t)block && p[o + len]) ++len; ++len; break;
-            case 'B': {
-                const char sub = (char)p[o];
-                uint32_t cnt; memcpy(&cnt, p + o + 1, 4);
-                const size_t es = (sub == 'c' || sub == 'C') ? 1 : (sub == 's' || sub == 'S') ? 2 : 4;
-                len = 5 + es * cnt;
-                break;
-            }
-            default: throw std::runtime_error("unknown BAM aux type");
-            }
-            if (t0 == 'r' && t1 == 'q' && ty == 'f') memcpy(&r.rq, p + o, 4);
-            if (ty == 'Z' && t1 == 'q' && (t0 == 'd' || t0 == 'i' || t0 == 's')) {
-                std::string &dst = t0 == 'd' ? r.dq : t0 == 'i' ? r.iq : r.sq;
-                dst.assign((const char *)p + o, len - 1);
-            }
-            o += len;
-        }
+        parse_aux(p, o, (size_t)block, r);
         return true;
     }
 

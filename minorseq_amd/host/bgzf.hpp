@@ -7,6 +7,7 @@
 #include <atomic>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <future>
 #include <stdexcept>
@@ -25,7 +26,8 @@ public:
     {
         if (!f_) throw std::runtime_error("cannot open " + path);
         unsigned hw = std::thread::hardware_concurrency();
-        n_threads_ = threads ? threads : std::min(8u, hw ? hw : 1u);
+        n_threads_ = threads ? threads : std::min(16u, hw ? hw : 1u);
+        if (const char *e = getenv("JL_BGZF_THREADS")) { const int v = atoi(e); if (v > 0 && v <= 64) n_threads_ = (unsigned)v; }
         uint8_t hdr[18];
         const size_t got = fread(hdr, 1, sizeof hdr, f_);
         block_mode_ = got == sizeof hdr && is_bgzf_header(hdr);
@@ -44,6 +46,18 @@ public:
     }
     // read exactly n bytes; returns false on clean EOF at a record boundary (n bytes not started)
     bool read(void *dst, size_t n) { return block_mode_ ? read_blocks(dst, n) : read_stream(dst, n); }
+    // the next n bytes in place when they lie inside the inflated batch at hand (valid until the next call), else
+    // nullptr: the caller then copies them with read()
+    const uint8_t *peek(size_t n)
+    {
+        if (!block_mode_) return nullptr;
+        while (out_pos_ == out_.size())
+            if (!refill()) return nullptr;
+        if (out_.size() - out_pos_ < n) return nullptr;
+        const uint8_t *p = out_.data() + out_pos_;
+        out_pos_ += n;
+        return p;
+    }
 
 private:
     static bool is_bgzf_header(const uint8_t *h)

@@ -1,7 +1,11 @@
 // msa_builder.hpp — aligned BAM records -> by-row symbol matrix of one reference window
 // (doc/JULIET.md:50-58 input contract; :26-27 insertions ignored, deletions are '-'; :256-259 filtered base = N).
 #pragma once
+#include <sys/mman.h>
+
+#include <filesystem>
 #include <limits>
+#include <system_error>
 
 #include "bam.hpp"
 
@@ -127,39 +131,86 @@ struct RecordArrays {
 };
 
 // One pass over the file: every kept record of reference `ref_id` (-1: the reference of the first kept record), plus
-// the extent those records cover.  `refs` / `header_text` receive the BAM header when given.
+// the extent those records cover.  `refs` / `header_text` receive the BAM header when given.  Records are parsed in
+// place in the inflated BGZF batch: positions, cigar words and BAM's packed bases are copied once, into the arrays
+// the device ingests; qualities and tags are only looked at when a filter needs them.
 inline ReadExtent collect_records(const std::string &bam, const IngestOptions &opt, int ref_id, bool want_qual, RecordArrays &out,
                                   std::vector<BamRef> *refs = nullptr, std::string *header_text = nullptr)
 {
     BamReader in(bam);
     if (refs) *refs = in.refs();
     if (header_text) *header_text = in.header_text();
-    BamRecord r;
     ReadExtent e;
     e.ref_id = ref_id;
+    {   // address space for the big arrays up front (untouched pages cost nothing): growing by doubling would copy them
+        // and fault every page in again.  CCS BAMs inflate 5-10x; the bases are about a quarter of that
+        std::error_code ec;
+        const uintmax_t fsz = std::filesystem::file_size(bam, ec);
+        if (!ec && fsz > 0) {
+            const size_t cap = (size_t)std::min<uintmax_t>(fsz * 4, (uintmax_t)4 << 30);
+            try {
+                out.seq4.reserve(cap);
+                out.cigar.reserve(cap / 8);
+                if (want_qual) out.qual.reserve(cap * 2);
+                // fewer page faults while the arrays fill (transparent huge pages are opt-in on most hosts)
+                auto huge = [](void *p, size_t bytes) {
+                    const uintptr_t a = ((uintptr_t)p + (2u << 20) - 1) & ~(uintptr_t)((2u << 20) - 1);
+                    const uintptr_t b = ((uintptr_t)p + bytes) & ~(uintptr_t)((2u << 20) - 1);
+                    if (b > a) madvise((void *)a, b - a, MADV_HUGEPAGE);
+                };
+                huge(out.seq4.data(), out.seq4.capacity());
+                huge(out.cigar.data(), out.cigar.capacity() * 4);
+                if (want_qual) huge(out.qual.data(), out.qual.capacity());
+            } catch (const std::bad_alloc &) {}   // doubling takes over
+        }
+    }
+    const bool need_tags = want_qual || opt.min_rq > 0.0;
+    BamRecord r;   // only its tag fields and qualities are used, and only when need_tags
     std::vector<uint8_t> eq;
-    while (in.next(r, /*unpack_seq=*/false)) {
-        if (!keep_record(r)) continue;
-        if (opt.min_rq > 0.0 && r.rq >= 0.f && r.rq < opt.min_rq) continue;
-        if (e.ref_id < 0) e.ref_id = r.ref_id;
-        if (r.ref_id != e.ref_id) continue;
-        for (uint32_t c : r.cigar)
-            if ((c & 15) == CIG_M)
-                throw std::runtime_error("read " + r.name + ": cigar M is forbidden in PacBio-compliant BAM (doc/JULIET.md:53)");
+    const uint8_t *p;
+    size_t len;
+    while (in.next_raw(p, len)) {
+        auto u32 = [&](size_t o) { uint32_t v; memcpy(&v, p + o, 4); return v; };
+        auto u16 = [&](size_t o) { uint16_t v; memcpy(&v, p + o, 2); return v; };
+        const int32_t rid = (int32_t)u32(0), pos = (int32_t)u32(4);
+        const uint32_t l_name = p[8], n_cigar = u16(12), flag = u16(14), l_seq = u32(16);
+        const size_t o_cig = 32 + (size_t)l_name, o_seq = o_cig + (size_t)n_cigar * 4, o_qual = o_seq + (l_seq + 1) / 2,
+                     o_aux = o_qual + l_seq;
+        if (o_aux > len) throw std::runtime_error("corrupt BAM record");
+        // "Reads that are not primary or supplementary alignments, get ignored" (doc/JULIET.md:58)
+        if ((flag & 0x4) || (flag & 0x100) || rid < 0 || pos < 0) continue;
+        if (need_tags) {
+            r.qual.assign(p + o_qual, p + o_aux);
+            BamReader::parse_aux(p, o_aux, len, r);
+            if (opt.min_rq > 0.0 && r.rq >= 0.f && r.rq < opt.min_rq) continue;
+        }
+        if (e.ref_id < 0) e.ref_id = rid;
+        if (rid != e.ref_id) continue;
+        const size_t c_at = out.cigar.size();
+        out.cigar.resize(c_at + n_cigar);
+        memcpy(out.cigar.data() + c_at, p + o_cig, (size_t)n_cigar * 4);
+        uint32_t span = 0;
+        for (size_t k = c_at; k < out.cigar.size(); ++k) {
+            const uint32_t op = out.cigar[k] & 15;
+            if (op == CIG_M) {
+                const std::string name((const char *)p + 32, l_name ? l_name - 1 : 0);
+                throw std::runtime_error("read " + name + ": cigar M is forbidden in PacBio-compliant BAM (doc/JULIET.md:53)");
+            }
+            if (op == CIG_D || op == CIG_N || op == CIG_EQ || op == CIG_X) span += out.cigar[k] >> 4;
+        }
         ++e.n_reads;
-        e.min_pos = std::min<int64_t>(e.min_pos, r.pos);
-        e.max_end = std::max<int64_t>(e.max_end, (int64_t)r.pos + ref_span(r));
-        out.pos.push_back(r.pos);
-        out.cigar.insert(out.cigar.end(), r.cigar.begin(), r.cigar.end());
+        e.min_pos = std::min<int64_t>(e.min_pos, pos);
+        e.max_end = std::max<int64_t>(e.max_end, (int64_t)pos + span);
+        out.pos.push_back(pos);
         out.cig_off.push_back(out.cigar.size());
-        out.seq4.insert(out.seq4.end(), r.seq4.begin(), r.seq4.end());
+        out.seq4.insert(out.seq4.end(), p + o_seq, p + o_qual);
         out.seq_off.push_back(out.seq4.size());
         if (want_qual) {
             effective_quals(r, eq);
             out.qual.insert(out.qual.end(), eq.begin(), eq.end());
             out.qual_off.push_back(out.qual.size());
         }
-        out.names.push_back(r.name);
+        out.names.emplace_back((const char *)p + 32, l_name ? l_name - 1 : 0);
     }
     return e;
 }
