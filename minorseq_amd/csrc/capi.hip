@@ -854,11 +854,15 @@ int jl_run_async(jl_ctx *ctx, const jl_gene *genes, uint32_t n_genes, const uint
 
     if (graphs_on) {
         const bool hit = ctx->graph_exec && ctx->graph_sig.size() == sizeof sig && memcmp(ctx->graph_sig.data(), &sig, sizeof sig) == 0;
+        // A configuration is captured the SECOND time it is run: capture + instantiation cost about 20 ms, which a
+        // one-shot caller (the juliet front end: one run per process) would pay for nothing.
+        const bool seen = ctx->graph_seen.size() == sizeof sig && memcmp(ctx->graph_seen.data(), &sig, sizeof sig) == 0;
         if (!hit) {
             if (ctx->graph_exec) { hipGraphExecDestroy(ctx->graph_exec); ctx->graph_exec = nullptr; }
             if (ctx->graph) { hipGraphDestroy(ctx->graph); ctx->graph = nullptr; }
             ctx->graph_sig.clear();
-            if (hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+            if (!seen) ctx->graph_seen.assign((const uint8_t *)&sig, (const uint8_t *)&sig + sizeof sig);
+            else if (hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
                 enqueue_path(ctx, prm, n_tests, drm_masks != nullptr, phasing != 0, min_reads, want_read_hap != 0);
                 hipGraph_t g = nullptr;
                 if (hipStreamEndCapture(ctx->stream, &g) == hipSuccess && g &&

@@ -256,6 +256,7 @@ struct jl_ctx {
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
     std::vector<uint8_t> graph_sig;
+    std::vector<uint8_t> graph_seen;   // signature of the last eager run (a configuration is captured on its second run)
     uint64_t alloc_version = 0;       // bumped by every (re)allocation: captured pointers go stale
     uint64_t plan_version = 0;
     int pileup_blocks_per_cu[16] = {0};  // occupancy per kernel variant, queried once

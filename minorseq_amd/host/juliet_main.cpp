@@ -344,6 +344,7 @@ int main(int argc, char **argv)
         if (jl_run_async(ctx, genes.data(), (uint32_t)genes.size(), refp, (uint32_t)refcodes.size(), &prm,
                          opt.drm_only ? drm_masks.data() : nullptr, opt.phasing, opt.min_reads, opt.phasing) != JL_OK)
             die_jl(ctx, "run");
+        tick("plan + enqueue");
 
         std::vector<jl_variant> var(4096);
         uint32_t nv = 0;
@@ -378,7 +379,7 @@ int main(int argc, char **argv)
             if (jl_phase_fetch(ctx, &ps, pos_cols.data(), hap_count.data(), hap_pattern.data(), hit.data(), read_hap.data(), nullptr, cap_var) != JL_OK)
                 die_jl(ctx, "phase fetch");
         }
-        tick("call + phase + fetch");
+        tick("kernels + fetch");
         jl_ctx_destroy(ctx);
 
         // ---------------------------------------------------------------- JSON (doc/JULIET.md:61-107, 207-211)
