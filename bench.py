@@ -67,8 +67,8 @@ def main():
 
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=400)   # 400 steps = 50 launches of 8 windows, about 12 ms timed
+    ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--reads", type=int, default=N_READS)
     ap.add_argument("--cols", type=int, default=N_COLS)
     ap.add_argument("--no-cpu-baseline", action="store_true")

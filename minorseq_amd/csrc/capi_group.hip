@@ -46,11 +46,17 @@ static void group_enqueue(jl_group *g, bool phasing)
     const uint32_t n = (uint32_t)g->ctxs.size();
     for (jl_ctx *c : g->ctxs)
         if (!c->have_ref) jl_launch_guess(c, g->stream);   // majority-codon mode: seed bases per window
+    // JL_GROUP_SKIP (tuning only, results are then stale): 1 = pileup alone, 2 = no phasing stages, 3 = no id launch
+    static const int skip = getenv("JL_GROUP_SKIP") ? atoi(getenv("JL_GROUP_SKIP")) : 0;
     jl_launch_pileup_group(g->ctxs.data(), n, g->h_pile.data(), g->max_chunks, g->stream);
-    jl_launch_call_group(g->h_call.data(), n, g->max_call_blocks, g->stream);
-    if (phasing) {
+    if (skip != 1) jl_launch_call_group(g->h_call.data(), n, g->max_call_blocks, g->stream);
+    if (phasing && skip != 1 && skip != 2) {
         jl_launch_phase_group(g->h_phase.data(), n, g->max_phase_blocks, g->stream);
-        if (!g->fold) jl_launch_assign_group(g->h_phase.data(), n, g->max_read_blocks, g->stream);
+        if (!g->fold && skip != 3) {
+            bool to_host = false;
+            for (jl_ctx *c : g->ctxs) to_host = to_host || c->read_hap_out != nullptr;
+            jl_launch_assign_group(g->h_phase.data(), n, g->max_read_blocks, to_host, g->stream);
+        }
     }
     // completion words of all windows, behind the end of the last stage (see enqueue_path in capi.hip)
     jl_launch_done_group(g->d_done, n, g->stream);

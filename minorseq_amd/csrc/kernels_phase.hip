@@ -19,6 +19,8 @@
 // Vp > 10: phase_keys_kernel, phase_group_kernel, phase_select_kernel, phase_assign_kernel.
 #include <string.h>
 
+#include <algorithm>
+
 #include "jl_internal.h"
 #include "phase_plan.h"
 
@@ -785,12 +787,13 @@ __global__ __launch_bounds__(256) void phase_assign_kernel(uint64_t n_reads, con
 {
     // eight reads per lane: one flag word, two 16-byte loads of slots, one 16-byte store of ids (the id buffer holds
     // 2 * col_stride entries, so the store of a live lane is always inside it)
-    const uint64_t t = (uint64_t)blockIdx.x * 256u + threadIdx.x;   // dword index within a column
-    if (t * 8u < n_reads) {
+    const bool phased = meta->vp != 0;
+    // t = dword index within a column; the grid may be smaller than the window (see jl_launch_assign_group)
+    for (uint64_t t = (uint64_t)blockIdx.x * 256u + threadIdx.x; t * 8u < n_reads; t += (uint64_t)gridDim.x * 256u) {
         uint16_t h[8];
 #pragma unroll
         for (int r = 0; r < 8; ++r) h[r] = JL_HAP_DAMAGED;
-        if (meta->vp != 0) {
+        if (phased) {
             const uint32_t f = flagw[t];
             const uint4 s0 = *reinterpret_cast<const uint4 *>(read_slot + t * 8u);
             const uint4 s1 = *reinterpret_cast<const uint4 *>(read_slot + t * 8u + 4u);
@@ -828,27 +831,38 @@ __global__ __launch_bounds__(256) void phase_assign_group_kernel(jl_phase_group_
     // eight reads per lane: one flag word, two 16-byte loads of slots, one 16-byte store of ids (a wave writes 1 KiB
     // contiguous — the ids usually go to pinned host memory, and PCIe likes long writes)
     const jl_win_phase &w = args.w[blockIdx.z];
-    const uint64_t t = (uint64_t)blockIdx.x * 256u + threadIdx.x;   // dword index within a column = 8 reads
-    if (t * 4u >= w.col_stride) return;
-    uint16_t h[8];
+    const bool phased = w.meta->vp != 0;
+    // dword index within a column = 8 reads; the grid may be smaller than the window (see jl_launch_assign_group)
+    for (uint64_t t = (uint64_t)blockIdx.x * 256u + threadIdx.x; t * 4u < w.col_stride; t += (uint64_t)gridDim.x * 256u) {
+        uint16_t h[8];
 #pragma unroll
-    for (int r = 0; r < 8; ++r) h[r] = JL_HAP_DAMAGED;
-    if (w.meta->vp != 0) {
-        const uint32_t f = w.flagw[t];
-        const uint4 s0 = *reinterpret_cast<const uint4 *>(w.read_slot + t * 8u);
-        const uint4 s1 = *reinterpret_cast<const uint4 *>(w.read_slot + t * 8u + 4u);
-        const uint32_t slot[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+        for (int r = 0; r < 8; ++r) h[r] = JL_HAP_DAMAGED;
+        if (phased) {
+            const uint32_t f = w.flagw[t];
+            const uint4 s0 = *reinterpret_cast<const uint4 *>(w.read_slot + t * 8u);
+            const uint4 s1 = *reinterpret_cast<const uint4 *>(w.read_slot + t * 8u + 4u);
+            const uint32_t slot[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
 #pragma unroll
-        for (int r = 0; r < 8; ++r)
-            if (((f >> (4 * r)) & 15u) == 0) h[r] = (uint16_t)w.S.slot_hap[slot[r]];   // clean reads only: their slot is valid
+            for (int r = 0; r < 8; ++r)
+                if (((f >> (4 * r)) & 15u) == 0) h[r] = (uint16_t)w.S.slot_hap[slot[r]];   // clean reads only: their slot is valid
+        }
+        uint4 v;
+        v.x = h[0] | ((uint32_t)h[1] << 16); v.y = h[2] | ((uint32_t)h[3] << 16);
+        v.z = h[4] | ((uint32_t)h[5] << 16); v.w = h[6] | ((uint32_t)h[7] << 16);
+        *reinterpret_cast<uint4 *>(w.S.read_hap + t * 8u) = v;   // the buffer holds 2 * col_stride entries
     }
-    uint4 v;
-    v.x = h[0] | ((uint32_t)h[1] << 16); v.y = h[2] | ((uint32_t)h[3] << 16);
-    v.z = h[4] | ((uint32_t)h[5] << 16); v.w = h[6] | ((uint32_t)h[7] << 16);
-    *reinterpret_cast<uint4 *>(w.S.read_hap + t * 8u) = v;   // the buffer holds 2 * col_stride entries
 }
 
 }  // namespace
+
+// workgroups per window of a launch that writes per-read ids (see jl_launch_assign_group)
+static uint32_t jl_assign_blocks(uint32_t n_win, uint32_t max_read_blocks, bool to_host)
+{
+    if (!to_host) return max_read_blocks;   // ids that stay in HBM: one workgroup per 2048 reads
+    static const int env_cap = getenv("JL_ASSIGN_BLOCKS") ? atoi(getenv("JL_ASSIGN_BLOCKS")) : -1;
+    const uint32_t cap = env_cap >= 0 ? (uint32_t)env_cap : std::max(1u, 32u / std::max(1u, n_win));
+    return cap > 0 ? std::min<uint32_t>(cap, max_read_blocks) : max_read_blocks;
+}
 
 // `signal`: this launch ends a jl_run_async — its last kernel stores the completion word (jl_run_wait)
 void jl_launch_result_pack(jl_ctx *ctx, bool phasing, bool signal)
@@ -926,7 +940,7 @@ void jl_launch_phase(jl_ctx *ctx, uint32_t min_reads, bool planned, bool signal)
                            (unsigned long long *)ctx->d_slot_key, ctx->d_sync, signal_select ? ctx->h_seq : nullptr);
     }
     if (fold) return;
-    hipLaunchKernelGGL(phase_assign_kernel, dim3(w.n_blocks), dim3(256), 0, st, ctx->n_reads, ctx->d_flagw, ctx->d_meta,
+    hipLaunchKernelGGL(phase_assign_kernel, dim3(jl_assign_blocks(1, w.n_blocks, ids_to_host)), dim3(256), 0, st, ctx->n_reads, ctx->d_flagw, ctx->d_meta,
                        ctx->d_read_slot, ctx->d_slot_hap, ctx->read_hap_out ? ctx->read_hap_out : ctx->d_read_hap,
                        ctx->d_sync + 3, ctx->d_sync, (signal && ids_to_host) ? ctx->h_seq : nullptr);
 }
@@ -944,9 +958,15 @@ void jl_launch_phase_group(const jl_win_phase *h_wins, uint32_t n_win, uint32_t 
     hipLaunchKernelGGL(phase_group_run_kernel, dim3(max_blocks, 1, n_win), dim3(256), 0, st, args);
 }
 
-void jl_launch_assign_group(const jl_win_phase *h_wins, uint32_t n_win, uint32_t max_read_blocks, hipStream_t st)
+void jl_launch_assign_group(const jl_win_phase *h_wins, uint32_t n_win, uint32_t max_read_blocks, bool to_host, hipStream_t st)
 {
     jl_phase_group_args args;
     fill_phase_group_args(&args, h_wins, n_win);
-    hipLaunchKernelGGL(phase_assign_group_kernel, dim3(max_read_blocks, 1, n_win), dim3(256), 0, st, args);
+    // The ids usually go to pinned host memory, i.e. over PCIe at a fiftieth of the HBM rate.  A launch that has all
+    // of them in flight at once (49 workgroups per 100k reads) fills the L2's write queues with host-bound lines and the
+    // pileups of the other launches on the chip wait behind them: 222 us per group of 8 windows against 209 us when
+    // about 32 workgroups (128 KiB of stores in flight) loop over the reads instead — PCIe is saturated either way.
+    // JL_ASSIGN_BLOCKS = workgroups per window (0: one per 2048 reads, as many as it takes).
+    const uint32_t bx = jl_assign_blocks(n_win, max_read_blocks, to_host);
+    hipLaunchKernelGGL(phase_assign_group_kernel, dim3(bx, 1, n_win), dim3(256), 0, st, args);
 }
