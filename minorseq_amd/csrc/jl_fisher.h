@@ -174,3 +174,51 @@ JL_FHD double jl_fisher_greater_equal_rows(uint32_t a_, uint32_t c_, uint32_t n_
     return p;
 }
 
+// The same p-value, unless it provably cannot lead to a call: P(X >= a) >= P(X = a), so when already the point mass,
+// Bonferroni-adjusted, reaches alpha the codon is not called and (uncalled codons are never reported) its p-value is
+// not needed — the tail sum, a division per term, is skipped and *skipped set.  Every value that IS returned comes from
+// the very expressions of jl_fisher_greater_equal_rows (the product pmf * sum, sum >= 1, is monotone in floating point
+// as well; the log/exp branch keeps a 1e-6 margin against a non-monotone last bit of exp).
+JL_FHD double jl_fisher_greater_equal_rows_or_skip(uint32_t a_, uint32_t c_, uint32_t n_, double n_tests, double alpha,
+                                                   double *logp, bool *skipped)
+{
+    *skipped = false;
+    if (a_ <= c_) return jl_fisher_greater_equal_rows(a_, c_, n_, logp);
+    const double a = a_, c = c_, n = n_;
+    const double K = a + c;
+    const double hi = K < n ? K : n;
+    const double lo = K > n ? K - n : 0.0;
+    if (a <= lo) { *logp = 0.0; return 1.0; }
+    const double gate = alpha * (1.0 + 1e-6);
+    if (K <= 64.0) {
+        const double pm = jl_pmf_equal_rows_small(a, K, n);
+        double adj = pm * n_tests;
+        if (adj > 1.0) adj = 1.0;
+        if (adj >= gate) { *skipped = true; *logp = 0.0; return 1.0; }
+        double term = 1.0, sum = 1.0;
+        for (double x = a; x < hi; x += 1.0) {
+            term *= ((K - x) * (n - x)) / ((x + 1.0) * (n - K + x + 1.0));
+            sum += term;
+        }
+        double pv = pm * sum;
+        if (pv > 1.0) pv = 1.0;
+        *logp = log(pv);
+        return pv;
+    }
+    const double l0 = jl_log_pmf_equal_rows(a, K, n);
+    if (l0 > -700.0) {
+        double adj = exp(l0) * n_tests;
+        if (adj > 1.0) adj = 1.0;
+        if (adj >= gate) { *skipped = true; *logp = 0.0; return 1.0; }
+    }
+    double term = 1.0, sum = 1.0;
+    for (double x = a; x < hi; x += 1.0) {
+        term *= ((K - x) * (n - x)) / ((x + 1.0) * (n - K + x + 1.0));
+        sum += term;
+        if (term < sum * 1e-17) break;
+    }
+    const double lp = l0 + log(sum);
+    *logp = lp < 0.0 ? lp : 0.0;
+    return lp < -745.0 ? 0.0 : (lp < 0.0 ? exp(lp) : 1.0);
+}
+

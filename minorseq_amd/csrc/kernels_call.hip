@@ -96,10 +96,11 @@ __device__ __forceinline__ void call_body(const jl_win_call &w)
             // uncalled codons are never reported, so their p-value is not needed.
             const double floor_adj = 0.5 * A.n_tests < 1.0 ? 0.5 * A.n_tests : 1.0;
             if (h > e || !(floor_adj >= A.alpha)) {
-                const double pv = jl_fisher_greater_equal_rows(h, e, cov, &lp);
+                bool skipped;
+                const double pv = jl_fisher_greater_equal_rows_or_skip(h, e, cov, A.n_tests, A.alpha, &lp, &skipped);
                 p_adj = pv * A.n_tests;
                 if (p_adj > 1.0) p_adj = 1.0;
-                is_called = p_adj < A.alpha;
+                is_called = !skipped && p_adj < A.alpha;
             }
             const double perc = 100.0 * (double)h / (double)cov;
             if (A.min_perc >= 0.0 && !(perc > A.min_perc)) is_called = false;
