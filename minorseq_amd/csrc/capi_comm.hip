@@ -16,7 +16,7 @@
 
 #include "jl_internal.h"
 
-#define JL_COMM_SLOTS 64
+#define JL_COMM_SLOTS 128
 
 // One communicator per (rank, device).  Collectives run on the communicator's OWN stream, issued by a worker
 // thread once the producing run's completion word has arrived in pinned memory, so that several contexts (batches
@@ -26,9 +26,10 @@ struct jl_comm_slot {
     const uint8_t *d_src = nullptr;  // this rank's contribution: the run's device result block (double-buffered by run parity)
     uint32_t run_seq = 0;        // the run whose results are exchanged: the worker waits for its completion word
     uint64_t seq = 0;            // enqueue order: jl_allgather_variants collects a context's OLDEST pending exchange
-    uint8_t *d_heads = nullptr;  // [world][JL_PACK_HEAD_BYTES]
-    uint8_t *h_heads = nullptr;  // pinned mirror
+    uint8_t *d_heads = nullptr;  // [world][JL_PACK_HEAD_BYTES]: slot k's share of the communicator's arena
+    uint8_t *h_heads = nullptr;  // pinned mirror (same layout: consecutive slots are consecutive in memory)
     hipEvent_t done = nullptr;
+    jl_comm_slot *done_at = nullptr;   // the slot whose event covers this exchange (the last one of its batch)
     bool pending = false;        // an exchange was requested and not yet collected (host thread only)
     bool enqueued = false;       // the worker has issued it and recorded `done` (guarded by jl_comm::mu)
     int status = 0;              // ncclResult_t / hip error of the enqueue, as jl_status
@@ -38,6 +39,7 @@ struct jl_comm {
     ncclComm_t comm = nullptr;
     int rank = 0, world = 1, device = 0;
     hipStream_t stream = nullptr;
+    uint8_t *d_arena = nullptr, *h_arena = nullptr;   // [JL_COMM_SLOTS][world][JL_PACK_HEAD_BYTES]
     jl_variant *d_all = nullptr;   // [world][JL_VARIANT_CAP]   (full-stride fallback)
     uint32_t *d_counts = nullptr;  // [world][2]
     jl_comm_slot slots[JL_COMM_SLOTS];
@@ -73,9 +75,23 @@ static void comm_worker(jl_comm *c)
         for (jl_comm_slot *s : batch)
             if (st == JL_OK && ncclAllGather(s->d_src, s->d_heads, JL_PACK_HEAD_BYTES, ncclUint8, c->comm, c->stream) != ncclSuccess) st = JL_ERR_COMM;
         if (grouped && ncclGroupEnd() != ncclSuccess && st == JL_OK) st = JL_ERR_COMM;
-        for (jl_comm_slot *s : batch) {
-            if (st == JL_OK && hipMemcpyAsync(s->h_heads, s->d_heads, JL_PACK_HEAD_BYTES * (size_t)c->world, hipMemcpyDeviceToHost, c->stream) != hipSuccess) st = JL_ERR_DEVICE;
-            if (hipEventRecord(s->done, c->stream) != hipSuccess && st == JL_OK) st = JL_ERR_DEVICE;
+        // the gathered heads go to pinned memory: ONE copy and ONE event for the batch when its slots are consecutive
+        // in the arena (jl_allgather_variants_async_many reserves them so), else one of each per exchange
+        const size_t stride = JL_PACK_HEAD_BYTES * (size_t)c->world;
+        bool consecutive = batch.size() > 1;
+        for (size_t k = 1; k < batch.size(); ++k)
+            if (batch[k]->d_heads != batch[k - 1]->d_heads + stride) consecutive = false;
+        if (consecutive) {
+            jl_comm_slot *last = batch.back();
+            if (st == JL_OK && hipMemcpyAsync(batch[0]->h_heads, batch[0]->d_heads, stride * batch.size(), hipMemcpyDeviceToHost, c->stream) != hipSuccess) st = JL_ERR_DEVICE;
+            if (hipEventRecord(last->done, c->stream) != hipSuccess && st == JL_OK) st = JL_ERR_DEVICE;
+            for (jl_comm_slot *s : batch) s->done_at = last;
+        } else {
+            for (jl_comm_slot *s : batch) {
+                if (st == JL_OK && hipMemcpyAsync(s->h_heads, s->d_heads, stride, hipMemcpyDeviceToHost, c->stream) != hipSuccess) st = JL_ERR_DEVICE;
+                if (hipEventRecord(s->done, c->stream) != hipSuccess && st == JL_OK) st = JL_ERR_DEVICE;
+                s->done_at = s;
+            }
         }
         {
             std::lock_guard<std::mutex> lk(c->mu);
@@ -126,9 +142,18 @@ int jl_comm_create(jl_ctx *ctx, const uint8_t id[128], int rank, int world, jl_c
         delete c;
         return jl_fail(ctx, JL_ERR_COMM, "ncclCommInitRank: %s", ncclGetErrorString(r));
     }
-    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipMalloc(&c->d_all, sizeof(jl_variant) * JL_VARIANT_CAP * world) != hipSuccess ||
-        hipMalloc(&c->d_counts, 8 * world) != hipSuccess) {
+    const size_t stride = JL_PACK_HEAD_BYTES * (size_t)world;
+    bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess &&
+              hipMalloc(&c->d_all, sizeof(jl_variant) * JL_VARIANT_CAP * world) == hipSuccess &&
+              hipMalloc(&c->d_counts, 8 * world) == hipSuccess &&
+              hipMalloc(&c->d_arena, stride * JL_COMM_SLOTS) == hipSuccess &&
+              hipHostMalloc(&c->h_arena, stride * JL_COMM_SLOTS, hipHostMallocDefault) == hipSuccess;
+    for (int k = 0; ok && k < JL_COMM_SLOTS; ++k) {
+        c->slots[k].d_heads = c->d_arena + stride * (size_t)k;
+        c->slots[k].h_heads = c->h_arena + stride * (size_t)k;
+        ok = hipEventCreateWithFlags(&c->slots[k].done, hipEventDisableTiming) == hipSuccess;
+    }
+    if (!ok) {
         jl_comm_destroy(c);
         return jl_fail(ctx, JL_ERR_MEMORY, "comm buffers");
     }
@@ -150,11 +175,10 @@ void jl_comm_destroy(jl_comm *c)
         c->worker.join();
     }
     if (c->stream) hipStreamSynchronize(c->stream);
-    for (jl_comm_slot &s : c->slots) {
-        if (s.d_heads) hipFree(s.d_heads);
-        if (s.h_heads) hipHostFree(s.h_heads);
+    for (jl_comm_slot &s : c->slots)
         if (s.done) hipEventDestroy(s.done);
-    }
+    if (c->d_arena) hipFree(c->d_arena);
+    if (c->h_arena) hipHostFree(c->h_arena);
     if (c->comm) ncclCommDestroy(c->comm);
     if (c->d_all) hipFree(c->d_all);
     if (c->d_counts) hipFree(c->d_counts);
@@ -162,20 +186,16 @@ void jl_comm_destroy(jl_comm *c)
     delete c;
 }
 
-// A context may have several exchanges in flight (each in its own slot): `free` = a slot of this context that is
-// not pending, created on demand; `oldest` = its pending slot with the smallest sequence number.
-static jl_comm_slot *comm_slot_free(jl_ctx *ctx, jl_comm *c)
+// A context may have several exchanges in flight, each in its own slot.  Slots are not tied to contexts: a slot is free
+// when no uncollected exchange uses it; `first_of_run` asks for the first of `n` consecutive free slots (the exchanges
+// of a batch then land next to each other in the arena); `oldest` = a context's pending slot with the smallest
+// sequence number.
+static jl_comm_slot *comm_slot_free(jl_comm *c, uint32_t n = 1)
 {
-    for (jl_comm_slot &s : c->slots)
-        if (s.ctx == ctx && !s.pending) return &s;
-    for (jl_comm_slot &s : c->slots) {
-        if (s.ctx) continue;
-        const size_t bytes = JL_PACK_HEAD_BYTES * (size_t)c->world;
-        if (hipMalloc(&s.d_heads, bytes) != hipSuccess || hipHostMalloc(&s.h_heads, bytes, hipHostMallocDefault) != hipSuccess ||
-            hipEventCreateWithFlags(&s.done, hipEventDisableTiming) != hipSuccess)
-            return nullptr;
-        s.ctx = ctx;
-        return &s;
+    uint32_t run = 0;
+    for (uint32_t k = 0; k < JL_COMM_SLOTS; ++k) {
+        run = c->slots[k].pending ? 0 : run + 1;
+        if (run == n) return &c->slots[k + 1 - n];
     }
     return nullptr;
 }
@@ -193,7 +213,7 @@ static jl_comm_slot *comm_slot_oldest(jl_ctx *ctx, jl_comm *c)
 // which waits for the run's completion word and then issues the collective.  The result block is double-buffered
 // by run parity, so the run that follows on this context does not disturb the exchange; a context can therefore
 // have TWO exchanges pending, a third is refused.
-static int comm_request(jl_ctx *ctx, jl_comm *c, jl_comm_slot **out)
+static int comm_request(jl_ctx *ctx, jl_comm *c, jl_comm_slot *at, jl_comm_slot **out)
 {
     if (!ctx->pack_valid) return jl_fail(ctx, JL_ERR_STATE, "jl_allgather_variants_async needs jl_run_async first");
     if (ctx->device != c->device) return jl_fail(ctx, JL_ERR_ARG, "context and communicator are on different devices");
@@ -201,8 +221,10 @@ static int comm_request(jl_ctx *ctx, jl_comm *c, jl_comm_slot **out)
     for (jl_comm_slot &q : c->slots)
         if (q.ctx == ctx && q.pending) ++n_pending;
     if (n_pending >= 2) return jl_fail(ctx, JL_ERR_STATE, "two exchanges of this context are pending: collect one first");
-    jl_comm_slot *s = comm_slot_free(ctx, c);
-    if (!s) return jl_fail(ctx, JL_ERR_MEMORY, "no free exchange slot (%d per communicator): collect pending exchanges first", JL_COMM_SLOTS);
+    jl_comm_slot *s = at ? at : comm_slot_free(c);
+    if (!s || s->pending) return jl_fail(ctx, JL_ERR_MEMORY, "no free exchange slot (%d per communicator): collect pending exchanges first", JL_COMM_SLOTS);
+    s->ctx = ctx;
+    s->done_at = s;
     s->run_seq = ctx->runs_launched;
     s->d_src = reinterpret_cast<const uint8_t *>(ctx->d_pack + ((ctx->runs_launched - 1u) & 1u));
     s->seq = c->next_seq++;
@@ -217,14 +239,14 @@ int jl_allgather_variants_async(jl_ctx *ctx, jl_comm *c)
 {
     if (!ctx || !c) return JL_ERR_ARG;
     jl_comm_slot *s = nullptr;
-    int rc = comm_request(ctx, c, &s);
+    int rc = comm_request(ctx, c, nullptr, &s);
     if (rc) return rc;
+    s->pending = true;
     {
         std::lock_guard<std::mutex> lk(c->mu);
         c->queue.emplace_back(1, s);
     }
     c->cv.notify_all();
-    s->pending = true;
     return JL_OK;
 }
 
@@ -234,10 +256,11 @@ int jl_allgather_variants_async_many(jl_ctx *const *ctxs, uint32_t n, jl_comm *c
 {
     if (!ctxs || !c || n == 0 || n > JL_COMM_SLOTS / 2) return JL_ERR_ARG;
     std::vector<jl_comm_slot *> batch;
+    jl_comm_slot *run0 = comm_slot_free(c, n);   // n consecutive slots when there are (one copy, one event for the batch)
     for (uint32_t k = 0; k < n; ++k) {
         if (!ctxs[k]) return JL_ERR_ARG;
         jl_comm_slot *s = nullptr;
-        int rc = comm_request(ctxs[k], c, &s);
+        int rc = comm_request(ctxs[k], c, run0 ? run0 + k : nullptr, &s);
         if (rc) {
             for (jl_comm_slot *b : batch) { b->pending = false; b->ctx->exch_pending--; }
             return rc;
@@ -291,13 +314,13 @@ int jl_allgather_variants(jl_ctx *ctx, jl_comm *c, jl_variant *all_rows, uint32_
             if (rc) return rc;
             s = comm_slot_oldest(ctx, c);
         }
-        s->pending = false;
         if (ctx->exch_pending) ctx->exch_pending--;
         comm_wait_enqueued(c, s);
+        struct release { jl_comm_slot *s; ~release() { s->pending = false; } } rel{s};   // free for reuse once the heads were read
         if (s->status != JL_OK) return jl_fail(ctx, s->status, "all-gather enqueue failed on the communicator thread");
         {   // spin on the event: a blocking hipEventSynchronize costs ~15 us of wake-up latency per step
             hipError_t q;
-            while ((q = hipEventQuery(s->done)) == hipErrorNotReady) {}
+            while ((q = hipEventQuery(s->done_at->done)) == hipErrorNotReady) {}
             if (q != hipSuccess) return jl_fail(ctx, JL_ERR_DEVICE, "all-gather: %s", hipGetErrorString(q));
         }
         bool compact = true;
