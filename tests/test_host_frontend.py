@@ -107,3 +107,15 @@ def test_rich_qv_tracks_mask_bases(tmp_path):
     ref = synth.reference(seed, l)
     assert (rows0[:, :l][exp == 5] == np.broadcast_to(ref, exp.shape)[exp == 5]).all()
     assert (rows0[:, :l][exp != 5] == exp[exp != 5]).all()
+
+
+def test_min_rq_filter_reads_the_rq_tag(tmp_path):
+    """doc/JULIET.md:56: filtering on predicted accuracy is left to the user; --min-rq applies it from the rq tag.
+    The generator writes rq = 0.999 on every read."""
+    bam, msa_out = str(tmp_path / "rq.bam"), str(tmp_path / "rq.msa")
+    subprocess.check_call([SYNTH, "--reads", "200", "--cols", "90", "--seed", "5", "-o", bam])
+    subprocess.check_call([JULIET, "--min-rq", "0.99", "--dump-msa", msa_out, bam])
+    rows, _ = read_msa(msa_out)
+    assert rows.shape[0] == 200
+    r = subprocess.run([JULIET, "--min-rq", "0.9995", "--dump-msa", msa_out, bam], capture_output=True, text=True)
+    assert r.returncode == 2 and "no primary or supplementary alignments" in r.stderr
