@@ -76,6 +76,10 @@ def test_front_end_ingest_under_asan_ubsan(san_bins):
     assert r.returncode == 0, r.stderr[-2000:]
     r = subprocess.run([juliet, "-c", cfg, "--dump-msa", msa_out, bam], capture_output=True, text=True, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
+    # the same with the filters that make the one-pass record parser read qualities and tags
+    r = subprocess.run([juliet, "-c", cfg, "--min-qv", "10", "--min-rq", "0.5", "--dump-msa", msa_out, bam],
+                       capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
     r = subprocess.run([juliet, "-c", cfg, "-r", "130-400", "--dump-config", cfg_out], capture_output=True, text=True, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     # malformed inputs must fail cleanly, not crash
