@@ -24,6 +24,11 @@ import time
 
 import numpy as np
 
+# Before anything loads the HIP runtime: by default it multiplexes a process's streams onto 4 hardware queues.  With
+# N > 1 a step loop keeps five streams busy (4 launches in flight + the exchange), and the exchange then shares a
+# queue with a launch: 0.0307 ms per step against 0.0291 with 8 queues (one-rank emulation); N = 1 is unaffected.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 

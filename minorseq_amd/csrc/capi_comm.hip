@@ -30,6 +30,9 @@ struct jl_comm_slot {
     uint8_t *h_heads = nullptr;  // pinned mirror (same layout: consecutive slots are consecutive in memory)
     hipEvent_t done = nullptr;
     jl_comm_slot *done_at = nullptr;   // the slot whose event covers this exchange (the last one of its batch)
+    // where rank r's head of this exchange lies in pinned memory: h_base + (r * batch_n + batch_k) * JL_PACK_HEAD_BYTES
+    const uint8_t *h_base = nullptr;
+    uint32_t batch_n = 1, batch_k = 0;
     bool pending = false;        // an exchange was requested and not yet collected (host thread only)
     bool enqueued = false;       // the worker has issued it and recorded `done` (guarded by jl_comm::mu)
     int status = 0;              // ncclResult_t / hip error of the enqueue, as jl_status
@@ -40,6 +43,7 @@ struct jl_comm {
     int rank = 0, world = 1, device = 0;
     hipStream_t stream = nullptr;
     uint8_t *d_arena = nullptr, *h_arena = nullptr;   // [JL_COMM_SLOTS][world][JL_PACK_HEAD_BYTES]
+    uint8_t *d_send = nullptr;                        // [JL_COMM_SLOTS][JL_PACK_HEAD_BYTES]: send buffers of batches
     jl_variant *d_all = nullptr;   // [world][JL_VARIANT_CAP]   (full-stride fallback)
     uint32_t *d_counts = nullptr;  // [world][2]
     jl_comm_slot slots[JL_COMM_SLOTS];
@@ -69,28 +73,43 @@ static void comm_worker(jl_comm *c)
         // the producing runs are complete when their sequence words are in pinned memory (jl_run_wait): no events
         for (jl_comm_slot *s : batch)
             if (jl_run_wait_seq(s->ctx, s->run_seq) != JL_OK) st = JL_ERR_DEVICE;
-        // one RCCL group for the whole batch: the all-gathers of the windows of a group run share one launch
-        const bool grouped = batch.size() > 1;
-        if (st == JL_OK && grouped && ncclGroupStart() != ncclSuccess) st = JL_ERR_COMM;
-        for (jl_comm_slot *s : batch)
-            if (st == JL_OK && ncclAllGather(s->d_src, s->d_heads, JL_PACK_HEAD_BYTES, ncclUint8, c->comm, c->stream) != ncclSuccess) st = JL_ERR_COMM;
-        if (grouped && ncclGroupEnd() != ncclSuccess && st == JL_OK) st = JL_ERR_COMM;
-        // the gathered heads go to pinned memory: ONE copy and ONE event for the batch when its slots are consecutive
-        // in the arena (jl_allgather_variants_async_many reserves them so), else one of each per exchange
+        // A batch whose slots are consecutive in the arena (jl_allgather_variants_async_many reserves them so) is ONE
+        // exchange: a small kernel puts the heads of its windows next to each other, one all-gather moves them
+        // ([rank][window][head] on every rank), one copy brings them to pinned memory, one event says so.  Otherwise
+        // an all-gather, a copy and an event per window.
         const size_t stride = JL_PACK_HEAD_BYTES * (size_t)c->world;
-        bool consecutive = batch.size() > 1;
+        bool consecutive = batch.size() > 1 && batch.size() <= JL_GATHER_MAX;
         for (size_t k = 1; k < batch.size(); ++k)
             if (batch[k]->d_heads != batch[k - 1]->d_heads + stride) consecutive = false;
         if (consecutive) {
+            const uint32_t n = (uint32_t)batch.size();
+            const size_t i0 = (size_t)(batch[0] - c->slots);
+            uint8_t *send = c->d_send + i0 * JL_PACK_HEAD_BYTES;
+            const uint8_t *srcs[JL_GATHER_MAX];
+            for (uint32_t k = 0; k < n; ++k) srcs[k] = batch[k]->d_src;
             jl_comm_slot *last = batch.back();
-            if (st == JL_OK && hipMemcpyAsync(batch[0]->h_heads, batch[0]->d_heads, stride * batch.size(), hipMemcpyDeviceToHost, c->stream) != hipSuccess) st = JL_ERR_DEVICE;
+            if (st == JL_OK) {
+                jl_launch_gather_heads(srcs, n, send, c->stream);
+                if (hipGetLastError() != hipSuccess) st = JL_ERR_DEVICE;
+            }
+            if (st == JL_OK && ncclAllGather(send, batch[0]->d_heads, JL_PACK_HEAD_BYTES * (size_t)n, ncclUint8, c->comm, c->stream) != ncclSuccess) st = JL_ERR_COMM;
+            if (st == JL_OK && hipMemcpyAsync(batch[0]->h_heads, batch[0]->d_heads, stride * n, hipMemcpyDeviceToHost, c->stream) != hipSuccess) st = JL_ERR_DEVICE;
             if (hipEventRecord(last->done, c->stream) != hipSuccess && st == JL_OK) st = JL_ERR_DEVICE;
-            for (jl_comm_slot *s : batch) s->done_at = last;
+            for (uint32_t k = 0; k < n; ++k) {
+                batch[k]->done_at = last;
+                batch[k]->h_base = batch[0]->h_heads;
+                batch[k]->batch_n = n;
+                batch[k]->batch_k = k;
+            }
         } else {
             for (jl_comm_slot *s : batch) {
+                if (st == JL_OK && ncclAllGather(s->d_src, s->d_heads, JL_PACK_HEAD_BYTES, ncclUint8, c->comm, c->stream) != ncclSuccess) st = JL_ERR_COMM;
                 if (st == JL_OK && hipMemcpyAsync(s->h_heads, s->d_heads, stride, hipMemcpyDeviceToHost, c->stream) != hipSuccess) st = JL_ERR_DEVICE;
                 if (hipEventRecord(s->done, c->stream) != hipSuccess && st == JL_OK) st = JL_ERR_DEVICE;
                 s->done_at = s;
+                s->h_base = s->h_heads;
+                s->batch_n = 1;
+                s->batch_k = 0;
             }
         }
         {
@@ -147,6 +166,7 @@ int jl_comm_create(jl_ctx *ctx, const uint8_t id[128], int rank, int world, jl_c
               hipMalloc(&c->d_all, sizeof(jl_variant) * JL_VARIANT_CAP * world) == hipSuccess &&
               hipMalloc(&c->d_counts, 8 * world) == hipSuccess &&
               hipMalloc(&c->d_arena, stride * JL_COMM_SLOTS) == hipSuccess &&
+              hipMalloc(&c->d_send, (size_t)JL_PACK_HEAD_BYTES * JL_COMM_SLOTS) == hipSuccess &&
               hipHostMalloc(&c->h_arena, stride * JL_COMM_SLOTS, hipHostMallocDefault) == hipSuccess;
     for (int k = 0; ok && k < JL_COMM_SLOTS; ++k) {
         c->slots[k].d_heads = c->d_arena + stride * (size_t)k;
@@ -178,6 +198,7 @@ void jl_comm_destroy(jl_comm *c)
     for (jl_comm_slot &s : c->slots)
         if (s.done) hipEventDestroy(s.done);
     if (c->d_arena) hipFree(c->d_arena);
+    if (c->d_send) hipFree(c->d_send);
     if (c->h_arena) hipHostFree(c->h_arena);
     if (c->comm) ncclCommDestroy(c->comm);
     if (c->d_all) hipFree(c->d_all);
@@ -254,7 +275,7 @@ int jl_allgather_variants_async(jl_ctx *ctx, jl_comm *c)
 // of n.  Every rank must pass the same number of contexts in the same call order.
 int jl_allgather_variants_async_many(jl_ctx *const *ctxs, uint32_t n, jl_comm *c)
 {
-    if (!ctxs || !c || n == 0 || n > JL_COMM_SLOTS / 2) return JL_ERR_ARG;
+    if (!ctxs || !c || n == 0 || n > JL_GATHER_MAX) return JL_ERR_ARG;
     std::vector<jl_comm_slot *> batch;
     jl_comm_slot *run0 = comm_slot_free(c, n);   // n consecutive slots when there are (one copy, one event for the batch)
     for (uint32_t k = 0; k < n; ++k) {
@@ -325,13 +346,13 @@ int jl_allgather_variants(jl_ctx *ctx, jl_comm *c, jl_variant *all_rows, uint32_
         }
         bool compact = true;
         for (int k = 0; k < c->world; ++k) {
-            const jl_pack *pk = reinterpret_cast<const jl_pack *>(s->h_heads + (size_t)k * JL_PACK_HEAD_BYTES);
+            const jl_pack *pk = reinterpret_cast<const jl_pack *>(s->h_base + ((size_t)k * s->batch_n + s->batch_k) * JL_PACK_HEAD_BYTES);
             if (pk->magic != JL_PACK_MAGIC || !pk->fits_call) compact = false;
         }
         if (compact) {
             int rc = JL_OK;
             for (int k = 0; k < c->world; ++k) {
-                const jl_pack *pk = reinterpret_cast<const jl_pack *>(s->h_heads + (size_t)k * JL_PACK_HEAD_BYTES);
+                const jl_pack *pk = reinterpret_cast<const jl_pack *>(s->h_base + ((size_t)k * s->batch_n + s->batch_k) * JL_PACK_HEAD_BYTES);
                 all_counts[k] = pk->nvar_total;
                 if (pk->nvar_total > cap_rows) { rc = JL_ERR_OVERFLOW; continue; }
                 memcpy(all_rows + (size_t)k * cap_rows, pk->variants, (size_t)pk->nvar_total * sizeof(jl_variant));

@@ -160,6 +160,12 @@ struct jl_call_group_args { jl_win_call w[JL_GROUP_MAX]; };
 struct jl_phase_group_args { jl_win_phase w[JL_GROUP_MAX]; };
 struct jl_pileup_group_args { jl_win_pileup w[JL_GROUP_MAX]; };
 
+// exchange: the heads of the result blocks of up to JL_GATHER_MAX windows copied next to each other (one send buffer,
+// one all-gather for the launch)
+#define JL_GATHER_MAX 32
+struct jl_gather_args { const uint8_t *src[JL_GATHER_MAX]; };
+void jl_launch_gather_heads(const uint8_t *const *srcs, uint32_t n, uint8_t *dst, hipStream_t st);
+
 struct jl_comm;
 
 struct jl_ctx {

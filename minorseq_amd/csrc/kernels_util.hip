@@ -2,6 +2,8 @@
 //   synth_kernel      synthetic aligned CCS reads (jl_synth.h), one dword (8 reads) of one column per step
 //   pack_rows_kernel  by-row uint8 codes -> column-packed nibbles (jl_msa_pack_rows)
 //   ingest_cols_kernel  aligned BAM records -> column-packed nibbles
+#include <string.h>
+
 #include <algorithm>
 
 #include "jl_internal.h"
@@ -242,6 +244,23 @@ __global__ void done_group_kernel(const jl_done_ent *__restrict__ ents, uint32_t
 void jl_launch_done_group(const jl_done_ent *d_ents, uint32_t n, hipStream_t st)
 {
     hipLaunchKernelGGL(done_group_kernel, dim3(1), dim3(64), 0, st, d_ents, n);
+}
+
+// the heads (header + first 128 rows) of n result blocks, one workgroup each, into one contiguous buffer
+__global__ __launch_bounds__(256) void gather_heads_kernel(jl_gather_args a, uint8_t *__restrict__ dst)
+{
+    static_assert(JL_PACK_HEAD_BYTES % 4 == 0, "heads are copied as dwords");
+    const uint32_t *s = reinterpret_cast<const uint32_t *>(a.src[blockIdx.x]);
+    uint32_t *d = reinterpret_cast<uint32_t *>(dst + (size_t)blockIdx.x * JL_PACK_HEAD_BYTES);
+    for (uint32_t i = threadIdx.x; i < JL_PACK_HEAD_BYTES / 4; i += 256) d[i] = s[i];
+}
+
+void jl_launch_gather_heads(const uint8_t *const *srcs, uint32_t n, uint8_t *dst, hipStream_t st)
+{
+    jl_gather_args a;
+    memset(&a, 0, sizeof a);
+    for (uint32_t k = 0; k < n && k < JL_GATHER_MAX; ++k) a.src[k] = srcs[k];
+    hipLaunchKernelGGL(gather_heads_kernel, dim3(n), dim3(256), 0, st, a, dst);
 }
 
 void jl_launch_done(jl_ctx *ctx)
