@@ -72,8 +72,8 @@ def main():
 
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=400)   # 400 steps = 50 launches of 8 windows, about 12 ms timed
-    ap.add_argument("--warmup", type=int, default=16)
+    ap.add_argument("--steps", type=int, default=1600)   # 200 launches of 8 windows, about 43 ms timed: the 4-deep pipeline fills and drains inside the timed region
+    ap.add_argument("--warmup", type=int, default=32)
     ap.add_argument("--reads", type=int, default=N_READS)
     ap.add_argument("--cols", type=int, default=N_COLS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -94,6 +94,11 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    # a launcher that narrows the visible devices per rank (HIP_VISIBLE_DEVICES) leaves one device, index 0
+    n_dev = torch.cuda.device_count()
+    if n_dev < 1:
+        raise SystemExit("bench.py: no GPU visible (the product path has no CPU fallback)")
+    local_rank %= n_dev
     torch.cuda.set_device(local_rank)
     # JL_BENCH_FORCE_DIST=1 drives the N > 1 code path (process group, RCCL bootstrap, all-gather) with one rank
     distributed = world > 1 or os.environ.get("JL_BENCH_FORCE_DIST") == "1"
