@@ -116,8 +116,8 @@ def main():
     ref_local = synth.reference(sp.seed, l)
     win_begin = rank * l
     G = max(1, args.group)
-    if G > 8:
-        raise SystemExit("bench.py: --group is at most 8 (a group launch carries its windows' argument blocks by value: JL_GROUP_MAX)")
+    if G > 32:
+        raise SystemExit("bench.py: --group is at most 32 (a group launch carries its windows' argument blocks by value: JL_GROUP_WINDOWS_MAX)")
     n_units = max(1, args.inflight)
     ctxs = []
     for _ in range(n_units * G):

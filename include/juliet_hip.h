@@ -244,7 +244,7 @@ typedef struct {
 int jl_run_view_get(jl_ctx *ctx, jl_run_view *out);
 
 /*
- * Group runs: the whole path for SEVERAL (at most 8) resident windows (one context each, same device) in three launches —
+ * Group runs: the whole path for SEVERAL (at most 32) resident windows (one context each, same device) in three launches —
  * one pileup stream over all windows, one Fisher/compaction launch, one phasing launch (blockIdx.z = window).
  * A 150 MB window is too short a stream to hide a launch's ramp and drain, and its Fisher and phasing stages are
  * latency chains that occupy a hardware queue while doing little; grouped, the pileup runs at the rate of one long

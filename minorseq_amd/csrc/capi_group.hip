@@ -49,13 +49,15 @@ static void group_enqueue(jl_group *g, bool phasing)
     // JL_GROUP_SKIP (tuning only, results are then stale): 1 = pileup alone, 2 = no phasing stages, 3 = no id launch
     static const int skip = getenv("JL_GROUP_SKIP") ? atoi(getenv("JL_GROUP_SKIP")) : 0;
     jl_launch_pileup_group(g->ctxs.data(), n, g->h_pile.data(), g->max_chunks, g->stream);
-    if (skip != 1) jl_launch_call_group(g->h_call.data(), n, g->max_call_blocks, g->stream);
-    if (phasing && skip != 1 && skip != 2) {
-        jl_launch_phase_group(g->h_phase.data(), n, g->max_phase_blocks, g->stream);
-        if (!g->fold && skip != 3) {
-            bool to_host = false;
-            for (jl_ctx *c : g->ctxs) to_host = to_host || c->read_hap_out != nullptr;
-            jl_launch_assign_group(g->h_phase.data(), n, g->max_read_blocks, to_host, g->stream);
+    // the later stages take their windows' argument blocks (250-350 bytes each) by value too: JL_GROUP_MAX per launch
+    bool to_host = false;
+    for (jl_ctx *c : g->ctxs) to_host = to_host || c->read_hap_out != nullptr;
+    for (uint32_t o = 0; o < n; o += JL_GROUP_MAX) {
+        const uint32_t m = std::min<uint32_t>(JL_GROUP_MAX, n - o);
+        if (skip != 1) jl_launch_call_group(g->h_call.data() + o, m, g->max_call_blocks, g->stream);
+        if (phasing && skip != 1 && skip != 2) {
+            jl_launch_phase_group(g->h_phase.data() + o, m, g->max_phase_blocks, g->stream);
+            if (!g->fold && skip != 3) jl_launch_assign_group(g->h_phase.data() + o, m, g->max_read_blocks, to_host, g->stream);
         }
     }
     // completion words of all windows, behind the end of the last stage (see enqueue_path in capi.hip)
@@ -66,7 +68,7 @@ extern "C" {
 
 int jl_group_create(jl_ctx *const *ctxs, uint32_t n_ctx, jl_group **out)
 {
-    if (!ctxs || !out || n_ctx == 0 || n_ctx > JL_GROUP_MAX) return JL_ERR_ARG;   // the argument blocks travel by value
+    if (!ctxs || !out || n_ctx == 0 || n_ctx > JL_GROUP_WINDOWS_MAX) return JL_ERR_ARG;   // the argument blocks travel by value
     *out = nullptr;
     for (uint32_t k = 0; k < n_ctx; ++k) {
         if (!ctxs[k] || ctxs[k]->device != ctxs[0]->device) return JL_ERR_ARG;

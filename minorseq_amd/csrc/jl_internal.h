@@ -155,10 +155,11 @@ struct jl_win_phase {
 // segment: pointers loaded from there are known to be global ones, while pointers loaded from a table in device memory
 // are generic to the compiler and every access through them becomes a flat access (slower, and never waited for with
 // an exact count).
-#define JL_GROUP_MAX 8
+#define JL_GROUP_MAX 8           // windows per call / phase / id launch (their argument blocks are 250-350 bytes each)
+#define JL_GROUP_WINDOWS_MAX 32  // windows per group = per pileup launch (56-byte argument blocks)
 struct jl_call_group_args { jl_win_call w[JL_GROUP_MAX]; };
 struct jl_phase_group_args { jl_win_phase w[JL_GROUP_MAX]; };
-struct jl_pileup_group_args { jl_win_pileup w[JL_GROUP_MAX]; };
+struct jl_pileup_group_args { jl_win_pileup w[JL_GROUP_WINDOWS_MAX]; };
 
 // exchange: the heads of the result blocks of up to JL_GATHER_MAX windows copied next to each other (one send buffer,
 // one all-gather for the launch)

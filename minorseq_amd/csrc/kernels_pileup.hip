@@ -514,7 +514,7 @@ void jl_fill_win_pileup(jl_ctx *ctx, jl_win_pileup *w)
 int jl_launch_pileup_group(jl_ctx *const *ctxs, uint32_t n_win, const jl_win_pileup *h_wins, uint32_t max_chunks, hipStream_t st)
 {
     const int idx = pick_variant(ctxs[0]);
-    if (n_win > JL_GROUP_MAX) return JL_ERR_ARG;
+    if (n_win > JL_GROUP_WINDOWS_MAX) return JL_ERR_ARG;
     for (uint32_t k = 0; k < n_win; ++k)
         if (pick_variant(ctxs[k]) != idx) return JL_ERR_ARG;
     jl_pileup_group_args args;

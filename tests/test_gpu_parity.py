@@ -574,13 +574,48 @@ def test_bench_configuration_group_of_eight_full_size_windows(oracle):
             j.close()
 
 
-def test_group_of_more_than_eight_windows_is_refused():
-    """The per-window argument blocks travel by value in the kernel arguments: a group holds at most 8 windows."""
-    ctxs = [capi.Juliet(0) for _ in range(9)]
+@pytest.mark.parametrize("fold", [True, False])
+def test_group_run_with_more_windows_than_a_stage_launch_takes(oracle, fold, monkeypatch):
+    """A group of 11 windows: ONE pileup launch, the call / phase / id stages in launches of 8 + 3 windows.  Every
+    window against the oracle, over a graph replay."""
+    if not fold:
+        monkeypatch.setenv("JL_NO_FOLD", "1")
+    l = 150
+    genes = np.array([(1, l + 1)], dtype=capi.GENE)
+    ref = synth.reference(41, l)
+    ctxs, exp = [], []
+    for k in range(11):
+        n = 1500 + 433 * k
+        j = capi.Juliet(0)
+        j.alloc(n, l)
+        j.synth_fill(synth.SynthParams(seed=41 + k, minor_permille=(60, 50, 40, 30), partial_rate=0.02 * k), ref)
+        j.sync()
+        rows = msa.unpack_columns(j.download_columns(), n)
+        ev = oracle.call(rows, genes, refseq=ref)
+        exp.append((ev, oracle.phase(rows, ev)))
+        ctxs.append(j)
+    grp = capi.Group(ctxs)
+    try:
+        for rep in range(3):
+            grp.run_async(genes, ref, capi.default_params(), True, 10, True)
+            for j, (ev, ep) in zip(ctxs, exp):
+                v = j.run_view()
+                assert v is not None
+                assert_variants_equal(v["variants"], ev)
+                assert_phase_equal(v["phase"], ep, len(ev))
+    finally:
+        grp.close()
+        for j in ctxs:
+            j.close()
+
+
+def test_group_of_more_than_32_windows_is_refused():
+    """The per-window argument blocks travel by value in the kernel arguments: a group holds at most 32 windows."""
+    ctxs = [capi.Juliet(0) for _ in range(33)]
     try:
         with pytest.raises(capi.JulietError):
             capi.Group(ctxs)
-        capi.Group(ctxs[:8]).close()
+        capi.Group(ctxs[:32]).close()
     finally:
         for j in ctxs:
             j.close()
