@@ -8,6 +8,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 #include <vector>
 #include <algorithm>
 
@@ -84,7 +85,7 @@ __global__ __launch_bounds__(256) void col_kernel(const uint8_t *__restrict__ ms
 struct launcher { const char *name; void (*fn)(const uint8_t *, uint32_t *, hipStream_t); };
 
 static uint64_t g_bytes, g_stride;
-static uint32_t g_cols;
+static uint32_t g_cols, g_lds;   // g_lds: dynamic LDS per block of the col kernels (caps the blocks per CU: 160 KB / g_lds)
 
 template <int U, bool NT, int BLOCKS> static void l_flat(const uint8_t *p, uint32_t *s, hipStream_t st)
 { hipLaunchKernelGGL((flat_kernel<U, NT>), dim3(BLOCKS), dim3(256), 0, st, (const u32x4 *)p, g_bytes / 16, s); }
@@ -93,13 +94,14 @@ template <int U, bool NT, int BLOCKS> static void l_slab(const uint8_t *p, uint3
 template <int W, bool NT, int RS> static void l_col(const uint8_t *p, uint32_t *s, hipStream_t st)
 {
     const uint32_t n_tiles = (uint32_t)((g_stride + 4095) / 4096);
-    hipLaunchKernelGGL((col_kernel<W, NT>), dim3((g_cols + W - 1) / W, RS), dim3(256), 0, st, p, g_stride, g_cols, n_tiles, s);
+    hipLaunchKernelGGL((col_kernel<W, NT>), dim3((g_cols + W - 1) / W, RS), dim3(256), g_lds, st, p, g_stride, g_cols, n_tiles, s);
 }
 
 int main(int argc, char **argv)
 {
     const uint64_t n_reads = argc > 1 ? strtoull(argv[1], 0, 10) : 100000;
     g_cols = argc > 2 ? atoi(argv[2]) : 3000;
+    g_lds = argc > 3 ? (uint32_t)atoi(argv[3]) : 0;
     g_stride = ((n_reads + 1) / 2 + 127) / 128 * 128;
     g_bytes = g_stride * g_cols;
     const int NB = 4, R = 20;
@@ -124,6 +126,7 @@ int main(int argc, char **argv)
     printf("window %llu reads x %u cols = %.1f MB (stride %llu)\n", (unsigned long long)n_reads, g_cols, g_bytes / 1e6, (unsigned long long)g_stride);
     printf("%-34s %10s %10s %10s %10s\n", "variant", "1x rot us", "b2b rot us", "1x same us", "b2b same us");
     for (const launcher &l : ls) {
+        if (g_lds && strncmp(l.name, "col", 3) != 0) continue;
         float res[4];
         for (int mode = 0; mode < 2; ++mode) {       // 0: rotate 4 buffers, 1: same buffer
             for (int w = 0; w < 8; ++w) l.fn(buf[mode ? 0 : w % NB], sink, st);
