@@ -917,6 +917,17 @@ int jl_run_wait_seq(jl_ctx *ctx, uint32_t want)
     return JL_OK;
 }
 
+// tuning aid, not part of the ABI header (tools_tuning/timeline.py): the device-clock stamps of the last
+// JL_TIMELINE_ROWS runs of this context (JL_TIMELINE=1), 100 MHz ticks
+int jl_debug_timeline(jl_ctx *ctx, uint64_t *out)
+{
+    if (!ctx || !out) return JL_ERR_ARG;
+    if (!ctx->d_timeline) return jl_fail(ctx, JL_ERR_STATE, "run with JL_TIMELINE=1");
+    JL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    JL_HIP(ctx, hipMemcpy(out, ctx->d_timeline, (size_t)JL_TIMELINE_ROWS * JL_TIMELINE_SLOTS * 8, hipMemcpyDeviceToHost));
+    return JL_OK;
+}
+
 int jl_run_wait(jl_ctx *ctx)
 {
     if (!ctx) return JL_ERR_ARG;
