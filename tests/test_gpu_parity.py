@@ -1063,6 +1063,53 @@ def test_pileup_genes_in_different_frames(jl, oracle, n, l):
     assert_phase_equal(out["phase"], oracle.phase(rows, exp_v), len(exp_v))
 
 
+def test_group_run_with_genes_in_different_frames(oracle):
+    """The grouped launches on the HIV-like layout above: chunks with and without halo columns in one pileup launch
+    (the general path of pileup_group_kernel), three windows of different depth, majority-codon mode included."""
+    l = 420
+    third = l // 3
+    def begin_in_frame(near, frame):
+        b = near
+        while (b - 1) % 3 != frame:
+            b += 1
+        return b
+    genes = np.array([(begin_in_frame(2, 1), third + 1), (begin_in_frame(third + 2, 2), 2 * third + 2),
+                      (begin_in_frame(max(1, 2 * third - 20), 0), l - 1), (5, 9), (l - 4, l + 5)], dtype=capi.GENE)
+    assert len({(int(g["begin"]) - 1) % 3 for g in genes[:3]}) >= 2
+    ref = synth.reference(515, l)
+    prm = capi.default_params()
+    ctxs, rows_all = [], []
+    for k, n in enumerate((2500, 7000, 4100)):
+        sp = synth.SynthParams(seed=515 + k, partial_rate=0.1 * k, mask_rate=0.03, del_rate=0.01,
+                               minor_permille=(60, 50, 40, 30))
+        rows = synth.rows(sp, l, 0, n, ref)
+        j = capi.Juliet(0)
+        j.upload_columns(msa.pack_columns(rows), n)
+        j.sync()
+        ctxs.append(j)
+        rows_all.append(rows)
+    grp = capi.Group(ctxs)
+    try:
+        for refseq in (ref, None):
+            for rep in range(2):   # the second launch replays the captured graph
+                grp.run_async(genes, refseq, prm, True, 10, True)
+            for j, rows in zip(ctxs, rows_all):
+                exp_v = oracle.call(rows, genes, refseq=refseq)
+                assert 0 < len(np.unique(exp_v["col"])) <= 10
+                v = j.run_view()
+                assert v is not None
+                assert_variants_equal(v["variants"], exp_v)
+                assert_phase_equal(v["phase"], oracle.phase(rows, exp_v), len(exp_v))
+                pf = j.pileup_fetch()
+                assert (pf["col_counts"] == oracle.pileup(rows)).all()
+                hist, cov = oracle.codon_hist(rows, pf["pos_col"])
+                assert (pf["hist"] == hist).all() and (pf["coverage"] == cov).all()
+    finally:
+        grp.close()
+        for j in ctxs:
+            j.close()
+
+
 # --------------------------------------------------------------------------------------------- torch plumbing
 def test_adopted_torch_tensor_and_caller_stream(oracle):
     """PyTorch as plumbing only: the resident matrix lives in a torch tensor (jl_msa_adopt) and all work of the
