@@ -1063,6 +1063,42 @@ def test_pileup_genes_in_different_frames(jl, oracle, n, l):
     assert_phase_equal(out["phase"], oracle.phase(rows, exp_v), len(exp_v))
 
 
+def test_group_run_with_a_window_without_variants(oracle):
+    """One window of the group carries no variant at all (every read is the reference) and one is empty of coverage
+    in half of its columns: the grouped call / phase / id launches must leave exactly the oracle's (empty) answer for
+    them and the full answer for their neighbour."""
+    l = 240
+    genes = np.array([(1, l + 1)], dtype=capi.GENE)
+    ref = synth.reference(33, l)
+    n = 3000
+    rows_ref = np.tile(ref, (n, 1)).astype(np.uint8)                       # no variant
+    rows_mix = synth.rows(synth.SynthParams(seed=34, minor_permille=(60, 50, 40, 30)), l, 0, n, ref)
+    rows_half = rows_mix.copy()
+    rows_half[:, l // 2:] = 6                                              # right half not covered by any read
+    ctxs, rows_all = [], [rows_ref, rows_mix, rows_half]
+    for rows in rows_all:
+        j = capi.Juliet(0)
+        j.upload_columns(msa.pack_columns(rows), n)
+        j.sync()
+        ctxs.append(j)
+    grp = capi.Group(ctxs)
+    try:
+        for rep in range(2):
+            grp.run_async(genes, ref, capi.default_params(), True, 10, True)
+        for k, (j, rows) in enumerate(zip(ctxs, rows_all)):
+            exp_v = oracle.call(rows, genes, refseq=ref)
+            v = j.run_view()
+            assert v is not None
+            assert_variants_equal(v["variants"], exp_v)
+            assert_phase_equal(v["phase"], oracle.phase(rows, exp_v), len(exp_v))
+            if k == 0:
+                assert len(exp_v) == 0 and v["phase"]["summary"]["n_haplotypes"] == 0
+    finally:
+        grp.close()
+        for j in ctxs:
+            j.close()
+
+
 def test_group_run_with_genes_in_different_frames(oracle):
     """The grouped launches on the HIV-like layout above: chunks with and without halo columns in one pileup launch
     (the general path of pileup_group_kernel), three windows of different depth, majority-codon mode included."""
