@@ -72,8 +72,8 @@ def main():
 
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1600)   # 200 launches of 8 windows, about 43 ms timed: the 4-deep pipeline fills and drains inside the timed region
-    ap.add_argument("--warmup", type=int, default=32)
+    ap.add_argument("--steps", type=int, default=16000)   # 2000 launches of 8 windows, about 0.4 s timed (fill and drain of the 4-deep pipeline and the clocks' ramp are inside the timed region)
+    ap.add_argument("--warmup", type=int, default=64)
     ap.add_argument("--reads", type=int, default=N_READS)
     ap.add_argument("--cols", type=int, default=N_COLS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
