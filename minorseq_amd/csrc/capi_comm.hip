@@ -277,11 +277,14 @@ int jl_allgather_variants_async_many(jl_ctx *const *ctxs, uint32_t n, jl_comm *c
 {
     if (!ctxs || !c || n == 0 || n > JL_GATHER_MAX) return JL_ERR_ARG;
     std::vector<jl_comm_slot *> batch;
-    jl_comm_slot *run0 = comm_slot_free(c, n);   // n consecutive slots when there are (one copy, one event for the batch)
+    // n consecutive slots: the batch is then ONE all-gather.  Which protocol a batch uses must not depend on what
+    // happens to be free (every rank has to issue the same collectives), so there is no fall-back to n all-gathers.
+    jl_comm_slot *run0 = comm_slot_free(c, n);
+    if (!run0) return jl_fail(ctxs[0], JL_ERR_MEMORY, "no %u consecutive free exchange slots (%d per communicator): collect pending exchanges first", n, JL_COMM_SLOTS);
     for (uint32_t k = 0; k < n; ++k) {
         if (!ctxs[k]) return JL_ERR_ARG;
         jl_comm_slot *s = nullptr;
-        int rc = comm_request(ctxs[k], c, run0 ? run0 + k : nullptr, &s);
+        int rc = comm_request(ctxs[k], c, run0 + k, &s);
         if (rc) {
             for (jl_comm_slot *b : batch) { b->pending = false; b->ctx->exch_pending--; }
             return rc;
