@@ -146,6 +146,10 @@ int jl_msa_ingest_records(jl_ctx *ctx, uint64_t n_reads, uint32_t n_cols, uint32
 int jl_msa_download(jl_ctx *ctx, uint8_t *colpacked, uint64_t bytes);
 /* Fill the resident matrix with synthetic reads, on the device. `ref` = n_cols base codes (host). */
 int jl_synth_fill(jl_ctx *ctx, const jl_synth_params *sp, const uint8_t *ref);
+/* The same reads seen through a WINDOW of a longer reference (BASELINE.json configs[3]/[4]: one reference whose
+ * reads span every window): `ref` = ref_len base codes of the whole reference, the resident matrix is its columns
+ * [win_begin, win_begin + n_cols).  Windows filled with the same parameters hold the same reads. */
+int jl_synth_fill_window(jl_ctx *ctx, const jl_synth_params *sp, const uint8_t *ref, uint32_t ref_len);
 
 /* ---------------------------------------------------------------- call */
 

@@ -29,7 +29,7 @@ SUMMARY = np.dtype([(n, "<u4") for n in SUMMARY_FIELDS])
 # every symbol include/juliet_hip.h declares (checked by tests/test_capi_exports.py)
 EXPORTS = ("jl_abi_version", "jl_strerror", "jl_device_count", "jl_ctx_create", "jl_ctx_destroy", "jl_last_error",
            "jl_sync", "jl_col_stride", "jl_msa_upload", "jl_msa_alloc", "jl_msa_adopt", "jl_msa_pack_rows",
-           "jl_msa_ingest_records", "jl_msa_download", "jl_synth_fill", "jl_pileup_async", "jl_n_positions", "jl_pileup_fetch",
+           "jl_msa_ingest_records", "jl_msa_download", "jl_synth_fill", "jl_synth_fill_window", "jl_pileup_async", "jl_n_positions", "jl_pileup_fetch",
            "jl_consensus_fetch", "jl_call_async", "jl_call_fetch", "jl_variant_table_device", "jl_phase_async", "jl_phase_fetch",
            "jl_run_async", "jl_run_wait", "jl_run_done", "jl_run_view_get", "jl_group_create", "jl_group_destroy",
            "jl_group_last_error", "jl_group_run_async", "jl_group_time_pileup", "jl_fisher_eval", "jl_time_pileup", "jl_time_pileup_set", "jl_pileup_kernel_name", "jl_comm_unique_id", "jl_comm_create", "jl_comm_destroy",
@@ -117,6 +117,7 @@ def load_library(path=LIB_PATH):
     lib.jl_msa_ingest_records.argtypes = [vp, u64, u32, u32] + [vp] * 7 + [u32]
     lib.jl_msa_download.argtypes = [vp, vp, u64]
     lib.jl_synth_fill.argtypes = [vp, C.POINTER(SynthParams), vp]
+    lib.jl_synth_fill_window.argtypes = [vp, C.POINTER(SynthParams), vp, u32]
     lib.jl_pileup_async.argtypes = [vp, vp, u32, vp, u32]
     lib.jl_n_positions.argtypes = [vp]
     lib.jl_n_positions.restype = u32
@@ -239,6 +240,13 @@ class Juliet:
         ref = np.ascontiguousarray(ref, dtype=np.uint8)
         assert len(ref) == self.n_cols
         self._chk(self.lib.jl_synth_fill(self.h, C.byref(csp), _p(ref)))
+
+    def synth_fill_window(self, sp, ref_full):
+        """The window [win_begin, win_begin + n_cols) of the reads synth.rows(sp, len(ref_full), ...) describes."""
+        csp = SynthParams(sp.seed, sp.sub_rate, sp.del_rate, sp.mask_rate, sp.partial_rate,
+                          (C.c_uint32 * 4)(*sp.minor_permille), 0)
+        ref_full = np.ascontiguousarray(ref_full, dtype=np.uint8)
+        self._chk(self.lib.jl_synth_fill_window(self.h, C.byref(csp), _p(ref_full), len(ref_full)))
 
     def download_columns(self):
         out = np.empty((self.n_cols, self.col_stride), dtype=np.uint8)

@@ -306,23 +306,39 @@ int jl_msa_download(jl_ctx *ctx, uint8_t *colpacked, uint64_t bytes)
     return JL_OK;
 }
 
-int jl_synth_fill(jl_ctx *ctx, const jl_synth_params *sp, const uint8_t *ref)
+// `ref` holds ref_len base codes of the WHOLE reference; the resident matrix is its window [win_begin, win_begin + n_cols)
+static int synth_fill(jl_ctx *ctx, const jl_synth_params *sp, const uint8_t *ref, uint32_t ref_len, uint32_t col0)
 {
-    if (!ctx || !sp || !ref || !ctx->d_msa) return JL_ERR_ARG;
     jl_synth_plan plan;
-    jl_synth_make_plan(&plan, sp->seed, ctx->n_cols, sp->sub_rate, sp->del_rate, sp->mask_rate, sp->partial_rate,
+    jl_synth_make_plan(&plan, sp->seed, ref_len, sp->sub_rate, sp->del_rate, sp->mask_rate, sp->partial_rate,
                        sp->minor_permille, ref);
     uint8_t *d_ref = nullptr;
     JL_HIP(ctx, hipMalloc(&d_ref, ctx->n_cols));
-    hipError_t e = hipMemcpyAsync(d_ref, ref, ctx->n_cols, hipMemcpyHostToDevice, ctx->stream);
+    hipError_t e = hipMemcpyAsync(d_ref, ref + col0, ctx->n_cols, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) {
-        jl_launch_synth(ctx, &plan, d_ref);
+        jl_launch_synth(ctx, &plan, d_ref, col0);
         e = hipStreamSynchronize(ctx->stream);
     }
     hipFree(d_ref);
     if (e != hipSuccess) return jl_fail(ctx, JL_ERR_DEVICE, "synth_fill: %s", hipGetErrorString(e));
     ctx->pileup_done = ctx->call_done = ctx->phase_done = false;
+    ctx->pack_valid = false;
     return JL_OK;
+}
+
+int jl_synth_fill(jl_ctx *ctx, const jl_synth_params *sp, const uint8_t *ref)
+{
+    if (!ctx || !sp || !ref || !ctx->d_msa) return JL_ERR_ARG;
+    return synth_fill(ctx, sp, ref, ctx->n_cols, 0);
+}
+
+int jl_synth_fill_window(jl_ctx *ctx, const jl_synth_params *sp, const uint8_t *ref, uint32_t ref_len)
+{
+    if (!ctx || !sp || !ref || !ctx->d_msa) return JL_ERR_ARG;
+    if ((uint64_t)ctx->win_begin + ctx->n_cols > ref_len)
+        return jl_fail(ctx, JL_ERR_ARG, "window [%u, %u) is not inside the %u-column reference", ctx->win_begin,
+                       ctx->win_begin + ctx->n_cols, ref_len);
+    return synth_fill(ctx, sp, ref, ref_len, ctx->win_begin);
 }
 
 /* ---------------------------------------------------------------- call */

@@ -299,7 +299,7 @@ int jl_launch_pileup_group(jl_ctx *const *ctxs, uint32_t n_win, const jl_win_pil
 void jl_launch_call_group(const jl_win_call *h_wins, uint32_t n_win, uint32_t max_blocks, hipStream_t st);
 void jl_launch_phase_group(const jl_win_phase *h_wins, uint32_t n_win, uint32_t max_blocks, hipStream_t st);
 void jl_launch_assign_group(const jl_win_phase *h_wins, uint32_t n_win, uint32_t max_read_blocks, bool to_host, hipStream_t st);
-void jl_launch_synth(jl_ctx *ctx, const jl_synth_plan *plan, const uint8_t *d_ref);
+void jl_launch_synth(jl_ctx *ctx, const jl_synth_plan *plan, const uint8_t *d_ref, uint32_t col0);
 void jl_launch_pack_rows(jl_ctx *ctx, const uint8_t *d_rows);
 void jl_launch_result_pack(jl_ctx *ctx, bool phasing, bool signal);
 void jl_launch_validate(jl_ctx *ctx, uint32_t *d_flag);

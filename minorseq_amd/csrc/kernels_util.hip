@@ -12,9 +12,10 @@ namespace {
 
 constexpr int kSynthColsPerBlock = 64;
 
+// `ref`, `msa`: the window's columns [col0, col0 + win_cols) of the pl.n_cols-column reference the plan describes
 __global__ __launch_bounds__(256) void synth_kernel(jl_synth_plan pl, const uint8_t *__restrict__ ref,
                                                      uint8_t *__restrict__ msa, uint64_t col_stride,
-                                                     uint64_t n_reads)
+                                                     uint64_t n_reads, uint32_t col0, uint32_t win_cols)
 {
     const uint64_t t = (uint64_t)blockIdx.x * 256u + threadIdx.x;  // dword index in a column
     if (t * 4u >= col_stride) return;
@@ -26,12 +27,12 @@ __global__ __launch_bounds__(256) void synth_kernel(jl_synth_plan pl, const uint
         else { hap[r] = 0; st[r] = 1; en[r] = 0; }  // empty range: padding reads are uncovered
     }
     const uint32_t c0 = blockIdx.y * kSynthColsPerBlock;
-    const uint32_t c1 = min(pl.n_cols, c0 + kSynthColsPerBlock);
+    const uint32_t c1 = min(win_cols, c0 + kSynthColsPerBlock);
     for (uint32_t c = c0; c < c1; ++c) {
         const uint32_t rb = ref[c];
         uint32_t w = 0;
 #pragma unroll
-        for (int r = 0; r < 8; ++r) w |= jl_synth_cell(&pl, t * 8u + r, c, hap[r], st[r], en[r], rb) << (4 * r);
+        for (int r = 0; r < 8; ++r) w |= jl_synth_cell(&pl, t * 8u + r, col0 + c, hap[r], st[r], en[r], rb) << (4 * r);
         *reinterpret_cast<uint32_t *>(msa + (uint64_t)c * col_stride + t * 4u) = w;
     }
 }
@@ -315,12 +316,12 @@ void jl_launch_ingest(jl_ctx *ctx, const int32_t *d_pos, const uint32_t *d_cigar
                        ctx->col_stride);
 }
 
-void jl_launch_synth(jl_ctx *ctx, const jl_synth_plan *plan, const uint8_t *d_ref)
+void jl_launch_synth(jl_ctx *ctx, const jl_synth_plan *plan, const uint8_t *d_ref, uint32_t col0)
 {
     const uint32_t n_dwords = (uint32_t)(ctx->col_stride / 4u);
     dim3 grid((n_dwords + 255u) / 256u, (ctx->n_cols + kSynthColsPerBlock - 1) / kSynthColsPerBlock);
     hipLaunchKernelGGL(synth_kernel, grid, dim3(256), 0, ctx->stream, *plan, d_ref, ctx->d_msa, ctx->col_stride,
-                       ctx->n_reads);
+                       ctx->n_reads, col0, ctx->n_cols);
 }
 
 void jl_launch_pack_rows(jl_ctx *ctx, const uint8_t *d_rows)

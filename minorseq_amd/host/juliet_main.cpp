@@ -13,6 +13,7 @@
 #include <iostream>
 
 #include "config.hpp"
+#include "format.hpp"
 #include "msa_builder.hpp"
 
 using namespace jlhost;
@@ -171,8 +172,7 @@ std::string render_html(const Json &root, const std::string &json_text)
                 for (const Json &vp : vps->arr)
                     for (const Json &aa : vp.get("variant_amino_acids")->arr)
                         for (const Json &vc : aa.get("variant_codons")->arr) {
-                            char pc[32];
-                            snprintf(pc, sizeof pc, "%.2g", 100.0 * vc.get("frequency")->num);
+                            const std::string pc = format_percent(100.0 * vc.get("frequency")->num);
                             h += "<tr><td>" + vp.get_str("ref_codon") + "</td><td>" + vp.get_str("ref_amino_acid") + "</td><td>" +
                                  std::to_string((long)vp.get("ref_position")->num) + "</td><td>" + aa.get_str("amino_acid") + "</td><td>" +
                                  vc.get_str("codon") + "</td><td>" + pc + "</td><td>" + std::to_string((long)vp.get("coverage")->num) +
@@ -185,8 +185,7 @@ std::string render_html(const Json &root, const std::string &json_text)
         h += "<h2>Drug Summaries</h2><table><tr><th>Drug</th><th>Gene</th><th>Mutation</th><th>%</th></tr>\n";
         for (const Json &d : ds->arr)
             for (const Json &v : d.get("variants")->arr) {
-                char pc[32];
-                snprintf(pc, sizeof pc, "%.2g", 100.0 * v.get("frequency")->num);
+                const std::string pc = format_percent(100.0 * v.get("frequency")->num);
                 h += "<tr><td>" + html_escape(d.get_str("drug")) + "</td><td>" + html_escape(v.get_str("gene")) + "</td><td>" +
                      v.get_str("mutation") + "</td><td>" + pc + "</td></tr>\n";
             }
@@ -420,6 +419,8 @@ int main(int argc, char **argv)
                     const char aa = translate(var[k].codon);
                     if (std::find(order.begin(), order.end(), aa) == order.end()) order.push_back(aa);
                 }
+                // amino acids in alphabetical order: juliet_abl-nohaplotype.png prints "A GCC" above "P CCA" at ABL1 223
+                std::sort(order.begin(), order.end());
                 for (char aa : order) {
                     Json aj = Json::object();
                     aj.set("amino_acid", Json::of(std::string(1, aa)));

@@ -17,7 +17,7 @@ int main(int argc, char **argv)
     uint32_t n_cols = 3000, ref_offset = 0;
     double sub = 1.75e-4, del = 1.3e-3, mask = 2.0e-2, partial = 0.0;
     uint32_t minor[4] = {10, 10, 10, 10};
-    std::string out, cfg_out;
+    std::string out, cfg_out, from_rows, ref_string;
     bool rich_qv = false;  // filtered bases keep their letter and get a low substitution QV (sq tag) instead of 'N'
     for (int i = 1; i < argc; ++i) {
         const std::string a = argv[i];
@@ -32,11 +32,61 @@ int main(int argc, char **argv)
         else if (a == "--minor-permille") { for (int k = 0; k < 4; ++k) minor[k] = (uint32_t)std::stoul(need()); }
         else if (a == "--ref-offset") ref_offset = (uint32_t)std::stoul(need());  // window starts here in a longer reference
         else if (a == "--rich-qv") rich_qv = true;
+        else if (a == "--from-rows") from_rows = need();   // a matrix in the --dump-msa format instead of the generator
+        else if (a == "--ref") ref_string = need();        // its reference bases (ACGT), one per column
         else if (a == "-o") out = need();
         else if (a == "--config-out") cfg_out = need();
         else { std::cerr << "usage: juliet-synth --reads N --cols L --seed S [--partial p] [--minor-permille a b c d] [--ref-offset k] -o out.bam [--config-out cfg.json]\n"; return 1; }
     }
     if (out.empty()) { std::cerr << "juliet-synth: -o out.bam is required\n"; return 1; }
+    if (!from_rows.empty()) {
+        // Any by-row matrix (codes 0..6, header {n_reads, n_cols, win_begin} as written by `juliet --dump-msa`) as a
+        // PacBio-style BAM: tests send hand-built alignments (the reference's printed scenarios) through the tool.
+        std::ifstream f(from_rows, std::ios::binary);
+        uint64_t hdr[3];
+        if (!f.read((char *)hdr, sizeof hdr)) { std::cerr << "juliet-synth: cannot read " << from_rows << "\n"; return 2; }
+        const uint64_t n = hdr[0], l = hdr[1], wb = hdr[2];
+        std::vector<uint8_t> m((size_t)n * l);
+        if (!f.read((char *)m.data(), (std::streamsize)m.size())) { std::cerr << "juliet-synth: short matrix\n"; return 2; }
+        if (ref_string.size() != l) { std::cerr << "juliet-synth: --ref needs one base per column\n"; return 1; }
+        const uint32_t rl = (uint32_t)(wb + l);
+        const std::string header = "@HD\tVN:1.5\tSO:unknown\tpb:3.0.1\n@SQ\tSN:ref\tLN:" + std::to_string(rl) +
+                                   "\n@RG\tID:rows\tPL:PACBIO\tPM:SEQUEL\tDS:READTYPE=CCS\n";
+        BamWriter bw(out, header, {{"ref", rl}});
+        for (uint64_t i = 0; i < n; ++i) {
+            const uint8_t *row = m.data() + (size_t)i * l;
+            uint64_t st = 0, en = l;
+            while (st < l && row[st] == 6) ++st;
+            while (en > st && row[en - 1] == 6) --en;
+            if (st == en) continue;   // a read that covers nothing has no record
+            BamRecord r;
+            r.ref_id = 0;
+            r.pos = (int32_t)(wb + st);
+            r.mapq = 254;
+            r.name = "rows/" + std::to_string(i) + "/ccs";
+            r.rq = 0.999f;
+            uint32_t run_op = 99, run_len = 0;
+            auto flush = [&]() { if (run_len) r.cigar.push_back(run_len << 4 | run_op); run_len = 0; };
+            for (uint64_t c = st; c < en; ++c) {
+                const uint8_t sy = row[c];
+                uint32_t op;
+                if (sy == 4) op = CIG_D;
+                else if (sy == 6) op = CIG_N;
+                else {
+                    const uint8_t rb = base_code(ref_string[c]);
+                    op = (sy < 4 && sy == rb) ? CIG_EQ : CIG_X;
+                    r.seq.push_back(sy < 4 ? sy : (uint8_t)4);
+                    r.qual.push_back(93);
+                }
+                if (op != run_op) { flush(); run_op = op; }
+                ++run_len;
+            }
+            flush();
+            bw.write(r);
+        }
+        bw.close();
+        return 0;
+    }
     std::vector<uint8_t> ref(n_cols);
     jl_synth_reference(seed, n_cols, ref.data());
     jl_synth_plan pl;

@@ -119,3 +119,36 @@ def test_min_rq_filter_reads_the_rq_tag(tmp_path):
     assert rows.shape[0] == 200
     r = subprocess.run([JULIET, "--min-rq", "0.9995", "--dump-msa", msa_out, bam], capture_output=True, text=True)
     assert r.returncode == 2 and "no primary or supplementary alignments" in r.stderr
+
+
+def test_from_rows_bam_roundtrip(tmp_path):
+    """`juliet-synth --from-rows`: any by-row matrix (gaps, filtered bases, ragged ends, interior reference skips) as a
+    PacBio-style BAM; `juliet --dump-msa` reads back exactly that matrix.  The scenario tests use this path."""
+    rng = np.random.default_rng(3)
+    n, l = 300, 60
+    rows = rng.integers(0, 4, size=(n, l), dtype=np.uint8)
+    rows[rng.random((n, l)) < 0.05] = 4
+    rows[rng.random((n, l)) < 0.05] = 5
+    for i in range(0, n, 7):
+        rows[i, : rng.integers(1, 20)] = 6
+        rows[i, l - rng.integers(1, 20):] = 6
+    rows[5, 20:30] = 6                       # an interior stretch the read does not cover (cigar N)
+    rows[:, 0][rows[:, 0] == 4] = 0          # a record cannot start or end with a deletion
+    rows[:, -1][rows[:, -1] == 4] = 0
+    for i in range(n):
+        cov = np.nonzero(rows[i] != 6)[0]
+        if rows[i, cov[0]] == 4:
+            rows[i, cov[0]] = 1
+        if rows[i, cov[-1]] == 4:
+            rows[i, cov[-1]] = 2
+    ref = rng.integers(0, 4, size=l, dtype=np.uint8)
+    mpath, bam, cfg, back = (str(tmp_path / x) for x in ("m.msa", "m.bam", "m.json", "back.msa"))
+    with open(mpath, "wb") as f:
+        f.write(np.array([n, l, 0], dtype=np.uint64).tobytes())
+        f.write(rows.tobytes())
+    refs = "".join("ACGT"[b] for b in ref)
+    subprocess.check_call([SYNTH, "--from-rows", mpath, "--ref", refs, "-o", bam])
+    json.dump({"genes": [{"name": "g", "begin": 1, "end": l + 1}], "referenceName": "r", "referenceSequence": refs}, open(cfg, "w"))
+    subprocess.check_call([JULIET, "-c", cfg, "--dump-msa", back, bam])
+    got, wb = read_msa(back)
+    assert wb == 0 and got.shape == (n, l) and (got == rows).all()
