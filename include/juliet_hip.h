@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define JL_ABI_VERSION 2
+#define JL_ABI_VERSION 3
 
 /* symbol codes of the MSA (SPEC §1; J:99-100, 256-259, 372-381) */
 enum { JL_SYM_A = 0, JL_SYM_C = 1, JL_SYM_G = 2, JL_SYM_T = 3, JL_SYM_GAP = 4, JL_SYM_MASK = 5, JL_SYM_NONE = 6 };
@@ -62,7 +62,7 @@ typedef struct {
     double n_tests;         /* Bonferroni factor; <= 0 selects sum of codons over all genes passed to jl_pileup */
     jl_error_model err;
     int32_t expected_round; /* 0 ceil (default), 1 floor, 2 nearest */
-    int32_t tail;           /* 0 one-sided greater (only mode implemented) */
+    int32_t tail;           /* 0 one-sided greater (default), 1 two-sided */
     double min_perc;        /* --min-perc: keep 100*count/coverage >  min_perc; < 0 disables (J:342-344) */
     double max_perc;        /* --max-perc: keep 100*count/coverage <  max_perc; < 0 disables (J:352-354) */
 } jl_params;
@@ -243,22 +243,33 @@ typedef struct {
     const uint8_t *hap_pattern;   /* [H][Vp] */
     const uint8_t *hit;           /* [n_var_phase][H] (haplotype_hit, J:207-209) */
     const uint32_t *cooc;         /* [n_var_phase][n_var_phase], NULL if it did not fit */
-    const uint16_t *read_hap;     /* [n_reads], NULL unless the run asked for the per-read ids */
+    /* Per-read haplotype ids (the haplotype block's read lists, J:209-211), NULL / 0 unless the run asked for them.
+     * They cross PCIe in the narrowest code that holds H: read_hap_bits = 4 (H <= 14: haplotype 0..13, 14 = insufficient
+     * coverage, 15 = damaged; read i in bits 4*(i&1).. of byte i/2), 8 (H <= 254: 254 insufficient, 255 damaged) or
+     * 16 (the ids themselves, JL_HAP_INSUFFICIENT / JL_HAP_DAMAGED).  `read_hap` is set only for 16-bit ids;
+     * jl_phase_fetch and jl_expand_read_hap give 16-bit ids for every width. */
+    const uint16_t *read_hap;
+    const void *read_hap_packed;
+    uint32_t read_hap_bits;
+    uint32_t reserved;
 } jl_run_view;
 int jl_run_view_get(jl_ctx *ctx, jl_run_view *out);
+/* Packed per-read ids of a view (read_hap_packed, read_hap_bits) -> out[n_reads] 16-bit ids.  Host only. */
+int jl_expand_read_hap(const void *packed, uint32_t bits, uint64_t n_reads, uint16_t *out);
 
 /*
- * Group runs: the whole path for SEVERAL (at most 32) resident windows (one context each, same device) in three launches —
- * one pileup stream over all windows, one Fisher/compaction launch, one phasing launch (blockIdx.z = window).
- * A 150 MB window is too short a stream to hide a launch's ramp and drain, and its Fisher and phasing stages are
- * latency chains that occupy a hardware queue while doing little; grouped, the pileup runs at the rate of one long
- * stream and the latency chains of all windows overlap.  Results are per window and identical to jl_run_async on
- * each context: every context keeps its own result block, per-read ids and completion word, so jl_run_wait,
- * jl_run_done, jl_run_view_get, jl_call_fetch, jl_phase_fetch and jl_allgather_variants_async apply unchanged.
- * All windows get the same genes / reference / parameters (they are windows of one reference, or samples of one
- * amplicon).  Limits: call + phase only, no --drm-only masks (they are per window: use jl_run_async); a window with more than 10
- * variant positions is flagged as in jl_run_async (its fetch calls then re-run the multi-word pipeline).  Every
- * window is counted by one block per column chunk, so windows of millions of reads are better run one by one.
+ * Group runs: the whole path for SEVERAL (at most 32) resident windows (one context each, same device) in a few launches —
+ * per stage ONE launch for up to eight windows (blockIdx.z = window): counting with the Fisher stage in its epilogue,
+ * phasing, per-read ids.  A 150 MB window is too short a stream to hide a launch's ramp and drain, and its phasing stage
+ * is a latency chain that occupies a hardware queue while doing little; grouped, the pileup runs at the rate of one long
+ * stream and the latency chains of all windows overlap.  Groups of more than eight windows are pipelined inside the
+ * launch: the counting of the next eight runs beside the phasing of the previous eight.
+ * Results are per window and identical to jl_run_async on each context: every context keeps its own result block,
+ * per-read ids and completion word, so jl_run_wait, jl_run_done, jl_run_view_get, jl_call_fetch, jl_phase_fetch and
+ * jl_allgather_variants_async apply unchanged.  All windows get the same genes / reference / parameters (they are windows
+ * of one reference, or samples of one amplicon); phasing may be off (call only).  A window with more than 10 variant
+ * positions is flagged as in jl_run_async (its fetch calls then re-run the multi-word pipeline).  Every window is counted
+ * by one block per column chunk, so windows of millions of reads are better run one by one.
  * The contexts' own streams must be idle (uploads finished).
  */
 typedef struct jl_group jl_group;
@@ -267,6 +278,11 @@ void jl_group_destroy(jl_group *group);
 const char *jl_group_last_error(const jl_group *group);
 int jl_group_run_async(jl_group *group, const jl_gene *genes, uint32_t n_genes, const uint8_t *refseq, uint32_t ref_len,
                        const jl_params *prm, int phasing, uint32_t min_reads, int want_read_hap);
+/* The same with --drm-only masks per window (J:370): drm_masks[k] = [P] 64-bit codon masks of window k as in
+ * jl_call_async, or NULL for a window without; drm_masks itself may be NULL. */
+int jl_group_run_masked_async(jl_group *group, const jl_gene *genes, uint32_t n_genes, const uint8_t *refseq,
+                              uint32_t ref_len, const jl_params *prm, const uint64_t *const *drm_masks, int phasing,
+                              uint32_t min_reads, int want_read_hap);
 /* Timing hook (bench): average device time in ms of the grouped pileup launch alone, `reps` back-to-back launches
  * rotating over `groups` (each must have run once); `bytes_per_launch` = algorithmic bytes of one launch of groups[0]. */
 int jl_group_time_pileup(jl_group *const *groups, uint32_t n_groups, uint32_t reps, float *ms_avg, uint64_t *bytes_per_launch);
@@ -280,6 +296,9 @@ int jl_group_time_pileup(jl_group *const *groups, uint32_t n_groups, uint32_t re
  */
 int jl_fisher_eval(jl_ctx *ctx, const uint32_t *a, const uint32_t *c, const uint32_t *cov, uint32_t n, double *p,
                    double *log_p);
+/* The same with the tail of jl_params: 0 = P(X >= a), 1 = two-sided. */
+int jl_fisher_eval_tail(jl_ctx *ctx, const uint32_t *a, const uint32_t *c, const uint32_t *cov, uint32_t n, int tail,
+                        double *p, double *log_p);
 
 /* ---------------------------------------------------------------- timing hooks (bench) */
 

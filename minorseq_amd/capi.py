@@ -32,7 +32,7 @@ EXPORTS = ("jl_abi_version", "jl_strerror", "jl_device_count", "jl_ctx_create", 
            "jl_msa_ingest_records", "jl_msa_download", "jl_synth_fill", "jl_synth_fill_window", "jl_pileup_async", "jl_n_positions", "jl_pileup_fetch",
            "jl_consensus_fetch", "jl_call_async", "jl_call_fetch", "jl_variant_table_device", "jl_phase_async", "jl_phase_fetch",
            "jl_run_async", "jl_run_wait", "jl_run_done", "jl_run_view_get", "jl_group_create", "jl_group_destroy",
-           "jl_group_last_error", "jl_group_run_async", "jl_group_time_pileup", "jl_fisher_eval", "jl_time_pileup", "jl_time_pileup_set", "jl_pileup_kernel_name", "jl_comm_unique_id", "jl_comm_create", "jl_comm_destroy",
+           "jl_group_last_error", "jl_group_run_async", "jl_group_run_masked_async", "jl_group_time_pileup", "jl_fisher_eval", "jl_fisher_eval_tail", "jl_expand_read_hap", "jl_time_pileup", "jl_time_pileup_set", "jl_pileup_kernel_name", "jl_comm_unique_id", "jl_comm_create", "jl_comm_destroy",
            "jl_allgather_variants", "jl_allgather_variants_async", "jl_allgather_variants_async_many", "jl_xwin_assemble_local",
            "jl_xwin_assemble_rccl")
 
@@ -61,7 +61,8 @@ class RunView(C.Structure):
                 ("n_positions", C.c_uint32), ("n_haplotypes", C.c_uint32), ("n_var_phase", C.c_uint32),
                 ("n_reads", C.c_uint64), ("summary", PhaseSummary), ("variants", C.c_void_p),
                 ("pos_cols", C.c_void_p), ("hap_count", C.c_void_p), ("hap_pattern", C.c_void_p),
-                ("hit", C.c_void_p), ("cooc", C.c_void_p), ("read_hap", C.c_void_p)]
+                ("hit", C.c_void_p), ("cooc", C.c_void_p), ("read_hap", C.c_void_p), ("read_hap_packed", C.c_void_p),
+                ("read_hap_bits", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 def _view(addr, dtype, count):
@@ -76,9 +77,34 @@ ERROR_MODELS = {  # docs/SPEC.md §5 (values UNPINNED)
 }
 
 
-def default_params(n_tests=0.0, alpha=0.01, chemistry="sequel", min_perc=-1.0, max_perc=-1.0, expected_round=0):
+def default_params(n_tests=0.0, alpha=0.01, chemistry="sequel", min_perc=-1.0, max_perc=-1.0, expected_round=0, tail=0):
     m, s, d = ERROR_MODELS[chemistry]
-    return Params(alpha, n_tests, ErrorModel(m, s, d), expected_round, 0, min_perc, max_perc)
+    return Params(alpha, n_tests, ErrorModel(m, s, d), expected_round, tail, min_perc, max_perc)
+
+
+def expand_ids(packed, bits, n_reads):
+    """Per-read haplotype ids as the kernels store them (4 / 8 / 16 bits per read, include/juliet_hip.h jl_run_view) ->
+    uint16 ids (HAP_INSUFFICIENT / HAP_DAMAGED for the two unreported categories)."""
+    if bits == 16:
+        return packed.view(np.uint16)[:n_reads]
+    p = packed.view(np.uint8)
+    if bits == 4:
+        b = p[: (n_reads + 1) // 2]
+        c = np.empty(2 * len(b), dtype=np.uint16)
+        c[0::2] = b & 15
+        c[1::2] = b >> 4
+        c = c[:n_reads]
+        out = c.copy()
+        out[c == 14] = HAP_INSUFFICIENT
+        out[c == 15] = HAP_DAMAGED
+        return out
+    if bits == 8:
+        c = p[:n_reads].astype(np.uint16)
+        out = c.copy()
+        out[c == 254] = HAP_INSUFFICIENT
+        out[c == 255] = HAP_DAMAGED
+        return out
+    raise ValueError(f"per-read ids of width {bits}")
 
 
 class JulietError(RuntimeError):
@@ -135,11 +161,14 @@ def load_library(path=LIB_PATH):
     lib.jl_group_last_error.argtypes = [vp]
     lib.jl_group_last_error.restype = C.c_char_p
     lib.jl_group_run_async.argtypes = [vp, vp, u32, vp, u32, C.POINTER(Params), C.c_int, u32, C.c_int]
+    lib.jl_group_run_masked_async.argtypes = [vp, vp, u32, vp, u32, C.POINTER(Params), vp, C.c_int, u32, C.c_int]
     lib.jl_group_time_pileup.argtypes = [vp, u32, u32, C.POINTER(C.c_float), C.POINTER(u64)]
     lib.jl_run_wait.argtypes = [vp]
     lib.jl_run_done.argtypes = [vp]
     lib.jl_run_view_get.argtypes = [vp, C.POINTER(RunView)]
     lib.jl_fisher_eval.argtypes = [vp, vp, vp, vp, u32, vp, vp]
+    lib.jl_fisher_eval_tail.argtypes = [vp, vp, vp, vp, u32, C.c_int, vp, vp]
+    lib.jl_expand_read_hap.argtypes = [vp, u32, u64, vp]
     lib.jl_time_pileup.argtypes = [vp, u32, C.POINTER(C.c_float)]
     lib.jl_time_pileup_set.argtypes = [vp, u32, u32, C.POINTER(C.c_float)]
     lib.jl_comm_unique_id.argtypes = [vp]
@@ -151,7 +180,7 @@ def load_library(path=LIB_PATH):
     lib.jl_allgather_variants_async_many.argtypes = [vp, u32, vp]
     lib.jl_xwin_assemble_local.argtypes = [vp, vp, u32, vp, u32, vp, vp, C.POINTER(u32)]
     lib.jl_xwin_assemble_rccl.argtypes = [vp, vp, vp, vp, vp, vp, u32, vp, vp, C.POINTER(u32)]
-    if lib.jl_abi_version() != 2:
+    if lib.jl_abi_version() != 3:
         raise ImportError("libjuliet_hip.so ABI version mismatch")
     _lib = lib
     return lib
@@ -159,6 +188,36 @@ def load_library(path=LIB_PATH):
 
 def _p(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class _LazyIds:
+    """The per-read ids of a run view: packed bytes in pinned memory + their width; expands to uint16 on first use
+    (a step loop that only reads the small results never touches them)."""
+
+    def __init__(self, packed, bits, n_reads):
+        self.packed, self.bits, self.n_reads = packed, int(bits), int(n_reads)
+        self._ids = None
+
+    def ids(self):
+        if self._ids is None:
+            self._ids = expand_ids(self.packed, self.bits, self.n_reads)
+        return self._ids
+
+    def __array__(self, dtype=None, copy=None):
+        a = self.ids()
+        return a if dtype is None else a.astype(dtype)
+
+    def __eq__(self, other):
+        return self.ids() == other
+
+    def __getitem__(self, k):
+        return self.ids()[k]
+
+    def __len__(self):
+        return self.n_reads
+
+    def copy(self):
+        return self.ids().copy()
 
 
 class Juliet:
@@ -318,11 +377,11 @@ class Juliet:
         return dict(summary=s, pos_cols=pos_cols[:vp].copy(), hap_count=hap_count[:h].copy(),
                     hap_pattern=hap_pattern[:h, :vp].copy(), hit=hit, read_hap=read_hap, cooc=cooc)
 
-    def fisher_eval(self, a, c, cov):
+    def fisher_eval(self, a, c, cov, tail=0):
         a, c, cov = (np.ascontiguousarray(x, dtype=np.uint32) for x in (a, c, cov))
         p = np.zeros(len(a), dtype=np.float64)
         lp = np.zeros(len(a), dtype=np.float64)
-        self._chk(self.lib.jl_fisher_eval(self.h, _p(a), _p(c), _p(cov), len(a), _p(p), _p(lp)))
+        self._chk(self.lib.jl_fisher_eval_tail(self.h, _p(a), _p(c), _p(cov), len(a), tail, _p(p), _p(lp)))
         return p, lp
 
     def sync(self):
@@ -412,7 +471,7 @@ class Juliet:
             self._chk(rc)
         if not v.complete:
             return None
-        key = (v.variants, v.read_hap, v.n_reads, v.phased)
+        key = (v.variants, v.read_hap_packed, v.n_reads, v.phased)
         c = self._rv_cache.get(key)
         if c is None:   # base arrays over the whole block, built once per allocation
             c = dict(variants=_view(v.variants, VARIANT, 128))
@@ -420,7 +479,7 @@ class Juliet:
                 c.update(pos_cols=_view(v.pos_cols, np.uint32, 128), hap_count=_view(v.hap_count, np.uint32, 128),
                          hap_pattern=_view(v.hap_pattern, np.uint8, 4096), hit=_view(v.hit, np.uint8, 4096),
                          cooc=_view(v.cooc, np.uint32, 1024) if v.cooc else None,
-                         read_hap=_view(v.read_hap, np.uint16, v.n_reads) if v.read_hap else None)
+                         ids=_view(v.read_hap_packed, np.uint8, 2 * v.n_reads) if v.read_hap_packed else None)
             self._rv_cache = {key: c}
         nv = v.n_variants
         out = dict(variants=c["variants"][:nv])
@@ -429,7 +488,8 @@ class Juliet:
             s = {n: getattr(v.summary, n) for n in SUMMARY_FIELDS}
             out["phase"] = dict(summary=s, pos_cols=c["pos_cols"][:vp], hap_count=c["hap_count"][:h],
                                 hap_pattern=c["hap_pattern"][:h * vp].reshape(h, vp),
-                                hit=c["hit"][:nvp * h].reshape(nvp, h), read_hap=c["read_hap"],
+                                hit=c["hit"][:nvp * h].reshape(nvp, h),
+                                read_hap=_LazyIds(c["ids"], v.read_hap_bits, v.n_reads) if c["ids"] is not None else None,
                                 cooc=None if c["cooc"] is None or not v.cooc else c["cooc"][:nvp * nvp].reshape(nvp, nvp))
         return out
 
@@ -501,6 +561,18 @@ class Group:
         if getattr(self, "h", None):
             self.lib.jl_group_destroy(self.h)
             self.h = None
+
+    def run_masked_async(self, genes, refseq, params, drm_masks, phasing=True, min_reads=10, want_read_hap=True):
+        """drm_masks: one uint64[P] array (or None) per window (--drm-only, doc/JULIET.md:370)."""
+        g = np.ascontiguousarray(genes, dtype=GENE)
+        r = None if refseq is None else np.ascontiguousarray(refseq, dtype=np.uint8)
+        prm = params or default_params()
+        keep = [None if m is None else np.ascontiguousarray(m, dtype=np.uint64) for m in drm_masks]
+        arr = (C.c_void_p * len(keep))(*[None if m is None else m.ctypes.data for m in keep])
+        rc = self.lib.jl_group_run_masked_async(self.h, _p(g), len(g), _p(r), 0 if r is None else len(r), C.byref(prm), arr,
+                                                1 if phasing else 0, min_reads, 1 if want_read_hap else 0)
+        if rc:
+            raise JulietError(rc, self.lib.jl_group_last_error(self.h).decode())
 
     def run_async(self, genes, refseq=None, params=None, phasing=True, min_reads=10, want_read_hap=True):
         key = (id(genes), id(refseq), id(params))

@@ -104,6 +104,7 @@ int jl_ctx_create(int device, void *stream, jl_ctx **out)
               hipMalloc(&ctx->d_cooc, sizeof(uint32_t) * ctx->cooc_cap * ctx->cooc_cap) == hipSuccess &&
               hipMalloc(&ctx->d_pack, 2 * sizeof(jl_pack)) == hipSuccess &&
               hipMalloc(&ctx->d_sync, 16 * sizeof(uint32_t)) == hipSuccess &&
+              hipMalloc(&ctx->d_callinfo, sizeof(jl_callinfo)) == hipSuccess &&
               hipHostMalloc(&ctx->h_pack, sizeof(jl_pack), hipHostMallocDefault) == hipSuccess &&
               hipHostMalloc((void **)&ctx->h_seq, 64, hipHostMallocDefault) == hipSuccess;
     if (!ok) { jl_ctx_destroy(ctx); return jl_fail(nullptr, JL_ERR_MEMORY, "context allocation failed"); }
@@ -139,7 +140,8 @@ void jl_ctx_destroy(jl_ctx *ctx)
                     ctx->d_counts, ctx->d_called, ctx->d_staged, ctx->d_drm, ctx->d_variants, ctx->d_nvar, ctx->d_meta, ctx->d_vpcols,
                     ctx->d_col2pos, ctx->d_varcol, ctx->d_keys, ctx->d_flagw, ctx->d_read_slot, ctx->d_read_hap,
                     ctx->d_slot_rep, ctx->d_slot_count, ctx->d_slot_key, ctx->d_slot_hap, ctx->d_occupied, ctx->d_hap_count,
-                    ctx->d_hap_pattern, ctx->d_hit, ctx->d_cooc, ctx->d_pack, ctx->d_sync, ctx->d_timeline};
+                    ctx->d_hap_pattern, ctx->d_hit, ctx->d_cooc, ctx->d_pack, ctx->d_sync, ctx->d_timeline,
+                    ctx->d_col_first, ctx->d_pos_next, ctx->d_callinfo};
     for (void *p : ptrs)
         if (p) hipFree(p);
     if (ctx->ev0) hipEventDestroy(ctx->ev0);
@@ -348,6 +350,7 @@ static int reserve_columns(jl_ctx *ctx)
 {
     int rc;
     if (ctx->col_capacity < ctx->n_cols) {
+        if ((rc = regrow(ctx, &ctx->d_col_first, ctx->n_cols))) return rc;
         if ((rc = regrow(ctx, &ctx->d_guess, (size_t)ctx->n_cols + JL_GUESS_PAD))) return rc;
         if ((rc = regrow(ctx, &ctx->d_col2pos, ctx->n_cols))) return rc;
         if ((rc = regrow(ctx, &ctx->d_varcol, ctx->n_cols))) return rc;
@@ -377,9 +380,11 @@ static void build_chunks(jl_ctx *ctx, const std::vector<uint8_t> &colflag, std::
     size_t crowded = 0;
     for (uint32_t c = 0; c + 2 < L; ++c)
         if ((colflag[c] & 1) && ((colflag[c + 1] & 1) || (colflag[c + 2] & 1))) ++crowded;
-    const char *env_w = getenv("JL_PILEUP_W");
     uint32_t W = (total && crowded * 4 > total) ? 6u : 3u;
-    if (env_w && *env_w) W = (uint32_t)atoi(env_w) % 100u;
+#ifdef JL_TUNING
+    if (const char *env_w = getenv("JL_PILEUP_W"))
+        if (*env_w) W = (uint32_t)atoi(env_w) % 100u;
+#endif
     if (W != 3 && W != 6 && W != 9 && W != 12) W = 3;
     (void)major;
     ctx->pileup_w = W;
@@ -460,6 +465,7 @@ static int build_plan(jl_ctx *ctx, const jl_gene *genes, uint32_t n_genes, const
         if ((rc = regrow(ctx, &ctx->d_called, P))) return rc;
         if ((rc = regrow(ctx, &ctx->d_staged, P * 64))) return rc;
         if ((rc = regrow(ctx, &ctx->d_drm, P))) return rc;
+        if ((rc = regrow(ctx, &ctx->d_pos_next, P))) return rc;
         ctx->pos_capacity = P;
     }
     ctx->n_chunks = (uint32_t)chunk_c0.size();
@@ -478,7 +484,17 @@ static int build_plan(jl_ctx *ctx, const jl_gene *genes, uint32_t n_genes, const
         const uint32_t meta = n | (startf << 4) | (halo << 16);
         recs[k] = (uint64_t)c0 | ((uint64_t)meta << 32);
     }
+    // positions by start column: the workgroup that counts a codon evaluates every position that starts there
+    // (several when genes overlap in one frame), in position order
+    std::vector<uint32_t> col_first(ctx->n_cols, 0xFFFFFFFFu), pos_next(P, 0xFFFFFFFFu);
+    for (uint32_t q = ctx->P; q-- > 0;) {
+        const uint32_t c = ctx->h_pos_col[q];
+        pos_next[q] = col_first[c];
+        col_first[c] = q;
+    }
     hipStream_t st = ctx->stream;
+    JL_HIP(ctx, hipMemcpyAsync(ctx->d_col_first, col_first.data(), (size_t)ctx->n_cols * 4, hipMemcpyHostToDevice, st));
+    JL_HIP(ctx, hipMemcpyAsync(ctx->d_pos_next, pos_next.data(), P * 4, hipMemcpyHostToDevice, st));
     JL_HIP(ctx, hipMemcpyAsync(ctx->d_chunks, recs.data(), recs.size() * 8, hipMemcpyHostToDevice, st));
     // the pad behind the last column is zero; in majority mode guess_kernel overwrites [0, n_cols) only
     JL_HIP(ctx, hipMemcpyAsync(ctx->d_guess, guess.data(), guess.size(), hipMemcpyHostToDevice, st));
@@ -492,6 +508,28 @@ static int build_plan(jl_ctx *ctx, const jl_gene *genes, uint32_t n_genes, const
     JL_HIP(ctx, hipStreamSynchronize(st));
     ctx->plan_valid = true;
     ctx->plan_version++;
+    ctx->callinfo_host.clear();
+    return JL_OK;
+}
+
+// The Fisher stage inside the pileup launch reads its parameters and tables from ctx->d_callinfo: refresh it when
+// anything in it changed (it is part of what a captured graph replays, so the copy is ordered before the launch).
+int jl_update_callinfo(jl_ctx *ctx, const jl_params *prm, double n_tests, bool use_drm, bool with_meta)
+{
+    jl_callinfo ci;
+    memset(&ci, 0, sizeof ci);
+    jl_fill_call_args(ctx, prm, n_tests, &ci.A);
+    ci.col_first = ctx->d_col_first; ci.pos_next = ctx->d_pos_next;
+    ci.pos_gene = ctx->d_pos_gene; ci.pos_codon = ctx->d_pos_codon; ci.pos_refcfg = ctx->d_pos_refcfg;
+    ci.drm = use_drm ? ctx->d_drm : nullptr;
+    ci.called = ctx->d_called; ci.staged = ctx->d_staged;
+    ci.meta = with_meta ? ctx->d_meta : nullptr;
+    if (ctx->callinfo_host.size() == sizeof ci && memcmp(ctx->callinfo_host.data(), &ci, sizeof ci) == 0) return JL_OK;
+    // the previous run of this context may still read the block: wait for it (a change of parameters, not the hot path)
+    JL_HIP(ctx, hipStreamSynchronize(ctx->run_stream ? ctx->run_stream : ctx->stream));
+    JL_HIP(ctx, hipMemcpyAsync(ctx->d_callinfo, &ci, sizeof ci, hipMemcpyHostToDevice, ctx->stream));
+    JL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->callinfo_host.assign((const uint8_t *)&ci, (const uint8_t *)&ci + sizeof ci);
     return JL_OK;
 }
 
@@ -516,7 +554,7 @@ int jl_pileup_async(jl_ctx *ctx, const jl_gene *genes, uint32_t n_genes, const u
     if (jl_pileup_needs_zero(ctx))
         JL_HIP(ctx, hipMemsetAsync(ctx->d_counts, 0, ctx->counts_words * sizeof(uint32_t), ctx->stream));
     if (!ctx->have_ref) jl_launch_guess(ctx, ctx->stream);
-    jl_launch_pileup(ctx, ctx->stream);
+    jl_launch_pileup(ctx, ctx->stream, false);
     JL_HIP(ctx, hipGetLastError());
     ctx->pileup_done = true;
     ctx->call_done = ctx->phase_done = false;
@@ -572,7 +610,7 @@ int jl_call_async(jl_ctx *ctx, const jl_params *prm, const uint64_t *drm_masks)
 {
     if (!ctx || !prm) return JL_ERR_ARG;
     if (!ctx->pileup_done) return jl_fail(ctx, JL_ERR_STATE, "jl_call_async before jl_pileup_async");
-    if (prm->tail != 0) return jl_fail(ctx, JL_ERR_ARG, "only the one-sided (greater) tail is implemented");
+    if (prm->tail != 0 && prm->tail != 1) return jl_fail(ctx, JL_ERR_ARG, "tail must be 0 (one-sided greater) or 1 (two-sided)");
     if (!(prm->alpha > 0.0) || !(prm->err.match > 0.0) || !(prm->err.substitution >= 0.0))
         return jl_fail(ctx, JL_ERR_ARG, "alpha/match must be > 0 and substitution >= 0");
     JL_HIP(ctx, hipSetDevice(ctx->device));
@@ -581,7 +619,8 @@ int jl_call_async(jl_ctx *ctx, const jl_params *prm, const uint64_t *drm_masks)
         JL_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
     const double n_tests = prm->n_tests > 0.0 ? prm->n_tests : ctx->default_n_tests;
-    jl_launch_call(ctx, prm, n_tests, drm_masks != nullptr, false);
+    jl_launch_call(ctx, ctx->stream, prm, n_tests, drm_masks != nullptr, false);
+    jl_launch_compact(ctx, ctx->stream, false, false, false);
     JL_HIP(ctx, hipGetLastError());
     ctx->call_done = true;
     ctx->phase_done = false;
@@ -692,10 +731,49 @@ int jl_phase_async(jl_ctx *ctx, const jl_variant *variants, uint32_t n_var, uint
     ctx->last_min_reads = min_reads;
     ctx->pack_mirror = nullptr;
     ctx->read_hap_out = nullptr;
-    jl_launch_phase(ctx, min_reads, false, false);
+    jl_launch_phase(ctx, ctx->stream, min_reads, false, false, false);
     JL_HIP(ctx, hipGetLastError());
     ctx->phase_done = true;
     ctx->pack_valid = false;
+    return JL_OK;
+}
+
+// per-read ids in their packed form -> 16-bit ids (JL_ID4_MAX_H / JL_ID8_MAX_H in jl_internal.h)
+void jl_expand_ids(const void *packed, uint32_t bits, uint64_t n_reads, uint16_t *out)
+{
+    if (bits == 4) {
+        const uint8_t *p = (const uint8_t *)packed;
+        for (uint64_t i = 0; i < n_reads; ++i) {
+            const uint32_t c = (p[i >> 1] >> (4u * (i & 1u))) & 15u;
+            out[i] = c == 15u ? (uint16_t)JL_HAP_DAMAGED : (c == 14u ? (uint16_t)JL_HAP_INSUFFICIENT : (uint16_t)c);
+        }
+    } else if (bits == 8) {
+        const uint8_t *p = (const uint8_t *)packed;
+        for (uint64_t i = 0; i < n_reads; ++i)
+            out[i] = p[i] == 255u ? (uint16_t)JL_HAP_DAMAGED : (p[i] == 254u ? (uint16_t)JL_HAP_INSUFFICIENT : (uint16_t)p[i]);
+    } else {
+        memcpy(out, packed, (size_t)n_reads * 2);
+    }
+}
+
+// the ids of the last phase launch: from the pinned block the kernels stored into, or copied out of HBM
+static int fetch_ids(jl_ctx *ctx, uint32_t bits, uint16_t *read_hap)
+{
+    if (bits != 4 && bits != 8 && bits != 16) return jl_fail(ctx, JL_ERR_STATE, "per-read ids of unknown width %u", bits);
+    if (ctx->read_hap_out) {
+        jl_expand_ids(ctx->h_read_hap, bits, ctx->n_reads, read_hap);
+        return JL_OK;
+    }
+    if (bits == 16) {
+        JL_HIP(ctx, hipMemcpyAsync(read_hap, ctx->d_read_hap, (size_t)ctx->n_reads * 2, hipMemcpyDeviceToHost, ctx->stream));
+        JL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        return JL_OK;
+    }
+    const size_t bytes = bits == 4 ? (size_t)(ctx->n_reads + 1) / 2 : (size_t)ctx->n_reads;
+    std::vector<uint8_t> tmp(bytes);
+    JL_HIP(ctx, hipMemcpyAsync(tmp.data(), ctx->d_read_hap, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    JL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    jl_expand_ids(tmp.data(), bits, ctx->n_reads, read_hap);
     return JL_OK;
 }
 
@@ -722,33 +800,39 @@ int jl_phase_fetch(jl_ctx *ctx, jl_phase_summary *summary, uint32_t *pos_cols, u
             if (cooc)
                 for (uint32_t v = 0; v < nv; ++v) memcpy(cooc + (size_t)v * cap_var, pk->cooc + (size_t)v * nv, (size_t)nv * 4);
             if (read_hap) {
-                if (ctx->read_hap_out) memcpy(read_hap, ctx->h_read_hap, (size_t)ctx->n_reads * 2);
-                else {
-                    JL_HIP(ctx, hipMemcpyAsync(read_hap, ctx->d_read_hap, (size_t)ctx->n_reads * 2, hipMemcpyDeviceToHost, st));
-                    JL_HIP(ctx, hipStreamSynchronize(st));
-                }
+                // a group run's stream is not the context's: its kernels are complete (the completion word), but a
+                // copy on the context stream must not overtake them in the eyes of the runtime
+                if (!ctx->read_hap_out && ctx->run_stream && ctx->run_stream != st) JL_HIP(ctx, hipStreamSynchronize(ctx->run_stream));
+                if (int rc = fetch_ids(ctx, pk->id_bits, read_hap)) return rc;
             }
             return JL_OK;
         }
     }
+    if (ctx->run_stream && ctx->run_stream != st) JL_HIP(ctx, hipStreamSynchronize(ctx->run_stream));
     jl_phase_meta meta;
-    const bool ids_pinned = ctx->read_hap_out != nullptr;  // the last phase launch stored them in h_read_hap
     JL_HIP(ctx, hipMemcpyAsync(&meta, ctx->d_meta, sizeof meta, hipMemcpyDeviceToHost, st));
-    if (read_hap && !ids_pinned) JL_HIP(ctx, hipMemcpyAsync(read_hap, ctx->d_read_hap, (size_t)ctx->n_reads * 2, hipMemcpyDeviceToHost, st));
     JL_HIP(ctx, hipStreamSynchronize(st));
     if (meta.overflow & 12u) {
         // more variant positions than the single-word kernels (bit 3) or the resident key buffer (bit 2) cover:
-        // switch to the generic pipeline / grow the buffer and run phasing again
+        // switch to the generic pipeline / grow the buffer and run phasing again (the variant table is resident)
         if (meta.vp_true > JL_POS_PER_WORD) ctx->phase_generic = true;
         int rc = reserve_phase(ctx, (meta.vp_true + JL_POS_PER_WORD - 1) / JL_POS_PER_WORD);
         if (rc) return rc;
-        jl_launch_phase(ctx, ctx->last_min_reads, false, false);
+        jl_launch_phase(ctx, st, ctx->last_min_reads, false, false, false);
         JL_HIP(ctx, hipGetLastError());
         JL_HIP(ctx, hipMemcpyAsync(&meta, ctx->d_meta, sizeof meta, hipMemcpyDeviceToHost, st));
-        if (read_hap && !ids_pinned) JL_HIP(ctx, hipMemcpyAsync(read_hap, ctx->d_read_hap, (size_t)ctx->n_reads * 2, hipMemcpyDeviceToHost, st));
         JL_HIP(ctx, hipStreamSynchronize(st));
+        if (meta.overflow & 4u) {   // the first re-run only learned the true number of positions: now with room for them
+            rc = reserve_phase(ctx, (meta.vp_true + JL_POS_PER_WORD - 1) / JL_POS_PER_WORD);
+            if (rc) return rc;
+            jl_launch_phase(ctx, st, ctx->last_min_reads, false, false, false);
+            JL_HIP(ctx, hipGetLastError());
+            JL_HIP(ctx, hipMemcpyAsync(&meta, ctx->d_meta, sizeof meta, hipMemcpyDeviceToHost, st));
+            JL_HIP(ctx, hipStreamSynchronize(st));
+        }
     }
-    if (read_hap && ids_pinned) memcpy(read_hap, ctx->h_read_hap, (size_t)ctx->n_reads * 2);
+    if (read_hap)
+        if (int rc = fetch_ids(ctx, meta.id_bits, read_hap)) return rc;
     if (summary) *summary = meta.summary;
     const uint32_t vp = meta.vp, H = meta.summary.n_haplotypes, nv = meta.n_var;
     if ((pos_cols || hap_pattern) && vp > cap_var) return jl_fail(ctx, JL_ERR_OVERFLOW, "%u variant positions, caller capacity %u", vp, cap_var);
@@ -770,34 +854,38 @@ int jl_phase_fetch(jl_ctx *ctx, jl_phase_summary *summary, uint32_t *pos_cols, u
 
 /* ---------------------------------------------------------------- the whole path as one enqueue */
 
+// One window through the path: the launches of a step.
+//   counting + Fisher   ONE launch when one workgroup counts a chunk alone (the Fisher stage rides in the epilogue
+//                       of the pileup launch); otherwise the pileup and call_kernel reading the histograms back
+//   phasing on          the fused phase launch: plan out of the call masks, keys, grouping, selection, result block,
+//                       and — small windows — the per-read ids and the completion word
+//   phasing off         compact_kernel: ordered table + result block
+//   multi-word phasing  compact_kernel (table + plan), then the generic phase pipeline
 static void enqueue_path(jl_ctx *ctx, const jl_params *prm, double n_tests, bool use_drm, bool phasing, uint32_t min_reads,
                          bool want_read_hap)
 {
     hipStream_t st = ctx->stream;
+    (void)want_read_hap;   // no copy nodes: results are stored straight into pinned host memory (ctx->pack_mirror / read_hap_out)
     if (jl_pileup_needs_zero(ctx)) hipMemsetAsync(ctx->d_counts, 0, ctx->counts_words * sizeof(uint32_t), st);
     if (!ctx->have_ref) jl_launch_guess(ctx, st);
     jl_launch_stamp(ctx, 0);
-    jl_launch_pileup(ctx, st);
+    const bool fused_call = jl_pileup_can_call(ctx);
+    jl_launch_pileup(ctx, st, fused_call);
+    if (!fused_call) jl_launch_call(ctx, st, prm, n_tests, use_drm, phasing);
     jl_launch_stamp(ctx, 1);
-    // tuning probe: leave stages out (bit 0 call, bit 1 phase) to see what each costs the pipelined step
-    const int skip = getenv("JL_SKIP_TAIL") ? atoi(getenv("JL_SKIP_TAIL")) : 0;
-    if (!(skip & 1)) jl_launch_call(ctx, prm, n_tests, use_drm, phasing);
-    jl_launch_stamp(ctx, 2);
     // The completion word (jl_run_wait) is stored by a one-thread node of its own behind the last stage: the end of
     // that stage's kernel is what pushes the results every compute die wrote for the host out of the dies' L2s.
-    // (Folding the word into the last kernel needs a system-scope release from every workgroup that wrote host
-    // memory — an L2 write-back each — and measured no faster: JL_SIGNAL_IN_KERNEL=1 keeps that variant.)
-    const bool own_done = skip != 0 || ctx->d_timeline != nullptr || getenv("JL_DUMMY_NODES") != nullptr ||
-                          getenv("JL_SIGNAL_IN_KERNEL") == nullptr;
-    if (phasing && !(skip & 2)) jl_launch_phase(ctx, min_reads, true, !own_done);
-    if (!(skip & 2)) jl_launch_result_pack(ctx, phasing, !own_done);
+    if (!phasing) {
+        jl_launch_compact(ctx, st, false, true, false);
+    } else if (ctx->phase_generic) {
+        jl_launch_compact(ctx, st, true, false, false);
+        jl_launch_stamp(ctx, 2);
+        jl_launch_phase(ctx, st, min_reads, true, false, false);
+    } else {
+        jl_launch_phase(ctx, st, min_reads, true, true, false);
+    }
     jl_launch_stamp(ctx, 3);
-    // no copy nodes: the result block and the per-read ids are stored straight into pinned host memory by the
-    // kernels that produce them (ctx->pack_mirror / ctx->read_hap_out, set by jl_run_async)
-    (void)want_read_hap;
-    if (const char *e = getenv("JL_DUMMY_NODES"))   // tuning probe (tools_tuning/): cost of extra dependent nodes
-        for (int k = atoi(e); k > 0; --k) jl_launch_noop(ctx);
-    if (own_done) jl_launch_done(ctx);
+    jl_launch_done(ctx);
 }
 
 // Everything of a run that allocates, uploads or waits: done before the enqueue (and before any capture).  Shared by
@@ -808,7 +896,7 @@ int jl_run_prepare(jl_ctx *ctx, const jl_gene *genes, uint32_t n_genes, const ui
 {
     if (!ctx || !prm || (!genes && n_genes)) return JL_ERR_ARG;
     if (!ctx->d_msa) return jl_fail(ctx, JL_ERR_STATE, "no resident matrix: call jl_msa_upload/alloc/adopt first");
-    if (prm->tail != 0) return jl_fail(ctx, JL_ERR_ARG, "only the one-sided (greater) tail is implemented");
+    if (prm->tail != 0 && prm->tail != 1) return jl_fail(ctx, JL_ERR_ARG, "tail must be 0 (one-sided greater) or 1 (two-sided)");
     if (!(prm->alpha > 0.0) || !(prm->err.match > 0.0) || !(prm->err.substitution >= 0.0))
         return jl_fail(ctx, JL_ERR_ARG, "alpha/match must be > 0 and substitution >= 0");
     if (ctx->exch_pending >= 2)
@@ -831,14 +919,17 @@ int jl_run_prepare(jl_ctx *ctx, const jl_gene *genes, uint32_t n_genes, const ui
             ctx->h_read_hap_cap = (size_t)ctx->col_stride * 2;
         }
     }
+#ifdef JL_TUNING
     if (!ctx->d_timeline && getenv("JL_TIMELINE")) {   // tuning aid, see stamp_kernel
         JL_HIP(ctx, hipMalloc(&ctx->d_timeline, (size_t)JL_TIMELINE_ROWS * JL_TIMELINE_SLOTS * 8));
         JL_HIP(ctx, hipMemset(ctx->d_timeline, 0, (size_t)JL_TIMELINE_ROWS * JL_TIMELINE_SLOTS * 8));
         ctx->alloc_version++;
     }
+#endif
     *n_tests_out = prm->n_tests > 0.0 ? prm->n_tests : ctx->default_n_tests;
     ctx->last_min_reads = min_reads;
     jl_prepare_pileup(ctx);
+    if ((rc = jl_update_callinfo(ctx, prm, *n_tests_out, drm_masks != nullptr, phasing != 0))) return rc;
     ctx->pack_mirror = ctx->h_pack;
     ctx->read_hap_out = (phasing && want_read_hap) ? ctx->h_read_hap : nullptr;
     return JL_OK;
@@ -865,7 +956,7 @@ int jl_run_async(jl_ctx *ctx, const jl_gene *genes, uint32_t n_genes, const uint
     memset(&sig, 0, sizeof sig);
     sig.alloc = ctx->alloc_version; sig.plan = ctx->plan_version; sig.prm = *prm; sig.n_tests = n_tests;
     sig.drm = drm_masks != nullptr; sig.phasing = phasing != 0; sig.min_reads = min_reads; sig.rh = want_read_hap != 0; sig.generic = ctx->phase_generic; sig.pad = (uint32_t)(uintptr_t)ctx->read_hap_out;
-    const bool graphs_on = !getenv("JL_NO_GRAPH");
+    static const bool graphs_on = !getenv("JL_NO_GRAPH");   // read once; eager launches are a debugging aid
     bool launched = false;
 
     if (graphs_on) {
@@ -933,6 +1024,7 @@ int jl_run_wait_seq(jl_ctx *ctx, uint32_t want)
     return JL_OK;
 }
 
+#ifdef JL_TUNING
 // tuning aid, not part of the ABI header (tools_tuning/timeline.py): the device-clock stamps of the last
 // JL_TIMELINE_ROWS runs of this context (JL_TIMELINE=1), 100 MHz ticks
 int jl_debug_timeline(jl_ctx *ctx, uint64_t *out)
@@ -943,6 +1035,7 @@ int jl_debug_timeline(jl_ctx *ctx, uint64_t *out)
     JL_HIP(ctx, hipMemcpy(out, ctx->d_timeline, (size_t)JL_TIMELINE_ROWS * JL_TIMELINE_SLOTS * 8, hipMemcpyDeviceToHost));
     return JL_OK;
 }
+#endif
 
 int jl_run_wait(jl_ctx *ctx)
 {
@@ -957,6 +1050,13 @@ int jl_run_done(jl_ctx *ctx)
     if ((int32_t)(*ctx->h_seq - ctx->runs_launched) < 0) return 0;
     __atomic_thread_fence(__ATOMIC_ACQUIRE);
     return 1;
+}
+
+int jl_expand_read_hap(const void *packed, uint32_t bits, uint64_t n_reads, uint16_t *out)
+{
+    if (!packed || !out || (bits != 4 && bits != 8 && bits != 16)) return JL_ERR_ARG;
+    jl_expand_ids(packed, bits, n_reads, out);
+    return JL_OK;
 }
 
 int jl_run_view_get(jl_ctx *ctx, jl_run_view *out)
@@ -984,7 +1084,11 @@ int jl_run_view_get(jl_ctx *ctx, jl_run_view *out)
         out->hap_pattern = pk->hap_pattern;
         out->hit = pk->hit;
         out->cooc = pk->cooc_fits ? pk->cooc : nullptr;
-        out->read_hap = ctx->run_read_hap ? ctx->h_read_hap : nullptr;
+        if (ctx->run_read_hap) {
+            out->read_hap_packed = ctx->h_read_hap;
+            out->read_hap_bits = pk->id_bits;
+            out->read_hap = pk->id_bits == 16 ? ctx->h_read_hap : nullptr;
+        }
     }
     out->complete = ok ? 1u : 0u;
     return JL_OK;
@@ -995,7 +1099,13 @@ int jl_run_view_get(jl_ctx *ctx, jl_run_view *out)
 int jl_fisher_eval(jl_ctx *ctx, const uint32_t *a, const uint32_t *c, const uint32_t *cov, uint32_t n, double *p,
                    double *log_p)
 {
-    if (!ctx || !a || !c || !cov || !p || !log_p) return JL_ERR_ARG;
+    return jl_fisher_eval_tail(ctx, a, c, cov, n, 0, p, log_p);
+}
+
+int jl_fisher_eval_tail(jl_ctx *ctx, const uint32_t *a, const uint32_t *c, const uint32_t *cov, uint32_t n, int tail, double *p,
+                        double *log_p)
+{
+    if (!ctx || !a || !c || !cov || !p || !log_p || (tail != 0 && tail != 1)) return JL_ERR_ARG;
     if (n == 0) return JL_OK;
     for (uint32_t i = 0; i < n; ++i)
         if (a[i] > cov[i] || c[i] > cov[i]) return jl_fail(ctx, JL_ERR_ARG, "table %u: a and c must be <= cov", i);
@@ -1009,7 +1119,7 @@ int jl_fisher_eval(jl_ctx *ctx, const uint32_t *a, const uint32_t *c, const uint
     if (e == hipSuccess) e = hipMemcpyAsync(d_in + n, c, (size_t)n * 4, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipMemcpyAsync(d_in + 2 * (size_t)n, cov, (size_t)n * 4, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) {
-        jl_launch_fisher_eval(ctx, n, d_in, d_in + n, d_in + 2 * (size_t)n, d_out, d_out + n);
+        jl_launch_fisher_eval(ctx, n, d_in, d_in + n, d_in + 2 * (size_t)n, tail, d_out, d_out + n);
         e = hipMemcpyAsync(p, d_out, (size_t)n * 8, hipMemcpyDeviceToHost, st);
     }
     if (e == hipSuccess) e = hipMemcpyAsync(log_p, d_out + n, (size_t)n * 8, hipMemcpyDeviceToHost, st);
@@ -1033,7 +1143,7 @@ int jl_time_pileup(jl_ctx *ctx, uint32_t reps, float *ms_avg)
         // events' own latency (~3 us around a single launch) is not charged to the kernel; the figure includes the
         // gaps between consecutive launches and agrees with rocprofv3's per-dispatch average to ~1 us
         JL_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-        for (uint32_t r = 0; r < reps; ++r) jl_launch_pileup(ctx, ctx->stream);
+        for (uint32_t r = 0; r < reps; ++r) jl_launch_pileup(ctx, ctx->stream, false);
         JL_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
         JL_HIP(ctx, hipEventSynchronize(ctx->ev1));
         JL_HIP(ctx, hipEventElapsedTime(&total, ctx->ev0, ctx->ev1));
@@ -1042,7 +1152,7 @@ int jl_time_pileup(jl_ctx *ctx, uint32_t reps, float *ms_avg)
             // the counters are cleared outside the timed interval; only the kernel sits between the events
             JL_HIP(ctx, hipMemsetAsync(ctx->d_counts, 0, ctx->counts_words * sizeof(uint32_t), ctx->stream));
             JL_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-            jl_launch_pileup(ctx, ctx->stream);
+            jl_launch_pileup(ctx, ctx->stream, false);
             JL_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
             JL_HIP(ctx, hipEventSynchronize(ctx->ev1));
             float ms = 0.f;
@@ -1070,9 +1180,12 @@ int jl_time_pileup_set(jl_ctx *const *ctxs, uint32_t n_ctx, uint32_t reps, float
     }
     JL_HIP(c0, hipSetDevice(c0->device));
     for (uint32_t k = 0; k < n_ctx; ++k) JL_HIP(c0, hipStreamSynchronize(ctxs[k]->stream));
-    for (uint32_t k = 0; k < n_ctx; ++k) jl_launch_pileup(ctxs[k], c0->stream);   // warm-up, one per window
+    // the variant the runs use: with the Fisher stage in its epilogue once a run has set the call parameters up
+    bool with_call = true;
+    for (uint32_t k = 0; k < n_ctx; ++k) with_call = with_call && !ctxs[k]->callinfo_host.empty() && jl_pileup_can_call(ctxs[k]);
+    for (uint32_t k = 0; k < n_ctx; ++k) jl_launch_pileup(ctxs[k], c0->stream, with_call);   // warm-up, one per window
     JL_HIP(c0, hipEventRecord(c0->ev0, c0->stream));
-    for (uint32_t r = 0; r < reps; ++r) jl_launch_pileup(ctxs[r % n_ctx], c0->stream);
+    for (uint32_t r = 0; r < reps; ++r) jl_launch_pileup(ctxs[r % n_ctx], c0->stream, with_call);
     JL_HIP(c0, hipEventRecord(c0->ev1, c0->stream));
     JL_HIP(c0, hipEventSynchronize(c0->ev1));
     float total = 0.f;

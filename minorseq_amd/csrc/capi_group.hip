@@ -1,12 +1,16 @@
-// capi_group.hip — group runs: the whole path for SEVERAL resident windows in three launches.
+// capi_group.hip — group runs: the whole path for SEVERAL resident windows in a few launches.
 //
 // Why.  A 3 kb x 100k-read window is a 150 MB stream: too short to hide a launch's ramp and drain (one pileup launch
-// reaches 0.61 of the HBM peak, a 600 MB stream 0.78), and its Fisher / phasing stages are chains of dependent memory
-// round trips that keep a hardware queue busy for tens of microseconds while doing almost nothing.  The chip runs
-// at most four queues at once (more are time-sliced: measured), so with one graph per window the queues' time — not
-// the HBM — bounds the throughput.  A group run gives each stage ONE launch for all windows of the group
-// (blockIdx.z = window, per-window argument blocks in device memory): the pileup becomes one long stream, and the
-// latency chains of the other stages run side by side instead of one after the other.
+// reaches 0.61 of the HBM peak, a 1.2 GB stream 0.77), and its phasing stage is a chain of dependent memory round
+// trips that keeps a hardware queue busy for tens of microseconds while doing almost nothing.  A group run gives each
+// stage ONE launch for up to JL_GROUP_MAX windows (blockIdx.z = window, per-window argument blocks by value):
+//   counting + Fisher   pileup_group_kernel with the Fisher stage in its epilogue
+//   phasing             phase_group_run_kernel (plan out of the call masks, keys, grouping, selection, result block)
+//   per-read ids        phase_assign_group_kernel (small groups fold them into the phasing launch)
+//   completion words    done_group_kernel
+// A group of more windows is cut into chunks of JL_GROUP_MAX that are PIPELINED inside one captured graph: the
+// pileups of consecutive chunks run back to back on the group's stream, each chunk's latency-bound tail runs on a
+// side stream next to the following chunk's pileup, so only the last (smallest) chunk's tail is ever exposed.
 //
 // Results are per window, exactly those of jl_run_async on each context: every context keeps its own result block,
 // per-read ids and completion word, so jl_run_wait / jl_run_view_get / jl_call_fetch / jl_phase_fetch work unchanged.
@@ -19,16 +23,23 @@
 
 #include "jl_internal.h"
 
+#define JL_GROUP_SIDE_STREAMS 2
+
 struct jl_group {
     int device = -1;
     hipStream_t stream = nullptr;
+    hipStream_t side[JL_GROUP_SIDE_STREAMS] = {nullptr, nullptr};
+    hipEvent_t ev_fork[JL_GROUP_WINDOWS_MAX / JL_GROUP_MAX] = {};
+    hipEvent_t ev_join[JL_GROUP_SIDE_STREAMS] = {};
     std::vector<jl_ctx *> ctxs;
     jl_done_ent *d_done = nullptr;
     std::vector<jl_win_pileup> h_pile;
     std::vector<jl_win_call> h_call;
+    std::vector<jl_win_compact> h_compact;
     std::vector<jl_win_phase> h_phase;
-    uint32_t max_chunks = 0, max_call_blocks = 0, max_phase_blocks = 0, max_read_blocks = 0;
-    bool fold = true;   // the phase launch also writes the per-read ids (its workgroups wait for each other)
+    struct chunk_t { uint32_t first, n, max_chunks, max_call_blocks, max_phase_blocks; bool fold, fused_call; };
+    std::vector<chunk_t> chunks;
+    bool phasing = true;
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
     std::vector<uint8_t> sig;   // everything the captured graph and the tables bake in
@@ -41,34 +52,57 @@ static int group_fail(jl_group *g, int status, const char *msg)
     return status;
 }
 
-static void group_enqueue(jl_group *g, bool phasing)
+// the latency-bound stages of one chunk, on `st`
+static void chunk_tail(jl_group *g, const jl_group::chunk_t &c, hipStream_t st)
 {
-    const uint32_t n = (uint32_t)g->ctxs.size();
-    for (jl_ctx *c : g->ctxs)
-        if (!c->have_ref) jl_launch_guess(c, g->stream);   // majority-codon mode: seed bases per window
-    // JL_GROUP_SKIP (tuning only, results are then stale): 1 = pileup alone, 2 = no phasing stages, 3 = no id launch
-    static const int skip = getenv("JL_GROUP_SKIP") ? atoi(getenv("JL_GROUP_SKIP")) : 0;
-    jl_launch_pileup_group(g->ctxs.data(), n, g->h_pile.data(), g->max_chunks, g->stream);
-    // the later stages take their windows' argument blocks (250-350 bytes each) by value too: JL_GROUP_MAX per launch
-    bool to_host = false;
-    for (jl_ctx *c : g->ctxs) to_host = to_host || c->read_hap_out != nullptr;
-    for (uint32_t o = 0; o < n; o += JL_GROUP_MAX) {
-        const uint32_t m = std::min<uint32_t>(JL_GROUP_MAX, n - o);
-        if (skip != 1) jl_launch_call_group(g->h_call.data() + o, m, g->max_call_blocks, g->stream);
-        if (phasing && skip != 1 && skip != 2) {
-            jl_launch_phase_group(g->h_phase.data() + o, m, g->max_phase_blocks, g->stream);
-            if (!g->fold && skip != 3) jl_launch_assign_group(g->h_phase.data() + o, m, g->max_read_blocks, to_host, g->stream);
+    if (!c.fused_call) jl_launch_call_group(g->h_call.data() + c.first, c.n, c.max_call_blocks, st);
+    if (!g->phasing) {
+        jl_launch_compact_group(g->h_compact.data() + c.first, c.n, st);
+    } else {
+        jl_launch_phase_group(g->h_phase.data() + c.first, c.n, c.max_phase_blocks, st);
+        if (!c.fold) {
+            bool to_host = false;
+            for (uint32_t k = 0; k < c.n; ++k) to_host = to_host || g->ctxs[c.first + k]->read_hap_out != nullptr;
+            jl_launch_assign_group(g->h_phase.data() + c.first, c.n, c.max_phase_blocks, to_host, st);
         }
     }
-    // completion words of all windows, behind the end of the last stage (see enqueue_path in capi.hip)
-    jl_launch_done_group(g->d_done, n, g->stream);
+    // completion words of the chunk's windows, behind the end of its last stage (see enqueue_path in capi.hip)
+    jl_launch_done_group(g->d_done + c.first, c.n, st);
+}
+
+static int group_enqueue(jl_group *g)
+{
+    for (jl_ctx *c : g->ctxs)
+        if (!c->have_ref) jl_launch_guess(c, g->stream);   // majority-codon mode: seed bases per window
+    const size_t nc = g->chunks.size();
+    bool side_used[JL_GROUP_SIDE_STREAMS] = {false, false};
+    for (size_t k = 0; k < nc; ++k) {
+        const jl_group::chunk_t &c = g->chunks[k];
+        int rc = jl_launch_pileup_group(g->ctxs.data() + c.first, c.n, g->h_pile.data() + c.first, c.max_chunks, g->stream,
+                                        c.fused_call);
+        if (rc) return rc;
+        if (k + 1 < nc) {   // the tail runs beside the next chunk's pileup
+            hipStream_t st = g->side[k % JL_GROUP_SIDE_STREAMS];
+            if (hipEventRecord(g->ev_fork[k], g->stream) != hipSuccess || hipStreamWaitEvent(st, g->ev_fork[k], 0) != hipSuccess)
+                return JL_ERR_DEVICE;
+            chunk_tail(g, c, st);
+            side_used[k % JL_GROUP_SIDE_STREAMS] = true;
+        } else {
+            chunk_tail(g, c, g->stream);
+        }
+    }
+    for (int i = 0; i < JL_GROUP_SIDE_STREAMS; ++i)
+        if (side_used[i] && (hipEventRecord(g->ev_join[i], g->side[i]) != hipSuccess ||
+                             hipStreamWaitEvent(g->stream, g->ev_join[i], 0) != hipSuccess))
+            return JL_ERR_DEVICE;
+    return JL_OK;
 }
 
 extern "C" {
 
 int jl_group_create(jl_ctx *const *ctxs, uint32_t n_ctx, jl_group **out)
 {
-    if (!ctxs || !out || n_ctx == 0 || n_ctx > JL_GROUP_WINDOWS_MAX) return JL_ERR_ARG;   // the argument blocks travel by value
+    if (!ctxs || !out || n_ctx == 0 || n_ctx > JL_GROUP_WINDOWS_MAX) return JL_ERR_ARG;
     *out = nullptr;
     for (uint32_t k = 0; k < n_ctx; ++k) {
         if (!ctxs[k] || ctxs[k]->device != ctxs[0]->device) return JL_ERR_ARG;
@@ -81,10 +115,18 @@ int jl_group_create(jl_ctx *const *ctxs, uint32_t n_ctx, jl_group **out)
     g->ctxs.assign(ctxs, ctxs + n_ctx);
     g->h_pile.resize(n_ctx);
     g->h_call.resize(n_ctx);
+    g->h_compact.resize(n_ctx);
     g->h_phase.resize(n_ctx);
     bool ok = hipSetDevice(g->device) == hipSuccess &&
               hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking) == hipSuccess &&
               hipMalloc(&g->d_done, sizeof(jl_done_ent) * n_ctx) == hipSuccess;
+    if (ok && n_ctx > JL_GROUP_MAX) {   // pipelined chunks: side streams for the tails
+        for (int i = 0; ok && i < JL_GROUP_SIDE_STREAMS; ++i)
+            ok = hipStreamCreateWithFlags(&g->side[i], hipStreamNonBlocking) == hipSuccess &&
+                 hipEventCreateWithFlags(&g->ev_join[i], hipEventDisableTiming) == hipSuccess;
+        for (auto &e : g->ev_fork)
+            ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
+    }
     if (!ok) {
         jl_group_destroy(g);
         return JL_ERR_MEMORY;
@@ -101,6 +143,12 @@ void jl_group_destroy(jl_group *g)
     if (g->graph_exec) hipGraphExecDestroy(g->graph_exec);
     if (g->graph) hipGraphDestroy(g->graph);
     if (g->d_done) hipFree(g->d_done);
+    for (auto &e : g->ev_fork)
+        if (e) hipEventDestroy(e);
+    for (int i = 0; i < JL_GROUP_SIDE_STREAMS; ++i) {
+        if (g->ev_join[i]) hipEventDestroy(g->ev_join[i]);
+        if (g->side[i]) hipStreamDestroy(g->side[i]);
+    }
     if (g->stream) hipStreamDestroy(g->stream);
     delete g;
 }
@@ -110,14 +158,22 @@ const char *jl_group_last_error(const jl_group *g) { return g ? g->err.c_str() :
 int jl_group_run_async(jl_group *g, const jl_gene *genes, uint32_t n_genes, const uint8_t *refseq, uint32_t ref_len,
                        const jl_params *prm, int phasing, uint32_t min_reads, int want_read_hap)
 {
+    return jl_group_run_masked_async(g, genes, n_genes, refseq, ref_len, prm, nullptr, phasing, min_reads, want_read_hap);
+}
+
+int jl_group_run_masked_async(jl_group *g, const jl_gene *genes, uint32_t n_genes, const uint8_t *refseq, uint32_t ref_len,
+                              const jl_params *prm, const uint64_t *const *drm_masks, int phasing, uint32_t min_reads,
+                              int want_read_hap)
+{
     if (!g || !prm) return JL_ERR_ARG;
     if (hipSetDevice(g->device) != hipSuccess) return group_fail(g, JL_ERR_DEVICE, "hipSetDevice failed");
     const uint32_t n = (uint32_t)g->ctxs.size();
     std::vector<double> n_tests(n);
-    // per-window preparation (plans, buffers): may allocate and wait, so it comes before any enqueue
+    // per-window preparation (plans, buffers, parameter blocks): may allocate and wait, so it comes before any enqueue
     for (uint32_t k = 0; k < n; ++k) {
         jl_ctx *c = g->ctxs[k];
-        int rc = jl_run_prepare(c, genes, n_genes, refseq, ref_len, prm, nullptr, phasing, min_reads, want_read_hap, &n_tests[k]);
+        int rc = jl_run_prepare(c, genes, n_genes, refseq, ref_len, prm, drm_masks ? drm_masks[k] : nullptr, phasing, min_reads,
+                                want_read_hap, &n_tests[k]);
         if (rc) return group_fail(g, rc, jl_last_error(c));
         // a group run reads what the window's own stream wrote (uploads, ingest): that stream must be idle
         if (hipStreamSynchronize(c->stream) != hipSuccess) return group_fail(g, JL_ERR_DEVICE, "context stream failed");
@@ -125,7 +181,7 @@ int jl_group_run_async(jl_group *g, const jl_gene *genes, uint32_t n_genes, cons
             return group_fail(g, JL_ERR_ARG, "a window needs the multi-word phasing pipeline: run it with jl_run_async");
     }
     // signature: anything that changes an argument block or the launch shapes
-    struct item { uint64_t alloc, plan; double n_tests; void *rh; uint32_t n_dw, pad; };
+    struct item { uint64_t alloc, plan; double n_tests; void *rh; uint32_t n_dw, drm; };
     std::vector<uint8_t> sig(sizeof(jl_params) + 16 + sizeof(item) * n);
     memcpy(sig.data(), prm, sizeof(jl_params));
     const uint32_t flags[4] = {(uint32_t)(phasing != 0), min_reads, (uint32_t)(want_read_hap != 0), n};
@@ -136,6 +192,7 @@ int jl_group_run_async(jl_group *g, const jl_gene *genes, uint32_t n_genes, cons
         memset(&it, 0, sizeof it);
         it.alloc = c->alloc_version; it.plan = c->plan_version; it.n_tests = n_tests[k]; it.rh = c->read_hap_out;
         it.n_dw = (uint32_t)(c->col_stride / 4u);
+        it.drm = (drm_masks && drm_masks[k]) ? 1u : 0u;
         memcpy(sig.data() + sizeof(jl_params) + 16 + sizeof(item) * k, &it, sizeof it);
     }
     if (sig != g->sig) {
@@ -143,42 +200,51 @@ int jl_group_run_async(jl_group *g, const jl_gene *genes, uint32_t n_genes, cons
         if (g->graph) { hipGraphDestroy(g->graph); g->graph = nullptr; }
         g->sig.clear();
         if (hipStreamSynchronize(g->stream) != hipSuccess) return group_fail(g, JL_ERR_DEVICE, "group stream failed");
-        g->max_chunks = g->max_call_blocks = g->max_phase_blocks = 0;
-        // The phase launch writes the per-read ids itself when ALL its workgroups can wait for each other, i.e. are
-        // resident at once — also while more such launches run: at most JL_FOLD_MAX_BLOCKS per launch against 1536
-        // places (six 75-register blocks per CU).  Larger groups take a separate launch for the ids: nothing waits
-        // for anything then.
-        uint32_t total_blocks = 0;
-        for (uint32_t k = 0; k < n; ++k) total_blocks += (uint32_t)((g->ctxs[k]->col_stride / 4u + 255u) / 256u);
-        g->fold = total_blocks <= JL_FOLD_MAX_BLOCKS && !getenv("JL_NO_FOLD");
-        g->max_read_blocks = 0;
-        for (uint32_t k = 0; k < n; ++k) {
-            jl_ctx *c = g->ctxs[k];
-            jl_fill_win_pileup(c, &g->h_pile[k]);
-            jl_fill_win_call(c, prm, n_tests[k], false, phasing != 0, &g->h_call[k]);
-            jl_fill_win_phase(c, min_reads, false, g->fold ? 0xFFFFFFFFu : 0u, &g->h_phase[k]);
-            if (!phasing) g->h_call[k].meta = nullptr;
-            g->max_chunks = std::max(g->max_chunks, g->h_pile[k].n_chunks);
-            g->max_call_blocks = std::max(g->max_call_blocks, g->h_call[k].n_blocks);
-            g->max_phase_blocks = std::max(g->max_phase_blocks, g->h_phase[k].n_blocks);
-            g->max_read_blocks = std::max(g->max_read_blocks, g->h_phase[k].n_blocks);   // 8 reads per lane there too
+        g->phasing = phasing != 0;
+        // same kernel variant everywhere?  (checked again by the launcher)
+        for (uint32_t k = 1; k < n; ++k)
+            if (g->ctxs[k]->pileup_w != g->ctxs[0]->pileup_w)
+                return group_fail(g, JL_ERR_ARG, "the windows of a group must share the pileup chunk width (gene layouts too different)");
+        // chunks of at most JL_GROUP_MAX windows; the remainder goes last (its tail is the exposed one)
+        g->chunks.clear();
+        for (uint32_t o = 0; o < n; o += JL_GROUP_MAX) {
+            jl_group::chunk_t c;
+            memset(&c, 0, sizeof c);
+            c.first = o;
+            c.n = std::min<uint32_t>(JL_GROUP_MAX, n - o);
+            // The phase launch writes the per-read ids itself when ALL its workgroups can wait for each other, i.e.
+            // are resident at once — also while more such launches run: at most JL_FOLD_MAX_BLOCKS per launch against
+            // 1536 places (six 75-register blocks per CU).  Larger chunks take a separate launch for the ids.
+            uint32_t total_blocks = 0;
+            c.fused_call = true;
+            for (uint32_t k = o; k < o + c.n; ++k) {
+                total_blocks += (uint32_t)((g->ctxs[k]->col_stride / 4u + 255u) / 256u) + 1u;
+                c.fused_call = c.fused_call && jl_pileup_can_call(g->ctxs[k]);
+            }
+            c.fold = total_blocks <= JL_FOLD_MAX_BLOCKS;
+            for (uint32_t k = o; k < o + c.n; ++k) {
+                jl_ctx *x = g->ctxs[k];
+                jl_fill_win_pileup(x, &g->h_pile[k]);
+                jl_fill_win_call(x, prm, n_tests[k], drm_masks && drm_masks[k], phasing != 0, &g->h_call[k]);
+                jl_fill_win_compact(x, false, true, false, &g->h_compact[k]);
+                jl_fill_win_phase(x, min_reads, false, c.fold ? 0xFFFFFFFFu : 0u, true, &g->h_phase[k]);
+                c.max_chunks = std::max(c.max_chunks, g->h_pile[k].n_chunks);
+                c.max_call_blocks = std::max(c.max_call_blocks, g->h_call[k].n_blocks);
+                c.max_phase_blocks = std::max(c.max_phase_blocks, g->h_phase[k].n_blocks);
+            }
+            g->chunks.push_back(c);
         }
-        if (!phasing)
-            return group_fail(g, JL_ERR_ARG, "group runs are built for call + phase; run call-only windows with jl_run_async");
         {
             std::vector<jl_done_ent> ents(n);
             for (uint32_t k = 0; k < n; ++k) { ents[k].seq_dev = g->ctxs[k]->d_sync; ents[k].seq_host = g->ctxs[k]->h_seq; }
             if (hipMemcpy(g->d_done, ents.data(), sizeof(jl_done_ent) * n, hipMemcpyHostToDevice) != hipSuccess)
                 return group_fail(g, JL_ERR_DEVICE, "argument tables");
         }
-        // same variant / launch shape everywhere?  (checked by the launcher; probe it outside the capture)
-        for (uint32_t k = 1; k < n; ++k)
-            if (g->ctxs[k]->pileup_w != g->ctxs[0]->pileup_w)
-                return group_fail(g, JL_ERR_ARG, "the windows of a group must share the pileup chunk width (gene layouts too different)");
-        if (!getenv("JL_NO_GRAPH") && hipStreamBeginCapture(g->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
-            group_enqueue(g, phasing != 0);
+        static const bool graphs_on = !getenv("JL_NO_GRAPH");
+        if (graphs_on && hipStreamBeginCapture(g->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+            const int erc = group_enqueue(g);
             hipGraph_t gr = nullptr;
-            if (hipStreamEndCapture(g->stream, &gr) == hipSuccess && gr &&
+            if (hipStreamEndCapture(g->stream, &gr) == hipSuccess && gr && erc == JL_OK &&
                 hipGraphInstantiate(&g->graph_exec, gr, nullptr, nullptr, 0) == hipSuccess) {
                 g->graph = gr;
             } else {
@@ -191,8 +257,8 @@ int jl_group_run_async(jl_group *g, const jl_gene *genes, uint32_t n_genes, cons
     }
     bool launched = g->graph_exec && hipGraphLaunch(g->graph_exec, g->stream) == hipSuccess;
     if (!launched) {
-        group_enqueue(g, phasing != 0);
-        if (hipGetLastError() != hipSuccess) return group_fail(g, JL_ERR_DEVICE, "group launch failed");
+        const int erc = group_enqueue(g);
+        if (erc != JL_OK || hipGetLastError() != hipSuccess) return group_fail(g, erc ? erc : JL_ERR_DEVICE, "group launch failed");
     }
     for (jl_ctx *c : g->ctxs) {
         jl_run_finish(c, phasing, want_read_hap);
@@ -201,9 +267,10 @@ int jl_group_run_async(jl_group *g, const jl_gene *genes, uint32_t n_genes, cons
     return JL_OK;
 }
 
-// Average device time in ms of the grouped pileup launch alone: `reps` back-to-back launches rotating over the
-// given groups (all on the first group's stream), one pair of HIP events around them.  Every group must have run
-// at least once (its argument table is what the launch reads).
+// Average device time in ms of the grouped pileup launch alone (the launch of a group's FIRST chunk, with the Fisher
+// stage in its epilogue as in a run): `reps` back-to-back launches rotating over the given groups (all on the first
+// group's stream), one pair of HIP events around them.  Every group must have run at least once (its argument
+// tables are what the launch reads).
 int jl_group_time_pileup(jl_group *const *groups, uint32_t n_groups, uint32_t reps, float *ms_avg, uint64_t *bytes_per_launch)
 {
     if (!groups || n_groups == 0 || !ms_avg || reps == 0) return JL_ERR_ARG;
@@ -217,7 +284,8 @@ int jl_group_time_pileup(jl_group *const *groups, uint32_t n_groups, uint32_t re
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return group_fail(g0, JL_ERR_DEVICE, "events");
     auto launch = [&](jl_group *g) {
-        return jl_launch_pileup_group(g->ctxs.data(), (uint32_t)g->ctxs.size(), g->h_pile.data(), g->max_chunks, g0->stream);
+        const jl_group::chunk_t &c = g->chunks[0];
+        return jl_launch_pileup_group(g->ctxs.data() + c.first, c.n, g->h_pile.data() + c.first, c.max_chunks, g0->stream, c.fused_call);
     };
     int rc = JL_OK;
     for (uint32_t k = 0; k < n_groups && rc == JL_OK; ++k) rc = launch(groups[k]);   // warm-up, once per group
@@ -232,7 +300,8 @@ int jl_group_time_pileup(jl_group *const *groups, uint32_t n_groups, uint32_t re
     *ms_avg = total / (float)reps;
     if (bytes_per_launch) {
         uint64_t b = 0;
-        for (jl_ctx *c : g0->ctxs) b += (uint64_t)c->n_reads * c->n_cols / 2u;
+        const jl_group::chunk_t &c = g0->chunks[0];
+        for (uint32_t k = c.first; k < c.first + c.n; ++k) b += (uint64_t)g0->ctxs[k]->n_reads * g0->ctxs[k]->n_cols / 2u;
         *bytes_per_launch = b;
     }
     for (uint32_t k = 0; k < n_groups; ++k)

@@ -174,6 +174,22 @@ JL_FHD double jl_fisher_greater_equal_rows(uint32_t a_, uint32_t c_, uint32_t n_
     return p;
 }
 
+// Two-sided p (sum of the probabilities of all tables no more likely than the observed one) for the same table.
+// X ~ Hypergeometric(2n, K, n) is symmetric about K/2 when both rows sum to n: P(X = x) = P(X = K - x).  The tables
+// at least as extreme as a are therefore x >= max(a, c) and their mirror images x <= min(a, c): p = 2 P(X >= max(a, c)),
+// and p = 1 when a = c (SPEC §5, `tail` = 1).
+JL_FHD double jl_fisher_two_sided_equal_rows(uint32_t a_, uint32_t c_, uint32_t n_, double *logp)
+{
+    if (a_ == c_) { *logp = 0.0; return 1.0; }
+    const uint32_t hi = a_ > c_ ? a_ : c_, lo = a_ > c_ ? c_ : a_;
+    double l1;
+    const double p1 = jl_fisher_greater_equal_rows(hi, lo, n_, &l1);
+    const double lp = l1 + 0.6931471805599453094;
+    *logp = lp < 0.0 ? lp : 0.0;
+    const double p = 2.0 * p1;
+    return p < 1.0 ? p : 1.0;
+}
+
 // The same p-value, unless it provably cannot lead to a call: P(X >= a) >= P(X = a), so when already the point mass,
 // Bonferroni-adjusted, reaches alpha the codon is not called and (uncalled codons are never reported) its p-value is
 // not needed — the tail sum, a division per term, is skipped and *skipped set.  Every value that IS returned comes from

@@ -10,6 +10,13 @@
 #include "../../include/juliet_hip.h"
 #include "jl_synth.h"
 
+// Tuning builds (make EXTRA=-DJL_TUNING; -DJL_PILEUP_TUNING implies it) compile in the probes of tools_tuning/:
+// environment switches for launch shapes, device-clock stamps between the stages, wrong-by-design kernel variants.
+// The shipped library has none of them and reads no environment variable on its launch paths.
+#if defined(JL_PILEUP_TUNING) && !defined(JL_TUNING)
+#define JL_TUNING 1
+#endif
+
 #define JL_VARIANT_CAP 4096u      // rows of the resident variant table (all-gather stride)
 #define JL_CAND_CAP 4096u         // haplotype candidates (groups with >= min_reads) the selector can rank
 #define JL_POS_PER_WORD 10u       // variant positions per 64-bit key word (6 bits each)
@@ -34,9 +41,19 @@ struct jl_phase_meta {  // device-resident scalars of one phasing run
     uint32_t overflow;  // bit0: more than JL_CAND_CAP candidates; bit1: more than JL_MAX_HAPLOTYPES qualified;
                         // bit2: the key buffer was too small for vp_true positions (phasing skipped, host re-runs)
     uint32_t vp_true;   // distinct variant columns before the capacity check
-    uint32_t pad_[2];
+    uint32_t id_bits;   // width of the per-read ids the run wrote: 4, 8 or 16 (see JL_ID_* below)
+    uint32_t pad_;
     jl_phase_summary summary;
 };
+
+// Per-read haplotype ids travel in the narrowest code that holds the run's haplotype count H (they cross PCIe into
+// pinned host memory: 2 bytes per read were the largest transfer of a step):
+//   4 bits (H <= 14): 0..13 haplotype, 14 insufficient coverage, 15 damaged; read i in nibble i & 7 of dword i >> 3
+//   8 bits (H <= 254): 0..253, 254 insufficient, 255 damaged
+//   16 bits: the id itself (JL_HAP_INSUFFICIENT / JL_HAP_DAMAGED)
+// jl_phase_fetch expands to 16 bits; jl_run_view hands out the packed form with its width.
+#define JL_ID4_MAX_H 14u
+#define JL_ID8_MAX_H 254u
 
 // Small fixed-size result block: everything a typical run returns except the per-read ids, gathered by one
 // tiny kernel so that ONE device-to-host copy into pinned memory ends the step (results that do not fit set
@@ -52,7 +69,7 @@ struct jl_pack {
     uint32_t magic, nvar_total, fits_call, fits_phase;
     uint32_t phase_ran, overflow, vp, H;
     jl_phase_summary summary;
-    uint32_t nv_phase, cooc_fits, pad_[6];
+    uint32_t nv_phase, cooc_fits, id_bits, pad_[5];
     jl_variant variants[JL_PACK_MAX_VAR];
     uint32_t pos_cols[JL_PACK_MAX_VP];
     uint32_t hap_count[JL_PACK_MAX_HAP];
@@ -80,6 +97,22 @@ struct jl_call_args {
     double alpha, n_tests, match, substitution, min_perc, max_perc;
     int32_t expected_round;
     uint32_t P;
+    int32_t tail;   // 0 one-sided greater, 1 two-sided
+    uint32_t pad_;
+};
+
+// What the call part of a fused pileup launch needs for one window.  Lives in device memory (ctx->d_callinfo): the
+// pileup argument blocks stay small (32 of them travel by value) and the epilogue reads it with scalar loads.
+struct jl_callinfo {
+    jl_call_args A;
+    const uint32_t *col_first;   // [n_cols] first position whose codon starts at the column, 0xFFFFFFFF: none
+    const uint32_t *pos_next;    // [P] next position with the same start column (overlapping genes in one frame)
+    const uint32_t *pos_gene, *pos_codon;
+    const uint8_t *pos_refcfg;
+    const uint64_t *drm;         // null: no --drm-only masks
+    uint64_t *called;            // [P] mask of called codons
+    jl_variant *staged;          // [P][64] finished rows of the called codons
+    jl_phase_meta *meta;         // run counters, zeroed by the first workgroup of the launch (null: phasing off)
 };
 
 struct jl_win_pileup {
@@ -89,24 +122,37 @@ struct jl_win_pileup {
     const uint2 *chunks;
     const uint32_t *guess32;
     uint32_t *counts, *hist;
+    const jl_callinfo *ci;       // null: count only
 };
 
-struct jl_win_call {
+struct jl_win_call {   // call_kernel: the Fisher stage from histograms in HBM (stage API, windows too deep for one block per chunk)
     jl_call_args A;
     const uint32_t *pos_gene, *pos_codon, *pos_col;
     const uint8_t *pos_refcfg;
     const uint32_t *hist;
     const uint64_t *drm;
     uint64_t *called;
-    jl_variant *staged, *rows;
-    uint32_t cap, n_cols;
+    jl_variant *staged;
+    jl_phase_meta *meta;   // run counters to zero (null: none)
+    uint32_t n_blocks, pad_;
+};
+
+// compact_kernel: ordered compaction of the staged rows into the variant table, then optionally the phasing plan
+// (multi-word pipeline, stage API) and / or the result block of a run without phasing
+struct jl_win_compact {
+    uint32_t P, cap, n_cols, kwords_cap;
+    const uint64_t *called;
+    const jl_variant *staged;
+    jl_variant *rows;
     uint32_t *n_rows;
     uint8_t *varcol;
     uint32_t *vpcols, *col2pos;
-    uint32_t kwords_cap, fast_only;
-    jl_phase_meta *meta;   // null: no plan (phasing off)
-    uint32_t *arrive;
-    uint32_t n_blocks, pad_;
+    jl_phase_meta *meta;
+    uint32_t plan, fast_only;        // plan != 0: distinct variant columns (phase_plan.h)
+    uint32_t pack, pad_;             // pack != 0: write the result block (run without phasing)
+    jl_pack *pk, *mirror;
+    uint32_t *seq_dev;
+    volatile uint32_t *seq_host;     // non-null: this launch ends a run
 };
 
 // what the last block of the fused phase launch needs to run the selection (and to end the run)
@@ -130,6 +176,14 @@ struct jl_select_args {
     uint32_t fold, pad_;
     uint32_t *flag, *arrive2;
     uint16_t *read_hap;
+    // plan from the call masks (whole-path runs): every workgroup derives the variant columns itself, one extra
+    // workgroup compacts the rows into the table meanwhile
+    const uint64_t *called;          // null: the plan is in meta / vpcols already (stage API, multi-word pipeline)
+    const jl_variant *staged;
+    const uint32_t *pos_col;
+    jl_variant *rows;
+    uint32_t *n_rows_out, *vpcols_out, *col2pos_out;
+    uint32_t P, cap, kwords_cap, pad2_;
 };
 
 struct jl_done_ent {   // completion word of one window (see done_kernel)
@@ -158,6 +212,7 @@ struct jl_win_phase {
 #define JL_GROUP_MAX 8           // windows per call / phase / id launch (their argument blocks are 250-350 bytes each)
 #define JL_GROUP_WINDOWS_MAX 32  // windows per group = per pileup launch (56-byte argument blocks)
 struct jl_call_group_args { jl_win_call w[JL_GROUP_MAX]; };
+struct jl_compact_group_args { jl_win_compact w[JL_GROUP_MAX]; };
 struct jl_phase_group_args { jl_win_phase w[JL_GROUP_MAX]; };
 struct jl_pileup_group_args { jl_win_pileup w[JL_GROUP_WINDOWS_MAX]; };
 
@@ -214,6 +269,10 @@ struct jl_ctx {
     uint64_t *d_called = nullptr;  // [P] mask of called codons
     jl_variant *d_staged = nullptr;  // [P][64] finished rows of the called codons, before the ordered compaction
     uint64_t *d_drm = nullptr;     // [P] optional
+    uint32_t *d_col_first = nullptr;   // [n_cols] first position starting at the column (0xFFFFFFFF: none)
+    uint32_t *d_pos_next = nullptr;    // [P] next position with the same start column
+    jl_callinfo *d_callinfo = nullptr; // what the Fisher stage inside the pileup launch reads (see jl_callinfo)
+    std::vector<uint8_t> callinfo_host;  // last uploaded contents
     jl_variant *d_variants = nullptr;  // [JL_VARIANT_CAP]
     uint32_t *d_nvar = nullptr;        // [0] rows needed, [1] spare
     bool call_done = false;
@@ -284,26 +343,30 @@ int jl_fail(jl_ctx *ctx, int status, const char *fmt, ...);
 
 // kernel launchers (defined in the .hip files) -------------------------------------------------
 void jl_launch_guess(jl_ctx *ctx, hipStream_t st);
-void jl_launch_pileup(jl_ctx *ctx, hipStream_t st);
+void jl_launch_pileup(jl_ctx *ctx, hipStream_t st, bool with_call);
+bool jl_pileup_can_call(jl_ctx *ctx);
 uint32_t jl_pileup_rsplit(jl_ctx *ctx);
 bool jl_pileup_needs_zero(jl_ctx *ctx);
 void jl_prepare_pileup(jl_ctx *ctx);
-void jl_launch_call(jl_ctx *ctx, const jl_params *prm, double n_tests, bool use_drm, bool with_plan);
-void jl_launch_phase(jl_ctx *ctx, uint32_t min_reads, bool planned, bool signal);
+void jl_launch_call(jl_ctx *ctx, hipStream_t st, const jl_params *prm, double n_tests, bool use_drm, bool with_meta);
+void jl_launch_compact(jl_ctx *ctx, hipStream_t st, bool plan, bool pack, bool signal);
+void jl_launch_phase(jl_ctx *ctx, hipStream_t st, uint32_t min_reads, bool planned, bool from_called, bool signal);
+void jl_fill_call_args(jl_ctx *ctx, const jl_params *prm, double n_tests, jl_call_args *A);
 // group runs: fill one window's argument block / launch a stage once for `n_win` <= JL_GROUP_MAX windows (the blocks
 // travel by value in the kernel arguments)
 void jl_fill_win_pileup(jl_ctx *ctx, jl_win_pileup *w);
-void jl_fill_win_call(jl_ctx *ctx, const jl_params *prm, double n_tests, bool use_drm, bool with_plan, jl_win_call *w);
-bool jl_fill_win_phase(jl_ctx *ctx, uint32_t min_reads, bool signal, uint32_t fold_budget, jl_win_phase *w);
-int jl_launch_pileup_group(jl_ctx *const *ctxs, uint32_t n_win, const jl_win_pileup *h_wins, uint32_t max_chunks, hipStream_t st);
+void jl_fill_win_call(jl_ctx *ctx, const jl_params *prm, double n_tests, bool use_drm, bool with_meta, jl_win_call *w);
+void jl_fill_win_compact(jl_ctx *ctx, bool plan, bool pack, bool signal, jl_win_compact *w);
+bool jl_fill_win_phase(jl_ctx *ctx, uint32_t min_reads, bool signal, uint32_t fold_budget, bool from_called, jl_win_phase *w);
+int jl_launch_pileup_group(jl_ctx *const *ctxs, uint32_t n_win, const jl_win_pileup *h_wins, uint32_t max_chunks, hipStream_t st,
+                           bool with_call);
 void jl_launch_call_group(const jl_win_call *h_wins, uint32_t n_win, uint32_t max_blocks, hipStream_t st);
+void jl_launch_compact_group(const jl_win_compact *h_wins, uint32_t n_win, hipStream_t st);
 void jl_launch_phase_group(const jl_win_phase *h_wins, uint32_t n_win, uint32_t max_blocks, hipStream_t st);
 void jl_launch_assign_group(const jl_win_phase *h_wins, uint32_t n_win, uint32_t max_read_blocks, bool to_host, hipStream_t st);
 void jl_launch_synth(jl_ctx *ctx, const jl_synth_plan *plan, const uint8_t *d_ref, uint32_t col0);
 void jl_launch_pack_rows(jl_ctx *ctx, const uint8_t *d_rows);
-void jl_launch_result_pack(jl_ctx *ctx, bool phasing, bool signal);
 void jl_launch_validate(jl_ctx *ctx, uint32_t *d_flag);
-void jl_launch_noop(jl_ctx *ctx);
 void jl_launch_done(jl_ctx *ctx);
 void jl_launch_done_group(const jl_done_ent *d_ents, uint32_t n, hipStream_t st);
 void jl_launch_stamp(jl_ctx *ctx, uint32_t slot);
@@ -317,5 +380,8 @@ void jl_launch_consensus(jl_ctx *ctx, uint8_t *d_out);
 void jl_launch_ingest(jl_ctx *ctx, const int32_t *d_pos, const uint32_t *d_cigar, const uint64_t *d_cig_off,
                       const uint8_t *d_seq4, const uint64_t *d_seq_off, const uint8_t *d_qual,
                       const uint64_t *d_qual_off, uint32_t min_qv);
-void jl_launch_fisher_eval(jl_ctx *ctx, uint32_t n, const uint32_t *a, const uint32_t *c, const uint32_t *cov,
+void jl_launch_fisher_eval(jl_ctx *ctx, uint32_t n, const uint32_t *a, const uint32_t *c, const uint32_t *cov, int tail,
                            double *p, double *lp);
+// per-read ids in their packed form (4 / 8 / 16 bits, see JL_ID4_MAX_H) expanded to 16-bit ids on the host
+extern "C" void jl_expand_ids(const void *packed, uint32_t bits, uint64_t n_reads, uint16_t *out);
+extern "C" int jl_update_callinfo(jl_ctx *ctx, const jl_params *prm, double n_tests, bool use_drm, bool with_meta);

@@ -21,8 +21,10 @@
 
 #include <algorithm>
 
+#include "call_eval.h"
 #include "jl_internal.h"
 #include "phase_plan.h"
+#include "result_pack.h"
 
 namespace {
 
@@ -200,102 +202,41 @@ __global__ __launch_bounds__(256) void phase_group_kernel(uint64_t n_reads, uint
     }
 }
 
-// Words that other workgroups of the SAME launch update with atomics (group counts, the read-category counters)
-// are read past the caches: memory-side atomics do not refresh a copy another XCD's L2 may still hold.
-// Words that other workgroups of the SAME launch update (group counts and keys, the occupied list, the read-category
-// counters) are read past this CU's L1 with agent-scope loads.
-__device__ __forceinline__ uint32_t ld_coherent(const uint32_t *p)
-{
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ unsigned long long ld_coherent64(const unsigned long long *p)
-{
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
+__device__ __forceinline__ uint32_t ld_coherent(const uint32_t *p) { return jl_ld_coherent(p); }
+__device__ __forceinline__ unsigned long long ld_coherent64(const unsigned long long *p) { return jl_ld_coherent64(p); }
+__device__ __forceinline__ void signal_done(uint32_t *seq_dev, volatile uint32_t *seq_host) { jl_signal_done(seq_dev, seq_host); }
 
-// Completion word of a run (see jl_run_wait): stored by ONE thread after everything the run wrote for the host
-// has been drained by its writers and a block barrier; `seq_host` is pinned host memory.
-__device__ __forceinline__ void signal_done(uint32_t *seq_dev, volatile uint32_t *seq_host)
-{
-    const uint32_t v = __hip_atomic_load(seq_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
-    __hip_atomic_store(seq_dev, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __threadfence_system();
-    __hip_atomic_store(const_cast<uint32_t *>(seq_host), v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-}
+// width of the per-read ids for H reported haplotypes (jl_internal.h: JL_ID4_MAX_H / JL_ID8_MAX_H)
+__device__ __forceinline__ uint32_t id_bits_for(uint32_t H) { return H <= JL_ID4_MAX_H ? 4u : (H <= JL_ID8_MAX_H ? 8u : 16u); }
 
-// ---------------------------------------------------------------------------------------- result pack
-// Block-level: gathers the small results into one fixed-size block for a single pinned D2H copy.
-__device__ __forceinline__ void result_pack_block(const jl_variant *__restrict__ variants, uint32_t n,
-                                                  const jl_phase_meta *meta, uint32_t phasing,
-                                                  const uint32_t *__restrict__ vpcols,
-                                                  const uint32_t *__restrict__ hap_count,
-                                                  const uint8_t *__restrict__ hap_pattern,
-                                                  const uint8_t *__restrict__ hit, const uint32_t *__restrict__ cooc,
-                                                  uint32_t cooc_cap, uint32_t cooc_ready, jl_pack *__restrict__ pk,
-                                                  jl_pack *__restrict__ pk2)
+// eight ids (16-bit codes: haplotype, JL_HAP_INSUFFICIENT, JL_HAP_DAMAGED) of reads 8t .. 8t+7 into the packed buffer
+__device__ __forceinline__ void store_ids(uint16_t *base, uint64_t t, const uint16_t (&h)[8], uint32_t bits)
 {
-    // pk: device copy (all-gather source); pk2: pinned host mirror (may be null) — both written directly
-    const uint32_t tid = threadIdx.x, nt = blockDim.x;
-    const uint32_t fits_call = n <= JL_PACK_MAX_VAR;
-    uint32_t vp = 0, H = 0, nv = 0, ovf = 0, fits_phase = 0, cooc_fits = 0;
-    if (phasing) {
-        vp = ld_coherent(&meta->vp); H = ld_coherent(&meta->summary.n_haplotypes); nv = ld_coherent(&meta->n_var);
-        ovf = ld_coherent(&meta->overflow);
-        fits_phase = ovf == 0 && fits_call && vp <= JL_PACK_MAX_VP && H <= JL_PACK_MAX_HAP &&
-                     H * vp <= JL_PACK_PATTERN_BYTES && nv * H <= JL_PACK_HIT_BYTES;
-        cooc_fits = cooc_ready && nv <= JL_PACK_COOC_N;
-    }
-    jl_pack *dsts[2] = {pk, pk2};
+    if (bits == 4u) {
+        uint32_t v = 0;
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        jl_pack *o = dsts[t];
-        if (!o) continue;
-        if (tid == 0) {
-            o->magic = JL_PACK_MAGIC; o->nvar_total = n; o->fits_call = fits_call; o->fits_phase = fits_phase;
-            o->phase_ran = phasing; o->overflow = ovf; o->vp = vp; o->H = H;
-            o->nv_phase = nv; o->cooc_fits = cooc_fits;
-            if (phasing) {   // the category counters were added to by other workgroups of this launch
-                jl_phase_summary sm;
-                sm.reported_reads = ld_coherent(&meta->summary.reported_reads);
-                sm.insufficient_reads = ld_coherent(&meta->summary.insufficient_reads);
-                sm.damaged_reads = ld_coherent(&meta->summary.damaged_reads);
-                sm.marginal_gap = ld_coherent(&meta->summary.marginal_gap);
-                sm.marginal_heteroduplex = ld_coherent(&meta->summary.marginal_heteroduplex);
-                sm.marginal_partial = ld_coherent(&meta->summary.marginal_partial);
-                sm.n_positions = ld_coherent(&meta->summary.n_positions);
-                sm.n_haplotypes = ld_coherent(&meta->summary.n_haplotypes);
-                o->summary = sm;
-            }
+        for (int r = 0; r < 8; ++r) {
+            const uint32_t c = h[r] == JL_HAP_DAMAGED ? 15u : (h[r] == JL_HAP_INSUFFICIENT ? 14u : (uint32_t)h[r]);
+            v |= c << (4 * r);
         }
-        if (fits_call)
-            for (uint32_t i = tid; i < n * (uint32_t)(sizeof(jl_variant) / 8); i += nt)
-                reinterpret_cast<uint64_t *>(o->variants)[i] = reinterpret_cast<const uint64_t *>(variants)[i];
-        if (fits_phase) {
-            for (uint32_t i = tid; i < vp; i += nt) o->pos_cols[i] = vpcols[i];
-            for (uint32_t i = tid; i < H; i += nt) o->hap_count[i] = hap_count[i];
-            for (uint32_t i = tid; i < H * vp; i += nt)
-                o->hap_pattern[i] = hap_pattern[(uint64_t)(i / vp) * JL_VARIANT_CAP + (i % vp)];
-            for (uint32_t i = tid; i < nv * H; i += nt) o->hit[i] = hit[(uint64_t)(i / H) * JL_MAX_HAPLOTYPES + (i % H)];
-            if (cooc_fits)
-                for (uint32_t i = tid; i < nv * nv; i += nt) o->cooc[i] = cooc[(uint64_t)(i / nv) * cooc_cap + (i % nv)];
+        reinterpret_cast<uint32_t *>(base)[t] = v;
+    } else if (bits == 8u) {
+        uint32_t lo = 0, hi = 0;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const uint32_t c = h[r] == JL_HAP_DAMAGED ? 255u : (h[r] == JL_HAP_INSUFFICIENT ? 254u : (uint32_t)h[r]);
+            if (r < 4) lo |= c << (8 * r);
+            else hi |= c << (8 * (r - 4));
         }
-    }
-}
-
-__global__ __launch_bounds__(256) void result_pack_kernel(const jl_variant *__restrict__ variants,
-                                                           const uint32_t *__restrict__ n_rows,
-                                                           const jl_phase_meta *__restrict__ meta,
-                                                           jl_pack *__restrict__ pk, jl_pack *__restrict__ mirror,
-                                                           uint32_t *seq_dev, volatile uint32_t *seq_host)
-{
-    // phasing off: only the variant table.  The device copy (the all-gather source) is double-buffered by the
-    // parity of the run index, so an exchange may still read run n's block while run n+1 writes its own.
-    pk += __hip_atomic_load(seq_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 1u;
-    result_pack_block(variants, n_rows[0], meta, 0u, nullptr, nullptr, nullptr, nullptr, nullptr, 0u, 0u, pk, mirror);
-    if (seq_host) {  // last kernel of the run
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (threadIdx.x == 0) signal_done(seq_dev, seq_host);
+        uint2 v;
+        v.x = lo; v.y = hi;
+        reinterpret_cast<uint2 *>(base)[t] = v;
+    } else {
+        uint4 v;
+        v.x = h[0] | ((uint32_t)h[1] << 16); v.y = h[2] | ((uint32_t)h[3] << 16);
+        v.z = h[4] | ((uint32_t)h[5] << 16); v.w = h[6] | ((uint32_t)h[7] << 16);
+        // reads_pad = 2 * col_stride entries: the 16-byte store of a live lane is always inside the buffer
+        reinterpret_cast<uint4 *>(base)[t] = v;
     }
 }
 
@@ -398,6 +339,7 @@ __device__ __forceinline__ void phase_select_block(uint32_t min_reads, uint64_t 
         meta->summary.reported_reads = s_reported;
         meta->summary.insufficient_reads = s_insufficient;
         meta->summary.n_haplotypes = H;
+        __hip_atomic_store(&meta->id_bits, id_bits_for(H), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     for (uint32_t q = tid; q < H * vp; q += nt) {
         const uint32_t h = q / vp, p = q - h * vp;
@@ -405,11 +347,15 @@ __device__ __forceinline__ void phase_select_block(uint32_t min_reads, uint64_t 
     }
     for (uint32_t q = tid; q < nv * H; q += nt) {
         const uint32_t v = q / H, h = q - v * H;
-        const uint32_t c = variants[v].col;
+        // BYKEY: the table (and col2pos) may come from another workgroup of this launch
+        const uint32_t c = BYKEY ? ld_coherent(&variants[v].col) : variants[v].col;
         uint8_t x = 0;
         if (c + 2u < n_cols) {  // rows outside this window never hit
-            const uint32_t p = col2pos[c];
-            x = pattern_code<BYKEY>(keys, slot_key, reads_pad, vp, s_hrep[h], p) == variants[v].codon;
+            const uint32_t p = BYKEY ? ld_coherent(&col2pos[c]) : col2pos[c];
+            // ref_codon / codon / flags share one dword
+            const uint32_t cw = BYKEY ? ld_coherent(reinterpret_cast<const uint32_t *>(&variants[v]) + 3) : 0u;
+            const uint32_t codon = BYKEY ? ((cw >> 8) & 0xFFu) : (uint32_t)variants[v].codon;
+            x = pattern_code<BYKEY>(keys, slot_key, reads_pad, vp, s_hrep[h], p) == codon;
         }
         hit[(uint64_t)v * JL_MAX_HAPLOTYPES + h] = x;
     }
@@ -425,11 +371,15 @@ __device__ __forceinline__ void phase_select_block(uint32_t min_reads, uint64_t 
             cooc[(uint64_t)v * cooc_cap + w] = sum;
         }
     }
-    }  // vp != 0
+    } else if (tid == 0) {
+        __hip_atomic_store(&meta->id_bits, 4u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // nothing phased: every read is "damaged"
+    }
     __syncthreads();
-    // device copy double-buffered by the parity of the run index (see result_pack_kernel)
+    // device copy double-buffered by the parity of the run index (an exchange may still read run n's block while
+    // run n+1 writes its own)
     pk += __hip_atomic_load(seq_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 1u;
-    result_pack_block(variants, n_rows[0], meta, 1u, vpcols, hap_count, hap_pattern, hit, cooc, cooc_cap, 1u, pk, mirror);
+    jl_result_pack_block(variants, ld_coherent(&n_rows[0]), meta, 1u, vpcols, hap_count, hap_pattern, hit, cooc, cooc_cap, 1u, pk,
+                         mirror, BYKEY);
     // leave the table empty for the next run: only the slots this run touched
     for (uint32_t q = tid; q < n_occ; q += nt) {
         const uint32_t s = ld_coherent(&occupied[q]);
@@ -466,6 +416,9 @@ typedef jl_select_args select_args;
 // ---------------------------------------------------------------------------------------- fused keys + group
 // Vp <= 10: the whole pattern is ONE 64-bit word, so the table can be keyed by value (64-bit CAS, no
 // representative lookup) and a block can aggregate before it touches HBM:
+//   0. (whole-path runs) every workgroup derives the variant columns from the call masks the Fisher stage left
+//      (a few KB, L2-resident) — no launch or workgroup hand-off between calling and phasing; one EXTRA workgroup
+//      meanwhile compacts the called rows into the ordered table,
 //   1. every lane builds the keys and flags of its 8 reads (30 independent dword loads in flight),
 //   2. the block's dominant key (that of its first clean read — the wild type for all but pathological
 //      inputs) is counted with popcount-style compares and costs ONE global insert per block,
@@ -474,6 +427,205 @@ typedef jl_select_args select_args;
 // Global atomics on the hot slot drop from one per wave to one per 2048 reads.
 constexpr uint32_t kLdsSlots = 1024;
 constexpr uint64_t kNoKey = ~0ull;
+constexpr uint32_t kPlanList = 256;   // called positions a workgroup can rank in LDS; more take the multi-word pipeline
+
+struct plan_state {   // LDS: what the prologue derives — identical in every workgroup of a window
+    uint32_t n_list, n_rows, vp, ovf;
+    uint32_t cols[JL_POS_PER_WORD];   // the variant columns, ascending (first 10)
+    uint32_t list[kPlanList];
+    uint8_t first[kPlanList];
+};
+
+// Distinct start columns of the called positions, ascending, from the call masks (SPEC §8).  All 256 threads.
+__device__ __forceinline__ void plan_prologue(const select_args &S, uint32_t n_cols, plan_state &L)
+{
+    const uint32_t tid = threadIdx.x;
+    if (tid == 0) { L.n_list = 0; L.n_rows = 0; L.vp = 0; L.ovf = 0; }
+    if (tid < JL_POS_PER_WORD) L.cols[tid] = 0;
+    __syncthreads();
+    const uint32_t P = S.P;
+    for (uint32_t base = 0; base < P; base += 1024u) {
+        unsigned long long m[4];
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; ++k) {   // four independent loads in flight per lane
+            const uint32_t q = base + k * 256u + tid;
+            m[k] = q < P ? S.called[q] : 0ull;
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; ++k) {
+            if (m[k]) {
+                const uint32_t c = S.pos_col[base + k * 256u + tid];
+                atomicAdd(&L.n_rows, (uint32_t)__popcll(m[k]));
+                if (c + 2u < n_cols) {
+                    const uint32_t i = atomicAdd(&L.n_list, 1u);
+                    if (i < kPlanList) L.list[i] = c;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const uint32_t n = min(L.n_list, kPlanList);
+    if (tid < n) {   // first occurrence of its column? (overlapping genes in one frame call the same column twice)
+        const uint32_t c = L.list[tid];
+        bool f = true;
+        for (uint32_t j = 0; j < tid; ++j) f = f && L.list[j] != c;
+        L.first[tid] = f;
+    }
+    __syncthreads();
+    if (tid < n && L.first[tid]) {
+        const uint32_t c = L.list[tid];
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < n; ++j) rank += (L.first[j] && L.list[j] < c) ? 1u : 0u;
+        if (rank < JL_POS_PER_WORD) L.cols[rank] = c;
+        atomicAdd(&L.vp, 1u);
+    }
+    if (tid == 0 && L.n_list > kPlanList) L.ovf = 1u;
+    __syncthreads();
+}
+
+__device__ __forceinline__ uint32_t key_code(uint64_t key, uint32_t vp, uint32_t p) { return (uint32_t)(key >> (6u * (vp - 1u - p))) & 63u; }
+
+// Selection of the single-word pipeline out of LDS: every table word it needs is fetched ONCE (occupied list -> counts
+// and keys: two dependent round trips), ranking, patterns, hit matrix and co-occurrence then run on LDS copies, and
+// the result block is stored from there.  The general routine above chases each of them through memory again (a
+// dozen dependent round trips on one CU: 10 us and more).  Handles what fits the result block (<= 128 candidates,
+// <= 128 variant rows, hit matrix <= 4 KB); returns false — with nothing but idempotent side effects — otherwise.
+constexpr uint32_t kSelCand = JL_PACK_MAX_HAP;
+struct sel_lds {
+    uint32_t slot[kSelCand], cnt[kSelCand];
+    unsigned long long key[kSelCand];
+    uint32_t hcnt[kSelCand];
+    unsigned long long hkey[kSelCand];
+    uint32_t vpos[JL_PACK_MAX_VAR];
+    uint8_t vcodon[JL_PACK_MAX_VAR];
+    uint8_t hit[JL_PACK_HIT_BYTES];
+    uint32_t ncand, insufficient, reported, bail;
+};
+static_assert(sizeof(sel_lds) <= kLdsSlots * 5u * 4u, "the selection's scratch must fit the grouping tables");
+
+__device__ __forceinline__ bool phase_select_lds(const jl_win_phase &w, const plan_state &L, uint32_t vp, uint32_t nv,
+                                                 uint32_t n_rows, sel_lds &T)
+{
+    const select_args &S = w.S;
+    jl_phase_meta *meta = w.meta;
+    const uint32_t tid = threadIdx.x, nt = blockDim.x;
+    const uint32_t n_occ = ld_coherent(&meta->n_occupied);
+    if (tid == 0) { T.ncand = 0; T.insufficient = 0; T.reported = 0; T.bail = (nv > JL_PACK_MAX_VAR || n_rows > JL_PACK_MAX_VAR) ? 1u : 0u; }
+    __syncthreads();
+    if (T.bail) return false;
+    for (uint32_t q = tid; q < n_occ; q += nt) {
+        const uint32_t s = ld_coherent(&w.occupied[q]);
+        const uint32_t c = ld_coherent(&w.slot_count[s]);
+        const unsigned long long k = ld_coherent64(&w.slot_key[s]);
+        if (c >= S.min_reads) {
+            const uint32_t i = atomicAdd(&T.ncand, 1u);
+            if (i < kSelCand) { T.slot[i] = s; T.cnt[i] = c; T.key[i] = k; }
+            else T.bail = 1u;
+        } else {
+            atomicAdd(&T.insufficient, c);
+            __hip_atomic_store(&S.slot_hap[s], (uint32_t)JL_HAP_INSUFFICIENT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    // the variant rows: column -> position index, codon (the table may come from another workgroup of this launch)
+    for (uint32_t v = tid; v < nv; v += nt) {
+        const uint32_t *row = reinterpret_cast<const uint32_t *>(S.variants + v);
+        const uint32_t c = ld_coherent(row + 2), cw = ld_coherent(row + 3);
+        uint32_t pos = 0xFFu;
+        if (c + 2u < S.n_cols)
+            for (uint32_t p = 0; p < vp; ++p) pos = L.cols[p] == c ? p : pos;
+        T.vpos[v] = pos;
+        T.vcodon[v] = (uint8_t)((cw >> 8) & 0xFFu);
+    }
+    __syncthreads();
+    const uint32_t H = T.ncand;
+    if (T.bail || nv * H > JL_PACK_HIT_BYTES) return false;
+    // rank: (count desc, pattern asc); patterns are unique, so the ranks are a permutation
+    for (uint32_t a = tid; a < H; a += nt) {
+        const uint32_t ca = T.cnt[a];
+        const unsigned long long ka = T.key[a];
+        uint32_t rank = 0;
+        for (uint32_t b = 0; b < H; ++b) rank += (T.cnt[b] > ca || (T.cnt[b] == ca && T.key[b] < ka)) ? 1u : 0u;
+        T.hcnt[rank] = ca;
+        T.hkey[rank] = ka;
+        __hip_atomic_store(&S.slot_hap[T.slot[a]], rank, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // read by other workgroups
+        atomicAdd(&T.reported, ca);
+    }
+    __syncthreads();
+    for (uint32_t q = tid; q < nv * H; q += nt) {
+        const uint32_t v = q / H, h = q - v * H;
+        const uint32_t pos = T.vpos[v];
+        T.hit[q] = (pos != 0xFFu && key_code(T.hkey[h], vp, pos) == T.vcodon[v]) ? 1 : 0;
+    }
+    __syncthreads();
+    const uint32_t bits = id_bits_for(H);
+    // ---- outputs.  The resident arrays (stage-API fetches read them) ...
+    for (uint32_t h = tid; h < H; h += nt) S.hap_count[h] = T.hcnt[h];
+    for (uint32_t q = tid; q < H * vp; q += nt) {
+        const uint32_t h = q / vp, p = q - h * vp;
+        S.hap_pattern[(uint64_t)h * JL_VARIANT_CAP + p] = (uint8_t)key_code(T.hkey[h], vp, p);
+    }
+    for (uint32_t q = tid; q < nv * H; q += nt) S.hit[(uint64_t)(q / H) * JL_MAX_HAPLOTYPES + (q % H)] = T.hit[q];
+    const uint32_t nvc = nv < S.cooc_cap ? nv : S.cooc_cap;
+    const bool cooc_fits = nv <= JL_PACK_COOC_N;
+    jl_pack *pk = S.pk + (__hip_atomic_load(S.seq_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 1u);
+    jl_pack *dsts[2] = {pk, S.mirror};
+    for (uint32_t q = tid; q < nvc * nvc; q += nt) {
+        const uint32_t v = q / nvc, x = q - v * nvc;
+        uint32_t sum = 0;
+        for (uint32_t h = 0; h < H; ++h) sum += (T.hit[v * H + h] & T.hit[x * H + h]) ? T.hcnt[h] : 0u;
+        S.cooc[(uint64_t)v * S.cooc_cap + x] = sum;
+        if (cooc_fits)
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+                if (dsts[t]) dsts[t]->cooc[v * nv + x] = sum;
+    }
+    // ... and the result block, device copy (all-gather source) and pinned host mirror, straight from LDS
+    if (tid == 0) {
+        jl_phase_summary sm;
+        sm.reported_reads = T.reported;
+        sm.insufficient_reads = T.insufficient;
+        sm.damaged_reads = ld_coherent(&meta->summary.damaged_reads);
+        sm.marginal_gap = ld_coherent(&meta->summary.marginal_gap);
+        sm.marginal_heteroduplex = ld_coherent(&meta->summary.marginal_heteroduplex);
+        sm.marginal_partial = ld_coherent(&meta->summary.marginal_partial);
+        sm.n_positions = vp;
+        sm.n_haplotypes = H;
+        meta->summary.reported_reads = sm.reported_reads;
+        meta->summary.insufficient_reads = sm.insufficient_reads;
+        meta->summary.n_haplotypes = H;
+        meta->summary.n_positions = vp;
+        __hip_atomic_store(&meta->id_bits, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            jl_pack *o = dsts[t];
+            if (!o) continue;
+            o->magic = JL_PACK_MAGIC; o->nvar_total = n_rows; o->fits_call = 1u; o->fits_phase = 1u;
+            o->phase_ran = 1u; o->overflow = 0u; o->vp = vp; o->H = H;
+            o->nv_phase = nv; o->cooc_fits = cooc_fits ? 1u : 0u; o->id_bits = bits;
+            o->summary = sm;
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        jl_pack *o = dsts[t];
+        if (!o) continue;
+        for (uint32_t i = tid; i < nv * (uint32_t)(sizeof(jl_variant) / 8); i += nt)
+            reinterpret_cast<unsigned long long *>(o->variants)[i] =
+                ld_coherent64(reinterpret_cast<const unsigned long long *>(S.variants) + i);
+        for (uint32_t i = tid; i < vp; i += nt) o->pos_cols[i] = L.cols[i];
+        for (uint32_t i = tid; i < H; i += nt) o->hap_count[i] = T.hcnt[i];
+        for (uint32_t i = tid; i < H * vp; i += nt) o->hap_pattern[i] = (uint8_t)key_code(T.hkey[i / vp], vp, i % vp);
+        for (uint32_t i = tid; i < nv * H; i += nt) o->hit[i] = T.hit[i];
+    }
+    // leave the table empty for the next run: only the slots this run touched
+    for (uint32_t q = tid; q < n_occ; q += nt) {
+        const uint32_t s = ld_coherent(&w.occupied[q]);
+        w.slot_key[s] = ~0ull;
+        w.slot_rep[s] = 0xFFFFFFFFu;
+        w.slot_count[s] = 0;
+    }
+    return true;
+}
 
 __device__ __forceinline__ uint32_t global_insert64(uint64_t key, uint32_t cnt, uint32_t first, uint64_t slots_mask,
                                                     unsigned long long *__restrict__ slot_key,
@@ -503,7 +655,6 @@ __device__ __forceinline__ void phase_fused1_body(const jl_win_phase &w)
 {
     const uint8_t *__restrict__ msa = w.msa;
     const uint64_t col_stride = w.col_stride, n_reads = w.n_reads, reads_pad = w.reads_pad;
-    const uint32_t *__restrict__ vpcols = w.vpcols;
     jl_phase_meta *meta = w.meta;
     uint64_t *keys = w.keys;
     uint32_t *flagw = w.flagw;
@@ -511,55 +662,98 @@ __device__ __forceinline__ void phase_fused1_body(const jl_win_phase &w)
     unsigned long long *slot_key = w.slot_key;
     uint32_t *slot_rep = w.slot_rep, *slot_count = w.slot_count, *occupied = w.occupied, *read_slot = w.read_slot;
     const select_args &S = w.S;
-    const uint32_t vp = meta->vp, kw = meta->kwords;  // one scalar round trip for both; the plan wrote them
-    const bool work = (vp != 0) & (kw == 1);           // block-uniform
     // one LDS block: the grouping tables (8 + 3 x 4 KB), lent to the selection once the grouping is done
-    static_assert(kLdsSlots * 5u >= JL_SELECT_LDS_WORDS, "the selection's scratch must fit the grouping tables");
     __shared__ unsigned long long s_tables[kLdsSlots * 5u / 2u];
     unsigned long long *s_key = s_tables;                                          // [kLdsSlots]
     uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_tables + kLdsSlots);          // [kLdsSlots]
     uint32_t *s_first = s_cnt + kLdsSlots, *s_gslot = s_first + kLdsSlots;         // [kLdsSlots] each
+    __shared__ plan_state s_plan;
     __shared__ unsigned long long s_dom;
     __shared__ uint32_t s_domcnt, s_domfirst, s_domslot;
-    __shared__ uint32_t s_last, s_cat[4];
+    __shared__ uint32_t s_last, s_cat[4], s_idbits, s_scan[4], s_running;
     const uint32_t tid = threadIdx.x;
+    const bool from_called = S.called != nullptr;
+    // whole-path runs launch one workgroup more than the reads need: it compacts the called rows meanwhile
+    const uint32_t n_arrive = w.n_blocks + (from_called ? 1u : 0u);
+    const bool plan_block = from_called && blockIdx.x == w.n_blocks;
+
+    // ---- 0. the plan
+    uint32_t vp, n_rows;
+    bool work;
+    if (from_called) {
+        plan_prologue(S, S.n_cols, s_plan);
+        const uint32_t vpt = s_plan.vp;
+        work = !s_plan.ovf && vpt >= 1u && vpt <= JL_POS_PER_WORD;
+        vp = work ? vpt : 0u;
+        n_rows = s_plan.n_rows;
+        if (plan_block) {
+            // the ordered table (SPEC §6) + what the fetch calls and a multi-word re-run read: written through, the
+            // selection runs in whichever workgroup arrives last
+            const uint32_t n = jl_compact_rows_block<false>(S.P, S.called, S.staged, S.rows, S.cap, s_scan, &s_running,
+                                                            nullptr, 0u, true);
+            if (tid < vp) {
+                __hip_atomic_store(&S.vpcols_out[tid], s_plan.cols[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&S.col2pos_out[s_plan.cols[tid]], tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (tid == 0) {
+                __hip_atomic_store(S.n_rows_out, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t need_kw = (vpt + JL_POS_PER_WORD - 1u) / JL_POS_PER_WORD;
+                uint32_t ovf = 0;
+                if (!work && (vpt != 0u || s_plan.ovf)) ovf = (s_plan.ovf || need_kw <= S.kwords_cap) ? 8u : 4u;
+                __hip_atomic_store(&meta->n_var, n < S.cap ? n : S.cap, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&meta->vp_true, s_plan.ovf ? JL_POS_PER_WORD + 1u : vpt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&meta->vp, vp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&meta->kwords, work ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&meta->overflow, ovf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&meta->summary.n_positions, vp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    } else {
+        const uint32_t mvp = meta->vp, kw = meta->kwords;  // one scalar round trip for both; the plan kernel wrote them
+        work = (mvp != 0) & (kw == 1);                       // block-uniform
+        vp = work ? mvp : 0u;
+        // all ten column indices in one go (the array always holds JL_VARIANT_CAP words; entries past vp are never used)
+        if (tid < JL_POS_PER_WORD) s_plan.cols[tid] = w.vpcols[tid];
+        if (tid == 0) s_plan.n_rows = 0;
+        n_rows = 0;
+        __syncthreads();
+    }
     const uint64_t t = (uint64_t)blockIdx.x * 256u + tid;  // dword index within a column = 8 reads
-    const bool live = t * 4u < col_stride;
+    const bool live = t * 4u < col_stride;                 // never for the extra workgroup
     uint32_t clean_keep = 0;   // bit 4r: read r of this lane is clean
     uint32_t gslot[8];         // global table slot of each clean read
 #pragma unroll
     for (int r = 0; r < 8; ++r) gslot[r] = 0;
-    if (work) {
+    if (work && !plan_block) {
     for (uint32_t i = tid; i < kLdsSlots; i += 256u) { s_key[i] = kNoKey; s_cnt[i] = 0; s_first[i] = 0xFFFFFFFFu; }
     if (tid == 0) { s_dom = kNoKey; s_domcnt = 0; s_domfirst = 0xFFFFFFFFu; s_domslot = 0; }
     if (tid < 4) s_cat[tid] = 0;
     __syncthreads();
 
     // ---- 1. keys and flags
-    // All ten column indices in one go (the array always holds JL_VARIANT_CAP words; entries past vp are never
-    // used): a load per position behind `p < vp` makes each wait for its own scalar round trip.  Lanes past the
-    // end of the columns load from a clamped address and drop the value, so the loads need no per-lane branch.
+    // Lanes past the end of the columns load from a clamped address and drop the value, so the loads need no
+    // per-lane branch.
     uint32_t cols[JL_POS_PER_WORD];
 #pragma unroll
-    for (uint32_t p = 0; p < JL_POS_PER_WORD; ++p) cols[p] = vpcols[p];
+    for (uint32_t p = 0; p < JL_POS_PER_WORD; ++p) cols[p] = s_plan.cols[p];
     const uint64_t t_ld = live ? t : 0u;
-    uint32_t w[JL_POS_PER_WORD][3];
+    uint32_t wd[JL_POS_PER_WORD][3];
 #pragma unroll
     for (uint32_t p = 0; p < JL_POS_PER_WORD; ++p) {
         if (p < vp) {  // block-uniform
 #pragma unroll
             for (int k = 0; k < 3; ++k)
-                w[p][k] = *reinterpret_cast<const uint32_t *>(msa + (uint64_t)(cols[p] + k) * col_stride + t_ld * 4u);
+                wd[p][k] = *reinterpret_cast<const uint32_t *>(msa + (uint64_t)(cols[p] + k) * col_stride + t_ld * 4u);
         } else {
 #pragma unroll
-            for (int k = 0; k < 3; ++k) w[p][k] = 0x66666666u;
+            for (int k = 0; k < 3; ++k) wd[p][k] = 0x66666666u;
         }
     }
     if (!live) {
 #pragma unroll
         for (uint32_t p = 0; p < JL_POS_PER_WORD; ++p)
 #pragma unroll
-            for (int k = 0; k < 3; ++k) w[p][k] = 0x66666666u;
+            for (int k = 0; k < 3; ++k) wd[p][k] = 0x66666666u;
     }
     uint32_t gap = 0, het = 0, par = 0;
     uint64_t key[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -568,13 +762,13 @@ __device__ __forceinline__ void phase_fused1_body(const jl_win_phase &w)
         if (p < vp) {
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
-                const uint32_t b0 = w[p][k] & kM1, b1 = (w[p][k] >> 1) & kM1, b2 = (w[p][k] >> 2) & kM1;
+                const uint32_t b0 = wd[p][k] & kM1, b1 = (wd[p][k] >> 1) & kM1, b2 = (wd[p][k] >> 2) & kM1;
                 gap |= b2 & ~b1 & ~b0;
                 het |= b2 & b0;
                 par |= b2 & b1;
             }
-            const uint32_t hi2 = w[p][0] & 0x33333333u;
-            const uint32_t lo4 = ((w[p][1] & 0x33333333u) << 2) | (w[p][2] & 0x33333333u);
+            const uint32_t hi2 = wd[p][0] & 0x33333333u;
+            const uint32_t lo4 = ((wd[p][1] & 0x33333333u) << 2) | (wd[p][2] & 0x33333333u);
 #pragma unroll
             for (int r = 0; r < 8; ++r)
                 key[r] = (key[r] << 6) | ((((hi2 >> (4 * r)) & 3u) << 4) | ((lo4 >> (4 * r)) & 15u));
@@ -589,8 +783,11 @@ __device__ __forceinline__ void phase_fused1_body(const jl_win_phase &w)
     gap &= valid; het &= valid; par &= valid;
     const uint32_t dirty = gap | het | par;
     const uint32_t cleanm = valid & ~dirty;  // bit 4r: read r is clean
-    if (live) {
+    if (live && !S.fold) {
+        // the flags and slots of every read are only needed by a later launch that writes the ids
         flagw[t] = gap | (het << 1) | (par << 2) | ((valid ^ kM1) << 3);
+    }
+    if (live && !S.run) {   // the multi-word pipeline's own group launch reads the keys
         uint64_t *dst = keys + t * 8u;
 #pragma unroll
         for (int r = 0; r < 8; r += 2) {
@@ -682,22 +879,23 @@ __device__ __forceinline__ void phase_fused1_body(const jl_win_phase &w)
             else  // LDS table full (> 1024 distinct patterns in 2048 reads): straight to the global table
                 g = global_insert64(key[r], 1u, (uint32_t)(t * 8u + r), slots_mask, slot_key, slot_rep, slot_count,
                                     occupied, meta);
-            read_slot[t * 8u + r] = g;
+            if (!S.fold) read_slot[t * 8u + r] = g;
             gslot[r] = g;
         }
     }
     clean_keep = cleanm;
     }  // work
     if (!S.run) return;  // the generic pipeline has its own select launch
-    // ---- hand-off: the block that arrives last ranks the groups and writes the result block (see call_kernel).
-    // Everything the selection reads was written by agent-scope atomics or write-through stores (slot keys and
-    // counts, the occupied list, the read-category counters): no release fence.  The bulk outputs (keys, flags,
-    // per-read slots) are for the NEXT kernel.
+    // ---- hand-off: the block that arrives last ranks the groups and writes the result block.  Everything the
+    // selection reads was written by agent-scope atomics or write-through stores (slot keys and counts, the occupied
+    // list, the read-category counters, the compacted rows): no release fence — an L2 write-back per block serialises
+    // in the L2.  Every wave drains its stores -> block barrier -> one lane: the arrival add; the last arriver reads
+    // with agent-scope loads (past its L1).  The counter is zero before the first launch and the last arriver leaves it zero.
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
         const uint32_t prev = __hip_atomic_fetch_add(S.arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const uint32_t last = prev == w.n_blocks - 1u;
+        const uint32_t last = prev == n_arrive - 1u;
         if (last) {
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -709,9 +907,16 @@ __device__ __forceinline__ void phase_fused1_body(const jl_win_phase &w)
     const bool last = s_last != 0;
     if (!last && !S.fold) return;
     if (last) {
-        phase_select_block<true>(S.min_reads, reads_pad, keys, meta, slot_rep, slot_count, occupied, S.slot_hap, S.variants,
-                                 S.col2pos, S.n_cols, S.hap_count, S.hap_pattern, S.hit, S.n_rows, vpcols, S.cooc, S.cooc_cap,
-                                 S.pk, S.mirror, slot_key, S.seq_dev, reinterpret_cast<uint32_t *>(s_tables));
+        uint32_t nv = from_called ? (n_rows < S.cap ? n_rows : S.cap) : ld_coherent(&meta->n_var);
+        if (!from_called) n_rows = ld_coherent(&S.n_rows[0]);
+        bool done = false;
+        if (work) done = phase_select_lds(w, s_plan, vp, nv, n_rows, *reinterpret_cast<sel_lds *>(s_tables));
+        if (!done) {
+            __syncthreads();
+            phase_select_block<true>(S.min_reads, reads_pad, keys, meta, slot_rep, slot_count, occupied, S.slot_hap, S.variants,
+                                     S.col2pos, S.n_cols, S.hap_count, S.hap_pattern, S.hit, S.n_rows, w.vpcols, S.cooc, S.cooc_cap,
+                                     S.pk, S.mirror, slot_key, S.seq_dev, reinterpret_cast<uint32_t *>(s_tables));
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         // The result block went to pinned host memory from THIS compute die; the completion word will be stored by
@@ -723,17 +928,24 @@ __device__ __forceinline__ void phase_fused1_body(const jl_win_phase &w)
             if (S.seq_host && tid == 0) signal_done(S.seq_dev, S.seq_host);  // no per-read ids wanted: the run ends here
             return;
         }
-        // the slot -> haplotype table is complete (write-through stores, drained above): release the waiting workgroups
-        if (tid == 0) __hip_atomic_store(S.flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else {
-        // wait for the selection.  Every workgroup of this launch is resident (the host folds only grids of at
-        // most 256), so the flag does arrive; the bound turns a broken invariant into a loud failure, not a hang.
+        // the slot -> haplotype table is complete (write-through stores, drained above): release the waiting
+        // workgroups; the flag carries the width of the ids
         if (tid == 0) {
-            uint32_t spins = 0;
-            while (__hip_atomic_load(S.flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
-                __builtin_amdgcn_s_sleep(32);   // ~1 us between polls
-                if (++spins > (1u << 21)) __builtin_trap();
+            const uint32_t bits = ld_coherent(&meta->id_bits);
+            s_idbits = bits;
+            __hip_atomic_store(S.flag, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+    } else {
+        // wait for the selection.  Every workgroup of this launch is resident (the host folds only small grids), so
+        // the flag does arrive; the bound turns a broken invariant into a loud failure, not a hang.
+        if (tid == 0) {
+            uint32_t spins = 0, bits;
+            while ((bits = __hip_atomic_load(S.flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0u) {
+                __builtin_amdgcn_s_sleep(8);
+                if (++spins > (1u << 23)) __builtin_trap();
             }
+            s_idbits = bits;
         }
         __syncthreads();
     }
@@ -746,11 +958,7 @@ __device__ __forceinline__ void phase_fused1_body(const jl_win_phase &w)
             if ((clean_keep >> (4 * r)) & 1u)
                 h[r] = (uint16_t)__hip_atomic_load(&S.slot_hap[gslot[r]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        uint4 v;
-        v.x = h[0] | ((uint32_t)h[1] << 16); v.y = h[2] | ((uint32_t)h[3] << 16);
-        v.z = h[4] | ((uint32_t)h[5] << 16); v.w = h[6] | ((uint32_t)h[7] << 16);
-        // reads_pad = 2 * col_stride entries: the 16-byte store of a live lane is always inside the buffer
-        *reinterpret_cast<uint4 *>(S.read_hap + t * 8u) = v;
+        store_ids(S.read_hap, t, h, s_idbits);
     }
     // Second arrival: every workgroup is past the flag by now, so the one that arrives last resets it (and the
     // counter) for the next launch and, when this launch ends a run, stores the completion word behind all the ids.
@@ -759,7 +967,7 @@ __device__ __forceinline__ void phase_fused1_body(const jl_win_phase &w)
     if (tid == 0) {
         if (S.seq_host) __threadfence_system();   // this workgroup's ids leave its die's L2 before it arrives (see above)
         const uint32_t prev = __hip_atomic_fetch_add(S.arrive2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (prev == w.n_blocks - 1u) {
+        if (prev == n_arrive - 1u) {
             __hip_atomic_store(S.arrive2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(S.flag, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (S.seq_host) signal_done(S.seq_dev, S.seq_host);
@@ -769,27 +977,25 @@ __device__ __forceinline__ void phase_fused1_body(const jl_win_phase &w)
 
 __global__ __launch_bounds__(256) void phase_fused1_kernel(jl_win_phase w) { phase_fused1_body(w); }
 
-// one launch for several windows: blockIdx.z = window, argument blocks in device memory
+// one launch for several windows: blockIdx.z = window
 __global__ __launch_bounds__(256) void phase_group_run_kernel(jl_phase_group_args args)
 {
     const jl_win_phase &w = args.w[blockIdx.z];
-    if (blockIdx.x >= w.n_blocks) return;
+    if (blockIdx.x >= w.n_blocks + (w.S.called ? 1u : 0u)) return;
     phase_fused1_body(w);
 }
 
 // ---------------------------------------------------------------------------------------- assign
-__global__ __launch_bounds__(256) void phase_assign_kernel(uint64_t n_reads, const uint32_t *__restrict__ flagw,
-                                                            const jl_phase_meta *__restrict__ meta,
-                                                            const uint32_t *__restrict__ read_slot,
-                                                            const uint32_t *__restrict__ slot_hap,
-                                                            uint16_t *__restrict__ read_hap, uint32_t *arrive,
-                                                            uint32_t *seq_dev, volatile uint32_t *seq_host)
+// Per-read ids by a launch of their own (launches too large for their workgroups to wait for each other, and the
+// multi-word pipeline).  Eight reads per lane: one flag word, two 16-byte loads of slots, one store of packed ids.
+__device__ __forceinline__ void assign_body(uint64_t n_dwords, const uint32_t *__restrict__ flagw,
+                                            const jl_phase_meta *__restrict__ meta, const uint32_t *__restrict__ read_slot,
+                                            const uint32_t *__restrict__ slot_hap, uint16_t *__restrict__ read_hap)
 {
-    // eight reads per lane: one flag word, two 16-byte loads of slots, one 16-byte store of ids (the id buffer holds
-    // 2 * col_stride entries, so the store of a live lane is always inside it)
     const bool phased = meta->vp != 0;
+    const uint32_t bits = meta->id_bits;
     // t = dword index within a column; the grid may be smaller than the window (see jl_launch_assign_group)
-    for (uint64_t t = (uint64_t)blockIdx.x * 256u + threadIdx.x; t * 8u < n_reads; t += (uint64_t)gridDim.x * 256u) {
+    for (uint64_t t = (uint64_t)blockIdx.x * 256u + threadIdx.x; t < n_dwords; t += (uint64_t)gridDim.x * 256u) {
         uint16_t h[8];
 #pragma unroll
         for (int r = 0; r < 8; ++r) h[r] = JL_HAP_DAMAGED;
@@ -802,55 +1008,24 @@ __global__ __launch_bounds__(256) void phase_assign_kernel(uint64_t n_reads, con
             for (int r = 0; r < 8; ++r)
                 if (((f >> (4 * r)) & 15u) == 0) h[r] = (uint16_t)slot_hap[slot[r]];   // clean reads only: their slot is valid
         }
-        uint4 v;
-        v.x = h[0] | ((uint32_t)h[1] << 16); v.y = h[2] | ((uint32_t)h[3] << 16);
-        v.z = h[4] | ((uint32_t)h[5] << 16); v.w = h[6] | ((uint32_t)h[7] << 16);
-        *reinterpret_cast<uint4 *>(read_hap + t * 8u) = v;
-    }
-    if (seq_host) {
-        // JL_SIGNAL_IN_KERNEL=1 only (comparison variant): the block that arrives last stores the completion word
-        // behind everybody's ids.  Every block releases its ids at system scope first — they may still sit in its
-        // die's L2 otherwise (see done_kernel) — which is what makes this variant slower than a node of its own.
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            __threadfence_system();
-            const uint32_t prev = __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (prev == gridDim.x - 1u) {
-                __hip_atomic_store(arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                signal_done(seq_dev, seq_host);
-            }
-        }
+        store_ids(read_hap, t, h, bits);
     }
 }
 
-// the same for the windows of a group launch (blockIdx.z = window) — used when the group is too large for the
-// launch that groups the reads to write the ids itself (its workgroups would have to be resident all at once)
+__global__ __launch_bounds__(256) void phase_assign_kernel(uint64_t n_dwords, const uint32_t *__restrict__ flagw,
+                                                            const jl_phase_meta *__restrict__ meta,
+                                                            const uint32_t *__restrict__ read_slot,
+                                                            const uint32_t *__restrict__ slot_hap,
+                                                            uint16_t *__restrict__ read_hap)
+{
+    assign_body(n_dwords, flagw, meta, read_slot, slot_hap, read_hap);
+}
+
+// the same for the windows of a group launch (blockIdx.z = window)
 __global__ __launch_bounds__(256) void phase_assign_group_kernel(jl_phase_group_args args)
 {
-    // eight reads per lane: one flag word, two 16-byte loads of slots, one 16-byte store of ids (a wave writes 1 KiB
-    // contiguous — the ids usually go to pinned host memory, and PCIe likes long writes)
     const jl_win_phase &w = args.w[blockIdx.z];
-    const bool phased = w.meta->vp != 0;
-    // dword index within a column = 8 reads; the grid may be smaller than the window (see jl_launch_assign_group)
-    for (uint64_t t = (uint64_t)blockIdx.x * 256u + threadIdx.x; t * 4u < w.col_stride; t += (uint64_t)gridDim.x * 256u) {
-        uint16_t h[8];
-#pragma unroll
-        for (int r = 0; r < 8; ++r) h[r] = JL_HAP_DAMAGED;
-        if (phased) {
-            const uint32_t f = w.flagw[t];
-            const uint4 s0 = *reinterpret_cast<const uint4 *>(w.read_slot + t * 8u);
-            const uint4 s1 = *reinterpret_cast<const uint4 *>(w.read_slot + t * 8u + 4u);
-            const uint32_t slot[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
-#pragma unroll
-            for (int r = 0; r < 8; ++r)
-                if (((f >> (4 * r)) & 15u) == 0) h[r] = (uint16_t)w.S.slot_hap[slot[r]];   // clean reads only: their slot is valid
-        }
-        uint4 v;
-        v.x = h[0] | ((uint32_t)h[1] << 16); v.y = h[2] | ((uint32_t)h[3] << 16);
-        v.z = h[4] | ((uint32_t)h[5] << 16); v.w = h[6] | ((uint32_t)h[7] << 16);
-        *reinterpret_cast<uint4 *>(w.S.read_hap + t * 8u) = v;   // the buffer holds 2 * col_stride entries
-    }
+    assign_body(w.col_stride / 4u, w.flagw, w.meta, w.read_slot, w.S.slot_hap, w.S.read_hap);
 }
 
 }  // namespace
@@ -859,23 +1034,15 @@ __global__ __launch_bounds__(256) void phase_assign_group_kernel(jl_phase_group_
 static uint32_t jl_assign_blocks(uint32_t n_win, uint32_t max_read_blocks, bool to_host)
 {
     if (!to_host) return max_read_blocks;   // ids that stay in HBM: one workgroup per 2048 reads
-    static const int env_cap = getenv("JL_ASSIGN_BLOCKS") ? atoi(getenv("JL_ASSIGN_BLOCKS")) : -1;
-    const uint32_t cap = env_cap >= 0 ? (uint32_t)env_cap : std::max(1u, 32u / std::max(1u, n_win));
-    return cap > 0 ? std::min<uint32_t>(cap, max_read_blocks) : max_read_blocks;
+    const uint32_t cap = std::max(1u, 32u / std::max(1u, n_win));
+    return std::min<uint32_t>(cap, max_read_blocks);
 }
 
-// `signal`: this launch ends a jl_run_async — its last kernel stores the completion word (jl_run_wait)
-void jl_launch_result_pack(jl_ctx *ctx, bool phasing, bool signal)
-{
-    if (phasing) return;  // the selection packs at its end
-    hipLaunchKernelGGL(result_pack_kernel, dim3(1), dim3(256), 0, ctx->stream, ctx->d_variants, ctx->d_nvar, ctx->d_meta,
-                       ctx->d_pack, ctx->pack_mirror, ctx->d_sync, signal ? ctx->h_seq : nullptr);
-}
-
-// Argument block of the fused phase launch for one window.  `fold_budget`: workgroups that may still be added to a
-// launch whose members all wait for each other (the per-read ids are then written by the same launch); returns
-// whether this window folds.
-bool jl_fill_win_phase(jl_ctx *ctx, uint32_t min_reads, bool signal, uint32_t fold_budget, jl_win_phase *w)
+// Argument block of the fused phase launch for one window.  `from_called`: the plan comes out of the call masks of
+// the Fisher stage (whole-path runs); otherwise meta / vpcols hold it already.  `fold_budget`: workgroups that may
+// still be added to a launch whose members all wait for each other (the per-read ids are then written by the same
+// launch); returns whether this window folds.
+bool jl_fill_win_phase(jl_ctx *ctx, uint32_t min_reads, bool signal, uint32_t fold_budget, bool from_called, jl_win_phase *w)
 {
     memset(w, 0, sizeof *w);
     const bool generic = ctx->phase_generic;
@@ -897,26 +1064,31 @@ bool jl_fill_win_phase(jl_ctx *ctx, uint32_t min_reads, bool signal, uint32_t fo
     S.cooc = ctx->d_cooc; S.pk = ctx->d_pack; S.mirror = ctx->pack_mirror;
     S.arrive = ctx->d_sync + 2; S.seq_dev = ctx->d_sync;
     // a launch of at most JL_FOLD_MAX_BLOCKS workgroups in all also writes the per-read ids: one launch less
-    const bool fold = !generic && fblocks <= fold_budget && !getenv("JL_NO_FOLD");
+    const bool fold = !generic && fblocks + 1u <= fold_budget;
     S.fold = fold ? 1u : 0u;
     S.flag = ctx->d_sync + 4; S.arrive2 = ctx->d_sync + 3;
     S.read_hap = ctx->read_hap_out ? ctx->read_hap_out : ctx->d_read_hap;
     S.seq_host = (fold ? signal : signal_select) ? ctx->h_seq : nullptr;
+    if (from_called && !generic) {
+        S.called = ctx->d_called; S.staged = ctx->d_staged; S.pos_col = ctx->d_pos_col; S.rows = ctx->d_variants;
+        S.n_rows_out = ctx->d_nvar; S.vpcols_out = ctx->d_vpcols; S.col2pos_out = ctx->d_col2pos;
+        S.P = ctx->P; S.cap = JL_VARIANT_CAP; S.kwords_cap = ctx->keys_words;
+    }
     return fold;
 }
 
-// `planned`: call_kernel already ran the plan (jl_run_async); otherwise the stand-alone plan kernel runs here.
-// ctx->phase_generic selects the multi-word pipeline; the default runs only the single-word (Vp <= 10) kernel,
-// whose last block also does the selection, and lets the plan flag inputs that need more (jl_phase_fetch then
+// The phasing launches behind a plan.  `from_called`: whole-path run, the Fisher stage left call masks (ignored by the
+// multi-word pipeline, whose plan a compact launch made); otherwise the stand-alone plan kernel runs here when
+// `planned` is false.  ctx->phase_generic selects the multi-word pipeline; the default runs only the single-word
+// (Vp <= 10) kernel, whose last block also does the selection, and flags inputs that need more (jl_phase_fetch then
 // switches and re-runs).  `signal`: this launch ends a jl_run_async — its last kernel stores the completion word.
-void jl_launch_phase(jl_ctx *ctx, uint32_t min_reads, bool planned, bool signal)
+void jl_launch_phase(jl_ctx *ctx, hipStream_t st, uint32_t min_reads, bool planned, bool from_called, bool signal)
 {
-    hipStream_t st = ctx->stream;
     const uint64_t reads_pad = ctx->col_stride * 2u;
     const bool generic = ctx->phase_generic;
     const bool ids_to_host = ctx->read_hap_out != nullptr;
     const bool signal_select = signal && !ids_to_host;
-    if (!planned)
+    if (!planned && !(from_called && !generic))
         hipLaunchKernelGGL(phase_plan_kernel, dim3(1), dim3(1024), 0, st, ctx->d_variants, ctx->d_nvar, JL_VARIANT_CAP,
                            ctx->n_cols, ctx->d_varcol, ctx->d_vpcols, ctx->d_col2pos, ctx->keys_words,
                            generic ? 0u : 1u, ctx->d_meta);
@@ -927,8 +1099,8 @@ void jl_launch_phase(jl_ctx *ctx, uint32_t min_reads, bool planned, bool signal)
                            ctx->col_stride, ctx->n_reads, reads_pad, ctx->d_vpcols, ctx->d_meta, ctx->d_keys,
                            ctx->d_flagw);
     jl_win_phase w;
-    const bool fold = jl_fill_win_phase(ctx, min_reads, signal, JL_FOLD_MAX_BLOCKS, &w);
-    hipLaunchKernelGGL(phase_fused1_kernel, dim3(w.n_blocks), dim3(256), 0, st, w);
+    const bool fold = jl_fill_win_phase(ctx, min_reads, signal, JL_FOLD_MAX_BLOCKS, from_called, &w);
+    hipLaunchKernelGGL(phase_fused1_kernel, dim3(w.n_blocks + (w.S.called ? 1u : 0u)), dim3(256), 0, st, w);
     if (generic) {
         hipLaunchKernelGGL(phase_group_kernel, dim3(rblocks), dim3(256), 0, st, ctx->n_reads, reads_pad, ctx->d_keys,
                            ctx->d_flagw, ctx->d_meta, ctx->table_slots - 1u, ctx->d_slot_rep, ctx->d_slot_count,
@@ -940,9 +1112,9 @@ void jl_launch_phase(jl_ctx *ctx, uint32_t min_reads, bool planned, bool signal)
                            (unsigned long long *)ctx->d_slot_key, ctx->d_sync, signal_select ? ctx->h_seq : nullptr);
     }
     if (fold) return;
-    hipLaunchKernelGGL(phase_assign_kernel, dim3(jl_assign_blocks(1, w.n_blocks, ids_to_host)), dim3(256), 0, st, ctx->n_reads, ctx->d_flagw, ctx->d_meta,
-                       ctx->d_read_slot, ctx->d_slot_hap, ctx->read_hap_out ? ctx->read_hap_out : ctx->d_read_hap,
-                       ctx->d_sync + 3, ctx->d_sync, (signal && ids_to_host) ? ctx->h_seq : nullptr);
+    hipLaunchKernelGGL(phase_assign_kernel, dim3(jl_assign_blocks(1, w.n_blocks, ids_to_host)), dim3(256), 0, st,
+                       (uint64_t)n_dwords, ctx->d_flagw, ctx->d_meta, ctx->d_read_slot, ctx->d_slot_hap,
+                       ctx->read_hap_out ? ctx->read_hap_out : ctx->d_read_hap);
 }
 
 static void fill_phase_group_args(jl_phase_group_args *args, const jl_win_phase *h_wins, uint32_t n_win)
@@ -955,7 +1127,7 @@ void jl_launch_phase_group(const jl_win_phase *h_wins, uint32_t n_win, uint32_t 
 {
     jl_phase_group_args args;
     fill_phase_group_args(&args, h_wins, n_win);
-    hipLaunchKernelGGL(phase_group_run_kernel, dim3(max_blocks, 1, n_win), dim3(256), 0, st, args);
+    hipLaunchKernelGGL(phase_group_run_kernel, dim3(max_blocks + 1u, 1, n_win), dim3(256), 0, st, args);
 }
 
 void jl_launch_assign_group(const jl_win_phase *h_wins, uint32_t n_win, uint32_t max_read_blocks, bool to_host, hipStream_t st)
@@ -964,9 +1136,8 @@ void jl_launch_assign_group(const jl_win_phase *h_wins, uint32_t n_win, uint32_t
     fill_phase_group_args(&args, h_wins, n_win);
     // The ids usually go to pinned host memory, i.e. over PCIe at a fiftieth of the HBM rate.  A launch that has all
     // of them in flight at once (49 workgroups per 100k reads) fills the L2's write queues with host-bound lines and the
-    // pileups of the other launches on the chip wait behind them: 222 us per group of 8 windows against 209 us when
-    // about 32 workgroups (128 KiB of stores in flight) loop over the reads instead — PCIe is saturated either way.
-    // JL_ASSIGN_BLOCKS = workgroups per window (0: one per 2048 reads, as many as it takes).
+    // pileups of the other launches on the chip wait behind them; about 32 workgroups looping over the reads keep PCIe
+    // saturated all the same.
     const uint32_t bx = jl_assign_blocks(n_win, max_read_blocks, to_host);
     hipLaunchKernelGGL(phase_assign_group_kernel, dim3(bx, 1, n_win), dim3(256), 0, st, args);
 }

@@ -28,6 +28,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include "call_eval.h"
 #include "jl_internal.h"
 
 // Register prefetch of the next tile while the current one is counted: 27.4 us vs 31.6 us per 150 MB launch
@@ -262,10 +263,13 @@ __device__ __forceinline__ void pileup_stream(const uint8_t JL_AS1 *msa, uint64_
     }
 }
 
-template <int W, bool PIPE, int MODE>
+// CALL: the Fisher stage runs here too — the workgroup that counted a codon evaluates its positions from the histogram
+// still in LDS (one wave per position, call_eval.h) instead of a later launch reading it back from HBM.  Only when one
+// workgroup counts a chunk alone (gridDim.y = 1); the host picks the variant.
+template <int W, bool PIPE, int MODE, bool CALL>
 __device__ __forceinline__ void pileup_body(const uint8_t JL_AS1 *msa, uint64_t col_stride, uint32_t n_cols,
                                             uint32_t n_tiles, const uint2 JL_AS1 *chunks, const uint32_t JL_AS1 *guess32,
-                                            uint32_t JL_AS1 *counts, uint32_t JL_AS1 *hist)
+                                            uint32_t JL_AS1 *counts, uint32_t JL_AS1 *hist, const jl_callinfo *ci_mem)
 {
     __shared__ uint32_t s_hist[W][64];
     __shared__ uint32_t s_col[W][6];   // A C G T - N
@@ -336,30 +340,56 @@ __device__ __forceinline__ void pileup_body(const uint8_t JL_AS1 *msa, uint64_t 
             else if (v) atomicAdd((uint32_t *)(hist + (uint64_t)(c0 + j) * 64u + (i & 63u)), v);
         }
     }
+    if (CALL) {
+        // ---- Fisher stage of this chunk's positions: wave w takes every fourth codon start.
+        const uint32_t wid = tid >> 6, lane = tid & 63u;
+        const jl_callinfo *ci = ci_mem;
+        if (blockIdx.x == 0 && tid == 0 && ci->meta) {
+            // counters of the phasing launch that follows on the stream
+            jl_phase_meta *m = ci->meta;
+            m->n_occupied = 0;
+            m->overflow = 0;
+            jl_phase_summary z = {0, 0, 0, 0, 0, 0, 0, 0};
+            m->summary = z;
+        }
+        uint32_t nstart = 0;
+#pragma clang loop unroll(disable)
+        for (uint32_t j = 0; j < (uint32_t)W; ++j) {
+            if (!(startf & (1u << j))) continue;
+            if ((nstart++ & 3u) != wid) continue;
+            const uint32_t col = c0 + j;
+            const uint32_t h = (&s_hist[0][0])[j * 64u + lane];
+#pragma clang loop unroll(disable)
+            for (uint32_t p = ci->col_first[col]; p != 0xFFFFFFFFu; p = ci->pos_next[p])   // wave-uniform
+                jl_call_position<false>(ci->A, p, col, h, ci->pos_refcfg[p], ci->pos_gene[p], ci->pos_codon[p], ci->drm,
+                                        ci->called, ci->staged);
+        }
+    }
 }
 
-template <int W, bool PIPE, int MODE>
-__global__ __launch_bounds__(256) void pileup_kernel(const uint8_t *__restrict__ msa, uint64_t col_stride,
+template <int W, bool PIPE, int MODE, bool CALL>
+__global__ __launch_bounds__(256, CALL ? 5 : 1) void pileup_kernel(const uint8_t *__restrict__ msa, uint64_t col_stride,
                                                       uint32_t n_cols, uint32_t n_tiles,
                                                       const uint2 *__restrict__ chunks,
                                                       const uint32_t *__restrict__ guess32,
-                                                      uint32_t *__restrict__ counts, uint32_t *__restrict__ hist)
+                                                      uint32_t *__restrict__ counts, uint32_t *__restrict__ hist,
+                                                      const jl_callinfo *__restrict__ ci)
 {
-    pileup_body<W, PIPE, MODE>((const uint8_t JL_AS1 *)msa, col_stride, n_cols, n_tiles, (const uint2 JL_AS1 *)chunks,
-                               (const uint32_t JL_AS1 *)guess32, (uint32_t JL_AS1 *)counts, (uint32_t JL_AS1 *)hist);
+    pileup_body<W, PIPE, MODE, CALL>((const uint8_t JL_AS1 *)msa, col_stride, n_cols, n_tiles, (const uint2 JL_AS1 *)chunks,
+                                     (const uint32_t JL_AS1 *)guess32, (uint32_t JL_AS1 *)counts, (uint32_t JL_AS1 *)hist, ci);
 }
 
 // One launch over several resident windows (blockIdx.z = window, argument blocks in device memory): the stream of a
 // 150 MB window is too short to hide a launch's ramp and drain, four of them in one grid run at the rate of a
 // 600 MB stream.  Every window is counted by one block per chunk (gridDim.y = 1: plain stores, no zeroing pass).
-template <int W, bool PIPE, int MODE>
-__global__ __launch_bounds__(256) void pileup_group_kernel(jl_pileup_group_args args)
+template <int W, bool PIPE, int MODE, bool CALL>
+__global__ __launch_bounds__(256, CALL ? 5 : 1) void pileup_group_kernel(jl_pileup_group_args args)
 {
     const jl_win_pileup &w = args.w[blockIdx.z];
     if (blockIdx.x >= w.n_chunks) return;
     // the pointers come out of memory: say that they are global ones, or the loads become flat loads (JL_AS1)
-    pileup_body<W, PIPE, MODE>((const uint8_t JL_AS1 *)w.msa, w.col_stride, w.n_cols, w.n_tiles, (const uint2 JL_AS1 *)w.chunks,
-                               (const uint32_t JL_AS1 *)w.guess32, (uint32_t JL_AS1 *)w.counts, (uint32_t JL_AS1 *)w.hist);
+    pileup_body<W, PIPE, MODE, CALL>((const uint8_t JL_AS1 *)w.msa, w.col_stride, w.n_cols, w.n_tiles, (const uint2 JL_AS1 *)w.chunks,
+                                     (const uint32_t JL_AS1 *)w.guess32, (uint32_t JL_AS1 *)w.counts, (uint32_t JL_AS1 *)w.hist, w.ci);
 }
 
 // Seed base per column for majority-codon mode: majority base among the first reads of the column.
@@ -397,13 +427,16 @@ struct variant_t {
     int w;
     bool pipe;
     int mode;  // bit 0: loads only (probe), bit 1: popcount measurements (probe), bit 2: non-temporal loads, bit 3: no stream (probe)
-    void (*fn)(const uint8_t *, uint64_t, uint32_t, uint32_t, const uint2 *, const uint32_t *, uint32_t *, uint32_t *);
+    void (*fn)(const uint8_t *, uint64_t, uint32_t, uint32_t, const uint2 *, const uint32_t *, uint32_t *, uint32_t *, const jl_callinfo *);
     void (*gfn)(jl_pileup_group_args);
+    // the same with the Fisher stage in the epilogue
+    void (*fn_call)(const uint8_t *, uint64_t, uint32_t, uint32_t, const uint2 *, const uint32_t *, uint32_t *, uint32_t *, const jl_callinfo *);
+    void (*gfn_call)(jl_pileup_group_args);
 };
 
 // Default builds use non-temporal loads: every cell is read once, and at 2.4 GB they lift the stream from 5.6 to
 // 6.3 TB/s (no difference at 150 MB).
-#define JL_V(W, P, M) {W, P, M, pileup_kernel<W, P, M>, pileup_group_kernel<W, P, M>}
+#define JL_V(W, P, M) {W, P, M, pileup_kernel<W, P, M, false>, pileup_group_kernel<W, P, M, false>, pileup_kernel<W, P, M, true>, pileup_group_kernel<W, P, M, true>}
 const variant_t kVariants[] = {
     JL_V(6, false, 4), JL_V(6, true, 4), JL_V(12, false, 4), JL_V(3, false, 4), JL_V(3, true, 4),
 #ifdef JL_PILEUP_TUNING   // probes (results wrong by design except mode 0/6): JL_PILEUP_MODE selects
@@ -412,15 +445,21 @@ const variant_t kVariants[] = {
 #endif
 };
 
+// Launch-shape switches exist for tuning builds only (make EXTRA=-DJL_TUNING); the shipped library reads no
+// environment variable on its launch paths.
+#ifdef JL_TUNING
 int env_int(const char *name, int dflt)
 {
     const char *s = getenv(name);
     return s && *s ? atoi(s) : dflt;
 }
+#else
+constexpr int env_int(const char *, int dflt) { return dflt; }
+#endif
 
 }  // namespace
 
-const char *jl_pileup_kernel_name(void) { return "pileup_kernel"; }
+const char *jl_pileup_kernel_name(void) { return "pileup_kernel"; }   // rocprofv3 prints the template arguments behind it
 
 void jl_launch_guess(jl_ctx *ctx, hipStream_t st)
 {
@@ -480,20 +519,24 @@ uint32_t jl_pileup_rsplit(jl_ctx *ctx)
 // With one read split every chunk is counted by exactly one block, which stores its totals: no zeroing needed.
 bool jl_pileup_needs_zero(jl_ctx *ctx) { return jl_pileup_rsplit(ctx) != 1u; }
 
-void jl_launch_pileup(jl_ctx *ctx, hipStream_t st)
+void jl_launch_pileup(jl_ctx *ctx, hipStream_t st, bool with_call)
 {
     const int idx = pick_variant(ctx);
     const variant_t *var = &kVariants[idx];
     const uint32_t n_tiles = (uint32_t)((ctx->col_stride + JL_PILEUP_TILE_BYTES - 1) / JL_PILEUP_TILE_BYTES);
     const uint32_t rsplit = jl_pileup_rsplit(ctx);
+    if (with_call && rsplit != 1u) with_call = false;   // callers check jl_pileup_can_call first; never evaluate partial histograms
     // Unused dynamic LDS caps the blocks per CU: one pileup launch then fills the chip's block slots by itself, so
     // a second batch's pileup (another stream) starts as this one's blocks retire instead of running beside it —
     // two 150 MB streams side by side reach 3.6 TB/s together, one alone 5.5 (tools_tuning/timeline.py).
     const uint32_t lds_pad = (uint32_t)env_int("JL_PILEUP_LDS_KB", 0) * 1024u;
-    hipLaunchKernelGGL(var->fn, dim3(ctx->n_chunks, rsplit), dim3(256), lds_pad, st, ctx->d_msa, ctx->col_stride,
-                       ctx->n_cols, n_tiles, (const uint2 *)ctx->d_chunks, (const uint32_t *)ctx->d_guess, ctx->d_counts,
-                       ctx->d_hist);
+    hipLaunchKernelGGL(with_call ? var->fn_call : var->fn, dim3(ctx->n_chunks, rsplit), dim3(256), lds_pad, st, ctx->d_msa,
+                       ctx->col_stride, ctx->n_cols, n_tiles, (const uint2 *)ctx->d_chunks, (const uint32_t *)ctx->d_guess,
+                       ctx->d_counts, ctx->d_hist, (const jl_callinfo *)(with_call ? ctx->d_callinfo : nullptr));
 }
+
+// The Fisher stage can ride in the pileup launch when one workgroup counts every chunk alone.
+bool jl_pileup_can_call(jl_ctx *ctx) { return jl_pileup_rsplit(ctx) == 1u; }
 
 void jl_fill_win_pileup(jl_ctx *ctx, jl_win_pileup *w)
 {
@@ -507,11 +550,13 @@ void jl_fill_win_pileup(jl_ctx *ctx, jl_win_pileup *w)
     w->guess32 = (const uint32_t *)ctx->d_guess;
     w->counts = ctx->d_counts;
     w->hist = ctx->d_hist;
+    w->ci = nullptr;
 }
 
 // Every window of a group must use the same kernel variant; each is counted by ONE block per chunk whatever its
 // depth (a single run would split very long columns over several blocks).
-int jl_launch_pileup_group(jl_ctx *const *ctxs, uint32_t n_win, const jl_win_pileup *h_wins, uint32_t max_chunks, hipStream_t st)
+int jl_launch_pileup_group(jl_ctx *const *ctxs, uint32_t n_win, const jl_win_pileup *h_wins, uint32_t max_chunks, hipStream_t st,
+                           bool with_call)
 {
     const int idx = pick_variant(ctxs[0]);
     if (n_win > JL_GROUP_WINDOWS_MAX) return JL_ERR_ARG;
@@ -520,6 +565,7 @@ int jl_launch_pileup_group(jl_ctx *const *ctxs, uint32_t n_win, const jl_win_pil
     jl_pileup_group_args args;
     memset(&args, 0, sizeof args);
     memcpy(args.w, h_wins, sizeof(jl_win_pileup) * n_win);
-    hipLaunchKernelGGL(kVariants[idx].gfn, dim3(max_chunks, 1, n_win), dim3(256), 0, st, args);
+    for (uint32_t k = 0; k < n_win; ++k) args.w[k].ci = with_call ? ctxs[k]->d_callinfo : nullptr;
+    hipLaunchKernelGGL(with_call ? kVariants[idx].gfn_call : kVariants[idx].gfn, dim3(max_chunks, 1, n_win), dim3(256), 0, st, args);
     return JL_OK;
 }

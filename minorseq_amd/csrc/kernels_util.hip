@@ -269,6 +269,7 @@ void jl_launch_done(jl_ctx *ctx)
     hipLaunchKernelGGL(done_kernel, dim3(1), dim3(1), 0, ctx->stream, ctx->d_sync, ctx->h_seq);
 }
 
+#ifdef JL_TUNING
 // tuning aid (JL_TIMELINE=1): a one-thread node that records the device's constant-rate clock between the stages of
 // a run, row = runs completed so far; read back with jl_debug_timeline (tools_tuning/timeline.py)
 __global__ void stamp_kernel(const uint32_t *__restrict__ seq_dev, uint64_t *__restrict__ tl, uint32_t slot)
@@ -280,10 +281,9 @@ void jl_launch_stamp(jl_ctx *ctx, uint32_t slot)
     if (!ctx->d_timeline) return;
     hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(1), 0, ctx->stream, ctx->d_sync, ctx->d_timeline, slot);
 }
-
-// tuning probe: what does one more (empty) dependent node cost a pipelined step?
-__global__ void noop_kernel(uint32_t *p) { if (p == nullptr && threadIdx.x == 12345u) *p = 0; }
-void jl_launch_noop(jl_ctx *ctx) { hipLaunchKernelGGL(noop_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->d_nvar); }
+#else
+void jl_launch_stamp(jl_ctx *, uint32_t) {}
+#endif
 
 void jl_launch_consensus(jl_ctx *ctx, uint8_t *d_out)
 {

@@ -1,0 +1,87 @@
+// result_pack.h — block-level device routines shared by the kernels that END a run: the fixed-size result block
+// (device copy = all-gather source, pinned host mirror) and the completion word (see jl_run_wait).
+#pragma once
+#include "jl_internal.h"
+
+// Words that other workgroups of the SAME launch update (group counts and keys, the occupied list, the read-category
+// counters) are read past this CU's L1 with agent-scope loads: memory-side atomics do not refresh a copy another
+// XCD's L2 may still hold.
+__device__ __forceinline__ uint32_t jl_ld_coherent(const uint32_t *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long jl_ld_coherent64(const unsigned long long *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Completion word of a run: stored by ONE thread after everything the run wrote for the host has been drained by
+// its writers and a block barrier; `seq_host` is pinned host memory.
+__device__ __forceinline__ void jl_signal_done(uint32_t *seq_dev, volatile uint32_t *seq_host)
+{
+    const uint32_t v = __hip_atomic_load(seq_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+    __hip_atomic_store(seq_dev, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence_system();
+    __hip_atomic_store(const_cast<uint32_t *>(seq_host), v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// Gathers the small results into one fixed-size block.  pk: device copy; pk2: pinned host mirror (may be null) —
+// both written directly.  `variants_coherent`: the rows were written by another workgroup of this launch.
+__device__ __forceinline__ void jl_result_pack_block(const jl_variant *__restrict__ variants, uint32_t n,
+                                                     const jl_phase_meta *meta, uint32_t phasing,
+                                                     const uint32_t *__restrict__ vpcols,
+                                                     const uint32_t *__restrict__ hap_count,
+                                                     const uint8_t *__restrict__ hap_pattern,
+                                                     const uint8_t *__restrict__ hit, const uint32_t *__restrict__ cooc,
+                                                     uint32_t cooc_cap, uint32_t cooc_ready, jl_pack *__restrict__ pk,
+                                                     jl_pack *__restrict__ pk2, bool variants_coherent = false)
+{
+    const uint32_t tid = threadIdx.x, nt = blockDim.x;
+    const uint32_t fits_call = n <= JL_PACK_MAX_VAR;
+    uint32_t vp = 0, H = 0, nv = 0, ovf = 0, fits_phase = 0, cooc_fits = 0, id_bits = 16;
+    if (phasing) {
+        vp = jl_ld_coherent(&meta->vp); H = jl_ld_coherent(&meta->summary.n_haplotypes); nv = jl_ld_coherent(&meta->n_var);
+        ovf = jl_ld_coherent(&meta->overflow);
+        id_bits = jl_ld_coherent(&meta->id_bits);
+        fits_phase = ovf == 0 && fits_call && vp <= JL_PACK_MAX_VP && H <= JL_PACK_MAX_HAP &&
+                     H * vp <= JL_PACK_PATTERN_BYTES && nv * H <= JL_PACK_HIT_BYTES;
+        cooc_fits = cooc_ready && nv <= JL_PACK_COOC_N;
+    }
+    jl_pack *dsts[2] = {pk, pk2};
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        jl_pack *o = dsts[t];
+        if (!o) continue;
+        if (tid == 0) {
+            o->magic = JL_PACK_MAGIC; o->nvar_total = n; o->fits_call = fits_call; o->fits_phase = fits_phase;
+            o->phase_ran = phasing; o->overflow = ovf; o->vp = vp; o->H = H;
+            o->nv_phase = nv; o->cooc_fits = cooc_fits; o->id_bits = id_bits;
+            if (phasing) {   // the category counters were added to by other workgroups of this launch
+                jl_phase_summary sm;
+                sm.reported_reads = jl_ld_coherent(&meta->summary.reported_reads);
+                sm.insufficient_reads = jl_ld_coherent(&meta->summary.insufficient_reads);
+                sm.damaged_reads = jl_ld_coherent(&meta->summary.damaged_reads);
+                sm.marginal_gap = jl_ld_coherent(&meta->summary.marginal_gap);
+                sm.marginal_heteroduplex = jl_ld_coherent(&meta->summary.marginal_heteroduplex);
+                sm.marginal_partial = jl_ld_coherent(&meta->summary.marginal_partial);
+                sm.n_positions = jl_ld_coherent(&meta->summary.n_positions);
+                sm.n_haplotypes = jl_ld_coherent(&meta->summary.n_haplotypes);
+                o->summary = sm;
+            }
+        }
+        if (fits_call)
+            for (uint32_t i = tid; i < n * (uint32_t)(sizeof(jl_variant) / 8); i += nt) {
+                const unsigned long long *src = reinterpret_cast<const unsigned long long *>(variants) + i;
+                reinterpret_cast<unsigned long long *>(o->variants)[i] = variants_coherent ? jl_ld_coherent64(src) : *src;
+            }
+        if (fits_phase) {
+            for (uint32_t i = tid; i < vp; i += nt) o->pos_cols[i] = vpcols[i];
+            for (uint32_t i = tid; i < H; i += nt) o->hap_count[i] = hap_count[i];
+            for (uint32_t i = tid; i < H * vp; i += nt)
+                o->hap_pattern[i] = hap_pattern[(uint64_t)(i / vp) * JL_VARIANT_CAP + (i % vp)];
+            for (uint32_t i = tid; i < nv * H; i += nt) o->hit[i] = hit[(uint64_t)(i / H) * JL_MAX_HAPLOTYPES + (i % H)];
+            if (cooc_fits)
+                for (uint32_t i = tid; i < nv * nv; i += nt) o->cooc[i] = cooc[(uint64_t)(i / nv) * cooc_cap + (i % nv)];
+        }
+    }
+}

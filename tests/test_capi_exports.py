@@ -76,6 +76,6 @@ def test_header_is_plain_c_and_links(tmp_path):
     out = subprocess.run([str(exe)], capture_output=True, text=True)
     assert out.returncode == 0, out.stderr
     ver, n, rc, msg = out.stdout.strip().split(" ", 3)
-    assert ver == "2"
+    assert ver == "3"
     if n == "0":
         assert rc == "-2" and "no CPU fallback" in msg      # loud failure without a device

@@ -112,7 +112,7 @@ def test_config3_whole_reference_as_eight_windows_on_one_gpu(oracle):
         # five are the planted ones (wild type, then the four 1 % minors; Y181C + G190A travel together, A.3)
         assert s["n_haplotypes"] >= 5 and ph["hit"][:, 0].sum() == 0
         assert sorted(int(ph["hit"][:, h].sum()) for h in range(1, 5)) == [1, 1, 1, 2]
-        assert (ph["hap_count"][1:5] > 0.008 * n).all() and (ph["hap_count"][5:] < 0.001 * n).all()
+        assert (ph["hap_count"][1:5] > 0.005 * n).all() and (ph["hap_count"][5:] < 0.001 * n).all()
         # the per-GPU share with phasing on, through one jl_run_async (rank 1 holds three of the five variants)
         out = ctxs[1].run(genes, ref, prm, phasing=True)
         assert_variants_equal(out["variants"], exp_tables[1])

@@ -403,14 +403,13 @@ def test_run_graph_replay_tracks_new_data_and_parameters(jl, oracle):
     exp_v = oracle.call(rows3, g3)
     assert_variants_equal(out["variants"], exp_v)
     assert_phase_equal(out["phase"], oracle.phase(rows3, exp_v), len(exp_v))
-    # eager path (no graph) gives the same answer
-    os.environ["JL_NO_GRAPH"] = "1"
-    try:
-        out2 = j.run(g3, None, capi.default_params())
-    finally:
-        del os.environ["JL_NO_GRAPH"]
-    assert (out2["variants"] == out["variants"]).all()
-    assert out2["phase"]["summary"] == out["phase"]["summary"]
+    # a configuration runs eagerly the first time and as a captured graph from its second run on: same answers
+    prm3 = capi.default_params()
+    for _ in range(3):
+        out2 = j.run(g3, None, prm3)
+        assert (out2["variants"] == out["variants"]).all()
+        assert out2["phase"]["summary"] == out["phase"]["summary"]
+        assert (out2["phase"]["read_hap"] == out["phase"]["read_hap"]).all()
     j.close()
 
 
@@ -478,16 +477,16 @@ def test_run_view_and_completion_word(jl, oracle):
 
 
 @pytest.mark.parametrize("fold", [True, False])
-def test_group_run_equals_single_runs_and_oracle(jl, oracle, fold, monkeypatch):
+def test_group_run_equals_single_runs_and_oracle(jl, oracle, fold):
     """jl_group_run_async: several windows through the path in three launches (blockIdx.z = window).  Windows of
     different depth and noise, the same genes: every window's results must equal the oracle's (and so a single
     run's), over graph replays, after new reads were generated into the same buffers, and in majority-codon mode.
-    fold = False: the layout large groups use (per-read ids from a launch of their own, nothing waits in a launch)."""
-    if not fold:
-        monkeypatch.setenv("JL_NO_FOLD", "1")
+    fold = False: windows deep enough that the phasing launch has more workgroups than may wait for each other (128):
+    the layout large groups use (per-read ids from a launch of their own, nothing waits in a launch)."""
     l = 300
     genes = np.array([(1, l + 1)], dtype=capi.GENE)
-    shapes = [(9000, 0.05), (5000, 0.0), (12345, 0.2), (2048, 0.1)]
+    k_ = 1 if fold else 15
+    shapes = [(9000 * k_, 0.05), (5000 * k_, 0.0), (12345 * k_, 0.2), (2048 * k_, 0.1)]
     ref = synth.reference(90, l)
     ctxs = []
     for k, (n, partial) in enumerate(shapes):
@@ -575,17 +574,16 @@ def test_bench_configuration_group_of_eight_full_size_windows(oracle):
 
 
 @pytest.mark.parametrize("fold", [True, False])
-def test_group_run_with_more_windows_than_a_stage_launch_takes(oracle, fold, monkeypatch):
-    """A group of 11 windows: ONE pileup launch, the call / phase / id stages in launches of 8 + 3 windows.  Every
-    window against the oracle, over a graph replay."""
-    if not fold:
-        monkeypatch.setenv("JL_NO_FOLD", "1")
+def test_group_run_with_more_windows_than_a_stage_launch_takes(oracle, fold):
+    """A group of 19 windows = chunks of 8 + 8 + 3 pipelined inside one captured graph (the counting of a chunk beside
+    the phasing of the previous one, side streams forked and joined by events).  Every window against the oracle, over
+    graph replays.  fold = False: deeper windows, the per-read ids come from a launch of their own."""
     l = 150
     genes = np.array([(1, l + 1)], dtype=capi.GENE)
     ref = synth.reference(41, l)
     ctxs, exp = [], []
-    for k in range(11):
-        n = 1500 + 433 * k
+    for k in range(19):
+        n = (1500 + 433 * k) * (1 if fold else 12)
         j = capi.Juliet(0)
         j.alloc(n, l)
         j.synth_fill(synth.SynthParams(seed=41 + k, minor_permille=(60, 50, 40, 30), partial_rate=0.02 * k), ref)

@@ -1,0 +1,236 @@
+"""GPU parity for what round 2 added to the C ABI: the two-sided Fisher tail, packed per-read ids (4 / 8 / 16 bits),
+group runs without phasing and with --drm-only masks per window, overlapping genes that share start columns
+(several positions evaluated by the workgroup that counted the codon), and a soak test of the hand-offs between
+workgroups (fresh reads in every buffer on every replay)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle_lib
+from minorseq_amd import capi, msa, synth
+from test_gpu_parity import P_ABS_TOL, assert_phase_equal, assert_variants_equal, oracle_params
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def jl():
+    j = capi.Juliet(0)
+    yield j
+    j.close()
+
+
+def test_two_sided_tail_on_the_device(jl, oracle):
+    """`tail` = 1.  Device numerics (symmetric closed form) against the oracle's brute-force sum
+    over all tables, then whole calls: codons observed significantly LESS often than expected are called too."""
+    rng = np.random.default_rng(7)
+    n = rng.integers(1, 200000, size=4000).astype(np.uint32)
+    a = np.minimum(rng.integers(0, 400, size=4000), n).astype(np.uint32)
+    c = np.minimum(rng.integers(0, 60, size=4000), n).astype(np.uint32)
+    p, lp = jl.fisher_eval(a, c, n, tail=1)
+    for i in range(0, 4000, 7):
+        op, olp = oracle.fisher(int(a[i]), int(n[i] - a[i]), int(c[i]), int(n[i] - c[i]), tail=1)
+        assert abs(p[i] - op) <= P_ABS_TOL
+        if np.isfinite(olp) and olp < -1e-9:
+            assert abs(lp[i] - olp) <= 1e-8 * max(1.0, abs(olp))
+    sp = synth.SynthParams(seed=21, minor_permille=(60, 50, 40, 30), sub_rate=0.004)
+    l, nreads = 300, 6000
+    ref = synth.reference(sp.seed, l)
+    rows = synth.rows(sp, l, 0, nreads, ref)
+    genes = np.array([(1, l + 1)], dtype=capi.GENE)
+    jl.upload_rows(rows)
+    for tail in (1, 0):
+        prm = capi.default_params(tail=tail, alpha=0.05, n_tests=50)
+        out = jl.run(genes, ref, prm, phasing=True)
+        ev = oracle.call(rows, genes, refseq=ref, params=oracle_params(prm))
+        assert len(ev) > 5
+        assert_variants_equal(out["variants"], ev)
+        assert_phase_equal(out["phase"], oracle.phase(rows, ev), len(ev))
+    # stage API too
+    prm = capi.default_params(tail=1, alpha=0.05, n_tests=50)
+    jl.pileup_async(genes, ref)
+    jl.call_async(prm)
+    assert_variants_equal(jl.call_fetch(), oracle.call(rows, genes, refseq=ref, params=oracle_params(prm)))
+
+
+def many_haplotypes(n_hap, reads_each, rng):
+    """A 6-column matrix with n_hap distinct clean patterns of >= 10 reads each (plus damaged and sparse reads)."""
+    pats = []
+    for c0 in range(64):
+        for c1 in range(64):
+            pats.append((c0, c1))
+    rng.shuffle(pats)
+    pats = [(0, 0)] + [p for p in pats if p != (0, 0)][: n_hap - 1]
+    rows = []
+    for k, (c0, c1) in enumerate(pats):
+        cnt = reads_each + (k % 7)
+        r = np.zeros((cnt, 6), dtype=np.uint8)
+        r[:, 0:3] = [c0 >> 4, (c0 >> 2) & 3, c0 & 3]
+        r[:, 3:6] = [c1 >> 4, (c1 >> 2) & 3, c1 & 3]
+        rows.append(r)
+    extra = np.zeros((50, 6), dtype=np.uint8)
+    extra[:20, 1] = msa.SYM_GAP
+    extra[20:40, 4] = msa.SYM_MASK
+    extra[40:45, :] = [3, 3, 3, 3, 3, 2]     # five reads of a pattern of its own: insufficient coverage
+    extra[45:, 0] = msa.SYM_NONE
+    m = np.concatenate(rows + [extra])
+    return m[rng.permutation(len(m))]
+
+
+@pytest.mark.parametrize("n_hap,bits", [(5, 4), (14, 4), (15, 8), (200, 8), (254, 8), (255, 16), (400, 16)])
+def test_per_read_ids_travel_in_the_narrowest_code(jl, oracle, n_hap, bits):
+    """4 bits up to 14 haplotypes, 8 up to 254, 16 beyond: the run view exposes the packed form and its width, every
+    fetch gives the oracle's 16-bit ids; single run (ids written by the phasing launch) and group run."""
+    rng = np.random.default_rng(n_hap)
+    rows = many_haplotypes(n_hap, 12, rng)
+    var = np.zeros(2, dtype=capi.VARIANT)
+    var["col"] = [0, 3]
+    exp = oracle.phase(rows, var.astype(oracle_lib.VARIANT))
+    assert exp["summary"]["n_haplotypes"] == n_hap
+    genes = np.array([(1, 7)], dtype=capi.GENE)
+    # through the whole path: majority mode calls every non-major codon that is frequent enough; compare with the oracle
+    jl.upload_rows(rows)
+    prm = capi.default_params(alpha=0.5, n_tests=1)
+    jl.run_async(genes, None, prm, None, True, 10, True)
+    ev = oracle.call(rows, genes, params=oracle_params(prm))
+    ep = oracle.phase(rows, ev)
+    view = jl.run_view()
+    rv = capi.RunView()
+    assert jl.lib.jl_run_view_get(jl.h, C.byref(rv)) == 0
+    if view is not None:
+        H = view["phase"]["summary"]["n_haplotypes"]
+        assert rv.read_hap_bits == (4 if H <= 14 else 8 if H <= 254 else 16)
+        assert bool(rv.read_hap) == (rv.read_hap_bits == 16) and rv.read_hap_packed
+        out = np.zeros(len(rows), dtype=np.uint16)
+        assert jl.lib.jl_expand_read_hap(rv.read_hap_packed, rv.read_hap_bits, len(rows), out.ctypes.data_as(C.c_void_p)) == 0
+        assert (out == ep["read_hap"]).all() and (np.asarray(view["phase"]["read_hap"]) == ep["read_hap"]).all()
+    f = jl.run_fetch(True, True, cap_var=max(64, len(ev)))
+    assert_variants_equal(f["variants"], ev)
+    assert_phase_equal(f["phase"], ep, len(ev))
+    # stage API with a host table: exactly n_hap haplotypes
+    jl.phase_async(var, 10)
+    got = jl.phase_fetch(cap_var=8)
+    got["hit"] = got["hit"][:2]
+    assert got["summary"] == exp["summary"] and (got["read_hap"] == exp["read_hap"]).all()
+    assert (got["hap_count"] == exp["hap_count"]).all()
+
+
+def test_group_run_without_phasing_and_with_drm_masks(oracle):
+    """jl_group_run_async with phasing off (configs[1] through the group path) and jl_group_run_masked_async with a
+    --drm-only mask on some windows only: per window the oracle's table, filtered by that window's mask."""
+    l = 240
+    genes = np.array([(1, l + 1)], dtype=capi.GENE)
+    ref = synth.reference(77, l)
+    ctxs, rows_all = [], []
+    for k in range(5):
+        n = 4000 + 900 * k
+        sp = synth.SynthParams(seed=77 + k, minor_permille=(60, 50, 40, 30), sub_rate=0.003)
+        j = capi.Juliet(0)
+        j.alloc(n, l)
+        j.synth_fill(sp, ref)
+        j.sync()
+        rows_all.append(msa.unpack_columns(j.download_columns(), n))
+        ctxs.append(j)
+    grp = capi.Group(ctxs)
+    prm = capi.default_params()
+    try:
+        for rep in range(3):
+            grp.run_async(genes, ref, prm, False, 10, False)
+            for j, rows in zip(ctxs, rows_all):
+                v = j.run_view() or j.run_fetch(False, False)
+                assert "phase" not in v
+                assert_variants_equal(v["variants"], oracle.call(rows, genes, refseq=ref))
+        # masks: window k keeps only codons whose index is divisible by (k + 2); windows 1 and 3 have none
+        P = l // 3
+        masks = []
+        for k in range(5):
+            if k in (1, 3):
+                masks.append(None)
+                continue
+            bits = sum(1 << c for c in range(64) if c % (k + 2) == 0)
+            masks.append(np.full(P, bits, dtype=np.uint64))
+        for phasing in (True, False):
+            grp.run_masked_async(genes, ref, prm, masks, phasing, 10, phasing)
+            for k, (j, rows) in enumerate(zip(ctxs, rows_all)):
+                ev = oracle.call(rows, genes, refseq=ref)
+                if masks[k] is not None:
+                    ev = ev[ev["codon"] % (k + 2) == 0]
+                v = j.run_view() or j.run_fetch(phasing, phasing)
+                assert_variants_equal(v["variants"], ev)
+                if phasing:
+                    assert_phase_equal(v["phase"], oracle.phase(rows, ev), len(ev))
+    finally:
+        grp.close()
+        for j in ctxs:
+            j.close()
+
+
+def test_overlapping_genes_sharing_start_columns(jl, oracle):
+    """Genes in ONE frame that overlap (and a duplicate gene): several positions start at the same column and are
+    evaluated by the workgroup that counted the codon, rows appear once per (gene, codon); the plan sees each
+    column once."""
+    n, l = 9000, 360
+    sp = synth.SynthParams(seed=33, minor_permille=(60, 50, 40, 30))
+    ref = synth.reference(sp.seed, l)
+    rows = synth.rows(sp, l, 0, n, ref)
+    genes = np.array([(1, 181), (91, 361), (1, 361), (91, 361), (2, 359)], dtype=capi.GENE)
+    jl.upload_rows(rows)
+    for use_ref in (True, False):
+        out = jl.run(genes, ref if use_ref else None, capi.default_params(), phasing=True)
+        ev = oracle.call(rows, genes, refseq=ref if use_ref else None)
+        assert len(ev) > 8 and len(np.unique(ev["col"])) < len(ev)
+        assert_variants_equal(out["variants"], ev)
+        assert_phase_equal(out["phase"], oracle.phase(rows, ev), len(ev))
+
+
+def test_soak_fresh_reads_every_replay(oracle):
+    """The hand-offs between workgroups (arrival counters, write-through stores, the completion word) under load: 2000
+    replays of a group of six windows and of a single-window graph, NEW reads generated into the buffers before every
+    replay (seed = replay number, different per window), every window's result compared with the oracle's — via a
+    table of expectations for the 25 seeds the loop cycles through.  A stale header, a stale per-read id or a lost
+    table row shows as a mismatch."""
+    l, n_seeds, n_win = 90, 25, 6
+    genes = np.array([(1, l + 1)], dtype=capi.GENE)
+    ref = synth.reference(3, l)
+    shapes = [3000 + 1700 * k for k in range(n_win)]
+    ctxs = []
+    for n in shapes:
+        j = capi.Juliet(0)
+        j.alloc(n, l)
+        ctxs.append(j)
+    single = capi.Juliet(0)
+    single.alloc(5000, l)
+    prm = capi.default_params()
+    expect = {}
+    for s in range(n_seeds):
+        for k, n in enumerate(shapes + [5000]):
+            sp = synth.SynthParams(seed=1000 * k + s, minor_permille=(50 + s, 40, 30 + 2 * s, 25), partial_rate=0.01 * (s % 5))
+            rows = synth.rows(sp, l, 0, n, ref)
+            ev = oracle.call(rows, genes, refseq=ref)
+            ep = oracle.phase(rows, ev)
+            expect[(k, s)] = (sp, ev, ep, int(ep["read_hap"].astype(np.uint64).dot(np.arange(1, n + 1, dtype=np.uint64) % 1009)))
+    grp = capi.Group(ctxs)
+    try:
+        for it in range(2000):
+            s = (it * 7) % n_seeds
+            for k, j in enumerate(ctxs):
+                j.synth_fill(expect[(k, (s + k) % n_seeds)][0], ref)
+            single.synth_fill(expect[(n_win, s)][0], ref)
+            grp.run_async(genes, ref, prm, True, 10, True)
+            single.run_async(genes, ref, prm, None, True, 10, True)
+            for k, j in enumerate(ctxs + [single]):
+                _, ev, ep, chk = expect[(k, (s + k) % n_seeds if k < n_win else s)]
+                v = j.run_view()
+                assert v is not None, (it, k)
+                assert len(v["variants"]) == len(ev) and (v["variants"]["count"] == ev["count"]).all(), (it, k)
+                assert v["phase"]["summary"] == ep["summary"], (it, k)
+                assert (v["phase"]["hap_count"] == ep["hap_count"]).all(), (it, k)
+                ids = np.asarray(v["phase"]["read_hap"])
+                got = int(ids.astype(np.uint64).dot(np.arange(1, len(ids) + 1, dtype=np.uint64) % 1009))
+                assert got == chk, (it, k)
+    finally:
+        grp.close()
+        single.close()
+        for j in ctxs:
+            j.close()
