@@ -350,7 +350,7 @@ bool jl_pileup_needs_zero(jl_ctx *ctx);
 void jl_prepare_pileup(jl_ctx *ctx);
 void jl_launch_call(jl_ctx *ctx, hipStream_t st, const jl_params *prm, double n_tests, bool use_drm, bool with_meta);
 void jl_launch_compact(jl_ctx *ctx, hipStream_t st, bool plan, bool pack, bool signal);
-void jl_launch_phase(jl_ctx *ctx, hipStream_t st, uint32_t min_reads, bool planned, bool from_called, bool signal);
+bool jl_launch_phase(jl_ctx *ctx, hipStream_t st, uint32_t min_reads, bool planned, bool from_called, bool signal);
 void jl_fill_call_args(jl_ctx *ctx, const jl_params *prm, double n_tests, jl_call_args *A);
 // group runs: fill one window's argument block / launch a stage once for `n_win` <= JL_GROUP_MAX windows (the blocks
 // travel by value in the kernel arguments)

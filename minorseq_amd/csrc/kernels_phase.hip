@@ -1030,11 +1030,15 @@ __global__ __launch_bounds__(256) void phase_assign_group_kernel(jl_phase_group_
 
 }  // namespace
 
+#ifndef JL_ASSIGN_HOST_BLOCKS
+#define JL_ASSIGN_HOST_BLOCKS 128u
+#endif
 // workgroups per window of a launch that writes per-read ids (see jl_launch_assign_group)
 static uint32_t jl_assign_blocks(uint32_t n_win, uint32_t max_read_blocks, bool to_host)
 {
     if (!to_host) return max_read_blocks;   // ids that stay in HBM: one workgroup per 2048 reads
-    const uint32_t cap = std::max(1u, 32u / std::max(1u, n_win));
+    // to pinned host memory: JL_ASSIGN_HOST_BLOCKS workgroups in all (see jl_launch_assign_group)
+    const uint32_t cap = std::max(1u, JL_ASSIGN_HOST_BLOCKS / std::max(1u, n_win));
     return std::min<uint32_t>(cap, max_read_blocks);
 }
 
@@ -1082,7 +1086,8 @@ bool jl_fill_win_phase(jl_ctx *ctx, uint32_t min_reads, bool signal, uint32_t fo
 // `planned` is false.  ctx->phase_generic selects the multi-word pipeline; the default runs only the single-word
 // (Vp <= 10) kernel, whose last block also does the selection, and flags inputs that need more (jl_phase_fetch then
 // switches and re-runs).  `signal`: this launch ends a jl_run_async — its last kernel stores the completion word.
-void jl_launch_phase(jl_ctx *ctx, hipStream_t st, uint32_t min_reads, bool planned, bool from_called, bool signal)
+// Returns whether the launches store the run's completion word themselves (otherwise the caller adds done_kernel).
+bool jl_launch_phase(jl_ctx *ctx, hipStream_t st, uint32_t min_reads, bool planned, bool from_called, bool signal)
 {
     const uint64_t reads_pad = ctx->col_stride * 2u;
     const bool generic = ctx->phase_generic;
@@ -1111,10 +1116,11 @@ void jl_launch_phase(jl_ctx *ctx, hipStream_t st, uint32_t min_reads, bool plann
                            ctx->d_nvar, ctx->d_vpcols, ctx->d_cooc, ctx->cooc_cap, ctx->d_pack, ctx->pack_mirror,
                            (unsigned long long *)ctx->d_slot_key, ctx->d_sync, signal_select ? ctx->h_seq : nullptr);
     }
-    if (fold) return;
+    if (fold) return signal;
     hipLaunchKernelGGL(phase_assign_kernel, dim3(jl_assign_blocks(1, w.n_blocks, ids_to_host)), dim3(256), 0, st,
                        (uint64_t)n_dwords, ctx->d_flagw, ctx->d_meta, ctx->d_read_slot, ctx->d_slot_hap,
                        ctx->read_hap_out ? ctx->read_hap_out : ctx->d_read_hap);
+    return false;
 }
 
 static void fill_phase_group_args(jl_phase_group_args *args, const jl_win_phase *h_wins, uint32_t n_win)

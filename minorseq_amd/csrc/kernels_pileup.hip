@@ -31,6 +31,10 @@
 #include "call_eval.h"
 #include "jl_internal.h"
 
+#ifndef JL_CALL_MIN_WAVES
+#define JL_CALL_MIN_WAVES 5
+#endif
+
 // Register prefetch of the next tile while the current one is counted: 27.4 us vs 31.6 us per 150 MB launch
 // (rocprofv3), neutral to +3 % on GB-sized windows.  JL_PILEUP_PIPE=0 in the environment selects the plain loop.
 #ifndef JL_PILEUP_PIPE
@@ -368,7 +372,7 @@ __device__ __forceinline__ void pileup_body(const uint8_t JL_AS1 *msa, uint64_t 
 }
 
 template <int W, bool PIPE, int MODE, bool CALL>
-__global__ __launch_bounds__(256, CALL ? 5 : 1) void pileup_kernel(const uint8_t *__restrict__ msa, uint64_t col_stride,
+__global__ __launch_bounds__(256, CALL ? JL_CALL_MIN_WAVES : 1) void pileup_kernel(const uint8_t *__restrict__ msa, uint64_t col_stride,
                                                       uint32_t n_cols, uint32_t n_tiles,
                                                       const uint2 *__restrict__ chunks,
                                                       const uint32_t *__restrict__ guess32,
@@ -383,7 +387,7 @@ __global__ __launch_bounds__(256, CALL ? 5 : 1) void pileup_kernel(const uint8_t
 // 150 MB window is too short to hide a launch's ramp and drain, four of them in one grid run at the rate of a
 // 600 MB stream.  Every window is counted by one block per chunk (gridDim.y = 1: plain stores, no zeroing pass).
 template <int W, bool PIPE, int MODE, bool CALL>
-__global__ __launch_bounds__(256, CALL ? 5 : 1) void pileup_group_kernel(jl_pileup_group_args args)
+__global__ __launch_bounds__(256, CALL ? JL_CALL_MIN_WAVES : 1) void pileup_group_kernel(jl_pileup_group_args args)
 {
     const jl_win_pileup &w = args.w[blockIdx.z];
     if (blockIdx.x >= w.n_chunks) return;
@@ -436,7 +440,11 @@ struct variant_t {
 
 // Default builds use non-temporal loads: every cell is read once, and at 2.4 GB they lift the stream from 5.6 to
 // 6.3 TB/s (no difference at 150 MB).
+#ifdef JL_FUSED_CALL
 #define JL_V(W, P, M) {W, P, M, pileup_kernel<W, P, M, false>, pileup_group_kernel<W, P, M, false>, pileup_kernel<W, P, M, true>, pileup_group_kernel<W, P, M, true>}
+#else   // the fused variants are not even compiled
+#define JL_V(W, P, M) {W, P, M, pileup_kernel<W, P, M, false>, pileup_group_kernel<W, P, M, false>, nullptr, nullptr}
+#endif
 const variant_t kVariants[] = {
     JL_V(6, false, 4), JL_V(6, true, 4), JL_V(12, false, 4), JL_V(3, false, 4), JL_V(3, true, 4),
 #ifdef JL_PILEUP_TUNING   // probes (results wrong by design except mode 0/6): JL_PILEUP_MODE selects
@@ -535,8 +543,20 @@ void jl_launch_pileup(jl_ctx *ctx, hipStream_t st, bool with_call)
                        ctx->d_counts, ctx->d_hist, (const jl_callinfo *)(with_call ? ctx->d_callinfo : nullptr));
 }
 
-// The Fisher stage can ride in the pileup launch when one workgroup counts every chunk alone.
-bool jl_pileup_can_call(jl_ctx *ctx) { return jl_pileup_rsplit(ctx) == 1u; }
+// The Fisher stage CAN ride in the pileup launch when one workgroup counts every chunk alone (the CALL variants).  It is
+// a measured loss and off unless the library is built with -DJL_FUSED_CALL: the FP64 evaluation runs on one wave while
+// the workgroup's other three hold their registers for 2-3 us of a 31 us lifetime, and it needs 137 VGPRs where the
+// stream needs 92 — 229 us per 1.2 GB launch at three waves per SIMD, 270 us capped to five waves with 240 bytes of
+// scratch, against 196 us for the plain kernel; call_kernel evaluates the same 8000 positions in ~5 us of its own.
+bool jl_pileup_can_call(jl_ctx *ctx)
+{
+#ifdef JL_FUSED_CALL
+    return jl_pileup_rsplit(ctx) == 1u;
+#else
+    (void)ctx;
+    return false;
+#endif
+}
 
 void jl_fill_win_pileup(jl_ctx *ctx, jl_win_pileup *w)
 {

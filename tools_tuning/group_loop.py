@@ -8,6 +8,9 @@ import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from minorseq_amd import capi, synth  # noqa: E402
 
+if os.environ.get("JL_LIB"):
+    capi.load_library(os.environ["JL_LIB"])
+
 n, l, G, NG = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
 rounds = 100
 sp = synth.SynthParams(seed=2)

@@ -12,6 +12,9 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from minorseq_amd import capi, synth  # noqa: E402
 
+if os.environ.get("JL_LIB"):
+    capi.load_library(os.environ["JL_LIB"])
+
 sched = [int(x) for x in sys.argv[1].split(",")]
 idle_ms = float(sys.argv[2]) if len(sys.argv) > 2 else 0.0
 n, l = 100_000, 3000
