@@ -6,13 +6,20 @@ A "step" is one pass of the hot path over one resident batch of synthetic aligne
   (-> the one RCCL all-gather of the variant table when N > 1) -> read x variant phasing -> results on the host.
 Batches are independent windows; `--group G` of them (default 8) go through the path in ONE launch per stage
 (jl_group_run_async: blockIdx.z = window), so a launch is G steps, and `--inflight` launches are kept in flight.
-Every batch's results (variant table, haplotypes, per-read ids) land in pinned host memory and are read each step.
+Every resident batch holds DIFFERENT reads (its own seed); every batch's results (variant table, haplotypes,
+per-read ids) land in pinned host memory, are read each step, and one window per launch is compared with what the
+same window gave when it was run alone before the timed region (a stale or mixed-up result block fails the run).
+
 Workload at N=1: BASELINE.json configs[2] (= configs[1] with phasing on): 100k CCS reads x 3 kb reference.
-N > 1: reference windows shard independently (one 3 kb window x 100k reads per rank, weak scaling), the only
-exchange is the all-gather of the fixed-stride variant table.
+N > 1 (`value`): reference windows shard independently — one 3 kb window x 100k reads per rank and batch (weak
+scaling), the only exchange is the RCCL all-gather of the fixed-stride variant table.
+Every N also times BASELINE.json configs[3] as stated — ONE 10 kb reference whose 1M reads span all windows, split
+into N column windows (strong scaling): call per window with the global Bonferroni factor, all-gather of the table,
+the variant columns broadcast by their owners, phasing across windows — reported as `config3_strong` in the same line.
 
 Prints ONE JSON line on rank 0 (see the driver contract in the task brief), including
-  roofline     the dominant kernel (pileup) against the 8 TB/s HBM peak: algorithmic bytes = reads x columns / 2
+  roofline     the dominant kernel (pileup) against the 8 TB/s HBM peak: algorithmic bytes = reads x columns / 2;
+               `step_frac` = the same bytes over the whole timed step
   cpu_baseline this repo's CPU restatement (oracle/, kind "port": the reference ships no source) on the host cores.
 """
 import argparse
@@ -35,10 +42,12 @@ sys.path.insert(0, ROOT)
 N_READS = 100_000
 N_COLS = 3000
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+C3_READS, C3_COLS = 1_000_000, 10_000   # BASELINE.json configs[3]
 
 
-def cpu_baseline(jl, genes, ref, budget_s=12.0, threads=1, rows=None):
-    """Oracle (CPU restatement) call+phase on the same reads, bounded to ~budget_s of wall time.
+def cpu_baseline(jl, genes, ref, expect, budget_s=12.0, threads=1, rows=None):
+    """Oracle (CPU restatement) call+phase on the same reads, bounded to ~budget_s of wall time; also the checker of
+    this window's device result (`expect`).
     threads = 1: the plain restatement (no thread option is documented for juliet, so this is the faithful stand-in);
     threads > 1: its two counting sweeps split over reads with OpenMP (SURVEY.md §8d "all host cores")."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -54,13 +63,31 @@ def cpu_baseline(jl, genes, ref, budget_s=12.0, threads=1, rows=None):
         t0 = time.perf_counter()
         v = orc.call(rows, genes, refseq=ref)
         orc.pileup(rows)
-        orc.phase(rows, v)
+        ph = orc.phase(rows, v)
         t_total += time.perf_counter() - t0
         reps += 1
     orc.set_threads(1)
+    if expect is not None:   # the device's table and haplotypes of this window are the oracle's
+        ok = (len(v) == len(expect["count"]) and (v["count"] == expect["count"]).all() and (v["col"] == expect["col"]).all()
+              and (ph["hap_count"] == expect["hap_count"]).all() and ph["summary"] == expect["summary"])
+        if not ok:
+            raise SystemExit("bench.py: the device result of window 0 differs from the oracle's")
     return {"value": jl.n_reads * reps / t_total, "unit": "reads/s", "cores": threads, "kind": "port",
             "sample": f"{reps} x the full workload ({jl.n_reads} reads x {jl.n_cols} columns), call+phase, "
                       f"oracle/juliet_oracle.c, {threads} thread(s), {t_total:.1f} s"}, rows
+
+
+def signature(out):
+    """What a window's results are compared by in the step loop: a few small arrays, not the per-read ids."""
+    v, ph = out["variants"], out["phase"]
+    return dict(count=v["count"].copy(), col=v["col"].copy(), hap_count=ph["hap_count"].copy(), summary=dict(ph["summary"]))
+
+
+def same(sig, out):
+    v, ph = out["variants"], out["phase"]
+    return (len(v) == len(sig["count"]) and (v["count"] == sig["count"]).all() and (v["col"] == sig["col"]).all()
+            and len(ph["hap_count"]) == len(sig["hap_count"]) and (ph["hap_count"] == sig["hap_count"]).all()
+            and ph["summary"] == sig["summary"])
 
 
 def main():
@@ -72,11 +99,12 @@ def main():
 
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=16000)   # 2000 launches of 8 windows, about 0.4 s timed (fill and drain of the 4-deep pipeline and the clocks' ramp are inside the timed region)
+    ap.add_argument("--steps", type=int, default=16000)   # 2000 launches of 8 windows, about 0.4 s timed
     ap.add_argument("--warmup", type=int, default=64)
     ap.add_argument("--reads", type=int, default=N_READS)
     ap.add_argument("--cols", type=int, default=N_COLS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-config3", action="store_true", help="skip the configs[3] strong-scaling measurement")
     ap.add_argument("--inflight", type=int, default=4,
                     help="launches in flight per GPU (each on its own stream, with its own captured graph)")
     ap.add_argument("--group", type=int, default=8,
@@ -87,7 +115,7 @@ def main():
     import torch
     import torch.distributed as dist
 
-    from minorseq_amd import capi, synth
+    from minorseq_amd import capi, sharding, synth
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -110,20 +138,22 @@ def main():
 
     n, l = args.reads, args.cols
     # window `rank` of a world*l reference; one ORF spans everything, so Bonferroni's n is global.
-    # `inflight` contexts hold one resident batch each (same workload); steps alternate between them so that
-    # one batch's latency-bound tail (Fisher, phasing, result copy) overlaps the next batch's pileup stream.
-    sp = synth.SynthParams(seed=2 + rank)
-    ref_local = synth.reference(sp.seed, l)
+    # Every resident batch has its own reads (seed), so a result that lands in the wrong block cannot go unnoticed.
+    ref_local = synth.reference(2 + rank, l)
     win_begin = rank * l
     G = max(1, args.group)
     if G > 32:
         raise SystemExit("bench.py: --group is at most 32 (a group launch carries its windows' argument blocks by value: JL_GROUP_WINDOWS_MAX)")
     n_units = max(1, args.inflight)
-    ctxs = []
-    for _ in range(n_units * G):
+    genes = np.array([(1, world * l + 1)], dtype=capi.GENE)
+    refseq = np.full(world * l, 4, dtype=np.uint8)
+    refseq[win_begin:win_begin + l] = ref_local
+    prm = capi.default_params()
+    ctxs, expected = [], {}
+    for k in range(n_units * G):
         c = capi.Juliet(local_rank)
         c.alloc(n, l, win_begin=win_begin)
-        c.synth_fill(sp, ref_local)
+        c.synth_fill(synth.SynthParams(seed=1000 * (rank + 1) + k), ref_local)
         c.sync()
         ctxs.append(c)
     jl = ctxs[0]
@@ -133,15 +163,12 @@ def main():
     groups = [capi.Group(u) for u in units] if G > 1 else None
     partial_groups = {}
     handle_arrays = {}
-    genes = np.array([(1, world * l + 1)], dtype=capi.GENE)
-    refseq = np.full(world * l, 4, dtype=np.uint8)
-    refseq[win_begin:win_begin + l] = ref_local
-    prm = capi.default_params()
 
     comm = None
     exchange = "RCCL all-gather of the variant table (jl_allgather_variants)"
-    if distributed and os.environ.get('JL_BENCH_NO_COMM') != '1':
-        # one RCCL communicator per rank (its own stream); the 128-byte id is made on rank 0 and broadcast
+    if distributed:
+        # one RCCL communicator per rank (its own stream); the 128-byte id is made on rank 0 and broadcast.  A rank
+        # whose communicator fails ends the run: a bench must not silently time a different exchange.
         idbuf = np.zeros(128, dtype=np.uint8)
         if rank == 0:
             assert jl.lib.jl_comm_unique_id(idbuf.ctypes.data_as(C.c_void_p)) == 0
@@ -151,25 +178,13 @@ def main():
         dist.broadcast(t, 0)
         idbuf = t.cpu().numpy()
         comm = C.c_void_p()
-        try:
-            jl._chk(jl.lib.jl_comm_create(jl.h, idbuf.ctypes.data_as(C.c_void_p), rank, world, C.byref(comm)))
-            ok = 1
-        except capi.JulietError as e:   # keep the run alive and say so: the exchange then goes through the process group
-            print(f"[bench] rank {rank}: RCCL communicator failed ({e}); falling back to a torch.distributed all-gather",
-                  file=sys.stderr, flush=True)
-            comm, ok = None, 0
-        flag = torch.tensor([ok], dtype=torch.int32)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag.item()) == 0:
-            if comm is not None:
-                jl.lib.jl_comm_destroy(comm)
-            comm = None
-            exchange = "torch.distributed all_gather (RCCL communicator unavailable)"
+        jl._chk(jl.lib.jl_comm_create(jl.h, idbuf.ctypes.data_as(C.c_void_p), rank, world, C.byref(comm)))
         all_rows = np.zeros(world * capi.VARIANT_CAP, dtype=capi.VARIANT)
         all_counts = np.zeros(world, dtype=np.uint32)
         p_rows, p_counts = all_rows.ctypes.data_as(C.c_void_p), all_counts.ctypes.data_as(C.c_void_p)
 
     pending = {id(c): 0 for c in ctxs}   # exchanges enqueued and not yet collected, per context
+    state = dict(checked=0, gathered_rows=0)
 
     def launch(u, count=G):
         """Enqueue `count` steps (batches) of unit u: the whole path, results stored into pinned memory by the
@@ -203,22 +218,31 @@ def main():
             if rc:
                 c._chk(rc)
             pending[id(c)] -= 1
+            state["gathered_rows"] = int(all_counts.sum())
 
-    def collect(members, final=False):
+    def collect(members, final=False, check=True):
         last = None
-        for c in members:
+        pick = state["checked"] % len(members)
+        for i, c in enumerate(members):
             # results are read in place: the kernels stored them into pinned host memory, completion is a sequence
-            # word behind a system-scope fence (jl_run_view_get); results too large for that block use the copying fetch
-            out = c.run_view() or c.run_fetch(True, True, cap_var=64)
+            # word behind a system-scope fence (jl_run_view_get: counts, read categories, pointers into the block);
+            # results too large for that block use the copying fetch.  numpy views are built for the window that is
+            # checked and for the last one only (2 us of Python each).
+            if i == pick or i == len(members) - 1:
+                out = c.run_view() or c.run_fetch(True, True, cap_var=64)
+                if check and i == pick and not same(expected[id(c)], out):
+                    # one window per launch against what it gave when it ran alone, before the timed region
+                    raise SystemExit(f"bench.py: rank {rank}: a window's results changed between runs (stale or mixed result block)")
+                last = out
+            else:
+                rv = c.run_view_raw()
+                if not rv.complete or rv.n_variants != len(expected[id(c)]["count"]) or rv.n_haplotypes != len(expected[id(c)]["hap_count"]):
+                    raise SystemExit(f"bench.py: rank {rank}: a window's result block is incomplete or changed")
             # the exchange of this context's PREVIOUS step is collected now (its own is still crossing xGMI): every
             # step's all-gather is consumed, one cycle late, and its latency never stalls the launching thread
             if comm is not None and pending[id(c)] > (0 if final else 1):
                 drain(c, 1)
-            if distributed and comm is None and os.environ.get('JL_BENCH_NO_COMM') != '1':
-                from minorseq_amd import sharding
-                tabs = sharding.allgather_tables(out["variants"])
-                all_counts[:] = [len(t) for t in tabs]
-            last = (out["variants"], out["phase"])
+        state["checked"] += 1
         return last
 
     def run_steps(k):
@@ -227,21 +251,13 @@ def main():
         inflight = []   # (unit, members) in launch order
         done = 0
         u = 0
-        dbg = os.environ.get("JL_BENCH_DEBUG")
-        tl = tc = 0
         while done < k:
             if len(inflight) == n_units:
-                t_ = time.perf_counter_ns()
                 last = collect(inflight.pop(0)[1])
-                tc += time.perf_counter_ns() - t_
             count = min(G, k - done)
-            t_ = time.perf_counter_ns()
             inflight.append((u, launch(u, count)))
-            tl += time.perf_counter_ns() - t_
             done += count
             u = (u + 1) % n_units
-        if dbg:
-            print(f"[bench debug] {k} steps: launch {tl / 1e3:.0f} us, collect {tc / 1e3:.0f} us", file=sys.stderr)
         while inflight:
             last = collect(inflight.pop(0)[1], final=True)
         if comm is not None:
@@ -254,8 +270,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # set-up, before the warm-up steps: every launch unit (and the smaller groups that step counts which are not a
-    # multiple of G will need) runs once, so that no graph capture or table upload falls into the timed steps
+    # set-up, before the warm-up steps: every window alone once (its expected results), then every launch unit (and the
+    # smaller groups that step counts which are not a multiple of G will need) once, so that no graph capture or table
+    # upload falls into the timed steps
+    for c in ctxs:
+        c.run_async(genes, refseq, prm, None, True, 10, True)
+        expected[id(c)] = signature(c.run_view() or c.run_fetch(True, True, cap_var=64))
+    if len({tuple(e["count"]) + tuple(e["hap_count"]) for e in expected.values()}) < max(2, len(ctxs) // 2):
+        raise SystemExit("bench.py: the resident windows do not hold different reads")
     for u in range(n_units):
         collect(launch(u, G), final=True)
         for k in (args.warmup, args.steps):
@@ -268,7 +290,7 @@ def main():
     run_steps(args.warmup)
     fence()
     t0 = time.perf_counter()
-    table, ph = run_steps(args.steps)
+    last = run_steps(args.steps)
     fence()
     elapsed = time.perf_counter() - t0
     if distributed:
@@ -276,6 +298,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     ms_per_step = 1000.0 * elapsed / args.steps
+    table, ph = last["variants"], last["phase"]
 
     # latency of ONE batch through the path (its own graph, nothing else on the GPU), for the record
     def one_batch():
@@ -291,7 +314,8 @@ def main():
     latency_ms = 1000.0 * (time.perf_counter() - t1) / 20
 
     # dominant kernel alone: HIP events on the stream it is launched on, around back-to-back launches that rotate
-    # over the resident batches (no launch finds its windows in the 256 MiB Infinity Cache)
+    # over the resident batches (no launch finds its windows in the 256 MiB Infinity Cache).  rocprofv3 sees exactly
+    # these launches when bench.py runs with --kernel-only (profiles/README.md).
     if G > 1:
         run_steps(n_units * G)   # the timing hook reads each group's argument table: every group has run
         fence()
@@ -315,7 +339,7 @@ def main():
         except Exception:
             traffic = None
 
-    n_var = int(all_counts.sum()) if distributed and os.environ.get('JL_BENCH_NO_COMM') != '1' else len(table)
+    step_bytes = n * l / 2.0
     out = {
         "metric": "aligned CCS reads/sec through juliet call+phase",
         "value": world * n / (ms_per_step * 1e-3),
@@ -330,33 +354,125 @@ def main():
         "dtype": "u4 symbols / u32 counts / f64 p-values",
         "data": "synthetic",
         "config": {"workload": f"configs[2]: {n} CCS reads x {l} bp reference per GPU, pileup + Fisher-exact + phasing "
-                               "(96% major + four 1% minor haplotypes, sub 1.75e-4, del 1.3e-3, N 2e-2)",
+                               "(96% major + four 1% minor haplotypes, sub 1.75e-4, del 1.3e-3, N 2e-2); every resident "
+                               "batch holds different reads",
                    "reads_per_gpu": n, "ref_columns_per_gpu": l,
                    "parallelism": f"window-sharded x{world}, {exchange}" if distributed
                    else "single GPU",
                    "batches_per_launch": G, "launches_in_flight": n_units, "resident_batches": len(ctxs),
                    "one_batch_latency_ms": latency_ms,
-                   "variants_called": n_var, "haplotypes": ph["summary"]["n_haplotypes"]},
+                   "variants_called": state["gathered_rows"] if comm is not None else len(table),
+                   "haplotypes": ph["summary"]["n_haplotypes"],
+                   "windows_verified_in_loop": state["checked"]},
         "roofline": {"bound": "hbm", "kernel": kernel_name, "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": t_pileup_ms},
+                     "traffic_source": "profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                                       "command (a separate run; counters cannot be read from inside bench.py)" if traffic else None,
+                     "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": t_pileup_ms,
+                     # the same bytes over the whole step (launch gaps, Fisher, phasing, results on the host included)
+                     "step_achieved": step_bytes / (ms_per_step * 1e-3) / 1e9,
+                     "step_frac": step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
     }
+    for g in (groups or []) + list(partial_groups.values()):
+        g.close()
+    if not args.no_config3:
+        out["config3_strong"] = config3_strong(capi, sharding, synth, torch, dist, distributed, comm, rank, world, local_rank,
+                                               [c for c in ctxs[1:]])
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"], rows_host = cpu_baseline(jl, genes, refseq)
+        out["cpu_baseline"], rows_host = cpu_baseline(jl, genes, refseq, expected[id(jl)])
         ncores = min(os.cpu_count() or 1, 64)
         if ncores > 1:
-            out["cpu_baseline_all_cores"], _ = cpu_baseline(jl, genes, refseq, budget_s=6.0, threads=ncores, rows=rows_host)
+            out["cpu_baseline_all_cores"], _ = cpu_baseline(jl, genes, refseq, None, budget_s=6.0, threads=ncores, rows=rows_host)
     if rank == 0:
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if comm is not None:
         jl.lib.jl_comm_destroy(comm)
-    for g in (groups or []) + list(partial_groups.values()):
-        g.close()
     for c in ctxs:
         c.close()
     if distributed:
         dist.destroy_process_group()
+
+
+def config3_strong(capi, sharding, synth, torch, dist, distributed, comm, rank, world, local_rank, free_ctxs, reps=12):
+    """BASELINE.json configs[3] as stated: 1M CCS reads x ONE 10 kb reference, split into `world` column windows (rank
+    r holds the 1M reads' columns of window r: 5 GB / world).  A step = call per window with the GLOBAL Bonferroni
+    factor -> all-gather of the variant table (RCCL) -> every variant position's three columns broadcast by their
+    owner (RCCL, the second exchange) -> phasing across windows, replicated on the compact matrix.  `value` = 1M / t.
+    The per-read ids stay on the device inside the loop (fetched once at the end): at 1e6 reads expanding them on the
+    host would be most of a step."""
+    for c in free_ctxs:   # make room: the weak-scaling batches are no longer needed
+        c.close()
+    n, l = C3_READS, C3_COLS
+    sp = synth.SynthParams(seed=4)
+    ref = synth.reference(sp.seed, l)
+    genes = np.array([(1, 3 * (l // 3) + 1)], dtype=capi.GENE)
+    prm = capi.default_params(n_tests=sharding.default_n_tests(genes))
+    wb = sharding.window_bounds(l, world)
+    b, e = wb[rank]
+    win = capi.Juliet(local_rank)
+    win.alloc(n, e - b, win_begin=b)
+    win.synth_fill_window(sp, ref)
+    win.sync()
+    pc = capi.Juliet(local_rank)
+    remapped = np.zeros(capi.VARIANT_CAP, dtype=capi.VARIANT)
+    pos_global = np.zeros(capi.VARIANT_CAP, dtype=np.uint32)
+    vp = C.c_uint32()
+    if world > 1:
+        rows = np.zeros(world * capi.VARIANT_CAP, dtype=capi.VARIANT)
+        counts = np.zeros(world, dtype=np.uint32)
+        wbeg = np.array([x for x, _ in wb], dtype=np.uint32)
+        wnc = np.array([y - x for x, y in wb], dtype=np.uint32)
+
+    def step(want_reads=False):
+        win.run_async(genes, ref, prm, None, False, 10, False)
+        if world > 1:
+            win._chk(win.lib.jl_allgather_variants(win.h, comm, rows.ctypes.data_as(C.c_void_p), counts.ctypes.data_as(C.c_void_p),
+                                                   capi.VARIANT_CAP))
+            tables = [rows[r * capi.VARIANT_CAP: r * capi.VARIANT_CAP + int(counts[r])] for r in range(world)]
+            merged = sharding.merge_tables(tables, wbeg)
+            pc._chk(pc.lib.jl_xwin_assemble_rccl(pc.h, win.h, comm, capi._p(wbeg), capi._p(wnc), capi._p(merged), len(merged),
+                                                 capi._p(remapped), capi._p(pos_global), C.byref(vp)))
+        else:
+            merged = sharding.merge_tables([win.run_fetch(False, False)["variants"]], [b])
+            arr = (C.c_void_p * 1)(win.h)
+            pc._chk(pc.lib.jl_xwin_assemble_local(pc.h, arr, 1, capi._p(merged), len(merged), capi._p(remapped), capi._p(pos_global),
+                                                  C.byref(vp)))
+        pc._shape(n, 3 * vp.value, win.col_stride)
+        pc.phase_async(remapped[: len(merged)], 10)
+        return merged, pc.phase_fetch(want_reads=want_reads, cap_var=max(8, len(merged)))
+
+    def fence():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(2):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        merged, ph = step()
+    fence()
+    t = (time.perf_counter() - t0) / reps
+    if distributed:
+        tt = torch.tensor([t], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        t = float(tt.item())
+    merged, ph = step(want_reads=True)
+    s = ph["summary"]
+    assert s["reported_reads"] + s["insufficient_reads"] + s["damaged_reads"] == n      # doc/JULIET.md:378-379
+    t_k = win.time_pileup(reps=5)
+    out = {"workload": f"configs[3]: {n} CCS reads x {l} bp reference split into {world} column window(s), call per window + "
+                       "all-gather + cross-window phasing (jl_xwin_assemble_*), replicated phasing (SURVEY 8e option B)",
+           "value": n / t, "unit": "reads/s", "ms_per_step": 1000.0 * t, "scaling": "strong", "n_gpus": world,
+           "columns_per_gpu": int(e - b), "variants_called": int(len(merged)), "variant_positions": int(s["n_positions"]),
+           "haplotypes": int(s["n_haplotypes"]),
+           "exchanges": "none (one window)" if world == 1 else "1 ncclAllGather of the variant table + 1 group of ncclBroadcast (3 columns per variant position)",
+           "pileup_kernel_ms": t_k, "pileup_frac_of_hbm_peak": (n * (e - b) / 2.0) / (t_k * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    pc.close()
+    win.close()
+    return out
 
 
 if __name__ == "__main__":

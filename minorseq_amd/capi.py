@@ -457,6 +457,19 @@ class Juliet:
     def run_done(self):
         return bool(self.lib.jl_run_done(self.h))
 
+    def run_view_raw(self):
+        """The jl_run_view struct itself (counts, read categories, pointers into the pinned result block): waits for the
+        run like run_view, without building numpy views.  `complete` = 0: use run_fetch."""
+        v = getattr(self, "_rv", None)
+        if v is None:
+            v = self._rv = RunView()
+            self._rv_ref = C.byref(v)
+            self._rv_cache = {}
+        rc = self.lib.jl_run_view_get(self.h, self._rv_ref)
+        if rc:
+            self._chk(rc)
+        return v
+
     def run_view(self):
         """Zero-copy results of the last run_async: numpy views of the pinned block the kernels stored into
         (valid until the next run on this context).  Returns None when the results do not fit that block
