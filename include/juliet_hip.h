@@ -331,8 +331,10 @@ int jl_allgather_variants(jl_ctx *ctx, jl_comm *comm, jl_variant *all_rows, uint
  * communicator's stream.  The device result block is double-buffered by run parity, so a context may launch its
  * next run — and request that run's exchange — before collecting this one: at most TWO exchanges pending per
  * context (a third, and a run started while two are pending, are refused with JL_ERR_STATE);
- * jl_allgather_variants returns the OLDEST pending one.
- * At most 64 exchanges in flight per communicator.
+ * jl_allgather_variants returns the OLDEST pending one.  A run that called more than 128 variants on some rank falls back
+ * to the full fixed-stride table, which is not double-buffered: such an exchange must be collected before the
+ * context's next run (JL_ERR_STATE otherwise, on every rank alike).
+ * At most 128 exchanges in flight per communicator; every collective of a communicator is issued by its worker thread.
  */
 int jl_allgather_variants_async(jl_ctx *ctx, jl_comm *comm);
 /* The same for several contexts at once (the windows of a group run): their all-gathers are issued as ONE RCCL group,
@@ -350,6 +352,11 @@ int jl_allgather_variants_async_many(jl_ctx *const *ctxs, uint32_t n, jl_comm *c
  * All windows must hold the same reads in the same order.  Phasing itself then runs replicated on the
  * compact matrix (3*Vp columns: a few MB even at 1e7 reads).
  */
+/* The plan alone, on the host (no device, no communicator — what both functions below compute first, exposed for hosts that
+ * move the columns themselves): vp_total distinct positions, pos_global[k] ascending, remapped rows (col = 3k), and
+ * owner[k] = index of the window [win_begin[w], win_begin[w] + win_ncols[w]) that holds columns pos..pos+2 (-1: none). */
+int jl_xwin_plan(const uint32_t *win_begin, const uint32_t *win_ncols, uint32_t n_windows, const jl_variant *merged,
+                 uint32_t n_var, jl_variant *remapped, uint32_t *pos_global, int32_t *owner, uint32_t *vp_total);
 /* every window resident on this device: device-to-device copies */
 int jl_xwin_assemble_local(jl_ctx *pc, jl_ctx *const *windows, uint32_t n_windows, const jl_variant *merged,
                            uint32_t n_var, jl_variant *remapped, uint32_t *pos_global, uint32_t *vp_total);

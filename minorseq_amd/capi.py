@@ -33,7 +33,7 @@ EXPORTS = ("jl_abi_version", "jl_strerror", "jl_device_count", "jl_ctx_create", 
            "jl_consensus_fetch", "jl_call_async", "jl_call_fetch", "jl_variant_table_device", "jl_phase_async", "jl_phase_fetch",
            "jl_run_async", "jl_run_wait", "jl_run_done", "jl_run_view_get", "jl_group_create", "jl_group_destroy",
            "jl_group_last_error", "jl_group_run_async", "jl_group_run_masked_async", "jl_group_time_pileup", "jl_fisher_eval", "jl_fisher_eval_tail", "jl_expand_read_hap", "jl_time_pileup", "jl_time_pileup_set", "jl_pileup_kernel_name", "jl_comm_unique_id", "jl_comm_create", "jl_comm_destroy",
-           "jl_allgather_variants", "jl_allgather_variants_async", "jl_allgather_variants_async_many", "jl_xwin_assemble_local",
+           "jl_allgather_variants", "jl_allgather_variants_async", "jl_allgather_variants_async_many", "jl_xwin_plan", "jl_xwin_assemble_local",
            "jl_xwin_assemble_rccl")
 
 
@@ -178,6 +178,7 @@ def load_library(path=LIB_PATH):
     lib.jl_allgather_variants.argtypes = [vp, vp, vp, vp, u32]
     lib.jl_allgather_variants_async.argtypes = [vp, vp]
     lib.jl_allgather_variants_async_many.argtypes = [vp, u32, vp]
+    lib.jl_xwin_plan.argtypes = [vp, vp, u32, vp, u32, vp, vp, vp, C.POINTER(u32)]
     lib.jl_xwin_assemble_local.argtypes = [vp, vp, u32, vp, u32, vp, vp, C.POINTER(u32)]
     lib.jl_xwin_assemble_rccl.argtypes = [vp, vp, vp, vp, vp, vp, u32, vp, vp, C.POINTER(u32)]
     if lib.jl_abi_version() != 3:
@@ -522,6 +523,23 @@ class Juliet:
         if phasing:
             res["phase"] = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in out["phase"].items()}
         return res
+
+
+def xwin_plan(win_begins, win_ncols, merged):
+    """Host-only plan of the cross-window column exchange (jl_xwin_plan): (remapped table, global positions, owner window
+    of each position).  Needs no GPU."""
+    lib = load_library()
+    merged = np.ascontiguousarray(merged, dtype=VARIANT)
+    wb = np.ascontiguousarray(win_begins, dtype=np.uint32)
+    wn = np.ascontiguousarray(win_ncols, dtype=np.uint32)
+    remapped = np.zeros(max(1, len(merged)), dtype=VARIANT)
+    pos = np.zeros(max(1, len(merged)), dtype=np.uint32)
+    owner = np.zeros(max(1, len(merged)), dtype=np.int32)
+    vp = C.c_uint32()
+    rc = lib.jl_xwin_plan(_p(wb), _p(wn), len(wb), _p(merged), len(merged), _p(remapped), _p(pos), _p(owner), C.byref(vp))
+    if rc:
+        raise JulietError(rc, "jl_xwin_plan")
+    return remapped[: len(merged)].copy(), pos[: vp.value].copy(), owner[: vp.value].copy()
 
 
 def phase_across_windows(windows, merged, min_reads=10, comm=None, win_begins=None, win_ncols=None, device=0):

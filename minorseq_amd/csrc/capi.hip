@@ -199,12 +199,22 @@ static int reserve_msa(jl_ctx *ctx, size_t bytes)
 
 int jl_msa_alloc(jl_ctx *ctx, uint64_t n_reads, uint32_t n_cols, uint32_t win_begin)
 {
+    return jl_msa_alloc_strided(ctx, n_reads, n_cols, jl_col_stride(n_reads), win_begin);
+}
+}  // extern "C"
+
+// internal: a resident matrix with the caller's column stride (cross-window phasing keeps the stride of the windows
+// whose columns it copies)
+int jl_msa_alloc_strided(jl_ctx *ctx, uint64_t n_reads, uint32_t n_cols, uint64_t col_stride, uint32_t win_begin)
+{
     if (!ctx) return JL_ERR_ARG;
     JL_HIP(ctx, hipSetDevice(ctx->device));
-    int rc = set_shape(ctx, n_reads, n_cols, jl_col_stride(n_reads), win_begin);
+    int rc = set_shape(ctx, n_reads, n_cols, col_stride, win_begin);
     if (rc) return rc;
     return reserve_msa(ctx, (size_t)ctx->col_stride * n_cols);
 }
+
+extern "C" {
 
 int jl_msa_upload(jl_ctx *ctx, const uint8_t *colpacked, uint64_t n_reads, uint32_t n_cols, uint64_t col_stride,
                   uint32_t win_begin)
@@ -266,9 +276,20 @@ int jl_msa_ingest_records(jl_ctx *ctx, uint64_t n_reads, uint32_t n_cols, uint32
                           const uint8_t *qual, const uint64_t *qual_off, uint32_t min_qv)
 {
     if (!ctx || !pos || !cigar || !cig_off || !seq4 || !seq_off || (qual && !qual_off)) return JL_ERR_ARG;
-    for (uint64_t k = cig_off[0]; k < cig_off[n_reads]; ++k)
-        if ((cigar[k] & 15u) == 0u)
-            return jl_fail(ctx, JL_ERR_ARG, "cigar M is forbidden in PacBio-compliant BAM (doc/JULIET.md:53)");
+    for (uint64_t r = 0; r < n_reads; ++r) {
+        if (cig_off[r + 1] < cig_off[r] || seq_off[r + 1] < seq_off[r] || (qual && qual_off[r + 1] < qual_off[r]))
+            return jl_fail(ctx, JL_ERR_ARG, "record %llu: offsets must not decrease", (unsigned long long)r);
+        uint64_t query = 0;
+        for (uint64_t k = cig_off[r]; k < cig_off[r + 1]; ++k) {
+            const uint32_t op = cigar[k] & 15u;
+            if (op == 0u) return jl_fail(ctx, JL_ERR_ARG, "cigar M is forbidden in PacBio-compliant BAM (doc/JULIET.md:53)");
+            if (op == 1u || op == 4u || op == 7u || op == 8u) query += cigar[k] >> 4;
+        }
+        // the kernel indexes the read's bases (two per byte) and qualities by the cigar's query offsets
+        if (query > 2 * (seq_off[r + 1] - seq_off[r]) || (qual && query > qual_off[r + 1] - qual_off[r]))
+            return jl_fail(ctx, JL_ERR_ARG, "record %llu: its cigar consumes %llu bases, more than the record holds",
+                           (unsigned long long)r, (unsigned long long)query);
+    }
     int rc = jl_msa_alloc(ctx, n_reads, n_cols, win_begin);
     if (rc) return rc;
     const size_t n_cig = (size_t)cig_off[n_reads], n_seq = (size_t)seq_off[n_reads], n_q = qual ? (size_t)qual_off[n_reads] : 0;
@@ -908,9 +929,12 @@ int jl_run_prepare(jl_ctx *ctx, const jl_gene *genes, uint32_t n_genes, const ui
     if (prm->tail != 0 && prm->tail != 1) return jl_fail(ctx, JL_ERR_ARG, "tail must be 0 (one-sided greater) or 1 (two-sided)");
     if (!(prm->alpha > 0.0) || !(prm->err.match > 0.0) || !(prm->err.substitution >= 0.0))
         return jl_fail(ctx, JL_ERR_ARG, "alpha/match must be > 0 and substitution >= 0");
-    if (ctx->exch_pending >= 2)
-        return jl_fail(ctx, JL_ERR_STATE, "two exchanges of this context are pending and each reads one of its two result "
-                                          "blocks: collect one (jl_allgather_variants) before the next run");
+    // The device result block is double-buffered by run parity; an uncollected exchange still reads the block of its
+    // run.  The next run (runs_launched + 1) writes the block of its own parity: refuse when that is a block in use.
+    for (uint32_t r : ctx->exch_runs)
+        if (((ctx->runs_launched + 1u - r) & 1u) == 0u)
+            return jl_fail(ctx, JL_ERR_STATE, "the exchange of run %u is not collected yet and reads the result block this run "
+                                              "would write: collect it (jl_allgather_variants) first", r);
     JL_HIP(ctx, hipSetDevice(ctx->device));
     int rc;
     if (!same_plan(ctx, genes, n_genes, refseq, ref_len) && (rc = build_plan(ctx, genes, n_genes, refseq, ref_len))) return rc;
@@ -959,6 +983,12 @@ int jl_run_async(jl_ctx *ctx, const jl_gene *genes, uint32_t n_genes, const uint
     double n_tests = 0.0;
     int rc = jl_run_prepare(ctx, genes, n_genes, refseq, ref_len, prm, drm_masks, phasing, min_reads, want_read_hap, &n_tests);
     if (rc) return rc;
+    if (ctx->run_stream && ctx->run_stream != ctx->stream) {
+        // the previous run of this context was a group run on the group's stream: this one, on the context's own
+        // stream, must not overtake it (same buffers, and the result block's parity is counted on the device)
+        JL_HIP(ctx, hipStreamSynchronize(ctx->run_stream));
+        ctx->run_stream = ctx->stream;
+    }
 
     // signature of everything a captured graph bakes in
     struct { uint64_t alloc, plan; jl_params prm; double n_tests; uint32_t drm, phasing, min_reads, rh, generic, pad; } sig;

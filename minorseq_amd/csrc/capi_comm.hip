@@ -33,9 +33,31 @@ struct jl_comm_slot {
     // where rank r's head of this exchange lies in pinned memory: h_base + (r * batch_n + batch_k) * JL_PACK_HEAD_BYTES
     const uint8_t *h_base = nullptr;
     uint32_t batch_n = 1, batch_k = 0;
-    bool pending = false;        // an exchange was requested and not yet collected (host thread only)
+    bool pending = false;        // the slot is reserved: requested, and its batch not yet collected completely (host thread only)
+    bool collected = false;      // this member was collected; the slot stays reserved until the whole batch is (its
+                                 // region of the arena is ONE [rank][window][head] block, its event the batch's)
+    jl_comm_slot *leader = nullptr;   // first slot of the batch
+    uint32_t batch_left = 0;     // leader only: members not yet collected
+    uint32_t batch_size = 1;     // leader only
     bool enqueued = false;       // the worker has issued it and recorded `done` (guarded by jl_comm::mu)
     int status = 0;              // ncclResult_t / hip error of the enqueue, as jl_status
+};
+
+// the full-stride gather (tables of more than 128 rows, stage-by-stage callers): issued by the worker too — the
+// communicator is never used from two threads
+struct jl_comm_full {
+    jl_ctx *ctx = nullptr;
+    uint32_t cap_rows = 0;
+    uint32_t wait_seq = 0;       // != 0: the run whose completion word the worker waits for first
+    jl_variant *all_rows = nullptr;
+    uint32_t *all_counts = nullptr;
+    int status = 0;
+    bool done = false;           // guarded by jl_comm::mu
+};
+
+struct jl_comm_job {
+    std::vector<jl_comm_slot *> batch;
+    jl_comm_full *full = nullptr;
 };
 
 struct jl_comm {
@@ -53,22 +75,60 @@ struct jl_comm {
     std::thread worker;
     std::mutex mu;
     std::condition_variable cv;
-    std::deque<std::vector<jl_comm_slot *>> queue;   // batches: the exchanges of one batch go out as ONE RCCL group
+    std::deque<jl_comm_job> queue;   // FIFO: batches (the exchanges of one batch go out as ONE all-gather) and full-stride gathers
     bool stop = false;
 };
+
+// fixed-stride table (+ row counts) over RCCL/xGMI, on the communicator's stream; blocks the worker until the rows are
+// in the caller's arrays
+static void comm_full_gather(jl_comm *c, jl_comm_full *f)
+{
+    jl_ctx *ctx = f->ctx;
+    int st = JL_OK;
+    if (f->wait_seq && jl_run_wait_seq(ctx, f->wait_seq) != JL_OK) st = JL_ERR_DEVICE;
+    if (st == JL_OK) {
+        ncclResult_t r = ncclGroupStart();
+        if (r == ncclSuccess) r = ncclAllGather(ctx->d_variants, c->d_all, sizeof(jl_variant) * (size_t)f->cap_rows, ncclUint8, c->comm, c->stream);
+        if (r == ncclSuccess) r = ncclAllGather(ctx->d_nvar, c->d_counts, 8, ncclUint8, c->comm, c->stream);
+        if (r == ncclSuccess) r = ncclGroupEnd();
+        if (r != ncclSuccess) st = JL_ERR_COMM;
+    }
+    std::vector<uint32_t> cnt(2 * (size_t)c->world);
+    if (st == JL_OK &&
+        (hipMemcpyAsync(f->all_rows, c->d_all, sizeof(jl_variant) * (size_t)f->cap_rows * c->world, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+         hipMemcpyAsync(cnt.data(), c->d_counts, 8 * (size_t)c->world, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+         hipStreamSynchronize(c->stream) != hipSuccess))
+        st = JL_ERR_DEVICE;
+    if (st == JL_OK)
+        for (int k = 0; k < c->world; ++k) {
+            f->all_counts[k] = cnt[2 * k];
+            if (cnt[2 * k] > f->cap_rows) st = JL_ERR_OVERFLOW;
+        }
+    f->status = st;
+}
 
 static void comm_worker(jl_comm *c)
 {
     hipSetDevice(c->device);
     for (;;) {
-        std::vector<jl_comm_slot *> batch;
+        jl_comm_job job;
         {
             std::unique_lock<std::mutex> lk(c->mu);
             c->cv.wait(lk, [&] { return c->stop || !c->queue.empty(); });
             if (c->queue.empty()) return;  // stop requested and nothing left
-            batch.swap(c->queue.front());
+            job = std::move(c->queue.front());
             c->queue.pop_front();
         }
+        if (job.full) {
+            comm_full_gather(c, job.full);
+            {
+                std::lock_guard<std::mutex> lk(c->mu);
+                job.full->done = true;
+            }
+            c->cv.notify_all();
+            continue;
+        }
+        std::vector<jl_comm_slot *> &batch = job.batch;
         int st = JL_OK;
         // the producing runs are complete when their sequence words are in pinned memory (jl_run_wait): no events
         for (jl_comm_slot *s : batch)
@@ -208,9 +268,8 @@ void jl_comm_destroy(jl_comm *c)
 }
 
 // A context may have several exchanges in flight, each in its own slot.  Slots are not tied to contexts: a slot is free
-// when no uncollected exchange uses it; `first_of_run` asks for the first of `n` consecutive free slots (the exchanges
-// of a batch then land next to each other in the arena); `oldest` = a context's pending slot with the smallest
-// sequence number.
+// when no uncollected BATCH uses it; `n` asks for the first of n consecutive free slots (the exchanges of a batch then
+// land next to each other in the arena); `oldest` = a context's uncollected slot with the smallest sequence number.
 static jl_comm_slot *comm_slot_free(jl_comm *c, uint32_t n = 1)
 {
     uint32_t run = 0;
@@ -225,8 +284,19 @@ static jl_comm_slot *comm_slot_oldest(jl_ctx *ctx, jl_comm *c)
 {
     jl_comm_slot *best = nullptr;
     for (jl_comm_slot &s : c->slots)
-        if (s.ctx == ctx && s.pending && (!best || s.seq < best->seq)) best = &s;
+        if (s.ctx == ctx && s.pending && !s.collected && (!best || s.seq < best->seq)) best = &s;
     return best;
+}
+
+// A member of a batch was collected: its slot (its bytes of the batch's ONE result region, the batch's event) stays
+// reserved until every member is, then the whole run of slots is free again.
+static void comm_slot_release(jl_comm_slot *s)
+{
+    s->collected = true;
+    jl_comm_slot *lead = s->leader ? s->leader : s;
+    if (lead->batch_left > 0) --lead->batch_left;
+    if (lead->batch_left == 0)
+        for (uint32_t k = 0; k < lead->batch_size; ++k) lead[k].pending = false;
 }
 
 // Enqueue-only half: after jl_run_async, all-gather the head of the run's device result block (header + up to 128
@@ -238,22 +308,33 @@ static int comm_request(jl_ctx *ctx, jl_comm *c, jl_comm_slot *at, jl_comm_slot 
 {
     if (!ctx->pack_valid) return jl_fail(ctx, JL_ERR_STATE, "jl_allgather_variants_async needs jl_run_async first");
     if (ctx->device != c->device) return jl_fail(ctx, JL_ERR_ARG, "context and communicator are on different devices");
-    int n_pending = 0;
-    for (jl_comm_slot &q : c->slots)
-        if (q.ctx == ctx && q.pending) ++n_pending;
-    if (n_pending >= 2) return jl_fail(ctx, JL_ERR_STATE, "two exchanges of this context are pending: collect one first");
+    if (ctx->exch_runs.size() >= 2) return jl_fail(ctx, JL_ERR_STATE, "two exchanges of this context are pending: collect one first");
+    for (uint32_t r : ctx->exch_runs)
+        if (r == ctx->runs_launched) return jl_fail(ctx, JL_ERR_STATE, "this run's exchange was already requested");
     jl_comm_slot *s = at ? at : comm_slot_free(c);
     if (!s || s->pending) return jl_fail(ctx, JL_ERR_MEMORY, "no free exchange slot (%d per communicator): collect pending exchanges first", JL_COMM_SLOTS);
     s->ctx = ctx;
     s->done_at = s;
+    s->leader = s;
+    s->batch_left = 1;
+    s->batch_size = 1;
+    s->collected = false;
     s->run_seq = ctx->runs_launched;
     s->d_src = reinterpret_cast<const uint8_t *>(ctx->d_pack + ((ctx->runs_launched - 1u) & 1u));
     s->seq = c->next_seq++;
     s->enqueued = false;   // not yet visible to the worker: no lock needed
     s->status = JL_OK;
-    ctx->exch_pending++;
+    ctx->exch_runs.push_back(s->run_seq);
+    ctx->exch_pending = (uint32_t)ctx->exch_runs.size();
     *out = s;
     return JL_OK;
+}
+
+static void comm_forget_run(jl_ctx *ctx, uint32_t run_seq)
+{
+    for (size_t k = 0; k < ctx->exch_runs.size(); ++k)
+        if (ctx->exch_runs[k] == run_seq) { ctx->exch_runs.erase(ctx->exch_runs.begin() + (long)k); break; }
+    ctx->exch_pending = (uint32_t)ctx->exch_runs.size();
 }
 
 int jl_allgather_variants_async(jl_ctx *ctx, jl_comm *c)
@@ -265,13 +346,15 @@ int jl_allgather_variants_async(jl_ctx *ctx, jl_comm *c)
     s->pending = true;
     {
         std::lock_guard<std::mutex> lk(c->mu);
-        c->queue.emplace_back(1, s);
+        jl_comm_job job;
+        job.batch.assign(1, s);
+        c->queue.push_back(std::move(job));
     }
     c->cv.notify_all();
     return JL_OK;
 }
 
-// The exchanges of several contexts (the windows of one group run) as ONE RCCL group: one collective launch instead
+// The exchanges of several contexts (the windows of one group run) as ONE all-gather: one collective launch instead
 // of n.  Every rank must pass the same number of contexts in the same call order.
 int jl_allgather_variants_async_many(jl_ctx *const *ctxs, uint32_t n, jl_comm *c)
 {
@@ -286,38 +369,48 @@ int jl_allgather_variants_async_many(jl_ctx *const *ctxs, uint32_t n, jl_comm *c
         jl_comm_slot *s = nullptr;
         int rc = comm_request(ctxs[k], c, run0 + k, &s);
         if (rc) {
-            for (jl_comm_slot *b : batch) { b->pending = false; b->ctx->exch_pending--; }
+            for (jl_comm_slot *b : batch) { b->pending = false; comm_forget_run(b->ctx, b->run_seq); }
             return rc;
         }
         s->pending = true;   // reserves the slot for the following comm_slot_free calls
+        s->leader = run0;
         batch.push_back(s);
     }
+    run0->batch_left = n;
+    run0->batch_size = n;
     {
         std::lock_guard<std::mutex> lk(c->mu);
-        c->queue.push_back(batch);
+        jl_comm_job job;
+        job.batch = batch;
+        c->queue.push_back(std::move(job));
     }
     c->cv.notify_all();
     return JL_OK;
 }
 
-static int allgather_full(jl_ctx *ctx, jl_comm *c, jl_variant *all_rows, uint32_t *all_counts, uint32_t cap_rows)
+// The full fixed stride, through the worker's FIFO like every other collective of the communicator (every rank reaches
+// this at the same point of its program, so the job takes the same place in every rank's queue).
+static int allgather_full(jl_ctx *ctx, jl_comm *c, jl_variant *all_rows, uint32_t *all_counts, uint32_t cap_rows, uint32_t wait_seq)
 {
-    // fixed-stride table (+ row counts) over RCCL/xGMI; blocking, so it can simply use the ctx stream
-    ncclResult_t r = ncclGroupStart();
-    if (r == ncclSuccess) r = ncclAllGather(ctx->d_variants, c->d_all, sizeof(jl_variant) * (size_t)cap_rows, ncclUint8, c->comm, ctx->stream);
-    if (r == ncclSuccess) r = ncclAllGather(ctx->d_nvar, c->d_counts, 8, ncclUint8, c->comm, ctx->stream);
-    if (r == ncclSuccess) r = ncclGroupEnd();
-    if (r != ncclSuccess) return jl_fail(ctx, JL_ERR_COMM, "ncclAllGather: %s", ncclGetErrorString(r));
-    std::vector<uint32_t> cnt(2 * (size_t)c->world);
-    JL_HIP(ctx, hipMemcpyAsync(all_rows, c->d_all, sizeof(jl_variant) * (size_t)cap_rows * c->world, hipMemcpyDeviceToHost, ctx->stream));
-    JL_HIP(ctx, hipMemcpyAsync(cnt.data(), c->d_counts, 8 * (size_t)c->world, hipMemcpyDeviceToHost, ctx->stream));
-    JL_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    int rc = JL_OK;
-    for (int k = 0; k < c->world; ++k) {
-        all_counts[k] = cnt[2 * k];
-        if (cnt[2 * k] > cap_rows) rc = JL_ERR_OVERFLOW;
+    jl_comm_full f;
+    f.ctx = ctx;
+    f.cap_rows = cap_rows;
+    f.wait_seq = wait_seq;
+    f.all_rows = all_rows;
+    f.all_counts = all_counts;
+    {
+        std::lock_guard<std::mutex> lk(c->mu);
+        jl_comm_job job;
+        job.full = &f;
+        c->queue.push_back(std::move(job));
     }
-    if (rc) return jl_fail(ctx, rc, "a rank produced more than %u variant rows", cap_rows);
+    c->cv.notify_all();
+    {
+        std::unique_lock<std::mutex> lk(c->mu);
+        c->cv.wait(lk, [&] { return f.done; });
+    }
+    if (f.status == JL_ERR_OVERFLOW) return jl_fail(ctx, JL_ERR_OVERFLOW, "a rank produced more than %u variant rows", cap_rows);
+    if (f.status != JL_OK) return jl_fail(ctx, f.status, "full-stride all-gather failed on the communicator thread");
     return JL_OK;
 }
 
@@ -331,40 +424,50 @@ int jl_allgather_variants(jl_ctx *ctx, jl_comm *c, jl_variant *all_rows, uint32_
     if (!ctx->call_done) return jl_fail(ctx, JL_ERR_STATE, "jl_allgather_variants before jl_call_async");
     if (cap_rows == 0 || cap_rows > JL_VARIANT_CAP) return jl_fail(ctx, JL_ERR_ARG, "cap_rows must be 1..%u", JL_VARIANT_CAP);
     JL_HIP(ctx, hipSetDevice(ctx->device));
-    if (ctx->pack_valid) {
-        jl_comm_slot *s = comm_slot_oldest(ctx, c);
-        if (!s) {
-            int rc = jl_allgather_variants_async(ctx, c);
-            if (rc) return rc;
-            s = comm_slot_oldest(ctx, c);
-        }
-        if (ctx->exch_pending) ctx->exch_pending--;
-        comm_wait_enqueued(c, s);
-        struct release { jl_comm_slot *s; ~release() { s->pending = false; } } rel{s};   // free for reuse once the heads were read
-        if (s->status != JL_OK) return jl_fail(ctx, s->status, "all-gather enqueue failed on the communicator thread");
-        {   // spin on the event: a blocking hipEventSynchronize costs ~15 us of wake-up latency per step
-            hipError_t q;
-            while ((q = hipEventQuery(s->done_at->done)) == hipErrorNotReady) {}
-            if (q != hipSuccess) return jl_fail(ctx, JL_ERR_DEVICE, "all-gather: %s", hipGetErrorString(q));
-        }
-        bool compact = true;
+    if (!ctx->pack_valid) {
+        // stage-by-stage caller: the table is final once the context's stream is idle
+        JL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        return allgather_full(ctx, c, all_rows, all_counts, cap_rows, 0);
+    }
+    jl_comm_slot *s = comm_slot_oldest(ctx, c);
+    if (!s) {
+        int rc = jl_allgather_variants_async(ctx, c);
+        if (rc) return rc;
+        s = comm_slot_oldest(ctx, c);
+    }
+    const uint32_t run_seq = s->run_seq;
+    comm_forget_run(ctx, run_seq);
+    comm_wait_enqueued(c, s);
+    struct release { jl_comm_slot *s; ~release() { comm_slot_release(s); } } rel{s};   // free for reuse once the heads were read
+    if (s->status != JL_OK) return jl_fail(ctx, s->status, "all-gather enqueue failed on the communicator thread");
+    {   // spin on the event: a blocking hipEventSynchronize costs ~15 us of wake-up latency per step
+        hipError_t q;
+        while ((q = hipEventQuery(s->done_at->done)) == hipErrorNotReady) {}
+        if (q != hipSuccess) return jl_fail(ctx, JL_ERR_DEVICE, "all-gather: %s", hipGetErrorString(q));
+    }
+    bool compact = true;
+    for (int k = 0; k < c->world; ++k) {
+        const jl_pack *pk = reinterpret_cast<const jl_pack *>(s->h_base + ((size_t)k * s->batch_n + s->batch_k) * JL_PACK_HEAD_BYTES);
+        if (pk->magic != JL_PACK_MAGIC || !pk->fits_call) compact = false;
+    }
+    if (compact) {
+        int rc = JL_OK;
         for (int k = 0; k < c->world; ++k) {
             const jl_pack *pk = reinterpret_cast<const jl_pack *>(s->h_base + ((size_t)k * s->batch_n + s->batch_k) * JL_PACK_HEAD_BYTES);
-            if (pk->magic != JL_PACK_MAGIC || !pk->fits_call) compact = false;
+            all_counts[k] = pk->nvar_total;
+            if (pk->nvar_total > cap_rows) { rc = JL_ERR_OVERFLOW; continue; }
+            memcpy(all_rows + (size_t)k * cap_rows, pk->variants, (size_t)pk->nvar_total * sizeof(jl_variant));
         }
-        if (compact) {
-            int rc = JL_OK;
-            for (int k = 0; k < c->world; ++k) {
-                const jl_pack *pk = reinterpret_cast<const jl_pack *>(s->h_base + ((size_t)k * s->batch_n + s->batch_k) * JL_PACK_HEAD_BYTES);
-                all_counts[k] = pk->nvar_total;
-                if (pk->nvar_total > cap_rows) { rc = JL_ERR_OVERFLOW; continue; }
-                memcpy(all_rows + (size_t)k * cap_rows, pk->variants, (size_t)pk->nvar_total * sizeof(jl_variant));
-            }
-            if (rc) return jl_fail(ctx, rc, "a rank produced more than %u variant rows", cap_rows);
-            return JL_OK;
-        }
+        if (rc) return jl_fail(ctx, rc, "a rank produced more than %u variant rows", cap_rows);
+        return JL_OK;
     }
-    return allgather_full(ctx, c, all_rows, all_counts, cap_rows);
+    // Some rank's table does not fit the 128-row head: the full stride, from the resident table.  That table is NOT
+    // double-buffered — if this context has launched another run since, it holds that run's rows.  Every rank sees the
+    // same headers and runs the same program, so every rank refuses here together.
+    if (ctx->runs_launched != run_seq)
+        return jl_fail(ctx, JL_ERR_STATE, "a rank called more than %u variants: such a run's exchange must be collected before the "
+                                          "context's next run (the full table is not double-buffered)", JL_PACK_MAX_VAR);
+    return allgather_full(ctx, c, all_rows, all_counts, cap_rows, run_seq);
 }
 
 
@@ -397,6 +500,23 @@ static int xwin_owner(const uint32_t *win_begin, const uint32_t *win_ncols, uint
     return -1;
 }
 
+// Host-only plan of the column exchange (no device, no communicator): the distinct variant positions of the merged
+// table in ascending global order, the table remapped onto the compact matrix (position k -> columns 3k..3k+2), and
+// for every position the window that holds its three columns entirely (-1: none does).
+int jl_xwin_plan(const uint32_t *win_begin, const uint32_t *win_ncols, uint32_t n_windows, const jl_variant *merged, uint32_t n_var,
+                 jl_variant *remapped, uint32_t *pos_global, int32_t *owner, uint32_t *vp_total)
+{
+    if (!win_begin || !win_ncols || n_windows == 0 || (!merged && n_var) || !vp_total) return JL_ERR_ARG;
+    std::vector<uint32_t> pos(n_var ? n_var : 1);
+    const uint32_t vp = xwin_remap(merged, n_var, remapped, pos.data());
+    *vp_total = vp;
+    for (uint32_t k = 0; k < vp; ++k) {
+        if (pos_global) pos_global[k] = pos[k];
+        if (owner) owner[k] = xwin_owner(win_begin, win_ncols, n_windows, pos[k]);
+    }
+    return JL_OK;
+}
+
 // All windows on THIS device (a 288 GB GPU holds many): device-to-device copies of 3 columns per position.
 int jl_xwin_assemble_local(jl_ctx *pc, jl_ctx *const *windows, uint32_t n_windows, const jl_variant *merged, uint32_t n_var,
                            jl_variant *remapped, uint32_t *pos_global, uint32_t *vp_total)
@@ -416,9 +536,9 @@ int jl_xwin_assemble_local(jl_ctx *pc, jl_ctx *const *windows, uint32_t n_window
     *vp_total = vp;
     if (pos_global) std::copy(pos.begin(), pos.begin() + vp, pos_global);
     if (vp == 0) return JL_OK;
-    int rc = jl_msa_alloc(pc, windows[0]->n_reads, 3u * vp, 0);
-    if (rc) return rc;
     const uint64_t stride = windows[0]->col_stride;
+    int rc = jl_msa_alloc_strided(pc, windows[0]->n_reads, 3u * vp, stride, 0);   // the windows' stride, whatever it is
+    if (rc) return rc;
     for (uint32_t k = 0; k < vp; ++k) {
         const int w = xwin_owner(wb.data(), wn.data(), n_windows, pos[k]);
         if (w < 0) return jl_fail(pc, JL_ERR_ARG, "variant column %u is not fully inside any window", pos[k]);
@@ -444,9 +564,9 @@ int jl_xwin_assemble_rccl(jl_ctx *pc, jl_ctx *window, jl_comm *c, const uint32_t
     *vp_total = vp;
     if (pos_global) std::copy(pos.begin(), pos.begin() + vp, pos_global);
     if (vp == 0) return JL_OK;
-    int rc = jl_msa_alloc(pc, window->n_reads, 3u * vp, 0);
+    const uint64_t stride = window->col_stride;   // every rank's window must use the same stride (same reads)
+    int rc = jl_msa_alloc_strided(pc, window->n_reads, 3u * vp, stride, 0);
     if (rc) return rc;
-    const uint64_t stride = window->col_stride;
     JL_HIP(pc, hipStreamSynchronize(window->stream));
     ncclResult_t r = ncclGroupStart();
     for (uint32_t k = 0; k < vp && r == ncclSuccess; ++k) {

@@ -317,6 +317,7 @@ struct jl_ctx {
     volatile uint32_t *h_seq = nullptr;  // pinned
     uint32_t runs_launched = 0;
     uint32_t exch_pending = 0;        // exchanges requested and not yet collected: each still reads one of the two result blocks
+    std::vector<uint32_t> exch_runs;  // ... and the runs (values of runs_launched) whose blocks they read
     hipStream_t run_stream = nullptr;  // where the last run was enqueued (the ctx stream, or a group's)
     uint64_t *d_timeline = nullptr;   // JL_TIMELINE=1 only: [JL_TIMELINE_ROWS][JL_TIMELINE_SLOTS] device clock stamps
     hipGraph_t graph = nullptr;
@@ -384,4 +385,5 @@ void jl_launch_fisher_eval(jl_ctx *ctx, uint32_t n, const uint32_t *a, const uin
                            double *p, double *lp);
 // per-read ids in their packed form (4 / 8 / 16 bits, see JL_ID4_MAX_H) expanded to 16-bit ids on the host
 extern "C" void jl_expand_ids(const void *packed, uint32_t bits, uint64_t n_reads, uint16_t *out);
+int jl_msa_alloc_strided(jl_ctx *ctx, uint64_t n_reads, uint32_t n_cols, uint64_t col_stride, uint32_t win_begin);
 extern "C" int jl_update_callinfo(jl_ctx *ctx, const jl_params *prm, double n_tests, bool use_drm, bool with_meta);

@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) void ingest_cols_kernel(uint64_t n_reads, uint
 
     uint64_t ci = 0, cend = 0;
     const uint32_t *sqw = nullptr;
-    uint32_t q_adj = 0, sq_last = 0;
+    uint32_t q_adj = 0, sq_last = 0, ql_last = 0;
     const uint8_t *ql = nullptr;
     int64_t rel = 0;   // reference offset, relative to the read's first base, of column cs
     if (have) {
@@ -102,7 +102,12 @@ __global__ __launch_bounds__(256) void ingest_cols_kernel(uint64_t n_reads, uint
         sqw = reinterpret_cast<const uint32_t *>(seq4 + (so & ~(uint64_t)3));
         q_adj = (uint32_t)(so & 3u) * 2u;
         sq_last = (uint32_t)((seq_off[r + 1] - (so & ~(uint64_t)3) + 3u) >> 2);   // the arrays are padded by 16 bytes
-        if (qual && min_qv) ql = qual + qual_off[r];
+        if (qual && min_qv) {
+            ql = qual + qual_off[r];
+            const uint64_t nq = qual_off[r + 1] - qual_off[r];
+            ql_last = nq ? (uint32_t)(nq - 1) : 0u;
+            if (!nq) ql = nullptr;
+        }
         rel = (int64_t)win_begin + cs - (int64_t)pos[r];
     }
     // cursor: the op covering reference offsets [r_beg, r_end), which starts at query offset q_beg
@@ -164,7 +169,8 @@ __global__ __launch_bounds__(256) void ingest_cols_kernel(uint64_t n_reads, uint
                             const uint32_t b16 = (seq_w >> (8u * ((qa >> 1) & 3u) + ((qa & 1u) ? 0u : 4u))) & 15u;
                             // A=1 C=2 G=4 T=8 -> 0..3; anything else is an ambiguous base (N)
                             sym = (uint32_t)((0x5555555355525105ull >> (4u * b16)) & 15ull);
-                            if (ql) { const uint8_t qv = ql[q]; if (qv != 0xFFu && qv < min_qv) sym = JL_SYM_MASK; }
+                            // a cigar that runs past the read's bases (malformed input) stays inside the read's arrays
+                            if (ql) { const uint8_t qv = ql[min(q, ql_last)]; if (qv != 0xFFu && qv < min_qv) sym = JL_SYM_MASK; }
                         }
                     }
                 }

@@ -70,14 +70,16 @@ public:
             case 'i': case 'I': case 'f': len = 4; break;
             case 'Z': case 'H': while (o + len < block && p[o + len]) ++len; ++len; break;
             case 'B': {
+                if (o + 5 > block) throw std::runtime_error("truncated BAM aux array");
                 const char sub = (char)p[o];
                 uint32_t cnt; memcpy(&cnt, p + o + 1, 4);
                 const size_t es = (sub == 'c' || sub == 'C') ? 1 : (sub == 's' || sub == 'S') ? 2 : 4;
-                len = 5 + es * cnt;
+                len = 5 + es * (size_t)cnt;
                 break;
             }
             default: throw std::runtime_error("unknown BAM aux type");
             }
+            if (o + len > block) throw std::runtime_error("truncated BAM aux field");
             if (t0 == 'r' && t1 == 'q' && ty == 'f') memcpy(&r.rq, p + o, 4);
             if (ty == 'Z' && t1 == 'q' && (t0 == 'd' || t0 == 'i' || t0 == 's')) {
                 std::string &dst = t0 == 'd' ? r.dq : t0 == 'i' ? r.iq : r.sq;
@@ -122,6 +124,9 @@ public:
         r.flag = u16(14);
         const uint32_t l_seq = u32(16);
         size_t o = 32;
+        // untrusted input: the variable-length parts must lie inside the record
+        if (32 + (size_t)l_read_name + (size_t)n_cigar * 4 + ((size_t)l_seq + 1) / 2 + (size_t)l_seq > (size_t)block)
+            throw std::runtime_error("corrupt BAM record");
         r.name.assign((const char *)p + o, l_read_name ? l_read_name - 1 : 0);
         o += l_read_name;
         r.cigar.resize(n_cigar);

@@ -190,6 +190,7 @@ inline ReadExtent collect_records(const std::string &bam, const IngestOptions &o
         out.cigar.resize(c_at + n_cigar);
         memcpy(out.cigar.data() + c_at, p + o_cig, (size_t)n_cigar * 4);
         uint32_t span = 0;
+        uint64_t query = 0;
         for (size_t k = c_at; k < out.cigar.size(); ++k) {
             const uint32_t op = out.cigar[k] & 15;
             if (op == CIG_M) {
@@ -197,6 +198,14 @@ inline ReadExtent collect_records(const std::string &bam, const IngestOptions &o
                 throw std::runtime_error("read " + name + ": cigar M is forbidden in PacBio-compliant BAM (doc/JULIET.md:53)");
             }
             if (op == CIG_D || op == CIG_N || op == CIG_EQ || op == CIG_X) span += out.cigar[k] >> 4;
+            if (op == CIG_I || op == CIG_S || op == CIG_EQ || op == CIG_X) query += out.cigar[k] >> 4;
+        }
+        // the device walks the cigar into the read's bases and qualities: a cigar that consumes more (or fewer) bases
+        // than the record holds would index past them
+        if (query != l_seq) {
+            const std::string name((const char *)p + 32, l_name ? l_name - 1 : 0);
+            throw std::runtime_error("read " + name + ": cigar consumes " + std::to_string(query) + " bases, the record holds " +
+                                     std::to_string(l_seq));
         }
         ++e.n_reads;
         e.min_pos = std::min<int64_t>(e.min_pos, pos);

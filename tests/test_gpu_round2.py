@@ -234,3 +234,93 @@ def test_soak_fresh_reads_every_replay(oracle):
         single.close()
         for j in ctxs:
             j.close()
+
+
+def _comm(jl):
+    idbuf = np.zeros(128, dtype=np.uint8)
+    assert jl.lib.jl_comm_unique_id(idbuf.ctypes.data_as(C.c_void_p)) == 0
+    comm = C.c_void_p()
+    jl._chk(jl.lib.jl_comm_create(jl.h, idbuf.ctypes.data_as(C.c_void_p), 0, 1, C.byref(comm)))
+    return comm
+
+
+def _gather(c, comm):
+    rows = np.zeros(capi.VARIANT_CAP, dtype=capi.VARIANT)
+    cnt = np.zeros(1, dtype=np.uint32)
+    rc = c.lib.jl_allgather_variants(c.h, comm, rows.ctypes.data_as(C.c_void_p), cnt.ctypes.data_as(C.c_void_p), capi.VARIANT_CAP)
+    return rc, rows[: int(cnt[0])].copy()
+
+
+def test_exchange_of_a_table_larger_than_the_head(oracle):
+    """More than 128 called rows: the exchange falls back to the full fixed stride — issued by the communicator's
+    worker like every other collective — and, because the full table is not double-buffered, is refused when the
+    context has launched another run in between."""
+    n, l = 5000, 600
+    sp = synth.SynthParams(seed=12, sub_rate=0.02, minor_permille=(70, 60, 50, 40))
+    ref = synth.reference(sp.seed, l)
+    genes = np.array([(1, l + 1)], dtype=capi.GENE)
+    prm = capi.default_params(alpha=0.5, n_tests=1)
+    j = capi.Juliet(0)
+    j.alloc(n, l)
+    j.synth_fill(sp, ref)
+    comm = _comm(j)
+    try:
+        j.run_async(genes, ref, prm, None, False, 10, False)
+        table = j.run_fetch(False, False)["variants"].copy()
+        assert len(table) > 128
+        rc, got = _gather(j, comm)
+        assert rc == 0 and (got == table).all()
+        # requested, then another run before the collect: every rank refuses alike
+        j.run_async(genes, ref, prm, None, False, 10, False)
+        assert j.lib.jl_allgather_variants_async(j.h, comm) == 0
+        j.run_async(genes, ref, prm, None, False, 10, False)
+        rc, _ = _gather(j, comm)
+        assert rc == -4 and b"not double-buffered" in j.lib.jl_last_error(j.h)
+        # stage API: full stride as well
+        j.pileup_async(genes, ref)
+        j.call_async(prm)
+        rc, got = _gather(j, comm)
+        assert rc == 0 and (got == table).all()
+    finally:
+        j.lib.jl_comm_destroy(comm)
+        j.close()
+
+
+def test_batched_exchange_keeps_its_slots_until_all_members_are_collected(oracle):
+    """A batch of three exchanges is ONE [rank][window][head] region with one event: collecting the first member must
+    not free its slot for a new request whose all-gather would overwrite the heads of the other two."""
+    l = 150
+    genes = np.array([(1, l + 1)], dtype=capi.GENE)
+    ref = synth.reference(5, l)
+    prm = capi.default_params()
+    ctxs, tables = [], []
+    for k in range(3):
+        j = capi.Juliet(0)
+        j.alloc(3000 + 500 * k, l)
+        j.synth_fill(synth.SynthParams(seed=50 + k, minor_permille=(60 + 10 * k, 50, 40, 30)), ref)
+        ctxs.append(j)
+    comm = _comm(ctxs[0])
+    try:
+        for rnd in range(20):
+            for j in ctxs:
+                j.run_async(genes, ref, prm, None, True, 10, False)
+            tables = [j.run_fetch(True, False)["variants"].copy() for j in ctxs]
+            arr = (C.c_void_p * 3)(*[j.h for j in ctxs])
+            assert ctxs[0].lib.jl_allgather_variants_async_many(arr, 3, comm) == 0
+            rc, got = _gather(ctxs[0], comm)
+            assert rc == 0 and (got == tables[0]).all()
+            # new work and a new exchange on the context that was just collected, while two members are outstanding
+            ctxs[0].synth_fill(synth.SynthParams(seed=900 + rnd, minor_permille=(90, 80, 70, 60)), ref)
+            ctxs[0].run_async(genes, ref, prm, None, True, 10, False)
+            t0 = ctxs[0].run_fetch(True, False)["variants"].copy()
+            assert ctxs[0].lib.jl_allgather_variants_async(ctxs[0].h, comm) == 0
+            rc, got = _gather(ctxs[0], comm)
+            assert rc == 0 and (got == t0).all()
+            for k in (1, 2):
+                rc, got = _gather(ctxs[k], comm)
+                assert rc == 0 and (got == tables[k]).all(), (rnd, k)
+            ctxs[0].synth_fill(synth.SynthParams(seed=50, minor_permille=(60, 50, 40, 30)), ref)
+    finally:
+        ctxs[0].lib.jl_comm_destroy(comm)
+        for j in ctxs:
+            j.close()

@@ -152,3 +152,62 @@ def test_from_rows_bam_roundtrip(tmp_path):
     subprocess.check_call([JULIET, "-c", cfg, "--dump-msa", back, bam])
     got, wb = read_msa(back)
     assert wb == 0 and got.shape == (n, l) and (got == rows).all()
+
+
+def _bgzf(raw):
+    """Uncompressed bytes -> BGZF (blocks of <= 60000 bytes + the empty EOF block)."""
+    import struct
+    import zlib
+    out = b""
+    for o in list(range(0, len(raw), 60000)) + [None]:
+        chunk = b"" if o is None else raw[o:o + 60000]
+        co = zlib.compressobj(6, zlib.DEFLATED, -15)
+        body = co.compress(chunk) + co.flush()
+        bsize = 12 + 6 + len(body) + 8 - 1
+        out += struct.pack("<BBBBIBBHBBHH", 31, 139, 8, 4, 0, 0, 255, 6, 66, 67, 2, bsize) + body
+        out += struct.pack("<II", zlib.crc32(chunk) & 0xFFFFFFFF, len(chunk))
+    return out
+
+
+def test_malformed_records_are_rejected(tmp_path):
+    """Untrusted input: a cigar that consumes more bases than the record holds, a record whose variable-length
+    parts overrun its block, an aux array that overruns it — each ends with exit status 2 and a message, never a crash."""
+    import gzip
+    import struct
+    bam = str(tmp_path / "ok.bam")
+    subprocess.check_call([SYNTH, "--reads", "3", "--cols", "60", "--seed", "1", "--sub", "0", "--del", "0", "--mask", "0", "-o", bam])
+    raw = bytearray(gzip.open(bam, "rb").read())
+    l_text, = struct.unpack_from("<i", raw, 4)
+    o = 8 + l_text
+    n_ref, = struct.unpack_from("<i", raw, o)
+    o += 4
+    for _ in range(n_ref):
+        l_name, = struct.unpack_from("<i", raw, o)
+        o += 4 + l_name + 4
+    rec0 = o                                   # block_size word of the first record
+    block, = struct.unpack_from("<i", raw, rec0)
+    l_name = raw[rec0 + 4 + 8]
+    n_cigar, = struct.unpack_from("<H", raw, rec0 + 4 + 12)
+    assert n_cigar == 1
+    cig_at = rec0 + 4 + 32 + l_name
+
+    def run(mutated, *flags):
+        p = str(tmp_path / "bad.bam")
+        open(p, "wb").write(_bgzf(bytes(mutated)))
+        return subprocess.run([JULIET, *flags, "--dump-msa", str(tmp_path / "bad.msa"), p], capture_output=True, text=True)
+
+    assert run(raw).returncode == 0            # the re-compressed original is fine
+    m = bytearray(raw)                         # cigar 60= -> 90=: 30 bases more than the record holds
+    struct.pack_into("<I", m, cig_at, (90 << 4) | 7)
+    r = run(m)
+    assert r.returncode == 2 and "cigar consumes 90 bases, the record holds 60" in r.stderr
+    m = bytearray(raw)                         # l_seq larger than the block
+    struct.pack_into("<I", m, rec0 + 4 + 16, 100000)
+    r = run(m)
+    assert r.returncode == 2 and "corrupt BAM record" in r.stderr
+    m = bytearray(raw)                         # a B-array tag whose count overruns the record, in place of the rq tag
+    aux = rec0 + 4 + 32 + l_name + 4 + 30 + 60
+    assert bytes(m[aux:aux + 3]) == b"rqf"
+    m[aux:aux + 7] = b"zzBc" + struct.pack("<I", 1 << 30)[:3]
+    r = run(m, "--min-rq", "0.5")
+    assert r.returncode == 2 and "truncated BAM aux" in r.stderr

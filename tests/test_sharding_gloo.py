@@ -88,3 +88,64 @@ def test_sharded_call_equals_unsharded(world, oracle):
 def test_allgather_overflow_is_loud():
     with pytest.raises(OverflowError):
         sharding.allgather_tables(np.zeros(5, dtype=capi.VARIANT), cap_rows=4)
+
+
+def _xwin_worker(rank, world, port, q):
+    """configs[3]/[4] on CPU ranks: reads span all windows.  Call per window (oracle), all-gather of the table (gloo),
+    the product's host-side plan of the column exchange (jl_xwin_plan: positions, remapped table, owner rank of each
+    position), the owner's three columns broadcast over gloo where the GPU build uses ncclBroadcast, phasing on the
+    compact matrix."""
+    import torch
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        orc = oracle_lib.load()
+        ref, rows = _data()
+        wb = sharding.window_bounds(L, world)
+        b, e = wb[rank]
+        mine = np.ascontiguousarray(rows[:, b:e])                   # this rank only ever touches its own window
+        prm = oracle_lib.default_params(n_tests=sharding.default_n_tests(GENES))
+        local = orc.call(mine, GENES, win_begin=b, refseq=ref, params=prm)
+        merged = sharding.merge_tables(sharding.allgather_tables(local), [w[0] for w in wb])
+        remapped, pos, owner = capi.xwin_plan([w[0] for w in wb], [w[1] - w[0] for w in wb], merged)
+        assert (owner >= 0).all() and len(pos) == len(np.unique(merged["col"]))
+        compact = np.empty((N, 3 * len(pos)), dtype=np.uint8)
+        for k, (c, w) in enumerate(zip(pos, owner)):
+            buf = torch.from_numpy(np.ascontiguousarray(mine[:, c - b: c - b + 3]) if w == rank else np.zeros((N, 3), dtype=np.uint8))
+            dist.broadcast(buf, int(w))
+            compact[:, 3 * k: 3 * k + 3] = buf.numpy()
+        ph = orc.phase(compact, remapped)
+        if rank == world - 1:     # any rank: phasing is replicated
+            q.put((merged.tobytes(), pos.tobytes(), owner.tobytes(), ph["summary"], ph["hap_count"].tobytes(), ph["read_hap"].tobytes(),
+                   ph["hit"].tobytes()))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_cross_window_phasing_plan_and_exchange(world, oracle):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_xwin_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    merged_b, pos_b, owner_b, summary, hc, rh, hit = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ref, rows = _data()
+    full = oracle.call(rows, GENES, refseq=ref)
+    exp = oracle.phase(rows, full)
+    assert (np.frombuffer(merged_b, dtype=capi.VARIANT) == full).all()
+    pos, owner = np.frombuffer(pos_b, dtype=np.uint32), np.frombuffer(owner_b, dtype=np.int32)
+    assert (pos == exp["pos_cols"]).all()
+    wb = sharding.window_bounds(L, world)
+    assert all(wb[w][0] <= c and c + 3 <= wb[w][1] for c, w in zip(pos, owner))
+    assert len(set(owner.tolist())) >= 2                         # the positions really live on different ranks
+    assert summary == exp["summary"]
+    assert (np.frombuffer(hc, dtype=np.uint32) == exp["hap_count"]).all()
+    assert (np.frombuffer(rh, dtype=np.uint16) == exp["read_hap"]).all()
+    assert (np.frombuffer(hit, dtype=np.uint8).reshape(exp["hit"].shape) == exp["hit"]).all()
