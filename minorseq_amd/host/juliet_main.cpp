@@ -14,6 +14,7 @@
 
 #include "config.hpp"
 #include "format.hpp"
+#include "html.hpp"
 #include "msa_builder.hpp"
 
 using namespace jlhost;
@@ -142,57 +143,6 @@ void die_jl(jl_ctx *ctx, const char *what)
 {
     std::cerr << "juliet: " << what << ": " << jl_last_error(ctx) << "\n";
     std::exit(3);
-}
-
-std::string html_escape(const std::string &s)
-{
-    std::string o;
-    for (char c : s) {
-        if (c == '<') o += "&lt;"; else if (c == '>') o += "&gt;"; else if (c == '&') o += "&amp;"; else o += c;
-    }
-    return o;
-}
-
-// Plain rendering of the JSON (doc/JULIET.md:68-69: "The HTML page is a 1:1 conversion of the JSON file").
-std::string render_html(const Json &root, const std::string &json_text)
-{
-    std::string h = "<!DOCTYPE html><html><head><meta charset=\"utf-8\"><title>juliet</title>"
-                    "<style>body{font-family:sans-serif}table{border-collapse:collapse}td,th{border:1px solid #999;padding:2px 8px}</style>"
-                    "</head><body>\n<h1>juliet</h1>\n";
-    if (const Json *in = root.get("input")) {
-        h += "<h2>Input data</h2><table>";
-        for (auto &kv : in->obj) h += "<tr><th>" + html_escape(kv.first) + "</th><td>" + html_escape(kv.second.str) + "</td></tr>";
-        h += "</table>\n";
-    }
-    if (const Json *genes = root.get("genes")) {
-        h += "<h2>Variant Discovery</h2>\n";
-        for (const Json &g : genes->arr) {
-            h += "<h3>" + html_escape(g.get_str("name")) + "</h3><table><tr><th>Codon</th><th>AA</th><th>Pos</th><th>AA</th><th>Codon</th><th>%</th><th>Coverage</th><th>Affected Drugs</th></tr>\n";
-            if (const Json *vps = g.get("variant_positions"))
-                for (const Json &vp : vps->arr)
-                    for (const Json &aa : vp.get("variant_amino_acids")->arr)
-                        for (const Json &vc : aa.get("variant_codons")->arr) {
-                            const std::string pc = format_percent(100.0 * vc.get("frequency")->num);
-                            h += "<tr><td>" + vp.get_str("ref_codon") + "</td><td>" + vp.get_str("ref_amino_acid") + "</td><td>" +
-                                 std::to_string((long)vp.get("ref_position")->num) + "</td><td>" + aa.get_str("amino_acid") + "</td><td>" +
-                                 vc.get_str("codon") + "</td><td>" + pc + "</td><td>" + std::to_string((long)vp.get("coverage")->num) +
-                                 "</td><td>" + html_escape(vc.get_str("known_drm")) + "</td></tr>\n";
-                        }
-            h += "</table>\n";
-        }
-    }
-    if (const Json *ds = root.get("drug_summaries")) {
-        h += "<h2>Drug Summaries</h2><table><tr><th>Drug</th><th>Gene</th><th>Mutation</th><th>%</th></tr>\n";
-        for (const Json &d : ds->arr)
-            for (const Json &v : d.get("variants")->arr) {
-                const std::string pc = format_percent(100.0 * v.get("frequency")->num);
-                h += "<tr><td>" + html_escape(d.get_str("drug")) + "</td><td>" + html_escape(v.get_str("gene")) + "</td><td>" +
-                     v.get_str("mutation") + "</td><td>" + pc + "</td></tr>\n";
-            }
-        h += "</table>\n";
-    }
-    h += "<h2>JSON</h2><pre>" + html_escape(json_text) + "</pre></body></html>\n";
-    return h;
 }
 
 }  // namespace
@@ -530,7 +480,7 @@ int main(int argc, char **argv)
             std::ofstream f(out);
             if (!f) { std::cerr << "juliet: cannot write " << out << "\n"; return 2; }
             if (out.substr(out.size() - 5) == ".json") f << text;
-            else f << render_html(root, text);
+            else f << render_html(root);
         }
         tick("json / html");
         return 0;

@@ -196,3 +196,125 @@ def test_rich_qv_filter_end_to_end(tmp_path, oracle):
     # unfiltered: coverage is higher because nothing is masked
     j0 = run_juliet(tmp_path, bam, "-c", cfg)
     assert all(a[4]["coverage"] > b[4]["coverage"] for a, b in zip(flat_variants(j0), got))
+
+
+class _Dom:
+    """Minimal HTML tree (tag, attrs, children, text) — enough to read the page back cell by cell."""
+
+    def __init__(self, html):
+        from html.parser import HTMLParser
+
+        root = dict(tag="root", attrs={}, children=[], text="")
+        stack = [root]
+
+        class P(HTMLParser):
+            def handle_starttag(self, tag, attrs):
+                node = dict(tag=tag, attrs=dict(attrs), children=[], text="")
+                stack[-1]["children"].append(node)
+                if tag not in ("meta", "br"):
+                    stack.append(node)
+
+            def handle_endtag(self, tag):
+                while len(stack) > 1 and stack[-1]["tag"] != tag:
+                    stack.pop()
+                if len(stack) > 1:
+                    stack.pop()
+
+            def handle_data(self, data):
+                stack[-1]["text"] += data
+
+        P(convert_charrefs=True).feed(html)
+        self.root = root
+
+    def find(self, node=None, **want):
+        node = node or self.root
+        out = []
+        for c in node["children"]:
+            ok = all((c["tag"] == v) if k == "tag" else (c["attrs"].get(k.rstrip("_")) == v) for k, v in want.items())
+            if ok:
+                out.append(c)
+            out += self.find(c, **want)
+        return out
+
+    @staticmethod
+    def text(node):
+        return node["text"] + "".join(_Dom.text(c) for c in node["children"])
+
+    def rows(self, table):
+        return [[self.text(c).strip() for c in tr["children"] if c["tag"] in ("td", "th")] for tr in table["children"] if tr["tag"] == "tr"]
+
+
+def test_html_is_a_one_to_one_rendering_of_the_json(sample):
+    """doc/JULIET.md:68-69: "The HTML page is a 1:1 conversion of the JSON file and contains the identical information".
+    Both outputs of ONE run; the page is parsed back and every cell compared with the JSON value it renders (numbers in
+    the display format the reference's screenshots print), every JSON leaf must be on the page, and no table has rows
+    the JSON does not."""
+    import scenarios as sc
+    d, bam, cfg, rows, ref = sample
+    subprocess.check_call([JULIET, "-c", cfg, "--mode-phasing", bam, str(d / "one.json"), str(d / "one.html")])
+    j = json.load(open(d / "one.json"))
+    dom = _Dom(open(d / "one.html").read())
+    # section 1 and 2: key / value tables
+    (t,) = dom.find(tag="table", id="input-table")
+    assert dict(dom.rows(t)) == {k: str(v) for k, v in j["input"].items()}
+    (t,) = dom.find(tag="table", id="target-table")
+    want = {k: (str(v) if not isinstance(v, float) else repr(v)) for k, v in j["target_config"].items() if k != "genes"}
+    assert dict(dom.rows(t)) == want
+    (ul,) = dom.find(tag="ul", id="target-genes")
+    lis = [c for c in ul["children"] if c["tag"] == "li"]
+    assert len(lis) == len(j["target_config"]["genes"])
+    for li, g in zip(lis, j["target_config"]["genes"]):
+        assert (li["attrs"]["data-begin"], li["attrs"]["data-end"]) == (str(g["begin"]), str(g["end"]))
+        assert dom.text(dom.find(li, tag="b")[0]) == g["name"]
+        drms = dom.find(li, tag="li", class_="drm")
+        assert [dom.text(dom.find(x, tag="span", class_="drm-name")[0]) for x in drms] == [q["name"] for q in g["drms"]]
+        assert [[dom.text(s) for s in dom.find(x, tag="span", class_="drm-pos")] for x in drms] == [q["positions"] for q in g["drms"]]
+    # section 3: one table per gene, one row per variant codon, haplotype columns, context tables
+    haps = j["haplotype"]["haplotypes"]
+    tables = dom.find(tag="table", class_="gene")
+    assert [t["attrs"]["data-gene"] for t in tables] == [g["name"] for g in j["genes"]]
+    n_rows = 0
+    for t, g in zip(tables, j["genes"]):
+        head = dom.rows(t)
+        assert head[0][2:] == [h["name"] for h in haps]
+        assert head[1][8:] == [sc.fmt_hap_percent(100.0 * h["frequency"]) for h in haps]
+        vrows = [tr for tr in t["children"] if tr["attrs"].get("class") == "variant"]
+        crows = [tr for tr in t["children"] if tr["attrs"].get("class") == "context"]
+        flat = [(vp, aa, vc) for vp in g["variant_positions"] for aa in vp["variant_amino_acids"] for vc in aa["variant_codons"]]
+        assert len(vrows) == len(flat) and len(crows) == len(g["variant_positions"])
+        for tr, (vp, aa, vc) in zip(vrows, flat):
+            cells = [dom.text(c).strip() for c in tr["children"]]
+            assert cells[:8] == [vp["ref_codon"], vp["ref_amino_acid"], str(vp["ref_position"]), aa["amino_acid"], vc["codon"],
+                                 sc.fmt_percent(100.0 * vc["frequency"]), str(vp["coverage"]), vc["known_drm"]]
+            assert [c == "x" for c in cells[8:]] == vc["haplotype_hit"]
+            title = dict(kv.split("=") for kv in tr["attrs"]["title"].split())
+            assert int(title["count"]) == vc["count"] and int(title["expected"]) == vc["expected"]
+            assert float(title["pValue"]) == vc["pValue"] and float(title["log_pValue"]) == vc["log_pValue"]
+            n_rows += 1
+        for tr, vp in zip(crows, g["variant_positions"]):
+            (mt,) = dom.find(tr, tag="table", class_="msa")
+            got = dom.rows(mt)[1:]
+            assert got == [[str(m["rel_pos"]), str(m["abs_pos"])] + [str(m[s]) for s in "ACGT-N"] + [m["wt"]] for m in vp["msa"]]
+    assert n_rows >= 4
+    # section 4
+    (t,) = dom.find(tag="table", id="drug-table")
+    want = [[dd["drug"], v["gene"], v["mutation"], v["codon"], sc.fmt_percent(100.0 * v["frequency"])] for dd in j["drug_summaries"] for v in dd["variants"]]
+    assert dom.rows(t)[1:] == want
+    # the haplotype block: read categories, positions, counts, codons, read names
+    hb = j["haplotype"]
+    (t,) = dom.find(tag="table", id="hap-categories")
+    got = {tr["attrs"]["data-key"]: dom.text([c for c in tr["children"] if c["tag"] == "td"][0]) for tr in t["children"] if "data-key" in tr["attrs"]}
+    assert got == {k: str(hb[k]) for k in ("reported_reads", "insufficient_coverage_reads", "damaged_reads", "marginal_gaps",
+                                           "marginal_heteroduplexes", "marginal_partial")}
+    (p,) = dom.find(tag="p", id="hap-positions")
+    assert [dom.text(s) for s in dom.find(p, tag="span")] == [str(x) for x in hb["variant_positions_abs"]]
+    (t,) = dom.find(tag="table", id="hap-table")
+    trs = [tr for tr in t["children"] if tr["tag"] == "tr"][1:]
+    assert len(trs) == len(haps)
+    for tr, hp in zip(trs, haps):
+        tds = [c for c in tr["children"] if c["tag"] == "td"]
+        assert [dom.text(c).strip() for c in tds[:3]] == [hp["name"], sc.fmt_hap_percent(100.0 * hp["frequency"]), str(hp["reads"])]
+        assert dom.text(tds[3]).split() == hp["codons"]
+        assert [dom.text(s) for s in dom.find(tds[4], tag="span", class_="rn")] == hp["read_names"]
+    # nothing of the JSON is left out: every top-level key has its section
+    assert set(j) == {"input", "target_config", "genes", "drug_summaries", "haplotype"}
