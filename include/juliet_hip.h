@@ -142,6 +142,14 @@ int jl_msa_pack_rows(jl_ctx *ctx, const uint8_t *rows, uint64_t n_reads, uint32_
 int jl_msa_ingest_records(jl_ctx *ctx, uint64_t n_reads, uint32_t n_cols, uint32_t win_begin, const int32_t *pos,
                           const uint32_t *cigar, const uint64_t *cig_off, const uint8_t *seq4, const uint64_t *seq_off,
                           const uint8_t *qual, const uint64_t *qual_off, uint32_t min_qv);
+/*
+ * Insertions are not part of the matrix (J:26-27) but `fuse` "includes in-frame insertions with a certain distance to
+ * each other" (doc/FUSE.md:19): with tracking on, jl_msa_ingest_records also counts them per window column — an
+ * insertion sits BEFORE the column of the next reference base.  len_hist[n_cols][32]: insertions by length (31 = longer
+ * than 30); base_counts[n_cols][30][4]: inserted bases A C G T by offset.  Either pointer may be NULL.
+ */
+int jl_msa_track_insertions(jl_ctx *ctx, int on);
+int jl_insertions_fetch(jl_ctx *ctx, uint32_t *len_hist, uint32_t *base_counts);
 /* Copy the resident matrix back to the host (tests). */
 int jl_msa_download(jl_ctx *ctx, uint8_t *colpacked, uint64_t bytes);
 /* Fill the resident matrix with synthetic reads, on the device. `ref` = n_cols base codes (host). */

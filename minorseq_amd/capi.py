@@ -29,7 +29,7 @@ SUMMARY = np.dtype([(n, "<u4") for n in SUMMARY_FIELDS])
 # every symbol include/juliet_hip.h declares (checked by tests/test_capi_exports.py)
 EXPORTS = ("jl_abi_version", "jl_strerror", "jl_device_count", "jl_ctx_create", "jl_ctx_destroy", "jl_last_error",
            "jl_sync", "jl_col_stride", "jl_msa_upload", "jl_msa_alloc", "jl_msa_adopt", "jl_msa_pack_rows",
-           "jl_msa_ingest_records", "jl_msa_download", "jl_synth_fill", "jl_synth_fill_window", "jl_pileup_async", "jl_n_positions", "jl_pileup_fetch",
+           "jl_msa_ingest_records", "jl_msa_track_insertions", "jl_insertions_fetch", "jl_msa_download", "jl_synth_fill", "jl_synth_fill_window", "jl_pileup_async", "jl_n_positions", "jl_pileup_fetch",
            "jl_consensus_fetch", "jl_call_async", "jl_call_fetch", "jl_variant_table_device", "jl_phase_async", "jl_phase_fetch",
            "jl_run_async", "jl_run_wait", "jl_run_done", "jl_run_view_get", "jl_group_create", "jl_group_destroy",
            "jl_group_last_error", "jl_group_run_async", "jl_group_run_masked_async", "jl_group_time_pileup", "jl_fisher_eval", "jl_fisher_eval_tail", "jl_expand_read_hap", "jl_time_pileup", "jl_time_pileup_set", "jl_pileup_kernel_name", "jl_comm_unique_id", "jl_comm_create", "jl_comm_destroy",
@@ -141,6 +141,8 @@ def load_library(path=LIB_PATH):
     lib.jl_msa_adopt.argtypes = [vp, vp, u64, u32, u64, u32]
     lib.jl_msa_pack_rows.argtypes = [vp, vp, u64, u32, u32]
     lib.jl_msa_ingest_records.argtypes = [vp, u64, u32, u32] + [vp] * 7 + [u32]
+    lib.jl_msa_track_insertions.argtypes = [vp, C.c_int]
+    lib.jl_insertions_fetch.argtypes = [vp, vp, vp]
     lib.jl_msa_download.argtypes = [vp, vp, u64]
     lib.jl_synth_fill.argtypes = [vp, C.POINTER(SynthParams), vp]
     lib.jl_synth_fill_window.argtypes = [vp, C.POINTER(SynthParams), vp, u32]
@@ -283,6 +285,16 @@ class Juliet:
         self._chk(self.lib.jl_msa_ingest_records(self.h, n, n_cols, win_begin, _p(pos), _p(cigar), _p(cig_off), _p(seq4),
                                                  _p(seq_off), _p(qual), _p(qual_off), min_qv))
         self._shape(n, n_cols, self.lib.jl_col_stride(n))
+
+    def track_insertions(self, on=True):
+        self._chk(self.lib.jl_msa_track_insertions(self.h, 1 if on else 0))
+
+    def insertions_fetch(self):
+        """(len_hist[n_cols][32], base_counts[n_cols][30][4]) of the last ingest_records with tracking on."""
+        lh = np.zeros((self.n_cols, 32), dtype=np.uint32)
+        bc = np.zeros((self.n_cols, 30, 4), dtype=np.uint32)
+        self._chk(self.lib.jl_insertions_fetch(self.h, _p(lh), _p(bc)))
+        return lh, bc
 
     def alloc(self, n_reads, n_cols, win_begin=0):
         self._chk(self.lib.jl_msa_alloc(self.h, n_reads, n_cols, win_begin))

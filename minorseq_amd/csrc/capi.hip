@@ -148,7 +148,7 @@ void jl_ctx_destroy(jl_ctx *ctx)
                     ctx->d_col2pos, ctx->d_varcol, ctx->d_keys, ctx->d_flagw, ctx->d_read_slot, ctx->d_read_hap,
                     ctx->d_slot_rep, ctx->d_slot_count, ctx->d_slot_key, ctx->d_slot_hap, ctx->d_occupied, ctx->d_hap_count,
                     ctx->d_hap_pattern, ctx->d_hit, ctx->d_cooc, ctx->d_pack, ctx->d_sync, ctx->d_timeline,
-                    ctx->d_col_first, ctx->d_pos_next, ctx->d_callinfo};
+                    ctx->d_col_first, ctx->d_pos_next, ctx->d_callinfo, ctx->d_ins_len, ctx->d_ins_base};
     for (void *p : ptrs)
         if (p) hipFree(p);
     if (ctx->ev0) hipEventDestroy(ctx->ev0);
@@ -184,6 +184,7 @@ static int set_shape(jl_ctx *ctx, uint64_t n_reads, uint32_t n_cols, uint64_t co
     ctx->alloc_version++;
     ctx->pack_valid = false;
     ctx->pileup_done = ctx->call_done = ctx->phase_done = false;
+    ctx->ins_valid = false;
     return JL_OK;
 }
 
@@ -315,6 +316,25 @@ int jl_msa_ingest_records(jl_ctx *ctx, uint64_t n_reads, uint32_t n_cols, uint32
     if (e == hipSuccess && n_reads) e = hipMemcpyAsync(d_pos, pos, (size_t)n_reads * 4, hipMemcpyHostToDevice, st);
     if (e == hipSuccess && qual && n_q) e = hipMemcpyAsync(d_qual, qual, n_q, hipMemcpyHostToDevice, st);
     if (e == hipSuccess && qual) e = hipMemcpyAsync(d_qo, qual_off, off_bytes, hipMemcpyHostToDevice, st);
+    ctx->ins_valid = false;
+    if (e == hipSuccess && ctx->track_insertions) {
+        if (ctx->ins_capacity < n_cols) {
+            if (ctx->d_ins_len) hipFree(ctx->d_ins_len);
+            if (ctx->d_ins_base) hipFree(ctx->d_ins_base);
+            ctx->d_ins_len = ctx->d_ins_base = nullptr;
+            ctx->ins_capacity = 0;
+            e = hipMalloc(&ctx->d_ins_len, (size_t)n_cols * JL_INS_LEN_BINS * 4);
+            if (e == hipSuccess) e = hipMalloc(&ctx->d_ins_base, (size_t)n_cols * JL_INS_MAX_BASES * 16);
+            if (e == hipSuccess) ctx->ins_capacity = n_cols;
+        }
+        if (e == hipSuccess) e = hipMemsetAsync(ctx->d_ins_len, 0, (size_t)n_cols * JL_INS_LEN_BINS * 4, st);
+        if (e == hipSuccess) e = hipMemsetAsync(ctx->d_ins_base, 0, (size_t)n_cols * JL_INS_MAX_BASES * 16, st);
+        if (e == hipSuccess) {
+            jl_launch_insertions(ctx, d_pos, d_cig, d_co, d_seq, d_so);
+            e = hipGetLastError();
+            ctx->ins_valid = e == hipSuccess;
+        }
+    }
     if (e == hipSuccess) {
         jl_launch_ingest(ctx, d_pos, d_cig, d_co, d_seq, d_so, d_qual, d_qo, min_qv);
         e = hipGetLastError();
@@ -324,6 +344,24 @@ int jl_msa_ingest_records(jl_ctx *ctx, uint64_t n_reads, uint32_t n_cols, uint32
     for (void *p : tmp)
         if (p) hipFree(p);
     if (e != hipSuccess) return jl_fail(ctx, e == hipErrorOutOfMemory ? JL_ERR_MEMORY : JL_ERR_DEVICE, "ingest: %s", hipGetErrorString(e));
+    return JL_OK;
+}
+
+int jl_msa_track_insertions(jl_ctx *ctx, int on)
+{
+    if (!ctx) return JL_ERR_ARG;
+    ctx->track_insertions = on != 0;
+    return JL_OK;
+}
+
+int jl_insertions_fetch(jl_ctx *ctx, uint32_t *len_hist, uint32_t *base_counts)
+{
+    if (!ctx) return JL_ERR_ARG;
+    if (!ctx->ins_valid) return jl_fail(ctx, JL_ERR_STATE, "no insertion counts: jl_msa_track_insertions(ctx, 1) before jl_msa_ingest_records");
+    JL_HIP(ctx, hipSetDevice(ctx->device));
+    if (len_hist) JL_HIP(ctx, hipMemcpyAsync(len_hist, ctx->d_ins_len, (size_t)ctx->n_cols * JL_INS_LEN_BINS * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (base_counts) JL_HIP(ctx, hipMemcpyAsync(base_counts, ctx->d_ins_base, (size_t)ctx->n_cols * JL_INS_MAX_BASES * 16, hipMemcpyDeviceToHost, ctx->stream));
+    JL_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return JL_OK;
 }
 

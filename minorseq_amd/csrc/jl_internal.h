@@ -26,6 +26,8 @@
 #define JL_FOLD_MAX_BLOCKS 128u
 #define JL_TIMELINE_ROWS 4096u
 #define JL_TIMELINE_SLOTS 8u
+#define JL_INS_LEN_BINS 32u        // insertion lengths 0..30 by value, 31 = longer
+#define JL_INS_MAX_BASES 30u       // inserted bases tracked per insertion
 #define JL_GUESS_PAD 32u           // zero bytes after the last column's seed base
 #define JL_PILEUP_TILE_BYTES 4096u  // bytes of one column a 256-thread block reads per iteration (16 B / lane)
 
@@ -239,6 +241,13 @@ struct jl_ctx {
     uint64_t col_stride = 0;
     uint32_t win_begin = 0;
 
+    // ---- insertions per column (fuse-style consensus; off unless jl_msa_track_insertions)
+    bool track_insertions = false;
+    bool ins_valid = false;
+    uint32_t *d_ins_len = nullptr;    // [n_cols][JL_INS_LEN_BINS]
+    uint32_t *d_ins_base = nullptr;   // [n_cols][JL_INS_MAX_BASES][4]
+    size_t ins_capacity = 0;          // columns
+
     // ---- pileup plan (host copies + device arrays)
     std::vector<jl_gene> genes;
     std::vector<uint8_t> refseq;
@@ -381,6 +390,8 @@ void jl_launch_consensus(jl_ctx *ctx, uint8_t *d_out);
 void jl_launch_ingest(jl_ctx *ctx, const int32_t *d_pos, const uint32_t *d_cigar, const uint64_t *d_cig_off,
                       const uint8_t *d_seq4, const uint64_t *d_seq_off, const uint8_t *d_qual,
                       const uint64_t *d_qual_off, uint32_t min_qv);
+void jl_launch_insertions(jl_ctx *ctx, const int32_t *d_pos, const uint32_t *d_cigar, const uint64_t *d_cig_off,
+                          const uint8_t *d_seq4, const uint64_t *d_seq_off);
 void jl_launch_fisher_eval(jl_ctx *ctx, uint32_t n, const uint32_t *a, const uint32_t *c, const uint32_t *cov, int tail,
                            double *p, double *lp);
 // per-read ids in their packed form (4 / 8 / 16 bits, see JL_ID4_MAX_H) expanded to 16-bit ids on the host

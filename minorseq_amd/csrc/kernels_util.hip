@@ -196,6 +196,48 @@ __global__ __launch_bounds__(256) void ingest_cols_kernel(uint64_t n_reads, uint
     }
 }
 
+// Insertions per window column (doc/FUSE.md:19 "Fuse includes in-frame insertions"): they are not part of the MSA
+// (doc/JULIET.md:26-27), so they are counted from the records.  One thread per read walks its cigar; an insertion sits
+// BEFORE the window column of the next reference base: len_hist[c][min(len, 31)]++, base_counts[c][j][base]++ for the
+// inserted bases at offsets j < 30.  Integer atomics commute: bit-exact against the oracle's loops.
+__global__ __launch_bounds__(256) void insertions_kernel(uint64_t n_reads, uint32_t n_cols, uint32_t win_begin,
+                                                          const int32_t *__restrict__ pos, const uint32_t *__restrict__ cigar,
+                                                          const uint64_t *__restrict__ cig_off, const uint8_t *__restrict__ seq4,
+                                                          const uint64_t *__restrict__ seq_off, uint32_t *__restrict__ len_hist,
+                                                          uint32_t *__restrict__ base_counts)
+{
+    const uint64_t r = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (r >= n_reads) return;
+    int64_t rp = pos[r];
+    uint64_t qp = 0;
+    const uint8_t *sq = seq4 + seq_off[r];
+    const uint64_t n_bases = (seq_off[r + 1] - seq_off[r]) * 2u;
+    for (uint64_t k = cig_off[r]; k < cig_off[r + 1]; ++k) {
+        const uint32_t op = cigar[k] & 15u, len = cigar[k] >> 4;
+        if (op == 1u) {
+            const int64_t c = rp - (int64_t)win_begin;
+            if (c >= 0 && c < (int64_t)n_cols) {
+                atomicAdd(&len_hist[(uint64_t)c * JL_INS_LEN_BINS + (len < 31u ? len : 31u)], 1u);
+                for (uint32_t j = 0; j < len && j < JL_INS_MAX_BASES; ++j) {
+                    const uint64_t q = qp + j;
+                    if (q >= n_bases) break;   // malformed input stays inside the read's bases
+                    const uint32_t b16 = (q & 1u) ? (sq[q >> 1] & 15u) : (sq[q >> 1] >> 4);
+                    const uint32_t b = (uint32_t)((0x5555555355525105ull >> (4u * b16)) & 15ull);   // A=1 C=2 G=4 T=8 -> 0..3, else 5
+                    if (b < 4u) atomicAdd(&base_counts[((uint64_t)c * JL_INS_MAX_BASES + j) * 4u + b], 1u);
+                }
+            }
+            qp += len;
+        } else if (op == 4u) {
+            qp += len;
+        } else if (op == 7u || op == 8u) {
+            qp += len;
+            rp += len;
+        } else if (op == 2u || op == 3u) {
+            rp += len;
+        }
+    }
+}
+
 // Per-column consensus from the pileup (doc/FUSE.md:17-20, the part that needs no insertion tracking):
 // majority among A C G T -; a column whose majority is '-' is marked removed (4); no covering read => 5.
 __global__ __launch_bounds__(256) void consensus_kernel(const uint32_t *__restrict__ counts, uint32_t n_cols,
@@ -320,6 +362,13 @@ void jl_launch_ingest(jl_ctx *ctx, const int32_t *d_pos, const uint32_t *d_cigar
     hipLaunchKernelGGL(ingest_cols_kernel, grid, dim3(256), 0, ctx->stream, ctx->n_reads, ctx->n_cols, ctx->win_begin,
                        seg_cols, d_pos, d_cigar, d_cig_off, d_seq4, d_seq_off, d_qual, d_qual_off, min_qv, ctx->d_msa,
                        ctx->col_stride);
+}
+
+void jl_launch_insertions(jl_ctx *ctx, const int32_t *d_pos, const uint32_t *d_cigar, const uint64_t *d_cig_off,
+                          const uint8_t *d_seq4, const uint64_t *d_seq_off)
+{
+    hipLaunchKernelGGL(insertions_kernel, dim3((uint32_t)((ctx->n_reads + 255u) / 256u)), dim3(256), 0, ctx->stream, ctx->n_reads,
+                       ctx->n_cols, ctx->win_begin, d_pos, d_cigar, d_cig_off, d_seq4, d_seq_off, ctx->d_ins_len, ctx->d_ins_base);
 }
 
 void jl_launch_synth(jl_ctx *ctx, const jl_synth_plan *plan, const uint8_t *d_ref, uint32_t col0)

@@ -14,6 +14,7 @@
 
 #include "config.hpp"
 #include "format.hpp"
+#include "fuse.hpp"
 #include "html.hpp"
 #include "msa_builder.hpp"
 
@@ -38,6 +39,8 @@ struct Options {
     double min_rq = 0.0;
     int device = 0;
     std::string dump_msa, dump_config, consensus;
+    double ins_min_frac = 0.5;     // an insertion enters the consensus when more than this share of the covering reads carries it
+    uint32_t ins_min_distance = 10;  // ... and the previous included insertion lies at least this many columns back (UNPINNED)
     bool timing = false;
 };
 
@@ -55,7 +58,9 @@ struct Options {
         "      --alpha 0.01  --n-tests <auto>  --chemistry auto|sequel|permissive\n"
         "      --match-rate <r> --substitution-rate <r> --expected-round ceil|floor|nearest\n"
         "      --min-reads 10  --min-qv 0  --min-rq 0  --device 0\n"
-        "      --consensus <out.fasta>         also write the window's majority consensus (fuse-style, no insertions)\n"
+        "      --consensus <out.fasta>         also write the window's consensus as `fuse` would (doc/FUSE.md:17-20):\n"
+        "                                      majority base, major deletions removed, in-frame majority insertions kept\n"
+        "      --ins-min-frac 0.5  --ins-min-distance 10   when an insertion enters the consensus\n"
         "      --timing                        wall time of each stage on stderr\n"
         "  diagnostics (no GPU needed): --dump-msa <file>  --dump-config <file>\n";
     std::exit(code);
@@ -100,6 +105,8 @@ Options parse(int argc, char **argv)
         else if (a == "--min-rq") o.min_rq = std::stod(need(i));
         else if (a == "--device") o.device = std::stoi(need(i));
         else if (a == "--consensus") o.consensus = need(i);
+        else if (a == "--ins-min-frac") o.ins_min_frac = std::stod(need(i));
+        else if (a == "--ins-min-distance") o.ins_min_distance = (uint32_t)std::stoul(need(i));
         else if (a == "--dump-msa") o.dump_msa = need(i);
         else if (a == "--dump-config") o.dump_config = need(i);
         else if (a == "--timing") o.timing = true;
@@ -268,6 +275,7 @@ int main(int argc, char **argv)
         jl_ctx *ctx = up.second;
         if (up.first != JL_OK) die_jl(nullptr, "no usable GPU (this tool has no CPU fallback)");
         tick("context ready");
+        if (!opt.consensus.empty()) jl_msa_track_insertions(ctx, 1);   // fuse keeps in-frame insertions (doc/FUSE.md:19)
         if (jl_msa_ingest_records(ctx, n_reads, n_cols, win_begin, rec.pos.data(), rec.cigar.data(), rec.cig_off.data(),
                                   rec.seq4.data(), rec.seq_off.data(), opt.min_qv ? rec.qual.data() : nullptr,
                                   opt.min_qv ? rec.qual_off.data() : nullptr, opt.min_qv) != JL_OK)
@@ -302,16 +310,13 @@ int main(int argc, char **argv)
         std::vector<uint32_t> col_counts((size_t)n_cols * 6);
         if (jl_pileup_fetch(ctx, col_counts.data(), nullptr, nullptr, nullptr, nullptr, nullptr) != JL_OK) die_jl(ctx, "pileup fetch");
 
-        if (!opt.consensus.empty()) {  // by-product of the pileup (doc/FUSE.md:17-24): majority base, major deletions removed
-            std::vector<uint8_t> cons(n_cols);
-            if (jl_consensus_fetch(ctx, cons.data()) != JL_OK) die_jl(ctx, "consensus");
+        if (!opt.consensus.empty()) {  // what `fuse` writes for this window (doc/FUSE.md:17-24)
+            std::vector<uint32_t> len_hist((size_t)n_cols * 32), base_counts((size_t)n_cols * 120);
+            if (jl_insertions_fetch(ctx, len_hist.data(), base_counts.data()) != JL_OK) die_jl(ctx, "insertions");
+            const std::string seq = fuse_consensus(n_cols, col_counts, len_hist, base_counts, opt.ins_min_frac, opt.ins_min_distance);
             std::ofstream f(opt.consensus);
             if (!f) { std::cerr << "juliet: cannot write " << opt.consensus << "\n"; return 2; }
             f << ">consensus window=" << (win_begin + 1) << "-" << (win_begin + n_cols) << " source=" << opt.bam << "\n";
-            std::string seq;
-            for (uint8_t s : cons)
-                if (s < 4) seq += "ACGT"[s];
-                else if (s == 5) seq += 'N';      // uncovered; majority-deletion columns (4) are dropped
             for (size_t i = 0; i < seq.size(); i += 70) f << seq.substr(i, 70) << "\n";
         }
         jl_phase_summary ps = {};

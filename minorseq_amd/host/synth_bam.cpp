@@ -18,6 +18,8 @@ int main(int argc, char **argv)
     double sub = 1.75e-4, del = 1.3e-3, mask = 2.0e-2, partial = 0.0;
     uint32_t minor[4] = {10, 10, 10, 10};
     std::string out, cfg_out, from_rows, ref_string;
+    struct Plant { uint32_t col, len, permille; };
+    std::vector<Plant> plants;   // --insert col:len:permille — insertions before window column `col` in that share of the reads
     bool rich_qv = false;  // filtered bases keep their letter and get a low substitution QV (sq tag) instead of 'N'
     for (int i = 1; i < argc; ++i) {
         const std::string a = argv[i];
@@ -32,6 +34,12 @@ int main(int argc, char **argv)
         else if (a == "--minor-permille") { for (int k = 0; k < 4; ++k) minor[k] = (uint32_t)std::stoul(need()); }
         else if (a == "--ref-offset") ref_offset = (uint32_t)std::stoul(need());  // window starts here in a longer reference
         else if (a == "--rich-qv") rich_qv = true;
+        else if (a == "--insert") {
+            const std::string v = need();
+            Plant p;
+            if (sscanf(v.c_str(), "%u:%u:%u", &p.col, &p.len, &p.permille) != 3) { std::cerr << "--insert wants col:len:permille\n"; return 1; }
+            plants.push_back(p);
+        }
         else if (a == "--from-rows") from_rows = need();   // a matrix in the --dump-msa format instead of the generator
         else if (a == "--ref") ref_string = need();        // its reference bases (ACGT), one per column
         else if (a == "-o") out = need();
@@ -110,6 +118,21 @@ int main(int argc, char **argv)
         uint32_t run_op = 99, run_len = 0;
         auto flush = [&]() { if (run_len) r.cigar.push_back(run_len << 4 | run_op); run_len = 0; };
         for (uint32_t c = st; c < en; ++c) {
+            for (size_t pi = 0; pi < plants.size(); ++pi) {
+                // an insertion of plants[pi].len bases (a fixed sequence derived from the column) before column c;
+                // which reads carry it is a hash of (read, plant)
+                const Plant &p = plants[pi];
+                if (p.col != c || c == st) continue;
+                if (jl_splitmix64(seed * 0x9E3779B9ull + 1000003ull * i + 7919ull * pi) % 1000u >= p.permille) continue;
+                flush();
+                run_op = 99;
+                r.cigar.push_back(p.len << 4 | CIG_I);
+                for (uint32_t j = 0; j < p.len; ++j) {
+                    r.seq.push_back((uint8_t)((p.col * 7u + j * 3u + 1u) & 3u));
+                    r.qual.push_back(93);
+                    if (rich_qv) { r.sq.push_back((char)(33 + 60)); r.dq.push_back((char)(33 + 60)); r.iq.push_back((char)(33 + 60)); }
+                }
+            }
             const uint32_t s = jl_synth_cell(&pl, i, c, hap, st, en, ref[c]);
             uint32_t op;
             if (s == 4) op = CIG_D;

@@ -503,3 +503,95 @@ int orc_phase(const uint8_t *msa, uint64_t n_reads, uint32_t n_cols, const orc_v
 /* sizes, so the ctypes side can assert its dtype matches */
 uint32_t orc_sizeof_variant(void) { return (uint32_t)sizeof(orc_variant); }
 uint32_t orc_sizeof_params(void) { return (uint32_t)sizeof(orc_params); }
+
+/* ------------------------------------------------------------------ fuse-style consensus (doc/FUSE.md:17-20) */
+
+/*
+ * "Fuse includes in-frame insertions with a certain distance to each other.  Major deletions are being removed."
+ * Insertions are not part of the MSA (J:26-27), so they are counted from the aligned records: an insertion (cigar I)
+ * sits BEFORE the window column of the next reference base.  len_hist[c][min(len, 31)] counts insertions by length,
+ * base_counts[c][j][b] the inserted bases at offset j < 30 (b = 0..3; other letters are not counted).
+ * pos: 0-based leftmost reference position; cigar words (len << 4 | op); seq4: BAM's packed bases, read r from byte
+ * seq_off[r], first base in the high nibble.  SPEC §11.
+ */
+enum { ORC_INS_LEN_BINS = 32, ORC_INS_MAX_BASES = 30 };
+
+int orc_insertions(uint64_t n_reads, uint32_t n_cols, uint32_t win_begin, const int32_t *pos, const uint32_t *cigar,
+                   const uint64_t *cig_off, const uint8_t *seq4, const uint64_t *seq_off, uint32_t *len_hist,
+                   uint32_t *base_counts)
+{
+    static const uint8_t code_of[16] = {4, 0, 1, 4, 2, 4, 4, 4, 3, 4, 4, 4, 4, 4, 4, 4}; /* =ACMGRSVTWYHKDBN */
+    memset(len_hist, 0, (size_t)n_cols * ORC_INS_LEN_BINS * sizeof(uint32_t));
+    memset(base_counts, 0, (size_t)n_cols * ORC_INS_MAX_BASES * 4 * sizeof(uint32_t));
+    for (uint64_t r = 0; r < n_reads; ++r) {
+        int64_t rp = pos[r];
+        uint64_t qp = 0;
+        const uint8_t *sq = seq4 + seq_off[r];
+        for (uint64_t k = cig_off[r]; k < cig_off[r + 1]; ++k) {
+            uint32_t op = cigar[k] & 15u, len = cigar[k] >> 4;
+            if (op == 1) { /* I */
+                int64_t c = rp - (int64_t)win_begin;
+                if (c >= 0 && c < (int64_t)n_cols) {
+                    len_hist[(size_t)c * ORC_INS_LEN_BINS + (len < 31 ? len : 31)]++;
+                    for (uint32_t j = 0; j < len && j < ORC_INS_MAX_BASES; ++j) {
+                        uint64_t q = qp + j;
+                        uint8_t b16 = (q & 1) ? (sq[q >> 1] & 15) : (sq[q >> 1] >> 4);
+                        uint8_t b = code_of[b16];
+                        if (b < 4) base_counts[((size_t)c * ORC_INS_MAX_BASES + j) * 4 + b]++;
+                    }
+                }
+                qp += len;
+            } else if (op == 4) { /* S */
+                qp += len;
+            } else if (op == 7 || op == 8 || op == 0) { /* = X (M) */
+                qp += len;
+                rp += len;
+            } else if (op == 2 || op == 3) { /* D N */
+                rp += len;
+            }
+        }
+    }
+    return 0;
+}
+
+/*
+ * The consensus of a window: per column the majority of A C G T - (lowest code on ties); a column whose majority is
+ * '-' is removed ("major deletions are being removed"), a column nobody covers is N.  Before column c an insertion is
+ * included iff an IN-FRAME length L (3, 6, ... 30; the most frequent, the shorter on ties) is carried by more than
+ * `min_frac` of the reads covering c and the last included insertion lies at least `min_distance` columns back
+ * ("in-frame insertions with a certain distance to each other"; both UNPINNED, SPEC §11); its bases are the majority
+ * base per offset.  out: characters, at most n_cols * 31; returns the length.
+ */
+uint32_t orc_fuse(uint32_t n_cols, const uint32_t *col_counts, const uint32_t *len_hist, const uint32_t *base_counts,
+                  double min_frac, uint32_t min_distance, char *out)
+{
+    uint32_t n = 0;
+    int64_t last_ins = -(int64_t)min_distance - 1;
+    for (uint32_t c = 0; c < n_cols; ++c) {
+        const uint32_t *k = col_counts + (size_t)c * 6;
+        uint32_t covering = k[0] + k[1] + k[2] + k[3] + k[4] + k[5];
+        if (len_hist && covering) {
+            uint32_t bestL = 0, bestN = 0;
+            for (uint32_t L = 3; L <= ORC_INS_MAX_BASES; L += 3) {
+                uint32_t v = len_hist[(size_t)c * ORC_INS_LEN_BINS + L];
+                if (v > bestN) { bestN = v; bestL = L; }
+            }
+            if (bestL && (double)bestN > min_frac * (double)covering && (int64_t)c - last_ins >= (int64_t)min_distance) {
+                for (uint32_t j = 0; j < bestL; ++j) {
+                    const uint32_t *b = base_counts + ((size_t)c * ORC_INS_MAX_BASES + j) * 4;
+                    uint32_t best = 0;
+                    for (uint32_t s = 1; s < 4; ++s)
+                        if (b[s] > b[best]) best = s;
+                    out[n++] = "ACGT"[best];
+                }
+                last_ins = c;
+            }
+        }
+        uint32_t best = 0, bv = k[0];
+        for (uint32_t s = 1; s < 5; ++s)
+            if (k[s] > bv) { bv = k[s]; best = s; }
+        if (bv == 0) out[n++] = 'N';
+        else if (best < 4) out[n++] = "ACGT"[best];
+    }
+    return n;
+}

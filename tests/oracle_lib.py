@@ -134,6 +134,40 @@ class Oracle:
                     cooc=cooc[:nv, :nv].copy())
 
 
+def _insertions(self, n_cols, win_begin, pos, cigar, cig_off, seq4, seq_off):
+    """orc_insertions: (len_hist[n_cols][32], base_counts[n_cols][30][4]) of aligned records (BAM-decoded arrays)."""
+    pos = np.ascontiguousarray(pos, dtype=np.int32)
+    cigar = np.ascontiguousarray(cigar, dtype=np.uint32)
+    cig_off = np.ascontiguousarray(cig_off, dtype=np.uint64)
+    seq4 = np.ascontiguousarray(seq4, dtype=np.uint8)
+    seq_off = np.ascontiguousarray(seq_off, dtype=np.uint64)
+    lh = np.zeros((n_cols, 32), dtype=np.uint32)
+    bc = np.zeros((n_cols, 30, 4), dtype=np.uint32)
+    vp = C.c_void_p
+    self.lib.orc_insertions(C.c_uint64(len(pos)), C.c_uint32(n_cols), C.c_uint32(win_begin), pos.ctypes.data_as(vp),
+                            cigar.ctypes.data_as(vp), cig_off.ctypes.data_as(vp), seq4.ctypes.data_as(vp), seq_off.ctypes.data_as(vp),
+                            lh.ctypes.data_as(vp), bc.ctypes.data_as(vp))
+    return lh, bc
+
+
+def _fuse(self, col_counts, len_hist, base_counts, min_frac=0.5, min_distance=10):
+    """orc_fuse: the consensus string of a window (doc/FUSE.md:17-20)."""
+    col_counts = np.ascontiguousarray(col_counts, dtype=np.uint32)
+    n_cols = len(col_counts)
+    out = C.create_string_buffer(n_cols * 31 + 1)
+    vp = C.c_void_p
+    self.lib.orc_fuse.restype = C.c_uint32
+    lh = None if len_hist is None else np.ascontiguousarray(len_hist, dtype=np.uint32)
+    bc = None if base_counts is None else np.ascontiguousarray(base_counts, dtype=np.uint32)
+    n = self.lib.orc_fuse(C.c_uint32(n_cols), col_counts.ctypes.data_as(vp), None if lh is None else lh.ctypes.data_as(vp),
+                          None if bc is None else bc.ctypes.data_as(vp), C.c_double(min_frac), C.c_uint32(min_distance), out)
+    return out.raw[:n].decode()
+
+
+Oracle.insertions = _insertions
+Oracle.fuse = _fuse
+
+
 def build():
     subprocess.check_call(["make", "-s", "-C", ORACLE_DIR])
 

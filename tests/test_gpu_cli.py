@@ -318,3 +318,35 @@ def test_html_is_a_one_to_one_rendering_of_the_json(sample):
         assert [dom.text(s) for s in dom.find(tds[4], tag="span", class_="rn")] == hp["read_names"]
     # nothing of the JSON is left out: every top-level key has its section
     assert set(j) == {"input", "target_config", "genes", "drug_summaries", "haplotype"}
+
+
+def test_consensus_keeps_in_frame_majority_insertions(tmp_path, oracle):
+    """`juliet --consensus` = the documented scope of `fuse` (doc/FUSE.md:17-24): planted insertions — an in-frame one in
+    80 % of the reads, an in-frame one in 30 %, a 4-base one in 90 %, and two in-frame majority ones 6 columns apart —
+    against the known answer (the 96 % major clone is the reference) and against the oracle's rule on the same counts."""
+    n, l, seed = 3000, 300, 6
+    bam, cfg, fa = (str(tmp_path / x) for x in ("ins.bam", "ins.json", "ins.fasta"))
+    plants = [(60, 3, 800), (90, 6, 300), (120, 4, 900), (150, 6, 850), (156, 3, 900), (240, 9, 700)]
+    args = []
+    for c, k, pm in plants:
+        args += ["--insert", f"{c}:{k}:{pm}"]
+    subprocess.check_call([SYNTH, "--reads", str(n), "--cols", str(l), "--seed", str(seed), *args, "-o", bam, "--config-out", cfg])
+    subprocess.check_call([JULIET, "-c", cfg, "--consensus", fa, bam, str(tmp_path / "o.json")])
+    seq = "".join(open(fa).read().splitlines()[1:])
+    ref = synth.reference(seed, l)
+    ins_seq = lambda c, k: "".join("ACGT"[(c * 7 + j * 3 + 1) & 3] for j in range(k))   # noqa: E731  juliet-synth's bases
+    want = ""
+    for c in range(l):
+        if c in (60, 150, 240):            # in frame and in most reads; 156 is within 10 columns of 150
+            want += ins_seq(c, dict((p[0], p[1]) for p in plants)[c])
+        want += "ACGT"[ref[c]]
+    assert seq == want
+    # a smaller distance lets the second of the close pair in; the calls themselves ignore insertions (doc/JULIET.md:26-27)
+    subprocess.check_call([JULIET, "-c", cfg, "--consensus", fa, "--ins-min-distance", "6", bam, str(tmp_path / "o2.json")])
+    seq6 = "".join(open(fa).read().splitlines()[1:])
+    assert len(seq6) == len(seq) + 3 and ins_seq(156, 3) in seq6
+    j1, j2 = json.load(open(tmp_path / "o.json")), json.load(open(tmp_path / "o2.json"))
+    assert j1["genes"] == j2["genes"]
+    rows = synth.rows(synth.SynthParams(seed=seed), l, 0, n, ref)
+    exp = oracle.call(rows, np.array([(1, l + 1)], dtype=capi.GENE), refseq=ref)
+    assert [(r[1], r[2]) for r in flat_variants(j1)] == [(e["codon_pos"], e["codon"]) for e in exp]

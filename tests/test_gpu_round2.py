@@ -324,3 +324,51 @@ def test_batched_exchange_keeps_its_slots_until_all_members_are_collected(oracle
         ctxs[0].lib.jl_comm_destroy(comm)
         for j in ctxs:
             j.close()
+
+
+def test_insertion_counters_match_the_oracle(jl, oracle):
+    """insertions per window column, counted on the device from the records (jl_msa_track_insertions),
+    against the oracle's loops: lengths 1..30 and longer, inserted bases by offset, windows that cut the reads."""
+    from test_gpu_parity import rows_to_records
+    rng = np.random.default_rng(8)
+    n, l = 3000, 240
+    sp = synth.SynthParams(seed=8, partial_rate=0.3)
+    ref = synth.reference(sp.seed, l)
+    rows = synth.rows(sp, l, 0, n, ref)
+    pos, cigar, cig_off, seq4, seq_off, qual, qual_off = rows_to_records(rows, ref, rng)
+    # longer insertions than the noise ops have: splice a 33-base and a 9-base insertion into some reads' cigars
+    cg, so, s4, co = [], [0], [], [0]
+    for r in range(n):
+        ops = [int(x) for x in cigar[int(cig_off[r]): int(cig_off[r + 1])]]
+        bases = []
+        raw = seq4[int(seq_off[r]): int(seq_off[r + 1])]
+        for b in raw:
+            bases += [b >> 4, b & 15]
+        q_total = sum(x >> 4 for x in ops if (x & 15) in (1, 4, 7, 8))
+        bases = bases[:q_total]
+        if r % 5 == 0 and len(ops) > 3:
+            # after the third op: an insertion of 9 (r % 10 == 0) or 33 bases
+            k = 9 if r % 10 == 0 else 33
+            q_before = sum(x >> 4 for x in ops[:3] if (x & 15) in (1, 4, 7, 8))
+            ins = [[1, 2, 4, 8][(r + j) % 4] for j in range(k)]
+            bases = bases[:q_before] + ins + bases[q_before:]
+            ops = ops[:3] + [(k << 4) | 1] + ops[3:]
+        cg += ops
+        co.append(len(cg))
+        if len(bases) % 2:
+            bases.append(0)
+        s4 += [(bases[i] << 4) | bases[i + 1] for i in range(0, len(bases), 2)]
+        so.append(len(s4))
+    cigar, cig_off, seq4, seq_off = (np.array(cg, dtype=np.uint32), np.array(co, dtype=np.uint64), np.array(s4, dtype=np.uint8),
+                                     np.array(so, dtype=np.uint64))
+    for wb, we in ((0, l), (37, 200)):
+        jl.track_insertions(True)
+        jl.ingest_records(we - wb, wb, pos, cigar, cig_off, seq4, seq_off)
+        lh, bc = jl.insertions_fetch()
+        elh, ebc = oracle.insertions(we - wb, wb, pos, cigar, cig_off, seq4, seq_off)
+        assert (lh == elh).all() and (bc == ebc).all()
+        assert lh[:, 9].sum() > 50 and lh[:, 31].sum() > 50 and lh[:, 1:3].sum() > 100
+    jl.track_insertions(False)
+    jl.ingest_records(l, 0, pos, cigar, cig_off, seq4, seq_off)
+    with pytest.raises(capi.JulietError):
+        jl.insertions_fetch()

@@ -229,3 +229,38 @@ def test_appendix_a_fixture_relationships():
     c = a["a4_categories"]
     assert c["reported"] + c["insufficient"] + c["damaged"] == c["total"]   # doc/JULIET.md:378-379
     assert c["marginal_gaps"] + c["marginal_heteroduplexes"] + c["marginal_partial"] > c["damaged"]   # marginals overlap
+
+
+def test_fuse_consensus_rule(oracle):
+    """doc/FUSE.md:17-20 as docs/SPEC.md §11 fixes it: majority base per column, majority-deletion columns removed,
+    an IN-FRAME insertion carried by more than half of the covering reads is included, out-of-frame and minority ones
+    are not, and of two majority insertions closer than the minimal distance only the first is."""
+    l, n = 40, 1000
+    col = np.zeros((l, 6), dtype=np.uint32)
+    ref = (np.arange(l) * 7 + 3) % 4
+    col[np.arange(l), ref] = n
+    col[5] = [100, 0, 0, 0, 900, 0]              # majority deletion: the column disappears
+    col[30] = 0                                   # nobody covers it: N
+    lh = np.zeros((l, 32), dtype=np.uint32)
+    bc = np.zeros((l, 30, 4), dtype=np.uint32)
+
+    def plant(c, length, count, seq):
+        lh[c, min(length, 31)] += count
+        for j, b in enumerate(seq[:30]):
+            bc[c, j, "ACGT".index(b)] += count
+
+    plant(8, 3, 700, "GGT")                       # included
+    plant(12, 6, 400, "ACGTAC")                   # minority: no
+    plant(14, 4, 900, "TTTT")                     # out of frame: no
+    plant(15, 3, 900, "CCC")                      # 7 columns after the insertion at 8: too close at distance 10 ...
+    plant(20, 9, 800, "AAACCCGGG")                # ... 12 columns after: included
+    plant(20, 3, 100, "TTT")                      # a rarer length at the same place does not win, its bases do not either
+    def expect(included):
+        return "".join(included.get(c, "") + ("" if c == 5 else "N" if c == 30 else "ACGT"[ref[c]]) for c in range(l))
+
+    assert oracle.fuse(col, lh, bc, 0.5, 10) == expect({8: "GGT", 20: "AAACCCGGG"})
+    # at distance 7 the insertion at 15 is far enough from the one at 8 — and the one at 20 then too close to it
+    assert oracle.fuse(col, lh, bc, 0.5, 7) == expect({8: "GGT", 15: "CCC"})
+    assert oracle.fuse(col, lh, bc, 0.5, 5) == expect({8: "GGT", 15: "CCC", 20: "AAACCCGGG"})
+    assert oracle.fuse(col, None, None) == "".join("" if c == 5 else "N" if c == 30 else "ACGT"[ref[c]] for c in range(l))
+    assert oracle.fuse(col, lh, bc, 0.95, 1) == oracle.fuse(col, None, None)           # nothing reaches 95 %
