@@ -277,9 +277,12 @@ int jl_msa_ingest_records(jl_ctx *ctx, uint64_t n_reads, uint32_t n_cols, uint32
                           const uint8_t *qual, const uint64_t *qual_off, uint32_t min_qv)
 {
     if (!ctx || !pos || !cigar || !cig_off || !seq4 || !seq_off || (qual && !qual_off)) return JL_ERR_ARG;
+    uint64_t max_ops = 0, max_seq_bytes = 0;
     for (uint64_t r = 0; r < n_reads; ++r) {
         if (cig_off[r + 1] < cig_off[r] || seq_off[r + 1] < seq_off[r] || (qual && qual_off[r + 1] < qual_off[r]))
             return jl_fail(ctx, JL_ERR_ARG, "record %llu: offsets must not decrease", (unsigned long long)r);
+        max_ops = std::max(max_ops, cig_off[r + 1] - cig_off[r]);
+        max_seq_bytes = std::max(max_seq_bytes, seq_off[r + 1] - seq_off[r]);
         uint64_t query = 0;
         for (uint64_t k = cig_off[r]; k < cig_off[r + 1]; ++k) {
             const uint32_t op = cigar[k] & 15u;
@@ -296,7 +299,7 @@ int jl_msa_ingest_records(jl_ctx *ctx, uint64_t n_reads, uint32_t n_cols, uint32
     const size_t n_cig = (size_t)cig_off[n_reads], n_seq = (size_t)seq_off[n_reads], n_q = qual ? (size_t)qual_off[n_reads] : 0;
     const size_t off_bytes = (size_t)(n_reads + 1) * 8;
     uint8_t *d_seq = nullptr, *d_qual = nullptr;
-    uint32_t *d_cig = nullptr;
+    uint32_t *d_cig = nullptr, *d_rows4 = nullptr;
     uint64_t *d_co = nullptr, *d_so = nullptr, *d_qo = nullptr;
     int32_t *d_pos = nullptr;
     hipStream_t st = ctx->stream;
@@ -308,6 +311,7 @@ int jl_msa_ingest_records(jl_ctx *ctx, uint64_t n_reads, uint32_t n_cols, uint32
     if (e == hipSuccess) e = hipMalloc(&d_pos, (size_t)(n_reads ? n_reads : 1) * 4);
     if (e == hipSuccess && qual) e = hipMalloc(&d_qual, n_q ? n_q : 1);
     if (e == hipSuccess && qual) e = hipMalloc(&d_qo, off_bytes);
+    if (e == hipSuccess) e = hipMalloc(&d_rows4, (size_t)jl_ingest_batch_reads(ctx) * jl_ingest_row_dwords(ctx) * 4);
     if (e == hipSuccess) e = hipMemsetAsync(d_seq + n_seq, 0, 16, st);
     if (e == hipSuccess && n_seq) e = hipMemcpyAsync(d_seq, seq4, n_seq, hipMemcpyHostToDevice, st);
     if (e == hipSuccess && n_cig) e = hipMemcpyAsync(d_cig, cigar, n_cig * 4, hipMemcpyHostToDevice, st);
@@ -336,11 +340,11 @@ int jl_msa_ingest_records(jl_ctx *ctx, uint64_t n_reads, uint32_t n_cols, uint32
         }
     }
     if (e == hipSuccess) {
-        jl_launch_ingest(ctx, d_pos, d_cig, d_co, d_seq, d_so, d_qual, d_qo, min_qv);
+        jl_launch_ingest(ctx, d_pos, d_cig, d_co, d_seq, d_so, d_qual, d_qo, min_qv, d_rows4, max_ops, max_seq_bytes);
         e = hipGetLastError();
         if (e == hipSuccess) e = hipStreamSynchronize(st);
     }
-    void *tmp[] = {d_seq, d_cig, d_co, d_so, d_pos, d_qual, d_qo};
+    void *tmp[] = {d_seq, d_cig, d_co, d_so, d_pos, d_qual, d_qo, d_rows4};
     for (void *p : tmp)
         if (p) hipFree(p);
     if (e != hipSuccess) return jl_fail(ctx, e == hipErrorOutOfMemory ? JL_ERR_MEMORY : JL_ERR_DEVICE, "ingest: %s", hipGetErrorString(e));

@@ -389,7 +389,9 @@ extern "C" int jl_run_wait_seq(jl_ctx *ctx, uint32_t want);
 void jl_launch_consensus(jl_ctx *ctx, uint8_t *d_out);
 void jl_launch_ingest(jl_ctx *ctx, const int32_t *d_pos, const uint32_t *d_cigar, const uint64_t *d_cig_off,
                       const uint8_t *d_seq4, const uint64_t *d_seq_off, const uint8_t *d_qual,
-                      const uint64_t *d_qual_off, uint32_t min_qv);
+                      const uint64_t *d_qual_off, uint32_t min_qv, uint32_t *d_rows4, uint64_t max_ops, uint64_t max_seq_bytes);
+uint32_t jl_ingest_row_dwords(const jl_ctx *ctx);
+uint64_t jl_ingest_batch_reads(const jl_ctx *ctx);
 void jl_launch_insertions(jl_ctx *ctx, const int32_t *d_pos, const uint32_t *d_cigar, const uint64_t *d_cig_off,
                           const uint8_t *d_seq4, const uint64_t *d_seq_off);
 void jl_launch_fisher_eval(jl_ctx *ctx, uint32_t n, const uint32_t *a, const uint32_t *c, const uint32_t *cov, int tail,

@@ -57,142 +57,222 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(const uint8_t *__restric
 
 
 // ---------------------------------------------------------------------------------------- record ingest
-// Aligned records -> column-packed nibbles in ONE pass: doc/JULIET.md:26-27 (insertions dropped, deletions '-'),
-// :53 (PacBio cigars = X I D S H N; M rejected on the host), :256-259 (filtered base = N).
-// One LANE per read: the lane walks its own cigar while the wave walks the columns of a segment of the window, so at
-// every column the wave holds the 64 symbols of 64 consecutive reads — the 32 bytes that are contiguous in the
-// column-packed matrix.  Four columns are gathered per lane into one dword, eight such dwords are transposed through a
-// 2 KiB LDS tile per wave, and every lane then stores the packed nibbles of 8 reads for 4 columns.  The next cigar word
-// and the next eight bases of every lane are loaded ahead of their use.  (Loading a tile's worth of cigar words and
-// bases per lane up front was measured and is slower: the kernel is bound by the instructions of the per-lane cursor
-// under divergence — some lane of 64 changes its op at nearly every column — not by load latency.)  Reads past n_reads (the padding of a column up
-// to its 128-byte stride) and columns outside a read's span are 'not covered'.
-constexpr uint32_t kIngestSegAlign = 32;   // columns per transposed tile
+// Aligned records -> column-packed nibbles: doc/JULIET.md:26-27 (insertions dropped, deletions '-'), :53 (PacBio cigars
+// = X I D S H N; M rejected on the host), :256-259 (filtered base = N).  Two streaming kernels:
+//   expand_rows_kernel   ONE WAVE per read.  The wave scans the read's cigar once into LDS (prefix sums of reference and
+//                        query lengths), then every lane produces 8 consecutive columns = one dword of the read's row
+//                        in a by-row nibble matrix: a binary search finds the op that covers its first column; when
+//                        all 8 columns lie inside one op (runs of '=' are tens of columns long) they are taken at
+//                        once — eight packed BAM bases fetched as two dwords, converted nibble-parallel — otherwise
+//                        column by column.  No divergence over reads: a wave only ever looks at one cigar.
+//   transpose_rows_kernel  by-row nibbles -> the column-packed matrix through a 128-read x 256-column LDS tile: 128-byte
+//                        reads, 64-byte writes.
+// (The first build walked one read per LANE while the wave swept the columns: some lane of 64 changed its op at
+// nearly every column and the kernel was bound by the cursor's instructions under divergence, 0.29 TB/s.)
+// Reads past n_reads (the padding of a column up to its 128-byte stride) and columns outside a read's span are 'not covered'.
+constexpr uint32_t kExpandOps = 256;    // cigar ops of a read held in LDS at a time; longer cigars go through in pieces
+constexpr uint32_t kExpandSeqDw = 1024; // dwords of a read's packed bases staged in LDS (8192 bases); longer reads load from HBM
 
 __device__ __forceinline__ bool cig_ref(uint32_t op) { return op == 2u || op == 3u || op == 7u || op == 8u; }    // D N = X
 __device__ __forceinline__ bool cig_query(uint32_t op) { return op == 1u || op == 4u || op == 7u || op == 8u; }  // I S = X
 
-__global__ __launch_bounds__(256) void ingest_cols_kernel(uint64_t n_reads, uint32_t n_cols, uint32_t win_begin, uint32_t seg_cols,
-                                                           const int32_t *__restrict__ pos,
+// eight BAM base codes (nt16: A=1 C=2 G=4 T=8, everything else ambiguous) -> symbol codes 0..3 / 5, nibble-parallel
+__device__ __forceinline__ uint32_t nt16_to_sym8(uint32_t w)
+{
+    const uint32_t m = 0x11111111u;
+    const uint32_t b0 = w & m, b1 = (w >> 1) & m, b2 = (w >> 2) & m, b3 = (w >> 3) & m;
+    const uint32_t cnt = b0 + b1 + b2 + b3;          // set bits per nibble, 0..4
+    const uint32_t idx = b1 + 2u * b2 + 3u * b3;     // one-hot -> 0..3
+    const uint32_t t = cnt ^ m;                      // non-zero where the nibble is not one-hot
+    const uint32_t bad = (t | (t >> 1) | (t >> 2)) & m;
+    return (idx & ~(bad * 15u)) | (bad * 5u);
+}
+
+__global__ __launch_bounds__(256) void expand_rows_kernel(uint64_t r0, uint64_t n_batch, uint64_t n_reads, uint32_t n_cols,
+                                                           uint32_t win_begin, const int32_t *__restrict__ pos,
                                                            const uint32_t *__restrict__ cigar,
                                                            const uint64_t *__restrict__ cig_off,
                                                            const uint8_t *__restrict__ seq4,
                                                            const uint64_t *__restrict__ seq_off,
                                                            const uint8_t *__restrict__ qual,
                                                            const uint64_t *__restrict__ qual_off, uint32_t min_qv,
-                                                           uint8_t *__restrict__ msa, uint64_t col_stride)
+                                                           uint32_t *__restrict__ rows4, uint32_t row_dwords,
+                                                           uint32_t ops_cap, uint32_t seq_cap)
 {
-    __shared__ uint32_t s_t[4][8][64];   // per wave: 8 groups of 4 columns x 64 reads
+    // LDS per wave, sized by the launch for the longest cigar (up to kExpandOps) and read (up to kExpandSeqDw dwords) of
+    // the input: short reads leave room for every wave slot of the CU
+    extern __shared__ uint32_t s_dyn[];
     const uint32_t wid = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    const uint64_t wave_r0 = ((uint64_t)blockIdx.x * 4u + wid) * 64u;
-    if (wave_r0 * 4u >= col_stride * 8u) return;   // col_stride * 2 reads per column (wave-uniform)
-    const uint64_t r = wave_r0 + lane;
-    const bool have = r < n_reads;
-    const uint32_t cs = blockIdx.y * seg_cols, ce = min(n_cols, cs + seg_cols);
-
-    uint64_t ci = 0, cend = 0;
-    const uint32_t *sqw = nullptr;
-    uint32_t q_adj = 0, sq_last = 0, ql_last = 0;
-    const uint8_t *ql = nullptr;
-    int64_t rel = 0;   // reference offset, relative to the read's first base, of column cs
-    if (have) {
-        ci = cig_off[r];
-        cend = cig_off[r + 1];
-        const uint64_t so = seq_off[r];
-        sqw = reinterpret_cast<const uint32_t *>(seq4 + (so & ~(uint64_t)3));
-        q_adj = (uint32_t)(so & 3u) * 2u;
-        sq_last = (uint32_t)((seq_off[r + 1] - (so & ~(uint64_t)3) + 3u) >> 2);   // the arrays are padded by 16 bytes
-        if (qual && min_qv) {
-            ql = qual + qual_off[r];
-            const uint64_t nq = qual_off[r + 1] - qual_off[r];
-            ql_last = nq ? (uint32_t)(nq - 1) : 0u;
-            if (!nq) ql = nullptr;
-        }
-        rel = (int64_t)win_begin + cs - (int64_t)pos[r];
+    uint32_t *s_base = s_dyn + (size_t)wid * (2u * ops_cap + seq_cap + 2u);
+    // RUNS of the cigar: '=' and 'X' alternate in a PacBio cigar while reference and query advance together, so a
+    // stretch of them is ONE run of aligned bases; D and N are runs of their own; I / S / H / P only end a run.  A CCS
+    // read is a handful of runs of hundreds of columns, where its cigar has an op every few dozen.
+    uint32_t *s_rbeg = s_base;                    // [ops_cap] reference offset (relative to the read's first base) of run i
+    uint32_t *s_rq = s_base + ops_cap;            // [ops_cap] its first query offset (28 bits) | kind << 28 (1 bases, 2 '-', 3 skip)
+    uint32_t *s_seq = s_base + 2u * ops_cap;      // [seq_cap + 2] the read's packed bases from the aligned dword that holds its first one
+    const uint64_t b = (uint64_t)blockIdx.x * 4u + wid;   // read of this wave, within the batch
+    if (b >= n_batch) return;
+    const uint64_t r = r0 + b;
+    uint32_t *row = rows4 + b * (uint64_t)row_dwords;
+    if (r >= n_reads) {   // padding read: not covered anywhere
+        for (uint32_t d = lane; d < row_dwords; d += 64u) row[d] = 0x66666666u;
+        return;
     }
-    // cursor: the op covering reference offsets [r_beg, r_end), which starts at query offset q_beg
-    int64_t r_beg = 0, r_end = 0;
-    uint32_t q_beg = 0, q_next = 0, op = 15u;
-    bool done = !have;
-    // ---- skip to the segment: four cigar words per step
-    if (have && rel > 0) {
-        while (ci < cend && r_end <= rel) {
-            uint32_t cw[4];
+    const uint64_t c_beg = cig_off[r], c_end = cig_off[r + 1];
+    const uint64_t so = seq_off[r];
+    const uint64_t n_bases = (seq_off[r + 1] - so) * 2u;
+    const uint8_t *ql = (qual && min_qv) ? qual + qual_off[r] : nullptr;
+    const uint64_t n_qual = ql ? qual_off[r + 1] - qual_off[r] : 0u;
+    const int64_t rel0 = (int64_t)win_begin - (int64_t)pos[r];   // reference offset (relative to the read) of window column 0
+    const bool single = c_end - c_beg <= ops_cap;
+    // the first piece of the cigar: all loads issued before anything waits for one
+    uint32_t cw_first[kExpandOps / 64u];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) cw[k] = cigar[min(ci + k, cend - 1)];
+    for (uint32_t i = 0; i < kExpandOps / 64u; ++i) {
+        const uint64_t k = c_beg + i * 64u + lane;
+        cw_first[i] = (i * 64u < ops_cap && k < c_end) ? cigar[k] : 0u;
+    }
+    // ---- the read's bases into LDS: every later fetch is an LDS access, not a dependent trip to HBM
+    const uint64_t so_al = so & ~(uint64_t)3;                      // aligned start
+    const uint32_t seq_dw = (uint32_t)((seq_off[r + 1] - so_al + 3u) / 4u) + 1u;   // the arrays are padded by 16 bytes
+    const bool seq_lds = seq_dw <= seq_cap + 2u;
+    const uint32_t *seq_g = reinterpret_cast<const uint32_t *>(seq4 + so_al);
+    if (seq_lds)
+        for (uint32_t i = lane; i < seq_dw; i += 64u) s_seq[i] = seq_g[i];
+    const uint32_t lb0 = (uint32_t)(so - so_al);                   // byte of the first base within the staged dwords
+    if (!single)
+        for (uint32_t d = lane; d < row_dwords; d += 64u) row[d] = 0x66666666u;
+    uint32_t ref_carry = 0, q_carry = 0;
+    for (uint64_t base = c_beg; base < c_end || base == c_beg; base += ops_cap) {
+        const uint32_t m = (uint32_t)min<uint64_t>(ops_cap, c_end - base);
+        const uint32_t ref_first = ref_carry;
+        // ---- prefix sums of this piece of the cigar, and its runs
+        uint32_t n_runs = 0, prev_kind = 0;   // kind of the op before this chunk's first (a piece starts a new run)
+        for (uint32_t k0 = 0; k0 < m; k0 += 64u) {
+            const uint32_t k = k0 + lane;
+            uint32_t cw = 0u;
+            if (base == c_beg) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                if (ci < cend && r_end <= rel) {
-                    const uint32_t o = cw[k] & 15u, len = cw[k] >> 4;
-                    op = o; r_beg = r_end; q_beg = q_next;
-                    if (cig_ref(o)) r_end += len;
-                    if (cig_query(o)) q_next += len;
-                    ++ci;
-                }
+                for (uint32_t i = 0; i < kExpandOps / 64u; ++i)
+                    if (k0 == i * 64u) cw = cw_first[i];
+            } else if (k < m) cw = cigar[base + k];
+            const uint32_t op = cw & 15u, len = cw >> 4;
+            const bool live = k < m;
+            const uint32_t rl = (live && cig_ref(op)) ? len : 0u, qlx = (live && cig_query(op)) ? len : 0u;
+            uint32_t ri = rl, qi = qlx;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t ur = __shfl_up(ri, o, 64), uq = __shfl_up(qi, o, 64);
+                if ((int)lane >= o) { ri += ur; qi += uq; }
             }
+            const uint32_t kind = !live ? 0u : (op == 7u || op == 8u) ? 1u : op == 2u ? 2u : op == 3u ? 3u : 0u;
+            uint32_t before = __shfl_up(kind, 1, 64);
+            if (lane == 0) before = prev_kind;
+            const bool starts = kind != 0u && len != 0u && !(kind == 1u && before == 1u);
+            const uint64_t bal = __ballot(starts);
+            if (starts) {
+                const uint32_t idx = n_runs + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+                s_rbeg[idx] = ref_carry + ri - rl;
+                s_rq[idx] = ((q_carry + qi - qlx) & 0x0FFFFFFFu) | (kind << 28);
+            }
+            n_runs += (uint32_t)__popcll(bal);
+            prev_kind = __shfl(kind, 63, 64);
+            ref_carry += __shfl(ri, 63, 64);
+            q_carry += __shfl(qi, 63, 64);
         }
-    }
-    uint32_t cw_next = (have && ci < cend) ? cigar[ci] : 0u;
-    uint32_t seq_idx = 0xFFFFFFFEu, seq_w = 0, seq_wn = 0;   // dword seq_idx of the read's bases, and the one after it
-
-    for (uint32_t c0 = cs; c0 < ce; c0 += kIngestSegAlign) {
-#pragma unroll 1
-        for (uint32_t g = 0; g < 8u; ++g) {
-            uint32_t pk = 0;
-#pragma unroll
-            for (uint32_t j = 0; j < 4u; ++j) {
-                const int64_t x = rel + (int64_t)(c0 - cs + 4u * g + j);
-                uint32_t sym = JL_SYM_NONE;
-                if (!done && x >= 0) {
-                    while (x >= r_end) {   // next op (those that consume no reference leave r_end where it is)
-                        if (ci >= cend) { done = true; break; }
-                        const uint32_t o = cw_next & 15u, len = cw_next >> 4;
-                        ++ci;
-                        if (ci < cend) cw_next = cigar[ci];
-                        op = o; r_beg = r_end; q_beg = q_next;
-                        if (cig_ref(o)) r_end += len;
-                        if (cig_query(o)) q_next += len;
-                    }
-                    if (!done) {
-                        if (op == 2u) sym = JL_SYM_GAP;
-                        else if (op == 3u) sym = JL_SYM_NONE;
-                        else {
-                            const uint32_t q = q_beg + (uint32_t)(x - r_beg);
-                            const uint32_t qa = q + q_adj, idx = qa >> 3;
-                            if (idx != seq_idx) {
-                                if (idx == seq_idx + 1u) seq_w = seq_wn;
-                                else seq_w = sqw[min(idx, sq_last)];
-                                seq_wn = sqw[min(idx + 1u, sq_last)];
-                                seq_idx = idx;
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t ref_last = ref_carry;   // this piece covers reference offsets [ref_first, ref_last)
+        // eight bases starting at query offset q, as nt16 codes in nibble order
+        auto fetch8 = [&](uint64_t q) -> uint32_t {
+            const uint32_t lb = lb0 + (uint32_t)(q >> 1);          // byte within the staged dwords
+            const uint32_t dw = lb >> 2;
+            uint64_t v;
+            if (seq_lds) v = (uint64_t)s_seq[dw] | ((uint64_t)s_seq[dw + 1u] << 32);
+            else v = (uint64_t)seq_g[dw] | ((uint64_t)seq_g[dw + 1u] << 32);
+            v >>= 8u * (lb & 3u);
+            v = ((v & 0x0F0F0F0F0F0F0F0Full) << 4) | ((v >> 4) & 0x0F0F0F0F0F0F0F0Full);   // base order = nibble order
+            v >>= 4u * (uint32_t)(q & 1u);
+            return (uint32_t)v;
+        };
+        // ---- the row, one dword (8 columns) per lane and step
+        for (uint32_t d = lane; d < row_dwords; d += 64u) {
+            const int64_t x0 = rel0 + (int64_t)d * 8;
+            // columns of this dword the piece can say something about
+            if (!single && (x0 + 8 <= (int64_t)ref_first || x0 >= (int64_t)ref_last)) continue;
+            uint32_t out = single ? 0x66666666u : row[d];
+            if (x0 + 8 > (int64_t)ref_first && x0 < (int64_t)ref_last && n_runs) {
+                const uint32_t xs = x0 > (int64_t)ref_first ? (uint32_t)x0 : ref_first;   // first offset to look up
+                // last run that starts at or before xs
+                uint32_t lo = 0, hi = n_runs;
+                while (lo < hi) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (s_rbeg[mid] <= xs) lo = mid + 1;
+                    else hi = mid;
+                }
+                uint32_t i = lo ? lo - 1u : 0u;
+                const uint32_t ncol = (uint64_t)d * 8u + 8u <= n_cols ? 8u : n_cols - d * 8u;
+                uint32_t j = (uint32_t)((int64_t)xs - x0);   // first column of the dword this piece covers
+                if (s_rbeg[i] > xs) j = ncol;                // (only a piece that begins with ops without reference)
+                while (j < ncol && i < n_runs) {
+                    const uint32_t x = (uint32_t)(x0 + (int64_t)j);
+                    const uint32_t rend = i + 1u < n_runs ? s_rbeg[i + 1u] : ref_last;
+                    if (x >= rend) { ++i; continue; }
+                    const uint32_t rq = s_rq[i], kind = rq >> 28;
+                    const uint32_t cnt = min(ncol - j, rend - x);            // columns of this run inside the dword
+                    const uint32_t keep = cnt >= 8u ? 0xFFFFFFFFu : ((1u << (4u * cnt)) - 1u);
+                    uint32_t sym;
+                    if (kind == 2u) sym = 0x44444444u;
+                    else if (kind == 3u) sym = 0x66666666u;
+                    else {
+                        const uint64_t q = (uint64_t)(rq & 0x0FFFFFFFu) + (x - s_rbeg[i]);
+                        sym = nt16_to_sym8(fetch8(q));
+                        if (q + cnt > n_bases)   // malformed input: never past the read's own bases
+                            for (uint32_t t = 0; t < cnt; ++t)
+                                if (q + t >= n_bases) sym = (sym & ~(15u << (4u * t))) | (5u << (4u * t));
+                        if (ql)
+                            for (uint32_t t = 0; t < cnt; ++t) {
+                                const uint8_t qv = ql[min(q + t, n_qual ? n_qual - 1u : 0u)];
+                                if (qv != 0xFFu && qv < min_qv) sym = (sym & ~(15u << (4u * t))) | ((uint32_t)JL_SYM_MASK << (4u * t));
                             }
-                            // BAM: two bases per byte, the first in the high nibble
-                            const uint32_t b16 = (seq_w >> (8u * ((qa >> 1) & 3u) + ((qa & 1u) ? 0u : 4u))) & 15u;
-                            // A=1 C=2 G=4 T=8 -> 0..3; anything else is an ambiguous base (N)
-                            sym = (uint32_t)((0x5555555355525105ull >> (4u * b16)) & 15ull);
-                            // a cigar that runs past the read's bases (malformed input) stays inside the read's arrays
-                            if (ql) { const uint8_t qv = ql[min(q, ql_last)]; if (qv != 0xFFu && qv < min_qv) sym = JL_SYM_MASK; }
-                        }
                     }
+                    const uint32_t mask = keep << (4u * j);
+                    out = (out & ~mask) | ((sym << (4u * j)) & mask);
+                    j += cnt;
                 }
-                pk |= sym << (8u * j);
             }
-            s_t[wid][g][lane] = pk;
+            row[d] = out;
         }
         __builtin_amdgcn_wave_barrier();
-        // transposed: lane = (group of 4 columns, group of 8 reads)
-        const uint32_t tg = lane >> 3, tk = lane & 7u;
-        uint32_t w[8];
+        if (c_end == c_beg) break;
+    }
+}
+
+// by-row nibbles of a batch of reads -> the column-packed matrix.  Tile = 128 reads x 256 columns through LDS.
+__global__ __launch_bounds__(256) void transpose_rows_kernel(const uint32_t *__restrict__ rows4, uint32_t row_dwords,
+                                                              uint64_t r0, uint64_t n_batch, uint32_t n_cols,
+                                                              uint8_t *__restrict__ msa, uint64_t col_stride)
+{
+    __shared__ uint32_t s_t[128][33];
+    const uint32_t tid = threadIdx.x;
+    const uint64_t rb = (uint64_t)blockIdx.x * 128u;          // first read of the tile, within the batch
+    const uint32_t d0 = blockIdx.y * 32u;                     // first dword of the tile's columns
+    for (uint32_t i = tid; i < 128u * 32u; i += 256u) {
+        const uint32_t rr = i >> 5, dd = i & 31u;
+        uint32_t v = 0x66666666u;
+        if (rb + rr < n_batch && d0 + dd < row_dwords) v = rows4[(rb + rr) * (uint64_t)row_dwords + d0 + dd];
+        s_t[rr][dd] = v;
+    }
+    __syncthreads();
+    for (uint32_t o = tid; o < 256u * 16u; o += 256u) {
+        const uint32_t col = o >> 4, g = o & 15u;             // column of the tile, group of 8 reads
+        const uint32_t c = d0 * 8u + col;
+        if (c >= n_cols) continue;
+        const uint32_t sh = 4u * (col & 7u), dd = col >> 3;
+        uint32_t w = 0;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) w[j] = s_t[wid][tg][8u * tk + j];
-#pragma unroll
-        for (uint32_t cc = 0; cc < 4u; ++cc) {
-            const uint32_t c = c0 + 4u * tg + cc;
-            uint32_t o = 0;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) o |= ((w[j] >> (8u * cc)) & 15u) << (4 * j);
-            if (c < ce) *reinterpret_cast<uint32_t *>(msa + (uint64_t)c * col_stride + wave_r0 / 2u + 4u * tk) = o;
-        }
-        __builtin_amdgcn_wave_barrier();
+        for (uint32_t j = 0; j < 8u; ++j) w |= ((s_t[g * 8u + j][dd] >> sh) & 15u) << (4u * j);
+        const uint64_t byte = (r0 + rb + (uint64_t)g * 8u) / 2u;
+        if (byte < col_stride) *reinterpret_cast<uint32_t *>(msa + (uint64_t)c * col_stride + byte) = w;
     }
 }
 
@@ -347,21 +427,32 @@ void jl_launch_validate(jl_ctx *ctx, uint32_t *d_flag)
     hipLaunchKernelGGL(validate_kernel, dim3(blocks), dim3(256), 0, ctx->stream, ctx->d_msa, n_bytes, d_flag);
 }
 
+// rows4: scratch of jl_ingest_batch_reads(ctx) x jl_ingest_row_dwords(ctx) dwords
+uint32_t jl_ingest_row_dwords(const jl_ctx *ctx) { return (ctx->n_cols + 7u) / 8u; }
+uint64_t jl_ingest_batch_reads(const jl_ctx *ctx)
+{
+    const uint64_t pad = ctx->col_stride * 2u;   // reads incl. the padding of a column: a multiple of 256
+    return pad < (1ull << 20) ? pad : (1ull << 20);
+}
+
+// max_ops / max_seq_bytes: the longest cigar and the most packed-base bytes of any read (they size the waves' LDS)
 void jl_launch_ingest(jl_ctx *ctx, const int32_t *d_pos, const uint32_t *d_cigar, const uint64_t *d_cig_off,
                       const uint8_t *d_seq4, const uint64_t *d_seq_off, const uint8_t *d_qual,
-                      const uint64_t *d_qual_off, uint32_t min_qv)
+                      const uint64_t *d_qual_off, uint32_t min_qv, uint32_t *d_rows4, uint64_t max_ops, uint64_t max_seq_bytes)
 {
-    // waves = 64-read groups x column segments; enough segments for some thousands of waves
-    const uint64_t waves_x = (ctx->col_stride * 2u + 63u) / 64u;
-    const uint32_t max_seg = (ctx->n_cols + kIngestSegAlign - 1u) / kIngestSegAlign;
-    uint32_t nseg = (uint32_t)std::min<uint64_t>(max_seg, std::max<uint64_t>(1, (8192u + waves_x - 1u) / waves_x));
-    uint32_t seg_cols = (ctx->n_cols + nseg - 1u) / nseg;
-    seg_cols = (seg_cols + kIngestSegAlign - 1u) / kIngestSegAlign * kIngestSegAlign;
-    nseg = (ctx->n_cols + seg_cols - 1u) / seg_cols;
-    dim3 grid((uint32_t)((waves_x + 3u) / 4u), nseg);
-    hipLaunchKernelGGL(ingest_cols_kernel, grid, dim3(256), 0, ctx->stream, ctx->n_reads, ctx->n_cols, ctx->win_begin,
-                       seg_cols, d_pos, d_cigar, d_cig_off, d_seq4, d_seq_off, d_qual, d_qual_off, min_qv, ctx->d_msa,
-                       ctx->col_stride);
+    const uint64_t pad = ctx->col_stride * 2u, batch = jl_ingest_batch_reads(ctx);
+    const uint32_t row_dwords = jl_ingest_row_dwords(ctx);
+    const uint32_t ops_cap = (uint32_t)std::min<uint64_t>(kExpandOps, std::max<uint64_t>(64, (max_ops + 63u) / 64u * 64u));
+    const uint32_t seq_cap = (uint32_t)std::min<uint64_t>(kExpandSeqDw, (max_seq_bytes + 3u) / 4u + 2u);
+    const uint32_t lds = 4u * (2u * ops_cap + seq_cap + 2u) * 4u;
+    for (uint64_t r0 = 0; r0 < pad; r0 += batch) {
+        const uint64_t nb = pad - r0 < batch ? pad - r0 : batch;
+        hipLaunchKernelGGL(expand_rows_kernel, dim3((uint32_t)((nb + 3u) / 4u)), dim3(256), lds, ctx->stream, r0, nb, ctx->n_reads,
+                           ctx->n_cols, ctx->win_begin, d_pos, d_cigar, d_cig_off, d_seq4, d_seq_off, d_qual, d_qual_off, min_qv,
+                           d_rows4, row_dwords, ops_cap, seq_cap);
+        hipLaunchKernelGGL(transpose_rows_kernel, dim3((uint32_t)((nb + 127u) / 128u), (row_dwords + 31u) / 32u), dim3(256), 0,
+                           ctx->stream, (const uint32_t *)d_rows4, row_dwords, r0, nb, ctx->n_cols, ctx->d_msa, ctx->col_stride);
+    }
 }
 
 void jl_launch_insertions(jl_ctx *ctx, const int32_t *d_pos, const uint32_t *d_cigar, const uint64_t *d_cig_off,
