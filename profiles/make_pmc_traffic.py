@@ -1,8 +1,8 @@
 """Condense the two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) into profiles/<tag>_pmc_*.csv and pmc_traffic.json.
 
 usage: python profiles/make_pmc_traffic.py <tag> <dir of the FETCH_SIZE pass> <dir of the WRITE_SIZE pass>
-The passes: JL_NO_GRAPH=1 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d <dir> -- python3 bench.py
-            --steps 8 --warmup 8 --no-cpu-baseline --inflight 1     (and the same with --pmc WRITE_SIZE)
+The passes: rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d <dir> -- python3 profiles/isolated_pileup.py 25
+            (and the same with --pmc WRITE_SIZE): the dominant kernel alone, every dispatch attributed
 Correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE counts 64-byte units of the wide stream twice too low on
 gfx950 -> x2; WRITE_SIZE as read; both in KB."""
 import csv
@@ -31,7 +31,7 @@ def condense(rs, counter):
         w = csv.writer(f)
         w.writerow(keep)
         for r in rs:
-            name = "pileup_group_kernel<3,true,4>" if "<3, true, 4>" in r["Kernel_Name"] else r["Kernel_Name"][:60]
+            name = "pileup_group_kernel<3,true,4>" if "<3, true, 4" in r["Kernel_Name"] else r["Kernel_Name"][:60]
             w.writerow([r["Dispatch_Id"], name] + [r[k] for k in keep[2:]])
     # full launches only (the set-up pass also launches partial groups)
     full = max(int(r["Grid_Size"]) for r in rs)
@@ -54,7 +54,7 @@ new = {
     "pileup_kernel_hbm_bytes_per_launch": hbm,
     "algorithmic_bytes_per_launch": alg,
     "ratio": hbm / alg,
-    "source": f"profiles/{tag}_pmc_FETCH_SIZE.csv, profiles/{tag}_pmc_WRITE_SIZE.csv (separate --pmc passes with --kernel-trace only, JL_NO_GRAPH=1, --inflight 1; profiles/make_pmc_traffic.py)",
+    "source": f"profiles/{tag}_pmc_FETCH_SIZE.csv, profiles/{tag}_pmc_WRITE_SIZE.csv (separate --pmc passes with --kernel-trace only over profiles/isolated_pileup.py; profiles/make_pmc_traffic.py)",
     "four_window_launch": old.get("four_window_launch"),
     "single_window_kernel": old.get("single_window_kernel"),
 }
