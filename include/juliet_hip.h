@@ -143,6 +143,20 @@ int jl_msa_ingest_records(jl_ctx *ctx, uint64_t n_reads, uint32_t n_cols, uint32
                           const uint32_t *cigar, const uint64_t *cig_off, const uint8_t *seq4, const uint64_t *seq_off,
                           const uint8_t *qual, const uint64_t *qual_off, uint32_t min_qv);
 /*
+ * The same in pieces, so a decoder can hand over each batch of records while it inflates the next one (the upload
+ * then hides under the decode; the kernels run in jl_records_finish, once the window is known).  The hints size the
+ * device arrays up front (they grow when exceeded; qual_bytes_hint 0 = no qualities expected).  A chunk's offsets
+ * index ITS arrays (read r of the chunk owns cigar[cig_off[r] .. cig_off[r+1]) etc., cig_off[0] need not be 0); the
+ * host arrays may be reused as soon as jl_records_append returns.  Either every chunk carries qualities or none.
+ * Validation and errors are those of jl_msa_ingest_records, which is begin + one append + finish.  One thread at
+ * a time per context.
+ */
+int jl_records_begin(jl_ctx *ctx, uint64_t reads_hint, uint64_t cigar_words_hint, uint64_t seq_bytes_hint,
+                     uint64_t qual_bytes_hint);
+int jl_records_append(jl_ctx *ctx, uint64_t n_reads, const int32_t *pos, const uint32_t *cigar, const uint64_t *cig_off,
+                      const uint8_t *seq4, const uint64_t *seq_off, const uint8_t *qual, const uint64_t *qual_off);
+int jl_records_finish(jl_ctx *ctx, uint32_t n_cols, uint32_t win_begin, uint32_t min_qv);
+/*
  * Insertions are not part of the matrix (J:26-27) but `fuse` "includes in-frame insertions with a certain distance to
  * each other" (doc/FUSE.md:19): with tracking on, jl_msa_ingest_records also counts them per window column — an
  * insertion sits BEFORE the column of the next reference base.  len_hist[n_cols][32]: insertions by length (31 = longer

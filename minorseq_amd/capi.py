@@ -29,7 +29,7 @@ SUMMARY = np.dtype([(n, "<u4") for n in SUMMARY_FIELDS])
 # every symbol include/juliet_hip.h declares (checked by tests/test_capi_exports.py)
 EXPORTS = ("jl_abi_version", "jl_strerror", "jl_device_count", "jl_ctx_create", "jl_ctx_destroy", "jl_last_error",
            "jl_sync", "jl_col_stride", "jl_msa_upload", "jl_msa_alloc", "jl_msa_adopt", "jl_msa_pack_rows",
-           "jl_msa_ingest_records", "jl_msa_track_insertions", "jl_insertions_fetch", "jl_msa_download", "jl_synth_fill", "jl_synth_fill_window", "jl_pileup_async", "jl_n_positions", "jl_pileup_fetch",
+           "jl_msa_ingest_records", "jl_records_begin", "jl_records_append", "jl_records_finish", "jl_msa_track_insertions", "jl_insertions_fetch", "jl_msa_download", "jl_synth_fill", "jl_synth_fill_window", "jl_pileup_async", "jl_n_positions", "jl_pileup_fetch",
            "jl_consensus_fetch", "jl_call_async", "jl_call_fetch", "jl_variant_table_device", "jl_phase_async", "jl_phase_fetch",
            "jl_run_async", "jl_run_wait", "jl_run_done", "jl_run_view_get", "jl_group_create", "jl_group_destroy",
            "jl_group_last_error", "jl_group_run_async", "jl_group_run_masked_async", "jl_group_time_pileup", "jl_fisher_eval", "jl_fisher_eval_tail", "jl_expand_read_hap", "jl_time_pileup", "jl_time_pileup_set", "jl_pileup_kernel_name", "jl_comm_unique_id", "jl_comm_create", "jl_comm_destroy",
@@ -141,6 +141,9 @@ def load_library(path=LIB_PATH):
     lib.jl_msa_adopt.argtypes = [vp, vp, u64, u32, u64, u32]
     lib.jl_msa_pack_rows.argtypes = [vp, vp, u64, u32, u32]
     lib.jl_msa_ingest_records.argtypes = [vp, u64, u32, u32] + [vp] * 7 + [u32]
+    lib.jl_records_begin.argtypes = [vp, u64, u64, u64, u64]
+    lib.jl_records_append.argtypes = [vp, u64] + [vp] * 7
+    lib.jl_records_finish.argtypes = [vp, u32, u32, u32]
     lib.jl_msa_track_insertions.argtypes = [vp, C.c_int]
     lib.jl_insertions_fetch.argtypes = [vp, vp, vp]
     lib.jl_msa_download.argtypes = [vp, vp, u64]
@@ -284,6 +287,30 @@ class Juliet:
         n = len(pos)
         self._chk(self.lib.jl_msa_ingest_records(self.h, n, n_cols, win_begin, _p(pos), _p(cigar), _p(cig_off), _p(seq4),
                                                  _p(seq_off), _p(qual), _p(qual_off), min_qv))
+        self._shape(n, n_cols, self.lib.jl_col_stride(n))
+
+    def ingest_records_chunked(self, n_cols, win_begin, pos, cigar, cig_off, seq4, seq_off, qual=None, qual_off=None,
+                               min_qv=0, chunk_reads=1000, hints=(0, 0, 0, 0)):
+        """The same through jl_records_begin / _append / _finish, `chunk_reads` records per append; every chunk passes
+        slices of the caller's arrays with offsets that do not start at 0 (the library rebases them)."""
+        pos = np.ascontiguousarray(pos, dtype=np.int32)
+        cigar = np.ascontiguousarray(cigar, dtype=np.uint32)
+        cig_off = np.ascontiguousarray(cig_off, dtype=np.uint64)
+        seq4 = np.ascontiguousarray(seq4, dtype=np.uint8)
+        seq_off = np.ascontiguousarray(seq_off, dtype=np.uint64)
+        if qual is not None:
+            qual = np.ascontiguousarray(qual, dtype=np.uint8)
+            qual_off = np.ascontiguousarray(qual_off, dtype=np.uint64)
+        n = len(pos)
+        hq = hints[3] if qual is not None else 0
+        self._chk(self.lib.jl_records_begin(self.h, hints[0], hints[1], hints[2], hq))
+        for a in range(0, n, chunk_reads):
+            b = min(n, a + chunk_reads)
+            co, so = np.ascontiguousarray(cig_off[a:b + 1]), np.ascontiguousarray(seq_off[a:b + 1])
+            qo = np.ascontiguousarray(qual_off[a:b + 1]) if qual is not None else None
+            self._chk(self.lib.jl_records_append(self.h, b - a, _p(np.ascontiguousarray(pos[a:b])), _p(cigar), _p(co), _p(seq4),
+                                                 _p(so), _p(qual), _p(qo)))
+        self._chk(self.lib.jl_records_finish(self.h, n_cols, win_begin, min_qv))
         self._shape(n, n_cols, self.lib.jl_col_stride(n))
 
     def track_insertions(self, on=True):

@@ -132,6 +132,8 @@ static void free_msa(jl_ctx *ctx)
     ctx->msa_capacity = 0;
 }
 
+static void records_drop(jl_ctx *ctx);
+
 void jl_ctx_destroy(jl_ctx *ctx)
 {
     if (!ctx) return;
@@ -143,6 +145,7 @@ void jl_ctx_destroy(jl_ctx *ctx)
     if (ctx->h_seq) hipHostFree((void *)ctx->h_seq);
     if (ctx->h_read_hap) hipHostFree(ctx->h_read_hap);
     free_msa(ctx);
+    records_drop(ctx);
     void *ptrs[] = {ctx->d_pos_gene, ctx->d_pos_codon, ctx->d_pos_col, ctx->d_pos_refcfg, ctx->d_guess, ctx->d_chunks,
                     ctx->d_counts, ctx->d_called, ctx->d_staged, ctx->d_drm, ctx->d_variants, ctx->d_nvar, ctx->d_meta, ctx->d_vpcols,
                     ctx->d_col2pos, ctx->d_varcol, ctx->d_keys, ctx->d_flagw, ctx->d_read_slot, ctx->d_read_hap,
@@ -272,54 +275,161 @@ int jl_msa_pack_rows(jl_ctx *ctx, const uint8_t *rows, uint64_t n_reads, uint32_
 // Aligned records straight to the resident layout: cigar expansion, QV masking and the transpose all run
 // on the device.  Arrays are what a BAM decoder holds: per read its leftmost position, its
 // cigar words (len << 4 | op), its 4-bit packed bases exactly as stored in BAM, optionally its qualities.
-int jl_msa_ingest_records(jl_ctx *ctx, uint64_t n_reads, uint32_t n_cols, uint32_t win_begin, const int32_t *pos,
-                          const uint32_t *cigar, const uint64_t *cig_off, const uint8_t *seq4, const uint64_t *seq_off,
-                          const uint8_t *qual, const uint64_t *qual_off, uint32_t min_qv)
+// Streamed form: jl_records_begin / jl_records_append (any number of chunks, e.g. one per inflated BGZF batch,
+// so the upload hides under the decode of the next chunk) / jl_records_finish (alloc + kernels).
+static void records_drop(jl_ctx *ctx)
+{
+    jl_records &r = ctx->rec;
+    void *tmp[] = {r.d_seq, r.d_cig, r.d_co, r.d_so, r.d_pos, r.d_qual, r.d_qo};
+    for (void *p : tmp)
+        if (p) hipFree(p);
+    r = jl_records();
+}
+
+// room for `need` elements of `elem` bytes (+pad bytes behind them); what is already there moves along
+static hipError_t records_room_bytes(jl_ctx *ctx, void **d, size_t *cap, size_t elem, size_t used, size_t need, size_t pad_bytes)
+{
+    if (*d && need <= *cap) return hipSuccess;
+    const size_t ncap = std::max<size_t>({need, *cap + *cap / 2, (size_t)1024});
+    void *nd = nullptr;
+    hipError_t e = hipMalloc(&nd, ncap * elem + pad_bytes);
+    if (e != hipSuccess) return e;
+    if (*d && used) e = hipMemcpyAsync(nd, *d, used * elem, hipMemcpyDeviceToDevice, ctx->stream);
+    if (*d) {
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        hipFree(*d);
+    }
+    *d = nd;
+    *cap = ncap;
+    return e;
+}
+#define records_room(ctx, d, cap, used, need, pad) records_room_bytes(ctx, (void **)&(d), &(cap), sizeof(*(d)), used, need, pad)
+
+int jl_records_begin(jl_ctx *ctx, uint64_t reads_hint, uint64_t cigar_words_hint, uint64_t seq_bytes_hint, uint64_t qual_bytes_hint)
+{
+    if (!ctx) return JL_ERR_ARG;
+    JL_HIP(ctx, hipSetDevice(ctx->device));
+    records_drop(ctx);
+    jl_records &r = ctx->rec;
+    r.open = true;
+    hipError_t e = records_room(ctx, r.d_pos, r.cap_pos, 0, (size_t)reads_hint, 0);
+    if (e == hipSuccess) e = records_room(ctx, r.d_co, r.cap_co, 0, (size_t)reads_hint + 1, 0);
+    if (e == hipSuccess) e = records_room(ctx, r.d_so, r.cap_so, 0, (size_t)reads_hint + 1, 0);
+    if (e == hipSuccess) e = records_room(ctx, r.d_cig, r.cap_cig, 0, (size_t)cigar_words_hint, 0);
+    if (e == hipSuccess) e = records_room(ctx, r.d_seq, r.cap_seq, 0, (size_t)seq_bytes_hint, 16);
+    if (e == hipSuccess && qual_bytes_hint) e = records_room(ctx, r.d_qual, r.cap_qual, 0, (size_t)qual_bytes_hint, 0);
+    if (e == hipSuccess && qual_bytes_hint) e = records_room(ctx, r.d_qo, r.cap_qo, 0, (size_t)reads_hint + 1, 0);
+    if (e != hipSuccess) {
+        records_drop(ctx);
+        return jl_fail(ctx, e == hipErrorOutOfMemory ? JL_ERR_MEMORY : JL_ERR_DEVICE, "records: %s", hipGetErrorString(e));
+    }
+    return JL_OK;
+}
+
+int jl_records_append(jl_ctx *ctx, uint64_t n_reads, const int32_t *pos, const uint32_t *cigar, const uint64_t *cig_off,
+                      const uint8_t *seq4, const uint64_t *seq_off, const uint8_t *qual, const uint64_t *qual_off)
 {
     if (!ctx || !pos || !cigar || !cig_off || !seq4 || !seq_off || (qual && !qual_off)) return JL_ERR_ARG;
-    uint64_t max_ops = 0, max_seq_bytes = 0;
+    jl_records &R = ctx->rec;
+    if (!R.open) return jl_fail(ctx, JL_ERR_STATE, "jl_records_append before jl_records_begin");
+    if (R.n_reads && (qual != nullptr) != R.have_qual) {
+        records_drop(ctx);
+        return jl_fail(ctx, JL_ERR_ARG, "records: either every chunk carries qualities or none does");
+    }
+    if (!n_reads) return JL_OK;
+    uint64_t max_ops = R.max_ops, max_seq_bytes = R.max_seq_bytes;
+    const uint64_t first = R.n_reads;
+    // a chunk that fails validation ends the stream (jl_records_begin starts over)
+    auto bad = [&](uint64_t r, const char *what, uint64_t v) {
+        records_drop(ctx);
+        return jl_fail(ctx, JL_ERR_ARG, what, (unsigned long long)(first + r), (unsigned long long)v);
+    };
     for (uint64_t r = 0; r < n_reads; ++r) {
         if (cig_off[r + 1] < cig_off[r] || seq_off[r + 1] < seq_off[r] || (qual && qual_off[r + 1] < qual_off[r]))
-            return jl_fail(ctx, JL_ERR_ARG, "record %llu: offsets must not decrease", (unsigned long long)r);
+            return bad(r, "record %llu: offsets must not decrease", 0);
         max_ops = std::max(max_ops, cig_off[r + 1] - cig_off[r]);
         max_seq_bytes = std::max(max_seq_bytes, seq_off[r + 1] - seq_off[r]);
         uint64_t query = 0;
         for (uint64_t k = cig_off[r]; k < cig_off[r + 1]; ++k) {
             const uint32_t op = cigar[k] & 15u;
-            if (op == 0u) return jl_fail(ctx, JL_ERR_ARG, "cigar M is forbidden in PacBio-compliant BAM (doc/JULIET.md:53)");
+            if (op == 0u) return bad(r, "record %llu: cigar M is forbidden in PacBio-compliant BAM (doc/JULIET.md:53)", 0);
             if (op == 1u || op == 4u || op == 7u || op == 8u) query += cigar[k] >> 4;
         }
         // the kernel indexes the read's bases (two per byte) and qualities by the cigar's query offsets
         if (query > 2 * (seq_off[r + 1] - seq_off[r]) || (qual && query > qual_off[r + 1] - qual_off[r]))
-            return jl_fail(ctx, JL_ERR_ARG, "record %llu: its cigar consumes %llu bases, more than the record holds",
-                           (unsigned long long)r, (unsigned long long)query);
+            return bad(r, "record %llu: its cigar consumes %llu bases, more than the record holds", query);
     }
-    int rc = jl_msa_alloc(ctx, n_reads, n_cols, win_begin);
-    if (rc) return rc;
-    const size_t n_cig = (size_t)cig_off[n_reads], n_seq = (size_t)seq_off[n_reads], n_q = qual ? (size_t)qual_off[n_reads] : 0;
-    const size_t off_bytes = (size_t)(n_reads + 1) * 8;
-    uint8_t *d_seq = nullptr, *d_qual = nullptr;
-    uint32_t *d_cig = nullptr, *d_rows4 = nullptr;
-    uint64_t *d_co = nullptr, *d_so = nullptr, *d_qo = nullptr;
-    int32_t *d_pos = nullptr;
+    JL_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
+    // the chunk's arrays start wherever its offsets say; on the device everything is one run of arrays
+    const uint64_t c0 = cig_off[0], s0 = seq_off[0], q0 = qual ? qual_off[0] : 0;
+    const size_t n_cig = (size_t)(cig_off[n_reads] - c0), n_seq = (size_t)(seq_off[n_reads] - s0),
+                 n_q = qual ? (size_t)(qual_off[n_reads] - q0) : 0;
+    const size_t nr = (size_t)R.n_reads;
+    hipError_t e = records_room(ctx, R.d_pos, R.cap_pos, nr, nr + n_reads, 0);
+    if (e == hipSuccess) e = records_room(ctx, R.d_co, R.cap_co, nr + 1, nr + n_reads + 1, 0);
+    if (e == hipSuccess) e = records_room(ctx, R.d_so, R.cap_so, nr + 1, nr + n_reads + 1, 0);
+    if (e == hipSuccess) e = records_room(ctx, R.d_cig, R.cap_cig, (size_t)R.n_cig, (size_t)R.n_cig + n_cig, 0);
     // the kernel reads the bases a dword at a time and one dword ahead: 16 bytes of padding behind them
-    hipError_t e = hipMalloc(&d_seq, n_seq + 16);
-    if (e == hipSuccess) e = hipMalloc(&d_cig, (n_cig ? n_cig : 1) * 4);
-    if (e == hipSuccess) e = hipMalloc(&d_co, off_bytes);
-    if (e == hipSuccess) e = hipMalloc(&d_so, off_bytes);
-    if (e == hipSuccess) e = hipMalloc(&d_pos, (size_t)(n_reads ? n_reads : 1) * 4);
-    if (e == hipSuccess && qual) e = hipMalloc(&d_qual, n_q ? n_q : 1);
-    if (e == hipSuccess && qual) e = hipMalloc(&d_qo, off_bytes);
+    if (e == hipSuccess) e = records_room(ctx, R.d_seq, R.cap_seq, (size_t)R.n_seq, (size_t)R.n_seq + n_seq, 16);
+    if (e == hipSuccess && qual) e = records_room(ctx, R.d_qual, R.cap_qual, (size_t)R.n_qual, (size_t)R.n_qual + n_q, 0);
+    if (e == hipSuccess && qual) e = records_room(ctx, R.d_qo, R.cap_qo, nr + 1, nr + n_reads + 1, 0);
+    std::vector<uint64_t> off((size_t)(n_reads + 1) * (qual ? 3 : 2));
+    uint64_t *co = off.data(), *so = co + n_reads + 1, *qo = so + n_reads + 1;
+    for (uint64_t r = 0; r <= n_reads; ++r) {
+        co[r] = cig_off[r] - c0 + R.n_cig;
+        so[r] = seq_off[r] - s0 + R.n_seq;
+        if (qual) qo[r] = qual_off[r] - q0 + R.n_qual;
+    }
+    const size_t off_bytes = (size_t)(n_reads + 1) * 8;
+    if (e == hipSuccess && n_seq) e = hipMemcpyAsync(R.d_seq + R.n_seq, seq4 + s0, n_seq, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess && n_cig) e = hipMemcpyAsync(R.d_cig + R.n_cig, cigar + c0, n_cig * 4, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(R.d_co + nr, co, off_bytes, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(R.d_so + nr, so, off_bytes, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(R.d_pos + nr, pos, (size_t)n_reads * 4, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess && qual && n_q) e = hipMemcpyAsync(R.d_qual + R.n_qual, qual + q0, n_q, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess && qual) e = hipMemcpyAsync(R.d_qo + nr, qo, off_bytes, hipMemcpyHostToDevice, st);
+    // the caller may reuse its chunk buffers (and `off` goes away) as soon as this returns
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) {
+        records_drop(ctx);
+        return jl_fail(ctx, e == hipErrorOutOfMemory ? JL_ERR_MEMORY : JL_ERR_DEVICE, "records: %s", hipGetErrorString(e));
+    }
+    R.have_qual = qual != nullptr;
+    R.n_reads += n_reads;
+    R.n_cig += n_cig;
+    R.n_seq += n_seq;
+    R.n_qual += n_q;
+    R.max_ops = max_ops;
+    R.max_seq_bytes = max_seq_bytes;
+    return JL_OK;
+}
+
+int jl_records_finish(jl_ctx *ctx, uint32_t n_cols, uint32_t win_begin, uint32_t min_qv)
+{
+    if (!ctx) return JL_ERR_ARG;
+    jl_records &R = ctx->rec;
+    if (!R.open) return jl_fail(ctx, JL_ERR_STATE, "jl_records_finish before jl_records_begin");
+    JL_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = jl_msa_alloc(ctx, R.n_reads, n_cols, win_begin);
+    if (rc) {
+        records_drop(ctx);
+        return rc;
+    }
+    hipStream_t st = ctx->stream;
+    uint32_t *d_rows4 = nullptr;
+    hipError_t e = hipSuccess;
+    if (!R.n_reads) {   // nothing was appended: the offset arrays still need their first entry
+        e = records_room(ctx, R.d_co, R.cap_co, 0, 1, 0);
+        if (e == hipSuccess) e = records_room(ctx, R.d_so, R.cap_so, 0, 1, 0);
+        if (e == hipSuccess) e = records_room(ctx, R.d_pos, R.cap_pos, 0, 1, 0);
+        if (e == hipSuccess) e = records_room(ctx, R.d_cig, R.cap_cig, 0, 1, 0);
+        if (e == hipSuccess) e = records_room(ctx, R.d_seq, R.cap_seq, 0, 1, 16);
+        if (e == hipSuccess) e = hipMemsetAsync(R.d_co, 0, 8, st);
+        if (e == hipSuccess) e = hipMemsetAsync(R.d_so, 0, 8, st);
+    }
     if (e == hipSuccess) e = hipMalloc(&d_rows4, (size_t)jl_ingest_batch_reads(ctx) * jl_ingest_row_dwords(ctx) * 4);
-    if (e == hipSuccess) e = hipMemsetAsync(d_seq + n_seq, 0, 16, st);
-    if (e == hipSuccess && n_seq) e = hipMemcpyAsync(d_seq, seq4, n_seq, hipMemcpyHostToDevice, st);
-    if (e == hipSuccess && n_cig) e = hipMemcpyAsync(d_cig, cigar, n_cig * 4, hipMemcpyHostToDevice, st);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_co, cig_off, off_bytes, hipMemcpyHostToDevice, st);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_so, seq_off, off_bytes, hipMemcpyHostToDevice, st);
-    if (e == hipSuccess && n_reads) e = hipMemcpyAsync(d_pos, pos, (size_t)n_reads * 4, hipMemcpyHostToDevice, st);
-    if (e == hipSuccess && qual && n_q) e = hipMemcpyAsync(d_qual, qual, n_q, hipMemcpyHostToDevice, st);
-    if (e == hipSuccess && qual) e = hipMemcpyAsync(d_qo, qual_off, off_bytes, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemsetAsync(R.d_seq + R.n_seq, 0, 16, st);
     ctx->ins_valid = false;
     if (e == hipSuccess && ctx->track_insertions) {
         if (ctx->ins_capacity < n_cols) {
@@ -334,21 +444,34 @@ int jl_msa_ingest_records(jl_ctx *ctx, uint64_t n_reads, uint32_t n_cols, uint32
         if (e == hipSuccess) e = hipMemsetAsync(ctx->d_ins_len, 0, (size_t)n_cols * JL_INS_LEN_BINS * 4, st);
         if (e == hipSuccess) e = hipMemsetAsync(ctx->d_ins_base, 0, (size_t)n_cols * JL_INS_MAX_BASES * 16, st);
         if (e == hipSuccess) {
-            jl_launch_insertions(ctx, d_pos, d_cig, d_co, d_seq, d_so);
+            jl_launch_insertions(ctx, R.d_pos, R.d_cig, R.d_co, R.d_seq, R.d_so);
             e = hipGetLastError();
             ctx->ins_valid = e == hipSuccess;
         }
     }
     if (e == hipSuccess) {
-        jl_launch_ingest(ctx, d_pos, d_cig, d_co, d_seq, d_so, d_qual, d_qo, min_qv, d_rows4, max_ops, max_seq_bytes);
+        jl_launch_ingest(ctx, R.d_pos, R.d_cig, R.d_co, R.d_seq, R.d_so, R.have_qual ? R.d_qual : nullptr,
+                         R.have_qual ? R.d_qo : nullptr, min_qv, d_rows4, R.max_ops, R.max_seq_bytes);
         e = hipGetLastError();
         if (e == hipSuccess) e = hipStreamSynchronize(st);
     }
-    void *tmp[] = {d_seq, d_cig, d_co, d_so, d_pos, d_qual, d_qo, d_rows4};
-    for (void *p : tmp)
-        if (p) hipFree(p);
+    if (d_rows4) hipFree(d_rows4);
+    records_drop(ctx);
     if (e != hipSuccess) return jl_fail(ctx, e == hipErrorOutOfMemory ? JL_ERR_MEMORY : JL_ERR_DEVICE, "ingest: %s", hipGetErrorString(e));
     return JL_OK;
+}
+
+int jl_msa_ingest_records(jl_ctx *ctx, uint64_t n_reads, uint32_t n_cols, uint32_t win_begin, const int32_t *pos,
+                          const uint32_t *cigar, const uint64_t *cig_off, const uint8_t *seq4, const uint64_t *seq_off,
+                          const uint8_t *qual, const uint64_t *qual_off, uint32_t min_qv)
+{
+    if (!ctx || !pos || !cigar || !cig_off || !seq4 || !seq_off || (qual && !qual_off)) return JL_ERR_ARG;
+    int rc = jl_records_begin(ctx, n_reads, cig_off[n_reads] - cig_off[0], seq_off[n_reads] - seq_off[0],
+                              qual ? std::max<uint64_t>(qual_off[n_reads] - qual_off[0], 1) : 0);
+    if (rc == JL_OK) rc = jl_records_append(ctx, n_reads, pos, cigar, cig_off, seq4, seq_off, qual, qual_off);
+    if (rc == JL_OK) rc = jl_records_finish(ctx, n_cols, win_begin, min_qv);
+    else if (ctx->rec.open) records_drop(ctx);
+    return rc;
 }
 
 int jl_msa_track_insertions(jl_ctx *ctx, int on)

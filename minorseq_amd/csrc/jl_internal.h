@@ -226,6 +226,17 @@ void jl_launch_gather_heads(const uint8_t *const *srcs, uint32_t n, uint8_t *dst
 
 struct jl_comm;
 
+// Records uploaded so far by jl_records_append: one run of device arrays, offsets rebased to it.
+struct jl_records {
+    bool open = false, have_qual = false;
+    uint8_t *d_seq = nullptr, *d_qual = nullptr;
+    uint32_t *d_cig = nullptr;
+    uint64_t *d_co = nullptr, *d_so = nullptr, *d_qo = nullptr;
+    int32_t *d_pos = nullptr;
+    size_t cap_seq = 0, cap_qual = 0, cap_cig = 0, cap_co = 0, cap_so = 0, cap_qo = 0, cap_pos = 0;
+    uint64_t n_reads = 0, n_cig = 0, n_seq = 0, n_qual = 0, max_ops = 0, max_seq_bytes = 0;
+};
+
 struct jl_ctx {
     int device = -1;
     hipStream_t stream = nullptr;
@@ -247,6 +258,9 @@ struct jl_ctx {
     uint32_t *d_ins_len = nullptr;    // [n_cols][JL_INS_LEN_BINS]
     uint32_t *d_ins_base = nullptr;   // [n_cols][JL_INS_MAX_BASES][4]
     size_t ins_capacity = 0;          // columns
+
+    // ---- aligned records on their way in (jl_records_begin / _append / _finish)
+    jl_records rec;
 
     // ---- pileup plan (host copies + device arrays)
     std::vector<jl_gene> genes;

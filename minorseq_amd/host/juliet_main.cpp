@@ -6,11 +6,17 @@
 // leaves open is an explicit flag with the docs/SPEC.md default.  All compute happens on the GPU through
 // the C ABI; without a gfx950 device the tool exits with status 3.
 #include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
+#include <thread>
 #include <future>
 #include <cstdlib>
 #include <ctime>
+#include <filesystem>
 #include <fstream>
 #include <iostream>
+#include <memory>
 
 #include "config.hpp"
 #include "format.hpp"
@@ -152,6 +158,122 @@ void die_jl(jl_ctx *ctx, const char *what)
     std::exit(3);
 }
 
+// Hands decoded records to the device chunk by chunk while the parser works on the next chunk: the upload (0.03 s for
+// 100k reads) hides under the decode whenever the GPU context is up before the file ends; chunks that arrive earlier
+// simply wait.  One consumer thread: chunks stay in file order.
+class RecordUploader {
+public:
+    RecordUploader(std::shared_future<std::pair<int, jl_ctx *>> ctx_up, uint64_t file_bytes, bool want_qual)
+        : ctx_up_(std::move(ctx_up)), file_bytes_(file_bytes), want_qual_(want_qual), th_([this] { run(); })
+    {
+    }
+    ~RecordUploader() { finish(); }
+    RecordUploader(const RecordUploader &) = delete;
+    RecordUploader &operator=(const RecordUploader &) = delete;
+
+    // parser side: trade the full chunk for an empty one
+    void give(RecordArrays &chunk)
+    {
+        RecordArrays fresh;
+        const size_t want_seq = chunk.seq4.size() + chunk.seq4.size() / 4, want_cig = chunk.cigar.size() + chunk.cigar.size() / 4,
+                     want_qual = chunk.qual.size() + chunk.qual.size() / 4, want_reads = chunk.pos.size() + 1;
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            if (!pool_.empty()) {
+                fresh = std::move(pool_.back());
+                pool_.pop_back();
+            }
+            q_.push_back(std::move(chunk));
+        }
+        cv_.notify_one();
+        chunk = std::move(fresh);
+        chunk.clear();
+        // a new chunk starts at the size of the one before it instead of growing by doubling
+        chunk.seq4.reserve(want_seq);
+        chunk.cigar.reserve(want_cig);
+        chunk.qual.reserve(want_qual);
+        chunk.pos.reserve(want_reads);
+        chunk.cig_off.reserve(want_reads);
+        chunk.seq_off.reserve(want_reads);
+        if (want_qual) chunk.qual_off.reserve(want_reads);
+        chunk.names.reserve(want_reads);
+    }
+    // no more chunks: waits for the uploads; the records are on the device when this returns JL_OK
+    int finish()
+    {
+        if (th_.joinable()) {
+            {
+                std::lock_guard<std::mutex> lk(m_);
+                done_ = true;
+            }
+            cv_.notify_one();
+            th_.join();
+        }
+        return rc_;
+    }
+    jl_ctx *ctx() const { return ctx_; }
+    std::vector<std::string> names;
+    uint64_t n_reads = 0;
+    double ms_begin = 0, ms_append = 0, ms_append_max = 0, ms_names = 0;   // --timing
+    unsigned n_appends = 0;
+
+private:
+    static double ms_since(std::chrono::steady_clock::time_point t)
+    {
+        return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count();
+    }
+    void run()
+    {
+        const auto up = ctx_up_.get();
+        ctx_ = up.second;
+        rc_ = up.first;
+        if (rc_ == JL_OK) {
+            // CCS BAMs inflate 5-10x; the packed bases are about a quarter of that, qualities half (arrays grow if not)
+            const uint64_t seq_hint = std::min<uint64_t>(file_bytes_ * 2, (uint64_t)2 << 30);
+            const auto t = std::chrono::steady_clock::now();
+            rc_ = jl_records_begin(ctx_, seq_hint / 1024 + 1024, seq_hint / 64 + 1024, seq_hint, want_qual_ ? seq_hint * 2 : 0);
+            ms_begin = ms_since(t);
+        }
+        for (;;) {
+            RecordArrays c;
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_.wait(lk, [this] { return done_ || !q_.empty(); });
+                if (q_.empty()) return;
+                c = std::move(q_.front());
+                q_.pop_front();
+            }
+            auto t = std::chrono::steady_clock::now();
+            if (rc_ == JL_OK)
+                rc_ = jl_records_append(ctx_, c.pos.size(), c.pos.data(), c.cigar.data(), c.cig_off.data(), c.seq4.data(),
+                                        c.seq_off.data(), want_qual_ ? c.qual.data() : nullptr,
+                                        want_qual_ ? c.qual_off.data() : nullptr);
+            const double ms = ms_since(t);
+            ms_append += ms;
+            ms_append_max = std::max(ms_append_max, ms);
+            ++n_appends;
+            t = std::chrono::steady_clock::now();
+            n_reads += c.pos.size();
+            for (std::string &nm : c.names) names.push_back(std::move(nm));
+            c.clear();
+            ms_names += ms_since(t);
+            std::lock_guard<std::mutex> lk(m_);
+            if (pool_.size() < 8) pool_.push_back(std::move(c));
+        }
+    }
+    std::shared_future<std::pair<int, jl_ctx *>> ctx_up_;
+    uint64_t file_bytes_;
+    bool want_qual_;
+    std::mutex m_;
+    std::condition_variable cv_;
+    std::deque<RecordArrays> q_;
+    std::vector<RecordArrays> pool_;
+    bool done_ = false;
+    int rc_ = JL_OK;
+    jl_ctx *ctx_ = nullptr;
+    std::thread th_;   // last: starts in the constructor's initialiser list
+};
+
 }  // namespace
 
 int main(int argc, char **argv)
@@ -192,19 +314,27 @@ int main(int argc, char **argv)
         io.min_rq = opt.min_rq;
         // the GPU context comes up (runtime start, stream, pinned blocks) while the host reads the BAM
         const bool need_gpu = !opt.outputs.empty();
-        std::future<std::pair<int, jl_ctx *>> ctx_up;
-        if (need_gpu)
+        std::shared_future<std::pair<int, jl_ctx *>> ctx_up;
+        std::unique_ptr<RecordUploader> uploader;
+        RecordSink sink;
+        if (need_gpu) {
             ctx_up = std::async(std::launch::async, [dev = opt.device]() {
                 jl_ctx *c = nullptr;
                 const int rc = jl_ctx_create(dev, nullptr, &c);
                 return std::make_pair(rc, c);
-            });
+            }).share();
+            std::error_code ec;
+            const uintmax_t fsz = std::filesystem::file_size(opt.bam, ec);
+            uploader.reset(new RecordUploader(ctx_up, ec ? 0 : (uint64_t)fsz, opt.min_qv > 0));
+            sink.give = [&uploader](RecordArrays &c) { uploader->give(c); };
+        }
         // ONE pass over the file: records as decoded from BAM (cigar expansion, QV masking and the transpose run on
         // the device) and the extent they cover
         RecordArrays rec;
         std::vector<BamRef> bam_refs;
         std::string header_text;
-        const ReadExtent ext = collect_records(opt.bam, io, io.ref_id, opt.min_qv > 0, rec, &bam_refs, &header_text);
+        const ReadExtent ext = collect_records(opt.bam, io, io.ref_id, opt.min_qv > 0, rec, &bam_refs, &header_text,
+                                               uploader ? &sink : nullptr);
         tick("bam decode");
         if (ext.n_reads == 0) { std::cerr << "juliet: no primary or supplementary alignments in " << opt.bam << "\n"; return 2; }
         int64_t ref_len = std::numeric_limits<int64_t>::max();
@@ -241,8 +371,7 @@ int main(int argc, char **argv)
             f.write((const char *)rows.data(), (std::streamsize)((size_t)n_reads * n_cols));
             if (opt.outputs.empty()) return 0;
         }
-        n_reads = rec.pos.size();
-        names.swap(rec.names);
+        n_reads = ext.n_reads;
 
         // ---------------------------------------------------------------- parameters
         std::string chem = opt.chemistry;
@@ -275,13 +404,16 @@ int main(int argc, char **argv)
         jl_ctx *ctx = up.second;
         if (up.first != JL_OK) die_jl(nullptr, "no usable GPU (this tool has no CPU fallback)");
         tick("context ready");
+        if (uploader->finish() != JL_OK) die_jl(ctx, "record upload");
+        if (uploader->n_reads != n_reads) die_jl(nullptr, "record upload lost reads");
+        names.swap(uploader->names);
+        tick("rest of the upload");
+        if (opt.timing)
+            fprintf(stderr, "juliet: timing   uploader thread: begin %.1f ms, %u appends %.1f ms (longest %.1f), names %.1f ms\n",
+                    uploader->ms_begin, uploader->n_appends, uploader->ms_append, uploader->ms_append_max, uploader->ms_names);
         if (!opt.consensus.empty()) jl_msa_track_insertions(ctx, 1);   // fuse keeps in-frame insertions (doc/FUSE.md:19)
-        if (jl_msa_ingest_records(ctx, n_reads, n_cols, win_begin, rec.pos.data(), rec.cigar.data(), rec.cig_off.data(),
-                                  rec.seq4.data(), rec.seq_off.data(), opt.min_qv ? rec.qual.data() : nullptr,
-                                  opt.min_qv ? rec.qual_off.data() : nullptr, opt.min_qv) != JL_OK)
-            die_jl(ctx, "ingest");
-        rec = RecordArrays();
-        tick("upload + device ingest");
+        if (jl_records_finish(ctx, n_cols, win_begin, opt.min_qv) != JL_OK) die_jl(ctx, "ingest");
+        tick("device ingest");
 
         // --drm-only needs the position list, which the plan of a first pileup provides
         std::vector<uint64_t> drm_masks;

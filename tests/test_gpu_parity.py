@@ -825,6 +825,45 @@ def test_device_ingest_matches_rows(jl, n, l, partial, win):
     assert "cigar M" in str(err.value)
 
 
+@pytest.mark.parametrize("chunk,hints", [(1, (0, 0, 0, 0)), (37, (0, 0, 0, 0)), (256, (5000, 100000, 1 << 20, 1 << 21)), (10000, (0, 0, 0, 0))])
+def test_device_ingest_in_chunks(jl, chunk, hints):
+    """jl_records_begin / _append / _finish: any chunking (one read per append, ragged chunks, one chunk; device arrays
+    that grow from nothing or are sized up front) gives the matrix of the one-call form, with and without qualities,
+    and the insertion counters as well."""
+    n, l = 1500, 333
+    rng = np.random.default_rng(chunk)
+    sp = synth.SynthParams(seed=77, partial_rate=0.3, del_rate=0.02, mask_rate=0.03, sub_rate=0.01)
+    ref = synth.reference(sp.seed, l)
+    rows = synth.rows(sp, l, 0, n, ref)
+    rows[11] = 6
+    pos, cigar, cig_off, seq4, seq_off, qual, qual_off = rows_to_records(rows, ref, rng)
+    jl.track_insertions(True)
+    jl.ingest_records(l - 20, 13, pos, cigar, cig_off, seq4, seq_off)
+    want = jl.download_columns().copy()
+    want_ins = jl.insertions_fetch()
+    jl.ingest_records_chunked(l - 20, 13, pos, cigar, cig_off, seq4, seq_off, chunk_reads=chunk, hints=hints)
+    assert (jl.download_columns() == want).all()
+    assert (msa.unpack_columns(jl.download_columns(), n) == rows[:, 13:l - 7]).all()
+    got_ins = jl.insertions_fetch()
+    assert (got_ins[0] == want_ins[0]).all() and (got_ins[1] == want_ins[1]).all()
+    jl.track_insertions(False)
+    jl.ingest_records_chunked(l - 20, 13, pos, cigar, cig_off, seq4, seq_off, qual, qual_off, min_qv=94, chunk_reads=chunk, hints=hints)
+    exp = rows[:, 13:l - 7].copy()
+    exp[exp < 4] = 5
+    assert (msa.unpack_columns(jl.download_columns(), n) == exp).all()
+    # errors are those of the one-call form, and a failed append leaves nothing behind
+    bad = cigar.copy()
+    bad[int(cig_off[n // 2])] &= ~np.uint32(15)
+    with pytest.raises(capi.JulietError) as err:
+        jl.ingest_records_chunked(l, 0, pos, bad, cig_off, seq4, seq_off, chunk_reads=chunk)
+    assert "cigar M" in str(err.value)
+    with pytest.raises(capi.JulietError) as err:      # a failed append ends the stream: nothing to finish
+        jl._chk(jl.lib.jl_records_finish(jl.h, l, 0, 0))
+    assert "before jl_records_begin" in str(err.value)
+    jl.ingest_records_chunked(l, 0, pos, cigar, cig_off, seq4, seq_off, chunk_reads=chunk)
+    assert (msa.unpack_columns(jl.download_columns(), n) == rows).all()
+
+
 def test_device_ingest_long_cigar(jl):
     """One op per base: 5000 ops per read, every lane fetches a cigar word at every column."""
     l = 5000
