@@ -65,8 +65,8 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(const uint8_t *__restric
 //                        all 8 columns lie inside one op (runs of '=' are tens of columns long) they are taken at
 //                        once — eight packed BAM bases fetched as two dwords, converted nibble-parallel — otherwise
 //                        column by column.  No divergence over reads: a wave only ever looks at one cigar.
-//   transpose_rows_kernel  by-row nibbles -> the column-packed matrix through a 128-read x 256-column LDS tile: 128-byte
-//                        reads, 64-byte writes.
+//   transpose_rows_kernel  by-row nibbles -> the column-packed matrix through a 256-read x 256-column LDS tile (bank-
+//                        conflict-free both ways), 8 x 8 nibble blocks transposed in registers: 128-byte reads and writes.
 // (The first build walked one read per LANE while the wave swept the columns: some lane of 64 changed its op at
 // nearly every column and the kernel was bound by the cursor's instructions under divergence, 0.29 TB/s.)
 // Reads past n_reads (the padding of a column up to its 128-byte stride) and columns outside a read's span are 'not covered'.
@@ -248,31 +248,68 @@ __global__ __launch_bounds__(256) void expand_rows_kernel(uint64_t r0, uint64_t 
 }
 
 // by-row nibbles of a batch of reads -> the column-packed matrix.  Tile = 128 reads x 256 columns through LDS.
+// 8 x 8 nibbles held as 8 dwords (row i = m[i], element j at bits 4j) -> their transpose
+__device__ __forceinline__ void transpose_nibbles_8x8(uint32_t (&m)[8])
+{
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t a = m[i], b = m[i + 4];
+        m[i] = (a & 0x0000FFFFu) | (b << 16);
+        m[i + 4] = (a >> 16) | (b & 0xFFFF0000u);
+    }
+#pragma unroll
+    for (int h = 0; h < 8; h += 4)
+#pragma unroll
+        for (int i = h; i < h + 2; ++i) {
+            const uint32_t a = m[i], b = m[i + 2];
+            m[i] = (a & 0x00FF00FFu) | ((b & 0x00FF00FFu) << 8);
+            m[i + 2] = ((a >> 8) & 0x00FF00FFu) | (b & 0xFF00FF00u);
+        }
+#pragma unroll
+    for (int i = 0; i < 8; i += 2) {
+        const uint32_t a = m[i], b = m[i + 1];
+        m[i] = (a & 0x0F0F0F0Fu) | ((b & 0x0F0F0F0Fu) << 4);
+        m[i + 1] = ((a >> 4) & 0x0F0F0F0Fu) | (b & 0xF0F0F0F0u);
+    }
+}
+
+// LDS tile of 256 reads x 32 dwords: dword d of read r at (r & 7) * kTrOct + (r >> 3) * 33 + d.  Rows go in with one read
+// per half-wave (banks d), groups of 8 reads come out with one group per lane (banks 33 g = g): no conflicts either way.
+constexpr uint32_t kTrOct = 1060;
+static_assert(kTrOct % 32u == 4u && kTrOct >= 32u * 33u, "LDS tile layout");
+
 __global__ __launch_bounds__(256) void transpose_rows_kernel(const uint32_t *__restrict__ rows4, uint32_t row_dwords,
                                                               uint64_t r0, uint64_t n_batch, uint32_t n_cols,
                                                               uint8_t *__restrict__ msa, uint64_t col_stride)
 {
-    __shared__ uint32_t s_t[128][33];
+    __shared__ uint32_t s_t[8u * kTrOct];
     const uint32_t tid = threadIdx.x;
-    const uint64_t rb = (uint64_t)blockIdx.x * 128u;          // first read of the tile, within the batch
+    const uint64_t rb = (uint64_t)blockIdx.x * 256u;          // first read of the tile, within the batch
     const uint32_t d0 = blockIdx.y * 32u;                     // first dword of the tile's columns
-    for (uint32_t i = tid; i < 128u * 32u; i += 256u) {
+#pragma unroll 8
+    for (uint32_t i = tid; i < 256u * 32u; i += 256u) {
         const uint32_t rr = i >> 5, dd = i & 31u;
         uint32_t v = 0x66666666u;
         if (rb + rr < n_batch && d0 + dd < row_dwords) v = rows4[(rb + rr) * (uint64_t)row_dwords + d0 + dd];
-        s_t[rr][dd] = v;
+        s_t[(rr & 7u) * kTrOct + (rr >> 3) * 33u + dd] = v;
     }
     __syncthreads();
-    for (uint32_t o = tid; o < 256u * 16u; o += 256u) {
-        const uint32_t col = o >> 4, g = o & 15u;             // column of the tile, group of 8 reads
-        const uint32_t c = d0 * 8u + col;
-        if (c >= n_cols) continue;
-        const uint32_t sh = 4u * (col & 7u), dd = col >> 3;
-        uint32_t w = 0;
+    // 32 groups of 8 reads x 32 dwords of 8 columns: 8 x 8 nibbles at a time, 128-byte segments of 8 columns out
 #pragma unroll
-        for (uint32_t j = 0; j < 8u; ++j) w |= ((s_t[g * 8u + j][dd] >> sh) & 15u) << (4u * j);
+    for (uint32_t item = tid; item < 32u * 32u; item += 256u) {
+        const uint32_t g = item & 31u, dwi = item >> 5;
+        uint32_t m[8];
+#pragma unroll
+        for (uint32_t i = 0; i < 8u; ++i) m[i] = s_t[i * kTrOct + g * 33u + dwi];
+        transpose_nibbles_8x8(m);
         const uint64_t byte = (r0 + rb + (uint64_t)g * 8u) / 2u;
-        if (byte < col_stride) *reinterpret_cast<uint32_t *>(msa + (uint64_t)c * col_stride + byte) = w;
+        if (byte < col_stride) {
+#pragma unroll
+            for (uint32_t j = 0; j < 8u; ++j) {
+                const uint32_t c = (d0 + dwi) * 8u + j;
+                if (c < n_cols) *reinterpret_cast<uint32_t *>(msa + (uint64_t)c * col_stride + byte) = m[j];
+            }
+        }
     }
 }
 
@@ -450,7 +487,7 @@ void jl_launch_ingest(jl_ctx *ctx, const int32_t *d_pos, const uint32_t *d_cigar
         hipLaunchKernelGGL(expand_rows_kernel, dim3((uint32_t)((nb + 3u) / 4u)), dim3(256), lds, ctx->stream, r0, nb, ctx->n_reads,
                            ctx->n_cols, ctx->win_begin, d_pos, d_cigar, d_cig_off, d_seq4, d_seq_off, d_qual, d_qual_off, min_qv,
                            d_rows4, row_dwords, ops_cap, seq_cap);
-        hipLaunchKernelGGL(transpose_rows_kernel, dim3((uint32_t)((nb + 127u) / 128u), (row_dwords + 31u) / 32u), dim3(256), 0,
+        hipLaunchKernelGGL(transpose_rows_kernel, dim3((uint32_t)((nb + 255u) / 256u), (row_dwords + 31u) / 32u), dim3(256), 0,
                            ctx->stream, (const uint32_t *)d_rows4, row_dwords, r0, nb, ctx->n_cols, ctx->d_msa, ctx->col_stride);
     }
 }
