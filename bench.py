@@ -243,7 +243,15 @@ def main():
             if comm is not None and pending[id(c)] > (0 if final else 1):
                 drain(c, 1)
         state["checked"] += 1
+        if final:
+            # The launch is complete (its completion words were read above); retiring its commands in the runtime now
+            # (hipStreamSynchronize on the launch's stream, about 10 us of host time) overlaps with the launches still
+            # running.  Left to the closing torch.cuda.synchronize() the same bookkeeping is done stream after stream
+            # behind the last result: 10 us per stream that has run since the last fence (tools_tuning/sync_cost.py).
+            members[0].sync()
         return last
+
+    trace = [] if os.environ.get("JL_BENCH_TRACE") else None   # tuning aid: host time stamps of the timed steps
 
     def run_steps(k):
         """k steps; at most n_units launches (G steps each) in flight; every step's results are read on the host."""
@@ -256,10 +264,14 @@ def main():
                 last = collect(inflight.pop(0)[1])
             count = min(G, k - done)
             inflight.append((u, launch(u, count)))
+            if trace is not None:
+                trace.append(("launched", time.perf_counter()))
             done += count
             u = (u + 1) % n_units
         while inflight:
             last = collect(inflight.pop(0)[1], final=True)
+            if trace is not None:
+                trace.append(("collected+synced", time.perf_counter()))
         if comm is not None:
             for c in ctxs:
                 drain(c, pending[id(c)])
@@ -290,9 +302,14 @@ def main():
     run_steps(args.warmup)
     fence()
     t0 = time.perf_counter()
+    if trace is not None:
+        del trace[:]
     last = run_steps(args.steps)
     fence()
     elapsed = time.perf_counter() - t0
+    if trace:
+        sys.stderr.write("bench trace (us after t0): " + ", ".join(f"{w} {1e6 * (t - t0):.1f}" for w, t in trace[:12]) +
+                         f", fence done {1e6 * elapsed:.1f}\n")
     if distributed:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -401,8 +418,9 @@ def config3_strong(capi, sharding, synth, torch, dist, distributed, comm, rank, 
     owner (RCCL, the second exchange) -> phasing across windows, replicated on the compact matrix.  `value` = 1M / t.
     The per-read ids stay on the device inside the loop (fetched once at the end): at 1e6 reads expanding them on the
     host would be most of a step."""
-    for c in free_ctxs:   # make room: the weak-scaling batches are no longer needed
-        c.close()
+    # The weak-scaling batches stay allocated (4.8 + 5 GB of 288): device memory that was freed and is allocated again
+    # runs slower on this driver — the pileup by 4 %, the phasing's random-access tables 3x (tools_tuning/
+    # config3_stages.py runs both generations) — and a job that runs configs[3] alone never sees second-hand memory.
     n, l = C3_READS, C3_COLS
     sp = synth.SynthParams(seed=4)
     ref = synth.reference(sp.seed, l)

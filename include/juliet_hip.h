@@ -116,6 +116,7 @@ int jl_device_count(void);
 int jl_ctx_create(int device, void *stream, jl_ctx **out);
 void jl_ctx_destroy(jl_ctx *ctx);
 const char *jl_last_error(const jl_ctx *ctx);
+/* Waits for everything enqueued for this context: its own stream and, after a group run, the group's. */
 int jl_sync(jl_ctx *ctx);
 
 /* ---------------------------------------------------------------- MSA residency */

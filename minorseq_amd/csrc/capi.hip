@@ -165,6 +165,8 @@ int jl_sync(jl_ctx *ctx)
 {
     if (!ctx) return JL_ERR_ARG;
     JL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    // the last run may have been enqueued on a group's stream
+    if (ctx->run_stream && ctx->run_stream != ctx->stream) JL_HIP(ctx, hipStreamSynchronize(ctx->run_stream));
     return JL_OK;
 }
 
