@@ -6,7 +6,8 @@
 #   5. the juliet front end on a 100k-read BAM                                 -> r02_cli_*
 set -e
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r02
+TAG=${1:-r02}
+O=$R/gpurun_out/$TAG
 rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/a -o a -- python3 $R/bench.py --gpus 1 --steps 20 --warmup 5 > $O/a_bench_line.json 2> $O/a.err
