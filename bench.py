@@ -27,6 +27,7 @@ import ctypes as C
 import json
 import os
 import sys
+import threading
 import time
 
 import numpy as np
@@ -105,6 +106,7 @@ def main():
     ap.add_argument("--cols", type=int, default=N_COLS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-config3", action="store_true", help="skip the configs[3] strong-scaling measurement")
+    ap.add_argument("--config3-timeout", type=float, default=120.0, help="N > 1: seconds the configs[3] measurement may take")
     ap.add_argument("--inflight", type=int, default=4,
                     help="launches in flight per GPU (each on its own stream, with its own captured graph)")
     ap.add_argument("--group", type=int, default=8,
@@ -393,8 +395,26 @@ def main():
     for g in (groups or []) + list(partial_groups.values()):
         g.close()
     if not args.no_config3:
-        out["config3_strong"] = config3_strong(capi, sharding, synth, torch, dist, distributed, comm, rank, world, local_rank,
-                                               [c for c in ctxs[1:]])
+        # The weak-scaling measurement above is complete.  The strong-scaling form adds two exchanges that have only ever
+        # run with one rank on hardware: should it fail or stall on some rank, every rank leaves after
+        # `--config3-timeout` seconds and the line still goes out with what was measured, the failure named in it.
+        def leave(reason):
+            out["config3_strong"] = {"error": reason, "scaling": "strong", "n_gpus": world}
+            if rank == 0:
+                os.write(real_stdout, (json.dumps(out) + "\n").encode())
+            os._exit(0)
+        watchdog = threading.Timer(args.config3_timeout, leave, (f"no result after {args.config3_timeout} s",))
+        watchdog.daemon = True
+        if distributed:
+            watchdog.start()
+        try:
+            out["config3_strong"] = config3_strong(capi, sharding, synth, torch, dist, distributed, comm, rank, world, local_rank,
+                                                   [c for c in ctxs[1:]])
+        except Exception as exc:   # noqa: BLE001 — at N > 1 the other ranks are inside a collective: they leave by their timers
+            if not distributed:
+                raise
+            leave(f"rank {rank}: {exc!r}")
+        watchdog.cancel()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"], rows_host = cpu_baseline(jl, genes, refseq, expected[id(jl)])
         ncores = min(os.cpu_count() or 1, 64)
@@ -474,7 +494,7 @@ def config3_strong(capi, sharding, synth, torch, dist, distributed, comm, rank, 
     fence()
     t = (time.perf_counter() - t0) / reps
     if distributed:
-        tt = torch.tensor([t], dtype=torch.float64)
+        tt = torch.tensor([t], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         t = float(tt.item())
     merged, ph = step(want_reads=True)
