@@ -198,6 +198,32 @@ def test_rich_qv_filter_end_to_end(tmp_path, oracle):
     assert all(a[4]["coverage"] > b[4]["coverage"] for a, b in zip(flat_variants(j0), got))
 
 
+@pytest.mark.parametrize("rich", [False, True])
+def test_records_in_several_chunks_keep_their_order(tmp_path, oracle, rich):
+    """The front end hands the records to the device 8192 at a time while it parses the next chunk (jl_records_append):
+    20 000 reads = three chunks.  Calls, read categories and — the part that depends on chunk ORDER — the read names of
+    every haplotype must be those of the reads in file order; with --min-qv the qualities travel in the same chunks."""
+    n, l, seed = 20_000, 300, 31
+    bam, cfg = str(tmp_path / "c.bam"), str(tmp_path / "c.json")
+    subprocess.check_call([SYNTH, "--reads", str(n), "--cols", str(l), "--seed", str(seed), "--partial", "0.15",
+                           *( ["--rich-qv"] if rich else []), "--minor-permille", "60", "50", "40", "30", "-o", bam, "--config-out", cfg])
+    sp = synth.SynthParams(seed=seed, partial_rate=0.15, minor_permille=(60, 50, 40, 30))
+    ref = synth.reference(seed, l)
+    rows = synth.rows(sp, l, 0, n, ref)
+    j = run_juliet(tmp_path, bam, "-c", cfg, "--mode-phasing", *(["--min-qv", "10"] if rich else []))
+    exp = oracle.call(rows, np.array([(1, l + 1)], dtype=capi.GENE), refseq=ref)
+    got = flat_variants(j)
+    assert [(r[1], r[2], r[3]["count"], r[4]["coverage"]) for r in got] == \
+        [(e["codon_pos"], e["codon"], e["count"], e["coverage"]) for e in exp] and len(exp) >= 4
+    ph = oracle.phase(rows, exp)
+    hb = j["haplotype"]
+    assert [h["reads"] for h in hb["haplotypes"]] == ph["hap_count"].tolist()
+    for hi, h in enumerate(hb["haplotypes"]):
+        idx = [int(nm.split("/")[1]) for nm in h["read_names"]]
+        assert idx == np.nonzero(ph["read_hap"] == hi)[0].tolist()      # file order, across the chunk boundaries at 8192, 16384
+    assert hb["reported_reads"] + hb["insufficient_coverage_reads"] + hb["damaged_reads"] == n
+
+
 class _Dom:
     """Minimal HTML tree (tag, attrs, children, text) — enough to read the page back cell by cell."""
 
