@@ -65,8 +65,9 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(const uint8_t *__restric
 //                        all 8 columns lie inside one op (runs of '=' are tens of columns long) they are taken at
 //                        once — eight packed BAM bases fetched as two dwords, converted nibble-parallel — otherwise
 //                        column by column.  No divergence over reads: a wave only ever looks at one cigar.
-//   transpose_rows_kernel  by-row nibbles -> the column-packed matrix through a 256-read x 256-column LDS tile (bank-
-//                        conflict-free both ways), 8 x 8 nibble blocks transposed in registers: 128-byte reads and writes.
+//   transpose_rows_kernel  by-row nibbles -> the column-packed matrix through a 256-read x 256-column LDS tile, 8 x 8
+//                        nibble blocks transposed in registers: 128-byte reads (16 bytes per lane, eight loads in
+//                        flight per thread) and writes.  300 MB in 50 us = 6 TB/s.
 // (The first build walked one read per LANE while the wave swept the columns: some lane of 64 changed its op at
 // nearly every column and the kernel was bound by the cursor's instructions under divergence, 0.29 TB/s.)
 // Reads past n_reads (the padding of a column up to its 128-byte stride) and columns outside a read's span are 'not covered'.
@@ -286,12 +287,21 @@ __global__ __launch_bounds__(256) void transpose_rows_kernel(const uint32_t *__r
     const uint32_t tid = threadIdx.x;
     const uint64_t rb = (uint64_t)blockIdx.x * 256u;          // first read of the tile, within the batch
     const uint32_t d0 = blockIdx.y * 32u;                     // first dword of the tile's columns
-#pragma unroll 8
-    for (uint32_t i = tid; i < 256u * 32u; i += 256u) {
-        const uint32_t rr = i >> 5, dd = i & 31u;
-        uint32_t v = 0x66666666u;
-        if (rb + rr < n_batch && d0 + dd < row_dwords) v = rows4[(rb + rr) * (uint64_t)row_dwords + d0 + dd];
-        s_t[(rr & 7u) * kTrOct + (rr >> 3) * 33u + dd] = v;
+    // 16 bytes per lane and load, all eight of a thread in flight before the first is used (dword loads left the kernel
+    // at 1.7 TB/s: too few bytes in flight); the scratch rows are 128-byte aligned, so a piece never leaves its row
+    uint4 v[8];
+#pragma unroll
+    for (uint32_t k = 0; k < 8u; ++k) {
+        const uint32_t i = tid + 256u * k, rr = i >> 3, q = i & 7u;
+        v[k] = make_uint4(0x66666666u, 0x66666666u, 0x66666666u, 0x66666666u);
+        if (rb + rr < n_batch && d0 + 4u * q < row_dwords)
+            v[k] = *reinterpret_cast<const uint4 *>(rows4 + (rb + rr) * (uint64_t)row_dwords + d0 + 4u * q);
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < 8u; ++k) {
+        const uint32_t i = tid + 256u * k, rr = i >> 3, q = i & 7u;
+        uint32_t *dst = s_t + (rr & 7u) * kTrOct + (rr >> 3) * 33u + 4u * q;
+        dst[0] = v[k].x; dst[1] = v[k].y; dst[2] = v[k].z; dst[3] = v[k].w;
     }
     __syncthreads();
     // 32 groups of 8 reads x 32 dwords of 8 columns: 8 x 8 nibbles at a time, 128-byte segments of 8 columns out
@@ -465,7 +475,9 @@ void jl_launch_validate(jl_ctx *ctx, uint32_t *d_flag)
 }
 
 // rows4: scratch of jl_ingest_batch_reads(ctx) x jl_ingest_row_dwords(ctx) dwords
-uint32_t jl_ingest_row_dwords(const jl_ctx *ctx) { return (ctx->n_cols + 7u) / 8u; }
+// a by-row scratch row holds 8 columns per dword; rows start on 128-byte lines, so that a transpose tile's 128-byte
+// pieces of 256 rows are whole lines (unaligned they straddle two: 1.5x the read traffic)
+uint32_t jl_ingest_row_dwords(const jl_ctx *ctx) { return ((ctx->n_cols + 7u) / 8u + 31u) & ~31u; }
 uint64_t jl_ingest_batch_reads(const jl_ctx *ctx)
 {
     const uint64_t pad = ctx->col_stride * 2u;   // reads incl. the padding of a column: a multiple of 256
