@@ -388,6 +388,37 @@ int jl_xwin_assemble_rccl(jl_ctx *pc, jl_ctx *window, jl_comm *comm, const uint3
                           const uint32_t *win_ncols, const jl_variant *merged, uint32_t n_var, jl_variant *remapped,
                           uint32_t *pos_global, uint32_t *vp_total);
 
+/*
+ * Cross-window phasing with the READS sharded (SURVEY §8e option A; docs/SPEC.md §8).  Rank s phases reads
+ * [slice_begin[s], slice_begin[s+1]) only: its compact matrix holds that slice of every variant position's three columns,
+ * so the second exchange moves 1/world of the bytes and every rank groups 1/world of the reads.  Sequence per rank:
+ *   jl_xwin_assemble_slice_*  ->  jl_phase_groups_async  ->  jl_phase_groups_fetch  (this slice's groups: pattern + count)
+ *   all-gather of the group tables (KB) and merge on the host: counts of equal patterns add up; the merged groups with
+ *     >= min_reads reads are the haplotypes, ordered as SPEC §8 says; hit and co-occurrence follow from patterns and counts
+ *   jl_phase_regroup          (each exported group's haplotype id back to the device: per-read ids of the slice)
+ * Slices start on multiples of 256 reads.  The host side of the merge is minorseq_amd/sharding.py (merge_groups,
+ * select_haplotypes); tests/test_gpu_sharded_phase.py checks the whole sequence against the unsharded run.
+ */
+int jl_xwin_assemble_slice_local(jl_ctx *pc, jl_ctx *const *windows, uint32_t n_windows, const jl_variant *merged,
+                                 uint32_t n_var, uint64_t read_begin, uint64_t n_slice, jl_variant *remapped,
+                                 uint32_t *pos_global, uint32_t *vp_total);
+/* one window per rank: the owner of a position sends rank s its slice (ncclSend / ncclRecv in one group);
+ * slice_begin has world + 1 entries, the same on every rank */
+int jl_xwin_assemble_slice_rccl(jl_ctx *pc, jl_ctx *window, jl_comm *comm, const uint32_t *win_begin,
+                                const uint32_t *win_ncols, const jl_variant *merged, uint32_t n_var,
+                                const uint64_t *slice_begin, jl_variant *remapped, uint32_t *pos_global, uint32_t *vp_total);
+/* keys + grouping of the resident matrix, the groups written out instead of ranked (variants as in jl_phase_async) */
+int jl_phase_groups_async(jl_ctx *ctx, const jl_variant *variants, uint32_t n_var);
+/* group q: counts[q] reads with codon code patterns[q * pattern_stride + p] at variant position p (pos_cols[p]);
+ * *partial: this matrix's damaged reads and marginals, its clean reads under insufficient_reads.  Pointers except
+ * n_groups / n_positions may be NULL. */
+int jl_phase_groups_fetch(jl_ctx *ctx, uint8_t *patterns, uint32_t pattern_stride, uint32_t *counts, uint32_t cap_groups,
+                          uint32_t *n_groups, uint32_t *n_positions, uint32_t *pos_cols, uint32_t cap_var,
+                          jl_phase_summary *partial);
+/* hap_of_group[q] = haplotype id of exported group q after the merge (JL_HAP_INSUFFICIENT: not reported);
+ * read_hap (optional, [n_reads of this matrix]) receives the per-read ids */
+int jl_phase_regroup(jl_ctx *ctx, const uint16_t *hap_of_group, uint32_t n_groups, uint32_t n_haplotypes, uint16_t *read_hap);
+
 #ifdef __cplusplus
 }
 #endif

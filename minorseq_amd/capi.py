@@ -34,7 +34,8 @@ EXPORTS = ("jl_abi_version", "jl_strerror", "jl_device_count", "jl_ctx_create", 
            "jl_run_async", "jl_run_wait", "jl_run_done", "jl_run_view_get", "jl_group_create", "jl_group_destroy",
            "jl_group_last_error", "jl_group_run_async", "jl_group_run_masked_async", "jl_group_time_pileup", "jl_fisher_eval", "jl_fisher_eval_tail", "jl_expand_read_hap", "jl_time_pileup", "jl_time_pileup_set", "jl_pileup_kernel_name", "jl_comm_unique_id", "jl_comm_create", "jl_comm_destroy",
            "jl_allgather_variants", "jl_allgather_variants_async", "jl_allgather_variants_async_many", "jl_xwin_plan", "jl_xwin_assemble_local",
-           "jl_xwin_assemble_rccl")
+           "jl_xwin_assemble_rccl", "jl_xwin_assemble_slice_local", "jl_xwin_assemble_slice_rccl", "jl_phase_groups_async",
+           "jl_phase_groups_fetch", "jl_phase_regroup")
 
 
 class ErrorModel(C.Structure):
@@ -186,6 +187,11 @@ def load_library(path=LIB_PATH):
     lib.jl_xwin_plan.argtypes = [vp, vp, u32, vp, u32, vp, vp, vp, C.POINTER(u32)]
     lib.jl_xwin_assemble_local.argtypes = [vp, vp, u32, vp, u32, vp, vp, C.POINTER(u32)]
     lib.jl_xwin_assemble_rccl.argtypes = [vp, vp, vp, vp, vp, vp, u32, vp, vp, C.POINTER(u32)]
+    lib.jl_xwin_assemble_slice_local.argtypes = [vp, vp, u32, vp, u32, u64, u64, vp, vp, C.POINTER(u32)]
+    lib.jl_xwin_assemble_slice_rccl.argtypes = [vp, vp, vp, vp, vp, vp, u32, vp, vp, vp, C.POINTER(u32)]
+    lib.jl_phase_groups_async.argtypes = [vp, vp, u32]
+    lib.jl_phase_groups_fetch.argtypes = [vp, vp, u32, vp, u32, C.POINTER(u32), C.POINTER(u32), vp, u32, vp]
+    lib.jl_phase_regroup.argtypes = [vp, vp, u32, u32, vp]
     if lib.jl_abi_version() != 3:
         raise ImportError("libjuliet_hip.so ABI version mismatch")
     _lib = lib
@@ -417,6 +423,49 @@ class Juliet:
         return dict(summary=s, pos_cols=pos_cols[:vp].copy(), hap_count=hap_count[:h].copy(),
                     hap_pattern=hap_pattern[:h, :vp].copy(), hit=hit, read_hap=read_hap, cooc=cooc)
 
+    # ------------------------------------------------------------------ phasing sharded by reads (SURVEY §8e option A)
+    def phase_groups_async(self, variants):
+        """Keys + grouping of the resident matrix (a slice of the reads); the groups are exported, not ranked."""
+        variants = np.ascontiguousarray(variants, dtype=VARIANT)
+        buf = variants if len(variants) else np.zeros(1, dtype=VARIANT)
+        self._chk(self.lib.jl_phase_groups_async(self.h, _p(buf), len(variants)))
+
+    def phase_groups_fetch(self, cap_var=64):
+        """dict(patterns uint8[G][Vp], counts uint32[G], pos_cols, summary): the groups of the last phase_groups_async."""
+        ng, vp = C.c_uint32(), C.c_uint32()
+        summ = np.zeros(1, dtype=SUMMARY)
+        self._chk(self.lib.jl_phase_groups_fetch(self.h, None, 0, None, 0, C.byref(ng), C.byref(vp), None, 0, _p(summ)))
+        g, v = ng.value, vp.value
+        patterns = np.zeros((max(g, 1), max(v, 1)), dtype=np.uint8)
+        counts = np.zeros(max(g, 1), dtype=np.uint32)
+        pos_cols = np.zeros(max(v, 1), dtype=np.uint32)
+        self._chk(self.lib.jl_phase_groups_fetch(self.h, _p(patterns), patterns.shape[1], _p(counts), len(counts), C.byref(ng),
+                                                 C.byref(vp), _p(pos_cols), len(pos_cols), _p(summ)))
+        return dict(patterns=patterns[:g, :v].copy(), counts=counts[:g].copy(), pos_cols=pos_cols[:v].copy(),
+                    summary={k: int(summ[0][k]) for k in SUMMARY_FIELDS})
+
+    def phase_regroup(self, hap_of_group, n_haplotypes, want_reads=True):
+        """hap_of_group[q] = haplotype of exported group q after the merge (HAP_INSUFFICIENT: not reported) -> per-read ids."""
+        hap = np.ascontiguousarray(hap_of_group, dtype=np.uint16)
+        read_hap = np.zeros(self.n_reads, dtype=np.uint16) if want_reads else None
+        self._chk(self.lib.jl_phase_regroup(self.h, _p(hap if len(hap) else np.zeros(1, dtype=np.uint16)), len(hap), n_haplotypes,
+                                            _p(read_hap)))
+        return read_hap
+
+    def xwin_assemble_slice_local(self, windows, merged, read_begin, n_slice):
+        """This context becomes the compact matrix of reads [read_begin, read_begin + n_slice) of the windows' variant
+        columns.  Returns (remapped table, pos_global)."""
+        merged = np.ascontiguousarray(merged, dtype=VARIANT)
+        arr = (C.c_void_p * len(windows))(*[w.h for w in windows])
+        remapped = np.zeros(max(len(merged), 1), dtype=VARIANT)
+        pos_global = np.zeros(max(len(merged), 1), dtype=np.uint32)
+        vp = C.c_uint32()
+        self._chk(self.lib.jl_xwin_assemble_slice_local(self.h, arr, len(windows), _p(merged if len(merged) else remapped), len(merged),
+                                                        read_begin, n_slice, _p(remapped), _p(pos_global), C.byref(vp)))
+        if vp.value and n_slice:
+            self._shape(n_slice, 3 * vp.value, self.lib.jl_col_stride(n_slice))
+        return remapped[: len(merged)], pos_global[: vp.value]
+
     def fisher_eval(self, a, c, cov, tail=0):
         a, c, cov = (np.ascontiguousarray(x, dtype=np.uint32) for x in (a, c, cov))
         p = np.zeros(len(a), dtype=np.float64)
@@ -610,6 +659,49 @@ def phase_across_windows(windows, merged, min_reads=10, comm=None, win_begins=No
         ph["cooc"] = ph["cooc"][: len(merged), : len(merged)].copy()
     pc.close()
     return ph, pos_global[: vp.value].copy()
+
+
+def phase_sharded_by_reads(windows, merged, n_shards, min_reads=10, device=0, want_reads=True):
+    """Cross-window phasing with the reads sharded (SURVEY §8e option A), every shard on THIS device — what the ranks of a
+    multi-GPU run do, one after the other: slice assembly, grouping + export per shard, merge and selection on the host
+    (sharding.merge_groups / select_haplotypes), the ids of every shard from jl_phase_regroup.
+    Returns (phase result as phase_across_windows gives it, global columns of the positions)."""
+    from . import sharding
+
+    merged = np.ascontiguousarray(merged, dtype=VARIANT)
+    n = windows[0].n_reads
+    bounds = sharding.read_slices(n, n_shards)
+    shards, tables, remapped, pos_global = [], [], None, None
+    for s in range(n_shards):
+        pc = Juliet(device)
+        remapped, pos_global = pc.xwin_assemble_slice_local(windows, merged, bounds[s], bounds[s + 1] - bounds[s])
+        if len(pos_global) == 0:
+            pc.close()
+            for q in shards:
+                q.close()
+            return None, pos_global
+        if bounds[s + 1] > bounds[s]:
+            pc.phase_groups_async(remapped)
+            tables.append(pc.phase_groups_fetch(cap_var=max(1, len(pos_global))))
+        else:   # a rank without reads contributes nothing
+            tables.append(dict(patterns=np.zeros((0, len(pos_global)), dtype=np.uint8), counts=np.zeros(0, dtype=np.uint32),
+                               pos_cols=3 * np.arange(len(pos_global), dtype=np.uint32),
+                               summary={k: 0 for k in SUMMARY_FIELDS}))
+        shards.append(pc)
+    patterns, counts, index = sharding.merge_groups(tables)
+    pos_cols = next(t["pos_cols"] for t in tables if len(t["pos_cols"]))
+    ph = sharding.select_haplotypes(patterns, counts, remapped, pos_cols, min_reads, [t["summary"] for t in tables])
+    ids = []
+    for s, pc in enumerate(shards):
+        if bounds[s + 1] > bounds[s]:
+            hap = ph["hap_of_merged"][index[s]].astype(np.uint16)
+            r = pc.phase_regroup(hap, ph["summary"]["n_haplotypes"], want_reads)
+            if want_reads:
+                ids.append(r)
+        pc.close()
+    ph["read_hap"] = np.concatenate(ids) if want_reads and ids else None
+    ph["pos_cols"] = pos_global.copy()
+    return ph, pos_global.copy()
 
 
 class Group:

@@ -151,7 +151,8 @@ void jl_ctx_destroy(jl_ctx *ctx)
                     ctx->d_col2pos, ctx->d_varcol, ctx->d_keys, ctx->d_flagw, ctx->d_read_slot, ctx->d_read_hap,
                     ctx->d_slot_rep, ctx->d_slot_count, ctx->d_slot_key, ctx->d_slot_hap, ctx->d_occupied, ctx->d_hap_count,
                     ctx->d_hap_pattern, ctx->d_hit, ctx->d_cooc, ctx->d_pack, ctx->d_sync, ctx->d_timeline,
-                    ctx->d_col_first, ctx->d_pos_next, ctx->d_callinfo, ctx->d_ins_len, ctx->d_ins_base};
+                    ctx->d_col_first, ctx->d_pos_next, ctx->d_callinfo, ctx->d_ins_len, ctx->d_ins_base, ctx->d_exp_count,
+                    ctx->d_exp_pattern, ctx->d_exp_hap};
     for (void *p : ptrs)
         if (p) hipFree(p);
     if (ctx->ev0) hipEventDestroy(ctx->ev0);
@@ -896,7 +897,29 @@ static int reserve_phase(jl_ctx *ctx, uint32_t kwords_needed)
     return JL_OK;
 }
 
-int jl_phase_async(jl_ctx *ctx, const jl_variant *variants, uint32_t n_var, uint32_t min_reads)
+// room for the groups an exporting run writes out: one count and kwords * JL_POS_PER_WORD pattern bytes per group, for
+// as many groups as the table can hold, within 256 MB
+static int reserve_export(jl_ctx *ctx, uint32_t kwords)
+{
+    const uint32_t stride = kwords * JL_POS_PER_WORD;
+    uint64_t cap = ctx->table_slots ? ctx->table_slots : 1024;
+    const uint64_t budget = ((uint64_t)256 << 20) / stride;
+    if (cap > budget) cap = budget;
+    if (ctx->exp_cap >= cap && ctx->exp_stride >= stride) return JL_OK;
+    void *old[] = {ctx->d_exp_count, ctx->d_exp_pattern, ctx->d_exp_hap};
+    for (void *p : old)
+        if (p) hipFree(p);
+    ctx->d_exp_count = nullptr; ctx->d_exp_pattern = nullptr; ctx->d_exp_hap = nullptr;
+    ctx->exp_cap = ctx->exp_stride = 0;
+    JL_HIP(ctx, hipMalloc(&ctx->d_exp_count, (size_t)cap * 4));
+    JL_HIP(ctx, hipMalloc(&ctx->d_exp_pattern, (size_t)cap * stride));
+    JL_HIP(ctx, hipMalloc(&ctx->d_exp_hap, (size_t)cap * 2));
+    ctx->exp_cap = (uint32_t)cap;
+    ctx->exp_stride = stride;
+    return JL_OK;
+}
+
+static int phase_async_impl(jl_ctx *ctx, const jl_variant *variants, uint32_t n_var, uint32_t min_reads, bool exporting)
 {
     if (!ctx) return JL_ERR_ARG;
     if (!ctx->d_msa) return jl_fail(ctx, JL_ERR_STATE, "no resident matrix");
@@ -923,6 +946,8 @@ int jl_phase_async(jl_ctx *ctx, const jl_variant *variants, uint32_t n_var, uint
     if (kwords == 0) kwords = 1;
     int rc = reserve_phase(ctx, kwords);
     if (rc) return rc;
+    if (exporting && (rc = reserve_export(ctx, kwords))) return rc;
+    ctx->phase_export = exporting;
     ctx->last_min_reads = min_reads;
     ctx->pack_mirror = nullptr;
     ctx->read_hap_out = nullptr;
@@ -931,6 +956,18 @@ int jl_phase_async(jl_ctx *ctx, const jl_variant *variants, uint32_t n_var, uint
     ctx->phase_done = true;
     ctx->pack_valid = false;
     return JL_OK;
+}
+
+int jl_phase_async(jl_ctx *ctx, const jl_variant *variants, uint32_t n_var, uint32_t min_reads)
+{
+    return phase_async_impl(ctx, variants, n_var, min_reads, false);
+}
+
+// Phasing sharded by reads (SURVEY §8e option A): keys and grouping of THIS matrix (a slice of the reads), the groups
+// written out instead of ranked.  Every read keeps its flags and its slot for jl_phase_regroup.
+int jl_phase_groups_async(jl_ctx *ctx, const jl_variant *variants, uint32_t n_var)
+{
+    return phase_async_impl(ctx, variants, n_var, 0xFFFFFFFFu, true);
 }
 
 // per-read ids in their packed form -> 16-bit ids (JL_ID4_MAX_H / JL_ID8_MAX_H in jl_internal.h)
@@ -972,6 +1009,34 @@ static int fetch_ids(jl_ctx *ctx, uint32_t bits, uint16_t *read_hap)
     return JL_OK;
 }
 
+// Waits for the last phase launch and reads its scalars; a launch that found more variant positions than its kernels
+// or its key buffer cover is run again with what it needs (the variant table is resident).
+static int phase_settle(jl_ctx *ctx, jl_phase_meta *out)
+{
+    hipStream_t st = ctx->stream;
+    if (ctx->run_stream && ctx->run_stream != st) JL_HIP(ctx, hipStreamSynchronize(ctx->run_stream));
+    jl_phase_meta meta;
+    JL_HIP(ctx, hipMemcpyAsync(&meta, ctx->d_meta, sizeof meta, hipMemcpyDeviceToHost, st));
+    JL_HIP(ctx, hipStreamSynchronize(st));
+    if (meta.overflow & 12u) {
+        // more variant positions than the single-word kernels (bit 3) or the resident key buffer (bit 2) cover:
+        // switch to the generic pipeline / grow the buffer and run phasing again (the variant table is resident)
+        if (meta.vp_true > JL_POS_PER_WORD) ctx->phase_generic = true;
+        for (int attempt = 0; attempt < 2 && (meta.overflow & 12u); ++attempt) {
+            const uint32_t kw = (meta.vp_true + JL_POS_PER_WORD - 1) / JL_POS_PER_WORD;
+            int rc = reserve_phase(ctx, kw);
+            if (rc == JL_OK && ctx->phase_export) rc = reserve_export(ctx, kw);
+            if (rc) return rc;
+            jl_launch_phase(ctx, st, ctx->last_min_reads, false, false, false);
+            JL_HIP(ctx, hipGetLastError());
+            JL_HIP(ctx, hipMemcpyAsync(&meta, ctx->d_meta, sizeof meta, hipMemcpyDeviceToHost, st));
+            JL_HIP(ctx, hipStreamSynchronize(st));
+        }
+    }
+    *out = meta;
+    return JL_OK;
+}
+
 int jl_phase_fetch(jl_ctx *ctx, jl_phase_summary *summary, uint32_t *pos_cols, uint32_t *hap_count,
                    uint8_t *hap_pattern, uint8_t *hit, uint16_t *read_hap, uint32_t *cooc, uint32_t cap_var)
 {
@@ -1003,29 +1068,8 @@ int jl_phase_fetch(jl_ctx *ctx, jl_phase_summary *summary, uint32_t *pos_cols, u
             return JL_OK;
         }
     }
-    if (ctx->run_stream && ctx->run_stream != st) JL_HIP(ctx, hipStreamSynchronize(ctx->run_stream));
     jl_phase_meta meta;
-    JL_HIP(ctx, hipMemcpyAsync(&meta, ctx->d_meta, sizeof meta, hipMemcpyDeviceToHost, st));
-    JL_HIP(ctx, hipStreamSynchronize(st));
-    if (meta.overflow & 12u) {
-        // more variant positions than the single-word kernels (bit 3) or the resident key buffer (bit 2) cover:
-        // switch to the generic pipeline / grow the buffer and run phasing again (the variant table is resident)
-        if (meta.vp_true > JL_POS_PER_WORD) ctx->phase_generic = true;
-        int rc = reserve_phase(ctx, (meta.vp_true + JL_POS_PER_WORD - 1) / JL_POS_PER_WORD);
-        if (rc) return rc;
-        jl_launch_phase(ctx, st, ctx->last_min_reads, false, false, false);
-        JL_HIP(ctx, hipGetLastError());
-        JL_HIP(ctx, hipMemcpyAsync(&meta, ctx->d_meta, sizeof meta, hipMemcpyDeviceToHost, st));
-        JL_HIP(ctx, hipStreamSynchronize(st));
-        if (meta.overflow & 4u) {   // the first re-run only learned the true number of positions: now with room for them
-            rc = reserve_phase(ctx, (meta.vp_true + JL_POS_PER_WORD - 1) / JL_POS_PER_WORD);
-            if (rc) return rc;
-            jl_launch_phase(ctx, st, ctx->last_min_reads, false, false, false);
-            JL_HIP(ctx, hipGetLastError());
-            JL_HIP(ctx, hipMemcpyAsync(&meta, ctx->d_meta, sizeof meta, hipMemcpyDeviceToHost, st));
-            JL_HIP(ctx, hipStreamSynchronize(st));
-        }
-    }
+    if (int rc = phase_settle(ctx, &meta)) return rc;
     if (read_hap)
         if (int rc = fetch_ids(ctx, meta.id_bits, read_hap)) return rc;
     if (summary) *summary = meta.summary;
@@ -1044,6 +1088,60 @@ int jl_phase_fetch(jl_ctx *ctx, jl_phase_summary *summary, uint32_t *pos_cols, u
     }
     JL_HIP(ctx, hipStreamSynchronize(st));
     if (meta.overflow & 1u) return jl_fail(ctx, JL_ERR_OVERFLOW, "more than %u haplotype candidates", JL_CAND_CAP);
+    return JL_OK;
+}
+
+// The groups of the last jl_phase_groups_async: for group q (the order is kept for jl_phase_regroup) its read count and
+// its pattern, one codon code per variant position (patterns[q * pattern_stride + p]); the partial summary holds this
+// matrix's damaged reads and marginals, its clean reads under insufficient_reads.
+int jl_phase_groups_fetch(jl_ctx *ctx, uint8_t *patterns, uint32_t pattern_stride, uint32_t *counts, uint32_t cap_groups,
+                          uint32_t *n_groups, uint32_t *n_positions, uint32_t *pos_cols, uint32_t cap_var,
+                          jl_phase_summary *partial)
+{
+    if (!ctx || !n_groups || !n_positions) return JL_ERR_ARG;
+    if (!ctx->phase_done || !ctx->phase_export) return jl_fail(ctx, JL_ERR_STATE, "jl_phase_groups_fetch needs jl_phase_groups_async first");
+    jl_phase_meta meta;
+    if (int rc = phase_settle(ctx, &meta)) return rc;
+    if (meta.overflow & 16u)
+        return jl_fail(ctx, JL_ERR_OVERFLOW, "%u groups of reads, the export holds %u", meta.n_occupied, ctx->exp_cap);
+    const uint32_t vp = meta.vp, ng = vp ? meta.n_occupied : 0u;
+    *n_groups = ng;
+    *n_positions = vp;
+    if (partial) *partial = meta.summary;
+    if (pos_cols && vp > cap_var) return jl_fail(ctx, JL_ERR_OVERFLOW, "%u variant positions, caller capacity %u", vp, cap_var);
+    if ((patterns || counts) && ng > cap_groups) return jl_fail(ctx, JL_ERR_OVERFLOW, "%u groups, caller capacity %u", ng, cap_groups);
+    if (patterns && vp > pattern_stride) return jl_fail(ctx, JL_ERR_OVERFLOW, "%u variant positions, pattern stride %u", vp, pattern_stride);
+    hipStream_t st = ctx->stream;
+    if (pos_cols && vp) JL_HIP(ctx, hipMemcpyAsync(pos_cols, ctx->d_vpcols, (size_t)vp * 4, hipMemcpyDeviceToHost, st));
+    if (counts && ng) JL_HIP(ctx, hipMemcpyAsync(counts, ctx->d_exp_count, (size_t)ng * 4, hipMemcpyDeviceToHost, st));
+    if (patterns && ng && vp)
+        JL_HIP(ctx, hipMemcpy2DAsync(patterns, pattern_stride, ctx->d_exp_pattern, ctx->exp_stride, vp, ng, hipMemcpyDeviceToHost, st));
+    JL_HIP(ctx, hipStreamSynchronize(st));
+    return JL_OK;
+}
+
+// The merge's answer: hap_of_group[q] = haplotype id of exported group q (JL_HAP_INSUFFICIENT for a group that is not
+// reported), n_haplotypes = haplotypes reported in all.  Maps this matrix's reads; read_hap (optional, [n_reads]) gets
+// their ids (JL_HAP_DAMAGED for flagged reads).
+int jl_phase_regroup(jl_ctx *ctx, const uint16_t *hap_of_group, uint32_t n_groups, uint32_t n_haplotypes, uint16_t *read_hap)
+{
+    if (!ctx || (!hap_of_group && n_groups)) return JL_ERR_ARG;
+    if (!ctx->phase_done || !ctx->phase_export) return jl_fail(ctx, JL_ERR_STATE, "jl_phase_regroup needs jl_phase_groups_async first");
+    if (n_groups > ctx->exp_cap) return jl_fail(ctx, JL_ERR_ARG, "%u groups, the export held %u", n_groups, ctx->exp_cap);
+    if (n_haplotypes > JL_MAX_HAPLOTYPES) return jl_fail(ctx, JL_ERR_ARG, "%u haplotypes, at most %u have names", n_haplotypes, JL_MAX_HAPLOTYPES);
+    for (uint32_t q = 0; q < n_groups; ++q)
+        if (hap_of_group[q] != JL_HAP_INSUFFICIENT && hap_of_group[q] >= n_haplotypes)
+            return jl_fail(ctx, JL_ERR_ARG, "group %u: haplotype %u of %u", q, hap_of_group[q], n_haplotypes);
+    JL_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    if (n_groups) JL_HIP(ctx, hipMemcpyAsync(ctx->d_exp_hap, hap_of_group, (size_t)n_groups * 2, hipMemcpyHostToDevice, st));
+    jl_launch_regroup(ctx, ctx->d_exp_hap, n_groups, n_haplotypes);
+    JL_HIP(ctx, hipGetLastError());
+    JL_HIP(ctx, hipStreamSynchronize(st));   // hap_of_group may be pageable: the copy has read it by now
+    if (read_hap) {
+        const uint32_t bits = n_haplotypes <= JL_ID4_MAX_H ? 4u : (n_haplotypes <= JL_ID8_MAX_H ? 8u : 16u);
+        if (int rc = fetch_ids(ctx, bits, read_hap)) return rc;
+    }
     return JL_OK;
 }
 
@@ -1093,6 +1191,7 @@ int jl_run_prepare(jl_ctx *ctx, const jl_gene *genes, uint32_t n_genes, const ui
 {
     if (!ctx || !prm || (!genes && n_genes)) return JL_ERR_ARG;
     if (!ctx->d_msa) return jl_fail(ctx, JL_ERR_STATE, "no resident matrix: call jl_msa_upload/alloc/adopt first");
+    ctx->phase_export = false;
     if (prm->tail != 0 && prm->tail != 1) return jl_fail(ctx, JL_ERR_ARG, "tail must be 0 (one-sided greater) or 1 (two-sided)");
     if (!(prm->alpha > 0.0) || !(prm->err.match > 0.0) || !(prm->err.substitution >= 0.0))
         return jl_fail(ctx, JL_ERR_ARG, "alpha/match must be > 0 and substitution >= 0");

@@ -581,4 +581,111 @@ int jl_xwin_assemble_rccl(jl_ctx *pc, jl_ctx *window, jl_comm *c, const uint32_t
     return JL_OK;
 }
 
+// ---- the same with the READS sharded (SURVEY §8e option A): the compact matrix holds reads [read_begin,
+// read_begin + n_slice) only, so a rank phases 1/world of the reads and the second exchange moves 1/world of the bytes.
+// read_begin must be a multiple of 256 (a slice starts on a 128-byte line of every column).
+static int xwin_slice_alloc(jl_ctx *pc, uint64_t n_slice, uint32_t vp)
+{
+    int rc = jl_msa_alloc(pc, n_slice, 3u * vp, 0);
+    if (rc) return rc;
+    // padding nibbles of a column (reads past the slice) are 'not covered'
+    JL_HIP(pc, hipMemsetAsync(pc->d_msa, 0x66, (size_t)pc->col_stride * 3u * vp, pc->stream));
+    return JL_OK;
+}
+
+int jl_xwin_assemble_slice_local(jl_ctx *pc, jl_ctx *const *windows, uint32_t n_windows, const jl_variant *merged, uint32_t n_var,
+                                 uint64_t read_begin, uint64_t n_slice, jl_variant *remapped, uint32_t *pos_global,
+                                 uint32_t *vp_total)
+{
+    if (!pc || !windows || n_windows == 0 || (!merged && n_var) || !vp_total) return JL_ERR_ARG;
+    if (n_var > JL_VARIANT_CAP) return jl_fail(pc, JL_ERR_OVERFLOW, "%u variants, table holds %u", n_var, JL_VARIANT_CAP);
+    std::vector<uint32_t> wb(n_windows), wn(n_windows);
+    for (uint32_t w = 0; w < n_windows; ++w) {
+        if (!windows[w] || !windows[w]->d_msa) return jl_fail(pc, JL_ERR_ARG, "window %u has no resident matrix", w);
+        if (windows[w]->n_reads != windows[0]->n_reads || windows[w]->col_stride != windows[0]->col_stride)
+            return jl_fail(pc, JL_ERR_ARG, "windows must hold the same reads (window %u differs)", w);
+        wb[w] = windows[w]->win_begin;
+        wn[w] = windows[w]->n_cols;
+    }
+    const uint64_t n_reads = windows[0]->n_reads;
+    if ((n_slice && (read_begin & 255u)) || read_begin > n_reads || n_slice > n_reads - read_begin)
+        return jl_fail(pc, JL_ERR_ARG, "slice [%llu, +%llu) of %llu reads: the start must be a multiple of 256 and the slice inside",
+                       (unsigned long long)read_begin, (unsigned long long)n_slice, (unsigned long long)n_reads);
+    std::vector<uint32_t> pos(n_var ? n_var : 1);
+    const uint32_t vp = xwin_remap(merged, n_var, remapped, pos.data());
+    *vp_total = vp;
+    if (pos_global) std::copy(pos.begin(), pos.begin() + vp, pos_global);
+    if (vp == 0 || n_slice == 0) return JL_OK;
+    int rc = xwin_slice_alloc(pc, n_slice, vp);
+    if (rc) return rc;
+    const uint64_t src_stride = windows[0]->col_stride, bytes = (n_slice + 1u) / 2u;
+    for (uint32_t k = 0; k < vp; ++k) {
+        const int w = xwin_owner(wb.data(), wn.data(), n_windows, pos[k]);
+        if (w < 0) return jl_fail(pc, JL_ERR_ARG, "variant column %u is not fully inside any window", pos[k]);
+        JL_HIP(pc, hipStreamSynchronize(windows[w]->stream));
+        JL_HIP(pc, hipMemcpy2DAsync(pc->d_msa + (uint64_t)3 * k * pc->col_stride, pc->col_stride,
+                                    windows[w]->d_msa + (uint64_t)(pos[k] - wb[w]) * src_stride + read_begin / 2u, src_stride, bytes, 3,
+                                    hipMemcpyDeviceToDevice, pc->stream));
+    }
+    JL_HIP(pc, hipStreamSynchronize(pc->stream));
+    return JL_OK;
+}
+
+// One window per rank, reads sharded: rank s phases reads [slice_begin[s], slice_begin[s + 1]) (world + 1 entries, the
+// same on every rank, multiples of 256 except the last = n_reads).  The owner of each variant position sends rank s
+// that slice of its three columns (ncclSend / ncclRecv in one group; its own slice by a device copy).
+int jl_xwin_assemble_slice_rccl(jl_ctx *pc, jl_ctx *window, jl_comm *c, const uint32_t *win_begin, const uint32_t *win_ncols,
+                                const jl_variant *merged, uint32_t n_var, const uint64_t *slice_begin, jl_variant *remapped,
+                                uint32_t *pos_global, uint32_t *vp_total)
+{
+    if (!pc || !window || !c || !win_begin || !win_ncols || (!merged && n_var) || !slice_begin || !vp_total) return JL_ERR_ARG;
+    if (!window->d_msa) return jl_fail(pc, JL_ERR_ARG, "window has no resident matrix");
+    if (n_var > JL_VARIANT_CAP) return jl_fail(pc, JL_ERR_OVERFLOW, "%u variants, table holds %u", n_var, JL_VARIANT_CAP);
+    const int world = c->world, me = c->rank;
+    for (int s = 0; s < world; ++s)
+        if ((slice_begin[s + 1] > slice_begin[s] && (slice_begin[s] & 255u)) || slice_begin[s + 1] < slice_begin[s] ||
+            slice_begin[s + 1] > window->n_reads)
+            return jl_fail(pc, JL_ERR_ARG, "slice %d of the reads is not 256-aligned or not inside the %llu reads", s,
+                           (unsigned long long)window->n_reads);
+    std::vector<uint32_t> pos(n_var ? n_var : 1);
+    const uint32_t vp = xwin_remap(merged, n_var, remapped, pos.data());
+    *vp_total = vp;
+    if (pos_global) std::copy(pos.begin(), pos.begin() + vp, pos_global);
+    const uint64_t n_mine = slice_begin[me + 1] - slice_begin[me];
+    if (vp == 0) return JL_OK;
+    if (n_mine) {
+        int rc = xwin_slice_alloc(pc, n_mine, vp);
+        if (rc) return rc;
+    }
+    const uint64_t src_stride = window->col_stride;
+    JL_HIP(pc, hipStreamSynchronize(window->stream));
+    ncclResult_t r = ncclGroupStart();
+    for (uint32_t k = 0; k < vp && r == ncclSuccess; ++k) {
+        const int w = xwin_owner(win_begin, win_ncols, (uint32_t)world, pos[k]);
+        if (w < 0) { ncclGroupEnd(); return jl_fail(pc, JL_ERR_ARG, "variant column %u is not fully inside any window", pos[k]); }
+        for (uint32_t j = 0; j < 3u && r == ncclSuccess; ++j) {
+            if (w == me) {
+                const uint8_t *col = window->d_msa + (uint64_t)(pos[k] - win_begin[w] + j) * src_stride;
+                for (int s = 0; s < world && r == ncclSuccess; ++s) {
+                    const uint64_t bytes = (slice_begin[s + 1] - slice_begin[s] + 1u) / 2u;
+                    if (!bytes) continue;
+                    if (s == me) {
+                        if (hipMemcpyAsync(pc->d_msa + (uint64_t)(3u * k + j) * pc->col_stride, col + slice_begin[s] / 2u, bytes,
+                                           hipMemcpyDeviceToDevice, pc->stream) != hipSuccess) r = ncclUnhandledCudaError;
+                    } else {
+                        r = ncclSend(col + slice_begin[s] / 2u, bytes, ncclUint8, s, c->comm, pc->stream);
+                    }
+                }
+            } else if (n_mine) {
+                r = ncclRecv(pc->d_msa + (uint64_t)(3u * k + j) * pc->col_stride, (n_mine + 1u) / 2u, ncclUint8, w, c->comm, pc->stream);
+            }
+        }
+    }
+    if (r == ncclSuccess) r = ncclGroupEnd();
+    else ncclGroupEnd();
+    if (r != ncclSuccess) return jl_fail(pc, JL_ERR_COMM, "column slices: %s", ncclGetErrorString(r));
+    JL_HIP(pc, hipStreamSynchronize(pc->stream));
+    return JL_OK;
+}
+
 }  // extern "C"

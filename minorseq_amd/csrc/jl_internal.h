@@ -186,6 +186,12 @@ struct jl_select_args {
     jl_variant *rows;
     uint32_t *n_rows_out, *vpcols_out, *col2pos_out;
     uint32_t P, cap, kwords_cap, pad2_;
+    // export (phasing sharded by reads, SURVEY §8e option A): instead of ranking the groups of THIS matrix the
+    // selection writes them out — count and pattern of every occupied slot, in the order of the occupied list — for the
+    // host to merge with the other ranks' (jl_phase_groups_fetch); the per-read ids follow in jl_phase_regroup
+    uint32_t *exp_count;             // null: normal selection
+    uint8_t *exp_pattern;            // [exp_cap][exp_stride]
+    uint32_t exp_cap, exp_stride;
 };
 
 struct jl_done_ent {   // completion word of one window (see done_kernel)
@@ -261,6 +267,13 @@ struct jl_ctx {
 
     // ---- aligned records on their way in (jl_records_begin / _append / _finish)
     jl_records rec;
+
+    // ---- phasing sharded by reads: the groups of this matrix exported for the merge (jl_phase_groups_async / _fetch)
+    bool phase_export = false;        // the phase launch in flight / last run exported instead of selecting
+    uint32_t *d_exp_count = nullptr;  // [exp_cap]
+    uint8_t *d_exp_pattern = nullptr; // [exp_cap][exp_stride]
+    uint16_t *d_exp_hap = nullptr;    // [exp_cap] the merge's answer on its way to the slots
+    uint32_t exp_cap = 0, exp_stride = 0;
 
     // ---- pileup plan (host copies + device arrays)
     std::vector<jl_gene> genes;
@@ -405,6 +418,7 @@ void jl_launch_ingest(jl_ctx *ctx, const int32_t *d_pos, const uint32_t *d_cigar
                       const uint8_t *d_seq4, const uint64_t *d_seq_off, const uint8_t *d_qual,
                       const uint64_t *d_qual_off, uint32_t min_qv, uint32_t *d_rows4, uint64_t max_ops, uint64_t max_seq_bytes);
 uint32_t jl_ingest_row_dwords(const jl_ctx *ctx);
+void jl_launch_regroup(jl_ctx *ctx, const uint16_t *d_hap_of_group, uint32_t n_groups, uint32_t n_haplotypes);
 uint64_t jl_ingest_batch_reads(const jl_ctx *ctx);
 void jl_launch_insertions(jl_ctx *ctx, const int32_t *d_pos, const uint32_t *d_cigar, const uint64_t *d_cig_off,
                           const uint8_t *d_seq4, const uint64_t *d_seq_off);

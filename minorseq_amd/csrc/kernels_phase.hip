@@ -268,7 +268,9 @@ __device__ __forceinline__ void phase_select_block(uint32_t min_reads, uint64_t 
                                                    uint32_t *hap_count, uint8_t *hap_pattern, uint8_t *hit,
                                                    const uint32_t *n_rows, const uint32_t *vpcols, uint32_t *cooc,
                                                    uint32_t cooc_cap, jl_pack *pk, jl_pack *mirror,
-                                                   unsigned long long *slot_key, uint32_t *seq_dev, uint32_t *lds)
+                                                   unsigned long long *slot_key, uint32_t *seq_dev, uint32_t *lds,
+                                                   uint32_t *exp_count = nullptr, uint8_t *exp_pattern = nullptr,
+                                                   uint32_t exp_cap = 0, uint32_t exp_stride = 0)
 {
     // `lds`: JL_SELECT_LDS_WORDS words of LDS of the caller (the fused launch lends the tables its grouping is done with)
     uint32_t *s_cand = lds;                               // [JL_CAND_CAP] slot of each candidate
@@ -279,7 +281,30 @@ __device__ __forceinline__ void phase_select_block(uint32_t min_reads, uint64_t 
     const uint32_t kwords = ld_coherent(&meta->kwords);
     const uint32_t nv = ld_coherent(&meta->n_var);
     const uint32_t n_occ = ld_coherent(&meta->n_occupied);
-    if (vp != 0) {  // block-uniform
+    if (vp != 0 && exp_count) {  // block-uniform: the groups go out as they are (see jl_select_args)
+        if (tid == 0) s_insufficient = 0;
+        __syncthreads();
+        for (uint32_t q = tid; q < n_occ; q += nt) {
+            const uint32_t s = ld_coherent(&occupied[q]);
+            const uint32_t c = ld_coherent(&slot_count[s]);
+            atomicAdd(&s_insufficient, c);
+            __hip_atomic_store(&slot_hap[s], (uint32_t)JL_HAP_INSUFFICIENT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (q < exp_cap) {
+                exp_count[q] = c;
+                const uint32_t rep = BYKEY ? s : ld_coherent(&slot_rep[s]);
+                for (uint32_t p = 0; p < vp; ++p)
+                    exp_pattern[(uint64_t)q * exp_stride + p] = (uint8_t)pattern_code<BYKEY>(keys, slot_key, reads_pad, vp, rep, p);
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            if (n_occ > exp_cap) meta->overflow |= 16u;
+            meta->summary.reported_reads = 0;
+            meta->summary.insufficient_reads = s_insufficient;   // clean reads: the merge decides which are reported
+            meta->summary.n_haplotypes = 0;
+            __hip_atomic_store(&meta->id_bits, 16u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    } else if (vp != 0) {  // block-uniform
     if (tid == 0) { s_ncand = 0; s_insufficient = 0; s_reported = 0; s_nhap = 0; }
     __syncthreads();
     for (uint32_t q = tid; q < n_occ; q += nt) {
@@ -398,12 +423,14 @@ __global__ __launch_bounds__(1024) void phase_select_kernel(uint32_t min_reads, 
                                                              const uint32_t *n_rows, const uint32_t *vpcols,
                                                              uint32_t *cooc, uint32_t cooc_cap, jl_pack *pk,
                                                              jl_pack *mirror, unsigned long long *slot_key,
-                                                             uint32_t *seq_dev, volatile uint32_t *seq_host)
+                                                             uint32_t *seq_dev, volatile uint32_t *seq_host,
+                                                             uint32_t *exp_count, uint8_t *exp_pattern, uint32_t exp_cap,
+                                                             uint32_t exp_stride)
 {
     __shared__ uint32_t s_select[JL_SELECT_LDS_WORDS];
     phase_select_block<false>(min_reads, reads_pad, keys, meta, slot_rep, slot_count, occupied, slot_hap, variants, col2pos,
                               n_cols, hap_count, hap_pattern, hit, n_rows, vpcols, cooc, cooc_cap, pk, mirror, slot_key, seq_dev,
-                              s_select);
+                              s_select, exp_count, exp_pattern, exp_cap, exp_stride);
     if (seq_host) {  // last kernel of the run: the result block is on its way to the host
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -910,12 +937,13 @@ __device__ __forceinline__ void phase_fused1_body(const jl_win_phase &w)
         uint32_t nv = from_called ? (n_rows < S.cap ? n_rows : S.cap) : ld_coherent(&meta->n_var);
         if (!from_called) n_rows = ld_coherent(&S.n_rows[0]);
         bool done = false;
-        if (work) done = phase_select_lds(w, s_plan, vp, nv, n_rows, *reinterpret_cast<sel_lds *>(s_tables));
+        if (work && !S.exp_count) done = phase_select_lds(w, s_plan, vp, nv, n_rows, *reinterpret_cast<sel_lds *>(s_tables));
         if (!done) {
             __syncthreads();
             phase_select_block<true>(S.min_reads, reads_pad, keys, meta, slot_rep, slot_count, occupied, S.slot_hap, S.variants,
                                      S.col2pos, S.n_cols, S.hap_count, S.hap_pattern, S.hit, S.n_rows, w.vpcols, S.cooc, S.cooc_cap,
-                                     S.pk, S.mirror, slot_key, S.seq_dev, reinterpret_cast<uint32_t *>(s_tables));
+                                     S.pk, S.mirror, slot_key, S.seq_dev, reinterpret_cast<uint32_t *>(s_tables), S.exp_count,
+                                     S.exp_pattern, S.exp_cap, S.exp_stride);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -1068,7 +1096,12 @@ bool jl_fill_win_phase(jl_ctx *ctx, uint32_t min_reads, bool signal, uint32_t fo
     S.cooc = ctx->d_cooc; S.pk = ctx->d_pack; S.mirror = ctx->pack_mirror;
     S.arrive = ctx->d_sync + 2; S.seq_dev = ctx->d_sync;
     // a launch of at most JL_FOLD_MAX_BLOCKS workgroups in all also writes the per-read ids: one launch less
-    const bool fold = !generic && fblocks + 1u <= fold_budget;
+    if (ctx->phase_export) {
+        S.exp_count = ctx->d_exp_count; S.exp_pattern = ctx->d_exp_pattern;
+        S.exp_cap = ctx->exp_cap; S.exp_stride = ctx->exp_stride;
+    }
+    // (an exporting run keeps every read's flags and slot: jl_phase_regroup maps them once the merge is known)
+    const bool fold = !generic && !ctx->phase_export && fblocks + 1u <= fold_budget;
     S.fold = fold ? 1u : 0u;
     S.flag = ctx->d_sync + 4; S.arrive2 = ctx->d_sync + 3;
     S.read_hap = ctx->read_hap_out ? ctx->read_hap_out : ctx->d_read_hap;
@@ -1114,9 +1147,12 @@ bool jl_launch_phase(jl_ctx *ctx, hipStream_t st, uint32_t min_reads, bool plann
                            ctx->d_meta, ctx->d_slot_rep, ctx->d_slot_count, ctx->d_occupied, ctx->d_slot_hap,
                            ctx->d_variants, ctx->d_col2pos, ctx->n_cols, ctx->d_hap_count, ctx->d_hap_pattern, ctx->d_hit,
                            ctx->d_nvar, ctx->d_vpcols, ctx->d_cooc, ctx->cooc_cap, ctx->d_pack, ctx->pack_mirror,
-                           (unsigned long long *)ctx->d_slot_key, ctx->d_sync, signal_select ? ctx->h_seq : nullptr);
+                           (unsigned long long *)ctx->d_slot_key, ctx->d_sync, signal_select ? ctx->h_seq : nullptr,
+                           ctx->phase_export ? ctx->d_exp_count : nullptr, ctx->phase_export ? ctx->d_exp_pattern : nullptr,
+                           ctx->exp_cap, ctx->exp_stride);
     }
     if (fold) return signal;
+    if (ctx->phase_export) return false;   // the ids wait for the merge (jl_phase_regroup)
     hipLaunchKernelGGL(phase_assign_kernel, dim3(jl_assign_blocks(1, w.n_blocks, ids_to_host)), dim3(256), 0, st,
                        (uint64_t)n_dwords, ctx->d_flagw, ctx->d_meta, ctx->d_read_slot, ctx->d_slot_hap,
                        ctx->read_hap_out ? ctx->read_hap_out : ctx->d_read_hap);
@@ -1146,4 +1182,30 @@ void jl_launch_assign_group(const jl_win_phase *h_wins, uint32_t n_win, uint32_t
     // saturated all the same.
     const uint32_t bx = jl_assign_blocks(n_win, max_read_blocks, to_host);
     hipLaunchKernelGGL(phase_assign_group_kernel, dim3(bx, 1, n_win), dim3(256), 0, st, args);
+}
+
+
+// ---------------------------------------------------------------------------------------- sharded by reads: the merge's answer
+// hap_of_group[q] = haplotype id (or JL_HAP_INSUFFICIENT) of the q-th group this matrix exported
+__global__ __launch_bounds__(256) void regroup_kernel(const uint32_t *__restrict__ occupied,
+                                                       const uint16_t *__restrict__ hap_of_group, uint32_t n_groups,
+                                                       uint32_t *__restrict__ slot_hap, jl_phase_meta *__restrict__ meta,
+                                                       uint32_t n_haplotypes)
+{
+    const uint32_t q = blockIdx.x * 256u + threadIdx.x;
+    if (q < n_groups) slot_hap[occupied[q]] = hap_of_group[q];
+    if (q == 0) {
+        meta->summary.n_haplotypes = n_haplotypes;
+        meta->id_bits = id_bits_for(n_haplotypes);
+    }
+}
+
+void jl_launch_regroup(jl_ctx *ctx, const uint16_t *d_hap_of_group, uint32_t n_groups, uint32_t n_haplotypes)
+{
+    hipStream_t st = ctx->stream;
+    hipLaunchKernelGGL(regroup_kernel, dim3((n_groups + 255u) / 256u + (n_groups ? 0u : 1u)), dim3(256), 0, st, ctx->d_occupied,
+                       d_hap_of_group, n_groups, ctx->d_slot_hap, ctx->d_meta, n_haplotypes);
+    const uint32_t n_dwords = (uint32_t)(ctx->col_stride / 4u);
+    hipLaunchKernelGGL(phase_assign_kernel, dim3(jl_assign_blocks(1, (n_dwords + 255u) / 256u, false)), dim3(256), 0, st,
+                       (uint64_t)n_dwords, ctx->d_flagw, ctx->d_meta, ctx->d_read_slot, ctx->d_slot_hap, ctx->d_read_hap);
 }

@@ -1,0 +1,106 @@
+"""Cross-window phasing with the READS sharded (SURVEY.md §8e option A): every shard groups its slice of the reads on the
+device, the group tables are merged on the host, the merged groups' haplotype ids go back to the shards.  The result must
+be the unsharded one — summary, haplotypes, hit, co-occurrence and every read's id — for any number of shards."""
+import numpy as np
+import pytest
+
+from minorseq_amd import capi, msa, sharding, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def assert_same(got, exp, n_var):
+    assert got["summary"] == exp["summary"]
+    h = exp["summary"]["n_haplotypes"]
+    assert (got["pos_cols"] == exp["pos_cols"]).all()
+    assert (got["hap_count"] == exp["hap_count"]).all()
+    assert (got["hap_pattern"] == exp["hap_pattern"]).all()
+    assert (got["hit"][:n_var, :h] == exp["hit"]).all()
+    assert (got["cooc"][:n_var, :n_var] == exp["cooc"]).all()
+    assert (got["read_hap"] == exp["read_hap"]).all()
+
+
+def windows_of(rows, n, l, world, genes, ref):
+    wb = sharding.window_bounds(l, world)
+    prm = capi.default_params(n_tests=sharding.default_n_tests(genes))
+    ctxs, tables = [], []
+    for b, e in wb:
+        c = capi.Juliet(0)
+        c.upload_columns(msa.pack_columns(rows[:, b:e]), n, win_begin=b)
+        c.pileup_async(genes, ref)
+        c.call_async(prm)
+        tables.append(c.call_fetch())
+        ctxs.append(c)
+    return ctxs, sharding.merge_tables(tables, [b for b, _ in wb])
+
+
+@pytest.mark.parametrize("n,shards", [(7000, 1), (7000, 2), (7000, 3), (7000, 8), (1000, 8), (100_000, 4)])
+def test_sharded_by_reads_equals_unsharded(oracle, n, shards):
+    l = 900
+    sp = synth.SynthParams(seed=29 + n, minor_permille=(70, 60, 50, 40), partial_rate=0.15)
+    ref = synth.reference(sp.seed, l)
+    rows = synth.rows(sp, l, 0, n, ref)
+    genes = np.array([(1, l + 1)], dtype=capi.GENE)
+    rows[: n // 20, 700:703] = (rows[: n // 20, 700:703] + 1) % 4          # haplotypes that span windows
+    rows[n // 40: n // 16, 820:823] = (rows[n // 40: n // 16, 820:823] + 2) % 4
+    ctxs, merged = windows_of(rows, n, l, 3, genes, ref)
+    exp = oracle.phase(rows, oracle.call(rows, genes, refseq=ref))
+    got, pos_global = capi.phase_sharded_by_reads(ctxs, merged, shards)
+    assert_same(got, exp, len(merged))
+    # the replicated form (option B) on the same windows gives the same
+    rep, _ = capi.phase_across_windows(ctxs, merged)
+    assert rep["summary"] == got["summary"] and (rep["read_hap"] == got["read_hap"]).all()
+    for c in ctxs:
+        c.close()
+
+
+def test_a_group_below_the_threshold_in_every_shard_is_still_reported(oracle):
+    """The >= 10 reads rule applies to the MERGED count: a pattern carried by 4 reads in each of three slices is reported
+    (12 reads) although no slice holds 10 of them; 9 reads in a single slice are not, nor are the 4 reads of the first
+    slice that carry the major edit as well (a pattern of their own)."""
+    n, l = 4 * 1024, 60
+    ref = synth.reference(5, l)
+    rows = np.tile(ref, (n, 1)).astype(np.uint8)
+    rows[: n // 3, 30:33] = (rows[: n // 3, 30:33] + 1) % 4              # a real minor variant: the call
+    for s in range(4):                                                    # 4 reads per slice share a second edit at 9..11
+        rows[s * 1024 + 500: s * 1024 + 504, 9:12] = (rows[s * 1024 + 500: s * 1024 + 504, 9:12] + 2) % 4
+    rows[2048 + 700: 2048 + 709, 45:48] = (rows[2048 + 700: 2048 + 709, 45:48] + 3) % 4      # 9 reads, one slice only
+    genes = np.array([(1, l + 1)], dtype=capi.GENE)
+    # phase against a hand-made table: the three edited codons
+    import oracle_lib
+    full = oracle.call(rows, genes, refseq=ref, params=oracle_lib.default_params(n_tests=1.0, alpha=1.0))
+    keep = np.isin(full["col"], [9, 30, 45])
+    table = full[keep]
+    assert len(np.unique(table["col"])) == 3
+    exp = oracle.phase(rows, table)
+    c = capi.Juliet(0)
+    c.upload_columns(msa.pack_columns(rows), n)
+    got, _ = capi.phase_sharded_by_reads([c], table, 4)
+    assert_same(got, exp, len(table))
+    counts = sorted(got["hap_count"].tolist())
+    assert 12 in counts and 9 not in counts and 4 not in counts
+    assert got["summary"]["insufficient_reads"] == 9 + 4
+    c.close()
+
+
+def test_many_positions_take_the_multi_word_keys(oracle):
+    """More than ten variant positions: the exporting run switches to multi-word keys like any other (jl_phase_groups_fetch
+    re-runs it), and patterns of 14 positions merge the same way."""
+    n, l = 6000, 300
+    sp = synth.SynthParams(seed=91, minor_permille=(80, 70, 60, 50))
+    ref = synth.reference(sp.seed, l)
+    rows = synth.rows(sp, l, 0, n, ref)
+    rng = np.random.default_rng(3)
+    for k in range(12):                                                   # twelve more edited codons, ~3 % of the reads each
+        who = rng.choice(n, n // 30, replace=False)
+        c0 = 3 * (5 + 7 * k)
+        rows[who, c0:c0 + 3] = (rows[who, c0:c0 + 3] + 1 + k % 3) % 4
+    genes = np.array([(1, l + 1)], dtype=capi.GENE)
+    table = oracle.call(rows, genes, refseq=ref)
+    assert len(np.unique(table["col"])) > 10
+    exp = oracle.phase(rows, table)
+    c = capi.Juliet(0)
+    c.upload_columns(msa.pack_columns(rows), n)
+    got, _ = capi.phase_sharded_by_reads([c], table, 3)
+    assert_same(got, exp, len(table))
+    c.close()
