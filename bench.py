@@ -434,8 +434,10 @@ def main():
 def config3_strong(capi, sharding, synth, torch, dist, distributed, comm, rank, world, local_rank, free_ctxs, reps=12):
     """BASELINE.json configs[3] as stated: 1M CCS reads x ONE 10 kb reference, split into `world` column windows (rank
     r holds the 1M reads' columns of window r: 5 GB / world).  A step = call per window with the GLOBAL Bonferroni
-    factor -> all-gather of the variant table (RCCL) -> every variant position's three columns broadcast by their
-    owner (RCCL, the second exchange) -> phasing across windows, replicated on the compact matrix.  `value` = 1M / t.
+    factor -> all-gather of the variant table (RCCL) -> phasing across windows with the READS sharded (SURVEY 8e option A):
+    the owner of every variant position sends rank s the slice s of its three columns (RCCL send/recv, the second
+    exchange: 1/world of the bytes a broadcast would move), every rank groups its 1M/world reads, the group tables
+    (KB) are all-gathered and merged on the host, each rank maps its own reads.  `value` = 1M / t.
     The per-read ids stay on the device inside the loop (fetched once at the end): at 1e6 reads expanding them on the
     host would be most of a step."""
     # The weak-scaling batches stay allocated (4.8 + 5 GB of 288): device memory that was freed and is allocated again
@@ -453,9 +455,9 @@ def config3_strong(capi, sharding, synth, torch, dist, distributed, comm, rank, 
     win.synth_fill_window(sp, ref)
     win.sync()
     pc = capi.Juliet(local_rank)
-    remapped = np.zeros(capi.VARIANT_CAP, dtype=capi.VARIANT)
-    pos_global = np.zeros(capi.VARIANT_CAP, dtype=np.uint32)
-    vp = C.c_uint32()
+    # the reads are sharded for phasing (SURVEY 8e option A): rank r groups reads [sb[r], sb[r+1])
+    sb = sharding.read_slices(n, world)
+    n_mine = sb[rank + 1] - sb[rank]
     if world > 1:
         rows = np.zeros(world * capi.VARIANT_CAP, dtype=capi.VARIANT)
         counts = np.zeros(world, dtype=np.uint32)
@@ -469,16 +471,18 @@ def config3_strong(capi, sharding, synth, torch, dist, distributed, comm, rank, 
                                                    capi.VARIANT_CAP))
             tables = [rows[r * capi.VARIANT_CAP: r * capi.VARIANT_CAP + int(counts[r])] for r in range(world)]
             merged = sharding.merge_tables(tables, wbeg)
-            pc._chk(pc.lib.jl_xwin_assemble_rccl(pc.h, win.h, comm, capi._p(wbeg), capi._p(wnc), capi._p(merged), len(merged),
-                                                 capi._p(remapped), capi._p(pos_global), C.byref(vp)))
+            remapped, pos_global, vp = pc.xwin_assemble_slice_rccl(win, comm, wbeg, wnc, merged, sb)
+            pc._shape(n_mine, 3 * vp, pc.lib.jl_col_stride(n_mine))
         else:
             merged = sharding.merge_tables([win.run_fetch(False, False)["variants"]], [b])
-            arr = (C.c_void_p * 1)(win.h)
-            pc._chk(pc.lib.jl_xwin_assemble_local(pc.h, arr, 1, capi._p(merged), len(merged), capi._p(remapped), capi._p(pos_global),
-                                                  C.byref(vp)))
-        pc._shape(n, 3 * vp.value, win.col_stride)
-        pc.phase_async(remapped[: len(merged)], 10)
-        return merged, pc.phase_fetch(want_reads=want_reads, cap_var=max(8, len(merged)))
+            remapped, pos_global = pc.xwin_assemble_slice_local([win], merged, 0, n)
+        pc.phase_groups_async(remapped)
+        mine = pc.phase_groups_fetch()
+        groups = sharding.allgather_groups(mine) if world > 1 else [mine]
+        patterns, gcounts, index = sharding.merge_groups(groups)
+        ph = sharding.select_haplotypes(patterns, gcounts, remapped, mine["pos_cols"], 10, [t["summary"] for t in groups])
+        ph["read_hap"] = pc.phase_regroup(ph["hap_of_merged"][index[rank]].astype(np.uint16), ph["summary"]["n_haplotypes"], want_reads)
+        return merged, ph
 
     def fence():
         if distributed:
@@ -502,11 +506,12 @@ def config3_strong(capi, sharding, synth, torch, dist, distributed, comm, rank, 
     assert s["reported_reads"] + s["insufficient_reads"] + s["damaged_reads"] == n      # doc/JULIET.md:378-379
     t_k = win.time_pileup(reps=5)
     out = {"workload": f"configs[3]: {n} CCS reads x {l} bp reference split into {world} column window(s), call per window + "
-                       "all-gather + cross-window phasing (jl_xwin_assemble_*), replicated phasing (SURVEY 8e option B)",
+                       "all-gather + cross-window phasing with the reads sharded (jl_xwin_assemble_slice_*, jl_phase_groups_*, "
+                       "jl_phase_regroup: SURVEY 8e option A)",
            "value": n / t, "unit": "reads/s", "ms_per_step": 1000.0 * t, "scaling": "strong", "n_gpus": world,
            "columns_per_gpu": int(e - b), "variants_called": int(len(merged)), "variant_positions": int(s["n_positions"]),
            "haplotypes": int(s["n_haplotypes"]),
-           "exchanges": "none (one window)" if world == 1 else "1 ncclAllGather of the variant table + 1 group of ncclBroadcast (3 columns per variant position)",
+           "exchanges": "none (one window)" if world == 1 else "1 ncclAllGather of the variant table + 1 group of ncclSend/ncclRecv (slice r of 3 columns per variant position to rank r) + 1 all-gather of the group tables (KB, control plane)",
            "pileup_kernel_ms": t_k, "pileup_frac_of_hbm_peak": (n * (e - b) / 2.0) / (t_k * 1e-3) / 1e9 / HBM_PEAK_GBS}
     pc.close()
     win.close()

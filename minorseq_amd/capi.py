@@ -466,6 +466,20 @@ class Juliet:
             self._shape(n_slice, 3 * vp.value, self.lib.jl_col_stride(n_slice))
         return remapped[: len(merged)], pos_global[: vp.value]
 
+    def xwin_assemble_slice_rccl(self, window, comm, win_begins, win_ncols, merged, slice_begin):
+        """One window per rank: this context becomes the compact matrix of THIS rank's slice of the reads
+        (slice_begin: world + 1 starts, sharding.read_slices).  Returns (remapped table, pos_global, reads of the slice)."""
+        merged = np.ascontiguousarray(merged, dtype=VARIANT)
+        wb = np.ascontiguousarray(win_begins, dtype=np.uint32)
+        wn = np.ascontiguousarray(win_ncols, dtype=np.uint32)
+        sb = np.ascontiguousarray(slice_begin, dtype=np.uint64)
+        remapped = np.zeros(max(len(merged), 1), dtype=VARIANT)
+        pos_global = np.zeros(max(len(merged), 1), dtype=np.uint32)
+        vp = C.c_uint32()
+        self._chk(self.lib.jl_xwin_assemble_slice_rccl(self.h, window.h, comm, _p(wb), _p(wn), _p(merged if len(merged) else remapped),
+                                                       len(merged), _p(sb), _p(remapped), _p(pos_global), C.byref(vp)))
+        return remapped[: len(merged)], pos_global[: vp.value], vp.value
+
     def fisher_eval(self, a, c, cov, tail=0):
         a, c, cov = (np.ascontiguousarray(x, dtype=np.uint32) for x in (a, c, cov))
         p = np.zeros(len(a), dtype=np.float64)

@@ -112,8 +112,9 @@ def select_haplotypes(patterns, counts, variants, pos_cols, min_reads=10, partia
     counts = np.asarray(counts, dtype=np.int64)
     m, vp = patterns.shape if patterns.ndim == 2 else (0, 0)
     qualified = np.nonzero(counts >= min_reads)[0]
-    # patterns arrive ascending: a stable sort by descending count keeps that order inside equal counts
-    order = qualified[np.argsort(-counts[qualified], kind="stable")]
+    # (count descending, then pattern ascending position by position): lexsort's LAST key is the primary one
+    keys = [patterns[qualified, p] for p in range(vp - 1, -1, -1)] + [-counts[qualified]]
+    order = qualified[np.lexsort(keys)] if len(qualified) else qualified
     reported = order[:MAX_HAPLOTYPES]
     hap_of_merged = np.full(m, HAP_INSUFFICIENT, dtype=np.int64)
     hap_of_merged[reported] = np.arange(len(reported))

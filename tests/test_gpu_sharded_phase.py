@@ -104,3 +104,41 @@ def test_many_positions_take_the_multi_word_keys(oracle):
     got, _ = capi.phase_sharded_by_reads([c], table, 3)
     assert_same(got, exp, len(table))
     c.close()
+
+
+def test_slice_exchange_over_rccl_single_rank(oracle):
+    """The RCCL form of the slice exchange (ncclSend / ncclRecv per position and rank; a rank's own slice by a device copy)
+    with a one-rank communicator: everything but the wire."""
+    import ctypes as C
+    n, l = 5000, 300
+    sp = synth.SynthParams(seed=41, minor_permille=(70, 60, 50, 40), partial_rate=0.1)
+    ref = synth.reference(sp.seed, l)
+    rows = synth.rows(sp, l, 0, n, ref)
+    genes = np.array([(1, l + 1)], dtype=capi.GENE)
+    win = capi.Juliet(0)
+    win.upload_columns(msa.pack_columns(rows), n)
+    win.pileup_async(genes, ref)
+    win.call_async(capi.default_params())
+    table = win.call_fetch()
+    idbuf = np.zeros(128, dtype=np.uint8)
+    assert win.lib.jl_comm_unique_id(idbuf.ctypes.data_as(C.c_void_p)) == 0
+    comm = C.c_void_p()
+    win._chk(win.lib.jl_comm_create(win.h, idbuf.ctypes.data_as(C.c_void_p), 0, 1, C.byref(comm)))
+    pc = capi.Juliet(0)
+    try:
+        remapped, pos_global, vp = pc.xwin_assemble_slice_rccl(win, comm, [0], [l], table, sharding.read_slices(n, 1))
+    finally:
+        win.lib.jl_comm_destroy(comm)
+    pc._shape(n, 3 * vp, pc.lib.jl_col_stride(n))
+    pc.phase_groups_async(remapped)
+    t = pc.phase_groups_fetch()
+    patterns, counts, index = sharding.merge_groups([t])
+    ph = sharding.select_haplotypes(patterns, counts, remapped, t["pos_cols"], 10, [t["summary"]])
+    ph["read_hap"] = pc.phase_regroup(ph["hap_of_merged"][index[0]].astype(np.uint16), ph["summary"]["n_haplotypes"])
+    ph["pos_cols"] = pos_global
+    assert_same(ph, oracle.phase(rows, table), len(table))
+    # an unaligned slice start is refused
+    with pytest.raises(capi.JulietError):
+        pc.xwin_assemble_slice_local([win], table, 100, 1000)
+    pc.close()
+    win.close()

@@ -149,3 +149,127 @@ def test_cross_window_phasing_plan_and_exchange(world, oracle):
     assert (np.frombuffer(hc, dtype=np.uint32) == exp["hap_count"]).all()
     assert (np.frombuffer(rh, dtype=np.uint16) == exp["read_hap"]).all()
     assert (np.frombuffer(hit, dtype=np.uint8).reshape(exp["hit"].shape) == exp["hit"]).all()
+
+
+def _slice_groups(compact):
+    """CPU stand-in for jl_phase_groups_async / _fetch on one slice of the reads: flags, patterns of the clean reads, the
+    groups (pattern, count) in first-occurrence order like a hash table would hold them, and the partial summary."""
+    vp = compact.shape[1] // 3
+    gap = (compact == 4).any(axis=1)
+    het = (compact == 5).any(axis=1)
+    par = (compact == 6).any(axis=1)
+    dirty = gap | het | par
+    clean = compact[~dirty].astype(np.uint32)
+    codes = (clean[:, 0::3] * 16 + clean[:, 1::3] * 4 + clean[:, 2::3]).astype(np.uint8) if vp else np.zeros((len(clean), 0), dtype=np.uint8)
+    uniq, first, inverse, counts = np.unique(codes, axis=0, return_index=True, return_inverse=True, return_counts=True)
+    order = np.argsort(first)                       # not sorted by pattern: the merge must not rely on any order
+    rank_of = np.empty(len(order), dtype=np.int64)
+    rank_of[order] = np.arange(len(order))
+    summary = dict(reported_reads=0, insufficient_reads=int((~dirty).sum()), damaged_reads=int(dirty.sum()), marginal_gap=int(gap.sum()),
+                   marginal_heteroduplex=int(het.sum()), marginal_partial=int(par.sum()), n_positions=vp, n_haplotypes=0)
+    group_of_clean = rank_of[np.asarray(inverse).reshape(-1)]
+    return dict(patterns=uniq[order], counts=counts[order].astype(np.uint32), summary=summary), dirty, group_of_clean
+
+
+def _sharded_phase_worker(rank, world, port, q):
+    """SURVEY §8e option A on CPU ranks: call per window (oracle), all-gather of the table (gloo), plan (product), the
+    owner of each position SCATTERS the slices of its three columns (gloo stands in for ncclSend / ncclRecv), every rank
+    groups its own slice of the reads, the group tables are all-gathered and merged, the haplotypes selected (product:
+    sharding.allgather_groups / merge_groups / select_haplotypes), and each rank maps its reads."""
+    import torch
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        orc = oracle_lib.load()
+        ref, rows = _data()
+        wb = sharding.window_bounds(L, world)
+        b, e = wb[rank]
+        mine = np.ascontiguousarray(rows[:, b:e])
+        prm = oracle_lib.default_params(n_tests=sharding.default_n_tests(GENES))
+        local = orc.call(mine, GENES, win_begin=b, refseq=ref, params=prm)
+        merged = sharding.merge_tables(sharding.allgather_tables(local), [w[0] for w in wb])
+        remapped, pos, owner = capi.xwin_plan([w[0] for w in wb], [w[1] - w[0] for w in wb], merged)
+        sb = sharding.read_slices(N, world)
+        assert sb[0] == 0 and sb[-1] == N and all(x % 256 == 0 for x in sb[:-1])
+        n_mine = sb[rank + 1] - sb[rank]
+        compact = np.empty((n_mine, 3 * len(pos)), dtype=np.uint8)
+        for k, (c, w) in enumerate(zip(pos, owner)):
+            recv = torch.zeros((n_mine, 3), dtype=torch.uint8)
+            parts = None
+            if w == rank:
+                parts = [torch.from_numpy(np.ascontiguousarray(mine[sb[s]:sb[s + 1], c - b: c - b + 3])) for s in range(world)]
+            # gloo's scatter wants equal shapes: pad every part to the longest slice
+            longest = max(sb[s + 1] - sb[s] for s in range(world))
+            buf = torch.zeros((longest, 3), dtype=torch.uint8)
+            if parts is not None:
+                parts = [torch.cat([p, torch.zeros((longest - len(p), 3), dtype=torch.uint8)]) for p in parts]
+            dist.scatter(buf, parts, src=int(w))
+            compact[:, 3 * k: 3 * k + 3] = buf[:n_mine].numpy()
+        table, dirty, group_of_clean = _slice_groups(compact)
+        tables = sharding.allgather_groups(table)
+        patterns, counts, index = sharding.merge_groups(tables)
+        ph = sharding.select_haplotypes(patterns, counts, remapped, 3 * np.arange(len(pos)), 10, [t["summary"] for t in tables])
+        ids = np.full(n_mine, 0xFFFF, dtype=np.uint16)
+        ids[~dirty] = ph["hap_of_merged"][index[rank]][group_of_clean].astype(np.uint16)
+        gathered = [None] * world
+        dist.all_gather_object(gathered, ids)
+        if rank == 0:
+            q.put((ph["summary"], ph["hap_count"].tobytes(), ph["hap_pattern"].tobytes(), ph["hit"].tobytes(), ph["cooc"].tobytes(),
+                   np.concatenate(gathered).tobytes(), merged.tobytes()))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_phasing_sharded_by_reads_over_gloo(world, oracle):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sharded_phase_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    summary, hc, hp, hit, cooc, rh, merged_b = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ref, rows = _data()
+    full = oracle.call(rows, GENES, refseq=ref)
+    assert np.frombuffer(merged_b, dtype=capi.VARIANT).tobytes() == full.tobytes()
+    exp = oracle.phase(rows, full)
+    assert summary == exp["summary"] and summary["n_haplotypes"] >= 3
+    h, vp, nv = summary["n_haplotypes"], summary["n_positions"], len(full)
+    assert (np.frombuffer(hc, dtype=np.uint32) == exp["hap_count"]).all()
+    assert (np.frombuffer(hp, dtype=np.uint8).reshape(h, vp) == exp["hap_pattern"]).all()
+    assert (np.frombuffer(hit, dtype=np.uint8).reshape(nv, h) == exp["hit"]).all()
+    assert (np.frombuffer(cooc, dtype=np.uint32).reshape(nv, nv) == exp["cooc"]).all()
+    assert (np.frombuffer(rh, dtype=np.uint16) == exp["read_hap"]).all()
+
+
+def test_read_slices_and_group_merge_edge_cases():
+    assert sharding.read_slices(1000, 8) == [0, 256, 512, 768, 1000, 1000, 1000, 1000, 1000]
+    assert sharding.read_slices(4096, 4) == [0, 1024, 2048, 3072, 4096]
+    assert sharding.read_slices(1, 3) == [0, 1, 1, 1]
+    a = dict(patterns=np.array([[3, 1], [0, 2]], dtype=np.uint8), counts=np.array([4, 6], dtype=np.uint32))
+    b = dict(patterns=np.zeros((0, 2), dtype=np.uint8), counts=np.zeros(0, dtype=np.uint32))
+    c = dict(patterns=np.array([[0, 2], [3, 1], [3, 0]], dtype=np.uint8), counts=np.array([5, 6, 9], dtype=np.uint32))
+    p, n, idx = sharding.merge_groups([a, b, c])
+    assert p.tolist() == [[0, 2], [3, 0], [3, 1]] and n.tolist() == [11, 9, 10]
+    assert idx[0].tolist() == [2, 0] and len(idx[1]) == 0 and idx[2].tolist() == [0, 2, 1]
+    v = np.zeros(2, dtype=capi.VARIANT)
+    v["col"] = [0, 3]
+    v["codon"] = [3, 2]
+    ph = sharding.select_haplotypes(p, n, v, [0, 3], 10)
+    # 11 reads of (0,2) first, then the 10 of (3,1); the 9 of (3,0) are insufficient
+    assert ph["hap_count"].tolist() == [11, 10] and ph["hap_pattern"].tolist() == [[0, 2], [3, 1]]
+    assert ph["hap_of_merged"].tolist() == [0, sharding.HAP_INSUFFICIENT, 1]
+    assert ph["hit"].tolist() == [[0, 1], [1, 0]] and ph["cooc"].tolist() == [[10, 0], [0, 11]]
+    assert ph["summary"]["reported_reads"] == 21 and ph["summary"]["insufficient_reads"] == 9
+    # equal counts: pattern ascending
+    ph = sharding.select_haplotypes(np.array([[1, 9], [1, 2], [0, 7]], dtype=np.uint8), [12, 12, 12], v[:1], [0, 3], 10)
+    assert ph["hap_pattern"].tolist() == [[0, 7], [1, 2], [1, 9]] and ph["hap_of_merged"].tolist() == [2, 1, 0]
+    # nothing to phase
+    p0, n0, _ = sharding.merge_groups([b])
+    ph = sharding.select_haplotypes(p0, n0, v[:0], [], 10)
+    assert ph["summary"]["n_haplotypes"] == 0 and ph["hap_count"].tolist() == []
