@@ -45,6 +45,7 @@ struct Options {
     double min_rq = 0.0;
     int device = 0;
     std::string dump_msa, dump_config, consensus;
+    bool fuse_only = false;        // invoked as `fuse in.bam out.fasta` (doc/FUSE.md:26-31): the consensus and nothing else
     double ins_min_frac = 0.5;     // an insertion enters the consensus when more than this share of the covering reads carries it
     uint32_t ins_min_distance = 10;  // ... and the previous included insertion lies at least this many columns back (UNPINNED)
     bool timing = false;
@@ -120,6 +121,17 @@ Options parse(int argc, char **argv)
         else pos.push_back(a);
     }
     if (!o.dump_config.empty() && pos.empty()) return o;
+    {   // `fuse in.bam out.fasta` (doc/FUSE.md:26-31): the same front end, asked for the consensus only
+        const std::string prog = argv[0];
+        const size_t slash = prog.find_last_of('/');
+        if ((slash == std::string::npos ? prog : prog.substr(slash + 1)) == "fuse") {
+            if (pos.size() != 2) { std::cerr << "fuse: usage: fuse in.align.bam out.fasta\n"; std::exit(1); }
+            o.bam = pos[0];
+            o.consensus = pos[1];
+            o.fuse_only = true;
+            return o;
+        }
+    }
     if (pos.size() < 2 && o.dump_msa.empty()) { std::cerr << "juliet: need an input BAM and at least one output\n"; usage(1); }
     if (pos.empty()) usage(1);
     o.bam = pos[0];
@@ -313,7 +325,7 @@ int main(int argc, char **argv)
         io.min_qv = opt.min_qv;
         io.min_rq = opt.min_rq;
         // the GPU context comes up (runtime start, stream, pinned blocks) while the host reads the BAM
-        const bool need_gpu = !opt.outputs.empty();
+        const bool need_gpu = !opt.outputs.empty() || opt.fuse_only;
         std::shared_future<std::pair<int, jl_ctx *>> ctx_up;
         std::unique_ptr<RecordUploader> uploader;
         RecordSink sink;
@@ -430,14 +442,16 @@ int main(int argc, char **argv)
                     if (!cfg.known_drms(pg[p], pk[p] + g.first_codon, translate(cod)).empty()) drm_masks[p] |= 1ull << cod;
             }
         }
-        if (jl_run_async(ctx, genes.data(), (uint32_t)genes.size(), refp, (uint32_t)refcodes.size(), &prm,
-                         opt.drm_only ? drm_masks.data() : nullptr, opt.phasing, opt.min_reads, opt.phasing) != JL_OK)
+        if (opt.fuse_only) {   // the column pileup is all a consensus needs
+            if (jl_pileup_async(ctx, genes.data(), (uint32_t)genes.size(), refp, (uint32_t)refcodes.size()) != JL_OK) die_jl(ctx, "pileup");
+        } else if (jl_run_async(ctx, genes.data(), (uint32_t)genes.size(), refp, (uint32_t)refcodes.size(), &prm,
+                                opt.drm_only ? drm_masks.data() : nullptr, opt.phasing, opt.min_reads, opt.phasing) != JL_OK)
             die_jl(ctx, "run");
         tick("plan + enqueue");
 
         std::vector<jl_variant> var(4096);
         uint32_t nv = 0;
-        if (jl_call_fetch(ctx, var.data(), 4096, &nv) != JL_OK) die_jl(ctx, "call fetch");
+        if (!opt.fuse_only && jl_call_fetch(ctx, var.data(), 4096, &nv) != JL_OK) die_jl(ctx, "call fetch");
         var.resize(nv);
         std::vector<uint32_t> col_counts((size_t)n_cols * 6);
         if (jl_pileup_fetch(ctx, col_counts.data(), nullptr, nullptr, nullptr, nullptr, nullptr) != JL_OK) die_jl(ctx, "pileup fetch");
@@ -450,6 +464,11 @@ int main(int argc, char **argv)
             if (!f) { std::cerr << "juliet: cannot write " << opt.consensus << "\n"; return 2; }
             f << ">consensus window=" << (win_begin + 1) << "-" << (win_begin + n_cols) << " source=" << opt.bam << "\n";
             for (size_t i = 0; i < seq.size(); i += 70) f << seq.substr(i, 70) << "\n";
+        }
+        if (opt.fuse_only) {
+            tick("pileup + consensus");
+            jl_ctx_destroy(ctx);
+            return 0;
         }
         jl_phase_summary ps = {};
         std::vector<uint32_t> pos_cols, hap_count;

@@ -26,7 +26,7 @@ def built():
     """The binaries normally travel with the tree; build them only if they are missing (never under a loaded .so)."""
     if not os.path.exists(os.path.join(ROOT, "minorseq_amd", "libjuliet_hip.so")):
         subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "minorseq_amd", "csrc")])
-    if not (os.path.exists(JULIET) and os.path.exists(SYNTH)):
+    if not (os.path.exists(JULIET) and os.path.exists(SYNTH) and os.path.exists(os.path.join(os.path.dirname(JULIET), "fuse"))):
         subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "minorseq_amd", "host")])
 
 
@@ -371,6 +371,13 @@ def test_consensus_keeps_in_frame_majority_insertions(tmp_path, oracle):
     subprocess.check_call([JULIET, "-c", cfg, "--consensus", fa, "--ins-min-distance", "6", bam, str(tmp_path / "o2.json")])
     seq6 = "".join(open(fa).read().splitlines()[1:])
     assert len(seq6) == len(seq) + 3 and ins_seq(156, 3) in seq6
+    # `fuse in.bam out.fasta` (doc/FUSE.md:26-31) is the same front end under its own name: no config, the covered window
+    fuse_bin = os.path.join(os.path.dirname(JULIET), "fuse")
+    fa2 = str(tmp_path / "fuse.fasta")
+    subprocess.check_call([fuse_bin, bam, fa2])
+    head, *body = open(fa2).read().splitlines()
+    assert head.startswith(">consensus") and "".join(body) == want
+    assert subprocess.run([fuse_bin, bam], capture_output=True).returncode == 1      # usage
     j1, j2 = json.load(open(tmp_path / "o.json")), json.load(open(tmp_path / "o2.json"))
     assert j1["genes"] == j2["genes"]
     rows = synth.rows(synth.SynthParams(seed=seed), l, 0, n, ref)
