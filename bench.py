@@ -181,16 +181,29 @@ def main():
         idbuf = t.cpu().numpy()
         comm = C.c_void_p()
         jl._chk(jl.lib.jl_comm_create(jl.h, idbuf.ctypes.data_as(C.c_void_p), rank, world, C.byref(comm)))
-        all_rows = np.zeros(world * capi.VARIANT_CAP, dtype=capi.VARIANT)
-        all_counts = np.zeros(world, dtype=np.uint32)
+        # room for the exchanges of one launch's windows, collected by ONE call (jl_allgather_variants_many); 128 rows per
+        # rank and window is the stride the compact exchange itself carries (JL_PACK_MAX_VAR)
+        XROWS = 128
+        all_rows = np.zeros(G * world * XROWS, dtype=capi.VARIANT)
+        all_counts = np.zeros(G * world, dtype=np.uint32)
         p_rows, p_counts = all_rows.ctypes.data_as(C.c_void_p), all_counts.ctypes.data_as(C.c_void_p)
 
     pending = {id(c): 0 for c in ctxs}   # exchanges enqueued and not yet collected, per context
     state = dict(checked=0, gathered_rows=0)
 
+    host = dict(launch=0.0, drain=0.0, collect=0.0, n=0)   # JL_BENCH_TRACE: host seconds inside the step loop's calls
+
     def launch(u, count=G):
         """Enqueue `count` steps (batches) of unit u: the whole path, results stored into pinned memory by the
         kernels; the all-gather (N > 1) is the only other device work of a step and is requested right behind it."""
+        t_in = time.perf_counter()
+        try:
+            return launch_(u, count)
+        finally:
+            host["launch"] += time.perf_counter() - t_in
+            host["n"] += 1
+
+    def launch_(u, count=G):
         members = units[u][:count]
         if G == 1:
             members[0].run_async(genes, refseq, prm, None, True, 10, True)
@@ -215,12 +228,34 @@ def main():
         return members
 
     def drain(c, k):
+        t_in = time.perf_counter()
+        try:
+            drain_(c, k)
+        finally:
+            host["drain"] += time.perf_counter() - t_in
+
+    def drain_(c, k):
         for _ in range(k):
-            rc = c.lib.jl_allgather_variants(c.h, comm, p_rows, p_counts, capi.VARIANT_CAP)
+            rc = c.lib.jl_allgather_variants(c.h, comm, p_rows, p_counts, XROWS)
             if rc:
                 c._chk(rc)
             pending[id(c)] -= 1
-            state["gathered_rows"] = int(all_counts.sum())
+            state["gathered_rows"] = int(all_counts[:world].sum())
+
+    def drain_many(members, arr):
+        """The oldest pending exchange of every member, one call (they were requested as one batch)."""
+        t_in = time.perf_counter()
+        rc = jl.lib.jl_allgather_variants_many(arr, len(members), comm, p_rows, p_counts, XROWS)
+        if rc:
+            for c in members:
+                msg = c.lib.jl_last_error(c.h).decode()
+                if msg:
+                    raise capi.JulietError(rc, msg)
+            raise capi.JulietError(rc, "jl_allgather_variants_many failed")
+        for c in members:
+            pending[id(c)] -= 1
+        state["gathered_rows"] = int(all_counts[: len(members) * world].sum())
+        host["drain"] += time.perf_counter() - t_in
 
     def collect(members, final=False, check=True):
         last = None
@@ -240,10 +275,19 @@ def main():
                 rv = c.run_view_raw()
                 if not rv.complete or rv.n_variants != len(expected[id(c)]["count"]) or rv.n_haplotypes != len(expected[id(c)]["hap_count"]):
                     raise SystemExit(f"bench.py: rank {rank}: a window's result block is incomplete or changed")
-            # the exchange of this context's PREVIOUS step is collected now (its own is still crossing xGMI): every
-            # step's all-gather is consumed, one cycle late, and its latency never stalls the launching thread
-            if comm is not None and pending[id(c)] > (0 if final else 1):
-                drain(c, 1)
+        # the exchange of these contexts' PREVIOUS step is collected now (their own is still crossing xGMI): every
+        # step's all-gather is consumed, one cycle late, and its latency never stalls the launching thread.  The windows
+        # of a launch were requested as one batch and are collected by one call.
+        if comm is not None:
+            floor = 0 if final else 1
+            while all(pending[id(c)] > floor for c in members):
+                arr = handle_arrays.get(("m", id(members[0]), len(members)))
+                if arr is None:
+                    arr = handle_arrays[("m", id(members[0]), len(members))] = (C.c_void_p * len(members))(*[c.h for c in members])
+                drain_many(members, arr)
+            for c in members:   # (members whose exchanges were not requested together)
+                if pending[id(c)] > floor:
+                    drain(c, pending[id(c)] - floor)
         state["checked"] += 1
         if final:
             # The launch is complete (its completion words were read above); retiring its commands in the runtime now
@@ -309,6 +353,9 @@ def main():
     last = run_steps(args.steps)
     fence()
     elapsed = time.perf_counter() - t0
+    if trace is not None:
+        sys.stderr.write(f"bench host time per launch (us): launch {1e6 * host['launch'] / max(1, host['n']):.1f}, "
+                         f"drain {1e6 * host['drain'] / max(1, host['n']):.1f} over {host['n']} launches incl. warm-up\n")
     if trace:
         sys.stderr.write("bench trace (us after t0): " + ", ".join(f"{w} {1e6 * (t - t0):.1f}" for w, t in trace[:12]) +
                          f", fence done {1e6 * elapsed:.1f}\n")

@@ -364,6 +364,10 @@ int jl_allgather_variants_async(jl_ctx *ctx, jl_comm *comm);
  * i.e. one collective launch.  Every rank must pass the same number of contexts in the same call order.  Collect
  * each context's exchange with jl_allgather_variants as usual. */
 int jl_allgather_variants_async_many(jl_ctx *const *ctxs, uint32_t n, jl_comm *comm);
+/* The collecting half for several contexts in one call (e.g. the windows of one launch, one cycle later):
+ * all_rows [n_ctx][world][cap_rows], all_counts [n_ctx][world]; jl_last_error of the failing context tells why. */
+int jl_allgather_variants_many(jl_ctx *const *ctxs, uint32_t n_ctx, jl_comm *comm, jl_variant *all_rows,
+                               uint32_t *all_counts, uint32_t cap_rows);
 
 /* ---------------------------------------------------------------- cross-window phasing */
 

@@ -33,7 +33,7 @@ EXPORTS = ("jl_abi_version", "jl_strerror", "jl_device_count", "jl_ctx_create", 
            "jl_consensus_fetch", "jl_call_async", "jl_call_fetch", "jl_variant_table_device", "jl_phase_async", "jl_phase_fetch",
            "jl_run_async", "jl_run_wait", "jl_run_done", "jl_run_view_get", "jl_group_create", "jl_group_destroy",
            "jl_group_last_error", "jl_group_run_async", "jl_group_run_masked_async", "jl_group_time_pileup", "jl_fisher_eval", "jl_fisher_eval_tail", "jl_expand_read_hap", "jl_time_pileup", "jl_time_pileup_set", "jl_pileup_kernel_name", "jl_comm_unique_id", "jl_comm_create", "jl_comm_destroy",
-           "jl_allgather_variants", "jl_allgather_variants_async", "jl_allgather_variants_async_many", "jl_xwin_plan", "jl_xwin_assemble_local",
+           "jl_allgather_variants", "jl_allgather_variants_async", "jl_allgather_variants_async_many", "jl_allgather_variants_many", "jl_xwin_plan", "jl_xwin_assemble_local",
            "jl_xwin_assemble_rccl", "jl_xwin_assemble_slice_local", "jl_xwin_assemble_slice_rccl", "jl_phase_groups_async",
            "jl_phase_groups_fetch", "jl_phase_regroup")
 
@@ -184,6 +184,7 @@ def load_library(path=LIB_PATH):
     lib.jl_allgather_variants.argtypes = [vp, vp, vp, vp, u32]
     lib.jl_allgather_variants_async.argtypes = [vp, vp]
     lib.jl_allgather_variants_async_many.argtypes = [vp, u32, vp]
+    lib.jl_allgather_variants_many.argtypes = [vp, u32, vp, vp, vp, u32]
     lib.jl_xwin_plan.argtypes = [vp, vp, u32, vp, u32, vp, vp, vp, C.POINTER(u32)]
     lib.jl_xwin_assemble_local.argtypes = [vp, vp, u32, vp, u32, vp, vp, C.POINTER(u32)]
     lib.jl_xwin_assemble_rccl.argtypes = [vp, vp, vp, vp, vp, vp, u32, vp, vp, C.POINTER(u32)]

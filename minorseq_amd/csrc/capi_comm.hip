@@ -39,6 +39,8 @@ struct jl_comm_slot {
     jl_comm_slot *leader = nullptr;   // first slot of the batch
     uint32_t batch_left = 0;     // leader only: members not yet collected
     uint32_t batch_size = 1;     // leader only
+    bool event_seen = false;     // host thread only: `done` was seen complete (a batch's members share one event: the
+                                 // first collector pays for the query, 5-10 us in the runtime, the others do not)
     bool enqueued = false;       // the worker has issued it and recorded `done` (guarded by jl_comm::mu)
     int status = 0;              // ncclResult_t / hip error of the enqueue, as jl_status
 };
@@ -322,6 +324,7 @@ static int comm_request(jl_ctx *ctx, jl_comm *c, jl_comm_slot *at, jl_comm_slot 
     s->run_seq = ctx->runs_launched;
     s->d_src = reinterpret_cast<const uint8_t *>(ctx->d_pack + ((ctx->runs_launched - 1u) & 1u));
     s->seq = c->next_seq++;
+    s->event_seen = false;
     s->enqueued = false;   // not yet visible to the worker: no lock needed
     s->status = JL_OK;
     ctx->exch_runs.push_back(s->run_seq);
@@ -440,10 +443,11 @@ int jl_allgather_variants(jl_ctx *ctx, jl_comm *c, jl_variant *all_rows, uint32_
     comm_wait_enqueued(c, s);
     struct release { jl_comm_slot *s; ~release() { comm_slot_release(s); } } rel{s};   // free for reuse once the heads were read
     if (s->status != JL_OK) return jl_fail(ctx, s->status, "all-gather enqueue failed on the communicator thread");
-    {   // spin on the event: a blocking hipEventSynchronize costs ~15 us of wake-up latency per step
+    if (!s->done_at->event_seen) {   // spin on the event: a blocking hipEventSynchronize costs ~15 us of wake-up latency per step
         hipError_t q;
         while ((q = hipEventQuery(s->done_at->done)) == hipErrorNotReady) {}
         if (q != hipSuccess) return jl_fail(ctx, JL_ERR_DEVICE, "all-gather: %s", hipGetErrorString(q));
+        s->done_at->event_seen = true;
     }
     bool compact = true;
     for (int k = 0; k < c->world; ++k) {
@@ -468,6 +472,20 @@ int jl_allgather_variants(jl_ctx *ctx, jl_comm *c, jl_variant *all_rows, uint32_
         return jl_fail(ctx, JL_ERR_STATE, "a rank called more than %u variants: such a run's exchange must be collected before the "
                                           "context's next run (the full table is not double-buffered)", JL_PACK_MAX_VAR);
     return allgather_full(ctx, c, all_rows, all_counts, cap_rows, run_seq);
+}
+
+
+// The exchanges of several contexts collected in one call (the windows of one launch): all_rows [n_ctx][world][cap_rows],
+// all_counts [n_ctx][world].  Stops at the first failure.
+int jl_allgather_variants_many(jl_ctx *const *ctxs, uint32_t n_ctx, jl_comm *c, jl_variant *all_rows, uint32_t *all_counts,
+                               uint32_t cap_rows)
+{
+    if (!ctxs || !c || !all_rows || !all_counts) return JL_ERR_ARG;
+    for (uint32_t k = 0; k < n_ctx; ++k) {
+        const int rc = jl_allgather_variants(ctxs[k], c, all_rows + (size_t)k * c->world * cap_rows, all_counts + (size_t)k * c->world, cap_rows);
+        if (rc) return rc;
+    }
+    return JL_OK;
 }
 
 
