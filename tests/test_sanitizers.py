@@ -89,3 +89,26 @@ def test_front_end_ingest_under_asan_ubsan(san_bins):
     open(str(d / "garbage.bam"), "wb").write(b"\x1f\x8b" + b"not a bam" * 50)
     r = subprocess.run([juliet, "--dump-msa", msa_out, str(d / "garbage.bam")], capture_output=True, text=True, env=env)
     assert r.returncode == 2 and "AddressSanitizer" not in r.stderr
+
+
+def test_front_end_pipeline_under_tsan(tmp_path):
+    """The front end is four kinds of threads (inflate workers, the record parser, the uploader that hands chunks to the
+    device, the context start-up): ThreadSanitizer over the hand-overs.  No GPU is needed for that — without one the
+    context fails, the uploader still takes every chunk off the queue and recycles it, and the run ends with the
+    'no usable GPU' message (exit 3); with one it runs through."""
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "minorseq_amd", "csrc")])
+    synth = os.path.join(ROOT, "minorseq_amd", "bin", "juliet-synth")
+    if not os.path.exists(synth):
+        subprocess.check_call(["make", "-s", "-C", HOST])
+    juliet = str(tmp_path / "juliet-tsan")
+    subprocess.check_call(["g++", "-std=c++17", "-fsanitize=thread", "-g", "-O1", "-I" + os.path.join(ROOT, "include"), "-o", juliet,
+                           os.path.join(HOST, "juliet_main.cpp"), "-L" + os.path.join(ROOT, "minorseq_amd"), "-ljuliet_hip",
+                           "-lz", "-lpthread", "-Wl,-rpath," + os.path.join(ROOT, "minorseq_amd"),
+                           "-Wl,-rpath-link,/opt/rocm/lib"])
+    bam, cfg = str(tmp_path / "t.bam"), str(tmp_path / "t.json")
+    subprocess.check_call([synth, "--reads", "30000", "--cols", "300", "--seed", "9", "-o", bam, "--config-out", cfg])   # 4 chunks
+    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=0 report_signal_unsafe=0")
+    r = subprocess.run([juliet, "-c", cfg, "--mode-phasing", bam, str(tmp_path / "o.json")], capture_output=True, text=True, env=env,
+                       timeout=600)
+    assert "ThreadSanitizer" not in r.stderr, r.stderr[-3000:]
+    assert r.returncode in (0, 3), r.stderr[-2000:]
