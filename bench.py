@@ -118,6 +118,8 @@ def main():
     import torch.distributed as dist
 
     from minorseq_amd import capi, sharding, synth
+    if os.environ.get("JL_LIB"):   # tuning aid: an alternative build of the library
+        capi.load_library(os.environ["JL_LIB"])
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
