@@ -148,7 +148,7 @@ def main():
     G = max(1, args.group)
     if G > 32:
         raise SystemExit("bench.py: --group is at most 32 (a group launch carries its windows' argument blocks by value: JL_GROUP_WINDOWS_MAX)")
-    n_units = max(1, args.inflight)
+    n_flight = n_units = max(1, args.inflight)
     genes = np.array([(1, world * l + 1)], dtype=capi.GENE)
     refseq = np.full(world * l, 4, dtype=np.uint8)
     refseq[win_begin:win_begin + l] = ref_local
@@ -216,7 +216,9 @@ def main():
                 grp = partial_groups.get((u, count))
                 if grp is None:
                     grp = partial_groups[(u, count)] = capi.Group(members)
+            t_g = time.perf_counter()
             grp.run_async(genes, refseq, prm, True, 10, True)
+            host["run_async"] = host.get("run_async", 0.0) + time.perf_counter() - t_g
         if comm is not None:
             # the all-gathers of the launch's windows go out as one RCCL group (one collective launch)
             arr = handle_arrays.get((u, count))
@@ -302,13 +304,14 @@ def main():
     trace = [] if os.environ.get("JL_BENCH_TRACE") else None   # tuning aid: host time stamps of the timed steps
 
     def run_steps(k):
-        """k steps; at most n_units launches (G steps each) in flight; every step's results are read on the host."""
+        """k steps; at most n_flight launches (G steps each) in flight, rotating over the n_units launch units; every
+        step's results are read on the host."""
         last = None
         inflight = []   # (unit, members) in launch order
         done = 0
         u = 0
         while done < k:
-            if len(inflight) == n_units:
+            if len(inflight) == n_flight:
                 last = collect(inflight.pop(0)[1])
             count = min(G, k - done)
             inflight.append((u, launch(u, count)))
@@ -356,7 +359,8 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if trace is not None:
-        sys.stderr.write(f"bench host time per launch (us): launch {1e6 * host['launch'] / max(1, host['n']):.1f}, "
+        sys.stderr.write(f"bench host time per launch (us): group run_async {1e6 * host.get('run_async', 0.0) / max(1, host['n']):.1f}, "
+                         f"launch {1e6 * host['launch'] / max(1, host['n']):.1f}, "
                          f"drain {1e6 * host['drain'] / max(1, host['n']):.1f} over {host['n']} launches incl. warm-up\n")
     if trace:
         sys.stderr.write("bench trace (us after t0): " + ", ".join(f"{w} {1e6 * (t - t0):.1f}" for w, t in trace[:12]) +
@@ -427,7 +431,7 @@ def main():
                    "reads_per_gpu": n, "ref_columns_per_gpu": l,
                    "parallelism": f"window-sharded x{world}, {exchange}" if distributed
                    else "single GPU",
-                   "batches_per_launch": G, "launches_in_flight": n_units, "resident_batches": len(ctxs),
+                   "batches_per_launch": G, "launches_in_flight": n_flight, "resident_batches": len(ctxs),
                    "one_batch_latency_ms": latency_ms,
                    "variants_called": state["gathered_rows"] if comm is not None else len(table),
                    "haplotypes": ph["summary"]["n_haplotypes"],
