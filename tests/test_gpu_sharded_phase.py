@@ -142,3 +142,42 @@ def test_slice_exchange_over_rccl_single_rank(oracle):
         pc.xwin_assemble_slice_local([win], table, 100, 1000)
     pc.close()
     win.close()
+
+
+def test_state_and_argument_errors_are_loud(oracle):
+    n, l = 3000, 120
+    sp = synth.SynthParams(seed=8, minor_permille=(70, 60, 50, 40))
+    ref = synth.reference(sp.seed, l)
+    rows = synth.rows(sp, l, 0, n, ref)
+    genes = np.array([(1, l + 1)], dtype=capi.GENE)
+    c = capi.Juliet(0)
+    c.upload_columns(msa.pack_columns(rows), n)
+    table = oracle.call(rows, genes, refseq=ref)
+    with pytest.raises(capi.JulietError) as e:            # nothing exported yet
+        c.phase_groups_fetch()
+    assert "jl_phase_groups_async" in str(e.value)
+    with pytest.raises(capi.JulietError):
+        c.phase_regroup(np.zeros(1, dtype=np.uint16), 1)
+    c.phase_async(table, 10)                               # a normal phase run does not export either
+    c.phase_fetch()
+    with pytest.raises(capi.JulietError):
+        c.phase_groups_fetch()
+    c.phase_groups_async(table)
+    t = c.phase_groups_fetch()
+    g = len(t["counts"])
+    assert g >= 5 and int(t["counts"].sum()) == t["summary"]["insufficient_reads"] == n - t["summary"]["damaged_reads"]
+    with pytest.raises(capi.JulietError) as e:            # a haplotype id outside the merged set
+        c.phase_regroup(np.full(g, 7, dtype=np.uint16), 3)
+    assert "haplotype 7 of 3" in str(e.value)
+    with pytest.raises(capi.JulietError):                  # more haplotypes than have names
+        c.phase_regroup(np.zeros(g, dtype=np.uint16), 703)
+    # every group insufficient: all clean reads carry 0xFFFE, flagged ones 0xFFFF
+    ids = c.phase_regroup(np.full(g, capi.HAP_INSUFFICIENT, dtype=np.uint16), 0)
+    exp = oracle.phase(rows, table)
+    assert ((ids == capi.HAP_DAMAGED) == (exp["read_hap"] == capi.HAP_DAMAGED)).all()
+    assert (ids[ids != capi.HAP_DAMAGED] == capi.HAP_INSUFFICIENT).all()
+    # the whole-path run afterwards is not disturbed by the export state
+    c.run_async(genes, ref, capi.default_params(), None, True, 10, True)
+    v = c.run_view() or c.run_fetch(True, True, cap_var=64)
+    assert (np.asarray(v["phase"]["hap_count"]) == exp["hap_count"]).all()
+    c.close()
