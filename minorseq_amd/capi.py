@@ -17,6 +17,7 @@ MAX_HAPLOTYPES = 702
 HAP_INSUFFICIENT = 0xFFFE
 HAP_DAMAGED = 0xFFFF
 VARIANT_CAP = 4096
+PACK_PATTERN_BYTES, PACK_HIT_BYTES = 8192, 16384   # jl_internal.h: what the pinned result block holds of hap_pattern / hit
 
 GENE = np.dtype([("begin", "<u4"), ("end", "<u4")])
 VARIANT = np.dtype([("gene", "<u4"), ("codon_pos", "<u4"), ("col", "<u4"), ("ref_codon", "u1"), ("codon", "u1"),
@@ -594,7 +595,7 @@ class Juliet:
             c = dict(variants=_view(v.variants, VARIANT, 128))
             if v.phased:
                 c.update(pos_cols=_view(v.pos_cols, np.uint32, 128), hap_count=_view(v.hap_count, np.uint32, 128),
-                         hap_pattern=_view(v.hap_pattern, np.uint8, 4096), hit=_view(v.hit, np.uint8, 4096),
+                         hap_pattern=_view(v.hap_pattern, np.uint8, PACK_PATTERN_BYTES), hit=_view(v.hit, np.uint8, PACK_HIT_BYTES),
                          cooc=_view(v.cooc, np.uint32, 1024) if v.cooc else None,
                          ids=_view(v.read_hap_packed, np.uint8, 2 * v.n_reads) if v.read_hap_packed else None)
             self._rv_cache = {key: c}

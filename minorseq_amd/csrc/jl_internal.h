@@ -63,8 +63,9 @@ struct jl_phase_meta {  // device-resident scalars of one phasing run
 #define JL_PACK_MAX_VAR 128u
 #define JL_PACK_MAX_VP 128u
 #define JL_PACK_MAX_HAP 128u
-#define JL_PACK_PATTERN_BYTES 4096u
-#define JL_PACK_HIT_BYTES 4096u
+#define JL_PACK_PATTERN_BYTES 8192u   // e.g. 128 haplotypes x 64 positions
+#define JL_PACK_HIT_BYTES 16384u      // e.g. 128 variants x 128 haplotypes
+#define JL_SEL_HIT_BYTES 4096u        // what the selection out of LDS holds of it (larger results take the general path)
 #define JL_PACK_COOC_N 32u
 #define JL_PACK_MAGIC 0x4A4C504Bu
 struct jl_pack {

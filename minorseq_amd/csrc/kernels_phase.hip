@@ -270,7 +270,7 @@ __device__ __forceinline__ void phase_select_block(uint32_t min_reads, uint64_t 
                                                    uint32_t cooc_cap, jl_pack *pk, jl_pack *mirror,
                                                    unsigned long long *slot_key, uint32_t *seq_dev, uint32_t *lds,
                                                    uint32_t *exp_count = nullptr, uint8_t *exp_pattern = nullptr,
-                                                   uint32_t exp_cap = 0, uint32_t exp_stride = 0)
+                                                   uint32_t exp_cap = 0, uint32_t exp_stride = 0, uint32_t *cache = nullptr)
 {
     // `lds`: JL_SELECT_LDS_WORDS words of LDS of the caller (the fused launch lends the tables its grouping is done with)
     uint32_t *s_cand = lds;                               // [JL_CAND_CAP] slot of each candidate
@@ -325,13 +325,25 @@ __device__ __forceinline__ void phase_select_block(uint32_t min_reads, uint64_t 
         if (tid == 0) meta->overflow |= 1u;
         ncand = JL_CAND_CAP;
     }
+    // `cache` (2 * JL_CAND_CAP words of LDS, the general launch has them): every candidate's count and representative
+    // once, instead of a trip past the L1 per comparison (300 candidates: 104 us of a 234 us run)
+    uint32_t *s_ccnt = cache, *s_crep = cache ? cache + JL_CAND_CAP : nullptr;
+    if (cache) {
+        for (uint32_t a = tid; a < ncand; a += nt) {
+            const uint32_t sa = s_cand[a];
+            s_ccnt[a] = ld_coherent(&slot_count[sa]);
+            s_crep[a] = BYKEY ? sa : ld_coherent(&slot_rep[sa]);
+        }
+        __syncthreads();
+    }
     // rank sort: (count desc, pattern asc); patterns are unique so ranks are a permutation
     for (uint32_t a = tid; a < ncand; a += nt) {
-        const uint32_t sa = s_cand[a], ca = ld_coherent(&slot_count[sa]), ra = BYKEY ? sa : ld_coherent(&slot_rep[sa]);
+        const uint32_t sa = s_cand[a], ca = cache ? s_ccnt[a] : ld_coherent(&slot_count[sa]);
+        const uint32_t ra = cache ? s_crep[a] : (BYKEY ? sa : ld_coherent(&slot_rep[sa]));
         uint32_t rank = 0;
         for (uint32_t b = 0; b < ncand; ++b) {
             if (b == a) continue;
-            const uint32_t sb = s_cand[b], cb = ld_coherent(&slot_count[sb]);
+            const uint32_t sb = s_cand[b], cb = cache ? s_ccnt[b] : ld_coherent(&slot_count[sb]);
             if (cb > ca) { ++rank; continue; }
             if (cb < ca) continue;
             if (BYKEY) {
@@ -340,7 +352,7 @@ __device__ __forceinline__ void phase_select_block(uint32_t min_reads, uint64_t 
                 if (kb < ka) ++rank;
                 continue;
             }
-            const uint32_t rb = ld_coherent(&slot_rep[sb]);
+            const uint32_t rb = cache ? s_crep[b] : ld_coherent(&slot_rep[sb]);
             for (uint32_t g = 0; g < kwords; ++g) {
                 const uint64_t ka = keys[(uint64_t)g * reads_pad + ra], kb = keys[(uint64_t)g * reads_pad + rb];
                 if (kb != ka) { if (kb < ka) ++rank; break; }
@@ -370,6 +382,18 @@ __device__ __forceinline__ void phase_select_block(uint32_t min_reads, uint64_t 
         const uint32_t h = q / vp, p = q - h * vp;
         hap_pattern[(uint64_t)h * JL_VARIANT_CAP + p] = (uint8_t)pattern_code<BYKEY>(keys, slot_key, reads_pad, vp, s_hrep[h], p);
     }
+    // With the cache (free again after the ranking) the co-occurrence sums run out of LDS: the haplotype counts and, per
+    // variant, the set of haplotypes that carry it as a bit mask — filled by the hit loop below.  (Summing over two
+    // global hit rows per pair was most of this launch at 49 variants x 125 haplotypes: 98 us.)
+    const uint32_t nvc_l = nv < cooc_cap ? nv : cooc_cap;
+    constexpr uint32_t kHapWords = (JL_MAX_HAPLOTYPES + 31u) / 32u;
+    const bool cooc_lds = cache && (uint64_t)nvc_l * kHapWords + 1024u <= 2u * JL_CAND_CAP;
+    uint32_t *s_hc = cache, *s_bits = cache ? cache + 1024 : nullptr;   // [JL_MAX_HAPLOTYPES <= 1024], [nvc][kHapWords]
+    if (cooc_lds) {
+        __syncthreads();   // every thread is done with the ranking's use of the cache
+        for (uint32_t q = tid; q < nvc_l * kHapWords; q += nt) s_bits[q] = 0;
+        __syncthreads();
+    }
     for (uint32_t q = tid; q < nv * H; q += nt) {
         const uint32_t v = q / H, h = q - v * H;
         // BYKEY: the table (and col2pos) may come from another workgroup of this launch
@@ -383,11 +407,27 @@ __device__ __forceinline__ void phase_select_block(uint32_t min_reads, uint64_t 
             x = pattern_code<BYKEY>(keys, slot_key, reads_pad, vp, s_hrep[h], p) == codon;
         }
         hit[(uint64_t)v * JL_MAX_HAPLOTYPES + h] = x;
+        if (cooc_lds && x && v < nvc_l) atomicOr(&s_bits[v * kHapWords + (h >> 5)], 1u << (h & 31u));
     }
     __syncthreads();
     // co-occurrence over the reported haplotypes, for the first cooc_cap variants
-    {
-        const uint32_t nvc = nv < cooc_cap ? nv : cooc_cap;
+    if (cooc_lds) {
+        for (uint32_t h = tid; h < H; h += nt) s_hc[h] = hap_count[h];
+        __syncthreads();
+        for (uint32_t q = tid; q < nvc_l * nvc_l; q += nt) {
+            const uint32_t v = q / nvc_l, w = q - v * nvc_l;
+            uint32_t sum = 0;
+            for (uint32_t j = 0; j < (H + 31u) / 32u; ++j) {
+                uint32_t m = s_bits[v * kHapWords + j] & s_bits[w * kHapWords + j];
+                while (m) {
+                    sum += s_hc[32u * j + (uint32_t)__ffs((int)m) - 1u];
+                    m &= m - 1u;
+                }
+            }
+            cooc[(uint64_t)v * cooc_cap + w] = sum;
+        }
+    } else {
+        const uint32_t nvc = nvc_l;
         for (uint32_t q = tid; q < nvc * nvc; q += nt) {
             const uint32_t v = q / nvc, w = q - v * nvc;
             uint32_t sum = 0;
@@ -428,9 +468,10 @@ __global__ __launch_bounds__(1024) void phase_select_kernel(uint32_t min_reads, 
                                                              uint32_t exp_stride)
 {
     __shared__ uint32_t s_select[JL_SELECT_LDS_WORDS];
+    __shared__ uint32_t s_cache[2u * JL_CAND_CAP];
     phase_select_block<false>(min_reads, reads_pad, keys, meta, slot_rep, slot_count, occupied, slot_hap, variants, col2pos,
                               n_cols, hap_count, hap_pattern, hit, n_rows, vpcols, cooc, cooc_cap, pk, mirror, slot_key, seq_dev,
-                              s_select, exp_count, exp_pattern, exp_cap, exp_stride);
+                              s_select, exp_count, exp_pattern, exp_cap, exp_stride, s_cache);
     if (seq_host) {  // last kernel of the run: the result block is on its way to the host
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -525,7 +566,7 @@ struct sel_lds {
     unsigned long long hkey[kSelCand];
     uint32_t vpos[JL_PACK_MAX_VAR];
     uint8_t vcodon[JL_PACK_MAX_VAR];
-    uint8_t hit[JL_PACK_HIT_BYTES];
+    uint8_t hit[JL_SEL_HIT_BYTES];
     uint32_t ncand, insufficient, reported, bail;
 };
 static_assert(sizeof(sel_lds) <= kLdsSlots * 5u * 4u, "the selection's scratch must fit the grouping tables");
@@ -565,7 +606,7 @@ __device__ __forceinline__ bool phase_select_lds(const jl_win_phase &w, const pl
     }
     __syncthreads();
     const uint32_t H = T.ncand;
-    if (T.bail || nv * H > JL_PACK_HIT_BYTES) return false;
+    if (T.bail || nv * H > JL_SEL_HIT_BYTES) return false;
     // rank: (count desc, pattern asc); patterns are unique, so the ranks are a permutation
     for (uint32_t a = tid; a < H; a += nt) {
         const uint32_t ca = T.cnt[a];
