@@ -270,7 +270,8 @@ __device__ __forceinline__ void phase_select_block(uint32_t min_reads, uint64_t 
                                                    uint32_t cooc_cap, jl_pack *pk, jl_pack *mirror,
                                                    unsigned long long *slot_key, uint32_t *seq_dev, uint32_t *lds,
                                                    uint32_t *exp_count = nullptr, uint8_t *exp_pattern = nullptr,
-                                                   uint32_t exp_cap = 0, uint32_t exp_stride = 0, uint32_t *cache = nullptr)
+                                                   uint32_t exp_cap = 0, uint32_t exp_stride = 0, uint32_t *cache = nullptr,
+                                                   unsigned long long *key_cache = nullptr, uint32_t key_cache_words = 0)
 {
     // `lds`: JL_SELECT_LDS_WORDS words of LDS of the caller (the fused launch lends the tables its grouping is done with)
     uint32_t *s_cand = lds;                               // [JL_CAND_CAP] slot of each candidate
@@ -336,6 +337,16 @@ __device__ __forceinline__ void phase_select_block(uint32_t min_reads, uint64_t 
         }
         __syncthreads();
     }
+    // ... and, when they fit, the candidates' keys: equal counts are common among the small groups, and every tie was two
+    // more trips to the key buffer
+    const bool keys_lds = !BYKEY && cache && key_cache && (uint64_t)ncand * kwords <= key_cache_words;
+    if (keys_lds) {
+        for (uint32_t q = tid; q < ncand * kwords; q += nt) {
+            const uint32_t a = q / kwords, g = q - a * kwords;
+            key_cache[q] = keys[(uint64_t)g * reads_pad + s_crep[a]];
+        }
+        __syncthreads();
+    }
     // rank sort: (count desc, pattern asc); patterns are unique so ranks are a permutation
     for (uint32_t a = tid; a < ncand; a += nt) {
         const uint32_t sa = s_cand[a], ca = cache ? s_ccnt[a] : ld_coherent(&slot_count[sa]);
@@ -350,6 +361,13 @@ __device__ __forceinline__ void phase_select_block(uint32_t min_reads, uint64_t 
                 const uint64_t ka = ld_coherent64(&slot_key[sa]);
                 const uint64_t kb = ld_coherent64(&slot_key[sb]);
                 if (kb < ka) ++rank;
+                continue;
+            }
+            if (keys_lds) {
+                for (uint32_t g = 0; g < kwords; ++g) {
+                    const uint64_t ka = key_cache[a * kwords + g], kb = key_cache[b * kwords + g];
+                    if (kb != ka) { if (kb < ka) ++rank; break; }
+                }
                 continue;
             }
             const uint32_t rb = cache ? s_crep[b] : ld_coherent(&slot_rep[sb]);
@@ -469,9 +487,10 @@ __global__ __launch_bounds__(1024) void phase_select_kernel(uint32_t min_reads, 
 {
     __shared__ uint32_t s_select[JL_SELECT_LDS_WORDS];
     __shared__ uint32_t s_cache[2u * JL_CAND_CAP];
+    __shared__ unsigned long long s_keys[2048];
     phase_select_block<false>(min_reads, reads_pad, keys, meta, slot_rep, slot_count, occupied, slot_hap, variants, col2pos,
                               n_cols, hap_count, hap_pattern, hit, n_rows, vpcols, cooc, cooc_cap, pk, mirror, slot_key, seq_dev,
-                              s_select, exp_count, exp_pattern, exp_cap, exp_stride, s_cache);
+                              s_select, exp_count, exp_pattern, exp_cap, exp_stride, s_cache, s_keys, 2048u);
     if (seq_host) {  // last kernel of the run: the result block is on its way to the host
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
