@@ -372,3 +372,40 @@ def test_insertion_counters_match_the_oracle(jl, oracle):
     jl.ingest_records(l, 0, pos, cigar, cig_off, seq4, seq_off)
     with pytest.raises(capi.JulietError):
         jl.insertions_fetch()
+
+
+def test_result_block_holds_a_sixteen_position_window(oracle):
+    """More than ten variant positions (multi-word keys) with ~100 haplotypes: 49 variants x 125 haplotypes of `hit` used to
+    overflow the pinned result block (4 KB), so every run fell back to the copying fetch.  The zero-copy view must now
+    carry it, bit-exact, on the first run (single-word launch flags, fetch re-runs) and on the following ones."""
+    n, l = 100_000, 900
+    sp = synth.SynthParams(seed=23)
+    ref = synth.reference(sp.seed, l)
+    rows = synth.rows(sp, l, 0, n, ref)
+    rng = np.random.default_rng(3)
+    for k in range(12):
+        who = rng.choice(n, n // 30, replace=False)
+        c0 = 3 * (20 + 22 * k)
+        rows[who, c0:c0 + 3] = (rows[who, c0:c0 + 3] + 1 + k % 3) % 4
+    genes = np.array([(1, l + 1)], dtype=capi.GENE)
+    exp_v = oracle.call(rows, genes, refseq=ref)
+    exp = oracle.phase(rows, exp_v)
+    assert exp["summary"]["n_positions"] > 10 and len(exp_v) * exp["summary"]["n_haplotypes"] > 4096
+    assert len(exp_v) <= 128 and exp["summary"]["n_haplotypes"] <= 128       # the block's row limits
+    c = capi.Juliet(0)
+    c.upload_columns(msa.pack_columns(rows), n)
+    prm = capi.default_params()
+    for rep in range(3):
+        c.run_async(genes, ref, prm, None, True, 10, True)
+        v = c.run_view()
+        if rep == 0 and v is None:      # the flagged first run may need the copying fetch (it re-runs the pipeline)
+            v = c.run_fetch(True, True, cap_var=128)
+        assert v is not None, "the result block must hold this window"
+        ph = v["phase"]
+        h = exp["summary"]["n_haplotypes"]
+        assert ph["summary"] == exp["summary"]
+        assert (np.asarray(ph["hap_count"])[:h] == exp["hap_count"]).all()
+        assert (np.asarray(ph["hap_pattern"])[:h, :exp["summary"]["n_positions"]] == exp["hap_pattern"]).all()
+        assert (np.asarray(ph["hit"])[:len(exp_v), :h] == exp["hit"]).all()
+        assert (np.asarray(ph["read_hap"]) == exp["read_hap"]).all()
+    c.close()
