@@ -110,7 +110,10 @@ def select_haplotypes(patterns, counts, variants, pos_cols, min_reads=10, partia
     -> dict like Juliet.phase_fetch (no read_hap) + hap_of_merged int64[M] (HAP_INSUFFICIENT where not reported)."""
     patterns = np.asarray(patterns, dtype=np.uint8)
     counts = np.asarray(counts, dtype=np.int64)
-    m, vp = patterns.shape if patterns.ndim == 2 else (0, 0)
+    m = patterns.shape[0] if patterns.ndim == 2 else 0
+    vp = len(pos_cols)            # the positions exist even when no read is clean (no groups at all)
+    if m == 0:
+        patterns = np.zeros((0, vp), dtype=np.uint8)
     qualified = np.nonzero(counts >= min_reads)[0]
     # (count descending, then pattern ascending position by position): lexsort's LAST key is the primary one
     keys = [patterns[qualified, p] for p in range(vp - 1, -1, -1)] + [-counts[qualified]]

@@ -181,3 +181,30 @@ def test_state_and_argument_errors_are_loud(oracle):
     v = c.run_view() or c.run_fetch(True, True, cap_var=64)
     assert (np.asarray(v["phase"]["hap_count"]) == exp["hap_count"]).all()
     c.close()
+
+
+def test_random_shapes_against_the_unsharded_oracle(oracle):
+    """Random reads, window counts, shard counts, error rates (up to 200 variant positions = 20-word keys; samples where
+    not one read is clean): the sharded run equals the unsharded oracle in everything."""
+    rng = np.random.default_rng(12345)
+    seen_many, seen_none = False, False
+    for trial in range(12):
+        n = int(rng.integers(300, 30000))
+        l = int(rng.choice([120, 300, 600]))
+        shards, world = int(rng.integers(1, 7)), int(rng.integers(1, 4))
+        sp = synth.SynthParams(seed=int(rng.integers(1, 1 << 30)), minor_permille=tuple(int(x) for x in rng.integers(20, 120, 4)),
+                               partial_rate=float(rng.choice([0.0, 0.1, 0.4])), sub_rate=float(rng.choice([1.75e-4, 5e-3])))
+        ref = synth.reference(sp.seed, l)
+        rows = synth.rows(sp, l, 0, n, ref)
+        genes = np.array([(1, 3 * (l // 3) + 1)], dtype=capi.GENE)
+        ctxs, merged = windows_of(rows, n, l, world, genes, ref)
+        full = oracle.call(rows, genes, refseq=ref)
+        assert len(merged) == len(full) and all((merged[k] == full[k]).all() for k in ("gene", "codon_pos", "col", "codon", "count", "coverage"))
+        exp = oracle.phase(rows, full)
+        got, _ = capi.phase_sharded_by_reads(ctxs, merged, shards)
+        assert_same(got, exp, len(full))
+        seen_many |= exp["summary"]["n_positions"] > 10
+        seen_none |= exp["summary"]["n_positions"] > 0 and exp["summary"]["reported_reads"] + exp["summary"]["insufficient_reads"] == 0
+        for c in ctxs:
+            c.close()
+    assert seen_many and seen_none

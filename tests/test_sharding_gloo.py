@@ -269,6 +269,10 @@ def test_read_slices_and_group_merge_edge_cases():
     # equal counts: pattern ascending
     ph = sharding.select_haplotypes(np.array([[1, 9], [1, 2], [0, 7]], dtype=np.uint8), [12, 12, 12], v[:1], [0, 3], 10)
     assert ph["hap_pattern"].tolist() == [[0, 7], [1, 2], [1, 9]] and ph["hap_of_merged"].tolist() == [2, 1, 0]
+    # positions but not one clean read (every read flagged): no groups, the positions still count
+    p0, n0, _ = sharding.merge_groups([b])
+    ph = sharding.select_haplotypes(p0, n0, v, [0, 3], 10, [dict(damaged_reads=7, marginal_gap=7, marginal_heteroduplex=0, marginal_partial=1)])
+    assert ph["summary"]["n_positions"] == 2 and ph["summary"]["damaged_reads"] == 7 and ph["hit"].shape == (2, 0)
     # nothing to phase
     p0, n0, _ = sharding.merge_groups([b])
     ph = sharding.select_haplotypes(p0, n0, v[:0], [], 10)
