@@ -352,6 +352,44 @@ __device__ __forceinline__ void phase_select_block(uint32_t min_reads, uint64_t 
         const uint32_t sa = s_cand[a], ca = cache ? s_ccnt[a] : ld_coherent(&slot_count[sa]);
         const uint32_t ra = cache ? s_crep[a] : (BYKEY ? sa : ld_coherent(&slot_rep[sa]));
         uint32_t rank = 0;
+        if (cache && (BYKEY || keys_lds)) {
+            // everything the comparison needs sits in LDS: one pass without a trip to memory
+            const uint64_t ka0 = BYKEY ? ld_coherent64(&slot_key[sa]) : key_cache[a * kwords];
+            // eight candidates per trip, count and first key word of each read unconditionally (independent LDS reads in
+            // flight: one at a time behind a data-dependent branch was 380 cycles per candidate, and equal counts are the
+            // rule among small groups); only equal counts AND equal first words go on to the remaining words
+            // (the caches arrive as generic pointers: typed as LDS here, or every read is a flat load)
+            typedef __attribute__((address_space(3))) const uint32_t lds_u32;
+            typedef __attribute__((address_space(3))) const unsigned long long lds_u64;
+            lds_u32 *l_ccnt = (lds_u32 *)s_ccnt;
+            lds_u32 *l_cand = (lds_u32 *)s_cand;
+            lds_u64 *l_key = (lds_u64 *)key_cache;
+            for (uint32_t b0 = 0; b0 < ncand; b0 += 8u) {
+                uint32_t cb[8];
+                uint64_t kb[8];
+#pragma unroll
+                for (uint32_t j = 0; j < 8u; ++j) {
+                    const uint32_t b = b0 + j < ncand ? b0 + j : a;
+                    cb[j] = l_ccnt[b];
+                    kb[j] = BYKEY ? ld_coherent64(&slot_key[l_cand[b]]) : l_key[b * kwords];
+                }
+                uint32_t ties = 0;
+#pragma unroll
+                for (uint32_t j = 0; j < 8u; ++j) {
+                    const bool live = b0 + j < ncand && b0 + j != a;
+                    rank += (live && (cb[j] > ca || (cb[j] == ca && kb[j] < ka0))) ? 1u : 0u;
+                    ties |= (live && cb[j] == ca && kb[j] == ka0) ? 1u << j : 0u;
+                }
+                while (!BYKEY && ties) {   // same count, same first ten positions: the later words decide
+                    const uint32_t b = b0 + (uint32_t)__ffs((int)ties) - 1u;
+                    ties &= ties - 1u;
+                    for (uint32_t g = 1; g < kwords; ++g) {
+                        const uint64_t ka = key_cache[a * kwords + g], kbg = key_cache[b * kwords + g];
+                        if (kbg != ka) { rank += kbg < ka ? 1u : 0u; break; }
+                    }
+                }
+            }
+        } else
         for (uint32_t b = 0; b < ncand; ++b) {
             if (b == a) continue;
             const uint32_t sb = s_cand[b], cb = cache ? s_ccnt[b] : ld_coherent(&slot_count[sb]);
@@ -361,13 +399,6 @@ __device__ __forceinline__ void phase_select_block(uint32_t min_reads, uint64_t 
                 const uint64_t ka = ld_coherent64(&slot_key[sa]);
                 const uint64_t kb = ld_coherent64(&slot_key[sb]);
                 if (kb < ka) ++rank;
-                continue;
-            }
-            if (keys_lds) {
-                for (uint32_t g = 0; g < kwords; ++g) {
-                    const uint64_t ka = key_cache[a * kwords + g], kb = key_cache[b * kwords + g];
-                    if (kb != ka) { if (kb < ka) ++rank; break; }
-                }
                 continue;
             }
             const uint32_t rb = cache ? s_crep[b] : ld_coherent(&slot_rep[sb]);
@@ -1269,3 +1300,4 @@ void jl_launch_regroup(jl_ctx *ctx, const uint16_t *d_hap_of_group, uint32_t n_g
     hipLaunchKernelGGL(phase_assign_kernel, dim3(jl_assign_blocks(1, (n_dwords + 255u) / 256u, false)), dim3(256), 0, st,
                        (uint64_t)n_dwords, ctx->d_flagw, ctx->d_meta, ctx->d_read_slot, ctx->d_slot_hap, ctx->d_read_hap);
 }
+
