@@ -1033,6 +1033,9 @@ static int phase_settle(jl_ctx *ctx, jl_phase_meta *out)
             JL_HIP(ctx, hipStreamSynchronize(st));
         }
     }
+    if (meta.overflow & 32u)
+        return jl_fail(ctx, JL_ERR_DEVICE, "a phasing workgroup gave up waiting for the selection of its launch (the launch's "
+                                           "workgroups were not resident together): the run's phasing results are invalid");
     *out = meta;
     return JL_OK;
 }

@@ -1057,19 +1057,26 @@ __device__ __forceinline__ void phase_fused1_body(const jl_win_phase &w)
         __syncthreads();
     } else {
         // wait for the selection.  Every workgroup of this launch is resident (the host folds only small grids), so
-        // the flag does arrive; the bound turns a broken invariant into a loud failure, not a hang.
+        // the flag does arrive; the bound turns a broken invariant into a loud failure, not a hang — and not a fault
+        // either (a trap can take the device down for every tenant): the run is marked failed where both ways of reading
+        // it look (the phase scalars for jl_phase_fetch, the pinned block's magic for jl_run_view_get), this workgroup
+        // writes no ids and goes on to the second arrival so that the launch still ends.
         if (tid == 0) {
             uint32_t spins = 0, bits;
             while ((bits = __hip_atomic_load(S.flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0u) {
                 __builtin_amdgcn_s_sleep(8);
-                if (++spins > (1u << 23)) __builtin_trap();
+                if (++spins > (1u << 23)) {
+                    atomicOr(&meta->overflow, 32u);
+                    if (S.mirror) __hip_atomic_store(&S.mirror->magic, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    break;
+                }
             }
-            s_idbits = bits;
+            s_idbits = bits;   // 0: timed out
         }
         __syncthreads();
     }
     // ---- per-read haplotype ids of this workgroup's own reads, straight from the slots still in registers
-    if (live) {
+    if (live && s_idbits) {
         uint16_t h[8];
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
