@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void phase_keys_kernel(const uint8_t *__restri
                                                           uint64_t *__restrict__ keys, uint32_t *__restrict__ flagw)
 {
     const uint32_t vp = meta->vp;
-    if (vp == 0 || meta->kwords == 1) return;  // single-word keys take the fused kernel below
+    if (vp == 0) return;   // (a context on the multi-word pipeline takes it for every run, whatever the run's key width)
     const uint64_t t = (uint64_t)blockIdx.x * 256u + threadIdx.x;  // dword index within a column
     const bool live = t * 4u < col_stride;
     uint32_t gap = 0, het = 0, par = 0;
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256) void phase_group_kernel(uint64_t n_reads, uint
                                                            uint32_t *__restrict__ read_slot)
 {
     const uint32_t kwords = meta->kwords;
-    if (kwords <= 1) return;  // 0: nothing to phase; 1: fused kernel
+    if (kwords == 0) return;  // nothing to phase
     const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63u;
     bool active = false;
@@ -1236,7 +1236,8 @@ bool jl_launch_phase(jl_ctx *ctx, hipStream_t st, uint32_t min_reads, bool plann
                            ctx->d_flagw);
     jl_win_phase w;
     const bool fold = jl_fill_win_phase(ctx, min_reads, signal, JL_FOLD_MAX_BLOCKS, from_called, &w);
-    hipLaunchKernelGGL(phase_fused1_kernel, dim3(w.n_blocks + (w.S.called ? 1u : 0u)), dim3(256), 0, st, w);
+    // (the multi-word pipeline has its own keys / grouping / selection launches: the fused launch would find nothing to do)
+    if (!generic) hipLaunchKernelGGL(phase_fused1_kernel, dim3(w.n_blocks + (w.S.called ? 1u : 0u)), dim3(256), 0, st, w);
     if (generic) {
         hipLaunchKernelGGL(phase_group_kernel, dim3(rblocks), dim3(256), 0, st, ctx->n_reads, reads_pad, ctx->d_keys,
                            ctx->d_flagw, ctx->d_meta, ctx->table_slots - 1u, ctx->d_slot_rep, ctx->d_slot_count,
