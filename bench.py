@@ -455,7 +455,7 @@ def main():
             out["config3_strong"] = {"error": reason, "scaling": "strong", "n_gpus": world}
             if rank == 0:
                 os.write(real_stdout, (json.dumps(out) + "\n").encode())
-            os._exit(0)
+            os._exit(3)   # the line is out, and the failure shows in the exit code too
         watchdog = threading.Timer(args.config3_timeout, leave, (f"no result after {args.config3_timeout} s",))
         watchdog.daemon = True
         if distributed:
@@ -487,10 +487,11 @@ def main():
 def config3_strong(capi, sharding, synth, torch, dist, distributed, comm, rank, world, local_rank, free_ctxs, reps=12):
     """BASELINE.json configs[3] as stated: 1M CCS reads x ONE 10 kb reference, split into `world` column windows (rank
     r holds the 1M reads' columns of window r: 5 GB / world).  A step = call per window with the GLOBAL Bonferroni
-    factor -> all-gather of the variant table (RCCL) -> phasing across windows with the READS sharded (SURVEY 8e option A):
-    the owner of every variant position sends rank s the slice s of its three columns (RCCL send/recv, the second
-    exchange: 1/world of the bytes a broadcast would move), every rank groups its 1M/world reads, the group tables
-    (KB) are all-gathered and merged on the host, each rank maps its own reads.  `value` = 1M / t.
+    factor (jl_run_async, phasing off) and ONE call of the C ABI for the rest (jl_xwin_phase_sharded): all-gather of the
+    variant table (RCCL) -> merge + plan -> one packed send per peer of the variant columns' read slices (RCCL; SURVEY 8e
+    option A) -> every rank groups its 1M/world reads -> all-gather of the group tables (RCCL) -> merge + selection on the
+    merged counts (C++) -> per-read ids of the rank's slice.  No Python, numpy or pickle between the stages; every
+    hand-off to the host is a word in pinned memory.  `value` = 1M / t.
     The per-read ids stay on the device inside the loop (fetched once at the end): at 1e6 reads expanding them on the
     host would be most of a step."""
     # The weak-scaling batches stay allocated (4.8 + 5 GB of 288): device memory that was freed and is allocated again
@@ -507,35 +508,13 @@ def config3_strong(capi, sharding, synth, torch, dist, distributed, comm, rank, 
     win.alloc(n, e - b, win_begin=b)
     win.synth_fill_window(sp, ref)
     win.sync()
-    pc = capi.Juliet(local_rank)
     # the reads are sharded for phasing (SURVEY 8e option A): rank r groups reads [sb[r], sb[r+1])
     sb = sharding.read_slices(n, world)
-    n_mine = sb[rank + 1] - sb[rank]
-    if world > 1:
-        rows = np.zeros(world * capi.VARIANT_CAP, dtype=capi.VARIANT)
-        counts = np.zeros(world, dtype=np.uint32)
-        wbeg = np.array([x for x, _ in wb], dtype=np.uint32)
-        wnc = np.array([y - x for x, y in wb], dtype=np.uint32)
+    xw = capi.Xwin([win], [x for x, _ in wb], [y - x for x, y in wb], list(range(world)), sb, comm if world > 1 else None)
 
-    def step(want_reads=False):
+    def step():
         win.run_async(genes, ref, prm, None, False, 10, False)
-        if world > 1:
-            win._chk(win.lib.jl_allgather_variants(win.h, comm, rows.ctypes.data_as(C.c_void_p), counts.ctypes.data_as(C.c_void_p),
-                                                   capi.VARIANT_CAP))
-            tables = [rows[r * capi.VARIANT_CAP: r * capi.VARIANT_CAP + int(counts[r])] for r in range(world)]
-            merged = sharding.merge_tables(tables, wbeg)
-            remapped, pos_global, vp = pc.xwin_assemble_slice_rccl(win, comm, wbeg, wnc, merged, sb)
-            pc._shape(n_mine, 3 * vp, pc.lib.jl_col_stride(n_mine))
-        else:
-            merged = sharding.merge_tables([win.run_fetch(False, False)["variants"]], [b])
-            remapped, pos_global = pc.xwin_assemble_slice_local([win], merged, 0, n)
-        pc.phase_groups_async(remapped)
-        mine = pc.phase_groups_fetch()
-        groups = sharding.allgather_groups(mine) if world > 1 else [mine]
-        patterns, gcounts, index = sharding.merge_groups(groups)
-        ph = sharding.select_haplotypes(patterns, gcounts, remapped, mine["pos_cols"], 10, [t["summary"] for t in groups])
-        ph["read_hap"] = pc.phase_regroup(ph["hap_of_merged"][index[rank]].astype(np.uint16), ph["summary"]["n_haplotypes"], want_reads)
-        return merged, ph
+        return xw.phase_raw(10)
 
     def fence():
         if distributed:
@@ -549,7 +528,7 @@ def config3_strong(capi, sharding, synth, torch, dist, distributed, comm, rank, 
     per_step = []
     for _ in range(reps):
         t_s = time.perf_counter()
-        merged, ph = step()      # ends with the device idle: every step fetches its results
+        step()      # ends with the device idle: the call returns once the slice's ids are in HBM
         per_step.append(time.perf_counter() - t_s)
     fence()
     t = (time.perf_counter() - t0) / reps
@@ -558,20 +537,26 @@ def config3_strong(capi, sharding, synth, torch, dist, distributed, comm, rank, 
         tt = torch.tensor([t], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         t = float(tt.item())
-    merged, ph = step(want_reads=True)
-    s = ph["summary"]
+    res = xw.phase(10, want_reads=True)
+    s = res["summary"]
     assert s["reported_reads"] + s["insufficient_reads"] + s["damaged_reads"] == n      # doc/JULIET.md:378-379
+    ids = res["read_hap"]
+    assert len(ids) == sb[rank + 1] - sb[rank]
+    if world == 1:   # every read's id is consistent with the categories
+        assert int((ids == capi.HAP_DAMAGED).sum()) == s["damaged_reads"] and int((ids < s["n_haplotypes"]).sum()) == s["reported_reads"]
     t_k = win.time_pileup(reps=5)
     out = {"workload": f"configs[3]: {n} CCS reads x {l} bp reference split into {world} column window(s), call per window + "
-                       "all-gather + cross-window phasing with the reads sharded (jl_xwin_assemble_slice_*, jl_phase_groups_*, "
-                       "jl_phase_regroup: SURVEY 8e option A)",
+                       "jl_xwin_phase_sharded (all-gather of the table, packed column-slice exchange, grouping per read slice, "
+                       "all-gather + C++ merge of the group tables, ids: SURVEY 8e option A)",
            "value": n / t, "unit": "reads/s", "ms_per_step": 1000.0 * t, "ms_per_step_median": 1000.0 * t_median,
            "scaling": "strong", "n_gpus": world,
-           "columns_per_gpu": int(e - b), "variants_called": int(len(merged)), "variant_positions": int(s["n_positions"]),
+           "columns_per_gpu": int(e - b), "variants_called": int(len(res["merged"])), "variant_positions": int(s["n_positions"]),
            "haplotypes": int(s["n_haplotypes"]),
-           "exchanges": "none (one window)" if world == 1 else "1 ncclAllGather of the variant table + 1 group of ncclSend/ncclRecv (slice r of 3 columns per variant position to rank r) + 1 all-gather of the group tables (KB, control plane)",
-           "pileup_kernel_ms": t_k, "pileup_frac_of_hbm_peak": (n * (e - b) / 2.0) / (t_k * 1e-3) / 1e9 / HBM_PEAK_GBS}
-    pc.close()
+           "exchanges": "none (one window)" if world == 1 else "1 ncclAllGather of the variant tables + 1 group of packed ncclSend/ncclRecv (slice r of the owned columns to rank r, one message per peer) + 1 ncclAllGather of the group tables",
+           "pileup_kernel_ms": t_k, "pileup_frac_of_hbm_peak": (n * (e - b) / 2.0) / (t_k * 1e-3) / 1e9 / HBM_PEAK_GBS,
+           # what does NOT shrink like the pileup when the columns are split over more GPUs (the Amdahl term of 1 -> 8 scaling)
+           "serial_residue_ms": 1000.0 * t - t_k, "serial_residue_ms_median": 1000.0 * t_median - t_k}
+    xw.close()
     win.close()
     return out
 

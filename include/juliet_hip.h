@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define JL_ABI_VERSION 3
+#define JL_ABI_VERSION 4
 
 /* symbol codes of the MSA (SPEC §1; J:99-100, 256-259, 372-381) */
 enum { JL_SYM_A = 0, JL_SYM_C = 1, JL_SYM_G = 2, JL_SYM_T = 3, JL_SYM_GAP = 4, JL_SYM_MASK = 5, JL_SYM_NONE = 6 };
@@ -422,6 +422,104 @@ int jl_phase_groups_fetch(jl_ctx *ctx, uint8_t *patterns, uint32_t pattern_strid
 /* hap_of_group[q] = haplotype id of exported group q after the merge (JL_HAP_INSUFFICIENT: not reported);
  * read_hap (optional, [n_reads of this matrix]) receives the per-read ids */
 int jl_phase_regroup(jl_ctx *ctx, const uint16_t *hap_of_group, uint32_t n_groups, uint32_t n_haplotypes, uint16_t *read_hap);
+
+/* ---------------------------------------------------------------- the merge of the sharded path: host only
+ *
+ * No device and no communicator: these run anywhere the library loads (the gloo tests call them on CPU ranks).
+ * Behaviour: the >= 10-read rule applies to the MERGED count of a pattern (J:253-254); order, ids, haplotype_hit and the
+ * read categories as docs/SPEC.md §8 (J:192-211, 372-381). */
+
+/* Per-window tables (window-relative `col`) -> one table with GLOBAL columns in (gene, codon_pos, codon) order.
+ * tables[t] has counts[t] rows and belongs to the window starting at reference column win_begin[t].
+ * JL_ERR_OVERFLOW if the rows do not fit `cap` (*n_merged then holds the number needed). */
+int jl_merge_tables(const jl_variant *const *tables, const uint32_t *counts, const uint32_t *win_begin, uint32_t n_tables,
+                    jl_variant *merged, uint32_t cap, uint32_t *n_merged);
+/* Exported group tables (jl_phase_groups_fetch: patterns[t][q * pattern_stride[t] + p], counts[t][q], n_groups[t] groups
+ * of vp positions) -> the distinct patterns in ascending order (codon codes compared position by position), the summed
+ * counts, and index[t][q] = merged row of group q of table t (index or index[t] may be NULL). */
+int jl_merge_groups(const uint8_t *const *patterns, const uint32_t *pattern_stride, const uint32_t *const *counts,
+                    const uint32_t *n_groups, uint32_t n_tables, uint32_t vp, uint8_t *merged_patterns /* [cap][vp] */,
+                    uint64_t *merged_counts, uint32_t cap, uint32_t *n_merged, uint32_t *const *index);
+/* docs/SPEC.md §8 on merged groups: reported = count >= min_reads, ordered by (count desc, pattern asc), at most
+ * JL_MAX_HAPLOTYPES.  `variants`: the table with col = 3 * position index (jl_xwin_plan's `remapped`) or any table whose
+ * `col` values appear in pos_cols[vp].  partials[n_partials]: each slice's damaged reads and marginals.
+ * Outputs (any may be NULL): summary; hap_count[H]; hap_pattern[H][vp]; hit[n_var][hit_stride] (J:207-209);
+ * cooc[n_var][n_var]; hap_of_group[n_groups] (JL_HAP_INSUFFICIENT where not reported). */
+int jl_select_haplotypes(const uint8_t *patterns, const uint64_t *counts, uint32_t n_groups, uint32_t vp,
+                         const jl_variant *variants, uint32_t n_var, const uint32_t *pos_cols, uint32_t min_reads,
+                         const jl_phase_summary *partials, uint32_t n_partials, jl_phase_summary *summary,
+                         uint32_t *hap_count, uint8_t *hap_pattern, uint8_t *hit, uint32_t hit_stride, uint32_t *cooc,
+                         uint16_t *hap_of_group);
+
+/* The schedule of the column-slice exchange as data (what jl_xwin_phase_sharded / jl_xwin_assemble_slice_rccl issue):
+ * positions are ascending global columns and windows ascending column ranges, so the positions a rank owns are ONE run
+ * k_begin .. k_begin + k_count, and a rank sends every peer ONE packed message: slice s of the 3 * k_count owned
+ * columns, each column padded with 'not covered' (0x66) to dst_stride = jl_col_stride(reads of slice s) — exactly the
+ * bytes of columns 3 * k_begin .. of the receiver's compact matrix, where the matching receive lands them.
+ * win_rank[w] = rank that holds window w (non-decreasing).  ops of rank `rank`, in issue order: its own slice (a device
+ * copy), then per peer in ascending order the send and the receive.  Every send has exactly one matching receive
+ * (same byte count) in the peer's list.  JL_ERR_ARG if a variant column lies in no window. */
+enum { JL_XWIN_OP_LOCAL = 0, JL_XWIN_OP_SEND = 1, JL_XWIN_OP_RECV = 2 };
+typedef struct {
+    int32_t op, peer;            /* peer: the other rank (own rank for JL_XWIN_OP_LOCAL) */
+    uint32_t k_begin, k_count;   /* positions whose columns travel */
+    uint64_t read_begin, n_reads;/* the slice of the reads (the RECEIVER's slice) */
+    uint64_t dst_stride;         /* bytes per column in the message = the receiver's column stride */
+    uint64_t bytes;              /* 3 * k_count * dst_stride */
+    uint64_t dst_offset;         /* where the message lands in the receiver's compact matrix: 3 * k_begin * dst_stride */
+} jl_xwin_op;
+int jl_xwin_slice_plan(const uint32_t *win_begin, const uint32_t *win_ncols, const int32_t *win_rank, uint32_t n_windows,
+                       const jl_variant *merged, uint32_t n_var, const uint64_t *slice_begin, int32_t world, int32_t rank,
+                       jl_xwin_op *ops, uint32_t cap_ops, uint32_t *n_ops);
+
+/* ---------------------------------------------------------------- cross-window phasing, the whole sequence
+ *
+ * A session = this rank's windows of ONE reference whose reads span every window (BASELINE.json configs[3]/[4]), the
+ * communicator (NULL when world = 1: every window is on this device), the column layout of ALL windows and the read
+ * slices.  windows[0 .. n_local) are this rank's windows in ascending column order, i.e. the windows w with
+ * win_rank[w] == rank.  Slices start on multiples of 256 reads; slice_begin has world + 1 entries.
+ *
+ * jl_xwin_phase_sharded, called by every rank after its windows' call stage (jl_run_async / jl_group_run_async with
+ * phasing off, or jl_call_async), runs the rest of the path with the reads sharded (option A):
+ *   all-gather of the variant tables (RCCL, one collective; none at world = 1)  ->  merge + plan on the host  ->
+ *   one packed send per peer of the variant columns' slices (RCCL; a device copy for the own slice)  ->
+ *   keys + grouping of the slice on the device, the groups exported  ->  all-gather of the group tables (RCCL) ->
+ *   merge + selection on the host (jl_merge_groups, jl_select_haplotypes)  ->  per-read ids of the slice on the device.
+ * The result's pointers are into the session and stay valid until the next call; the per-read ids stay in HBM until
+ * jl_xwin_read_hap_fetch.  While the call runs the communicator must have no asynchronous exchange pending
+ * (JL_ERR_STATE otherwise): the session issues its collectives from the calling thread. */
+typedef struct jl_xwin jl_xwin;
+typedef struct {
+    uint32_t n_variants;          /* rows of `merged` */
+    uint32_t n_positions;         /* Vp */
+    uint32_t n_haplotypes;        /* H */
+    uint32_t n_groups;            /* distinct patterns over all slices */
+    jl_phase_summary summary;     /* read categories over ALL reads (J:372-381) */
+    const jl_variant *merged;     /* every window's rows, global columns, (gene, codon_pos, codon) order */
+    const uint32_t *pos_global;   /* [Vp] ascending global columns */
+    const uint32_t *hap_count;    /* [H] */
+    const uint8_t *hap_pattern;   /* [H][Vp] */
+    const uint8_t *hit;           /* [n_variants][H] (haplotype_hit, J:207-209) */
+    const uint32_t *cooc;         /* [n_variants][n_variants] */
+    uint64_t slice_begin, slice_reads;  /* this rank's reads */
+    uint32_t read_hap_bits;       /* width of the per-read ids in HBM: 4, 8 or 16 */
+    uint32_t reserved;
+} jl_xwin_result;
+int jl_xwin_create(jl_ctx *const *windows, uint32_t n_local, jl_comm *comm, const uint32_t *win_begin,
+                   const uint32_t *win_ncols, const int32_t *win_rank, uint32_t n_windows, const uint64_t *slice_begin,
+                   jl_xwin **out);
+void jl_xwin_destroy(jl_xwin *x);
+const char *jl_xwin_last_error(const jl_xwin *x);
+int jl_xwin_phase_sharded(jl_xwin *x, uint32_t min_reads, jl_xwin_result *out);
+/* 16-bit ids of this rank's slice (read_hap[slice_reads]) of the last jl_xwin_phase_sharded. */
+int jl_xwin_read_hap_fetch(jl_xwin *x, uint16_t *read_hap);
+/* The collective on its own, for hosts that drive the stages themselves: fixed-stride all-gather over RCCL of the
+ * groups jl_phase_groups_async exported on `ctx` (cap_groups rows of pattern_stride bytes per rank, plus counts, the
+ * partial summary and the number of positions).  Host outputs: patterns[world][cap_groups][pattern_stride],
+ * counts[world][cap_groups], n_groups[world], partials[world].  JL_ERR_OVERFLOW, on every rank alike, when a rank
+ * exported more than cap_groups groups. */
+int jl_allgather_groups(jl_ctx *ctx, jl_comm *comm, uint32_t cap_groups, uint32_t pattern_stride, uint8_t *patterns,
+                        uint32_t *counts, uint32_t *n_groups, jl_phase_summary *partials, uint32_t *n_positions);
 
 #ifdef __cplusplus
 }

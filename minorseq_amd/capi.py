@@ -36,7 +36,9 @@ EXPORTS = ("jl_abi_version", "jl_strerror", "jl_device_count", "jl_ctx_create", 
            "jl_group_last_error", "jl_group_run_async", "jl_group_run_masked_async", "jl_group_time_pileup", "jl_fisher_eval", "jl_fisher_eval_tail", "jl_expand_read_hap", "jl_time_pileup", "jl_time_pileup_set", "jl_pileup_kernel_name", "jl_comm_unique_id", "jl_comm_create", "jl_comm_destroy",
            "jl_allgather_variants", "jl_allgather_variants_async", "jl_allgather_variants_async_many", "jl_allgather_variants_many", "jl_xwin_plan", "jl_xwin_assemble_local",
            "jl_xwin_assemble_rccl", "jl_xwin_assemble_slice_local", "jl_xwin_assemble_slice_rccl", "jl_phase_groups_async",
-           "jl_phase_groups_fetch", "jl_phase_regroup")
+           "jl_phase_groups_fetch", "jl_phase_regroup", "jl_merge_tables", "jl_merge_groups", "jl_select_haplotypes",
+           "jl_xwin_slice_plan", "jl_xwin_create", "jl_xwin_destroy", "jl_xwin_last_error", "jl_xwin_phase_sharded",
+           "jl_xwin_read_hap_fetch", "jl_allgather_groups")
 
 
 class ErrorModel(C.Structure):
@@ -55,6 +57,24 @@ class SynthParams(C.Structure):
 
 class PhaseSummary(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in SUMMARY_FIELDS]
+
+
+class XwinOp(C.Structure):
+    """jl_xwin_op: one step of a rank's column-slice exchange (include/juliet_hip.h)."""
+    _fields_ = [("op", C.c_int32), ("peer", C.c_int32), ("k_begin", C.c_uint32), ("k_count", C.c_uint32),
+                ("read_begin", C.c_uint64), ("n_reads", C.c_uint64), ("dst_stride", C.c_uint64), ("bytes", C.c_uint64),
+                ("dst_offset", C.c_uint64)]
+
+
+XWIN_OP_LOCAL, XWIN_OP_SEND, XWIN_OP_RECV = 0, 1, 2
+
+
+class XwinResult(C.Structure):
+    """jl_xwin_result: what jl_xwin_phase_sharded returns (pointers into the session)."""
+    _fields_ = [("n_variants", C.c_uint32), ("n_positions", C.c_uint32), ("n_haplotypes", C.c_uint32), ("n_groups", C.c_uint32),
+                ("summary", PhaseSummary), ("merged", C.c_void_p), ("pos_global", C.c_void_p), ("hap_count", C.c_void_p),
+                ("hap_pattern", C.c_void_p), ("hit", C.c_void_p), ("cooc", C.c_void_p), ("slice_begin", C.c_uint64),
+                ("slice_reads", C.c_uint64), ("read_hap_bits", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class RunView(C.Structure):
@@ -194,7 +214,19 @@ def load_library(path=LIB_PATH):
     lib.jl_phase_groups_async.argtypes = [vp, vp, u32]
     lib.jl_phase_groups_fetch.argtypes = [vp, vp, u32, vp, u32, C.POINTER(u32), C.POINTER(u32), vp, u32, vp]
     lib.jl_phase_regroup.argtypes = [vp, vp, u32, u32, vp]
-    if lib.jl_abi_version() != 3:
+    lib.jl_merge_tables.argtypes = [vp, vp, vp, u32, vp, u32, C.POINTER(u32)]
+    lib.jl_merge_groups.argtypes = [vp, vp, vp, vp, u32, u32, vp, vp, u32, C.POINTER(u32), vp]
+    lib.jl_select_haplotypes.argtypes = [vp, vp, u32, u32, vp, u32, vp, u32, vp, u32, vp, vp, vp, vp, u32, vp, vp]
+    lib.jl_xwin_slice_plan.argtypes = [vp, vp, vp, u32, vp, u32, vp, C.c_int32, C.c_int32, vp, u32, C.POINTER(u32)]
+    lib.jl_xwin_create.argtypes = [vp, u32, vp, vp, vp, vp, u32, vp, C.POINTER(vp)]
+    lib.jl_xwin_destroy.argtypes = [vp]
+    lib.jl_xwin_destroy.restype = None
+    lib.jl_xwin_last_error.argtypes = [vp]
+    lib.jl_xwin_last_error.restype = C.c_char_p
+    lib.jl_xwin_phase_sharded.argtypes = [vp, u32, C.POINTER(XwinResult)]
+    lib.jl_xwin_read_hap_fetch.argtypes = [vp, vp]
+    lib.jl_allgather_groups.argtypes = [vp, vp, u32, u32, vp, vp, vp, vp, C.POINTER(u32)]
+    if lib.jl_abi_version() != 4:
         raise ImportError("libjuliet_hip.so ABI version mismatch")
     _lib = lib
     return lib
@@ -646,6 +678,175 @@ def xwin_plan(win_begins, win_ncols, merged):
     return remapped[: len(merged)].copy(), pos[: vp.value].copy(), owner[: vp.value].copy()
 
 
+def merge_tables(tables, win_begins):
+    """jl_merge_tables: per-window tables (window-relative `col`) -> one table, global columns, (gene, codon_pos, codon) order."""
+    lib = load_library()
+    tabs = [np.ascontiguousarray(t, dtype=VARIANT) for t in tables]
+    n = len(tabs)
+    ptrs = (C.c_void_p * max(1, n))(*[t.ctypes.data if len(t) else None for t in tabs])
+    counts = np.array([len(t) for t in tabs], dtype=np.uint32)
+    wb = np.ascontiguousarray(win_begins, dtype=np.uint32)
+    total = int(counts.sum())
+    out = np.zeros(max(1, total), dtype=VARIANT)
+    got = C.c_uint32()
+    rc = lib.jl_merge_tables(ptrs, _p(counts), _p(wb), n, _p(out), len(out), C.byref(got))
+    if rc:
+        raise JulietError(rc, "jl_merge_tables")
+    return out[: got.value].copy()
+
+
+def merge_groups(tables):
+    """jl_merge_groups: per-slice group tables dict(patterns uint8[G][Vp], counts uint32[G]) -> (distinct patterns ascending,
+    summed counts int64, per table the merged row of each of its groups)."""
+    lib = load_library()
+    vp = max((np.asarray(t["patterns"]).reshape(len(t["counts"]), -1).shape[1] for t in tables if len(t["counts"])), default=0)
+    pats = [np.ascontiguousarray(np.asarray(t["patterns"], dtype=np.uint8).reshape(len(t["counts"]), -1)[:, :vp]) if len(t["counts"])
+            else np.zeros((0, vp), dtype=np.uint8) for t in tables]
+    cnts = [np.ascontiguousarray(t["counts"], dtype=np.uint32) for t in tables]
+    n = len(tables)
+    total = sum(len(c) for c in cnts)
+    index = [np.zeros(max(1, len(c)), dtype=np.uint32) for c in cnts]
+    pp = (C.c_void_p * max(1, n))(*[p.ctypes.data if p.size else None for p in pats])
+    cp = (C.c_void_p * max(1, n))(*[c.ctypes.data if len(c) else None for c in cnts])
+    ip = (C.c_void_p * max(1, n))(*[i.ctypes.data for i in index])
+    strides = np.full(max(1, n), max(vp, 1), dtype=np.uint32)
+    strides[:n] = [p.shape[1] if p.size else max(vp, 1) for p in pats]
+    ng = np.array([len(c) for c in cnts] or [0], dtype=np.uint32)
+    mp = np.zeros((max(1, total), max(1, vp)), dtype=np.uint8)
+    mc = np.zeros(max(1, total), dtype=np.uint64)
+    got = C.c_uint32()
+    # merged_patterns is [cap][vp]: contiguous rows of exactly vp bytes
+    flat = np.zeros(max(1, total) * max(1, vp), dtype=np.uint8)
+    rc = lib.jl_merge_groups(pp, _p(strides), cp, _p(ng), n, vp, _p(flat), _p(mc), max(1, total), C.byref(got), ip)
+    if rc:
+        raise JulietError(rc, "jl_merge_groups")
+    m = got.value
+    mp = flat[: m * vp].reshape(m, vp).copy() if vp else np.zeros((m, 0), dtype=np.uint8)
+    return mp, mc[:m].astype(np.int64), [i[: len(c)].astype(np.int64) for i, c in zip(index, cnts)]
+
+
+def select_haplotypes(patterns, counts, variants, pos_cols, min_reads=10, partials=()):
+    """jl_select_haplotypes (docs/SPEC.md §8 on merged groups) -> dict like Juliet.phase_fetch (no read_hap) +
+    hap_of_merged int64[M] (HAP_INSUFFICIENT where not reported)."""
+    lib = load_library()
+    patterns = np.ascontiguousarray(patterns, dtype=np.uint8)
+    counts = np.ascontiguousarray(counts, dtype=np.uint64)
+    m = len(counts)
+    vp = len(pos_cols)
+    patterns = patterns.reshape(m, vp) if m else np.zeros((0, vp), dtype=np.uint8)
+    variants = np.ascontiguousarray(variants, dtype=VARIANT)
+    nv = len(variants)
+    pc = np.ascontiguousarray(pos_cols, dtype=np.uint32)
+    parts = np.zeros(max(1, len(partials)), dtype=SUMMARY)
+    for k, p in enumerate(partials):
+        for f in ("damaged_reads", "marginal_gap", "marginal_heteroduplex", "marginal_partial"):
+            parts[k][f] = int(p[f])
+    summ = np.zeros(1, dtype=SUMMARY)
+    hap_count = np.zeros(MAX_HAPLOTYPES, dtype=np.uint32)
+    hap_pattern = np.zeros((MAX_HAPLOTYPES, max(1, vp)), dtype=np.uint8)
+    hcap = max(1, min(MAX_HAPLOTYPES, m))
+    hit = np.zeros((max(1, nv), hcap), dtype=np.uint8)
+    cooc = np.zeros((max(1, nv), max(1, nv)), dtype=np.uint32)
+    hom = np.zeros(max(1, m), dtype=np.uint16)
+    flatp = np.ascontiguousarray(patterns).reshape(-1) if patterns.size else np.zeros(1, dtype=np.uint8)
+    hp_flat = np.zeros(MAX_HAPLOTYPES * max(1, vp), dtype=np.uint8)
+    rc = lib.jl_select_haplotypes(_p(flatp), _p(counts if m else np.zeros(1, dtype=np.uint64)), m, vp,
+                                  _p(variants if nv else np.zeros(1, dtype=VARIANT)), nv, _p(pc if vp else np.zeros(1, dtype=np.uint32)),
+                                  min_reads, _p(parts), len(partials), _p(summ), _p(hap_count), _p(hp_flat), _p(hit), hcap, _p(cooc), _p(hom))
+    if rc:
+        raise JulietError(rc, "jl_select_haplotypes")
+    s = {k: int(summ[0][k]) for k in SUMMARY_FIELDS}
+    h = s["n_haplotypes"]
+    hap_of_merged = hom[:m].astype(np.int64)
+    return dict(summary=s, hap_count=hap_count[:h].copy(), hap_pattern=hp_flat[: h * vp].reshape(h, vp).copy() if vp else np.zeros((h, 0), dtype=np.uint8),
+                hit=hit[:nv, :h].copy(), cooc=cooc[:nv, :nv].copy(), hap_of_merged=hap_of_merged)
+
+
+def xwin_slice_plan(win_begins, win_ncols, win_rank, merged, slice_begin, world, rank):
+    """jl_xwin_slice_plan: the ops of `rank` in issue order, as dicts (op, peer, k_begin, k_count, read_begin, n_reads,
+    dst_stride, bytes, dst_offset).  Needs no GPU."""
+    lib = load_library()
+    merged = np.ascontiguousarray(merged, dtype=VARIANT)
+    wb = np.ascontiguousarray(win_begins, dtype=np.uint32)
+    wn = np.ascontiguousarray(win_ncols, dtype=np.uint32)
+    wr = np.ascontiguousarray(win_rank, dtype=np.int32)
+    sb = np.ascontiguousarray(slice_begin, dtype=np.uint64)
+    cap = 2 * world + 1
+    ops = (XwinOp * cap)()
+    n = C.c_uint32()
+    rc = lib.jl_xwin_slice_plan(_p(wb), _p(wn), _p(wr), len(wb), _p(merged if len(merged) else np.zeros(1, dtype=VARIANT)), len(merged),
+                                _p(sb), world, rank, ops, cap, C.byref(n))
+    if rc:
+        raise JulietError(rc, "jl_xwin_slice_plan")
+    return [{f: getattr(ops[k], f) for f, _ in XwinOp._fields_} for k in range(n.value)]
+
+
+class Xwin:
+    """A cross-window phasing session (jl_xwin_*): this rank's windows of ONE reference whose reads span every window.
+    `windows`: this rank's Juliet contexts in ascending column order; `comm`: the RCCL communicator handle (None when every
+    window is on this device); `win_begins/win_ncols/win_rank`: the layout of ALL windows; `slice_begin`: world + 1 starts."""
+
+    def __init__(self, windows, win_begins, win_ncols, win_rank, slice_begin, comm=None):
+        self.lib = load_library()
+        self.windows = list(windows)
+        arr = (C.c_void_p * len(self.windows))(*[w.h for w in self.windows])
+        wb = np.ascontiguousarray(win_begins, dtype=np.uint32)
+        wn = np.ascontiguousarray(win_ncols, dtype=np.uint32)
+        wr = np.ascontiguousarray(win_rank, dtype=np.int32)
+        sb = np.ascontiguousarray(slice_begin, dtype=np.uint64)
+        h = C.c_void_p()
+        rc = self.lib.jl_xwin_create(arr, len(self.windows), comm, _p(wb), _p(wn), _p(wr), len(wb), _p(sb), C.byref(h))
+        if rc:
+            raise JulietError(rc, "jl_xwin_create: bad layout (windows / ranks / slices)")
+        self.h = h
+        self._res = XwinResult()
+        self._res_ref = C.byref(self._res)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.jl_xwin_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def phase_raw(self, min_reads=10):
+        """One jl_xwin_phase_sharded call; returns the result struct (pointers into the session, no copies)."""
+        rc = self.lib.jl_xwin_phase_sharded(self.h, min_reads, self._res_ref)
+        if rc:
+            raise JulietError(rc, self.lib.jl_xwin_last_error(self.h).decode())
+        return self._res
+
+    def phase(self, min_reads=10, want_reads=True):
+        """dict like phase_across_windows' (copies): merged table, summary, haplotypes, hit, cooc, pos_cols (global
+        columns), read_hap of THIS rank's slice."""
+        r = self.phase_raw(min_reads)
+        nv, vp, h = r.n_variants, r.n_positions, r.n_haplotypes
+        merged = _view(r.merged, VARIANT, nv).copy() if nv else np.zeros(0, dtype=VARIANT)
+        out = dict(merged=merged, pos_cols=_view(r.pos_global, np.uint32, vp).copy() if vp else np.zeros(0, dtype=np.uint32),
+                   summary={n: getattr(r.summary, n) for n in SUMMARY_FIELDS}, n_groups=r.n_groups,
+                   slice=(int(r.slice_begin), int(r.slice_reads)))
+        if vp:
+            out.update(hap_count=_view(r.hap_count, np.uint32, h).copy() if h else np.zeros(0, dtype=np.uint32),
+                       hap_pattern=_view(r.hap_pattern, np.uint8, h * vp).reshape(h, vp).copy() if h else np.zeros((0, vp), dtype=np.uint8),
+                       hit=_view(r.hit, np.uint8, nv * h).reshape(nv, h).copy() if nv * h else np.zeros((nv, h), dtype=np.uint8),
+                       cooc=_view(r.cooc, np.uint32, nv * nv).reshape(nv, nv).copy() if nv else np.zeros((0, 0), dtype=np.uint32))
+        if want_reads:
+            out["read_hap"] = self.read_hap()
+        return out
+
+    def read_hap(self):
+        n = int(self._res.slice_reads)
+        ids = np.zeros(max(1, n), dtype=np.uint16)
+        rc = self.lib.jl_xwin_read_hap_fetch(self.h, _p(ids))
+        if rc:
+            raise JulietError(rc, self.lib.jl_xwin_last_error(self.h).decode())
+        return ids[:n]
+
+
 def phase_across_windows(windows, merged, min_reads=10, comm=None, win_begins=None, win_ncols=None, device=0):
     """Cross-window phasing: `windows` = contexts holding the SAME reads over different column
     windows (all on this device), or a single context plus an RCCL `comm` when every rank owns one window.
@@ -704,9 +905,9 @@ def phase_sharded_by_reads(windows, merged, n_shards, min_reads=10, device=0, wa
                                pos_cols=3 * np.arange(len(pos_global), dtype=np.uint32),
                                summary={k: 0 for k in SUMMARY_FIELDS}))
         shards.append(pc)
-    patterns, counts, index = sharding.merge_groups(tables)
+    patterns, counts, index = merge_groups(tables)
     pos_cols = next(t["pos_cols"] for t in tables if len(t["pos_cols"]))
-    ph = sharding.select_haplotypes(patterns, counts, remapped, pos_cols, min_reads, [t["summary"] for t in tables])
+    ph = select_haplotypes(patterns, counts, remapped, pos_cols, min_reads, [t["summary"] for t in tables])
     ids = []
     for s, pc in enumerate(shards):
         if bounds[s + 1] > bounds[s]:

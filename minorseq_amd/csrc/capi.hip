@@ -948,6 +948,9 @@ static int phase_async_impl(jl_ctx *ctx, const jl_variant *variants, uint32_t n_
     if (rc) return rc;
     if (exporting && (rc = reserve_export(ctx, kwords))) return rc;
     ctx->phase_export = exporting;
+    ctx->exp_known = false;
+    ctx->exp_ext_count = nullptr; ctx->exp_ext_pattern = nullptr; ctx->exp_ext_head = nullptr;
+    ctx->exp_ext_cap = ctx->exp_ext_stride = 0;
     ctx->last_min_reads = min_reads;
     ctx->pack_mirror = nullptr;
     ctx->read_hap_out = nullptr;
@@ -1115,6 +1118,9 @@ int jl_phase_groups_fetch(jl_ctx *ctx, uint8_t *patterns, uint32_t pattern_strid
     const uint32_t vp = meta.vp, ng = vp ? meta.n_occupied : 0u;
     *n_groups = ng;
     *n_positions = vp;
+    ctx->exp_n_groups = ng;   // what jl_phase_regroup has to answer for
+    ctx->exp_vp = vp;
+    ctx->exp_known = true;
     if (partial) *partial = meta.summary;
     if (pos_cols && vp > cap_var) return jl_fail(ctx, JL_ERR_OVERFLOW, "%u variant positions, caller capacity %u", vp, cap_var);
     if ((patterns || counts) && ng > cap_groups) return jl_fail(ctx, JL_ERR_OVERFLOW, "%u groups, caller capacity %u", ng, cap_groups);
@@ -1140,7 +1146,10 @@ int jl_phase_regroup(jl_ctx *ctx, const uint16_t *hap_of_group, uint32_t n_group
 {
     if (!ctx || (!hap_of_group && n_groups)) return JL_ERR_ARG;
     if (!ctx->phase_done || !ctx->phase_export) return jl_fail(ctx, JL_ERR_STATE, "jl_phase_regroup needs jl_phase_groups_async first");
-    if (n_groups > ctx->exp_cap) return jl_fail(ctx, JL_ERR_ARG, "%u groups, the export held %u", n_groups, ctx->exp_cap);
+    if (!ctx->exp_known) return jl_fail(ctx, JL_ERR_STATE, "jl_phase_regroup needs jl_phase_groups_fetch first (the number of exported groups)");
+    // one answer per exported group: a shorter table would leave reads of the other groups without a haplotype
+    if (n_groups != ctx->exp_n_groups)
+        return jl_fail(ctx, JL_ERR_ARG, "%u groups, the run exported %u", n_groups, ctx->exp_n_groups);
     if (n_haplotypes > JL_MAX_HAPLOTYPES) return jl_fail(ctx, JL_ERR_ARG, "%u haplotypes, at most %u have names", n_haplotypes, JL_MAX_HAPLOTYPES);
     for (uint32_t q = 0; q < n_groups; ++q)
         if (hap_of_group[q] != JL_HAP_INSUFFICIENT && hap_of_group[q] >= n_haplotypes)
@@ -1148,7 +1157,7 @@ int jl_phase_regroup(jl_ctx *ctx, const uint16_t *hap_of_group, uint32_t n_group
     JL_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     if (n_groups) JL_HIP(ctx, hipMemcpyAsync(ctx->d_exp_hap, hap_of_group, (size_t)n_groups * 2, hipMemcpyHostToDevice, st));
-    jl_launch_regroup(ctx, ctx->d_exp_hap, n_groups, n_haplotypes);
+    jl_launch_regroup(ctx, ctx->d_exp_hap, n_groups, n_haplotypes, ctx->exp_vp != 0);
     JL_HIP(ctx, hipGetLastError());
     JL_HIP(ctx, hipStreamSynchronize(st));   // hap_of_group may be pageable: the copy has read it by now
     if (read_hap) {
@@ -1157,6 +1166,61 @@ int jl_phase_regroup(jl_ctx *ctx, const uint16_t *hap_of_group, uint32_t n_group
     }
     return JL_OK;
 }
+
+}  // extern "C"
+
+// A session's exporting phase run (capi_xwin.hip): the buffers jl_phase_groups_async would reserve, for a compact matrix
+// whose plan — vp positions at columns 3k — the session's own kernel writes.  The caller sets ctx->exp_ext_* and launches.
+int jl_phase_groups_prepare(jl_ctx *ctx, uint32_t vp)
+{
+    if (!ctx || !ctx->d_msa) return JL_ERR_ARG;
+    JL_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = reserve_columns(ctx);
+    if (rc) return rc;
+    uint32_t kwords = (vp + JL_POS_PER_WORD - 1) / JL_POS_PER_WORD;
+    if (kwords == 0) kwords = 1;
+    if ((rc = reserve_phase(ctx, kwords))) return rc;
+    ctx->phase_generic = vp > JL_POS_PER_WORD;
+    ctx->phase_export = true;
+    ctx->exp_known = false;
+    ctx->last_min_reads = 0xFFFFFFFFu;
+    ctx->pack_mirror = nullptr;
+    ctx->read_hap_out = nullptr;
+    ctx->phase_done = true;
+    ctx->pack_valid = false;
+    return JL_OK;
+}
+
+// The variant table of the context's last call stage, on the host.
+int jl_ctx_table_host(jl_ctx *ctx, std::vector<jl_variant> *scratch, const jl_variant **rows, uint32_t *n)
+{
+    if (!ctx->call_done) return jl_fail(ctx, JL_ERR_STATE, "no variant table: run the call stage first");
+    if (ctx->pack_valid) {
+        if (int rc = jl_run_wait_impl(ctx)) return rc;
+        const jl_pack *pk = ctx->h_pack;
+        if (pk->magic == JL_PACK_MAGIC && pk->fits_call) {
+            *rows = pk->variants;
+            *n = pk->nvar_total;
+            return JL_OK;
+        }
+    }
+    JL_HIP(ctx, hipSetDevice(ctx->device));
+    if (ctx->run_stream && ctx->run_stream != ctx->stream) JL_HIP(ctx, hipStreamSynchronize(ctx->run_stream));
+    uint32_t cnt = 0;
+    JL_HIP(ctx, hipMemcpyAsync(&cnt, ctx->d_nvar, 4, hipMemcpyDeviceToHost, ctx->stream));
+    JL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (cnt > JL_VARIANT_CAP) return jl_fail(ctx, JL_ERR_OVERFLOW, "%u variant rows, the device table holds %u", cnt, JL_VARIANT_CAP);
+    scratch->resize(cnt ? cnt : 1);
+    if (cnt) {
+        JL_HIP(ctx, hipMemcpyAsync(scratch->data(), ctx->d_variants, (size_t)cnt * sizeof(jl_variant), hipMemcpyDeviceToHost, ctx->stream));
+        JL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    *rows = scratch->data();
+    *n = cnt;
+    return JL_OK;
+}
+
+extern "C" {
 
 /* ---------------------------------------------------------------- the whole path as one enqueue */
 
@@ -1276,8 +1340,12 @@ int jl_run_async(jl_ctx *ctx, const jl_gene *genes, uint32_t n_genes, const uint
     sig.drm = drm_masks != nullptr; sig.phasing = phasing != 0; sig.min_reads = min_reads; sig.rh = want_read_hap != 0; sig.generic = ctx->phase_generic; sig.pad = (uint32_t)(uintptr_t)ctx->read_hap_out;
     static const bool graphs_on = !getenv("JL_NO_GRAPH");   // read once; eager launches are a debugging aid
     bool launched = false;
+    // A graph replay reaches the queue 10-16 us after the call, a plain launch 3-5 us (MI355X guide, graph-replay-floor);
+    // the remaining launches of an eager run are enqueued while the first kernel runs.  For a window whose counting
+    // stage alone takes hundreds of microseconds the replay's head start is all a graph changes: such runs go eagerly.
+    const bool long_run = (uint64_t)ctx->col_stride * ctx->n_cols >= ((uint64_t)512 << 20);
 
-    if (graphs_on) {
+    if (graphs_on && !long_run) {
         const bool hit = ctx->graph_exec && ctx->graph_sig.size() == sizeof sig && memcmp(ctx->graph_sig.data(), &sig, sizeof sig) == 0;
         // A configuration is captured the SECOND time it is run: capture + instantiation cost about 20 ms, which a
         // one-shot caller (the juliet front end: one run per process) would pay for nothing.
@@ -1319,10 +1387,10 @@ int jl_run_async(jl_ctx *ctx, const jl_gene *genes, uint32_t n_genes, const uint
 // ever, so after a long wait the stream is asked directly.
 int jl_run_wait_impl(jl_ctx *ctx) { return jl_run_wait_seq(ctx, ctx->runs_launched); }
 
-// `want`: the value of runs_launched right after the run of interest was launched (any thread may wait)
-int jl_run_wait_seq(jl_ctx *ctx, uint32_t want)
+// `want`: the value of runs_launched right after the run of interest was launched.  1: the stream failed, 2: it went
+// idle without the word.  Touches nothing of the context but the pinned word: any thread may wait.
+static int run_wait_word(volatile uint32_t *p, uint32_t want, hipStream_t stream, hipError_t *err)
 {
-    volatile uint32_t *p = ctx->h_seq;
     uint64_t spins = 0;
     while ((int32_t)(*p - want) < 0) {
         __builtin_ia32_pause();
@@ -1330,17 +1398,36 @@ int jl_run_wait_seq(jl_ctx *ctx, uint32_t want)
             // A long wait (tens of ms): a device fault would leave the word unset for ever, so ask the stream.  A
             // blocking synchronize, not a query: the first launch of a freshly instantiated graph can sit in the
             // runtime for milliseconds before it reaches the queue, during which a query calls the stream idle.
-            const hipError_t q = hipStreamSynchronize(ctx->run_stream ? ctx->run_stream : ctx->stream);
-            if (q != hipSuccess) return jl_fail(ctx, JL_ERR_DEVICE, "run failed: %s", hipGetErrorString(q));
+            *err = hipStreamSynchronize(stream);
+            if (*err != hipSuccess) return 1;
             for (int k = 0; k < 1000000 && (int32_t)(*p - want) < 0; ++k) __builtin_ia32_pause();
-            if ((int32_t)(*p - want) < 0)
-                return jl_fail(ctx, JL_ERR_DEVICE, "run finished without its completion word (%u of %u)", *p, want);
+            if ((int32_t)(*p - want) < 0) return 2;
             break;
         }
     }
     __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    return 0;
+}
+
+int jl_run_wait_seq(jl_ctx *ctx, uint32_t want)
+{
+    hipError_t e = hipSuccess;
+    const int r = run_wait_word(ctx->h_seq, want, ctx->run_stream ? ctx->run_stream : ctx->stream, &e);
+    if (r == 1) return jl_fail(ctx, JL_ERR_DEVICE, "run failed: %s", hipGetErrorString(e));
+    if (r == 2) return jl_fail(ctx, JL_ERR_DEVICE, "run finished without its completion word (%u of %u)", *ctx->h_seq, want);
     return JL_OK;
 }
+}  // extern "C"
+
+// for threads other than the context's owner (the communicator's worker): no write to ctx->err, and the stream the run
+// was enqueued on is the one the requesting thread saw
+int jl_run_wait_seq_quiet(jl_ctx *ctx, uint32_t want, hipStream_t stream)
+{
+    hipError_t e = hipSuccess;
+    return run_wait_word(ctx->h_seq, want, stream, &e) ? JL_ERR_DEVICE : JL_OK;
+}
+
+extern "C" {
 
 #ifdef JL_TUNING
 // tuning aid, not part of the ABI header (tools_tuning/timeline.py): the device-clock stamps of the last

@@ -1,85 +1,19 @@
-// capi_comm.hip — the multi-GPU part of the C ABI: RCCL communicator, the all-gather of the variant
-// table, and the cross-window column exchange.  One communicator per (rank, device); collectives run on the
-// communicator's own stream and are issued by a worker thread.
-#include <rccl/rccl.h>
+// capi_comm.hip — the multi-GPU part of the C ABI: RCCL communicator and the all-gather of the variant
+// table.  One communicator per (rank, device); the asynchronous exchanges run on the communicator's own stream and are
+// issued by its worker thread; the blocking cross-window exchanges (capi_xwin.hip) take the communicator for the
+// duration of the call (jl_comm_direct_begin).
 #include <stddef.h>
 #include <string.h>
 
 #include <algorithm>
-#include <atomic>
-#include <condition_variable>
-#include <deque>
-#include <mutex>
+#include <chrono>
 #include <new>
-#include <thread>
-#include <vector>
 
-#include "jl_internal.h"
+#include "jl_comm_internal.h"
 
-#define JL_COMM_SLOTS 128
-
-// One communicator per (rank, device).  Collectives run on the communicator's OWN stream, issued by a worker
-// thread once the producing run's completion word has arrived in pinned memory, so that several contexts (batches
-// in flight) never have an RCCL launch — nor any HIP call it would imply — on the thread that launches batches.
-struct jl_comm_slot {
-    jl_ctx *ctx = nullptr;
-    const uint8_t *d_src = nullptr;  // this rank's contribution: the run's device result block (double-buffered by run parity)
-    uint32_t run_seq = 0;        // the run whose results are exchanged: the worker waits for its completion word
-    uint64_t seq = 0;            // enqueue order: jl_allgather_variants collects a context's OLDEST pending exchange
-    uint8_t *d_heads = nullptr;  // [world][JL_PACK_HEAD_BYTES]: slot k's share of the communicator's arena
-    uint8_t *h_heads = nullptr;  // pinned mirror (same layout: consecutive slots are consecutive in memory)
-    hipEvent_t done = nullptr;
-    jl_comm_slot *done_at = nullptr;   // the slot whose event covers this exchange (the last one of its batch)
-    // where rank r's head of this exchange lies in pinned memory: h_base + (r * batch_n + batch_k) * JL_PACK_HEAD_BYTES
-    const uint8_t *h_base = nullptr;
-    uint32_t batch_n = 1, batch_k = 0;
-    bool pending = false;        // the slot is reserved: requested, and its batch not yet collected completely (host thread only)
-    bool collected = false;      // this member was collected; the slot stays reserved until the whole batch is (its
-                                 // region of the arena is ONE [rank][window][head] block, its event the batch's)
-    jl_comm_slot *leader = nullptr;   // first slot of the batch
-    uint32_t batch_left = 0;     // leader only: members not yet collected
-    uint32_t batch_size = 1;     // leader only
-    bool event_seen = false;     // host thread only: `done` was seen complete (a batch's members share one event: the
-                                 // first collector pays for the query, 5-10 us in the runtime, the others do not)
-    bool enqueued = false;       // the worker has issued it and recorded `done` (guarded by jl_comm::mu)
-    int status = 0;              // ncclResult_t / hip error of the enqueue, as jl_status
-};
-
-// the full-stride gather (tables of more than 128 rows, stage-by-stage callers): issued by the worker too — the
-// communicator is never used from two threads
-struct jl_comm_full {
-    jl_ctx *ctx = nullptr;
-    uint32_t cap_rows = 0;
-    uint32_t wait_seq = 0;       // != 0: the run whose completion word the worker waits for first
-    jl_variant *all_rows = nullptr;
-    uint32_t *all_counts = nullptr;
-    int status = 0;
-    bool done = false;           // guarded by jl_comm::mu
-};
-
-struct jl_comm_job {
-    std::vector<jl_comm_slot *> batch;
-    jl_comm_full *full = nullptr;
-};
-
-struct jl_comm {
-    ncclComm_t comm = nullptr;
-    int rank = 0, world = 1, device = 0;
-    hipStream_t stream = nullptr;
-    uint8_t *d_arena = nullptr, *h_arena = nullptr;   // [JL_COMM_SLOTS][world][JL_PACK_HEAD_BYTES]
-    uint8_t *d_send = nullptr;                        // [JL_COMM_SLOTS][JL_PACK_HEAD_BYTES]: send buffers of batches
-    jl_variant *d_all = nullptr;   // [world][JL_VARIANT_CAP]   (full-stride fallback)
-    uint32_t *d_counts = nullptr;  // [world][2]
-    jl_comm_slot slots[JL_COMM_SLOTS];
-    uint64_t next_seq = 1;
-    // RCCL enqueues cost the host ~20 us each; a worker thread issues them (FIFO, so every rank keeps the
-    // same collective order) while the caller's thread goes on launching the next batch
-    std::thread worker;
-    std::mutex mu;
-    std::condition_variable cv;
-    std::deque<jl_comm_job> queue;   // FIFO: batches (the exchanges of one batch go out as ONE all-gather) and full-stride gathers
-    bool stop = false;
-};
+#ifndef JL_COMM_TIMEOUT_S
+#define JL_COMM_TIMEOUT_S 60
+#endif
 
 // fixed-stride table (+ row counts) over RCCL/xGMI, on the communicator's stream; blocks the worker until the rows are
 // in the caller's arrays
@@ -87,13 +21,16 @@ static void comm_full_gather(jl_comm *c, jl_comm_full *f)
 {
     jl_ctx *ctx = f->ctx;
     int st = JL_OK;
-    if (f->wait_seq && jl_run_wait_seq(ctx, f->wait_seq) != JL_OK) st = JL_ERR_DEVICE;
-    if (st == JL_OK) {
+    if (f->wait_seq && jl_run_wait_seq_quiet(ctx, f->wait_seq, f->run_stream) != JL_OK) st = JL_ERR_DEVICE;
+    {
+        // The collective is issued whatever happened on this rank: the peers have issued theirs and would wait for ever.
+        // A failed rank sends an impossible row count, so every rank takes the same error branch.
+        const void *cnt_src = st == JL_OK ? (const void *)ctx->d_nvar : (const void *)c->d_poison;
         ncclResult_t r = ncclGroupStart();
         if (r == ncclSuccess) r = ncclAllGather(ctx->d_variants, c->d_all, sizeof(jl_variant) * (size_t)f->cap_rows, ncclUint8, c->comm, c->stream);
-        if (r == ncclSuccess) r = ncclAllGather(ctx->d_nvar, c->d_counts, 8, ncclUint8, c->comm, c->stream);
+        if (r == ncclSuccess) r = ncclAllGather(cnt_src, c->d_counts, 8, ncclUint8, c->comm, c->stream);
         if (r == ncclSuccess) r = ncclGroupEnd();
-        if (r != ncclSuccess) st = JL_ERR_COMM;
+        if (r != ncclSuccess && st == JL_OK) st = JL_ERR_COMM;
     }
     std::vector<uint32_t> cnt(2 * (size_t)c->world);
     if (st == JL_OK &&
@@ -104,7 +41,8 @@ static void comm_full_gather(jl_comm *c, jl_comm_full *f)
     if (st == JL_OK)
         for (int k = 0; k < c->world; ++k) {
             f->all_counts[k] = cnt[2 * k];
-            if (cnt[2 * k] > f->cap_rows) st = JL_ERR_OVERFLOW;
+            if (cnt[2 * k] == 0xFFFFFFFFu) st = JL_ERR_COMM;   // that rank's run failed
+            else if (cnt[2 * k] > f->cap_rows && st == JL_OK) st = JL_ERR_OVERFLOW;
         }
     f->status = st;
 }
@@ -116,16 +54,19 @@ static void comm_worker(jl_comm *c)
         jl_comm_job job;
         {
             std::unique_lock<std::mutex> lk(c->mu);
-            c->cv.wait(lk, [&] { return c->stop || !c->queue.empty(); });
+            // a blocking call of another thread may hold the communicator (jl_comm_direct_begin): nothing starts meanwhile
+            c->cv.wait(lk, [&] { return (c->stop || !c->queue.empty()) && !c->direct_busy; });
             if (c->queue.empty()) return;  // stop requested and nothing left
             job = std::move(c->queue.front());
             c->queue.pop_front();
+            c->worker_busy = true;
         }
         if (job.full) {
             comm_full_gather(c, job.full);
             {
                 std::lock_guard<std::mutex> lk(c->mu);
                 job.full->done = true;
+                c->worker_busy = false;
             }
             c->cv.notify_all();
             continue;
@@ -133,12 +74,16 @@ static void comm_worker(jl_comm *c)
         std::vector<jl_comm_slot *> &batch = job.batch;
         int st = JL_OK;
         // the producing runs are complete when their sequence words are in pinned memory (jl_run_wait): no events
+        bool run_ok = true;
         for (jl_comm_slot *s : batch)
-            if (jl_run_wait_seq(s->ctx, s->run_seq) != JL_OK) st = JL_ERR_DEVICE;
+            if (jl_run_wait_seq_quiet(s->ctx, s->run_seq, s->run_stream) != JL_OK) run_ok = false;
+        if (!run_ok) st = JL_ERR_DEVICE;
         // A batch whose slots are consecutive in the arena (jl_allgather_variants_async_many reserves them so) is ONE
         // exchange: a small kernel puts the heads of its windows next to each other, one all-gather moves them
         // ([rank][window][head] on every rank), one copy brings them to pinned memory, one event says so.  Otherwise
         // an all-gather, a copy and an event per window.
+        // Whatever failed on THIS rank before the collective, the collective is issued: the peers have issued theirs.
+        // The heads of a failed rank are zeros (no magic word), which every rank reads as that rank's failure.
         const size_t stride = JL_PACK_HEAD_BYTES * (size_t)c->world;
         bool consecutive = batch.size() > 1 && batch.size() <= JL_GATHER_MAX;
         for (size_t k = 1; k < batch.size(); ++k)
@@ -150,12 +95,14 @@ static void comm_worker(jl_comm *c)
             const uint8_t *srcs[JL_GATHER_MAX];
             for (uint32_t k = 0; k < n; ++k) srcs[k] = batch[k]->d_src;
             jl_comm_slot *last = batch.back();
+            const uint8_t *sendbuf = send;
             if (st == JL_OK) {
                 jl_launch_gather_heads(srcs, n, send, c->stream);
                 if (hipGetLastError() != hipSuccess) st = JL_ERR_DEVICE;
             }
-            if (st == JL_OK && ncclAllGather(send, batch[0]->d_heads, JL_PACK_HEAD_BYTES * (size_t)n, ncclUint8, c->comm, c->stream) != ncclSuccess) st = JL_ERR_COMM;
-            if (st == JL_OK && hipMemcpyAsync(batch[0]->h_heads, batch[0]->d_heads, stride * n, hipMemcpyDeviceToHost, c->stream) != hipSuccess) st = JL_ERR_DEVICE;
+            if (st != JL_OK) sendbuf = c->d_zero;
+            if (ncclAllGather(sendbuf, batch[0]->d_heads, JL_PACK_HEAD_BYTES * (size_t)n, ncclUint8, c->comm, c->stream) != ncclSuccess && st == JL_OK) st = JL_ERR_COMM;
+            if (hipMemcpyAsync(batch[0]->h_heads, batch[0]->d_heads, stride * n, hipMemcpyDeviceToHost, c->stream) != hipSuccess && st == JL_OK) st = JL_ERR_DEVICE;
             if (hipEventRecord(last->done, c->stream) != hipSuccess && st == JL_OK) st = JL_ERR_DEVICE;
             for (uint32_t k = 0; k < n; ++k) {
                 batch[k]->done_at = last;
@@ -165,8 +112,9 @@ static void comm_worker(jl_comm *c)
             }
         } else {
             for (jl_comm_slot *s : batch) {
-                if (st == JL_OK && ncclAllGather(s->d_src, s->d_heads, JL_PACK_HEAD_BYTES, ncclUint8, c->comm, c->stream) != ncclSuccess) st = JL_ERR_COMM;
-                if (st == JL_OK && hipMemcpyAsync(s->h_heads, s->d_heads, stride, hipMemcpyDeviceToHost, c->stream) != hipSuccess) st = JL_ERR_DEVICE;
+                const uint8_t *sendbuf = st == JL_OK ? s->d_src : c->d_zero;
+                if (ncclAllGather(sendbuf, s->d_heads, JL_PACK_HEAD_BYTES, ncclUint8, c->comm, c->stream) != ncclSuccess && st == JL_OK) st = JL_ERR_COMM;
+                if (hipMemcpyAsync(s->h_heads, s->d_heads, stride, hipMemcpyDeviceToHost, c->stream) != hipSuccess && st == JL_OK) st = JL_ERR_DEVICE;
                 if (hipEventRecord(s->done, c->stream) != hipSuccess && st == JL_OK) st = JL_ERR_DEVICE;
                 s->done_at = s;
                 s->h_base = s->h_heads;
@@ -180,9 +128,29 @@ static void comm_worker(jl_comm *c)
                 s->status = st;
                 s->enqueued = true;
             }
+            c->worker_busy = false;
         }
         c->cv.notify_all();
     }
+}
+
+int jl_comm_direct_begin(jl_comm *c)
+{
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (c->direct_busy || c->worker_busy || !c->queue.empty()) return JL_ERR_STATE;
+    for (const jl_comm_slot &s : c->slots)
+        if (s.pending) return JL_ERR_STATE;
+    c->direct_busy = true;
+    return JL_OK;
+}
+
+void jl_comm_direct_end(jl_comm *c)
+{
+    {
+        std::lock_guard<std::mutex> lk(c->mu);
+        c->direct_busy = false;
+    }
+    c->cv.notify_all();
 }
 
 static void comm_wait_enqueued(jl_comm *c, jl_comm_slot *s)
@@ -229,6 +197,10 @@ int jl_comm_create(jl_ctx *ctx, const uint8_t id[128], int rank, int world, jl_c
               hipMalloc(&c->d_counts, 8 * world) == hipSuccess &&
               hipMalloc(&c->d_arena, stride * JL_COMM_SLOTS) == hipSuccess &&
               hipMalloc(&c->d_send, (size_t)JL_PACK_HEAD_BYTES * JL_COMM_SLOTS) == hipSuccess &&
+              hipMalloc(&c->d_zero, (size_t)JL_PACK_HEAD_BYTES * JL_GATHER_MAX) == hipSuccess &&
+              hipMalloc(&c->d_poison, 8) == hipSuccess &&
+              hipMemset(c->d_zero, 0, (size_t)JL_PACK_HEAD_BYTES * JL_GATHER_MAX) == hipSuccess &&
+              hipMemset(c->d_poison, 0xFF, 8) == hipSuccess &&
               hipHostMalloc(&c->h_arena, stride * JL_COMM_SLOTS, hipHostMallocDefault) == hipSuccess;
     for (int k = 0; ok && k < JL_COMM_SLOTS; ++k) {
         c->slots[k].d_heads = c->d_arena + stride * (size_t)k;
@@ -261,6 +233,8 @@ void jl_comm_destroy(jl_comm *c)
         if (s.done) hipEventDestroy(s.done);
     if (c->d_arena) hipFree(c->d_arena);
     if (c->d_send) hipFree(c->d_send);
+    if (c->d_zero) hipFree(c->d_zero);
+    if (c->d_poison) hipFree(c->d_poison);
     if (c->h_arena) hipHostFree(c->h_arena);
     if (c->comm) ncclCommDestroy(c->comm);
     if (c->d_all) hipFree(c->d_all);
@@ -322,6 +296,7 @@ static int comm_request(jl_ctx *ctx, jl_comm *c, jl_comm_slot *at, jl_comm_slot 
     s->batch_size = 1;
     s->collected = false;
     s->run_seq = ctx->runs_launched;
+    s->run_stream = ctx->run_stream ? ctx->run_stream : ctx->stream;
     s->d_src = reinterpret_cast<const uint8_t *>(ctx->d_pack + ((ctx->runs_launched - 1u) & 1u));
     s->seq = c->next_seq++;
     s->event_seen = false;
@@ -399,6 +374,7 @@ static int allgather_full(jl_ctx *ctx, jl_comm *c, jl_variant *all_rows, uint32_
     f.ctx = ctx;
     f.cap_rows = cap_rows;
     f.wait_seq = wait_seq;
+    f.run_stream = ctx->run_stream ? ctx->run_stream : ctx->stream;
     f.all_rows = all_rows;
     f.all_counts = all_counts;
     {
@@ -413,6 +389,7 @@ static int allgather_full(jl_ctx *ctx, jl_comm *c, jl_variant *all_rows, uint32_
         c->cv.wait(lk, [&] { return f.done; });
     }
     if (f.status == JL_ERR_OVERFLOW) return jl_fail(ctx, JL_ERR_OVERFLOW, "a rank produced more than %u variant rows", cap_rows);
+    if (f.status == JL_ERR_COMM) return jl_fail(ctx, JL_ERR_COMM, "the exchange failed: RCCL error, or a rank's run did not complete (it says so in its own error)");
     if (f.status != JL_OK) return jl_fail(ctx, f.status, "full-stride all-gather failed on the communicator thread");
     return JL_OK;
 }
@@ -445,14 +422,22 @@ int jl_allgather_variants(jl_ctx *ctx, jl_comm *c, jl_variant *all_rows, uint32_
     if (s->status != JL_OK) return jl_fail(ctx, s->status, "all-gather enqueue failed on the communicator thread");
     if (!s->done_at->event_seen) {   // spin on the event: a blocking hipEventSynchronize costs ~15 us of wake-up latency per step
         hipError_t q;
-        while ((q = hipEventQuery(s->done_at->done)) == hipErrorNotReady) {}
+        // ... but not for ever: a peer that died before its collective leaves this one incomplete
+        const auto deadline = std::chrono::steady_clock::now() + std::chrono::seconds(JL_COMM_TIMEOUT_S);
+        uint32_t polls = 0;
+        while ((q = hipEventQuery(s->done_at->done)) == hipErrorNotReady)
+            if ((++polls & 0xFFFu) == 0 && std::chrono::steady_clock::now() > deadline)
+                return jl_fail(ctx, JL_ERR_COMM, "all-gather not complete after %d s: a peer has not issued its collective", JL_COMM_TIMEOUT_S);
         if (q != hipSuccess) return jl_fail(ctx, JL_ERR_DEVICE, "all-gather: %s", hipGetErrorString(q));
         s->done_at->event_seen = true;
     }
     bool compact = true;
     for (int k = 0; k < c->world; ++k) {
         const jl_pack *pk = reinterpret_cast<const jl_pack *>(s->h_base + ((size_t)k * s->batch_n + s->batch_k) * JL_PACK_HEAD_BYTES);
-        if (pk->magic != JL_PACK_MAGIC || !pk->fits_call) compact = false;
+        // a head without the magic word is what a rank sends whose run failed (comm_worker): every rank sees it and
+        // returns the same error; nobody goes on to a second collective
+        if (pk->magic != JL_PACK_MAGIC) return jl_fail(ctx, JL_ERR_COMM, "rank %d's run did not complete: its head of the exchange is empty", k);
+        if (!pk->fits_call) compact = false;
     }
     if (compact) {
         int rc = JL_OK;
@@ -488,222 +473,5 @@ int jl_allgather_variants_many(jl_ctx *const *ctxs, uint32_t n_ctx, jl_comm *c, 
     return JL_OK;
 }
 
-
-/* ---------------------------------------------------------------- cross-window phasing */
-
-// Distinct variant positions of the merged (global-column) table, ascending, and the remapped table whose
-// columns index the compact matrix: position k lives in compact columns 3k..3k+2.
-static uint32_t xwin_remap(const jl_variant *merged, uint32_t n_var, jl_variant *remapped, uint32_t *pos_global)
-{
-    std::vector<uint32_t> cols;
-    cols.reserve(n_var);
-    for (uint32_t v = 0; v < n_var; ++v) cols.push_back(merged[v].col);
-    std::sort(cols.begin(), cols.end());
-    cols.erase(std::unique(cols.begin(), cols.end()), cols.end());
-    for (uint32_t v = 0; v < n_var; ++v) {
-        const uint32_t k = (uint32_t)(std::lower_bound(cols.begin(), cols.end(), merged[v].col) - cols.begin());
-        if (remapped) {
-            remapped[v] = merged[v];
-            remapped[v].col = 3u * k;
-        }
-    }
-    if (pos_global) std::copy(cols.begin(), cols.end(), pos_global);
-    return (uint32_t)cols.size();
-}
-
-static int xwin_owner(const uint32_t *win_begin, const uint32_t *win_ncols, uint32_t n_windows, uint32_t col)
-{
-    for (uint32_t w = 0; w < n_windows; ++w)
-        if (col >= win_begin[w] && (uint64_t)col + 3 <= (uint64_t)win_begin[w] + win_ncols[w]) return (int)w;
-    return -1;
-}
-
-// Host-only plan of the column exchange (no device, no communicator): the distinct variant positions of the merged
-// table in ascending global order, the table remapped onto the compact matrix (position k -> columns 3k..3k+2), and
-// for every position the window that holds its three columns entirely (-1: none does).
-int jl_xwin_plan(const uint32_t *win_begin, const uint32_t *win_ncols, uint32_t n_windows, const jl_variant *merged, uint32_t n_var,
-                 jl_variant *remapped, uint32_t *pos_global, int32_t *owner, uint32_t *vp_total)
-{
-    if (!win_begin || !win_ncols || n_windows == 0 || (!merged && n_var) || !vp_total) return JL_ERR_ARG;
-    std::vector<uint32_t> pos(n_var ? n_var : 1);
-    const uint32_t vp = xwin_remap(merged, n_var, remapped, pos.data());
-    *vp_total = vp;
-    for (uint32_t k = 0; k < vp; ++k) {
-        if (pos_global) pos_global[k] = pos[k];
-        if (owner) owner[k] = xwin_owner(win_begin, win_ncols, n_windows, pos[k]);
-    }
-    return JL_OK;
-}
-
-// All windows on THIS device (a 288 GB GPU holds many): device-to-device copies of 3 columns per position.
-int jl_xwin_assemble_local(jl_ctx *pc, jl_ctx *const *windows, uint32_t n_windows, const jl_variant *merged, uint32_t n_var,
-                           jl_variant *remapped, uint32_t *pos_global, uint32_t *vp_total)
-{
-    if (!pc || !windows || n_windows == 0 || (!merged && n_var) || !vp_total) return JL_ERR_ARG;
-    if (n_var > JL_VARIANT_CAP) return jl_fail(pc, JL_ERR_OVERFLOW, "%u variants, table holds %u", n_var, JL_VARIANT_CAP);
-    std::vector<uint32_t> wb(n_windows), wn(n_windows);
-    for (uint32_t w = 0; w < n_windows; ++w) {
-        if (!windows[w] || !windows[w]->d_msa) return jl_fail(pc, JL_ERR_ARG, "window %u has no resident matrix", w);
-        if (windows[w]->n_reads != windows[0]->n_reads || windows[w]->col_stride != windows[0]->col_stride)
-            return jl_fail(pc, JL_ERR_ARG, "windows must hold the same reads (window %u differs)", w);
-        wb[w] = windows[w]->win_begin;
-        wn[w] = windows[w]->n_cols;
-    }
-    std::vector<uint32_t> pos(n_var ? n_var : 1);
-    const uint32_t vp = xwin_remap(merged, n_var, remapped, pos.data());
-    *vp_total = vp;
-    if (pos_global) std::copy(pos.begin(), pos.begin() + vp, pos_global);
-    if (vp == 0) return JL_OK;
-    const uint64_t stride = windows[0]->col_stride;
-    int rc = jl_msa_alloc_strided(pc, windows[0]->n_reads, 3u * vp, stride, 0);   // the windows' stride, whatever it is
-    if (rc) return rc;
-    for (uint32_t k = 0; k < vp; ++k) {
-        const int w = xwin_owner(wb.data(), wn.data(), n_windows, pos[k]);
-        if (w < 0) return jl_fail(pc, JL_ERR_ARG, "variant column %u is not fully inside any window", pos[k]);
-        JL_HIP(pc, hipStreamSynchronize(windows[w]->stream));
-        JL_HIP(pc, hipMemcpyAsync(pc->d_msa + (uint64_t)3 * k * stride, windows[w]->d_msa + (uint64_t)(pos[k] - wb[w]) * stride,
-                                  3 * stride, hipMemcpyDeviceToDevice, pc->stream));
-    }
-    JL_HIP(pc, hipStreamSynchronize(pc->stream));
-    return JL_OK;
-}
-
-// One window per rank: the owner of each position broadcasts its 3 columns over RCCL/xGMI into every rank's
-// compact matrix (the second exchange of a cross-window run; 3*Vp*col_stride bytes in total).
-int jl_xwin_assemble_rccl(jl_ctx *pc, jl_ctx *window, jl_comm *c, const uint32_t *win_begin, const uint32_t *win_ncols,
-                          const jl_variant *merged, uint32_t n_var, jl_variant *remapped, uint32_t *pos_global,
-                          uint32_t *vp_total)
-{
-    if (!pc || !window || !c || !win_begin || !win_ncols || (!merged && n_var) || !vp_total) return JL_ERR_ARG;
-    if (!window->d_msa) return jl_fail(pc, JL_ERR_ARG, "window has no resident matrix");
-    if (n_var > JL_VARIANT_CAP) return jl_fail(pc, JL_ERR_OVERFLOW, "%u variants, table holds %u", n_var, JL_VARIANT_CAP);
-    std::vector<uint32_t> pos(n_var ? n_var : 1);
-    const uint32_t vp = xwin_remap(merged, n_var, remapped, pos.data());
-    *vp_total = vp;
-    if (pos_global) std::copy(pos.begin(), pos.begin() + vp, pos_global);
-    if (vp == 0) return JL_OK;
-    const uint64_t stride = window->col_stride;   // every rank's window must use the same stride (same reads)
-    int rc = jl_msa_alloc_strided(pc, window->n_reads, 3u * vp, stride, 0);
-    if (rc) return rc;
-    JL_HIP(pc, hipStreamSynchronize(window->stream));
-    ncclResult_t r = ncclGroupStart();
-    for (uint32_t k = 0; k < vp && r == ncclSuccess; ++k) {
-        const int w = xwin_owner(win_begin, win_ncols, (uint32_t)c->world, pos[k]);
-        if (w < 0) { ncclGroupEnd(); return jl_fail(pc, JL_ERR_ARG, "variant column %u is not fully inside any window", pos[k]); }
-        const uint8_t *src = (w == c->rank) ? window->d_msa + (uint64_t)(pos[k] - win_begin[w]) * stride : pc->d_msa;
-        r = ncclBroadcast(src, pc->d_msa + (uint64_t)3 * k * stride, 3 * stride, ncclUint8, w, c->comm, pc->stream);
-    }
-    if (r == ncclSuccess) r = ncclGroupEnd();
-    if (r != ncclSuccess) return jl_fail(pc, JL_ERR_COMM, "ncclBroadcast: %s", ncclGetErrorString(r));
-    JL_HIP(pc, hipStreamSynchronize(pc->stream));
-    return JL_OK;
-}
-
-// ---- the same with the READS sharded (SURVEY §8e option A): the compact matrix holds reads [read_begin,
-// read_begin + n_slice) only, so a rank phases 1/world of the reads and the second exchange moves 1/world of the bytes.
-// read_begin must be a multiple of 256 (a slice starts on a 128-byte line of every column).
-static int xwin_slice_alloc(jl_ctx *pc, uint64_t n_slice, uint32_t vp)
-{
-    int rc = jl_msa_alloc(pc, n_slice, 3u * vp, 0);
-    if (rc) return rc;
-    // padding nibbles of a column (reads past the slice) are 'not covered'
-    JL_HIP(pc, hipMemsetAsync(pc->d_msa, 0x66, (size_t)pc->col_stride * 3u * vp, pc->stream));
-    return JL_OK;
-}
-
-int jl_xwin_assemble_slice_local(jl_ctx *pc, jl_ctx *const *windows, uint32_t n_windows, const jl_variant *merged, uint32_t n_var,
-                                 uint64_t read_begin, uint64_t n_slice, jl_variant *remapped, uint32_t *pos_global,
-                                 uint32_t *vp_total)
-{
-    if (!pc || !windows || n_windows == 0 || (!merged && n_var) || !vp_total) return JL_ERR_ARG;
-    if (n_var > JL_VARIANT_CAP) return jl_fail(pc, JL_ERR_OVERFLOW, "%u variants, table holds %u", n_var, JL_VARIANT_CAP);
-    std::vector<uint32_t> wb(n_windows), wn(n_windows);
-    for (uint32_t w = 0; w < n_windows; ++w) {
-        if (!windows[w] || !windows[w]->d_msa) return jl_fail(pc, JL_ERR_ARG, "window %u has no resident matrix", w);
-        if (windows[w]->n_reads != windows[0]->n_reads || windows[w]->col_stride != windows[0]->col_stride)
-            return jl_fail(pc, JL_ERR_ARG, "windows must hold the same reads (window %u differs)", w);
-        wb[w] = windows[w]->win_begin;
-        wn[w] = windows[w]->n_cols;
-    }
-    const uint64_t n_reads = windows[0]->n_reads;
-    if ((n_slice && (read_begin & 255u)) || read_begin > n_reads || n_slice > n_reads - read_begin)
-        return jl_fail(pc, JL_ERR_ARG, "slice [%llu, +%llu) of %llu reads: the start must be a multiple of 256 and the slice inside",
-                       (unsigned long long)read_begin, (unsigned long long)n_slice, (unsigned long long)n_reads);
-    std::vector<uint32_t> pos(n_var ? n_var : 1);
-    const uint32_t vp = xwin_remap(merged, n_var, remapped, pos.data());
-    *vp_total = vp;
-    if (pos_global) std::copy(pos.begin(), pos.begin() + vp, pos_global);
-    if (vp == 0 || n_slice == 0) return JL_OK;
-    int rc = xwin_slice_alloc(pc, n_slice, vp);
-    if (rc) return rc;
-    const uint64_t src_stride = windows[0]->col_stride, bytes = (n_slice + 1u) / 2u;
-    for (uint32_t k = 0; k < vp; ++k) {
-        const int w = xwin_owner(wb.data(), wn.data(), n_windows, pos[k]);
-        if (w < 0) return jl_fail(pc, JL_ERR_ARG, "variant column %u is not fully inside any window", pos[k]);
-        JL_HIP(pc, hipStreamSynchronize(windows[w]->stream));
-        JL_HIP(pc, hipMemcpy2DAsync(pc->d_msa + (uint64_t)3 * k * pc->col_stride, pc->col_stride,
-                                    windows[w]->d_msa + (uint64_t)(pos[k] - wb[w]) * src_stride + read_begin / 2u, src_stride, bytes, 3,
-                                    hipMemcpyDeviceToDevice, pc->stream));
-    }
-    JL_HIP(pc, hipStreamSynchronize(pc->stream));
-    return JL_OK;
-}
-
-// One window per rank, reads sharded: rank s phases reads [slice_begin[s], slice_begin[s + 1]) (world + 1 entries, the
-// same on every rank, multiples of 256 except the last = n_reads).  The owner of each variant position sends rank s
-// that slice of its three columns (ncclSend / ncclRecv in one group; its own slice by a device copy).
-int jl_xwin_assemble_slice_rccl(jl_ctx *pc, jl_ctx *window, jl_comm *c, const uint32_t *win_begin, const uint32_t *win_ncols,
-                                const jl_variant *merged, uint32_t n_var, const uint64_t *slice_begin, jl_variant *remapped,
-                                uint32_t *pos_global, uint32_t *vp_total)
-{
-    if (!pc || !window || !c || !win_begin || !win_ncols || (!merged && n_var) || !slice_begin || !vp_total) return JL_ERR_ARG;
-    if (!window->d_msa) return jl_fail(pc, JL_ERR_ARG, "window has no resident matrix");
-    if (n_var > JL_VARIANT_CAP) return jl_fail(pc, JL_ERR_OVERFLOW, "%u variants, table holds %u", n_var, JL_VARIANT_CAP);
-    const int world = c->world, me = c->rank;
-    for (int s = 0; s < world; ++s)
-        if ((slice_begin[s + 1] > slice_begin[s] && (slice_begin[s] & 255u)) || slice_begin[s + 1] < slice_begin[s] ||
-            slice_begin[s + 1] > window->n_reads)
-            return jl_fail(pc, JL_ERR_ARG, "slice %d of the reads is not 256-aligned or not inside the %llu reads", s,
-                           (unsigned long long)window->n_reads);
-    std::vector<uint32_t> pos(n_var ? n_var : 1);
-    const uint32_t vp = xwin_remap(merged, n_var, remapped, pos.data());
-    *vp_total = vp;
-    if (pos_global) std::copy(pos.begin(), pos.begin() + vp, pos_global);
-    const uint64_t n_mine = slice_begin[me + 1] - slice_begin[me];
-    if (vp == 0) return JL_OK;
-    if (n_mine) {
-        int rc = xwin_slice_alloc(pc, n_mine, vp);
-        if (rc) return rc;
-    }
-    const uint64_t src_stride = window->col_stride;
-    JL_HIP(pc, hipStreamSynchronize(window->stream));
-    ncclResult_t r = ncclGroupStart();
-    for (uint32_t k = 0; k < vp && r == ncclSuccess; ++k) {
-        const int w = xwin_owner(win_begin, win_ncols, (uint32_t)world, pos[k]);
-        if (w < 0) { ncclGroupEnd(); return jl_fail(pc, JL_ERR_ARG, "variant column %u is not fully inside any window", pos[k]); }
-        for (uint32_t j = 0; j < 3u && r == ncclSuccess; ++j) {
-            if (w == me) {
-                const uint8_t *col = window->d_msa + (uint64_t)(pos[k] - win_begin[w] + j) * src_stride;
-                for (int s = 0; s < world && r == ncclSuccess; ++s) {
-                    const uint64_t bytes = (slice_begin[s + 1] - slice_begin[s] + 1u) / 2u;
-                    if (!bytes) continue;
-                    if (s == me) {
-                        if (hipMemcpyAsync(pc->d_msa + (uint64_t)(3u * k + j) * pc->col_stride, col + slice_begin[s] / 2u, bytes,
-                                           hipMemcpyDeviceToDevice, pc->stream) != hipSuccess) r = ncclUnhandledCudaError;
-                    } else {
-                        r = ncclSend(col + slice_begin[s] / 2u, bytes, ncclUint8, s, c->comm, pc->stream);
-                    }
-                }
-            } else if (n_mine) {
-                r = ncclRecv(pc->d_msa + (uint64_t)(3u * k + j) * pc->col_stride, (n_mine + 1u) / 2u, ncclUint8, w, c->comm, pc->stream);
-            }
-        }
-    }
-    if (r == ncclSuccess) r = ncclGroupEnd();
-    else ncclGroupEnd();
-    if (r != ncclSuccess) return jl_fail(pc, JL_ERR_COMM, "column slices: %s", ncclGetErrorString(r));
-    JL_HIP(pc, hipStreamSynchronize(pc->stream));
-    return JL_OK;
-}
 
 }  // extern "C"

@@ -193,7 +193,15 @@ struct jl_select_args {
     uint32_t *exp_count;             // null: normal selection
     uint8_t *exp_pattern;            // [exp_cap][exp_stride]
     uint32_t exp_cap, exp_stride;
+    uint32_t *exp_head;              // optional: [JL_EXP_HEAD_WORDS] what a merge needs of the run's scalars (jl_exp_head)
 };
+
+// head of an exported group table: the block's first words when it travels (pinned host memory, or the all-gather)
+struct jl_exp_head {
+    uint32_t n_groups, vp, overflow;   // overflow != 0: more groups than the block holds (n_groups = the number needed)
+    uint32_t damaged, gap, heteroduplex, partial, clean;   // the slice's read categories (clean = in some group)
+};
+#define JL_EXP_HEAD_WORDS 8u
 
 struct jl_done_ent {   // completion word of one window (see done_kernel)
     uint32_t *seq_dev;
@@ -232,6 +240,34 @@ struct jl_gather_args { const uint8_t *src[JL_GATHER_MAX]; };
 void jl_launch_gather_heads(const uint8_t *const *srcs, uint32_t n, uint8_t *dst, hipStream_t st);
 
 struct jl_comm;
+
+// ---- cross-window phasing with the reads sharded (kernels_xwin.hip)
+#define JL_XW_POS_MAX 48u    // owned variant positions per pack launch
+#define JL_XW_DST_MAX 8u     // destination ranks per pack launch
+#define JL_XW_TAB_MAX 1024u  // exported groups whose haplotypes travel in the kernel arguments
+struct jl_xw_pack_args {
+    const uint8_t *src[JL_XW_POS_MAX];   // column 0 of each owned position in its window, at read 0
+    uint64_t src_stride;
+    uint32_t n_pos, n_dst;
+    struct { uint8_t *dst; uint64_t dst_stride, byte_begin, bytes; } d[JL_XW_DST_MAX];   // dst: where source column 0 of this launch goes
+    // the compact matrix's phasing plan, written by the first launch of a step (meta == null: not by this one)
+    jl_phase_meta *meta;
+    uint32_t *vpcols, *col2pos;
+    uint32_t vp_total, kwords, n_var, pad_;
+};
+struct jl_xw_assign_args {
+    uint64_t n_dwords;
+    const uint32_t *flagw, *read_slot, *slot_hap;
+    uint16_t *read_hap;
+    uint32_t n_groups, bits, phased, pad_;
+    uint32_t *arrive, *seq_dev;
+    volatile uint32_t *seq_host;     // null: no completion word
+};
+struct jl_xw_hap_table { uint16_t h[JL_XW_TAB_MAX]; };
+void jl_launch_xw_pack(const jl_xw_pack_args *a, hipStream_t st);
+void jl_launch_xw_assign(const jl_xw_assign_args *a, const uint16_t *host_tab, const uint16_t *d_tab, hipStream_t st);
+void jl_launch_xw_fetch(const void *d_src, void *h_dst, uint64_t bytes, uint32_t *arrive, uint32_t *seq_dev, volatile uint32_t *seq_host,
+                        hipStream_t st);
 
 // Records uploaded so far by jl_records_append: one run of device arrays, offsets rebased to it.
 struct jl_records {
@@ -275,6 +311,15 @@ struct jl_ctx {
     uint8_t *d_exp_pattern = nullptr; // [exp_cap][exp_stride]
     uint16_t *d_exp_hap = nullptr;    // [exp_cap] the merge's answer on its way to the slots
     uint32_t exp_cap = 0, exp_stride = 0;
+    uint32_t exp_n_groups = 0;        // groups the last export produced, once the host has read the count (regroup checks it)
+    uint32_t exp_vp = 0;              // ... and its variant positions (0: nothing was phased, no read has flags or a slot)
+    bool exp_known = false;
+    // a session (capi_xwin.hip) has the groups written into its own block instead (pinned host memory, or the send
+    // buffer of the all-gather); null: the context's arrays above
+    uint32_t *exp_ext_count = nullptr;
+    uint8_t *exp_ext_pattern = nullptr;
+    uint32_t *exp_ext_head = nullptr;
+    uint32_t exp_ext_cap = 0, exp_ext_stride = 0;
 
     // ---- pileup plan (host copies + device arrays)
     std::vector<jl_gene> genes;
@@ -419,7 +464,7 @@ void jl_launch_ingest(jl_ctx *ctx, const int32_t *d_pos, const uint32_t *d_cigar
                       const uint8_t *d_seq4, const uint64_t *d_seq_off, const uint8_t *d_qual,
                       const uint64_t *d_qual_off, uint32_t min_qv, uint32_t *d_rows4, uint64_t max_ops, uint64_t max_seq_bytes);
 uint32_t jl_ingest_row_dwords(const jl_ctx *ctx);
-void jl_launch_regroup(jl_ctx *ctx, const uint16_t *d_hap_of_group, uint32_t n_groups, uint32_t n_haplotypes);
+void jl_launch_regroup(jl_ctx *ctx, const uint16_t *d_hap_of_group, uint32_t n_groups, uint32_t n_haplotypes, bool phased);
 uint64_t jl_ingest_batch_reads(const jl_ctx *ctx);
 void jl_launch_insertions(jl_ctx *ctx, const int32_t *d_pos, const uint32_t *d_cigar, const uint64_t *d_cig_off,
                           const uint8_t *d_seq4, const uint64_t *d_seq_off);
@@ -429,3 +474,10 @@ void jl_launch_fisher_eval(jl_ctx *ctx, uint32_t n, const uint32_t *a, const uin
 extern "C" void jl_expand_ids(const void *packed, uint32_t bits, uint64_t n_reads, uint16_t *out);
 int jl_msa_alloc_strided(jl_ctx *ctx, uint64_t n_reads, uint32_t n_cols, uint64_t col_stride, uint32_t win_begin);
 extern "C" int jl_update_callinfo(jl_ctx *ctx, const jl_params *prm, double n_tests, bool use_drm, bool with_meta);
+// capi_xwin.hip: buffers of an exporting phase run whose plan (vp positions at columns 3k) a kernel of the caller writes
+int jl_phase_groups_prepare(jl_ctx *ctx, uint32_t vp);
+// the variant table of a context's last call stage on the host: a pointer into the pinned result block when the run left
+// it there, else copied into `scratch`
+int jl_ctx_table_host(jl_ctx *ctx, std::vector<jl_variant> *scratch, const jl_variant **rows, uint32_t *n);
+// jl_run_wait_seq without touching ctx->err (threads other than the context's owner)
+int jl_run_wait_seq_quiet(jl_ctx *ctx, uint32_t want, hipStream_t stream);

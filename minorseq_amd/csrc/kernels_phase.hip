@@ -209,36 +209,7 @@ __device__ __forceinline__ void signal_done(uint32_t *seq_dev, volatile uint32_t
 // width of the per-read ids for H reported haplotypes (jl_internal.h: JL_ID4_MAX_H / JL_ID8_MAX_H)
 __device__ __forceinline__ uint32_t id_bits_for(uint32_t H) { return H <= JL_ID4_MAX_H ? 4u : (H <= JL_ID8_MAX_H ? 8u : 16u); }
 
-// eight ids (16-bit codes: haplotype, JL_HAP_INSUFFICIENT, JL_HAP_DAMAGED) of reads 8t .. 8t+7 into the packed buffer
-__device__ __forceinline__ void store_ids(uint16_t *base, uint64_t t, const uint16_t (&h)[8], uint32_t bits)
-{
-    if (bits == 4u) {
-        uint32_t v = 0;
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            const uint32_t c = h[r] == JL_HAP_DAMAGED ? 15u : (h[r] == JL_HAP_INSUFFICIENT ? 14u : (uint32_t)h[r]);
-            v |= c << (4 * r);
-        }
-        reinterpret_cast<uint32_t *>(base)[t] = v;
-    } else if (bits == 8u) {
-        uint32_t lo = 0, hi = 0;
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            const uint32_t c = h[r] == JL_HAP_DAMAGED ? 255u : (h[r] == JL_HAP_INSUFFICIENT ? 254u : (uint32_t)h[r]);
-            if (r < 4) lo |= c << (8 * r);
-            else hi |= c << (8 * (r - 4));
-        }
-        uint2 v;
-        v.x = lo; v.y = hi;
-        reinterpret_cast<uint2 *>(base)[t] = v;
-    } else {
-        uint4 v;
-        v.x = h[0] | ((uint32_t)h[1] << 16); v.y = h[2] | ((uint32_t)h[3] << 16);
-        v.z = h[4] | ((uint32_t)h[5] << 16); v.w = h[6] | ((uint32_t)h[7] << 16);
-        // reads_pad = 2 * col_stride entries: the 16-byte store of a live lane is always inside the buffer
-        reinterpret_cast<uint4 *>(base)[t] = v;
-    }
-}
+__device__ __forceinline__ void store_ids(uint16_t *base, uint64_t t, const uint16_t (&h)[8], uint32_t bits) { jl_store_ids(base, t, h, bits); }
 
 // ---------------------------------------------------------------------------------------- select
 template <bool BYKEY>
@@ -271,7 +242,8 @@ __device__ __forceinline__ void phase_select_block(uint32_t min_reads, uint64_t 
                                                    unsigned long long *slot_key, uint32_t *seq_dev, uint32_t *lds,
                                                    uint32_t *exp_count = nullptr, uint8_t *exp_pattern = nullptr,
                                                    uint32_t exp_cap = 0, uint32_t exp_stride = 0, uint32_t *cache = nullptr,
-                                                   unsigned long long *key_cache = nullptr, uint32_t key_cache_words = 0)
+                                                   unsigned long long *key_cache = nullptr, uint32_t key_cache_words = 0,
+                                                   uint32_t *exp_head = nullptr)
 {
     // `lds`: JL_SELECT_LDS_WORDS words of LDS of the caller (the fused launch lends the tables its grouping is done with)
     uint32_t *s_cand = lds;                               // [JL_CAND_CAP] slot of each candidate
@@ -289,7 +261,8 @@ __device__ __forceinline__ void phase_select_block(uint32_t min_reads, uint64_t 
             const uint32_t s = ld_coherent(&occupied[q]);
             const uint32_t c = ld_coherent(&slot_count[s]);
             atomicAdd(&s_insufficient, c);
-            __hip_atomic_store(&slot_hap[s], (uint32_t)JL_HAP_INSUFFICIENT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // the slot remembers WHICH exported group it is: the merge answers per group (jl_phase_regroup, jl_xwin_phase_sharded)
+            __hip_atomic_store(&slot_hap[s], q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (q < exp_cap) {
                 exp_count[q] = c;
                 const uint32_t rep = BYKEY ? s : ld_coherent(&slot_rep[s]);
@@ -304,6 +277,12 @@ __device__ __forceinline__ void phase_select_block(uint32_t min_reads, uint64_t 
             meta->summary.insufficient_reads = s_insufficient;   // clean reads: the merge decides which are reported
             meta->summary.n_haplotypes = 0;
             __hip_atomic_store(&meta->id_bits, 16u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (exp_head) {   // the scalars a merge needs, next to the groups (pinned host memory or an all-gather's send buffer)
+                exp_head[0] = n_occ; exp_head[1] = vp; exp_head[2] = n_occ > exp_cap ? 1u : 0u;
+                exp_head[3] = ld_coherent(&meta->summary.damaged_reads); exp_head[4] = ld_coherent(&meta->summary.marginal_gap);
+                exp_head[5] = ld_coherent(&meta->summary.marginal_heteroduplex); exp_head[6] = ld_coherent(&meta->summary.marginal_partial);
+                exp_head[7] = s_insufficient;
+            }
         }
     } else if (vp != 0) {  // block-uniform
     if (tid == 0) { s_ncand = 0; s_insufficient = 0; s_reported = 0; s_nhap = 0; }
@@ -487,13 +466,19 @@ __device__ __forceinline__ void phase_select_block(uint32_t min_reads, uint64_t 
     }
     } else if (tid == 0) {
         __hip_atomic_store(&meta->id_bits, 4u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // nothing phased: every read is "damaged"
+        if (exp_head) {
+            exp_head[0] = 0; exp_head[1] = 0; exp_head[2] = 0;
+            exp_head[3] = 0; exp_head[4] = 0; exp_head[5] = 0; exp_head[6] = 0; exp_head[7] = 0;
+        }
     }
     __syncthreads();
     // device copy double-buffered by the parity of the run index (an exchange may still read run n's block while
-    // run n+1 writes its own)
-    pk += __hip_atomic_load(seq_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 1u;
-    jl_result_pack_block(variants, ld_coherent(&n_rows[0]), meta, 1u, vpcols, hap_count, hap_pattern, hit, cooc, cooc_cap, 1u, pk,
-                         mirror, BYKEY);
+    // run n+1 writes its own); an exporting run has no result block: its groups ARE the result
+    if (!exp_count) {
+        pk += __hip_atomic_load(seq_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 1u;
+        jl_result_pack_block(variants, ld_coherent(&n_rows[0]), meta, 1u, vpcols, hap_count, hap_pattern, hit, cooc, cooc_cap, 1u, pk,
+                             mirror, BYKEY);
+    }
     // leave the table empty for the next run: only the slots this run touched
     for (uint32_t q = tid; q < n_occ; q += nt) {
         const uint32_t s = ld_coherent(&occupied[q]);
@@ -514,14 +499,14 @@ __global__ __launch_bounds__(1024) void phase_select_kernel(uint32_t min_reads, 
                                                              jl_pack *mirror, unsigned long long *slot_key,
                                                              uint32_t *seq_dev, volatile uint32_t *seq_host,
                                                              uint32_t *exp_count, uint8_t *exp_pattern, uint32_t exp_cap,
-                                                             uint32_t exp_stride)
+                                                             uint32_t exp_stride, uint32_t *exp_head)
 {
     __shared__ uint32_t s_select[JL_SELECT_LDS_WORDS];
     __shared__ uint32_t s_cache[2u * JL_CAND_CAP];
     __shared__ unsigned long long s_keys[2048];
     phase_select_block<false>(min_reads, reads_pad, keys, meta, slot_rep, slot_count, occupied, slot_hap, variants, col2pos,
                               n_cols, hap_count, hap_pattern, hit, n_rows, vpcols, cooc, cooc_cap, pk, mirror, slot_key, seq_dev,
-                              s_select, exp_count, exp_pattern, exp_cap, exp_stride, s_cache, s_keys, 2048u);
+                              s_select, exp_count, exp_pattern, exp_cap, exp_stride, s_cache, s_keys, 2048u, exp_head);
     if (seq_host) {  // last kernel of the run: the result block is on its way to the host
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -1034,7 +1019,7 @@ __device__ __forceinline__ void phase_fused1_body(const jl_win_phase &w)
             phase_select_block<true>(S.min_reads, reads_pad, keys, meta, slot_rep, slot_count, occupied, S.slot_hap, S.variants,
                                      S.col2pos, S.n_cols, S.hap_count, S.hap_pattern, S.hit, S.n_rows, w.vpcols, S.cooc, S.cooc_cap,
                                      S.pk, S.mirror, slot_key, S.seq_dev, reinterpret_cast<uint32_t *>(s_tables), S.exp_count,
-                                     S.exp_pattern, S.exp_cap, S.exp_stride);
+                                     S.exp_pattern, S.exp_cap, S.exp_stride, nullptr, nullptr, 0u, S.exp_head);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -1195,8 +1180,13 @@ bool jl_fill_win_phase(jl_ctx *ctx, uint32_t min_reads, bool signal, uint32_t fo
     S.arrive = ctx->d_sync + 2; S.seq_dev = ctx->d_sync;
     // a launch of at most JL_FOLD_MAX_BLOCKS workgroups in all also writes the per-read ids: one launch less
     if (ctx->phase_export) {
-        S.exp_count = ctx->d_exp_count; S.exp_pattern = ctx->d_exp_pattern;
-        S.exp_cap = ctx->exp_cap; S.exp_stride = ctx->exp_stride;
+        if (ctx->exp_ext_count) {   // a session's block (pinned host memory, or the send buffer of the all-gather)
+            S.exp_count = ctx->exp_ext_count; S.exp_pattern = ctx->exp_ext_pattern; S.exp_head = ctx->exp_ext_head;
+            S.exp_cap = ctx->exp_ext_cap; S.exp_stride = ctx->exp_ext_stride;
+        } else {
+            S.exp_count = ctx->d_exp_count; S.exp_pattern = ctx->d_exp_pattern;
+            S.exp_cap = ctx->exp_cap; S.exp_stride = ctx->exp_stride;
+        }
     }
     // (an exporting run keeps every read's flags and slot: jl_phase_regroup maps them once the merge is known)
     const bool fold = !generic && !ctx->phase_export && fblocks + 1u <= fold_budget;
@@ -1247,8 +1237,7 @@ bool jl_launch_phase(jl_ctx *ctx, hipStream_t st, uint32_t min_reads, bool plann
                            ctx->d_variants, ctx->d_col2pos, ctx->n_cols, ctx->d_hap_count, ctx->d_hap_pattern, ctx->d_hit,
                            ctx->d_nvar, ctx->d_vpcols, ctx->d_cooc, ctx->cooc_cap, ctx->d_pack, ctx->pack_mirror,
                            (unsigned long long *)ctx->d_slot_key, ctx->d_sync, signal_select ? ctx->h_seq : nullptr,
-                           ctx->phase_export ? ctx->d_exp_count : nullptr, ctx->phase_export ? ctx->d_exp_pattern : nullptr,
-                           ctx->exp_cap, ctx->exp_stride);
+                           w.S.exp_count, w.S.exp_pattern, w.S.exp_cap, w.S.exp_stride, w.S.exp_head);
     }
     if (fold) return signal;
     if (ctx->phase_export) return false;   // the ids wait for the merge (jl_phase_regroup)
@@ -1285,27 +1274,16 @@ void jl_launch_assign_group(const jl_win_phase *h_wins, uint32_t n_win, uint32_t
 
 
 // ---------------------------------------------------------------------------------------- sharded by reads: the merge's answer
-// hap_of_group[q] = haplotype id (or JL_HAP_INSUFFICIENT) of the q-th group this matrix exported
-__global__ __launch_bounds__(256) void regroup_kernel(const uint32_t *__restrict__ occupied,
-                                                       const uint16_t *__restrict__ hap_of_group, uint32_t n_groups,
-                                                       uint32_t *__restrict__ slot_hap, jl_phase_meta *__restrict__ meta,
-                                                       uint32_t n_haplotypes)
+// hap_of_group[q] = haplotype id (or JL_HAP_INSUFFICIENT) of the q-th group this matrix exported; every table slot holds
+// its group's index since the exporting selection (kernels_xwin.hip maps the reads)
+void jl_launch_regroup(jl_ctx *ctx, const uint16_t *d_hap_of_group, uint32_t n_groups, uint32_t n_haplotypes, bool phased)
 {
-    const uint32_t q = blockIdx.x * 256u + threadIdx.x;
-    if (q < n_groups) slot_hap[occupied[q]] = hap_of_group[q];
-    if (q == 0) {
-        meta->summary.n_haplotypes = n_haplotypes;
-        meta->id_bits = id_bits_for(n_haplotypes);
-    }
+    jl_xw_assign_args a;
+    memset(&a, 0, sizeof a);
+    a.n_dwords = ctx->col_stride / 4u;
+    a.flagw = ctx->d_flagw; a.read_slot = ctx->d_read_slot; a.slot_hap = ctx->d_slot_hap; a.read_hap = ctx->d_read_hap;
+    a.n_groups = n_groups;
+    a.bits = n_haplotypes <= JL_ID4_MAX_H ? 4u : (n_haplotypes <= JL_ID8_MAX_H ? 8u : 16u);
+    a.phased = phased ? 1u : 0u;   // no variant position: every read is "damaged", flags and slots were never written
+    jl_launch_xw_assign(&a, nullptr, d_hap_of_group, ctx->stream);
 }
-
-void jl_launch_regroup(jl_ctx *ctx, const uint16_t *d_hap_of_group, uint32_t n_groups, uint32_t n_haplotypes)
-{
-    hipStream_t st = ctx->stream;
-    hipLaunchKernelGGL(regroup_kernel, dim3((n_groups + 255u) / 256u + (n_groups ? 0u : 1u)), dim3(256), 0, st, ctx->d_occupied,
-                       d_hap_of_group, n_groups, ctx->d_slot_hap, ctx->d_meta, n_haplotypes);
-    const uint32_t n_dwords = (uint32_t)(ctx->col_stride / 4u);
-    hipLaunchKernelGGL(phase_assign_kernel, dim3(jl_assign_blocks(1, (n_dwords + 255u) / 256u, false)), dim3(256), 0, st,
-                       (uint64_t)n_dwords, ctx->d_flagw, ctx->d_meta, ctx->d_read_slot, ctx->d_slot_hap, ctx->d_read_hap);
-}
-

@@ -85,3 +85,35 @@ __device__ __forceinline__ void jl_result_pack_block(const jl_variant *__restric
         }
     }
 }
+
+// Per-read ids in the narrowest code that holds the run's haplotype count (jl_internal.h: JL_ID4_MAX_H / JL_ID8_MAX_H):
+// eight ids (16-bit codes: haplotype, JL_HAP_INSUFFICIENT, JL_HAP_DAMAGED) of reads 8t .. 8t+7 into the packed buffer
+__device__ __forceinline__ void jl_store_ids(uint16_t *base, uint64_t t, const uint16_t (&h)[8], uint32_t bits)
+{
+    if (bits == 4u) {
+        uint32_t v = 0;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const uint32_t c = h[r] == JL_HAP_DAMAGED ? 15u : (h[r] == JL_HAP_INSUFFICIENT ? 14u : (uint32_t)h[r]);
+            v |= c << (4 * r);
+        }
+        reinterpret_cast<uint32_t *>(base)[t] = v;
+    } else if (bits == 8u) {
+        uint32_t lo = 0, hi = 0;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const uint32_t c = h[r] == JL_HAP_DAMAGED ? 255u : (h[r] == JL_HAP_INSUFFICIENT ? 254u : (uint32_t)h[r]);
+            if (r < 4) lo |= c << (8 * r);
+            else hi |= c << (8 * (r - 4));
+        }
+        uint2 v;
+        v.x = lo; v.y = hi;
+        reinterpret_cast<uint2 *>(base)[t] = v;
+    } else {
+        uint4 v;
+        v.x = h[0] | ((uint32_t)h[1] << 16); v.y = h[2] | ((uint32_t)h[3] << 16);
+        v.z = h[4] | ((uint32_t)h[5] << 16); v.w = h[6] | ((uint32_t)h[7] << 16);
+        // reads_pad = 2 * col_stride entries: the 16-byte store of a live lane is always inside the buffer
+        reinterpret_cast<uint4 *>(base)[t] = v;
+    }
+}

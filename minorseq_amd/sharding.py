@@ -29,15 +29,10 @@ def default_n_tests(genes) -> float:
 
 
 def merge_tables(tables, win_begins):
-    """Per-rank tables (window-relative `col`) -> one table in (gene, codon_pos, codon) order, global columns."""
-    parts = []
-    for t, b in zip(tables, win_begins):
-        t = np.array(t, dtype=VARIANT, copy=True)
-        t["col"] += np.uint32(b)
-        parts.append(t)
-    allv = np.concatenate(parts) if parts else np.zeros(0, dtype=VARIANT)
-    order = np.lexsort((allv["codon"], allv["codon_pos"], allv["gene"]))
-    return allv[order]
+    """Per-rank tables (window-relative `col`) -> one table in (gene, codon_pos, codon) order, global columns.
+    The product code is jl_merge_tables (C ABI, host only); this is its caller."""
+    from . import capi
+    return capi.merge_tables(tables, win_begins)
 
 
 def allgather_tables(local_rows, group=None, cap_rows=VARIANT_CAP):
@@ -84,62 +79,20 @@ def read_slices(n_reads: int, world: int):
 def merge_groups(tables):
     """tables: per rank dict(patterns uint8[G][Vp], counts uint32[G]) as jl_phase_groups_fetch returns them.
     -> (patterns uint8[M][Vp], counts int64[M], index): the distinct patterns in ascending order (codon codes compared
-    position by position), their summed counts, and per rank the merged row of each of its groups."""
-    vp = max((t["patterns"].shape[1] for t in tables if len(t["counts"])), default=0)
-    rows = [np.asarray(t["patterns"], dtype=np.uint8).reshape(len(t["counts"]), -1)[:, :vp] if len(t["counts"])
-            else np.zeros((0, vp), dtype=np.uint8) for t in tables]
-    allp = np.concatenate(rows) if rows else np.zeros((0, vp), dtype=np.uint8)
-    allc = np.concatenate([np.asarray(t["counts"], dtype=np.int64) for t in tables]) if tables else np.zeros(0, dtype=np.int64)
-    if len(allp) == 0:
-        return np.zeros((0, vp), dtype=np.uint8), np.zeros(0, dtype=np.int64), [np.zeros(0, dtype=np.int64) for _ in tables]
-    uniq, inverse = np.unique(allp, axis=0, return_inverse=True)    # rows sorted lexicographically = pattern ascending
-    inverse = np.asarray(inverse).reshape(-1)
-    counts = np.bincount(inverse, weights=allc, minlength=len(uniq)).astype(np.int64)
-    index, o = [], 0
-    for t in tables:
-        g = len(t["counts"])
-        index.append(inverse[o:o + g])
-        o += g
-    return uniq, counts, index
+    position by position), their summed counts, and per rank the merged row of each of its groups.
+    The product code is jl_merge_groups (C ABI, host only); this is its caller."""
+    from . import capi
+    return capi.merge_groups(tables)
 
 
 def select_haplotypes(patterns, counts, variants, pos_cols, min_reads=10, partials=()):
     """docs/SPEC.md §8 on merged groups: reported = count >= min_reads, ordered by (count desc, pattern asc), at most 702;
     hit, co-occurrence and the read categories (the partial summaries carry each slice's damaged reads and marginals).
     `variants`: the remapped table (col = 3 * position index); pos_cols: the compact columns of the positions.
-    -> dict like Juliet.phase_fetch (no read_hap) + hap_of_merged int64[M] (HAP_INSUFFICIENT where not reported)."""
-    patterns = np.asarray(patterns, dtype=np.uint8)
-    counts = np.asarray(counts, dtype=np.int64)
-    m = patterns.shape[0] if patterns.ndim == 2 else 0
-    vp = len(pos_cols)            # the positions exist even when no read is clean (no groups at all)
-    if m == 0:
-        patterns = np.zeros((0, vp), dtype=np.uint8)
-    qualified = np.nonzero(counts >= min_reads)[0]
-    # (count descending, then pattern ascending position by position): lexsort's LAST key is the primary one
-    keys = [patterns[qualified, p] for p in range(vp - 1, -1, -1)] + [-counts[qualified]]
-    order = qualified[np.lexsort(keys)] if len(qualified) else qualified
-    reported = order[:MAX_HAPLOTYPES]
-    hap_of_merged = np.full(m, HAP_INSUFFICIENT, dtype=np.int64)
-    hap_of_merged[reported] = np.arange(len(reported))
-    hap_count = counts[reported].astype(np.uint32)
-    hap_pattern = patterns[reported] if vp else np.zeros((len(reported), 0), dtype=np.uint8)
-    variants = np.asarray(variants, dtype=VARIANT)
-    col2pos = {int(c): k for k, c in enumerate(np.asarray(pos_cols).tolist())}
-    nv, h = len(variants), len(reported)
-    hit = np.zeros((nv, h), dtype=np.uint8)
-    for v in range(nv):
-        k = col2pos.get(int(variants[v]["col"]))
-        if k is not None and h:
-            hit[v] = hap_pattern[:, k] == variants[v]["codon"]
-    cooc = (hit.astype(np.int64) * hap_count.astype(np.int64)[None, :]) @ hit.astype(np.int64).T if nv else np.zeros((0, 0), dtype=np.int64)
-    summary = dict(reported_reads=int(hap_count.sum()), insufficient_reads=int(counts.sum() - hap_count.sum()),
-                   damaged_reads=sum(int(p["damaged_reads"]) for p in partials),
-                   marginal_gap=sum(int(p["marginal_gap"]) for p in partials),
-                   marginal_heteroduplex=sum(int(p["marginal_heteroduplex"]) for p in partials),
-                   marginal_partial=sum(int(p["marginal_partial"]) for p in partials),
-                   n_positions=int(vp), n_haplotypes=int(h))
-    return dict(summary=summary, hap_count=hap_count, hap_pattern=hap_pattern, hit=hit, cooc=cooc.astype(np.uint32),
-                hap_of_merged=hap_of_merged)
+    -> dict like Juliet.phase_fetch (no read_hap) + hap_of_merged int64[M] (HAP_INSUFFICIENT where not reported).
+    The product code is jl_select_haplotypes (C ABI, host only); this is its caller."""
+    from . import capi
+    return capi.select_haplotypes(patterns, counts, variants, pos_cols, min_reads, partials)
 
 
 def allgather_groups(local, group=None):

@@ -208,3 +208,187 @@ def test_random_shapes_against_the_unsharded_oracle(oracle):
         for c in ctxs:
             c.close()
     assert seen_many and seen_none
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The whole sequence behind ONE call of the C ABI (jl_xwin_phase_sharded): tables -> merge -> plan -> packed column
+# exchange -> grouping + export -> gather -> merge + selection -> per-read ids.
+
+def _one_rank_comm(ctx):
+    import ctypes as C
+    idbuf = np.zeros(128, dtype=np.uint8)
+    assert ctx.lib.jl_comm_unique_id(idbuf.ctypes.data_as(C.c_void_p)) == 0
+    comm = C.c_void_p()
+    ctx._chk(ctx.lib.jl_comm_create(ctx.h, idbuf.ctypes.data_as(C.c_void_p), 0, 1, C.byref(comm)))
+    return comm
+
+
+def _run_windows(rows, n, l, k_windows, genes, ref, whole_path=True):
+    wb = sharding.window_bounds(l, k_windows)
+    prm = capi.default_params(n_tests=sharding.default_n_tests(genes))
+    ctxs = []
+    for b, e in wb:
+        c = capi.Juliet(0)
+        c.upload_columns(msa.pack_columns(rows[:, b:e]), n, win_begin=b)
+        if whole_path:
+            c.run_async(genes, ref, prm, None, False, 10, False)     # call only: the table lands in the pinned result block
+        else:
+            c.pileup_async(genes, ref)
+            c.call_async(prm)
+        ctxs.append(c)
+    return ctxs, wb
+
+
+def assert_session(res, full, exp):
+    assert res["merged"].tobytes() == full.tobytes()
+    assert_same(res, exp, len(full))
+
+
+@pytest.mark.parametrize("n,k_windows,with_comm,whole_path", [(7000, 1, False, True), (7000, 3, False, True), (7000, 3, True, True),
+                                                                (7000, 8, False, False), (100_000, 4, True, True), (1000, 2, False, False)])
+def test_session_equals_unsharded(oracle, n, k_windows, with_comm, whole_path):
+    l = 900
+    sp = synth.SynthParams(seed=31 + n, minor_permille=(70, 60, 50, 40), partial_rate=0.15)
+    ref = synth.reference(sp.seed, l)
+    rows = synth.rows(sp, l, 0, n, ref)
+    genes = np.array([(1, l + 1)], dtype=capi.GENE)
+    rows[: n // 20, 700:703] = (rows[: n // 20, 700:703] + 1) % 4          # haplotypes that span windows
+    rows[n // 40: n // 16, 820:823] = (rows[n // 40: n // 16, 820:823] + 2) % 4
+    ctxs, wb = _run_windows(rows, n, l, k_windows, genes, ref, whole_path)
+    full = oracle.call(rows, genes, refseq=ref)
+    exp = oracle.phase(rows, full)
+    comm = _one_rank_comm(ctxs[0]) if with_comm else None
+    xw = capi.Xwin(ctxs, [b for b, _ in wb], [e - b for b, e in wb], [0] * k_windows, [0, n], comm)
+    try:
+        for _ in range(3):                       # a session is a step loop: the same answer every time
+            assert_session(xw.phase(10), full, exp)
+    finally:
+        xw.close()
+        if comm is not None:
+            ctxs[0].lib.jl_comm_destroy(comm)
+    for c in ctxs:
+        c.close()
+
+
+def test_session_many_positions_and_many_groups(oracle):
+    """More than ten positions (multi-word keys) and more groups than a block or the by-value table holds (1024): the
+    session grows its blocks and runs the step again; the haplotypes of the exported groups travel through HBM."""
+    n, l = 30000, 300
+    sp = synth.SynthParams(seed=77, minor_permille=(80, 70, 60, 50))
+    ref = synth.reference(sp.seed, l)
+    rows = synth.rows(sp, l, 0, n, ref)
+    rng = np.random.default_rng(5)
+    for k in range(13):                                                   # thirteen more edited codons, 35 % of the reads each
+        who = rng.choice(n, int(n * 0.35), replace=False)
+        c0 = 3 * (5 + 7 * k)
+        rows[who, c0:c0 + 3] = (rows[who, c0:c0 + 3] + 1 + k % 3) % 4
+    genes = np.array([(1, l + 1)], dtype=capi.GENE)
+    ctxs, wb = _run_windows(rows, n, l, 2, genes, ref)
+    full = oracle.call(rows, genes, refseq=ref)
+    exp = oracle.phase(rows, full)
+    assert exp["summary"]["n_positions"] > 10
+    for comm_on in (False, True):
+        comm = _one_rank_comm(ctxs[0]) if comm_on else None
+        xw = capi.Xwin(ctxs, [b for b, _ in wb], [e - b for b, e in wb], [0, 0], [0, n], comm)
+        res = xw.phase(10)
+        assert res["n_groups"] > 1024
+        assert_session(res, full, exp)
+        assert_session(xw.phase(10), full, exp)
+        xw.close()
+        if comm is not None:
+            ctxs[0].lib.jl_comm_destroy(comm)
+    for c in ctxs:
+        c.close()
+
+
+def test_session_without_variants_and_bad_layouts(oracle):
+    n, l = 3000, 120
+    ref = synth.reference(3, l)
+    rows = np.tile(ref, (n, 1)).astype(np.uint8)                           # not one variant
+    genes = np.array([(1, l + 1)], dtype=capi.GENE)
+    ctxs, wb = _run_windows(rows, n, l, 2, genes, ref)
+    xw = capi.Xwin(ctxs, [b for b, _ in wb], [e - b for b, e in wb], [0, 0], [0, n])
+    res = xw.phase(10)
+    assert len(res["merged"]) == 0 and res["summary"]["n_positions"] == 0 and (res["read_hap"] == capi.HAP_DAMAGED).all()
+    xw.close()
+    with pytest.raises(capi.JulietError):      # slices must cover the reads
+        capi.Xwin(ctxs, [b for b, _ in wb], [e - b for b, e in wb], [0, 0], [0, n - 1])
+    with pytest.raises(capi.JulietError):      # the layout must describe the contexts
+        capi.Xwin(ctxs, [0, 10], [e - b for b, e in wb], [0, 0], [0, n])
+    with pytest.raises(capi.JulietError):      # one rank, two windows: both are local
+        capi.Xwin(ctxs[:1], [b for b, _ in wb], [e - b for b, e in wb], [0, 0], [0, n])
+    for c in ctxs:
+        c.close()
+
+
+def test_session_refuses_a_busy_communicator(oracle):
+    """The cross-window calls issue their collectives from the calling thread: with an asynchronous exchange of the
+    communicator still uncollected they are refused (JL_ERR_STATE), and work again once it is collected."""
+    import ctypes as C
+    n, l = 4000, 300
+    sp = synth.SynthParams(seed=13, minor_permille=(70, 60, 50, 40))
+    ref = synth.reference(sp.seed, l)
+    rows = synth.rows(sp, l, 0, n, ref)
+    genes = np.array([(1, l + 1)], dtype=capi.GENE)
+    ctxs, wb = _run_windows(rows, n, l, 1, genes, ref)
+    win = ctxs[0]
+    comm = _one_rank_comm(win)
+    full = oracle.call(rows, genes, refseq=ref)
+    exp = oracle.phase(rows, full)
+    xw = capi.Xwin(ctxs, [0], [l], [0], [0, n], comm)
+    win._chk(win.lib.jl_allgather_variants_async(win.h, comm))             # requested, not collected
+    with pytest.raises(capi.JulietError) as e:
+        xw.phase(10)
+    assert e.value.status == -4 and "uncollected" in str(e.value)
+    pc = capi.Juliet(0)
+    with pytest.raises(capi.JulietError) as e:
+        pc.xwin_assemble_slice_rccl(win, comm, [0], [l], full, [0, n])
+    assert e.value.status == -4
+    rows_out = np.zeros(128, dtype=capi.VARIANT)
+    cnt = np.zeros(1, dtype=np.uint32)
+    win._chk(win.lib.jl_allgather_variants(win.h, comm, rows_out.ctypes.data_as(C.c_void_p), cnt.ctypes.data_as(C.c_void_p), 128))
+    assert int(cnt[0]) == len(full)
+    assert_session(xw.phase(10), full, exp)
+    pc.close()
+    xw.close()
+    win.lib.jl_comm_destroy(comm)
+    win.close()
+
+
+def test_allgather_groups_single_rank(oracle):
+    """jl_allgather_groups with a one-rank communicator: the exported groups come back as the fetch gives them."""
+    import ctypes as C
+    n, l = 5000, 300
+    sp = synth.SynthParams(seed=43, minor_permille=(70, 60, 50, 40), partial_rate=0.1)
+    ref = synth.reference(sp.seed, l)
+    rows = synth.rows(sp, l, 0, n, ref)
+    genes = np.array([(1, l + 1)], dtype=capi.GENE)
+    c = capi.Juliet(0)
+    c.upload_columns(msa.pack_columns(rows), n)
+    table = oracle.call(rows, genes, refseq=ref)
+    c.phase_groups_async(table)
+    t = c.phase_groups_fetch()
+    g, vp = len(t["counts"]), len(t["pos_cols"])
+    comm = _one_rank_comm(c)
+    cap, stride = 256, 16
+    pats = np.zeros((1, cap, stride), dtype=np.uint8)
+    cnts = np.zeros((1, cap), dtype=np.uint32)
+    ng = np.zeros(1, dtype=np.uint32)
+    parts = np.zeros(1, dtype=capi.SUMMARY)
+    npos = C.c_uint32()
+    c._chk(c.lib.jl_allgather_groups(c.h, comm, cap, stride, pats.ctypes.data_as(C.c_void_p), cnts.ctypes.data_as(C.c_void_p),
+                                     ng.ctypes.data_as(C.c_void_p), parts.ctypes.data_as(C.c_void_p), C.byref(npos)))
+    assert int(ng[0]) == g and npos.value == vp
+    assert (cnts[0, :g] == t["counts"]).all() and (pats[0, :g, :vp] == t["patterns"]).all()
+    assert int(parts[0]["damaged_reads"]) == t["summary"]["damaged_reads"]
+    with pytest.raises(capi.JulietError) as e:     # a block too small for the groups: loud, on every rank alike
+        c.lib.jl_allgather_groups.restype = C.c_int
+        c._chk(c.lib.jl_allgather_groups(c.h, comm, 2, stride, pats.ctypes.data_as(C.c_void_p), cnts.ctypes.data_as(C.c_void_p),
+                                         ng.ctypes.data_as(C.c_void_p), parts.ctypes.data_as(C.c_void_p), C.byref(npos)))
+    assert e.value.status == -5
+    # jl_phase_regroup answers for every exported group: a shorter table is refused
+    with pytest.raises(capi.JulietError) as e:
+        c.phase_regroup(np.zeros(g - 1, dtype=np.uint16), 1)
+    assert "exported" in str(e.value)
+    c.lib.jl_comm_destroy(comm)
+    c.close()

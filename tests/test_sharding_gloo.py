@@ -10,7 +10,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 import oracle_lib
-from minorseq_amd import capi, sharding, synth
+from minorseq_amd import capi, msa, sharding, synth
 
 
 def test_window_bounds_cover_every_codon_once():
@@ -171,12 +171,48 @@ def _slice_groups(compact):
     return dict(patterns=uniq[order], counts=counts[order].astype(np.uint32), summary=summary), dirty, group_of_clean
 
 
-def _sharded_phase_worker(rank, world, port, q):
-    """SURVEY §8e option A on CPU ranks: call per window (oracle), all-gather of the table (gloo), plan (product), the
-    owner of each position SCATTERS the slices of its three columns (gloo stands in for ncclSend / ncclRecv), every rank
-    groups its own slice of the reads, the group tables are all-gathered and merged, the haplotypes selected (product:
-    sharding.allgather_groups / merge_groups / select_haplotypes), and each rank maps its reads."""
+def _run_ops(ops, rank, packed_window, win_begin, pos, n_mine):
+    """Executes one rank's op list (jl_xwin_slice_plan) with gloo point-to-point calls IN LIST ORDER: what
+    jl_xwin_phase_sharded does with the pack kernel, ncclSend and ncclRecv.  `packed_window`: this rank's window in the
+    device layout (msa.pack_columns).  Returns the compact matrix of the rank's slice, by rows."""
     import torch
+    stride_me = msa.col_stride(n_mine) if n_mine else 0
+    compact = np.full(3 * len(pos) * stride_me, 0x66, dtype=np.uint8)
+    pending, keep = [], []
+
+    def message(op):   # slice [read_begin, +n_reads) of the 3 * k_count owned columns, each padded to dst_stride with 'not covered'
+        msg = np.full((3 * op["k_count"], op["dst_stride"]), 0x66, dtype=np.uint8)
+        b0, nb = op["read_begin"] // 2, (op["n_reads"] + 1) // 2
+        for i in range(op["k_count"]):
+            c = int(pos[op["k_begin"] + i]) - win_begin
+            msg[3 * i: 3 * i + 3, :nb] = packed_window[c: c + 3, b0: b0 + nb]
+        assert msg.size == op["bytes"]
+        return msg.reshape(-1)
+
+    for op in ops:
+        if op["op"] == capi.XWIN_OP_LOCAL:
+            compact[op["dst_offset"]: op["dst_offset"] + op["bytes"]] = message(op)
+        elif op["op"] == capi.XWIN_OP_SEND:
+            t = torch.from_numpy(message(op).copy())
+            keep.append(t)
+            pending.append((dist.isend(t, op["peer"]), None, None))
+        else:
+            t = torch.empty(op["bytes"], dtype=torch.uint8)
+            pending.append((dist.irecv(t, op["peer"]), t, op))
+    for req, t, op in pending:
+        req.wait()
+        if t is not None:
+            compact[op["dst_offset"]: op["dst_offset"] + op["bytes"]] = t.numpy()
+    if not n_mine:
+        return np.zeros((0, 3 * len(pos)), dtype=np.uint8)
+    return msa.unpack_columns(compact.reshape(3 * len(pos), stride_me), n_mine)
+
+
+def _sharded_phase_worker(rank, world, port, q):
+    """SURVEY §8e option A on CPU ranks: call per window (oracle), all-gather of the table (gloo), the product's schedule
+    of the column-slice exchange (jl_xwin_slice_plan) EXECUTED op by op over gloo send / recv, every rank groups its own
+    slice of the reads, the group tables are all-gathered and merged and the haplotypes selected by the product's C
+    functions (jl_merge_tables / jl_merge_groups / jl_select_haplotypes through sharding.py), and each rank maps its reads."""
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -189,40 +225,53 @@ def _sharded_phase_worker(rank, world, port, q):
         prm = oracle_lib.default_params(n_tests=sharding.default_n_tests(GENES))
         local = orc.call(mine, GENES, win_begin=b, refseq=ref, params=prm)
         merged = sharding.merge_tables(sharding.allgather_tables(local), [w[0] for w in wb])
-        remapped, pos, owner = capi.xwin_plan([w[0] for w in wb], [w[1] - w[0] for w in wb], merged)
+        wbeg, wnc = [w[0] for w in wb], [w[1] - w[0] for w in wb]
+        remapped, pos, owner = capi.xwin_plan(wbeg, wnc, merged)
         sb = sharding.read_slices(N, world)
-        assert sb[0] == 0 and sb[-1] == N and all(x % 256 == 0 for x in sb[:-1])
+        assert sb[0] == 0 and sb[-1] == N and all(sb[k] % 256 == 0 for k in range(world) if sb[k + 1] > sb[k])
         n_mine = sb[rank + 1] - sb[rank]
-        compact = np.empty((n_mine, 3 * len(pos)), dtype=np.uint8)
-        for k, (c, w) in enumerate(zip(pos, owner)):
-            recv = torch.zeros((n_mine, 3), dtype=torch.uint8)
-            parts = None
-            if w == rank:
-                parts = [torch.from_numpy(np.ascontiguousarray(mine[sb[s]:sb[s + 1], c - b: c - b + 3])) for s in range(world)]
-            # gloo's scatter wants equal shapes: pad every part to the longest slice
-            longest = max(sb[s + 1] - sb[s] for s in range(world))
-            buf = torch.zeros((longest, 3), dtype=torch.uint8)
-            if parts is not None:
-                parts = [torch.cat([p, torch.zeros((longest - len(p), 3), dtype=torch.uint8)]) for p in parts]
-            dist.scatter(buf, parts, src=int(w))
-            compact[:, 3 * k: 3 * k + 3] = buf[:n_mine].numpy()
+        ops = capi.xwin_slice_plan(wbeg, wnc, list(range(world)), merged, sb, world, rank)
+        compact = _run_ops(ops, rank, msa.pack_columns(mine), b, pos, n_mine)
         table, dirty, group_of_clean = _slice_groups(compact)
         tables = sharding.allgather_groups(table)
         patterns, counts, index = sharding.merge_groups(tables)
         ph = sharding.select_haplotypes(patterns, counts, remapped, 3 * np.arange(len(pos)), 10, [t["summary"] for t in tables])
         ids = np.full(n_mine, 0xFFFF, dtype=np.uint16)
         ids[~dirty] = ph["hap_of_merged"][index[rank]][group_of_clean].astype(np.uint16)
-        gathered = [None] * world
+        gathered, all_ops = [None] * world, [None] * world
         dist.all_gather_object(gathered, ids)
+        dist.all_gather_object(all_ops, ops)
         if rank == 0:
             q.put((ph["summary"], ph["hap_count"].tobytes(), ph["hap_pattern"].tobytes(), ph["hit"].tobytes(), ph["cooc"].tobytes(),
-                   np.concatenate(gathered).tobytes(), merged.tobytes()))
+                   np.concatenate(gathered).tobytes(), merged.tobytes(), all_ops, owner.tolist()))
         dist.barrier()
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
+def _check_pairing(all_ops, world):
+    """Every send has exactly one matching receive (same byte count) in the peer's list, at most one message per ordered
+    pair of ranks, and both sides meet their peers in ascending order — the order RCCL pairs point-to-point calls by."""
+    sends, recvs = {}, {}
+    for r, ops in enumerate(all_ops):
+        peers = [o["peer"] for o in ops if o["op"] != capi.XWIN_OP_LOCAL]
+        assert peers == sorted(peers)
+        assert sum(1 for o in ops if o["op"] == capi.XWIN_OP_LOCAL) <= 1
+        for o in ops:
+            if o["op"] == capi.XWIN_OP_SEND:
+                assert (r, o["peer"]) not in sends
+                sends[(r, o["peer"])] = o
+            elif o["op"] == capi.XWIN_OP_RECV:
+                assert (o["peer"], r) not in recvs
+                recvs[(o["peer"], r)] = o
+    assert sorted(sends) == sorted(recvs)
+    for key, snd in sends.items():
+        rcv = recvs[key]
+        assert all(snd[f] == rcv[f] for f in ("bytes", "k_begin", "k_count", "read_begin", "n_reads", "dst_stride", "dst_offset"))
+    return len(sends)
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_phasing_sharded_by_reads_over_gloo(world, oracle):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -230,9 +279,9 @@ def test_phasing_sharded_by_reads_over_gloo(world, oracle):
     procs = [ctx.Process(target=_sharded_phase_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    summary, hc, hp, hit, cooc, rh, merged_b = q.get(timeout=180)
+    summary, hc, hp, hit, cooc, rh, merged_b, all_ops, owner = q.get(timeout=300)
     for p in procs:
-        p.join(timeout=60)
+        p.join(timeout=120)
         assert p.exitcode == 0
     ref, rows = _data()
     full = oracle.call(rows, GENES, refseq=ref)
@@ -245,6 +294,13 @@ def test_phasing_sharded_by_reads_over_gloo(world, oracle):
     assert (np.frombuffer(hit, dtype=np.uint8).reshape(nv, h) == exp["hit"]).all()
     assert (np.frombuffer(cooc, dtype=np.uint32).reshape(nv, nv) == exp["cooc"]).all()
     assert (np.frombuffer(rh, dtype=np.uint16) == exp["read_hap"]).all()
+    # the schedule: owners with positions send to every peer that has reads, nothing else travels
+    n_msgs = _check_pairing(all_ops, world)
+    owners = set(owner)
+    sb = sharding.read_slices(N, world)
+    readers = {s for s in range(world) if sb[s + 1] > sb[s]}
+    assert n_msgs == sum(1 for o in owners for s in readers if s != o)
+    assert len(owners) >= 2
 
 
 def test_read_slices_and_group_merge_edge_cases():
