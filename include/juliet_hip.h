@@ -511,6 +511,11 @@ int jl_xwin_create(jl_ctx *const *windows, uint32_t n_local, jl_comm *comm, cons
 void jl_xwin_destroy(jl_xwin *x);
 const char *jl_xwin_last_error(const jl_xwin *x);
 int jl_xwin_phase_sharded(jl_xwin *x, uint32_t min_reads, jl_xwin_result *out);
+/* Host time of the last jl_xwin_phase_sharded by stage, in microseconds (out[JL_XWIN_STAGES]): 0 the windows' tables on
+ * the host (waits for their call stage), 1 all-gather + merge of the tables, 2 plan, 3 pack + exchange + grouping
+ * enqueued, 4 waiting for the groups (and their all-gather), 5 merge + selection, 6 per-read ids. */
+enum { JL_XWIN_STAGES = 8 };
+int jl_xwin_stage_us(const jl_xwin *x, float *out);
 /* 16-bit ids of this rank's slice (read_hap[slice_reads]) of the last jl_xwin_phase_sharded. */
 int jl_xwin_read_hap_fetch(jl_xwin *x, uint16_t *read_hap);
 /* The collective on its own, for hosts that drive the stages themselves: fixed-stride all-gather over RCCL of the

@@ -38,7 +38,7 @@ EXPORTS = ("jl_abi_version", "jl_strerror", "jl_device_count", "jl_ctx_create", 
            "jl_xwin_assemble_rccl", "jl_xwin_assemble_slice_local", "jl_xwin_assemble_slice_rccl", "jl_phase_groups_async",
            "jl_phase_groups_fetch", "jl_phase_regroup", "jl_merge_tables", "jl_merge_groups", "jl_select_haplotypes",
            "jl_xwin_slice_plan", "jl_xwin_create", "jl_xwin_destroy", "jl_xwin_last_error", "jl_xwin_phase_sharded",
-           "jl_xwin_read_hap_fetch", "jl_allgather_groups")
+           "jl_xwin_read_hap_fetch", "jl_xwin_stage_us", "jl_allgather_groups")
 
 
 class ErrorModel(C.Structure):
@@ -225,6 +225,7 @@ def load_library(path=LIB_PATH):
     lib.jl_xwin_last_error.restype = C.c_char_p
     lib.jl_xwin_phase_sharded.argtypes = [vp, u32, C.POINTER(XwinResult)]
     lib.jl_xwin_read_hap_fetch.argtypes = [vp, vp]
+    lib.jl_xwin_stage_us.argtypes = [vp, vp]
     lib.jl_allgather_groups.argtypes = [vp, vp, u32, u32, vp, vp, vp, vp, C.POINTER(u32)]
     if lib.jl_abi_version() != 4:
         raise ImportError("libjuliet_hip.so ABI version mismatch")
@@ -837,6 +838,15 @@ class Xwin:
         if want_reads:
             out["read_hap"] = self.read_hap()
         return out
+
+    STAGES = ("tables on the host", "gather + merge of the tables", "plan", "pack + exchange + grouping enqueued", "wait for the groups",
+              "merge + selection", "per-read ids")
+
+    def stage_us(self):
+        """Host microseconds of the last phase call by stage (jl_xwin_stage_us)."""
+        out = np.zeros(8, dtype=np.float32)
+        self.lib.jl_xwin_stage_us(self.h, _p(out))
+        return dict(zip(self.STAGES, out.tolist()))
 
     def read_hap(self):
         n = int(self._res.slice_reads)

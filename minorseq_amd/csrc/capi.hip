@@ -152,7 +152,7 @@ void jl_ctx_destroy(jl_ctx *ctx)
                     ctx->d_slot_rep, ctx->d_slot_count, ctx->d_slot_key, ctx->d_slot_hap, ctx->d_occupied, ctx->d_hap_count,
                     ctx->d_hap_pattern, ctx->d_hit, ctx->d_cooc, ctx->d_pack, ctx->d_sync, ctx->d_timeline,
                     ctx->d_col_first, ctx->d_pos_next, ctx->d_callinfo, ctx->d_ins_len, ctx->d_ins_base, ctx->d_exp_count,
-                    ctx->d_exp_pattern, ctx->d_exp_hap};
+                    ctx->d_exp_pattern, ctx->d_exp_hap, ctx->d_blockcat};
     for (void *p : ptrs)
         if (p) hipFree(p);
     if (ctx->ev0) hipEventDestroy(ctx->ev0);
@@ -873,6 +873,7 @@ static int reserve_phase(jl_ctx *ctx, uint32_t kwords_needed)
         while (slots < 2 * (uint64_t)ctx->n_reads) slots <<= 1;
         ctx->table_slots = slots;
         if ((rc = regrow(ctx, &ctx->d_flagw, reads_pad / 8))) return rc;
+        if ((rc = regrow(ctx, &ctx->d_blockcat, (reads_pad / 2048u + 2u) * 4u))) return rc;
         if ((rc = regrow(ctx, &ctx->d_read_slot, reads_pad))) return rc;
         if ((rc = regrow(ctx, &ctx->d_read_hap, reads_pad))) return rc;
         if ((rc = regrow(ctx, &ctx->d_occupied, reads_pad))) return rc;
@@ -901,7 +902,7 @@ static int reserve_phase(jl_ctx *ctx, uint32_t kwords_needed)
 // as many groups as the table can hold, within 256 MB
 static int reserve_export(jl_ctx *ctx, uint32_t kwords)
 {
-    const uint32_t stride = kwords * JL_POS_PER_WORD;
+    const uint32_t stride = (kwords * JL_POS_PER_WORD + 7u) / 8u * 8u;   // rows are written 8 bytes at a time
     uint64_t cap = ctx->table_slots ? ctx->table_slots : 1024;
     const uint64_t budget = ((uint64_t)256 << 20) / stride;
     if (cap > budget) cap = budget;
@@ -1247,8 +1248,10 @@ static void enqueue_path(jl_ctx *ctx, const jl_params *prm, double n_tests, bool
     // that stage's kernel is what pushes the results every compute die wrote for the host out of the dies' L2s.
     bool signaled = false;
     if (!phasing) {
-        jl_launch_compact(ctx, st, false, true, JL_SIGNAL_IN_KERNEL != 0);
-        signaled = JL_SIGNAL_IN_KERNEL != 0;
+        // ONE workgroup compacts the table and writes the result block: it stores the completion word itself, behind its own
+        // drained stores and a system-scope fence (no other die has written anything the host reads)
+        jl_launch_compact(ctx, st, false, true, true);
+        signaled = true;
     } else if (ctx->phase_generic) {
         jl_launch_compact(ctx, st, true, false, false);
         jl_launch_stamp(ctx, 2);

@@ -16,6 +16,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <new>
 #include <string>
 #include <vector>
@@ -107,7 +108,8 @@ int xw_pack(jl_ctx *pc, jl_ctx *const *wins, const xw_layout &lay, const xwin_sc
         }
     }
     if (!plan_done) jl_launch_xw_pack(plan, pc->stream);   // nothing to pack on this rank: the plan alone
-    if (hipGetLastError() != hipSuccess) return xw_fail(pc, err, JL_ERR_DEVICE, "pack launch of the column exchange failed");
+    const hipError_t le = hipGetLastError();
+    if (le != hipSuccess) return xw_fail(pc, err, JL_ERR_DEVICE, std::string("pack launch of the column exchange: ") + hipGetErrorString(le));
     return JL_OK;
 }
 
@@ -331,15 +333,12 @@ int jl_xwin_assemble_slice_rccl(jl_ctx *pc, jl_ctx *window, jl_comm *c, const ui
     JL_HIP(pc, hipStreamSynchronize(window->stream));
     xw_send_buf send;
     jl_ctx *wins[1] = {window};
+    // the communicator is taken whatever its size: the call is refused alike on one rank and on eight
+    if (jl_comm_direct_begin(c) != JL_OK)
+        return jl_fail(pc, JL_ERR_STATE, "the communicator has asynchronous exchanges queued or uncollected: collect them first");
     rc = xw_pack(pc, wins, lay, sch, slice_begin, world, me, nullptr, &send, nullptr, nullptr);
-    if (rc == JL_OK && world > 1) {
-        if (jl_comm_direct_begin(c) != JL_OK)
-            rc = jl_fail(pc, JL_ERR_STATE, "the communicator has asynchronous exchanges queued or uncollected: collect them first");
-        else {
-            rc = xw_send_recv(pc, c, sch, slice_begin, send, nullptr);
-            jl_comm_direct_end(c);
-        }
-    }
+    if (rc == JL_OK && world > 1) rc = xw_send_recv(pc, c, sch, slice_begin, send, nullptr);
+    jl_comm_direct_end(c);
     const hipError_t e = hipStreamSynchronize(pc->stream);
     if (send.d) hipFree(send.d);
     if (rc) return rc;
@@ -389,6 +388,7 @@ struct jl_xwin {
     jl_phase_summary summary{};
     uint32_t n_haplotypes = 0, n_merged_groups = 0, my_groups = 0, bits = 4;
     bool ids_on_device = false;
+    float stage_us[JL_XWIN_STAGES] = {};   // host time of the last call, by stage (jl_xwin_stage_us)
 };
 
 namespace {
@@ -602,6 +602,13 @@ int jl_xwin_phase_sharded(jl_xwin *x, uint32_t min_reads, jl_xwin_result *out)
     const int world = x->world, me = x->rank;
     // with a communicator every collective is issued, also when it has one rank (all but the wire, on one GPU)
     const bool collective = x->comm != nullptr;
+    auto t_prev = std::chrono::steady_clock::now();
+    memset(x->stage_us, 0, sizeof x->stage_us);
+    auto lap = [&](int stage) {
+        const auto t = std::chrono::steady_clock::now();
+        x->stage_us[stage] += std::chrono::duration<float, std::micro>(t - t_prev).count();
+        t_prev = t;
+    };
 
     // ---- 1. this rank's tables: in pinned memory already when the windows ran through jl_run_async / a group run
     std::vector<const jl_variant *> rows(x->wins.size());
@@ -609,6 +616,7 @@ int jl_xwin_phase_sharded(jl_xwin *x, uint32_t min_reads, jl_xwin_result *out)
     for (size_t w = 0; w < x->wins.size(); ++w)
         if (int rc = jl_ctx_table_host(x->wins[w], &x->scratch[w], &rows[w], &counts[w])) return xs_fail_ctx(x, rc, x->wins[w]);
 
+    lap(0);
     struct guard_t {   // the communicator is this thread's for the rest of the call
         jl_comm *c;
         ~guard_t() { if (c) jl_comm_direct_end(c); }
@@ -633,6 +641,7 @@ int jl_xwin_phase_sharded(jl_xwin *x, uint32_t min_reads, jl_xwin_result *out)
         return rc;
     }
     const uint32_t n_var = (uint32_t)x->merged.size();
+    lap(1);
 
     // ---- 3. plan: positions, owners, the exchange
     x->remapped.resize(n_var ? n_var : 1);
@@ -654,6 +663,7 @@ int jl_xwin_phase_sharded(jl_xwin *x, uint32_t min_reads, jl_xwin_result *out)
     x->n_haplotypes = 0;
     x->bits = 4;
     memset(&x->summary, 0, sizeof x->summary);
+    lap(2);
     if (vp == 0) {   // nothing to phase (every rank sees the same table and leaves here together)
         out->read_hap_bits = 4;
         return JL_OK;
@@ -661,7 +671,7 @@ int jl_xwin_phase_sharded(jl_xwin *x, uint32_t min_reads, jl_xwin_result *out)
 
     // ---- 4 + 5. column slices into the compact matrix, keys + grouping, the groups exported
     const uint32_t kwords = (vp + JL_POS_PER_WORD - 1) / JL_POS_PER_WORD;
-    if ((rc = xs_reserve_blocks(x, std::max<uint32_t>(JL_XW_GCAP0, x->gcap), kwords * JL_POS_PER_WORD))) return rc;
+    if ((rc = xs_reserve_blocks(x, std::max<uint32_t>(JL_XW_GCAP0, x->gcap), (kwords * JL_POS_PER_WORD + 7u) / 8u * 8u))) return rc;
     for (int attempt = 0;; ++attempt) {
         uint8_t *blk_dev = collective ? x->d_blk_send : x->h_blk;   // where THIS rank's kernels write its block
         if (x->n_mine) {
@@ -683,6 +693,7 @@ int jl_xwin_phase_sharded(jl_xwin *x, uint32_t min_reads, jl_xwin_result *out)
                           x->n_mine ? &plan : nullptr, &x->err)))
             return rc;
         if (world > 1 && (rc = xw_send_recv(pc, x->comm, x->sch, x->slice_begin.data(), x->send, &x->err))) return rc;
+        lap(3);
         if (x->n_mine) {
             // the selection of this launch ends a "run" of pc when nothing else follows on the device (no gather): its
             // last workgroup stores the completion word behind the exported block
@@ -703,6 +714,7 @@ int jl_xwin_phase_sharded(jl_xwin *x, uint32_t min_reads, jl_xwin_result *out)
                 return xs_fail(x, JL_ERR_COMM, "all-gather of the group tables");
             if ((rc = xs_fetch_and_wait(x, x->d_blk_recv, x->h_blk, x->blk * (size_t)world))) return rc;
         }
+        lap(4);
         uint32_t most = 0;
         bool ovf = false;
         for (int r = 0; r < world; ++r) {
@@ -764,6 +776,7 @@ int jl_xwin_phase_sharded(jl_xwin *x, uint32_t min_reads, jl_xwin_result *out)
     }
     x->bits = H <= JL_ID4_MAX_H ? 4u : (H <= JL_ID8_MAX_H ? 8u : 16u);
 
+    lap(5);
     // ---- 7. the merge's answer back to the device: per-read ids of this rank's slice (they stay in HBM)
     if (x->n_mine) {
         x->tab.resize(std::max<uint32_t>(1, x->my_groups));
@@ -797,6 +810,7 @@ int jl_xwin_phase_sharded(jl_xwin *x, uint32_t min_reads, jl_xwin_result *out)
         if (jl_run_wait_seq(pc, pc->runs_launched)) return xs_fail_ctx(x, JL_ERR_DEVICE, pc);
         x->ids_on_device = true;
     }
+    lap(6);
 
     out->n_haplotypes = H;
     out->n_groups = m;
@@ -806,6 +820,13 @@ int jl_xwin_phase_sharded(jl_xwin *x, uint32_t min_reads, jl_xwin_result *out)
     out->hit = x->hit.data();
     out->cooc = x->cooc.data();
     out->read_hap_bits = x->bits;
+    return JL_OK;
+}
+
+int jl_xwin_stage_us(const jl_xwin *x, float *out)
+{
+    if (!x || !out) return JL_ERR_ARG;
+    memcpy(out, x->stage_us, sizeof x->stage_us);
     return JL_OK;
 }
 

@@ -218,6 +218,7 @@ struct jl_win_phase {
     uint64_t slots_mask;
     unsigned long long *slot_key;
     uint32_t *slot_rep, *slot_count, *occupied, *read_slot;
+    uint32_t *blockcat;
     jl_select_args S;
     uint32_t n_blocks, pad_;
 };
@@ -369,6 +370,7 @@ struct jl_ctx {
     uint32_t keys_words = 0;        // 64-bit words per read the key buffer holds
     uint32_t last_min_reads = 10;
     uint32_t *d_flagw = nullptr;    // [reads_pad/8] nibble flags
+    uint32_t *d_blockcat = nullptr; // [phase workgroups][4] read categories of each workgroup's reads (summed by the selection)
     uint32_t *d_read_slot = nullptr;  // [reads_pad]
     uint16_t *d_read_hap = nullptr;   // [reads_pad]
     uint32_t *d_slot_rep = nullptr, *d_slot_count = nullptr;  // [M]

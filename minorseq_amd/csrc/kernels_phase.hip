@@ -265,9 +265,25 @@ __device__ __forceinline__ void phase_select_block(uint32_t min_reads, uint64_t 
             __hip_atomic_store(&slot_hap[s], q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (q < exp_cap) {
                 exp_count[q] = c;
+                // the group's key words once each, its row of codon codes stored 8 bytes at a time (exp_stride is a multiple
+                // of 8: the rows may lie in pinned host memory, where every store is a transaction of its own)
                 const uint32_t rep = BYKEY ? s : ld_coherent(&slot_rep[s]);
-                for (uint32_t p = 0; p < vp; ++p)
-                    exp_pattern[(uint64_t)q * exp_stride + p] = (uint8_t)pattern_code<BYKEY>(keys, slot_key, reads_pad, vp, rep, p);
+                uint64_t word = 0;
+                uint32_t have = 0xFFFFFFFFu;
+                for (uint32_t p8 = 0; p8 < vp; p8 += 8u) {
+                    unsigned long long out = 0;
+                    for (uint32_t j = 0; j < 8u && p8 + j < vp; ++j) {
+                        const uint32_t p = p8 + j, g = p / JL_POS_PER_WORD;
+                        if (g != have) {
+                            word = BYKEY ? (uint64_t)ld_coherent64(&slot_key[s]) : keys[(uint64_t)g * reads_pad + rep];
+                            have = g;
+                        }
+                        const uint32_t in_word = min(JL_POS_PER_WORD, vp - g * JL_POS_PER_WORD);
+                        const uint32_t sh = 6u * (in_word - 1u - (p - g * JL_POS_PER_WORD));
+                        out |= (unsigned long long)((word >> sh) & 63u) << (8u * j);
+                    }
+                    *reinterpret_cast<unsigned long long *>(exp_pattern + (uint64_t)q * exp_stride + p8) = out;
+                }
             }
         }
         __syncthreads();
@@ -737,9 +753,11 @@ __device__ __forceinline__ uint32_t global_insert64(uint64_t key, uint32_t cnt, 
 {
     uint64_t s = mix64(key + 0x9E3779B97F4A7C15ull) & slots_mask;
     for (;;) {
-        // one round trip: the CAS returns the resident key whether or not it installs ours (a block calls
-        // this once per distinct key, so the hot slot sees one CAS per 2048 reads)
-        unsigned long long old = atomicCAS(&slot_key[s], (unsigned long long)kNoKey, (unsigned long long)key);
+        // Look first: a slot's key never changes within a run, so a resident key read past the L1 is final and needs no
+        // atomic.  Same-address atomics serialise at the memory side (about 12 ns each): with one CAS per workgroup on
+        // the wild type's slot a million reads queued 500 of them in front of every workgroup's arrival.
+        unsigned long long old = ld_coherent64(&slot_key[s]);
+        if (old == kNoKey) old = atomicCAS(&slot_key[s], (unsigned long long)kNoKey, (unsigned long long)key);
         if (old == kNoKey) {
             // write-through stores: the selection may run in another workgroup of this launch
             __hip_atomic_store(&slot_rep[s], first, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // any read carrying the key
@@ -967,11 +985,10 @@ __device__ __forceinline__ void phase_fused1_body(const jl_win_phase &w)
                                          occupied, meta);
     if (tid == 0 && s_domcnt)
         s_domslot = global_insert64(dom, s_domcnt, s_domfirst, slots_mask, slot_key, slot_rep, slot_count, occupied, meta);
-    if (tid >= 64u && tid < 68u && s_cat[tid - 64u]) {  // a lane of another wave than the inserting one
-        uint32_t *dst = tid == 64u ? &meta->summary.damaged_reads : tid == 65u ? &meta->summary.marginal_gap
-                      : tid == 66u ? &meta->summary.marginal_heteroduplex : &meta->summary.marginal_partial;
-        atomicAdd(dst, s_cat[tid - 64u]);
-    }
+    // read categories of this workgroup's reads: written through to its own four words; the selection adds the workgroups
+    // up (four atomics per workgroup on ONE cache line were the longest queue of the launch at a million reads)
+    if (tid >= 64u && tid < 68u)  // a lane of another wave than the inserting one
+        __hip_atomic_store(&w.blockcat[blockIdx.x * 4u + (tid - 64u)], s_cat[tid - 64u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
@@ -1010,8 +1027,35 @@ __device__ __forceinline__ void phase_fused1_body(const jl_win_phase &w)
     const bool last = s_last != 0;
     if (!last && !S.fold) return;
     if (last) {
-        uint32_t nv = from_called ? (n_rows < S.cap ? n_rows : S.cap) : ld_coherent(&meta->n_var);
-        if (!from_called) n_rows = ld_coherent(&S.n_rows[0]);
+        uint32_t nv = 0;
+        if (!S.exp_count) {   // (an exporting selection needs neither: it ranks nothing)
+            nv = from_called ? (n_rows < S.cap ? n_rows : S.cap) : ld_coherent(&meta->n_var);
+            if (!from_called) n_rows = ld_coherent(&S.n_rows[0]);
+        }
+        if (work) {   // the read categories: every workgroup's four words, summed here
+            uint32_t c4[4] = {0, 0, 0, 0};
+            for (uint32_t b = tid; b < w.n_blocks; b += 256u) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) c4[k] += ld_coherent(&w.blockcat[b * 4u + k]);   // written through by their workgroups
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) c4[k] = wave_sum_all(c4[k]);
+            if (tid < 4u) s_cat[tid] = 0;
+            __syncthreads();
+            if ((tid & 63u) == 0) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) atomicAdd(&s_cat[k], c4[k]);
+            }
+            __syncthreads();
+            if (tid == 0) {
+                __hip_atomic_store(&meta->summary.damaged_reads, s_cat[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&meta->summary.marginal_gap, s_cat[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&meta->summary.marginal_heteroduplex, s_cat[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&meta->summary.marginal_partial, s_cat[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
         bool done = false;
         if (work && !S.exp_count) done = phase_select_lds(w, s_plan, vp, nv, n_rows, *reinterpret_cast<sel_lds *>(s_tables));
         if (!done) {
@@ -1170,6 +1214,7 @@ bool jl_fill_win_phase(jl_ctx *ctx, uint32_t min_reads, bool signal, uint32_t fo
     w->slots_mask = ctx->table_slots - 1u; w->slot_key = (unsigned long long *)ctx->d_slot_key;
     w->slot_rep = ctx->d_slot_rep; w->slot_count = ctx->d_slot_count; w->occupied = ctx->d_occupied;
     w->read_slot = ctx->d_read_slot;
+    w->blockcat = ctx->d_blockcat;
     w->n_blocks = fblocks;
     select_args &S = w->S;
     S.run = generic ? 0u : 1u;

@@ -89,13 +89,16 @@ __device__ __forceinline__ void xw_assign_body(const jl_xw_assign_args &a, const
     }
 }
 
+// `host_stores`: this launch wrote host memory (every workgroup releases it at system scope before it arrives, so that the
+// word cannot overtake another die's stores); ids that stay in HBM need none of that — the next kernel on the stream sees them
+template <bool HOST_STORES>
 __device__ __forceinline__ void xw_arrive_and_signal(uint32_t *arrive, uint32_t *seq_dev, volatile uint32_t *seq_host)
 {
     if (!seq_host) return;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
-        __threadfence_system();   // this workgroup's stores leave its die's L2 before it arrives
+        if (HOST_STORES) __threadfence_system();   // this workgroup's stores leave its die's L2 before it arrives
         const uint32_t prev = __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (prev == gridDim.x - 1u) {
             __hip_atomic_store(arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -110,20 +113,20 @@ __global__ __launch_bounds__(256) void xwin_assign_val_kernel(jl_xw_assign_args 
     for (uint32_t q = threadIdx.x; q < a.n_groups; q += 256u) s_tab[q] = tab.h[q];
     __syncthreads();
     xw_assign_body<true>(a, s_tab);
-    xw_arrive_and_signal(a.arrive, a.seq_dev, a.seq_host);
+    xw_arrive_and_signal<false>(a.arrive, a.seq_dev, a.seq_host);
 }
 
 __global__ __launch_bounds__(256) void xwin_assign_ptr_kernel(jl_xw_assign_args a, const uint16_t *__restrict__ tab)
 {
     xw_assign_body<false>(a, tab);
-    xw_arrive_and_signal(a.arrive, a.seq_dev, a.seq_host);
+    xw_arrive_and_signal<false>(a.arrive, a.seq_dev, a.seq_host);
 }
 
 __global__ __launch_bounds__(256) void xwin_fetch_kernel(const uint4 *__restrict__ src, uint4 *__restrict__ dst, uint64_t n16,
                                                           uint32_t *arrive, uint32_t *seq_dev, volatile uint32_t *seq_host)
 {
     for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < n16; i += (uint64_t)gridDim.x * 256u) dst[i] = src[i];
-    xw_arrive_and_signal(arrive, seq_dev, seq_host);
+    xw_arrive_and_signal<true>(arrive, seq_dev, seq_host);
 }
 
 }  // namespace

@@ -1,4 +1,7 @@
-"""configs[3] whole on one GPU through the reads-sharded phasing path (bench.py config3_strong at world 1): stage times."""
+"""configs[3] whole on one GPU through the session (bench.py config3_strong at world 1): host time by stage
+(jl_xwin_stage_us) next to the step and the pileup kernel.  `python tools_tuning/config3_sharded_stages.py [comm]`:
+with `comm` the session gets a one-rank communicator, i.e. every collective is issued (all but the wire)."""
+import ctypes as C
 import os
 import sys
 import time
@@ -17,46 +20,39 @@ win = capi.Juliet(0)
 win.alloc(n, l, win_begin=0)
 win.synth_fill_window(sp, ref)
 win.sync()
-pc = capi.Juliet(0)
-T = {}
-
-
-def lap(name, t0):
-    t1 = time.perf_counter()
-    T[name] = T.get(name, 0.0) + (t1 - t0)
-    return t1
+comm = None
+if len(sys.argv) > 1 and sys.argv[1] == "comm":
+    idbuf = np.zeros(128, dtype=np.uint8)
+    assert win.lib.jl_comm_unique_id(idbuf.ctypes.data_as(C.c_void_p)) == 0
+    comm = C.c_void_p()
+    win._chk(win.lib.jl_comm_create(win.h, idbuf.ctypes.data_as(C.c_void_p), 0, 1, C.byref(comm)))
+xw = capi.Xwin([win], [0], [l], [0], [0, n], comm)
+T, t_run = {}, 0.0
 
 
 def step():
-    t = time.perf_counter()
+    global t_run
+    t0 = time.perf_counter()
     win.run_async(genes, ref, prm, None, False, 10, False)
-    v = win.run_fetch(False, False)["variants"]
-    t = lap("pileup + call + fetch", t)
-    merged = sharding.merge_tables([v], [0])
-    t = lap("merge_tables", t)
-    remapped, pos_global = pc.xwin_assemble_slice_local([win], merged, 0, n)
-    t = lap("assemble slice", t)
-    pc.phase_groups_async(remapped)
-    t = lap("groups_async (enqueue)", t)
-    mine = pc.phase_groups_fetch()
-    t = lap("groups_fetch", t)
-    patterns, gcounts, index = sharding.merge_groups([mine])
-    t = lap("merge_groups (numpy)", t)
-    ph = sharding.select_haplotypes(patterns, gcounts, remapped, mine["pos_cols"], 10, [mine["summary"]])
-    t = lap("select_haplotypes (numpy)", t)
-    pc.phase_regroup(ph["hap_of_merged"][index[0]].astype(np.uint16), ph["summary"]["n_haplotypes"], False)
-    t = lap("regroup", t)
-    return mine, ph
+    t_run += time.perf_counter() - t0
+    r = xw.phase_raw(10)
+    for k, v in xw.stage_us().items():
+        T[k] = T.get(k, 0.0) + v
+    return r
 
 
 for _ in range(4):
-    mine, ph = step()
+    step()
 T.clear()
+t_run = 0.0
 R = 20
 t0 = time.perf_counter()
 for _ in range(R):
-    step()
+    r = step()
 tt = (time.perf_counter() - t0) / R
+t_k = win.time_pileup(reps=5)
+print(f"{'jl_run_async (enqueue)':40s} {t_run / R * 1e6:8.1f} us")
 for k, v in T.items():
-    print(f"{k:36s} {v / R * 1e3:8.3f} ms")
-print(f"{'step':36s} {tt * 1e3:8.3f} ms; groups {len(mine['counts'])}, haplotypes {ph['summary']['n_haplotypes']}")
+    print(f"{k:40s} {v / R:8.1f} us")
+print(f"{'step':40s} {tt * 1e6:8.1f} us; pileup kernel {t_k * 1e3:.1f} us; residue {tt * 1e6 - t_k * 1e3:.1f} us; "
+      f"groups {r.n_groups}, haplotypes {r.n_haplotypes}, communicator {'yes' if comm else 'no'}")
