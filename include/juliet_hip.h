@@ -485,8 +485,8 @@ int jl_xwin_slice_plan(const uint32_t *win_begin, const uint32_t *win_ncols, con
  *   one packed send per peer of the variant columns' slices (RCCL; a device copy for the own slice)  ->
  *   keys + grouping of the slice on the device, the groups exported  ->  all-gather of the group tables (RCCL) ->
  *   merge + selection on the host (jl_merge_groups, jl_select_haplotypes)  ->  per-read ids of the slice on the device.
- * The result's pointers are into the session and stay valid until the next call; the per-read ids stay in HBM until
- * jl_xwin_read_hap_fetch.  While the call runs the communicator must have no asynchronous exchange pending
+ * The result's pointers are into the session and stay valid until the next call; the per-read ids stay in HBM — their
+ * launch is enqueued when the call returns, not awaited — until jl_xwin_read_hap_fetch (which waits for it).  While the call runs the communicator must have no asynchronous exchange pending
  * (JL_ERR_STATE otherwise): the session issues its collectives from the calling thread. */
 typedef struct jl_xwin jl_xwin;
 typedef struct {

@@ -949,6 +949,7 @@ static int phase_async_impl(jl_ctx *ctx, const jl_variant *variants, uint32_t n_
     if (rc) return rc;
     if (exporting && (rc = reserve_export(ctx, kwords))) return rc;
     ctx->phase_export = exporting;
+    ctx->direct.on = 0;
     ctx->exp_known = false;
     ctx->exp_ext_count = nullptr; ctx->exp_ext_pattern = nullptr; ctx->exp_ext_head = nullptr;
     ctx->exp_ext_cap = ctx->exp_ext_stride = 0;
@@ -1182,6 +1183,7 @@ int jl_phase_groups_prepare(jl_ctx *ctx, uint32_t vp)
     if (kwords == 0) kwords = 1;
     if ((rc = reserve_phase(ctx, kwords))) return rc;
     ctx->phase_generic = vp > JL_POS_PER_WORD;
+    ctx->direct.on = 0;
     ctx->phase_export = true;
     ctx->exp_known = false;
     ctx->last_min_reads = 0xFFFFFFFFu;
@@ -1272,6 +1274,7 @@ int jl_run_prepare(jl_ctx *ctx, const jl_gene *genes, uint32_t n_genes, const ui
     if (!ctx || !prm || (!genes && n_genes)) return JL_ERR_ARG;
     if (!ctx->d_msa) return jl_fail(ctx, JL_ERR_STATE, "no resident matrix: call jl_msa_upload/alloc/adopt first");
     ctx->phase_export = false;
+    ctx->direct.on = 0;
     if (prm->tail != 0 && prm->tail != 1) return jl_fail(ctx, JL_ERR_ARG, "tail must be 0 (one-sided greater) or 1 (two-sided)");
     if (!(prm->alpha > 0.0) || !(prm->err.match > 0.0) || !(prm->err.substitution >= 0.0))
         return jl_fail(ctx, JL_ERR_ARG, "alpha/match must be > 0 and substitution >= 0");

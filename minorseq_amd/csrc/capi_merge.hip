@@ -47,22 +47,41 @@ int jl_merge_groups(const uint8_t *const *patterns, const uint32_t *pattern_stri
                     uint32_t cap, uint32_t *n_merged, uint32_t *const *index)
 {
     if (!n_merged || ((!patterns || !pattern_stride || !counts || !n_groups) && n_tables)) return JL_ERR_ARG;
-    struct ref_t { uint32_t t, q; };
-    std::vector<ref_t> all;
+    size_t total = 0;
     for (uint32_t t = 0; t < n_tables; ++t) {
         if (n_groups[t] && (!counts[t] || (vp && (!patterns[t] || pattern_stride[t] < vp)))) return JL_ERR_ARG;
-        for (uint32_t q = 0; q < n_groups[t]; ++q) all.push_back({t, q});
+        total += n_groups[t];
     }
+    // A group = (pattern, table, row).  Patterns of up to eight positions compare as ONE big-endian 64-bit word (codon
+    // codes are bytes, so word order is position-by-position order); longer ones by memcmp.
+    struct ref_t { uint64_t key; uint32_t t, q; };
+    std::vector<ref_t> all;
+    all.reserve(total);
+    const bool by_word = vp <= 8u;
+    for (uint32_t t = 0; t < n_tables; ++t)
+        for (uint32_t q = 0; q < n_groups[t]; ++q) {
+            uint64_t k = 0;
+            if (by_word) {
+                const uint8_t *p = patterns[t] + (size_t)q * pattern_stride[t];
+                for (uint32_t j = 0; j < vp; ++j) k = (k << 8) | p[j];
+            }
+            all.push_back({k, t, q});
+        }
     auto pat = [&](const ref_t &r) { return patterns[r.t] + (size_t)r.q * pattern_stride[r.t]; };
-    std::sort(all.begin(), all.end(), [&](const ref_t &a, const ref_t &b) {
-        const int c = vp ? memcmp(pat(a), pat(b), vp) : 0;   // codon codes are bytes: memcmp is position by position
-        if (c) return c < 0;
-        return a.t != b.t ? a.t < b.t : a.q < b.q;
-    });
+    if (by_word)
+        std::sort(all.begin(), all.end(), [](const ref_t &a, const ref_t &b) {
+            if (a.key != b.key) return a.key < b.key;
+            return a.t != b.t ? a.t < b.t : a.q < b.q;
+        });
+    else
+        std::sort(all.begin(), all.end(), [&](const ref_t &a, const ref_t &b) {
+            const int c = memcmp(pat(a), pat(b), vp);
+            if (c) return c < 0;
+            return a.t != b.t ? a.t < b.t : a.q < b.q;
+        });
     uint32_t m = 0;
-    int rc = JL_OK;
     for (size_t i = 0; i < all.size(); ++i) {
-        const bool fresh = i == 0 || (vp && memcmp(pat(all[i]), pat(all[i - 1]), vp) != 0);
+        const bool fresh = i == 0 || (by_word ? all[i].key != all[i - 1].key : memcmp(pat(all[i]), pat(all[i - 1]), vp) != 0);
         if (fresh) {
             if (m < cap && merged_patterns && vp) memcpy(merged_patterns + (size_t)m * vp, pat(all[i]), vp);
             if (m < cap && merged_counts) merged_counts[m] = 0;
@@ -72,8 +91,7 @@ int jl_merge_groups(const uint8_t *const *patterns, const uint32_t *pattern_stri
         if (index && index[all[i].t]) index[all[i].t][all[i].q] = m - 1;
     }
     *n_merged = m;
-    if (m > cap && (merged_patterns || merged_counts)) rc = JL_ERR_OVERFLOW;
-    return rc;
+    return (m > cap && (merged_patterns || merged_counts)) ? JL_ERR_OVERFLOW : JL_OK;
 }
 
 int jl_select_haplotypes(const uint8_t *patterns, const uint64_t *counts, uint32_t n_groups, uint32_t vp, const jl_variant *variants,
@@ -89,6 +107,8 @@ int jl_select_haplotypes(const uint8_t *patterns, const uint64_t *counts, uint32
         clean += counts[q];
         if (counts[q] >= min_reads) order.push_back(q);
     }
+    // (merged groups arrive in ascending pattern order, so the index breaks ties the way the pattern would; callers that
+    // pass unsorted groups get the comparison itself)
     std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
         if (counts[a] != counts[b]) return counts[a] > counts[b];
         const int c = vp ? memcmp(patterns + (size_t)a * vp, patterns + (size_t)b * vp, vp) : 0;

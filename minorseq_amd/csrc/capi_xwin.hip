@@ -683,16 +683,33 @@ int jl_xwin_phase_sharded(jl_xwin *x, uint32_t min_reads, jl_xwin_result *out)
             pc->exp_ext_cap = x->gcap;
             pc->exp_ext_stride = x->pstride;
         }
-        jl_xw_pack_args plan;
-        memset(&plan, 0, sizeof plan);
-        if (x->n_mine) {
-            plan.meta = pc->d_meta; plan.vpcols = pc->d_vpcols; plan.col2pos = pc->d_col2pos;
-            plan.vp_total = vp; plan.kwords = kwords; plan.n_var = std::min<uint32_t>(n_var, JL_VARIANT_CAP);
+        // Every position in a window of THIS device and one key word: the phase launch reads the columns where they lie
+        // (no compact matrix, no pack launch, no plan in front).  Otherwise: pack (+ the plan), then the peers' slices.
+        const bool direct = x->n_mine && vp <= JL_POS_PER_WORD && x->sch.k_count[(size_t)me] == vp && world == 1;
+        if (direct) {
+            jl_direct_cols &d = pc->direct;
+            memset(&d, 0, sizeof d);
+            const uint64_t src_stride = x->wins[0]->col_stride;
+            for (uint32_t k = 0; k < vp; ++k) {
+                const uint32_t w = (uint32_t)x->sch.owner_win[k];
+                d.col[k] = x->wins[w - x->lay.first_local]->d_msa + (uint64_t)(x->sch.pos[k] - x->lay.win_begin[w]) * src_stride +
+                           x->slice_begin[(size_t)me] / 2u;
+            }
+            d.stride = src_stride;
+            d.vp = vp;
+            d.on = 1;
+        } else {
+            jl_xw_pack_args plan;
+            memset(&plan, 0, sizeof plan);
+            if (x->n_mine) {
+                plan.meta = pc->d_meta; plan.vpcols = pc->d_vpcols; plan.col2pos = pc->d_col2pos;
+                plan.vp_total = vp; plan.kwords = kwords; plan.n_var = std::min<uint32_t>(n_var, JL_VARIANT_CAP);
+            }
+            if ((rc = xw_pack(pc, x->wins.data(), x->lay, x->sch, x->slice_begin.data(), world, me, nullptr, &x->send,
+                              x->n_mine ? &plan : nullptr, &x->err)))
+                return rc;
+            if (world > 1 && (rc = xw_send_recv(pc, x->comm, x->sch, x->slice_begin.data(), x->send, &x->err))) return rc;
         }
-        if ((rc = xw_pack(pc, x->wins.data(), x->lay, x->sch, x->slice_begin.data(), world, me, nullptr, &x->send,
-                          x->n_mine ? &plan : nullptr, &x->err)))
-            return rc;
-        if (world > 1 && (rc = xw_send_recv(pc, x->comm, x->sch, x->slice_begin.data(), x->send, &x->err))) return rc;
         lap(3);
         if (x->n_mine) {
             // the selection of this launch ends a "run" of pc when nothing else follows on the device (no gather): its
@@ -786,7 +803,10 @@ int jl_xwin_phase_sharded(jl_xwin *x, uint32_t min_reads, jl_xwin_result *out)
         a.n_dwords = pc->col_stride / 4u;
         a.flagw = pc->d_flagw; a.read_slot = pc->d_read_slot; a.slot_hap = pc->d_slot_hap; a.read_hap = pc->d_read_hap;
         a.n_groups = x->my_groups; a.bits = x->bits; a.phased = 1u;
-        a.arrive = pc->d_sync + 6; a.seq_dev = pc->d_sync; a.seq_host = pc->h_seq;
+        // no completion word: nothing of this launch is read by the host before jl_xwin_read_hap_fetch, which waits for
+        // the stream, and the next step's launches on this stream come behind it — the ids of step k are written while
+        // the windows' next call stage is already running
+        a.arrive = pc->d_sync + 6; a.seq_dev = pc->d_sync; a.seq_host = nullptr;
         const uint16_t *d_tab = nullptr;
         if (x->my_groups > JL_XW_TAB_MAX) {
             if (x->tab_cap < x->my_groups) {
@@ -806,8 +826,6 @@ int jl_xwin_phase_sharded(jl_xwin *x, uint32_t min_reads, jl_xwin_result *out)
         }
         jl_launch_xw_assign(&a, x->tab.data(), d_tab, pc->stream);
         if (hipGetLastError() != hipSuccess) return xs_fail(x, JL_ERR_DEVICE, "id launch failed");
-        pc->runs_launched++;
-        if (jl_run_wait_seq(pc, pc->runs_launched)) return xs_fail_ctx(x, JL_ERR_DEVICE, pc);
         x->ids_on_device = true;
     }
     lap(6);

@@ -203,6 +203,15 @@ struct jl_exp_head {
 };
 #define JL_EXP_HEAD_WORDS 8u
 
+// The fused phase launch reading its variant columns where they lie (a session whose positions are all in windows of this
+// device: no compact matrix, no pack launch, no plan kernel in front).  Position p = three columns of `stride` bytes
+// starting at col[p] (already offset to the slice's first read); vp travels by value.
+struct jl_direct_cols {
+    const uint8_t *col[JL_POS_PER_WORD];
+    uint64_t stride;
+    uint32_t on, vp;
+};
+
 struct jl_done_ent {   // completion word of one window (see done_kernel)
     uint32_t *seq_dev;
     volatile uint32_t *seq_host;
@@ -321,6 +330,7 @@ struct jl_ctx {
     uint8_t *exp_ext_pattern = nullptr;
     uint32_t *exp_ext_head = nullptr;
     uint32_t exp_ext_cap = 0, exp_ext_stride = 0;
+    jl_direct_cols direct = {};       // direct.on: the next fused phase launch reads these columns (see jl_direct_cols)
 
     // ---- pileup plan (host copies + device arrays)
     std::vector<jl_gene> genes;

@@ -544,6 +544,12 @@ typedef jl_select_args select_args;
 //   3. the remaining clean reads go through an LDS table (CAS on the 64-bit key), which is then flushed
 //      with one global insert per distinct key per block.
 // Global atomics on the hot slot drop from one per wave to one per 2048 reads.
+#ifdef JL_EXP_STAMPS   // experiment builds only: device-clock stamps (100 MHz) of one workgroup's way through the fused launch
+__device__ unsigned long long g_stamps[64];
+#define JL_STAMP(k) do { if (threadIdx.x == 0 && (blockIdx.x == 0 || (k) >= 8)) g_stamps[(k)] = wall_clock64(); } while (0)
+#else
+#define JL_STAMP(k) do { } while (0)
+#endif
 constexpr uint32_t kLdsSlots = 1024;
 constexpr uint64_t kNoKey = ~0ull;
 constexpr uint32_t kPlanList = 256;   // called positions a workgroup can rank in LDS; more take the multi-word pipeline
@@ -746,6 +752,68 @@ __device__ __forceinline__ bool phase_select_lds(const jl_win_phase &w, const pl
     return true;
 }
 
+// The exporting selection of the single-word pipeline (phasing sharded by reads: the groups go to the merge as they are),
+// written for its latency: it is the tail of a launch the host waits for.  Everything it needs arrives in TWO dependent
+// round trips — {group count, the first 256 entries of the occupied list, the run counter} and {count, key of each group} —
+// where the general routine chases a dozen; the groups' rows leave 8 bytes at a time (they may lie in pinned host memory).
+// `cat`: the read categories of the whole matrix, summed by the caller (LDS).
+__device__ __forceinline__ void phase_export_fast(const jl_win_phase &w, uint32_t vp, const uint32_t *cat, uint32_t *s_acc)
+{
+    const select_args &S = w.S;
+    jl_phase_meta *meta = w.meta;
+    const uint32_t tid = threadIdx.x, nt = blockDim.x;
+    if (tid == 0) *s_acc = 0;
+    // trip 1 (the occupied list always holds at least one entry per thread: it is sized by the reads)
+    const uint32_t n_occ = ld_coherent(&meta->n_occupied);
+    uint32_t s_first = ld_coherent(&w.occupied[tid]);
+    __syncthreads();
+    uint32_t clean = 0;
+    for (uint32_t q = tid; q < n_occ; q += nt) {
+        const uint32_t s = q == tid ? s_first : ld_coherent(&w.occupied[q]);
+        // trip 2: both words of the group before either is used
+        const uint32_t c = ld_coherent(&w.slot_count[s]);
+        const unsigned long long key = ld_coherent64(&w.slot_key[s]);
+        clean += c;
+        // the slot remembers WHICH exported group it is: the merge answers per group
+        __hip_atomic_store(&S.slot_hap[s], q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (q < S.exp_cap) {
+            S.exp_count[q] = c;
+            for (uint32_t p8 = 0; p8 < vp; p8 += 8u) {
+                unsigned long long out = 0;
+                for (uint32_t j = 0; j < 8u && p8 + j < vp; ++j) out |= (unsigned long long)key_code(key, vp, p8 + j) << (8u * j);
+                *reinterpret_cast<unsigned long long *>(S.exp_pattern + (uint64_t)q * S.exp_stride + p8) = out;
+            }
+        }
+        // leave the table empty for the next run: only the slots this run touched
+        w.slot_key[s] = ~0ull;
+        w.slot_rep[s] = 0xFFFFFFFFu;
+        w.slot_count[s] = 0;
+    }
+    clean = wave_sum_all(clean);
+    if ((tid & 63u) == 0 && clean) atomicAdd(s_acc, clean);
+    __syncthreads();
+    if (tid == 0) {
+        const uint32_t total_clean = *s_acc;
+        if (S.exp_head) {
+            S.exp_head[0] = n_occ; S.exp_head[1] = vp; S.exp_head[2] = n_occ > S.exp_cap ? 1u : 0u;
+            S.exp_head[3] = cat[0]; S.exp_head[4] = cat[1]; S.exp_head[5] = cat[2]; S.exp_head[6] = cat[3];
+            S.exp_head[7] = total_clean;
+        }
+        // the run's scalars for the stage API (jl_phase_groups_fetch reads them from here)
+        if (n_occ > S.exp_cap) atomicOr(&meta->overflow, 16u);
+        meta->summary.reported_reads = 0;
+        meta->summary.insufficient_reads = total_clean;   // clean reads: the merge decides which are reported
+        meta->summary.damaged_reads = cat[0];
+        meta->summary.marginal_gap = cat[1];
+        meta->summary.marginal_heteroduplex = cat[2];
+        meta->summary.marginal_partial = cat[3];
+        meta->summary.n_haplotypes = 0;
+        meta->id_bits = 16u;
+        // a session's next launch may come without a plan kernel in front (jl_direct_cols): the group list starts empty
+        if (S.exp_head) { meta->n_occupied = 0; meta->overflow = 0; }
+    }
+}
+
 __device__ __forceinline__ uint32_t global_insert64(uint64_t key, uint32_t cnt, uint32_t first, uint64_t slots_mask,
                                                     unsigned long long *__restrict__ slot_key,
                                                     uint32_t *__restrict__ slot_rep, uint32_t *__restrict__ slot_count,
@@ -772,7 +840,7 @@ __device__ __forceinline__ uint32_t global_insert64(uint64_t key, uint32_t cnt, 
     }
 }
 
-__device__ __forceinline__ void phase_fused1_body(const jl_win_phase &w)
+__device__ __forceinline__ void phase_fused1_body(const jl_win_phase &w, const jl_direct_cols *dc = nullptr)
 {
     const uint8_t *__restrict__ msa = w.msa;
     const uint64_t col_stride = w.col_stride, n_reads = w.n_reads, reads_pad = w.reads_pad;
@@ -791,12 +859,14 @@ __device__ __forceinline__ void phase_fused1_body(const jl_win_phase &w)
     __shared__ plan_state s_plan;
     __shared__ unsigned long long s_dom;
     __shared__ uint32_t s_domcnt, s_domfirst, s_domslot;
-    __shared__ uint32_t s_last, s_cat[4], s_idbits, s_scan[4], s_running;
+    __shared__ uint32_t s_last, s_cat[4], s_idbits, s_scan[4], s_running, s_nlist;
+    __shared__ uint16_t s_list[kLdsSlots];
     const uint32_t tid = threadIdx.x;
     const bool from_called = S.called != nullptr;
     // whole-path runs launch one workgroup more than the reads need: it compacts the called rows meanwhile
     const uint32_t n_arrive = w.n_blocks + (from_called ? 1u : 0u);
     const bool plan_block = from_called && blockIdx.x == w.n_blocks;
+    JL_STAMP(0);
 
     // ---- 0. the plan
     uint32_t vp, n_rows;
@@ -829,6 +899,10 @@ __device__ __forceinline__ void phase_fused1_body(const jl_win_phase &w)
                 __hip_atomic_store(&meta->summary.n_positions, vp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
+    } else if (dc && dc->on) {   // columns by pointer, vp by value: nothing to read, no kernel in front
+        work = dc->vp != 0;
+        vp = dc->vp;
+        n_rows = 0;
     } else {
         const uint32_t mvp = meta->vp, kw = meta->kwords;  // one scalar round trip for both; the plan kernel wrote them
         work = (mvp != 0) & (kw == 1);                       // block-uniform
@@ -841,13 +915,14 @@ __device__ __forceinline__ void phase_fused1_body(const jl_win_phase &w)
     }
     const uint64_t t = (uint64_t)blockIdx.x * 256u + tid;  // dword index within a column = 8 reads
     const bool live = t * 4u < col_stride;                 // never for the extra workgroup
+    JL_STAMP(1);
     uint32_t clean_keep = 0;   // bit 4r: read r of this lane is clean
     uint32_t gslot[8];         // global table slot of each clean read
 #pragma unroll
     for (int r = 0; r < 8; ++r) gslot[r] = 0;
     if (work && !plan_block) {
     for (uint32_t i = tid; i < kLdsSlots; i += 256u) { s_key[i] = kNoKey; s_cnt[i] = 0; s_first[i] = 0xFFFFFFFFu; }
-    if (tid == 0) { s_dom = kNoKey; s_domcnt = 0; s_domfirst = 0xFFFFFFFFu; s_domslot = 0; }
+    if (tid == 0) { s_dom = kNoKey; s_domcnt = 0; s_domfirst = 0xFFFFFFFFu; s_domslot = 0; s_nlist = 0; }
     if (tid < 4) s_cat[tid] = 0;
     __syncthreads();
 
@@ -859,12 +934,15 @@ __device__ __forceinline__ void phase_fused1_body(const jl_win_phase &w)
     for (uint32_t p = 0; p < JL_POS_PER_WORD; ++p) cols[p] = s_plan.cols[p];
     const uint64_t t_ld = live ? t : 0u;
     uint32_t wd[JL_POS_PER_WORD][3];
+    const bool direct = dc && dc->on;   // block-uniform
 #pragma unroll
     for (uint32_t p = 0; p < JL_POS_PER_WORD; ++p) {
         if (p < vp) {  // block-uniform
+            const uint8_t *c0 = direct ? dc->col[p] : msa + (uint64_t)cols[p] * col_stride;
+            const uint64_t cs = direct ? dc->stride : col_stride;
 #pragma unroll
             for (int k = 0; k < 3; ++k)
-                wd[p][k] = *reinterpret_cast<const uint32_t *>(msa + (uint64_t)(cols[p] + k) * col_stride + t_ld * 4u);
+                wd[p][k] = *reinterpret_cast<const uint32_t *>(c0 + (uint64_t)k * cs + t_ld * 4u);
         } else {
 #pragma unroll
             for (int k = 0; k < 3; ++k) wd[p][k] = 0x66666666u;
@@ -901,6 +979,7 @@ __device__ __forceinline__ void phase_fused1_body(const jl_win_phase &w)
         for (int r = 0; r < 8; ++r)
             if (t * 8u + r < n_reads) valid |= 1u << (4 * r);
     }
+    JL_STAMP(2);
     gap &= valid; het &= valid; par &= valid;
     const uint32_t dirty = gap | het | par;
     const uint32_t cleanm = valid & ~dirty;  // bit 4r: read r is clean
@@ -956,6 +1035,7 @@ __device__ __forceinline__ void phase_fused1_body(const jl_win_phase &w)
         const uint32_t c = wave_sum_all(__popc(isdom));
         if ((tid & 63u) == 0 && c) atomicAdd(&s_domcnt, c);
     }
+    JL_STAMP(3);
     // ---- 3. everything else through the LDS table
     uint32_t rest = cleanm & ~isdom;
     uint32_t myslot[8];
@@ -979,12 +1059,25 @@ __device__ __forceinline__ void phase_fused1_body(const jl_win_phase &w)
         }
     }
     __syncthreads();
-    for (uint32_t s = tid; s < kLdsSlots; s += 256u)
-        if (s_cnt[s])
-            s_gslot[s] = global_insert64(s_key[s], s_cnt[s], s_first[s], slots_mask, slot_key, slot_rep, slot_count,
-                                         occupied, meta);
-    if (tid == 0 && s_domcnt)
-        s_domslot = global_insert64(dom, s_domcnt, s_domfirst, slots_mask, slot_key, slot_rep, slot_count, occupied, meta);
+    JL_STAMP(4);
+    // One global insert per distinct key of the block, ALL AT ONCE: the keys are listed densely first, so thread i takes the
+    // i-th (a sweep over the 1024 table slots, four per thread, made the thread that owned
+    // two occupied slots — and thread 0, which also had the dominant key — do its inserts one after the other: 8.7 us of
+    // a 25 us launch at a million reads, two to three dependent round trips each).  The dominant key goes with the last
+    // thread, which has a list entry of its own only in blocks with 256 or more distinct keys.
+    {
+        // (the list is made by a sweep over the table: four LDS reads per thread and a barrier)
+        for (uint32_t s = tid; s < kLdsSlots; s += 256u)
+            if (s_cnt[s]) s_list[atomicAdd(&s_nlist, 1u)] = (uint16_t)s;
+        __syncthreads();
+        const uint32_t n_list = s_nlist;
+        for (uint32_t i = tid; i < n_list; i += 256u) {
+            const uint32_t s = s_list[i];
+            s_gslot[s] = global_insert64(s_key[s], s_cnt[s], s_first[s], slots_mask, slot_key, slot_rep, slot_count, occupied, meta);
+        }
+        if (tid == 255u && s_domcnt)
+            s_domslot = global_insert64(dom, s_domcnt, s_domfirst, slots_mask, slot_key, slot_rep, slot_count, occupied, meta);
+    }
     // read categories of this workgroup's reads: written through to its own four words; the selection adds the workgroups
     // up (four atomics per workgroup on ONE cache line were the longest queue of the launch at a million reads)
     if (tid >= 64u && tid < 68u)  // a lane of another wave than the inserting one
@@ -1003,6 +1096,7 @@ __device__ __forceinline__ void phase_fused1_body(const jl_win_phase &w)
             gslot[r] = g;
         }
     }
+    JL_STAMP(5);
     clean_keep = cleanm;
     }  // work
     if (!S.run) return;  // the generic pipeline has its own select launch
@@ -1011,6 +1105,7 @@ __device__ __forceinline__ void phase_fused1_body(const jl_win_phase &w)
     // list, the read-category counters, the compacted rows): no release fence — an L2 write-back per block serialises
     // in the L2.  Every wave drains its stores -> block barrier -> one lane: the arrival add; the last arriver reads
     // with agent-scope loads (past its L1).  The counter is zero before the first launch and the last arriver leaves it zero.
+    JL_STAMP(6);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
@@ -1024,13 +1119,18 @@ __device__ __forceinline__ void phase_fused1_body(const jl_win_phase &w)
         s_last = last;
     }
     __syncthreads();
+    JL_STAMP(7);
     const bool last = s_last != 0;
     if (!last && !S.fold) return;
     if (last) {
-        uint32_t nv = 0;
+        JL_STAMP(8);
+        uint32_t nv = 0, seq_before = 0;
+        const bool fast_export = work && S.exp_count != nullptr;
         if (!S.exp_count) {   // (an exporting selection needs neither: it ranks nothing)
             nv = from_called ? (n_rows < S.cap ? n_rows : S.cap) : ld_coherent(&meta->n_var);
             if (!from_called) n_rows = ld_coherent(&S.n_rows[0]);
+        } else if (tid == 0 && S.seq_host) {
+            seq_before = ld_coherent(S.seq_dev);   // beside the loads below: not a round trip of its own at the end
         }
         if (work) {   // the read categories: every workgroup's four words, summed here
             uint32_t c4[4] = {0, 0, 0, 0};
@@ -1047,14 +1147,29 @@ __device__ __forceinline__ void phase_fused1_body(const jl_win_phase &w)
                 for (int k = 0; k < 4; ++k) atomicAdd(&s_cat[k], c4[k]);
             }
             __syncthreads();
-            if (tid == 0) {
-                __hip_atomic_store(&meta->summary.damaged_reads, s_cat[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&meta->summary.marginal_gap, s_cat[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&meta->summary.marginal_heteroduplex, s_cat[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&meta->summary.marginal_partial, s_cat[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (!fast_export) {   // the selection routines read them from the run's scalars
+                if (tid == 0) {
+                    __hip_atomic_store(&meta->summary.damaged_reads, s_cat[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&meta->summary.marginal_gap, s_cat[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&meta->summary.marginal_heteroduplex, s_cat[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&meta->summary.marginal_partial, s_cat[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
             }
+        }
+        JL_STAMP(9);
+        if (fast_export) {
+            phase_export_fast(w, vp, s_cat, &s_running);
+            JL_STAMP(10);
+            // every wave's stores (the groups may lie in host memory) are performed; ONE system-scope release, carried by
+            // the completion word's store, pushes them out in front of it: data and word leave the same workgroup
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
+            JL_STAMP(11);
+            if (S.seq_host && tid == 0) jl_signal_done_from(seq_before, S.seq_dev, S.seq_host);
+            JL_STAMP(12);
+            return;
         }
         bool done = false;
         if (work && !S.exp_count) done = phase_select_lds(w, s_plan, vp, nv, n_rows, *reinterpret_cast<sel_lds *>(s_tables));
@@ -1131,6 +1246,7 @@ __device__ __forceinline__ void phase_fused1_body(const jl_win_phase &w)
 }
 
 __global__ __launch_bounds__(256) void phase_fused1_kernel(jl_win_phase w) { phase_fused1_body(w); }
+__global__ __launch_bounds__(256) void phase_fused1_direct_kernel(jl_win_phase w, jl_direct_cols dc) { phase_fused1_body(w, &dc); }
 
 // one launch for several windows: blockIdx.z = window
 __global__ __launch_bounds__(256) void phase_group_run_kernel(jl_phase_group_args args)
@@ -1184,6 +1300,13 @@ __global__ __launch_bounds__(256) void phase_assign_group_kernel(jl_phase_group_
 }
 
 }  // namespace
+
+#ifdef JL_EXP_STAMPS
+extern "C" int jl_debug_stamps(unsigned long long *out)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(g_stamps)) == hipSuccess ? 0 : -2;
+}
+#endif
 
 #ifndef JL_ASSIGN_HOST_BLOCKS
 #define JL_ASSIGN_HOST_BLOCKS 128u
@@ -1272,7 +1395,9 @@ bool jl_launch_phase(jl_ctx *ctx, hipStream_t st, uint32_t min_reads, bool plann
     jl_win_phase w;
     const bool fold = jl_fill_win_phase(ctx, min_reads, signal, JL_FOLD_MAX_BLOCKS, from_called, &w);
     // (the multi-word pipeline has its own keys / grouping / selection launches: the fused launch would find nothing to do)
-    if (!generic) hipLaunchKernelGGL(phase_fused1_kernel, dim3(w.n_blocks + (w.S.called ? 1u : 0u)), dim3(256), 0, st, w);
+    if (!generic && ctx->direct.on && !w.S.called)
+        hipLaunchKernelGGL(phase_fused1_direct_kernel, dim3(w.n_blocks), dim3(256), 0, st, w, ctx->direct);
+    else if (!generic) hipLaunchKernelGGL(phase_fused1_kernel, dim3(w.n_blocks + (w.S.called ? 1u : 0u)), dim3(256), 0, st, w);
     if (generic) {
         hipLaunchKernelGGL(phase_group_kernel, dim3(rblocks), dim3(256), 0, st, ctx->n_reads, reads_pad, ctx->d_keys,
                            ctx->d_flagw, ctx->d_meta, ctx->table_slots - 1u, ctx->d_slot_rep, ctx->d_slot_count,

@@ -35,31 +35,41 @@ __device__ __forceinline__ void plan_init(const jl_xw_pack_args &a)
     }
 }
 
-// grid: x = 4 KiB pieces of a destination column, y = source column (3 per owned position), z = destination
+// grid: x = 16 KiB pieces of a destination column (four 16-byte pieces per lane, loaded before any is stored), y = source
+// column (3 per owned position), z = destination
+constexpr uint32_t kPackPieces = 4;
 __global__ __launch_bounds__(256) void xwin_pack_kernel(jl_xw_pack_args a)
 {
     if (a.meta && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) plan_init(a);
     if (blockIdx.z >= a.n_dst || blockIdx.y >= 3u * a.n_pos) return;
     const uint64_t dst_stride = a.d[blockIdx.z].dst_stride;
-    const uint64_t off = ((uint64_t)blockIdx.x * 256u + threadIdx.x) * 16u;
-    if (off >= dst_stride) return;
     const uint64_t bytes = a.d[blockIdx.z].bytes;
     const uint32_t p = blockIdx.y / 3u, j = blockIdx.y - 3u * p;
-    uint4 v = make_uint4(0x66666666u, 0x66666666u, 0x66666666u, 0x66666666u);   // padding: 'not covered'
-    if (off < bytes) {
-        // the source column continues past the slice (more reads, or the column's own padding): a whole 16-byte load is
-        // always inside it; bytes past the slice's last read become padding
-        const u32x4 ld = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(a.src[p] + (uint64_t)j * a.src_stride + a.d[blockIdx.z].byte_begin + off));
-        v = make_uint4(ld.x, ld.y, ld.z, ld.w);
-        if (off + 16u > bytes) {
-            uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    const uint8_t *src = a.src[p] + (uint64_t)j * a.src_stride + a.d[blockIdx.z].byte_begin;
+    uint8_t *dst = a.d[blockIdx.z].dst + (uint64_t)blockIdx.y * dst_stride;
+    u32x4 v[kPackPieces];
+    uint64_t off[kPackPieces];
 #pragma unroll
-            for (uint32_t b = 0; b < 16u; ++b)
-                if (off + b >= bytes) w[b >> 2] = (w[b >> 2] & ~(0xFFu << (8u * (b & 3u)))) | (0x66u << (8u * (b & 3u)));
-            v = make_uint4(w[0], w[1], w[2], w[3]);
-        }
+    for (uint32_t k = 0; k < kPackPieces; ++k) {
+        off[k] = (((uint64_t)blockIdx.x * kPackPieces + k) * 256u + threadIdx.x) * 16u;
+        // the source column continues past the slice (more reads, or the column's own padding): a whole 16-byte load
+        // below `bytes` is always inside it
+        if (off[k] < bytes) v[k] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(src + off[k]));
     }
-    *reinterpret_cast<uint4 *>(a.d[blockIdx.z].dst + (uint64_t)blockIdx.y * dst_stride + off) = v;
+#pragma unroll
+    for (uint32_t k = 0; k < kPackPieces; ++k) {
+        if (off[k] >= dst_stride) continue;
+        uint32_t w[4] = {0x66666666u, 0x66666666u, 0x66666666u, 0x66666666u};   // padding: 'not covered'
+        if (off[k] < bytes) {
+            w[0] = v[k].x; w[1] = v[k].y; w[2] = v[k].z; w[3] = v[k].w;
+            if (off[k] + 16u > bytes) {   // bytes past the slice's last read become padding
+#pragma unroll
+                for (uint32_t b = 0; b < 16u; ++b)
+                    if (off[k] + b >= bytes) w[b >> 2] = (w[b >> 2] & ~(0xFFu << (8u * (b & 3u)))) | (0x66u << (8u * (b & 3u)));
+            }
+        }
+        *reinterpret_cast<uint4 *>(dst + off[k]) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
 }
 
 __global__ __launch_bounds__(256) void xwin_plan_kernel(jl_xw_pack_args a) { plan_init(a); }
@@ -99,10 +109,12 @@ __device__ __forceinline__ void xw_arrive_and_signal(uint32_t *arrive, uint32_t 
     __syncthreads();
     if (threadIdx.x == 0) {
         if (HOST_STORES) __threadfence_system();   // this workgroup's stores leave its die's L2 before it arrives
+        // (the run counter rides along with the arrival: no round trip of its own in the last workgroup)
+        const uint32_t seq_before = __hip_atomic_load(seq_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const uint32_t prev = __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (prev == gridDim.x - 1u) {
             __hip_atomic_store(arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            jl_signal_done(seq_dev, seq_host);
+            jl_signal_done_from(seq_before, seq_dev, seq_host);
         }
     }
 }
@@ -139,7 +151,7 @@ void jl_launch_xw_pack(const jl_xw_pack_args *a, hipStream_t st)
     }
     uint64_t max_stride = 0;
     for (uint32_t k = 0; k < a->n_dst; ++k) max_stride = a->d[k].dst_stride > max_stride ? a->d[k].dst_stride : max_stride;
-    const uint32_t gx = (uint32_t)((max_stride + 4095u) / 4096u);
+    const uint32_t gx = (uint32_t)((max_stride + 16383u) / 16384u);
     hipLaunchKernelGGL(xwin_pack_kernel, dim3(gx, 3u * a->n_pos, a->n_dst), dim3(256), 0, st, *a);
 }
 

@@ -21,7 +21,17 @@ __device__ __forceinline__ void jl_signal_done(uint32_t *seq_dev, volatile uint3
 {
     const uint32_t v = __hip_atomic_load(seq_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
     __hip_atomic_store(seq_dev, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __threadfence_system();
+    // ONE system-scope release: the store below carries it (write-back of this die's L2, wait, store).  A fence of its
+    // own in front of a release store paid for the same write-back twice (about 2 us each in every run's tail).
+    __hip_atomic_store(const_cast<uint32_t *>(seq_host), v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// The same for a caller that read the run counter earlier (`seq_before`, loaded beside other loads it had to wait for
+// anyway: one dependent round trip less at the very end of the run).
+__device__ __forceinline__ void jl_signal_done_from(uint32_t seq_before, uint32_t *seq_dev, volatile uint32_t *seq_host)
+{
+    const uint32_t v = seq_before + 1u;
+    __hip_atomic_store(seq_dev, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(const_cast<uint32_t *>(seq_host), v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 

@@ -11,6 +11,9 @@ import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from minorseq_amd import capi, sharding, synth  # noqa: E402
 
+if os.environ.get("JL_LIB"):   # an experimental build of the library
+    capi.load_library(os.environ["JL_LIB"])
+
 n, l = 1_000_000, 10_000
 sp = synth.SynthParams(seed=4)
 ref = synth.reference(sp.seed, l)
@@ -56,3 +59,13 @@ for k, v in T.items():
     print(f"{k:40s} {v / R:8.1f} us")
 print(f"{'step':40s} {tt * 1e6:8.1f} us; pileup kernel {t_k * 1e3:.1f} us; residue {tt * 1e6 - t_k * 1e3:.1f} us; "
       f"groups {r.n_groups}, haplotypes {r.n_haplotypes}, communicator {'yes' if comm else 'no'}")
+
+if hasattr(win.lib, "jl_debug_stamps"):   # -DJL_EXP_STAMPS build: device-clock stamps of the last fused phase launch
+    st = np.zeros(64, dtype=np.uint64)
+    win.lib.jl_debug_stamps(st.ctypes.data_as(C.c_void_p))
+    names = ["entry", "plan read", "keys built", "dominant key", "LDS table", "global inserts + slots", "before arrival",
+             "after arrival", "LAST: start", "LAST: categories", "LAST: export done", "LAST: stores drained", "LAST: signalled"]
+    t0 = int(st[0])
+    print("fused phase launch, workgroup 0 then the last arriver (us after workgroup 0's entry):")
+    for k, nm in enumerate(names):
+        print(f"  {nm:28s} {(int(st[k]) - t0) / 100.0:8.2f}")
