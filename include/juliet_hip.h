@@ -157,6 +157,11 @@ int jl_records_begin(jl_ctx *ctx, uint64_t reads_hint, uint64_t cigar_words_hint
 int jl_records_append(jl_ctx *ctx, uint64_t n_reads, const int32_t *pos, const uint32_t *cigar, const uint64_t *cig_off,
                       const uint8_t *seq4, const uint64_t *seq_off, const uint8_t *qual, const uint64_t *qual_off);
 int jl_records_finish(jl_ctx *ctx, uint32_t n_cols, uint32_t win_begin, uint32_t min_qv);
+/* One upload, several column windows (`juliet --windows K`: the BAM is decoded and uploaded once): the resident matrix
+ * of `window` — another context of the same device — from the records appended to `records`, which stay until
+ * jl_records_drop (or jl_records_finish on `records` itself). */
+int jl_records_window(jl_ctx *records, jl_ctx *window, uint32_t n_cols, uint32_t win_begin, uint32_t min_qv);
+int jl_records_drop(jl_ctx *records);
 /*
  * Insertions are not part of the matrix (J:26-27) but `fuse` "includes in-frame insertions with a certain distance to
  * each other" (doc/FUSE.md:19): with tracking on, jl_msa_ingest_records also counts them per window column — an

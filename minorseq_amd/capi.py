@@ -30,7 +30,7 @@ SUMMARY = np.dtype([(n, "<u4") for n in SUMMARY_FIELDS])
 # every symbol include/juliet_hip.h declares (checked by tests/test_capi_exports.py)
 EXPORTS = ("jl_abi_version", "jl_strerror", "jl_device_count", "jl_ctx_create", "jl_ctx_destroy", "jl_last_error",
            "jl_sync", "jl_col_stride", "jl_msa_upload", "jl_msa_alloc", "jl_msa_adopt", "jl_msa_pack_rows",
-           "jl_msa_ingest_records", "jl_records_begin", "jl_records_append", "jl_records_finish", "jl_msa_track_insertions", "jl_insertions_fetch", "jl_msa_download", "jl_synth_fill", "jl_synth_fill_window", "jl_pileup_async", "jl_n_positions", "jl_pileup_fetch",
+           "jl_msa_ingest_records", "jl_records_begin", "jl_records_append", "jl_records_finish", "jl_records_window", "jl_records_drop", "jl_msa_track_insertions", "jl_insertions_fetch", "jl_msa_download", "jl_synth_fill", "jl_synth_fill_window", "jl_pileup_async", "jl_n_positions", "jl_pileup_fetch",
            "jl_consensus_fetch", "jl_call_async", "jl_call_fetch", "jl_variant_table_device", "jl_phase_async", "jl_phase_fetch",
            "jl_run_async", "jl_run_wait", "jl_run_done", "jl_run_view_get", "jl_group_create", "jl_group_destroy",
            "jl_group_last_error", "jl_group_run_async", "jl_group_run_masked_async", "jl_group_time_pileup", "jl_fisher_eval", "jl_fisher_eval_tail", "jl_expand_read_hap", "jl_time_pileup", "jl_time_pileup_set", "jl_pileup_kernel_name", "jl_comm_unique_id", "jl_comm_create", "jl_comm_destroy",
@@ -166,6 +166,8 @@ def load_library(path=LIB_PATH):
     lib.jl_records_begin.argtypes = [vp, u64, u64, u64, u64]
     lib.jl_records_append.argtypes = [vp, u64] + [vp] * 7
     lib.jl_records_finish.argtypes = [vp, u32, u32, u32]
+    lib.jl_records_window.argtypes = [vp, vp, u32, u32, u32]
+    lib.jl_records_drop.argtypes = [vp]
     lib.jl_msa_track_insertions.argtypes = [vp, C.c_int]
     lib.jl_insertions_fetch.argtypes = [vp, vp, vp]
     lib.jl_msa_download.argtypes = [vp, vp, u64]

@@ -408,59 +408,82 @@ int jl_records_append(jl_ctx *ctx, uint64_t n_reads, const int32_t *pos, const u
     return JL_OK;
 }
 
-int jl_records_finish(jl_ctx *ctx, uint32_t n_cols, uint32_t win_begin, uint32_t min_qv)
+// The resident matrix of `dst` from the records uploaded to `src` (the same context for jl_records_finish; another one of
+// the same device when one upload feeds several column windows).  The records stay.
+static int records_build(jl_ctx *src, jl_ctx *dst, uint32_t n_cols, uint32_t win_begin, uint32_t min_qv)
 {
-    if (!ctx) return JL_ERR_ARG;
-    jl_records &R = ctx->rec;
-    if (!R.open) return jl_fail(ctx, JL_ERR_STATE, "jl_records_finish before jl_records_begin");
-    JL_HIP(ctx, hipSetDevice(ctx->device));
-    int rc = jl_msa_alloc(ctx, R.n_reads, n_cols, win_begin);
-    if (rc) {
-        records_drop(ctx);
-        return rc;
-    }
-    hipStream_t st = ctx->stream;
+    jl_records &R = src->rec;
+    int rc = jl_msa_alloc(dst, R.n_reads, n_cols, win_begin);
+    if (rc) return rc;
+    hipStream_t st = dst->stream;
     uint32_t *d_rows4 = nullptr;
     hipError_t e = hipSuccess;
     if (!R.n_reads) {   // nothing was appended: the offset arrays still need their first entry
-        e = records_room(ctx, R.d_co, R.cap_co, 0, 1, 0);
-        if (e == hipSuccess) e = records_room(ctx, R.d_so, R.cap_so, 0, 1, 0);
-        if (e == hipSuccess) e = records_room(ctx, R.d_pos, R.cap_pos, 0, 1, 0);
-        if (e == hipSuccess) e = records_room(ctx, R.d_cig, R.cap_cig, 0, 1, 0);
-        if (e == hipSuccess) e = records_room(ctx, R.d_seq, R.cap_seq, 0, 1, 16);
+        e = records_room(src, R.d_co, R.cap_co, 0, 1, 0);
+        if (e == hipSuccess) e = records_room(src, R.d_so, R.cap_so, 0, 1, 0);
+        if (e == hipSuccess) e = records_room(src, R.d_pos, R.cap_pos, 0, 1, 0);
+        if (e == hipSuccess) e = records_room(src, R.d_cig, R.cap_cig, 0, 1, 0);
+        if (e == hipSuccess) e = records_room(src, R.d_seq, R.cap_seq, 0, 1, 16);
         if (e == hipSuccess) e = hipMemsetAsync(R.d_co, 0, 8, st);
         if (e == hipSuccess) e = hipMemsetAsync(R.d_so, 0, 8, st);
     }
-    if (e == hipSuccess) e = hipMalloc(&d_rows4, (size_t)jl_ingest_batch_reads(ctx) * jl_ingest_row_dwords(ctx) * 4);
+    if (e == hipSuccess) e = hipMalloc(&d_rows4, (size_t)jl_ingest_batch_reads(dst) * jl_ingest_row_dwords(dst) * 4);
     if (e == hipSuccess) e = hipMemsetAsync(R.d_seq + R.n_seq, 0, 16, st);
-    ctx->ins_valid = false;
-    if (e == hipSuccess && ctx->track_insertions) {
-        if (ctx->ins_capacity < n_cols) {
-            if (ctx->d_ins_len) hipFree(ctx->d_ins_len);
-            if (ctx->d_ins_base) hipFree(ctx->d_ins_base);
-            ctx->d_ins_len = ctx->d_ins_base = nullptr;
-            ctx->ins_capacity = 0;
-            e = hipMalloc(&ctx->d_ins_len, (size_t)n_cols * JL_INS_LEN_BINS * 4);
-            if (e == hipSuccess) e = hipMalloc(&ctx->d_ins_base, (size_t)n_cols * JL_INS_MAX_BASES * 16);
-            if (e == hipSuccess) ctx->ins_capacity = n_cols;
+    dst->ins_valid = false;
+    if (e == hipSuccess && dst->track_insertions) {
+        if (dst->ins_capacity < n_cols) {
+            if (dst->d_ins_len) hipFree(dst->d_ins_len);
+            if (dst->d_ins_base) hipFree(dst->d_ins_base);
+            dst->d_ins_len = dst->d_ins_base = nullptr;
+            dst->ins_capacity = 0;
+            e = hipMalloc(&dst->d_ins_len, (size_t)n_cols * JL_INS_LEN_BINS * 4);
+            if (e == hipSuccess) e = hipMalloc(&dst->d_ins_base, (size_t)n_cols * JL_INS_MAX_BASES * 16);
+            if (e == hipSuccess) dst->ins_capacity = n_cols;
         }
-        if (e == hipSuccess) e = hipMemsetAsync(ctx->d_ins_len, 0, (size_t)n_cols * JL_INS_LEN_BINS * 4, st);
-        if (e == hipSuccess) e = hipMemsetAsync(ctx->d_ins_base, 0, (size_t)n_cols * JL_INS_MAX_BASES * 16, st);
+        if (e == hipSuccess) e = hipMemsetAsync(dst->d_ins_len, 0, (size_t)n_cols * JL_INS_LEN_BINS * 4, st);
+        if (e == hipSuccess) e = hipMemsetAsync(dst->d_ins_base, 0, (size_t)n_cols * JL_INS_MAX_BASES * 16, st);
         if (e == hipSuccess) {
-            jl_launch_insertions(ctx, R.d_pos, R.d_cig, R.d_co, R.d_seq, R.d_so);
+            jl_launch_insertions(dst, R.d_pos, R.d_cig, R.d_co, R.d_seq, R.d_so);
             e = hipGetLastError();
-            ctx->ins_valid = e == hipSuccess;
+            dst->ins_valid = e == hipSuccess;
         }
     }
     if (e == hipSuccess) {
-        jl_launch_ingest(ctx, R.d_pos, R.d_cig, R.d_co, R.d_seq, R.d_so, R.have_qual ? R.d_qual : nullptr,
+        jl_launch_ingest(dst, R.d_pos, R.d_cig, R.d_co, R.d_seq, R.d_so, R.have_qual ? R.d_qual : nullptr,
                          R.have_qual ? R.d_qo : nullptr, min_qv, d_rows4, R.max_ops, R.max_seq_bytes);
         e = hipGetLastError();
         if (e == hipSuccess) e = hipStreamSynchronize(st);
     }
     if (d_rows4) hipFree(d_rows4);
+    if (e != hipSuccess) return jl_fail(dst, e == hipErrorOutOfMemory ? JL_ERR_MEMORY : JL_ERR_DEVICE, "ingest: %s", hipGetErrorString(e));
+    return JL_OK;
+}
+
+int jl_records_finish(jl_ctx *ctx, uint32_t n_cols, uint32_t win_begin, uint32_t min_qv)
+{
+    if (!ctx) return JL_ERR_ARG;
+    if (!ctx->rec.open) return jl_fail(ctx, JL_ERR_STATE, "jl_records_finish before jl_records_begin");
+    JL_HIP(ctx, hipSetDevice(ctx->device));
+    const int rc = records_build(ctx, ctx, n_cols, win_begin, min_qv);
     records_drop(ctx);
-    if (e != hipSuccess) return jl_fail(ctx, e == hipErrorOutOfMemory ? JL_ERR_MEMORY : JL_ERR_DEVICE, "ingest: %s", hipGetErrorString(e));
+    return rc;
+}
+
+int jl_records_window(jl_ctx *records, jl_ctx *window, uint32_t n_cols, uint32_t win_begin, uint32_t min_qv)
+{
+    if (!records || !window) return JL_ERR_ARG;
+    if (!records->rec.open) return jl_fail(window, JL_ERR_STATE, "jl_records_window: no records uploaded (jl_records_begin / _append)");
+    if (records->device != window->device) return jl_fail(window, JL_ERR_ARG, "records and window are on different devices");
+    JL_HIP(window, hipSetDevice(window->device));
+    JL_HIP(window, hipStreamSynchronize(records->stream));   // the uploads are complete
+    return records_build(records, window, n_cols, win_begin, min_qv);
+}
+
+int jl_records_drop(jl_ctx *ctx)
+{
+    if (!ctx) return JL_ERR_ARG;
+    JL_HIP(ctx, hipSetDevice(ctx->device));
+    records_drop(ctx);
     return JL_OK;
 }
 

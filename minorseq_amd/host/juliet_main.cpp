@@ -44,6 +44,8 @@ struct Options {
     uint32_t min_reads = 10, min_qv = 0;
     double min_rq = 0.0;
     int device = 0;
+    uint32_t windows = 1;            // column windows the reference is cut into (doc/JULIET.md:261-264: the split never shows)
+    std::vector<int> devices;        // --devices a,b,...: one rank (thread) per device, consecutive windows each
     std::string dump_msa, dump_config, consensus;
     bool fuse_only = false;        // invoked as `fuse in.bam out.fasta` (doc/FUSE.md:26-31): the consensus and nothing else
     double ins_min_frac = 0.5;     // an insertion enters the consensus when more than this share of the covering reads carries it
@@ -65,6 +67,9 @@ struct Options {
         "      --alpha 0.01  --n-tests <auto>  --chemistry auto|sequel|permissive\n"
         "      --match-rate <r> --substitution-rate <r> --expected-round ceil|floor|nearest\n"
         "      --min-reads 10  --min-qv 0  --min-rq 0  --device 0\n"
+        "      --windows K [--devices a,b,...] cut the reference into K column windows (2-column overlap, global Bonferroni\n"
+        "                                      factor), consecutive windows per device; phasing runs across the windows with\n"
+        "                                      the reads sharded over the devices.  The output is that of one window.\n"
         "      --consensus <out.fasta>         also write the window's consensus as `fuse` would (doc/FUSE.md:17-20):\n"
         "                                      majority base, major deletions removed, in-frame majority insertions kept\n"
         "      --ins-min-frac 0.5  --ins-min-distance 10   when an insertion enters the consensus\n"
@@ -111,6 +116,16 @@ Options parse(int argc, char **argv)
         else if (a == "--min-qv") o.min_qv = (uint32_t)std::stoul(need(i));
         else if (a == "--min-rq") o.min_rq = std::stod(need(i));
         else if (a == "--device") o.device = std::stoi(need(i));
+        else if (a == "--windows") o.windows = (uint32_t)std::stoul(need(i));
+        else if (a == "--devices") {
+            const std::string v = need(i);
+            size_t b = 0;
+            while (b <= v.size()) {
+                const size_t e = std::min(v.find(',', b), v.size());
+                if (e > b) o.devices.push_back(std::stoi(v.substr(b, e - b)));
+                b = e + 1;
+            }
+        }
         else if (a == "--consensus") o.consensus = need(i);
         else if (a == "--ins-min-frac") o.ins_min_frac = std::stod(need(i));
         else if (a == "--ins-min-distance") o.ins_min_distance = (uint32_t)std::stoul(need(i));
@@ -120,7 +135,7 @@ Options parse(int argc, char **argv)
         else if (!a.empty() && a[0] == '-') { std::cerr << "juliet: unknown option " << a << "\n"; usage(1); }
         else pos.push_back(a);
     }
-    if (!o.dump_config.empty() && pos.empty()) return o;
+    if (!o.dump_config.empty() && pos.empty()) { if (o.devices.empty()) o.devices.push_back(o.device); return o; }
     {   // `fuse in.bam out.fasta` (doc/FUSE.md:26-31): the same front end, asked for the consensus only
         const std::string prog = argv[0];
         const size_t slash = prog.find_last_of('/');
@@ -129,8 +144,17 @@ Options parse(int argc, char **argv)
             o.bam = pos[0];
             o.consensus = pos[1];
             o.fuse_only = true;
+            o.devices.assign(1, o.device);
+            o.windows = 1;
             return o;
         }
+    }
+    if (o.devices.empty()) o.devices.push_back(o.device);
+    if (o.windows == 0 || o.windows > 32u * o.devices.size()) { std::cerr << "juliet: --windows wants 1 .. 32 per device\n"; usage(1); }
+    if (o.windows < o.devices.size()) { std::cerr << "juliet: fewer windows than devices\n"; usage(1); }
+    if ((o.windows > 1 || o.devices.size() > 1) && !o.consensus.empty()) {
+        std::cerr << "juliet: --consensus works on one window (drop --windows / --devices)\n";
+        usage(1);
     }
     if (pos.size() < 2 && o.dump_msa.empty()) { std::cerr << "juliet: need an input BAM and at least one output\n"; usage(1); }
     if (pos.empty()) usage(1);
@@ -175,7 +199,8 @@ void die_jl(jl_ctx *ctx, const char *what)
 // simply wait.  One consumer thread: chunks stay in file order.
 class RecordUploader {
 public:
-    RecordUploader(std::shared_future<std::pair<int, jl_ctx *>> ctx_up, uint64_t file_bytes, bool want_qual)
+    // one records context per device: every chunk goes to each of them (one rank per device reads its windows out of it)
+    RecordUploader(std::vector<std::shared_future<std::pair<int, jl_ctx *>>> ctx_up, uint64_t file_bytes, bool want_qual)
         : ctx_up_(std::move(ctx_up)), file_bytes_(file_bytes), want_qual_(want_qual), th_([this] { run(); })
     {
     }
@@ -223,7 +248,8 @@ public:
         }
         return rc_;
     }
-    jl_ctx *ctx() const { return ctx_; }
+    jl_ctx *ctx(size_t k = 0) const { return k < ctxs_.size() ? ctxs_[k] : nullptr; }
+    jl_ctx *failed() const { return failed_; }
     std::vector<std::string> names;
     uint64_t n_reads = 0;
     double ms_begin = 0, ms_append = 0, ms_append_max = 0, ms_names = 0;   // --timing
@@ -236,15 +262,19 @@ private:
     }
     void run()
     {
-        const auto up = ctx_up_.get();
-        ctx_ = up.second;
-        rc_ = up.first;
-        if (rc_ == JL_OK) {
+        for (auto &f : ctx_up_) {
+            const auto up = f.get();
+            ctxs_.push_back(up.second);
+            if (up.first != JL_OK && rc_ == JL_OK) rc_ = up.first;
+        }
+        for (jl_ctx *c : ctxs_) {
+            if (rc_ != JL_OK) break;
             // CCS BAMs inflate 5-10x; the packed bases are about a quarter of that, qualities half (arrays grow if not)
             const uint64_t seq_hint = std::min<uint64_t>(file_bytes_ * 2, (uint64_t)2 << 30);
             const auto t = std::chrono::steady_clock::now();
-            rc_ = jl_records_begin(ctx_, seq_hint / 1024 + 1024, seq_hint / 64 + 1024, seq_hint, want_qual_ ? seq_hint * 2 : 0);
-            ms_begin = ms_since(t);
+            rc_ = jl_records_begin(c, seq_hint / 1024 + 1024, seq_hint / 64 + 1024, seq_hint, want_qual_ ? seq_hint * 2 : 0);
+            if (rc_ != JL_OK) failed_ = c;
+            ms_begin += ms_since(t);
         }
         for (;;) {
             RecordArrays c;
@@ -256,10 +286,13 @@ private:
                 q_.pop_front();
             }
             auto t = std::chrono::steady_clock::now();
-            if (rc_ == JL_OK)
-                rc_ = jl_records_append(ctx_, c.pos.size(), c.pos.data(), c.cigar.data(), c.cig_off.data(), c.seq4.data(),
+            for (jl_ctx *dst : ctxs_) {
+                if (rc_ != JL_OK) break;
+                rc_ = jl_records_append(dst, c.pos.size(), c.pos.data(), c.cigar.data(), c.cig_off.data(), c.seq4.data(),
                                         c.seq_off.data(), want_qual_ ? c.qual.data() : nullptr,
                                         want_qual_ ? c.qual_off.data() : nullptr);
+                if (rc_ != JL_OK) failed_ = dst;
+            }
             const double ms = ms_since(t);
             ms_append += ms;
             ms_append_max = std::max(ms_append_max, ms);
@@ -273,7 +306,7 @@ private:
             if (pool_.size() < 8) pool_.push_back(std::move(c));
         }
     }
-    std::shared_future<std::pair<int, jl_ctx *>> ctx_up_;
+    std::vector<std::shared_future<std::pair<int, jl_ctx *>>> ctx_up_;
     uint64_t file_bytes_;
     bool want_qual_;
     std::mutex m_;
@@ -282,9 +315,165 @@ private:
     std::vector<RecordArrays> pool_;
     bool done_ = false;
     int rc_ = JL_OK;
-    jl_ctx *ctx_ = nullptr;
+    std::vector<jl_ctx *> ctxs_;
+    jl_ctx *failed_ = nullptr;
     std::thread th_;   // last: starts in the constructor's initialiser list
 };
+
+
+// What the device stage hands to the writers, whichever way it ran (one window, or K windows over R devices).
+struct Results {
+    std::vector<jl_variant> var;          // (gene, codon_pos, codon) order; col relative to the overall window
+    std::vector<uint32_t> col_counts;     // [n_cols][6] of the overall window
+    jl_phase_summary ps = {};
+    std::vector<uint32_t> pos_cols, hap_count;   // pos_cols relative to the overall window
+    std::vector<uint8_t> hap_pattern, hit;
+    size_t pat_stride = 0, hit_stride = 0;       // hap_pattern[h * pat_stride + p], hit[v * hit_stride + h]
+    std::vector<uint16_t> read_hap;
+};
+
+struct WindowPlan {
+    uint32_t begin = 0, ncols = 0;   // reference columns [begin, begin + ncols)
+    uint32_t own_begin = 0, own_end = 0;   // the columns whose pileup counts this window contributes (no overlap)
+    int rank = 0;
+};
+
+// K windows with a 2-column overlap, so that every codon is evaluated by exactly one window whatever its frame
+// (minorseq_amd/sharding.py window_bounds); consecutive windows per rank.
+std::vector<WindowPlan> plan_windows(uint32_t win_begin, uint32_t n_cols, uint32_t k_windows, uint32_t n_ranks)
+{
+    std::vector<WindowPlan> w(k_windows);
+    for (uint32_t k = 0; k < k_windows; ++k) {
+        const uint32_t c0 = (uint32_t)((uint64_t)n_cols * k / k_windows), c1 = (uint32_t)((uint64_t)n_cols * (k + 1) / k_windows);
+        w[k].begin = win_begin + c0;
+        w[k].ncols = std::min(n_cols, c1 + (k + 1 < k_windows ? 2u : 0u)) - c0;
+        w[k].own_begin = c0;
+        w[k].own_end = c1;
+        w[k].rank = (int)((uint64_t)k * n_ranks / k_windows);
+    }
+    return w;
+}
+
+struct DeviceStageInput {
+    const Options *opt;
+    const TargetConfig *cfg;
+    const std::vector<jl_gene> *genes;
+    const std::vector<uint8_t> *refcodes;
+    jl_params prm;
+    uint32_t win_begin, n_cols;
+    uint64_t n_reads;
+};
+
+// --drm-only: the codons of the config's DRMs per evaluated position of one window (doc/JULIET.md:370)
+int drm_masks_of(jl_ctx *ctx, const DeviceStageInput &in, std::vector<uint64_t> &masks)
+{
+    const uint8_t *refp = in.refcodes->empty() ? nullptr : in.refcodes->data();
+    if (jl_pileup_async(ctx, in.genes->data(), (uint32_t)in.genes->size(), refp, (uint32_t)in.refcodes->size()) != JL_OK) return 1;
+    const uint32_t P = jl_n_positions(ctx);
+    std::vector<uint32_t> pg(P), pk(P);
+    if (jl_pileup_fetch(ctx, nullptr, pg.data(), pk.data(), nullptr, nullptr, nullptr) != JL_OK) return 1;
+    masks.assign(P, 0);
+    for (uint32_t p = 0; p < P; ++p) {
+        const GeneCfg &g = in.cfg->genes[pg[p]];
+        for (unsigned cod = 0; cod < 64; ++cod)
+            if (!in.cfg->known_drms(pg[p], pk[p] + g.first_codon, translate(cod)).empty()) masks[p] |= 1ull << cod;
+    }
+    return 0;
+}
+
+// One rank = one device: its windows out of the records uploaded to it, the call stage per window with the GLOBAL
+// Bonferroni factor, then — with phasing — its share of the cross-window sequence (jl_xwin_phase_sharded: the ranks'
+// collectives meet inside).  Every rank ends with the whole result; rank 0's is written.
+struct RankJob {
+    int rank = 0, world = 1, device = 0;
+    jl_ctx *records = nullptr;
+    std::vector<uint32_t> widx;          // this rank's windows (indices into the plan)
+    std::vector<jl_ctx *> wins;
+    jl_comm *comm = nullptr;
+    std::string error;                   // empty: fine
+    // outputs
+    std::vector<std::vector<jl_variant>> tables;   // per window (window-relative columns), call only
+    Results res;                         // with phasing: the merged table and the haplotypes (rank 0's is used)
+    uint64_t slice_begin = 0, slice_reads = 0;
+    std::vector<uint16_t> ids;           // this rank's slice
+};
+
+void run_rank(RankJob &job, const DeviceStageInput &in, const std::vector<WindowPlan> &plan, const uint8_t *comm_id,
+              std::vector<uint32_t> &col_counts, const std::vector<uint64_t> &slice_begin)
+{
+    auto fail = [&](const char *what, jl_ctx *c) { job.error = std::string(what) + ": " + (c ? jl_last_error(c) : "failed"); };
+    const Options &opt = *in.opt;
+    const uint8_t *refp = in.refcodes->empty() ? nullptr : in.refcodes->data();
+    for (uint32_t k : job.widx) {
+        jl_ctx *w = nullptr;
+        if (jl_ctx_create(job.device, nullptr, &w) != JL_OK) return fail("context", nullptr);
+        job.wins.push_back(w);
+        if (jl_records_window(job.records, w, plan[k].ncols, plan[k].begin, opt.min_qv) != JL_OK) return fail("ingest", w);
+    }
+    jl_records_drop(job.records);
+    // the call stage of every window: enqueued one after the other on the windows' own streams (they overlap on the device)
+    std::vector<std::vector<uint64_t>> masks(job.wins.size());
+    for (size_t i = 0; i < job.wins.size(); ++i) {
+        if (opt.drm_only && drm_masks_of(job.wins[i], in, masks[i])) return fail("pileup", job.wins[i]);
+        if (jl_run_async(job.wins[i], in.genes->data(), (uint32_t)in.genes->size(), refp, (uint32_t)in.refcodes->size(), &in.prm,
+                         opt.drm_only ? masks[i].data() : nullptr, 0, opt.min_reads, 0) != JL_OK)
+            return fail("run", job.wins[i]);
+    }
+    // column counts of the columns each window owns (the MSA context of the output, doc/JULIET.md:99-100)
+    for (size_t i = 0; i < job.wins.size(); ++i) {
+        const WindowPlan &wp = plan[job.widx[i]];
+        std::vector<uint32_t> cc((size_t)wp.ncols * 6);
+        if (jl_pileup_fetch(job.wins[i], cc.data(), nullptr, nullptr, nullptr, nullptr, nullptr) != JL_OK) return fail("pileup fetch", job.wins[i]);
+        const uint32_t off = wp.own_begin - (wp.begin - in.win_begin);   // 0: a window starts where its own columns start
+        std::copy(cc.begin() + (size_t)off * 6, cc.begin() + (size_t)(off + wp.own_end - wp.own_begin) * 6,
+                  col_counts.begin() + (size_t)wp.own_begin * 6);
+    }
+    if (!opt.phasing) {
+        for (jl_ctx *w : job.wins) {
+            std::vector<jl_variant> t(4096);
+            uint32_t n = 0;
+            if (jl_call_fetch(w, t.data(), 4096, &n) != JL_OK) return fail("call fetch", w);
+            t.resize(n);
+            job.tables.push_back(std::move(t));
+        }
+        return;
+    }
+    if (job.world > 1 && jl_comm_create(job.wins[0], comm_id, job.rank, job.world, &job.comm) != JL_OK) return fail("communicator", job.wins[0]);
+    std::vector<uint32_t> wb, wn;
+    std::vector<int32_t> wr;
+    for (const WindowPlan &wp : plan) { wb.push_back(wp.begin); wn.push_back(wp.ncols); wr.push_back(wp.rank); }
+    jl_xwin *x = nullptr;
+    if (jl_xwin_create(job.wins.data(), (uint32_t)job.wins.size(), job.comm, wb.data(), wn.data(), wr.data(), (uint32_t)plan.size(),
+                       slice_begin.data(), &x) != JL_OK)
+        return fail("cross-window session", nullptr);
+    jl_xwin_result r;
+    if (jl_xwin_phase_sharded(x, opt.min_reads, &r) != JL_OK) {
+        job.error = std::string("cross-window phasing: ") + jl_xwin_last_error(x);
+        jl_xwin_destroy(x);
+        return;
+    }
+    Results &R = job.res;
+    R.var.assign(r.merged, r.merged + r.n_variants);
+    for (jl_variant &v : R.var) v.col -= in.win_begin;
+    R.ps = r.summary;
+    R.ps.n_positions = r.n_positions;
+    R.ps.n_haplotypes = r.n_haplotypes;
+    R.pos_cols.resize(r.n_positions);
+    for (uint32_t p = 0; p < r.n_positions; ++p) R.pos_cols[p] = r.pos_global[p] - in.win_begin;
+    if (r.n_positions) {
+        R.hap_count.assign(r.hap_count, r.hap_count + r.n_haplotypes);
+        R.hap_pattern.assign(r.hap_pattern, r.hap_pattern + (size_t)r.n_haplotypes * r.n_positions);
+        R.hit.assign(r.hit, r.hit + (size_t)r.n_variants * r.n_haplotypes);
+    }
+    R.pat_stride = r.n_positions;
+    R.hit_stride = r.n_haplotypes;
+    job.slice_begin = r.slice_begin;
+    job.slice_reads = r.slice_reads;
+    job.ids.resize(r.slice_reads ? r.slice_reads : 1);
+    if (jl_xwin_read_hap_fetch(x, job.ids.data()) != JL_OK) job.error = std::string("per-read ids: ") + jl_xwin_last_error(x);
+    job.ids.resize(r.slice_reads);
+    jl_xwin_destroy(x);
+}
 
 }  // namespace
 
@@ -326,18 +515,19 @@ int main(int argc, char **argv)
         io.min_rq = opt.min_rq;
         // the GPU context comes up (runtime start, stream, pinned blocks) while the host reads the BAM
         const bool need_gpu = !opt.outputs.empty() || opt.fuse_only;
-        std::shared_future<std::pair<int, jl_ctx *>> ctx_up;
+        std::vector<std::shared_future<std::pair<int, jl_ctx *>>> ctx_ups;
         std::unique_ptr<RecordUploader> uploader;
         RecordSink sink;
         if (need_gpu) {
-            ctx_up = std::async(std::launch::async, [dev = opt.device]() {
-                jl_ctx *c = nullptr;
-                const int rc = jl_ctx_create(dev, nullptr, &c);
-                return std::make_pair(rc, c);
-            }).share();
+            for (int dev : opt.devices)
+                ctx_ups.push_back(std::async(std::launch::async, [dev]() {
+                    jl_ctx *c = nullptr;
+                    const int rc = jl_ctx_create(dev, nullptr, &c);
+                    return std::make_pair(rc, c);
+                }).share());
             std::error_code ec;
             const uintmax_t fsz = std::filesystem::file_size(opt.bam, ec);
-            uploader.reset(new RecordUploader(ctx_up, ec ? 0 : (uint64_t)fsz, opt.min_qv > 0));
+            uploader.reset(new RecordUploader(ctx_ups, ec ? 0 : (uint64_t)fsz, opt.min_qv > 0));
             sink.give = [&uploader](RecordArrays &c) { uploader->give(c); };
         }
         // ONE pass over the file: records as decoded from BAM (cigar expansion, QV masking and the transpose run on
@@ -412,36 +602,95 @@ int main(int argc, char **argv)
             for (char ch : cfg.reference_sequence) refcodes.push_back(base_code(ch));
 
         // ---------------------------------------------------------------- device
-        const auto up = ctx_up.get();
-        jl_ctx *ctx = up.second;
-        if (up.first != JL_OK) die_jl(nullptr, "no usable GPU (this tool has no CPU fallback)");
+        jl_ctx *ctx = nullptr;
+        for (auto &f : ctx_ups) {
+            const auto up = f.get();
+            if (up.first != JL_OK) die_jl(nullptr, "no usable GPU (this tool has no CPU fallback)");
+            if (!ctx) ctx = up.second;
+        }
         tick("context ready");
-        if (uploader->finish() != JL_OK) die_jl(ctx, "record upload");
+        if (uploader->finish() != JL_OK) die_jl(uploader->failed() ? uploader->failed() : ctx, "record upload");
         if (uploader->n_reads != n_reads) die_jl(nullptr, "record upload lost reads");
         names.swap(uploader->names);
         tick("rest of the upload");
         if (opt.timing)
             fprintf(stderr, "juliet: timing   uploader thread: begin %.1f ms, %u appends %.1f ms (longest %.1f), names %.1f ms\n",
                     uploader->ms_begin, uploader->n_appends, uploader->ms_append, uploader->ms_append_max, uploader->ms_names);
+        const uint8_t *refp = refcodes.empty() ? nullptr : refcodes.data();
+        Results R;
+        R.col_counts.assign((size_t)n_cols * 6, 0);
+        DeviceStageInput in{&opt, &cfg, &genes, &refcodes, prm, win_begin, n_cols, n_reads};
+        const size_t n_ranks = opt.devices.size();
+        if (opt.windows > 1 || n_ranks > 1) {
+            // ---- K column windows over R devices (doc/JULIET.md:261-264: each gene is treated separately, so the split
+            // never shows): one rank (thread) per device; the Bonferroni factor counts the codons of ALL genes in every window
+            const uint32_t K = std::min<uint32_t>(opt.windows, std::max<uint32_t>(1, n_cols / 8));
+            if (K < n_ranks) { std::cerr << "juliet: the window is too narrow for " << n_ranks << " devices\n"; return 1; }
+            const std::vector<WindowPlan> plan = plan_windows(win_begin, n_cols, K, (uint32_t)n_ranks);
+            // read slices for phasing: starts on multiples of 256 reads (a 128-byte line of every column)
+            std::vector<uint64_t> slices(n_ranks + 1, n_reads);
+            {
+                uint64_t per = (n_reads + n_ranks - 1) / n_ranks;
+                per = (per + 255) / 256 * 256;
+                for (size_t r = 0; r < n_ranks; ++r) slices[r] = std::min<uint64_t>(n_reads, r * per);
+            }
+            uint8_t comm_id[128] = {0};
+            if (opt.phasing && n_ranks > 1 && jl_comm_unique_id(comm_id) != JL_OK) die_jl(nullptr, "communicator id");
+            std::vector<RankJob> jobs(n_ranks);
+            for (size_t r = 0; r < n_ranks; ++r) {
+                jobs[r].rank = (int)r;
+                jobs[r].world = (int)n_ranks;
+                jobs[r].device = opt.devices[r];
+                jobs[r].records = uploader->ctx(r);
+                for (uint32_t k = 0; k < K; ++k)
+                    if (plan[k].rank == (int)r) jobs[r].widx.push_back(k);
+            }
+            std::vector<std::thread> threads;
+            for (size_t r = 1; r < n_ranks; ++r)
+                threads.emplace_back([&, r] { run_rank(jobs[r], in, plan, comm_id, R.col_counts, slices); });
+            run_rank(jobs[0], in, plan, comm_id, R.col_counts, slices);
+            for (std::thread &t : threads) t.join();
+            for (const RankJob &j : jobs)
+                if (!j.error.empty()) { std::cerr << "juliet: rank " << j.rank << " (device " << j.device << "): " << j.error << "\n"; return 3; }
+            tick("windows: ingest + call + phase");
+            std::vector<uint32_t> cc;
+            cc.swap(R.col_counts);
+            if (opt.phasing) {
+                R = std::move(jobs[0].res);
+                R.read_hap.assign(n_reads, (uint16_t)JL_HAP_DAMAGED);
+                for (const RankJob &j : jobs) std::copy(j.ids.begin(), j.ids.end(), R.read_hap.begin() + (ptrdiff_t)j.slice_begin);
+            } else {
+                std::vector<const jl_variant *> tabs;
+                std::vector<uint32_t> cnt, begins;
+                for (const RankJob &j : jobs)
+                    for (size_t i = 0; i < j.tables.size(); ++i) {
+                        tabs.push_back(j.tables[i].data());
+                        cnt.push_back((uint32_t)j.tables[i].size());
+                        begins.push_back(plan[j.widx[i]].begin - win_begin);
+                    }
+                uint64_t total = 0;
+                for (uint32_t c : cnt) total += c;
+                R.var.resize(total ? total : 1);
+                uint32_t n = 0;
+                if (jl_merge_tables(tabs.data(), cnt.data(), begins.data(), (uint32_t)tabs.size(), R.var.data(), (uint32_t)R.var.size(), &n) != JL_OK)
+                    die_jl(nullptr, "merge of the windows' tables");
+                R.var.resize(n);
+            }
+            R.col_counts.swap(cc);
+            for (RankJob &j : jobs) {
+                for (jl_ctx *w : j.wins) jl_ctx_destroy(w);
+                if (j.comm) jl_comm_destroy(j.comm);
+                if (j.records) jl_ctx_destroy(j.records);
+            }
+            tick("kernels + fetch");
+        } else {
         if (!opt.consensus.empty()) jl_msa_track_insertions(ctx, 1);   // fuse keeps in-frame insertions (doc/FUSE.md:19)
         if (jl_records_finish(ctx, n_cols, win_begin, opt.min_qv) != JL_OK) die_jl(ctx, "ingest");
         tick("device ingest");
 
         // --drm-only needs the position list, which the plan of a first pileup provides
         std::vector<uint64_t> drm_masks;
-        const uint8_t *refp = refcodes.empty() ? nullptr : refcodes.data();
-        if (opt.drm_only) {
-            if (jl_pileup_async(ctx, genes.data(), (uint32_t)genes.size(), refp, (uint32_t)refcodes.size()) != JL_OK) die_jl(ctx, "pileup");
-            const uint32_t P = jl_n_positions(ctx);
-            std::vector<uint32_t> pg(P), pk(P);
-            if (jl_pileup_fetch(ctx, nullptr, pg.data(), pk.data(), nullptr, nullptr, nullptr) != JL_OK) die_jl(ctx, "pileup fetch");
-            drm_masks.assign(P, 0);
-            for (uint32_t p = 0; p < P; ++p) {
-                const GeneCfg &g = cfg.genes[pg[p]];
-                for (unsigned cod = 0; cod < 64; ++cod)
-                    if (!cfg.known_drms(pg[p], pk[p] + g.first_codon, translate(cod)).empty()) drm_masks[p] |= 1ull << cod;
-            }
-        }
+        if (opt.drm_only && drm_masks_of(ctx, in, drm_masks)) die_jl(ctx, "pileup");
         if (opt.fuse_only) {   // the column pileup is all a consensus needs
             if (jl_pileup_async(ctx, genes.data(), (uint32_t)genes.size(), refp, (uint32_t)refcodes.size()) != JL_OK) die_jl(ctx, "pileup");
         } else if (jl_run_async(ctx, genes.data(), (uint32_t)genes.size(), refp, (uint32_t)refcodes.size(), &prm,
@@ -449,17 +698,16 @@ int main(int argc, char **argv)
             die_jl(ctx, "run");
         tick("plan + enqueue");
 
-        std::vector<jl_variant> var(4096);
+        R.var.resize(4096);
         uint32_t nv = 0;
-        if (!opt.fuse_only && jl_call_fetch(ctx, var.data(), 4096, &nv) != JL_OK) die_jl(ctx, "call fetch");
-        var.resize(nv);
-        std::vector<uint32_t> col_counts((size_t)n_cols * 6);
-        if (jl_pileup_fetch(ctx, col_counts.data(), nullptr, nullptr, nullptr, nullptr, nullptr) != JL_OK) die_jl(ctx, "pileup fetch");
+        if (!opt.fuse_only && jl_call_fetch(ctx, R.var.data(), 4096, &nv) != JL_OK) die_jl(ctx, "call fetch");
+        R.var.resize(nv);
+        if (jl_pileup_fetch(ctx, R.col_counts.data(), nullptr, nullptr, nullptr, nullptr, nullptr) != JL_OK) die_jl(ctx, "pileup fetch");
 
         if (!opt.consensus.empty()) {  // what `fuse` writes for this window (doc/FUSE.md:17-24)
             std::vector<uint32_t> len_hist((size_t)n_cols * 32), base_counts((size_t)n_cols * 120);
             if (jl_insertions_fetch(ctx, len_hist.data(), base_counts.data()) != JL_OK) die_jl(ctx, "insertions");
-            const std::string seq = fuse_consensus(n_cols, col_counts, len_hist, base_counts, opt.ins_min_frac, opt.ins_min_distance);
+            const std::string seq = fuse_consensus(n_cols, R.col_counts, len_hist, base_counts, opt.ins_min_frac, opt.ins_min_distance);
             std::ofstream f(opt.consensus);
             if (!f) { std::cerr << "juliet: cannot write " << opt.consensus << "\n"; return 2; }
             f << ">consensus window=" << (win_begin + 1) << "-" << (win_begin + n_cols) << " source=" << opt.bam << "\n";
@@ -470,22 +718,27 @@ int main(int argc, char **argv)
             jl_ctx_destroy(ctx);
             return 0;
         }
-        jl_phase_summary ps = {};
-        std::vector<uint32_t> pos_cols, hap_count;
-        std::vector<uint8_t> hap_pattern, hit;
-        std::vector<uint16_t> read_hap;
         const uint32_t cap_var = std::max<uint32_t>(1, nv);
         if (opt.phasing) {
-            pos_cols.resize(cap_var);
-            hap_count.resize(JL_MAX_HAPLOTYPES);
-            hap_pattern.resize((size_t)JL_MAX_HAPLOTYPES * cap_var);
-            hit.resize((size_t)cap_var * JL_MAX_HAPLOTYPES);
-            read_hap.resize(n_reads);
-            if (jl_phase_fetch(ctx, &ps, pos_cols.data(), hap_count.data(), hap_pattern.data(), hit.data(), read_hap.data(), nullptr, cap_var) != JL_OK)
+            R.pos_cols.resize(cap_var);
+            R.hap_count.resize(JL_MAX_HAPLOTYPES);
+            R.hap_pattern.resize((size_t)JL_MAX_HAPLOTYPES * cap_var);
+            R.hit.resize((size_t)cap_var * JL_MAX_HAPLOTYPES);
+            R.read_hap.resize(n_reads);
+            R.pat_stride = cap_var;
+            R.hit_stride = JL_MAX_HAPLOTYPES;
+            if (jl_phase_fetch(ctx, &R.ps, R.pos_cols.data(), R.hap_count.data(), R.hap_pattern.data(), R.hit.data(), R.read_hap.data(), nullptr, cap_var) != JL_OK)
                 die_jl(ctx, "phase fetch");
         }
         tick("kernels + fetch");
         jl_ctx_destroy(ctx);
+        }
+        const std::vector<jl_variant> &var = R.var;
+        const std::vector<uint32_t> &col_counts = R.col_counts;
+        const jl_phase_summary &ps = R.ps;
+        const std::vector<uint32_t> &pos_cols = R.pos_cols, &hap_count = R.hap_count;
+        const std::vector<uint8_t> &hap_pattern = R.hap_pattern, &hit = R.hit;
+        const std::vector<uint16_t> &read_hap = R.read_hap;
 
         // ---------------------------------------------------------------- JSON (doc/JULIET.md:61-107, 207-211)
         Json root = Json::object();
@@ -543,7 +796,7 @@ int main(int argc, char **argv)
                         cj.set("known_drm", Json::of(cfg.known_drms(g, aa_pos, aa)));
                         if (opt.phasing) {
                             Json hh = Json::array();
-                            for (uint32_t h = 0; h < H; ++h) hh.push(Json::of(hit[(size_t)k * JL_MAX_HAPLOTYPES + h] != 0));
+                            for (uint32_t h = 0; h < H; ++h) hh.push(Json::of(hit[(size_t)k * R.hit_stride + h] != 0));
                             cj.set("haplotype_hit", hh);  // doc/JULIET.md:207-209
                         }
                         cods.push(cj);
@@ -615,7 +868,7 @@ int main(int argc, char **argv)
                 hj.set("name", Json::of(haplotype_name(h))).set("reads", Json::of(hap_count[h]));
                 hj.set("frequency", Json::of(ps.reported_reads ? (double)hap_count[h] / (double)ps.reported_reads : 0.0));
                 Json cods = Json::array();
-                for (uint32_t p = 0; p < ps.n_positions; ++p) cods.push(Json::of(codon_string(hap_pattern[(size_t)h * cap_var + p])));
+                for (uint32_t p = 0; p < ps.n_positions; ++p) cods.push(Json::of(codon_string(hap_pattern[(size_t)h * R.pat_stride + p])));
                 hj.set("codons", cods);
                 Json rn = Json::array();
                 for (uint32_t i : members[h]) rn.push(Json::of(names[i]));

@@ -383,3 +383,76 @@ def test_consensus_keeps_in_frame_majority_insertions(tmp_path, oracle):
     rows = synth.rows(synth.SynthParams(seed=seed), l, 0, n, ref)
     exp = oracle.call(rows, np.array([(1, l + 1)], dtype=capi.GENE), refseq=ref)
     assert [(r[1], r[2]) for r in flat_variants(j1)] == [(e["codon_pos"], e["codon"]) for e in exp]
+
+
+def _strip(j):
+    """A JSON document without what legitimately differs between two runs of the same input."""
+    j = json.loads(json.dumps(j))
+    j["input"].pop("timestamp")
+    j["input"].pop("command_line")
+    return j
+
+
+@pytest.mark.parametrize("extra", [("--mode-phasing",), (), ("--mode-phasing", "--drm-only"), ("--mode-phasing", "--max-perc", "90")])
+def test_windows_give_the_json_of_one_window(sample, oracle, extra):
+    """`juliet --windows K` (doc/JULIET.md:261-264: each gene is treated separately, so cutting the reference into column
+    windows never shows): the BAM is decoded and uploaded once, K windows are called with the global Bonferroni factor,
+    phasing runs across the windows — and the JSON is the one-window JSON, byte for byte outside the input block."""
+    d, bam, cfg, rows, ref = sample
+    one = run_juliet(d, bam, "-c", cfg, *extra, out="w1.json")
+    for k in (2, 3, 8):
+        many = run_juliet(d, bam, "-c", cfg, "--windows", str(k), *extra, out=f"w{k}.json")
+        assert _strip(many) == _strip(one), k
+    if extra == ("--mode-phasing",):       # ... and it is the oracle's answer
+        genes = np.array([(1, L + 1)], dtype=capi.GENE)
+        table = oracle.call(rows, genes, refseq=ref)
+        exp = oracle.phase(rows, table)
+        hb = one["haplotype"]
+        assert [h["reads"] for h in hb["haplotypes"]] == exp["hap_count"].tolist()
+        assert hb["reported_reads"] == exp["summary"]["reported_reads"] and hb["damaged_reads"] == exp["summary"]["damaged_reads"]
+
+
+def test_windows_on_a_long_reference_with_overlapping_genes(tmp_path, oracle):
+    """A reduced configs[3]: 20 000 reads x 10 kb, three genes in different frames (two overlap), eight windows on one GPU
+    against the one-window run and the oracle."""
+    n, l, seed = 20000, 10000, 11
+    bam, cfg = str(tmp_path / "long.bam"), str(tmp_path / "cfg.json")
+    subprocess.check_call([SYNTH, "--reads", str(n), "--cols", str(l), "--seed", str(seed), "--minor-permille", "60", "50", "40", "30",
+                           "-o", bam, "--config-out", cfg])
+    c = json.load(open(cfg))
+    c["genes"] = [dict(name="g0", begin=1, end=3001, drms=[]), dict(name="g1", begin=2900, end=7100, drms=[]),
+                  dict(name="g2", begin=7102, end=10000, drms=[])]
+    json.dump(c, open(cfg, "w"))
+    one = run_juliet(tmp_path, bam, "-c", cfg, "--mode-phasing", out="one.json")
+    many = run_juliet(tmp_path, bam, "-c", cfg, "--mode-phasing", "--windows", "8", out="many.json")
+    assert _strip(many) == _strip(one)
+    sp = synth.SynthParams(seed=seed, minor_permille=(60, 50, 40, 30))
+    ref = synth.reference(seed, l)
+    rows = synth.rows(sp, l, 0, n, ref)
+    genes = np.array([(1, 3001), (2900, 7100), (7102, 10000)], dtype=capi.GENE)
+    table = oracle.call(rows, genes, refseq=ref)
+    got = flat_variants(many)
+    assert len(got) == len(table) >= 4
+    for (gi, pos, cod, vc, vp, aa), e in zip(got, table):
+        assert (gi, pos, cod) == (e["gene"], e["codon_pos"], e["codon"]) and vc["count"] == e["count"] and vp["coverage"] == e["coverage"]
+    exp = oracle.phase(rows, table)
+    assert [h["reads"] for h in many["haplotype"]["haplotypes"]] == exp["hap_count"].tolist()
+    assert len(many["haplotype"]["variant_positions_abs"]) == exp["summary"]["n_positions"]
+
+
+def test_two_ranks_on_one_device(sample, tmp_path):
+    """`--devices a,b` starts one rank (thread) per device, each with consecutive windows of its own.  One GPU per box
+    here, so the two ranks share device 0 — call only: phasing across ranks needs an RCCL communicator, and RCCL refuses
+    two ranks on one device (a loud failure, not a hang).  The JSON is the one-window JSON.
+    (The rank threads cannot run under ThreadSanitizer: a TSan build of the front end dies at start-up once the GPU runtime
+    maps its apertures, and the container that runs the sanitizer tests has no GPU, so the ranks never start there.  What
+    they share is small: disjoint ranges of one column-count array and a job record each.)"""
+    d, bam, cfg, rows, ref = sample
+    one = run_juliet(d, bam, "-c", cfg, out="r1.json")
+    for k in (2, 5):
+        two = run_juliet(d, bam, "-c", cfg, "--windows", str(k), "--devices", "0,0", out=f"r{k}.json")
+        assert _strip(two) == _strip(one)
+    out = str(tmp_path / "t.json")
+    r = subprocess.run([JULIET, "-c", cfg, "--mode-phasing", "--windows", "4", "--devices", "0,0", bam, out], capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode == 3 and "communicator" in r.stderr
