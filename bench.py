@@ -44,6 +44,11 @@ N_READS = 100_000
 N_COLS = 3000
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 C3_READS, C3_COLS = 1_000_000, 10_000   # BASELINE.json configs[3]
+C4_READS, C4_COLS = 10_000_000, 9719    # BASELINE.json configs[4]: full-HIV reference, deep coverage
+# genes as on doc/img/juliet_target.png (5'LTR ... Protease; p6 / Protease overlap in different frames), continued with
+# HIV-like ORFs in all three frames (tests/test_gpu_configs.py checks this layout against the oracle at full size)
+HIV_GENES = [(1, 634), (790, 1186), (1186, 1879), (1879, 1921), (1921, 2086), (2086, 2134), (2134, 2292), (2253, 2550),
+             (2550, 4230), (4230, 5096), (5041, 5619), (5559, 5850), (6062, 6310), (6225, 8795), (8797, 9417)]
 
 
 def cpu_baseline(jl, genes, ref, expect, budget_s=12.0, threads=1, rows=None):
@@ -106,7 +111,8 @@ def main():
     ap.add_argument("--cols", type=int, default=N_COLS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-config3", action="store_true", help="skip the configs[3] strong-scaling measurement")
-    ap.add_argument("--config3-timeout", type=float, default=120.0, help="N > 1: seconds the configs[3] measurement may take")
+    ap.add_argument("--no-config4", action="store_true", help="skip the configs[4] strong-scaling measurement (48.6 GB / N per GPU)")
+    ap.add_argument("--config3-timeout", type=float, default=180.0, help="N > 1: seconds the configs[3] + configs[4] measurements may take")
     ap.add_argument("--inflight", type=int, default=4,
                     help="launches in flight per GPU (each on its own stream, with its own captured graph)")
     ap.add_argument("--group", type=int, default=8,
@@ -452,7 +458,8 @@ def main():
         # run with one rank on hardware: should it fail or stall on some rank, every rank leaves after
         # `--config3-timeout` seconds and the line still goes out with what was measured, the failure named in it.
         def leave(reason):
-            out["config3_strong"] = {"error": reason, "scaling": "strong", "n_gpus": world}
+            out.setdefault("config3_strong", {"error": reason, "scaling": "strong", "n_gpus": world})
+            out.setdefault("config4_strong", {"error": reason, "scaling": "strong", "n_gpus": world})
             if rank == 0:
                 os.write(real_stdout, (json.dumps(out) + "\n").encode())
             os._exit(3)   # the line is out, and the failure shows in the exit code too
@@ -463,6 +470,11 @@ def main():
         try:
             out["config3_strong"] = config3_strong(capi, sharding, synth, torch, dist, distributed, comm, rank, world, local_rank,
                                                    [c for c in ctxs[1:]])
+            if not args.no_config4:
+                # configs[4] the same way: 10M reads x 9719 columns (48.6 GB / N per rank) — the workload whose pileup is long
+                # enough for the fixed costs of a step (launches, hand-offs, three small exchanges) to leave 1 -> 8 room
+                out["config4_strong"] = config3_strong(capi, sharding, synth, torch, dist, distributed, comm, rank, world, local_rank,
+                                                       [], reps=6, which=4)
         except Exception as exc:   # noqa: BLE001 — at N > 1 the other ranks are inside a collective: they leave by their timers
             if not distributed:
                 raise
@@ -484,9 +496,11 @@ def main():
         dist.destroy_process_group()
 
 
-def config3_strong(capi, sharding, synth, torch, dist, distributed, comm, rank, world, local_rank, free_ctxs, reps=12):
+def config3_strong(capi, sharding, synth, torch, dist, distributed, comm, rank, world, local_rank, free_ctxs, reps=12,
+                   which=3):
     """BASELINE.json configs[3] as stated: 1M CCS reads x ONE 10 kb reference, split into `world` column windows (rank
-    r holds the 1M reads' columns of window r: 5 GB / world).  A step = call per window with the GLOBAL Bonferroni
+    r holds the 1M reads' columns of window r: 5 GB / world).  `which` = 4: configs[4] the same way — 10M reads x the
+    9719-column full-HIV reference with fifteen ORFs in three frames (48.6 GB / world per rank).  A step = call per window with the GLOBAL Bonferroni
     factor (jl_run_async, phasing off) and ONE call of the C ABI for the rest (jl_xwin_phase_sharded): all-gather of the
     variant table (RCCL) -> merge + plan -> one packed send per peer of the variant columns' read slices (RCCL; SURVEY 8e
     option A) -> every rank groups its 1M/world reads -> all-gather of the group tables (RCCL) -> merge + selection on the
@@ -497,10 +511,15 @@ def config3_strong(capi, sharding, synth, torch, dist, distributed, comm, rank, 
     # The weak-scaling batches stay allocated (4.8 + 5 GB of 288): device memory that was freed and is allocated again
     # runs slower on this driver — the pileup by 4 %, the phasing's random-access tables 3x (tools_tuning/
     # config3_stages.py runs both generations) — and a job that runs configs[3] alone never sees second-hand memory.
-    n, l = C3_READS, C3_COLS
-    sp = synth.SynthParams(seed=4)
+    if which == 4:
+        n, l = C4_READS, C4_COLS
+        sp = synth.SynthParams(seed=5)
+        genes = np.array(HIV_GENES, dtype=capi.GENE)
+    else:
+        n, l = C3_READS, C3_COLS
+        sp = synth.SynthParams(seed=4)
+        genes = np.array([(1, 3 * (l // 3) + 1)], dtype=capi.GENE)
     ref = synth.reference(sp.seed, l)
-    genes = np.array([(1, 3 * (l // 3) + 1)], dtype=capi.GENE)
     prm = capi.default_params(n_tests=sharding.default_n_tests(genes))
     wb = sharding.window_bounds(l, world)
     b, e = wb[rank]
@@ -545,7 +564,7 @@ def config3_strong(capi, sharding, synth, torch, dist, distributed, comm, rank, 
     if world == 1:   # every read's id is consistent with the categories
         assert int((ids == capi.HAP_DAMAGED).sum()) == s["damaged_reads"] and int((ids < s["n_haplotypes"]).sum()) == s["reported_reads"]
     t_k = win.time_pileup(reps=5)
-    out = {"workload": f"configs[3]: {n} CCS reads x {l} bp reference split into {world} column window(s), call per window + "
+    out = {"workload": f"configs[{which}]: {n} CCS reads x {l} bp reference ({len(genes)} ORF(s)) split into {world} column window(s), call per window + "
                        "jl_xwin_phase_sharded (all-gather of the table, packed column-slice exchange, grouping per read slice, "
                        "all-gather + C++ merge of the group tables, ids: SURVEY 8e option A)",
            "value": n / t, "unit": "reads/s", "ms_per_step": 1000.0 * t, "ms_per_step_median": 1000.0 * t_median,

@@ -197,3 +197,91 @@ def test_config4_per_gpu_share_ten_million_reads(oracle):
         assert s["reported_reads"] + s["insufficient_reads"] + s["damaged_reads"] == n
     finally:
         oracle.set_threads(1)
+
+
+def test_config4_whole_reference_eight_windows_resident_on_one_gpu(oracle):
+    """configs[4] WHOLE on one MI355X: 10M CCS reads x the 9719-column full-HIV reference (48.6 GB of 288) as the eight
+    column windows an 8-GPU run gives one rank each, all resident together; fifteen ORFs in three frames, several of
+    them overlapping across window borders.  Checked at full size:
+      * every window's column counts and histograms by their size-independent properties (one symbol per read and column,
+        histogram sums = coverage <= column depth);
+      * calls and column counts against the oracle over ALL 9719 columns of the full 10M reads, by column chunks (calls are
+        independent per column given the global Bonferroni factor), bit-exact;
+      * phasing across the eight windows — once through the session (jl_xwin_phase_sharded) and once with the reads cut into
+        eight slices as eight ranks would hold them — against the oracle on the variant columns of all 10M reads;
+      * the read categories add up to 10M (doc/JULIET.md:378-379)."""
+    n, l, world = 10_000_000, 9719, 8
+    sp = synth.SynthParams(seed=5)
+    ref = synth.reference(sp.seed, l)
+    genes = np.array(HIV_GENES, dtype=capi.GENE)
+    prm = capi.default_params(n_tests=sharding.default_n_tests(genes))
+    oprm = oracle_params(prm)
+    wb = sharding.window_bounds(l, world)
+    ctxs, tables = [], []
+    for b, e in wb:                                              # all eight windows resident before anything runs
+        c = capi.Juliet(0)
+        c.alloc(n, e - b, win_begin=b)
+        c.synth_fill_window(sp, ref)
+        ctxs.append(c)
+    for c in ctxs:
+        c.run_async(genes, ref, prm, None, False, 10, False)     # call only, every window with the GLOBAL Bonferroni factor
+    oracle.set_threads(THREADS)
+    try:
+        var_cols = {}                                            # global column -> packed [3][stride] of the variant codon
+        chunk = 100
+        checked_chunks = total_chunks = 0
+        for (b, e), c in zip(wb, ctxs):
+            got = c.run_fetch(False, False)["variants"].copy()
+            tables.append(got)
+            pf = c.pileup_fetch()
+            check_pileup_properties(pf, n, True)
+            packed = c.download_columns()
+            lw = e - b
+            k = max(1, (lw + chunk - 1) // chunk)
+            bounds = sharding.window_bounds(lw, k)
+            total_chunks += k
+            for i, (cb, ce) in enumerate(bounds):
+                checked_chunks += 1
+                rows = msa.unpack_columns(packed[cb:ce], n)
+                assert (pf["col_counts"][cb:ce] == oracle.pileup(rows)).all()
+                ev = oracle.call(rows, genes, win_begin=b + cb, refseq=ref, params=oprm)
+                ev["col"] += np.uint32(cb)
+                # the device's rows whose codon lies inside this chunk (chunks overlap by two columns: a codon is in one)
+                own_hi = ce - 2 if i + 1 < k else ce
+                mine = got[(got["col"] >= cb) & (got["col"] < own_hi)]
+                ev = ev[(ev["col"] >= cb) & (ev["col"] < own_hi)]
+                assert_variants_equal(mine, ev[np.lexsort((ev["codon"], ev["codon_pos"], ev["gene"]))])
+                del rows
+            for col in np.unique(got["col"]):
+                var_cols[b + int(col)] = packed[int(col): int(col) + 3].copy()
+            del packed
+        assert checked_chunks == total_chunks >= 96
+        merged = sharding.merge_tables(tables, [b for b, _ in wb])
+        assert len(merged) >= 5 and len(np.unique(merged["gene"])) >= 3 and len({int(c) * world // l for c in merged["col"]}) >= 2   # the planted edits span two windows and three ORFs
+        assert (merged["p_value"] == 0.0).any() and np.isfinite(merged["log_p"]).all()      # p underflows at 1e7 reads, log-p is carried
+        # the oracle's phasing on the variant columns of all 10M reads
+        pos = np.array(sorted(var_cols), dtype=np.uint32)
+        assert (pos == np.unique(merged["col"])).all()
+        rows_v = msa.unpack_columns(np.concatenate([var_cols[int(c)] for c in pos]), n)
+        ev = merged.copy()
+        ev["col"] = [3 * int(np.searchsorted(pos, c)) for c in merged["col"]]
+        exp = oracle.phase(rows_v, ev)
+        exp["pos_cols"] = pos
+        del rows_v
+        # (a) the session: one call of the C ABI
+        xw = capi.Xwin(ctxs, [b for b, _ in wb], [e - b for b, e in wb], [0] * world, [0, n])
+        res = xw.phase(10)
+        xw.close()
+        assert_variants_equal(res["merged"], merged)
+        assert_phase_equal(res, exp, len(merged))
+        s = res["summary"]
+        assert s["reported_reads"] + s["insufficient_reads"] + s["damaged_reads"] == n
+        assert s["n_haplotypes"] >= 5 and res["hit"][:, 0].sum() == 0
+        # (b) the reads in eight slices, as eight ranks would hold them
+        ph, pos_global = capi.phase_sharded_by_reads(ctxs, merged, world)
+        assert (pos_global == pos).all()
+        assert_phase_equal(dict(ph, pos_cols=pos_global), exp, len(merged))
+    finally:
+        oracle.set_threads(1)
+        for c in ctxs:
+            c.close()
