@@ -419,7 +419,10 @@ def main():
 
     step_bytes = n * l / 2.0
     out = {
-        "metric": "aligned CCS reads/sec through juliet call+phase",
+        # at N > 1 `value` is WEAK scaling (one independent 100k x 3kb window per GPU and batch); ONE reference split over
+        # the GPUs (strong scaling) is config3_strong / config4_strong in the same line
+        "metric": "aligned CCS reads/sec through juliet call+phase" + (" (weak scaling: independent windows per GPU; strong scaling "
+                                                                        "of one reference: config3_strong, config4_strong)" if world > 1 else ""),
         "value": world * n / (ms_per_step * 1e-3),
         "unit": "reads/s",
         "n_gpus": world,

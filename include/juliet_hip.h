@@ -287,8 +287,7 @@ int jl_expand_read_hap(const void *packed, uint32_t bits, uint64_t n_reads, uint
 
 /*
  * Group runs: the whole path for SEVERAL (at most 32) resident windows (one context each, same device) in a few launches —
- * per stage ONE launch for up to eight windows (blockIdx.z = window): counting with the Fisher stage in its epilogue,
- * phasing, per-read ids.  A 150 MB window is too short a stream to hide a launch's ramp and drain, and its phasing stage
+ * per stage ONE launch for up to eight windows (blockIdx.z = window): counting, the Fisher stage, phasing, per-read ids.  A 150 MB window is too short a stream to hide a launch's ramp and drain, and its phasing stage
  * is a latency chain that occupies a hardware queue while doing little; grouped, the pileup runs at the rate of one long
  * stream and the latency chains of all windows overlap.  Groups of more than eight windows are pipelined inside the
  * launch: the counting of the next eight runs beside the phasing of the previous eight.

@@ -3,6 +3,7 @@
 #include <stdarg.h>
 #include <stddef.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -18,6 +19,12 @@
 #endif
 
 static thread_local std::string g_create_error;
+
+// The HIP runtime multiplexes a process's streams onto 4 hardware queues unless told otherwise, and reads the setting when
+// it initialises, i.e. at the process's first HIP call.  A host that keeps several launches in flight beside an exchange
+// wants 8: set here, when the library is loaded, unless the environment already says something — which
+// takes effect whenever this library is loaded before anything in the process has touched HIP.
+__attribute__((constructor)) static void jl_runtime_defaults() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
 
 int jl_fail(jl_ctx *ctx, int status, const char *fmt, ...)
 {

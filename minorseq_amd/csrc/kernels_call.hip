@@ -3,11 +3,11 @@
 // to the number of expected mutations ... Bonferroni-corrected Fisher's Exact test"), :133-134
 // (reference codon vs major codon), :342-357 (min/max percentage), :370 (drm-only); docs/SPEC.md §4-7.
 //
-// The evaluation of one position (one wave, lane = codon) is call_eval.h.  In a whole-path run it rides in the
-// epilogue of the pileup launch (kernels_pileup.hip, CALL): the workgroup that counted a codon tests it from the
-// histogram still in LDS.  The kernels here serve the rest:
-//   call_kernel     the same evaluation from histograms in HBM — the stage API (jl_call_async) and windows so deep
-//                   that several workgroups count one chunk (their histogram is complete only when the launch ends)
+// The evaluation of one position (one wave, lane = codon) is call_eval.h.  The kernels here run it:
+//   call_kernel     from the histograms the pileup launch left in HBM — every run and the stage API (jl_call_async).
+//                   (A variant that rides in the epilogue of the pileup launch, the workgroup that counted a codon
+//                   testing it from the histogram still in LDS, is built only with -DJL_FUSED_CALL: measured slower,
+//                   DESIGN.md "Tried and not kept".)
 //   compact_kernel  one workgroup per window: the called rows in (gene, codon, codon index) order into the
 //                   fixed-stride table (SPEC §6); optionally the distinct variant columns for the multi-word phasing
 //                   pipeline (phase_plan.h) and, for runs without phasing, the result block and the completion word

@@ -1240,6 +1240,14 @@ __device__ __forceinline__ void phase_fused1_body(const jl_win_phase &w, const j
         if (prev == n_arrive - 1u) {
             __hip_atomic_store(S.arrive2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(S.flag, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // A workgroup that gave up waiting marked the run failed; a selection that was only LATE has since written a
+            // valid result block over that mark.  The mark in the run's scalars is the lasting one: whoever arrives last
+            // makes the blocks say so again, just before the completion word.
+            if (ld_coherent(&meta->overflow) & 32u) {
+                if (S.mirror) __hip_atomic_store(&S.mirror->magic, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                jl_pack *pk = S.pk + (__hip_atomic_load(S.seq_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 1u);
+                __hip_atomic_store(&pk->magic, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
             if (S.seq_host) signal_done(S.seq_dev, S.seq_host);
         }
     }

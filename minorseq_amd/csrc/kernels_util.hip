@@ -211,7 +211,8 @@ __global__ __launch_bounds__(256) void expand_rows_kernel(uint64_t r0, uint64_t 
                     else hi = mid;
                 }
                 uint32_t i = lo ? lo - 1u : 0u;
-                const uint32_t ncol = (uint64_t)d * 8u + 8u <= n_cols ? 8u : n_cols - d * 8u;
+                // (scratch dwords wholly past the last column hold no column at all)
+                const uint32_t ncol = (uint64_t)d * 8u + 8u <= n_cols ? 8u : ((uint64_t)d * 8u < n_cols ? n_cols - d * 8u : 0u);
                 uint32_t j = (uint32_t)((int64_t)xs - x0);   // first column of the dword this piece covers
                 if (s_rbeg[i] > xs) j = ncol;                // (only a piece that begins with ops without reference)
                 while (j < ncol && i < n_runs) {
@@ -325,8 +326,8 @@ __global__ __launch_bounds__(256) void transpose_rows_kernel(const uint32_t *__r
 
 // Insertions per window column (doc/FUSE.md:19 "Fuse includes in-frame insertions"): they are not part of the MSA
 // (doc/JULIET.md:26-27), so they are counted from the records.  One thread per read walks its cigar; an insertion sits
-// BEFORE the window column of the next reference base: len_hist[c][min(len, 31)]++, base_counts[c][j][base]++ for the
-// inserted bases at offsets j < 30.  Integer atomics commute: bit-exact against the oracle's loops.
+// BEFORE the window column of the next reference base: len_hist[c][min(len, 31)]++, and for IN-FRAME insertions of at most
+// 30 bases base_counts[c][j][base]++ for the inserted bases.  Integer atomics commute: bit-exact against the oracle's loops.
 __global__ __launch_bounds__(256) void insertions_kernel(uint64_t n_reads, uint32_t n_cols, uint32_t win_begin,
                                                           const int32_t *__restrict__ pos, const uint32_t *__restrict__ cigar,
                                                           const uint64_t *__restrict__ cig_off, const uint8_t *__restrict__ seq4,
@@ -345,7 +346,10 @@ __global__ __launch_bounds__(256) void insertions_kernel(uint64_t n_reads, uint3
             const int64_t c = rp - (int64_t)win_begin;
             if (c >= 0 && c < (int64_t)n_cols) {
                 atomicAdd(&len_hist[(uint64_t)c * JL_INS_LEN_BINS + (len < 31u ? len : 31u)], 1u);
-                for (uint32_t j = 0; j < len && j < JL_INS_MAX_BASES; ++j) {
+                // bases only of insertions that can enter a consensus: in-frame, at most 30 long (an out-of-frame insertion
+                // at the same column must not vote on the bases of the accepted one; SPEC §11)
+                const bool votes = len % 3u == 0u && len <= JL_INS_MAX_BASES;
+                for (uint32_t j = 0; votes && j < len; ++j) {
                     const uint64_t q = qp + j;
                     if (q >= n_bases) break;   // malformed input stays inside the read's bases
                     const uint32_t b16 = (q & 1u) ? (sq[q >> 1] & 15u) : (sq[q >> 1] >> 4);

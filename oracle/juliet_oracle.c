@@ -10,7 +10,7 @@
  * doc/JULIET.md as J:line, and follows docs/SPEC.md for each constant the text leaves open.
  * What pins it: (i) tests/golden/fisher_golden.json (mpmath 50-digit hypergeometric tails, made by
  * tests/golden/make_fisher_golden.py), (ii) the screenshot relationships of SURVEY.md Appendix A
- * (tests/test_oracle_appendix_a.py).
+ * (tests/test_oracle_golden_rows.py: every printed row, the A-I table, the FAQ scenarios).
  *
  * Deliberately simple: by-row uint8 MSA, plain loops, long-double lgammal for the test.
  * Independent of the device code: shares no header with it.
@@ -533,7 +533,8 @@ int orc_insertions(uint64_t n_reads, uint32_t n_cols, uint32_t win_begin, const 
                 int64_t c = rp - (int64_t)win_begin;
                 if (c >= 0 && c < (int64_t)n_cols) {
                     len_hist[(size_t)c * ORC_INS_LEN_BINS + (len < 31 ? len : 31)]++;
-                    for (uint32_t j = 0; j < len && j < ORC_INS_MAX_BASES; ++j) {
+                    /* only insertions that can enter a consensus vote on its bases: in-frame, at most 30 long (SPEC 11) */
+                    for (uint32_t j = 0; len % 3 == 0 && len <= ORC_INS_MAX_BASES && j < len; ++j) {
                         uint64_t q = qp + j;
                         uint8_t b16 = (q & 1) ? (sq[q >> 1] & 15) : (sq[q >> 1] >> 4);
                         uint8_t b = code_of[b16];
@@ -593,5 +594,104 @@ uint32_t orc_fuse(uint32_t n_cols, const uint32_t *col_counts, const uint32_t *l
         if (bv == 0) out[n++] = 'N';
         else if (best < 4) out[n++] = "ACGT"[best];
     }
+    return n;
+}
+
+/*
+ * The same consensus computed a second way, straight from the aligned records and the by-row matrix — no counters: the
+ * insertions of every read are collected as explicit records (column, length, bases), sorted by column, and each column is
+ * decided from its own records and from a sweep over the matrix rows.  This is the checker of the front end's consensus
+ * (minorseq_amd/host/fuse.hpp works from the device's counters; the two share nothing but the rule of SPEC 11).
+ * rows: uint8[n_reads][n_cols] symbol codes of the window.  Returns the length written to `out` (at most n_cols * 31).
+ */
+typedef struct { uint32_t col, len; uint8_t base[ORC_INS_MAX_BASES]; } orc_ins_rec;
+
+static int orc_ins_cmp(const void *a, const void *b)
+{
+    const orc_ins_rec *x = (const orc_ins_rec *)a, *y = (const orc_ins_rec *)b;
+    return x->col < y->col ? -1 : x->col > y->col;
+}
+
+uint32_t orc_fuse_records(const uint8_t *rows, uint64_t n_reads, uint32_t n_cols, uint32_t win_begin, const int32_t *pos,
+                          const uint32_t *cigar, const uint64_t *cig_off, const uint8_t *seq4, const uint64_t *seq_off,
+                          double min_frac, uint32_t min_distance, char *out)
+{
+    static const char nt16[] = "=ACMGRSVTWYHKDBN";
+    /* pass 1: one record per insertion that starts inside the window */
+    size_t cap = 1024, n_rec = 0;
+    orc_ins_rec *rec = (orc_ins_rec *)malloc(cap * sizeof *rec);
+    for (uint64_t r = 0; r < n_reads && rec; ++r) {
+        int64_t ref = pos[r];
+        uint64_t q = 0;
+        for (uint64_t k = cig_off[r]; k < cig_off[r + 1]; ++k) {
+            const uint32_t op = cigar[k] & 15u, len = cigar[k] >> 4;
+            const int consumes_query = op == 0 || op == 1 || op == 4 || op == 7 || op == 8;
+            const int consumes_ref = op == 0 || op == 2 || op == 3 || op == 7 || op == 8;
+            if (op == 1 && ref >= (int64_t)win_begin && ref < (int64_t)win_begin + n_cols) {
+                if (n_rec == cap) {
+                    cap *= 2;
+                    rec = (orc_ins_rec *)realloc(rec, cap * sizeof *rec);
+                    if (!rec) break;
+                }
+                orc_ins_rec *x = &rec[n_rec++];
+                x->col = (uint32_t)(ref - (int64_t)win_begin);
+                x->len = len;
+                for (uint32_t j = 0; j < len && j < ORC_INS_MAX_BASES; ++j) {
+                    const uint64_t b = q + j;
+                    const uint8_t code = (b & 1) ? (uint8_t)(seq4[seq_off[r] + (b >> 1)] & 15) : (uint8_t)(seq4[seq_off[r] + (b >> 1)] >> 4);
+                    x->base[j] = (uint8_t)nt16[code];
+                }
+            }
+            if (consumes_query) q += len;
+            if (consumes_ref) ref += len;
+        }
+    }
+    if (!rec) return 0;
+    qsort(rec, n_rec, sizeof *rec, orc_ins_cmp);
+    /* pass 2: column by column */
+    uint32_t n = 0;
+    size_t at = 0;
+    int have_last = 0;
+    uint32_t last_col = 0;
+    for (uint32_t c = 0; c < n_cols; ++c) {
+        uint32_t sym[7] = {0, 0, 0, 0, 0, 0, 0};
+        for (uint64_t r = 0; r < n_reads; ++r) sym[rows[r * n_cols + c] < 7 ? rows[r * n_cols + c] : 6]++;
+        const uint32_t covering = sym[0] + sym[1] + sym[2] + sym[3] + sym[4] + sym[5];
+        const size_t first = at;
+        while (at < n_rec && rec[at].col == c) ++at;
+        /* the most frequent in-frame length among this column's records (the shorter one on ties) */
+        uint32_t bestL = 0, bestN = 0;
+        for (uint32_t L = 3; L <= ORC_INS_MAX_BASES; L += 3) {
+            uint32_t cnt = 0;
+            for (size_t i = first; i < at; ++i) cnt += rec[i].len == L;
+            if (cnt > bestN) { bestN = cnt; bestL = L; }
+        }
+        const int far_enough = !have_last || c - last_col >= min_distance;
+        if (covering && bestL && (double)bestN > min_frac * (double)covering && far_enough) {
+            for (uint32_t j = 0; j < bestL; ++j) {   /* majority base per offset over the column's in-frame insertions */
+                uint32_t votes[4] = {0, 0, 0, 0};
+                for (size_t i = first; i < at; ++i) {
+                    if (rec[i].len % 3 != 0 || rec[i].len > ORC_INS_MAX_BASES || j >= rec[i].len) continue;
+                    const char ch = (char)rec[i].base[j];
+                    const int b = ch == 'A' ? 0 : ch == 'C' ? 1 : ch == 'G' ? 2 : ch == 'T' ? 3 : -1;
+                    if (b >= 0) votes[b]++;
+                }
+                int best = 0;
+                for (int b = 1; b < 4; ++b)
+                    if (votes[b] > votes[best]) best = b;
+                out[n++] = "ACGT"[best];
+            }
+            have_last = 1;
+            last_col = c;
+        }
+        /* the column itself: majority of A C G T - (lowest code on ties); '-' drops it; nobody covering prints N */
+        int best = -1;
+        uint32_t most = 0;
+        for (int b = 0; b < 5; ++b)
+            if (sym[b] > most) { most = sym[b]; best = b; }
+        if (best < 0) out[n++] = 'N';
+        else if (best < 4) out[n++] = "ACGT"[best];
+    }
+    free(rec);
     return n;
 }

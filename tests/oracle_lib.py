@@ -164,8 +164,28 @@ def _fuse(self, col_counts, len_hist, base_counts, min_frac=0.5, min_distance=10
     return out.raw[:n].decode()
 
 
+def _fuse_records(self, rows, win_begin, pos, cigar, cig_off, seq4, seq_off, min_frac=0.5, min_distance=10):
+    """orc_fuse_records: the consensus straight from the records and the by-row matrix (no counters): the independent
+    checker of the front end's consensus."""
+    rows = np.ascontiguousarray(rows, dtype=np.uint8)
+    n, l = rows.shape
+    pos = np.ascontiguousarray(pos, dtype=np.int32)
+    cigar = np.ascontiguousarray(cigar, dtype=np.uint32)
+    cig_off = np.ascontiguousarray(cig_off, dtype=np.uint64)
+    seq4 = np.ascontiguousarray(seq4, dtype=np.uint8)
+    seq_off = np.ascontiguousarray(seq_off, dtype=np.uint64)
+    out = C.create_string_buffer(l * 31 + 1)
+    vp = C.c_void_p
+    self.lib.orc_fuse_records.restype = C.c_uint32
+    k = self.lib.orc_fuse_records(rows.ctypes.data_as(vp), C.c_uint64(n), C.c_uint32(l), C.c_uint32(win_begin), pos.ctypes.data_as(vp),
+                                  cigar.ctypes.data_as(vp), cig_off.ctypes.data_as(vp), seq4.ctypes.data_as(vp), seq_off.ctypes.data_as(vp),
+                                  C.c_double(min_frac), C.c_uint32(min_distance), out)
+    return out.raw[:k].decode()
+
+
 Oracle.insertions = _insertions
 Oracle.fuse = _fuse
+Oracle.fuse_records = _fuse_records
 
 
 def build():

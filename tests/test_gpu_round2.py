@@ -368,6 +368,15 @@ def test_insertion_counters_match_the_oracle(jl, oracle):
         elh, ebc = oracle.insertions(we - wb, wb, pos, cigar, cig_off, seq4, seq_off)
         assert (lh == elh).all() and (bc == ebc).all()
         assert lh[:, 9].sum() > 50 and lh[:, 31].sum() > 50 and lh[:, 1:3].sum() > 100
+        # the consensus rule on the DEVICE's counters against the oracle's second formulation, which never sees a counter:
+        # explicit insertion records + a sweep over the window's rows (orc_fuse_records)
+        genes = np.array([(wb + 1, wb + 1 + 3 * ((we - wb) // 3))], dtype=capi.GENE)
+        jl.pileup_async(genes, None)
+        col = jl.pileup_fetch()["col_counts"]
+        win_rows = msa.unpack_columns(jl.download_columns(), n)
+        for frac, dist in ((0.5, 10), (0.05, 1), (0.0, 1), (0.001, 3)):
+            assert oracle.fuse(col, lh, bc, frac, dist) == oracle.fuse_records(win_rows, wb, pos, cigar, cig_off, seq4, seq_off, frac, dist)
+        assert len(oracle.fuse(col, lh, bc, 0.0, 1)) > len(oracle.fuse(col, None, None)) + 30    # insertions did enter
     jl.track_insertions(False)
     jl.ingest_records(l, 0, pos, cigar, cig_off, seq4, seq_off)
     with pytest.raises(capi.JulietError):

@@ -264,3 +264,60 @@ def test_fuse_consensus_rule(oracle):
     assert oracle.fuse(col, lh, bc, 0.5, 5) == expect({8: "GGT", 15: "CCC", 20: "AAACCCGGG"})
     assert oracle.fuse(col, None, None) == "".join("" if c == 5 else "N" if c == 30 else "ACGT"[ref[c]] for c in range(l))
     assert oracle.fuse(col, lh, bc, 0.95, 1) == oracle.fuse(col, None, None)           # nothing reaches 95 %
+
+
+def test_two_formulations_of_the_consensus_agree(oracle):
+    """orc_fuse decides from counters (what the front end's fuse.hpp does with the device's), orc_fuse_records from explicit
+    insertion records and a sweep over the rows.  Random records with planted insertions: an in-frame insertion in most
+    reads, and at the SAME column an out-of-frame one with other bases in a fifth of them — it must not vote on the bases."""
+    rng = np.random.default_rng(21)
+    n, l = 600, 90
+    ref = rng.integers(0, 4, l).astype(np.uint8)
+    rows = np.tile(ref, (n, 1))
+    noise = rng.random((n, l))
+    rows[noise < 0.02] = 4                                   # deletions
+    rows[(noise >= 0.02) & (noise < 0.03)] = 5               # masked bases
+    code = [1, 2, 4, 8]                                      # BAM nt16 of A C G T
+    pos = np.zeros(n, dtype=np.int32)
+    cig, co, s4, so = [], [0], [], [0]
+    plan = {30: ("ACGTTG", 0.7, "TTAC", 0.2), 60: ("GGA", 0.6, None, 0.0), 66: ("CCC", 0.9, None, 0.0), 12: ("AC", 0.8, None, 0.0)}
+    for r in range(n):
+        ops, bases, c = [], [], 0
+        u = rng.random(len(plan) * 2)
+        k = 0
+        while c < l:
+            if c in plan:
+                inf, pf, outf, po = plan[c]
+                x = u[k]; k += 1
+                ins = inf if x < pf else (outf if outf and x < pf + po else None)
+                if ins:
+                    ops.append((len(ins) << 4) | 1)
+                    bases += [code["ACGT".index(b)] for b in ins]
+            sym = int(rows[r, c])
+            if sym == 4:
+                ops.append((1 << 4) | 2)                     # D
+            else:
+                ops.append((1 << 4) | 7)                     # =
+                bases.append(code[ref[c]] if sym < 4 else 15)   # N where masked: still a query base
+                if sym == 5:
+                    rows[r, c] = 5
+            c += 1
+        cig += ops
+        co.append(len(cig))
+        if len(bases) % 2:
+            bases.append(0)
+        s4 += [(bases[i] << 4) | bases[i + 1] for i in range(0, len(bases), 2)]
+        so.append(len(s4))
+    cigar, cig_off = np.array(cig, dtype=np.uint32), np.array(co, dtype=np.uint64)
+    seq4, seq_off = np.array(s4, dtype=np.uint8), np.array(so, dtype=np.uint64)
+    col = oracle.pileup(rows)
+    lh, bc = oracle.insertions(l, 0, pos, cigar, cig_off, seq4, seq_off)
+    assert bc[30].sum() == lh[30, 6] * 6 and lh[30, 4] > 50          # the 4-base insertion is counted by length, not by base
+    for frac, dist in ((0.5, 10), (0.5, 5), (0.1, 1)):
+        a = oracle.fuse(col, lh, bc, frac, dist)
+        b = oracle.fuse_records(rows, 0, pos, cigar, cig_off, seq4, seq_off, frac, dist)
+        assert a == b
+    a = oracle.fuse(col, lh, bc, 0.5, 5)
+    want = "".join(("ACGTTG" if c == 30 else "GGA" if c == 60 else "CCC" if c == 66 else "") + "ACGT"[ref[c]] for c in range(l))
+    assert a == want                                                   # in frame and in most reads; the 2-base one never
+    assert "CCC" + "ACGT"[ref[66]] not in oracle.fuse(col, lh, bc, 0.5, 10)[60:80]     # 6 columns behind the one at 60: too close at distance 10
