@@ -120,12 +120,14 @@ int jl_ctx_create(int device, void *stream, jl_ctx **out)
               hipMalloc(&ctx->d_sync, 16 * sizeof(uint32_t)) == hipSuccess &&
               hipMalloc(&ctx->d_callinfo, sizeof(jl_callinfo)) == hipSuccess &&
               hipHostMalloc(&ctx->h_pack, sizeof(jl_pack), hipHostMallocDefault) == hipSuccess &&
-              hipHostMalloc((void **)&ctx->h_seq, 64, hipHostMallocDefault) == hipSuccess;
+              hipHostMalloc((void **)&ctx->h_seq, 64, hipHostMallocDefault) == hipSuccess &&
+              hipHostMalloc(&ctx->h_scratch, (size_t)1 << 20, hipHostMallocDefault) == hipSuccess;
+    if (ok) ctx->h_scratch_cap = (size_t)1 << 20;
     if (!ok) { jl_ctx_destroy(ctx); return jl_fail(nullptr, JL_ERR_MEMORY, "context allocation failed"); }
     hipMemsetAsync(ctx->d_nvar, 0, 2 * sizeof(uint32_t), ctx->stream);
     hipMemsetAsync(ctx->d_meta, 0, sizeof(jl_phase_meta), ctx->stream);
     hipMemsetAsync(ctx->d_sync, 0, 16 * sizeof(uint32_t), ctx->stream);
-    *ctx->h_seq = 0;
+    for (int k = 0; k < 16; ++k) ctx->h_seq[k] = 0;
     *out = ctx;
     return JL_OK;
 }
@@ -151,6 +153,7 @@ void jl_ctx_destroy(jl_ctx *ctx)
     if (ctx->h_pack) hipHostFree(ctx->h_pack);
     if (ctx->h_seq) hipHostFree((void *)ctx->h_seq);
     if (ctx->h_read_hap) hipHostFree(ctx->h_read_hap);
+    if (ctx->h_scratch) hipHostFree(ctx->h_scratch);
     free_msa(ctx);
     records_drop(ctx);
     void *ptrs[] = {ctx->d_pos_gene, ctx->d_pos_codon, ctx->d_pos_col, ctx->d_pos_refcfg, ctx->d_guess, ctx->d_chunks,
@@ -790,20 +793,51 @@ int jl_pileup_async(jl_ctx *ctx, const jl_gene *genes, uint32_t n_genes, const u
 
 uint32_t jl_n_positions(const jl_ctx *ctx) { return ctx ? ctx->P : 0; }
 
+}  // extern "C"
+
+int jl_fetch_to_host(jl_ctx *ctx, const void *d_src, size_t bytes, void *dst, size_t readable)
+{
+    // `readable` >= bytes: how much of the source may be read (the copy moves whole 16-byte pieces)
+    const size_t moved = (bytes + 15u) & ~(size_t)15u;
+    hipStream_t st = ctx->run_stream ? ctx->run_stream : ctx->stream;
+    if (ctx->run_stream && ctx->run_stream != ctx->stream) JL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (moved > ctx->h_scratch_cap || moved > readable || ((uintptr_t)d_src & 15u)) {   // large or odd: the runtime's copy
+        JL_HIP(ctx, hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, st));
+        JL_HIP(ctx, hipStreamSynchronize(st));
+        return JL_OK;
+    }
+    jl_launch_xw_fetch(d_src, ctx->h_scratch, moved, ctx->d_sync + 9, ctx->d_sync + 8, ctx->h_seq + 4, st);
+    JL_HIP(ctx, hipGetLastError());
+    const uint32_t want = ++ctx->fetches;
+    volatile uint32_t *p = ctx->h_seq + 4;
+    uint64_t spins = 0;
+    while ((int32_t)(*p - want) < 0) {
+        __builtin_ia32_pause();
+        if ((++spins & 0x3FFFFFu) == 0) {   // a long wait: ask the stream (a fault would leave the word unset for ever)
+            JL_HIP(ctx, hipStreamSynchronize(st));
+            if ((int32_t)(*p - want) < 0) return jl_fail(ctx, JL_ERR_DEVICE, "fetch finished without its completion word");
+        }
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    memcpy(dst, ctx->h_scratch, bytes);
+    return JL_OK;
+}
+
+extern "C" {
+
 int jl_pileup_fetch(jl_ctx *ctx, uint32_t *col_counts, uint32_t *pos_gene, uint32_t *pos_codon, uint32_t *pos_col,
                     uint32_t *hist, uint32_t *coverage)
 {
     if (!ctx) return JL_ERR_ARG;
     if (!ctx->pileup_done) return jl_fail(ctx, JL_ERR_STATE, "jl_pileup_fetch before jl_pileup_async");
-    hipStream_t st = ctx->stream;
+    JL_HIP(ctx, hipSetDevice(ctx->device));
     if (col_counts)
-        JL_HIP(ctx, hipMemcpyAsync(col_counts, ctx->d_counts, (size_t)ctx->n_cols * 6 * 4, hipMemcpyDeviceToHost, st));
+        if (int rc = jl_fetch_to_host(ctx, ctx->d_counts, (size_t)ctx->n_cols * 6 * 4, col_counts, ctx->counts_words * 4)) return rc;
     std::vector<uint32_t> full;
     if ((hist || coverage) && ctx->P) {
         full.resize((size_t)ctx->n_cols * 64);
-        JL_HIP(ctx, hipMemcpyAsync(full.data(), ctx->d_hist, full.size() * 4, hipMemcpyDeviceToHost, st));
+        if (int rc = jl_fetch_to_host(ctx, ctx->d_hist, full.size() * 4, full.data(), full.size() * 4)) return rc;
     }
-    JL_HIP(ctx, hipStreamSynchronize(st));
     for (uint32_t p = 0; p < ctx->P; ++p) {
         if (pos_gene) pos_gene[p] = ctx->h_pos_gene[p];
         if (pos_codon) pos_codon[p] = ctx->h_pos_codon[p];

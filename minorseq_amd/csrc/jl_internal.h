@@ -408,7 +408,10 @@ struct jl_ctx {
     bool run_read_hap = false;
     // completion without a HIP sync: the last kernel of a run bumps d_sync[0] and stores it to *h_seq (pinned)
     uint32_t *d_sync = nullptr;       // [16] zeroed once: [0] runs completed, [1..] arrival counters of fused kernels
-    volatile uint32_t *h_seq = nullptr;  // pinned
+    volatile uint32_t *h_seq = nullptr;  // pinned [16]: [0] the run word; [4] the word of jl_fetch_to_host
+    uint8_t *h_scratch = nullptr;     // pinned: small device arrays on their way to the host (a first pageable copy of a
+    size_t h_scratch_cap = 0;         // process costs the runtime milliseconds: staging buffers, pinning the target)
+    uint32_t fetches = 0;             // completed jl_fetch_to_host calls (device word d_sync[8], host word h_seq[4])
     uint32_t runs_launched = 0;
     uint32_t exch_pending = 0;        // exchanges requested and not yet collected: each still reads one of the two result blocks
     std::vector<uint32_t> exch_runs;  // ... and the runs (values of runs_launched) whose blocks they read
@@ -493,3 +496,6 @@ int jl_phase_groups_prepare(jl_ctx *ctx, uint32_t vp);
 int jl_ctx_table_host(jl_ctx *ctx, std::vector<jl_variant> *scratch, const jl_variant **rows, uint32_t *n);
 // jl_run_wait_seq without touching ctx->err (threads other than the context's owner)
 int jl_run_wait_seq_quiet(jl_ctx *ctx, uint32_t want, hipStream_t stream);
+// `bytes` of device memory to `dst` (pageable is fine) behind everything enqueued on the context's run stream: a copy kernel into
+// the context's pinned scratch + a completion word, no runtime copy path
+int jl_fetch_to_host(jl_ctx *ctx, const void *d_src, size_t bytes, void *dst, size_t readable);

@@ -19,6 +19,7 @@
 #include <memory>
 
 #include "config.hpp"
+#include "decode.hpp"
 #include "format.hpp"
 #include "fuse.hpp"
 #include "html.hpp"
@@ -535,8 +536,12 @@ int main(int argc, char **argv)
         RecordArrays rec;
         std::vector<BamRef> bam_refs;
         std::string header_text;
-        const ReadExtent ext = collect_records(opt.bam, io, io.ref_id, opt.min_qv > 0, rec, &bam_refs, &header_text,
-                                               uploader ? &sink : nullptr);
+        // (with a device behind it: the pipelined reader — inflate and record parsing on every core, chunks to the uploader
+        // in file order; the GPU-free diagnostics and non-BGZF files take the sequential one)
+        const ReadExtent ext = (uploader && PipelinedBamReader::is_bgzf(opt.bam))
+                                   ? PipelinedBamReader::run(opt.bam, io, io.ref_id, opt.min_qv > 0, sink, &bam_refs, &header_text)
+                                   : collect_records(opt.bam, io, io.ref_id, opt.min_qv > 0, rec, &bam_refs, &header_text,
+                                                     uploader ? &sink : nullptr);
         tick("bam decode");
         if (ext.n_reads == 0) { std::cerr << "juliet: no primary or supplementary alignments in " << opt.bam << "\n"; return 2; }
         int64_t ref_len = std::numeric_limits<int64_t>::max();
@@ -677,11 +682,8 @@ int main(int argc, char **argv)
                 R.var.resize(n);
             }
             R.col_counts.swap(cc);
-            for (RankJob &j : jobs) {
-                for (jl_ctx *w : j.wins) jl_ctx_destroy(w);
-                if (j.comm) jl_comm_destroy(j.comm);
-                if (j.records) jl_ctx_destroy(j.records);
-            }
+            for (RankJob &j : jobs)
+                if (j.comm) jl_comm_destroy(j.comm);   // (RCCL wants its communicators closed; contexts end with the process)
             tick("kernels + fetch");
         } else {
         if (!opt.consensus.empty()) jl_msa_track_insertions(ctx, 1);   // fuse keeps in-frame insertions (doc/FUSE.md:19)
@@ -702,7 +704,9 @@ int main(int argc, char **argv)
         uint32_t nv = 0;
         if (!opt.fuse_only && jl_call_fetch(ctx, R.var.data(), 4096, &nv) != JL_OK) die_jl(ctx, "call fetch");
         R.var.resize(nv);
+        tick("  wait for the run + table");
         if (jl_pileup_fetch(ctx, R.col_counts.data(), nullptr, nullptr, nullptr, nullptr, nullptr) != JL_OK) die_jl(ctx, "pileup fetch");
+        tick("  column counts");
 
         if (!opt.consensus.empty()) {  // what `fuse` writes for this window (doc/FUSE.md:17-24)
             std::vector<uint32_t> len_hist((size_t)n_cols * 32), base_counts((size_t)n_cols * 120);
@@ -730,8 +734,9 @@ int main(int argc, char **argv)
             if (jl_phase_fetch(ctx, &R.ps, R.pos_cols.data(), R.hap_count.data(), R.hap_pattern.data(), R.hit.data(), R.read_hap.data(), nullptr, cap_var) != JL_OK)
                 die_jl(ctx, "phase fetch");
         }
-        tick("kernels + fetch");
-        jl_ctx_destroy(ctx);
+        tick("  haplotypes + ids");
+        // (the context is not torn down: the process is about to end, and freeing two dozen device buffers one by one took
+        // 4-6 ms of a 0.1 s run)
         }
         const std::vector<jl_variant> &var = R.var;
         const std::vector<uint32_t> &col_counts = R.col_counts;

@@ -169,6 +169,66 @@ struct RecordSink {
     std::function<void(RecordArrays &)> give;   // swaps the full chunk for an empty one
 };
 
+// One record of the stream -> the arrays the device ingests (shared by the sequential and the pipelined reader).
+// `ref_id`: -1 = not known yet (the first kept record decides; sequential reader only).  Returns whether it was kept.
+inline bool parse_record(const uint8_t *p, size_t len, const IngestOptions &opt, bool want_qual, int &ref_id, RecordArrays &out,
+                         ReadExtent &e, BamRecord &scratch, std::vector<uint8_t> &eq)
+{
+    auto u32 = [&](size_t o) { uint32_t v; memcpy(&v, p + o, 4); return v; };
+    auto u16 = [&](size_t o) { uint16_t v; memcpy(&v, p + o, 2); return v; };
+    if (len < 32) throw std::runtime_error("corrupt BAM record");
+    const int32_t rid = (int32_t)u32(0), pos = (int32_t)u32(4);
+    const uint32_t l_name = p[8], n_cigar = u16(12), flag = u16(14), l_seq = u32(16);
+    const size_t o_cig = 32 + (size_t)l_name, o_seq = o_cig + (size_t)n_cigar * 4, o_qual = o_seq + ((size_t)l_seq + 1) / 2,
+                 o_aux = o_qual + l_seq;
+    if (o_aux > len) throw std::runtime_error("corrupt BAM record");
+    // "Reads that are not primary or supplementary alignments, get ignored" (doc/JULIET.md:58)
+    if ((flag & 0x4) || (flag & 0x100) || rid < 0 || pos < 0) return false;
+    const bool need_tags = want_qual || opt.min_rq > 0.0;
+    if (need_tags) {
+        scratch.qual.assign(p + o_qual, p + o_aux);
+        BamReader::parse_aux(p, o_aux, len, scratch);
+        if (opt.min_rq > 0.0 && scratch.rq >= 0.f && scratch.rq < opt.min_rq) return false;
+    }
+    if (ref_id < 0) ref_id = rid;
+    if (rid != ref_id) return false;
+    const size_t c_at = out.cigar.size();
+    out.cigar.resize(c_at + n_cigar);
+    memcpy(out.cigar.data() + c_at, p + o_cig, (size_t)n_cigar * 4);
+    uint32_t span = 0;
+    uint64_t query = 0;
+    for (size_t k = c_at; k < out.cigar.size(); ++k) {
+        const uint32_t op = out.cigar[k] & 15;
+        if (op == CIG_M) {
+            const std::string name((const char *)p + 32, l_name ? l_name - 1 : 0);
+            throw std::runtime_error("read " + name + ": cigar M is forbidden in PacBio-compliant BAM (doc/JULIET.md:53)");
+        }
+        if (op == CIG_D || op == CIG_N || op == CIG_EQ || op == CIG_X) span += out.cigar[k] >> 4;
+        if (op == CIG_I || op == CIG_S || op == CIG_EQ || op == CIG_X) query += out.cigar[k] >> 4;
+    }
+    // the device walks the cigar into the read's bases and qualities: a cigar that consumes more (or fewer) bases
+    // than the record holds would index past them
+    if (query != l_seq) {
+        const std::string name((const char *)p + 32, l_name ? l_name - 1 : 0);
+        throw std::runtime_error("read " + name + ": cigar consumes " + std::to_string(query) + " bases, the record holds " +
+                                 std::to_string(l_seq));
+    }
+    ++e.n_reads;
+    e.min_pos = std::min<int64_t>(e.min_pos, pos);
+    e.max_end = std::max<int64_t>(e.max_end, (int64_t)pos + span);
+    out.pos.push_back(pos);
+    out.cig_off.push_back(out.cigar.size());
+    out.seq4.insert(out.seq4.end(), p + o_seq, p + o_qual);
+    out.seq_off.push_back(out.seq4.size());
+    if (want_qual) {
+        effective_quals(scratch, eq);
+        out.qual.insert(out.qual.end(), eq.begin(), eq.end());
+        out.qual_off.push_back(out.qual.size());
+    }
+    out.names.emplace_back((const char *)p + 32, l_name ? l_name - 1 : 0);
+    return true;
+}
+
 // One pass over the file: every kept record of reference `ref_id` (-1: the reference of the first kept record), plus
 // the extent those records cover.  `refs` / `header_text` receive the BAM header when given.  Records are parsed in
 // place in the inflated BGZF batch: positions, cigar words and BAM's packed bases are copied once, into the arrays
@@ -195,62 +255,12 @@ inline ReadExtent collect_records(const std::string &bam, const IngestOptions &o
             } catch (const std::bad_alloc &) {}   // doubling takes over
         }
     }
-    const bool need_tags = want_qual || opt.min_rq > 0.0;
-    BamRecord r;   // only its tag fields and qualities are used, and only when need_tags
+    BamRecord r;   // only its tag fields and qualities are used, and only when a filter needs them
     std::vector<uint8_t> eq;
     const uint8_t *p;
     size_t len;
     while (in.next_raw(p, len)) {
-        auto u32 = [&](size_t o) { uint32_t v; memcpy(&v, p + o, 4); return v; };
-        auto u16 = [&](size_t o) { uint16_t v; memcpy(&v, p + o, 2); return v; };
-        const int32_t rid = (int32_t)u32(0), pos = (int32_t)u32(4);
-        const uint32_t l_name = p[8], n_cigar = u16(12), flag = u16(14), l_seq = u32(16);
-        const size_t o_cig = 32 + (size_t)l_name, o_seq = o_cig + (size_t)n_cigar * 4, o_qual = o_seq + (l_seq + 1) / 2,
-                     o_aux = o_qual + l_seq;
-        if (o_aux > len) throw std::runtime_error("corrupt BAM record");
-        // "Reads that are not primary or supplementary alignments, get ignored" (doc/JULIET.md:58)
-        if ((flag & 0x4) || (flag & 0x100) || rid < 0 || pos < 0) continue;
-        if (need_tags) {
-            r.qual.assign(p + o_qual, p + o_aux);
-            BamReader::parse_aux(p, o_aux, len, r);
-            if (opt.min_rq > 0.0 && r.rq >= 0.f && r.rq < opt.min_rq) continue;
-        }
-        if (e.ref_id < 0) e.ref_id = rid;
-        if (rid != e.ref_id) continue;
-        const size_t c_at = out.cigar.size();
-        out.cigar.resize(c_at + n_cigar);
-        memcpy(out.cigar.data() + c_at, p + o_cig, (size_t)n_cigar * 4);
-        uint32_t span = 0;
-        uint64_t query = 0;
-        for (size_t k = c_at; k < out.cigar.size(); ++k) {
-            const uint32_t op = out.cigar[k] & 15;
-            if (op == CIG_M) {
-                const std::string name((const char *)p + 32, l_name ? l_name - 1 : 0);
-                throw std::runtime_error("read " + name + ": cigar M is forbidden in PacBio-compliant BAM (doc/JULIET.md:53)");
-            }
-            if (op == CIG_D || op == CIG_N || op == CIG_EQ || op == CIG_X) span += out.cigar[k] >> 4;
-            if (op == CIG_I || op == CIG_S || op == CIG_EQ || op == CIG_X) query += out.cigar[k] >> 4;
-        }
-        // the device walks the cigar into the read's bases and qualities: a cigar that consumes more (or fewer) bases
-        // than the record holds would index past them
-        if (query != l_seq) {
-            const std::string name((const char *)p + 32, l_name ? l_name - 1 : 0);
-            throw std::runtime_error("read " + name + ": cigar consumes " + std::to_string(query) + " bases, the record holds " +
-                                     std::to_string(l_seq));
-        }
-        ++e.n_reads;
-        e.min_pos = std::min<int64_t>(e.min_pos, pos);
-        e.max_end = std::max<int64_t>(e.max_end, (int64_t)pos + span);
-        out.pos.push_back(pos);
-        out.cig_off.push_back(out.cigar.size());
-        out.seq4.insert(out.seq4.end(), p + o_seq, p + o_qual);
-        out.seq_off.push_back(out.seq4.size());
-        if (want_qual) {
-            effective_quals(r, eq);
-            out.qual.insert(out.qual.end(), eq.begin(), eq.end());
-            out.qual_off.push_back(out.qual.size());
-        }
-        out.names.emplace_back((const char *)p + 32, l_name ? l_name - 1 : 0);
+        parse_record(p, len, opt, want_qual, e.ref_id, out, e, r, eq);
         if (sink && out.pos.size() >= sink->chunk_reads) sink->give(out);
     }
     if (sink && !out.pos.empty()) sink->give(out);

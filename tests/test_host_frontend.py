@@ -194,7 +194,14 @@ def test_malformed_records_are_rejected(tmp_path):
     def run(mutated, *flags):
         p = str(tmp_path / "bad.bam")
         open(p, "wb").write(_bgzf(bytes(mutated)))
-        return subprocess.run([JULIET, *flags, "--dump-msa", str(tmp_path / "bad.msa"), p], capture_output=True, text=True)
+        seq = subprocess.run([JULIET, *flags, "--dump-msa", str(tmp_path / "bad.msa"), p], capture_output=True, text=True)
+        # the same file through the pipelined reader (an output is asked for, so the uploader exists; without a GPU a good
+        # file ends with "no usable GPU", exit 3 — a bad one must fail in the decode, exit 2, with the same message)
+        pipe = subprocess.run([JULIET, *flags, p, str(tmp_path / "bad.json")], capture_output=True, text=True)
+        assert (pipe.returncode == 2) == (seq.returncode == 2), (seq.stderr, pipe.stderr)
+        if seq.returncode == 2:
+            assert seq.stderr.strip().splitlines()[-1] == pipe.stderr.strip().splitlines()[-1]
+        return seq
 
     assert run(raw).returncode == 0            # the re-compressed original is fine
     m = bytearray(raw)                         # cigar 60= -> 90=: 30 bases more than the record holds
@@ -211,3 +218,72 @@ def test_malformed_records_are_rejected(tmp_path):
     m[aux:aux + 7] = b"zzBc" + struct.pack("<I", 1 << 30)[:3]
     r = run(m, "--min-rq", "0.5")
     assert r.returncode == 2 and "truncated BAM aux" in r.stderr
+
+
+def test_pipelined_reader_equals_sequential(tmp_path):
+    """The pipelined decode (segments of BGZF blocks inflated and parsed on a pool, chunks in file order) against the
+    sequential one on a file of many segments with records that straddle them, with and without the filters that read
+    qualities and tags: a small C++ driver prints a checksum of everything either reader hands over."""
+    import textwrap
+    bam = str(tmp_path / "p.bam")
+    subprocess.check_call([SYNTH, "--reads", "20000", "--cols", "900", "--seed", "5", "--partial", "0.2", "--rich-qv", "-o", bam])
+    src = tmp_path / "cmp.cpp"
+    src.write_text(textwrap.dedent(r"""
+        #include <cstdio>
+        #include "juliet_hip.h"
+        #include "decode.hpp"
+        using namespace jlhost;
+        static uint64_t mix(uint64_t h, const void *p, size_t n) {
+            const uint8_t *b = (const uint8_t *)p;
+            for (size_t i = 0; i < n; ++i) h = (h ^ b[i]) * 1099511628211ull;
+            return h;
+        }
+        struct Sum { uint64_t h = 1469598103934665603ull, reads = 0, chunks = 0; };
+        static void eat(Sum &s, RecordArrays &c) {
+            for (size_t r = 0; r < c.pos.size(); ++r) {
+                s.h = mix(s.h, &c.pos[r], 4);
+                s.h = mix(s.h, c.cigar.data() + c.cig_off[r], (c.cig_off[r + 1] - c.cig_off[r]) * 4);
+                s.h = mix(s.h, c.seq4.data() + c.seq_off[r], c.seq_off[r + 1] - c.seq_off[r]);
+                if (c.qual_off.size() > r + 1) s.h = mix(s.h, c.qual.data() + c.qual_off[r], c.qual_off[r + 1] - c.qual_off[r]);
+                s.h = mix(s.h, c.names[r].data(), c.names[r].size());
+            }
+            s.reads += c.pos.size();
+            ++s.chunks;
+            c.clear();
+        }
+        int main(int argc, char **argv) {
+            IngestOptions io;
+            io.min_qv = (uint32_t)atoi(argv[2]);
+            io.min_rq = atof(argv[3]);
+            const bool want_qual = io.min_qv > 0;
+            for (int pass = 0; pass < 2; ++pass) {
+                Sum s;
+                RecordSink sink;
+                sink.give = [&](RecordArrays &c) { eat(s, c); };
+                RecordArrays rec;
+                std::vector<BamRef> refs;
+                std::string text;
+                const ReadExtent e = pass ? PipelinedBamReader::run(argv[1], io, -1, want_qual, sink, &refs, &text, 7)
+                                          : collect_records(argv[1], io, -1, want_qual, rec, &refs, &text, &sink);
+                printf("%llu %llu %lld %lld %d %zu %zu %llu\n", (unsigned long long)s.h, (unsigned long long)e.n_reads, (long long)e.min_pos,
+                       (long long)e.max_end, e.ref_id, refs.size(), text.size(), (unsigned long long)s.reads);
+            }
+            return 0;
+        }
+        """))
+    exe = str(tmp_path / "cmp")
+    host = os.path.join(ROOT, "minorseq_amd", "host")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-I" + host, "-I" + os.path.join(ROOT, "include"), "-o", exe, str(src), "-lz", "-lpthread"])
+    for qv, rq in (("0", "0"), ("12", "0"), ("0", "0.9985"), ("10", "0.999")):
+        out = subprocess.run([exe, bam, qv, rq], capture_output=True, text=True)
+        assert out.returncode == 0, out.stderr
+        a, b = out.stdout.strip().splitlines()
+        assert a == b, (qv, rq, a, b)
+        assert int(a.split()[1]) > 1000
+    # a file cut in the middle of a record, and one cut inside the header
+    raw = open(bam, "rb").read()
+    for cut, msg in ((len(raw) // 2, "truncated"), (40, "")):
+        bad = str(tmp_path / "cut.bam")
+        open(bad, "wb").write(raw[:cut])
+        out = subprocess.run([exe, bad, "0", "0"], capture_output=True, text=True)
+        assert out.returncode != 0
