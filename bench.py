@@ -391,6 +391,35 @@ def main():
     fence()
     latency_ms = 1000.0 * (time.perf_counter() - t1) / 20
 
+    # the same for a window with SIXTEEN variant positions (the reference's own screenshots show 9-13 and more,
+    # doc/JULIET.md:350, 362): beyond ten positions a pattern takes two key words — the two-word fused launch
+    many_ms = None
+    if world == 1 and (n, l) == (N_READS, N_COLS):
+        from minorseq_amd import msa
+        mp = capi.Juliet(local_rank)
+        rows = msa.unpack_columns(jl.download_columns(), n)
+        rng = np.random.default_rng(3)
+        for k in range(11):                       # eleven more edited codons, about 3 % of the reads each
+            who = rng.choice(n, n // 30, replace=False)
+            c0 = 3 * (100 + 61 * k)
+            rows[who, c0:c0 + 3] = (rows[who, c0:c0 + 3] + 1 + k % 3) % 4
+        mp.upload_rows(rows, win_begin=win_begin)
+        del rows
+
+        def many():
+            mp.run_async(genes, refseq, prm, None, True, 10, True)
+            return mp.run_view() or mp.run_fetch(True, True, cap_var=64)
+        for _ in range(4):
+            mv = many()
+        fence()
+        t2 = time.perf_counter()
+        for _ in range(20):
+            mv = many()
+        fence()
+        many_ms = 1000.0 * (time.perf_counter() - t2) / 20
+        many_positions = int(mv["phase"]["summary"]["n_positions"])
+        mp.close()
+
     # dominant kernel alone: HIP events on the stream it is launched on, around back-to-back launches that rotate
     # over the resident batches (no launch finds its windows in the 256 MiB Infinity Cache).  rocprofv3 sees exactly
     # these launches when bench.py runs with --kernel-only (profiles/README.md).
@@ -442,6 +471,7 @@ def main():
                    else "single GPU",
                    "batches_per_launch": G, "launches_in_flight": n_flight, "resident_batches": len(ctxs),
                    "one_batch_latency_ms": latency_ms,
+                   "many_positions_latency_ms": many_ms, "many_positions": many_positions if many_ms is not None else None,
                    "variants_called": state["gathered_rows"] if comm is not None else len(table),
                    "haplotypes": ph["summary"]["n_haplotypes"],
                    "windows_verified_in_loop": state["checked"]},
@@ -451,6 +481,8 @@ def main():
                                        "command (a separate run; counters cannot be read from inside bench.py)" if traffic else None,
                      "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": t_pileup_ms,
                      # the same bytes over the whole step (launch gaps, Fisher, phasing, results on the host included)
+                     # one window alone through the whole path (what `juliet in.bam out.json` does): its bytes over its latency
+                     "one_batch_frac": step_bytes / (latency_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                      "step_achieved": step_bytes / (ms_per_step * 1e-3) / 1e9,
                      "step_frac": step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
     }

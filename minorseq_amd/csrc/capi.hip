@@ -162,7 +162,7 @@ void jl_ctx_destroy(jl_ctx *ctx)
                     ctx->d_slot_rep, ctx->d_slot_count, ctx->d_slot_key, ctx->d_slot_hap, ctx->d_occupied, ctx->d_hap_count,
                     ctx->d_hap_pattern, ctx->d_hit, ctx->d_cooc, ctx->d_pack, ctx->d_sync, ctx->d_timeline,
                     ctx->d_col_first, ctx->d_pos_next, ctx->d_callinfo, ctx->d_ins_len, ctx->d_ins_base, ctx->d_exp_count,
-                    ctx->d_exp_pattern, ctx->d_exp_hap, ctx->d_blockcat};
+                    ctx->d_exp_pattern, ctx->d_exp_hap, ctx->d_blockcat, ctx->d_slot_key_a, ctx->d_slot_key_b, ctx->d_occ_a, ctx->d_occ_b};
     for (void *p : ptrs)
         if (p) hipFree(p);
     if (ctx->ev0) hipEventDestroy(ctx->ev0);
@@ -953,6 +953,25 @@ static int reserve_phase(jl_ctx *ctx, uint32_t kwords_needed)
         ctx->reads_capacity = reads_pad;
         ctx->keys_capacity = 0;
     }
+    if (ctx->phase_two && ctx->two_slots != ctx->table_slots) {   // the two-word fused launch numbers its half keys here
+        void *old[] = {ctx->d_slot_key_a, ctx->d_slot_key_b, ctx->d_occ_a, ctx->d_occ_b};
+        for (void *p : old)
+            if (p) hipFree(p);
+        ctx->d_slot_key_a = ctx->d_slot_key_b = nullptr;
+        ctx->d_occ_a = ctx->d_occ_b = nullptr;
+        ctx->two_slots = 0;
+        ctx->alloc_version++;
+        const size_t slots = (size_t)ctx->table_slots;
+        JL_HIP(ctx, hipMalloc(&ctx->d_slot_key_a, slots * 8));
+        JL_HIP(ctx, hipMalloc(&ctx->d_slot_key_b, slots * 8));
+        JL_HIP(ctx, hipMalloc(&ctx->d_occ_a, reads_pad * 4));
+        JL_HIP(ctx, hipMalloc(&ctx->d_occ_b, reads_pad * 4));
+        JL_HIP(ctx, hipMemsetAsync(ctx->d_slot_key_a, 0xFF, slots * 8, ctx->stream));
+        JL_HIP(ctx, hipMemsetAsync(ctx->d_slot_key_b, 0xFF, slots * 8, ctx->stream));
+        JL_HIP(ctx, hipMemsetAsync(ctx->d_sync + 10, 0, 8, ctx->stream));
+        JL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->two_slots = ctx->table_slots;
+    }
     const size_t need = (size_t)kwords_needed * reads_pad;
     if (ctx->keys_capacity < need) {
         if ((rc = regrow(ctx, &ctx->d_keys, need))) return rc;
@@ -1088,10 +1107,14 @@ static int phase_settle(jl_ctx *ctx, jl_phase_meta *out)
     JL_HIP(ctx, hipMemcpyAsync(&meta, ctx->d_meta, sizeof meta, hipMemcpyDeviceToHost, st));
     JL_HIP(ctx, hipStreamSynchronize(st));
     if (meta.overflow & 12u) {
-        // more variant positions than the single-word kernels (bit 3) or the resident key buffer (bit 2) cover:
-        // switch to the generic pipeline / grow the buffer and run phasing again (the variant table is resident)
-        if (meta.vp_true > JL_POS_PER_WORD) ctx->phase_generic = true;
-        for (int attempt = 0; attempt < 2 && (meta.overflow & 12u); ++attempt) {
+        // more variant positions than the fused launch in use (bit 3) or the resident key buffer (bit 2) covers: up to 20
+        // positions take the two-word fused launch, more — or a result beyond its selection — the multi-word pipeline;
+        // grow the buffer if need be and run phasing again (the variant table is resident)
+        for (int attempt = 0; attempt < 3 && (meta.overflow & 12u); ++attempt) {
+            if (meta.vp_true > JL_POS_PER_WORD) {
+                if (meta.vp_true <= 2u * JL_POS_PER_WORD && !ctx->phase_two && !ctx->phase_generic && !ctx->phase_export) ctx->phase_two = true;
+                else ctx->phase_generic = true;
+            }
             const uint32_t kw = (meta.vp_true + JL_POS_PER_WORD - 1) / JL_POS_PER_WORD;
             int rc = reserve_phase(ctx, kw);
             if (rc == JL_OK && ctx->phase_export) rc = reserve_export(ctx, kw);
@@ -1245,8 +1268,10 @@ int jl_phase_groups_prepare(jl_ctx *ctx, uint32_t vp)
     if (rc) return rc;
     uint32_t kwords = (vp + JL_POS_PER_WORD - 1) / JL_POS_PER_WORD;
     if (kwords == 0) kwords = 1;
+    // up to 10 positions one key word, up to 20 the two-word fused launch, more the multi-word pipeline
+    ctx->phase_two = vp > JL_POS_PER_WORD && vp <= 2u * JL_POS_PER_WORD;
+    ctx->phase_generic = vp > 2u * JL_POS_PER_WORD;
     if ((rc = reserve_phase(ctx, kwords))) return rc;
-    ctx->phase_generic = vp > JL_POS_PER_WORD;
     ctx->direct.on = 0;
     ctx->phase_export = true;
     ctx->exp_known = false;
@@ -1356,7 +1381,7 @@ int jl_run_prepare(jl_ctx *ctx, const jl_gene *genes, uint32_t n_genes, const ui
         JL_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
     if (phasing) {
-        if ((rc = reserve_phase(ctx, ctx->keys_words > 4 ? ctx->keys_words : 4))) return rc;
+        if ((rc = reserve_phase(ctx, ctx->keys_words > 4 ? ctx->keys_words : 4))) return rc;   // (with the half-key tables once the context is in two-word mode)
         if (want_read_hap && ctx->h_read_hap_cap < (size_t)ctx->col_stride * 2) {
             if (ctx->h_read_hap) hipHostFree(ctx->h_read_hap);
             ctx->h_read_hap = nullptr;
@@ -1407,7 +1432,7 @@ int jl_run_async(jl_ctx *ctx, const jl_gene *genes, uint32_t n_genes, const uint
     struct { uint64_t alloc, plan; jl_params prm; double n_tests; uint32_t drm, phasing, min_reads, rh, generic, pad; } sig;
     memset(&sig, 0, sizeof sig);
     sig.alloc = ctx->alloc_version; sig.plan = ctx->plan_version; sig.prm = *prm; sig.n_tests = n_tests;
-    sig.drm = drm_masks != nullptr; sig.phasing = phasing != 0; sig.min_reads = min_reads; sig.rh = want_read_hap != 0; sig.generic = ctx->phase_generic; sig.pad = (uint32_t)(uintptr_t)ctx->read_hap_out;
+    sig.drm = drm_masks != nullptr; sig.phasing = phasing != 0; sig.min_reads = min_reads; sig.rh = want_read_hap != 0; sig.generic = (ctx->phase_generic ? 1u : 0u) | (ctx->phase_two ? 2u : 0u); sig.pad = (uint32_t)(uintptr_t)ctx->read_hap_out;
     static const bool graphs_on = !getenv("JL_NO_GRAPH");   // read once; eager launches are a debugging aid
     bool launched = false;
     // A graph replay reaches the queue 10-16 us after the call, a plain launch 3-5 us (MI355X guide, graph-replay-floor);

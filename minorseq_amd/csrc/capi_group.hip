@@ -180,8 +180,8 @@ int jl_group_run_masked_async(jl_group *g, const jl_gene *genes, uint32_t n_gene
         if (rc) return group_fail(g, rc, jl_last_error(c));
         // a group run reads what the window's own stream wrote (uploads, ingest): that stream must be idle
         if (hipStreamSynchronize(c->stream) != hipSuccess) return group_fail(g, JL_ERR_DEVICE, "context stream failed");
-        if (phasing && c->phase_generic)
-            return group_fail(g, JL_ERR_ARG, "a window needs the multi-word phasing pipeline: run it with jl_run_async");
+        if (phasing && (c->phase_generic || c->phase_two))
+            return group_fail(g, JL_ERR_ARG, "a window needs the two-word or the multi-word phasing pipeline: run it with jl_run_async");
     }
     // signature: anything that changes an argument block or the launch shapes
     struct item { uint64_t alloc, plan; double n_tests; void *rh; uint32_t n_dw, drm; };

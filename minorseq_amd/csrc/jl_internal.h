@@ -65,7 +65,7 @@ struct jl_phase_meta {  // device-resident scalars of one phasing run
 #define JL_PACK_MAX_HAP 128u
 #define JL_PACK_PATTERN_BYTES 8192u   // e.g. 128 haplotypes x 64 positions
 #define JL_PACK_HIT_BYTES 16384u      // e.g. 128 variants x 128 haplotypes
-#define JL_SEL_HIT_BYTES 4096u        // what the selection out of LDS holds of it (larger results take the general path)
+#define JL_SEL_HIT_BYTES 8192u        // what the selection out of LDS holds of it (larger results take the general path)
 #define JL_PACK_COOC_N 32u
 #define JL_PACK_MAGIC 0x4A4C504Bu
 struct jl_pack {
@@ -210,6 +210,16 @@ struct jl_direct_cols {
     const uint8_t *col[JL_POS_PER_WORD];
     uint64_t stride;
     uint32_t on, vp;
+};
+
+// The fused phase launch for 11..20 variant positions (two key words): every read's pattern is grouped in three rounds of
+// the one-word machinery — its first word numbered in table A, its second word in table B, the PAIR of those numbers
+// (one 64-bit word again) in the main table.  Exact by construction: equal pairs <=> equal words <=> equal patterns.
+// The half-key tables only number their keys: no counts, no representatives.
+struct jl_two_word {
+    unsigned long long *key_a, *key_b;   // [table slots] each, emptied after every run
+    uint32_t *occ_a, *occ_b;             // the slots a run touched
+    uint32_t *n_occ;                     // [2] how many
 };
 
 struct jl_done_ent {   // completion word of one window (see done_kernel)
@@ -395,7 +405,11 @@ struct jl_ctx {
     uint32_t *d_cooc = nullptr;        // [cooc_cap][cooc_cap]
     uint32_t cooc_cap = 256;
     bool phase_done = false;
-    bool phase_generic = false;  // multi-word (Vp > 10) pipeline selected
+    bool phase_generic = false;  // multi-word pipeline selected (more than 20 positions, or results beyond the fused selection)
+    bool phase_two = false;      // 11..20 positions: the two-word fused launch (jl_two_word)
+    uint64_t *d_slot_key_a = nullptr, *d_slot_key_b = nullptr;   // its half-key tables [table slots]
+    uint32_t *d_occ_a = nullptr, *d_occ_b = nullptr;             // [reads_pad]
+    uint64_t two_slots = 0;                                      // table size the half-key tables were made for
 
     // ---- whole-path run: result pack, pinned mirrors, captured graph
     jl_pack *d_pack = nullptr;        // [2]: run n writes block n & 1 (an exchange may still read the other one)

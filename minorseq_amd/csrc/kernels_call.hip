@@ -135,7 +135,7 @@ void jl_fill_win_compact(jl_ctx *ctx, bool plan, bool pack, bool signal, jl_win_
     w->P = ctx->P; w->cap = JL_VARIANT_CAP; w->n_cols = ctx->n_cols; w->kwords_cap = ctx->keys_words;
     w->called = ctx->d_called; w->staged = ctx->d_staged; w->rows = ctx->d_variants; w->n_rows = ctx->d_nvar;
     w->varcol = ctx->d_varcol; w->vpcols = ctx->d_vpcols; w->col2pos = ctx->d_col2pos; w->meta = ctx->d_meta;
-    w->plan = plan ? 1u : 0u; w->fast_only = ctx->phase_generic ? 0u : 1u;
+    w->plan = plan ? 1u : 0u; w->fast_only = ctx->phase_generic ? 0u : (ctx->phase_two ? 2u : 1u);
     w->pack = pack ? 1u : 0u;
     w->pk = ctx->d_pack; w->mirror = ctx->pack_mirror;
     w->seq_dev = ctx->d_sync; w->seq_host = signal ? ctx->h_seq : nullptr;

@@ -547,8 +547,11 @@ typedef jl_select_args select_args;
 #ifdef JL_EXP_STAMPS   // experiment builds only: device-clock stamps (100 MHz) of one workgroup's way through the fused launch
 __device__ unsigned long long g_stamps[64];
 #define JL_STAMP(k) do { if (threadIdx.x == 0 && (blockIdx.x == 0 || (k) >= 8)) g_stamps[(k)] = wall_clock64(); } while (0)
+#define JL_STAMP_ON 1
 #else
 #define JL_STAMP(k) do { } while (0)
+#define JL_STAMP_ON 0
+__device__ unsigned long long g_stamps[1];
 #endif
 constexpr uint32_t kLdsSlots = 1024;
 constexpr uint64_t kNoKey = ~0ull;
@@ -556,7 +559,7 @@ constexpr uint32_t kPlanList = 256;   // called positions a workgroup can rank i
 
 struct plan_state {   // LDS: what the prologue derives — identical in every workgroup of a window
     uint32_t n_list, n_rows, vp, ovf;
-    uint32_t cols[JL_POS_PER_WORD];   // the variant columns, ascending (first 10)
+    uint32_t cols[2u * JL_POS_PER_WORD];   // the variant columns, ascending (first 20: two key words)
     uint32_t list[kPlanList];
     uint8_t first[kPlanList];
 };
@@ -566,7 +569,7 @@ __device__ __forceinline__ void plan_prologue(const select_args &S, uint32_t n_c
 {
     const uint32_t tid = threadIdx.x;
     if (tid == 0) { L.n_list = 0; L.n_rows = 0; L.vp = 0; L.ovf = 0; }
-    if (tid < JL_POS_PER_WORD) L.cols[tid] = 0;
+    if (tid < 2u * JL_POS_PER_WORD) L.cols[tid] = 0;
     __syncthreads();
     const uint32_t P = S.P;
     for (uint32_t base = 0; base < P; base += 1024u) {
@@ -601,7 +604,7 @@ __device__ __forceinline__ void plan_prologue(const select_args &S, uint32_t n_c
         const uint32_t c = L.list[tid];
         uint32_t rank = 0;
         for (uint32_t j = 0; j < n; ++j) rank += (L.first[j] && L.list[j] < c) ? 1u : 0u;
-        if (rank < JL_POS_PER_WORD) L.cols[rank] = c;
+        if (rank < 2u * JL_POS_PER_WORD) L.cols[rank] = c;
         atomicAdd(&L.vp, 1u);
     }
     if (tid == 0 && L.n_list > kPlanList) L.ovf = 1u;
@@ -609,27 +612,48 @@ __device__ __forceinline__ void plan_prologue(const select_args &S, uint32_t n_c
 }
 
 __device__ __forceinline__ uint32_t key_code(uint64_t key, uint32_t vp, uint32_t p) { return (uint32_t)(key >> (6u * (vp - 1u - p))) & 63u; }
+// the same for a pattern of up to 20 positions in two words: positions 0..9 in w0, the rest in w1
+__device__ __forceinline__ uint32_t key_code2(uint64_t w0, uint64_t w1, uint32_t vp, uint32_t p)
+{
+    const uint32_t n0 = vp < JL_POS_PER_WORD ? vp : JL_POS_PER_WORD;
+    return p < n0 ? key_code(w0, n0, p) : key_code(w1, vp - n0, p - n0);
+}
 
 // Selection of the single-word pipeline out of LDS: every table word it needs is fetched ONCE (occupied list -> counts
 // and keys: two dependent round trips), ranking, patterns, hit matrix and co-occurrence then run on LDS copies, and
 // the result block is stored from there.  The general routine above chases each of them through memory again (a
 // dozen dependent round trips on one CU: 10 us and more).  Handles what fits the result block (<= 128 candidates,
 // <= 128 variant rows, hit matrix <= 4 KB); returns false — with nothing but idempotent side effects — otherwise.
+// the half-key tables of a two-word launch, emptied of what the run put there (and their counters)
+__device__ __forceinline__ void two_word_cleanup(const jl_two_word &tw)
+{
+    const uint32_t tid = threadIdx.x, nt = blockDim.x;
+    const uint32_t na = ld_coherent(&tw.n_occ[0]), nb = ld_coherent(&tw.n_occ[1]);
+    for (uint32_t q = tid; q < na; q += nt) tw.key_a[ld_coherent(&tw.occ_a[q])] = ~0ull;
+    for (uint32_t q = tid; q < nb; q += nt) tw.key_b[ld_coherent(&tw.occ_b[q])] = ~0ull;
+    __syncthreads();
+    if (tid == 0) { tw.n_occ[0] = 0; tw.n_occ[1] = 0; }
+}
+
 constexpr uint32_t kSelCand = JL_PACK_MAX_HAP;
 struct sel_lds {
     uint32_t slot[kSelCand], cnt[kSelCand];
-    unsigned long long key[kSelCand];
+    unsigned long long key[kSelCand], key1[kSelCand];     // key1 / hkey1: the second word of a two-word pattern
     uint32_t hcnt[kSelCand];
-    unsigned long long hkey[kSelCand];
+    unsigned long long hkey[kSelCand], hkey1[kSelCand];
     uint32_t vpos[JL_PACK_MAX_VAR];
     uint8_t vcodon[JL_PACK_MAX_VAR];
     uint8_t hit[JL_SEL_HIT_BYTES];
+    uint32_t hmask[JL_PACK_MAX_VAR][kSelCand / 32u];   // per variant: the haplotypes that carry it (co-occurrence sums)
     uint32_t ncand, insufficient, reported, bail;
 };
 static_assert(sizeof(sel_lds) <= kLdsSlots * 5u * 4u, "the selection's scratch must fit the grouping tables");
 
+// KW = 2: the main table's key of a group is the pair (slot of its first word in table A, slot of its second word in
+// table B); the words themselves are one more round trip away (jl_two_word).
+template <int KW>
 __device__ __forceinline__ bool phase_select_lds(const jl_win_phase &w, const plan_state &L, uint32_t vp, uint32_t nv,
-                                                 uint32_t n_rows, sel_lds &T)
+                                                 uint32_t n_rows, sel_lds &T, const jl_two_word *tw = nullptr)
 {
     const select_args &S = w.S;
     jl_phase_meta *meta = w.meta;
@@ -638,17 +662,35 @@ __device__ __forceinline__ bool phase_select_lds(const jl_win_phase &w, const pl
     if (tid == 0) { T.ncand = 0; T.insufficient = 0; T.reported = 0; T.bail = (nv > JL_PACK_MAX_VAR || n_rows > JL_PACK_MAX_VAR) ? 1u : 0u; }
     __syncthreads();
     if (T.bail) return false;
-    for (uint32_t q = tid; q < n_occ; q += nt) {
-        const uint32_t s = ld_coherent(&w.occupied[q]);
-        const uint32_t c = ld_coherent(&w.slot_count[s]);
-        const unsigned long long k = ld_coherent64(&w.slot_key[s]);
-        if (c >= S.min_reads) {
-            const uint32_t i = atomicAdd(&T.ncand, 1u);
-            if (i < kSelCand) { T.slot[i] = s; T.cnt[i] = c; T.key[i] = k; }
-            else T.bail = 1u;
-        } else {
-            atomicAdd(&T.insufficient, c);
-            __hip_atomic_store(&S.slot_hap[s], (uint32_t)JL_HAP_INSUFFICIENT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // The groups, four per thread and trip: all of a thread's list entries are loaded before any is used, then all their
+    // counts and keys (one dependent round trip per 1024 groups each way instead of one per 256: at 725 groups the scan was
+    // a quarter of the selection).
+    for (uint32_t q0 = 0; q0 < n_occ; q0 += 4u * nt) {
+        uint32_t sl[4], cn[4];
+        unsigned long long ky[4];
+#pragma unroll
+        for (uint32_t j = 0; j < 4u; ++j) {
+            const uint32_t q = q0 + j * nt + tid;
+            sl[j] = q < n_occ ? ld_coherent(&w.occupied[q]) : 0xFFFFFFFFu;
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < 4u; ++j) {
+            if (sl[j] == 0xFFFFFFFFu) continue;
+            cn[j] = ld_coherent(&w.slot_count[sl[j]]);
+            ky[j] = ld_coherent64(&w.slot_key[sl[j]]);
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < 4u; ++j) {
+            if (sl[j] == 0xFFFFFFFFu) continue;
+            const uint32_t s = sl[j], c = cn[j];
+            if (c >= S.min_reads) {
+                const uint32_t i = atomicAdd(&T.ncand, 1u);
+                if (i < kSelCand) { T.slot[i] = s; T.cnt[i] = c; T.key[i] = ky[j]; }
+                else T.bail = 1u;
+            } else {
+                atomicAdd(&T.insufficient, c);
+                __hip_atomic_store(&S.slot_hap[s], (uint32_t)JL_HAP_INSUFFICIENT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
     }
     // the variant rows: column -> position index, codon (the table may come from another workgroup of this launch)
@@ -662,32 +704,70 @@ __device__ __forceinline__ bool phase_select_lds(const jl_win_phase &w, const pl
         T.vcodon[v] = (uint8_t)((cw >> 8) & 0xFFu);
     }
     __syncthreads();
+    JL_STAMP(13);
     const uint32_t H = T.ncand;
     if (T.bail || nv * H > JL_SEL_HIT_BYTES) return false;
-    // rank: (count desc, pattern asc); patterns are unique, so the ranks are a permutation
-    for (uint32_t a = tid; a < H; a += nt) {
+    if (KW == 2) {   // the candidates' two words, from the half-key tables
+        for (uint32_t a = tid; a < H; a += nt) {
+            const unsigned long long pair = T.key[a];
+            T.key[a] = ld_coherent64(&tw->key_a[(uint32_t)(pair >> 32)]);
+            T.key1[a] = ld_coherent64(&tw->key_b[(uint32_t)pair]);
+        }
+        __syncthreads();
+    }
+    // rank: (count desc, pattern asc); patterns are unique, so the ranks are a permutation.  Two threads per candidate
+    // (at most 128 of them, 256 threads): each counts the competitors of one half that come before it.
+    uint32_t *half_rank = reinterpret_cast<uint32_t *>(T.hit);   // [kSelCand] scratch: the hit matrix is filled later
+    uint32_t my_rank = 0;
+    {
+        const uint32_t a = tid & 127u;
+        if (a < H) {
+            const uint32_t ca = T.cnt[a];
+            const unsigned long long ka = T.key[a], ka1 = KW == 2 ? T.key1[a] : 0ull;
+            const uint32_t b0 = tid < 128u ? 0u : H / 2u, b1 = tid < 128u ? H / 2u : H;
+            uint32_t r = 0;
+            for (uint32_t b = b0; b < b1; ++b) {
+                const bool before = KW == 2 ? (T.key[b] < ka || (T.key[b] == ka && T.key1[b] < ka1)) : T.key[b] < ka;
+                r += (T.cnt[b] > ca || (T.cnt[b] == ca && before)) ? 1u : 0u;
+            }
+            if (tid < 128u) my_rank = r;
+            else half_rank[a] = r;
+        }
+    }
+    __syncthreads();
+    for (uint32_t a = tid; a < H; a += nt) {   // (H <= 128: the threads that hold my_rank)
         const uint32_t ca = T.cnt[a];
-        const unsigned long long ka = T.key[a];
-        uint32_t rank = 0;
-        for (uint32_t b = 0; b < H; ++b) rank += (T.cnt[b] > ca || (T.cnt[b] == ca && T.key[b] < ka)) ? 1u : 0u;
+        const unsigned long long ka = T.key[a], ka1 = KW == 2 ? T.key1[a] : 0ull;
+        const uint32_t rank = my_rank + half_rank[a];
         T.hcnt[rank] = ca;
         T.hkey[rank] = ka;
+        if (KW == 2) T.hkey1[rank] = ka1;
         __hip_atomic_store(&S.slot_hap[T.slot[a]], rank, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // read by other workgroups
         atomicAdd(&T.reported, ca);
     }
     __syncthreads();
-    for (uint32_t q = tid; q < nv * H; q += nt) {
-        const uint32_t v = q / H, h = q - v * H;
-        const uint32_t pos = T.vpos[v];
-        T.hit[q] = (pos != 0xFFu && key_code(T.hkey[h], vp, pos) == T.vcodon[v]) ? 1 : 0;
+    // hit[v][h] and, per variant, the set of haplotypes that carry it as bits: a wave per variant, a lane per haplotype
+    // (no division per element; the set makes the co-occurrence sums a walk over a few common bits instead of H terms)
+    for (uint32_t v = tid >> 6; v < nv; v += nt >> 6) {
+        const uint32_t pos = T.vpos[v], codon = T.vcodon[v];
+        for (uint32_t h0 = 0; h0 < H; h0 += 64u) {
+            const uint32_t h = h0 + (tid & 63u);
+            bool x = false;
+            if (h < H && pos != 0xFFu)
+                x = (KW == 2 ? key_code2(T.hkey[h], T.hkey1[h], vp, pos) : key_code(T.hkey[h], vp, pos)) == codon;
+            if (h < H) T.hit[v * H + h] = x ? 1 : 0;
+            const unsigned long long m = __ballot(x);
+            if ((tid & 63u) == 0) { T.hmask[v][h0 / 32u] = (uint32_t)m; T.hmask[v][h0 / 32u + 1u] = (uint32_t)(m >> 32); }
+        }
     }
     __syncthreads();
     const uint32_t bits = id_bits_for(H);
+    JL_STAMP(14);
     // ---- outputs.  The resident arrays (stage-API fetches read them) ...
     for (uint32_t h = tid; h < H; h += nt) S.hap_count[h] = T.hcnt[h];
     for (uint32_t q = tid; q < H * vp; q += nt) {
         const uint32_t h = q / vp, p = q - h * vp;
-        S.hap_pattern[(uint64_t)h * JL_VARIANT_CAP + p] = (uint8_t)key_code(T.hkey[h], vp, p);
+        S.hap_pattern[(uint64_t)h * JL_VARIANT_CAP + p] = (uint8_t)(KW == 2 ? key_code2(T.hkey[h], T.hkey1[h], vp, p) : key_code(T.hkey[h], vp, p));
     }
     for (uint32_t q = tid; q < nv * H; q += nt) S.hit[(uint64_t)(q / H) * JL_MAX_HAPLOTYPES + (q % H)] = T.hit[q];
     const uint32_t nvc = nv < S.cooc_cap ? nv : S.cooc_cap;
@@ -697,13 +777,20 @@ __device__ __forceinline__ bool phase_select_lds(const jl_win_phase &w, const pl
     for (uint32_t q = tid; q < nvc * nvc; q += nt) {
         const uint32_t v = q / nvc, x = q - v * nvc;
         uint32_t sum = 0;
-        for (uint32_t h = 0; h < H; ++h) sum += (T.hit[v * H + h] & T.hit[x * H + h]) ? T.hcnt[h] : 0u;
+        for (uint32_t j = 0; j < (H + 31u) / 32u; ++j) {
+            uint32_t m = T.hmask[v][j] & T.hmask[x][j];
+            while (m) {
+                sum += T.hcnt[32u * j + (uint32_t)__ffs((int)m) - 1u];
+                m &= m - 1u;
+            }
+        }
         S.cooc[(uint64_t)v * S.cooc_cap + x] = sum;
         if (cooc_fits)
 #pragma unroll
             for (int t = 0; t < 2; ++t)
                 if (dsts[t]) dsts[t]->cooc[v * nv + x] = sum;
     }
+    JL_STAMP(15);
     // ... and the result block, device copy (all-gather source) and pinned host mirror, straight from LDS
     if (tid == 0) {
         jl_phase_summary sm;
@@ -739,9 +826,11 @@ __device__ __forceinline__ bool phase_select_lds(const jl_win_phase &w, const pl
                 ld_coherent64(reinterpret_cast<const unsigned long long *>(S.variants) + i);
         for (uint32_t i = tid; i < vp; i += nt) o->pos_cols[i] = L.cols[i];
         for (uint32_t i = tid; i < H; i += nt) o->hap_count[i] = T.hcnt[i];
-        for (uint32_t i = tid; i < H * vp; i += nt) o->hap_pattern[i] = (uint8_t)key_code(T.hkey[i / vp], vp, i % vp);
+        for (uint32_t i = tid; i < H * vp; i += nt)
+            o->hap_pattern[i] = (uint8_t)(KW == 2 ? key_code2(T.hkey[i / vp], T.hkey1[i / vp], vp, i % vp) : key_code(T.hkey[i / vp], vp, i % vp));
         for (uint32_t i = tid; i < nv * H; i += nt) o->hit[i] = T.hit[i];
     }
+    JL_STAMP(16);
     // leave the table empty for the next run: only the slots this run touched
     for (uint32_t q = tid; q < n_occ; q += nt) {
         const uint32_t s = ld_coherent(&w.occupied[q]);
@@ -749,6 +838,9 @@ __device__ __forceinline__ bool phase_select_lds(const jl_win_phase &w, const pl
         w.slot_rep[s] = 0xFFFFFFFFu;
         w.slot_count[s] = 0;
     }
+    if (KW == 2) two_word_cleanup(*tw);
+    JL_STAMP(17);
+    if (tid == 0 && JL_STAMP_ON) g_stamps[18] = n_occ;
     return true;
 }
 
@@ -757,7 +849,9 @@ __device__ __forceinline__ bool phase_select_lds(const jl_win_phase &w, const pl
 // round trips — {group count, the first 256 entries of the occupied list, the run counter} and {count, key of each group} —
 // where the general routine chases a dozen; the groups' rows leave 8 bytes at a time (they may lie in pinned host memory).
 // `cat`: the read categories of the whole matrix, summed by the caller (LDS).
-__device__ __forceinline__ void phase_export_fast(const jl_win_phase &w, uint32_t vp, const uint32_t *cat, uint32_t *s_acc)
+template <int KW>
+__device__ __forceinline__ void phase_export_fast(const jl_win_phase &w, uint32_t vp, const uint32_t *cat, uint32_t *s_acc,
+                                                  const jl_two_word *tw = nullptr)
 {
     const select_args &S = w.S;
     jl_phase_meta *meta = w.meta;
@@ -772,7 +866,12 @@ __device__ __forceinline__ void phase_export_fast(const jl_win_phase &w, uint32_
         const uint32_t s = q == tid ? s_first : ld_coherent(&w.occupied[q]);
         // trip 2: both words of the group before either is used
         const uint32_t c = ld_coherent(&w.slot_count[s]);
-        const unsigned long long key = ld_coherent64(&w.slot_key[s]);
+        unsigned long long key = ld_coherent64(&w.slot_key[s]), key_b = 0;
+        if (KW == 2) {   // the pair of half-key slots -> the two words (one more round trip, all groups at once)
+            const unsigned long long pair = key;
+            key = ld_coherent64(&tw->key_a[(uint32_t)(pair >> 32)]);
+            key_b = ld_coherent64(&tw->key_b[(uint32_t)pair]);
+        }
         clean += c;
         // the slot remembers WHICH exported group it is: the merge answers per group
         __hip_atomic_store(&S.slot_hap[s], q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -780,7 +879,8 @@ __device__ __forceinline__ void phase_export_fast(const jl_win_phase &w, uint32_
             S.exp_count[q] = c;
             for (uint32_t p8 = 0; p8 < vp; p8 += 8u) {
                 unsigned long long out = 0;
-                for (uint32_t j = 0; j < 8u && p8 + j < vp; ++j) out |= (unsigned long long)key_code(key, vp, p8 + j) << (8u * j);
+                for (uint32_t j = 0; j < 8u && p8 + j < vp; ++j)
+                    out |= (unsigned long long)(KW == 2 ? key_code2(key, key_b, vp, p8 + j) : key_code(key, vp, p8 + j)) << (8u * j);
                 *reinterpret_cast<unsigned long long *>(S.exp_pattern + (uint64_t)q * S.exp_stride + p8) = out;
             }
         }
@@ -812,13 +912,18 @@ __device__ __forceinline__ void phase_export_fast(const jl_win_phase &w, uint32_
         // a session's next launch may come without a plan kernel in front (jl_direct_cols): the group list starts empty
         if (S.exp_head) { meta->n_occupied = 0; meta->overflow = 0; }
     }
+    if (KW == 2) {
+        __syncthreads();
+        two_word_cleanup(*tw);
+    }
 }
 
 __device__ __forceinline__ uint32_t global_insert64(uint64_t key, uint32_t cnt, uint32_t first, uint64_t slots_mask,
                                                     unsigned long long *__restrict__ slot_key,
                                                     uint32_t *__restrict__ slot_rep, uint32_t *__restrict__ slot_count,
-                                                    uint32_t *__restrict__ occupied, jl_phase_meta *__restrict__ meta)
+                                                    uint32_t *__restrict__ occupied, uint32_t *__restrict__ n_occupied)
 {
+    // (slot_rep / slot_count null: a table that only numbers its keys — the half-key tables of the two-word launch)
     uint64_t s = mix64(key + 0x9E3779B97F4A7C15ull) & slots_mask;
     for (;;) {
         // Look first: a slot's key never changes within a run, so a resident key read past the L1 is final and needs no
@@ -828,20 +933,22 @@ __device__ __forceinline__ uint32_t global_insert64(uint64_t key, uint32_t cnt, 
         if (old == kNoKey) old = atomicCAS(&slot_key[s], (unsigned long long)kNoKey, (unsigned long long)key);
         if (old == kNoKey) {
             // write-through stores: the selection may run in another workgroup of this launch
-            __hip_atomic_store(&slot_rep[s], first, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // any read carrying the key
-            __hip_atomic_store(&occupied[atomicAdd(&meta->n_occupied, 1u)], (uint32_t)s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (slot_rep) __hip_atomic_store(&slot_rep[s], first, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // any read carrying the key
+            __hip_atomic_store(&occupied[atomicAdd(n_occupied, 1u)], (uint32_t)s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             old = key;
         }
         if (old == key) {
-            atomicAdd(&slot_count[s], cnt);
+            if (slot_count) atomicAdd(&slot_count[s], cnt);
             return (uint32_t)s;
         }
         s = (s + 1u) & slots_mask;
     }
 }
 
-__device__ __forceinline__ void phase_fused1_body(const jl_win_phase &w, const jl_direct_cols *dc = nullptr)
+template <int KW>
+__device__ __forceinline__ void phase_fused1_body(const jl_win_phase &w, const jl_direct_cols *dc = nullptr, const jl_two_word *tw = nullptr)
 {
+    constexpr uint32_t NP = (uint32_t)KW * JL_POS_PER_WORD;   // positions this instantiation covers
     const uint8_t *__restrict__ msa = w.msa;
     const uint64_t col_stride = w.col_stride, n_reads = w.n_reads, reads_pad = w.reads_pad;
     jl_phase_meta *meta = w.meta;
@@ -874,7 +981,7 @@ __device__ __forceinline__ void phase_fused1_body(const jl_win_phase &w, const j
     if (from_called) {
         plan_prologue(S, S.n_cols, s_plan);
         const uint32_t vpt = s_plan.vp;
-        work = !s_plan.ovf && vpt >= 1u && vpt <= JL_POS_PER_WORD;
+        work = !s_plan.ovf && vpt >= 1u && vpt <= NP;
         vp = work ? vpt : 0u;
         n_rows = s_plan.n_rows;
         if (plan_block) {
@@ -894,7 +1001,7 @@ __device__ __forceinline__ void phase_fused1_body(const jl_win_phase &w, const j
                 __hip_atomic_store(&meta->n_var, n < S.cap ? n : S.cap, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(&meta->vp_true, s_plan.ovf ? JL_POS_PER_WORD + 1u : vpt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(&meta->vp, vp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&meta->kwords, work ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&meta->kwords, work ? (uint32_t)KW : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(&meta->overflow, ovf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(&meta->summary.n_positions, vp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
@@ -905,10 +1012,10 @@ __device__ __forceinline__ void phase_fused1_body(const jl_win_phase &w, const j
         n_rows = 0;
     } else {
         const uint32_t mvp = meta->vp, kw = meta->kwords;  // one scalar round trip for both; the plan kernel wrote them
-        work = (mvp != 0) & (kw == 1);                       // block-uniform
+        work = (mvp != 0) & (kw >= 1) & (kw <= (uint32_t)KW);   // block-uniform
         vp = work ? mvp : 0u;
-        // all ten column indices in one go (the array always holds JL_VARIANT_CAP words; entries past vp are never used)
-        if (tid < JL_POS_PER_WORD) s_plan.cols[tid] = w.vpcols[tid];
+        // all the column indices in one go (the array always holds JL_VARIANT_CAP words; entries past vp are never used)
+        if (tid < NP) s_plan.cols[tid] = w.vpcols[tid];
         if (tid == 0) s_plan.n_rows = 0;
         n_rows = 0;
         __syncthreads();
@@ -929,16 +1036,16 @@ __device__ __forceinline__ void phase_fused1_body(const jl_win_phase &w, const j
     // ---- 1. keys and flags
     // Lanes past the end of the columns load from a clamped address and drop the value, so the loads need no
     // per-lane branch.
-    uint32_t cols[JL_POS_PER_WORD];
+    uint32_t cols[NP];
 #pragma unroll
-    for (uint32_t p = 0; p < JL_POS_PER_WORD; ++p) cols[p] = s_plan.cols[p];
+    for (uint32_t p = 0; p < NP; ++p) cols[p] = s_plan.cols[p];
     const uint64_t t_ld = live ? t : 0u;
-    uint32_t wd[JL_POS_PER_WORD][3];
+    uint32_t wd[NP][3];
     const bool direct = dc && dc->on;   // block-uniform
 #pragma unroll
-    for (uint32_t p = 0; p < JL_POS_PER_WORD; ++p) {
+    for (uint32_t p = 0; p < NP; ++p) {
         if (p < vp) {  // block-uniform
-            const uint8_t *c0 = direct ? dc->col[p] : msa + (uint64_t)cols[p] * col_stride;
+            const uint8_t *c0 = (direct && p < JL_POS_PER_WORD) ? dc->col[p] : msa + (uint64_t)cols[p] * col_stride;
             const uint64_t cs = direct ? dc->stride : col_stride;
 #pragma unroll
             for (int k = 0; k < 3; ++k)
@@ -950,14 +1057,15 @@ __device__ __forceinline__ void phase_fused1_body(const jl_win_phase &w, const j
     }
     if (!live) {
 #pragma unroll
-        for (uint32_t p = 0; p < JL_POS_PER_WORD; ++p)
+        for (uint32_t p = 0; p < NP; ++p)
 #pragma unroll
             for (int k = 0; k < 3; ++k) wd[p][k] = 0x66666666u;
     }
     uint32_t gap = 0, het = 0, par = 0;
     uint64_t key[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t key1[KW == 2 ? 8 : 1] = {0};   // positions 10 .. 19 (two-word launch)
 #pragma unroll
-    for (uint32_t p = 0; p < JL_POS_PER_WORD; ++p) {
+    for (uint32_t p = 0; p < NP; ++p) {
         if (p < vp) {
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
@@ -969,8 +1077,11 @@ __device__ __forceinline__ void phase_fused1_body(const jl_win_phase &w, const j
             const uint32_t hi2 = wd[p][0] & 0x33333333u;
             const uint32_t lo4 = ((wd[p][1] & 0x33333333u) << 2) | (wd[p][2] & 0x33333333u);
 #pragma unroll
-            for (int r = 0; r < 8; ++r)
-                key[r] = (key[r] << 6) | ((((hi2 >> (4 * r)) & 3u) << 4) | ((lo4 >> (4 * r)) & 15u));
+            for (int r = 0; r < 8; ++r) {
+                const uint64_t code = (((hi2 >> (4 * r)) & 3u) << 4) | ((lo4 >> (4 * r)) & 15u);
+                if (KW == 1 || p < JL_POS_PER_WORD) key[r] = (key[r] << 6) | code;
+                else key1[KW == 2 ? r : 0] = (key1[KW == 2 ? r : 0] << 6) | code;
+            }
         }
     }
     uint32_t valid = 0;
@@ -987,7 +1098,7 @@ __device__ __forceinline__ void phase_fused1_body(const jl_win_phase &w, const j
         // the flags and slots of every read are only needed by a later launch that writes the ids
         flagw[t] = gap | (het << 1) | (par << 2) | ((valid ^ kM1) << 3);
     }
-    if (live && !S.run) {   // the multi-word pipeline's own group launch reads the keys
+    if (KW == 1 && live && !S.run) {   // the multi-word pipeline's own group launch reads the keys
         uint64_t *dst = keys + t * 8u;
 #pragma unroll
         for (int r = 0; r < 8; r += 2) {
@@ -1009,92 +1120,117 @@ __device__ __forceinline__ void phase_fused1_body(const jl_win_phase &w, const j
             if (n_par) atomicAdd(&s_cat[3], n_par);
         }
     }
-    // ---- 2. dominant key of the block = key of its first clean read
-    uint32_t myfirst = 0xFFFFFFFFu;
-    if (cleanm) myfirst = (uint32_t)(t * 8u) + ((uint32_t)__ffs((int)cleanm) - 1u) / 4u;
-    {
-        uint32_t m = myfirst;
+    // One ROUND of grouping: the clean reads' 64-bit keys `kk` -> the slot of each in the global table T (gs[r]).
+    // The one-word launch runs it once, on the patterns themselves; the two-word launch three times (jl_two_word).
+    auto group_round = [&](const uint64_t (&kk)[8], unsigned long long *T_key, uint32_t *T_rep, uint32_t *T_cnt, uint32_t *T_occ,
+                           uint32_t *T_nocc, uint32_t (&gs)[8], bool first_round) {
+        if (!first_round) {   // (the first round's tables were cleared while the columns were on their way)
+            for (uint32_t i = tid; i < kLdsSlots; i += 256u) { s_key[i] = kNoKey; s_cnt[i] = 0; s_first[i] = 0xFFFFFFFFu; }
+            if (tid == 0) { s_dom = kNoKey; s_domcnt = 0; s_domfirst = 0xFFFFFFFFu; s_domslot = 0; s_nlist = 0; }
+            __syncthreads();
+        }
+        // ---- 2. dominant key of the block = key of its first clean read
+        uint32_t myfirst = 0xFFFFFFFFu;
+        if (cleanm) myfirst = (uint32_t)(t * 8u) + ((uint32_t)__ffs((int)cleanm) - 1u) / 4u;
+        {
+            uint32_t m = myfirst;
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) m = min(m, (uint32_t)__shfl_xor((int)m, o, 64));
-        if ((tid & 63u) == 0 && m != 0xFFFFFFFFu) atomicMin(&s_domfirst, m);
-    }
-    __syncthreads();
-    const uint32_t domfirst = s_domfirst;
-    if (domfirst != 0xFFFFFFFFu && (uint64_t)(domfirst >> 3) == t) {
+            for (int o = 32; o > 0; o >>= 1) m = min(m, (uint32_t)__shfl_xor((int)m, o, 64));
+            if ((tid & 63u) == 0 && m != 0xFFFFFFFFu) atomicMin(&s_domfirst, m);
+        }
+        __syncthreads();
+        const uint32_t domfirst = s_domfirst;
+        if (domfirst != 0xFFFFFFFFu && (uint64_t)(domfirst >> 3) == t) {
 #pragma unroll
-        for (int r = 0; r < 8; ++r)  // static indices keep key[] in registers
-            if ((domfirst & 7u) == (uint32_t)r) s_dom = key[r];
-    }
-    __syncthreads();
-    const unsigned long long dom = s_dom;
-    uint32_t isdom = 0;  // bit 4r
+            for (int r = 0; r < 8; ++r)  // static indices keep the keys in registers
+                if ((domfirst & 7u) == (uint32_t)r) s_dom = kk[r];
+        }
+        __syncthreads();
+        const unsigned long long dom = s_dom;
+        uint32_t isdom = 0;  // bit 4r
 #pragma unroll
-    for (int r = 0; r < 8; ++r)
-        if (((cleanm >> (4 * r)) & 1u) && key[r] == dom) isdom |= 1u << (4 * r);
-    {
-        const uint32_t c = wave_sum_all(__popc(isdom));
-        if ((tid & 63u) == 0 && c) atomicAdd(&s_domcnt, c);
-    }
-    JL_STAMP(3);
-    // ---- 3. everything else through the LDS table
-    uint32_t rest = cleanm & ~isdom;
-    uint32_t myslot[8];
+        for (int r = 0; r < 8; ++r)
+            if (((cleanm >> (4 * r)) & 1u) && kk[r] == dom) isdom |= 1u << (4 * r);
+        {
+            const uint32_t c = wave_sum_all(__popc(isdom));
+            if ((tid & 63u) == 0 && c) atomicAdd(&s_domcnt, c);
+        }
+        JL_STAMP(3);
+        // ---- 3. everything else through the LDS table
+        uint32_t rest = cleanm & ~isdom;
+        uint32_t myslot[8];
 #pragma unroll
-    for (int r = 0; r < 8; ++r) myslot[r] = 0xFFFFFFFFu;
+        for (int r = 0; r < 8; ++r) myslot[r] = 0xFFFFFFFFu;
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
-        if ((rest >> (4 * r)) & 1u) {
-            const unsigned long long k = key[r];
-            uint32_t s = (uint32_t)mix64(k) & (kLdsSlots - 1u);
-            for (uint32_t probe = 0; probe < kLdsSlots; ++probe) {
-                const unsigned long long old = atomicCAS(&s_key[s], (unsigned long long)kNoKey, k);
-                if (old == kNoKey || old == k) {
-                    atomicAdd(&s_cnt[s], 1u);
-                    atomicMin(&s_first[s], (uint32_t)(t * 8u + r));
-                    myslot[r] = s;
-                    break;
+        for (int r = 0; r < 8; ++r) {
+            if ((rest >> (4 * r)) & 1u) {
+                const unsigned long long k = kk[r];
+                uint32_t s = (uint32_t)mix64(k) & (kLdsSlots - 1u);
+                for (uint32_t probe = 0; probe < kLdsSlots; ++probe) {
+                    const unsigned long long old = atomicCAS(&s_key[s], (unsigned long long)kNoKey, k);
+                    if (old == kNoKey || old == k) {
+                        atomicAdd(&s_cnt[s], 1u);
+                        atomicMin(&s_first[s], (uint32_t)(t * 8u + r));
+                        myslot[r] = s;
+                        break;
+                    }
+                    s = (s + 1u) & (kLdsSlots - 1u);
                 }
-                s = (s + 1u) & (kLdsSlots - 1u);
             }
         }
-    }
-    __syncthreads();
-    JL_STAMP(4);
-    // One global insert per distinct key of the block, ALL AT ONCE: the keys are listed densely first, so thread i takes the
-    // i-th (a sweep over the 1024 table slots, four per thread, made the thread that owned
-    // two occupied slots — and thread 0, which also had the dominant key — do its inserts one after the other: 8.7 us of
-    // a 25 us launch at a million reads, two to three dependent round trips each).  The dominant key goes with the last
-    // thread, which has a list entry of its own only in blocks with 256 or more distinct keys.
-    {
-        // (the list is made by a sweep over the table: four LDS reads per thread and a barrier)
-        for (uint32_t s = tid; s < kLdsSlots; s += 256u)
-            if (s_cnt[s]) s_list[atomicAdd(&s_nlist, 1u)] = (uint16_t)s;
         __syncthreads();
-        const uint32_t n_list = s_nlist;
-        for (uint32_t i = tid; i < n_list; i += 256u) {
-            const uint32_t s = s_list[i];
-            s_gslot[s] = global_insert64(s_key[s], s_cnt[s], s_first[s], slots_mask, slot_key, slot_rep, slot_count, occupied, meta);
+        JL_STAMP(4);
+        // One global insert per distinct key of the block, ALL AT ONCE: the keys are listed densely first, so thread i takes
+        // the i-th (a sweep over the 1024 table slots, four per thread, made the thread that owned two occupied slots — and
+        // thread 0, which also had the dominant key — do its inserts one after the other: 8.7 us of a 25 us launch at a
+        // million reads, two to three dependent round trips each).  The dominant key goes with the last thread, which has
+        // a list entry of its own only in blocks with 256 or more distinct keys.
+        {
+            // (the list is made by a sweep over the table: four LDS reads per thread and a barrier)
+            for (uint32_t s = tid; s < kLdsSlots; s += 256u)
+                if (s_cnt[s]) s_list[atomicAdd(&s_nlist, 1u)] = (uint16_t)s;
+            __syncthreads();
+            const uint32_t n_list = s_nlist;
+            for (uint32_t i = tid; i < n_list; i += 256u) {
+                const uint32_t s = s_list[i];
+                s_gslot[s] = global_insert64(s_key[s], s_cnt[s], s_first[s], slots_mask, T_key, T_rep, T_cnt, T_occ, T_nocc);
+            }
+            if (tid == 255u && s_domcnt)
+                s_domslot = global_insert64(dom, s_domcnt, s_domfirst, slots_mask, T_key, T_rep, T_cnt, T_occ, T_nocc);
         }
-        if (tid == 255u && s_domcnt)
-            s_domslot = global_insert64(dom, s_domcnt, s_domfirst, slots_mask, slot_key, slot_rep, slot_count, occupied, meta);
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            if ((cleanm >> (4 * r)) & 1u) {
+                uint32_t g;
+                if ((isdom >> (4 * r)) & 1u) g = s_domslot;
+                else if (myslot[r] != 0xFFFFFFFFu) g = s_gslot[myslot[r]];
+                else  // LDS table full (> 1024 distinct keys in 2048 reads): straight to the global table
+                    g = global_insert64(kk[r], 1u, (uint32_t)(t * 8u + r), slots_mask, T_key, T_rep, T_cnt, T_occ, T_nocc);
+                gs[r] = g;
+            }
+        }
+        if (KW == 2) __syncthreads();   // the next round clears the LDS tables this one still reads
+    };
+    if constexpr (KW == 1) {
+        group_round(key, slot_key, slot_rep, slot_count, occupied, &meta->n_occupied, gslot, true);
+    } else {
+        uint32_t g0[8] = {0, 0, 0, 0, 0, 0, 0, 0}, g1[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        group_round(key, tw->key_a, nullptr, nullptr, tw->occ_a, tw->n_occ, g0, true);
+        group_round(key1, tw->key_b, nullptr, nullptr, tw->occ_b, tw->n_occ + 1, g1, false);
+        uint64_t key2[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) key2[r] = ((uint64_t)g0[r] << 32) | g1[r];   // never all ones: slots are 31-bit numbers
+        group_round(key2, slot_key, slot_rep, slot_count, occupied, &meta->n_occupied, gslot, false);
     }
     // read categories of this workgroup's reads: written through to its own four words; the selection adds the workgroups
     // up (four atomics per workgroup on ONE cache line were the longest queue of the launch at a million reads)
-    if (tid >= 64u && tid < 68u)  // a lane of another wave than the inserting one
+    if (tid >= 64u && tid < 68u)
         __hip_atomic_store(&w.blockcat[blockIdx.x * 4u + (tid - 64u)], s_cat[tid - 64u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
+    if (!S.fold) {
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
-        if ((cleanm >> (4 * r)) & 1u) {
-            uint32_t g;
-            if ((isdom >> (4 * r)) & 1u) g = s_domslot;
-            else if (myslot[r] != 0xFFFFFFFFu) g = s_gslot[myslot[r]];
-            else  // LDS table full (> 1024 distinct patterns in 2048 reads): straight to the global table
-                g = global_insert64(key[r], 1u, (uint32_t)(t * 8u + r), slots_mask, slot_key, slot_rep, slot_count,
-                                    occupied, meta);
-            if (!S.fold) read_slot[t * 8u + r] = g;
-            gslot[r] = g;
-        }
+        for (int r = 0; r < 8; ++r)
+            if ((cleanm >> (4 * r)) & 1u) read_slot[t * 8u + r] = gslot[r];
     }
     JL_STAMP(5);
     clean_keep = cleanm;
@@ -1160,7 +1296,7 @@ __device__ __forceinline__ void phase_fused1_body(const jl_win_phase &w, const j
         }
         JL_STAMP(9);
         if (fast_export) {
-            phase_export_fast(w, vp, s_cat, &s_running);
+            phase_export_fast<KW>(w, vp, s_cat, &s_running, tw);
             JL_STAMP(10);
             // every wave's stores (the groups may lie in host memory) are performed; ONE system-scope release, carried by
             // the completion word's store, pushes them out in front of it: data and word leave the same workgroup
@@ -1172,7 +1308,31 @@ __device__ __forceinline__ void phase_fused1_body(const jl_win_phase &w, const j
             return;
         }
         bool done = false;
-        if (work && !S.exp_count) done = phase_select_lds(w, s_plan, vp, nv, n_rows, *reinterpret_cast<sel_lds *>(s_tables));
+        if (work && !S.exp_count) done = phase_select_lds<KW>(w, s_plan, vp, nv, n_rows, *reinterpret_cast<sel_lds *>(s_tables), tw);
+        if (KW == 2 && !done) {
+            // More candidates / rows than the selection out of LDS holds (or nothing to phase): the general routine reads
+            // one-word keys, so the run is handed to the multi-word pipeline — tables emptied, the run flagged as one that
+            // needs it (the fetch calls re-run it, as they do for more than 20 positions).
+            __syncthreads();
+            if (work) {
+                const uint32_t n_occ = ld_coherent(&meta->n_occupied);
+                for (uint32_t q = tid; q < n_occ; q += 256u) {
+                    const uint32_t sl = ld_coherent(&occupied[q]);
+                    slot_key[sl] = ~0ull;
+                    slot_rep[sl] = 0xFFFFFFFFu;
+                    slot_count[sl] = 0;
+                }
+                two_word_cleanup(*tw);
+                if (tid == 0) {
+                    __hip_atomic_store(&meta->overflow, 8u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&meta->vp_true, 2u * JL_POS_PER_WORD + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&meta->vp, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&meta->kwords, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&meta->n_occupied, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the general routine below reads these scalars back
+        }
         if (!done) {
             __syncthreads();
             phase_select_block<true>(S.min_reads, reads_pad, keys, meta, slot_rep, slot_count, occupied, S.slot_hap, S.variants,
@@ -1253,15 +1413,17 @@ __device__ __forceinline__ void phase_fused1_body(const jl_win_phase &w, const j
     }
 }
 
-__global__ __launch_bounds__(256) void phase_fused1_kernel(jl_win_phase w) { phase_fused1_body(w); }
-__global__ __launch_bounds__(256) void phase_fused1_direct_kernel(jl_win_phase w, jl_direct_cols dc) { phase_fused1_body(w, &dc); }
+__global__ __launch_bounds__(256) void phase_fused1_kernel(jl_win_phase w) { phase_fused1_body<1>(w); }
+__global__ __launch_bounds__(256) void phase_fused1_direct_kernel(jl_win_phase w, jl_direct_cols dc) { phase_fused1_body<1>(w, &dc); }
+// 11 .. 20 variant positions: the same launch with two key words (jl_two_word)
+__global__ __launch_bounds__(256) void phase_fused2_kernel(jl_win_phase w, jl_two_word tw) { phase_fused1_body<2>(w, nullptr, &tw); }
 
 // one launch for several windows: blockIdx.z = window
 __global__ __launch_bounds__(256) void phase_group_run_kernel(jl_phase_group_args args)
 {
     const jl_win_phase &w = args.w[blockIdx.z];
     if (blockIdx.x >= w.n_blocks + (w.S.called ? 1u : 0u)) return;
-    phase_fused1_body(w);
+    phase_fused1_body<1>(w);
 }
 
 // ---------------------------------------------------------------------------------------- assign
@@ -1390,10 +1552,11 @@ bool jl_launch_phase(jl_ctx *ctx, hipStream_t st, uint32_t min_reads, bool plann
     const bool generic = ctx->phase_generic;
     const bool ids_to_host = ctx->read_hap_out != nullptr;
     const bool signal_select = signal && !ids_to_host;
+    const bool two = ctx->phase_two && !generic;
     if (!planned && !(from_called && !generic))
         hipLaunchKernelGGL(phase_plan_kernel, dim3(1), dim3(1024), 0, st, ctx->d_variants, ctx->d_nvar, JL_VARIANT_CAP,
                            ctx->n_cols, ctx->d_varcol, ctx->d_vpcols, ctx->d_col2pos, ctx->keys_words,
-                           generic ? 0u : 1u, ctx->d_meta);
+                           generic ? 0u : (two ? 2u : 1u), ctx->d_meta);
     const uint32_t n_dwords = (uint32_t)(ctx->col_stride / 4u);
     const uint32_t rblocks = (uint32_t)((ctx->n_reads + 255u) / 256u);
     if (generic)
@@ -1405,7 +1568,12 @@ bool jl_launch_phase(jl_ctx *ctx, hipStream_t st, uint32_t min_reads, bool plann
     // (the multi-word pipeline has its own keys / grouping / selection launches: the fused launch would find nothing to do)
     if (!generic && ctx->direct.on && !w.S.called)
         hipLaunchKernelGGL(phase_fused1_direct_kernel, dim3(w.n_blocks), dim3(256), 0, st, w, ctx->direct);
-    else if (!generic) hipLaunchKernelGGL(phase_fused1_kernel, dim3(w.n_blocks + (w.S.called ? 1u : 0u)), dim3(256), 0, st, w);
+    else if (two) {
+        jl_two_word tw;
+        tw.key_a = (unsigned long long *)ctx->d_slot_key_a; tw.key_b = (unsigned long long *)ctx->d_slot_key_b;
+        tw.occ_a = ctx->d_occ_a; tw.occ_b = ctx->d_occ_b; tw.n_occ = ctx->d_sync + 10;
+        hipLaunchKernelGGL(phase_fused2_kernel, dim3(w.n_blocks + (w.S.called ? 1u : 0u)), dim3(256), 0, st, w, tw);
+    } else if (!generic) hipLaunchKernelGGL(phase_fused1_kernel, dim3(w.n_blocks + (w.S.called ? 1u : 0u)), dim3(256), 0, st, w);
     if (generic) {
         hipLaunchKernelGGL(phase_group_kernel, dim3(rblocks), dim3(256), 0, st, ctx->n_reads, reads_pad, ctx->d_keys,
                            ctx->d_flagw, ctx->d_meta, ctx->table_slots - 1u, ctx->d_slot_rep, ctx->d_slot_count,

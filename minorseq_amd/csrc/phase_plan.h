@@ -6,7 +6,7 @@
 #define JL_PLAN_LDS_WORDS 4096u   // column bitset kept in LDS: windows of up to 131072 columns
 
 // Call with every thread of a block (any multiple of 64 up to 1024).  Writes vpcols / col2pos / meta.
-// `fast_only`: the caller will only run the single-word (Vp <= 10) kernels; more positions set overflow bit 3
+// `fast_only` (1 or 2): the caller will only run the fused launch of that many key words (Vp <= 10 / 20); more positions set overflow bit 3
 // and leave vp = 0 so that the following kernels do nothing and the host re-runs the generic pipeline.
 // Windows of up to 131072 columns mark the variant columns in an LDS bitset and rank them by prefix popcounts
 // (no global round trips besides the variant rows themselves, and not even those when the caller passes their
@@ -85,7 +85,7 @@ __device__ __forceinline__ void jl_phase_plan_block(const jl_variant *variants, 
             meta->overflow = 4u;
             vp = 0;
             kw = 0;
-        } else if (fast_only && kw > 1u) {
+        } else if (fast_only && kw > fast_only) {   // fast_only = key words the fused launch in use covers (1 or 2)
             meta->overflow = 8u;
             vp = 0;
             kw = 0;
