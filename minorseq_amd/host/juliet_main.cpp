@@ -390,6 +390,7 @@ struct RankJob {
     jl_ctx *records = nullptr;
     std::vector<uint32_t> widx;          // this rank's windows (indices into the plan)
     std::vector<jl_ctx *> wins;
+    std::vector<jl_ctx *> spare;         // contexts made in the background while the BAM was decoded
     jl_comm *comm = nullptr;
     std::string error;                   // empty: fine
     // outputs
@@ -407,7 +408,8 @@ void run_rank(RankJob &job, const DeviceStageInput &in, const std::vector<Window
     const uint8_t *refp = in.refcodes->empty() ? nullptr : in.refcodes->data();
     for (uint32_t k : job.widx) {
         jl_ctx *w = nullptr;
-        if (jl_ctx_create(job.device, nullptr, &w) != JL_OK) return fail("context", nullptr);
+        if (!job.spare.empty()) { w = job.spare.back(); job.spare.pop_back(); }
+        else if (jl_ctx_create(job.device, nullptr, &w) != JL_OK) return fail("context", nullptr);
         job.wins.push_back(w);
         if (jl_records_window(job.records, w, plan[k].ncols, plan[k].begin, opt.min_qv) != JL_OK) return fail("ingest", w);
     }
@@ -517,6 +519,9 @@ int main(int argc, char **argv)
         // the GPU context comes up (runtime start, stream, pinned blocks) while the host reads the BAM
         const bool need_gpu = !opt.outputs.empty() || opt.fuse_only;
         std::vector<std::shared_future<std::pair<int, jl_ctx *>>> ctx_ups;
+        // --windows K: the K window contexts come up in the background as well (a context is two dozen device buffers and
+        // three pinned blocks: about 10 ms each, 90 ms for eight when they were made after the decode)
+        std::vector<std::shared_future<std::vector<jl_ctx *>>> win_ups;
         std::unique_ptr<RecordUploader> uploader;
         RecordSink sink;
         if (need_gpu) {
@@ -526,6 +531,20 @@ int main(int argc, char **argv)
                     const int rc = jl_ctx_create(dev, nullptr, &c);
                     return std::make_pair(rc, c);
                 }).share());
+            if (opt.windows > 1 || opt.devices.size() > 1)
+                for (size_t r = 0; r < opt.devices.size(); ++r) {
+                    const size_t R = opt.devices.size();
+                    const uint32_t mine = (uint32_t)((opt.windows * (r + 1) + R - 1) / R - (opt.windows * r) / R) + 1u;   // an upper bound
+                    win_ups.push_back(std::async(std::launch::async, [dev = opt.devices[r], mine]() {
+                        std::vector<jl_ctx *> v;
+                        for (uint32_t k = 0; k < mine; ++k) {
+                            jl_ctx *c = nullptr;
+                            if (jl_ctx_create(dev, nullptr, &c) != JL_OK) break;
+                            v.push_back(c);
+                        }
+                        return v;
+                    }).share());
+                }
             std::error_code ec;
             const uintmax_t fsz = std::filesystem::file_size(opt.bam, ec);
             uploader.reset(new RecordUploader(ctx_ups, ec ? 0 : (uint64_t)fsz, opt.min_qv > 0));
@@ -647,6 +666,7 @@ int main(int argc, char **argv)
                 jobs[r].world = (int)n_ranks;
                 jobs[r].device = opt.devices[r];
                 jobs[r].records = uploader->ctx(r);
+                if (r < win_ups.size()) jobs[r].spare = win_ups[r].get();
                 for (uint32_t k = 0; k < K; ++k)
                     if (plan[k].rank == (int)r) jobs[r].widx.push_back(k);
             }
