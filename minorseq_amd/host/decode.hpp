@@ -25,6 +25,7 @@
 #include <mutex>
 #include <thread>
 
+#include "fast_inflate.hpp"
 #include "msa_builder.hpp"
 
 namespace jlhost {
@@ -256,33 +257,36 @@ private:
         if (free_chunks_.size() < 64) free_chunks_.push_back(std::move(c));
     }
 
+    static uint64_t thread_cpu_ns()
+    {
+        timespec t;
+        clock_gettime(CLOCK_THREAD_CPUTIME_ID, &t);
+        return (uint64_t)t.tv_sec * 1000000000ull + (uint64_t)t.tv_nsec;
+    }
+
     void inflate_segment(Segment &s)
     {
+        const uint64_t c0 = thread_cpu_ns();
         try {
             s.out = take_out();
             s.out.alloc(s.out_total);   // (on a pool thread: a first touch of its pages is part of the parallel work)
-            z_stream z;
+            static thread_local jlz::Inflater inf;   // (26 KB of tables: one per pool thread)
             for (const Segment::Blk &k : s.blks) {
                 if (k.isize == 0) continue;
-                memset(&z, 0, sizeof z);
-                if (inflateInit2(&z, -15) != Z_OK) throw std::runtime_error("inflateInit2 failed");
-                z.next_in = s.comp.data() + k.in_off;
-                z.avail_in = (uInt)k.in_len;
-                z.next_out = s.out.data() + k.out_off;
-                z.avail_out = k.isize;
-                const int rc = inflate(&z, Z_FINISH);
-                inflateEnd(&z);
-                if (rc != Z_STREAM_END || z.avail_out != 0) throw std::runtime_error("BGZF block failed to inflate");
+                if (inf.run(s.comp.data() + k.in_off, k.in_len, s.out.data() + k.out_off, k.isize) != 0)
+                    throw std::runtime_error("BGZF block failed to inflate");
             }
             std::vector<uint8_t>().swap(s.comp);
         } catch (const std::exception &ex) {
             s.error = ex.what();
         }
+        cpu_inflate_ns_ += thread_cpu_ns() - c0;
         set_flag(s, &Segment::inflated);
     }
 
     void parse_segment(Segment &s)
     {
+        const uint64_t c0 = thread_cpu_ns();
         try {
             if (s.error.empty()) {
                 BamRecord scratch;
@@ -317,6 +321,7 @@ private:
         } catch (const std::exception &ex) {
             s.error = ex.what();
         }
+        cpu_parse_ns_ += thread_cpu_ns() - c0;
         set_flag(s, &Segment::parsed);
     }
 
@@ -528,6 +533,9 @@ private:
         reader.join();
         splitter.join();
         if (!err.empty()) throw std::runtime_error(err);
+        if (getenv("JL_DECODE_STATS"))
+            fprintf(stderr, "juliet: decode: %u pool threads, cpu inflate %.1f ms, cpu parse %.1f ms\n", pool_.size(),
+                    cpu_inflate_ns_.load() * 1e-6, cpu_parse_ns_.load() * 1e-6);
         e.ref_id = ref_id_;
         if (refs) *refs = refs_;
         if (header_text) *header_text = text_;
@@ -540,6 +548,7 @@ private:
     bool want_qual_;
     WorkPool pool_;
     size_t max_inflight_;
+    std::atomic<uint64_t> cpu_inflate_ns_{0}, cpu_parse_ns_{0};   // thread CPU time of the two kinds of pool work
     std::atomic<bool> stop_{false};   // set by the consumer on the first error (pushes stop waiting for room; everything still drains)
     Channel to_split_, to_consume_;
     std::mutex pool_m_;

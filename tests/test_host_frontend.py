@@ -287,3 +287,22 @@ def test_pipelined_reader_equals_sequential(tmp_path):
         open(bad, "wb").write(raw[:cut])
         out = subprocess.run([exe, bad, "0", "0"], capture_output=True, text=True)
         assert out.returncode != 0
+
+
+def test_fast_inflate_equals_zlib(tmp_path):
+    """minorseq_amd/host/fast_inflate.hpp (the decoder of the pipelined BAM reader) against zlib on the same raw DEFLATE
+    streams, built with AddressSanitizer + UBSan: every level and strategy of zlib's deflate over seven kinds of input
+    and thirteen sizes, wrong output sizes refused, then corrupted and truncated copies, which must get zlib's verdict
+    and, where both accept, zlib's bytes (tests/cpp/inflate_check.cpp).  Then the blocks of a synthetic BAM."""
+    host = os.path.join(ROOT, "minorseq_amd", "host")
+    exe = str(tmp_path / "inflate_check")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+                           "-I" + host, os.path.join(ROOT, "tests", "cpp", "inflate_check.cpp"), "-lz", "-o", exe])
+    out = subprocess.run([exe, "11", "8"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr + out.stdout
+    assert out.stdout.startswith("ok:")
+    bam = str(tmp_path / "b.bam")
+    subprocess.check_call([os.path.join(ROOT, "minorseq_amd", "bin", "juliet-synth"), "--reads", "2000", "--cols", "900", "--seed", "4",
+                           "-o", bam, "--config-out", str(tmp_path / "b.json")])
+    out = subprocess.run([exe, "bench", bam], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "bytes agree" in out.stdout, out.stderr + out.stdout
