@@ -631,7 +631,7 @@ class Juliet:
             if v.phased:
                 c.update(pos_cols=_view(v.pos_cols, np.uint32, 128), hap_count=_view(v.hap_count, np.uint32, 128),
                          hap_pattern=_view(v.hap_pattern, np.uint8, PACK_PATTERN_BYTES), hit=_view(v.hit, np.uint8, PACK_HIT_BYTES),
-                         cooc=_view(v.cooc, np.uint32, 1024) if v.cooc else None,
+                         cooc=_view(v.cooc, np.uint32, 4096) if v.cooc else None,
                          ids=_view(v.read_hap_packed, np.uint8, 2 * v.n_reads) if v.read_hap_packed else None)
             self._rv_cache = {key: c}
         nv = v.n_variants

@@ -66,7 +66,7 @@ struct jl_phase_meta {  // device-resident scalars of one phasing run
 #define JL_PACK_PATTERN_BYTES 8192u   // e.g. 128 haplotypes x 64 positions
 #define JL_PACK_HIT_BYTES 16384u      // e.g. 128 variants x 128 haplotypes
 #define JL_SEL_HIT_BYTES 8192u        // what the selection out of LDS holds of it (larger results take the general path)
-#define JL_PACK_COOC_N 32u
+#define JL_PACK_COOC_N 64u
 #define JL_PACK_MAGIC 0x4A4C504Bu
 struct jl_pack {
     uint32_t magic, nvar_total, fits_call, fits_phase;

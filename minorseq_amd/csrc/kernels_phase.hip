@@ -641,58 +641,91 @@ struct sel_lds {
     unsigned long long key[kSelCand], key1[kSelCand];     // key1 / hkey1: the second word of a two-word pattern
     uint32_t hcnt[kSelCand];
     unsigned long long hkey[kSelCand], hkey1[kSelCand];
-    uint32_t vpos[JL_PACK_MAX_VAR];
-    uint8_t vcodon[JL_PACK_MAX_VAR];
+    uint32_t vpos[JL_PACK_MAX_VAR];   // per variant row: how its position reads out of a pattern (see the selection)
     uint8_t hit[JL_SEL_HIT_BYTES];
     uint32_t hmask[JL_PACK_MAX_VAR][kSelCand / 32u];   // per variant: the haplotypes that carry it (co-occurrence sums)
     uint32_t ncand, insufficient, reported, bail;
 };
 static_assert(sizeof(sel_lds) <= kLdsSlots * 5u * 4u, "the selection's scratch must fit the grouping tables");
+static_assert(offsetof(sel_lds, hmask) % 8 == 0, "a variant's haplotype set is read as two 64-bit words");
 
 // KW = 2: the main table's key of a group is the pair (slot of its first word in table A, slot of its second word in
 // table B); the words themselves are one more round trip away (jl_two_word).
 template <int KW>
 __device__ __forceinline__ bool phase_select_lds(const jl_win_phase &w, const plan_state &L, uint32_t vp, uint32_t nv,
-                                                 uint32_t n_rows, sel_lds &T, const jl_two_word *tw = nullptr)
+                                                 uint32_t n_rows, sel_lds &T, const jl_two_word *tw, uint32_t n_occ, uint32_t occ0,
+                                                 const uint32_t *cat, uint32_t *id_bits_out)
 {
+    // n_occ, occ0: the group count and this thread's first entry of the group list, loaded by the caller beside the read
+    // categories (occ0 is only meaningful below n_occ); cat: the read categories of the whole window (LDS)
     const select_args &S = w.S;
     jl_phase_meta *meta = w.meta;
     const uint32_t tid = threadIdx.x, nt = blockDim.x;
-    const uint32_t n_occ = ld_coherent(&meta->n_occupied);
     if (tid == 0) { T.ncand = 0; T.insufficient = 0; T.reported = 0; T.bail = (nv > JL_PACK_MAX_VAR || n_rows > JL_PACK_MAX_VAR) ? 1u : 0u; }
     __syncthreads();
     if (T.bail) return false;
     // The groups, four per thread and trip: all of a thread's list entries are loaded before any is used, then all their
     // counts and keys (one dependent round trip per 1024 groups each way instead of one per 256: at 725 groups the scan was
     // a quarter of the selection).
+    // Same-address LDS atomics serialise: one per non-candidate group (616 of 725 at sixteen positions) was most of the
+    // scan.  The read counts of those groups add up in registers (one atomic per wave at the end); candidates are numbered
+    // a wave at a time (ballot + one atomic per wave and trip).
+    uint32_t insufficient = 0;
+    const uint32_t lane = tid & 63u;
+    uint32_t sl_keep[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};   // the first 1024 groups' slots: emptied from registers below
+    // the two-word launch's half-key lists, for the same purpose: counts and each thread's first entries, requested now
+    uint32_t tw_n[2] = {0, 0}, tw_first[2] = {0, 0};
+    if (KW == 2) {
+        tw_n[0] = ld_coherent(&tw->n_occ[0]);
+        tw_n[1] = ld_coherent(&tw->n_occ[1]);
+        tw_first[0] = ld_coherent(&tw->occ_a[tid]);   // (the lists hold at least 256 entries; used below the counts only)
+        tw_first[1] = ld_coherent(&tw->occ_b[tid]);
+    }
     for (uint32_t q0 = 0; q0 < n_occ; q0 += 4u * nt) {
         uint32_t sl[4], cn[4];
         unsigned long long ky[4];
 #pragma unroll
         for (uint32_t j = 0; j < 4u; ++j) {
             const uint32_t q = q0 + j * nt + tid;
-            sl[j] = q < n_occ ? ld_coherent(&w.occupied[q]) : 0xFFFFFFFFu;
+            sl[j] = q < n_occ ? ((q0 == 0u && j == 0u) ? occ0 : ld_coherent(&w.occupied[q])) : 0xFFFFFFFFu;
         }
 #pragma unroll
         for (uint32_t j = 0; j < 4u; ++j) {
-            if (sl[j] == 0xFFFFFFFFu) continue;
-            cn[j] = ld_coherent(&w.slot_count[sl[j]]);
-            ky[j] = ld_coherent64(&w.slot_key[sl[j]]);
-        }
-#pragma unroll
-        for (uint32_t j = 0; j < 4u; ++j) {
-            if (sl[j] == 0xFFFFFFFFu) continue;
-            const uint32_t s = sl[j], c = cn[j];
-            if (c >= S.min_reads) {
-                const uint32_t i = atomicAdd(&T.ncand, 1u);
-                if (i < kSelCand) { T.slot[i] = s; T.cnt[i] = c; T.key[i] = ky[j]; }
-                else T.bail = 1u;
-            } else {
-                atomicAdd(&T.insufficient, c);
-                __hip_atomic_store(&S.slot_hap[s], (uint32_t)JL_HAP_INSUFFICIENT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            cn[j] = 0;
+            ky[j] = 0;
+            if (sl[j] != 0xFFFFFFFFu) {
+                cn[j] = ld_coherent(&w.slot_count[sl[j]]);
+                ky[j] = ld_coherent64(&w.slot_key[sl[j]]);
             }
         }
+#pragma unroll
+        for (uint32_t j = 0; j < 4u; ++j) {
+            const bool have = sl[j] != 0xFFFFFFFFu;
+            const bool cand = have && cn[j] >= S.min_reads;
+            const unsigned long long m = __ballot(cand);
+            if (m) {   // wave-uniform
+                uint32_t base = 0;
+                const uint32_t leader = (uint32_t)__ffsll((long long)m) - 1u;
+                if (lane == leader) base = atomicAdd(&T.ncand, (uint32_t)__popcll(m));
+                base = (uint32_t)__shfl((int)base, (int)leader, 64);
+                if (cand) {
+                    const uint32_t i = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                    if (i < kSelCand) { T.slot[i] = sl[j]; T.cnt[i] = cn[j]; T.key[i] = ky[j]; }
+                    else T.bail = 1u;
+                }
+            }
+            if (have && !cand) {
+                insufficient += cn[j];
+                __hip_atomic_store(&S.slot_hap[sl[j]], (uint32_t)JL_HAP_INSUFFICIENT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        if (q0 == 0u) {
+#pragma unroll
+            for (uint32_t j = 0; j < 4u; ++j) sl_keep[j] = sl[j];
+        }
     }
+    insufficient = wave_sum_all(insufficient);
+    if (lane == 0 && insufficient) atomicAdd(&T.insufficient, insufficient);
     // the variant rows: column -> position index, codon (the table may come from another workgroup of this launch)
     for (uint32_t v = tid; v < nv; v += nt) {
         const uint32_t *row = reinterpret_cast<const uint32_t *>(S.variants + v);
@@ -700,8 +733,13 @@ __device__ __forceinline__ bool phase_select_lds(const jl_win_phase &w, const pl
         uint32_t pos = 0xFFu;
         if (c + 2u < S.n_cols)
             for (uint32_t p = 0; p < vp; ++p) pos = L.cols[p] == c ? p : pos;
-        T.vpos[v] = pos;
-        T.vcodon[v] = (uint8_t)((cw >> 8) & 0xFFu);
+        // how the hit loop reads this variant's position out of a pattern: bits 0-5 the shift, bit 6 the word, bits 8-15
+        // the codon; bit 31: no such position
+        const uint32_t n0 = vp < JL_POS_PER_WORD ? vp : JL_POS_PER_WORD;
+        uint32_t e = 0x80000000u;
+        if (pos != 0xFFu)
+            e = (pos < n0 ? 6u * (n0 - 1u - pos) : (64u | (6u * (vp - n0 - 1u - (pos - n0))))) | (((cw >> 8) & 0xFFu) << 8);
+        T.vpos[v] = e;
     }
     __syncthreads();
     JL_STAMP(13);
@@ -715,6 +753,30 @@ __device__ __forceinline__ bool phase_select_lds(const jl_win_phase &w, const pl
         }
         __syncthreads();
     }
+    JL_STAMP(23);
+    // Nothing below gives the run back to the general routine, and nothing reads the tables again: they are left empty for
+    // the next run now (only the slots this run touched) — stores that go out beside the ranking instead of behind it.
+    // (the first 1024 groups' slots are still in registers from the scan: stores only)
+#pragma unroll
+    for (uint32_t j = 0; j < 4u; ++j)
+        if (sl_keep[j] != 0xFFFFFFFFu) {
+            w.slot_key[sl_keep[j]] = ~0ull;
+            w.slot_rep[sl_keep[j]] = 0xFFFFFFFFu;
+            w.slot_count[sl_keep[j]] = 0;
+        }
+    for (uint32_t q = 4u * nt + tid; q < n_occ; q += nt) {
+        const uint32_t sl = ld_coherent(&w.occupied[q]);
+        w.slot_key[sl] = ~0ull;
+        w.slot_rep[sl] = 0xFFFFFFFFu;
+        w.slot_count[sl] = 0;
+    }
+    if (KW == 2) {
+        if (tid < tw_n[0]) tw->key_a[tw_first[0]] = ~0ull;
+        if (tid < tw_n[1]) tw->key_b[tw_first[1]] = ~0ull;
+        for (uint32_t q = nt + tid; q < tw_n[0]; q += nt) tw->key_a[ld_coherent(&tw->occ_a[q])] = ~0ull;
+        for (uint32_t q = nt + tid; q < tw_n[1]; q += nt) tw->key_b[ld_coherent(&tw->occ_b[q])] = ~0ull;
+        if (tid == 0) { tw->n_occ[0] = 0; tw->n_occ[1] = 0; }   // (every thread has its copy of the counts)
+    }
     // rank: (count desc, pattern asc); patterns are unique, so the ranks are a permutation.  Two threads per candidate
     // (at most 128 of them, 256 threads): each counts the competitors of one half that come before it.
     uint32_t *half_rank = reinterpret_cast<uint32_t *>(T.hit);   // [kSelCand] scratch: the hit matrix is filled later
@@ -726,80 +788,142 @@ __device__ __forceinline__ bool phase_select_lds(const jl_win_phase &w, const pl
             const unsigned long long ka = T.key[a], ka1 = KW == 2 ? T.key1[a] : 0ull;
             const uint32_t b0 = tid < 128u ? 0u : H / 2u, b1 = tid < 128u ? H / 2u : H;
             uint32_t r = 0;
-            for (uint32_t b = b0; b < b1; ++b) {
-                const bool before = KW == 2 ? (T.key[b] < ka || (T.key[b] == ka && T.key1[b] < ka1)) : T.key[b] < ka;
-                r += (T.cnt[b] > ca || (T.cnt[b] == ca && before)) ? 1u : 0u;
+            // eight competitors' words are on their way from LDS before the first is compared (one at a time the loop
+            // waited out an LDS round trip per competitor: 8 us at 109 candidates)
+            for (uint32_t b = b0; b < b1; b += 8u) {
+                uint32_t cb[8];
+                unsigned long long kb[8], kb1[8];
+#pragma unroll
+                for (uint32_t j = 0; j < 8u; ++j) {
+                    const uint32_t i = b + j < b1 ? b + j : b1 - 1u;
+                    cb[j] = T.cnt[i];
+                    kb[j] = T.key[i];
+                    kb1[j] = KW == 2 ? T.key1[i] : 0ull;
+                }
+#pragma unroll
+                for (uint32_t j = 0; j < 8u; ++j) {
+                    const bool before = KW == 2 ? (kb[j] < ka || (kb[j] == ka && kb1[j] < ka1)) : kb[j] < ka;
+                    r += (b + j < b1 && (cb[j] > ca || (cb[j] == ca && before))) ? 1u : 0u;
+                }
             }
             if (tid < 128u) my_rank = r;
             else half_rank[a] = r;
         }
     }
     __syncthreads();
-    for (uint32_t a = tid; a < H; a += nt) {   // (H <= 128: the threads that hold my_rank)
-        const uint32_t ca = T.cnt[a];
-        const unsigned long long ka = T.key[a], ka1 = KW == 2 ? T.key1[a] : 0ull;
-        const uint32_t rank = my_rank + half_rank[a];
-        T.hcnt[rank] = ca;
-        T.hkey[rank] = ka;
-        if (KW == 2) T.hkey1[rank] = ka1;
-        __hip_atomic_store(&S.slot_hap[T.slot[a]], rank, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // read by other workgroups
-        atomicAdd(&T.reported, ca);
+    JL_STAMP(24);
+    {   // (H <= 128: the threads that hold my_rank)
+        uint32_t ca = 0;
+        if (tid < H) {
+            ca = T.cnt[tid];
+            const unsigned long long ka = T.key[tid], ka1 = KW == 2 ? T.key1[tid] : 0ull;
+            const uint32_t rank = my_rank + half_rank[tid];
+            T.hcnt[rank] = ca;
+            T.hkey[rank] = ka;
+            if (KW == 2) T.hkey1[rank] = ka1;
+            __hip_atomic_store(&S.slot_hap[T.slot[tid]], rank, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // read by other workgroups
+        }
+        const uint32_t rs = wave_sum_all(ca);
+        if ((tid & 63u) == 0 && rs) atomicAdd(&T.reported, rs);
     }
     __syncthreads();
-    // hit[v][h] and, per variant, the set of haplotypes that carry it as bits: a wave per variant, a lane per haplotype
-    // (no division per element; the set makes the co-occurrence sums a walk over a few common bits instead of H terms)
-    for (uint32_t v = tid >> 6; v < nv; v += nt >> 6) {
-        const uint32_t pos = T.vpos[v], codon = T.vcodon[v];
-        for (uint32_t h0 = 0; h0 < H; h0 += 64u) {
-            const uint32_t h = h0 + (tid & 63u);
-            bool x = false;
-            if (h < H && pos != 0xFFu)
-                x = (KW == 2 ? key_code2(T.hkey[h], T.hkey1[h], vp, pos) : key_code(T.hkey[h], vp, pos)) == codon;
+    JL_STAMP(25);
+    // hit[v][h] and, per variant, the set of haplotypes that carry it as bits: a lane per haplotype (its pattern words in
+    // registers), a wave per variant (no division per element; the set makes the co-occurrence sums a walk over a few
+    // common bits instead of H terms).  Beside it the patterns as bytes, [h][p], in the scratch the ranking is done with.
+    uint8_t *pat = reinterpret_cast<uint8_t *>(T.slot);
+    static_assert(offsetof(sel_lds, hcnt) >= kSelCand * 2u * JL_POS_PER_WORD + 8u, "the pattern bytes reuse slot/cnt/key/key1");
+    for (uint32_t h0 = 0; h0 < H; h0 += 64u) {
+        const uint32_t h = h0 + (tid & 63u);
+        const unsigned long long k0 = h < H ? T.hkey[h] : 0ull, k1 = (KW == 2 && h < H) ? T.hkey1[h] : 0ull;
+        for (uint32_t v = tid >> 6; v < nv; v += nt >> 6) {
+            const uint32_t e = T.vpos[v];   // (wave-uniform)
+            const unsigned long long word = (KW == 2 && (e & 64u)) ? k1 : k0;
+            const bool x = h < H && !(e & 0x80000000u) && ((uint32_t)(word >> (e & 63u)) & 63u) == ((e >> 8) & 0xFFu);
             if (h < H) T.hit[v * H + h] = x ? 1 : 0;
             const unsigned long long m = __ballot(x);
             if ((tid & 63u) == 0) { T.hmask[v][h0 / 32u] = (uint32_t)m; T.hmask[v][h0 / 32u + 1u] = (uint32_t)(m >> 32); }
         }
     }
+    for (uint32_t h = tid & 127u; h < H; h += 128u) {   // (slot / cnt / key / key1 are dead: the ranks are out)
+        const unsigned long long k0 = T.hkey[h], k1 = KW == 2 ? T.hkey1[h] : 0ull;
+        for (uint32_t p = tid >> 7; p < vp; p += 2u) pat[h * vp + p] = (uint8_t)(KW == 2 ? key_code2(k0, k1, vp, p) : key_code(k0, vp, p));
+    }
+    if (tid < 8u) {   // whole 8-byte words leave below: their tails are zeros
+        pat[H * vp + tid] = 0;
+        if (nv * H + tid < JL_SEL_HIT_BYTES) T.hit[nv * H + tid] = 0;
+    }
     __syncthreads();
     const uint32_t bits = id_bits_for(H);
+    *id_bits_out = bits;   // (every thread: a register of the caller)
     JL_STAMP(14);
-    // ---- outputs.  The resident arrays (stage-API fetches read them) ...
-    for (uint32_t h = tid; h < H; h += nt) S.hap_count[h] = T.hcnt[h];
-    for (uint32_t q = tid; q < H * vp; q += nt) {
-        const uint32_t h = q / vp, p = q - h * vp;
-        S.hap_pattern[(uint64_t)h * JL_VARIANT_CAP + p] = (uint8_t)(KW == 2 ? key_code2(T.hkey[h], T.hkey1[h], vp, p) : key_code(T.hkey[h], vp, p));
-    }
-    for (uint32_t q = tid; q < nv * H; q += nt) S.hit[(uint64_t)(q / H) * JL_MAX_HAPLOTYPES + (q % H)] = T.hit[q];
     const uint32_t nvc = nv < S.cooc_cap ? nv : S.cooc_cap;
     const bool cooc_fits = nv <= JL_PACK_COOC_N;
+    // ---- outputs.  The resident arrays are what the stage-API fetches read; a whole-path run whose results fit the result
+    // block is read from that block alone (jl_phase_fetch, jl_run_view_get), so they are not written then (byte stores
+    // with a division each: 6 us of the 36 the selection took at sixteen positions) ...
+    const bool resident = S.called == nullptr || !cooc_fits;
+    if (resident) {
+        for (uint32_t h = tid; h < H; h += nt) S.hap_count[h] = T.hcnt[h];
+        for (uint32_t h = tid & 127u; h < H; h += 128u)
+            for (uint32_t p = tid >> 7; p < vp; p += 2u) S.hap_pattern[(uint64_t)h * JL_VARIANT_CAP + p] = pat[h * vp + p];
+        for (uint32_t v = tid >> 6; v < nv; v += nt >> 6)
+            for (uint32_t h = tid & 63u; h < H; h += 64u) S.hit[(uint64_t)v * JL_MAX_HAPLOTYPES + h] = T.hit[v * H + h];
+    }
+    JL_STAMP(26);
     jl_pack *pk = S.pk + (__hip_atomic_load(S.seq_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 1u);
     jl_pack *dsts[2] = {pk, S.mirror};
-    for (uint32_t q = tid; q < nvc * nvc; q += nt) {
-        const uint32_t v = q / nvc, x = q - v * nvc;
-        uint32_t sum = 0;
-        for (uint32_t j = 0; j < (H + 31u) / 32u; ++j) {
-            uint32_t m = T.hmask[v][j] & T.hmask[x][j];
-            while (m) {
-                sum += T.hcnt[32u * j + (uint32_t)__ffs((int)m) - 1u];
-                m &= m - 1u;
-            }
+    // Co-occurrence C[v][x] = sum over the haplotypes that carry both of their read counts.  The counts are cut into bit
+    // planes (plane b = the haplotypes whose count has bit b set, as a 128-bit set): C = sum_b 2^b popcount(set_v & set_x &
+    // plane_b) — a fixed two dozen words per pair, no walk over the common haplotypes (7 us at 38 variants x 109
+    // haplotypes).  The matrix is symmetric: a thread per pair v <= x of the upper triangle.
+    unsigned long long *plane = T.hkey;   // [32][2]: the patterns are out as bytes, their words are dead
+    static_assert(sizeof(T.hkey) >= 32u * 2u * 8u && kSelCand == 128u, "the bit planes reuse hkey; a set is two 64-bit words");
+    const uint32_t n_planes = 32u - (uint32_t)__clz((int)(T.hcnt[0] | 1u));   // rank 0 holds the largest count
+    if (tid < 128u) {
+        const uint32_t c = tid < H ? T.hcnt[tid] : 0u;
+        for (uint32_t b = 0; b < n_planes; ++b) {
+            const unsigned long long m = __ballot((c >> b) & 1u);
+            if ((tid & 63u) == 0) plane[b * 2u + (tid >> 6)] = m;
         }
-        S.cooc[(uint64_t)v * S.cooc_cap + x] = sum;
+    }
+    __syncthreads();
+    const uint32_t n_pairs = nvc * (nvc + 1u) / 2u;
+    for (uint32_t q = tid; q < n_pairs; q += nt) {
+        // q -> (v, x) of the upper triangle, rows v = 0 .. nvc-1 of lengths nvc, nvc-1, ...: the row from the closed form
+        // (single precision is exact enough below 2^24 pairs), then at most one step either way
+        const float nn = 2.0f * (float)nvc + 1.0f;
+        uint32_t v = (uint32_t)((nn - __fsqrt_rn(nn * nn - 8.0f * (float)q)) * 0.5f);
+        if (v >= nvc) v = nvc - 1u;
+        while (v > 0u && v * nvc - v * (v - 1u) / 2u > q) --v;
+        while ((v + 1u) * nvc - (v + 1u) * v / 2u <= q) ++v;
+        const uint32_t x = v + (q - (v * nvc - v * (v - 1u) / 2u));
+        const unsigned long long *mv = reinterpret_cast<const unsigned long long *>(T.hmask[v]);
+        const unsigned long long *mx = reinterpret_cast<const unsigned long long *>(T.hmask[x]);
+        const unsigned long long a0 = mv[0] & mx[0], a1 = mv[1] & mx[1];
+        uint32_t sum = 0;
+        if (a0 | a1)
+            for (uint32_t b = 0; b < n_planes; ++b)
+                sum += (uint32_t)(__popcll(a0 & plane[b * 2u]) + __popcll(a1 & plane[b * 2u + 1u])) << b;
+        if (resident) {
+            S.cooc[(uint64_t)v * S.cooc_cap + x] = sum;
+            S.cooc[(uint64_t)x * S.cooc_cap + v] = sum;
+        }
         if (cooc_fits)
 #pragma unroll
             for (int t = 0; t < 2; ++t)
-                if (dsts[t]) dsts[t]->cooc[v * nv + x] = sum;
+                if (dsts[t]) { dsts[t]->cooc[v * nv + x] = sum; dsts[t]->cooc[x * nv + v] = sum; }
     }
     JL_STAMP(15);
-    // ... and the result block, device copy (all-gather source) and pinned host mirror, straight from LDS
+    // ... and the result block, device copy (all-gather source) and pinned host mirror, straight from LDS, eight bytes a store
     if (tid == 0) {
         jl_phase_summary sm;
         sm.reported_reads = T.reported;
         sm.insufficient_reads = T.insufficient;
-        sm.damaged_reads = ld_coherent(&meta->summary.damaged_reads);
-        sm.marginal_gap = ld_coherent(&meta->summary.marginal_gap);
-        sm.marginal_heteroduplex = ld_coherent(&meta->summary.marginal_heteroduplex);
-        sm.marginal_partial = ld_coherent(&meta->summary.marginal_partial);
+        sm.damaged_reads = cat[0];
+        sm.marginal_gap = cat[1];
+        sm.marginal_heteroduplex = cat[2];
+        sm.marginal_partial = cat[3];
         sm.n_positions = vp;
         sm.n_haplotypes = H;
         meta->summary.reported_reads = sm.reported_reads;
@@ -817,28 +941,29 @@ __device__ __forceinline__ bool phase_select_lds(const jl_win_phase &w, const pl
             o->summary = sm;
         }
     }
+    static_assert(offsetof(jl_pack, hap_pattern) % 8 == 0 && offsetof(jl_pack, hit) % 8 == 0 && offsetof(jl_pack, hap_count) % 8 == 0 &&
+                  offsetof(jl_pack, variants) % 8 == 0 && offsetof(sel_lds, hit) % 8 == 0 && offsetof(sel_lds, hcnt) % 8 == 0,
+                  "the result block's arrays leave as 8-byte words");
+    {
+        const unsigned long long *pat8 = reinterpret_cast<const unsigned long long *>(pat);
+        const unsigned long long *hit8 = reinterpret_cast<const unsigned long long *>(T.hit);
+        const unsigned long long *cnt8 = reinterpret_cast<const unsigned long long *>(T.hcnt);
+        const uint32_t n_pat8 = (H * vp + 7u) / 8u, n_hit8 = (nv * H + 7u) / 8u < JL_SEL_HIT_BYTES / 8u ? (nv * H + 7u) / 8u : JL_SEL_HIT_BYTES / 8u;
+        const uint32_t n_cnt8 = (H + 1u) / 2u;   // (hcnt holds kSelCand words: an odd H takes one stale word along, never read)
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        jl_pack *o = dsts[t];
-        if (!o) continue;
-        for (uint32_t i = tid; i < nv * (uint32_t)(sizeof(jl_variant) / 8); i += nt)
-            reinterpret_cast<unsigned long long *>(o->variants)[i] =
-                ld_coherent64(reinterpret_cast<const unsigned long long *>(S.variants) + i);
-        for (uint32_t i = tid; i < vp; i += nt) o->pos_cols[i] = L.cols[i];
-        for (uint32_t i = tid; i < H; i += nt) o->hap_count[i] = T.hcnt[i];
-        for (uint32_t i = tid; i < H * vp; i += nt)
-            o->hap_pattern[i] = (uint8_t)(KW == 2 ? key_code2(T.hkey[i / vp], T.hkey1[i / vp], vp, i % vp) : key_code(T.hkey[i / vp], vp, i % vp));
-        for (uint32_t i = tid; i < nv * H; i += nt) o->hit[i] = T.hit[i];
+        for (int t = 0; t < 2; ++t) {
+            jl_pack *o = dsts[t];
+            if (!o) continue;
+            for (uint32_t i = tid; i < nv * (uint32_t)(sizeof(jl_variant) / 8); i += nt)
+                reinterpret_cast<unsigned long long *>(o->variants)[i] =
+                    ld_coherent64(reinterpret_cast<const unsigned long long *>(S.variants) + i);
+            for (uint32_t i = tid; i < vp; i += nt) o->pos_cols[i] = L.cols[i];
+            for (uint32_t i = tid; i < n_cnt8; i += nt) reinterpret_cast<unsigned long long *>(o->hap_count)[i] = cnt8[i];
+            for (uint32_t i = tid; i < n_pat8; i += nt) reinterpret_cast<unsigned long long *>(o->hap_pattern)[i] = pat8[i];
+            for (uint32_t i = tid; i < n_hit8; i += nt) reinterpret_cast<unsigned long long *>(o->hit)[i] = hit8[i];
+        }
     }
     JL_STAMP(16);
-    // leave the table empty for the next run: only the slots this run touched
-    for (uint32_t q = tid; q < n_occ; q += nt) {
-        const uint32_t s = ld_coherent(&w.occupied[q]);
-        w.slot_key[s] = ~0ull;
-        w.slot_rep[s] = 0xFFFFFFFFu;
-        w.slot_count[s] = 0;
-    }
-    if (KW == 2) two_word_cleanup(*tw);
     JL_STAMP(17);
     if (tid == 0 && JL_STAMP_ON) g_stamps[18] = n_occ;
     return true;
@@ -1262,6 +1387,12 @@ __device__ __forceinline__ void phase_fused1_body(const jl_win_phase &w, const j
         JL_STAMP(8);
         uint32_t nv = 0, seq_before = 0;
         const bool fast_export = work && S.exp_count != nullptr;
+        // the selection's first loads go out beside those of the read categories (the list entry is used below the count only)
+        uint32_t n_occ_pre = 0, occ_pre = 0;
+        if (work && !S.exp_count) {
+            n_occ_pre = ld_coherent(&meta->n_occupied);
+            occ_pre = ld_coherent(&occupied[tid]);   // (the list holds at least 256 entries: reserve_phase)
+        }
         if (!S.exp_count) {   // (an exporting selection needs neither: it ranks nothing)
             nv = from_called ? (n_rows < S.cap ? n_rows : S.cap) : ld_coherent(&meta->n_var);
             if (!from_called) n_rows = ld_coherent(&S.n_rows[0]);
@@ -1283,15 +1414,11 @@ __device__ __forceinline__ void phase_fused1_body(const jl_win_phase &w, const j
                 for (int k = 0; k < 4; ++k) atomicAdd(&s_cat[k], c4[k]);
             }
             __syncthreads();
-            if (!fast_export) {   // the selection routines read them from the run's scalars
-                if (tid == 0) {
-                    __hip_atomic_store(&meta->summary.damaged_reads, s_cat[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(&meta->summary.marginal_gap, s_cat[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(&meta->summary.marginal_heteroduplex, s_cat[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(&meta->summary.marginal_partial, s_cat[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
+            if (!fast_export && tid == 0) {   // the run's scalars (the general selection and the stage-API fetches read them there)
+                __hip_atomic_store(&meta->summary.damaged_reads, s_cat[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&meta->summary.marginal_gap, s_cat[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&meta->summary.marginal_heteroduplex, s_cat[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&meta->summary.marginal_partial, s_cat[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
         JL_STAMP(9);
@@ -1308,7 +1435,10 @@ __device__ __forceinline__ void phase_fused1_body(const jl_win_phase &w, const j
             return;
         }
         bool done = false;
-        if (work && !S.exp_count) done = phase_select_lds<KW>(w, s_plan, vp, nv, n_rows, *reinterpret_cast<sel_lds *>(s_tables), tw);
+        uint32_t sel_bits = 0;   // width of the ids, when the selection out of LDS ran
+        if (work && !S.exp_count)
+            done = phase_select_lds<KW>(w, s_plan, vp, nv, n_rows, *reinterpret_cast<sel_lds *>(s_tables), tw, n_occ_pre, occ_pre, s_cat,
+                                        &sel_bits);
         if (KW == 2 && !done) {
             // More candidates / rows than the selection out of LDS holds (or nothing to phase): the general routine reads
             // one-word keys, so the run is handed to the multi-word pipeline — tables emptied, the run flagged as one that
@@ -1334,6 +1464,7 @@ __device__ __forceinline__ void phase_fused1_body(const jl_win_phase &w, const j
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the general routine below reads these scalars back
         }
         if (!done) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the read categories: it reads them from the run's scalars)
             __syncthreads();
             phase_select_block<true>(S.min_reads, reads_pad, keys, meta, slot_rep, slot_count, occupied, S.slot_hap, S.variants,
                                      S.col2pos, S.n_cols, S.hap_count, S.hap_pattern, S.hit, S.n_rows, w.vpcols, S.cooc, S.cooc_cap,
@@ -1354,10 +1485,11 @@ __device__ __forceinline__ void phase_fused1_body(const jl_win_phase &w, const j
         // the slot -> haplotype table is complete (write-through stores, drained above): release the waiting
         // workgroups; the flag carries the width of the ids
         if (tid == 0) {
-            const uint32_t bits = ld_coherent(&meta->id_bits);
+            const uint32_t bits = done ? sel_bits : ld_coherent(&meta->id_bits);
             s_idbits = bits;
             __hip_atomic_store(S.flag, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        JL_STAMP(19);
         __syncthreads();
     } else {
         // wait for the selection.  Every workgroup of this launch is resident (the host folds only small grids), so
@@ -1377,6 +1509,7 @@ __device__ __forceinline__ void phase_fused1_body(const jl_win_phase &w, const j
             }
             s_idbits = bits;   // 0: timed out
         }
+        JL_STAMP(20);
         __syncthreads();
     }
     // ---- per-read haplotype ids of this workgroup's own reads, straight from the slots still in registers
@@ -1394,6 +1527,7 @@ __device__ __forceinline__ void phase_fused1_body(const jl_win_phase &w, const j
     // counter) for the next launch and, when this launch ends a run, stores the completion word behind all the ids.
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    JL_STAMP(21);
     if (tid == 0) {
         if (S.seq_host) __threadfence_system();   // this workgroup's ids leave its die's L2 before it arrives (see above)
         const uint32_t prev = __hip_atomic_fetch_add(S.arrive2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1409,6 +1543,7 @@ __device__ __forceinline__ void phase_fused1_body(const jl_win_phase &w, const j
                 __hip_atomic_store(&pk->magic, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             if (S.seq_host) signal_done(S.seq_dev, S.seq_host);
+            JL_STAMP(22);
         }
     }
 }

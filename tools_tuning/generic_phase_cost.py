@@ -57,12 +57,11 @@ if hasattr(jl.lib, "jl_debug_stamps"):   # -DJL_EXP_STAMPS build: device-clock s
     import ctypes as C
     st = np.zeros(64, dtype=np.uint64)
     jl.lib.jl_debug_stamps(st.ctypes.data_as(C.c_void_p))
-    names = ["entry", "plan", "keys built", "dominant key (last round)", "LDS table (last round)", "after the rounds", "before arrival",
-             "after arrival", "LAST: start", "LAST: categories", "LAST: export done", "LAST: stores drained", "LAST: signalled"]
     t0 = int(st[0])
-    for k, nm in enumerate(names[:9]):
-        print(f"  {nm:28s} {(int(st[k]) - t0) / 100.0:8.2f}")
-    for k, nm in ((13, "SELECT: groups scanned"), (14, "SELECT: ranked + hit"), (15, "SELECT: resident arrays"), (16, "SELECT: result blocks"),
-                  (17, "SELECT: tables emptied")):
-        print(f"  {nm:28s} {(int(st[k]) - t0) / 100.0:8.2f}")
+    for k, nm in ((0, "entry (workgroup 0)"), (1, "plan"), (2, "keys built"), (3, "dominant key (last round)"), (4, "LDS table (last round)"),
+                  (5, "global inserts done"), (6, "before arrival"), (7, "after arrival"), (8, "LAST: start"), (9, "LAST: categories"),
+                  (13, "SELECT: groups scanned"), (23, "SELECT: two-word keys"), (24, "SELECT: rank counted"), (25, "SELECT: ranked"), (14, "SELECT: hit"), (26, "SELECT: resident hap arrays"), (15, "SELECT: resident arrays"), (16, "SELECT: result blocks"),
+                  (17, "SELECT: tables emptied"), (19, "LAST: flag released"), (20, "a waiter saw the flag (latest)"),
+                  (21, "ids stored (latest)"), (22, "completion word stored")):
+        print(f"  {nm:32s} {(int(st[k]) - t0) / 100.0:8.2f}")
     print("  groups in the table:", int(st[18]))
