@@ -173,6 +173,7 @@ def main():
     groups = [capi.Group(u) for u in units] if G > 1 else None
     partial_groups = {}
     handle_arrays = {}
+    member_group, group_expect = {}, {}   # first member -> {count: group}; (first member, count) -> expected counts per window
 
     comm = None
     exchange = "RCCL all-gather of the variant table (jl_allgather_variants)"
@@ -222,6 +223,10 @@ def main():
                 grp = partial_groups.get((u, count))
                 if grp is None:
                     grp = partial_groups[(u, count)] = capi.Group(members)
+            member_group.setdefault(id(members[0]), {})[count] = grp
+            if (id(members[0]), count) not in group_expect and all(id(c) in expected for c in members):
+                group_expect[(id(members[0]), count)] = (np.array([len(expected[id(c)]["count"]) for c in members], dtype=np.uint32),
+                                                         np.array([len(expected[id(c)]["hap_count"]) for c in members], dtype=np.uint32))
             t_g = time.perf_counter()
             grp.run_async(genes, refseq, prm, True, 10, True)
             host["run_async"] = host.get("run_async", 0.0) + time.perf_counter() - t_g
@@ -270,7 +275,21 @@ def main():
     def collect(members, final=False, check=True):
         last = None
         pick = state["checked"] % len(members)
-        for i, c in enumerate(members):
+        grp = member_group.get(id(members[0]), {}).get(len(members)) if G > 1 else None
+        if grp is not None:
+            # every window's result block in ONE call (jl_group_views: waits for each window's completion word in turn), the
+            # counts of all of them compared at once; numpy views are built for the window that is checked and for the last
+            exp_nv, exp_h = group_expect[(id(members[0]), len(members))]
+            vw = grp.views()
+            if not (vw["complete"].all() and (vw["n_variants"] == exp_nv).all() and (vw["n_haplotypes"] == exp_h).all()):
+                raise SystemExit(f"bench.py: rank {rank}: a window's result block is incomplete or changed")
+            for i in sorted({pick, len(members) - 1}):
+                c = members[i]
+                out = c.run_view() or c.run_fetch(True, True, cap_var=64)
+                if check and i == pick and not same(expected[id(c)], out):
+                    raise SystemExit(f"bench.py: rank {rank}: a window's results changed between runs (stale or mixed result block)")
+                last = out
+        for i, c in enumerate(members if grp is None else ()):
             # results are read in place: the kernels stored them into pinned host memory, completion is a sequence
             # word behind a system-scope fence (jl_run_view_get: counts, read categories, pointers into the block);
             # results too large for that block use the copying fetch.  numpy views are built for the window that is

@@ -312,6 +312,10 @@ int jl_group_run_masked_async(jl_group *group, const jl_gene *genes, uint32_t n_
                               uint32_t min_reads, int want_read_hap);
 /* Timing hook (bench): average device time in ms of the grouped pileup launch alone, `reps` back-to-back launches
  * rotating over `groups` (each must have run once); `bytes_per_launch` = algorithmic bytes of one launch of groups[0]. */
+/* The results of the last group run, one view per window (the group's context order): jl_run_view_get on every context in
+ * ONE call — waits for each window's completion word in turn.  out[cap]; *n = the group's windows.  A window whose view
+ * fails ends the call with its status (jl_group_last_error names it). */
+int jl_group_views(jl_group *group, jl_run_view *out, uint32_t cap, uint32_t *n);
 int jl_group_time_pileup(jl_group *const *groups, uint32_t n_groups, uint32_t reps, float *ms_avg, uint64_t *bytes_per_launch);
 
 /* ---------------------------------------------------------------- numerics self-check */

@@ -33,7 +33,7 @@ EXPORTS = ("jl_abi_version", "jl_strerror", "jl_device_count", "jl_ctx_create", 
            "jl_msa_ingest_records", "jl_records_begin", "jl_records_append", "jl_records_finish", "jl_records_window", "jl_records_drop", "jl_msa_track_insertions", "jl_insertions_fetch", "jl_msa_download", "jl_synth_fill", "jl_synth_fill_window", "jl_pileup_async", "jl_n_positions", "jl_pileup_fetch",
            "jl_consensus_fetch", "jl_call_async", "jl_call_fetch", "jl_variant_table_device", "jl_phase_async", "jl_phase_fetch",
            "jl_run_async", "jl_run_wait", "jl_run_done", "jl_run_view_get", "jl_group_create", "jl_group_destroy",
-           "jl_group_last_error", "jl_group_run_async", "jl_group_run_masked_async", "jl_group_time_pileup", "jl_fisher_eval", "jl_fisher_eval_tail", "jl_expand_read_hap", "jl_time_pileup", "jl_time_pileup_set", "jl_pileup_kernel_name", "jl_comm_unique_id", "jl_comm_create", "jl_comm_destroy",
+           "jl_group_last_error", "jl_group_run_async", "jl_group_run_masked_async", "jl_group_views", "jl_group_time_pileup", "jl_fisher_eval", "jl_fisher_eval_tail", "jl_expand_read_hap", "jl_time_pileup", "jl_time_pileup_set", "jl_pileup_kernel_name", "jl_comm_unique_id", "jl_comm_create", "jl_comm_destroy",
            "jl_allgather_variants", "jl_allgather_variants_async", "jl_allgather_variants_async_many", "jl_allgather_variants_many", "jl_xwin_plan", "jl_xwin_assemble_local",
            "jl_xwin_assemble_rccl", "jl_xwin_assemble_slice_local", "jl_xwin_assemble_slice_rccl", "jl_phase_groups_async",
            "jl_phase_groups_fetch", "jl_phase_regroup", "jl_merge_tables", "jl_merge_groups", "jl_select_haplotypes",
@@ -191,6 +191,7 @@ def load_library(path=LIB_PATH):
     lib.jl_group_last_error.restype = C.c_char_p
     lib.jl_group_run_async.argtypes = [vp, vp, u32, vp, u32, C.POINTER(Params), C.c_int, u32, C.c_int]
     lib.jl_group_run_masked_async.argtypes = [vp, vp, u32, vp, u32, C.POINTER(Params), vp, C.c_int, u32, C.c_int]
+    lib.jl_group_views.argtypes = [vp, C.c_void_p, u32, C.POINTER(u32)]
     lib.jl_group_time_pileup.argtypes = [vp, u32, u32, C.POINTER(C.c_float), C.POINTER(u64)]
     lib.jl_run_wait.argtypes = [vp]
     lib.jl_run_done.argtypes = [vp]
@@ -952,6 +953,21 @@ class Group:
         if getattr(self, "h", None):
             self.lib.jl_group_destroy(self.h)
             self.h = None
+
+    def views(self):
+        """jl_group_views: the jl_run_view of every window after a group run, ONE call (it waits for each window in turn).
+        Returns a numpy record array over the structs (fields complete, n_variants, n_haplotypes, ...), reused between
+        calls."""
+        if getattr(self, "_views", None) is None:
+            self._views = (RunView * len(self.ctxs))()
+            self._views_n = C.c_uint32()
+            dt = np.dtype(dict(names=["complete", "n_variants", "phased", "n_positions", "n_haplotypes", "n_var_phase"],
+                               formats=[np.uint32] * 6, offsets=[0, 4, 8, 12, 16, 20], itemsize=C.sizeof(RunView)))
+            self._views_np = np.frombuffer(self._views, dtype=dt)
+        rc = self.lib.jl_group_views(self.h, self._views, len(self.ctxs), C.byref(self._views_n))
+        if rc:
+            raise JulietError(rc, self.lib.jl_group_last_error(self.h).decode())
+        return self._views_np
 
     def run_masked_async(self, genes, refseq, params, drm_masks, phasing=True, min_reads=10, want_read_hap=True):
         """drm_masks: one uint64[P] array (or None) per window (--drm-only, doc/JULIET.md:370)."""

@@ -158,6 +158,19 @@ void jl_group_destroy(jl_group *g)
 
 const char *jl_group_last_error(const jl_group *g) { return g ? g->err.c_str() : ""; }
 
+int jl_group_views(jl_group *g, jl_run_view *out, uint32_t cap, uint32_t *n)
+{
+    if (!g || !n || (!out && cap)) return JL_ERR_ARG;
+    *n = (uint32_t)g->ctxs.size();
+    if (g->ctxs.size() > cap) return group_fail(g, JL_ERR_OVERFLOW, "jl_group_views: more windows than the caller's array holds");
+    for (size_t k = 0; k < g->ctxs.size(); ++k)
+        if (int rc = jl_run_view_get(g->ctxs[k], &out[k])) {
+            g->err = "window " + std::to_string(k) + ": " + jl_last_error(g->ctxs[k]);
+            return rc;
+        }
+    return JL_OK;
+}
+
 int jl_group_run_async(jl_group *g, const jl_gene *genes, uint32_t n_genes, const uint8_t *refseq, uint32_t ref_len,
                        const jl_params *prm, int phasing, uint32_t min_reads, int want_read_hap)
 {

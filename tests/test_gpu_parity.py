@@ -511,6 +511,12 @@ def test_group_run_equals_single_runs_and_oracle(jl, oracle, fold):
         exp = fill_and_expect(seed0, use_ref)
         for rep in range(4):
             grp.run_async(genes, ref if use_ref else None, prm, True, 10, True)
+            if rep % 2:   # all windows' views in one call (jl_group_views) first: it waits for every window
+                vw = grp.views()
+                assert vw["complete"].all() and vw["phased"].all()
+                assert list(vw["n_variants"]) == [len(e[0]) for e in exp]
+                assert list(vw["n_haplotypes"]) == [len(e[1]["hap_count"]) for e in exp]
+                assert list(vw["n_positions"]) == [e[1]["summary"]["n_positions"] for e in exp]
             for j, (exp_v, exp_p) in zip(ctxs, exp):
                 v = j.run_view()
                 assert v is not None
