@@ -114,6 +114,9 @@ const char *jl_strerror(int status);
 int jl_device_count(void);
 /* `stream` = NULL: the ctx creates its own non-blocking stream; else a hipStream_t owned by the caller. */
 int jl_ctx_create(int device, void *stream, jl_ctx **out);
+/* The hipStream_t this context orders its work on (its own or the caller's).  Contexts of one device that a thread drives
+ * one after the other may share one: a stream of its own costs the runtime about 8 ms to create. */
+void *jl_ctx_stream(const jl_ctx *ctx);
 void jl_ctx_destroy(jl_ctx *ctx);
 const char *jl_last_error(const jl_ctx *ctx);
 /* Waits for everything enqueued for this context: its own stream and, after a group run, the group's. */

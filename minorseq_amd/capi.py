@@ -32,7 +32,7 @@ EXPORTS = ("jl_abi_version", "jl_strerror", "jl_device_count", "jl_ctx_create", 
            "jl_sync", "jl_col_stride", "jl_msa_upload", "jl_msa_alloc", "jl_msa_adopt", "jl_msa_pack_rows",
            "jl_msa_ingest_records", "jl_records_begin", "jl_records_append", "jl_records_finish", "jl_records_window", "jl_records_drop", "jl_msa_track_insertions", "jl_insertions_fetch", "jl_msa_download", "jl_synth_fill", "jl_synth_fill_window", "jl_pileup_async", "jl_n_positions", "jl_pileup_fetch",
            "jl_consensus_fetch", "jl_call_async", "jl_call_fetch", "jl_variant_table_device", "jl_phase_async", "jl_phase_fetch",
-           "jl_run_async", "jl_run_wait", "jl_run_done", "jl_run_view_get", "jl_group_create", "jl_group_destroy",
+           "jl_ctx_stream", "jl_run_async", "jl_run_wait", "jl_run_done", "jl_run_view_get", "jl_group_create", "jl_group_destroy",
            "jl_group_last_error", "jl_group_run_async", "jl_group_run_masked_async", "jl_group_views", "jl_group_time_pileup", "jl_fisher_eval", "jl_fisher_eval_tail", "jl_expand_read_hap", "jl_time_pileup", "jl_time_pileup_set", "jl_pileup_kernel_name", "jl_comm_unique_id", "jl_comm_create", "jl_comm_destroy",
            "jl_allgather_variants", "jl_allgather_variants_async", "jl_allgather_variants_async_many", "jl_allgather_variants_many", "jl_xwin_plan", "jl_xwin_assemble_local",
            "jl_xwin_assemble_rccl", "jl_xwin_assemble_slice_local", "jl_xwin_assemble_slice_rccl", "jl_phase_groups_async",
@@ -155,6 +155,8 @@ def load_library(path=LIB_PATH):
     lib.jl_col_stride.restype = u64
     lib.jl_col_stride.argtypes = [u64]
     lib.jl_ctx_create.argtypes = [C.c_int, vp, C.POINTER(vp)]
+    lib.jl_ctx_stream.argtypes = [vp]
+    lib.jl_ctx_stream.restype = vp
     lib.jl_ctx_destroy.argtypes = [vp]
     lib.jl_ctx_destroy.restype = None
     lib.jl_sync.argtypes = [vp]

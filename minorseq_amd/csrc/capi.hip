@@ -143,6 +143,8 @@ static void free_msa(jl_ctx *ctx)
 
 static void records_drop(jl_ctx *ctx);
 
+void *jl_ctx_stream(const jl_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
 void jl_ctx_destroy(jl_ctx *ctx)
 {
     if (!ctx) return;

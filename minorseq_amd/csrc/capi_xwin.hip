@@ -571,7 +571,10 @@ int jl_xwin_create(jl_ctx *const *windows, uint32_t n_local, jl_comm *comm, cons
     x->n_mine = slice_begin[x->rank + 1] - slice_begin[x->rank];
     x->scratch.resize(n_local);
     if (hipSetDevice(x->device) != hipSuccess) return bail(JL_ERR_DEVICE);
-    int rc = jl_ctx_create(x->device, nullptr, &x->pc);
+    // the session's own context (assembled columns, grouping, ids) orders its work on the first window's stream: the
+    // session's launches come after that window's tables are on the host anyway, and a stream of its own is a hardware
+    // queue the runtime takes 8 ms to create — a sixth of `juliet --windows 8` on a 100k-read BAM
+    int rc = jl_ctx_create(x->device, windows[0]->stream, &x->pc);
     if (rc) return bail(rc);
     *out = x;
     return JL_OK;
@@ -859,10 +862,15 @@ int jl_xwin_read_hap_fetch(jl_xwin *x, uint16_t *read_hap)
     if (hipSetDevice(x->device) != hipSuccess) return xs_fail(x, JL_ERR_DEVICE, "hipSetDevice failed");
     jl_ctx *pc = x->pc;
     const size_t bytes = x->bits == 16 ? (size_t)x->n_mine * 2u : (x->bits == 8 ? (size_t)x->n_mine : (size_t)(x->n_mine + 1) / 2u);
+    // through the context's pinned block, a megabyte at a time (a runtime copy into pageable memory takes milliseconds the
+    // first time a process makes one: 7 of the 30 ms `juliet --windows 8` spent behind the upload)
     std::vector<uint8_t> tmp(bytes);
-    if (hipMemcpyAsync(tmp.data(), pc->d_read_hap, bytes, hipMemcpyDeviceToHost, pc->stream) != hipSuccess ||
-        hipStreamSynchronize(pc->stream) != hipSuccess)
-        return xs_fail(x, JL_ERR_DEVICE, "copy of the per-read ids");
+    const size_t readable = (size_t)pc->col_stride * 2u * 2u;   // d_read_hap holds 16 bits for every read of the padded stride
+    for (size_t o = 0; o < bytes; o += pc->h_scratch_cap) {
+        const size_t n = std::min(bytes - o, pc->h_scratch_cap);
+        if (int rc = jl_fetch_to_host(pc, reinterpret_cast<const uint8_t *>(pc->d_read_hap) + o, n, tmp.data() + o, readable - o))
+            return xs_fail_ctx(x, rc, pc);
+    }
     jl_expand_ids(tmp.data(), x->bits, x->n_mine, read_hap);
     return JL_OK;
 }

@@ -390,9 +390,9 @@ struct RankJob {
     jl_ctx *records = nullptr;
     std::vector<uint32_t> widx;          // this rank's windows (indices into the plan)
     std::vector<jl_ctx *> wins;
-    std::vector<jl_ctx *> spare;         // contexts made in the background while the BAM was decoded
     jl_comm *comm = nullptr;
     std::string error;                   // empty: fine
+    std::vector<std::pair<const char *, double>> laps;   // --timing: milliseconds by stage of this rank (rank 0's are printed)
     // outputs
     std::vector<std::vector<jl_variant>> tables;   // per window (window-relative columns), call only
     Results res;                         // with phasing: the merged table and the haplotypes (rank 0's is used)
@@ -404,16 +404,26 @@ void run_rank(RankJob &job, const DeviceStageInput &in, const std::vector<Window
               std::vector<uint32_t> &col_counts, const std::vector<uint64_t> &slice_begin)
 {
     auto fail = [&](const char *what, jl_ctx *c) { job.error = std::string(what) + ": " + (c ? jl_last_error(c) : "failed"); };
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        const auto now = std::chrono::steady_clock::now();
+        job.laps.emplace_back(what, std::chrono::duration<double, std::milli>(now - t_last).count());
+        t_last = now;
+    };
     const Options &opt = *in.opt;
     const uint8_t *refp = in.refcodes->empty() ? nullptr : in.refcodes->data();
     for (uint32_t k : job.widx) {
+        // a window's context orders its work on the stream of this rank's records context: a stream of its own is a hardware
+        // queue the runtime takes 8 ms to create (tools_tuning/ctx_startup.cpp), eight windows 70 ms — and one rank drives its
+        // windows one after the other anyway
         jl_ctx *w = nullptr;
-        if (!job.spare.empty()) { w = job.spare.back(); job.spare.pop_back(); }
-        else if (jl_ctx_create(job.device, nullptr, &w) != JL_OK) return fail("context", nullptr);
+        if (jl_ctx_create(job.device, jl_ctx_stream(job.records), &w) != JL_OK) return fail("context", nullptr);
         job.wins.push_back(w);
         if (jl_records_window(job.records, w, plan[k].ncols, plan[k].begin, opt.min_qv) != JL_OK) return fail("ingest", w);
     }
+    lap("window contexts + device ingest");
     jl_records_drop(job.records);
+    lap("records dropped");
     // the call stage of every window: enqueued one after the other on the windows' own streams (they overlap on the device)
     std::vector<std::vector<uint64_t>> masks(job.wins.size());
     for (size_t i = 0; i < job.wins.size(); ++i) {
@@ -422,6 +432,7 @@ void run_rank(RankJob &job, const DeviceStageInput &in, const std::vector<Window
                          opt.drm_only ? masks[i].data() : nullptr, 0, opt.min_reads, 0) != JL_OK)
             return fail("run", job.wins[i]);
     }
+    lap("call stage enqueued");
     // column counts of the columns each window owns (the MSA context of the output, doc/JULIET.md:99-100)
     for (size_t i = 0; i < job.wins.size(); ++i) {
         const WindowPlan &wp = plan[job.widx[i]];
@@ -431,6 +442,7 @@ void run_rank(RankJob &job, const DeviceStageInput &in, const std::vector<Window
         std::copy(cc.begin() + (size_t)off * 6, cc.begin() + (size_t)(off + wp.own_end - wp.own_begin) * 6,
                   col_counts.begin() + (size_t)wp.own_begin * 6);
     }
+    lap("column counts");
     if (!opt.phasing) {
         for (jl_ctx *w : job.wins) {
             std::vector<jl_variant> t(4096);
@@ -449,12 +461,14 @@ void run_rank(RankJob &job, const DeviceStageInput &in, const std::vector<Window
     if (jl_xwin_create(job.wins.data(), (uint32_t)job.wins.size(), job.comm, wb.data(), wn.data(), wr.data(), (uint32_t)plan.size(),
                        slice_begin.data(), &x) != JL_OK)
         return fail("cross-window session", nullptr);
+    lap("communicator + session");
     jl_xwin_result r;
     if (jl_xwin_phase_sharded(x, opt.min_reads, &r) != JL_OK) {
         job.error = std::string("cross-window phasing: ") + jl_xwin_last_error(x);
         jl_xwin_destroy(x);
         return;
     }
+    lap("cross-window phasing");
     Results &R = job.res;
     R.var.assign(r.merged, r.merged + r.n_variants);
     for (jl_variant &v : R.var) v.col -= in.win_begin;
@@ -475,7 +489,9 @@ void run_rank(RankJob &job, const DeviceStageInput &in, const std::vector<Window
     job.ids.resize(r.slice_reads ? r.slice_reads : 1);
     if (jl_xwin_read_hap_fetch(x, job.ids.data()) != JL_OK) job.error = std::string("per-read ids: ") + jl_xwin_last_error(x);
     job.ids.resize(r.slice_reads);
+    lap("per-read ids");
     jl_xwin_destroy(x);
+    lap("session closed");
 }
 
 }  // namespace
@@ -519,9 +535,6 @@ int main(int argc, char **argv)
         // the GPU context comes up (runtime start, stream, pinned blocks) while the host reads the BAM
         const bool need_gpu = !opt.outputs.empty() || opt.fuse_only;
         std::vector<std::shared_future<std::pair<int, jl_ctx *>>> ctx_ups;
-        // --windows K: the K window contexts come up in the background as well (a context is two dozen device buffers and
-        // three pinned blocks: about 10 ms each, 90 ms for eight when they were made after the decode)
-        std::vector<std::shared_future<std::vector<jl_ctx *>>> win_ups;
         std::unique_ptr<RecordUploader> uploader;
         RecordSink sink;
         if (need_gpu) {
@@ -531,20 +544,6 @@ int main(int argc, char **argv)
                     const int rc = jl_ctx_create(dev, nullptr, &c);
                     return std::make_pair(rc, c);
                 }).share());
-            if (opt.windows > 1 || opt.devices.size() > 1)
-                for (size_t r = 0; r < opt.devices.size(); ++r) {
-                    const size_t R = opt.devices.size();
-                    const uint32_t mine = (uint32_t)((opt.windows * (r + 1) + R - 1) / R - (opt.windows * r) / R) + 1u;   // an upper bound
-                    win_ups.push_back(std::async(std::launch::async, [dev = opt.devices[r], mine]() {
-                        std::vector<jl_ctx *> v;
-                        for (uint32_t k = 0; k < mine; ++k) {
-                            jl_ctx *c = nullptr;
-                            if (jl_ctx_create(dev, nullptr, &c) != JL_OK) break;
-                            v.push_back(c);
-                        }
-                        return v;
-                    }).share());
-                }
             std::error_code ec;
             const uintmax_t fsz = std::filesystem::file_size(opt.bam, ec);
             uploader.reset(new RecordUploader(ctx_ups, ec ? 0 : (uint64_t)fsz, opt.min_qv > 0));
@@ -666,7 +665,6 @@ int main(int argc, char **argv)
                 jobs[r].world = (int)n_ranks;
                 jobs[r].device = opt.devices[r];
                 jobs[r].records = uploader->ctx(r);
-                if (r < win_ups.size()) jobs[r].spare = win_ups[r].get();
                 for (uint32_t k = 0; k < K; ++k)
                     if (plan[k].rank == (int)r) jobs[r].widx.push_back(k);
             }
@@ -678,6 +676,8 @@ int main(int argc, char **argv)
             for (const RankJob &j : jobs)
                 if (!j.error.empty()) { std::cerr << "juliet: rank " << j.rank << " (device " << j.device << "): " << j.error << "\n"; return 3; }
             tick("windows: ingest + call + phase");
+            if (opt.timing)
+                for (const auto &l : jobs[0].laps) fprintf(stderr, "juliet: timing   rank 0: %-34s %6.1f ms\n", l.first, l.second);
             std::vector<uint32_t> cc;
             cc.swap(R.col_counts);
             if (opt.phasing) {

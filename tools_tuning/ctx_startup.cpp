@@ -46,6 +46,22 @@ int main()
     nop_kernel<<<1, 64, 0, s>>>(nullptr);
     hipStreamSynchronize(s);
     lap("first launch of this program's kernel + sync");
+    hipStream_t s2;
+    hipStreamCreateWithFlags(&s2, hipStreamNonBlocking);
+    lap("second hipStreamCreate");
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    lap("two hipEventCreate");
+    for (int i = 0; i < 14; ++i) hipMalloc(&d, 4096 << (i % 5));
+    lap("14 small hipMalloc");
+    hipMalloc(&d, 300 << 20);
+    lap("hipMalloc 300 MB");
+    hipHostMalloc(&h, 64 << 10, hipHostMallocDefault);
+    lap("hipHostMalloc 64 KB");
+    hipMemsetAsync(d, 0, 1 << 20, s2);
+    hipStreamSynchronize(s2);
+    lap("memset 1 MB + sync on the new stream");
     jl_ctx *c = nullptr;
     jl_ctx_create(0, nullptr, &c);
     lap("jl_ctx_create #1");
