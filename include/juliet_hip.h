@@ -351,6 +351,12 @@ int jl_comm_unique_id(uint8_t id[128]);
 /* One communicator per (rank, device); any context on that device may use it.  Collectives run on the
  * communicator's own stream, ordered behind the producing context by an event. */
 int jl_comm_create(jl_ctx *ctx, const uint8_t id[128], int rank, int world, jl_comm **out);
+/* The same communicator for ranks that are THREADS OF ONE PROCESS (a host that drives several devices from one process,
+ * or — RCCL refuses that — several ranks on one device): every exchange is a set of device copies between the ranks'
+ * buffers (same device, or peer devices over xGMI) between two barriers of the rank threads; no RCCL communicator is
+ * made.  `id`: 128 bytes that name the world (jl_comm_unique_id, or any bytes unique in the process); every rank of the
+ * world calls this once.  Everything that takes a jl_comm works on it unchanged. */
+int jl_comm_create_inproc(jl_ctx *ctx, const uint8_t id[128], int rank, int world, jl_comm **out);
 void jl_comm_destroy(jl_comm *comm);
 /*
  * The one collective of the path: all-gather of the fixed-stride variant table over RCCL/xGMI.

@@ -15,6 +15,180 @@
 #define JL_COMM_TIMEOUT_S 60
 #endif
 
+#include <map>
+#include <memory>
+
+/* ---------------------------------------------------------------- the transport: RCCL, or device copies between rank threads */
+
+// The ranks of an in-process communicator.  An exchange = every rank posts what it offers (pointers, an event that says
+// "ready" on its stream), a barrier of the rank threads, every rank copies what is addressed to it on its own stream
+// (same device: device-to-device; another device: hipMemcpyPeerAsync, i.e. xGMI), waits for its copies, a second barrier
+// (only then may a sender reuse its buffers).  A rank that does not show up within JL_COMM_TIMEOUT_S fails the exchange on
+// every rank (the world stays failed: the ranks' programs have diverged).
+struct jl_inproc_world {
+    int world = 0;
+    std::mutex mu;
+    std::condition_variable cv;
+    int arrived = 0;
+    uint64_t generation = 0;
+    bool failed = false;
+    struct post_t {
+        int device = 0;
+        hipEvent_t ready = nullptr;
+        const void *send[2] = {nullptr, nullptr};       // all-gather(s)
+        size_t bytes[2] = {0, 0};
+        std::vector<jl_tp_msg> msgs;                    // exchange
+        std::vector<jl_tp_bcast> bcasts;                // broadcasts
+    };
+    std::vector<post_t> post;
+    int members = 0;   // communicators alive
+};
+
+namespace {
+std::mutex g_inproc_mu;
+std::map<std::string, std::shared_ptr<jl_inproc_world>> g_inproc;   // by the 128-byte id
+
+int tp_fail(jl_comm *c, int status, const std::string &what)
+{
+    c->tp_error = what;
+    return status;
+}
+
+bool inproc_barrier(jl_inproc_world *w)
+{
+    std::unique_lock<std::mutex> lk(w->mu);
+    if (w->failed) return false;
+    const uint64_t gen = w->generation;
+    if (++w->arrived == w->world) {
+        w->arrived = 0;
+        ++w->generation;
+        w->cv.notify_all();
+        return true;
+    }
+    if (!w->cv.wait_for(lk, std::chrono::seconds(JL_COMM_TIMEOUT_S), [&] { return w->generation != gen || w->failed; })) {
+        w->failed = true;   // a rank is missing: nobody may go on as if the exchange had happened
+        w->cv.notify_all();
+        return false;
+    }
+    return !w->failed;
+}
+
+hipError_t inproc_copy(jl_comm *c, void *dst, const void *src, size_t bytes, int src_device, hipStream_t st)
+{
+    if (!bytes) return hipSuccess;
+    if (src_device == c->device) return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, st);
+    return hipMemcpyPeerAsync(dst, c->device, src, src_device, bytes, st);
+}
+
+// the frame of every in-process exchange: post (the caller filled its post_t), barrier, `copy_mine` on st, wait, barrier
+template <class F>
+int inproc_run(jl_comm *c, hipStream_t st, F copy_mine)
+{
+    jl_inproc_world *w = c->inproc;
+    jl_inproc_world::post_t &me = w->post[(size_t)c->rank];
+    me.device = c->device;
+    me.ready = c->ready;
+    hipError_t e = hipEventRecord(c->ready, st);
+    const bool b1 = inproc_barrier(w);   // reached whatever happened locally: the peers are waiting in theirs
+    if (!b1) return tp_fail(c, JL_ERR_COMM, "in-process exchange: a rank did not arrive (or the world has failed before)");
+    if (e == hipSuccess) {
+        for (int p = 0; p < w->world && e == hipSuccess; ++p)
+            if (p != c->rank) e = hipStreamWaitEvent(st, w->post[(size_t)p].ready, 0);
+        if (e == hipSuccess) e = copy_mine(w);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+    }
+    const bool b2 = inproc_barrier(w);
+    if (e != hipSuccess) return tp_fail(c, JL_ERR_DEVICE, std::string("in-process exchange: ") + hipGetErrorString(e));
+    if (!b2) return tp_fail(c, JL_ERR_COMM, "in-process exchange: a rank did not finish");
+    return JL_OK;
+}
+}  // namespace
+
+int jl_tp_allgather2(jl_comm *c, const void *send_a, void *recv_a, size_t bytes_a, const void *send_b, void *recv_b, size_t bytes_b,
+                     hipStream_t st)
+{
+    if (!c->inproc) {
+        ncclResult_t r = ncclGroupStart();
+        if (r == ncclSuccess) r = ncclAllGather(send_a, recv_a, bytes_a, ncclUint8, c->comm, st);
+        if (r == ncclSuccess && send_b) r = ncclAllGather(send_b, recv_b, bytes_b, ncclUint8, c->comm, st);
+        const ncclResult_t e = ncclGroupEnd();
+        if (r == ncclSuccess) r = e;
+        return r == ncclSuccess ? JL_OK : tp_fail(c, JL_ERR_COMM, std::string("ncclAllGather: ") + ncclGetErrorString(r));
+    }
+    jl_inproc_world::post_t &me = c->inproc->post[(size_t)c->rank];
+    me.send[0] = send_a; me.bytes[0] = bytes_a;
+    me.send[1] = send_b; me.bytes[1] = send_b ? bytes_b : 0;
+    return inproc_run(c, st, [&](jl_inproc_world *w) {
+        hipError_t e = hipSuccess;
+        for (int p = 0; p < w->world && e == hipSuccess; ++p) {
+            const jl_inproc_world::post_t &q = w->post[(size_t)p];
+            if (q.bytes[0] != bytes_a || q.bytes[1] != (send_b ? bytes_b : 0)) return hipErrorInvalidValue;   // the ranks disagree
+            e = inproc_copy(c, (uint8_t *)recv_a + (size_t)p * bytes_a, q.send[0], bytes_a, q.device, st);
+            if (e == hipSuccess && send_b) e = inproc_copy(c, (uint8_t *)recv_b + (size_t)p * bytes_b, q.send[1], bytes_b, q.device, st);
+        }
+        return e;
+    });
+}
+
+int jl_tp_allgather(jl_comm *c, const void *send, void *recv, size_t bytes, hipStream_t st)
+{
+    return jl_tp_allgather2(c, send, recv, bytes, nullptr, nullptr, 0, st);
+}
+
+int jl_tp_exchange(jl_comm *c, const jl_tp_msg *msgs, size_t n, hipStream_t st)
+{
+    if (!c->inproc) {
+        ncclResult_t r = ncclGroupStart();
+        for (size_t i = 0; i < n && r == ncclSuccess; ++i)
+            r = msgs[i].send ? ncclSend(msgs[i].ptr, msgs[i].bytes, ncclUint8, msgs[i].peer, c->comm, st)
+                             : ncclRecv(msgs[i].ptr, msgs[i].bytes, ncclUint8, msgs[i].peer, c->comm, st);
+        const ncclResult_t e = ncclGroupEnd();
+        if (r == ncclSuccess) r = e;
+        return r == ncclSuccess ? JL_OK : tp_fail(c, JL_ERR_COMM, std::string("ncclSend / ncclRecv: ") + ncclGetErrorString(r));
+    }
+    c->inproc->post[(size_t)c->rank].msgs.assign(msgs, msgs + n);
+    return inproc_run(c, st, [&](jl_inproc_world *w) {
+        // my i-th receive from peer p takes p's i-th send to me: messages of a pair match in list order, as in RCCL
+        std::vector<size_t> next((size_t)w->world, 0);
+        for (size_t i = 0; i < n; ++i) {
+            if (msgs[i].send) continue;
+            const int p = msgs[i].peer;
+            if (p < 0 || p >= w->world) return hipErrorInvalidValue;
+            const jl_inproc_world::post_t &q = w->post[(size_t)p];
+            size_t &k = next[(size_t)p];
+            while (k < q.msgs.size() && !(q.msgs[k].send && q.msgs[k].peer == c->rank)) ++k;
+            if (k == q.msgs.size() || q.msgs[k].bytes != msgs[i].bytes) return hipErrorInvalidValue;   // no send for this receive
+            const hipError_t e = inproc_copy(c, msgs[i].ptr, q.msgs[k].ptr, msgs[i].bytes, q.device, st);
+            if (e != hipSuccess) return e;
+            ++k;
+        }
+        return hipSuccess;
+    });
+}
+
+int jl_tp_broadcasts(jl_comm *c, const jl_tp_bcast *b, size_t n, hipStream_t st)
+{
+    if (!c->inproc) {
+        ncclResult_t r = ncclGroupStart();
+        for (size_t i = 0; i < n && r == ncclSuccess; ++i) r = ncclBroadcast(b[i].buf, b[i].buf, b[i].bytes, ncclUint8, b[i].root, c->comm, st);
+        const ncclResult_t e = ncclGroupEnd();
+        if (r == ncclSuccess) r = e;
+        return r == ncclSuccess ? JL_OK : tp_fail(c, JL_ERR_COMM, std::string("ncclBroadcast: ") + ncclGetErrorString(r));
+    }
+    c->inproc->post[(size_t)c->rank].bcasts.assign(b, b + n);
+    return inproc_run(c, st, [&](jl_inproc_world *w) {
+        for (size_t i = 0; i < n; ++i) {
+            if (b[i].root == c->rank) continue;
+            if (b[i].root < 0 || b[i].root >= w->world) return hipErrorInvalidValue;
+            const jl_inproc_world::post_t &q = w->post[(size_t)b[i].root];
+            if (i >= q.bcasts.size() || q.bcasts[i].bytes != b[i].bytes || q.bcasts[i].root != b[i].root) return hipErrorInvalidValue;
+            const hipError_t e = inproc_copy(c, b[i].buf, q.bcasts[i].buf, b[i].bytes, q.device, st);
+            if (e != hipSuccess) return e;
+        }
+        return hipSuccess;
+    });
+}
+
 // fixed-stride table (+ row counts) over RCCL/xGMI, on the communicator's stream; blocks the worker until the rows are
 // in the caller's arrays
 static void comm_full_gather(jl_comm *c, jl_comm_full *f)
@@ -26,11 +200,8 @@ static void comm_full_gather(jl_comm *c, jl_comm_full *f)
         // The collective is issued whatever happened on this rank: the peers have issued theirs and would wait for ever.
         // A failed rank sends an impossible row count, so every rank takes the same error branch.
         const void *cnt_src = st == JL_OK ? (const void *)ctx->d_nvar : (const void *)c->d_poison;
-        ncclResult_t r = ncclGroupStart();
-        if (r == ncclSuccess) r = ncclAllGather(ctx->d_variants, c->d_all, sizeof(jl_variant) * (size_t)f->cap_rows, ncclUint8, c->comm, c->stream);
-        if (r == ncclSuccess) r = ncclAllGather(cnt_src, c->d_counts, 8, ncclUint8, c->comm, c->stream);
-        if (r == ncclSuccess) r = ncclGroupEnd();
-        if (r != ncclSuccess && st == JL_OK) st = JL_ERR_COMM;
+        const int rc = jl_tp_allgather2(c, ctx->d_variants, c->d_all, sizeof(jl_variant) * (size_t)f->cap_rows, cnt_src, c->d_counts, 8, c->stream);
+        if (rc != JL_OK && st == JL_OK) st = JL_ERR_COMM;
     }
     std::vector<uint32_t> cnt(2 * (size_t)c->world);
     if (st == JL_OK &&
@@ -101,7 +272,7 @@ static void comm_worker(jl_comm *c)
                 if (hipGetLastError() != hipSuccess) st = JL_ERR_DEVICE;
             }
             if (st != JL_OK) sendbuf = c->d_zero;
-            if (ncclAllGather(sendbuf, batch[0]->d_heads, JL_PACK_HEAD_BYTES * (size_t)n, ncclUint8, c->comm, c->stream) != ncclSuccess && st == JL_OK) st = JL_ERR_COMM;
+            if (jl_tp_allgather(c, sendbuf, batch[0]->d_heads, JL_PACK_HEAD_BYTES * (size_t)n, c->stream) != JL_OK && st == JL_OK) st = JL_ERR_COMM;
             if (hipMemcpyAsync(batch[0]->h_heads, batch[0]->d_heads, stride * n, hipMemcpyDeviceToHost, c->stream) != hipSuccess && st == JL_OK) st = JL_ERR_DEVICE;
             if (hipEventRecord(last->done, c->stream) != hipSuccess && st == JL_OK) st = JL_ERR_DEVICE;
             for (uint32_t k = 0; k < n; ++k) {
@@ -113,7 +284,7 @@ static void comm_worker(jl_comm *c)
         } else {
             for (jl_comm_slot *s : batch) {
                 const uint8_t *sendbuf = st == JL_OK ? s->d_src : c->d_zero;
-                if (ncclAllGather(sendbuf, s->d_heads, JL_PACK_HEAD_BYTES, ncclUint8, c->comm, c->stream) != ncclSuccess && st == JL_OK) st = JL_ERR_COMM;
+                if (jl_tp_allgather(c, sendbuf, s->d_heads, JL_PACK_HEAD_BYTES, c->stream) != JL_OK && st == JL_OK) st = JL_ERR_COMM;
                 if (hipMemcpyAsync(s->h_heads, s->d_heads, stride, hipMemcpyDeviceToHost, c->stream) != hipSuccess && st == JL_OK) st = JL_ERR_DEVICE;
                 if (hipEventRecord(s->done, c->stream) != hipSuccess && st == JL_OK) st = JL_ERR_DEVICE;
                 s->done_at = s;
@@ -175,21 +346,53 @@ int jl_comm_unique_id(uint8_t id[128])
     return JL_OK;
 }
 
-int jl_comm_create(jl_ctx *ctx, const uint8_t id[128], int rank, int world, jl_comm **out)
+static int comm_create(jl_ctx *ctx, const uint8_t id[128], int rank, int world, bool inproc, jl_comm **out)
 {
     if (!ctx || !id || !out || world < 1 || rank < 0 || rank >= world) return JL_ERR_ARG;
+    *out = nullptr;
     JL_HIP(ctx, hipSetDevice(ctx->device));
     jl_comm *c = new (std::nothrow) jl_comm();
     if (!c) return JL_ERR_MEMORY;
     c->rank = rank;
     c->world = world;
     c->device = ctx->device;
-    ncclUniqueId u;
-    memcpy(&u, id, 128);
-    ncclResult_t r = ncclCommInitRank(&c->comm, world, u, rank);
-    if (r != ncclSuccess) {
-        delete c;
-        return jl_fail(ctx, JL_ERR_COMM, "ncclCommInitRank: %s", ncclGetErrorString(r));
+    if (inproc) {
+        std::shared_ptr<jl_inproc_world> w;
+        {
+            std::lock_guard<std::mutex> lk(g_inproc_mu);
+            std::shared_ptr<jl_inproc_world> &slot = g_inproc[std::string((const char *)id, 128)];
+            if (!slot) {
+                slot = std::make_shared<jl_inproc_world>();
+                slot->world = world;
+                slot->post.resize((size_t)world);
+            }
+            w = slot;
+            if (w->world != world || w->post[(size_t)rank].ready) {   // (ready: the rank is taken)
+                delete c;
+                return jl_fail(ctx, JL_ERR_ARG, "in-process communicator: rank %d of %d does not fit the ranks that joined under this id", rank, world);
+            }
+            ++w->members;
+        }
+        c->inproc = w.get();
+        if (hipEventCreateWithFlags(&c->ready, hipEventDisableTiming) != hipSuccess) {
+            jl_comm_destroy(c);
+            return jl_fail(ctx, JL_ERR_DEVICE, "hipEventCreate failed");
+        }
+        {
+            std::lock_guard<std::mutex> lk(g_inproc_mu);
+            w->post[(size_t)rank].ready = c->ready;
+            w->post[(size_t)rank].device = c->device;
+        }
+        // peers on other devices are copied from directly
+        // (enabled lazily by the runtime for hipMemcpyPeerAsync; nothing to do here)
+    } else {
+        ncclUniqueId u;
+        memcpy(&u, id, 128);
+        ncclResult_t r = ncclCommInitRank(&c->comm, world, u, rank);
+        if (r != ncclSuccess) {
+            delete c;
+            return jl_fail(ctx, JL_ERR_COMM, "ncclCommInitRank: %s", ncclGetErrorString(r));
+        }
     }
     const size_t stride = JL_PACK_HEAD_BYTES * (size_t)world;
     bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess &&
@@ -216,6 +419,13 @@ int jl_comm_create(jl_ctx *ctx, const uint8_t id[128], int rank, int world, jl_c
     return JL_OK;
 }
 
+int jl_comm_create(jl_ctx *ctx, const uint8_t id[128], int rank, int world, jl_comm **out) { return comm_create(ctx, id, rank, world, false, out); }
+
+int jl_comm_create_inproc(jl_ctx *ctx, const uint8_t id[128], int rank, int world, jl_comm **out)
+{
+    return comm_create(ctx, id, rank, world, true, out);
+}
+
 void jl_comm_destroy(jl_comm *c)
 {
     if (!c) return;
@@ -237,6 +447,14 @@ void jl_comm_destroy(jl_comm *c)
     if (c->d_poison) hipFree(c->d_poison);
     if (c->h_arena) hipHostFree(c->h_arena);
     if (c->comm) ncclCommDestroy(c->comm);
+    if (c->inproc) {
+        std::lock_guard<std::mutex> lk(g_inproc_mu);
+        c->inproc->post[(size_t)c->rank].ready = nullptr;
+        if (--c->inproc->members == 0)
+            for (auto it = g_inproc.begin(); it != g_inproc.end(); ++it)
+                if (it->second.get() == c->inproc) { g_inproc.erase(it); break; }
+    }
+    if (c->ready) hipEventDestroy(c->ready);
     if (c->d_all) hipFree(c->d_all);
     if (c->d_counts) hipFree(c->d_counts);
     if (c->stream) hipStreamDestroy(c->stream);

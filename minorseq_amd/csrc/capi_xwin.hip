@@ -119,20 +119,17 @@ int xw_send_recv(jl_ctx *pc, jl_comm *c, const xwin_schedule &sch, const uint64_
 {
     std::vector<jl_xwin_op> ops;
     xwin_ops_of_rank(sch, slice_begin, c->world, c->rank, &ops);
-    ncclResult_t r = ncclGroupStart();
+    std::vector<jl_tp_msg> msgs;
     size_t off = 0;
     for (const jl_xwin_op &o : ops) {
-        if (r != ncclSuccess) break;
         if (o.op == JL_XWIN_OP_SEND) {
-            r = ncclSend(send.d + off, o.bytes, ncclUint8, o.peer, c->comm, pc->stream);
+            msgs.push_back({o.peer, send.d + off, (size_t)o.bytes, true});
             off += o.bytes;
         } else if (o.op == JL_XWIN_OP_RECV) {
-            r = ncclRecv(pc->d_msa + o.dst_offset, o.bytes, ncclUint8, o.peer, c->comm, pc->stream);
+            msgs.push_back({o.peer, pc->d_msa + o.dst_offset, (size_t)o.bytes, false});
         }
     }
-    const ncclResult_t e = ncclGroupEnd();
-    if (r == ncclSuccess) r = e;
-    if (r != ncclSuccess) return xw_fail(pc, err, JL_ERR_COMM, std::string("column slices: ") + ncclGetErrorString(r));
+    if (jl_tp_exchange(c, msgs.data(), msgs.size(), pc->stream) != JL_OK) return xw_fail(pc, err, JL_ERR_COMM, "column slices: " + c->tp_error);
     return JL_OK;
 }
 
@@ -247,16 +244,14 @@ int jl_xwin_assemble_rccl(jl_ctx *pc, jl_ctx *window, jl_comm *c, const uint32_t
     if (rc) return rc;
     if (jl_comm_direct_begin(c) != JL_OK)
         return jl_fail(pc, JL_ERR_STATE, "the communicator has asynchronous exchanges queued or uncollected: collect them first");
-    ncclResult_t r = ncclGroupStart();
-    for (int o = 0; o < world && r == ncclSuccess; ++o) {
+    std::vector<jl_tp_bcast> bc;
+    for (int o = 0; o < world; ++o) {
         if (!sch.k_count[(size_t)o]) continue;
-        uint8_t *run = pc->d_msa + (uint64_t)3 * sch.k_begin[(size_t)o] * stride;
-        r = ncclBroadcast(run, run, (size_t)3 * sch.k_count[(size_t)o] * stride, ncclUint8, o, c->comm, pc->stream);
+        bc.push_back({pc->d_msa + (uint64_t)3 * sch.k_begin[(size_t)o] * stride, (size_t)3 * sch.k_count[(size_t)o] * stride, o});
     }
-    const ncclResult_t e = ncclGroupEnd();
+    const int brc = jl_tp_broadcasts(c, bc.data(), bc.size(), pc->stream);
     jl_comm_direct_end(c);
-    if (r == ncclSuccess) r = e;
-    if (r != ncclSuccess) return jl_fail(pc, JL_ERR_COMM, "ncclBroadcast: %s", ncclGetErrorString(r));
+    if (brc != JL_OK) return jl_fail(pc, JL_ERR_COMM, "broadcast of the variant columns: %s", c->tp_error.c_str());
     JL_HIP(pc, hipStreamSynchronize(pc->stream));
     return JL_OK;
 }
@@ -497,8 +492,8 @@ int xs_gather_tables(jl_xwin *x, const std::vector<const jl_variant *> &rows, co
         const size_t used = 16u + (size_t)std::min(mine, x->xrows) * sizeof(jl_variant);
         if (hipMemcpyAsync(x->d_tsend, x->h_tsend, used, hipMemcpyHostToDevice, pc->stream) != hipSuccess)
             return xs_fail(x, JL_ERR_DEVICE, "table upload");
-        if (ncclAllGather(x->d_tsend, x->d_trecv, x->tblk, ncclUint8, x->comm->comm, pc->stream) != ncclSuccess)
-            return xs_fail(x, JL_ERR_COMM, "all-gather of the variant tables");
+        if (jl_tp_allgather(x->comm, x->d_tsend, x->d_trecv, x->tblk, pc->stream) != JL_OK)
+            return xs_fail(x, JL_ERR_COMM, "all-gather of the variant tables: " + x->comm->tp_error);
         if ((rc = xs_fetch_and_wait(x, x->d_trecv, x->h_trecv, x->tblk * (size_t)x->world))) return rc;
         uint32_t most = 0;
         uint64_t total = 0;
@@ -730,8 +725,8 @@ int jl_xwin_phase_sharded(jl_xwin *x, uint32_t min_reads, jl_xwin_result *out)
             memset(x->h_blk, 0, sizeof(jl_exp_head));
         }
         if (collective) {
-            if (ncclAllGather(x->d_blk_send, x->d_blk_recv, x->blk, ncclUint8, x->comm->comm, pc->stream) != ncclSuccess)
-                return xs_fail(x, JL_ERR_COMM, "all-gather of the group tables");
+            if (jl_tp_allgather(x->comm, x->d_blk_send, x->d_blk_recv, x->blk, pc->stream) != JL_OK)
+                return xs_fail(x, JL_ERR_COMM, "all-gather of the group tables: " + x->comm->tp_error);
             if ((rc = xs_fetch_and_wait(x, x->d_blk_recv, x->h_blk, x->blk * (size_t)world))) return rc;
         }
         lap(4);
@@ -911,14 +906,14 @@ int jl_allgather_groups(jl_ctx *ctx, jl_comm *c, uint32_t cap_groups, uint32_t p
         return jl_fail(ctx, JL_ERR_STATE, "the communicator has asynchronous exchanges queued or uncollected: collect them first");
     }
     hipError_t e = hipMemcpyAsync(d_send, mine.data(), blk, hipMemcpyHostToDevice, ctx->stream);
-    ncclResult_t r = ncclSuccess;
-    if (e == hipSuccess) r = ncclAllGather(d_send, d_recv, blk, ncclUint8, c->comm, ctx->stream);
+    int r = JL_OK;
+    if (e == hipSuccess) r = jl_tp_allgather(c, d_send, d_recv, blk, ctx->stream);
     jl_comm_direct_end(c);
-    if (e == hipSuccess && r == ncclSuccess) e = hipMemcpyAsync(all.data(), d_recv, blk * (size_t)world, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess && r == JL_OK) e = hipMemcpyAsync(all.data(), d_recv, blk * (size_t)world, hipMemcpyDeviceToHost, ctx->stream);
     const hipError_t e2 = hipStreamSynchronize(ctx->stream);
     hipFree(d_send);
     hipFree(d_recv);
-    if (r != ncclSuccess) return jl_fail(ctx, JL_ERR_COMM, "all-gather of the group tables: %s", ncclGetErrorString(r));
+    if (r != JL_OK) return jl_fail(ctx, JL_ERR_COMM, "all-gather of the group tables: %s", c->tp_error.c_str());
     if (e != hipSuccess || e2 != hipSuccess) return jl_fail(ctx, JL_ERR_DEVICE, "group-table exchange: %s", hipGetErrorString(e != hipSuccess ? e : e2));
     if (local_rc != JL_OK && local_rc != JL_ERR_OVERFLOW) return local_rc;
     bool ovf = false;

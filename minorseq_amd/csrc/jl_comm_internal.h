@@ -6,6 +6,7 @@
 #include <condition_variable>
 #include <deque>
 #include <mutex>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -59,8 +60,16 @@ struct jl_comm_job {
     jl_comm_full *full = nullptr;
 };
 
+struct jl_inproc_world;   // capi_comm.hip: the ranks of an in-process communicator (threads of this process)
+
 struct jl_comm {
     ncclComm_t comm = nullptr;
+    // In-process form (jl_comm_create_inproc): the ranks are threads of ONE process — a host that drives several devices,
+    // or several ranks on one device — and every exchange is a set of device copies (same device, or peer devices over
+    // xGMI) between two barriers of the rank threads.  No RCCL communicator exists then.
+    jl_inproc_world *inproc = nullptr;
+    hipEvent_t ready = nullptr;      // in-process form: "what this rank sends is ready" for the exchange at hand
+    std::string tp_error;            // the transport's last failure, for the caller's message
     int rank = 0, world = 1, device = 0;
     hipStream_t stream = nullptr;
     uint8_t *d_arena = nullptr, *h_arena = nullptr;   // [JL_COMM_SLOTS][world][JL_PACK_HEAD_BYTES]
@@ -90,3 +99,24 @@ struct jl_comm {
 // rank is refused alike — and the worker starts nothing until it is given back.
 int jl_comm_direct_begin(jl_comm *c);
 void jl_comm_direct_end(jl_comm *c);
+
+// The transport: the three exchange shapes the library uses, on stream `st`, over RCCL or in process.  0 or JL_ERR_COMM /
+// JL_ERR_DEVICE (c->tp_error says what).  Stream-ordered with RCCL; the in-process form also blocks the calling thread
+// until every rank has its data (two barriers of the rank threads), so on return the send buffers are free either way once
+// the stream has passed the call.  Every rank makes the same calls in the same order (as RCCL demands).
+struct jl_tp_msg {
+    int peer;
+    void *ptr;        // what to send / where to receive
+    size_t bytes;
+    bool send;
+};
+int jl_tp_allgather(jl_comm *c, const void *send, void *recv, size_t bytes, hipStream_t st);      // recv = [world][bytes]
+int jl_tp_allgather2(jl_comm *c, const void *send_a, void *recv_a, size_t bytes_a, const void *send_b, void *recv_b, size_t bytes_b,
+                     hipStream_t st);                                                            // two of them as one group
+int jl_tp_exchange(jl_comm *c, const jl_tp_msg *msgs, size_t n, hipStream_t st);                  // sends and receives, one group
+struct jl_tp_bcast {
+    void *buf;        // the root's data / where the others receive it
+    size_t bytes;
+    int root;
+};
+int jl_tp_broadcasts(jl_comm *c, const jl_tp_bcast *b, size_t n, hipStream_t st);                 // one group

@@ -52,6 +52,7 @@ struct Options {
     double ins_min_frac = 0.5;     // an insertion enters the consensus when more than this share of the covering reads carries it
     uint32_t ins_min_distance = 10;  // ... and the previous included insertion lies at least this many columns back (UNPINNED)
     bool timing = false;
+    std::string exchange;            // --exchange rccl|inproc: how the rank threads exchange (default: rccl, inproc when a device repeats)
 };
 
 [[noreturn]] void usage(int code)
@@ -71,6 +72,9 @@ struct Options {
         "      --windows K [--devices a,b,...] cut the reference into K column windows (2-column overlap, global Bonferroni\n"
         "                                      factor), consecutive windows per device; phasing runs across the windows with\n"
         "                                      the reads sharded over the devices.  The output is that of one window.\n"
+        "      --exchange rccl|inproc          how the rank threads exchange: RCCL (default), or device copies between the ranks'\n"
+        "                                      buffers (peer copies over xGMI; the default when a device is named twice,\n"
+        "                                      which RCCL refuses)\n"
         "      --consensus <out.fasta>         also write the window's consensus as `fuse` would (doc/FUSE.md:17-20):\n"
         "                                      majority base, major deletions removed, in-frame majority insertions kept\n"
         "      --ins-min-frac 0.5  --ins-min-distance 10   when an insertion enters the consensus\n"
@@ -118,6 +122,10 @@ Options parse(int argc, char **argv)
         else if (a == "--min-rq") o.min_rq = std::stod(need(i));
         else if (a == "--device") o.device = std::stoi(need(i));
         else if (a == "--windows") o.windows = (uint32_t)std::stoul(need(i));
+        else if (a == "--exchange") {
+            o.exchange = need(i);
+            if (o.exchange != "rccl" && o.exchange != "inproc") { std::cerr << "juliet: --exchange wants rccl or inproc\n"; usage(1); }
+        }
         else if (a == "--devices") {
             const std::string v = need(i);
             size_t b = 0;
@@ -391,6 +399,7 @@ struct RankJob {
     std::vector<uint32_t> widx;          // this rank's windows (indices into the plan)
     std::vector<jl_ctx *> wins;
     jl_comm *comm = nullptr;
+    bool inproc = false;                 // the ranks exchange by device copies, not over RCCL
     std::string error;                   // empty: fine
     std::vector<std::pair<const char *, double>> laps;   // --timing: milliseconds by stage of this rank (rank 0's are printed)
     // outputs
@@ -453,7 +462,9 @@ void run_rank(RankJob &job, const DeviceStageInput &in, const std::vector<Window
         }
         return;
     }
-    if (job.world > 1 && jl_comm_create(job.wins[0], comm_id, job.rank, job.world, &job.comm) != JL_OK) return fail("communicator", job.wins[0]);
+    if (job.world > 1 && (job.inproc ? jl_comm_create_inproc(job.wins[0], comm_id, job.rank, job.world, &job.comm)
+                                     : jl_comm_create(job.wins[0], comm_id, job.rank, job.world, &job.comm)) != JL_OK)
+        return fail("communicator", job.wins[0]);
     std::vector<uint32_t> wb, wn;
     std::vector<int32_t> wr;
     for (const WindowPlan &wp : plan) { wb.push_back(wp.begin); wn.push_back(wp.ncols); wr.push_back(wp.rank); }
@@ -659,8 +670,14 @@ int main(int argc, char **argv)
             }
             uint8_t comm_id[128] = {0};
             if (opt.phasing && n_ranks > 1 && jl_comm_unique_id(comm_id) != JL_OK) die_jl(nullptr, "communicator id");
+            // RCCL refuses two ranks on one device; ranks that are threads of one process can exchange by device copies
+            bool inproc = opt.exchange == "inproc";
+            if (opt.exchange.empty())
+                for (size_t a = 0; a < n_ranks; ++a)
+                    for (size_t b = a + 1; b < n_ranks; ++b) inproc = inproc || opt.devices[a] == opt.devices[b];
             std::vector<RankJob> jobs(n_ranks);
             for (size_t r = 0; r < n_ranks; ++r) {
+                jobs[r].inproc = inproc;
                 jobs[r].rank = (int)r;
                 jobs[r].world = (int)n_ranks;
                 jobs[r].device = opt.devices[r];

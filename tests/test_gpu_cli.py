@@ -442,8 +442,9 @@ def test_windows_on_a_long_reference_with_overlapping_genes(tmp_path, oracle):
 
 def test_two_ranks_on_one_device(sample, tmp_path):
     """`--devices a,b` starts one rank (thread) per device, each with consecutive windows of its own.  One GPU per box
-    here, so the two ranks share device 0 — call only: phasing across ranks needs an RCCL communicator, and RCCL refuses
-    two ranks on one device (a loud failure, not a hang).  The JSON is the one-window JSON.
+    here, so the ranks share device 0 — which RCCL refuses, so the ranks exchange in process (device copies between their
+    buffers: `--exchange inproc`, the default when a device is named twice).  With and without phasing, two and three ranks:
+    the JSON is the one-window JSON.  Asking for RCCL on one device fails loudly, not with a hang.
     (The rank threads cannot run under ThreadSanitizer: a TSan build of the front end dies at start-up once the GPU runtime
     maps its apertures, and the container that runs the sanitizer tests has no GPU, so the ranks never start there.  What
     they share is small: disjoint ranges of one column-count array and a job record each.)"""
@@ -452,7 +453,12 @@ def test_two_ranks_on_one_device(sample, tmp_path):
     for k in (2, 5):
         two = run_juliet(d, bam, "-c", cfg, "--windows", str(k), "--devices", "0,0", out=f"r{k}.json")
         assert _strip(two) == _strip(one)
+    onep = run_juliet(d, bam, "-c", cfg, "--mode-phasing", out="p1.json")
+    assert onep["haplotype"]
+    for k, devs in ((2, "0,0"), (5, "0,0"), (7, "0,0,0")):
+        twop = run_juliet(d, bam, "-c", cfg, "--mode-phasing", "--windows", str(k), "--devices", devs, out=f"p{k}.json")
+        assert _strip(twop) == _strip(onep)
     out = str(tmp_path / "t.json")
-    r = subprocess.run([JULIET, "-c", cfg, "--mode-phasing", "--windows", "4", "--devices", "0,0", bam, out], capture_output=True, text=True,
-                       timeout=300)
+    r = subprocess.run([JULIET, "-c", cfg, "--mode-phasing", "--windows", "4", "--devices", "0,0", "--exchange", "rccl", bam, out],
+                       capture_output=True, text=True, timeout=300)
     assert r.returncode == 3 and "communicator" in r.stderr

@@ -396,3 +396,137 @@ def test_allgather_groups_single_rank(oracle):
     assert "exported" in str(e.value)
     c.lib.jl_comm_destroy(comm)
     c.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# More than one rank on the one GPU of the box: the ranks are threads, the communicator is the in-process one
+# (jl_comm_create_inproc: every exchange = device copies between the ranks' buffers between two barriers; RCCL refuses two
+# ranks on one device).  Everything of the multi-rank sequence runs for real — the table gather of several ranks, the
+# exchange schedule with its packed sends and receives, grouping per read slice, the group gather, merge + selection,
+# per-read ids of each rank's slice — except RCCL's own wire.
+
+def _ranks_in_threads(world, body):
+    """body(rank) in one thread per rank; re-raises the first failure."""
+    import threading
+    errs = [None] * world
+    outs = [None] * world
+
+    def run(r):
+        try:
+            outs[r] = body(r)
+        except BaseException as e:   # noqa: BLE001 - reported below
+            errs[r] = e
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(600)
+    for e in errs:
+        if e is not None:
+            raise e
+    return outs
+
+
+@pytest.mark.parametrize("n,world,k_windows", [(7000, 2, 2), (7000, 3, 5), (1000, 3, 3), (40_000, 2, 4), (300, 4, 4)])
+def test_session_with_several_ranks_in_one_process(oracle, n, world, k_windows):
+    import ctypes as C
+    l = 900
+    sp = synth.SynthParams(seed=57 + n + world, minor_permille=(70, 60, 50, 40), partial_rate=0.15)
+    ref = synth.reference(sp.seed, l)
+    rows = synth.rows(sp, l, 0, n, ref)
+    genes = np.array([(1, l + 1)], dtype=capi.GENE)
+    rows[: n // 20, 700:703] = (rows[: n // 20, 700:703] + 1) % 4          # haplotypes that span windows (and ranks)
+    rows[n // 40: n // 16, 820:823] = (rows[n // 40: n // 16, 820:823] + 2) % 4
+    rows[n // 30: n // 12, 100:103] = (rows[n // 30: n // 12, 100:103] + 3) % 4
+    full = oracle.call(rows, genes, refseq=ref)
+    exp = oracle.phase(rows, full)
+    wb = sharding.window_bounds(l, k_windows)
+    win_rank = [min(world - 1, k * world // k_windows) for k in range(k_windows)]   # consecutive windows per rank
+    slice_begin = sharding.read_slices(n, world)     # n = 300, world = 4: ranks without reads
+    slices = [(slice_begin[r], slice_begin[r + 1]) for r in range(world)]
+    idbuf = np.frombuffer(np.random.default_rng(n * 7 + world).bytes(128), dtype=np.uint8).copy()
+    prm = capi.default_params(n_tests=sharding.default_n_tests(genes))
+
+    def body(rank):
+        mine = [k for k in range(k_windows) if win_rank[k] == rank]
+        ctxs = []
+        for k in mine:
+            b, e = wb[k]
+            c = capi.Juliet(0)
+            c.upload_columns(msa.pack_columns(rows[:, b:e]), n, win_begin=b)
+            c.run_async(genes, ref, prm, None, False, 10, False)
+            ctxs.append(c)
+        comm = C.c_void_p()
+        ctxs[0]._chk(ctxs[0].lib.jl_comm_create_inproc(ctxs[0].h, idbuf.ctypes.data_as(C.c_void_p), rank, world, C.byref(comm)))
+        xw = capi.Xwin(ctxs, [b for b, _ in wb], [e - b for b, e in wb], win_rank, slice_begin, comm)
+        try:
+            res = [xw.phase(10) for _ in range(2)]        # a step loop: the same answer every time
+        finally:
+            xw.close()
+            ctxs[0].lib.jl_comm_destroy(comm)
+            for c in ctxs:
+                c.close()
+        return res
+
+    outs = _ranks_in_threads(world, body)
+    ids = np.full(n, 0xABCD, dtype=np.uint16)
+    for rank, res in enumerate(outs):
+        for r in res:
+            m = r["merged"]
+            assert len(m) == len(full)
+            for k in ("gene", "codon_pos", "col", "ref_codon", "codon", "count", "coverage", "expected"):
+                assert (m[k] == full[k]).all(), (rank, k)
+            assert r["summary"] == exp["summary"], rank
+            assert (r["pos_cols"] == exp["pos_cols"]).all() and (r["hap_count"] == exp["hap_count"]).all()
+            assert (r["hap_pattern"] == exp["hap_pattern"]).all() and (r["hit"] == exp["hit"]).all() and (r["cooc"] == exp["cooc"]).all()
+            b, cnt = r["slice"]
+            assert (b, cnt) == (slices[rank][0], slices[rank][1] - slices[rank][0])
+            ids[b:b + cnt] = r["read_hap"][:cnt]
+    assert (ids == exp["read_hap"]).all()               # every read's id, each from the rank that owns its slice
+
+
+def test_weak_scaling_exchange_with_two_ranks_in_one_process(oracle):
+    """jl_allgather_variants (the call path's one collective) between two rank threads on one device: each rank's table
+    arrives at both, through the asynchronous batch form and the blocking full-stride form."""
+    import ctypes as C
+    n, l, world = 6000, 300, 2
+    genes = np.array([(1, world * l + 1)], dtype=capi.GENE)
+    idbuf = np.frombuffer(np.random.default_rng(99).bytes(128), dtype=np.uint8).copy()
+    tabs = [None, None]
+
+    def body(rank):
+        sp = synth.SynthParams(seed=300 + rank, minor_permille=(70, 60, 50, 40))
+        ref_local = synth.reference(sp.seed, l)
+        refseq = np.full(world * l, 4, dtype=np.uint8)
+        refseq[rank * l:(rank + 1) * l] = ref_local
+        c = capi.Juliet(0)
+        c.alloc(n, l, win_begin=rank * l)
+        c.synth_fill(sp, ref_local)
+        c.sync()
+        comm = C.c_void_p()
+        c._chk(c.lib.jl_comm_create_inproc(c.h, idbuf.ctypes.data_as(C.c_void_p), rank, world, C.byref(comm)))
+        out = []
+        try:
+            for _ in range(3):
+                c.run_async(genes, refseq, capi.default_params(), None, True, 10, False)
+                c._chk(c.lib.jl_allgather_variants_async(c.h, comm))
+                rows_ = np.zeros(world * 128, dtype=capi.VARIANT)
+                counts = np.zeros(world, dtype=np.uint32)
+                c._chk(c.lib.jl_allgather_variants(c.h, comm, rows_.ctypes.data_as(C.c_void_p), counts.ctypes.data_as(C.c_void_p), 128))
+                own = c.run_view()["variants"].copy()
+                out.append((rows_.copy(), counts.copy(), own))
+        finally:
+            c.lib.jl_comm_destroy(comm)
+            c.close()
+        return out
+
+    outs = _ranks_in_threads(world, body)
+    for rank in range(world):
+        for rows_, counts, own in outs[rank]:
+            for peer in range(world):
+                theirs = outs[peer][0][2]
+                assert counts[peer] == len(theirs) and len(theirs) >= 4
+                got = rows_[peer * 128: peer * 128 + counts[peer]]
+                for k in ("gene", "codon_pos", "col", "codon", "count", "coverage"):
+                    assert (got[k] == theirs[k]).all(), (rank, peer, k)
