@@ -154,14 +154,14 @@ def test_from_rows_bam_roundtrip(tmp_path):
     assert wb == 0 and got.shape == (n, l) and (got == rows).all()
 
 
-def _bgzf(raw):
-    """Uncompressed bytes -> BGZF (blocks of <= 60000 bytes + the empty EOF block)."""
+def _bgzf(raw, level=6, strategy=0, block=60000):
+    """Uncompressed bytes -> BGZF (blocks of <= `block` bytes + the empty EOF block)."""
     import struct
     import zlib
     out = b""
-    for o in list(range(0, len(raw), 60000)) + [None]:
-        chunk = b"" if o is None else raw[o:o + 60000]
-        co = zlib.compressobj(6, zlib.DEFLATED, -15)
+    for o in list(range(0, len(raw), block)) + [None]:
+        chunk = b"" if o is None else raw[o:o + block]
+        co = zlib.compressobj(level, zlib.DEFLATED, -15, 8, strategy)
         body = co.compress(chunk) + co.flush()
         bsize = 12 + 6 + len(body) + 8 - 1
         out += struct.pack("<BBBBIBBHBBHH", 31, 139, 8, 4, 0, 0, 255, 6, 66, 67, 2, bsize) + body
@@ -280,6 +280,24 @@ def test_pipelined_reader_equals_sequential(tmp_path):
         a, b = out.stdout.strip().splitlines()
         assert a == b, (qv, rq, a, b)
         assert int(a.split()[1]) > 1000
+    # the same records in BGZF files of other shapes: stored blocks (level 0), fixed and dynamic Huffman codes, run-length
+    # and Huffman-only strategies, blocks of 300 bytes (hundreds of blocks per record: every record straddles) up to the
+    # largest a BGZF block may hold — both readers, and the same checksum as the file they were made from
+    import gzip
+    import zlib
+    small = str(tmp_path / "s.bam")
+    subprocess.check_call([SYNTH, "--reads", "2500", "--cols", "900", "--seed", "6", "--partial", "0.2", "--rich-qv", "-o", small])
+    ref_line = subprocess.run([exe, small, "0", "0"], capture_output=True, text=True).stdout.strip().splitlines()
+    assert ref_line[0] == ref_line[1]
+    inflated = gzip.decompress(open(small, "rb").read())
+    for level, strategy, block in ((0, 0, 60000), (1, 0, 65280), (9, 0, 300), (6, zlib.Z_FIXED, 5000), (6, zlib.Z_RLE, 20000),
+                                   (6, zlib.Z_HUFFMAN_ONLY, 65280), (4, zlib.Z_FILTERED, 1111)):
+        v = str(tmp_path / "v.bam")
+        open(v, "wb").write(_bgzf(inflated, level, strategy, block))
+        out = subprocess.run([exe, v, "0", "0"], capture_output=True, text=True)
+        assert out.returncode == 0, (level, strategy, block, out.stderr)
+        a, b = out.stdout.strip().splitlines()
+        assert a == b == ref_line[0], (level, strategy, block)
     # a file cut in the middle of a record, and one cut inside the header
     raw = open(bam, "rb").read()
     for cut, msg in ((len(raw) // 2, "truncated"), (40, "")):
