@@ -132,8 +132,34 @@ int jl_ctx_create(int device, void *stream, jl_ctx **out)
     return JL_OK;
 }
 
+// The library has just written the matrix (on ctx->stream): make the counting kernel's bit planes from it, on the same
+// stream.  No room for them (they take three quarters of the matrix again): the context counts from the nibbles.
+static void planes_refresh(jl_ctx *ctx)
+{
+    ctx->planes_valid = false;
+    if (!ctx->d_msa || !ctx->own_msa || (ctx->col_stride & 127u) || !ctx->n_cols) return;
+    const uint64_t ps = ctx->col_stride / 4u;
+    const size_t need = (size_t)ps * 3u * ctx->n_cols;
+    if (ctx->planes_capacity < need) {
+        if (ctx->d_planes) hipFree(ctx->d_planes);
+        ctx->d_planes = nullptr;
+        ctx->planes_capacity = 0;
+        ctx->alloc_version++;
+        if (hipMalloc(&ctx->d_planes, need) != hipSuccess) {
+            (void)hipGetLastError();
+            return;
+        }
+        ctx->planes_capacity = need;
+    }
+    if (ctx->plane_stride != ps) ctx->alloc_version++;   // (captured launches carry the stride)
+    ctx->plane_stride = ps;
+    jl_launch_planes(ctx, ctx->stream);
+    ctx->planes_valid = hipGetLastError() == hipSuccess;
+}
+
 static void free_msa(jl_ctx *ctx)
 {
+    ctx->planes_valid = false;
     ctx->alloc_version++;
     if (ctx->own_msa && ctx->d_msa) hipFree(ctx->d_msa);
     ctx->d_msa = nullptr;
@@ -164,7 +190,8 @@ void jl_ctx_destroy(jl_ctx *ctx)
                     ctx->d_slot_rep, ctx->d_slot_count, ctx->d_slot_key, ctx->d_slot_hap, ctx->d_occupied, ctx->d_hap_count,
                     ctx->d_hap_pattern, ctx->d_hit, ctx->d_cooc, ctx->d_pack, ctx->d_sync, ctx->d_timeline,
                     ctx->d_col_first, ctx->d_pos_next, ctx->d_callinfo, ctx->d_ins_len, ctx->d_ins_base, ctx->d_exp_count,
-                    ctx->d_exp_pattern, ctx->d_exp_hap, ctx->d_blockcat, ctx->d_slot_key_a, ctx->d_slot_key_b, ctx->d_occ_a, ctx->d_occ_b};
+                    ctx->d_exp_pattern, ctx->d_exp_hap, ctx->d_blockcat, ctx->d_slot_key_a, ctx->d_slot_key_b, ctx->d_occ_a, ctx->d_occ_b,
+                    ctx->d_planes};
     for (void *p : ptrs)
         if (p) hipFree(p);
     if (ctx->ev0) hipEventDestroy(ctx->ev0);
@@ -203,6 +230,7 @@ static int set_shape(jl_ctx *ctx, uint64_t n_reads, uint32_t n_cols, uint64_t co
     ctx->pack_valid = false;
     ctx->pileup_done = ctx->call_done = ctx->phase_done = false;
     ctx->ins_valid = false;
+    ctx->planes_valid = false;   // whoever writes the matrix next makes them again
     return JL_OK;
 }
 
@@ -255,6 +283,7 @@ int jl_msa_upload(jl_ctx *ctx, const uint8_t *colpacked, uint64_t n_reads, uint3
         free_msa(ctx);
         return jl_fail(ctx, JL_ERR_ARG, "matrix holds a symbol code outside 0..6");
     }
+    planes_refresh(ctx);
     return JL_OK;
 }
 
@@ -284,6 +313,7 @@ int jl_msa_pack_rows(jl_ctx *ctx, const uint8_t *rows, uint64_t n_reads, uint32_
     }
     hipFree(d_rows);
     if (e != hipSuccess) return jl_fail(ctx, JL_ERR_DEVICE, "pack_rows: %s", hipGetErrorString(e));
+    planes_refresh(ctx);
     return JL_OK;
 }
 
@@ -468,6 +498,7 @@ static int records_build(jl_ctx *src, jl_ctx *dst, uint32_t n_cols, uint32_t win
     }
     if (d_rows4) hipFree(d_rows4);
     if (e != hipSuccess) return jl_fail(dst, e == hipErrorOutOfMemory ? JL_ERR_MEMORY : JL_ERR_DEVICE, "ingest: %s", hipGetErrorString(e));
+    planes_refresh(dst);
     return JL_OK;
 }
 
@@ -556,6 +587,7 @@ static int synth_fill(jl_ctx *ctx, const jl_synth_params *sp, const uint8_t *ref
     if (e != hipSuccess) return jl_fail(ctx, JL_ERR_DEVICE, "synth_fill: %s", hipGetErrorString(e));
     ctx->pileup_done = ctx->call_done = ctx->phase_done = false;
     ctx->pack_valid = false;
+    planes_refresh(ctx);
     return JL_OK;
 }
 

@@ -30,6 +30,7 @@
 #define JL_INS_MAX_BASES 30u       // inserted bases tracked per insertion
 #define JL_GUESS_PAD 32u           // zero bytes after the last column's seed base
 #define JL_PILEUP_TILE_BYTES 4096u  // bytes of one column a 256-thread block reads per iteration (16 B / lane)
+#define JL_PLANE_TILE_BYTES 2048u   // the same for one bit plane of a column (8 B / lane = 64 reads)
 
 // resolved reference codon per position
 #define JL_REF_MAJORITY 0xFFu
@@ -119,8 +120,8 @@ struct jl_callinfo {
 };
 
 struct jl_win_pileup {
-    const uint8_t *msa;
-    uint64_t col_stride;
+    const uint8_t *msa;          // the nibble matrix, or its bit planes (the launch says which kernel reads it)
+    uint64_t col_stride;         // bytes per column of the nibble matrix / per PLANE of the bit planes
     uint32_t n_cols, n_tiles, n_chunks, pad_;
     const uint2 *chunks;
     const uint32_t *guess32;
@@ -257,6 +258,7 @@ struct jl_pileup_group_args { jl_win_pileup w[JL_GROUP_WINDOWS_MAX]; };
 // one all-gather for the launch)
 #define JL_GATHER_MAX 32
 struct jl_gather_args { const uint8_t *src[JL_GATHER_MAX]; };
+void jl_launch_planes(jl_ctx *ctx, hipStream_t st);   // nibble matrix -> bit planes (kernels_util.hip)
 void jl_launch_gather_heads(const uint8_t *const *srcs, uint32_t n, uint8_t *dst, hipStream_t st);
 
 struct jl_comm;
@@ -310,6 +312,14 @@ struct jl_ctx {
     uint8_t *d_msa = nullptr;
     bool own_msa = false;
     size_t msa_capacity = 0;
+    // The counting kernel's own copy of the matrix: three BIT PLANES per column (bit k of every read's code, reads in bit
+    // order), 3 bits per cell where the nibble layout moves 4.  Made by the library whenever IT writes the matrix (upload,
+    // pack, ingest, synthetic fill); an adopted matrix (jl_msa_adopt: the caller may rewrite it at any time) has none and
+    // is counted from the nibbles.  plane k of column c at d_planes + (3 c + k) * plane_stride, plane_stride = col_stride / 4.
+    uint8_t *d_planes = nullptr;
+    size_t planes_capacity = 0;
+    uint64_t plane_stride = 0;
+    bool planes_valid = false;
     uint64_t n_reads = 0;
     uint32_t n_cols = 0;
     uint64_t col_stride = 0;

@@ -396,6 +396,242 @@ __global__ __launch_bounds__(256, CALL ? JL_CALL_MIN_WAVES : 1) void pileup_grou
                                      (const uint32_t JL_AS1 *)w.guess32, (uint32_t JL_AS1 *)w.counts, (uint32_t JL_AS1 *)w.hist, w.ci);
 }
 
+// ---------------------------------------------------------------------------------------- the same from BIT PLANES
+// The library's own copy of the matrix (jl_ctx::d_planes): per column three planes — bit k of every read's code, reads in
+// bit order — so a cell costs 3 bits of HBM traffic where the nibble layout costs 4, and one instruction handles 32 reads
+// where it handled 8:
+//   * column counts: six popcounts per 32 reads (b0, b1, b2, b0&b1, b0&b2, b1&b2; code 7 does not occur), from which
+//     T = n01, N = n02, uncovered = n12, C = n0 - n01 - n02, G = n1 - n01 - n12, '-' = n2 - n02 - n12, A = the rest;
+//   * codons against the seed: six xors against the seed's bits (block-uniform all-ones / all-zero words), or-ed together
+//     with the three b2 words (a code >= 4 anywhere: not a codon): reads equal to the seed codon are a popcount, the rare
+//     valid mismatches are walked bit by bit into the LDS histogram as before.
+// Same chunks, same seeds, same outputs, bit for bit: the two kernels count the same cells.  A lane takes 8 bytes = 64
+// reads of each plane per tile (a tile = 16384 reads); the next tile's 9 .. 24 words are prefetched as in the nibble kernel.
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+constexpr uint32_t kPlaneFlushTiles = 15;   // 64 lanes x 64 reads x 15 tiles = 61440 < 2^16
+
+template <int W>
+struct ptile_regs {
+    uint32_t d[W + 2][3][2];   // [column][plane][dword]
+};
+
+template <int W, bool FAST>
+__device__ __forceinline__ void load_ptile(ptile_regs<W> &r, const uint8_t JL_AS1 *planes, uint64_t plane_stride, uint32_t n_cols,
+                                           uint32_t c0, uint32_t ncols, uint64_t off, bool need_halo)
+{
+#pragma unroll
+    for (int j = 0; j < W + 2; ++j) {
+        if (FAST && j >= 3) continue;
+        const bool live = FAST ? true : (c0 + j < n_cols) && ((uint32_t)j < ncols || (need_halo && (uint32_t)j < ncols + 2u));
+        if (live) {
+            const uint8_t JL_AS1 *base = planes + (uint64_t)(c0 + j) * 3u * plane_stride + off;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const u32x2 v = __builtin_nontemporal_load((const u32x2 JL_AS1 *)(base + (uint64_t)k * plane_stride));
+                r.d[j][k][0] = v.x;
+                r.d[j][k][1] = v.y;
+            }
+        } else {   // code 6 everywhere: b0 = 0, b1 = b2 = 1
+            r.d[j][0][0] = r.d[j][0][1] = 0u;
+            r.d[j][1][0] = r.d[j][1][1] = r.d[j][2][0] = r.d[j][2][1] = 0xFFFFFFFFu;
+        }
+    }
+}
+
+template <int W, bool FAST>
+__device__ __forceinline__ void pileup_planes_stream(const uint8_t JL_AS1 *planes, uint64_t plane_stride, uint32_t n_cols,
+                                                     uint32_t n_tiles, uint32_t c0, uint32_t ncols, uint32_t startf, bool need_halo,
+                                                     const uint32_t (&g)[W + 2], uint32_t (*s_hist)[64], uint32_t (*s_col)[6],
+                                                     uint32_t *s_match)
+{
+    const uint32_t tid = threadIdx.x;
+    const bool last_lane = (tid & 63u) == 63u;
+    const uint64_t lane_off = (uint64_t)tid * 8u;
+    // the seed codon's bits as words: sh / sl[j] = all ones when bit 1 / bit 0 of column j's seed base is set
+    uint32_t sh[W + 2], sl[W + 2];
+#pragma unroll
+    for (int j = 0; j < W + 2; ++j) {
+        sh[j] = (g[j] & 2u) ? 0xFFFFFFFFu : 0u;
+        sl[j] = (g[j] & 1u) ? 0xFFFFFFFFu : 0u;
+    }
+
+    uint32_t tile = blockIdx.y;
+    ptile_regs<W> nxt;
+    bool nxt_live = false;
+    if (tile < n_tiles) {
+        const uint64_t off = (uint64_t)tile * JL_PLANE_TILE_BYTES + lane_off;
+        nxt_live = off < plane_stride;
+        if (nxt_live) load_ptile<W, FAST>(nxt, planes, plane_stride, n_cols, c0, ncols, off, need_halo);
+    }
+
+    while (tile < n_tiles) {
+        uint32_t acc[W][6];   // n0 n1 n2 n01 n02 n12
+        uint32_t match[W];
+#pragma unroll
+        for (int j = 0; j < W; ++j) {
+            match[j] = 0;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) acc[j][k] = 0;
+        }
+        uint32_t reads = 0;
+
+        for (uint32_t it = 0; it < kPlaneFlushTiles && tile < n_tiles; ++it, tile += gridDim.y) {
+            const ptile_regs<W> cur = nxt;
+            const bool live = nxt_live;
+            const uint32_t tn = tile + gridDim.y;
+            nxt_live = false;
+            if (tn < n_tiles) {
+                const uint64_t off = (uint64_t)tn * JL_PLANE_TILE_BYTES + lane_off;
+                nxt_live = off < plane_stride;
+                if (nxt_live) load_ptile<W, FAST>(nxt, planes, plane_stride, n_cols, c0, ncols, off, need_halo);
+            }
+            if (!live) continue;
+            reads += 64;
+#pragma unroll
+            for (int j = 0; j < W; ++j) {
+                if (FAST ? j < 3 : (uint32_t)j < ncols) {
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const uint32_t b0 = cur.d[j][0][q], b1 = cur.d[j][1][q], b2 = cur.d[j][2][q];
+                        acc[j][0] += __popc(b0);
+                        acc[j][1] += __popc(b1);
+                        acc[j][2] += __popc(b2);
+                        acc[j][3] += __popc(b0 & b1);
+                        acc[j][4] += __popc(b0 & b2);
+                        acc[j][5] += __popc(b1 & b2);
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < W; ++j) {
+                if (FAST ? j == 0 : (startf & (1u << j)) != 0) {
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const uint32_t inv = cur.d[j][2][q] | cur.d[j + 1][2][q] | cur.d[j + 2][2][q];   // some code >= 4: not in coverage
+                        const uint32_t x = (cur.d[j][1][q] ^ sh[j]) | (cur.d[j][0][q] ^ sl[j]) | (cur.d[j + 1][1][q] ^ sh[j + 1]) |
+                                           (cur.d[j + 1][0][q] ^ sl[j + 1]) | (cur.d[j + 2][1][q] ^ sh[j + 2]) | (cur.d[j + 2][0][q] ^ sl[j + 2]);
+                        match[j] += __popc(~(x | inv));      // valid and equal to the seed codon
+                        uint32_t rest = x & ~inv;            // valid codon, not the seed one
+                        while (rest) {
+                            const int b = __ffs((int)rest) - 1;
+                            rest &= rest - 1;
+                            const uint32_t idx = (((cur.d[j][1][q] >> b) & 1u) << 5) | (((cur.d[j][0][q] >> b) & 1u) << 4) |
+                                                 (((cur.d[j + 1][1][q] >> b) & 1u) << 3) | (((cur.d[j + 1][0][q] >> b) & 1u) << 2) |
+                                                 (((cur.d[j + 2][1][q] >> b) & 1u) << 1) | ((cur.d[j + 2][0][q] >> b) & 1u);
+                            atomicAdd(&s_hist[j][idx], 1u);
+                        }
+                    }
+                }
+            }
+        }
+
+        // ---- flush this batch: the counts from the six popcount sums, 16-bit packing, DPP wave sums, LDS atomics
+#pragma unroll
+        for (int j = 0; j < W; ++j) {
+            if (FAST && j >= 3) continue;
+            const uint32_t nT = acc[j][3], nN = acc[j][4], nU = acc[j][5];
+            const uint32_t nC = acc[j][0] - nT - nN, nG = acc[j][1] - nT - nU, nD = acc[j][2] - nN - nU;
+            const uint32_t nA = reads - (nC + nG + nT + nD + nN + nU);
+            const uint32_t p0 = wave_sum(nA | (nC << 16));
+            const uint32_t p1 = wave_sum(nG | (nT << 16));
+            const uint32_t p2 = wave_sum(nD | (nN << 16));
+            const bool starts = FAST ? j == 0 : (startf & (1u << j)) != 0;
+            uint32_t p3 = 0;
+            if (starts) p3 = wave_sum(match[j]);   // (block-uniform branch)
+            if (last_lane && (uint32_t)j < ncols) {
+                if (p0 & 0xFFFFu) atomicAdd(&s_col[j][0], p0 & 0xFFFFu);
+                if (p0 >> 16) atomicAdd(&s_col[j][1], p0 >> 16);
+                if (p1 & 0xFFFFu) atomicAdd(&s_col[j][2], p1 & 0xFFFFu);
+                if (p1 >> 16) atomicAdd(&s_col[j][3], p1 >> 16);
+                if (p2 & 0xFFFFu) atomicAdd(&s_col[j][4], p2 & 0xFFFFu);
+                if (p2 >> 16) atomicAdd(&s_col[j][5], p2 >> 16);
+                if (starts && p3) atomicAdd(&s_match[j], p3);
+            }
+        }
+    }
+}
+
+template <int W>
+__device__ __forceinline__ void pileup_planes_body(const uint8_t JL_AS1 *planes, uint64_t plane_stride, uint32_t n_cols, uint32_t n_tiles,
+                                                   const uint2 JL_AS1 *chunks, const uint32_t JL_AS1 *guess32, uint32_t JL_AS1 *counts,
+                                                   uint32_t JL_AS1 *hist)
+{
+    __shared__ uint32_t s_hist[W][64];
+    __shared__ uint32_t s_col[W][6];   // A C G T - N
+    __shared__ uint32_t s_match[W];
+    const uint32_t tid = threadIdx.x;
+    const uint2 rec = chunks[blockIdx.x];
+    const uint32_t c0 = rec.x;
+    const uint32_t ncols = rec.y & 15u;
+    const uint32_t startf = (rec.y >> 4) & 0xFFFu;
+    const bool need_halo = ((rec.y >> 16) & 1u) != 0;
+    constexpr int NG = (W + 2 + 3 + 3) / 4;
+    uint32_t gw[NG];
+#pragma unroll
+    for (int k = 0; k < NG; ++k) gw[k] = guess32[(c0 >> 2) + k];
+    uint32_t g[W + 2];   // the seed base of column c0 + j (0..3)
+#pragma unroll
+    for (int j = 0; j < W + 2; ++j) {
+        const uint32_t b = (c0 & 3u) + (uint32_t)j;
+        uint32_t word = gw[0];
+#pragma unroll
+        for (int k = 1; k < NG; ++k)
+            if ((b >> 2) == (uint32_t)k) word = gw[k];
+        g[j] = (word >> (8u * (b & 3u))) & 3u;
+    }
+    for (uint32_t i = tid; i < W * 64; i += 256) (&s_hist[0][0])[i] = 0;
+    if (tid < W * 6) (&s_col[0][0])[tid] = 0;
+    if (tid < W) s_match[tid] = 0;
+    __syncthreads();
+    if (W == 3 && rec.y == JL_CHUNK_META(3, 1, 0))
+        pileup_planes_stream<W, true>(planes, plane_stride, n_cols, n_tiles, c0, ncols, startf, need_halo, g, s_hist, s_col, s_match);
+    else
+        pileup_planes_stream<W, false>(planes, plane_stride, n_cols, n_tiles, c0, ncols, startf, need_halo, g, s_hist, s_col, s_match);
+    __syncthreads();
+    const bool excl = gridDim.y == 1;
+    if (tid < W * 6) {
+        const uint32_t j = tid / 6u, k = tid - j * 6u;
+        const uint32_t v = s_col[j][k];
+        if (j < ncols) {
+            if (excl) counts[(uint64_t)(c0 + j) * 6u + k] = v;
+            else if (v) atomicAdd((uint32_t *)(counts + (uint64_t)(c0 + j) * 6u + k), v);
+        }
+    }
+    if (tid < W && (startf & (1u << tid))) {
+        const uint32_t j = tid;
+        const uint32_t seed = (g[j] << 4) | (g[j + 1] << 2) | g[j + 2];
+        s_hist[j][seed] += s_match[j];   // reads equal to the seed codon were only counted, never binned
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < W * 64; i += 256) {
+        const uint32_t j = i >> 6;
+        const uint32_t v = s_hist[j][i & 63u];
+        if (startf & (1u << j)) {
+            if (excl) hist[(uint64_t)(c0 + j) * 64u + (i & 63u)] = v;
+            else if (v) atomicAdd((uint32_t *)(hist + (uint64_t)(c0 + j) * 64u + (i & 63u)), v);
+        }
+    }
+}
+
+template <int W>
+__global__ __launch_bounds__(256) void pileup_planes_kernel(const uint8_t *__restrict__ planes, uint64_t plane_stride, uint32_t n_cols,
+                                                            uint32_t n_tiles, const uint2 *__restrict__ chunks,
+                                                            const uint32_t *__restrict__ guess32, uint32_t *__restrict__ counts,
+                                                            uint32_t *__restrict__ hist)
+{
+    pileup_planes_body<W>((const uint8_t JL_AS1 *)planes, plane_stride, n_cols, n_tiles, (const uint2 JL_AS1 *)chunks,
+                          (const uint32_t JL_AS1 *)guess32, (uint32_t JL_AS1 *)counts, (uint32_t JL_AS1 *)hist);
+}
+
+template <int W>
+__global__ __launch_bounds__(256) void pileup_planes_group_kernel(jl_pileup_group_args args)
+{
+    const jl_win_pileup &w = args.w[blockIdx.z];
+    if (blockIdx.x >= w.n_chunks) return;
+    pileup_planes_body<W>((const uint8_t JL_AS1 *)w.msa, w.col_stride, w.n_cols, w.n_tiles, (const uint2 JL_AS1 *)w.chunks,
+                          (const uint32_t JL_AS1 *)w.guess32, (uint32_t JL_AS1 *)w.counts, (uint32_t JL_AS1 *)w.hist);
+}
+
 // Seed base per column for majority-codon mode: majority base among the first reads of the column.
 // (Any value is correct; a good seed keeps the codon compare on its fast path.)
 __global__ __launch_bounds__(64) void guess_kernel(const uint8_t *__restrict__ msa, uint64_t col_stride,
@@ -467,7 +703,11 @@ constexpr int env_int(const char *, int dflt) { return dflt; }
 
 }  // namespace
 
-const char *jl_pileup_kernel_name(void) { return "pileup_kernel"; }   // rocprofv3 prints the template arguments behind it
+const char *jl_pileup_kernel_name(void) { return "pileup_planes_kernel"; }   // rocprofv3 prints the template arguments behind it
+
+// the bit-plane kernels, by chunk width (build_chunks makes 3 or 6 in shipped builds)
+static bool planes_usable(const jl_ctx *ctx) { return ctx->planes_valid && ctx->d_planes && (ctx->pileup_w == 3 || ctx->pileup_w == 6); }
+static uint32_t planes_tiles(const jl_ctx *ctx) { return (uint32_t)((ctx->plane_stride + JL_PLANE_TILE_BYTES - 1) / JL_PLANE_TILE_BYTES); }
 
 void jl_launch_guess(jl_ctx *ctx, hipStream_t st)
 {
@@ -495,11 +735,14 @@ static int pick_variant(const jl_ctx *ctx)
 // occupancy query, once per variant and outside any stream capture
 void jl_prepare_pileup(jl_ctx *ctx)
 {
-    const int idx = pick_variant(ctx);
+    // (slots 14 and 15 of the occupancy table: the bit-plane kernels of width 3 and 6)
+    const bool planes = planes_usable(ctx);
+    const int idx = planes ? (ctx->pileup_w == 3 ? 14 : 15) : pick_variant(ctx);
     if (ctx->pileup_blocks_per_cu[idx] > 0) return;
+    const void *fn = planes ? (ctx->pileup_w == 3 ? (const void *)pileup_planes_kernel<3> : (const void *)pileup_planes_kernel<6>)
+                            : (const void *)kVariants[idx].fn;
     int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)kVariants[idx].fn, 256, 0) != hipSuccess || per_cu < 1)
-        per_cu = 2;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, 0) != hipSuccess || per_cu < 1) per_cu = 2;
     if (per_cu > 8) per_cu = 8;
     ctx->pileup_blocks_per_cu[idx] = per_cu;
 }
@@ -508,10 +751,11 @@ void jl_prepare_pileup(jl_ctx *ctx)
 // per CU) for short columns, four per slot for long ones; reads are split no finer than a tile.
 uint32_t jl_pileup_rsplit(jl_ctx *ctx)
 {
-    const int idx = pick_variant(ctx);
+    const bool planes = planes_usable(ctx);
+    const int idx = planes ? (ctx->pileup_w == 3 ? 14 : 15) : pick_variant(ctx);
     jl_prepare_pileup(ctx);
     const uint32_t n_chunks = ctx->n_chunks ? ctx->n_chunks : 1u;
-    const uint32_t n_tiles = (uint32_t)((ctx->col_stride + JL_PILEUP_TILE_BYTES - 1) / JL_PILEUP_TILE_BYTES);
+    const uint32_t n_tiles = planes ? planes_tiles(ctx) : (uint32_t)((ctx->col_stride + JL_PILEUP_TILE_BYTES - 1) / JL_PILEUP_TILE_BYTES);
     const int per_cu = ctx->pileup_blocks_per_cu[idx];
     // long columns: several blocks per slot smooth the tail; short ones: exactly one resident wave of blocks
     const uint32_t target = 256u * (uint32_t)per_cu * (uint32_t)env_int("JL_PILEUP_WAVES", n_tiles >= 64 ? 4 : 1);
@@ -529,6 +773,16 @@ bool jl_pileup_needs_zero(jl_ctx *ctx) { return jl_pileup_rsplit(ctx) != 1u; }
 
 void jl_launch_pileup(jl_ctx *ctx, hipStream_t st, bool with_call)
 {
+    if (planes_usable(ctx) && !with_call) {
+        const uint32_t rsplit = jl_pileup_rsplit(ctx);
+        if (ctx->pileup_w == 3)
+            hipLaunchKernelGGL(pileup_planes_kernel<3>, dim3(ctx->n_chunks, rsplit), dim3(256), 0, st, ctx->d_planes, ctx->plane_stride, ctx->n_cols,
+                               planes_tiles(ctx), (const uint2 *)ctx->d_chunks, (const uint32_t *)ctx->d_guess, ctx->d_counts, ctx->d_hist);
+        else
+            hipLaunchKernelGGL(pileup_planes_kernel<6>, dim3(ctx->n_chunks, rsplit), dim3(256), 0, st, ctx->d_planes, ctx->plane_stride, ctx->n_cols,
+                               planes_tiles(ctx), (const uint2 *)ctx->d_chunks, (const uint32_t *)ctx->d_guess, ctx->d_counts, ctx->d_hist);
+        return;
+    }
     const int idx = pick_variant(ctx);
     const variant_t *var = &kVariants[idx];
     const uint32_t n_tiles = (uint32_t)((ctx->col_stride + JL_PILEUP_TILE_BYTES - 1) / JL_PILEUP_TILE_BYTES);
@@ -585,7 +839,23 @@ int jl_launch_pileup_group(jl_ctx *const *ctxs, uint32_t n_win, const jl_win_pil
     jl_pileup_group_args args;
     memset(&args, 0, sizeof args);
     memcpy(args.w, h_wins, sizeof(jl_win_pileup) * n_win);
-    for (uint32_t k = 0; k < n_win; ++k) args.w[k].ci = with_call ? ctxs[k]->d_callinfo : nullptr;
-    hipLaunchKernelGGL(with_call ? kVariants[idx].gfn_call : kVariants[idx].gfn, dim3(max_chunks, 1, n_win), dim3(256), 0, st, args);
+    // one kernel for the whole launch: the bit planes when every window has them, else the nibbles for all
+    bool planes = !with_call;
+    for (uint32_t k = 0; k < n_win; ++k) planes = planes && planes_usable(ctxs[k]);
+    for (uint32_t k = 0; k < n_win; ++k) {
+        args.w[k].ci = with_call ? ctxs[k]->d_callinfo : nullptr;
+        if (planes) {
+            args.w[k].msa = ctxs[k]->d_planes;
+            args.w[k].col_stride = ctxs[k]->plane_stride;
+            args.w[k].n_tiles = planes_tiles(ctxs[k]);
+        } else {
+            args.w[k].msa = ctxs[k]->d_msa;
+            args.w[k].col_stride = ctxs[k]->col_stride;
+            args.w[k].n_tiles = (uint32_t)((ctxs[k]->col_stride + JL_PILEUP_TILE_BYTES - 1) / JL_PILEUP_TILE_BYTES);
+        }
+    }
+    if (planes && ctxs[0]->pileup_w == 3) hipLaunchKernelGGL(pileup_planes_group_kernel<3>, dim3(max_chunks, 1, n_win), dim3(256), 0, st, args);
+    else if (planes) hipLaunchKernelGGL(pileup_planes_group_kernel<6>, dim3(max_chunks, 1, n_win), dim3(256), 0, st, args);
+    else hipLaunchKernelGGL(with_call ? kVariants[idx].gfn_call : kVariants[idx].gfn, dim3(max_chunks, 1, n_win), dim3(256), 0, st, args);
     return JL_OK;
 }

@@ -403,6 +403,41 @@ __global__ __launch_bounds__(256) void validate_kernel(const uint8_t *__restrict
 // Last node of a run: everything before it on the stream has completed (including the stores the result
 // kernels made into pinned host memory), so a sequence word stored behind a system-scope fence tells a
 // polling host that the results are there — no hipStreamSynchronize on the hot path.
+// Nibble matrix -> bit planes (jl_ctx::d_planes).  One thread = 64 reads of one column: 32 bytes of nibbles in, 8 bytes of
+// each of the three planes out; bit r of a plane word = bit k of read r's code.  Runs once per upload, on the context's stream.
+__device__ __forceinline__ uint32_t plane_byte(uint32_t w, uint32_t k)
+{
+    uint32_t x = (w >> k) & 0x11111111u;     // bit k of the eight codes, one per nibble
+    x = (x | (x >> 3)) & 0x03030303u;        // two per byte
+    x = (x | (x >> 6)) & 0x000F000Fu;        // four per half
+    return (x | (x >> 12)) & 0xFFu;          // eight: read 0 in bit 0
+}
+
+__global__ __launch_bounds__(256) void planes_kernel(const uint8_t *__restrict__ msa, uint64_t col_stride, uint8_t *__restrict__ planes,
+                                                     uint64_t plane_stride)
+{
+    const uint64_t t = (uint64_t)blockIdx.x * 256u + threadIdx.x;   // 64-read unit within the column
+    if (t * 32u >= col_stride) return;
+    const uint32_t c = blockIdx.y;
+    const uint4 *src = reinterpret_cast<const uint4 *>(msa + (uint64_t)c * col_stride + t * 32u);
+    const uint4 a = src[0], b = src[1];
+    const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+    for (uint32_t k = 0; k < 3u; ++k) {
+        uint2 o;
+        o.x = plane_byte(w[0], k) | (plane_byte(w[1], k) << 8) | (plane_byte(w[2], k) << 16) | (plane_byte(w[3], k) << 24);
+        o.y = plane_byte(w[4], k) | (plane_byte(w[5], k) << 8) | (plane_byte(w[6], k) << 16) | (plane_byte(w[7], k) << 24);
+        *reinterpret_cast<uint2 *>(planes + ((uint64_t)c * 3u + k) * plane_stride + t * 8u) = o;
+    }
+}
+
+void jl_launch_planes(jl_ctx *ctx, hipStream_t st)
+{
+    const uint64_t units = ctx->col_stride / 32u;   // col_stride is a multiple of 128
+    hipLaunchKernelGGL(planes_kernel, dim3((uint32_t)((units + 255u) / 256u), ctx->n_cols), dim3(256), 0, st, ctx->d_msa, ctx->col_stride,
+                       ctx->d_planes, ctx->plane_stride);
+}
+
 __global__ void done_kernel(uint32_t *__restrict__ seq_dev, volatile uint32_t *__restrict__ seq_host)
 {
     const uint32_t v = *seq_dev + 1u;
