@@ -30,7 +30,7 @@
 #define JL_INS_MAX_BASES 30u       // inserted bases tracked per insertion
 #define JL_GUESS_PAD 32u           // zero bytes after the last column's seed base
 #define JL_PILEUP_TILE_BYTES 4096u  // bytes of one column a 256-thread block reads per iteration (16 B / lane)
-#define JL_PLANE_TILE_BYTES 2048u   // the same for one bit plane of a column (8 B / lane = 64 reads)
+
 
 // resolved reference codon per position
 #define JL_REF_MAJORITY 0xFFu

@@ -408,15 +408,20 @@ __global__ __launch_bounds__(256, CALL ? JL_CALL_MIN_WAVES : 1) void pileup_grou
 // Same chunks, same seeds, same outputs, bit for bit: the two kernels count the same cells.  A lane takes 8 bytes = 64
 // reads of each plane per tile (a tile = 16384 reads); the next tile's 9 .. 24 words are prefetched as in the nibble kernel.
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-constexpr uint32_t kPlaneFlushTiles = 15;   // 64 lanes x 64 reads x 15 tiles = 61440 < 2^16
+// NQ = dwords of a plane a lane reads per tile.  16 bytes (NQ = 4) stream best: 142 us per 0.9 GB launch of eight windows
+// against 149 with 8-byte loads — at 154 registers, three waves per SIMD, which a single short window pays for (22.8 us
+// against 20.5 for 100k reads x 3 kb): grouped launches and deep windows take NQ = 4, a short window alone NQ = 2; the
+// six-column chunks always NQ = 2 (eight columns of tiles twice over: 249 registers at 16 bytes).
+constexpr uint32_t plane_tile_bytes(int nq) { return 256u * 4u * (uint32_t)nq; }
+constexpr uint32_t plane_flush_tiles(int nq) { return 1023u / (32u * (uint32_t)nq); }   // 64 lanes x 32 nq reads x tiles < 2^16
 
-template <int W>
+template <int W, int NQ>
 struct ptile_regs {
-    uint32_t d[W + 2][3][2];   // [column][plane][dword]
+    uint32_t d[W + 2][3][NQ];   // [column][plane][dword]
 };
 
-template <int W, bool FAST>
-__device__ __forceinline__ void load_ptile(ptile_regs<W> &r, const uint8_t JL_AS1 *planes, uint64_t plane_stride, uint32_t n_cols,
+template <int W, int NQ, bool FAST>
+__device__ __forceinline__ void load_ptile(ptile_regs<W, NQ> &r, const uint8_t JL_AS1 *planes, uint64_t plane_stride, uint32_t n_cols,
                                            uint32_t c0, uint32_t ncols, uint64_t off, bool need_halo)
 {
 #pragma unroll
@@ -427,26 +432,38 @@ __device__ __forceinline__ void load_ptile(ptile_regs<W> &r, const uint8_t JL_AS
             const uint8_t JL_AS1 *base = planes + (uint64_t)(c0 + j) * 3u * plane_stride + off;
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
-                const u32x2 v = __builtin_nontemporal_load((const u32x2 JL_AS1 *)(base + (uint64_t)k * plane_stride));
-                r.d[j][k][0] = v.x;
-                r.d[j][k][1] = v.y;
+                if (NQ == 2) {
+                    const u32x2 v = __builtin_nontemporal_load((const u32x2 JL_AS1 *)(base + (uint64_t)k * plane_stride));
+                    r.d[j][k][0] = v.x;
+                    r.d[j][k][1] = v.y;
+                } else {
+                    const u32x4 v = __builtin_nontemporal_load((const u32x4 JL_AS1 *)(base + (uint64_t)k * plane_stride));
+                    r.d[j][k][0] = v.x;
+                    r.d[j][k][1] = v.y;
+                    r.d[j][k][NQ - 2] = v.z;
+                    r.d[j][k][NQ - 1] = v.w;
+                }
             }
         } else {   // code 6 everywhere: b0 = 0, b1 = b2 = 1
-            r.d[j][0][0] = r.d[j][0][1] = 0u;
-            r.d[j][1][0] = r.d[j][1][1] = r.d[j][2][0] = r.d[j][2][1] = 0xFFFFFFFFu;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                r.d[j][0][q] = 0u;
+                r.d[j][1][q] = r.d[j][2][q] = 0xFFFFFFFFu;
+            }
         }
     }
 }
 
-template <int W, bool FAST>
+template <int W, int NQ, bool FAST>
 __device__ __forceinline__ void pileup_planes_stream(const uint8_t JL_AS1 *planes, uint64_t plane_stride, uint32_t n_cols,
                                                      uint32_t n_tiles, uint32_t c0, uint32_t ncols, uint32_t startf, bool need_halo,
                                                      const uint32_t (&g)[W + 2], uint32_t (*s_hist)[64], uint32_t (*s_col)[6],
                                                      uint32_t *s_match)
 {
+    constexpr uint32_t TILE = plane_tile_bytes(NQ);
     const uint32_t tid = threadIdx.x;
     const bool last_lane = (tid & 63u) == 63u;
-    const uint64_t lane_off = (uint64_t)tid * 8u;
+    const uint64_t lane_off = (uint64_t)tid * 4u * NQ;
     // the seed codon's bits as words: sh / sl[j] = all ones when bit 1 / bit 0 of column j's seed base is set
     uint32_t sh[W + 2], sl[W + 2];
 #pragma unroll
@@ -456,12 +473,12 @@ __device__ __forceinline__ void pileup_planes_stream(const uint8_t JL_AS1 *plane
     }
 
     uint32_t tile = blockIdx.y;
-    ptile_regs<W> nxt;
+    ptile_regs<W, NQ> nxt;
     bool nxt_live = false;
     if (tile < n_tiles) {
-        const uint64_t off = (uint64_t)tile * JL_PLANE_TILE_BYTES + lane_off;
+        const uint64_t off = (uint64_t)tile * TILE + lane_off;
         nxt_live = off < plane_stride;
-        if (nxt_live) load_ptile<W, FAST>(nxt, planes, plane_stride, n_cols, c0, ncols, off, need_halo);
+        if (nxt_live) load_ptile<W, NQ, FAST>(nxt, planes, plane_stride, n_cols, c0, ncols, off, need_halo);
     }
 
     while (tile < n_tiles) {
@@ -475,23 +492,23 @@ __device__ __forceinline__ void pileup_planes_stream(const uint8_t JL_AS1 *plane
         }
         uint32_t reads = 0;
 
-        for (uint32_t it = 0; it < kPlaneFlushTiles && tile < n_tiles; ++it, tile += gridDim.y) {
-            const ptile_regs<W> cur = nxt;
+        for (uint32_t it = 0; it < plane_flush_tiles(NQ) && tile < n_tiles; ++it, tile += gridDim.y) {
+            const ptile_regs<W, NQ> cur = nxt;
             const bool live = nxt_live;
             const uint32_t tn = tile + gridDim.y;
             nxt_live = false;
             if (tn < n_tiles) {
-                const uint64_t off = (uint64_t)tn * JL_PLANE_TILE_BYTES + lane_off;
+                const uint64_t off = (uint64_t)tn * TILE + lane_off;
                 nxt_live = off < plane_stride;
-                if (nxt_live) load_ptile<W, FAST>(nxt, planes, plane_stride, n_cols, c0, ncols, off, need_halo);
+                if (nxt_live) load_ptile<W, NQ, FAST>(nxt, planes, plane_stride, n_cols, c0, ncols, off, need_halo);
             }
             if (!live) continue;
-            reads += 64;
+            reads += 32u * NQ;
 #pragma unroll
             for (int j = 0; j < W; ++j) {
                 if (FAST ? j < 3 : (uint32_t)j < ncols) {
 #pragma unroll
-                    for (int q = 0; q < 2; ++q) {
+                    for (int q = 0; q < NQ; ++q) {
                         const uint32_t b0 = cur.d[j][0][q], b1 = cur.d[j][1][q], b2 = cur.d[j][2][q];
                         acc[j][0] += __popc(b0);
                         acc[j][1] += __popc(b1);
@@ -506,7 +523,7 @@ __device__ __forceinline__ void pileup_planes_stream(const uint8_t JL_AS1 *plane
             for (int j = 0; j < W; ++j) {
                 if (FAST ? j == 0 : (startf & (1u << j)) != 0) {
 #pragma unroll
-                    for (int q = 0; q < 2; ++q) {
+                    for (int q = 0; q < NQ; ++q) {
                         const uint32_t inv = cur.d[j][2][q] | cur.d[j + 1][2][q] | cur.d[j + 2][2][q];   // some code >= 4: not in coverage
                         const uint32_t x = (cur.d[j][1][q] ^ sh[j]) | (cur.d[j][0][q] ^ sl[j]) | (cur.d[j + 1][1][q] ^ sh[j + 1]) |
                                            (cur.d[j + 1][0][q] ^ sl[j + 1]) | (cur.d[j + 2][1][q] ^ sh[j + 2]) | (cur.d[j + 2][0][q] ^ sl[j + 2]);
@@ -551,7 +568,7 @@ __device__ __forceinline__ void pileup_planes_stream(const uint8_t JL_AS1 *plane
     }
 }
 
-template <int W>
+template <int W, int NQ>
 __device__ __forceinline__ void pileup_planes_body(const uint8_t JL_AS1 *planes, uint64_t plane_stride, uint32_t n_cols, uint32_t n_tiles,
                                                    const uint2 JL_AS1 *chunks, const uint32_t JL_AS1 *guess32, uint32_t JL_AS1 *counts,
                                                    uint32_t JL_AS1 *hist)
@@ -584,9 +601,9 @@ __device__ __forceinline__ void pileup_planes_body(const uint8_t JL_AS1 *planes,
     if (tid < W) s_match[tid] = 0;
     __syncthreads();
     if (W == 3 && rec.y == JL_CHUNK_META(3, 1, 0))
-        pileup_planes_stream<W, true>(planes, plane_stride, n_cols, n_tiles, c0, ncols, startf, need_halo, g, s_hist, s_col, s_match);
+        pileup_planes_stream<W, NQ, true>(planes, plane_stride, n_cols, n_tiles, c0, ncols, startf, need_halo, g, s_hist, s_col, s_match);
     else
-        pileup_planes_stream<W, false>(planes, plane_stride, n_cols, n_tiles, c0, ncols, startf, need_halo, g, s_hist, s_col, s_match);
+        pileup_planes_stream<W, NQ, false>(planes, plane_stride, n_cols, n_tiles, c0, ncols, startf, need_halo, g, s_hist, s_col, s_match);
     __syncthreads();
     const bool excl = gridDim.y == 1;
     if (tid < W * 6) {
@@ -613,22 +630,22 @@ __device__ __forceinline__ void pileup_planes_body(const uint8_t JL_AS1 *planes,
     }
 }
 
-template <int W>
+template <int W, int NQ>
 __global__ __launch_bounds__(256) void pileup_planes_kernel(const uint8_t *__restrict__ planes, uint64_t plane_stride, uint32_t n_cols,
                                                             uint32_t n_tiles, const uint2 *__restrict__ chunks,
                                                             const uint32_t *__restrict__ guess32, uint32_t *__restrict__ counts,
                                                             uint32_t *__restrict__ hist)
 {
-    pileup_planes_body<W>((const uint8_t JL_AS1 *)planes, plane_stride, n_cols, n_tiles, (const uint2 JL_AS1 *)chunks,
+    pileup_planes_body<W, NQ>((const uint8_t JL_AS1 *)planes, plane_stride, n_cols, n_tiles, (const uint2 JL_AS1 *)chunks,
                           (const uint32_t JL_AS1 *)guess32, (uint32_t JL_AS1 *)counts, (uint32_t JL_AS1 *)hist);
 }
 
-template <int W>
+template <int W, int NQ>
 __global__ __launch_bounds__(256) void pileup_planes_group_kernel(jl_pileup_group_args args)
 {
     const jl_win_pileup &w = args.w[blockIdx.z];
     if (blockIdx.x >= w.n_chunks) return;
-    pileup_planes_body<W>((const uint8_t JL_AS1 *)w.msa, w.col_stride, w.n_cols, w.n_tiles, (const uint2 JL_AS1 *)w.chunks,
+    pileup_planes_body<W, NQ>((const uint8_t JL_AS1 *)w.msa, w.col_stride, w.n_cols, w.n_tiles, (const uint2 JL_AS1 *)w.chunks,
                           (const uint32_t JL_AS1 *)w.guess32, (uint32_t JL_AS1 *)w.counts, (uint32_t JL_AS1 *)w.hist);
 }
 
@@ -707,7 +724,13 @@ const char *jl_pileup_kernel_name(void) { return "pileup_planes_kernel"; }   // 
 
 // the bit-plane kernels, by chunk width (build_chunks makes 3 or 6 in shipped builds)
 static bool planes_usable(const jl_ctx *ctx) { return ctx->planes_valid && ctx->d_planes && (ctx->pileup_w == 3 || ctx->pileup_w == 6); }
-static uint32_t planes_tiles(const jl_ctx *ctx) { return (uint32_t)((ctx->plane_stride + JL_PLANE_TILE_BYTES - 1) / JL_PLANE_TILE_BYTES); }
+// the load width of a launch (see plane_tile_bytes above)
+static int planes_nq(const jl_ctx *ctx, bool grouped) { return ctx->pileup_w == 3 && (grouped || ctx->plane_stride >= 32768u) ? 4 : 2; }
+static uint32_t planes_tiles(const jl_ctx *ctx, bool grouped)
+{
+    const uint32_t tile = plane_tile_bytes(planes_nq(ctx, grouped));
+    return (uint32_t)((ctx->plane_stride + tile - 1) / tile);
+}
 
 void jl_launch_guess(jl_ctx *ctx, hipStream_t st)
 {
@@ -739,7 +762,9 @@ void jl_prepare_pileup(jl_ctx *ctx)
     const bool planes = planes_usable(ctx);
     const int idx = planes ? (ctx->pileup_w == 3 ? 14 : 15) : pick_variant(ctx);
     if (ctx->pileup_blocks_per_cu[idx] > 0) return;
-    const void *fn = planes ? (ctx->pileup_w == 3 ? (const void *)pileup_planes_kernel<3> : (const void *)pileup_planes_kernel<6>)
+    // (the single-window launch: a short window alone reads 8 bytes a lane, a deep one 16)
+    const void *fn = planes ? (ctx->pileup_w == 3 ? (planes_nq(ctx, false) == 4 ? (const void *)pileup_planes_kernel<3, 4> : (const void *)pileup_planes_kernel<3, 2>)
+                                                  : (const void *)pileup_planes_kernel<6, 2>)
                             : (const void *)kVariants[idx].fn;
     int per_cu = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, 0) != hipSuccess || per_cu < 1) per_cu = 2;
@@ -755,7 +780,7 @@ uint32_t jl_pileup_rsplit(jl_ctx *ctx)
     const int idx = planes ? (ctx->pileup_w == 3 ? 14 : 15) : pick_variant(ctx);
     jl_prepare_pileup(ctx);
     const uint32_t n_chunks = ctx->n_chunks ? ctx->n_chunks : 1u;
-    const uint32_t n_tiles = planes ? planes_tiles(ctx) : (uint32_t)((ctx->col_stride + JL_PILEUP_TILE_BYTES - 1) / JL_PILEUP_TILE_BYTES);
+    const uint32_t n_tiles = planes ? planes_tiles(ctx, false) : (uint32_t)((ctx->col_stride + JL_PILEUP_TILE_BYTES - 1) / JL_PILEUP_TILE_BYTES);
     const int per_cu = ctx->pileup_blocks_per_cu[idx];
     // long columns: several blocks per slot smooth the tail; short ones: exactly one resident wave of blocks
     const uint32_t target = 256u * (uint32_t)per_cu * (uint32_t)env_int("JL_PILEUP_WAVES", n_tiles >= 64 ? 4 : 1);
@@ -775,12 +800,14 @@ void jl_launch_pileup(jl_ctx *ctx, hipStream_t st, bool with_call)
 {
     if (planes_usable(ctx) && !with_call) {
         const uint32_t rsplit = jl_pileup_rsplit(ctx);
-        if (ctx->pileup_w == 3)
-            hipLaunchKernelGGL(pileup_planes_kernel<3>, dim3(ctx->n_chunks, rsplit), dim3(256), 0, st, ctx->d_planes, ctx->plane_stride, ctx->n_cols,
-                               planes_tiles(ctx), (const uint2 *)ctx->d_chunks, (const uint32_t *)ctx->d_guess, ctx->d_counts, ctx->d_hist);
-        else
-            hipLaunchKernelGGL(pileup_planes_kernel<6>, dim3(ctx->n_chunks, rsplit), dim3(256), 0, st, ctx->d_planes, ctx->plane_stride, ctx->n_cols,
-                               planes_tiles(ctx), (const uint2 *)ctx->d_chunks, (const uint32_t *)ctx->d_guess, ctx->d_counts, ctx->d_hist);
+        const uint32_t nt = planes_tiles(ctx, false);
+#define JL_LAUNCH_PLANES(W, NQ)                                                                                                          \
+    hipLaunchKernelGGL((pileup_planes_kernel<W, NQ>), dim3(ctx->n_chunks, rsplit), dim3(256), 0, st, ctx->d_planes, ctx->plane_stride,   \
+                       ctx->n_cols, nt, (const uint2 *)ctx->d_chunks, (const uint32_t *)ctx->d_guess, ctx->d_counts, ctx->d_hist)
+        if (ctx->pileup_w == 6) JL_LAUNCH_PLANES(6, 2);
+        else if (planes_nq(ctx, false) == 4) JL_LAUNCH_PLANES(3, 4);
+        else JL_LAUNCH_PLANES(3, 2);
+#undef JL_LAUNCH_PLANES
         return;
     }
     const int idx = pick_variant(ctx);
@@ -847,15 +874,15 @@ int jl_launch_pileup_group(jl_ctx *const *ctxs, uint32_t n_win, const jl_win_pil
         if (planes) {
             args.w[k].msa = ctxs[k]->d_planes;
             args.w[k].col_stride = ctxs[k]->plane_stride;
-            args.w[k].n_tiles = planes_tiles(ctxs[k]);
+            args.w[k].n_tiles = planes_tiles(ctxs[k], true);
         } else {
             args.w[k].msa = ctxs[k]->d_msa;
             args.w[k].col_stride = ctxs[k]->col_stride;
             args.w[k].n_tiles = (uint32_t)((ctxs[k]->col_stride + JL_PILEUP_TILE_BYTES - 1) / JL_PILEUP_TILE_BYTES);
         }
     }
-    if (planes && ctxs[0]->pileup_w == 3) hipLaunchKernelGGL(pileup_planes_group_kernel<3>, dim3(max_chunks, 1, n_win), dim3(256), 0, st, args);
-    else if (planes) hipLaunchKernelGGL(pileup_planes_group_kernel<6>, dim3(max_chunks, 1, n_win), dim3(256), 0, st, args);
+    if (planes && ctxs[0]->pileup_w == 3) hipLaunchKernelGGL((pileup_planes_group_kernel<3, 4>), dim3(max_chunks, 1, n_win), dim3(256), 0, st, args);
+    else if (planes) hipLaunchKernelGGL((pileup_planes_group_kernel<6, 2>), dim3(max_chunks, 1, n_win), dim3(256), 0, st, args);
     else hipLaunchKernelGGL(with_call ? kVariants[idx].gfn_call : kVariants[idx].gfn, dim3(max_chunks, 1, n_win), dim3(256), 0, st, args);
     return JL_OK;
 }

@@ -19,7 +19,7 @@ def rows(d, counter):
     out = []
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
-            if "pileup_group_kernel" in r["Kernel_Name"] and r["Counter_Name"] == counter:
+            if ("pileup_group_kernel" in r["Kernel_Name"] or "pileup_planes_group_kernel" in r["Kernel_Name"]) and r["Counter_Name"] == counter:
                 out.append(r)
     return out
 
@@ -31,7 +31,8 @@ def condense(rs, counter):
         w = csv.writer(f)
         w.writerow(keep)
         for r in rs:
-            name = "pileup_group_kernel<3,true,4>" if "<3, true, 4" in r["Kernel_Name"] else r["Kernel_Name"][:60]
+            name = ("pileup_planes_group_kernel<3>" if "planes_group_kernel<3>" in r["Kernel_Name"] else
+                    "pileup_group_kernel<3,true,4>" if "<3, true, 4" in r["Kernel_Name"] else r["Kernel_Name"][:60])
             w.writerow([r["Dispatch_Id"], name] + [r[k] for k in keep[2:]])
     # full launches only (the set-up pass also launches partial groups)
     full = max(int(r["Grid_Size"]) for r in rs)
@@ -45,8 +46,12 @@ windows = grid // 256 // 1000          # 1000 chunks (workgroups) per 3000-colum
 alg = windows * 150_000_000
 hbm = int(round((2.0 * fa + wa) * 1024))
 old = json.load(open(os.path.join(here, "pmc_traffic.json")))
+planes = any("planes" in r["Kernel_Name"] for r in rows(d_fetch, "FETCH_SIZE"))
 new = {
-    "kernel": "pileup_group_kernel<3,true,4>",
+    "kernel": "pileup_planes_group_kernel<3>" if planes else "pileup_group_kernel<3,true,4>",
+    "layout": ("bit planes: 3 bits per cell are moved (112.5 MB per 100k x 3000 window) where the algorithmic figure of SURVEY 8d counts "
+               "a 4-bit cell (150 MB)") if planes else "nibbles: 4 bits per cell",
+    "moved_bytes_per_launch_expected": windows * (112_500_000 if planes else 150_000_000),
     "windows_per_launch": windows,
     "workload": f"{windows} windows of 100000 reads x 3000 columns per launch (bench default: --group {windows})",
     "FETCH_SIZE_KB_avg": fa, "WRITE_SIZE_KB_avg": wa, "launches_averaged": [nf, nw],
