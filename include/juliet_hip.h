@@ -124,6 +124,11 @@ int jl_sync(jl_ctx *ctx);
 
 /* ---------------------------------------------------------------- MSA residency */
 
+/* A matrix the library writes itself (upload, pack_rows, record ingest, synthetic fill) is resident twice: the
+ * column-packed nibbles described here and, derived from them on the context's stream, three bit planes per column that
+ * the counting kernel streams (3 bits per cell: 0.75 x the nibble matrix in extra memory).  A matrix the caller owns
+ * (jl_msa_adopt) is never copied — the caller may rewrite it between runs — and is counted from its nibbles. */
+
 /* Bytes per column for n_reads reads (ceil(n/2) rounded up to 128). */
 uint64_t jl_col_stride(uint64_t n_reads);
 /* Copy a host column-packed matrix [n_cols][col_stride] into device memory owned by the ctx. */
