@@ -505,6 +505,8 @@ def main():
                      "moved_bytes_per_launch": alg_bytes * 3 // 4, "hbm_achieved": alg_bytes * 0.75 / (t_pileup_ms * 1e-3) / 1e9,
                      "hbm_frac": alg_bytes * 0.75 / (t_pileup_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                      "layout": "bit planes, 3 bits per cell (the resident nibble matrix is read by the phasing stage only)",
+                     "note": "achieved / frac use the ALGORITHMIC bytes of SURVEY 8d (a 4-bit cell); the kernel reads 3 bits per cell, so the "
+                             "physical figures are hbm_achieved / hbm_frac (and traffic, from the PMC counters): frac may exceed 1, hbm_frac cannot",
                      # the same bytes over the whole step (launch gaps, Fisher, phasing, results on the host included)
                      # one window alone through the whole path (what `juliet in.bam out.json` does): its bytes over its latency
                      "one_batch_frac": step_bytes / (latency_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
