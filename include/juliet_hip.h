@@ -24,7 +24,13 @@
 extern "C" {
 #endif
 
-#define JL_ABI_VERSION 4
+/* The library is built with -fvisibility=hidden: the functions declared between this push and the pop at the end of
+ * the file ARE its export list (tests/test_capi_exports.py checks the equality both ways). */
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility push(default)
+#endif
+
+#define JL_ABI_VERSION 5
 
 /* symbol codes of the MSA (SPEC §1; J:99-100, 256-259, 372-381) */
 enum { JL_SYM_A = 0, JL_SYM_C = 1, JL_SYM_G = 2, JL_SYM_T = 3, JL_SYM_GAP = 4, JL_SYM_MASK = 5, JL_SYM_NONE = 6 };
@@ -547,6 +553,10 @@ int jl_xwin_read_hap_fetch(jl_xwin *x, uint16_t *read_hap);
  * exported more than cap_groups groups. */
 int jl_allgather_groups(jl_ctx *ctx, jl_comm *comm, uint32_t cap_groups, uint32_t pattern_stride, uint8_t *patterns,
                         uint32_t *counts, uint32_t *n_groups, jl_phase_summary *partials, uint32_t *n_positions);
+
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility pop
+#endif
 
 #ifdef __cplusplus
 }

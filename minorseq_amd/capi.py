@@ -233,7 +233,7 @@ def load_library(path=LIB_PATH):
     lib.jl_xwin_read_hap_fetch.argtypes = [vp, vp]
     lib.jl_xwin_stage_us.argtypes = [vp, vp]
     lib.jl_allgather_groups.argtypes = [vp, vp, u32, u32, vp, vp, vp, vp, C.POINTER(u32)]
-    if lib.jl_abi_version() != 4:
+    if lib.jl_abi_version() != 5:
         raise ImportError("libjuliet_hip.so ABI version mismatch")
     _lib = lib
     return lib

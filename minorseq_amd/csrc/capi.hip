@@ -1561,7 +1561,7 @@ extern "C" {
 #ifdef JL_TUNING
 // tuning aid, not part of the ABI header (tools_tuning/timeline.py): the device-clock stamps of the last
 // JL_TIMELINE_ROWS runs of this context (JL_TIMELINE=1), 100 MHz ticks
-int jl_debug_timeline(jl_ctx *ctx, uint64_t *out)
+__attribute__((visibility("default"))) int jl_debug_timeline(jl_ctx *ctx, uint64_t *out)
 {
     if (!ctx || !out) return JL_ERR_ARG;
     if (!ctx->d_timeline) return jl_fail(ctx, JL_ERR_STATE, "run with JL_TIMELINE=1");

@@ -1607,7 +1607,7 @@ __global__ __launch_bounds__(256) void phase_assign_group_kernel(jl_phase_group_
 }  // namespace
 
 #ifdef JL_EXP_STAMPS
-extern "C" int jl_debug_stamps(unsigned long long *out)
+extern "C" __attribute__((visibility("default"))) int jl_debug_stamps(unsigned long long *out)
 {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(g_stamps)) == hipSuccess ? 0 : -2;
 }

@@ -42,6 +42,7 @@ struct Options {
     std::string chemistry = "auto";
     double match = -1.0, substitution = -1.0;
     int expected_round = 0;
+    int fisher_tail = 0;             // --fisher-tail greater|two-sided (doc/JULIET.md:38-42 leaves the sidedness open)
     uint32_t min_reads = 10, min_qv = 0;
     double min_rq = 0.0;
     int device = 0;
@@ -68,6 +69,7 @@ struct Options {
         "  parameters the reference text leaves open (docs/SPEC.md):\n"
         "      --alpha 0.01  --n-tests <auto>  --chemistry auto|sequel|permissive\n"
         "      --match-rate <r> --substitution-rate <r> --expected-round ceil|floor|nearest\n"
+        "      --fisher-tail greater|two-sided  sidedness of Fisher's exact test (default greater: an excess of observed codons)\n"
         "      --min-reads 10  --min-qv 0  --min-rq 0  --device 0\n"
         "      --windows K [--devices a,b,...] cut the reference into K column windows (2-column overlap, global Bonferroni\n"
         "                                      factor), consecutive windows per device; phasing runs across the windows with\n"
@@ -116,6 +118,12 @@ Options parse(int argc, char **argv)
         else if (a == "--expected-round") {
             const std::string v = need(i);
             o.expected_round = v == "floor" ? 1 : v == "nearest" ? 2 : 0;
+        }
+        else if (a == "--fisher-tail") {
+            const std::string v = need(i);
+            if (v == "greater") o.fisher_tail = 0;
+            else if (v == "two-sided") o.fisher_tail = 1;
+            else { std::cerr << "juliet: --fisher-tail takes greater or two-sided\n"; usage(1); }
         }
         else if (a == "--min-reads") o.min_reads = (uint32_t)std::stoul(need(i));
         else if (a == "--min-qv") o.min_qv = (uint32_t)std::stoul(need(i));
@@ -625,7 +633,7 @@ int main(int argc, char **argv)
         if (opt.match > 0) prm.err.match = opt.match;
         if (opt.substitution >= 0) prm.err.substitution = opt.substitution;
         prm.expected_round = opt.expected_round;
-        prm.tail = 0;
+        prm.tail = opt.fisher_tail;
         prm.min_perc = opt.min_perc;
         prm.max_perc = opt.max_perc;
 

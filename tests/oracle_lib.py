@@ -34,8 +34,8 @@ class Params(C.Structure):
                 ("tail", C.c_int32)]
 
 
-def default_params(n_tests=0.0, alpha=0.01, match=0.998826, substitution=5.8e-5, deletion=1.0e-3):
-    return Params(alpha, n_tests, ErrorModel(match, substitution, deletion), 0, 0)
+def default_params(n_tests=0.0, alpha=0.01, match=0.998826, substitution=5.8e-5, deletion=1.0e-3, tail=0):
+    return Params(alpha, n_tests, ErrorModel(match, substitution, deletion), 0, tail)
 
 
 def _ptr(a, t):

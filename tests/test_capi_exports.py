@@ -27,6 +27,18 @@ def test_library_exports_every_declared_symbol():
     assert sorted(capi.EXPORTS) == declared
 
 
+def test_header_is_the_export_list():
+    """-fvisibility=hidden + the header's visibility pragma + csrc/exports.map: the dynamic symbol table of the library
+    holds exactly the functions include/juliet_hip.h declares — no internal jl_* helper, no mangled C++ symbol, no kernel
+    handle."""
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", capi.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = sorted(line.split()[-1] for line in out.splitlines() if line.strip())
+    kinds = {line.split()[-2] for line in out.splitlines() if line.strip()}
+    assert exported == _declared()
+    assert kinds == {"T"}
+
+
 def test_pod_layouts():
     assert capi.VARIANT.itemsize == 48          # the all-gather row
     assert capi.GENE.itemsize == 8
@@ -76,7 +88,7 @@ def test_header_is_plain_c_and_links(tmp_path):
     out = subprocess.run([str(exe)], capture_output=True, text=True)
     assert out.returncode == 0, out.stderr
     ver, n, rc, msg = out.stdout.strip().split(" ", 3)
-    assert ver == "4"
+    assert ver == "5"
     if n == "0":
         assert rc == "-2" and "no CPU fallback" in msg      # loud failure without a device
 

@@ -124,6 +124,29 @@ def test_filters_and_region(sample, oracle):
     assert len(sub) >= 1
 
 
+def test_fisher_tail_flag(sample, oracle):
+    """--fisher-tail greater|two-sided (doc/JULIET.md:38-42 leaves the sidedness open): the CLI hands
+    jl_params.tail to the device; the JSON matches the oracle's two-sided table, p-values within 1e-10, and the two-sided
+    calls are a subset of the one-sided ones (p doubles)."""
+    d, bam, cfg, rows, ref = sample
+    genes = np.array([(1, L + 1)], dtype=capi.GENE)
+    one = oracle.call(rows, genes, refseq=ref)
+    two = oracle.call(rows, genes, refseq=ref, params=oracle_lib.default_params(tail=1))
+    j2 = flat_variants(run_juliet(d, bam, "-c", cfg, "--fisher-tail", "two-sided", out="two.json"))
+    j1 = flat_variants(run_juliet(d, bam, "-c", cfg, "--fisher-tail", "greater", out="one.json"))
+    for got, exp in ((j1, one), (j2, two)):
+        assert len(got) == len(exp) >= 4
+        for (gi, pos, cod, vc, vp, aa), e in zip(got, exp):
+            assert (gi, pos, cod, vc["count"], vp["coverage"]) == (e["gene"], e["codon_pos"], e["codon"], e["count"], e["coverage"])
+            assert abs(vc["pValue"] - e["p_value"]) <= 1e-10
+    k1 = {(r[0], r[1], r[2]): r[3]["pValue"] for r in j1}
+    for r in j2:
+        assert (r[0], r[1], r[2]) in k1
+        assert abs(r[3]["pValue"] - min(1.0, 2.0 * k1[(r[0], r[1], r[2])])) <= 1e-10 or r[3]["pValue"] >= k1[(r[0], r[1], r[2])]
+    bad = subprocess.run([JULIET, "-c", cfg, "--fisher-tail", "less", bam, str(d / "bad.json")], capture_output=True, text=True)
+    assert bad.returncode == 1 and "greater or two-sided" in bad.stderr
+
+
 def test_drm_only_keeps_only_config_mutations(tmp_path, oracle):
     """--drm-only (doc/JULIET.md:370) on a noisy sample where plenty of non-DRM codons are significant too."""
     n, l, seed = 3000, 300, 8
