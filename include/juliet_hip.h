@@ -130,20 +130,28 @@ int jl_sync(jl_ctx *ctx);
 
 /* ---------------------------------------------------------------- MSA residency */
 
-/* A matrix the library writes itself (upload, pack_rows, record ingest, synthetic fill) is resident twice: the
- * column-packed nibbles described here and, derived from them on the context's stream, three bit planes per column that
- * the counting kernel streams (3 bits per cell: 0.75 x the nibble matrix in extra memory).  A matrix the caller owns
- * (jl_msa_adopt) is never copied — the caller may rewrite it between runs — and is counted from its nibbles. */
+/* THE resident format (ABI 5): per column three BIT PLANES — plane k holds bit k of every read's 3-bit symbol code, read i
+ * in bit i & 7 of byte i >> 3; plane k of column c at base + (3 c + k) * plane_stride; reads past n_reads are padding with
+ * code 6 (plane 0 clear, planes 1 and 2 set).  3 bits per cell: 112.5 MB for 100k reads x 3 kb.  Every producer (upload,
+ * pack_rows, record ingest, synthetic fill) writes the planes directly and every stage (pileup, phasing, the exchange of
+ * cross-window phasing) reads them; there is no second copy.  The column-packed NIBBLE layout of earlier ABI versions
+ * (read i in byte i / 2, low nibble even; column stride jl_col_stride) remains the host-side INTERCHANGE format of
+ * jl_msa_upload and jl_msa_download only: it is converted on the device, a bounded run of columns at a time. */
 
-/* Bytes per column for n_reads reads (ceil(n/2) rounded up to 128). */
+/* Bytes per column of the interchange (nibble) format for n_reads reads (ceil(n/2) rounded up to 128). */
 uint64_t jl_col_stride(uint64_t n_reads);
-/* Copy a host column-packed matrix [n_cols][col_stride] into device memory owned by the ctx. */
+/* Bytes per plane of the resident format the library allocates: ceil(n/1024) * 128 (whole 128-byte lines). */
+uint64_t jl_plane_stride(uint64_t n_reads);
+/* A host matrix in the interchange format, [n_cols][col_stride] nibbles, into resident planes owned by the ctx; symbol
+ * codes outside 0..6 are rejected (JL_ERR_ARG); whatever the buffer holds past read n_reads - 1 of a column is ignored. */
 int jl_msa_upload(jl_ctx *ctx, const uint8_t *colpacked, uint64_t n_reads, uint32_t n_cols, uint64_t col_stride,
                   uint32_t win_begin);
 /* Allocate an uninitialised resident matrix (for jl_synth_fill / jl_msa_pack_rows). */
 int jl_msa_alloc(jl_ctx *ctx, uint64_t n_reads, uint32_t n_cols, uint32_t win_begin);
-/* Use caller-owned device memory (e.g. a torch tensor) as the resident matrix; not freed by the ctx. */
-int jl_msa_adopt(jl_ctx *ctx, void *d_colpacked, uint64_t n_reads, uint32_t n_cols, uint64_t col_stride,
+/* Use caller-owned device memory (e.g. a torch tensor) holding the resident format — [n_cols][3][plane_stride] bytes,
+ * 16-byte aligned, plane_stride a multiple of 16 and >= ceil(n_reads / 8), padding reads = code 6 — as the resident
+ * matrix; never copied, not freed by the ctx, and the caller may rewrite it between runs. */
+int jl_msa_adopt(jl_ctx *ctx, void *d_planes, uint64_t n_reads, uint32_t n_cols, uint64_t plane_stride,
                  uint32_t win_begin);
 /* Device-side transpose of a host by-row matrix uint8[n_reads][n_cols] (codes 0..6) into the resident layout. */
 int jl_msa_pack_rows(jl_ctx *ctx, const uint8_t *rows, uint64_t n_reads, uint32_t n_cols, uint32_t win_begin);
@@ -184,7 +192,7 @@ int jl_records_drop(jl_ctx *records);
  */
 int jl_msa_track_insertions(jl_ctx *ctx, int on);
 int jl_insertions_fetch(jl_ctx *ctx, uint32_t *len_hist, uint32_t *base_counts);
-/* Copy the resident matrix back to the host (tests). */
+/* The resident matrix back on the host in the interchange format, [n_cols][jl_col_stride(n_reads)] nibbles (tests). */
 int jl_msa_download(jl_ctx *ctx, uint8_t *colpacked, uint64_t bytes);
 /* Fill the resident matrix with synthetic reads, on the device. `ref` = n_cols base codes (host). */
 int jl_synth_fill(jl_ctx *ctx, const jl_synth_params *sp, const uint8_t *ref);
@@ -325,7 +333,8 @@ int jl_group_run_masked_async(jl_group *group, const jl_gene *genes, uint32_t n_
                               uint32_t ref_len, const jl_params *prm, const uint64_t *const *drm_masks, int phasing,
                               uint32_t min_reads, int want_read_hap);
 /* Timing hook (bench): average device time in ms of the grouped pileup launch alone, `reps` back-to-back launches
- * rotating over `groups` (each must have run once); `bytes_per_launch` = algorithmic bytes of one launch of groups[0]. */
+ * rotating over `groups` (each must have run once); `bytes_per_launch` = algorithmic bytes of one launch of groups[0]: 3 bits per cell,
+ * every cell read once. */
 /* The results of the last group run, one view per window (the group's context order): jl_run_view_get on every context in
  * ONE call — waits for each window's completion word in turn.  out[cap]; *n = the group's windows.  A window whose view
  * fails ends the call with its status (jl_group_last_error names it). */
@@ -481,9 +490,10 @@ int jl_select_haplotypes(const uint8_t *patterns, const uint64_t *counts, uint32
 
 /* The schedule of the column-slice exchange as data (what jl_xwin_phase_sharded / jl_xwin_assemble_slice_rccl issue):
  * positions are ascending global columns and windows ascending column ranges, so the positions a rank owns are ONE run
- * k_begin .. k_begin + k_count, and a rank sends every peer ONE packed message: slice s of the 3 * k_count owned
- * columns, each column padded with 'not covered' (0x66) to dst_stride = jl_col_stride(reads of slice s) — exactly the
- * bytes of columns 3 * k_begin .. of the receiver's compact matrix, where the matching receive lands them.
+ * k_begin .. k_begin + k_count, and a rank sends every peer ONE packed message: slice s of the 9 * k_count plane
+ * rows of the owned columns (three columns x three planes per position), each row padded with 'not covered' (code 6: 0x00
+ * in plane 0, 0xFF in planes 1 and 2) to dst_stride = jl_plane_stride(reads of slice s) — exactly the bytes of columns
+ * 3 * k_begin .. of the receiver's compact matrix, where the matching receive lands them.
  * win_rank[w] = rank that holds window w (non-decreasing).  ops of rank `rank`, in issue order: its own slice (a device
  * copy), then per peer in ascending order the send and the receive.  Every send has exactly one matching receive
  * (same byte count) in the peer's list.  JL_ERR_ARG if a variant column lies in no window. */
@@ -492,9 +502,9 @@ typedef struct {
     int32_t op, peer;            /* peer: the other rank (own rank for JL_XWIN_OP_LOCAL) */
     uint32_t k_begin, k_count;   /* positions whose columns travel */
     uint64_t read_begin, n_reads;/* the slice of the reads (the RECEIVER's slice) */
-    uint64_t dst_stride;         /* bytes per column in the message = the receiver's column stride */
-    uint64_t bytes;              /* 3 * k_count * dst_stride */
-    uint64_t dst_offset;         /* where the message lands in the receiver's compact matrix: 3 * k_begin * dst_stride */
+    uint64_t dst_stride;         /* bytes per plane row in the message = the receiver's plane stride */
+    uint64_t bytes;              /* 9 * k_count * dst_stride */
+    uint64_t dst_offset;         /* where the message lands in the receiver's compact matrix: 9 * k_begin * dst_stride */
 } jl_xwin_op;
 int jl_xwin_slice_plan(const uint32_t *win_begin, const uint32_t *win_ncols, const int32_t *win_rank, uint32_t n_windows,
                        const jl_variant *merged, uint32_t n_var, const uint64_t *slice_begin, int32_t world, int32_t rank,

@@ -29,7 +29,7 @@ SUMMARY = np.dtype([(n, "<u4") for n in SUMMARY_FIELDS])
 
 # every symbol include/juliet_hip.h declares (checked by tests/test_capi_exports.py)
 EXPORTS = ("jl_abi_version", "jl_strerror", "jl_device_count", "jl_ctx_create", "jl_ctx_destroy", "jl_last_error",
-           "jl_sync", "jl_col_stride", "jl_msa_upload", "jl_msa_alloc", "jl_msa_adopt", "jl_msa_pack_rows",
+           "jl_sync", "jl_col_stride", "jl_plane_stride", "jl_msa_upload", "jl_msa_alloc", "jl_msa_adopt", "jl_msa_pack_rows",
            "jl_msa_ingest_records", "jl_records_begin", "jl_records_append", "jl_records_finish", "jl_records_window", "jl_records_drop", "jl_msa_track_insertions", "jl_insertions_fetch", "jl_msa_download", "jl_synth_fill", "jl_synth_fill_window", "jl_pileup_async", "jl_n_positions", "jl_pileup_fetch",
            "jl_consensus_fetch", "jl_call_async", "jl_call_fetch", "jl_variant_table_device", "jl_phase_async", "jl_phase_fetch",
            "jl_ctx_stream", "jl_run_async", "jl_run_wait", "jl_run_done", "jl_run_view_get", "jl_group_create", "jl_group_destroy",
@@ -154,6 +154,8 @@ def load_library(path=LIB_PATH):
     lib.jl_pileup_kernel_name.restype = C.c_char_p
     lib.jl_col_stride.restype = u64
     lib.jl_col_stride.argtypes = [u64]
+    lib.jl_plane_stride.restype = u64
+    lib.jl_plane_stride.argtypes = [u64]
     lib.jl_ctx_create.argtypes = [C.c_int, vp, C.POINTER(vp)]
     lib.jl_ctx_stream.argtypes = [vp]
     lib.jl_ctx_stream.restype = vp
@@ -305,21 +307,25 @@ class Juliet:
         return rc
 
     # ------------------------------------------------------------------ residency
-    def _shape(self, n_reads, n_cols, stride):
-        self.n_reads, self.n_cols, self.col_stride = int(n_reads), int(n_cols), int(stride)
+    def _shape(self, n_reads, n_cols, stride=None):
+        """col_stride: the column stride of the INTERCHANGE format (what download_columns returns); the resident planes have
+        plane_stride bytes per plane (the library's, or the caller's for an adopted matrix)."""
+        self.n_reads, self.n_cols = int(n_reads), int(n_cols)
+        self.col_stride = int(self.lib.jl_col_stride(int(n_reads)))
+        self.plane_stride = int(stride) if stride is not None else int(self.lib.jl_plane_stride(int(n_reads)))
 
     def upload_columns(self, packed, n_reads, win_begin=0):
         packed = np.ascontiguousarray(packed, dtype=np.uint8)
         n_cols, stride = packed.shape
         self._chk(self.lib.jl_msa_upload(self.h, _p(packed), n_reads, n_cols, stride, win_begin))
-        self._shape(n_reads, n_cols, stride)
+        self._shape(n_reads, n_cols)
 
     def upload_rows(self, rows, win_begin=0):
-        """By-row uint8 codes; transposed and nibble-packed on the device."""
+        """By-row uint8 codes; transposed into the resident planes on the device."""
         rows = np.ascontiguousarray(rows, dtype=np.uint8)
         n, l = rows.shape
         self._chk(self.lib.jl_msa_pack_rows(self.h, _p(rows), n, l, win_begin))
-        self._shape(n, l, self.lib.jl_col_stride(n))
+        self._shape(n, l)
 
     def ingest_records(self, n_cols, win_begin, pos, cigar, cig_off, seq4, seq_off, qual=None, qual_off=None, min_qv=0):
         """Aligned records (BAM-decoded arrays) -> resident matrix, cigar expansion on the device."""
@@ -334,7 +340,7 @@ class Juliet:
         n = len(pos)
         self._chk(self.lib.jl_msa_ingest_records(self.h, n, n_cols, win_begin, _p(pos), _p(cigar), _p(cig_off), _p(seq4),
                                                  _p(seq_off), _p(qual), _p(qual_off), min_qv))
-        self._shape(n, n_cols, self.lib.jl_col_stride(n))
+        self._shape(n, n_cols)
 
     def ingest_records_chunked(self, n_cols, win_begin, pos, cigar, cig_off, seq4, seq_off, qual=None, qual_off=None,
                                min_qv=0, chunk_reads=1000, hints=(0, 0, 0, 0)):
@@ -358,7 +364,7 @@ class Juliet:
             self._chk(self.lib.jl_records_append(self.h, b - a, _p(np.ascontiguousarray(pos[a:b])), _p(cigar), _p(co), _p(seq4),
                                                  _p(so), _p(qual), _p(qo)))
         self._chk(self.lib.jl_records_finish(self.h, n_cols, win_begin, min_qv))
-        self._shape(n, n_cols, self.lib.jl_col_stride(n))
+        self._shape(n, n_cols)
 
     def track_insertions(self, on=True):
         self._chk(self.lib.jl_msa_track_insertions(self.h, 1 if on else 0))
@@ -372,11 +378,12 @@ class Juliet:
 
     def alloc(self, n_reads, n_cols, win_begin=0):
         self._chk(self.lib.jl_msa_alloc(self.h, n_reads, n_cols, win_begin))
-        self._shape(n_reads, n_cols, self.lib.jl_col_stride(n_reads))
+        self._shape(n_reads, n_cols)
 
-    def adopt(self, device_ptr, n_reads, n_cols, col_stride, win_begin=0, keep_alive=None):
-        self._chk(self.lib.jl_msa_adopt(self.h, C.c_void_p(device_ptr), n_reads, n_cols, col_stride, win_begin))
-        self._shape(n_reads, n_cols, col_stride)
+    def adopt(self, device_ptr, n_reads, n_cols, plane_stride, win_begin=0, keep_alive=None):
+        """Caller-owned device memory in the resident format: [n_cols][3][plane_stride] bytes (msa.pack_planes)."""
+        self._chk(self.lib.jl_msa_adopt(self.h, C.c_void_p(device_ptr), n_reads, n_cols, plane_stride, win_begin))
+        self._shape(n_reads, n_cols, plane_stride)
         self._keep = keep_alive
 
     def synth_fill(self, sp, ref):
@@ -504,7 +511,7 @@ class Juliet:
         self._chk(self.lib.jl_xwin_assemble_slice_local(self.h, arr, len(windows), _p(merged if len(merged) else remapped), len(merged),
                                                         read_begin, n_slice, _p(remapped), _p(pos_global), C.byref(vp)))
         if vp.value and n_slice:
-            self._shape(n_slice, 3 * vp.value, self.lib.jl_col_stride(n_slice))
+            self._shape(n_slice, 3 * vp.value)
         return remapped[: len(merged)], pos_global[: vp.value]
 
     def xwin_assemble_slice_rccl(self, window, comm, win_begins, win_ncols, merged, slice_begin):
@@ -884,7 +891,7 @@ def phase_across_windows(windows, merged, min_reads=10, comm=None, win_begins=No
     if vp.value == 0:
         pc.close()
         return None, pos_global[:0]
-    pc._shape(windows[0].n_reads, 3 * vp.value, windows[0].col_stride)
+    pc._shape(windows[0].n_reads, 3 * vp.value, windows[0].plane_stride)
     pc.phase_async(remapped[: len(merged)], min_reads)
     ph = pc.phase_fetch(want_reads=True, cap_var=max(1, len(merged)))
     ph["hit"] = ph["hit"][: len(merged), : ph["summary"]["n_haplotypes"]].copy()

@@ -20,11 +20,9 @@
 
 static thread_local std::string g_create_error;
 
-// The HIP runtime multiplexes a process's streams onto 4 hardware queues unless told otherwise, and reads the setting when
-// it initialises, i.e. at the process's first HIP call.  A host that keeps several launches in flight beside an exchange
-// wants 8: set here, when the library is loaded, unless the environment already says something — which
-// takes effect whenever this library is loaded before anything in the process has touched HIP.
-__attribute__((constructor)) static void jl_runtime_defaults() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+// (The library does not touch the process environment.  A host that keeps several launches in flight beside an exchange
+// wants GPU_MAX_HW_QUEUES=8 — the HIP runtime multiplexes a process's streams onto 4 hardware queues otherwise and reads the
+// setting at the process's first HIP call: the juliet front end and bench.py set it before that call, INTEGRATION.md says so.)
 
 int jl_fail(jl_ctx *ctx, int status, const char *fmt, ...)
 {
@@ -118,7 +116,6 @@ int jl_ctx_create(int device, void *stream, jl_ctx **out)
               hipMalloc(&ctx->d_cooc, sizeof(uint32_t) * ctx->cooc_cap * ctx->cooc_cap) == hipSuccess &&
               hipMalloc(&ctx->d_pack, 2 * sizeof(jl_pack)) == hipSuccess &&
               hipMalloc(&ctx->d_sync, 16 * sizeof(uint32_t)) == hipSuccess &&
-              hipMalloc(&ctx->d_callinfo, sizeof(jl_callinfo)) == hipSuccess &&
               hipHostMalloc(&ctx->h_pack, sizeof(jl_pack), hipHostMallocDefault) == hipSuccess &&
               hipHostMalloc((void **)&ctx->h_seq, 64, hipHostMallocDefault) == hipSuccess &&
               hipHostMalloc(&ctx->h_scratch, (size_t)1 << 20, hipHostMallocDefault) == hipSuccess;
@@ -132,34 +129,8 @@ int jl_ctx_create(int device, void *stream, jl_ctx **out)
     return JL_OK;
 }
 
-// The library has just written the matrix (on ctx->stream): make the counting kernel's bit planes from it, on the same
-// stream.  No room for them (they take three quarters of the matrix again): the context counts from the nibbles.
-static void planes_refresh(jl_ctx *ctx)
-{
-    ctx->planes_valid = false;
-    if (!ctx->d_msa || !ctx->own_msa || (ctx->col_stride & 127u) || !ctx->n_cols) return;
-    const uint64_t ps = ctx->col_stride / 4u;
-    const size_t need = (size_t)ps * 3u * ctx->n_cols;
-    if (ctx->planes_capacity < need) {
-        if (ctx->d_planes) hipFree(ctx->d_planes);
-        ctx->d_planes = nullptr;
-        ctx->planes_capacity = 0;
-        ctx->alloc_version++;
-        if (hipMalloc(&ctx->d_planes, need) != hipSuccess) {
-            (void)hipGetLastError();
-            return;
-        }
-        ctx->planes_capacity = need;
-    }
-    if (ctx->plane_stride != ps) ctx->alloc_version++;   // (captured launches carry the stride)
-    ctx->plane_stride = ps;
-    jl_launch_planes(ctx, ctx->stream);
-    ctx->planes_valid = hipGetLastError() == hipSuccess;
-}
-
 static void free_msa(jl_ctx *ctx)
 {
-    ctx->planes_valid = false;
     ctx->alloc_version++;
     if (ctx->own_msa && ctx->d_msa) hipFree(ctx->d_msa);
     ctx->d_msa = nullptr;
@@ -189,9 +160,8 @@ void jl_ctx_destroy(jl_ctx *ctx)
                     ctx->d_col2pos, ctx->d_varcol, ctx->d_keys, ctx->d_flagw, ctx->d_read_slot, ctx->d_read_hap,
                     ctx->d_slot_rep, ctx->d_slot_count, ctx->d_slot_key, ctx->d_slot_hap, ctx->d_occupied, ctx->d_hap_count,
                     ctx->d_hap_pattern, ctx->d_hit, ctx->d_cooc, ctx->d_pack, ctx->d_sync, ctx->d_timeline,
-                    ctx->d_col_first, ctx->d_pos_next, ctx->d_callinfo, ctx->d_ins_len, ctx->d_ins_base, ctx->d_exp_count,
-                    ctx->d_exp_pattern, ctx->d_exp_hap, ctx->d_blockcat, ctx->d_slot_key_a, ctx->d_slot_key_b, ctx->d_occ_a, ctx->d_occ_b,
-                    ctx->d_planes};
+                    ctx->d_ins_len, ctx->d_ins_base, ctx->d_exp_count,
+                    ctx->d_exp_pattern, ctx->d_exp_hap, ctx->d_blockcat, ctx->d_slot_key_a, ctx->d_slot_key_b, ctx->d_occ_a, ctx->d_occ_b};
     for (void *p : ptrs)
         if (p) hipFree(p);
     if (ctx->ev0) hipEventDestroy(ctx->ev0);
@@ -213,24 +183,25 @@ int jl_sync(jl_ctx *ctx)
 /* ---------------------------------------------------------------- MSA residency */
 
 uint64_t jl_col_stride(uint64_t n_reads) { return ((n_reads + 1) / 2 + 127) / 128 * 128; }
+uint64_t jl_plane_stride(uint64_t n_reads) { return (n_reads + 1023) / 1024 * 128; }
 
-static int set_shape(jl_ctx *ctx, uint64_t n_reads, uint32_t n_cols, uint64_t col_stride, uint32_t win_begin)
+static int set_shape(jl_ctx *ctx, uint64_t n_reads, uint32_t n_cols, uint64_t plane_stride, uint32_t win_begin)
 {
     if (n_reads == 0 || n_cols == 0) return jl_fail(ctx, JL_ERR_ARG, "empty matrix (%llu reads x %u columns)", (unsigned long long)n_reads, n_cols);
     if (n_reads > 0x7FFFFFFFull) return jl_fail(ctx, JL_ERR_ARG, "more than 2^31-1 reads per context");
-    if (col_stride % 128 != 0 || col_stride < (n_reads + 1) / 2)
-        return jl_fail(ctx, JL_ERR_ARG, "col_stride %llu must be a multiple of 128 and >= ceil(n_reads/2)", (unsigned long long)col_stride);
-    if (n_reads != ctx->n_reads || n_cols != ctx->n_cols || col_stride != ctx->col_stride || win_begin != ctx->win_begin)
+    if (plane_stride % 16 != 0 || plane_stride < (n_reads + 7) / 8)
+        return jl_fail(ctx, JL_ERR_ARG, "plane_stride %llu must be a multiple of 16 and >= ceil(n_reads/8)", (unsigned long long)plane_stride);
+    if (n_reads != ctx->n_reads || n_cols != ctx->n_cols || plane_stride != ctx->plane_stride || win_begin != ctx->win_begin)
         ctx->plan_valid = false;
     ctx->n_reads = n_reads;
     ctx->n_cols = n_cols;
-    ctx->col_stride = col_stride;
+    ctx->plane_stride = plane_stride;
+    ctx->col_stride = plane_stride * 4u;   // the same stride in 8-reads-per-dword units (jl_internal.h)
     ctx->win_begin = win_begin;
     ctx->alloc_version++;
     ctx->pack_valid = false;
     ctx->pileup_done = ctx->call_done = ctx->phase_done = false;
     ctx->ins_valid = false;
-    ctx->planes_valid = false;   // whoever writes the matrix next makes them again
     return JL_OK;
 }
 
@@ -246,56 +217,64 @@ static int reserve_msa(jl_ctx *ctx, size_t bytes)
 
 int jl_msa_alloc(jl_ctx *ctx, uint64_t n_reads, uint32_t n_cols, uint32_t win_begin)
 {
-    return jl_msa_alloc_strided(ctx, n_reads, n_cols, jl_col_stride(n_reads), win_begin);
+    return jl_msa_alloc_strided(ctx, n_reads, n_cols, jl_plane_stride(n_reads), win_begin);
 }
 }  // extern "C"
 
-// internal: a resident matrix with the caller's column stride (cross-window phasing keeps the stride of the windows
+// internal: a resident matrix with the caller's plane stride (cross-window phasing keeps the stride of the windows
 // whose columns it copies)
-int jl_msa_alloc_strided(jl_ctx *ctx, uint64_t n_reads, uint32_t n_cols, uint64_t col_stride, uint32_t win_begin)
+int jl_msa_alloc_strided(jl_ctx *ctx, uint64_t n_reads, uint32_t n_cols, uint64_t plane_stride, uint32_t win_begin)
 {
     if (!ctx) return JL_ERR_ARG;
     JL_HIP(ctx, hipSetDevice(ctx->device));
-    int rc = set_shape(ctx, n_reads, n_cols, col_stride, win_begin);
+    int rc = set_shape(ctx, n_reads, n_cols, plane_stride, win_begin);
     if (rc) return rc;
-    return reserve_msa(ctx, (size_t)ctx->col_stride * n_cols);
+    return reserve_msa(ctx, (size_t)ctx->plane_stride * 3u * n_cols);
 }
 
 extern "C" {
 
+// The interchange format (column-packed nibbles) goes through a bounded staging buffer: a run of columns is copied to the
+// device and ONE kernel validates its codes (0..6, SPEC §1) and writes its planes — no resident copy of the nibbles.
 int jl_msa_upload(jl_ctx *ctx, const uint8_t *colpacked, uint64_t n_reads, uint32_t n_cols, uint64_t col_stride,
                   uint32_t win_begin)
 {
     if (!ctx || !colpacked) return JL_ERR_ARG;
-    JL_HIP(ctx, hipSetDevice(ctx->device));
-    int rc = set_shape(ctx, n_reads, n_cols, col_stride, win_begin);
+    if (col_stride % 128 != 0 || col_stride < (n_reads + 1) / 2)
+        return jl_fail(ctx, JL_ERR_ARG, "col_stride %llu must be a multiple of 128 and >= ceil(n_reads/2)", (unsigned long long)col_stride);
+    int rc = jl_msa_alloc(ctx, n_reads, n_cols, win_begin);
     if (rc) return rc;
-    rc = reserve_msa(ctx, (size_t)col_stride * n_cols);
-    if (rc) return rc;
-    JL_HIP(ctx, hipMemcpyAsync(ctx->d_msa, colpacked, (size_t)col_stride * n_cols, hipMemcpyHostToDevice, ctx->stream));
-    // symbol codes are 0..6 (SPEC §1); anything else would corrupt the linear solve of the pileup counters
-    uint32_t bad[2] = {0, 0};
-    JL_HIP(ctx, hipMemsetAsync(ctx->d_nvar + 1, 0, 4, ctx->stream));
-    jl_launch_validate(ctx, ctx->d_nvar + 1);
-    JL_HIP(ctx, hipMemcpyAsync(bad, ctx->d_nvar + 1, 4, hipMemcpyDeviceToHost, ctx->stream));
-    JL_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (bad[0]) {
+    const uint32_t per = (uint32_t)std::min<uint64_t>(n_cols, std::max<uint64_t>(1, ((uint64_t)64 << 20) / col_stride));
+    uint8_t *d_stage = nullptr;
+    JL_HIP(ctx, hipMalloc(&d_stage, (size_t)per * col_stride));
+    uint32_t bad = 0;
+    hipError_t e = hipMemsetAsync(ctx->d_nvar + 1, 0, 4, ctx->stream);
+    for (uint32_t c0 = 0; c0 < n_cols && e == hipSuccess; c0 += per) {
+        const uint32_t n = std::min(per, n_cols - c0);
+        e = hipMemcpyAsync(d_stage, colpacked + (size_t)c0 * col_stride, (size_t)n * col_stride, hipMemcpyHostToDevice, ctx->stream);
+        if (e != hipSuccess) break;
+        jl_launch_nibbles_to_planes(ctx, d_stage, col_stride, c0, n, ctx->d_nvar + 1);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(&bad, ctx->d_nvar + 1, 4, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    hipFree(d_stage);
+    if (e != hipSuccess) { free_msa(ctx); return jl_fail(ctx, JL_ERR_DEVICE, "upload: %s", hipGetErrorString(e)); }
+    if (bad) {
         free_msa(ctx);
         return jl_fail(ctx, JL_ERR_ARG, "matrix holds a symbol code outside 0..6");
     }
-    planes_refresh(ctx);
     return JL_OK;
 }
 
-int jl_msa_adopt(jl_ctx *ctx, void *d_colpacked, uint64_t n_reads, uint32_t n_cols, uint64_t col_stride,
-                 uint32_t win_begin)
+int jl_msa_adopt(jl_ctx *ctx, void *d_planes, uint64_t n_reads, uint32_t n_cols, uint64_t plane_stride, uint32_t win_begin)
 {
-    if (!ctx || !d_colpacked) return JL_ERR_ARG;
-    if (((uintptr_t)d_colpacked & 15u) != 0) return jl_fail(ctx, JL_ERR_ARG, "adopted matrix must be 16-byte aligned");
-    int rc = set_shape(ctx, n_reads, n_cols, col_stride, win_begin);
+    if (!ctx || !d_planes) return JL_ERR_ARG;
+    if (((uintptr_t)d_planes & 15u) != 0) return jl_fail(ctx, JL_ERR_ARG, "adopted matrix must be 16-byte aligned");
+    int rc = set_shape(ctx, n_reads, n_cols, plane_stride, win_begin);
     if (rc) return rc;
     free_msa(ctx);
-    ctx->d_msa = (uint8_t *)d_colpacked;
+    ctx->d_msa = (uint8_t *)d_planes;
     return JL_OK;
 }
 
@@ -313,7 +292,6 @@ int jl_msa_pack_rows(jl_ctx *ctx, const uint8_t *rows, uint64_t n_reads, uint32_
     }
     hipFree(d_rows);
     if (e != hipSuccess) return jl_fail(ctx, JL_ERR_DEVICE, "pack_rows: %s", hipGetErrorString(e));
-    planes_refresh(ctx);
     return JL_OK;
 }
 
@@ -498,7 +476,6 @@ static int records_build(jl_ctx *src, jl_ctx *dst, uint32_t n_cols, uint32_t win
     }
     if (d_rows4) hipFree(d_rows4);
     if (e != hipSuccess) return jl_fail(dst, e == hipErrorOutOfMemory ? JL_ERR_MEMORY : JL_ERR_DEVICE, "ingest: %s", hipGetErrorString(e));
-    planes_refresh(dst);
     return JL_OK;
 }
 
@@ -561,12 +538,29 @@ int jl_insertions_fetch(jl_ctx *ctx, uint32_t *len_hist, uint32_t *base_counts)
     return JL_OK;
 }
 
+// The resident planes back in the interchange format (column stride jl_col_stride(n_reads)), through the same bounded staging.
 int jl_msa_download(jl_ctx *ctx, uint8_t *colpacked, uint64_t bytes)
 {
     if (!ctx || !colpacked || !ctx->d_msa) return JL_ERR_ARG;
-    if (bytes > (uint64_t)ctx->col_stride * ctx->n_cols) return jl_fail(ctx, JL_ERR_ARG, "download larger than the matrix");
-    JL_HIP(ctx, hipMemcpyAsync(colpacked, ctx->d_msa, bytes, hipMemcpyDeviceToHost, ctx->stream));
-    JL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const uint64_t stride = jl_col_stride(ctx->n_reads);
+    if (bytes > stride * ctx->n_cols) return jl_fail(ctx, JL_ERR_ARG, "download larger than the matrix");
+    JL_HIP(ctx, hipSetDevice(ctx->device));
+    const uint32_t n_cols = (uint32_t)((bytes + stride - 1) / stride);
+    if (!n_cols) return JL_OK;
+    const uint32_t per = (uint32_t)std::min<uint64_t>(n_cols, std::max<uint64_t>(1, ((uint64_t)64 << 20) / stride));
+    uint8_t *d_stage = nullptr;
+    JL_HIP(ctx, hipMalloc(&d_stage, (size_t)per * stride));
+    hipError_t e = hipSuccess;
+    for (uint32_t c0 = 0; c0 < n_cols && e == hipSuccess; c0 += per) {
+        const uint32_t n = std::min(per, n_cols - c0);
+        jl_launch_planes_to_nibbles(ctx, d_stage, stride, c0, n);
+        e = hipGetLastError();
+        const uint64_t lo = (uint64_t)c0 * stride, hi = std::min<uint64_t>(bytes, lo + (uint64_t)n * stride);
+        if (e == hipSuccess) e = hipMemcpyAsync(colpacked + lo, d_stage, (size_t)(hi - lo), hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    }
+    hipFree(d_stage);
+    if (e != hipSuccess) return jl_fail(ctx, JL_ERR_DEVICE, "download: %s", hipGetErrorString(e));
     return JL_OK;
 }
 
@@ -587,7 +581,6 @@ static int synth_fill(jl_ctx *ctx, const jl_synth_params *sp, const uint8_t *ref
     if (e != hipSuccess) return jl_fail(ctx, JL_ERR_DEVICE, "synth_fill: %s", hipGetErrorString(e));
     ctx->pileup_done = ctx->call_done = ctx->phase_done = false;
     ctx->pack_valid = false;
-    planes_refresh(ctx);
     return JL_OK;
 }
 
@@ -613,7 +606,6 @@ static int reserve_columns(jl_ctx *ctx)
 {
     int rc;
     if (ctx->col_capacity < ctx->n_cols) {
-        if ((rc = regrow(ctx, &ctx->d_col_first, ctx->n_cols))) return rc;
         if ((rc = regrow(ctx, &ctx->d_guess, (size_t)ctx->n_cols + JL_GUESS_PAD))) return rc;
         if ((rc = regrow(ctx, &ctx->d_col2pos, ctx->n_cols))) return rc;
         if ((rc = regrow(ctx, &ctx->d_varcol, ctx->n_cols))) return rc;
@@ -648,7 +640,7 @@ static void build_chunks(jl_ctx *ctx, const std::vector<uint8_t> &colflag, std::
     if (const char *env_w = getenv("JL_PILEUP_W"))
         if (*env_w) W = (uint32_t)atoi(env_w) % 100u;
 #endif
-    if (W != 3 && W != 6 && W != 9 && W != 12) W = 3;
+    if (W != 3 && W != 6) W = 3;   // the kernels exist for these two widths
     (void)major;
     ctx->pileup_w = W;
     c0s.clear();
@@ -728,7 +720,6 @@ static int build_plan(jl_ctx *ctx, const jl_gene *genes, uint32_t n_genes, const
         if ((rc = regrow(ctx, &ctx->d_called, P))) return rc;
         if ((rc = regrow(ctx, &ctx->d_staged, P * 64))) return rc;
         if ((rc = regrow(ctx, &ctx->d_drm, P))) return rc;
-        if ((rc = regrow(ctx, &ctx->d_pos_next, P))) return rc;
         ctx->pos_capacity = P;
     }
     ctx->n_chunks = (uint32_t)chunk_c0.size();
@@ -747,17 +738,7 @@ static int build_plan(jl_ctx *ctx, const jl_gene *genes, uint32_t n_genes, const
         const uint32_t meta = n | (startf << 4) | (halo << 16);
         recs[k] = (uint64_t)c0 | ((uint64_t)meta << 32);
     }
-    // positions by start column: the workgroup that counts a codon evaluates every position that starts there
-    // (several when genes overlap in one frame), in position order
-    std::vector<uint32_t> col_first(ctx->n_cols, 0xFFFFFFFFu), pos_next(P, 0xFFFFFFFFu);
-    for (uint32_t q = ctx->P; q-- > 0;) {
-        const uint32_t c = ctx->h_pos_col[q];
-        pos_next[q] = col_first[c];
-        col_first[c] = q;
-    }
     hipStream_t st = ctx->stream;
-    JL_HIP(ctx, hipMemcpyAsync(ctx->d_col_first, col_first.data(), (size_t)ctx->n_cols * 4, hipMemcpyHostToDevice, st));
-    JL_HIP(ctx, hipMemcpyAsync(ctx->d_pos_next, pos_next.data(), P * 4, hipMemcpyHostToDevice, st));
     JL_HIP(ctx, hipMemcpyAsync(ctx->d_chunks, recs.data(), recs.size() * 8, hipMemcpyHostToDevice, st));
     // the pad behind the last column is zero; in majority mode guess_kernel overwrites [0, n_cols) only
     JL_HIP(ctx, hipMemcpyAsync(ctx->d_guess, guess.data(), guess.size(), hipMemcpyHostToDevice, st));
@@ -771,28 +752,6 @@ static int build_plan(jl_ctx *ctx, const jl_gene *genes, uint32_t n_genes, const
     JL_HIP(ctx, hipStreamSynchronize(st));
     ctx->plan_valid = true;
     ctx->plan_version++;
-    ctx->callinfo_host.clear();
-    return JL_OK;
-}
-
-// The Fisher stage inside the pileup launch reads its parameters and tables from ctx->d_callinfo: refresh it when
-// anything in it changed (it is part of what a captured graph replays, so the copy is ordered before the launch).
-int jl_update_callinfo(jl_ctx *ctx, const jl_params *prm, double n_tests, bool use_drm, bool with_meta)
-{
-    jl_callinfo ci;
-    memset(&ci, 0, sizeof ci);
-    jl_fill_call_args(ctx, prm, n_tests, &ci.A);
-    ci.col_first = ctx->d_col_first; ci.pos_next = ctx->d_pos_next;
-    ci.pos_gene = ctx->d_pos_gene; ci.pos_codon = ctx->d_pos_codon; ci.pos_refcfg = ctx->d_pos_refcfg;
-    ci.drm = use_drm ? ctx->d_drm : nullptr;
-    ci.called = ctx->d_called; ci.staged = ctx->d_staged;
-    ci.meta = with_meta ? ctx->d_meta : nullptr;
-    if (ctx->callinfo_host.size() == sizeof ci && memcmp(ctx->callinfo_host.data(), &ci, sizeof ci) == 0) return JL_OK;
-    // the previous run of this context may still read the block: wait for it (a change of parameters, not the hot path)
-    JL_HIP(ctx, hipStreamSynchronize(ctx->run_stream ? ctx->run_stream : ctx->stream));
-    JL_HIP(ctx, hipMemcpyAsync(ctx->d_callinfo, &ci, sizeof ci, hipMemcpyHostToDevice, ctx->stream));
-    JL_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    ctx->callinfo_host.assign((const uint8_t *)&ci, (const uint8_t *)&ci + sizeof ci);
     return JL_OK;
 }
 
@@ -817,7 +776,7 @@ int jl_pileup_async(jl_ctx *ctx, const jl_gene *genes, uint32_t n_genes, const u
     if (jl_pileup_needs_zero(ctx))
         JL_HIP(ctx, hipMemsetAsync(ctx->d_counts, 0, ctx->counts_words * sizeof(uint32_t), ctx->stream));
     if (!ctx->have_ref) jl_launch_guess(ctx, ctx->stream);
-    jl_launch_pileup(ctx, ctx->stream, false);
+    jl_launch_pileup(ctx, ctx->stream);
     JL_HIP(ctx, hipGetLastError());
     ctx->pileup_done = true;
     ctx->call_done = ctx->phase_done = false;
@@ -1365,9 +1324,8 @@ static void enqueue_path(jl_ctx *ctx, const jl_params *prm, double n_tests, bool
     if (jl_pileup_needs_zero(ctx)) hipMemsetAsync(ctx->d_counts, 0, ctx->counts_words * sizeof(uint32_t), st);
     if (!ctx->have_ref) jl_launch_guess(ctx, st);
     jl_launch_stamp(ctx, 0);
-    const bool fused_call = jl_pileup_can_call(ctx);
-    jl_launch_pileup(ctx, st, fused_call);
-    if (!fused_call) jl_launch_call(ctx, st, prm, n_tests, use_drm, phasing);
+    jl_launch_pileup(ctx, st);
+    jl_launch_call(ctx, st, prm, n_tests, use_drm, phasing);
     jl_launch_stamp(ctx, 1);
     // The completion word (jl_run_wait) is stored by a one-thread node of its own behind the last stage: the end of
     // that stage's kernel is what pushes the results every compute die wrote for the host out of the dies' L2s.
@@ -1434,7 +1392,6 @@ int jl_run_prepare(jl_ctx *ctx, const jl_gene *genes, uint32_t n_genes, const ui
     *n_tests_out = prm->n_tests > 0.0 ? prm->n_tests : ctx->default_n_tests;
     ctx->last_min_reads = min_reads;
     jl_prepare_pileup(ctx);
-    if ((rc = jl_update_callinfo(ctx, prm, *n_tests_out, drm_masks != nullptr, phasing != 0))) return rc;
     ctx->pack_mirror = ctx->h_pack;
     ctx->read_hap_out = (phasing && want_read_hap) ? ctx->h_read_hap : nullptr;
     return JL_OK;
@@ -1677,7 +1634,7 @@ int jl_time_pileup(jl_ctx *ctx, uint32_t reps, float *ms_avg)
         // events' own latency (~3 us around a single launch) is not charged to the kernel; the figure includes the
         // gaps between consecutive launches and agrees with rocprofv3's per-dispatch average to ~1 us
         JL_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-        for (uint32_t r = 0; r < reps; ++r) jl_launch_pileup(ctx, ctx->stream, false);
+        for (uint32_t r = 0; r < reps; ++r) jl_launch_pileup(ctx, ctx->stream);
         JL_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
         JL_HIP(ctx, hipEventSynchronize(ctx->ev1));
         JL_HIP(ctx, hipEventElapsedTime(&total, ctx->ev0, ctx->ev1));
@@ -1686,7 +1643,7 @@ int jl_time_pileup(jl_ctx *ctx, uint32_t reps, float *ms_avg)
             // the counters are cleared outside the timed interval; only the kernel sits between the events
             JL_HIP(ctx, hipMemsetAsync(ctx->d_counts, 0, ctx->counts_words * sizeof(uint32_t), ctx->stream));
             JL_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-            jl_launch_pileup(ctx, ctx->stream, false);
+            jl_launch_pileup(ctx, ctx->stream);
             JL_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
             JL_HIP(ctx, hipEventSynchronize(ctx->ev1));
             float ms = 0.f;
@@ -1714,12 +1671,9 @@ int jl_time_pileup_set(jl_ctx *const *ctxs, uint32_t n_ctx, uint32_t reps, float
     }
     JL_HIP(c0, hipSetDevice(c0->device));
     for (uint32_t k = 0; k < n_ctx; ++k) JL_HIP(c0, hipStreamSynchronize(ctxs[k]->stream));
-    // the variant the runs use: with the Fisher stage in its epilogue once a run has set the call parameters up
-    bool with_call = true;
-    for (uint32_t k = 0; k < n_ctx; ++k) with_call = with_call && !ctxs[k]->callinfo_host.empty() && jl_pileup_can_call(ctxs[k]);
-    for (uint32_t k = 0; k < n_ctx; ++k) jl_launch_pileup(ctxs[k], c0->stream, with_call);   // warm-up, one per window
+    for (uint32_t k = 0; k < n_ctx; ++k) jl_launch_pileup(ctxs[k], c0->stream);   // warm-up, one per window
     JL_HIP(c0, hipEventRecord(c0->ev0, c0->stream));
-    for (uint32_t r = 0; r < reps; ++r) jl_launch_pileup(ctxs[r % n_ctx], c0->stream, with_call);
+    for (uint32_t r = 0; r < reps; ++r) jl_launch_pileup(ctxs[r % n_ctx], c0->stream);
     JL_HIP(c0, hipEventRecord(c0->ev1, c0->stream));
     JL_HIP(c0, hipEventSynchronize(c0->ev1));
     float total = 0.f;

@@ -4,7 +4,8 @@
 // reaches 0.61 of the HBM peak, a 1.2 GB stream 0.77), and its phasing stage is a chain of dependent memory round
 // trips that keeps a hardware queue busy for tens of microseconds while doing almost nothing.  A group run gives each
 // stage ONE launch for up to JL_GROUP_MAX windows (blockIdx.z = window, per-window argument blocks by value):
-//   counting + Fisher   pileup_group_kernel with the Fisher stage in its epilogue
+//   counting            pileup_planes_group_kernel (up to JL_GROUP_WINDOWS_MAX windows)
+//   Fisher              call_group_kernel
 //   phasing             phase_group_run_kernel (plan out of the call masks, keys, grouping, selection, result block)
 //   per-read ids        phase_assign_group_kernel (small groups fold them into the phasing launch)
 //   completion words    done_group_kernel
@@ -38,7 +39,7 @@ struct jl_group {
     std::vector<jl_win_call> h_call;
     std::vector<jl_win_compact> h_compact;
     std::vector<jl_win_phase> h_phase;
-    struct chunk_t { uint32_t first, n, max_chunks, max_call_blocks, max_phase_blocks; bool fold, fused_call; };
+    struct chunk_t { uint32_t first, n, max_chunks, max_call_blocks, max_phase_blocks; bool fold; };
     std::vector<chunk_t> chunks;
     bool phasing = true;
     hipGraph_t graph = nullptr;
@@ -56,7 +57,7 @@ static int group_fail(jl_group *g, int status, const char *msg)
 // the latency-bound stages of one chunk, on `st`
 static void chunk_tail(jl_group *g, const jl_group::chunk_t &c, hipStream_t st)
 {
-    if (!c.fused_call) jl_launch_call_group(g->h_call.data() + c.first, c.n, c.max_call_blocks, st);
+    jl_launch_call_group(g->h_call.data() + c.first, c.n, c.max_call_blocks, st);
     if (!g->phasing) {
         jl_launch_compact_group(g->h_compact.data() + c.first, c.n, st);
     } else {
@@ -79,8 +80,7 @@ static int group_enqueue(jl_group *g)
     bool side_used[JL_GROUP_SIDE_STREAMS] = {false, false};
     for (size_t k = 0; k < nc; ++k) {
         const jl_group::chunk_t &c = g->chunks[k];
-        int rc = jl_launch_pileup_group(g->ctxs.data() + c.first, c.n, g->h_pile.data() + c.first, c.max_chunks, g->stream,
-                                        c.fused_call);
+        int rc = jl_launch_pileup_group(g->ctxs.data() + c.first, c.n, g->h_pile.data() + c.first, c.max_chunks, g->stream);
         if (rc) return rc;
         if (k + 1 < nc) {   // the tail runs beside the next chunk's pileup
             hipStream_t st = g->side[k % JL_GROUP_SIDE_STREAMS];
@@ -232,11 +232,7 @@ int jl_group_run_masked_async(jl_group *g, const jl_gene *genes, uint32_t n_gene
             // are resident at once — also while more such launches run: at most JL_FOLD_MAX_BLOCKS per launch against
             // 1536 places (six 75-register blocks per CU).  Larger chunks take a separate launch for the ids.
             uint32_t total_blocks = 0;
-            c.fused_call = true;
-            for (uint32_t k = o; k < o + c.n; ++k) {
-                total_blocks += (uint32_t)((g->ctxs[k]->col_stride / 4u + 255u) / 256u) + 1u;
-                c.fused_call = c.fused_call && jl_pileup_can_call(g->ctxs[k]);
-            }
+            for (uint32_t k = o; k < o + c.n; ++k) total_blocks += (uint32_t)((g->ctxs[k]->col_stride / 4u + 255u) / 256u) + 1u;
             c.fold = total_blocks <= JL_FOLD_MAX_BLOCKS;
             for (uint32_t k = o; k < o + c.n; ++k) {
                 jl_ctx *x = g->ctxs[k];
@@ -304,7 +300,7 @@ int jl_group_time_pileup(jl_group *const *groups, uint32_t n_groups, uint32_t re
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return group_fail(g0, JL_ERR_DEVICE, "events");
     auto launch = [&](jl_group *g) {
         const jl_group::chunk_t &c = g->chunks[0];
-        return jl_launch_pileup_group(g->ctxs.data() + c.first, c.n, g->h_pile.data() + c.first, c.max_chunks, g0->stream, c.fused_call);
+        return jl_launch_pileup_group(g->ctxs.data() + c.first, c.n, g->h_pile.data() + c.first, c.max_chunks, g0->stream);
     };
     int rc = JL_OK;
     for (uint32_t k = 0; k < n_groups && rc == JL_OK; ++k) rc = launch(groups[k]);   // warm-up, once per group
@@ -320,7 +316,7 @@ int jl_group_time_pileup(jl_group *const *groups, uint32_t n_groups, uint32_t re
     if (bytes_per_launch) {
         uint64_t b = 0;
         const jl_group::chunk_t &c = g0->chunks[0];
-        for (uint32_t k = c.first; k < c.first + c.n; ++k) b += (uint64_t)g0->ctxs[k]->n_reads * g0->ctxs[k]->n_cols / 2u;
+        for (uint32_t k = c.first; k < c.first + c.n; ++k) b += (uint64_t)g0->ctxs[k]->n_reads * g0->ctxs[k]->n_cols * 3u / 8u;   // 3 bits per cell
         *bytes_per_launch = b;
     }
     for (uint32_t k = 0; k < n_groups; ++k)

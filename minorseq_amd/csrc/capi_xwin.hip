@@ -45,21 +45,21 @@ int xw_fail(jl_ctx *pc, std::string *err, int status, const std::string &msg)
     return status;
 }
 
-// Pack launches for this rank's owned positions: destination s gets slice s of the 3 * k_count owned columns, laid out
-// as columns of stride dst_stride[s] (the own slice: straight into the compact matrix).  `plan`: non-null for the first
+// Pack launches for this rank's owned positions: destination s gets slice s of the 9 * k_count plane rows of the owned
+// columns, laid out as rows of stride dst_stride[s] (the own slice: straight into the compact matrix).  `plan`: non-null for the first
 // launch of a step, which then also writes the compact matrix's phasing plan.
 int xw_pack(jl_ctx *pc, jl_ctx *const *wins, const xw_layout &lay, const xwin_schedule &sch, const uint64_t *slice_begin, int world,
             int rank, const uint64_t *dst_stride_override, xw_send_buf *send, const jl_xw_pack_args *plan, std::string *err)
 {
     const uint32_t k0 = sch.k_begin[(size_t)rank], kn = sch.k_count[(size_t)rank];
-    const uint64_t src_stride = wins ? wins[0]->col_stride : 0;
-    struct dst_t { uint8_t *dst; uint64_t stride, byte_begin, bytes; };
+    const uint64_t src_stride = wins ? wins[0]->plane_stride : 0;
+    struct dst_t { uint8_t *dst; uint64_t stride, byte_begin, bytes; uint32_t tail_mask; };
     std::vector<dst_t> dsts;
     if (kn) {
         size_t need = 0;
         for (int s = 0; s < world; ++s) {
             const uint64_t n_s = slice_begin[s + 1] - slice_begin[s];
-            if (s != rank && n_s) need += (size_t)3 * kn * xwin_stride(n_s);
+            if (s != rank && n_s) need += (size_t)9 * kn * xwin_stride(n_s);
         }
         if (need > send->cap) {
             if (send->d) hipFree(send->d);
@@ -74,10 +74,11 @@ int xw_pack(jl_ctx *pc, jl_ctx *const *wins, const xw_layout &lay, const xwin_sc
             if (!n_s) continue;
             dst_t d;
             d.stride = (s == rank && dst_stride_override) ? *dst_stride_override : xwin_stride(n_s);
-            d.byte_begin = slice_begin[s] / 2u;
-            d.bytes = (n_s + 1u) / 2u;
-            if (s == rank) d.dst = pc->d_msa + (uint64_t)3 * k0 * d.stride;
-            else { d.dst = send->d + off; off += (size_t)3 * kn * d.stride; }
+            d.byte_begin = slice_begin[s] / 8u;
+            d.bytes = (n_s + 7u) / 8u;
+            d.tail_mask = (n_s & 7u) ? (1u << (n_s & 7u)) - 1u : 0xFFu;
+            if (s == rank) d.dst = pc->d_msa + (uint64_t)9 * k0 * d.stride;
+            else { d.dst = send->d + off; off += (size_t)9 * kn * d.stride; }
             dsts.push_back(d);
         }
     }
@@ -92,17 +93,18 @@ int xw_pack(jl_ctx *pc, jl_ctx *const *wins, const xw_layout &lay, const xwin_sc
                 const uint32_t k = k0 + p0 + p;
                 const uint32_t w = (uint32_t)sch.owner_win[k];
                 const jl_ctx *wc = wins[w - lay.first_local];
-                a.src[p] = wc->d_msa + (uint64_t)(sch.pos[k] - lay.win_begin[w]) * src_stride;
+                a.src[p] = wc->d_msa + (uint64_t)(sch.pos[k] - lay.win_begin[w]) * 3u * src_stride;
             }
             a.src_stride = src_stride;
             a.n_pos = np;
             a.n_dst = (uint32_t)std::min<size_t>(JL_XW_DST_MAX, dsts.size() - d0);
             for (uint32_t j = 0; j < a.n_dst; ++j) {
                 const dst_t &d = dsts[d0 + j];
-                a.d[j].dst = d.dst + (uint64_t)3 * p0 * d.stride;
+                a.d[j].dst = d.dst + (uint64_t)9 * p0 * d.stride;
                 a.d[j].dst_stride = d.stride;
                 a.d[j].byte_begin = d.byte_begin;
                 a.d[j].bytes = d.bytes;
+                a.d[j].tail_mask = d.tail_mask;
             }
             jl_launch_xw_pack(&a, pc->stream);
         }
@@ -194,7 +196,7 @@ int jl_xwin_assemble_local(jl_ctx *pc, jl_ctx *const *windows, uint32_t n_window
     if (pos_global) std::copy(sch.pos.begin(), sch.pos.end(), pos_global);
     if (vp == 0) return JL_OK;
     JL_HIP(pc, hipSetDevice(pc->device));
-    const uint64_t stride = windows[0]->col_stride;   // the windows' stride, whatever it is
+    const uint64_t stride = windows[0]->plane_stride;   // the windows' plane stride, whatever it is
     rc = jl_msa_alloc_strided(pc, n_reads, 3u * vp, stride, 0);
     if (rc) return rc;
     for (uint32_t w = 0; w < n_windows; ++w) JL_HIP(pc, hipStreamSynchronize(windows[w]->stream));
@@ -234,7 +236,7 @@ int jl_xwin_assemble_rccl(jl_ctx *pc, jl_ctx *window, jl_comm *c, const uint32_t
     if (pos_global) std::copy(sch.pos.begin(), sch.pos.end(), pos_global);
     if (vp == 0) return JL_OK;
     JL_HIP(pc, hipSetDevice(pc->device));
-    const uint64_t stride = window->col_stride;   // every rank's window must use the same stride (same reads)
+    const uint64_t stride = window->plane_stride;   // every rank's window must use the same stride (same reads)
     rc = jl_msa_alloc_strided(pc, n_reads, 3u * vp, stride, 0);
     if (rc) return rc;
     JL_HIP(pc, hipStreamSynchronize(window->stream));
@@ -247,7 +249,7 @@ int jl_xwin_assemble_rccl(jl_ctx *pc, jl_ctx *window, jl_comm *c, const uint32_t
     std::vector<jl_tp_bcast> bc;
     for (int o = 0; o < world; ++o) {
         if (!sch.k_count[(size_t)o]) continue;
-        bc.push_back({pc->d_msa + (uint64_t)3 * sch.k_begin[(size_t)o] * stride, (size_t)3 * sch.k_count[(size_t)o] * stride, o});
+        bc.push_back({pc->d_msa + (uint64_t)9 * sch.k_begin[(size_t)o] * stride, (size_t)9 * sch.k_count[(size_t)o] * stride, o});
     }
     const int brc = jl_tp_broadcasts(c, bc.data(), bc.size(), pc->stream);
     jl_comm_direct_end(c);
@@ -687,11 +689,11 @@ int jl_xwin_phase_sharded(jl_xwin *x, uint32_t min_reads, jl_xwin_result *out)
         if (direct) {
             jl_direct_cols &d = pc->direct;
             memset(&d, 0, sizeof d);
-            const uint64_t src_stride = x->wins[0]->col_stride;
+            const uint64_t src_stride = x->wins[0]->plane_stride;
             for (uint32_t k = 0; k < vp; ++k) {
                 const uint32_t w = (uint32_t)x->sch.owner_win[k];
-                d.col[k] = x->wins[w - x->lay.first_local]->d_msa + (uint64_t)(x->sch.pos[k] - x->lay.win_begin[w]) * src_stride +
-                           x->slice_begin[(size_t)me] / 2u;
+                d.col[k] = x->wins[w - x->lay.first_local]->d_msa + (uint64_t)(x->sch.pos[k] - x->lay.win_begin[w]) * 3u * src_stride +
+                           x->slice_begin[(size_t)me] / 8u;
             }
             d.stride = src_stride;
             d.vp = vp;

@@ -105,28 +105,13 @@ struct jl_call_args {
     uint32_t pad_;
 };
 
-// What the call part of a fused pileup launch needs for one window.  Lives in device memory (ctx->d_callinfo): the
-// pileup argument blocks stay small (32 of them travel by value) and the epilogue reads it with scalar loads.
-struct jl_callinfo {
-    jl_call_args A;
-    const uint32_t *col_first;   // [n_cols] first position whose codon starts at the column, 0xFFFFFFFF: none
-    const uint32_t *pos_next;    // [P] next position with the same start column (overlapping genes in one frame)
-    const uint32_t *pos_gene, *pos_codon;
-    const uint8_t *pos_refcfg;
-    const uint64_t *drm;         // null: no --drm-only masks
-    uint64_t *called;            // [P] mask of called codons
-    jl_variant *staged;          // [P][64] finished rows of the called codons
-    jl_phase_meta *meta;         // run counters, zeroed by the first workgroup of the launch (null: phasing off)
-};
-
 struct jl_win_pileup {
-    const uint8_t *msa;          // the nibble matrix, or its bit planes (the launch says which kernel reads it)
-    uint64_t col_stride;         // bytes per column of the nibble matrix / per PLANE of the bit planes
+    const uint8_t *msa;          // the window's bit planes
+    uint64_t plane_stride;       // bytes per plane
     uint32_t n_cols, n_tiles, n_chunks, pad_;
     const uint2 *chunks;
     const uint32_t *guess32;
     uint32_t *counts, *hist;
-    const jl_callinfo *ci;       // null: count only
 };
 
 struct jl_win_call {   // call_kernel: the Fisher stage from histograms in HBM (stage API, windows too deep for one block per chunk)
@@ -205,8 +190,8 @@ struct jl_exp_head {
 #define JL_EXP_HEAD_WORDS 8u
 
 // The fused phase launch reading its variant columns where they lie (a session whose positions are all in windows of this
-// device: no compact matrix, no pack launch, no plan kernel in front).  Position p = three columns of `stride` bytes
-// starting at col[p] (already offset to the slice's first read); vp travels by value.
+// device: no compact matrix, no pack launch, no plan kernel in front).  Position p = nine plane rows (three columns x three
+// planes) of `stride` bytes starting at col[p] (already offset to the byte of the slice's first read); vp travels by value.
 struct jl_direct_cols {
     const uint8_t *col[JL_POS_PER_WORD];
     uint64_t stride;
@@ -258,7 +243,6 @@ struct jl_pileup_group_args { jl_win_pileup w[JL_GROUP_WINDOWS_MAX]; };
 // one all-gather for the launch)
 #define JL_GATHER_MAX 32
 struct jl_gather_args { const uint8_t *src[JL_GATHER_MAX]; };
-void jl_launch_planes(jl_ctx *ctx, hipStream_t st);   // nibble matrix -> bit planes (kernels_util.hip)
 void jl_launch_gather_heads(const uint8_t *const *srcs, uint32_t n, uint8_t *dst, hipStream_t st);
 
 struct jl_comm;
@@ -268,10 +252,12 @@ struct jl_comm;
 #define JL_XW_DST_MAX 8u     // destination ranks per pack launch
 #define JL_XW_TAB_MAX 1024u  // exported groups whose haplotypes travel in the kernel arguments
 struct jl_xw_pack_args {
-    const uint8_t *src[JL_XW_POS_MAX];   // column 0 of each owned position in its window, at read 0
-    uint64_t src_stride;
+    const uint8_t *src[JL_XW_POS_MAX];   // plane 0 of the first column of each owned position in its window, at read 0
+    uint64_t src_stride;                 // plane stride of the windows
     uint32_t n_pos, n_dst;
-    struct { uint8_t *dst; uint64_t dst_stride, byte_begin, bytes; } d[JL_XW_DST_MAX];   // dst: where source column 0 of this launch goes
+    // dst: where the first plane row of this launch goes; byte_begin / bytes: the slice within a plane row (8 reads a byte);
+    // tail_mask: the bits of the slice's last byte that are its reads (0xFF: all eight)
+    struct { uint8_t *dst; uint64_t dst_stride, byte_begin, bytes; uint32_t tail_mask, pad_; } d[JL_XW_DST_MAX];
     // the compact matrix's phasing plan, written by the first launch of a step (meta == null: not by this one)
     jl_phase_meta *meta;
     uint32_t *vpcols, *col2pos;
@@ -308,18 +294,17 @@ struct jl_ctx {
     bool own_stream = false;
     std::string err;
 
-    // ---- resident MSA (column-packed nibbles)
+    // ---- resident MSA: THE format, written directly by every producer (upload, by-row pack, record ingest, synthetic
+    // fill) and read by every consumer (pileup, phasing, cross-window exchange, an adopted matrix): per column three BIT
+    // PLANES — plane k holds bit k of every read's 3-bit symbol code (A C G T - N ' ' = 0..6), read i in bit i & 7 of byte
+    // i >> 3 — i.e. 3 bits per cell.  Plane k of column c at d_msa + (3 c + k) * plane_stride; plane_stride =
+    // jl_plane_stride(n_reads) (reads padded to a multiple of 1024 with code 6: whole 128-byte lines per plane), or the
+    // caller's for an adopted matrix.  `col_stride` = 4 * plane_stride is the same stride counted in "8 reads per dword"
+    // units: the phasing kernels give a lane 8 reads (dword t of a column <=> byte t of each plane), reads_pad = 2 col_stride.
     uint8_t *d_msa = nullptr;
     bool own_msa = false;
     size_t msa_capacity = 0;
-    // The counting kernel's own copy of the matrix: three BIT PLANES per column (bit k of every read's code, reads in bit
-    // order), 3 bits per cell where the nibble layout moves 4.  Made by the library whenever IT writes the matrix (upload,
-    // pack, ingest, synthetic fill); an adopted matrix (jl_msa_adopt: the caller may rewrite it at any time) has none and
-    // is counted from the nibbles.  plane k of column c at d_planes + (3 c + k) * plane_stride, plane_stride = col_stride / 4.
-    uint8_t *d_planes = nullptr;
-    size_t planes_capacity = 0;
     uint64_t plane_stride = 0;
-    bool planes_valid = false;
     uint64_t n_reads = 0;
     uint32_t n_cols = 0;
     uint64_t col_stride = 0;
@@ -382,10 +367,6 @@ struct jl_ctx {
     uint64_t *d_called = nullptr;  // [P] mask of called codons
     jl_variant *d_staged = nullptr;  // [P][64] finished rows of the called codons, before the ordered compaction
     uint64_t *d_drm = nullptr;     // [P] optional
-    uint32_t *d_col_first = nullptr;   // [n_cols] first position starting at the column (0xFFFFFFFF: none)
-    uint32_t *d_pos_next = nullptr;    // [P] next position with the same start column
-    jl_callinfo *d_callinfo = nullptr; // what the Fisher stage inside the pileup launch reads (see jl_callinfo)
-    std::vector<uint8_t> callinfo_host;  // last uploaded contents
     jl_variant *d_variants = nullptr;  // [JL_VARIANT_CAP]
     uint32_t *d_nvar = nullptr;        // [0] rows needed, [1] spare
     bool call_done = false;
@@ -465,8 +446,7 @@ int jl_fail(jl_ctx *ctx, int status, const char *fmt, ...);
 
 // kernel launchers (defined in the .hip files) -------------------------------------------------
 void jl_launch_guess(jl_ctx *ctx, hipStream_t st);
-void jl_launch_pileup(jl_ctx *ctx, hipStream_t st, bool with_call);
-bool jl_pileup_can_call(jl_ctx *ctx);
+void jl_launch_pileup(jl_ctx *ctx, hipStream_t st);
 uint32_t jl_pileup_rsplit(jl_ctx *ctx);
 bool jl_pileup_needs_zero(jl_ctx *ctx);
 void jl_prepare_pileup(jl_ctx *ctx);
@@ -480,15 +460,16 @@ void jl_fill_win_pileup(jl_ctx *ctx, jl_win_pileup *w);
 void jl_fill_win_call(jl_ctx *ctx, const jl_params *prm, double n_tests, bool use_drm, bool with_meta, jl_win_call *w);
 void jl_fill_win_compact(jl_ctx *ctx, bool plan, bool pack, bool signal, jl_win_compact *w);
 bool jl_fill_win_phase(jl_ctx *ctx, uint32_t min_reads, bool signal, uint32_t fold_budget, bool from_called, jl_win_phase *w);
-int jl_launch_pileup_group(jl_ctx *const *ctxs, uint32_t n_win, const jl_win_pileup *h_wins, uint32_t max_chunks, hipStream_t st,
-                           bool with_call);
+int jl_launch_pileup_group(jl_ctx *const *ctxs, uint32_t n_win, const jl_win_pileup *h_wins, uint32_t max_chunks, hipStream_t st);
 void jl_launch_call_group(const jl_win_call *h_wins, uint32_t n_win, uint32_t max_blocks, hipStream_t st);
 void jl_launch_compact_group(const jl_win_compact *h_wins, uint32_t n_win, hipStream_t st);
 void jl_launch_phase_group(const jl_win_phase *h_wins, uint32_t n_win, uint32_t max_blocks, hipStream_t st);
 void jl_launch_assign_group(const jl_win_phase *h_wins, uint32_t n_win, uint32_t max_read_blocks, bool to_host, hipStream_t st);
 void jl_launch_synth(jl_ctx *ctx, const jl_synth_plan *plan, const uint8_t *d_ref, uint32_t col0);
 void jl_launch_pack_rows(jl_ctx *ctx, const uint8_t *d_rows);
-void jl_launch_validate(jl_ctx *ctx, uint32_t *d_flag);
+// interchange format (column-packed nibbles, include/juliet_hip.h) <-> the resident planes, `n` columns from column c0 on
+void jl_launch_nibbles_to_planes(jl_ctx *ctx, const uint8_t *d_nib, uint64_t nib_stride, uint32_t c0, uint32_t n, uint32_t *d_bad);
+void jl_launch_planes_to_nibbles(jl_ctx *ctx, uint8_t *d_nib, uint64_t nib_stride, uint32_t c0, uint32_t n);
 void jl_launch_done(jl_ctx *ctx);
 void jl_launch_done_group(const jl_done_ent *d_ents, uint32_t n, hipStream_t st);
 void jl_launch_stamp(jl_ctx *ctx, uint32_t slot);
@@ -511,8 +492,7 @@ void jl_launch_fisher_eval(jl_ctx *ctx, uint32_t n, const uint32_t *a, const uin
                            double *p, double *lp);
 // per-read ids in their packed form (4 / 8 / 16 bits, see JL_ID4_MAX_H) expanded to 16-bit ids on the host
 extern "C" void jl_expand_ids(const void *packed, uint32_t bits, uint64_t n_reads, uint16_t *out);
-int jl_msa_alloc_strided(jl_ctx *ctx, uint64_t n_reads, uint32_t n_cols, uint64_t col_stride, uint32_t win_begin);
-extern "C" int jl_update_callinfo(jl_ctx *ctx, const jl_params *prm, double n_tests, bool use_drm, bool with_meta);
+int jl_msa_alloc_strided(jl_ctx *ctx, uint64_t n_reads, uint32_t n_cols, uint64_t plane_stride, uint32_t win_begin);
 // capi_xwin.hip: buffers of an exporting phase run whose plan (vp positions at columns 3k) a kernel of the caller writes
 int jl_phase_groups_prepare(jl_ctx *ctx, uint32_t vp);
 // the variant table of a context's last call stage on the host: a pointer into the pinned result block when the run left

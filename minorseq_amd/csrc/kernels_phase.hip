@@ -24,6 +24,7 @@
 #include "call_eval.h"
 #include "jl_internal.h"
 #include "phase_plan.h"
+#include "planes.h"
 #include "result_pack.h"
 
 namespace {
@@ -59,8 +60,8 @@ __global__ __launch_bounds__(1024) void phase_plan_kernel(const jl_variant *__re
 }
 
 // ---------------------------------------------------------------------------------------- keys
-// One lane = one dword of every variant column = 8 consecutive reads.
-__global__ __launch_bounds__(256) void phase_keys_kernel(const uint8_t *__restrict__ msa, uint64_t col_stride,
+// One lane = 8 consecutive reads = one byte of each plane of every variant column, put back together as a dword of eight codes.
+__global__ __launch_bounds__(256) void phase_keys_kernel(const uint8_t *__restrict__ msa, uint64_t plane_stride,
                                                           uint64_t n_reads, uint64_t reads_pad,
                                                           const uint32_t *__restrict__ vpcols,
                                                           jl_phase_meta *__restrict__ meta,
@@ -68,8 +69,8 @@ __global__ __launch_bounds__(256) void phase_keys_kernel(const uint8_t *__restri
 {
     const uint32_t vp = meta->vp;
     if (vp == 0) return;   // (a context on the multi-word pipeline takes it for every run, whatever the run's key width)
-    const uint64_t t = (uint64_t)blockIdx.x * 256u + threadIdx.x;  // dword index within a column
-    const bool live = t * 4u < col_stride;
+    const uint64_t t = (uint64_t)blockIdx.x * 256u + threadIdx.x;  // byte index within a plane
+    const bool live = t < plane_stride;
     uint32_t gap = 0, het = 0, par = 0;
     const uint32_t kwords = meta->kwords;
     for (uint32_t gw = 0; gw < kwords; ++gw) {
@@ -81,8 +82,7 @@ __global__ __launch_bounds__(256) void phase_keys_kernel(const uint8_t *__restri
             uint32_t w[3];
 #pragma unroll
             for (int k = 0; k < 3; ++k)
-                w[k] = live ? *reinterpret_cast<const uint32_t *>(msa + (uint64_t)(c + k) * col_stride + t * 4u)
-                            : 0x66666666u;
+                w[k] = live ? jl_load_codes8(msa + (uint64_t)(c + k) * 3u * plane_stride + t, plane_stride) : 0x66666666u;
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 const uint32_t b0 = w[k] & kM1, b1 = (w[k] >> 1) & kM1, b2 = (w[k] >> 2) & kM1;
@@ -1164,17 +1164,19 @@ __device__ __forceinline__ void phase_fused1_body(const jl_win_phase &w, const j
     uint32_t cols[NP];
 #pragma unroll
     for (uint32_t p = 0; p < NP; ++p) cols[p] = s_plan.cols[p];
-    const uint64_t t_ld = live ? t : 0u;
+    // (a lane whose eight reads are all past the last read loads nothing of its own: a slice read in place — `direct` —
+    // ends where the window's rows may end too)
+    const uint64_t t_ld = (live && t * 8u < n_reads) ? t : 0u;
     uint32_t wd[NP][3];
     const bool direct = dc && dc->on;   // block-uniform
 #pragma unroll
     for (uint32_t p = 0; p < NP; ++p) {
         if (p < vp) {  // block-uniform
-            const uint8_t *c0 = (direct && p < JL_POS_PER_WORD) ? dc->col[p] : msa + (uint64_t)cols[p] * col_stride;
-            const uint64_t cs = direct ? dc->stride : col_stride;
+            // nine plane rows per position (three columns x three planes), one byte = 8 reads of each
+            const uint64_t ps = direct ? dc->stride : col_stride / 4u;
+            const uint8_t *c0 = (direct && p < JL_POS_PER_WORD) ? dc->col[p] : msa + (uint64_t)cols[p] * 3u * ps;
 #pragma unroll
-            for (int k = 0; k < 3; ++k)
-                wd[p][k] = *reinterpret_cast<const uint32_t *>(c0 + (uint64_t)k * cs + t_ld * 4u);
+            for (int k = 0; k < 3; ++k) wd[p][k] = jl_load_codes8(c0 + (uint64_t)k * 3u * ps + t_ld, ps);
         } else {
 #pragma unroll
             for (int k = 0; k < 3; ++k) wd[p][k] = 0x66666666u;
@@ -1696,7 +1698,7 @@ bool jl_launch_phase(jl_ctx *ctx, hipStream_t st, uint32_t min_reads, bool plann
     const uint32_t rblocks = (uint32_t)((ctx->n_reads + 255u) / 256u);
     if (generic)
         hipLaunchKernelGGL(phase_keys_kernel, dim3((n_dwords + 255u) / 256u), dim3(256), 0, st, ctx->d_msa,
-                           ctx->col_stride, ctx->n_reads, reads_pad, ctx->d_vpcols, ctx->d_meta, ctx->d_keys,
+                           ctx->plane_stride, ctx->n_reads, reads_pad, ctx->d_vpcols, ctx->d_meta, ctx->d_keys,
                            ctx->d_flagw);
     jl_win_phase w;
     const bool fold = jl_fill_win_phase(ctx, min_reads, signal, JL_FOLD_MAX_BLOCKS, from_called, &w);

@@ -1,24 +1,49 @@
-// kernels_util.hip — device-side producers of the resident column-packed matrix:
-//   synth_kernel      synthetic aligned CCS reads (jl_synth.h), one dword (8 reads) of one column per step
-//   pack_rows_kernel  by-row uint8 codes -> column-packed nibbles (jl_msa_pack_rows)
-//   ingest_cols_kernel  aligned BAM records -> column-packed nibbles
+// kernels_util.hip — device-side producers of the resident matrix (three bit planes per column, jl_internal.h); every one
+// of them writes the planes directly:
+//   synth_kernel              synthetic aligned CCS reads (jl_synth.h)
+//   pack_rows_kernel          by-row uint8 codes (jl_msa_pack_rows)
+//   nibbles_to_planes_kernel  the interchange format of jl_msa_upload, validated on the way (planes_to_nibbles_kernel: jl_msa_download)
+//   expand_rows_kernel + transpose_rows_kernel   aligned BAM records
 #include <string.h>
 
 #include <algorithm>
 
 #include "jl_internal.h"
+#include "planes.h"
 
 namespace {
 
 constexpr int kSynthColsPerBlock = 64;
 
-// `ref`, `msa`: the window's columns [col0, col0 + win_cols) of the pl.n_cols-column reference the plan describes
+// four lanes hold one byte each (lane & 3 = byte index): every one of them gets the dword
+__device__ __forceinline__ uint32_t quad_bytes_to_dword(uint32_t byte, uint32_t lane)
+{
+    uint32_t x = byte << (8u * (lane & 3u));
+    x |= (uint32_t)__shfl_xor((int)x, 1, 64);
+    x |= (uint32_t)__shfl_xor((int)x, 2, 64);
+    return x;
+}
+
+// A thread's eight codes of one column (nibbles of w) into the planes: the four lanes of a quad put their bytes together
+// and lanes 0..2 of the quad store the dword of plane 0..2.  `t` = the thread's byte within a plane (8 reads).
+__device__ __forceinline__ void store_planes_quad(uint8_t *__restrict__ col_base, uint64_t plane_stride, uint64_t t, uint32_t w)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t d0 = quad_bytes_to_dword(jl_plane_bits8(w, 0), lane);
+    const uint32_t d1 = quad_bytes_to_dword(jl_plane_bits8(w, 1), lane);
+    const uint32_t d2 = quad_bytes_to_dword(jl_plane_bits8(w, 2), lane);
+    const uint32_t k = lane & 3u;
+    if (k < 3u && t < plane_stride)
+        *reinterpret_cast<uint32_t *>(col_base + (uint64_t)k * plane_stride + (t & ~(uint64_t)3)) = k == 0 ? d0 : (k == 1 ? d1 : d2);
+}
+
+// `ref`, `msa`: the window's columns [col0, col0 + win_cols) of the pl.n_cols-column reference the plan describes.
+// thread = 8 reads (one byte of every plane), a block's 256 threads x 64 columns
 __global__ __launch_bounds__(256) void synth_kernel(jl_synth_plan pl, const uint8_t *__restrict__ ref,
-                                                     uint8_t *__restrict__ msa, uint64_t col_stride,
+                                                     uint8_t *__restrict__ msa, uint64_t plane_stride,
                                                      uint64_t n_reads, uint32_t col0, uint32_t win_cols)
 {
-    const uint64_t t = (uint64_t)blockIdx.x * 256u + threadIdx.x;  // dword index in a column
-    if (t * 4u >= col_stride) return;
+    const uint64_t t = (uint64_t)blockIdx.x * 256u + threadIdx.x;  // byte index in a plane (plane_stride is a multiple of 4: whole quads)
     uint32_t hap[8], st[8], en[8];
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
@@ -33,18 +58,18 @@ __global__ __launch_bounds__(256) void synth_kernel(jl_synth_plan pl, const uint
         uint32_t w = 0;
 #pragma unroll
         for (int r = 0; r < 8; ++r) w |= jl_synth_cell(&pl, t * 8u + r, col0 + c, hap[r], st[r], en[r], rb) << (4 * r);
-        *reinterpret_cast<uint32_t *>(msa + (uint64_t)c * col_stride + t * 4u) = w;
+        store_planes_quad(msa + (uint64_t)c * 3u * plane_stride, plane_stride, t, w);
     }
 }
 
-// thread (x = column, y = dword of the column): gathers 8 reads of one column
+// by-row uint8 codes -> planes.  thread (x = 8 reads, y = column): gathers 8 reads of one column; the quad's bytes leave
+// as dwords.  (A test-size path: the by-row reads are strided.)
 __global__ __launch_bounds__(256) void pack_rows_kernel(const uint8_t *__restrict__ rows, uint64_t n_reads,
                                                          uint32_t n_cols, uint8_t *__restrict__ msa,
-                                                         uint64_t col_stride)
+                                                         uint64_t plane_stride)
 {
-    const uint32_t c = blockIdx.x * 64u + (threadIdx.x & 63u);
-    const uint64_t t = (uint64_t)blockIdx.y * 4u + (threadIdx.x >> 6);
-    if (c >= n_cols || t * 4u >= col_stride) return;
+    const uint64_t t = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    const uint32_t c = blockIdx.y;
     uint32_t w = 0;
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
@@ -52,12 +77,76 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(const uint8_t *__restric
         const uint32_t s = i < n_reads ? rows[i * n_cols + c] : 6u;
         w |= (s & 7u) << (4 * r);
     }
-    *reinterpret_cast<uint32_t *>(msa + (uint64_t)c * col_stride + t * 4u) = w;
+    store_planes_quad(msa + (uint64_t)c * 3u * plane_stride, plane_stride, t, w);
+}
+
+// Interchange format (column-packed nibbles: the host form of jl_msa_upload / jl_msa_download) -> planes, fused with the
+// validation of an upload: any nibble outside 0..6 (code 7 or bit 3 set) is rejected (SPEC §1).  One thread = 64 reads of
+// one column: 32 bytes of nibbles in, 8 bytes of each plane out.  Reads past the source column's stride are padding (6).
+__global__ __launch_bounds__(256) void nibbles_to_planes_kernel(const uint8_t *__restrict__ nib, uint64_t nib_stride, uint64_t n_reads,
+                                                                uint8_t *__restrict__ planes, uint64_t plane_stride, uint32_t c0,
+                                                                uint32_t *__restrict__ bad)
+{
+    const uint64_t t = (uint64_t)blockIdx.x * 256u + threadIdx.x;   // 64-read unit within the column
+    if (t * 8u >= plane_stride) return;
+    const uint32_t c = blockIdx.y;
+    uint32_t w[8];
+    if (t * 32u + 32u <= nib_stride) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(nib + (uint64_t)c * nib_stride + t * 32u);
+        const uint4 a = src[0], b = src[1];
+        w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
+    } else {
+#pragma unroll
+        for (uint32_t q = 0; q < 8u; ++q)
+            w[q] = t * 32u + q * 4u + 4u <= nib_stride ? *reinterpret_cast<const uint32_t *>(nib + (uint64_t)c * nib_stride + t * 32u + q * 4u)
+                                                        : 0x66666666u;
+    }
+    // whatever the caller's buffer holds past its last read is padding here
+    if (t * 64u + 64u > n_reads) {
+#pragma unroll
+        for (uint32_t q = 0; q < 8u; ++q) {
+            const uint64_t first = t * 64u + q * 8u;
+            if (first >= n_reads) w[q] = 0x66666666u;
+            else if (first + 8u > n_reads) {
+                const uint32_t keep = (1u << (4u * (uint32_t)(n_reads - first))) - 1u;
+                w[q] = (w[q] & keep) | (0x66666666u & ~keep);
+            }
+        }
+    }
+    uint32_t any = 0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) any |= (w[q] & 0x88888888u) | (w[q] & (w[q] >> 1) & (w[q] >> 2) & 0x11111111u);
+    if (any && bad) atomicOr(bad, 1u);
+#pragma unroll
+    for (uint32_t k = 0; k < 3u; ++k) {
+        uint2 o;
+        o.x = jl_plane_bits8(w[0], k) | (jl_plane_bits8(w[1], k) << 8) | (jl_plane_bits8(w[2], k) << 16) | (jl_plane_bits8(w[3], k) << 24);
+        o.y = jl_plane_bits8(w[4], k) | (jl_plane_bits8(w[5], k) << 8) | (jl_plane_bits8(w[6], k) << 16) | (jl_plane_bits8(w[7], k) << 24);
+        *reinterpret_cast<uint2 *>(planes + ((uint64_t)(c0 + c) * 3u + k) * plane_stride + t * 8u) = o;
+    }
+}
+
+// ... and back (jl_msa_download): one thread = 32 reads of one column, a dword of each plane in, 16 bytes of nibbles out
+__global__ __launch_bounds__(256) void planes_to_nibbles_kernel(const uint8_t *__restrict__ planes, uint64_t plane_stride, uint32_t c0,
+                                                                uint8_t *__restrict__ nib, uint64_t nib_stride)
+{
+    const uint64_t t = (uint64_t)blockIdx.x * 256u + threadIdx.x;   // 32-read unit
+    if (t * 16u >= nib_stride) return;
+    const uint32_t c = blockIdx.y;
+    uint32_t b[3] = {0u, 0xFFFFFFFFu, 0xFFFFFFFFu};   // past the planes: padding
+    if (t * 4u < plane_stride) {
+#pragma unroll
+        for (uint32_t k = 0; k < 3u; ++k) b[k] = *reinterpret_cast<const uint32_t *>(planes + ((uint64_t)(c0 + c) * 3u + k) * plane_stride + t * 4u);
+    }
+    uint32_t o[4];
+#pragma unroll
+    for (uint32_t q = 0; q < 4u; ++q) o[q] = jl_planes_to_nibbles8((b[0] >> (8u * q)) & 0xFFu, (b[1] >> (8u * q)) & 0xFFu, (b[2] >> (8u * q)) & 0xFFu);
+    *reinterpret_cast<uint4 *>(nib + (uint64_t)c * nib_stride + t * 16u) = make_uint4(o[0], o[1], o[2], o[3]);
 }
 
 
 // ---------------------------------------------------------------------------------------- record ingest
-// Aligned records -> column-packed nibbles: doc/JULIET.md:26-27 (insertions dropped, deletions '-'), :53 (PacBio cigars
+// Aligned records -> the resident planes: doc/JULIET.md:26-27 (insertions dropped, deletions '-'), :53 (PacBio cigars
 // = X I D S H N; M rejected on the host), :256-259 (filtered base = N).  Two streaming kernels:
 //   expand_rows_kernel   ONE WAVE per read.  The wave scans the read's cigar once into LDS (prefix sums of reference and
 //                        query lengths), then every lane produces 8 consecutive columns = one dword of the read's row
@@ -65,9 +154,9 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(const uint8_t *__restric
 //                        all 8 columns lie inside one op (runs of '=' are tens of columns long) they are taken at
 //                        once — eight packed BAM bases fetched as two dwords, converted nibble-parallel — otherwise
 //                        column by column.  No divergence over reads: a wave only ever looks at one cigar.
-//   transpose_rows_kernel  by-row nibbles -> the column-packed matrix through a 256-read x 256-column LDS tile, 8 x 8
-//                        nibble blocks transposed in registers: 128-byte reads (16 bytes per lane, eight loads in
-//                        flight per thread) and writes.  300 MB in 50 us = 6 TB/s.
+//   transpose_rows_kernel  by-row nibbles -> the planes through a 256-read x 256-column LDS tile: a thread takes 32 reads x
+//                        8 columns out of it, transposes four 8 x 8 nibble blocks in registers and splits the codes into
+//                        their three bits — a dword of each plane of each of the 8 columns, 32-byte runs per quad of lanes.
 // (The first build walked one read per LANE while the wave swept the columns: some lane of 64 changed its op at
 // nearly every column and the kernel was bound by the cursor's instructions under divergence, 0.29 TB/s.)
 // Reads past n_reads (the padding of a column up to its 128-byte stride) and columns outside a read's span are 'not covered'.
@@ -275,14 +364,34 @@ __device__ __forceinline__ void transpose_nibbles_8x8(uint32_t (&m)[8])
     }
 }
 
+// 32 reads x 8 columns, R[i] = the 8 codes (nibbles) of read i -> out[j][k] = plane k of column j, bit i = read i.
+// Four 8 x 8 nibble transposes — block g holds reads g, g + 4, ..., g + 28, so that after it nibble n of M[g][j] is read
+// 4 n + g at column j — then bit k of the four blocks' nibbles interleaves into the 32 read bits with four and-or steps.
+__device__ __forceinline__ void nibble_rows_to_plane_words(const uint32_t (&R)[32], uint32_t (&out)[8][3])
+{
+    uint32_t M[4][8];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) M[g][i] = R[4 * i + g];
+        transpose_nibbles_8x8(M[g]);
+    }
+    constexpr uint32_t m = 0x11111111u;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (uint32_t k = 0; k < 3u; ++k)
+            out[j][k] = ((M[0][j] >> k) & m) | (((M[1][j] >> k) & m) << 1) | (((M[2][j] >> k) & m) << 2) | (((M[3][j] >> k) & m) << 3);
+}
+
 // LDS tile of 256 reads x 32 dwords: dword d of read r at (r & 7) * kTrOct + (r >> 3) * 33 + d.  Rows go in with one read
-// per half-wave (banks d), groups of 8 reads come out with one group per lane (banks 33 g = g): no conflicts either way.
+// per half-wave (banks d); a thread takes 32 reads of one dword out.
 constexpr uint32_t kTrOct = 1060;
 static_assert(kTrOct % 32u == 4u && kTrOct >= 32u * 33u, "LDS tile layout");
 
 __global__ __launch_bounds__(256) void transpose_rows_kernel(const uint32_t *__restrict__ rows4, uint32_t row_dwords,
                                                               uint64_t r0, uint64_t n_batch, uint32_t n_cols,
-                                                              uint8_t *__restrict__ msa, uint64_t col_stride)
+                                                              uint8_t *__restrict__ msa, uint64_t plane_stride)
 {
     __shared__ uint32_t s_t[8u * kTrOct];
     const uint32_t tid = threadIdx.x;
@@ -305,20 +414,26 @@ __global__ __launch_bounds__(256) void transpose_rows_kernel(const uint32_t *__r
         dst[0] = v[k].x; dst[1] = v[k].y; dst[2] = v[k].z; dst[3] = v[k].w;
     }
     __syncthreads();
-    // 32 groups of 8 reads x 32 dwords of 8 columns: 8 x 8 nibbles at a time, 128-byte segments of 8 columns out
+    // 8 groups of 32 reads x 32 dwords of 8 columns, one per thread: a dword of each plane of each column out; the lanes of
+    // a quad... of eight lanes write 32 consecutive bytes of one plane
+    const uint32_t G = tid & 7u, dwi = tid >> 3;
+    uint32_t R[32];
 #pragma unroll
-    for (uint32_t item = tid; item < 32u * 32u; item += 256u) {
-        const uint32_t g = item & 31u, dwi = item >> 5;
-        uint32_t m[8];
+    for (uint32_t i = 0; i < 32u; ++i) {
+        const uint32_t rr = 32u * G + i;
+        R[i] = s_t[(rr & 7u) * kTrOct + (rr >> 3) * 33u + dwi];
+    }
+    uint32_t out[8][3];
+    nibble_rows_to_plane_words(R, out);
+    const uint64_t byte = (r0 + rb) / 8u + (uint64_t)G * 4u;
+    if (byte < plane_stride) {
 #pragma unroll
-        for (uint32_t i = 0; i < 8u; ++i) m[i] = s_t[i * kTrOct + g * 33u + dwi];
-        transpose_nibbles_8x8(m);
-        const uint64_t byte = (r0 + rb + (uint64_t)g * 8u) / 2u;
-        if (byte < col_stride) {
+        for (uint32_t j = 0; j < 8u; ++j) {
+            const uint32_t c = (d0 + dwi) * 8u + j;
+            if (c < n_cols) {
 #pragma unroll
-            for (uint32_t j = 0; j < 8u; ++j) {
-                const uint32_t c = (d0 + dwi) * 8u + j;
-                if (c < n_cols) *reinterpret_cast<uint32_t *>(msa + (uint64_t)c * col_stride + byte) = m[j];
+                for (uint32_t k = 0; k < 3u; ++k)
+                    *reinterpret_cast<uint32_t *>(msa + ((uint64_t)c * 3u + k) * plane_stride + byte) = out[j][k];
             }
         }
     }
@@ -384,60 +499,11 @@ __global__ __launch_bounds__(256) void consensus_kernel(const uint32_t *__restri
     out[c] = bv == 0 ? (uint8_t)5 : (uint8_t)best;
 }
 
-// any nibble outside 0..6 (code 7 or bit 3 set) is rejected at upload (SPEC §1)
-__global__ __launch_bounds__(256) void validate_kernel(const uint8_t *__restrict__ msa, uint64_t n_bytes,
-                                                        uint32_t *__restrict__ bad)
-{
-    uint32_t any = 0;
-    for (uint64_t i = ((uint64_t)blockIdx.x * 256u + threadIdx.x) * 16u; i < n_bytes; i += (uint64_t)gridDim.x * 256u * 16u) {
-        const uint4 v = *reinterpret_cast<const uint4 *>(msa + i);
-        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-        for (int q = 0; q < 4; ++q) any |= (w[q] & 0x88888888u) | (w[q] & (w[q] >> 1) & (w[q] >> 2) & 0x11111111u);
-    }
-    if (any) atomicOr(bad, 1u);
-}
-
 }  // namespace
 
 // Last node of a run: everything before it on the stream has completed (including the stores the result
 // kernels made into pinned host memory), so a sequence word stored behind a system-scope fence tells a
 // polling host that the results are there — no hipStreamSynchronize on the hot path.
-// Nibble matrix -> bit planes (jl_ctx::d_planes).  One thread = 64 reads of one column: 32 bytes of nibbles in, 8 bytes of
-// each of the three planes out; bit r of a plane word = bit k of read r's code.  Runs once per upload, on the context's stream.
-__device__ __forceinline__ uint32_t plane_byte(uint32_t w, uint32_t k)
-{
-    uint32_t x = (w >> k) & 0x11111111u;     // bit k of the eight codes, one per nibble
-    x = (x | (x >> 3)) & 0x03030303u;        // two per byte
-    x = (x | (x >> 6)) & 0x000F000Fu;        // four per half
-    return (x | (x >> 12)) & 0xFFu;          // eight: read 0 in bit 0
-}
-
-__global__ __launch_bounds__(256) void planes_kernel(const uint8_t *__restrict__ msa, uint64_t col_stride, uint8_t *__restrict__ planes,
-                                                     uint64_t plane_stride)
-{
-    const uint64_t t = (uint64_t)blockIdx.x * 256u + threadIdx.x;   // 64-read unit within the column
-    if (t * 32u >= col_stride) return;
-    const uint32_t c = blockIdx.y;
-    const uint4 *src = reinterpret_cast<const uint4 *>(msa + (uint64_t)c * col_stride + t * 32u);
-    const uint4 a = src[0], b = src[1];
-    const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-#pragma unroll
-    for (uint32_t k = 0; k < 3u; ++k) {
-        uint2 o;
-        o.x = plane_byte(w[0], k) | (plane_byte(w[1], k) << 8) | (plane_byte(w[2], k) << 16) | (plane_byte(w[3], k) << 24);
-        o.y = plane_byte(w[4], k) | (plane_byte(w[5], k) << 8) | (plane_byte(w[6], k) << 16) | (plane_byte(w[7], k) << 24);
-        *reinterpret_cast<uint2 *>(planes + ((uint64_t)c * 3u + k) * plane_stride + t * 8u) = o;
-    }
-}
-
-void jl_launch_planes(jl_ctx *ctx, hipStream_t st)
-{
-    const uint64_t units = ctx->col_stride / 32u;   // col_stride is a multiple of 128
-    hipLaunchKernelGGL(planes_kernel, dim3((uint32_t)((units + 255u) / 256u), ctx->n_cols), dim3(256), 0, st, ctx->d_msa, ctx->col_stride,
-                       ctx->d_planes, ctx->plane_stride);
-}
-
 __global__ void done_kernel(uint32_t *__restrict__ seq_dev, volatile uint32_t *__restrict__ seq_host)
 {
     const uint32_t v = *seq_dev + 1u;
@@ -505,12 +571,18 @@ void jl_launch_consensus(jl_ctx *ctx, uint8_t *d_out)
                        ctx->n_cols, d_out);
 }
 
-void jl_launch_validate(jl_ctx *ctx, uint32_t *d_flag)
+void jl_launch_nibbles_to_planes(jl_ctx *ctx, const uint8_t *d_nib, uint64_t nib_stride, uint32_t c0, uint32_t n, uint32_t *d_bad)
 {
-    const uint64_t n_bytes = (uint64_t)ctx->col_stride * ctx->n_cols;  // multiple of 128
-    uint32_t blocks = (uint32_t)std::min<uint64_t>(2048, (n_bytes / 16 + 255) / 256);
-    if (blocks == 0) blocks = 1;
-    hipLaunchKernelGGL(validate_kernel, dim3(blocks), dim3(256), 0, ctx->stream, ctx->d_msa, n_bytes, d_flag);
+    const uint64_t units = ctx->plane_stride / 8u;   // plane_stride is a multiple of 16
+    hipLaunchKernelGGL(nibbles_to_planes_kernel, dim3((uint32_t)((units + 255u) / 256u), n), dim3(256), 0, ctx->stream, d_nib, nib_stride,
+                       ctx->n_reads, ctx->d_msa, ctx->plane_stride, c0, d_bad);
+}
+
+void jl_launch_planes_to_nibbles(jl_ctx *ctx, uint8_t *d_nib, uint64_t nib_stride, uint32_t c0, uint32_t n)
+{
+    const uint64_t units = nib_stride / 16u;
+    hipLaunchKernelGGL(planes_to_nibbles_kernel, dim3((uint32_t)((units + 255u) / 256u), n), dim3(256), 0, ctx->stream, ctx->d_msa,
+                       ctx->plane_stride, c0, d_nib, nib_stride);
 }
 
 // rows4: scratch of jl_ingest_batch_reads(ctx) x jl_ingest_row_dwords(ctx) dwords
@@ -539,7 +611,7 @@ void jl_launch_ingest(jl_ctx *ctx, const int32_t *d_pos, const uint32_t *d_cigar
                            ctx->n_cols, ctx->win_begin, d_pos, d_cigar, d_cig_off, d_seq4, d_seq_off, d_qual, d_qual_off, min_qv,
                            d_rows4, row_dwords, ops_cap, seq_cap);
         hipLaunchKernelGGL(transpose_rows_kernel, dim3((uint32_t)((nb + 255u) / 256u), (row_dwords + 31u) / 32u), dim3(256), 0,
-                           ctx->stream, (const uint32_t *)d_rows4, row_dwords, r0, nb, ctx->n_cols, ctx->d_msa, ctx->col_stride);
+                           ctx->stream, (const uint32_t *)d_rows4, row_dwords, r0, nb, ctx->n_cols, ctx->d_msa, ctx->plane_stride);
     }
 }
 
@@ -552,16 +624,14 @@ void jl_launch_insertions(jl_ctx *ctx, const int32_t *d_pos, const uint32_t *d_c
 
 void jl_launch_synth(jl_ctx *ctx, const jl_synth_plan *plan, const uint8_t *d_ref, uint32_t col0)
 {
-    const uint32_t n_dwords = (uint32_t)(ctx->col_stride / 4u);
-    dim3 grid((n_dwords + 255u) / 256u, (ctx->n_cols + kSynthColsPerBlock - 1) / kSynthColsPerBlock);
-    hipLaunchKernelGGL(synth_kernel, grid, dim3(256), 0, ctx->stream, *plan, d_ref, ctx->d_msa, ctx->col_stride,
+    dim3 grid((uint32_t)((ctx->plane_stride + 255u) / 256u), (ctx->n_cols + kSynthColsPerBlock - 1) / kSynthColsPerBlock);
+    hipLaunchKernelGGL(synth_kernel, grid, dim3(256), 0, ctx->stream, *plan, d_ref, ctx->d_msa, ctx->plane_stride,
                        ctx->n_reads, col0, ctx->n_cols);
 }
 
 void jl_launch_pack_rows(jl_ctx *ctx, const uint8_t *d_rows)
 {
-    const uint32_t n_dwords = (uint32_t)(ctx->col_stride / 4u);
-    dim3 grid((ctx->n_cols + 63u) / 64u, (n_dwords + 3u) / 4u);
+    dim3 grid((uint32_t)((ctx->plane_stride + 255u) / 256u), ctx->n_cols);
     hipLaunchKernelGGL(pack_rows_kernel, grid, dim3(256), 0, ctx->stream, d_rows, ctx->n_reads, ctx->n_cols,
-                       ctx->d_msa, ctx->col_stride);
+                       ctx->d_msa, ctx->plane_stride);
 }

@@ -1,7 +1,7 @@
 // kernels_xwin.hip — device side of cross-window phasing with the reads sharded (SURVEY §8e option A):
-//   xwin_pack_kernel    slice s of every variant column this rank owns -> one packed message per destination rank (the
-//                       own slice straight into the compact matrix); also writes the phasing plan of the compact matrix
-//                       (position k = columns 3k..3k+2), so no variant table travels to the device
+//   xwin_pack_kernel    slice s of every variant column this rank owns (nine plane rows per position) -> one packed message
+//                       per destination rank (the own slice straight into the compact matrix); also writes the phasing plan
+//                       of the compact matrix (position k = columns 3k..3k+2), so no variant table travels to the device
 //   xwin_assign_kernel  per-read ids of the slice from the merge's answer (haplotype of each exported group), with the
 //                       completion word behind the last workgroup's ids
 //   xwin_fetch_kernel   an all-gathered block from HBM into pinned host memory + completion word (one launch where a
@@ -35,16 +35,20 @@ __device__ __forceinline__ void plan_init(const jl_xw_pack_args &a)
     }
 }
 
-// grid: x = 16 KiB pieces of a destination column (four 16-byte pieces per lane, loaded before any is stored), y = source
-// column (3 per owned position), z = destination
+// grid: x = 16 KiB pieces of a destination plane row (four 16-byte pieces per lane, loaded before any is stored), y = source
+// plane row (9 per owned position: three columns x three planes), z = destination.  Bytes past the slice's last read are
+// padding = code 6 = bit 0 clear, bits 1 and 2 set: 0x00 in plane 0, 0xFF in planes 1 and 2.
 constexpr uint32_t kPackPieces = 4;
 __global__ __launch_bounds__(256) void xwin_pack_kernel(jl_xw_pack_args a)
 {
     if (a.meta && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) plan_init(a);
-    if (blockIdx.z >= a.n_dst || blockIdx.y >= 3u * a.n_pos) return;
+    if (blockIdx.z >= a.n_dst || blockIdx.y >= 9u * a.n_pos) return;
     const uint64_t dst_stride = a.d[blockIdx.z].dst_stride;
     const uint64_t bytes = a.d[blockIdx.z].bytes;
-    const uint32_t p = blockIdx.y / 3u, j = blockIdx.y - 3u * p;
+    const uint32_t tail_mask = a.d[blockIdx.z].tail_mask;   // bits of the last byte that are reads of the slice
+    const uint32_t p = blockIdx.y / 9u, j = blockIdx.y - 9u * p;
+    const uint32_t pad = (j % 3u) == 0u ? 0u : 0xFFu;
+    const uint32_t padw = pad * 0x01010101u;
     const uint8_t *src = a.src[p] + (uint64_t)j * a.src_stride + a.d[blockIdx.z].byte_begin;
     uint8_t *dst = a.d[blockIdx.z].dst + (uint64_t)blockIdx.y * dst_stride;
     u32x4 v[kPackPieces];
@@ -52,20 +56,23 @@ __global__ __launch_bounds__(256) void xwin_pack_kernel(jl_xw_pack_args a)
 #pragma unroll
     for (uint32_t k = 0; k < kPackPieces; ++k) {
         off[k] = (((uint64_t)blockIdx.x * kPackPieces + k) * 256u + threadIdx.x) * 16u;
-        // the source column continues past the slice (more reads, or the column's own padding): a whole 16-byte load
+        // the source row continues past the slice (more reads, or the row's own padding): a whole 16-byte load
         // below `bytes` is always inside it
         if (off[k] < bytes) v[k] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(src + off[k]));
     }
 #pragma unroll
     for (uint32_t k = 0; k < kPackPieces; ++k) {
         if (off[k] >= dst_stride) continue;
-        uint32_t w[4] = {0x66666666u, 0x66666666u, 0x66666666u, 0x66666666u};   // padding: 'not covered'
+        uint32_t w[4] = {padw, padw, padw, padw};
         if (off[k] < bytes) {
             w[0] = v[k].x; w[1] = v[k].y; w[2] = v[k].z; w[3] = v[k].w;
-            if (off[k] + 16u > bytes) {   // bytes past the slice's last read become padding
+            if (off[k] + 16u >= bytes) {   // the slice ends in this piece: what lies past its last read becomes padding
 #pragma unroll
-                for (uint32_t b = 0; b < 16u; ++b)
-                    if (off[k] + b >= bytes) w[b >> 2] = (w[b >> 2] & ~(0xFFu << (8u * (b & 3u)))) | (0x66u << (8u * (b & 3u)));
+                for (uint32_t b = 0; b < 16u; ++b) {
+                    const uint32_t sh = 8u * (b & 3u);
+                    if (off[k] + b >= bytes) w[b >> 2] = (w[b >> 2] & ~(0xFFu << sh)) | (pad << sh);
+                    else if (off[k] + b + 1u == bytes) w[b >> 2] = (w[b >> 2] & ~((0xFFu & ~tail_mask) << sh)) | ((pad & ~tail_mask & 0xFFu) << sh);
+                }
             }
         }
         *reinterpret_cast<uint4 *>(dst + off[k]) = make_uint4(w[0], w[1], w[2], w[3]);
@@ -152,7 +159,7 @@ void jl_launch_xw_pack(const jl_xw_pack_args *a, hipStream_t st)
     uint64_t max_stride = 0;
     for (uint32_t k = 0; k < a->n_dst; ++k) max_stride = a->d[k].dst_stride > max_stride ? a->d[k].dst_stride : max_stride;
     const uint32_t gx = (uint32_t)((max_stride + 16383u) / 16384u);
-    hipLaunchKernelGGL(xwin_pack_kernel, dim3(gx, 3u * a->n_pos, a->n_dst), dim3(256), 0, st, *a);
+    hipLaunchKernelGGL(xwin_pack_kernel, dim3(gx, 9u * a->n_pos, a->n_dst), dim3(256), 0, st, *a);
 }
 
 void jl_launch_xw_assign(const jl_xw_assign_args *a, const uint16_t *host_tab, const uint16_t *d_tab, hipStream_t st)

@@ -92,7 +92,8 @@ static inline int xwin_make_schedule(const uint32_t *win_begin, const uint32_t *
     return JL_OK;
 }
 
-static inline uint64_t xwin_stride(uint64_t n_reads) { return ((n_reads + 1) / 2 + 127) / 128 * 128; }
+// plane stride of a compact matrix of n_reads reads (= jl_plane_stride: whole 128-byte lines, 1024 reads each)
+static inline uint64_t xwin_stride(uint64_t n_reads) { return (n_reads + 1023) / 1024 * 128; }
 
 // ops of one rank in issue order: its own slice, then per peer (ascending) the send and the receive
 static inline void xwin_ops_of_rank(const xwin_schedule &sch, const uint64_t *slice_begin, int32_t world, int32_t rank,
@@ -108,8 +109,8 @@ static inline void xwin_ops_of_rank(const xwin_schedule &sch, const uint64_t *sl
         o.read_begin = slice_begin[receiver];
         o.n_reads = slice_begin[receiver + 1] - slice_begin[receiver];
         o.dst_stride = xwin_stride(o.n_reads);
-        o.bytes = 3ull * o.k_count * o.dst_stride;
-        o.dst_offset = 3ull * o.k_begin * o.dst_stride;
+        o.bytes = 9ull * o.k_count * o.dst_stride;   // nine plane rows per position
+        o.dst_offset = 9ull * o.k_begin * o.dst_stride;
         return o;
     };
     const uint64_t n_mine = slice_begin[rank + 1] - slice_begin[rank];

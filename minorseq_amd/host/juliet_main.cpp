@@ -517,6 +517,9 @@ void run_rank(RankJob &job, const DeviceStageInput &in, const std::vector<Window
 
 int main(int argc, char **argv)
 {
+    // eight hardware queues instead of the runtime's four (the rank threads' streams beside the exchange): read by the HIP
+    // runtime at the process's first HIP call, so set here, before any thread exists and before that call
+    setenv("GPU_MAX_HW_QUEUES", "8", 0);
     Options opt;
     std::string cmdline;
     for (int i = 0; i < argc; ++i) cmdline += (i ? " " : "") + std::string(argv[i]);

@@ -47,6 +47,9 @@ def test_pod_layouts():
     lib = capi.load_library()
     assert lib.jl_col_stride(1) == 128 and lib.jl_col_stride(256) == 128 and lib.jl_col_stride(257) == 256
     assert lib.jl_col_stride(100000) == 50048
+    # the resident planes: whole 128-byte lines, 1024 reads each; 3 bits per cell
+    assert lib.jl_plane_stride(1) == 128 and lib.jl_plane_stride(1024) == 128 and lib.jl_plane_stride(1025) == 256
+    assert lib.jl_plane_stride(100000) == 12544 and 3 * 3000 * lib.jl_plane_stride(100000) < 113e6
     assert lib.jl_strerror(0) == b"ok" and b"gfx950" in lib.jl_strerror(-2)
 
 
@@ -138,8 +141,8 @@ int main(void) {
     /* two ranks, one window each; both positions belong to rank 1's window except column 6 */
     if (jl_xwin_slice_plan(wb, wn, wr, 2, merged, 3, sb, 2, 0, ops, 5, &n_ops) != JL_OK || n_ops != 3) return 10;
     if (ops[0].op != JL_XWIN_OP_LOCAL || ops[1].op != JL_XWIN_OP_SEND || ops[2].op != JL_XWIN_OP_RECV) return 11;
-    if (ops[0].k_count != 2 || ops[1].peer != 1 || ops[1].n_reads != 488 || ops[1].dst_stride != 256 || ops[1].bytes != 3 * 2 * 256) return 12;
-    if (ops[2].k_begin != 2 || ops[2].k_count != 1 || ops[2].dst_stride != 256 || ops[2].dst_offset != 3 * 2 * 256) return 13;
+    if (ops[0].k_count != 2 || ops[1].peer != 1 || ops[1].n_reads != 488 || ops[1].dst_stride != 128 || ops[1].bytes != 9 * 2 * 128) return 12;
+    if (ops[2].k_begin != 2 || ops[2].k_count != 1 || ops[2].dst_stride != 128 || ops[2].dst_offset != 9 * 2 * 128) return 13;
     for (k = 0; k < n_ops; ++k) printf("%d:%d:%llu ", ops[k].op, ops[k].peer, (unsigned long long)ops[k].bytes);
     printf("\n");
     return 0;
@@ -160,4 +163,4 @@ def test_merge_and_schedule_from_c99(tmp_path):
                            "-Wl,-rpath-link,/opt/rocm/lib"])
     out = subprocess.run([str(exe)], capture_output=True, text=True)
     assert out.returncode == 0, (out.returncode, out.stdout, out.stderr)
-    assert out.stdout.strip() == "0:0:1536 1:1:1536 2:1:768"
+    assert out.stdout.strip() == "0:0:2304 1:1:2304 2:1:1152"

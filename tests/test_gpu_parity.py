@@ -1194,17 +1194,23 @@ def test_adopted_torch_tensor_and_caller_stream(oracle):
     """PyTorch as plumbing only: the resident matrix lives in a torch tensor (jl_msa_adopt) and all work of the
     context is enqueued on a torch stream the caller owns."""
     import torch
-    n, l = 5000, 300
+    n, l = 5300, 300
     sp = synth.SynthParams(seed=19, minor_permille=(70, 60, 50, 40), partial_rate=0.1)
     ref = synth.reference(sp.seed, l)
     rows = synth.rows(sp, l, 0, n, ref)
-    packed = msa.pack_columns(rows)
+    # the resident format itself (three bit planes per column), with a caller-chosen stride: any multiple of 16 bytes
+    # that holds the reads (the library's own matrices use whole 128-byte lines)
+    stride = (n + 7) // 8 + 15 & ~15
+    assert stride != msa.plane_stride(n)
+    packed = msa.pack_planes(rows, stride)
+    assert (msa.unpack_planes(packed, n) == rows).all()
     stream = torch.cuda.Stream()
     with torch.cuda.stream(stream):
         t = torch.from_numpy(packed).cuda(non_blocking=False)
     stream.synchronize()
     j = capi.Juliet(0, stream=stream.cuda_stream)
-    j.adopt(t.data_ptr(), n, l, packed.shape[1], keep_alive=t)
+    j.adopt(t.data_ptr(), n, l, stride, keep_alive=t)
+    assert (msa.unpack_columns(j.download_columns(), n) == rows).all()   # (the interchange format out of an adopted matrix)
     genes = np.array([(1, l + 1)], dtype=capi.GENE)
     out = j.run(genes, ref)
     exp_v = oracle.call(rows, genes, refseq=ref)
@@ -1215,25 +1221,25 @@ def test_adopted_torch_tensor_and_caller_stream(oracle):
     rows_ptr, cnt_ptr, cap = j.variant_table_device()
     assert cap == capi.VARIANT_CAP and rows_ptr and cnt_ptr
     stream.synchronize()
-    # The caller owns an adopted matrix and may rewrite it at any time: the library keeps no derived copy of it (the bit
-    # planes the counting kernel reads exist only for matrices the library wrote itself), so new reads in the same buffer
-    # give the new answer.  And the two counting kernels agree: the same reads uploaded (bit planes) give the same counts.
+    # The caller owns an adopted matrix and may rewrite it at any time: the library keeps no derived copy of anything, so
+    # new reads in the same buffer give the new answer.  And an adopted matrix (caller's stride) counts like the same
+    # reads uploaded through the interchange format (the library's stride).
     rows2 = synth.rows(synth.SynthParams(seed=23, minor_permille=(90, 30, 20, 10), partial_rate=0.3), l, 0, n, ref)
     with torch.cuda.stream(stream):
-        t.copy_(torch.from_numpy(msa.pack_columns(rows2)))
+        t.copy_(torch.from_numpy(msa.pack_planes(rows2, stride)))
     stream.synchronize()
     out2 = j.run(genes, ref)
     exp2 = oracle.call(rows2, genes, refseq=ref)
     assert_variants_equal(out2["variants"], exp2)
     assert_phase_equal(out2["phase"], oracle.phase(rows2, exp2), len(exp2))
     j.pileup_async(genes, ref)
-    from_nibbles = j.pileup_fetch()
+    from_adopted = j.pileup_fetch()
     k = capi.Juliet(0)
     k.upload_columns(msa.pack_columns(rows2), n)
     k.pileup_async(genes, ref)
-    from_planes = k.pileup_fetch()
-    for key in from_nibbles:
-        assert (from_nibbles[key] == from_planes[key]).all(), key
+    from_upload = k.pileup_fetch()
+    for key in from_adopted:
+        assert (from_adopted[key] == from_upload[key]).all(), key
     k.close()
     j.close()
     del t

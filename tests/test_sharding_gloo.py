@@ -171,22 +171,23 @@ def _slice_groups(compact):
     return dict(patterns=uniq[order], counts=counts[order].astype(np.uint32), summary=summary), dirty, group_of_clean
 
 
-def _run_ops(ops, rank, packed_window, win_begin, pos, n_mine):
+def _run_ops(ops, rank, planes_window, win_begin, pos, n_mine):
     """Executes one rank's op list (jl_xwin_slice_plan) with gloo point-to-point calls IN LIST ORDER: what
-    jl_xwin_phase_sharded does with the pack kernel, ncclSend and ncclRecv.  `packed_window`: this rank's window in the
-    device layout (msa.pack_columns).  Returns the compact matrix of the rank's slice, by rows."""
+    jl_xwin_phase_sharded does with the pack kernel, ncclSend and ncclRecv.  `planes_window`: this rank's window in the
+    device layout (msa.pack_planes: [column][plane][bytes]).  Returns the compact matrix of the rank's slice, by rows."""
     import torch
-    stride_me = msa.col_stride(n_mine) if n_mine else 0
-    compact = np.full(3 * len(pos) * stride_me, 0x66, dtype=np.uint8)
+    stride_me = msa.plane_stride(n_mine) if n_mine else 0
+    pad_rows = np.array([0x00, 0xFF, 0xFF] * 3, dtype=np.uint8)   # 'not covered' = code 6: plane 0 clear, planes 1 and 2 set
+    compact = np.tile(np.repeat(pad_rows, stride_me), len(pos)) if stride_me else np.zeros(0, dtype=np.uint8)
     pending, keep = [], []
 
-    def message(op):   # slice [read_begin, +n_reads) of the 3 * k_count owned columns, each padded to dst_stride with 'not covered'
-        msg = np.full((3 * op["k_count"], op["dst_stride"]), 0x66, dtype=np.uint8)
-        b0, nb = op["read_begin"] // 2, (op["n_reads"] + 1) // 2
+    def message(op):   # slice [read_begin, +n_reads) of the 9 * k_count plane rows of the owned columns, each padded to dst_stride
+        msg = np.tile(pad_rows[:, None], (op["k_count"], op["dst_stride"]))
+        b0, nb = op["read_begin"] // 8, (op["n_reads"] + 7) // 8
         for i in range(op["k_count"]):
             c = int(pos[op["k_begin"] + i]) - win_begin
-            msg[3 * i: 3 * i + 3, :nb] = packed_window[c: c + 3, b0: b0 + nb]
-        assert msg.size == op["bytes"]
+            msg[9 * i: 9 * i + 9, :nb] = planes_window[c: c + 3, :, b0: b0 + nb].reshape(9, nb)
+        assert msg.size == op["bytes"] and op["dst_stride"] == msa.plane_stride(op["n_reads"])
         return msg.reshape(-1)
 
     for op in ops:
@@ -205,7 +206,7 @@ def _run_ops(ops, rank, packed_window, win_begin, pos, n_mine):
             compact[op["dst_offset"]: op["dst_offset"] + op["bytes"]] = t.numpy()
     if not n_mine:
         return np.zeros((0, 3 * len(pos)), dtype=np.uint8)
-    return msa.unpack_columns(compact.reshape(3 * len(pos), stride_me), n_mine)
+    return msa.unpack_planes(compact.reshape(3 * len(pos), 3, stride_me), n_mine)
 
 
 def _sharded_phase_worker(rank, world, port, q):
@@ -231,7 +232,7 @@ def _sharded_phase_worker(rank, world, port, q):
         assert sb[0] == 0 and sb[-1] == N and all(sb[k] % 256 == 0 for k in range(world) if sb[k + 1] > sb[k])
         n_mine = sb[rank + 1] - sb[rank]
         ops = capi.xwin_slice_plan(wbeg, wnc, list(range(world)), merged, sb, world, rank)
-        compact = _run_ops(ops, rank, msa.pack_columns(mine), b, pos, n_mine)
+        compact = _run_ops(ops, rank, msa.pack_planes(mine), b, pos, n_mine)
         table, dirty, group_of_clean = _slice_groups(compact)
         tables = sharding.allgather_groups(table)
         patterns, counts, index = sharding.merge_groups(tables)
