@@ -160,7 +160,8 @@ int jl_msa_pack_rows(jl_ctx *ctx, const uint8_t *rows, uint64_t n_reads, uint32_
  * J:53), insertions dropped and deletions '-' (J:26-27), optional QV masking to N (J:256-259), transpose.
  * pos[r]: 0-based leftmost reference position; cigar words are BAM's (len << 4 | op), read r owns
  * cigar[cig_off[r] .. cig_off[r+1]); seq4 holds BAM's 4-bit bases, read r starting at byte seq_off[r];
- * qual (optional, with qual_off) one byte per base, 0xFF = absent; bases with qual < min_qv become N.
+ * qual (optional, with qual_off) one byte per base, 0xFF = absent; bases with qual < min_qv become N (min_qv is
+ * taken as at most 127: BAM qualities end at 93).
  */
 int jl_msa_ingest_records(jl_ctx *ctx, uint64_t n_reads, uint32_t n_cols, uint32_t win_begin, const int32_t *pos,
                           const uint32_t *cigar, const uint64_t *cig_off, const uint8_t *seq4, const uint64_t *seq_off,
@@ -183,6 +184,10 @@ int jl_records_finish(jl_ctx *ctx, uint32_t n_cols, uint32_t win_begin, uint32_t
  * of `window` — another context of the same device — from the records appended to `records`, which stay until
  * jl_records_drop (or jl_records_finish on `records` itself). */
 int jl_records_window(jl_ctx *records, jl_ctx *window, uint32_t n_cols, uint32_t win_begin, uint32_t min_qv);
+/* The same, enqueued only (three launches on the window's stream, no allocation once a window of this shape was built on
+ * `window`): the matrix is complete when the window's stream gets there, so a run enqueued behind it (jl_run_async on
+ * `window`) reads it — records -> planes -> call + phase without a host round trip in between. */
+int jl_records_window_async(jl_ctx *records, jl_ctx *window, uint32_t n_cols, uint32_t win_begin, uint32_t min_qv);
 int jl_records_drop(jl_ctx *records);
 /*
  * Insertions are not part of the matrix (J:26-27) but `fuse` "includes in-frame insertions with a certain distance to

@@ -30,7 +30,7 @@ SUMMARY = np.dtype([(n, "<u4") for n in SUMMARY_FIELDS])
 # every symbol include/juliet_hip.h declares (checked by tests/test_capi_exports.py)
 EXPORTS = ("jl_abi_version", "jl_strerror", "jl_device_count", "jl_ctx_create", "jl_ctx_destroy", "jl_last_error",
            "jl_sync", "jl_col_stride", "jl_plane_stride", "jl_msa_upload", "jl_msa_alloc", "jl_msa_adopt", "jl_msa_pack_rows",
-           "jl_msa_ingest_records", "jl_records_begin", "jl_records_append", "jl_records_finish", "jl_records_window", "jl_records_drop", "jl_msa_track_insertions", "jl_insertions_fetch", "jl_msa_download", "jl_synth_fill", "jl_synth_fill_window", "jl_pileup_async", "jl_n_positions", "jl_pileup_fetch",
+           "jl_msa_ingest_records", "jl_records_begin", "jl_records_append", "jl_records_finish", "jl_records_window", "jl_records_window_async", "jl_records_drop", "jl_msa_track_insertions", "jl_insertions_fetch", "jl_msa_download", "jl_synth_fill", "jl_synth_fill_window", "jl_pileup_async", "jl_n_positions", "jl_pileup_fetch",
            "jl_consensus_fetch", "jl_call_async", "jl_call_fetch", "jl_variant_table_device", "jl_phase_async", "jl_phase_fetch",
            "jl_ctx_stream", "jl_run_async", "jl_run_wait", "jl_run_done", "jl_run_view_get", "jl_group_create", "jl_group_destroy",
            "jl_group_last_error", "jl_group_run_async", "jl_group_run_masked_async", "jl_group_views", "jl_group_time_pileup", "jl_fisher_eval", "jl_fisher_eval_tail", "jl_expand_read_hap", "jl_time_pileup", "jl_time_pileup_set", "jl_pileup_kernel_name", "jl_comm_unique_id", "jl_comm_create", "jl_comm_create_inproc", "jl_comm_destroy",
@@ -171,6 +171,7 @@ def load_library(path=LIB_PATH):
     lib.jl_records_append.argtypes = [vp, u64] + [vp] * 7
     lib.jl_records_finish.argtypes = [vp, u32, u32, u32]
     lib.jl_records_window.argtypes = [vp, vp, u32, u32, u32]
+    lib.jl_records_window_async.argtypes = [vp, vp, u32, u32, u32]
     lib.jl_records_drop.argtypes = [vp]
     lib.jl_msa_track_insertions.argtypes = [vp, C.c_int]
     lib.jl_insertions_fetch.argtypes = [vp, vp, vp]
@@ -365,6 +366,32 @@ class Juliet:
                                                  _p(so), _p(qual), _p(qo)))
         self._chk(self.lib.jl_records_finish(self.h, n_cols, win_begin, min_qv))
         self._shape(n, n_cols)
+
+    def records_upload(self, pos, cigar, cig_off, seq4, seq_off, qual=None, qual_off=None):
+        """jl_records_begin + one jl_records_append: the records stay resident on this context (for records_window /
+        records_window_async on other contexts of the device) until records_drop."""
+        pos = np.ascontiguousarray(pos, dtype=np.int32)
+        cigar = np.ascontiguousarray(cigar, dtype=np.uint32)
+        cig_off = np.ascontiguousarray(cig_off, dtype=np.uint64)
+        seq4 = np.ascontiguousarray(seq4, dtype=np.uint8)
+        seq_off = np.ascontiguousarray(seq_off, dtype=np.uint64)
+        if qual is not None:
+            qual = np.ascontiguousarray(qual, dtype=np.uint8)
+            qual_off = np.ascontiguousarray(qual_off, dtype=np.uint64)
+        n = len(pos)
+        self._chk(self.lib.jl_records_begin(self.h, n, len(cigar), len(seq4), len(qual) if qual is not None else 0))
+        self._chk(self.lib.jl_records_append(self.h, n, _p(pos), _p(cigar), _p(cig_off), _p(seq4), _p(seq_off), _p(qual), _p(qual_off)))
+        self._n_records = n
+
+    def records_window(self, records, n_cols, win_begin=0, min_qv=0, wait=True):
+        """This context's resident matrix from the records uploaded to `records` (another context of the device);
+        wait=False only enqueues the build on this context's stream (jl_records_window_async)."""
+        fn = self.lib.jl_records_window if wait else self.lib.jl_records_window_async
+        self._chk(fn(records.h, self.h, n_cols, win_begin, min_qv))
+        self._shape(records._n_records, n_cols)
+
+    def records_drop(self):
+        self._chk(self.lib.jl_records_drop(self.h))
 
     def track_insertions(self, on=True):
         self._chk(self.lib.jl_msa_track_insertions(self.h, 1 if on else 0))

@@ -160,7 +160,8 @@ void jl_ctx_destroy(jl_ctx *ctx)
                     ctx->d_col2pos, ctx->d_varcol, ctx->d_keys, ctx->d_flagw, ctx->d_read_slot, ctx->d_read_hap,
                     ctx->d_slot_rep, ctx->d_slot_count, ctx->d_slot_key, ctx->d_slot_hap, ctx->d_occupied, ctx->d_hap_count,
                     ctx->d_hap_pattern, ctx->d_hit, ctx->d_cooc, ctx->d_pack, ctx->d_sync, ctx->d_timeline,
-                    ctx->d_ins_len, ctx->d_ins_base, ctx->d_exp_count,
+                    ctx->d_ins_len, ctx->d_ins_base, ctx->d_ing_runs, ctx->d_ing_nruns, ctx->d_ing_first, ctx->d_ing_count, ctx->d_ing_slow,
+                    ctx->d_exp_count,
                     ctx->d_exp_pattern, ctx->d_exp_hap, ctx->d_blockcat, ctx->d_slot_key_a, ctx->d_slot_key_b, ctx->d_occ_a, ctx->d_occ_b};
     for (void *p : ptrs)
         if (p) hipFree(p);
@@ -340,7 +341,7 @@ int jl_records_begin(jl_ctx *ctx, uint64_t reads_hint, uint64_t cigar_words_hint
     if (e == hipSuccess) e = records_room(ctx, r.d_so, r.cap_so, 0, (size_t)reads_hint + 1, 0);
     if (e == hipSuccess) e = records_room(ctx, r.d_cig, r.cap_cig, 0, (size_t)cigar_words_hint, 0);
     if (e == hipSuccess) e = records_room(ctx, r.d_seq, r.cap_seq, 0, (size_t)seq_bytes_hint, 16);
-    if (e == hipSuccess && qual_bytes_hint) e = records_room(ctx, r.d_qual, r.cap_qual, 0, (size_t)qual_bytes_hint, 0);
+    if (e == hipSuccess && qual_bytes_hint) e = records_room(ctx, r.d_qual, r.cap_qual, 0, (size_t)qual_bytes_hint, 64);
     if (e == hipSuccess && qual_bytes_hint) e = records_room(ctx, r.d_qo, r.cap_qo, 0, (size_t)reads_hint + 1, 0);
     if (e != hipSuccess) {
         records_drop(ctx);
@@ -395,7 +396,7 @@ int jl_records_append(jl_ctx *ctx, uint64_t n_reads, const int32_t *pos, const u
     if (e == hipSuccess) e = records_room(ctx, R.d_cig, R.cap_cig, (size_t)R.n_cig, (size_t)R.n_cig + n_cig, 0);
     // the kernel reads the bases a dword at a time and one dword ahead: 16 bytes of padding behind them
     if (e == hipSuccess) e = records_room(ctx, R.d_seq, R.cap_seq, (size_t)R.n_seq, (size_t)R.n_seq + n_seq, 16);
-    if (e == hipSuccess && qual) e = records_room(ctx, R.d_qual, R.cap_qual, (size_t)R.n_qual, (size_t)R.n_qual + n_q, 0);
+    if (e == hipSuccess && qual) e = records_room(ctx, R.d_qual, R.cap_qual, (size_t)R.n_qual, (size_t)R.n_qual + n_q, 64);
     if (e == hipSuccess && qual) e = records_room(ctx, R.d_qo, R.cap_qo, nr + 1, nr + n_reads + 1, 0);
     std::vector<uint64_t> off((size_t)(n_reads + 1) * (qual ? 3 : 2));
     uint64_t *co = off.data(), *so = co + n_reads + 1, *qo = so + n_reads + 1;
@@ -428,15 +429,33 @@ int jl_records_append(jl_ctx *ctx, uint64_t n_reads, const int32_t *pos, const u
     return JL_OK;
 }
 
+// room for `n` elements of `elem` bytes in one of the ingest's scratch arrays of `ctx` (grow-only; the old contents are not kept)
+static hipError_t ingest_room_bytes(jl_ctx *ctx, void **d, size_t *cap, size_t elem, size_t n)
+{
+    if (*d && *cap >= n) return hipSuccess;
+    if (*d) {
+        hipError_t e = hipStreamSynchronize(ctx->stream);   // an earlier build may still read it
+        if (e != hipSuccess) return e;
+        hipFree(*d);
+    }
+    *d = nullptr;
+    *cap = 0;
+    const size_t want = n + n / 8 + 64;
+    hipError_t e = hipMalloc(d, want * elem);
+    if (e == hipSuccess) *cap = want;
+    return e;
+}
+#define ingest_room(ctx, d, cap, n) ingest_room_bytes(ctx, (void **)(d), cap, sizeof(**(d)), n)
+
 // The resident matrix of `dst` from the records uploaded to `src` (the same context for jl_records_finish; another one of
-// the same device when one upload feeds several column windows).  The records stay.
-static int records_build(jl_ctx *src, jl_ctx *dst, uint32_t n_cols, uint32_t win_begin, uint32_t min_qv)
+// the same device when one upload feeds several column windows).  The records stay.  Everything is ENQUEUED on dst's
+// stream (three launches + the insertion counters when asked for); `wait`: return when it has run.
+static int records_build(jl_ctx *src, jl_ctx *dst, uint32_t n_cols, uint32_t win_begin, uint32_t min_qv, bool wait)
 {
     jl_records &R = src->rec;
     int rc = jl_msa_alloc(dst, R.n_reads, n_cols, win_begin);
     if (rc) return rc;
     hipStream_t st = dst->stream;
-    uint32_t *d_rows4 = nullptr;
     hipError_t e = hipSuccess;
     if (!R.n_reads) {   // nothing was appended: the offset arrays still need their first entry
         e = records_room(src, R.d_co, R.cap_co, 0, 1, 0);
@@ -447,8 +466,13 @@ static int records_build(jl_ctx *src, jl_ctx *dst, uint32_t n_cols, uint32_t win
         if (e == hipSuccess) e = hipMemsetAsync(R.d_co, 0, 8, st);
         if (e == hipSuccess) e = hipMemsetAsync(R.d_so, 0, 8, st);
     }
-    if (e == hipSuccess) e = hipMalloc(&d_rows4, (size_t)jl_ingest_batch_reads(dst) * jl_ingest_row_dwords(dst) * 4);
-    if (e == hipSuccess) e = hipMemsetAsync(R.d_seq + R.n_seq, 0, 16, st);
+    const uint32_t ns = jl_ingest_sweeps(n_cols);
+    const size_t nr = (size_t)R.n_reads;
+    if (e == hipSuccess) e = ingest_room(dst, &dst->d_ing_runs, &dst->ing_cap_runs, (size_t)R.n_cig + nr + 1);
+    if (e == hipSuccess) e = ingest_room(dst, &dst->d_ing_nruns, &dst->ing_cap_reads, nr + 1);
+    if (e == hipSuccess) e = ingest_room(dst, &dst->d_ing_first, &dst->ing_cap_first, (nr + 1) * (ns + 1));
+    if (e == hipSuccess) e = ingest_room(dst, &dst->d_ing_slow, &dst->ing_cap_slow, (nr + 1) * ns);
+    if (e == hipSuccess && !dst->d_ing_count) e = hipMalloc(&dst->d_ing_count, 64);
     dst->ins_valid = false;
     if (e == hipSuccess && dst->track_insertions) {
         if (dst->ins_capacity < n_cols) {
@@ -470,11 +494,11 @@ static int records_build(jl_ctx *src, jl_ctx *dst, uint32_t n_cols, uint32_t win
     }
     if (e == hipSuccess) {
         jl_launch_ingest(dst, R.d_pos, R.d_cig, R.d_co, R.d_seq, R.d_so, R.have_qual ? R.d_qual : nullptr,
-                         R.have_qual ? R.d_qo : nullptr, min_qv, d_rows4, R.max_ops, R.max_seq_bytes);
+                         R.have_qual ? R.d_qo : nullptr, min_qv, dst->d_ing_runs, dst->d_ing_nruns, dst->d_ing_first, dst->d_ing_count,
+                         dst->d_ing_slow);
         e = hipGetLastError();
-        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e == hipSuccess && wait) e = hipStreamSynchronize(st);
     }
-    if (d_rows4) hipFree(d_rows4);
     if (e != hipSuccess) return jl_fail(dst, e == hipErrorOutOfMemory ? JL_ERR_MEMORY : JL_ERR_DEVICE, "ingest: %s", hipGetErrorString(e));
     return JL_OK;
 }
@@ -484,7 +508,7 @@ int jl_records_finish(jl_ctx *ctx, uint32_t n_cols, uint32_t win_begin, uint32_t
     if (!ctx) return JL_ERR_ARG;
     if (!ctx->rec.open) return jl_fail(ctx, JL_ERR_STATE, "jl_records_finish before jl_records_begin");
     JL_HIP(ctx, hipSetDevice(ctx->device));
-    const int rc = records_build(ctx, ctx, n_cols, win_begin, min_qv);
+    const int rc = records_build(ctx, ctx, n_cols, win_begin, min_qv, true);
     records_drop(ctx);
     return rc;
 }
@@ -496,7 +520,18 @@ int jl_records_window(jl_ctx *records, jl_ctx *window, uint32_t n_cols, uint32_t
     if (records->device != window->device) return jl_fail(window, JL_ERR_ARG, "records and window are on different devices");
     JL_HIP(window, hipSetDevice(window->device));
     JL_HIP(window, hipStreamSynchronize(records->stream));   // the uploads are complete
-    return records_build(records, window, n_cols, win_begin, min_qv);
+    return records_build(records, window, n_cols, win_begin, min_qv, true);
+}
+
+// The same, enqueued only: the window's matrix is complete when the window's stream reaches this point — a run enqueued
+// behind it on that stream (jl_run_async) reads it.  No allocation once a window of this shape has been built on `window`.
+int jl_records_window_async(jl_ctx *records, jl_ctx *window, uint32_t n_cols, uint32_t win_begin, uint32_t min_qv)
+{
+    if (!records || !window) return JL_ERR_ARG;
+    if (!records->rec.open) return jl_fail(window, JL_ERR_STATE, "jl_records_window_async: no records uploaded (jl_records_begin / _append)");
+    if (records->device != window->device) return jl_fail(window, JL_ERR_ARG, "records and window are on different devices");
+    JL_HIP(window, hipSetDevice(window->device));
+    return records_build(records, window, n_cols, win_begin, min_qv, false);
 }
 
 int jl_records_drop(jl_ctx *ctx)

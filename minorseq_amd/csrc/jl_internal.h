@@ -29,7 +29,7 @@
 #define JL_INS_LEN_BINS 32u        // insertion lengths 0..30 by value, 31 = longer
 #define JL_INS_MAX_BASES 30u       // inserted bases tracked per insertion
 #define JL_GUESS_PAD 32u           // zero bytes after the last column's seed base
-#define JL_PILEUP_TILE_BYTES 4096u  // bytes of one column a 256-thread block reads per iteration (16 B / lane)
+#define JL_INGEST_SWEEP 224u        // columns a workgroup of the record ingest expands at a time (kernels_ingest.hip)
 
 
 // resolved reference codon per position
@@ -319,6 +319,12 @@ struct jl_ctx {
 
     // ---- aligned records on their way in (jl_records_begin / _append / _finish)
     jl_records rec;
+    // scratch of the record ingest INTO this context (kernels_ingest.hip), kept between builds: the reads' runs, the run at
+    // every sweep's first column, the (read, sweep) pairs left to the slow kernel behind their counter
+    uint2 *d_ing_runs = nullptr;
+    uint32_t *d_ing_nruns = nullptr, *d_ing_first = nullptr, *d_ing_count = nullptr;
+    uint2 *d_ing_slow = nullptr;
+    size_t ing_cap_runs = 0, ing_cap_reads = 0, ing_cap_first = 0, ing_cap_slow = 0;
 
     // ---- phasing sharded by reads: the groups of this matrix exported for the merge (jl_phase_groups_async / _fetch)
     bool phase_export = false;        // the phase launch in flight / last run exported instead of selecting
@@ -482,10 +488,10 @@ extern "C" int jl_run_wait_seq(jl_ctx *ctx, uint32_t want);
 void jl_launch_consensus(jl_ctx *ctx, uint8_t *d_out);
 void jl_launch_ingest(jl_ctx *ctx, const int32_t *d_pos, const uint32_t *d_cigar, const uint64_t *d_cig_off,
                       const uint8_t *d_seq4, const uint64_t *d_seq_off, const uint8_t *d_qual,
-                      const uint64_t *d_qual_off, uint32_t min_qv, uint32_t *d_rows4, uint64_t max_ops, uint64_t max_seq_bytes);
-uint32_t jl_ingest_row_dwords(const jl_ctx *ctx);
+                      const uint64_t *d_qual_off, uint32_t min_qv, uint2 *d_runs, uint32_t *d_nruns, uint32_t *d_first,
+                      uint32_t *d_slow_count, uint2 *d_slow);
+uint32_t jl_ingest_sweeps(uint32_t n_cols);
 void jl_launch_regroup(jl_ctx *ctx, const uint16_t *d_hap_of_group, uint32_t n_groups, uint32_t n_haplotypes, bool phased);
-uint64_t jl_ingest_batch_reads(const jl_ctx *ctx);
 void jl_launch_insertions(jl_ctx *ctx, const int32_t *d_pos, const uint32_t *d_cigar, const uint64_t *d_cig_off,
                           const uint8_t *d_seq4, const uint64_t *d_seq_off);
 void jl_launch_fisher_eval(jl_ctx *ctx, uint32_t n, const uint32_t *a, const uint32_t *c, const uint32_t *cov, int tail,

@@ -1,0 +1,567 @@
+// kernels_ingest.hip — aligned BAM records -> the resident bit planes, entirely on the device.
+//
+// Behaviour: doc/JULIET.md:26-27 (insertions dropped, deletions '-'), :53 (PacBio cigars = X I D S H N; M is rejected on the
+// host), :256-259 (a QV-filtered base shows up as N).  Reads past n_reads (the padding of a plane up to its stride) and
+// columns outside a read's span are 'not covered' (code 6).
+//
+// Three launches, no by-row scratch in HBM (rounds 1-3 expanded every read into a by-row nibble matrix, transposed that
+// into a column-packed one and made the planes from it: 870 MB moved for the 270 MB that are needed):
+//   cigar_runs_kernel   one wave per read: prefix sums over the cigar -> the read's RUNS (stretches of '=' / 'X' merge into one
+//                       run of aligned bases; D and N are runs of their own; I / S / H / P only end a run), 8 bytes each, plus
+//                       for every column sweep of the window the index of the run that contains its first column.
+//   ingest_planes_kernel  one workgroup = 256 reads x one sweep of 224 columns.  It loads the handful of runs its reads have
+//                       in the sweep into LDS, then works INPUT-driven: a lane takes 16 aligned bytes = 32 bases of a read
+//                       straight from HBM (coalesced, all of a wave's loads in flight before the first is used), converts
+//                       them to symbol codes nibble-parallel, finds the run(s) they belong to and XORs them — shifted to
+//                       their columns — into a by-row nibble tile in LDS that starts out as 'not covered' (a cell is
+//                       written by exactly one run, so XOR against the initial code stores it; deletions are XORed in by a
+//                       pass over the D runs; reference skips need nothing).  The tile then leaves as planes: a thread
+//                       takes 32 reads x 8 columns, transposes four 8 x 8 nibble blocks in registers, splits the codes into
+//                       their three bits and stores a dword of each plane of each column; the four workgroups that share
+//                       the 128-byte lines of a sweep run on one XCD next to each other (blockIdx mapping), so the lines
+//                       are completed in that XCD's L2.
+//   ingest_slow_kernel  the (read, sweep) pairs a workgroup could not take — more runs in one sweep than its LDS list
+//                       holds (a deletion every other column), a huge insertion inside a sweep: column by column from the
+//                       runs in HBM, bits flipped with atomics.  Empty for real CCS data.
+#include <algorithm>
+
+#include "jl_internal.h"
+
+namespace {
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr uint32_t kSweep = JL_INGEST_SWEEP;        // columns per workgroup
+constexpr uint32_t kSweepDw = kSweep / 8u;          // dwords of 8 columns in a tile row
+constexpr uint32_t kTileReads = 256u;
+// tile row of read r (0..255) at (r & 31) * kRowI + (r >> 5) * kSweepDw: the eight reads a wave expands together lie one
+// bank apart, the 32 reads x 8 lanes of the transposing step lie four banks apart (see the T phase)
+constexpr uint32_t kRowI = 8u * kSweepDw + 1u;
+constexpr uint32_t kTileDw = 32u * kRowI;
+constexpr uint32_t kEntCap = 2048u;                 // run entries of the workgroup's reads in its sweep (LDS)
+constexpr uint32_t kRunMask = 0x3FFFFFFFu;          // reference offset of a run; kind in the two bits above
+constexpr uint32_t kMaxPieces = 1023u;
+static_assert(kSweep % 8u == 0 && kSweepDw <= 32u, "a sweep is at most 32 dwords wide");
+
+__device__ __forceinline__ bool cig_ref(uint32_t op) { return op == 2u || op == 3u || op == 7u || op == 8u; }    // D N = X
+__device__ __forceinline__ bool cig_query(uint32_t op) { return op == 1u || op == 4u || op == 7u || op == 8u; }  // I S = X
+
+// eight BAM base codes (nt16: A=1 C=2 G=4 T=8, everything else ambiguous) -> symbol codes 0..3 / 5, nibble-parallel
+__device__ __forceinline__ uint32_t nt16_to_sym8(uint32_t w)
+{
+    const uint32_t m = 0x11111111u;
+    const uint32_t b0 = w & m, b1 = (w >> 1) & m, b2 = (w >> 2) & m, b3 = (w >> 3) & m;
+    const uint32_t cnt = b0 + b1 + b2 + b3;          // set bits per nibble, 0..4
+    const uint32_t idx = b1 + 2u * b2 + 3u * b3;     // one-hot -> 0..3
+    const uint32_t t = cnt ^ m;                      // non-zero where the nibble is not one-hot
+    const uint32_t bad = (t | (t >> 1) | (t >> 2)) & m;
+    return (idx & ~(bad * 15u)) | (bad * 5u);
+}
+
+// ---------------------------------------------------------------------------------------- runs
+// runs[cig_off[r] + r + i] = {reference offset of run i relative to the read's first base | kind << 30, query offset};
+// kind 1 aligned bases, 2 deletion, 3 reference skip; entry n_runs = {the read's reference length, its query length}.
+// first_run[r][s], s = 0 .. n_sweeps: the number of runs i >= 1 (the end entry included) that begin at or before window
+// column s * kSweep = the index of the run that contains that column (0 before the read, n_runs behind it).
+__global__ __launch_bounds__(256) void cigar_runs_kernel(uint64_t n_reads, const int32_t *__restrict__ pos, const uint32_t *__restrict__ cigar,
+                                                         const uint64_t *__restrict__ cig_off, uint32_t win_begin, uint32_t n_cols,
+                                                         uint32_t n_sweeps, uint2 *__restrict__ runs, uint32_t *__restrict__ nruns,
+                                                         uint32_t *__restrict__ first_run)
+{
+    extern __shared__ uint32_t s_dyn[];
+    const uint32_t wid = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint64_t r = (uint64_t)blockIdx.x * 4u + wid;
+    if (r >= n_reads) return;
+    uint32_t *hist = s_dyn + (size_t)wid * (n_sweeps + 2u);
+    for (uint32_t s = lane; s < n_sweeps + 2u; s += 64u) hist[s] = 0;
+    const uint64_t c_beg = cig_off[r], c_end = cig_off[r + 1];
+    uint2 *out = runs + c_beg + r;
+    const int64_t base = (int64_t)pos[r] - (int64_t)win_begin;
+    auto sweep_of = [&](uint32_t rb) -> uint32_t {   // first sweep whose first column is at or behind the run's start
+        const int64_t w = base + (int64_t)rb;
+        if (w <= 0) return 0u;
+        const uint64_t s = ((uint64_t)w + kSweep - 1u) / kSweep;
+        return s > n_sweeps ? n_sweeps + 1u : (uint32_t)s;
+    };
+    uint32_t n_runs = 0, prev_kind = 0, ref_carry = 0, q_carry = 0;
+    for (uint64_t k0 = c_beg; k0 < c_end; k0 += 64u) {
+        const uint64_t k = k0 + lane;
+        const bool live = k < c_end;
+        const uint32_t cw = live ? cigar[k] : 0u;
+        const uint32_t op = cw & 15u, len = cw >> 4;
+        const uint32_t rl = (live && cig_ref(op)) ? len : 0u, ql = (live && cig_query(op)) ? len : 0u;
+        uint32_t ri = rl, qi = ql;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t ur = __shfl_up(ri, o, 64), uq = __shfl_up(qi, o, 64);
+            if ((int)lane >= o) { ri += ur; qi += uq; }
+        }
+        const uint32_t kind = !live ? 0u : (op == 7u || op == 8u) ? 1u : op == 2u ? 2u : op == 3u ? 3u : 0u;
+        uint32_t before = __shfl_up(kind, 1, 64);
+        if (lane == 0) before = prev_kind;
+        const bool starts = kind != 0u && len != 0u && !(kind == 1u && before == 1u);
+        const uint64_t bal = __ballot(starts);
+        if (starts) {
+            const uint32_t idx = n_runs + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+            const uint32_t rb = (ref_carry + ri - rl) & kRunMask;
+            out[idx] = make_uint2(rb | (kind << 30), q_carry + qi - ql);
+            if (idx >= 1u) atomicAdd(&hist[sweep_of(rb)], 1u);
+        }
+        n_runs += (uint32_t)__popcll(bal);
+        prev_kind = __shfl(kind, 63, 64);
+        ref_carry += __shfl(ri, 63, 64);
+        q_carry += __shfl(qi, 63, 64);
+    }
+    if (lane == 0) {
+        out[n_runs] = make_uint2(ref_carry & kRunMask, q_carry);
+        nruns[r] = n_runs;
+        if (n_runs) atomicAdd(&hist[sweep_of(ref_carry & kRunMask)], 1u);
+    }
+    __builtin_amdgcn_wave_barrier();
+    uint32_t carry = 0;
+    for (uint32_t s0 = 0; s0 <= n_sweeps; s0 += 64u) {
+        const uint32_t s = s0 + lane;
+        uint32_t v = s <= n_sweeps ? hist[s] : 0u;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t u = __shfl_up(v, o, 64);
+            if ((int)lane >= o) v += u;
+        }
+        if (s <= n_sweeps) first_run[r * (uint64_t)(n_sweeps + 1u) + s] = carry + v;
+        carry += __shfl(v, 63, 64);
+    }
+}
+
+// ---------------------------------------------------------------------------------------- the planes of one sweep
+struct read_info {     // what the expansion needs of one read of the tile (LDS)
+    int32_t base;      // window column of the read's first reference base
+    uint32_t ent;      // first entry in s_ent (bits 0-11) | entries (12-21) | pieces (22-31)
+    uint32_t p0_lo, p0_hi;   // byte offset, within the packed bases, of the read's first 16-byte piece in this sweep
+    int32_t q0;        // query offset of that piece's first base (>= -30: a piece may begin inside the previous read)
+    uint32_t pad_;
+};
+
+// 8 x 8 nibbles held as 8 dwords (row i = m[i], element j at bits 4j) -> their transpose
+__device__ __forceinline__ void transpose_nibbles_8x8(uint32_t (&m)[8])
+{
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t a = m[i], b = m[i + 4];
+        m[i] = (a & 0x0000FFFFu) | (b << 16);
+        m[i + 4] = (a >> 16) | (b & 0xFFFF0000u);
+    }
+#pragma unroll
+    for (int h = 0; h < 8; h += 4)
+#pragma unroll
+        for (int i = h; i < h + 2; ++i) {
+            const uint32_t a = m[i], b = m[i + 2];
+            m[i] = (a & 0x00FF00FFu) | ((b & 0x00FF00FFu) << 8);
+            m[i + 2] = ((a >> 8) & 0x00FF00FFu) | (b & 0xFF00FF00u);
+        }
+#pragma unroll
+    for (int i = 0; i < 8; i += 2) {
+        const uint32_t a = m[i], b = m[i + 1];
+        m[i] = (a & 0x0F0F0F0Fu) | ((b & 0x0F0F0F0Fu) << 4);
+        m[i + 1] = ((a >> 4) & 0x0F0F0F0Fu) | (b & 0xF0F0F0F0u);
+    }
+}
+
+// 32 reads x 8 columns, R[i] = the 8 codes (nibbles) of read i -> out[j][k] = plane k of column j, bit i = read i.
+// Four 8 x 8 nibble transposes — block g holds reads g, g + 4, ..., g + 28, so that after it nibble n of M[g][j] is read
+// 4 n + g at column j — then bit k of the four blocks' nibbles interleaves into the 32 read bits with four and-or steps.
+__device__ __forceinline__ void nibble_rows_to_plane_words(const uint32_t (&R)[32], uint32_t (&out)[8][3])
+{
+    uint32_t M[4][8];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) M[g][i] = R[4 * i + g];
+        transpose_nibbles_8x8(M[g]);
+    }
+    constexpr uint32_t m = 0x11111111u;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (uint32_t k = 0; k < 3u; ++k)
+            out[j][k] = ((M[0][j] >> k) & m) | (((M[1][j] >> k) & m) << 1) | (((M[2][j] >> k) & m) << 2) | (((M[3][j] >> k) & m) << 3);
+}
+
+struct ingest_args {
+    uint64_t n_reads;
+    uint32_t n_cols, n_sweeps, n_groups, n_pairs;   // n_groups: quartets of read tiles; n_pairs = n_groups * n_sweeps
+    uint32_t win_begin, min_qv;
+    const int32_t *pos;
+    const uint64_t *cig_off;
+    const uint8_t *seq4;
+    const uint64_t *seq_off;
+    const uint8_t *qual;         // null: no QV masking
+    const uint64_t *qual_off;
+    const uint2 *runs;
+    const uint32_t *nruns, *first_run;
+    uint32_t *slow_count;
+    uint2 *slow_list;            // {read, sweep}
+    uint8_t *msa;
+    uint64_t plane_stride;
+};
+
+// the nibbles [lo, hi) of the 32 a piece holds, as four dword masks
+__device__ __forceinline__ uint32_t range_mask8(int lo, int hi, int k)
+{
+    const int l = min(max(lo - 8 * k, 0), 8), h = min(max(hi - 8 * k, 0), 8);
+    if (h <= l) return 0u;
+    return (h - l == 8) ? 0xFFFFFFFFu : (((1u << (4 * (h - l))) - 1u) << (4 * l));
+}
+
+template <bool QV>
+__device__ __forceinline__ void expand_piece(const ingest_args &a, const uint2 *s_ent, uint32_t *s_row, const read_info &ri, uint32_t piece,
+                                             const uint4 &v, uint64_t qual_base, int X, int Xend)
+{
+    const uint32_t e_off = ri.ent & 0xFFFu, cnt = (ri.ent >> 12) & 0x3FFu;
+    const int Q = ri.q0 + 32 * (int)piece;     // query offset of the piece's first base
+    uint32_t S[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t w = ((S[k] & 0x0F0F0F0Fu) << 4) | ((S[k] >> 4) & 0x0F0F0F0Fu);   // base order = nibble order
+        S[k] = nt16_to_sym8(w);
+    }
+    const int lo_v = Q < 0 ? -Q : 0;           // bases before the read's first one belong to its neighbour
+    if (QV) {
+        // qualities of the piece's bases, one byte each, from the aligned dwords around them; a base below min_qv
+        // becomes N (0xFF = absent never does)
+        const int qb = Q + lo_v;                                   // first quality wanted
+        const uint64_t addr = qual_base + (uint64_t)qb;
+        const uint32_t *qp = reinterpret_cast<const uint32_t *>(a.qual + (addr & ~(uint64_t)3));
+        const uint32_t sh = (uint32_t)(addr & 3u);
+        uint32_t qw[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) qw[i] = qp[i];
+        const uint32_t T = a.min_qv * 0x01010101u;
+        uint32_t flags = 0;   // bit b: base lo_v + b is masked
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const uint32_t x = __builtin_amdgcn_alignbyte(qw[i + 1], qw[i], sh);
+            const uint32_t lt = ~((x | 0x80808080u) - T) & 0x80808080u;       // bytes below min_qv (and below 128)
+            uint32_t m = lt >> 7;
+            m = (m | (m >> 7)) & 0x00030003u;
+            m = (m | (m >> 14)) & 0xFu;
+            flags |= m << (4 * i);
+        }
+        const uint64_t f64 = (uint64_t)flags << lo_v;   // aligned to the piece's own base index (bases past 32 drop out below)
+        const uint32_t f = (uint32_t)f64;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            uint32_t b = (f >> (8 * k)) & 0xFFu;
+            b = (b | (b << 12)) & 0x000F000Fu;
+            b = (b | (b << 6)) & 0x03030303u;
+            b = (b | (b << 3)) & 0x11111111u;
+            const uint32_t m = b * 15u;
+            S[k] = (S[k] & ~m) | ((uint32_t)JL_SYM_MASK * 0x11111111u & m);
+        }
+    }
+    const int Qs = Q + lo_v;
+    // the last entry whose query offset is at or before the piece's first base
+    uint32_t i = 0;
+    for (uint32_t t = 1; t < cnt; ++t)
+        if ((int)s_ent[e_off + t].y <= Qs) i = t;
+    for (; i < cnt; ++i) {
+        const uint2 e = s_ent[e_off + i];
+        const int q = (int)e.y;
+        if (q >= Q + 32) break;
+        if ((e.x >> 30) != 1u) continue;
+        const int rb = (int)(e.x & kRunMask);
+        const int len = (int)(s_ent[e_off + i + 1u].x & kRunMask) - rb;
+        const int qa = max(q, Qs), qe = min(q + len, Q + 32);
+        if (qa >= qe) continue;
+        const int col_a = ri.base + rb + (qa - q);             // window column of base qa
+        const int ca = max(col_a, X), cb = min(col_a + (qe - qa), Xend);
+        if (ca >= cb) continue;
+        const int lo = qa - Q + (ca - col_a), hi = lo + (cb - ca);   // the piece's bases [lo, hi) go to tile columns ca - X ...
+        const int delta = (ca - X) - lo;                              // tile column of the piece's base 0
+        const uint32_t s4 = 4u * (uint32_t)(delta & 7);
+        const int dd = delta >> 3;
+        uint32_t P[6];
+        P[0] = 0; P[5] = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) P[k + 1] = (S[k] ^ 0x66666666u) & range_mask8(lo, hi, k);
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const uint32_t o = (uint32_t)((((uint64_t)P[j + 1] << 32) | P[j]) >> (32u - s4));
+            const uint32_t dw = (uint32_t)(dd + j);
+            if (o != 0u && dw < kSweepDw) atomicXor(&s_row[dw], o);
+        }
+    }
+}
+
+template <bool QV>
+__global__ __launch_bounds__(256) void ingest_planes_kernel(ingest_args a)
+{
+    __shared__ uint32_t s_tile[kTileDw];
+    __shared__ uint2 s_ent[kEntCap];
+    __shared__ read_info s_info[kTileReads];
+    __shared__ uint32_t s_qlo[QV ? kTileReads : 1], s_qhi[QV ? kTileReads : 1];   // qual_off of every read
+    __shared__ uint32_t s_wsum[4];
+    const uint32_t tid = threadIdx.x, wid = tid >> 6, lane = tid & 63u;
+    // block -> (read tile, sweep): the four tiles that share the 128-byte lines of a sweep are blocks b, b + 8, b + 16, b + 24
+    // — dealt to the same XCD one after the other — so their 32-byte pieces of a line meet in one L2
+    const uint32_t b = blockIdx.x, xcd = b & 7u, jb = b >> 3, sub = jb & 3u, g = jb >> 2;
+    const uint32_t pair = g * 8u + xcd;
+    if (pair >= a.n_pairs) return;
+    const uint32_t tile = 4u * (pair % a.n_groups) + sub, sweep = pair / a.n_groups;
+    const int X = (int)(sweep * kSweep), Xend = (int)min(a.n_cols, sweep * kSweep + kSweep);
+    const uint64_t r = (uint64_t)tile * kTileReads + tid;
+    const bool real = r < a.n_reads;
+
+    // ---- 0. what this read has in the sweep (the loads fly while the tile is set to 'not covered')
+    uint32_t f0 = 0, f1 = 0, nr = 0;
+    uint64_t co = 0, so = 0;
+    int32_t p = 0;
+    if (real) {
+        f0 = a.first_run[r * (uint64_t)(a.n_sweeps + 1u) + sweep];
+        f1 = a.first_run[r * (uint64_t)(a.n_sweeps + 1u) + sweep + 1u];
+        nr = a.nruns[r];
+        co = a.cig_off[r];
+        so = a.seq_off[r];
+        p = a.pos[r];
+        if (QV) {
+            const uint64_t qo = a.qual_off[r];
+            s_qlo[tid] = (uint32_t)qo;
+            s_qhi[tid] = (uint32_t)(qo >> 32);
+        }
+    }
+    for (uint32_t i = tid; i < kTileDw; i += 256u) s_tile[i] = 0x66666666u;
+    uint32_t cnt = 0;
+    if (real && nr && f0 < nr) cnt = min(f1, nr - 1u) - f0 + 1u;
+    uint32_t need = cnt ? cnt + 1u : 0u;   // + the entry behind the last run: its end
+    // exclusive scan of `need` over the workgroup
+    uint32_t inc = need;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t u = __shfl_up(inc, o, 64);
+        if ((int)lane >= o) inc += u;
+    }
+    if (lane == 63u) s_wsum[wid] = inc;
+    __syncthreads();
+    uint32_t off = inc - need;
+    for (uint32_t w = 0; w < wid; ++w) off += s_wsum[w];
+    bool slow = need != 0u && (cnt > 1022u || off + need > kEntCap);
+    const uint2 *src = a.runs + co + r + f0;
+    if (need && !slow)
+        for (uint32_t i = 0; i < need; ++i) s_ent[off + i] = src[i];
+    // the bases the sweep takes of this read: query range -> 16-byte pieces of its packed bases
+    const int base = (int)((int64_t)p - (int64_t)a.win_begin);
+    uint32_t q_lo = 0xFFFFFFFFu, q_hi = 0;
+    if (need && !slow) {
+        for (uint32_t i = 0; i < cnt; ++i) {
+            const uint2 e = s_ent[off + i];
+            if ((e.x >> 30) != 1u) continue;
+            const int rb = (int)(e.x & kRunMask), len = (int)(s_ent[off + i + 1u].x & kRunMask) - rb;
+            const int W = base + rb;
+            const int ca = max(W, X), cb = min(W + len, Xend);
+            if (ca >= cb) continue;
+            q_lo = min(q_lo, e.y + (uint32_t)(ca - W));
+            q_hi = max(q_hi, e.y + (uint32_t)(cb - W));
+        }
+    }
+    uint32_t np = 0;
+    uint64_t p0 = 0;
+    int32_t q0 = 0;
+    if (q_lo < q_hi) {
+        const uint64_t byte_lo = so + (q_lo >> 1), byte_hi = so + ((uint64_t)q_hi + 1u) / 2u;
+        p0 = byte_lo & ~(uint64_t)15;
+        const uint64_t n = (byte_hi - p0 + 15u) >> 4;
+        q0 = (int32_t)(2 * ((int64_t)p0 - (int64_t)so));
+        if (n > kMaxPieces) slow = true;   // (an insertion of tens of thousands of bases inside the sweep)
+        else np = (uint32_t)n;
+    }
+    if (slow) {
+        const uint32_t at = atomicAdd(a.slow_count, 1u);
+        a.slow_list[at] = make_uint2((uint32_t)r, sweep);
+        cnt = 0;
+        np = 0;
+    }
+    read_info ri;
+    ri.base = base;
+    ri.ent = (off & 0xFFFu) | (cnt << 12) | (np << 22);
+    ri.p0_lo = (uint32_t)p0;
+    ri.p0_hi = (uint32_t)(p0 >> 32);
+    ri.q0 = q0;
+    ri.pad_ = 0;
+    s_info[tid] = ri;
+    __syncthreads();
+
+    // ---- 1. deletions: every D run of this read inside the sweep ('-' = 4 = 'not covered' ^ 2)
+    {
+        uint32_t *row = s_tile + (tid & 31u) * kRowI + (tid >> 5) * kSweepDw;
+        for (uint32_t i = 0; i < cnt; ++i) {
+            const uint2 e = s_ent[off + i];
+            if ((e.x >> 30) != 2u) continue;
+            const int rb = (int)(e.x & kRunMask), len = (int)(s_ent[off + i + 1u].x & kRunMask) - rb;
+            const int W = base + rb;
+            const int ta = max(W, X) - X, tb = min(W + len, Xend) - X;
+            for (int d = ta >> 3; ta < tb && d <= (tb - 1) >> 3; ++d) {
+                const int l = max(ta - 8 * d, 0), h = min(tb - 8 * d, 8);
+                const uint32_t m = (h - l == 8) ? 0xFFFFFFFFu : (((1u << (4 * (h - l))) - 1u) << (4 * l));
+                atomicXor(&row[d], 0x22222222u & m);
+            }
+        }
+    }
+
+    // ---- 2. bases: a wave takes eight reads at a time, eight 16-byte pieces each; all eight rounds' loads go out first
+    {
+        const uint32_t slot = lane >> 3, piece = lane & 7u;
+        uint4 v[8];
+        uint32_t jr[8];
+#pragma unroll
+        for (uint32_t it = 0; it < 8u; ++it) {
+            const uint32_t grp = wid + 4u * it;                       // 32 groups of 8 reads: (grp >> 2) * 32 + (grp & 3) * 8 ...
+            jr[it] = (grp >> 2) * 32u + (grp & 3u) * 8u + slot;
+            const read_info &q = s_info[jr[it]];
+            v[it] = make_uint4(0, 0, 0, 0);
+            if (piece < (q.ent >> 22)) {
+                const uint64_t at = (((uint64_t)q.p0_hi << 32) | q.p0_lo) + 16u * piece;
+                const u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(a.seq4 + at));
+                v[it] = make_uint4(t.x, t.y, t.z, t.w);
+            }
+        }
+#pragma unroll
+        for (uint32_t it = 0; it < 8u; ++it) {
+            const read_info q = s_info[jr[it]];
+            const uint32_t j = jr[it];
+            uint32_t *row = s_tile + (j & 31u) * kRowI + (j >> 5) * kSweepDw;
+            const uint64_t qb = QV ? (((uint64_t)s_qhi[j] << 32) | s_qlo[j]) : 0u;
+            if (piece < (q.ent >> 22)) expand_piece<QV>(a, s_ent, row, q, piece, v[it], qb, X, Xend);
+            // a read with more than eight pieces in the sweep (insertions, or a sweep that begins late in a 16-byte piece)
+            for (uint32_t pp = piece + 8u; __ballot(pp < (q.ent >> 22)) != 0ull; pp += 8u) {
+                if (pp < (q.ent >> 22)) {
+                    const uint64_t at = (((uint64_t)q.p0_hi << 32) | q.p0_lo) + 16u * pp;
+                    const uint4 w = *reinterpret_cast<const uint4 *>(a.seq4 + at);
+                    expand_piece<QV>(a, s_ent, row, q, pp, w, qb, X, Xend);
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- 3. the tile as planes: thread = 32 reads x 8 columns; eight neighbouring lanes write 32 consecutive bytes of a plane
+    {
+        const uint32_t G = tid & 7u, dwi = tid >> 3;
+        if (dwi < kSweepDw && X + 8 * (int)dwi < Xend) {
+            uint32_t R[32];
+#pragma unroll
+            for (uint32_t i = 0; i < 32u; ++i) R[i] = s_tile[i * kRowI + G * kSweepDw + dwi];
+            uint32_t out[8][3];
+            nibble_rows_to_plane_words(R, out);
+            const uint64_t byte = (uint64_t)tile * (kTileReads / 8u) + (uint64_t)G * 4u;
+            if (byte < a.plane_stride) {
+#pragma unroll
+                for (uint32_t j = 0; j < 8u; ++j) {
+                    const uint32_t c = (uint32_t)X + 8u * dwi + j;
+                    if ((int)c < Xend) {
+#pragma unroll
+                        for (uint32_t k = 0; k < 3u; ++k)
+                            *reinterpret_cast<uint32_t *>(a.msa + ((uint64_t)c * 3u + k) * a.plane_stride + byte) = out[j][k];
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------- what the tiles left out
+// One wave per (read, sweep) pair: a lane per column looks its run up in HBM and flips the bits in which the symbol differs
+// from 'not covered' (which is what the tile's workgroup stored for the read).
+__global__ __launch_bounds__(256) void ingest_slow_kernel(ingest_args a, const int32_t *__restrict__ pos_, const uint32_t cap)
+{
+    const uint32_t wid = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    uint32_t n = *a.slow_count;
+    if (n > cap) n = cap;
+    for (uint32_t it = blockIdx.x * 4u + wid; it < n; it += gridDim.x * 4u) {
+        const uint2 pr = a.slow_list[it];
+        const uint64_t r = pr.x;
+        const uint32_t sweep = pr.y;
+        const int X = (int)(sweep * kSweep), Xend = (int)min(a.n_cols, sweep * kSweep + kSweep);
+        const uint2 *runs = a.runs + a.cig_off[r] + r;
+        const uint32_t nr = a.nruns[r];
+        const int64_t base = (int64_t)pos_[r] - (int64_t)a.win_begin;
+        const uint64_t so = a.seq_off[r];
+        const uint64_t qo = a.qual ? a.qual_off[r] : 0u;
+        for (int c = X + (int)lane; c < Xend; c += 64) {
+            const int64_t x = (int64_t)c - base;
+            if (x < 0 || nr == 0u) continue;
+            uint32_t lo = 0, hi = nr + 1u;   // entries 0 .. nr (the end entry); the last one with rbeg <= x
+            while (hi - lo > 1u) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if ((int64_t)(runs[mid].x & kRunMask) <= x) lo = mid;
+                else hi = mid;
+            }
+            if (lo >= nr) continue;          // behind the read
+            const uint2 e = runs[lo];
+            const uint32_t kind = e.x >> 30;
+            uint32_t sym = 6u;
+            if (kind == 2u) sym = 4u;
+            else if (kind == 1u) {
+                const uint64_t q = (uint64_t)e.y + (uint64_t)(x - (int64_t)(e.x & kRunMask));
+                const uint32_t by = a.seq4[so + (q >> 1)];
+                const uint32_t b16 = (q & 1u) ? (by & 15u) : (by >> 4);
+                sym = (uint32_t)((0x5555555355525105ull >> (4u * b16)) & 15ull);   // A=1 C=2 G=4 T=8 -> 0..3, else 5
+                if (a.qual) {
+                    const uint32_t qv = a.qual[qo + q];
+                    if (qv != 0xFFu && qv < a.min_qv) sym = JL_SYM_MASK;
+                }
+            }
+            const uint32_t flip = sym ^ 6u;
+            const uint32_t bit = 1u << (uint32_t)(r & 31u);
+#pragma unroll
+            for (uint32_t k = 0; k < 3u; ++k)
+                if ((flip >> k) & 1u)
+                    atomicXor(reinterpret_cast<uint32_t *>(a.msa + ((uint64_t)c * 3u + k) * a.plane_stride + (r >> 5) * 4u), bit);
+        }
+    }
+}
+
+}  // namespace
+
+uint32_t jl_ingest_sweeps(uint32_t n_cols) { return (n_cols + kSweep - 1u) / kSweep; }
+
+// d_runs: n_cig + n_reads + 1 entries; d_nruns: n_reads; d_first: n_reads x (sweeps + 1); d_slow: n_reads x sweeps pairs behind
+// one counter word (zeroed here).  Everything is enqueued on ctx->stream; nothing waits.
+void jl_launch_ingest(jl_ctx *ctx, const int32_t *d_pos, const uint32_t *d_cigar, const uint64_t *d_cig_off,
+                      const uint8_t *d_seq4, const uint64_t *d_seq_off, const uint8_t *d_qual,
+                      const uint64_t *d_qual_off, uint32_t min_qv, uint2 *d_runs, uint32_t *d_nruns, uint32_t *d_first,
+                      uint32_t *d_slow_count, uint2 *d_slow)
+{
+    hipStream_t st = ctx->stream;
+    const uint32_t ns = jl_ingest_sweeps(ctx->n_cols);
+    hipMemsetAsync(d_slow_count, 0, 4, st);
+    if (ctx->n_reads)
+        hipLaunchKernelGGL(cigar_runs_kernel, dim3((uint32_t)((ctx->n_reads + 3u) / 4u)), dim3(256), 4u * (ns + 2u) * 4u, st, ctx->n_reads, d_pos,
+                           d_cigar, d_cig_off, ctx->win_begin, ctx->n_cols, ns, d_runs, d_nruns, d_first);
+    ingest_args a;
+    a.n_reads = ctx->n_reads;
+    a.n_cols = ctx->n_cols;
+    a.n_sweeps = ns;
+    const uint64_t reads_pad = ctx->plane_stride * 8u;                 // a multiple of 1024: whole quartets of 256-read tiles
+    a.n_groups = (uint32_t)(reads_pad / (4u * kTileReads));
+    a.n_pairs = a.n_groups * ns;
+    a.win_begin = ctx->win_begin;
+    a.min_qv = std::min<uint32_t>(min_qv, 127u);   // (the byte-parallel compare of the QV path; BAM qualities end at 93)
+    a.pos = d_pos;
+    a.cig_off = d_cig_off;
+    a.seq4 = d_seq4;
+    a.seq_off = d_seq_off;
+    const bool qv = d_qual != nullptr && min_qv != 0u;
+    a.qual = qv ? d_qual : nullptr;
+    a.qual_off = qv ? d_qual_off : nullptr;
+    a.runs = d_runs;
+    a.nruns = d_nruns;
+    a.first_run = d_first;
+    a.slow_count = d_slow_count;
+    a.slow_list = d_slow;
+    a.msa = ctx->d_msa;
+    a.plane_stride = ctx->plane_stride;
+    const uint32_t grid = (a.n_pairs + 7u) / 8u * 32u;
+    if (qv) hipLaunchKernelGGL(ingest_planes_kernel<true>, dim3(grid), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(ingest_planes_kernel<false>, dim3(grid), dim3(256), 0, st, a);
+    const uint64_t cap = (uint64_t)ctx->n_reads * ns;
+    hipLaunchKernelGGL(ingest_slow_kernel, dim3(256), dim3(256), 0, st, a, d_pos, (uint32_t)std::min<uint64_t>(cap, 0xFFFFFFFFu));
+}

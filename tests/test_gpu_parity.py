@@ -870,6 +870,37 @@ def test_device_ingest_in_chunks(jl, chunk, hints):
     assert (msa.unpack_columns(jl.download_columns(), n) == rows).all()
 
 
+def test_device_ingest_dense_runs_take_the_slow_kernel(jl):
+    """A deletion at every other column: hundreds of runs per read and sweep, far more than a workgroup's LDS list holds
+    — most (read, sweep) pairs go through ingest_slow_kernel (runs looked up in HBM, bits flipped with atomics), the first
+    few reads of every tile through the tile path; both with and without QV masking, and as windows of one upload."""
+    n, l = 700, 1000
+    rng = np.random.default_rng(5)
+    sp = synth.SynthParams(seed=41, partial_rate=0.2, mask_rate=0.02, sub_rate=0.01)
+    ref = synth.reference(sp.seed, l)
+    rows = synth.rows(sp, l, 0, n, ref)
+    dense = rows[:, 1::2]
+    dense[dense < 6] = 4                        # every odd column of every covered stretch is a deletion
+    rows[3] = 6
+    pos, cigar, cig_off, seq4, seq_off, qual, qual_off = rows_to_records(rows, ref, rng)
+    assert (cig_off[1:] - cig_off[:-1]).max() > 600
+    jl.ingest_records(l, 0, pos, cigar, cig_off, seq4, seq_off)
+    assert (msa.unpack_columns(jl.download_columns(), n) == rows).all()
+    jl.ingest_records(l - 133, 77, pos, cigar, cig_off, seq4, seq_off, qual, qual_off, min_qv=94)
+    exp = rows[:, 77:l - 56].copy()
+    exp[exp < 4] = 5
+    assert (msa.unpack_columns(jl.download_columns(), n) == exp).all()
+    # two windows of ONE upload, built without waiting in between (jl_records_window_async), then a run behind each
+    rec, w0, w1 = capi.Juliet(0), capi.Juliet(0), capi.Juliet(0)
+    rec.records_upload(pos, cigar, cig_off, seq4, seq_off)
+    w0.records_window(rec, 500, 0, wait=False)
+    w1.records_window(rec, 502, 498, wait=False)
+    assert (msa.unpack_columns(w0.download_columns(), n) == rows[:, :500]).all()
+    assert (msa.unpack_columns(w1.download_columns(), n) == rows[:, 498:]).all()
+    for c in (w1, w0, rec):
+        c.close()
+
+
 def test_device_ingest_long_cigar(jl):
     """One op per base: 5000 ops per read, every lane fetches a cigar word at every column."""
     l = 5000
