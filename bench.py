@@ -18,10 +18,14 @@ into N column windows (strong scaling): call per window with the global Bonferro
 the variant columns broadcast by their owners, phasing across windows — reported as `config3_strong` in the same line.
 
 Prints ONE JSON line on rank 0 (see the driver contract in the task brief), including
-  roofline     the dominant kernel (pileup) against the 8 TB/s HBM peak: algorithmic bytes = reads x columns / 2 (a 4-bit
-               cell); `step_frac` = the same bytes over the whole timed step.  The kernel reads the library's
-               bit-plane copy of the matrix, 3 bits per cell: `moved_bytes_per_launch`, `hbm_achieved` and `hbm_frac` are what
-               actually crosses the HBM (what the PMC counters see), so `frac` can pass 1 while `hbm_frac` cannot
+  roofline     the dominant kernel (pileup) against the 8 TB/s HBM peak: algorithmic bytes = reads x columns x 3 / 8 — every
+               cell of the resident matrix read exactly once, 3 bits per cell (seven symbols; the bit planes are THE resident
+               format since round 4, DESIGN.md "Data layout") — so `frac` is physical: what crosses the HBM over the kernel's
+               time (`traffic` from the PMC counters agrees within a few percent).  `step_frac` = the same bytes over the whole
+               timed step.  (`frac_in_nibble_units`: the same time against SURVEY 8d's 4-bit cell, for comparison with rounds 1-3.)
+  once_through a FRESH window per step: aligned records resident in HBM -> ingest (cigar expansion + plane split, three
+               launches) -> pileup -> Fisher -> phasing -> results on the host; reads/s and the fraction of the HBM peak in
+               record bytes read + plane bytes written + plane bytes read.
   cpu_baseline this repo's CPU restatement (oracle/, kind "port": the reference ships no source) on the host cores.
 """
 import argparse
@@ -113,7 +117,9 @@ def main():
     ap.add_argument("--cols", type=int, default=N_COLS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-config3", action="store_true", help="skip the configs[3] strong-scaling measurement")
-    ap.add_argument("--no-config4", action="store_true", help="skip the configs[4] strong-scaling measurement (48.6 GB / N per GPU)")
+    ap.add_argument("--no-config4", action="store_true", help="skip the configs[4] strong-scaling measurement (36.4 GB / N per GPU)")
+    ap.add_argument("--no-once-through", action="store_true", help="skip the records -> ingest -> call+phase leg")
+    ap.add_argument("--once-steps", type=int, default=240, help="timed steps of the once_through leg")
     ap.add_argument("--config3-timeout", type=float, default=180.0, help="N > 1: seconds the configs[3] + configs[4] measurements may take")
     ap.add_argument("--inflight", type=int, default=4,
                     help="launches in flight per GPU (each on its own stream, with its own captured graph)")
@@ -450,7 +456,7 @@ def main():
         t_pileup_ms, alg_bytes = capi.time_pileup_groups(groups, reps=max(20, args.steps // G))
         kernel_name = "pileup_planes_group_kernel"
     else:
-        alg_bytes = n * l / 2.0
+        alg_bytes = n * l * 3.0 / 8.0
         kernel_name = jl.lib.jl_pileup_kernel_name().decode()
         try:
             t_pileup_ms = capi.time_pileup_set(ctxs, reps=max(20, args.steps))
@@ -467,7 +473,7 @@ def main():
         except Exception:
             traffic = None
 
-    step_bytes = n * l / 2.0
+    step_bytes = n * l * 3.0 / 8.0
     out = {
         # at N > 1 `value` is WEAK scaling (one independent 100k x 3kb window per GPU and batch); ONE reference split over
         # the GPUs (strong scaling) is config3_strong / config4_strong in the same line
@@ -482,7 +488,7 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "u3 symbol bit planes (u4 resident copy for phasing) / u32 counts / f64 p-values",
+        "dtype": "u3 symbols as bit planes / u32 counts / f64 p-values",
         "data": "synthetic",
         "config": {"workload": f"configs[2]: {n} CCS reads x {l} bp reference per GPU, pileup + Fisher-exact + phasing "
                                "(96% major + four 1% minor haplotypes, sub 1.75e-4, del 1.3e-3, N 2e-2); every resident "
@@ -501,12 +507,10 @@ def main():
                      "traffic_source": "profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
                                        "command (a separate run; counters cannot be read from inside bench.py)" if traffic else None,
                      "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": t_pileup_ms,
-                     # what the kernel actually reads: three bit planes per column = 3/4 of the algorithmic (nibble) bytes
-                     "moved_bytes_per_launch": alg_bytes * 3 // 4, "hbm_achieved": alg_bytes * 0.75 / (t_pileup_ms * 1e-3) / 1e9,
-                     "hbm_frac": alg_bytes * 0.75 / (t_pileup_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                     "layout": "bit planes, 3 bits per cell (the resident nibble matrix is read by the phasing stage only)",
-                     "note": "achieved / frac use the ALGORITHMIC bytes of SURVEY 8d (a 4-bit cell); the kernel reads 3 bits per cell, so the "
-                             "physical figures are hbm_achieved / hbm_frac (and traffic, from the PMC counters): frac may exceed 1, hbm_frac cannot",
+                     "algorithmic_unit": "3 bits per cell (reads x columns x 3 / 8 bytes): every cell of the resident bit planes read once",
+                     "layout": "bit planes, 3 bits per cell: the one resident format, written directly by every producer",
+                     # the same time against SURVEY 8d's original 4-bit cell (what rounds 1-3 called `frac`)
+                     "frac_in_nibble_units": alg_bytes * (4.0 / 3.0) / (t_pileup_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                      # the same bytes over the whole step (launch gaps, Fisher, phasing, results on the host included)
                      # one window alone through the whole path (what `juliet in.bam out.json` does): its bytes over its latency
                      "one_batch_frac": step_bytes / (latency_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -515,6 +519,12 @@ def main():
     }
     for g in (groups or []) + list(partial_groups.values()):
         g.close()
+    if not args.no_once_through and (n, l) == (N_READS, N_COLS):
+        try:
+            out["once_through"] = once_through(capi, synth, torch, jl, genes, refseq, prm, expected[id(jl)], rank, local_rank, n, l,
+                                               win_begin, args.once_steps)
+        except (OSError, capi.JulietError) as exc:   # the generator binary is missing, or the leg failed: the main figures stand
+            out["once_through"] = {"error": repr(exc)}
     if not args.no_config3:
         # The weak-scaling measurement above is complete.  The strong-scaling form adds two exchanges that have only ever
         # run with one rank on hardware: should it fail or stall on some rank, every rank leaves after
@@ -556,6 +566,83 @@ def main():
         c.close()
     if distributed:
         dist.destroy_process_group()
+
+
+def once_through(capi, synth, torch, jl0, genes, refseq, prm, expect, rank, local_rank, n, l, win_begin, steps):
+    """A FRESH window per step: aligned records (positions, cigars, BAM's packed bases — what a BAM decoder
+    holds, resident in HBM as the brief prescribes for `value`) -> ingest into the bit planes (jl_records_window_async: three
+    launches) -> pileup -> Fisher -> phasing -> results in pinned host memory, the whole chain enqueued on one stream per
+    window, four windows in flight.  The reads are those of resident batch 0 (same seed), so every step's result is compared
+    with that batch's; four copies of the records at different addresses and four window matrices rotate, so no step finds
+    its records or its planes in the 256 MiB Infinity Cache."""
+    rec = synth.raw_records(1000 * (rank + 1), n, l, ref_seed=2 + rank)
+    K = J = 4
+    recs, wins, streams = [], [], []
+    for k in range(K):
+        c = capi.Juliet(local_rank)
+        c.records_upload(rec["pos"], rec["cigar"], rec["cig_off"], rec["seq4"], rec["seq_off"])
+        recs.append(c)
+    for j in range(J):
+        st = torch.cuda.Stream()
+        streams.append(st)
+        wins.append(capi.Juliet(local_rank, stream=st.cuda_stream))
+    record_bytes = sum(rec[k].nbytes for k in ("pos", "cigar", "cig_off", "seq4", "seq_off"))
+    del rec
+
+    def enqueue(j, s):
+        wins[j].records_window(recs[s % K], l, win_begin, 0, wait=False)
+        wins[j].run_async(genes, refseq, prm, None, True, 10, True)
+
+    def check(j):
+        out = wins[j].run_view() or wins[j].run_fetch(True, True, cap_var=64)
+        if not same(expect, out):
+            raise SystemExit("bench.py: once_through: a fresh window's results differ from the resident batch with the same reads")
+        return out
+
+    for rep in range(3):          # every (window, records) pair's first build allocates; graphs are captured on a configuration's 2nd run
+        for j in range(J):
+            enqueue(j, j + rep)
+            check(j)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    busy = [False] * J
+    for s in range(steps):
+        j = s % J
+        if busy[j]:
+            check(j)
+        enqueue(j, s)
+        busy[j] = True
+    for j in range(J):
+        if busy[(steps + j) % J]:
+            check((steps + j) % J)
+    torch.cuda.synchronize()
+    t = (time.perf_counter() - t0) / steps
+    # the ingest alone: torch events on the windows' (torch) streams around back-to-back builds, rotating as above
+    reps = 40
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    with torch.cuda.stream(streams[0]):
+        e0.record()
+    for q in range(reps):
+        wins[0].records_window(recs[q % K], l, win_begin, 0, wait=False)
+    with torch.cuda.stream(streams[0]):
+        e1.record()
+    e1.synchronize()
+    t_ing = e0.elapsed_time(e1) / reps
+    plane_bytes = 3 * l * wins[0].plane_stride
+    io = record_bytes + 2 * plane_bytes          # records read + planes written (ingest) + planes read (pileup)
+    res = {"workload": f"a fresh window per step: records of {n} CCS reads x {l} bp (positions, cigars, 4-bit bases; resident in HBM) -> "
+                       "ingest into the bit planes -> pileup + Fisher + phasing -> results on the host; 4 windows in flight, "
+                       "every step's result verified",
+           "value": n / t, "unit": "reads/s", "ms_per_step": 1000.0 * t, "steps": steps,
+           "record_bytes": record_bytes, "plane_bytes": plane_bytes,
+           "bytes_per_step": io, "frac": io / t / 1e9 / HBM_PEAK_GBS,
+           "frac_records_plus_planes_once": (record_bytes + plane_bytes) / t / 1e9 / HBM_PEAK_GBS,
+           "ingest_ms": t_ing, "ingest_frac": (record_bytes + plane_bytes) / (t_ing * 1e-3) / 1e9 / HBM_PEAK_GBS,
+           "ingest_kernels": "cigar_runs_kernel + ingest_planes_kernel + ingest_slow_kernel (torch events on the window's stream, "
+                             f"{reps} back-to-back builds rotating over 4 record copies)"}
+    for c in wins + recs:
+        c.close()
+    return res
 
 
 def config3_strong(capi, sharding, synth, torch, dist, distributed, comm, rank, world, local_rank, free_ctxs, reps=12,
@@ -634,9 +721,8 @@ def config3_strong(capi, sharding, synth, torch, dist, distributed, comm, rank, 
            "columns_per_gpu": int(e - b), "variants_called": int(len(res["merged"])), "variant_positions": int(s["n_positions"]),
            "haplotypes": int(s["n_haplotypes"]),
            "exchanges": "none (one window)" if world == 1 else "1 ncclAllGather of the variant tables + 1 group of packed ncclSend/ncclRecv (slice r of the owned columns to rank r, one message per peer) + 1 ncclAllGather of the group tables",
-           "pileup_kernel_ms": t_k, "pileup_frac_of_hbm_peak": (n * (e - b) / 2.0) / (t_k * 1e-3) / 1e9 / HBM_PEAK_GBS,
-           # (algorithmic 4-bit cells as in roofline.frac; the bit planes the kernel reads are 3/4 of that)
-           "pileup_hbm_frac": (n * (e - b) * 0.375) / (t_k * 1e-3) / 1e9 / HBM_PEAK_GBS,
+           # (3 bits per cell, as roofline.frac)
+           "pileup_kernel_ms": t_k, "pileup_frac_of_hbm_peak": (n * (e - b) * 0.375) / (t_k * 1e-3) / 1e9 / HBM_PEAK_GBS,
            # what does NOT shrink like the pileup when the columns are split over more GPUs (the Amdahl term of 1 -> 8 scaling)
            "serial_residue_ms": 1000.0 * t - t_k, "serial_residue_ms_median": 1000.0 * t_median - t_k}
     xw.close()

@@ -340,7 +340,7 @@ int jl_records_begin(jl_ctx *ctx, uint64_t reads_hint, uint64_t cigar_words_hint
     if (e == hipSuccess) e = records_room(ctx, r.d_co, r.cap_co, 0, (size_t)reads_hint + 1, 0);
     if (e == hipSuccess) e = records_room(ctx, r.d_so, r.cap_so, 0, (size_t)reads_hint + 1, 0);
     if (e == hipSuccess) e = records_room(ctx, r.d_cig, r.cap_cig, 0, (size_t)cigar_words_hint, 0);
-    if (e == hipSuccess) e = records_room(ctx, r.d_seq, r.cap_seq, 0, (size_t)seq_bytes_hint, 16);
+    if (e == hipSuccess) e = records_room(ctx, r.d_seq, r.cap_seq, 0, (size_t)seq_bytes_hint, 64);
     if (e == hipSuccess && qual_bytes_hint) e = records_room(ctx, r.d_qual, r.cap_qual, 0, (size_t)qual_bytes_hint, 64);
     if (e == hipSuccess && qual_bytes_hint) e = records_room(ctx, r.d_qo, r.cap_qo, 0, (size_t)reads_hint + 1, 0);
     if (e != hipSuccess) {
@@ -394,8 +394,8 @@ int jl_records_append(jl_ctx *ctx, uint64_t n_reads, const int32_t *pos, const u
     if (e == hipSuccess) e = records_room(ctx, R.d_co, R.cap_co, nr + 1, nr + n_reads + 1, 0);
     if (e == hipSuccess) e = records_room(ctx, R.d_so, R.cap_so, nr + 1, nr + n_reads + 1, 0);
     if (e == hipSuccess) e = records_room(ctx, R.d_cig, R.cap_cig, (size_t)R.n_cig, (size_t)R.n_cig + n_cig, 0);
-    // the kernel reads the bases a dword at a time and one dword ahead: 16 bytes of padding behind them
-    if (e == hipSuccess) e = records_room(ctx, R.d_seq, R.cap_seq, (size_t)R.n_seq, (size_t)R.n_seq + n_seq, 16);
+    // the kernel reads the bases in aligned 32-byte pieces: padding behind them
+    if (e == hipSuccess) e = records_room(ctx, R.d_seq, R.cap_seq, (size_t)R.n_seq, (size_t)R.n_seq + n_seq, 64);
     if (e == hipSuccess && qual) e = records_room(ctx, R.d_qual, R.cap_qual, (size_t)R.n_qual, (size_t)R.n_qual + n_q, 64);
     if (e == hipSuccess && qual) e = records_room(ctx, R.d_qo, R.cap_qo, nr + 1, nr + n_reads + 1, 0);
     std::vector<uint64_t> off((size_t)(n_reads + 1) * (qual ? 3 : 2));
@@ -462,7 +462,7 @@ static int records_build(jl_ctx *src, jl_ctx *dst, uint32_t n_cols, uint32_t win
         if (e == hipSuccess) e = records_room(src, R.d_so, R.cap_so, 0, 1, 0);
         if (e == hipSuccess) e = records_room(src, R.d_pos, R.cap_pos, 0, 1, 0);
         if (e == hipSuccess) e = records_room(src, R.d_cig, R.cap_cig, 0, 1, 0);
-        if (e == hipSuccess) e = records_room(src, R.d_seq, R.cap_seq, 0, 1, 16);
+        if (e == hipSuccess) e = records_room(src, R.d_seq, R.cap_seq, 0, 1, 64);
         if (e == hipSuccess) e = hipMemsetAsync(R.d_co, 0, 8, st);
         if (e == hipSuccess) e = hipMemsetAsync(R.d_so, 0, 8, st);
     }

@@ -23,6 +23,8 @@
 //   ingest_slow_kernel  the (read, sweep) pairs a workgroup could not take — more runs in one sweep than its LDS list
 //                       holds (a deletion every other column), a huge insertion inside a sweep: column by column from the
 //                       runs in HBM, bits flipped with atomics.  Empty for real CCS data.
+#include <stdlib.h>
+
 #include <algorithm>
 
 #include "jl_internal.h"
@@ -33,15 +35,21 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr uint32_t kSweep = JL_INGEST_SWEEP;        // columns per workgroup
 constexpr uint32_t kSweepDw = kSweep / 8u;          // dwords of 8 columns in a tile row
-constexpr uint32_t kTileReads = 256u;
-// tile row of read r (0..255) at (r & 31) * kRowI + (r >> 5) * kSweepDw: the eight reads a wave expands together lie one
-// bank apart, the 32 reads x 8 lanes of the transposing step lie four banks apart (see the T phase)
-constexpr uint32_t kRowI = 8u * kSweepDw + 1u;
+#ifndef JL_INGEST_TILE
+#define JL_INGEST_TILE 128
+#endif
+constexpr uint32_t kTileReads = JL_INGEST_TILE;     // reads per workgroup: 128 (26 KB of LDS: six workgroups per CU) or 256
+constexpr uint32_t kTileGroups = kTileReads / 32u;  // groups of 32 reads = dwords of a plane the tile writes per column
+constexpr uint32_t kSubTiles = 1024u / kTileReads;  // tiles that share the 128-byte lines of the planes
+// tile row of read r at (r & 31) * kRowI + (r >> 5) * kSweepDw: the eight reads a wave expands together lie an odd number of
+// banks apart, the 32-read groups of the transposing step four banks apart
+constexpr uint32_t kRowI = kTileGroups * kSweepDw + 1u;
 constexpr uint32_t kTileDw = 32u * kRowI;
-constexpr uint32_t kEntCap = 2048u;                 // run entries of the workgroup's reads in its sweep (LDS)
+constexpr uint32_t kEntCap = 7u * kTileReads;       // run entries of the workgroup's reads in its sweep (LDS)
 constexpr uint32_t kRunMask = 0x3FFFFFFFu;          // reference offset of a run; kind in the two bits above
-constexpr uint32_t kMaxPieces = 1023u;
+constexpr uint32_t kMaxPieces = 1023u;              // pieces of a read in a sweep (10 bits; the deferral list holds 12)
 static_assert(kSweep % 8u == 0 && kSweepDw <= 32u, "a sweep is at most 32 dwords wide");
+static_assert(JL_INGEST_TILE % 64 == 0, "a wave expands sixteen reads a round");
 
 __device__ __forceinline__ bool cig_ref(uint32_t op) { return op == 2u || op == 3u || op == 7u || op == 8u; }    // D N = X
 __device__ __forceinline__ bool cig_query(uint32_t op) { return op == 1u || op == 4u || op == 7u || op == 8u; }  // I S = X
@@ -59,10 +67,26 @@ __device__ __forceinline__ uint32_t nt16_to_sym8(uint32_t w)
 }
 
 // ---------------------------------------------------------------------------------------- runs
+// inclusive prefix sum over the 64 lanes by DPP (four shifts within rows of 16, two row broadcasts)
+__device__ __forceinline__ uint32_t wave_scan(uint32_t v)
+{
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);   // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true);   // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true);   // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true);   // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);  // row_bcast:15 -> rows 1, 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);  // row_bcast:31 -> rows 2, 3
+    return v;
+}
+
 // runs[cig_off[r] + r + i] = {reference offset of run i relative to the read's first base | kind << 30, query offset};
 // kind 1 aligned bases, 2 deletion, 3 reference skip; entry n_runs = {the read's reference length, its query length}.
 // first_run[r][s], s = 0 .. n_sweeps: the number of runs i >= 1 (the end entry included) that begin at or before window
 // column s * kSweep = the index of the run that contains that column (0 before the read, n_runs behind it).
+// A wave takes four consecutive reads, a lane two consecutive cigar ops (128 ops a step: a CCS read's cigar in one or two
+// steps); the offsets and the first step's cigar words of all four reads are requested before anything waits — with one
+// read per wave the kernel was a chain of three trips to HBM per wave and nothing else (51 us for 100k reads).
+constexpr uint32_t kRunsReadsPerWave = 4u;
 __global__ __launch_bounds__(256) void cigar_runs_kernel(uint64_t n_reads, const int32_t *__restrict__ pos, const uint32_t *__restrict__ cigar,
                                                          const uint64_t *__restrict__ cig_off, uint32_t win_begin, uint32_t n_cols,
                                                          uint32_t n_sweeps, uint2 *__restrict__ runs, uint32_t *__restrict__ nruns,
@@ -70,65 +94,99 @@ __global__ __launch_bounds__(256) void cigar_runs_kernel(uint64_t n_reads, const
 {
     extern __shared__ uint32_t s_dyn[];
     const uint32_t wid = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    const uint64_t r = (uint64_t)blockIdx.x * 4u + wid;
-    if (r >= n_reads) return;
+    const uint64_t r0 = ((uint64_t)blockIdx.x * 4u + wid) * kRunsReadsPerWave;
+    if (r0 >= n_reads) return;
     uint32_t *hist = s_dyn + (size_t)wid * (n_sweeps + 2u);
-    for (uint32_t s = lane; s < n_sweeps + 2u; s += 64u) hist[s] = 0;
-    const uint64_t c_beg = cig_off[r], c_end = cig_off[r + 1];
-    uint2 *out = runs + c_beg + r;
-    const int64_t base = (int64_t)pos[r] - (int64_t)win_begin;
-    auto sweep_of = [&](uint32_t rb) -> uint32_t {   // first sweep whose first column is at or behind the run's start
-        const int64_t w = base + (int64_t)rb;
-        if (w <= 0) return 0u;
-        const uint64_t s = ((uint64_t)w + kSweep - 1u) / kSweep;
-        return s > n_sweeps ? n_sweeps + 1u : (uint32_t)s;
-    };
-    uint32_t n_runs = 0, prev_kind = 0, ref_carry = 0, q_carry = 0;
-    for (uint64_t k0 = c_beg; k0 < c_end; k0 += 64u) {
-        const uint64_t k = k0 + lane;
-        const bool live = k < c_end;
-        const uint32_t cw = live ? cigar[k] : 0u;
-        const uint32_t op = cw & 15u, len = cw >> 4;
-        const uint32_t rl = (live && cig_ref(op)) ? len : 0u, ql = (live && cig_query(op)) ? len : 0u;
-        uint32_t ri = rl, qi = ql;
+    // lanes 0..4: the cigar offsets of the wave's reads (one more than reads), lanes 0..3 their positions
+    const uint64_t rl_ = r0 + lane;
+    const uint64_t co_l = (lane <= kRunsReadsPerWave && rl_ <= n_reads) ? cig_off[rl_] : 0u;
+    const int32_t pos_l = (lane < kRunsReadsPerWave && rl_ < n_reads) ? pos[rl_] : 0;
+    uint64_t cb[kRunsReadsPerWave + 1u];
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t ur = __shfl_up(ri, o, 64), uq = __shfl_up(qi, o, 64);
-            if ((int)lane >= o) { ri += ur; qi += uq; }
-        }
-        const uint32_t kind = !live ? 0u : (op == 7u || op == 8u) ? 1u : op == 2u ? 2u : op == 3u ? 3u : 0u;
-        uint32_t before = __shfl_up(kind, 1, 64);
-        if (lane == 0) before = prev_kind;
-        const bool starts = kind != 0u && len != 0u && !(kind == 1u && before == 1u);
-        const uint64_t bal = __ballot(starts);
-        if (starts) {
-            const uint32_t idx = n_runs + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
-            const uint32_t rb = (ref_carry + ri - rl) & kRunMask;
-            out[idx] = make_uint2(rb | (kind << 30), q_carry + qi - ql);
-            if (idx >= 1u) atomicAdd(&hist[sweep_of(rb)], 1u);
-        }
-        n_runs += (uint32_t)__popcll(bal);
-        prev_kind = __shfl(kind, 63, 64);
-        ref_carry += __shfl(ri, 63, 64);
-        q_carry += __shfl(qi, 63, 64);
-    }
-    if (lane == 0) {
-        out[n_runs] = make_uint2(ref_carry & kRunMask, q_carry);
-        nruns[r] = n_runs;
-        if (n_runs) atomicAdd(&hist[sweep_of(ref_carry & kRunMask)], 1u);
-    }
-    __builtin_amdgcn_wave_barrier();
-    uint32_t carry = 0;
-    for (uint32_t s0 = 0; s0 <= n_sweeps; s0 += 64u) {
-        const uint32_t s = s0 + lane;
-        uint32_t v = s <= n_sweeps ? hist[s] : 0u;
+    for (uint32_t q = 0; q <= kRunsReadsPerWave; ++q)
+        cb[q] = ((uint64_t)(uint32_t)__shfl((int)(co_l >> 32), (int)q, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)co_l, (int)q, 64);
+    uint32_t cw0[kRunsReadsPerWave][2];
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t u = __shfl_up(v, o, 64);
-            if ((int)lane >= o) v += u;
+    for (uint32_t q = 0; q < kRunsReadsPerWave; ++q) {
+        const uint64_t k = cb[q] + 2u * lane;
+        const bool live = r0 + q < n_reads;
+        cw0[q][0] = (live && k < cb[q + 1u]) ? cigar[k] : 0u;
+        cw0[q][1] = (live && k + 1u < cb[q + 1u]) ? cigar[k + 1u] : 0u;
+    }
+    const uint64_t lt = (1ull << lane) - 1ull;
+#pragma unroll
+    for (uint32_t q = 0; q < kRunsReadsPerWave; ++q) {
+        const uint64_t r = r0 + q;
+        if (r >= n_reads) break;
+        for (uint32_t s = lane; s < n_sweeps + 2u; s += 64u) hist[s] = 0;
+        const uint64_t c_beg = cb[q], c_end = cb[q + 1u];
+        uint2 *out = runs + c_beg + r;
+        const int64_t base = (int64_t)__shfl(pos_l, (int)q, 64) - (int64_t)win_begin;
+        // first sweep whose first column is at or behind the run's start (32-bit arithmetic: the offset is clamped to the
+        // window first — a 64-bit division by the sweep width was a quarter of this kernel's instructions)
+        const int64_t lim = (int64_t)n_sweeps * kSweep;
+        auto sweep_of = [&](uint32_t rb) -> uint32_t {
+            const int64_t w = base + (int64_t)rb;
+            if (w <= 0) return 0u;
+            if (w > lim) return n_sweeps + 1u;
+            return ((uint32_t)w + kSweep - 1u) / kSweep;
+        };
+        uint32_t n_runs = 0, prev_kind = 0, ref_carry = 0, q_carry = 0;
+        for (uint64_t k0 = c_beg; k0 < c_end; k0 += 128u) {
+            uint32_t cw[2] = {cw0[q][0], cw0[q][1]};
+            if (k0 != c_beg) {
+                const uint64_t k = k0 + 2u * lane;
+                cw[0] = k < c_end ? cigar[k] : 0u;
+                cw[1] = k + 1u < c_end ? cigar[k + 1u] : 0u;
+            }
+            uint32_t kind[2], rl[2], ql[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const uint32_t op = cw[t] & 15u, len = cw[t] >> 4;   // (a missing op is the word 0: length 0, which is nothing)
+                rl[t] = cig_ref(op) ? len : 0u;
+                ql[t] = cig_query(op) ? len : 0u;
+                kind[t] = len == 0u ? 0u : (op == 7u || op == 8u) ? 1u : op == 2u ? 2u : op == 3u ? 3u : 0u;
+            }
+            const uint32_t ri = wave_scan(rl[0] + rl[1]), qi = wave_scan(ql[0] + ql[1]);   // inclusive, per lane pair
+            // the kind of the op before this lane's first one: the previous lane's second op
+            uint32_t before = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)kind[1], 0x138, 0xF, 0xF, false);   // wave_shr:1
+            if (lane == 0) before = prev_kind;
+            const bool st0 = kind[0] != 0u && !(kind[0] == 1u && before == 1u);
+            const bool st1 = kind[1] != 0u && !(kind[1] == 1u && kind[0] == 1u);
+            const uint64_t b0 = __ballot(st0), b1 = __ballot(st1);
+            const uint32_t ahead = (uint32_t)__popcll(b0 & lt) + (uint32_t)__popcll(b1 & lt);   // run starts in the lanes before
+            const uint32_t rbeg0 = ref_carry + ri - rl[0] - rl[1], qbeg0 = q_carry + qi - ql[0] - ql[1];
+            if (st0) {
+                const uint32_t idx = n_runs + ahead;
+                const uint32_t rb = rbeg0 & kRunMask;
+                out[idx] = make_uint2(rb | (kind[0] << 30), qbeg0);
+                if (idx >= 1u) atomicAdd(&hist[sweep_of(rb)], 1u);
+            }
+            if (st1) {
+                const uint32_t idx = n_runs + ahead + (st0 ? 1u : 0u);
+                const uint32_t rb = (rbeg0 + rl[0]) & kRunMask;
+                out[idx] = make_uint2(rb | (kind[1] << 30), qbeg0 + ql[0]);
+                if (idx >= 1u) atomicAdd(&hist[sweep_of(rb)], 1u);
+            }
+            n_runs += (uint32_t)__popcll(b0) + (uint32_t)__popcll(b1);
+            prev_kind = __shfl(kind[1], 63, 64);   // (only a full step has a successor)
+            ref_carry += __shfl(ri, 63, 64);
+            q_carry += __shfl(qi, 63, 64);
         }
-        if (s <= n_sweeps) first_run[r * (uint64_t)(n_sweeps + 1u) + s] = carry + v;
-        carry += __shfl(v, 63, 64);
+        if (lane == 0) {
+            out[n_runs] = make_uint2(ref_carry & kRunMask, q_carry);
+            nruns[r] = n_runs;
+            if (n_runs) atomicAdd(&hist[sweep_of(ref_carry & kRunMask)], 1u);
+        }
+        __builtin_amdgcn_wave_barrier();
+        uint32_t carry = 0;
+        for (uint32_t s0 = 0; s0 <= n_sweeps; s0 += 64u) {
+            const uint32_t s = s0 + lane;
+            const uint32_t v = wave_scan(s <= n_sweeps ? hist[s] : 0u);
+            if (s <= n_sweeps) first_run[r * (uint64_t)(n_sweeps + 1u) + s] = carry + v;
+            carry += __shfl(v, 63, 64);
+        }
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -188,7 +246,7 @@ __device__ __forceinline__ void nibble_rows_to_plane_words(const uint32_t (&R)[3
 
 struct ingest_args {
     uint64_t n_reads;
-    uint32_t n_cols, n_sweeps, n_groups, n_pairs;   // n_groups: quartets of read tiles; n_pairs = n_groups * n_sweeps
+    uint32_t n_cols, n_sweeps, n_groups, n_pairs;   // n_groups: groups of 1024 reads (the tiles that share lines); n_pairs = n_groups * n_sweeps
     uint32_t win_begin, min_qv;
     const int32_t *pos;
     const uint64_t *cig_off;
@@ -202,114 +260,149 @@ struct ingest_args {
     uint2 *slow_list;            // {read, sweep}
     uint8_t *msa;
     uint64_t plane_stride;
+    uint32_t skip;               // tuning builds: bit 0 no bases, bit 1 no deletions, bit 2 no stores, bit 3 no second pass, bit 4 no transposing
 };
+#ifdef JL_TUNING
+#define JL_ING_SKIP(a, bit) (((a).skip >> (bit)) & 1u)
+#else
+#define JL_ING_SKIP(a, bit) 0u
+#endif
 
-// the nibbles [lo, hi) of the 32 a piece holds, as four dword masks
-__device__ __forceinline__ uint32_t range_mask8(int lo, int hi, int k)
+constexpr int kPiece = 64;     // bases a lane expands at a time: 32 bytes of packed bases (two 16-byte loads)
+
+// the nibbles [lo, hi) of the 64 a piece holds, as four 64-bit masks (part k = nibbles 16 k .. 16 k + 15)
+__device__ __forceinline__ uint64_t range_mask16(int lo, int hi, int k)
 {
-    const int l = min(max(lo - 8 * k, 0), 8), h = min(max(hi - 8 * k, 0), 8);
-    if (h <= l) return 0u;
-    return (h - l == 8) ? 0xFFFFFFFFu : (((1u << (4 * (h - l))) - 1u) << (4 * l));
+    const int l = min(max(lo - 16 * k, 0), 16), h = min(max(hi - 16 * k, 0), 16);
+    if (h <= l) return 0ull;
+    const uint64_t upto = h == 16 ? ~0ull : ((1ull << (4 * h)) - 1ull);
+    return upto & ~((1ull << (4 * l)) - 1ull);
 }
 
+// 32 bytes of packed bases (BAM order: first base in the high nibble) -> 64 symbol codes, base b in nibble b & 7 of S[b >> 3];
+// QV: bases whose quality is below min_qv become N.  Q = query offset of the piece's base 0, lo_v = its first base that is
+// the read's own.
 template <bool QV>
-__device__ __forceinline__ void expand_piece(const ingest_args &a, const uint2 *s_ent, uint32_t *s_row, const read_info &ri, uint32_t piece,
-                                             const uint4 &v, uint64_t qual_base, int X, int Xend)
+__device__ __forceinline__ void piece_syms(const ingest_args &a, const uint4 &v0, const uint4 &v1, int Q, int lo_v, uint64_t qual_base,
+                                           uint32_t (&S)[8])
 {
-    const uint32_t e_off = ri.ent & 0xFFFu, cnt = (ri.ent >> 12) & 0x3FFu;
-    const int Q = ri.q0 + 32 * (int)piece;     // query offset of the piece's first base
-    uint32_t S[4] = {v.x, v.y, v.z, v.w};
+    const uint32_t w8[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+    constexpr uint32_t m = 0x11111111u;
+    uint32_t anybad = 0;
+    uint32_t cntw[8];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const uint32_t w = ((S[k] & 0x0F0F0F0Fu) << 4) | ((S[k] >> 4) & 0x0F0F0F0Fu);   // base order = nibble order
-        S[k] = nt16_to_sym8(w);
+    for (int k = 0; k < 8; ++k) {
+        const uint32_t w = ((w8[k] & 0x0F0F0F0Fu) << 4) | ((w8[k] >> 4) & 0x0F0F0F0Fu);   // base order = nibble order
+        const uint32_t t1 = w >> 1, t2 = w >> 2, t3 = w >> 3;
+        S[k] = ((t1 | t3) & m) | (((t2 | t3) & m) << 1);     // one-hot A C G T (1 2 4 8) -> 0..3
+        cntw[k] = (w & m) + (t1 & m) + (t2 & m) + (t3 & m);  // set bits per nibble
+        anybad |= cntw[k] ^ m;
     }
-    const int lo_v = Q < 0 ? -Q : 0;           // bases before the read's first one belong to its neighbour
+    if (anybad != 0u) {   // ambiguity codes (N = 15, '=' = 0, IUPAC): filtered base
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const uint32_t t = cntw[k] ^ m;
+            const uint32_t bad = (t | (t >> 1) | (t >> 2)) & m;
+            S[k] = (S[k] & ~(bad * 15u)) | (bad * 5u);
+        }
+    }
     if (QV) {
         // qualities of the piece's bases, one byte each, from the aligned dwords around them; a base below min_qv
         // becomes N (0xFF = absent never does)
-        const int qb = Q + lo_v;                                   // first quality wanted
-        const uint64_t addr = qual_base + (uint64_t)qb;
+        const uint64_t addr = qual_base + (uint64_t)(Q + lo_v);    // first quality wanted
         const uint32_t *qp = reinterpret_cast<const uint32_t *>(a.qual + (addr & ~(uint64_t)3));
         const uint32_t sh = (uint32_t)(addr & 3u);
-        uint32_t qw[9];
+        uint32_t qw[17];
 #pragma unroll
-        for (int i = 0; i < 9; ++i) qw[i] = qp[i];
+        for (int i = 0; i < 17; ++i) qw[i] = qp[i];
         const uint32_t T = a.min_qv * 0x01010101u;
-        uint32_t flags = 0;   // bit b: base lo_v + b is masked
+        uint64_t flags = 0;   // bit b: base lo_v + b is masked
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < 16; ++i) {
             const uint32_t x = __builtin_amdgcn_alignbyte(qw[i + 1], qw[i], sh);
             const uint32_t lt = ~((x | 0x80808080u) - T) & 0x80808080u;       // bytes below min_qv (and below 128)
-            uint32_t m = lt >> 7;
-            m = (m | (m >> 7)) & 0x00030003u;
-            m = (m | (m >> 14)) & 0xFu;
-            flags |= m << (4 * i);
+            uint32_t f = lt >> 7;
+            f = (f | (f >> 7)) & 0x00030003u;
+            f = (f | (f >> 14)) & 0xFu;
+            flags |= (uint64_t)f << (4 * i);
         }
-        const uint64_t f64 = (uint64_t)flags << lo_v;   // aligned to the piece's own base index (bases past 32 drop out below)
-        const uint32_t f = (uint32_t)f64;
+        flags <<= lo_v;   // by the piece's own base index (bases past 64 drop out)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            uint32_t b = (f >> (8 * k)) & 0xFFu;
+        for (int k = 0; k < 8; ++k) {
+            uint32_t b = (uint32_t)(flags >> (8 * k)) & 0xFFu;
             b = (b | (b << 12)) & 0x000F000Fu;
             b = (b | (b << 6)) & 0x03030303u;
             b = (b | (b << 3)) & 0x11111111u;
-            const uint32_t m = b * 15u;
-            S[k] = (S[k] & ~m) | ((uint32_t)JL_SYM_MASK * 0x11111111u & m);
-        }
-    }
-    const int Qs = Q + lo_v;
-    // the last entry whose query offset is at or before the piece's first base
-    uint32_t i = 0;
-    for (uint32_t t = 1; t < cnt; ++t)
-        if ((int)s_ent[e_off + t].y <= Qs) i = t;
-    for (; i < cnt; ++i) {
-        const uint2 e = s_ent[e_off + i];
-        const int q = (int)e.y;
-        if (q >= Q + 32) break;
-        if ((e.x >> 30) != 1u) continue;
-        const int rb = (int)(e.x & kRunMask);
-        const int len = (int)(s_ent[e_off + i + 1u].x & kRunMask) - rb;
-        const int qa = max(q, Qs), qe = min(q + len, Q + 32);
-        if (qa >= qe) continue;
-        const int col_a = ri.base + rb + (qa - q);             // window column of base qa
-        const int ca = max(col_a, X), cb = min(col_a + (qe - qa), Xend);
-        if (ca >= cb) continue;
-        const int lo = qa - Q + (ca - col_a), hi = lo + (cb - ca);   // the piece's bases [lo, hi) go to tile columns ca - X ...
-        const int delta = (ca - X) - lo;                              // tile column of the piece's base 0
-        const uint32_t s4 = 4u * (uint32_t)(delta & 7);
-        const int dd = delta >> 3;
-        uint32_t P[6];
-        P[0] = 0; P[5] = 0;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) P[k + 1] = (S[k] ^ 0x66666666u) & range_mask8(lo, hi, k);
-#pragma unroll
-        for (int j = 0; j < 5; ++j) {
-            const uint32_t o = (uint32_t)((((uint64_t)P[j + 1] << 32) | P[j]) >> (32u - s4));
-            const uint32_t dw = (uint32_t)(dd + j);
-            if (o != 0u && dw < kSweepDw) atomicXor(&s_row[dw], o);
+            const uint32_t mk = b * 15u;
+            S[k] = (S[k] & ~mk) | ((uint32_t)JL_SYM_MASK * 0x11111111u & mk);
         }
     }
 }
+
+// The part of a piece (bases Q .. Q + 63 of the read, the first lo_v of them not its own) that lies in ONE run of aligned
+// bases {rb, q, len} and inside the sweep goes into the tile row: XOR against 'not covered', shifted to its columns.
+// s_row may be XORed up to eight dwords before and behind the row's own: the payload there is zero (the guard dwords of
+// the tile take what would fall outside it).
+__device__ __forceinline__ void emit_run(const uint32_t (&S)[8], int Q, int lo_v, int rb, int q, int len, int base, int X, int Xend, uint32_t *s_row)
+{
+    const int qa = max(q, Q + lo_v), qe = min(q + len, Q + kPiece);
+    if (qa >= qe) return;
+    const int col_a = base + rb + (qa - q);                 // window column of base qa
+    const int ca = max(col_a, X), cb = min(col_a + (qe - qa), Xend);
+    if (ca >= cb) return;
+    const int lo = qa - Q + (ca - col_a), hi = lo + (cb - ca);   // the piece's bases [lo, hi) go to tile columns ca - X ...
+    const int delta = (ca - X) - lo;                              // tile column of the piece's base 0
+    const uint32_t s4 = 4u * (uint32_t)(delta & 7);
+    const int dd = delta >> 3;
+    uint32_t P[10];
+    P[0] = 0; P[9] = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint64_t mk = range_mask16(lo, hi, k);
+        P[2 * k + 1] = (S[2 * k] ^ 0x66666666u) & (uint32_t)mk;
+        P[2 * k + 2] = (S[2 * k + 1] ^ 0x66666666u) & (uint32_t)(mk >> 32);
+    }
+    uint32_t *dst = s_row + dd;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) atomicXor(&dst[j], (uint32_t)((((uint64_t)P[j + 1] << 32) | P[j]) >> (32u - s4)));
+}
+
+// every run from entry i on that the piece reaches (the general form: pieces that cross a run boundary, or begin in a gap)
+__device__ __forceinline__ void emit_rest(const uint32_t (&S)[8], int Q, int lo_v, const uint2 *ent, uint32_t i, uint32_t cnt, int base, int X,
+                                          int Xend, uint32_t *s_row)
+{
+    for (; i < cnt; ++i) {
+        const uint2 e = ent[i];
+        const int q = (int)e.y;
+        if (q >= Q + kPiece) break;
+        if ((e.x >> 30) != 1u) continue;
+        const int rb = (int)(e.x & kRunMask);
+        emit_run(S, Q, lo_v, rb, q, (int)(ent[i + 1u].x & kRunMask) - rb, base, X, Xend, s_row);
+    }
+}
+
+constexpr uint32_t kListCap = 2u * kTileReads;     // pieces a workgroup defers to its second pass
 
 template <bool QV>
 __global__ __launch_bounds__(256) void ingest_planes_kernel(ingest_args a)
 {
-    __shared__ uint32_t s_tile[kTileDw];
+    __shared__ uint32_t s_tile_g[kTileDw + 24u];   // guard dwords: 8 in front, 16 behind (see emit_run)
     __shared__ uint2 s_ent[kEntCap];
     __shared__ read_info s_info[kTileReads];
     __shared__ uint32_t s_qlo[QV ? kTileReads : 1], s_qhi[QV ? kTileReads : 1];   // qual_off of every read
-    __shared__ uint32_t s_wsum[4];
+    __shared__ uint32_t s_list[kListCap];
+    __shared__ uint32_t s_wsum[4], s_nlist;
+    uint32_t *s_tile = s_tile_g + 8;
     const uint32_t tid = threadIdx.x, wid = tid >> 6, lane = tid & 63u;
-    // block -> (read tile, sweep): the four tiles that share the 128-byte lines of a sweep are blocks b, b + 8, b + 16, b + 24
-    // — dealt to the same XCD one after the other — so their 32-byte pieces of a line meet in one L2
-    const uint32_t b = blockIdx.x, xcd = b & 7u, jb = b >> 3, sub = jb & 3u, g = jb >> 2;
+    // block -> (read tile, sweep): the tiles that share the 128-byte lines of a sweep are blocks b, b + 8, b + 16, ... — dealt
+    // to the same XCD one after the other — so their pieces of a line meet in one L2
+    const uint32_t b = blockIdx.x, xcd = b & 7u, jb = b >> 3, sub = jb % kSubTiles, g = jb / kSubTiles;
     const uint32_t pair = g * 8u + xcd;
     if (pair >= a.n_pairs) return;
-    const uint32_t tile = 4u * (pair % a.n_groups) + sub, sweep = pair / a.n_groups;
+    const uint32_t tile = kSubTiles * (pair % a.n_groups) + sub, sweep = pair / a.n_groups;
     const int X = (int)(sweep * kSweep), Xend = (int)min(a.n_cols, sweep * kSweep + kSweep);
     const uint64_t r = (uint64_t)tile * kTileReads + tid;
-    const bool real = r < a.n_reads;
+    const bool real = tid < kTileReads && r < a.n_reads;
 
     // ---- 0. what this read has in the sweep (the loads fly while the tile is set to 'not covered')
     uint32_t f0 = 0, f1 = 0, nr = 0;
@@ -328,7 +421,8 @@ __global__ __launch_bounds__(256) void ingest_planes_kernel(ingest_args a)
             s_qhi[tid] = (uint32_t)(qo >> 32);
         }
     }
-    for (uint32_t i = tid; i < kTileDw; i += 256u) s_tile[i] = 0x66666666u;
+    for (uint32_t i = tid; i < kTileDw + 24u; i += 256u) s_tile_g[i] = 0x66666666u;
+    if (tid == 0) s_nlist = 0;
     uint32_t cnt = 0;
     if (real && nr && f0 < nr) cnt = min(f1, nr - 1u) - f0 + 1u;
     uint32_t need = cnt ? cnt + 1u : 0u;   // + the entry behind the last run: its end
@@ -345,8 +439,16 @@ __global__ __launch_bounds__(256) void ingest_planes_kernel(ingest_args a)
     for (uint32_t w = 0; w < wid; ++w) off += s_wsum[w];
     bool slow = need != 0u && (cnt > 1022u || off + need > kEntCap);
     const uint2 *src = a.runs + co + r + f0;
-    if (need && !slow)
-        for (uint32_t i = 0; i < need; ++i) s_ent[off + i] = src[i];
+    if (need && !slow) {
+        // (the first four entries' loads go out together: a load-store loop pays a trip to HBM per entry)
+        uint2 e4[4];
+#pragma unroll
+        for (uint32_t i = 0; i < 4u; ++i) e4[i] = src[min(i, need - 1u)];
+#pragma unroll
+        for (uint32_t i = 0; i < 4u; ++i)
+            if (i < need) s_ent[off + i] = e4[i];
+        for (uint32_t i = 4; i < need; ++i) s_ent[off + i] = src[i];
+    }
     // the bases the sweep takes of this read: query range -> 16-byte pieces of its packed bases
     const int base = (int)((int64_t)p - (int64_t)a.win_begin);
     uint32_t q_lo = 0xFFFFFFFFu, q_hi = 0;
@@ -368,7 +470,7 @@ __global__ __launch_bounds__(256) void ingest_planes_kernel(ingest_args a)
     if (q_lo < q_hi) {
         const uint64_t byte_lo = so + (q_lo >> 1), byte_hi = so + ((uint64_t)q_hi + 1u) / 2u;
         p0 = byte_lo & ~(uint64_t)15;
-        const uint64_t n = (byte_hi - p0 + 15u) >> 4;
+        const uint64_t n = (byte_hi - p0 + 31u) >> 5;                // pieces of 32 bytes from a 16-byte boundary on
         q0 = (int32_t)(2 * ((int64_t)p0 - (int64_t)so));
         if (n > kMaxPieces) slow = true;   // (an insertion of tens of thousands of bases inside the sweep)
         else np = (uint32_t)n;
@@ -386,11 +488,11 @@ __global__ __launch_bounds__(256) void ingest_planes_kernel(ingest_args a)
     ri.p0_hi = (uint32_t)(p0 >> 32);
     ri.q0 = q0;
     ri.pad_ = 0;
-    s_info[tid] = ri;
+    if (tid < kTileReads) s_info[tid] = ri;
     __syncthreads();
 
     // ---- 1. deletions: every D run of this read inside the sweep ('-' = 4 = 'not covered' ^ 2)
-    {
+    if (tid < kTileReads && !JL_ING_SKIP(a, 1)) {
         uint32_t *row = s_tile + (tid & 31u) * kRowI + (tid >> 5) * kSweepDw;
         for (uint32_t i = 0; i < cnt; ++i) {
             const uint2 e = s_ent[off + i];
@@ -406,53 +508,102 @@ __global__ __launch_bounds__(256) void ingest_planes_kernel(ingest_args a)
         }
     }
 
-    // ---- 2. bases: a wave takes eight reads at a time, eight 16-byte pieces each; all eight rounds' loads go out first
-    {
-        const uint32_t slot = lane >> 3, piece = lane & 7u;
-        uint4 v[8];
-        uint32_t jr[8];
-#pragma unroll
-        for (uint32_t it = 0; it < 8u; ++it) {
-            const uint32_t grp = wid + 4u * it;                       // 32 groups of 8 reads: (grp >> 2) * 32 + (grp & 3) * 8 ...
-            jr[it] = (grp >> 2) * 32u + (grp & 3u) * 8u + slot;
-            const read_info &q = s_info[jr[it]];
-            v[it] = make_uint4(0, 0, 0, 0);
-            if (piece < (q.ent >> 22)) {
-                const uint64_t at = (((uint64_t)q.p0_hi << 32) | q.p0_lo) + 16u * piece;
-                const u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(a.seq4 + at));
-                v[it] = make_uint4(t.x, t.y, t.z, t.w);
+    // ---- 2. bases.  A wave takes sixteen reads at a time, four 32-byte pieces (64 bases) each — a sweep of 224 columns is
+    // at most four such pieces of a read from a 16-byte boundary on, insertions aside; the loads of a wave's rounds are all
+    // in flight before the first is used.  A lane puts the part of its piece that lies in the FIRST run it touches into the
+    // tile; the pieces that go on into another run (one in seven) are listed and finished in a second pass with full lanes
+    // — in line, the loop over a piece's runs made every wave walk two or three runs for them.
+    if (!JL_ING_SKIP(a, 0)) {
+        constexpr uint32_t kRounds = kTileReads / 64u;   // rounds of a wave: 16 reads x 4 waves each
+        const uint32_t slot = lane >> 2, piece = lane & 3u;
+        auto fetch = [&](uint32_t j, uint32_t pc, uint4 &v0, uint4 &v1) {
+            const read_info &q = s_info[j];
+            v0 = make_uint4(0, 0, 0, 0);
+            v1 = v0;
+            if (pc < (q.ent >> 22)) {
+                const uint64_t at = (((uint64_t)q.p0_hi << 32) | q.p0_lo) + 32u * pc;
+                const u32x4 t0 = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(a.seq4 + at));
+                const u32x4 t1 = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(a.seq4 + at + 16u));
+                v0 = make_uint4(t0.x, t0.y, t0.z, t0.w);
+                v1 = make_uint4(t1.x, t1.y, t1.z, t1.w);
             }
-        }
-#pragma unroll
-        for (uint32_t it = 0; it < 8u; ++it) {
-            const read_info q = s_info[jr[it]];
-            const uint32_t j = jr[it];
-            uint32_t *row = s_tile + (j & 31u) * kRowI + (j >> 5) * kSweepDw;
+        };
+        auto expand = [&](uint32_t j, uint32_t pc, const uint4 &v0, const uint4 &v1) {
+            const read_info q = s_info[j];
+            const uint32_t e_off = q.ent & 0xFFFu, cn = (q.ent >> 12) & 0x3FFu;
+            if (pc >= (q.ent >> 22) || cn == 0u) return;
+            const int Q = q.q0 + kPiece * (int)pc;
+            const int lo_v = Q < 0 ? -Q : 0;
+            uint32_t S[8];
             const uint64_t qb = QV ? (((uint64_t)s_qhi[j] << 32) | s_qlo[j]) : 0u;
-            if (piece < (q.ent >> 22)) expand_piece<QV>(a, s_ent, row, q, piece, v[it], qb, X, Xend);
-            // a read with more than eight pieces in the sweep (insertions, or a sweep that begins late in a 16-byte piece)
-            for (uint32_t pp = piece + 8u; __ballot(pp < (q.ent >> 22)) != 0ull; pp += 8u) {
-                if (pp < (q.ent >> 22)) {
-                    const uint64_t at = (((uint64_t)q.p0_hi << 32) | q.p0_lo) + 16u * pp;
-                    const uint4 w = *reinterpret_cast<const uint4 *>(a.seq4 + at);
-                    expand_piece<QV>(a, s_ent, row, q, pp, w, qb, X, Xend);
-                }
+            piece_syms<QV>(a, v0, v1, Q, lo_v, qb, S);
+            // the last entry whose query offset is at or before the piece's first base: eight entries' offsets at once
+            const uint2 *ent = s_ent + e_off;
+            const int Qs = Q + lo_v;
+            uint32_t qy[8];
+#pragma unroll
+            for (uint32_t t = 1; t < 8u; ++t) qy[t] = ent[min(t, cn - 1u)].y;
+            uint32_t i = 0;
+#pragma unroll
+            for (uint32_t t = 1; t < 8u; ++t) i += (t < cn && (int)qy[t] <= Qs) ? 1u : 0u;
+            if (i == 7u)
+                for (uint32_t t = 8; t < cn && (int)ent[t].y <= Qs; ++t) i = t;
+            const uint2 e = ent[i], nx = ent[i + 1u];
+            uint32_t *row = s_tile + (j & 31u) * kRowI + (j >> 5) * kSweepDw;
+            const int rb = (int)(e.x & kRunMask);
+            if ((e.x >> 30) == 1u) emit_run(S, Q, lo_v, rb, (int)e.y, (int)(nx.x & kRunMask) - rb, q.base, X, Xend, row);
+            if (i + 1u < cn && (int)nx.y < Q + kPiece) {       // the piece reaches the next entry: later
+                const uint32_t at = atomicAdd(&s_nlist, 1u);
+                if (at < kListCap) s_list[at] = (j << 24) | (pc << 12) | (i + 1u);
+                else emit_rest(S, Q, lo_v, ent, i + 1u, cn, q.base, X, Xend, row);
+            }
+        };
+        uint4 va[kRounds], vb[kRounds];
+#pragma unroll
+        for (uint32_t it = 0; it < kRounds; ++it) fetch((wid + 4u * it) * 16u + slot, piece, va[it], vb[it]);
+#pragma unroll
+        for (uint32_t it = 0; it < kRounds; ++it) {
+            const uint32_t j = (wid + 4u * it) * 16u + slot;
+            expand(j, piece, va[it], vb[it]);
+            // a read with more than four pieces in the sweep (insertions)
+            const uint32_t npj = s_info[j].ent >> 22;
+            for (uint32_t pp = piece + 4u; __ballot(pp < npj) != 0ull; pp += 4u) {
+                uint4 w0, w1;
+                fetch(j, pp, w0, w1);
+                expand(j, pp, w0, w1);
             }
         }
     }
     __syncthreads();
+    if (!JL_ING_SKIP(a, 3)) {   // the listed pieces, a lane each
+        const uint32_t nl = min(s_nlist, kListCap);
+        for (uint32_t k = tid; k < nl; k += 256u) {
+            const uint32_t it = s_list[k], j = it >> 24, pc = (it >> 12) & 0xFFFu;
+            const read_info q = s_info[j];
+            const uint64_t at = (((uint64_t)q.p0_hi << 32) | q.p0_lo) + 32u * pc;
+            const uint4 v0 = *reinterpret_cast<const uint4 *>(a.seq4 + at), v1 = *reinterpret_cast<const uint4 *>(a.seq4 + at + 16u);
+            const int Q = q.q0 + kPiece * (int)pc;
+            const int lo_v = Q < 0 ? -Q : 0;
+            uint32_t S[8];
+            const uint64_t qb = QV ? (((uint64_t)s_qhi[j] << 32) | s_qlo[j]) : 0u;
+            piece_syms<QV>(a, v0, v1, Q, lo_v, qb, S);
+            emit_rest(S, Q, lo_v, s_ent + (q.ent & 0xFFFu), it & 0xFFFu, (q.ent >> 12) & 0x3FFu, q.base, X, Xend,
+                      s_tile + (j & 31u) * kRowI + (j >> 5) * kSweepDw);
+        }
+    }
+    __syncthreads();
 
-    // ---- 3. the tile as planes: thread = 32 reads x 8 columns; eight neighbouring lanes write 32 consecutive bytes of a plane
+    // ---- 3. the tile as planes: thread = 32 reads x 8 columns; neighbouring lanes write consecutive dwords of a plane
     {
-        const uint32_t G = tid & 7u, dwi = tid >> 3;
-        if (dwi < kSweepDw && X + 8 * (int)dwi < Xend) {
+        const uint32_t G = tid % kTileGroups, dwi = tid / kTileGroups;
+        if (dwi < kSweepDw && X + 8 * (int)dwi < Xend && !JL_ING_SKIP(a, 4)) {
             uint32_t R[32];
 #pragma unroll
             for (uint32_t i = 0; i < 32u; ++i) R[i] = s_tile[i * kRowI + G * kSweepDw + dwi];
             uint32_t out[8][3];
             nibble_rows_to_plane_words(R, out);
             const uint64_t byte = (uint64_t)tile * (kTileReads / 8u) + (uint64_t)G * 4u;
-            if (byte < a.plane_stride) {
+            if (byte < a.plane_stride && (!JL_ING_SKIP(a, 2) || out[0][0] == 0x12345u)) {
 #pragma unroll
                 for (uint32_t j = 0; j < 8u; ++j) {
                     const uint32_t c = (uint32_t)X + 8u * dwi + j;
@@ -534,14 +685,14 @@ void jl_launch_ingest(jl_ctx *ctx, const int32_t *d_pos, const uint32_t *d_cigar
     const uint32_t ns = jl_ingest_sweeps(ctx->n_cols);
     hipMemsetAsync(d_slow_count, 0, 4, st);
     if (ctx->n_reads)
-        hipLaunchKernelGGL(cigar_runs_kernel, dim3((uint32_t)((ctx->n_reads + 3u) / 4u)), dim3(256), 4u * (ns + 2u) * 4u, st, ctx->n_reads, d_pos,
+        hipLaunchKernelGGL(cigar_runs_kernel, dim3((uint32_t)((ctx->n_reads + 4u * kRunsReadsPerWave - 1u) / (4u * kRunsReadsPerWave))), dim3(256), 4u * (ns + 2u) * 4u, st, ctx->n_reads, d_pos,
                            d_cigar, d_cig_off, ctx->win_begin, ctx->n_cols, ns, d_runs, d_nruns, d_first);
     ingest_args a;
     a.n_reads = ctx->n_reads;
     a.n_cols = ctx->n_cols;
     a.n_sweeps = ns;
-    const uint64_t reads_pad = ctx->plane_stride * 8u;                 // a multiple of 1024: whole quartets of 256-read tiles
-    a.n_groups = (uint32_t)(reads_pad / (4u * kTileReads));
+    const uint64_t reads_pad = ctx->plane_stride * 8u;                 // a multiple of 1024: whole line groups of tiles
+    a.n_groups = (uint32_t)(reads_pad / 1024u);
     a.n_pairs = a.n_groups * ns;
     a.win_begin = ctx->win_begin;
     a.min_qv = std::min<uint32_t>(min_qv, 127u);   // (the byte-parallel compare of the QV path; BAM qualities end at 93)
@@ -559,7 +710,11 @@ void jl_launch_ingest(jl_ctx *ctx, const int32_t *d_pos, const uint32_t *d_cigar
     a.slow_list = d_slow;
     a.msa = ctx->d_msa;
     a.plane_stride = ctx->plane_stride;
-    const uint32_t grid = (a.n_pairs + 7u) / 8u * 32u;
+    a.skip = 0;
+#ifdef JL_TUNING
+    if (const char *e = getenv("JL_ING_SKIP")) a.skip = (uint32_t)atoi(e);
+#endif
+    const uint32_t grid = (a.n_pairs + 7u) / 8u * 8u * kSubTiles;
     if (qv) hipLaunchKernelGGL(ingest_planes_kernel<true>, dim3(grid), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(ingest_planes_kernel<false>, dim3(grid), dim3(256), 0, st, a);
     const uint64_t cap = (uint64_t)ctx->n_reads * ns;

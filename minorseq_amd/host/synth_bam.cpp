@@ -21,6 +21,9 @@ int main(int argc, char **argv)
     struct Plant { uint32_t col, len, permille; };
     std::vector<Plant> plants;   // --insert col:len:permille — insertions before window column `col` in that share of the reads
     bool rich_qv = false;  // filtered bases keep their letter and get a low substitution QV (sq tag) instead of 'N'
+    std::string raw_out;   // --raw-out file: the records as the arrays jl_records_append takes, no BAM (bench.py once_through)
+    uint64_t ref_seed = 0;
+    bool have_ref_seed = false;
     for (int i = 1; i < argc; ++i) {
         const std::string a = argv[i];
         auto need = [&]() -> std::string { if (i + 1 >= argc) { std::cerr << a << " needs a value\n"; std::exit(1); } return argv[++i]; };
@@ -34,6 +37,8 @@ int main(int argc, char **argv)
         else if (a == "--minor-permille") { for (int k = 0; k < 4; ++k) minor[k] = (uint32_t)std::stoul(need()); }
         else if (a == "--ref-offset") ref_offset = (uint32_t)std::stoul(need());  // window starts here in a longer reference
         else if (a == "--rich-qv") rich_qv = true;
+        else if (a == "--raw-out") raw_out = need();
+        else if (a == "--ref-seed") { ref_seed = std::stoull(need()); have_ref_seed = true; }   // reference drawn from another seed than the reads
         else if (a == "--insert") {
             const std::string v = need();
             Plant p;
@@ -46,7 +51,7 @@ int main(int argc, char **argv)
         else if (a == "--config-out") cfg_out = need();
         else { std::cerr << "usage: juliet-synth --reads N --cols L --seed S [--partial p] [--minor-permille a b c d] [--ref-offset k] -o out.bam [--config-out cfg.json]\n"; return 1; }
     }
-    if (out.empty()) { std::cerr << "juliet-synth: -o out.bam is required\n"; return 1; }
+    if (out.empty() && raw_out.empty()) { std::cerr << "juliet-synth: -o out.bam (or --raw-out file) is required\n"; return 1; }
     if (!from_rows.empty()) {
         // Any by-row matrix (codes 0..6, header {n_reads, n_cols, win_begin} as written by `juliet --dump-msa`) as a
         // PacBio-style BAM: tests send hand-built alignments (the reference's printed scenarios) through the tool.
@@ -96,9 +101,69 @@ int main(int argc, char **argv)
         return 0;
     }
     std::vector<uint8_t> ref(n_cols);
-    jl_synth_reference(seed, n_cols, ref.data());
+    jl_synth_reference(have_ref_seed ? ref_seed : seed, n_cols, ref.data());
     jl_synth_plan pl;
     jl_synth_make_plan(&pl, seed, n_cols, sub, del, mask, partial, minor, ref.data());
+
+    if (!raw_out.empty()) {
+        // The same reads as the arrays a BAM decoder hands to jl_records_append (include/juliet_hip.h): pos, cigar words,
+        // cigar offsets, BAM's 4-bit packed bases, their byte offsets, one quality byte per base and its offsets.
+        // File: 8 u64 {magic, n_reads, n_cigar, n_seq_bytes, n_qual, 0, 0, 0}, then the arrays in that order, each padded to 8 bytes.
+        std::vector<int32_t> pos(n_reads);
+        std::vector<uint32_t> cigar;
+        std::vector<uint64_t> cig_off(n_reads + 1, 0), seq_off(n_reads + 1, 0), qual_off(n_reads + 1, 0);
+        std::vector<uint8_t> seq4, qual;
+        cigar.reserve(n_reads * 48);
+        seq4.reserve(n_reads * (size_t)(n_cols / 2 + 1));
+        qual.reserve(n_reads * (size_t)n_cols);
+        static const uint8_t nt16[5] = {1, 2, 4, 8, 15};
+        for (uint64_t i = 0; i < n_reads; ++i) {
+            uint32_t hap, st, en;
+            jl_synth_read(&pl, i, &hap, &st, &en);
+            pos[i] = (int32_t)(ref_offset + st);
+            uint32_t run_op = 99, run_len = 0;
+            auto flush = [&]() { if (run_len) cigar.push_back(run_len << 4 | run_op); run_len = 0; };
+            uint32_t nb = 0;
+            uint8_t half = 0;
+            for (uint32_t c = st; c < en; ++c) {
+                const uint32_t sy = jl_synth_cell(&pl, i, c, hap, st, en, ref[c]);
+                uint32_t op;
+                if (sy == 4) op = CIG_D;
+                else {
+                    op = (sy < 4 && sy == ref[c]) ? CIG_EQ : CIG_X;
+                    const uint8_t code = nt16[sy < 4 ? sy : 4];
+                    if (nb & 1u) seq4.push_back((uint8_t)(half << 4 | code));
+                    else half = code;
+                    ++nb;
+                    qual.push_back(93);
+                }
+                if (op != run_op) { flush(); run_op = op; }
+                ++run_len;
+            }
+            flush();
+            if (nb & 1u) seq4.push_back((uint8_t)(half << 4));
+            cig_off[i + 1] = cigar.size();
+            seq_off[i + 1] = seq4.size();
+            qual_off[i + 1] = qual.size();
+        }
+        std::ofstream f(raw_out, std::ios::binary);
+        const uint64_t hdr[8] = {0x4A4C524157303031ull, n_reads, cigar.size(), seq4.size(), qual.size(), 0, 0, 0};
+        auto put = [&](const void *p, size_t bytes) {
+            static const char zero[8] = {0};
+            f.write((const char *)p, (std::streamsize)bytes);
+            if (bytes % 8) f.write(zero, (std::streamsize)(8 - bytes % 8));
+        };
+        put(hdr, sizeof hdr);
+        put(pos.data(), pos.size() * 4);
+        put(cigar.data(), cigar.size() * 4);
+        put(cig_off.data(), cig_off.size() * 8);
+        put(seq4.data(), seq4.size());
+        put(seq_off.data(), seq_off.size() * 8);
+        put(qual.data(), qual.size());
+        put(qual_off.data(), qual_off.size() * 8);
+        if (!f) { std::cerr << "juliet-synth: cannot write " << raw_out << "\n"; return 2; }
+        if (out.empty()) return 0;
+    }
 
     const uint32_t ref_len = ref_offset + n_cols;
     const std::string header = "@HD\tVN:1.5\tSO:unknown\tpb:3.0.1\n@SQ\tSN:synthetic_ref\tLN:" + std::to_string(ref_len) +

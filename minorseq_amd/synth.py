@@ -124,3 +124,35 @@ def rows(sp: SynthParams, n_cols: int, read_begin: int, read_end: int, ref: np.n
         cell[(ci < s[:, None]) | (ci >= e[:, None])] = 6
         out[r0 - read_begin:r1 - read_begin] = cell
     return out
+
+
+def raw_records(seed, n_reads, n_cols, ref_seed=None, path=None, extra=()):
+    """The synthetic reads as BAM-style record arrays (what a decoder hands to jl_records_append), written by the C++
+    generator `juliet-synth --raw-out` (minorseq_amd/host/synth_bam.cpp: the same jl_synth.h cell function as everything
+    else) and read back: dict(pos, cigar, cig_off, seq4, seq_off, qual, qual_off)."""
+    import os
+    import subprocess
+    import tempfile
+    exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "bin", "juliet-synth")
+    own = path is None
+    if own:
+        fd, path = tempfile.mkstemp(suffix=".jlraw")
+        os.close(fd)
+    try:
+        cmd = [exe, "--reads", str(n_reads), "--cols", str(n_cols), "--seed", str(seed), "--raw-out", path, *extra]
+        if ref_seed is not None:
+            cmd += ["--ref-seed", str(ref_seed)]
+        subprocess.check_call(cmd)
+        hdr = np.fromfile(path, dtype=np.uint64, count=8)
+        assert hdr[0] == 0x4A4C524157303031, "not a juliet-synth --raw-out file"
+        n, n_cig, n_seq, n_qual = (int(x) for x in hdr[1:5])
+        off = 64
+        out = {}
+        for name, dt, cnt in (("pos", np.int32, n), ("cigar", np.uint32, n_cig), ("cig_off", np.uint64, n + 1), ("seq4", np.uint8, n_seq),
+                              ("seq_off", np.uint64, n + 1), ("qual", np.uint8, n_qual), ("qual_off", np.uint64, n + 1)):
+            out[name] = np.fromfile(path, dtype=dt, count=cnt, offset=off)
+            off += (cnt * np.dtype(dt).itemsize + 7) // 8 * 8
+        return out
+    finally:
+        if own and os.path.exists(path):
+            os.remove(path)
