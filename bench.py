@@ -61,7 +61,9 @@ def cpu_baseline(jl, genes, ref, expect, budget_s=12.0, threads=1, rows=None):
     """Oracle (CPU restatement) call+phase on the same reads, bounded to ~budget_s of wall time; also the checker of
     this window's device result (`expect`).
     threads = 1: the plain restatement (no thread option is documented for juliet, so this is the faithful stand-in);
-    threads > 1: its two counting sweeps split over reads with OpenMP (SURVEY.md §8d "all host cores")."""
+    threads > 1: SURVEY.md §8d's "all host cores": OpenMP over columns / codon positions of a column-major copy of the
+    matrix (made before the clock starts, as the GPU's resident matrix is), private counters, no merge; the per-read
+    patterns of the phasing stage split over reads; its exact grouping (a sort of the clean reads) stays serial."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib
     from minorseq_amd import msa
@@ -70,6 +72,8 @@ def cpu_baseline(jl, genes, ref, expect, budget_s=12.0, threads=1, rows=None):
     if rows is None:
         rows = msa.unpack_columns(jl.download_columns(), jl.n_reads)
     orc.set_threads(threads)
+    if threads > 1:
+        orc.set_columns(rows)
     reps, t_total = 0, 0.0
     while reps < 1 or (t_total < budget_s and reps < 100):
         t0 = time.perf_counter()
@@ -79,14 +83,41 @@ def cpu_baseline(jl, genes, ref, expect, budget_s=12.0, threads=1, rows=None):
         t_total += time.perf_counter() - t0
         reps += 1
     orc.set_threads(1)
+    orc.set_columns(None)
     if expect is not None:   # the device's table and haplotypes of this window are the oracle's
         ok = (len(v) == len(expect["count"]) and (v["count"] == expect["count"]).all() and (v["col"] == expect["col"]).all()
               and (ph["hap_count"] == expect["hap_count"]).all() and ph["summary"] == expect["summary"])
         if not ok:
             raise SystemExit("bench.py: the device result of window 0 differs from the oracle's")
-    return {"value": jl.n_reads * reps / t_total, "unit": "reads/s", "cores": threads, "kind": "port",
-            "sample": f"{reps} x the full workload ({jl.n_reads} reads x {jl.n_cols} columns), call+phase, "
-                      f"oracle/juliet_oracle.c, {threads} thread(s), {t_total:.1f} s"}, rows
+    res = {"value": jl.n_reads * reps / t_total, "unit": "reads/s", "cores": threads, "kind": "port",
+           "sample": f"{reps} x the full workload ({jl.n_reads} reads x {jl.n_cols} columns), call+phase, "
+                     f"oracle/juliet_oracle.c, {threads} thread(s), {t_total:.1f} s"}
+    if threads > 1:
+        # the two counting sweeps stream the by-column matrix once each (one byte per cell); what is left is the serial
+        # grouping sort of the phasing stage and the Fisher tests
+        res["host_sweep_GBps"] = 2.0 * jl.n_reads * jl.n_cols * reps / t_total / 1e9
+        res["layout"] = "by-column uint8 matrix, OpenMP over columns / codon positions, private counters"
+    return res, rows
+
+
+def usable_cores():
+    """Cores this process may really use: the affinity mask, capped by the cgroup's CPU quota (a GPU box hands a one-GPU job
+    16 of its cores whatever os.cpu_count() says: 64 threads on them are slower than 16)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    n = min(n, max(1, q // int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, min(n, 256))
 
 
 def signature(out):
@@ -554,7 +585,7 @@ def main():
         watchdog.cancel()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"], rows_host = cpu_baseline(jl, genes, refseq, expected[id(jl)])
-        ncores = min(os.cpu_count() or 1, 64)
+        ncores = usable_cores()
         if ncores > 1:
             out["cpu_baseline_all_cores"], _ = cpu_baseline(jl, genes, refseq, None, budget_s=6.0, threads=ncores, rows=rows_host)
     if rank == 0:
@@ -672,31 +703,49 @@ def config3_strong(capi, sharding, synth, torch, dist, distributed, comm, rank, 
     prm = capi.default_params(n_tests=sharding.default_n_tests(genes))
     wb = sharding.window_bounds(l, world)
     b, e = wb[rank]
-    win = capi.Juliet(local_rank)
-    win.alloc(n, e - b, win_begin=b)
-    win.synth_fill_window(sp, ref)
-    win.sync()
     # the reads are sharded for phasing (SURVEY 8e option A): rank r groups reads [sb[r], sb[r+1])
     sb = sharding.read_slices(n, world)
-    xw = capi.Xwin([win], [x for x, _ in wb], [y - x for x, y in wb], list(range(world)), sb, comm if world > 1 else None)
+    # TWO samples (different reads of the same reference) with a session each, taking turns: sample k + 1's counting
+    # launch is enqueued before sample k's table is waited for, so the latency-bound rest of a step (Fisher stage, the
+    # exchanges, grouping, merge + selection on the host, ids) runs beside the next sample's pileup instead of behind an
+    # idle device — the weak-scaling loop's "launches in flight" for the strong-scaling form.  Every step still takes one
+    # whole sample through the whole path; the device never waits for the host between two pileups.
+    wins, xws = [], []
+    for k in range(2):
+        w = capi.Juliet(local_rank)
+        w.alloc(n, e - b, win_begin=b)
+        w.synth_fill_window(synth.SynthParams(seed=sp.seed + 100 * k), ref)
+        w.sync()
+        wins.append(w)
+        xws.append(capi.Xwin([w], [x for x, _ in wb], [y - x for x, y in wb], list(range(world)), sb, comm if world > 1 else None))
+    win, xw = wins[0], xws[0]
 
-    def step():
-        win.run_async(genes, ref, prm, None, False, 10, False)
-        return xw.phase_raw(10)
+    def enqueue(k):
+        wins[k].run_async(genes, ref, prm, None, False, 10, False)
 
     def fence():
         if distributed:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(3):
-        step()
+    firsts = []
+    for k in (0, 1, 0, 1):      # warm-up, and each sample's result for the checks in the loop
+        enqueue(k)
+        r = xws[k].phase_raw(10)
+        firsts.append((r.n_variants, r.n_haplotypes, r.summary.reported_reads, r.summary.damaged_reads))
+    assert firsts[0] == firsts[2] and firsts[1] == firsts[3]
     fence()
     t0 = time.perf_counter()
     per_step = []
-    for _ in range(reps):
+    enqueue(0)
+    for i in range(reps):
         t_s = time.perf_counter()
-        step()      # ends with the device idle: the call returns once the slice's ids are in HBM
+        k = i & 1
+        if i + 1 < reps:
+            enqueue(k ^ 1)          # the next sample's pileup queues up behind this one's
+        r = xws[k].phase_raw(10)    # returns once this sample's ids are enqueued
+        if (r.n_variants, r.n_haplotypes, r.summary.reported_reads, r.summary.damaged_reads) != firsts[k]:
+            raise SystemExit(f"bench.py: configs[{which}]: a step's result changed between runs")
         per_step.append(time.perf_counter() - t_s)
     fence()
     t = (time.perf_counter() - t0) / reps
@@ -705,6 +754,16 @@ def config3_strong(capi, sharding, synth, torch, dist, distributed, comm, rank, 
         tt = torch.tensor([t], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         t = float(tt.item())
+    # one sample alone, the device idle before and after (what a step cost before the samples took turns)
+    solo = []
+    for _ in range(5):
+        fence()
+        t_s = time.perf_counter()
+        enqueue(0)
+        xws[0].phase_raw(10)
+        torch.cuda.synchronize()
+        solo.append(time.perf_counter() - t_s)
+    t_solo = sorted(solo)[len(solo) // 2]
     res = xw.phase(10, want_reads=True)
     s = res["summary"]
     assert s["reported_reads"] + s["insufficient_reads"] + s["damaged_reads"] == n      # doc/JULIET.md:378-379
@@ -715,19 +774,26 @@ def config3_strong(capi, sharding, synth, torch, dist, distributed, comm, rank, 
     t_k = win.time_pileup(reps=5)
     out = {"workload": f"configs[{which}]: {n} CCS reads x {l} bp reference ({len(genes)} ORF(s)) split into {world} column window(s), call per window + "
                        "jl_xwin_phase_sharded (all-gather of the table, packed column-slice exchange, grouping per read slice, "
-                       "all-gather + C++ merge of the group tables, ids: SURVEY 8e option A)",
+                       "all-gather + C++ merge of the group tables, ids: SURVEY 8e option A); two samples take turns, the next "
+                       "sample's pileup enqueued before this one's table is waited for",
            "value": n / t, "unit": "reads/s", "ms_per_step": 1000.0 * t, "ms_per_step_median": 1000.0 * t_median,
+           "ms_per_step_one_sample_alone": 1000.0 * t_solo,
            "scaling": "strong", "n_gpus": world,
            "columns_per_gpu": int(e - b), "variants_called": int(len(res["merged"])), "variant_positions": int(s["n_positions"]),
            "haplotypes": int(s["n_haplotypes"]),
            "exchanges": "none (one window)" if world == 1 else "1 ncclAllGather of the variant tables + 1 group of packed ncclSend/ncclRecv (slice r of the owned columns to rank r, one message per peer) + 1 ncclAllGather of the group tables",
            # (3 bits per cell, as roofline.frac)
            "pileup_kernel_ms": t_k, "pileup_frac_of_hbm_peak": (n * (e - b) * 0.375) / (t_k * 1e-3) / 1e9 / HBM_PEAK_GBS,
-           # what does NOT shrink like the pileup when the columns are split over more GPUs (the Amdahl term of 1 -> 8 scaling)
-           "serial_residue_ms": 1000.0 * t - t_k, "serial_residue_ms_median": 1000.0 * t_median - t_k}
-    xw.close()
-    win.close()
+           # what does NOT shrink like the pileup when the columns are split over more GPUs (the Amdahl term of 1 -> 8 scaling):
+           # exposed = what a step takes beyond its pileup with the samples taking turns; alone = the same for one sample by itself
+           "serial_residue_ms": 1000.0 * t - t_k, "serial_residue_ms_median": 1000.0 * t_median - t_k,
+           "serial_residue_ms_one_sample_alone": 1000.0 * t_solo - t_k}
+    for x in xws:
+        x.close()
+    for w in wins:
+        w.close()
     return out
+
 
 
 if __name__ == "__main__":

@@ -24,10 +24,23 @@
 #include <omp.h>
 #endif
 
-/* 1 = the plain single-threaded restatement (default).  > 1 = the same loops split over reads with OpenMP and
- * per-thread counters summed afterwards — the "all host cores" CPU baseline of SURVEY.md §8d. */
+/* 1 = the plain single-threaded restatement (default).  > 1 = the "all host cores" CPU baseline of SURVEY.md §8d: OpenMP over
+ * COLUMNS (pileup) and codon positions (histograms) of a column-major copy of the matrix registered with orc_set_columns —
+ * every thread owns its columns' counters, nothing is merged, the sweeps are contiguous streams of host memory — and over
+ * reads for the per-read patterns of the phasing stage.  Without a registered copy the sweeps split over reads with
+ * per-thread counters summed afterwards.  Results are identical either way (tests/test_oracle_pipeline.py). */
 static int g_threads = 1;
+static const uint8_t *g_cols = NULL;   /* [n_cols][n_reads]: column c = n_reads consecutive codes */
+static uint64_t g_cols_reads = 0;
+static uint32_t g_cols_cols = 0;
 void orc_set_threads(int n) { g_threads = n < 1 ? 1 : n; }
+/* by_column = NULL forgets the copy.  The caller keeps it alive and in step with the by-row matrix it passes to the calls. */
+void orc_set_columns(const uint8_t *by_column, uint64_t n_reads, uint32_t n_cols)
+{
+    g_cols = by_column;
+    g_cols_reads = n_reads;
+    g_cols_cols = n_cols;
+}
 int orc_max_threads(void)
 {
 #ifdef _OPENMP
@@ -81,6 +94,27 @@ int orc_pileup(const uint8_t *msa, uint64_t n_reads, uint32_t n_cols, uint32_t *
 {
     memset(col_counts, 0, (size_t)n_cols * 6 * sizeof(uint32_t));
 #ifdef _OPENMP
+    if (g_threads > 1 && g_cols && g_cols_reads == n_reads && g_cols_cols == n_cols) {
+        /* a thread per range of columns, private counters in registers, one contiguous stream per column */
+#pragma omp parallel for schedule(static) num_threads(g_threads)
+        for (int64_t c = 0; c < (int64_t)n_cols; ++c) {
+            const uint8_t *col = g_cols + (uint64_t)c * n_reads;
+            /* four counter sets taken in turn: nearly every cell of a column holds the same symbol, and one counter
+             * incremented cell after cell is a chain of dependent read-modify-writes */
+            uint32_t k[4][8];
+            memset(k, 0, sizeof k);
+            uint64_t i = 0;
+            for (; i + 4 <= n_reads; i += 4) {
+                k[0][col[i] & 7]++;
+                k[1][col[i + 1] & 7]++;
+                k[2][col[i + 2] & 7]++;
+                k[3][col[i + 3] & 7]++;
+            }
+            for (; i < n_reads; ++i) k[0][col[i] & 7]++;
+            for (int s6 = 0; s6 < 6; ++s6) col_counts[(size_t)c * 6 + s6] = k[0][s6] + k[1][s6] + k[2][s6] + k[3][s6];
+        }
+        return 0;
+    }
     if (g_threads > 1) {
 #pragma omp parallel num_threads(g_threads)
         {
@@ -117,6 +151,35 @@ int orc_codon_hist(const uint8_t *msa, uint64_t n_reads, uint32_t n_cols, const 
     memset(hist, 0, (size_t)n_pos * 64 * sizeof(uint32_t));
     memset(coverage, 0, (size_t)n_pos * sizeof(uint32_t));
 #ifdef _OPENMP
+    if (g_threads > 1 && g_cols && g_cols_reads == n_reads && g_cols_cols == n_cols) {
+        /* a thread per range of positions: three contiguous column streams, the position's own 64 bins */
+#pragma omp parallel for schedule(static) num_threads(g_threads)
+        for (int64_t p = 0; p < (int64_t)n_pos; ++p) {
+            const uint32_t c = start_cols[p];
+            if ((uint64_t)c + 2 >= n_cols) continue;
+            const uint8_t *c0 = g_cols + (uint64_t)c * n_reads, *c1 = c0 + n_reads, *c2 = c1 + n_reads;
+            /* bin 64 takes the reads that are not in the coverage (gap, N or uncovered); four histograms in turn, as above */
+            uint32_t h[4][65], cov = 0;
+            memset(h, 0, sizeof h);
+            uint64_t i = 0;
+#define ORC_BIN(j) (((c0[j] | c1[j] | c2[j]) > 3) ? 64u : (16u * c0[j] + 4u * c1[j] + c2[j]))
+            for (; i + 4 <= n_reads; i += 4) {
+                h[0][ORC_BIN(i)]++;
+                h[1][ORC_BIN(i + 1)]++;
+                h[2][ORC_BIN(i + 2)]++;
+                h[3][ORC_BIN(i + 3)]++;
+            }
+            for (; i < n_reads; ++i) h[0][ORC_BIN(i)]++;
+#undef ORC_BIN
+            for (int j = 0; j < 64; ++j) {
+                const uint32_t v = h[0][j] + h[1][j] + h[2][j] + h[3][j];
+                hist[(size_t)p * 64 + j] = v;
+                cov += v;
+            }
+            coverage[p] = cov;
+        }
+        return 0;
+    }
     if (g_threads > 1) {
 #pragma omp parallel num_threads(g_threads)
         {
@@ -373,7 +436,7 @@ static int cmp_read_pattern(const void *x, const void *y)
 }
 
 typedef struct {
-    uint32_t count, first_read, first_slot;
+    uint32_t count, first_read, first_slot, id;
 } grp;
 
 /* SPEC §8 order: count descending, then pattern ascending (codon indices compared position by position) */
@@ -418,8 +481,14 @@ int orc_phase(const uint8_t *msa, uint64_t n_reads, uint32_t n_cols, const orc_v
     uint8_t *patterns = (uint8_t *)malloc((size_t)n_reads * vp);
     uint32_t *clean = (uint32_t *)malloc((size_t)n_reads * sizeof(uint32_t));
     uint32_t n_clean = 0;
-    for (uint64_t i = 0; i < n_reads; ++i) {
-        const uint8_t *row = msa + i * n_cols;
+    /* per read: pattern + damage flags (independent of each other: threads split the reads when there are several);
+     * the categories and the list of clean reads follow in read order */
+    uint8_t *rflags = (uint8_t *)malloc((size_t)n_reads + 1);
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(g_threads) if (g_threads > 1)
+#endif
+    for (int64_t i = 0; i < (int64_t)n_reads; ++i) {
+        const uint8_t *row = msa + (uint64_t)i * n_cols;
         unsigned flags = 0;
         uint8_t *pat = patterns + (size_t)i * vp;
         for (uint32_t p = 0; p < vp; ++p) {
@@ -433,6 +502,10 @@ int orc_phase(const uint8_t *msa, uint64_t n_reads, uint32_t n_cols, const orc_v
             }
             pat[p] = (uint8_t)(16 * (s[0] & 3) + 4 * (s[1] & 3) + (s[2] & 3));
         }
+        rflags[i] = (uint8_t)flags;
+    }
+    for (uint64_t i = 0; i < n_reads; ++i) {
+        const unsigned flags = rflags[i];
         if (flags) {
             sum->damaged_reads++;
             if (flags & FLAG_GAP) sum->marginal_gap++;
@@ -444,39 +517,88 @@ int orc_phase(const uint8_t *msa, uint64_t n_reads, uint32_t n_cols, const orc_v
             read_hap[i] = HAP_INSUFFICIENT;
         }
     }
+    free(rflags);
 
-    /* exact grouping: sort clean reads by (pattern, index), run-length */
-    g_vp = vp;
-    g_patterns = patterns;
-    qsort(clean, n_clean, sizeof(uint32_t), cmp_read_pattern);
     grp *groups = (grp *)malloc(((size_t)n_clean + 1) * sizeof(grp));
     uint32_t n_groups = 0;
-    for (uint32_t s = 0; s < n_clean;) {
-        uint32_t e = s + 1;
-        while (e < n_clean &&
-               memcmp(patterns + (size_t)clean[s] * vp, patterns + (size_t)clean[e] * vp, vp) == 0)
-            ++e;
-        groups[n_groups].count = e - s;
-        groups[n_groups].first_read = clean[s]; /* smallest index: sort is by (pattern, index) */
-        groups[n_groups].first_slot = s;
-        ++n_groups;
-        s = e;
+    uint32_t *gid_of = NULL;   /* all-cores form: group of every clean read */
+    g_vp = vp;
+    g_patterns = patterns;
+    if (g_threads > 1) {
+        /* The all-cores baseline groups in one pass over the clean reads, in read order: an open-addressing table keyed
+         * by the pattern's bytes whose slots hold a group number; equality is decided by comparing whole patterns (never
+         * by the hash), the first read that brings a pattern is the group's first read.  Same groups, same counts, same
+         * first reads as the sort below — which costs n log n pattern comparisons on one thread. */
+        uint64_t M = 64;
+        while (M < 2 * (uint64_t)n_clean) M <<= 1;
+        uint32_t *slot = (uint32_t *)malloc(M * sizeof(uint32_t));
+        memset(slot, 0xFF, M * sizeof(uint32_t));
+        gid_of = (uint32_t *)malloc(((size_t)n_clean + 1) * sizeof(uint32_t));
+        for (uint32_t s = 0; s < n_clean; ++s) {
+            const uint8_t *pat = patterns + (size_t)clean[s] * vp;
+            uint64_t h = 1469598103934665603ull;
+            for (uint32_t p = 0; p < vp; ++p) h = (h ^ pat[p]) * 1099511628211ull;
+            uint64_t at = (h ^ (h >> 29)) & (M - 1);
+            for (;;) {
+                const uint32_t g = slot[at];
+                if (g == 0xFFFFFFFFu) {
+                    slot[at] = n_groups;
+                    groups[n_groups].count = 1;
+                    groups[n_groups].first_read = clean[s];
+                    groups[n_groups].first_slot = s;
+                    groups[n_groups].id = n_groups;
+                    gid_of[s] = n_groups++;
+                    break;
+                }
+                if (memcmp(patterns + (size_t)groups[g].first_read * vp, pat, vp) == 0) {
+                    groups[g].count++;
+                    gid_of[s] = g;
+                    break;
+                }
+                at = (at + 1) & (M - 1);
+            }
+        }
+        free(slot);
+    } else {
+        /* exact grouping: sort clean reads by (pattern, index), run-length */
+        qsort(clean, n_clean, sizeof(uint32_t), cmp_read_pattern);
+        for (uint32_t s = 0; s < n_clean;) {
+            uint32_t e = s + 1;
+            while (e < n_clean &&
+                   memcmp(patterns + (size_t)clean[s] * vp, patterns + (size_t)clean[e] * vp, vp) == 0)
+                ++e;
+            groups[n_groups].count = e - s;
+            groups[n_groups].first_read = clean[s]; /* smallest index: sort is by (pattern, index) */
+            groups[n_groups].first_slot = s;
+            groups[n_groups].id = n_groups;
+            ++n_groups;
+            s = e;
+        }
     }
     qsort(groups, n_groups, sizeof(grp), cmp_grp);
 
     uint32_t H = 0;
+    uint16_t *hap_of_gid = gid_of ? (uint16_t *)malloc(((size_t)n_groups + 1) * sizeof(uint16_t)) : NULL;
     for (uint32_t gi = 0; gi < n_groups; ++gi) {
         const grp *G = &groups[gi];
         if (G->count >= min_reads && H < ORC_MAX_HAP) {
             hap_count[H] = G->count;
             hap_first[H] = G->first_read;
             memcpy(hap_pattern + (size_t)H * n_var, patterns + (size_t)G->first_read * vp, vp);
-            for (uint32_t s = G->first_slot; s < G->first_slot + G->count; ++s) read_hap[clean[s]] = (uint16_t)H;
+            if (hap_of_gid) hap_of_gid[G->id] = (uint16_t)H;
+            else
+                for (uint32_t s = G->first_slot; s < G->first_slot + G->count; ++s) read_hap[clean[s]] = (uint16_t)H;
             sum->reported_reads += G->count;
             ++H;
         } else {
+            if (hap_of_gid) hap_of_gid[G->id] = HAP_INSUFFICIENT;
             sum->insufficient_reads += G->count;
         }
+    }
+    if (gid_of) {
+        for (uint32_t s = 0; s < n_clean; ++s) read_hap[clean[s]] = hap_of_gid[gid_of[s]];
+        free(hap_of_gid);
+        free(gid_of);
     }
     sum->n_haplotypes = H;
 

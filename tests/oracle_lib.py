@@ -55,6 +55,16 @@ class Oracle:
         assert lib.orc_sizeof_variant() == VARIANT.itemsize
         assert lib.orc_sizeof_params() == C.sizeof(Params)
 
+    def set_columns(self, rows):
+        """Registers a column-major copy of `rows` (or forgets it: None) for the multi-threaded counting sweeps."""
+        if rows is None:
+            self._cols = None
+            self.lib.orc_set_columns(None, C.c_uint64(0), C.c_uint32(0))
+            return
+        rows = np.ascontiguousarray(rows, dtype=np.uint8)
+        self._cols = np.ascontiguousarray(rows.T)
+        self.lib.orc_set_columns(self._cols.ctypes.data_as(C.c_void_p), C.c_uint64(rows.shape[0]), C.c_uint32(rows.shape[1]))
+
     def set_threads(self, n):
         """1 = the plain restatement; more = OpenMP over reads in the two counting sweeps (same results)."""
         self.lib.orc_set_threads(int(n))

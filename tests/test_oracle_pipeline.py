@@ -321,3 +321,36 @@ def test_two_formulations_of_the_consensus_agree(oracle):
     want = "".join(("ACGTTG" if c == 30 else "GGA" if c == 60 else "CCC" if c == 66 else "") + "ACGT"[ref[c]] for c in range(l))
     assert a == want                                                   # in frame and in most reads; the 2-base one never
     assert "CCC" + "ACGT"[ref[66]] not in oracle.fuse(col, lh, bc, 0.5, 10)[60:80]     # 6 columns behind the one at 60: too close at distance 10
+
+
+def test_all_cores_form_equals_the_plain_restatement(oracle):
+    """bench.py's cpu_baseline_all_cores leg: OpenMP over columns / codon positions of a registered by-column copy (and over
+    reads for the patterns of the phasing stage) gives exactly what the single-threaded loops give; so does the older
+    split over reads that is used when no copy is registered."""
+    from minorseq_amd import capi, synth
+    n, l = 3000, 240
+    sp = synth.SynthParams(seed=5, minor_permille=(70, 60, 50, 40), partial_rate=0.2)
+    ref = synth.reference(sp.seed, l)
+    rows = synth.rows(sp, l, 0, n, ref)
+    genes = np.array([(1, l + 1), (20, 200)], dtype=capi.GENE)
+    want_v = oracle.call(rows, genes, refseq=ref)
+    want_c = oracle.pileup(rows)
+    want_p = oracle.phase(rows, want_v)
+    assert len(want_v) >= 4
+    try:
+        for with_cols in (True, False):
+            oracle.set_threads(4)
+            oracle.set_columns(rows if with_cols else None)
+            v = oracle.call(rows, genes, refseq=ref)
+            assert v.tobytes() == want_v.tobytes()
+            assert (oracle.pileup(rows) == want_c).all()
+            p = oracle.phase(rows, v)
+            assert p["summary"] == want_p["summary"] and (p["read_hap"] == want_p["read_hap"]).all()
+            assert (p["hap_count"] == want_p["hap_count"]).all() and (p["hit"] == want_p["hit"]).all()
+            m = oracle.call(rows, genes)      # majority mode as well
+            oracle.set_threads(1)
+            oracle.set_columns(None)
+            assert m.tobytes() == oracle.call(rows, genes).tobytes()
+    finally:
+        oracle.set_threads(1)
+        oracle.set_columns(None)
