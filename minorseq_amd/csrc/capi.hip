@@ -1153,9 +1153,19 @@ static int phase_settle(jl_ctx *ctx, jl_phase_meta *out)
             JL_HIP(ctx, hipStreamSynchronize(st));
         }
     }
-    if (meta.overflow & 32u)
-        return jl_fail(ctx, JL_ERR_DEVICE, "a phasing workgroup gave up waiting for the selection of its launch (the launch's "
-                                           "workgroups were not resident together): the run's phasing results are invalid");
+    if (meta.overflow & 32u) {
+        // A workgroup of the folded launch gave up waiting for the selection (the launch's workgroups were not resident
+        // together): some reads have no id.  The stage runs again with the ids in a launch of their own — transparently;
+        // this context stays unfolded from now on.
+        ctx->no_fold = true;
+        ctx->fold_reruns++;
+        ctx->alloc_version++;
+        jl_launch_phase(ctx, st, ctx->last_min_reads, false, false, false);
+        JL_HIP(ctx, hipGetLastError());
+        JL_HIP(ctx, hipMemcpyAsync(&meta, ctx->d_meta, sizeof meta, hipMemcpyDeviceToHost, st));
+        JL_HIP(ctx, hipStreamSynchronize(st));
+        if (meta.overflow & 32u) return jl_fail(ctx, JL_ERR_DEVICE, "the unfolded phase launch reports a time-out");
+    }
     *out = meta;
     return JL_OK;
 }
@@ -1506,7 +1516,14 @@ int jl_run_async(jl_ctx *ctx, const jl_gene *genes, uint32_t n_genes, const uint
 
 // Spin on the pinned sequence word of the last run (see done_kernel).  A device fault would leave it unset for
 // ever, so after a long wait the stream is asked directly.
-int jl_run_wait_impl(jl_ctx *ctx) { return jl_run_wait_seq(ctx, ctx->runs_launched); }
+int jl_run_wait_impl(jl_ctx *ctx)
+{
+    int rc = jl_run_wait_seq(ctx, ctx->runs_launched);
+    // a result block without its magic behind a phasing run: the folded launch timed out (see jl_phase_rerun_unfolded)
+    if (rc == JL_OK && ctx->pack_valid && ctx->phase_done && ctx->h_pack && ctx->h_pack->magic != JL_PACK_MAGIC && !ctx->no_fold)
+        rc = jl_phase_rerun_unfolded(ctx);
+    return rc;
+}
 
 // `want`: the value of runs_launched right after the run of interest was launched.  1: the stream failed, 2: it went
 // idle without the word.  Touches nothing of the context but the pinned word: any thread may wait.
@@ -1528,6 +1545,31 @@ static int run_wait_word(volatile uint32_t *p, uint32_t want, hipStream_t stream
     }
     __atomic_thread_fence(__ATOMIC_ACQUIRE);
     return 0;
+}
+
+int jl_phase_rerun_unfolded(jl_ctx *ctx)
+{
+    hipStream_t st = ctx->run_stream ? ctx->run_stream : ctx->stream;
+    JL_HIP(ctx, hipSetDevice(ctx->device));
+    JL_HIP(ctx, hipStreamSynchronize(st));
+    uint32_t ovf = 0;
+    JL_HIP(ctx, hipMemcpy(&ovf, &ctx->d_meta->overflow, 4, hipMemcpyDeviceToHost));
+    if (!(ovf & 32u)) return jl_fail(ctx, JL_ERR_DEVICE, "the run's result block was not written (no folded launch timed out)");
+    ctx->no_fold = true;
+    ctx->fold_reruns++;
+    ctx->alloc_version++;   // captured graphs of this context folded
+    // the Fisher stage's masks and rows are resident: the plan comes out of them again, the ids from phase_assign_kernel,
+    // the completion word from a node of its own (only the fused launches fold, so the run is one of theirs).  The run
+    // counters are the Fisher launch's to zero (call_kernel): here a memset stands in for it.
+    JL_HIP(ctx, hipMemsetAsync(ctx->d_meta, 0, sizeof(jl_phase_meta), st));
+    jl_launch_phase(ctx, st, ctx->last_min_reads, true, true, false);
+    jl_launch_done_on(ctx, st);
+    JL_HIP(ctx, hipGetLastError());
+    ctx->runs_launched++;
+    int rc = jl_run_wait_seq(ctx, ctx->runs_launched);
+    if (rc) return rc;
+    if (ctx->h_pack->magic != JL_PACK_MAGIC) return jl_fail(ctx, JL_ERR_DEVICE, "the unfolded phase launch left no result block either");
+    return JL_OK;
 }
 
 int jl_run_wait_seq(jl_ctx *ctx, uint32_t want)

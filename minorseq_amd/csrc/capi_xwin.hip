@@ -48,6 +48,29 @@ int xw_fail(jl_ctx *pc, std::string *err, int status, const std::string &msg)
 // Pack launches for this rank's owned positions: destination s gets slice s of the 9 * k_count plane rows of the owned
 // columns, laid out as rows of stride dst_stride[s] (the own slice: straight into the compact matrix).  `plan`: non-null for the first
 // launch of a step, which then also writes the compact matrix's phasing plan.
+// room for what this rank sends its peers (nothing is enqueued: a rank that cannot allocate says so BEFORE the exchange)
+int xw_reserve_send(jl_ctx *pc, const xwin_schedule &sch, const uint64_t *slice_begin, int world, int rank, xw_send_buf *send, std::string *err)
+{
+    const uint32_t kn = sch.k_count[(size_t)rank];
+    size_t need = 0;
+    if (kn)
+        for (int s = 0; s < world; ++s) {
+            const uint64_t n_s = slice_begin[s + 1] - slice_begin[s];
+            if (s != rank && n_s) need += (size_t)9 * kn * xwin_stride(n_s);
+        }
+    if (need > send->cap) {
+        if (send->d) hipFree(send->d);
+        send->d = nullptr;
+        send->cap = 0;
+        if (hipMalloc(&send->d, need) != hipSuccess) {
+            (void)hipGetLastError();
+            return xw_fail(pc, err, JL_ERR_MEMORY, "send buffer of the column exchange");
+        }
+        send->cap = need;
+    }
+    return JL_OK;
+}
+
 int xw_pack(jl_ctx *pc, jl_ctx *const *wins, const xw_layout &lay, const xwin_schedule &sch, const uint64_t *slice_begin, int world,
             int rank, const uint64_t *dst_stride_override, xw_send_buf *send, const jl_xw_pack_args *plan, std::string *err)
 {
@@ -56,18 +79,7 @@ int xw_pack(jl_ctx *pc, jl_ctx *const *wins, const xw_layout &lay, const xwin_sc
     struct dst_t { uint8_t *dst; uint64_t stride, byte_begin, bytes; uint32_t tail_mask; };
     std::vector<dst_t> dsts;
     if (kn) {
-        size_t need = 0;
-        for (int s = 0; s < world; ++s) {
-            const uint64_t n_s = slice_begin[s + 1] - slice_begin[s];
-            if (s != rank && n_s) need += (size_t)9 * kn * xwin_stride(n_s);
-        }
-        if (need > send->cap) {
-            if (send->d) hipFree(send->d);
-            send->d = nullptr;
-            send->cap = 0;
-            if (hipMalloc(&send->d, need) != hipSuccess) return xw_fail(pc, err, JL_ERR_MEMORY, "send buffer of the column exchange");
-            send->cap = need;
-        }
+        if (int rc = xw_reserve_send(pc, sch, slice_begin, world, rank, send, err)) return rc;
         size_t off = 0;
         for (int s = 0; s < world; ++s) {
             const uint64_t n_s = slice_begin[s + 1] - slice_begin[s];
@@ -592,6 +604,35 @@ void jl_xwin_destroy(jl_xwin *x)
 
 const char *jl_xwin_last_error(const jl_xwin *x) { return x ? x->err.c_str() : ""; }
 
+// Before an exchange every rank says how it fares: an all-gather of {magic, status, group-block shape}.  A rank that failed
+// on its own between two collectives (an allocation, a launch) still takes part in THIS one, so its peers leave the step
+// with an error instead of waiting inside the exchange for a message that never comes; ranks whose group blocks have
+// different shapes (their histories diverged after an earlier local error) stop here too instead of decoding each other's
+// blocks with the wrong layout.  16 bytes per rank through the table blocks, which are free at this point.
+#define JL_XW_AGREE_MAGIC 0x4A4C4147u
+static int xs_agree(jl_xwin *x, int local_rc)
+{
+    jl_ctx *pc = x->pc;
+    if (!x->d_tsend || !x->d_trecv || x->tblk < 16u) return local_rc ? local_rc : xs_fail(x, JL_ERR_STATE, "no table blocks for the status exchange");
+    uint32_t *h = reinterpret_cast<uint32_t *>(x->h_tsend);
+    h[0] = JL_XW_AGREE_MAGIC; h[1] = (uint32_t)(-local_rc); h[2] = x->gcap; h[3] = x->pstride;
+    if (hipMemcpyAsync(x->d_tsend, x->h_tsend, 16, hipMemcpyHostToDevice, pc->stream) != hipSuccess) return xs_fail(x, JL_ERR_DEVICE, "status upload");
+    if (jl_tp_allgather(x->comm, x->d_tsend, x->d_trecv, 16, pc->stream) != JL_OK)
+        return xs_fail(x, JL_ERR_COMM, "status exchange before the column slices: " + x->comm->tp_error);
+    if (int rc = xs_fetch_and_wait(x, x->d_trecv, x->h_trecv, 16u * (size_t)x->world)) return rc;
+    for (int r = 0; r < x->world; ++r) {
+        const uint32_t *q = reinterpret_cast<const uint32_t *>(x->h_trecv + 16u * (size_t)r);
+        if (q[0] != JL_XW_AGREE_MAGIC) return xs_fail(x, JL_ERR_COMM, "rank " + std::to_string(r) + " sent no status");
+        if (q[1] != 0u)
+            return local_rc ? local_rc
+                            : xs_fail(x, JL_ERR_COMM, "rank " + std::to_string(r) + " failed before the exchange (status -" + std::to_string(q[1]) + "): the step ends on every rank");
+        if (q[2] != x->gcap || q[3] != x->pstride)
+            return xs_fail(x, JL_ERR_COMM, "rank " + std::to_string(r) + " holds group blocks of another shape (" + std::to_string(q[2]) + " x " +
+                                               std::to_string(q[3]) + " against " + std::to_string(x->gcap) + " x " + std::to_string(x->pstride) + ")");
+    }
+    return local_rc;
+}
+
 int jl_xwin_phase_sharded(jl_xwin *x, uint32_t min_reads, jl_xwin_result *out)
 {
     if (!x || !out) return JL_ERR_ARG;
@@ -674,9 +715,19 @@ int jl_xwin_phase_sharded(jl_xwin *x, uint32_t min_reads, jl_xwin_result *out)
     if ((rc = xs_reserve_blocks(x, std::max<uint32_t>(JL_XW_GCAP0, x->gcap), (kwords * JL_POS_PER_WORD + 7u) / 8u * 8u))) return rc;
     for (int attempt = 0;; ++attempt) {
         uint8_t *blk_dev = collective ? x->d_blk_send : x->h_blk;   // where THIS rank's kernels write its block
+        // everything that can fail on this rank alone comes first; with peers the verdict is shared before anything is sent
+        int local_rc = JL_OK;
         if (x->n_mine) {
-            if ((rc = jl_msa_alloc(pc, x->n_mine, 3u * vp, 0))) return xs_fail_ctx(x, rc, pc);
-            if ((rc = jl_phase_groups_prepare(pc, vp))) return xs_fail_ctx(x, rc, pc);
+            if ((local_rc = jl_msa_alloc(pc, x->n_mine, 3u * vp, 0))) xs_fail_ctx(x, local_rc, pc);
+            else if ((local_rc = jl_phase_groups_prepare(pc, vp))) xs_fail_ctx(x, local_rc, pc);
+        }
+        if (!local_rc && world > 1) local_rc = xw_reserve_send(pc, x->sch, x->slice_begin.data(), world, me, &x->send, &x->err);
+        if (collective && world > 1) {
+            if ((rc = xs_agree(x, local_rc))) return rc;
+        } else if (local_rc) {
+            return local_rc;
+        }
+        if (x->n_mine) {
             pc->exp_ext_head = reinterpret_cast<uint32_t *>(blk_dev);
             pc->exp_ext_count = reinterpret_cast<uint32_t *>(blk_dev + sizeof(jl_exp_head));
             pc->exp_ext_pattern = blk_dev + sizeof(jl_exp_head) + (size_t)x->gcap * 4u;

@@ -402,6 +402,9 @@ struct jl_ctx {
     uint32_t *d_cooc = nullptr;        // [cooc_cap][cooc_cap]
     uint32_t cooc_cap = 256;
     bool phase_done = false;
+    bool no_fold = false;        // a folded phase launch of this context timed out once (its workgroups were not resident together):
+                                 // from then on the per-read ids come from a launch of their own (jl_phase_rerun_unfolded)
+    uint32_t fold_reruns = 0;    // how often that happened
     bool phase_generic = false;  // multi-word pipeline selected (more than 20 positions, or results beyond the fused selection)
     bool phase_two = false;      // 11..20 positions: the two-word fused launch (jl_two_word)
     uint64_t *d_slot_key_a = nullptr, *d_slot_key_b = nullptr;   // its half-key tables [table slots]
@@ -477,6 +480,10 @@ void jl_launch_pack_rows(jl_ctx *ctx, const uint8_t *d_rows);
 void jl_launch_nibbles_to_planes(jl_ctx *ctx, const uint8_t *d_nib, uint64_t nib_stride, uint32_t c0, uint32_t n, uint32_t *d_bad);
 void jl_launch_planes_to_nibbles(jl_ctx *ctx, uint8_t *d_nib, uint64_t nib_stride, uint32_t c0, uint32_t n);
 void jl_launch_done(jl_ctx *ctx);
+void jl_launch_done_on(jl_ctx *ctx, hipStream_t st);
+// a run whose folded phase launch gave up waiting (meta.overflow & 32): the phasing stage again, unfolded, behind everything
+// on the run's stream; blocks until it is done.  The call stage's results are still resident.
+extern "C" int jl_phase_rerun_unfolded(jl_ctx *ctx);
 void jl_launch_done_group(const jl_done_ent *d_ents, uint32_t n, hipStream_t st);
 void jl_launch_stamp(jl_ctx *ctx, uint32_t slot);
 extern "C" int jl_run_prepare(jl_ctx *ctx, const jl_gene *genes, uint32_t n_genes, const uint8_t *refseq, uint32_t ref_len,

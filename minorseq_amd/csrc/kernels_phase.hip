@@ -1509,6 +1509,13 @@ __device__ __forceinline__ void phase_fused1_body(const jl_win_phase &w, const j
                     break;
                 }
             }
+#ifdef JL_TUNING
+            if (S.fold == 2u && bits != 0u) {   // forced: behave as if the wait had run out just before the selection arrived
+                atomicOr(&meta->overflow, 32u);
+                if (S.mirror) __hip_atomic_store(&S.mirror->magic, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                bits = 0u;
+            }
+#endif
             s_idbits = bits;   // 0: timed out
         }
         JL_STAMP(20);
@@ -1664,8 +1671,12 @@ bool jl_fill_win_phase(jl_ctx *ctx, uint32_t min_reads, bool signal, uint32_t fo
         }
     }
     // (an exporting run keeps every read's flags and slot: jl_phase_regroup maps them once the merge is known)
-    const bool fold = !generic && !ctx->phase_export && fblocks + 1u <= fold_budget;
+    const bool fold = !generic && !ctx->phase_export && !ctx->no_fold && fblocks + 1u <= fold_budget;
     S.fold = fold ? 1u : 0u;
+#ifdef JL_TUNING
+    // tests of the re-run: the waiting workgroups of a folded launch give up at once (as if they had not been resident together)
+    if (fold && getenv("JL_FORCE_FOLD_TIMEOUT")) S.fold = 2u;
+#endif
     S.flag = ctx->d_sync + 4; S.arrive2 = ctx->d_sync + 3;
     S.read_hap = ctx->read_hap_out ? ctx->read_hap_out : ctx->d_read_hap;
     S.seq_host = (fold ? signal : signal_select) ? ctx->h_seq : nullptr;

@@ -254,6 +254,10 @@ void jl_launch_done(jl_ctx *ctx)
 {
     hipLaunchKernelGGL(done_kernel, dim3(1), dim3(1), 0, ctx->stream, ctx->d_sync, ctx->h_seq);
 }
+void jl_launch_done_on(jl_ctx *ctx, hipStream_t st)
+{
+    hipLaunchKernelGGL(done_kernel, dim3(1), dim3(1), 0, st, ctx->d_sync, ctx->h_seq);
+}
 
 #ifdef JL_TUNING
 // tuning aid (JL_TIMELINE=1): a one-thread node that records the device's constant-rate clock between the stages of

@@ -401,6 +401,27 @@ int drm_masks_of(jl_ctx *ctx, const DeviceStageInput &in, std::vector<uint64_t> 
 // One rank = one device: its windows out of the records uploaded to it, the call stage per window with the GLOBAL
 // Bonferroni factor, then — with phasing — its share of the cross-window sequence (jl_xwin_phase_sharded: the ranks'
 // collectives meet inside).  Every rank ends with the whole result; rank 0's is written.
+// The rank threads of one process agree before they enter anything collective: a rank that failed on its own (context,
+// ingest, call stage) must not leave its peers waiting inside the communicator's bootstrap or an exchange.  Every rank
+// calls vote() exactly once; all of them learn whether all of them are fine.
+struct RankVote {
+    explicit RankVote(int n) : n_(n) {}
+    bool vote(bool ok)
+    {
+        std::unique_lock<std::mutex> lk(m_);
+        all_ok_ = all_ok_ && ok;
+        if (++arrived_ == n_) cv_.notify_all();
+        else cv_.wait(lk, [this] { return arrived_ == n_; });
+        return all_ok_;
+    }
+
+private:
+    std::mutex m_;
+    std::condition_variable cv_;
+    int n_, arrived_ = 0;
+    bool all_ok_ = true;
+};
+
 struct RankJob {
     int rank = 0, world = 1, device = 0;
     jl_ctx *records = nullptr;
@@ -417,11 +438,80 @@ struct RankJob {
     std::vector<uint16_t> ids;           // this rank's slice
 };
 
+// the stages of a rank that involve no other rank: window contexts, ingest, call stage, column counts
+static void run_rank_local(RankJob &job, const DeviceStageInput &in, const std::vector<WindowPlan> &plan, std::vector<uint32_t> &col_counts,
+                           std::chrono::steady_clock::time_point &t_last);
+
 void run_rank(RankJob &job, const DeviceStageInput &in, const std::vector<WindowPlan> &plan, const uint8_t *comm_id,
-              std::vector<uint32_t> &col_counts, const std::vector<uint64_t> &slice_begin)
+              std::vector<uint32_t> &col_counts, const std::vector<uint64_t> &slice_begin, RankVote *vote)
+{
+    auto t_last = std::chrono::steady_clock::now();
+    run_rank_local(job, in, plan, col_counts, t_last);
+    const Options &opt = *in.opt;
+    if (opt.phasing && job.world > 1 && vote) {
+        // nothing collective has been touched yet: either every rank goes on, or none does
+        if (!vote->vote(job.error.empty())) {
+            if (job.error.empty()) job.error = "stopped: another rank failed before the exchange";
+            return;
+        }
+    } else if (!job.error.empty()) {
+        return;
+    }
+    if (!opt.phasing) return;
+    auto lap = [&](const char *what) {
+        const auto now = std::chrono::steady_clock::now();
+        job.laps.emplace_back(what, std::chrono::duration<double, std::milli>(now - t_last).count());
+        t_last = now;
+    };
+    auto fail = [&](const char *what, jl_ctx *c) { job.error = std::string(what) + ": " + (c ? jl_last_error(c) : "failed"); };
+    // The communicator's bootstrap is collective too: a rank that fails in it leaves the others to RCCL's own time-out.
+    if (job.world > 1 && (job.inproc ? jl_comm_create_inproc(job.wins[0], comm_id, job.rank, job.world, &job.comm)
+                                     : jl_comm_create(job.wins[0], comm_id, job.rank, job.world, &job.comm)) != JL_OK)
+        return fail("communicator", job.wins[0]);
+    std::vector<uint32_t> wb, wn;
+    std::vector<int32_t> wr;
+    for (const WindowPlan &wp : plan) { wb.push_back(wp.begin); wn.push_back(wp.ncols); wr.push_back(wp.rank); }
+    jl_xwin *x = nullptr;
+    if (jl_xwin_create(job.wins.data(), (uint32_t)job.wins.size(), job.comm, wb.data(), wn.data(), wr.data(), (uint32_t)plan.size(),
+                       slice_begin.data(), &x) != JL_OK)
+        return fail("cross-window session", nullptr);
+    lap("communicator + session");
+    jl_xwin_result r;
+    if (jl_xwin_phase_sharded(x, opt.min_reads, &r) != JL_OK) {
+        job.error = std::string("cross-window phasing: ") + jl_xwin_last_error(x);
+        jl_xwin_destroy(x);
+        return;
+    }
+    lap("cross-window phasing");
+    Results &R = job.res;
+    R.var.assign(r.merged, r.merged + r.n_variants);
+    for (jl_variant &v : R.var) v.col -= in.win_begin;
+    R.ps = r.summary;
+    R.ps.n_positions = r.n_positions;
+    R.ps.n_haplotypes = r.n_haplotypes;
+    R.pos_cols.resize(r.n_positions);
+    for (uint32_t p = 0; p < r.n_positions; ++p) R.pos_cols[p] = r.pos_global[p] - in.win_begin;
+    if (r.n_positions) {
+        R.hap_count.assign(r.hap_count, r.hap_count + r.n_haplotypes);
+        R.hap_pattern.assign(r.hap_pattern, r.hap_pattern + (size_t)r.n_haplotypes * r.n_positions);
+        R.hit.assign(r.hit, r.hit + (size_t)r.n_variants * r.n_haplotypes);
+    }
+    R.pat_stride = r.n_positions;
+    R.hit_stride = r.n_haplotypes;
+    job.slice_begin = r.slice_begin;
+    job.slice_reads = r.slice_reads;
+    job.ids.resize(r.slice_reads ? r.slice_reads : 1);
+    if (jl_xwin_read_hap_fetch(x, job.ids.data()) != JL_OK) job.error = std::string("per-read ids: ") + jl_xwin_last_error(x);
+    job.ids.resize(r.slice_reads);
+    lap("per-read ids");
+    jl_xwin_destroy(x);
+    lap("session closed");
+}
+
+static void run_rank_local(RankJob &job, const DeviceStageInput &in, const std::vector<WindowPlan> &plan, std::vector<uint32_t> &col_counts,
+                           std::chrono::steady_clock::time_point &t_last)
 {
     auto fail = [&](const char *what, jl_ctx *c) { job.error = std::string(what) + ": " + (c ? jl_last_error(c) : "failed"); };
-    auto t_last = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) {
         const auto now = std::chrono::steady_clock::now();
         job.laps.emplace_back(what, std::chrono::duration<double, std::milli>(now - t_last).count());
@@ -470,47 +560,6 @@ void run_rank(RankJob &job, const DeviceStageInput &in, const std::vector<Window
         }
         return;
     }
-    if (job.world > 1 && (job.inproc ? jl_comm_create_inproc(job.wins[0], comm_id, job.rank, job.world, &job.comm)
-                                     : jl_comm_create(job.wins[0], comm_id, job.rank, job.world, &job.comm)) != JL_OK)
-        return fail("communicator", job.wins[0]);
-    std::vector<uint32_t> wb, wn;
-    std::vector<int32_t> wr;
-    for (const WindowPlan &wp : plan) { wb.push_back(wp.begin); wn.push_back(wp.ncols); wr.push_back(wp.rank); }
-    jl_xwin *x = nullptr;
-    if (jl_xwin_create(job.wins.data(), (uint32_t)job.wins.size(), job.comm, wb.data(), wn.data(), wr.data(), (uint32_t)plan.size(),
-                       slice_begin.data(), &x) != JL_OK)
-        return fail("cross-window session", nullptr);
-    lap("communicator + session");
-    jl_xwin_result r;
-    if (jl_xwin_phase_sharded(x, opt.min_reads, &r) != JL_OK) {
-        job.error = std::string("cross-window phasing: ") + jl_xwin_last_error(x);
-        jl_xwin_destroy(x);
-        return;
-    }
-    lap("cross-window phasing");
-    Results &R = job.res;
-    R.var.assign(r.merged, r.merged + r.n_variants);
-    for (jl_variant &v : R.var) v.col -= in.win_begin;
-    R.ps = r.summary;
-    R.ps.n_positions = r.n_positions;
-    R.ps.n_haplotypes = r.n_haplotypes;
-    R.pos_cols.resize(r.n_positions);
-    for (uint32_t p = 0; p < r.n_positions; ++p) R.pos_cols[p] = r.pos_global[p] - in.win_begin;
-    if (r.n_positions) {
-        R.hap_count.assign(r.hap_count, r.hap_count + r.n_haplotypes);
-        R.hap_pattern.assign(r.hap_pattern, r.hap_pattern + (size_t)r.n_haplotypes * r.n_positions);
-        R.hit.assign(r.hit, r.hit + (size_t)r.n_variants * r.n_haplotypes);
-    }
-    R.pat_stride = r.n_positions;
-    R.hit_stride = r.n_haplotypes;
-    job.slice_begin = r.slice_begin;
-    job.slice_reads = r.slice_reads;
-    job.ids.resize(r.slice_reads ? r.slice_reads : 1);
-    if (jl_xwin_read_hap_fetch(x, job.ids.data()) != JL_OK) job.error = std::string("per-read ids: ") + jl_xwin_last_error(x);
-    job.ids.resize(r.slice_reads);
-    lap("per-read ids");
-    jl_xwin_destroy(x);
-    lap("session closed");
 }
 
 }  // namespace
@@ -696,10 +745,11 @@ int main(int argc, char **argv)
                 for (uint32_t k = 0; k < K; ++k)
                     if (plan[k].rank == (int)r) jobs[r].widx.push_back(k);
             }
+            RankVote vote((int)n_ranks);
             std::vector<std::thread> threads;
             for (size_t r = 1; r < n_ranks; ++r)
-                threads.emplace_back([&, r] { run_rank(jobs[r], in, plan, comm_id, R.col_counts, slices); });
-            run_rank(jobs[0], in, plan, comm_id, R.col_counts, slices);
+                threads.emplace_back([&, r] { run_rank(jobs[r], in, plan, comm_id, R.col_counts, slices, &vote); });
+            run_rank(jobs[0], in, plan, comm_id, R.col_counts, slices, &vote);
             for (std::thread &t : threads) t.join();
             for (const RankJob &j : jobs)
                 if (!j.error.empty()) { std::cerr << "juliet: rank " << j.rank << " (device " << j.device << "): " << j.error << "\n"; return 3; }

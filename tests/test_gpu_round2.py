@@ -3,12 +3,14 @@ group runs without phasing and with --drm-only masks per window, overlapping gen
 (several positions evaluated by the workgroup that counted the codon), and a soak test of the hand-offs between
 workgroups (fresh reads in every buffer on every replay)."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
 
 import oracle_lib
 from minorseq_amd import capi, msa, synth
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 from test_gpu_parity import P_ABS_TOL, assert_phase_equal, assert_variants_equal, oracle_params
 
 pytestmark = pytest.mark.gpu
@@ -418,3 +420,59 @@ def test_result_block_holds_a_sixteen_position_window(oracle):
         assert (np.asarray(ph["hit"])[:len(exp_v), :h] == exp["hit"]).all()
         assert (np.asarray(ph["read_hap"]) == exp["read_hap"]).all()
     c.close()
+
+
+def test_fold_timeout_is_rerun_unfolded(tmp_path):
+    """A folded phase launch whose waiting workgroups give up (they were not resident together) marks the run failed on
+    the device; the host then runs the phasing stage again with the ids in a launch of their own — transparently: the
+    caller gets the right answer, the context stays unfolded.  The time-out is forced in a -DJL_TUNING build
+    (tools_tuning/build_tuning_lib.sh; JL_FORCE_FOLD_TIMEOUT), in a child process (the test process holds the shipped
+    library)."""
+    import subprocess
+    import sys
+    lib = os.path.join(ROOT, "tools_tuning", "lib_exp", "libjuliet_hip.so")
+    if not os.path.exists(lib):
+        pytest.skip("no tuning build of the library (tools_tuning/build_tuning_lib.sh)")
+    code = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, os.environ["JL_ROOT"]); sys.path.insert(0, os.path.join(os.environ["JL_ROOT"], "tests"))
+import oracle_lib
+from minorseq_amd import capi, msa, synth
+capi.load_library(os.environ["JL_LIB"])
+n, l = 5000, 300
+sp = synth.SynthParams(seed=31, minor_permille=(70, 60, 50, 40), partial_rate=0.1)
+ref = synth.reference(sp.seed, l)
+rows = synth.rows(sp, l, 0, n, ref)
+genes = np.array([(1, l + 1)], dtype=capi.GENE)
+orc = oracle_lib.load()
+ev = orc.call(rows, genes, refseq=ref)
+ep = orc.phase(rows, ev)
+jl = capi.Juliet(0)
+jl.upload_rows(rows)
+for rep in range(3):      # the first run times out and is run again; the next ones are unfolded from the start
+    out = jl.run(genes, ref)
+    assert (out["variants"]["count"] == ev["count"]).all()
+    assert out["phase"]["summary"] == ep["summary"] and (out["phase"]["read_hap"] == ep["read_hap"]).all(), rep
+# a group of two windows: both time out, both are run again on the group's stream
+a, b = capi.Juliet(0), capi.Juliet(0)
+a.upload_rows(rows); b.upload_rows(rows[::-1].copy())
+g = capi.Group([a, b])
+g.run_async(genes, ref, capi.default_params(), True, 10, True)
+va = a.run_view(); vb = b.run_view()
+assert (va["phase"]["read_hap"] == ep["read_hap"]).all() and (vb["phase"]["read_hap"] == ep["read_hap"][::-1]).all()
+# the stage API
+c = capi.Juliet(0)
+c.upload_rows(rows)
+c.pileup_async(genes, ref); c.call_async(); c.phase_async()
+ph = c.phase_fetch()
+assert ph["summary"] == ep["summary"] and (ph["read_hap"] == ep["read_hap"]).all()
+print("RERUN-OK")
+'''
+    env = dict(os.environ, JL_LIB=lib, JL_ROOT=ROOT, JL_FORCE_FOLD_TIMEOUT="1")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "RERUN-OK" in out.stdout, out.stdout + out.stderr
+    # ... and without the forced time-out the same build folds and needs no second run
+    env.pop("JL_FORCE_FOLD_TIMEOUT")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "RERUN-OK" in out.stdout, out.stdout + out.stderr
