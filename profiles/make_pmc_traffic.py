@@ -31,8 +31,7 @@ def condense(rs, counter):
         w = csv.writer(f)
         w.writerow(keep)
         for r in rs:
-            name = ("pileup_planes_group_kernel<3>" if "planes_group_kernel<3>" in r["Kernel_Name"] else
-                    "pileup_group_kernel<3,true,4>" if "<3, true, 4" in r["Kernel_Name"] else r["Kernel_Name"][:60])
+            name = "pileup_planes_group_kernel<3,4>" if "planes_group_kernel<3" in r["Kernel_Name"] else r["Kernel_Name"][:60]
             w.writerow([r["Dispatch_Id"], name] + [r[k] for k in keep[2:]])
     # full launches only (the set-up pass also launches partial groups)
     full = max(int(r["Grid_Size"]) for r in rs)
@@ -43,15 +42,12 @@ def condense(rs, counter):
 fa, nf, grid = condense(rows(d_fetch, "FETCH_SIZE"), "FETCH_SIZE")
 wa, nw, _ = condense(rows(d_write, "WRITE_SIZE"), "WRITE_SIZE")
 windows = grid // 256 // 1000          # 1000 chunks (workgroups) per 3000-column window
-alg = windows * 150_000_000
+alg = windows * 100_000 * 3000 * 3 // 8   # 3 bits per cell: every cell of the resident planes once
 hbm = int(round((2.0 * fa + wa) * 1024))
 old = json.load(open(os.path.join(here, "pmc_traffic.json")))
-planes = any("planes" in r["Kernel_Name"] for r in rows(d_fetch, "FETCH_SIZE"))
 new = {
-    "kernel": "pileup_planes_group_kernel<3>" if planes else "pileup_group_kernel<3,true,4>",
-    "layout": ("bit planes: 3 bits per cell are moved (112.5 MB per 100k x 3000 window) where the algorithmic figure of SURVEY 8d counts "
-               "a 4-bit cell (150 MB)") if planes else "nibbles: 4 bits per cell",
-    "moved_bytes_per_launch_expected": windows * (112_500_000 if planes else 150_000_000),
+    "kernel": "pileup_planes_group_kernel<3,4>",
+    "layout": "bit planes: 3 bits per cell, the one resident format (112.5 MB of cells per 100k x 3000 window; the library pads a plane to whole 128-byte lines: 112.9 MB allocated)",
     "windows_per_launch": windows,
     "workload": f"{windows} windows of 100000 reads x 3000 columns per launch (bench default: --group {windows})",
     "FETCH_SIZE_KB_avg": fa, "WRITE_SIZE_KB_avg": wa, "launches_averaged": [nf, nw],
@@ -59,9 +55,11 @@ new = {
     "pileup_kernel_hbm_bytes_per_launch": hbm,
     "algorithmic_bytes_per_launch": alg,
     "ratio": hbm / alg,
-    "source": f"profiles/{tag}_pmc_FETCH_SIZE.csv, profiles/{tag}_pmc_WRITE_SIZE.csv (separate --pmc passes with --kernel-trace only over profiles/isolated_pileup.py; profiles/make_pmc_traffic.py)",
-    "four_window_launch": old.get("four_window_launch"),
-    "single_window_kernel": old.get("single_window_kernel"),
+    "source": f"profiles/{tag}_pmc_FETCH_SIZE.csv, profiles/{tag}_pmc_WRITE_SIZE.csv (separate --pmc passes with --kernel-trace only over "
+              "profiles/isolated_pileup.py; profiles/make_pmc_traffic.py)",
 }
+for k in ("four_window_launch", "single_window_kernel"):
+    if k in old:
+        new[k + "_rounds_1_2_nibble_kernel"] = old[k]
 json.dump(new, open(os.path.join(here, "pmc_traffic.json"), "w"), indent=1)
-print(json.dumps({k: new[k] for k in ("windows_per_launch", "FETCH_SIZE_KB_avg", "WRITE_SIZE_KB_avg", "pileup_kernel_hbm_bytes_per_launch", "ratio")}))
+print(json.dumps(new, indent=1))
