@@ -178,7 +178,7 @@ int jl_sync(jl_ctx *ctx)
     JL_HIP(ctx, hipStreamSynchronize(ctx->stream));
     // the last run may have been enqueued on a group's stream
     if (ctx->run_stream && ctx->run_stream != ctx->stream) JL_HIP(ctx, hipStreamSynchronize(ctx->run_stream));
-    return JL_OK;
+    return jl_ingest_verdict(ctx);   // (an ingest that was only enqueued: what it found wrong with the records)
 }
 
 /* ---------------------------------------------------------------- MSA residency */
@@ -361,28 +361,18 @@ int jl_records_append(jl_ctx *ctx, uint64_t n_reads, const int32_t *pos, const u
         return jl_fail(ctx, JL_ERR_ARG, "records: either every chunk carries qualities or none does");
     }
     if (!n_reads) return JL_OK;
-    uint64_t max_ops = R.max_ops, max_seq_bytes = R.max_seq_bytes;
     const uint64_t first = R.n_reads;
-    // a chunk that fails validation ends the stream (jl_records_begin starts over)
+    // a chunk that fails validation ends the stream (jl_records_begin starts over).  Here: the offsets, which the uploads
+    // below follow; what the cigars say — an 'M', more bases than the record holds — is checked where they are walked, on
+    // the device (cigar_runs_kernel), and reported by the build (jl_records_finish / jl_records_window): the loop over
+    // twelve million cigar words was most of an append on the host.
     auto bad = [&](uint64_t r, const char *what, uint64_t v) {
         records_drop(ctx);
         return jl_fail(ctx, JL_ERR_ARG, what, (unsigned long long)(first + r), (unsigned long long)v);
     };
-    for (uint64_t r = 0; r < n_reads; ++r) {
+    for (uint64_t r = 0; r < n_reads; ++r)
         if (cig_off[r + 1] < cig_off[r] || seq_off[r + 1] < seq_off[r] || (qual && qual_off[r + 1] < qual_off[r]))
             return bad(r, "record %llu: offsets must not decrease", 0);
-        max_ops = std::max(max_ops, cig_off[r + 1] - cig_off[r]);
-        max_seq_bytes = std::max(max_seq_bytes, seq_off[r + 1] - seq_off[r]);
-        uint64_t query = 0;
-        for (uint64_t k = cig_off[r]; k < cig_off[r + 1]; ++k) {
-            const uint32_t op = cigar[k] & 15u;
-            if (op == 0u) return bad(r, "record %llu: cigar M is forbidden in PacBio-compliant BAM (doc/JULIET.md:53)", 0);
-            if (op == 1u || op == 4u || op == 7u || op == 8u) query += cigar[k] >> 4;
-        }
-        // the kernel indexes the read's bases (two per byte) and qualities by the cigar's query offsets
-        if (query > 2 * (seq_off[r + 1] - seq_off[r]) || (qual && query > qual_off[r + 1] - qual_off[r]))
-            return bad(r, "record %llu: its cigar consumes %llu bases, more than the record holds", query);
-    }
     JL_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     // the chunk's arrays start wherever its offsets say; on the device everything is one run of arrays
@@ -424,8 +414,6 @@ int jl_records_append(jl_ctx *ctx, uint64_t n_reads, const int32_t *pos, const u
     R.n_cig += n_cig;
     R.n_seq += n_seq;
     R.n_qual += n_q;
-    R.max_ops = max_ops;
-    R.max_seq_bytes = max_seq_bytes;
     return JL_OK;
 }
 
@@ -446,6 +434,24 @@ static hipError_t ingest_room_bytes(jl_ctx *ctx, void **d, size_t *cap, size_t e
     return e;
 }
 #define ingest_room(ctx, d, cap, n) ingest_room_bytes(ctx, (void **)(d), cap, sizeof(**(d)), n)
+
+// What the last record ingest into `ctx` found wrong with the records (its kernels have run): the first malformed read.
+// Called by the blocking builds, and by the first blocking call behind an enqueued one (jl_sync, jl_run_wait, the fetches).
+int jl_ingest_verdict(jl_ctx *ctx)
+{
+    if (!ctx->ing_check_pending) return JL_OK;
+    ctx->ing_check_pending = false;
+    // (through the context's pinned block: a process's first pageable device-to-host copy costs the runtime milliseconds)
+    unsigned long long both[2] = {0, ~0ull};
+    if (int rc = jl_fetch_to_host(ctx, ctx->d_ing_count, 16, both, 64)) return rc;
+    const unsigned long long w = both[1];
+    if (w == ~0ull) return JL_OK;
+    const unsigned long long r = w >> 8;
+    const unsigned code = (unsigned)(w & 0xFFu);
+    ctx->pileup_done = ctx->call_done = ctx->phase_done = false;
+    if (code == 1u) return jl_fail(ctx, JL_ERR_ARG, "record %llu: cigar M is forbidden in PacBio-compliant BAM (doc/JULIET.md:53)", r);
+    return jl_fail(ctx, JL_ERR_ARG, "record %llu: its cigar consumes more %s than the record holds", r, code == 2u ? "bases" : "qualities");
+}
 
 // The resident matrix of `dst` from the records uploaded to `src` (the same context for jl_records_finish; another one of
 // the same device when one upload feeds several column windows).  The records stay.  Everything is ENQUEUED on dst's
@@ -497,10 +503,11 @@ static int records_build(jl_ctx *src, jl_ctx *dst, uint32_t n_cols, uint32_t win
                          R.have_qual ? R.d_qo : nullptr, min_qv, dst->d_ing_runs, dst->d_ing_nruns, dst->d_ing_first, dst->d_ing_count,
                          dst->d_ing_slow);
         e = hipGetLastError();
+        dst->ing_check_pending = e == hipSuccess;
         if (e == hipSuccess && wait) e = hipStreamSynchronize(st);
     }
     if (e != hipSuccess) return jl_fail(dst, e == hipErrorOutOfMemory ? JL_ERR_MEMORY : JL_ERR_DEVICE, "ingest: %s", hipGetErrorString(e));
-    return JL_OK;
+    return wait ? jl_ingest_verdict(dst) : JL_OK;
 }
 
 int jl_records_finish(jl_ctx *ctx, uint32_t n_cols, uint32_t win_begin, uint32_t min_qv)
@@ -1519,6 +1526,7 @@ int jl_run_async(jl_ctx *ctx, const jl_gene *genes, uint32_t n_genes, const uint
 int jl_run_wait_impl(jl_ctx *ctx)
 {
     int rc = jl_run_wait_seq(ctx, ctx->runs_launched);
+    if (rc == JL_OK && ctx->ing_check_pending) rc = jl_ingest_verdict(ctx);   // the run read a matrix an enqueued ingest made
     // a result block without its magic behind a phasing run: the folded launch timed out (see jl_phase_rerun_unfolded)
     if (rc == JL_OK && ctx->pack_valid && ctx->phase_done && ctx->h_pack && ctx->h_pack->magic != JL_PACK_MAGIC && !ctx->no_fold)
         rc = jl_phase_rerun_unfolded(ctx);

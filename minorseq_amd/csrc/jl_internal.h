@@ -285,7 +285,7 @@ struct jl_records {
     uint64_t *d_co = nullptr, *d_so = nullptr, *d_qo = nullptr;
     int32_t *d_pos = nullptr;
     size_t cap_seq = 0, cap_qual = 0, cap_cig = 0, cap_co = 0, cap_so = 0, cap_qo = 0, cap_pos = 0;
-    uint64_t n_reads = 0, n_cig = 0, n_seq = 0, n_qual = 0, max_ops = 0, max_seq_bytes = 0;
+    uint64_t n_reads = 0, n_cig = 0, n_seq = 0, n_qual = 0;
 };
 
 struct jl_ctx {
@@ -325,6 +325,7 @@ struct jl_ctx {
     uint32_t *d_ing_nruns = nullptr, *d_ing_first = nullptr, *d_ing_count = nullptr;
     uint2 *d_ing_slow = nullptr;
     size_t ing_cap_runs = 0, ing_cap_reads = 0, ing_cap_first = 0, ing_cap_slow = 0;
+    bool ing_check_pending = false;   // an ingest ran (or is enqueued) whose verdict on the records has not been read yet
 
     // ---- phasing sharded by reads: the groups of this matrix exported for the merge (jl_phase_groups_async / _fetch)
     bool phase_export = false;        // the phase launch in flight / last run exported instead of selecting
@@ -498,6 +499,7 @@ void jl_launch_ingest(jl_ctx *ctx, const int32_t *d_pos, const uint32_t *d_cigar
                       const uint64_t *d_qual_off, uint32_t min_qv, uint2 *d_runs, uint32_t *d_nruns, uint32_t *d_first,
                       uint32_t *d_slow_count, uint2 *d_slow);
 uint32_t jl_ingest_sweeps(uint32_t n_cols);
+extern "C" int jl_ingest_verdict(jl_ctx *ctx);
 void jl_launch_regroup(jl_ctx *ctx, const uint16_t *d_hap_of_group, uint32_t n_groups, uint32_t n_haplotypes, bool phased);
 void jl_launch_insertions(jl_ctx *ctx, const int32_t *d_pos, const uint32_t *d_cigar, const uint64_t *d_cig_off,
                           const uint8_t *d_seq4, const uint64_t *d_seq_off);

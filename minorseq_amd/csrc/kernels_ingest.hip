@@ -87,10 +87,14 @@ __device__ __forceinline__ uint32_t wave_scan(uint32_t v)
 // steps); the offsets and the first step's cigar words of all four reads are requested before anything waits — with one
 // read per wave the kernel was a chain of three trips to HBM per wave and nothing else (51 us for 100k reads).
 constexpr uint32_t kRunsReadsPerWave = 4u;
+// The records are untrusted: a cigar with an 'M' (forbidden in PacBio BAM, doc/JULIET.md:53) or one that consumes more bases
+// (or qualities) than the record holds is reported — *bad = min over such reads of (read << 8 | code), code 1 'M', 2 bases,
+// 3 qualities — and the read is treated as covering nothing, so no later kernel follows its offsets anywhere.
 __global__ __launch_bounds__(256) void cigar_runs_kernel(uint64_t n_reads, const int32_t *__restrict__ pos, const uint32_t *__restrict__ cigar,
-                                                         const uint64_t *__restrict__ cig_off, uint32_t win_begin, uint32_t n_cols,
+                                                         const uint64_t *__restrict__ cig_off, const uint64_t *__restrict__ seq_off,
+                                                         const uint64_t *__restrict__ qual_off, uint32_t win_begin, uint32_t n_cols,
                                                          uint32_t n_sweeps, uint2 *__restrict__ runs, uint32_t *__restrict__ nruns,
-                                                         uint32_t *__restrict__ first_run)
+                                                         uint32_t *__restrict__ first_run, unsigned long long *__restrict__ bad)
 {
     extern __shared__ uint32_t s_dyn[];
     const uint32_t wid = threadIdx.x >> 6, lane = threadIdx.x & 63u;
@@ -132,6 +136,7 @@ __global__ __launch_bounds__(256) void cigar_runs_kernel(uint64_t n_reads, const
             return ((uint32_t)w + kSweep - 1u) / kSweep;
         };
         uint32_t n_runs = 0, prev_kind = 0, ref_carry = 0, q_carry = 0;
+        bool has_m = false;
         for (uint64_t k0 = c_beg; k0 < c_end; k0 += 128u) {
             uint32_t cw[2] = {cw0[q][0], cw0[q][1]};
             if (k0 != c_beg) {
@@ -146,6 +151,7 @@ __global__ __launch_bounds__(256) void cigar_runs_kernel(uint64_t n_reads, const
                 rl[t] = cig_ref(op) ? len : 0u;
                 ql[t] = cig_query(op) ? len : 0u;
                 kind[t] = len == 0u ? 0u : (op == 7u || op == 8u) ? 1u : op == 2u ? 2u : op == 3u ? 3u : 0u;
+                has_m = has_m || (op == 0u && (k0 + 2u * lane + (uint32_t)t) < c_end);
             }
             const uint32_t ri = wave_scan(rl[0] + rl[1]), qi = wave_scan(ql[0] + ql[1]);   // inclusive, per lane pair
             // the kind of the op before this lane's first one: the previous lane's second op
@@ -173,6 +179,16 @@ __global__ __launch_bounds__(256) void cigar_runs_kernel(uint64_t n_reads, const
             ref_carry += __shfl(ri, 63, 64);
             q_carry += __shfl(qi, 63, 64);
         }
+        uint32_t code = __ballot(has_m) != 0ull ? 1u : 0u;
+        if (!code) {
+            const uint64_t so0 = seq_off[r], so1 = seq_off[r + 1];
+            if ((uint64_t)q_carry > 2u * (so1 - so0)) code = 2u;
+            else if (qual_off && (uint64_t)q_carry > qual_off[r + 1] - qual_off[r]) code = 3u;
+        }
+        if (code) {
+            n_runs = 0;
+            if (lane == 0) atomicMin(bad, ((unsigned long long)r << 8) | code);
+        }
         if (lane == 0) {
             out[n_runs] = make_uint2(ref_carry & kRunMask, q_carry);
             nruns[r] = n_runs;
@@ -182,7 +198,7 @@ __global__ __launch_bounds__(256) void cigar_runs_kernel(uint64_t n_reads, const
         uint32_t carry = 0;
         for (uint32_t s0 = 0; s0 <= n_sweeps; s0 += 64u) {
             const uint32_t s = s0 + lane;
-            const uint32_t v = wave_scan(s <= n_sweeps ? hist[s] : 0u);
+            const uint32_t v = wave_scan((s <= n_sweeps && !code) ? hist[s] : 0u);
             if (s <= n_sweeps) first_run[r * (uint64_t)(n_sweeps + 1u) + s] = carry + v;
             carry += __shfl(v, 63, 64);
         }
@@ -677,7 +693,8 @@ __global__ __launch_bounds__(256) void ingest_slow_kernel(ingest_args a, const i
 uint32_t jl_ingest_sweeps(uint32_t n_cols) { return (n_cols + kSweep - 1u) / kSweep; }
 
 // d_runs: n_cig + n_reads + 1 entries; d_nruns: n_reads; d_first: n_reads x (sweeps + 1); d_slow: n_reads x sweeps pairs behind
-// one counter word (zeroed here).  Everything is enqueued on ctx->stream; nothing waits.
+// one counter word (zeroed here); d_slow_count[2..3] = the 64-bit word of the first malformed record (all ones: none).
+// Everything is enqueued on ctx->stream; nothing waits.
 void jl_launch_ingest(jl_ctx *ctx, const int32_t *d_pos, const uint32_t *d_cigar, const uint64_t *d_cig_off,
                       const uint8_t *d_seq4, const uint64_t *d_seq_off, const uint8_t *d_qual,
                       const uint64_t *d_qual_off, uint32_t min_qv, uint2 *d_runs, uint32_t *d_nruns, uint32_t *d_first,
@@ -686,9 +703,11 @@ void jl_launch_ingest(jl_ctx *ctx, const int32_t *d_pos, const uint32_t *d_cigar
     hipStream_t st = ctx->stream;
     const uint32_t ns = jl_ingest_sweeps(ctx->n_cols);
     hipMemsetAsync(d_slow_count, 0, 4, st);
+    hipMemsetAsync(d_slow_count + 2, 0xFF, 8, st);
     if (ctx->n_reads)
         hipLaunchKernelGGL(cigar_runs_kernel, dim3((uint32_t)((ctx->n_reads + 4u * kRunsReadsPerWave - 1u) / (4u * kRunsReadsPerWave))), dim3(256), 4u * (ns + 2u) * 4u, st, ctx->n_reads, d_pos,
-                           d_cigar, d_cig_off, ctx->win_begin, ctx->n_cols, ns, d_runs, d_nruns, d_first);
+                           d_cigar, d_cig_off, d_seq_off, d_qual ? d_qual_off : nullptr, ctx->win_begin, ctx->n_cols, ns, d_runs, d_nruns, d_first,
+                           reinterpret_cast<unsigned long long *>(d_slow_count + 2));
     ingest_args a;
     a.n_reads = ctx->n_reads;
     a.n_cols = ctx->n_cols;
