@@ -100,7 +100,7 @@ private:
         b.any = true;
         b.out.resize(out_total);
         std::atomic<size_t> next{0};
-        std::atomic<bool> bad{false};
+        std::atomic<bool> bad{false}, bad_crc{false};
         auto work = [&]() {
             z_stream z;
             for (;;) {
@@ -116,7 +116,10 @@ private:
                 z.avail_out = k.isize;
                 const int rc = inflate(&z, Z_FINISH);
                 inflateEnd(&z);
-                if (rc != Z_STREAM_END || z.avail_out != 0) { bad = true; return; }
+                if (rc != Z_STREAM_END || z.avail_out != 0 || z.avail_in != 0) { bad = true; return; }
+                uint32_t want;   // the block's CRC-32 behind the deflate data
+                memcpy(&want, b.comp.data() + k.in_off + k.in_len, 4);
+                if ((uint32_t)crc32(0L, b.out.data() + k.out_off, k.isize) != want) { bad_crc = true; bad = true; return; }
             }
         };
         const unsigned nt = (unsigned)std::min<size_t>(n_threads_, blks.size());
@@ -126,6 +129,7 @@ private:
             for (unsigned t = 0; t < nt; ++t) th.emplace_back(work);
             for (auto &t : th) t.join();
         }
+        if (bad_crc) throw std::runtime_error("BGZF block fails its CRC-32");
         if (bad) throw std::runtime_error("BGZF block failed to inflate");
     }
     bool refill()

@@ -22,7 +22,8 @@ namespace jlz {
 
 class Inflater {
 public:
-    // 0 when the stream ended with its final block exactly at out_len bytes; negative for malformed or mis-sized input
+    // 0 when the stream ended with its final block exactly at out_len bytes and at the end of the input; negative for
+    // malformed or mis-sized input
     int run(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_len)
     {
         const uint8_t *ip = in, *const iend = in + in_len;
@@ -268,7 +269,11 @@ public:
             if (final_block) break;
         }
         if (over * 8u > bc) return -2;
-        return op == oend ? 0 : -13;
+        if (op != oend) return -13;
+        // the body must end with its final block: whole bytes still in the bit buffer (or behind ip) are not part of a
+        // stream a BGZF writer made, and a block that is damaged but happens to inflate to ISIZE bytes often leaves some
+        if (ip - ((ptrdiff_t)(bc >> 3) - (ptrdiff_t)over) != iend) return -14;
+        return 0;
 #undef JLZ_NEED
 #undef JLZ_DROP
 #undef JLZ_REFILL

@@ -41,7 +41,7 @@ static bool zlib_inflate(const bytes &comp, bytes &out, size_t n)
     z.next_out = out.data();
     z.avail_out = (uInt)(n + 1);
     const int rc = inflate(&z, Z_FINISH);
-    const bool ok = rc == Z_STREAM_END && z.total_out == n;
+    const bool ok = rc == Z_STREAM_END && z.total_out == n && z.avail_in == 0;   // (bytes behind the final block: not a BGZF body)
     inflateEnd(&z);
     out.resize(n);
     return ok;

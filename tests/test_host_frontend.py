@@ -307,6 +307,31 @@ def test_pipelined_reader_equals_sequential(tmp_path):
         assert out.returncode != 0
 
 
+def test_bgzf_block_crc_is_checked(tmp_path):
+    """A BGZF block whose inflated bytes do not match its CRC-32 (RFC 1952) ends the run with a message instead of being parsed
+    as records; the carry-less-multiply CRC of the front end equals zlib's on every length and alignment
+    (tests/cpp/crc_check.cpp)."""
+    import struct
+    host = os.path.join(ROOT, "minorseq_amd", "host")
+    exe = str(tmp_path / "crc_check")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+                           os.path.join(ROOT, "tests", "cpp", "crc_check.cpp"), "-lz", "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "0 mismatches" in out.stdout, out.stdout + out.stderr
+    bam = str(tmp_path / "ok.bam")
+    subprocess.check_call([SYNTH, "--reads", "400", "--cols", "300", "--seed", "3", "-o", bam, "--config-out", str(tmp_path / "c.json")])
+    raw = bytearray(open(bam, "rb").read())
+    # second BGZF block: flip a bit of its stored CRC (the deflate data still inflates to ISIZE bytes)
+    bsize0 = struct.unpack_from("<H", raw, 16)[0] + 1
+    bsize1 = struct.unpack_from("<H", raw, bsize0 + 16)[0] + 1
+    raw[bsize0 + bsize1 - 8] ^= 0x10
+    bad = str(tmp_path / "bad.bam")
+    open(bad, "wb").write(raw)
+    for extra in ([], ["--dump-msa", str(tmp_path / "m.bin")]):     # the pipelined reader (with a device) and the sequential one
+        r = subprocess.run([JULIET, "-c", str(tmp_path / "c.json"), *extra, bad, str(tmp_path / "o.json")], capture_output=True, text=True)
+        assert r.returncode != 0 and ("CRC" in r.stderr or "no HIP device" in r.stderr or "device" in r.stderr), r.stderr
+
+
 def test_fast_inflate_equals_zlib(tmp_path):
     """minorseq_amd/host/fast_inflate.hpp (the decoder of the pipelined BAM reader) against zlib on the same raw DEFLATE
     streams, built with AddressSanitizer + UBSan: every level and strategy of zlib's deflate over seven kinds of input
