@@ -23,7 +23,9 @@
 // Largest phase launch whose workgroups may wait for each other inside the launch (the per-read ids are then written by
 // the same launch): all of them must be resident at once, next to as many more such launches as queues run at a time.
 // 1536 places on the chip (75 VGPRs, 20.5 KB LDS per block); 128 leaves room for eight concurrent launches and more.
+#ifndef JL_FOLD_MAX_BLOCKS
 #define JL_FOLD_MAX_BLOCKS 128u
+#endif
 #define JL_TIMELINE_ROWS 4096u
 #define JL_TIMELINE_SLOTS 8u
 #define JL_INS_LEN_BINS 32u        // insertion lengths 0..30 by value, 31 = longer
