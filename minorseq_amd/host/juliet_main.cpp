@@ -286,10 +286,12 @@ private:
         }
         for (jl_ctx *c : ctxs_) {
             if (rc_ != JL_OK) break;
-            // CCS BAMs inflate 5-10x; the packed bases are about a quarter of that, qualities half (arrays grow if not)
-            const uint64_t seq_hint = std::min<uint64_t>(file_bytes_ * 2, (uint64_t)2 << 30);
+            // CCS BAMs inflate 5-10x; the packed bases are about a third of that, qualities twice the bases, a cigar word per
+            // dozen bases when every filtered base is an X of its own (the arrays grow if not — each growth is an allocation, a
+            // device copy and a free behind a synchronisation, so the hints err on the large side: memory is not the constraint)
+            const uint64_t seq_hint = std::min<uint64_t>(file_bytes_ * 7 / 2, (uint64_t)4 << 30);
             const auto t = std::chrono::steady_clock::now();
-            rc_ = jl_records_begin(c, seq_hint / 1024 + 1024, seq_hint / 64 + 1024, seq_hint, want_qual_ ? seq_hint * 2 : 0);
+            rc_ = jl_records_begin(c, seq_hint / 512 + 1024, seq_hint / 8 + 1024, seq_hint, want_qual_ ? seq_hint * 2 : 0);
             if (rc_ != JL_OK) failed_ = c;
             ms_begin += ms_since(t);
         }
