@@ -236,6 +236,15 @@ def main():
         all_counts = np.zeros(G * world, dtype=np.uint32)
         p_rows, p_counts = all_rows.ctypes.data_as(C.c_void_p), all_counts.ctypes.data_as(C.c_void_p)
 
+    # The exchange of a launch of several windows rides with the launch (jl_group_exchange_bind: the run's kernels write the
+    # table heads into the pinned region ONE all-gather works in, in place, on the group's stream); JL_BENCH_EXCHANGE=worker
+    # takes the older form (gather kernel + all-gather + copy on the communicator's stream, issued by its worker thread).
+    bound = comm is not None and G > 1 and os.environ.get("JL_BENCH_EXCHANGE", "bound") == "bound"
+    gpending = {}                        # bound form: exchanges in flight per group
+    if bound:
+        for grp_ in groups:
+            grp_.bind_exchange(comm)
+        exchange = "RCCL all-gather of the table heads, carried by the launch (jl_group_exchange_bind)"
     pending = {id(c): 0 for c in ctxs}   # exchanges enqueued and not yet collected, per context
     state = dict(checked=0, gathered_rows=0)
 
@@ -262,6 +271,8 @@ def main():
                 grp = partial_groups.get((u, count))
                 if grp is None:
                     grp = partial_groups[(u, count)] = capi.Group(members)
+                    if bound:
+                        grp.bind_exchange(comm)
             member_group.setdefault(id(members[0]), {})[count] = grp
             if (id(members[0]), count) not in group_expect and all(id(c) in expected for c in members):
                 group_expect[(id(members[0]), count)] = (np.array([len(expected[id(c)]["count"]) for c in members], dtype=np.uint32),
@@ -269,7 +280,9 @@ def main():
             t_g = time.perf_counter()
             grp.run_async(genes, refseq, prm, True, 10, True)
             host["run_async"] = host.get("run_async", 0.0) + time.perf_counter() - t_g
-        if comm is not None:
+        if bound:
+            gpending[id(grp)] = gpending.get(id(grp), 0) + 1
+        elif comm is not None:
             # the all-gathers of the launch's windows go out as one RCCL group (one collective launch)
             arr = handle_arrays.get((u, count))
             if arr is None:
@@ -346,7 +359,17 @@ def main():
         # the exchange of these contexts' PREVIOUS step is collected now (their own is still crossing xGMI): every
         # step's all-gather is consumed, one cycle late, and its latency never stalls the launching thread.  The windows
         # of a launch were requested as one batch and are collected by one call.
-        if comm is not None:
+        if bound and grp is not None:
+            floor = 0 if final else 1
+            while gpending.get(id(grp), 0) > floor:
+                t_in = time.perf_counter()
+                rc = jl.lib.jl_group_exchange_collect(grp.h, p_rows, p_counts, XROWS)
+                if rc:
+                    raise capi.JulietError(rc, jl.lib.jl_group_last_error(grp.h).decode())
+                gpending[id(grp)] -= 1
+                state["gathered_rows"] = int(all_counts[: len(members) * world].sum())
+                host["drain"] += time.perf_counter() - t_in
+        elif comm is not None:
             floor = 0 if final else 1
             while all(pending[id(c)] > floor for c in members):
                 arr = handle_arrays.get(("m", id(members[0]), len(members)))

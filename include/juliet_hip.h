@@ -410,6 +410,27 @@ int jl_allgather_variants_async_many(jl_ctx *const *ctxs, uint32_t n, jl_comm *c
  * all_rows [n_ctx][world][cap_rows], all_counts [n_ctx][world]; jl_last_error of the failing context tells why. */
 int jl_allgather_variants_many(jl_ctx *const *ctxs, uint32_t n_ctx, jl_comm *comm, jl_variant *all_rows,
                                uint32_t *all_counts, uint32_t cap_rows);
+/*
+ * The exchange of a group run as ONE device operation, carried by the run itself.  After jl_group_exchange_bind(group, comm)
+ * every jl_group_run(_masked)_async of the group (at most 32 windows) also exchanges the heads of its windows' tables: the
+ * run's last kernels write them — besides the result blocks — into this rank's part of a pinned host region
+ * [rank][window][head], and the same call issues ONE all-gather IN PLACE in that region on the group's stream, behind
+ * the run, and one event.  No gather kernel, no copy back, no worker thread, no second stream; with one rank the
+ * all-gather is nothing at all.  The launching thread makes the RCCL call itself, behind whatever the communicator's
+ * worker still had to issue, so every rank keeps one order of collectives as long as every rank runs the same program.
+ * jl_group_exchange_collect returns the OLDEST pending exchange of the group — all_rows [n_windows][world][cap_rows],
+ * all_counts [n_windows][world], as jl_allgather_variants_many — spinning on its event (JL_ERR_COMM after 60 s, and when a
+ * rank's run did not reach its result block: every rank sees that rank's empty head).  Two regions by run parity: a
+ * group may launch its next run before collecting this one; a third pending exchange is refused (JL_ERR_STATE).  A run
+ * in which some rank called more than 128 variants falls back — on every rank alike — to the full fixed-stride table of
+ * every window, which must then be collected before the group's next run.
+ * Binding is a collective the first time a communicator is bound: the ranks try a 64-byte all-gather in pinned host memory
+ * and agree on the outcome; where that does not work (or with JL_EXCHANGE_STAGED=1) the all-gather works in device memory
+ * and a copy to the pinned region follows it (two operations).  comm = NULL unbinds.  In-process communicators block
+ * in the launching call, as all their exchanges do.  Match: SURVEY 8e "exchange the variant table", doc/JULIET.md:94-100.
+ */
+int jl_group_exchange_bind(jl_group *group, jl_comm *comm);
+int jl_group_exchange_collect(jl_group *group, jl_variant *all_rows, uint32_t *all_counts, uint32_t cap_rows);
 
 /* ---------------------------------------------------------------- cross-window phasing */
 

@@ -34,7 +34,7 @@ EXPORTS = ("jl_abi_version", "jl_strerror", "jl_device_count", "jl_ctx_create", 
            "jl_consensus_fetch", "jl_call_async", "jl_call_fetch", "jl_variant_table_device", "jl_phase_async", "jl_phase_fetch",
            "jl_ctx_stream", "jl_run_async", "jl_run_wait", "jl_run_done", "jl_run_view_get", "jl_group_create", "jl_group_destroy",
            "jl_group_last_error", "jl_group_run_async", "jl_group_run_masked_async", "jl_group_views", "jl_group_time_pileup", "jl_fisher_eval", "jl_fisher_eval_tail", "jl_expand_read_hap", "jl_time_pileup", "jl_time_pileup_set", "jl_pileup_kernel_name", "jl_comm_unique_id", "jl_comm_create", "jl_comm_create_inproc", "jl_comm_destroy",
-           "jl_allgather_variants", "jl_allgather_variants_async", "jl_allgather_variants_async_many", "jl_allgather_variants_many", "jl_xwin_plan", "jl_xwin_assemble_local",
+           "jl_allgather_variants", "jl_allgather_variants_async", "jl_allgather_variants_async_many", "jl_allgather_variants_many", "jl_group_exchange_bind", "jl_group_exchange_collect", "jl_xwin_plan", "jl_xwin_assemble_local",
            "jl_xwin_assemble_rccl", "jl_xwin_assemble_slice_local", "jl_xwin_assemble_slice_rccl", "jl_phase_groups_async",
            "jl_phase_groups_fetch", "jl_phase_regroup", "jl_merge_tables", "jl_merge_groups", "jl_select_haplotypes",
            "jl_xwin_slice_plan", "jl_xwin_create", "jl_xwin_destroy", "jl_xwin_last_error", "jl_xwin_phase_sharded",
@@ -215,6 +215,8 @@ def load_library(path=LIB_PATH):
     lib.jl_allgather_variants_async.argtypes = [vp, vp]
     lib.jl_allgather_variants_async_many.argtypes = [vp, u32, vp]
     lib.jl_allgather_variants_many.argtypes = [vp, u32, vp, vp, vp, u32]
+    lib.jl_group_exchange_bind.argtypes = [vp, vp]
+    lib.jl_group_exchange_collect.argtypes = [vp, vp, vp, u32]
     lib.jl_xwin_plan.argtypes = [vp, vp, u32, vp, u32, vp, vp, vp, C.POINTER(u32)]
     lib.jl_xwin_assemble_local.argtypes = [vp, vp, u32, vp, u32, vp, vp, C.POINTER(u32)]
     lib.jl_xwin_assemble_rccl.argtypes = [vp, vp, vp, vp, vp, vp, u32, vp, vp, C.POINTER(u32)]
@@ -990,6 +992,25 @@ class Group:
         if getattr(self, "h", None):
             self.lib.jl_group_destroy(self.h)
             self.h = None
+
+    def bind_exchange(self, comm):
+        """jl_group_exchange_bind: every run of the group from now on carries the all-gather of its windows' table heads
+        (comm: the jl_comm handle, None unbinds).  A collective the first time a communicator is bound."""
+        rc = self.lib.jl_group_exchange_bind(self.h, comm)
+        if rc:
+            raise JulietError(rc, self.lib.jl_group_last_error(self.h).decode())
+
+    def exchange_collect(self, world, cap_rows=128, rows=None, counts=None):
+        """jl_group_exchange_collect: the group's oldest pending exchange -> (rows [windows][world][cap_rows] of VARIANT,
+        counts [windows][world])."""
+        n = len(self.ctxs)
+        if rows is None:
+            rows = np.zeros(n * world * cap_rows, dtype=VARIANT)
+            counts = np.zeros(n * world, dtype=np.uint32)
+        rc = self.lib.jl_group_exchange_collect(self.h, rows.ctypes.data_as(C.c_void_p), counts.ctypes.data_as(C.c_void_p), cap_rows)
+        if rc:
+            raise JulietError(rc, self.lib.jl_group_last_error(self.h).decode())
+        return rows.reshape(n, world, cap_rows), counts.reshape(n, world)
 
     def views(self):
         """jl_group_views: the jl_run_view of every window after a group run, ONE call (it waits for each window in turn).

@@ -76,7 +76,8 @@ bool inproc_barrier(jl_inproc_world *w)
 hipError_t inproc_copy(jl_comm *c, void *dst, const void *src, size_t bytes, int src_device, hipStream_t st)
 {
     if (!bytes) return hipSuccess;
-    if (src_device == c->device) return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, st);
+    if (dst == src) return hipSuccess;   // an exchange in place: this rank's own part
+    if (src_device == c->device) return hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, st);   // (either end may be pinned host memory)
     return hipMemcpyPeerAsync(dst, c->device, src, src_device, bytes, st);
 }
 
@@ -322,6 +323,42 @@ void jl_comm_direct_end(jl_comm *c)
         c->direct_busy = false;
     }
     c->cv.notify_all();
+}
+
+void jl_comm_direct_wait_begin(jl_comm *c)
+{
+    std::unique_lock<std::mutex> lk(c->mu);
+    c->cv.wait(lk, [&] { return !c->direct_busy && !c->worker_busy && c->queue.empty(); });
+    c->direct_busy = true;
+}
+
+int jl_comm_host_gather(jl_comm *c)
+{
+    if (c->host_gather >= 0) return c->host_gather;
+    static const char *forced = getenv("JL_EXCHANGE_STAGED");   // tuning / tests: take the staged form
+    const size_t kPart = 64;
+    uint8_t *t = nullptr;
+    bool ok = !(forced && forced[0] == '1') && hipHostMalloc(&t, kPart * (size_t)c->world, hipHostMallocDefault) == hipSuccess;
+    jl_comm_direct_wait_begin(c);
+    if (ok) {
+        memset(t, 0, kPart * (size_t)c->world);
+        for (size_t i = 0; i < kPart; ++i) t[kPart * (size_t)c->rank + i] = (uint8_t)(0xA5u ^ (uint8_t)(31 * c->rank + (int)i));
+        ok = jl_tp_allgather(c, t + kPart * (size_t)c->rank, t, kPart, c->stream) == JL_OK && hipStreamSynchronize(c->stream) == hipSuccess;
+        for (int r = 0; ok && r < c->world; ++r)
+            for (size_t i = 0; i < kPart; ++i)
+                if (t[kPart * (size_t)r + i] != (uint8_t)(0xA5u ^ (uint8_t)(31 * r + (int)i))) ok = false;
+    }
+    (void)hipGetLastError();
+    // the verdicts of all ranks, in device memory (zeros: fine, ones: not here)
+    std::vector<uint32_t> v(2 * (size_t)c->world, 1u);
+    bool agreed = jl_tp_allgather(c, ok ? (const void *)c->d_zero : (const void *)c->d_poison, c->d_counts, 8, c->stream) == JL_OK &&
+                  hipMemcpyAsync(v.data(), c->d_counts, 8 * (size_t)c->world, hipMemcpyDeviceToHost, c->stream) == hipSuccess &&
+                  hipStreamSynchronize(c->stream) == hipSuccess;
+    jl_comm_direct_end(c);
+    for (uint32_t x : v) agreed = agreed && x == 0u;
+    if (t) hipHostFree(t);
+    c->host_gather = agreed ? 1 : 0;
+    return c->host_gather;
 }
 
 static void comm_wait_enqueued(jl_comm *c, jl_comm_slot *s)
@@ -610,6 +647,11 @@ static int allgather_full(jl_ctx *ctx, jl_comm *c, jl_variant *all_rows, uint32_
     if (f.status == JL_ERR_COMM) return jl_fail(ctx, JL_ERR_COMM, "the exchange failed: RCCL error, or a rank's run did not complete (it says so in its own error)");
     if (f.status != JL_OK) return jl_fail(ctx, f.status, "full-stride all-gather failed on the communicator thread");
     return JL_OK;
+}
+
+int jl_comm_allgather_full(jl_ctx *ctx, jl_comm *c, jl_variant *all_rows, uint32_t *all_counts, uint32_t cap_rows, uint32_t wait_seq)
+{
+    return allgather_full(ctx, c, all_rows, all_counts, cap_rows, wait_seq);
 }
 
 // The one collective of the path.  After jl_run_async the exchange is the 6.2 KB head of each rank's result

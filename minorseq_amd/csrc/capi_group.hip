@@ -22,9 +22,15 @@
 #include <string>
 #include <vector>
 
+#include <chrono>
+
+#include "jl_comm_internal.h"
 #include "jl_internal.h"
 
 #define JL_GROUP_SIDE_STREAMS 2
+#ifndef JL_COMM_TIMEOUT_S
+#define JL_COMM_TIMEOUT_S 60
+#endif
 
 struct jl_group {
     int device = -1;
@@ -42,11 +48,35 @@ struct jl_group {
     struct chunk_t { uint32_t first, n, max_chunks, max_call_blocks, max_phase_blocks; bool fold; };
     std::vector<chunk_t> chunks;
     bool phasing = true;
-    hipGraph_t graph = nullptr;
-    hipGraphExec_t graph_exec = nullptr;
+    // one captured graph per parity of a bound exchange (the heads' destination is baked in); unbound: [0] only
+    hipGraph_t graph[2] = {nullptr, nullptr};
+    hipGraphExec_t graph_exec[2] = {nullptr, nullptr};
+    bool graph_tried[2] = {false, false};
     std::vector<uint8_t> sig;   // everything the captured graph and the tables bake in
     std::string err;
+    // ---- bound exchange (jl_group_exchange_bind): every run carries the all-gather of its windows' table heads
+    jl_comm *xc = nullptr;
+    bool x_staged = false;           // the all-gather works in device memory and is copied to the pinned region behind it
+    uint8_t *x_host = nullptr;       // pinned [2][world][n][JL_PACK_HEAD_BYTES]: by run parity, [rank][window][head] each
+    uint8_t *x_dev = nullptr;        // staged form: the same in device memory
+    hipEvent_t x_done[2] = {nullptr, nullptr};
+    bool x_pending[2] = {false, false};
+    uint32_t x_run_seq[2][JL_GROUP_WINDOWS_MAX];   // each window's run number when the exchange went out
+    uint64_t x_launched = 0, x_collected = 0;
+
+    size_t x_part() const { return (size_t)JL_PACK_HEAD_BYTES * ctxs.size(); }                  // one rank's heads
+    size_t x_region() const { return x_part() * (size_t)(xc ? xc->world : 1); }                 // one exchange
+    uint8_t *x_work(uint32_t par) const { return (x_staged ? x_dev : x_host) + x_region() * par; }   // where the collective works
 };
+
+static void group_drop_graphs(jl_group *g)
+{
+    for (int p = 0; p < 2; ++p) {
+        if (g->graph_exec[p]) { hipGraphExecDestroy(g->graph_exec[p]); g->graph_exec[p] = nullptr; }
+        if (g->graph[p]) { hipGraphDestroy(g->graph[p]); g->graph[p] = nullptr; }
+        g->graph_tried[p] = false;
+    }
+}
 
 static int group_fail(jl_group *g, int status, const char *msg)
 {
@@ -142,8 +172,11 @@ void jl_group_destroy(jl_group *g)
     if (!g) return;
     hipSetDevice(g->device);
     if (g->stream) hipStreamSynchronize(g->stream);
-    if (g->graph_exec) hipGraphExecDestroy(g->graph_exec);
-    if (g->graph) hipGraphDestroy(g->graph);
+    group_drop_graphs(g);
+    if (g->x_host) hipHostFree(g->x_host);
+    if (g->x_dev) hipFree(g->x_dev);
+    for (auto &e : g->x_done)
+        if (e) hipEventDestroy(e);
     if (g->d_done) hipFree(g->d_done);
     if (g->ev_end) hipEventDestroy(g->ev_end);
     for (auto &e : g->ev_fork)
@@ -200,8 +233,11 @@ int jl_group_run_masked_async(jl_group *g, const jl_gene *genes, uint32_t n_gene
     struct item { uint64_t alloc, plan; double n_tests; void *rh; uint32_t n_dw, drm; };
     std::vector<uint8_t> sig(sizeof(jl_params) + 16 + sizeof(item) * n);
     memcpy(sig.data(), prm, sizeof(jl_params));
-    const uint32_t flags[4] = {(uint32_t)(phasing != 0), min_reads, (uint32_t)(want_read_hap != 0), n};
+    const uint32_t flags[4] = {(uint32_t)(phasing != 0) | (g->xc ? 2u : 0u) | (g->x_staged ? 4u : 0u), min_reads, (uint32_t)(want_read_hap != 0), n};
     memcpy(sig.data() + sizeof(jl_params), flags, 16);
+    const uint32_t par = g->xc ? (uint32_t)(g->x_launched & 1u) : 0u;
+    if (g->xc && g->x_pending[par])
+        return group_fail(g, JL_ERR_STATE, "two exchanges of this group are pending: collect one first (jl_group_exchange_collect)");
     for (uint32_t k = 0; k < n; ++k) {
         jl_ctx *c = g->ctxs[k];
         item it;
@@ -212,8 +248,7 @@ int jl_group_run_masked_async(jl_group *g, const jl_gene *genes, uint32_t n_gene
         memcpy(sig.data() + sizeof(jl_params) + 16 + sizeof(item) * k, &it, sizeof it);
     }
     if (sig != g->sig) {
-        if (g->graph_exec) { hipGraphExecDestroy(g->graph_exec); g->graph_exec = nullptr; }
-        if (g->graph) { hipGraphDestroy(g->graph); g->graph = nullptr; }
+        group_drop_graphs(g);
         g->sig.clear();
         if (hipStreamSynchronize(g->stream) != hipSuccess) return group_fail(g, JL_ERR_DEVICE, "group stream failed");
         g->phasing = phasing != 0;
@@ -252,33 +287,161 @@ int jl_group_run_masked_async(jl_group *g, const jl_gene *genes, uint32_t n_gene
             if (hipMemcpy(g->d_done, ents.data(), sizeof(jl_done_ent) * n, hipMemcpyHostToDevice) != hipSuccess)
                 return group_fail(g, JL_ERR_DEVICE, "argument tables");
         }
-        static const bool graphs_on = !getenv("JL_NO_GRAPH");
-        if (graphs_on && hipStreamBeginCapture(g->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+        g->sig = sig;
+    }
+    // bound exchange: this run's heads go to the region of its parity (this rank's part), whose magic words are cleared now
+    // — a run that dies on the device then leaves heads that every rank reads as this rank's failure
+    for (uint32_t k = 0; k < n; ++k) {
+        uint8_t *xh = g->xc ? g->x_work(par) + g->x_part() * (size_t)g->xc->rank + (size_t)JL_PACK_HEAD_BYTES * k : nullptr;
+        g->h_phase[k].S.xhead = xh;
+        g->h_compact[k].xhead = xh;
+    }
+    if (g->xc) {
+        uint8_t *mine = g->x_work(par) + g->x_part() * (size_t)g->xc->rank;
+        if (!g->x_staged) {
+            for (uint32_t k = 0; k < n; ++k) reinterpret_cast<jl_pack *>(mine + (size_t)JL_PACK_HEAD_BYTES * k)->magic = 0u;
+        } else if (hipMemsetAsync(mine, 0, g->x_part(), g->stream) != hipSuccess) {
+            return group_fail(g, JL_ERR_DEVICE, "exchange region");
+        }
+    }
+    static const bool graphs_on = !getenv("JL_NO_GRAPH");
+    if (graphs_on && !g->graph_exec[par] && !g->graph_tried[par]) {
+        g->graph_tried[par] = true;
+        if (hipStreamBeginCapture(g->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
             const int erc = group_enqueue(g);
             hipGraph_t gr = nullptr;
             if (hipStreamEndCapture(g->stream, &gr) == hipSuccess && gr && erc == JL_OK &&
-                hipGraphInstantiate(&g->graph_exec, gr, nullptr, nullptr, 0) == hipSuccess) {
-                g->graph = gr;
+                hipGraphInstantiate(&g->graph_exec[par], gr, nullptr, nullptr, 0) == hipSuccess) {
+                g->graph[par] = gr;
             } else {
                 if (gr) hipGraphDestroy(gr);
-                g->graph_exec = nullptr;
+                g->graph_exec[par] = nullptr;
             }
             (void)hipGetLastError();
         }
-        g->sig = sig;
     }
-    bool launched = g->graph_exec && hipGraphLaunch(g->graph_exec, g->stream) == hipSuccess;
+    bool launched = g->graph_exec[par] && hipGraphLaunch(g->graph_exec[par], g->stream) == hipSuccess;
     if (!launched) {
         const int erc = group_enqueue(g);
         if (erc != JL_OK || hipGetLastError() != hipSuccess) return group_fail(g, erc ? erc : JL_ERR_DEVICE, "group launch failed");
     }
-    // An event behind the launch: the runtime retires a stream whose last command is an event marker without a marker of
-    // its own (hipStreamSynchronize / the closing hipDeviceSynchronize of a short run: 12 instead of 20-30 us per stream).
-    if (g->ev_end) hipEventRecord(g->ev_end, g->stream);
-    for (jl_ctx *c : g->ctxs) {
+    int xrc = JL_OK;
+    if (g->xc) {
+        // The exchange of this run, behind it on the same stream: ONE collective, in place in the region the kernels have
+        // written this rank's heads into — pinned host memory (nothing else to do: the event behind it says the heads of
+        // all ranks are there), or its device stage and one copy.  Issued whatever happened above: the peers issue theirs.
+        jl_comm *c = g->xc;
+        uint8_t *work = g->x_work(par);
+        jl_comm_direct_wait_begin(c);
+        if (jl_tp_allgather(c, work + g->x_part() * (size_t)c->rank, work, g->x_part(), g->stream) != JL_OK) xrc = JL_ERR_COMM;
+        jl_comm_direct_end(c);
+        if (g->x_staged && hipMemcpyAsync(g->x_host + g->x_region() * par, work, g->x_region(), hipMemcpyDeviceToHost, g->stream) != hipSuccess &&
+            xrc == JL_OK)
+            xrc = JL_ERR_DEVICE;
+        if (hipEventRecord(g->x_done[par], g->stream) != hipSuccess && xrc == JL_OK) xrc = JL_ERR_DEVICE;
+        g->x_pending[par] = true;
+        ++g->x_launched;
+    } else if (g->ev_end) {
+        // An event behind the launch: the runtime retires a stream whose last command is an event marker without a marker of
+        // its own (hipStreamSynchronize / the closing hipDeviceSynchronize of a short run: 12 instead of 20-30 us per stream).
+        hipEventRecord(g->ev_end, g->stream);
+    }
+    for (uint32_t k = 0; k < n; ++k) {
+        jl_ctx *c = g->ctxs[k];
         jl_run_finish(c, phasing, want_read_hap);
         c->run_stream = g->stream;
+        if (g->xc) g->x_run_seq[par][k] = c->runs_launched;
     }
+    if (xrc != JL_OK) return group_fail(g, xrc, xrc == JL_ERR_COMM ? g->xc->tp_error.c_str() : "the run's exchange could not be enqueued");
+    return JL_OK;
+}
+
+int jl_group_exchange_bind(jl_group *g, jl_comm *c)
+{
+    if (!g) return JL_ERR_ARG;
+    if (hipSetDevice(g->device) != hipSuccess) return group_fail(g, JL_ERR_DEVICE, "hipSetDevice failed");
+    if (g->x_pending[0] || g->x_pending[1]) return group_fail(g, JL_ERR_STATE, "an exchange of this group is pending: collect it first");
+    if (c == g->xc) return JL_OK;
+    if (hipStreamSynchronize(g->stream) != hipSuccess) return group_fail(g, JL_ERR_DEVICE, "group stream failed");
+    group_drop_graphs(g);
+    g->sig.clear();
+    if (g->x_host) { hipHostFree(g->x_host); g->x_host = nullptr; }
+    if (g->x_dev) { hipFree(g->x_dev); g->x_dev = nullptr; }
+    g->xc = nullptr;
+    g->x_launched = g->x_collected = 0;
+    if (!c) return JL_OK;
+    if (c->device != g->device) return group_fail(g, JL_ERR_ARG, "group and communicator are on different devices");
+    if (g->ctxs.size() > JL_GATHER_MAX) return group_fail(g, JL_ERR_ARG, "a bound exchange carries at most 32 windows");
+    g->xc = c;
+    g->x_staged = jl_comm_host_gather(c) == 0;   // (a collective the first time a communicator is asked)
+    bool ok = hipHostMalloc(&g->x_host, 2 * g->x_region(), hipHostMallocDefault) == hipSuccess;
+    if (ok) memset(g->x_host, 0, 2 * g->x_region());
+    if (ok && g->x_staged) ok = hipMalloc(&g->x_dev, 2 * g->x_region()) == hipSuccess && hipMemset(g->x_dev, 0, 2 * g->x_region()) == hipSuccess;
+    for (auto &e : g->x_done)
+        if (ok && !e) ok = hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
+    if (!ok) {
+        g->xc = nullptr;
+        return group_fail(g, JL_ERR_MEMORY, "exchange regions");
+    }
+    return JL_OK;
+}
+
+int jl_group_exchange_collect(jl_group *g, jl_variant *all_rows, uint32_t *all_counts, uint32_t cap_rows)
+{
+    if (!g || !all_rows || !all_counts) return JL_ERR_ARG;
+    if (!g->xc) return group_fail(g, JL_ERR_STATE, "jl_group_exchange_collect: no exchange is bound to this group");
+    if (cap_rows == 0 || cap_rows > JL_VARIANT_CAP) return group_fail(g, JL_ERR_ARG, "cap_rows must be 1..4096");
+    const uint32_t par = (uint32_t)(g->x_collected & 1u);
+    if (!g->x_pending[par]) return group_fail(g, JL_ERR_STATE, "jl_group_exchange_collect: no exchange of this group is pending");
+    if (hipSetDevice(g->device) != hipSuccess) return group_fail(g, JL_ERR_DEVICE, "hipSetDevice failed");
+    jl_comm *c = g->xc;
+    {   // spin on the event (a blocking wait costs ~15 us of wake-up latency), but not for ever: a peer may have died
+        hipError_t q;
+        const auto deadline = std::chrono::steady_clock::now() + std::chrono::seconds(JL_COMM_TIMEOUT_S);
+        uint32_t polls = 0;
+        while ((q = hipEventQuery(g->x_done[par])) == hipErrorNotReady)
+            if ((++polls & 0xFFFu) == 0 && std::chrono::steady_clock::now() > deadline)
+                return group_fail(g, JL_ERR_COMM, "the group's exchange is not complete after the time-out: a peer has not issued its collective");
+        if (q != hipSuccess) return group_fail(g, JL_ERR_DEVICE, "the group's exchange failed on the device");
+    }
+    g->x_pending[par] = false;
+    ++g->x_collected;
+    const uint32_t n = (uint32_t)g->ctxs.size();
+    const uint8_t *base = g->x_host + g->x_region() * par;
+    auto head = [&](int r, uint32_t k) { return reinterpret_cast<const jl_pack *>(base + g->x_part() * (size_t)r + (size_t)JL_PACK_HEAD_BYTES * k); };
+    bool compact = true;
+    for (int r = 0; r < c->world; ++r)
+        for (uint32_t k = 0; k < n; ++k) {
+            // a head without the magic word: that rank's run did not reach its result block; every rank sees the same
+            if (head(r, k)->magic != JL_PACK_MAGIC) {
+                g->err = "rank " + std::to_string(r) + "'s run of window " + std::to_string(k) + " did not complete: its head of the exchange is empty";
+                return JL_ERR_COMM;
+            }
+            if (!head(r, k)->fits_call) compact = false;
+        }
+    int rc = JL_OK;
+    for (uint32_t k = 0; k < n; ++k) {
+        jl_variant *rows = all_rows + (size_t)k * c->world * cap_rows;
+        uint32_t *counts = all_counts + (size_t)k * c->world;
+        if (compact) {
+            for (int r = 0; r < c->world; ++r) {
+                const jl_pack *pk = head(r, k);
+                counts[r] = pk->nvar_total;
+                if (pk->nvar_total > cap_rows) { rc = JL_ERR_OVERFLOW; continue; }
+                memcpy(rows + (size_t)r * cap_rows, pk->variants, (size_t)pk->nvar_total * sizeof(jl_variant));
+            }
+            continue;
+        }
+        // Some rank's table has more rows than a head holds: the full stride from the resident tables, window by window —
+        // every rank takes this branch (same heads everywhere).  The resident table is the LAST run's.
+        jl_ctx *x = g->ctxs[k];
+        if (x->runs_launched != g->x_run_seq[par][k])
+            return group_fail(g, JL_ERR_STATE, "a rank called more than 128 variants: such a run's exchange must be collected before the "
+                                               "group's next run (the full table is not double-buffered)");
+        rc = jl_comm_allgather_full(x, c, rows, counts, cap_rows, g->x_run_seq[par][k]);
+        if (rc) return group_fail(g, rc, jl_last_error(x));
+    }
+    if (rc) return group_fail(g, rc, "a rank produced more rows than cap_rows");
     return JL_OK;
 }
 

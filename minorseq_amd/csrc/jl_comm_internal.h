@@ -91,6 +91,7 @@ struct jl_comm {
     bool stop = false;
     bool worker_busy = false;    // the worker is issuing a job (guarded by mu)
     bool direct_busy = false;    // a blocking call of another thread has taken the communicator (guarded by mu)
+    int host_gather = -1;        // may a collective work in pinned host memory?  -1: not tried yet (jl_comm_host_gather)
 };
 
 // A communicator is used by ONE thread at a time.  Asynchronous exchanges are issued by the worker thread; a blocking call
@@ -99,6 +100,15 @@ struct jl_comm {
 // rank is refused alike — and the worker starts nothing until it is given back.
 int jl_comm_direct_begin(jl_comm *c);
 void jl_comm_direct_end(jl_comm *c);
+// The same for a caller whose collective belongs BEHIND whatever the worker still has to issue (the exchange that a group
+// launch carries, jl_group_exchange_bind): waits until the worker's queue is empty, then takes the communicator.
+void jl_comm_direct_wait_begin(jl_comm *c);
+// May an all-gather of this communicator work in place in pinned host memory (one device operation per exchange, nothing
+// to copy back)?  Tried once — a collective: every rank calls this at the same point of its program — on a 64-byte pattern
+// per rank, and agreed on through a second all-gather in device memory, so every rank gets the same answer.  1 / 0.
+int jl_comm_host_gather(jl_comm *c);
+// the full fixed stride of ctx's resident table through the worker (jl_allgather_variants' fall-back)
+extern "C" int jl_comm_allgather_full(jl_ctx *ctx, jl_comm *c, jl_variant *all_rows, uint32_t *all_counts, uint32_t cap_rows, uint32_t wait_seq);
 
 // The transport: the three exchange shapes the library uses, on stream `st`, over RCCL or in process.  0 or JL_ERR_COMM /
 // JL_ERR_DEVICE (c->tp_error says what).  Stream-ordered with RCCL; the in-process form also blocks the calling thread

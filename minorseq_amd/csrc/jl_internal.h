@@ -144,6 +144,7 @@ struct jl_win_compact {
     jl_pack *pk, *mirror;
     uint32_t *seq_dev;
     volatile uint32_t *seq_host;     // non-null: this launch ends a run
+    uint8_t *xhead;                  // bound exchange: see jl_select_args
 };
 
 // what the last block of the fused phase launch needs to run the selection (and to end the run)
@@ -182,6 +183,9 @@ struct jl_select_args {
     uint8_t *exp_pattern;            // [exp_cap][exp_stride]
     uint32_t exp_cap, exp_stride;
     uint32_t *exp_head;              // optional: [JL_EXP_HEAD_WORDS] what a merge needs of the run's scalars (jl_exp_head)
+    // bound exchange (jl_group_exchange_bind): where the head of the result block goes a third time — this rank's part of the
+    // region the all-gather of the launch works in (pinned host memory, or its device stage).  Null: none.
+    uint8_t *xhead;
 };
 
 // head of an exported group table: the block's first words when it travels (pinned host memory, or the all-gather)

@@ -68,6 +68,12 @@ __device__ __forceinline__ void compact_body(const jl_win_compact &w)
         __syncthreads();
         jl_pack *pk = w.pk + (__hip_atomic_load(w.seq_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 1u);
         jl_result_pack_block(w.rows, n, nullptr, 0u, nullptr, nullptr, nullptr, nullptr, nullptr, 0u, 0u, pk, w.mirror);
+        if (w.xhead) {   // bound exchange
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            jl_result_head_copy(pk, w.xhead);
+            if (threadIdx.x == 0) __threadfence_system();
+        }
         if (w.seq_host) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();

@@ -1475,6 +1475,11 @@ __device__ __forceinline__ void phase_fused1_body(const jl_win_phase &w, const j
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        if (S.xhead) {   // bound exchange: the head into the region the launch's all-gather works in
+            jl_result_head_copy(S.pk + (__hip_atomic_load(S.seq_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 1u), S.xhead);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
         // The result block went to pinned host memory from THIS compute die; the completion word will be stored by
         // whichever workgroup arrives last, possibly on another die.  A system-scope release here pushes the block
         // out of this die's L2 first — without it the host now and then saw the word before the block's header

@@ -96,6 +96,18 @@ __device__ __forceinline__ void jl_result_pack_block(const jl_variant *__restric
     }
 }
 
+// The head of the result block this workgroup has just written (header + the rows in use) once more, to `xh`: the send part
+// of a bound exchange.  Read back past the L1 (the stores went through to this die's L2); the caller fences.
+__device__ __forceinline__ void jl_result_head_copy(const jl_pack *pk, uint8_t *xh)
+{
+    const unsigned long long *src = reinterpret_cast<const unsigned long long *>(pk);
+    unsigned long long *dst = reinterpret_cast<unsigned long long *>(xh);
+    const uint32_t n = jl_ld_coherent(&pk->nvar_total);
+    const uint32_t rows = n <= JL_PACK_MAX_VAR ? n : 0u;
+    const uint32_t words = (uint32_t)(offsetof(jl_pack, variants) / 8u) + rows * (uint32_t)(sizeof(jl_variant) / 8u);
+    for (uint32_t i = threadIdx.x; i < words; i += blockDim.x) dst[i] = jl_ld_coherent64(src + i);
+}
+
 // Per-read ids in the narrowest code that holds the run's haplotype count (jl_internal.h: JL_ID4_MAX_H / JL_ID8_MAX_H):
 // eight ids (16-bit codes: haplotype, JL_HAP_INSUFFICIENT, JL_HAP_DAMAGED) of reads 8t .. 8t+7 into the packed buffer
 __device__ __forceinline__ void jl_store_ids(uint16_t *base, uint64_t t, const uint16_t (&h)[8], uint32_t bits)

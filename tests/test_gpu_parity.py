@@ -745,6 +745,76 @@ def test_allgather_of_a_group_run_in_one_rccl_group(jl, oracle):
             c.close()
 
 
+@pytest.mark.parametrize("staged", [False, True])
+def test_group_run_carries_its_exchange(jl, oracle, staged):
+    """jl_group_exchange_bind over RCCL (one rank): the heads of the windows' tables are written by the run's last kernels
+    into the pinned region the all-gather works in (staged: into its device stage, copied behind the collective); two
+    exchanges pending per group, collected oldest first; a third run is refused; with and without phasing; a table of more
+    than 128 rows takes the full stride."""
+    import ctypes as C
+    import subprocess
+    import sys
+    if staged:   # the form is chosen once per communicator from the environment: a child process
+        env = dict(os.environ, JL_EXCHANGE_STAGED="1")
+        r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", __file__, "-k", "test_group_run_carries_its_exchange and False"],
+                           env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        return
+    l = 300
+    genes = np.array([(1, l + 1)], dtype=capi.GENE)
+    ref = synth.reference(51, l)
+    ctxs, exp = [], []
+    for k, n in enumerate((4000, 7000, 2500)):
+        sp = synth.SynthParams(seed=51 + k, minor_permille=(70, 60, 50, 40))
+        rows = synth.rows(sp, l, 0, n, ref)
+        j = capi.Juliet(0)
+        j.upload_columns(msa.pack_columns(rows), n)
+        j.sync()
+        ctxs.append(j)
+        exp.append(oracle.call(rows, genes, refseq=ref))
+    grp = capi.Group(ctxs)
+    idbuf = np.zeros(128, dtype=np.uint8)
+    assert jl.lib.jl_comm_unique_id(idbuf.ctypes.data_as(C.c_void_p)) == 0
+    comm = C.c_void_p()
+    ctxs[0]._chk(jl.lib.jl_comm_create(ctxs[0].h, idbuf.ctypes.data_as(C.c_void_p), 0, 1, C.byref(comm)))
+    try:
+        prm = capi.default_params()
+        with pytest.raises(capi.JulietError):
+            grp.exchange_collect(1)                       # nothing bound
+        grp.bind_exchange(comm)
+        with pytest.raises(capi.JulietError):
+            grp.exchange_collect(1)                       # nothing pending
+        for phasing in (True, False):
+            for rnd in range(2):   # two exchanges pending before the first is collected
+                grp.run_async(genes, ref, prm, phasing, 10, phasing)
+            with pytest.raises(capi.JulietError):
+                grp.run_async(genes, ref, prm, phasing, 10, phasing)
+            for rnd in range(2):
+                rows_, counts = grp.exchange_collect(1, cap_rows=capi.VARIANT_CAP)
+                for k, e in enumerate(exp):
+                    assert counts[k, 0] == len(e)
+                    assert_variants_equal(rows_[k, 0, : counts[k, 0]], e)
+            for c, e in zip(ctxs, exp):
+                assert_variants_equal(c.run_view()["variants"], e)
+        # a loose threshold: more than 128 rows in a window -> the full stride, window by window
+        loose = capi.default_params(alpha=1e9)
+        grp.run_async(genes, ref, loose, False, 10, False)
+        rows_, counts = grp.exchange_collect(1, cap_rows=capi.VARIANT_CAP)
+        for k, c in enumerate(ctxs):
+            own = c.call_fetch()
+            assert len(own) > 128 and counts[k, 0] == len(own)
+            assert_variants_equal(rows_[k, 0, : counts[k, 0]], own)
+        grp.bind_exchange(None)
+        grp.run_async(genes, ref, prm, True, 10, True)    # unbound again: a plain group run
+        for c, e in zip(ctxs, exp):
+            assert_variants_equal(c.run_view()["variants"], e)
+    finally:
+        grp.close()
+        jl.lib.jl_comm_destroy(comm)
+        for c in ctxs:
+            c.close()
+
+
 # --------------------------------------------------------------------------------------------- device ingest
 def rows_to_records(rows, ref, rng, with_noise_ops=True):
     """Re-express by-row symbols as BAM-style records (pos, cigar words, 4-bit packed bases, qualities):

@@ -530,3 +530,52 @@ def test_weak_scaling_exchange_with_two_ranks_in_one_process(oracle):
                 got = rows_[peer * 128: peer * 128 + counts[peer]]
                 for k in ("gene", "codon_pos", "col", "codon", "count", "coverage"):
                     assert (got[k] == theirs[k]).all(), (rank, peer, k)
+
+
+def test_bound_exchange_with_two_ranks_in_one_process(oracle):
+    """jl_group_exchange_bind: every group run carries the all-gather of its windows' table heads, in place in a pinned host
+    region the run's kernels write into.  Two rank threads on one device, two windows each, three runs; each rank's collected
+    tables = the tables both ranks read from their own result blocks."""
+    import ctypes as C
+    n, l, world, nw = 5000, 300, 2, 2
+    genes = np.array([(1, l + 1)], dtype=capi.GENE)
+    idbuf = np.frombuffer(np.random.default_rng(123).bytes(128), dtype=np.uint8).copy()
+
+    def body(rank):
+        ctxs = []
+        for k in range(nw):
+            sp = synth.SynthParams(seed=700 + 10 * rank + k, minor_permille=(70, 60, 50, 40))
+            c = capi.Juliet(0)
+            c.alloc(n + 500 * k, l)
+            c.synth_fill(sp, synth.reference(77, l))
+            c.sync()
+            ctxs.append(c)
+        comm = C.c_void_p()
+        ctxs[0]._chk(ctxs[0].lib.jl_comm_create_inproc(ctxs[0].h, idbuf.ctypes.data_as(C.c_void_p), rank, world, C.byref(comm)))
+        grp = capi.Group(ctxs)
+        out = []
+        try:
+            grp.bind_exchange(comm)
+            for _ in range(3):
+                grp.run_async(genes, synth.reference(77, l), capi.default_params(), True, 10, True)
+                rows_, counts = grp.exchange_collect(world)
+                own = [c.run_view()["variants"].copy() for c in ctxs]
+                out.append((rows_.copy(), counts.copy(), own))
+            grp.bind_exchange(None)
+        finally:
+            grp.close()
+            ctxs[0].lib.jl_comm_destroy(comm)
+            for c in ctxs:
+                c.close()
+        return out
+
+    outs = _ranks_in_threads(world, body)
+    for rank in range(world):
+        for rows_, counts, _own in outs[rank]:
+            for peer in range(world):
+                for k in range(nw):
+                    theirs = outs[peer][0][2][k]
+                    assert counts[k, peer] == len(theirs) and len(theirs) >= 4
+                    got = rows_[k, peer, : counts[k, peer]]
+                    for f in ("gene", "codon_pos", "col", "codon", "count", "coverage", "expected"):
+                        assert (got[f] == theirs[f]).all(), (rank, peer, k, f)
