@@ -269,7 +269,7 @@ public:
     jl_ctx *failed() const { return failed_; }
     std::vector<std::string> names;
     uint64_t n_reads = 0;
-    double ms_begin = 0, ms_append = 0, ms_append_max = 0, ms_names = 0;   // --timing
+    double ms_begin = 0, ms_append = 0, ms_append_max = 0, ms_names = 0, ms_gather = 0;   // --timing
     unsigned n_appends = 0;
 
 private:
@@ -277,7 +277,35 @@ private:
     {
         return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count();
     }
-    void run()
+    // Chunk after chunk (offsets relative to the chunk) behind each other in `big_`: what the decoder hands over while the
+    // GPU runtime is still starting goes to the device as a few LARGE copies once the contexts exist — a pageable copy pins its
+    // source range first, and sixty-one chunks of a few MB, each a buffer the runtime has not seen, cost 16-25 ms where the same
+    // 200 MB out of five arrays cost 5-6 (tools_tuning/h2d_threads.cpp: 21 against 36 GB/s on first touch).  The gathering
+    // itself runs beside the decode, on this thread.
+    void gather(const RecordArrays &c)
+    {
+        const size_t n = c.pos.size();
+        const uint64_t cb = big_.cigar.size(), sb = big_.seq4.size(), qb = big_.qual.size();
+        big_.pos.insert(big_.pos.end(), c.pos.begin(), c.pos.end());
+        big_.cigar.insert(big_.cigar.end(), c.cigar.begin(), c.cigar.end());
+        big_.seq4.insert(big_.seq4.end(), c.seq4.begin(), c.seq4.end());
+        for (size_t i = 1; i <= n; ++i) {
+            big_.cig_off.push_back(cb + c.cig_off[i] - c.cig_off[0]);
+            big_.seq_off.push_back(sb + c.seq_off[i] - c.seq_off[0]);
+        }
+        if (want_qual_) {
+            big_.qual.insert(big_.qual.end(), c.qual.begin(), c.qual.end());
+            for (size_t i = 1; i <= n; ++i) big_.qual_off.push_back(qb + c.qual_off[i] - c.qual_off[0]);
+        }
+    }
+    size_t gathered_bytes() const { return big_.seq4.size() + big_.qual.size() + 4 * big_.cigar.size(); }
+    bool contexts_ready() const
+    {
+        for (const auto &f : ctx_up_)
+            if (f.wait_for(std::chrono::seconds(0)) != std::future_status::ready) return false;
+        return true;
+    }
+    void open()   // waits for the contexts
     {
         for (auto &f : ctx_up_) {
             const auto up = f.get();
@@ -295,34 +323,69 @@ private:
             if (rc_ != JL_OK) failed_ = c;
             ms_begin += ms_since(t);
         }
+        ready_ = true;
+    }
+    void flush()
+    {
+        if (big_.pos.empty()) return;
+        const auto t = std::chrono::steady_clock::now();
+        for (jl_ctx *dst : ctxs_) {
+            if (rc_ != JL_OK) break;
+            rc_ = jl_records_append(dst, big_.pos.size(), big_.pos.data(), big_.cigar.data(), big_.cig_off.data(), big_.seq4.data(),
+                                    big_.seq_off.data(), want_qual_ ? big_.qual.data() : nullptr,
+                                    want_qual_ ? big_.qual_off.data() : nullptr);
+            if (rc_ != JL_OK) failed_ = dst;
+        }
+        const double ms = ms_since(t);
+        ms_append += ms;
+        ms_append_max = std::max(ms_append_max, ms);
+        ++n_appends;
+        big_.clear();
+    }
+    void run()
+    {
+        // the gathered arrays at about the size the device arrays get (virtual until touched), at most kGatherCap at a time
+        const size_t kGatherCap = (size_t)512 << 20;
+        {
+            const size_t seq_hint = (size_t)std::min<uint64_t>(file_bytes_ * 7 / 2, kGatherCap);
+            big_.seq4.reserve(seq_hint);
+            big_.cigar.reserve(seq_hint / 8);
+            if (want_qual_) big_.qual.reserve(2 * seq_hint);
+        }
         for (;;) {
-            RecordArrays c;
+            std::deque<RecordArrays> got;
+            bool finished = false;
             {
                 std::unique_lock<std::mutex> lk(m_);
-                cv_.wait(lk, [this] { return done_ || !q_.empty(); });
-                if (q_.empty()) return;
-                c = std::move(q_.front());
-                q_.pop_front();
+                if (ready_) cv_.wait(lk, [this] { return done_ || !q_.empty(); });
+                else cv_.wait_for(lk, std::chrono::microseconds(250), [this] { return done_ || !q_.empty(); });   // (the contexts too)
+                got.swap(q_);
+                finished = done_ && got.empty();
             }
-            auto t = std::chrono::steady_clock::now();
-            for (jl_ctx *dst : ctxs_) {
-                if (rc_ != JL_OK) break;
-                rc_ = jl_records_append(dst, c.pos.size(), c.pos.data(), c.cigar.data(), c.cig_off.data(), c.seq4.data(),
-                                        c.seq_off.data(), want_qual_ ? c.qual.data() : nullptr,
-                                        want_qual_ ? c.qual_off.data() : nullptr);
-                if (rc_ != JL_OK) failed_ = dst;
+            for (RecordArrays &c : got) {
+                auto t = std::chrono::steady_clock::now();
+                gather(c);
+                ms_gather += ms_since(t);
+                t = std::chrono::steady_clock::now();
+                n_reads += c.pos.size();
+                for (std::string &nm : c.names) names.push_back(std::move(nm));
+                c.clear();
+                ms_names += ms_since(t);
+                std::lock_guard<std::mutex> lk(m_);
+                if (pool_.size() < 8) pool_.push_back(std::move(c));
             }
-            const double ms = ms_since(t);
-            ms_append += ms;
-            ms_append_max = std::max(ms_append_max, ms);
-            ++n_appends;
-            t = std::chrono::steady_clock::now();
-            n_reads += c.pos.size();
-            for (std::string &nm : c.names) names.push_back(std::move(nm));
-            c.clear();
-            ms_names += ms_since(t);
-            std::lock_guard<std::mutex> lk(m_);
-            if (pool_.size() < 8) pool_.push_back(std::move(c));
+            if (!ready_ && (finished || gathered_bytes() >= kGatherCap || contexts_ready())) open();
+            // on the device as soon as nothing more is waiting to be gathered (while the decode still runs: chunk by chunk,
+            // hidden under it, as before)
+            if (ready_) {
+                bool idle;
+                {
+                    std::lock_guard<std::mutex> lk(m_);
+                    idle = q_.empty();
+                }
+                if (idle || finished || gathered_bytes() >= kGatherCap / 2) flush();
+            }
+            if (finished) return;
         }
     }
     std::vector<std::shared_future<std::pair<int, jl_ctx *>>> ctx_up_;
@@ -332,7 +395,8 @@ private:
     std::condition_variable cv_;
     std::deque<RecordArrays> q_;
     std::vector<RecordArrays> pool_;
-    bool done_ = false;
+    bool done_ = false, ready_ = false;
+    RecordArrays big_;
     int rc_ = JL_OK;
     std::vector<jl_ctx *> ctxs_;
     jl_ctx *failed_ = nullptr;
@@ -710,8 +774,8 @@ int main(int argc, char **argv)
         names.swap(uploader->names);
         tick("rest of the upload");
         if (opt.timing)
-            fprintf(stderr, "juliet: timing   uploader thread: begin %.1f ms, %u appends %.1f ms (longest %.1f), names %.1f ms\n",
-                    uploader->ms_begin, uploader->n_appends, uploader->ms_append, uploader->ms_append_max, uploader->ms_names);
+            fprintf(stderr, "juliet: timing   uploader thread: gather %.1f ms, begin %.1f ms, %u appends %.1f ms (longest %.1f), names %.1f ms\n",
+                    uploader->ms_gather, uploader->ms_begin, uploader->n_appends, uploader->ms_append, uploader->ms_append_max, uploader->ms_names);
         const uint8_t *refp = refcodes.empty() ? nullptr : refcodes.data();
         Results R;
         R.col_counts.assign((size_t)n_cols * 6, 0);
