@@ -12,7 +12,8 @@ same window gave when it was run alone before the timed region (a stale or mixed
 
 Workload at N=1: BASELINE.json configs[2] (= configs[1] with phasing on): 100k CCS reads x 3 kb reference.
 N > 1 (`value`): reference windows shard independently — one 3 kb window x 100k reads per rank and batch (weak
-scaling), the only exchange is the RCCL all-gather of the fixed-stride variant table.
+scaling), the only exchange is the RCCL all-gather of the variant table, which rides with each launch as one device
+operation (jl_group_exchange_bind; JL_BENCH_EXCHANGE=worker: the communicator's worker-thread form).
 Every N also times BASELINE.json configs[3] as stated — ONE 10 kb reference whose 1M reads span all windows, split
 into N column windows (strong scaling): call per window with the global Bonferroni factor, all-gather of the table,
 the variant columns broadcast by their owners, phasing across windows — reported as `config3_strong` in the same line.

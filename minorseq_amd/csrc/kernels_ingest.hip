@@ -48,8 +48,11 @@ constexpr uint32_t kTileDw = 32u * kRowI;
 constexpr uint32_t kEntCap = 7u * kTileReads;       // run entries of the workgroup's reads in its sweep (LDS)
 constexpr uint32_t kRunMask = 0x3FFFFFFFu;          // reference offset of a run; kind in the two bits above
 constexpr uint32_t kMaxPieces = 1023u;              // pieces of a read in a sweep (10 bits; the deferral list holds 12)
-static_assert(kSweep % 8u == 0 && kSweepDw <= 32u, "a sweep is at most 32 dwords wide");
-static_assert(JL_INGEST_TILE % 64 == 0, "a wave expands sixteen reads a round");
+// 32-byte pieces (64 bases) of a read that a sweep takes from a 16-byte boundary on, insertions aside: a power of two of lanes
+constexpr uint32_t kPiecesPerRead = (kSweep + 31u + 63u) / 64u <= 4u ? 4u : 8u;
+static_assert(kSweep % 8u == 0 && kSweep + 31u <= 64u * kPiecesPerRead, "a sweep is at most eight pieces of a read wide");
+static_assert((JL_INGEST_TILE * kPiecesPerRead) % 256u == 0 && JL_INGEST_TILE % 32 == 0, "whole rounds of the four waves; whole plane dwords");
+static_assert(256u / kTileGroups >= kSweepDw, "a thread per 32 reads x 8 columns in the transposing phase");
 
 __device__ __forceinline__ bool cig_ref(uint32_t op) { return op == 2u || op == 3u || op == 7u || op == 8u; }    // D N = X
 __device__ __forceinline__ bool cig_query(uint32_t op) { return op == 1u || op == 4u || op == 7u || op == 8u; }  // I S = X
@@ -530,8 +533,9 @@ __global__ __launch_bounds__(256) void ingest_planes_kernel(ingest_args a)
     // tile; the pieces that go on into another run (one in seven) are listed and finished in a second pass with full lanes
     // — in line, the loop over a piece's runs made every wave walk two or three runs for them.
     if (!JL_ING_SKIP(a, 0)) {
-        constexpr uint32_t kRounds = kTileReads / 64u;   // rounds of a wave: 16 reads x 4 waves each
-        const uint32_t slot = lane >> 2, piece = lane & 3u;
+        constexpr uint32_t kReadsPerRound = 64u / kPiecesPerRead;              // reads a wave expands at a time
+        constexpr uint32_t kRounds = kTileReads / (4u * kReadsPerRound);       // rounds of a wave
+        const uint32_t slot = lane / kPiecesPerRead, piece = lane % kPiecesPerRead;
         auto fetch = [&](uint32_t j, uint32_t pc, uint4 &v0, uint4 &v1) {
             const read_info &q = s_info[j];
             v0 = make_uint4(0, 0, 0, 0);
@@ -578,14 +582,14 @@ __global__ __launch_bounds__(256) void ingest_planes_kernel(ingest_args a)
         };
         uint4 va[kRounds], vb[kRounds];
 #pragma unroll
-        for (uint32_t it = 0; it < kRounds; ++it) fetch((wid + 4u * it) * 16u + slot, piece, va[it], vb[it]);
+        for (uint32_t it = 0; it < kRounds; ++it) fetch((wid + 4u * it) * kReadsPerRound + slot, piece, va[it], vb[it]);
 #pragma unroll
         for (uint32_t it = 0; it < kRounds; ++it) {
-            const uint32_t j = (wid + 4u * it) * 16u + slot;
+            const uint32_t j = (wid + 4u * it) * kReadsPerRound + slot;
             expand(j, piece, va[it], vb[it]);
-            // a read with more than four pieces in the sweep (insertions)
+            // a read with more pieces in the sweep (insertions)
             const uint32_t npj = s_info[j].ent >> 22;
-            for (uint32_t pp = piece + 4u; __ballot(pp < npj) != 0ull; pp += 4u) {
+            for (uint32_t pp = piece + kPiecesPerRead; __ballot(pp < npj) != 0ull; pp += kPiecesPerRead) {
                 uint4 w0, w1;
                 fetch(j, pp, w0, w1);
                 expand(j, pp, w0, w1);

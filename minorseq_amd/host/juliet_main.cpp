@@ -801,6 +801,14 @@ int main(int argc, char **argv)
             if (opt.exchange.empty())
                 for (size_t a = 0; a < n_ranks; ++a)
                     for (size_t b = a + 1; b < n_ranks; ++b) inproc = inproc || opt.devices[a] == opt.devices[b];
+            {   // distinct devices: the exchanges between them (RCCL, or peer copies in process) have never run on hardware
+                bool distinct = false;
+                for (size_t a = 0; a < n_ranks; ++a)
+                    for (size_t b = a + 1; b < n_ranks; ++b) distinct = distinct || opt.devices[a] != opt.devices[b];
+                if (distinct)
+                    fprintf(stderr, "juliet: warning: --devices with more than one distinct device is experimental: the exchange between devices is "
+                                    "covered by one-device tests only (in-process ranks, one-rank RCCL)\n");
+            }
             std::vector<RankJob> jobs(n_ranks);
             for (size_t r = 0; r < n_ranks; ++r) {
                 jobs[r].inproc = inproc;
