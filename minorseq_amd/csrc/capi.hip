@@ -8,6 +8,9 @@
 
 #include <algorithm>
 #include <new>
+#ifdef JL_TUNING
+#include <chrono>
+#endif
 
 #include "jl_internal.h"
 
@@ -78,22 +81,43 @@ int jl_device_count(void)
 
 const char *jl_last_error(const jl_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
+#ifdef JL_TUNING
+// JL_CTX_TIMES=1: where jl_ctx_create spends its time (tools_tuning/ctx_create_cost.py)
+#define JL_CTX_MARK(what)                                                                                              \
+    do {                                                                                                               \
+        if (ctx_times) {                                                                                               \
+            const auto now_ = std::chrono::steady_clock::now();                                                        \
+            fprintf(stderr, "  jl_ctx_create: %-28s %7.2f ms\n", what, std::chrono::duration<double, std::milli>(now_ - mark_).count()); \
+            mark_ = now_;                                                                                              \
+        }                                                                                                              \
+    } while (0)
+#else
+#define JL_CTX_MARK(what) do { } while (0)
+#endif
+
 int jl_ctx_create(int device, void *stream, jl_ctx **out)
 {
     if (!out) return JL_ERR_ARG;
     *out = nullptr;
+#ifdef JL_TUNING
+    const bool ctx_times = getenv("JL_CTX_TIMES") != nullptr;
+    auto mark_ = std::chrono::steady_clock::now();
+#endif
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
         return jl_fail(nullptr, JL_ERR_DEVICE, "no HIP device visible; this library has no CPU fallback");
     if (device < 0 || device >= n) return jl_fail(nullptr, JL_ERR_ARG, "device %d out of range (%d visible)", device, n);
+    JL_CTX_MARK("hipGetDeviceCount");
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) return jl_fail(nullptr, JL_ERR_DEVICE, "hipGetDeviceProperties failed");
+    JL_CTX_MARK("hipGetDeviceProperties");
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return jl_fail(nullptr, JL_ERR_DEVICE, "device %d is %s; kernels are built for gfx950 only", device, prop.gcnArchName);
     jl_ctx *ctx = new (std::nothrow) jl_ctx();
     if (!ctx) return JL_ERR_MEMORY;
     ctx->device = device;
     if (hipSetDevice(device) != hipSuccess) { delete ctx; return jl_fail(nullptr, JL_ERR_DEVICE, "hipSetDevice failed"); }
+    JL_CTX_MARK("hipSetDevice");
     if (stream) {
         ctx->stream = (hipStream_t)stream;
     } else {
@@ -103,8 +127,10 @@ int jl_ctx_create(int device, void *stream, jl_ctx **out)
         }
         ctx->own_stream = true;
     }
+    JL_CTX_MARK("stream");
     hipEventCreate(&ctx->ev0);
     hipEventCreate(&ctx->ev1);
+    JL_CTX_MARK("two events");
 
     bool ok = hipMalloc(&ctx->d_variants, sizeof(jl_variant) * JL_VARIANT_CAP) == hipSuccess &&
               hipMalloc(&ctx->d_nvar, 2 * sizeof(uint32_t)) == hipSuccess &&
@@ -115,16 +141,19 @@ int jl_ctx_create(int device, void *stream, jl_ctx **out)
               hipMalloc(&ctx->d_hit, (size_t)JL_VARIANT_CAP * JL_MAX_HAPLOTYPES) == hipSuccess &&
               hipMalloc(&ctx->d_cooc, sizeof(uint32_t) * ctx->cooc_cap * ctx->cooc_cap) == hipSuccess &&
               hipMalloc(&ctx->d_pack, 2 * sizeof(jl_pack)) == hipSuccess &&
-              hipMalloc(&ctx->d_sync, 16 * sizeof(uint32_t)) == hipSuccess &&
-              hipHostMalloc(&ctx->h_pack, sizeof(jl_pack), hipHostMallocDefault) == hipSuccess &&
+              hipMalloc(&ctx->d_sync, 16 * sizeof(uint32_t)) == hipSuccess;
+    JL_CTX_MARK("ten hipMalloc");
+    ok = ok && hipHostMalloc(&ctx->h_pack, sizeof(jl_pack), hipHostMallocDefault) == hipSuccess &&
               hipHostMalloc((void **)&ctx->h_seq, 64, hipHostMallocDefault) == hipSuccess &&
               hipHostMalloc(&ctx->h_scratch, (size_t)1 << 20, hipHostMallocDefault) == hipSuccess;
+    JL_CTX_MARK("three hipHostMalloc");
     if (ok) ctx->h_scratch_cap = (size_t)1 << 20;
     if (!ok) { jl_ctx_destroy(ctx); return jl_fail(nullptr, JL_ERR_MEMORY, "context allocation failed"); }
     hipMemsetAsync(ctx->d_nvar, 0, 2 * sizeof(uint32_t), ctx->stream);
     hipMemsetAsync(ctx->d_meta, 0, sizeof(jl_phase_meta), ctx->stream);
     hipMemsetAsync(ctx->d_sync, 0, 16 * sizeof(uint32_t), ctx->stream);
     for (int k = 0; k < 16; ++k) ctx->h_seq[k] = 0;
+    JL_CTX_MARK("three hipMemsetAsync");
     *out = ctx;
     return JL_OK;
 }
