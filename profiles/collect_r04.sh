@@ -4,7 +4,7 @@
 #   c  bench.py defaults, unprofiled                                                                  -> r04_c_bench_line.json
 #   e  the juliet front end on a 100k-read BAM: --timing x3, --windows 8, kernel trace (no planes_kernel) -> r04_e_cli_*
 #   f  a window with sixteen variant positions (two-word fused launch) + one window alone             -> r04_f_many_positions.txt
-#   g  one-rank emulation of the N > 1 step loop                                                      -> r04_g_*
+#   g  one-rank emulation of the N > 1 step loop: exchange carried by the launch (default), worker-thread form, staged form, plain -> r04_g_*
 #   h  the record ingest alone: kernel stats + PMC FETCH_SIZE / WRITE_SIZE of its kernels            -> r04_h_ingest_*
 set -e
 R=$GRAFT_REPO_ROOT
@@ -32,6 +32,8 @@ python3 tools_tuning/generic_phase_cost.py --check > $O/f_many_positions.txt 2> 
 python3 tools_tuning/one_window_latency.py >> $O/f_many_positions.txt 2>> $O/f.err
 echo "f done"
 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 MASTER_ADDR=127.0.0.1 MASTER_PORT=29517 JL_BENCH_FORCE_DIST=1 python3 bench.py --steps 4000 --warmup 64 --no-cpu-baseline --no-config4 --no-once-through > $O/g_dist_emulated_line.json 2> $O/g.err
+RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 MASTER_ADDR=127.0.0.1 MASTER_PORT=29518 JL_BENCH_FORCE_DIST=1 JL_BENCH_EXCHANGE=worker python3 bench.py --steps 4000 --warmup 64 --no-cpu-baseline --no-config3 --no-config4 --no-once-through > $O/g_dist_worker_form_line.json 2>> $O/g.err
+RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 MASTER_ADDR=127.0.0.1 MASTER_PORT=29519 JL_BENCH_FORCE_DIST=1 JL_EXCHANGE_STAGED=1 python3 bench.py --steps 4000 --warmup 64 --no-cpu-baseline --no-config3 --no-config4 --no-once-through > $O/g_dist_staged_form_line.json 2>> $O/g.err
 python3 bench.py --steps 4000 --warmup 64 --no-cpu-baseline --no-config3 --no-once-through > $O/g_plain_4000_line.json 2>> $O/g.err
 echo "g done"
 cd /tmp
