@@ -422,6 +422,8 @@ int jl_allgather_variants_many(jl_ctx *const *ctxs, uint32_t n_ctx, jl_comm *com
  * all_counts [n_windows][world], as jl_allgather_variants_many — spinning on its event (JL_ERR_COMM after 60 s, and when a
  * rank's run did not reach its result block: every rank sees that rank's empty head).  Two regions by run parity: a
  * group may launch its next run before collecting this one; a third pending exchange is refused (JL_ERR_STATE).  A run
+ * that fails on a rank before or at its launch still issues that rank's collective, with empty heads: the launching call
+ * returns the run's own error, the collecting calls of ALL ranks report that rank (JL_ERR_COMM), nobody waits for ever.  A run
  * in which some rank called more than 128 variants falls back — on every rank alike — to the full fixed-stride table of
  * every window, which must then be collected before the group's next run.
  * Binding is a collective the first time a communicator is bound: the ranks try a 64-byte all-gather in pinned host memory

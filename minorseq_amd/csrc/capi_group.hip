@@ -218,6 +218,23 @@ int jl_group_run_masked_async(jl_group *g, const jl_gene *genes, uint32_t n_gene
     if (hipSetDevice(g->device) != hipSuccess) return group_fail(g, JL_ERR_DEVICE, "hipSetDevice failed");
     const uint32_t n = (uint32_t)g->ctxs.size();
     std::vector<double> n_tests(n);
+    const uint32_t par = g->xc ? (uint32_t)(g->x_launched & 1u) : 0u;
+    if (g->xc && g->x_pending[par])   // (the same on every rank: nobody issues a collective)
+        return group_fail(g, JL_ERR_STATE, "two exchanges of this group are pending: collect one first (jl_group_exchange_collect)");
+    // Bound exchange: this run's heads go to the region of its parity (this rank's part), whose magic words are cleared first —
+    // whatever goes wrong below on THIS rank, on the host or on the device, the collective is still issued (the peers issue
+    // theirs and would wait for ever) and carries empty heads, which every rank reads as this rank's failure.
+    bool x_ok = true;
+    if (g->xc) {
+        uint8_t *mine = g->x_work(par) + g->x_part() * (size_t)g->xc->rank;
+        if (!g->x_staged) {
+            for (uint32_t k = 0; k < n; ++k) reinterpret_cast<jl_pack *>(mine + (size_t)JL_PACK_HEAD_BYTES * k)->magic = 0u;
+        } else if (hipMemsetAsync(mine, 0, g->x_part(), g->stream) != hipSuccess) {
+            x_ok = false;
+        }
+    }
+    // ---- the run itself
+    auto run_part = [&]() -> int {
     // per-window preparation (plans, buffers, parameter blocks): may allocate and wait, so it comes before any enqueue
     for (uint32_t k = 0; k < n; ++k) {
         jl_ctx *c = g->ctxs[k];
@@ -235,9 +252,6 @@ int jl_group_run_masked_async(jl_group *g, const jl_gene *genes, uint32_t n_gene
     memcpy(sig.data(), prm, sizeof(jl_params));
     const uint32_t flags[4] = {(uint32_t)(phasing != 0) | (g->xc ? 2u : 0u) | (g->x_staged ? 4u : 0u), min_reads, (uint32_t)(want_read_hap != 0), n};
     memcpy(sig.data() + sizeof(jl_params), flags, 16);
-    const uint32_t par = g->xc ? (uint32_t)(g->x_launched & 1u) : 0u;
-    if (g->xc && g->x_pending[par])
-        return group_fail(g, JL_ERR_STATE, "two exchanges of this group are pending: collect one first (jl_group_exchange_collect)");
     for (uint32_t k = 0; k < n; ++k) {
         jl_ctx *c = g->ctxs[k];
         item it;
@@ -289,20 +303,10 @@ int jl_group_run_masked_async(jl_group *g, const jl_gene *genes, uint32_t n_gene
         }
         g->sig = sig;
     }
-    // bound exchange: this run's heads go to the region of its parity (this rank's part), whose magic words are cleared now
-    // — a run that dies on the device then leaves heads that every rank reads as this rank's failure
     for (uint32_t k = 0; k < n; ++k) {
         uint8_t *xh = g->xc ? g->x_work(par) + g->x_part() * (size_t)g->xc->rank + (size_t)JL_PACK_HEAD_BYTES * k : nullptr;
         g->h_phase[k].S.xhead = xh;
         g->h_compact[k].xhead = xh;
-    }
-    if (g->xc) {
-        uint8_t *mine = g->x_work(par) + g->x_part() * (size_t)g->xc->rank;
-        if (!g->x_staged) {
-            for (uint32_t k = 0; k < n; ++k) reinterpret_cast<jl_pack *>(mine + (size_t)JL_PACK_HEAD_BYTES * k)->magic = 0u;
-        } else if (hipMemsetAsync(mine, 0, g->x_part(), g->stream) != hipSuccess) {
-            return group_fail(g, JL_ERR_DEVICE, "exchange region");
-        }
     }
     static const bool graphs_on = !getenv("JL_NO_GRAPH");
     if (graphs_on && !g->graph_exec[par] && !g->graph_tried[par]) {
@@ -325,7 +329,10 @@ int jl_group_run_masked_async(jl_group *g, const jl_gene *genes, uint32_t n_gene
         const int erc = group_enqueue(g);
         if (erc != JL_OK || hipGetLastError() != hipSuccess) return group_fail(g, erc ? erc : JL_ERR_DEVICE, "group launch failed");
     }
-    int xrc = JL_OK;
+    return JL_OK;
+    };
+    const int run_rc = run_part();
+    int xrc = x_ok ? JL_OK : JL_ERR_DEVICE;
     if (g->xc) {
         // The exchange of this run, behind it on the same stream: ONE collective, in place in the region the kernels have
         // written this rank's heads into — pinned host memory (nothing else to do: the event behind it says the heads of
@@ -333,7 +340,7 @@ int jl_group_run_masked_async(jl_group *g, const jl_gene *genes, uint32_t n_gene
         jl_comm *c = g->xc;
         uint8_t *work = g->x_work(par);
         jl_comm_direct_wait_begin(c);
-        if (jl_tp_allgather(c, work + g->x_part() * (size_t)c->rank, work, g->x_part(), g->stream) != JL_OK) xrc = JL_ERR_COMM;
+        if (jl_tp_allgather(c, work + g->x_part() * (size_t)c->rank, work, g->x_part(), g->stream) != JL_OK && xrc == JL_OK) xrc = JL_ERR_COMM;
         jl_comm_direct_end(c);
         if (g->x_staged && hipMemcpyAsync(g->x_host + g->x_region() * par, work, g->x_region(), hipMemcpyDeviceToHost, g->stream) != hipSuccess &&
             xrc == JL_OK)
@@ -341,11 +348,12 @@ int jl_group_run_masked_async(jl_group *g, const jl_gene *genes, uint32_t n_gene
         if (hipEventRecord(g->x_done[par], g->stream) != hipSuccess && xrc == JL_OK) xrc = JL_ERR_DEVICE;
         g->x_pending[par] = true;
         ++g->x_launched;
-    } else if (g->ev_end) {
+    } else if (g->ev_end && run_rc == JL_OK) {
         // An event behind the launch: the runtime retires a stream whose last command is an event marker without a marker of
         // its own (hipStreamSynchronize / the closing hipDeviceSynchronize of a short run: 12 instead of 20-30 us per stream).
         hipEventRecord(g->ev_end, g->stream);
     }
+    if (run_rc != JL_OK) return run_rc;   // (its message stands; the exchange, if any, went out with empty heads and is pending)
     for (uint32_t k = 0; k < n; ++k) {
         jl_ctx *c = g->ctxs[k];
         jl_run_finish(c, phasing, want_read_hap);

@@ -804,6 +804,15 @@ def test_group_run_carries_its_exchange(jl, oracle, staged):
             own = c.call_fetch()
             assert len(own) > 128 and counts[k, 0] == len(own)
             assert_variants_equal(rows_[k, 0, : counts[k, 0]], own)
+        # a run that fails on this rank before anything is launched still issues its collective, with empty heads: the
+        # caller gets the run's own error, the collecting call (here and on every peer) that rank's failure
+        with pytest.raises(capi.JulietError, match="tail"):
+            grp.run_async(genes, ref, capi.default_params(tail=2), True, 10, True)
+        with pytest.raises(capi.JulietError, match="did not complete"):
+            grp.exchange_collect(1)
+        grp.run_async(genes, ref, prm, True, 10, True)    # and the group goes on
+        rows_, counts = grp.exchange_collect(1)
+        assert [int(c) for c in counts[:, 0]] == [len(e) for e in exp]
         grp.bind_exchange(None)
         grp.run_async(genes, ref, prm, True, 10, True)    # unbound again: a plain group run
         for c, e in zip(ctxs, exp):
