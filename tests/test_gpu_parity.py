@@ -824,6 +824,42 @@ def test_group_run_carries_its_exchange(jl, oracle, staged):
             c.close()
 
 
+def test_bound_exchange_of_a_group_cut_into_chunks(jl, oracle):
+    """Ten windows = two chunks of the group pipeline (the first chunk's tail runs on a side stream beside the second chunk's
+    pileup): every window's head must be in the region before the all-gather behind the graph reads it."""
+    import ctypes as C
+    l = 300
+    genes = np.array([(1, l + 1)], dtype=capi.GENE)
+    ref = synth.reference(61, l)
+    ctxs, exp = [], []
+    for k in range(10):
+        sp = synth.SynthParams(seed=61 + k, minor_permille=(70, 60, 50, 40))
+        rows = synth.rows(sp, l, 0, 1500 + 100 * k, ref)
+        j = capi.Juliet(0)
+        j.upload_columns(msa.pack_columns(rows), len(rows))
+        j.sync()
+        ctxs.append(j)
+        exp.append(oracle.call(rows, genes, refseq=ref))
+    grp = capi.Group(ctxs)
+    idbuf = np.zeros(128, dtype=np.uint8)
+    assert jl.lib.jl_comm_unique_id(idbuf.ctypes.data_as(C.c_void_p)) == 0
+    comm = C.c_void_p()
+    ctxs[0]._chk(jl.lib.jl_comm_create(ctxs[0].h, idbuf.ctypes.data_as(C.c_void_p), 0, 1, C.byref(comm)))
+    try:
+        grp.bind_exchange(comm)
+        for rnd in range(3):
+            grp.run_async(genes, ref, capi.default_params(), True, 10, True)
+            rows_, counts = grp.exchange_collect(1)
+            for k, e in enumerate(exp):
+                assert counts[k, 0] == len(e), (rnd, k)
+                assert_variants_equal(rows_[k, 0, : counts[k, 0]], e)
+    finally:
+        grp.close()
+        jl.lib.jl_comm_destroy(comm)
+        for c in ctxs:
+            c.close()
+
+
 # --------------------------------------------------------------------------------------------- device ingest
 def rows_to_records(rows, ref, rng, with_noise_ops=True):
     """Re-express by-row symbols as BAM-style records (pos, cigar words, 4-bit packed bases, qualities):
