@@ -306,24 +306,24 @@ __device__ __forceinline__ void piece_syms(const ingest_args &a, const uint4 &v0
                                            uint32_t (&S)[8])
 {
     const uint32_t w8[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-    constexpr uint32_t m = 0x11111111u;
-    uint32_t anybad = 0;
-    uint32_t cntw[8];
+    // BAM's 4-bit base -> symbol code by table: A C G T (1 2 4 8) -> 0..3, everything else (N = 15, '=' = 0, the IUPAC
+    // ambiguity codes) -> N, a filtered base.  v_perm_b32 looks four bytes up in an 8-byte table: the low three bits of a
+    // base select in the table of the codes 0..7 and in that of 8..15, bit 3 picks between the two results.  The first base
+    // of a byte is its HIGH nibble and goes to the lower column: the two halves are put together the other way round.
+    // (Counting the set bits of every nibble, mapping one-hot to index and patching the rest was 29 instructions a dword,
+    // and two pieces in three hold an N; this is 18.)
+    constexpr uint32_t kLo03 = 0x05010005u, kLo47 = 0x05050502u;   // codes of 0..3 (bytes 0..3), of 4..7
+    constexpr uint32_t kHi03 = 0x05050503u, kHi47 = 0x05050505u;   // codes of 8..11, of 12..15
+    auto lookup4 = [&](uint32_t x) -> uint32_t {   // four bases, one per byte (0..15) -> four codes
+        const uint32_t sel = x & 0x07070707u;
+        const uint32_t lo = __builtin_amdgcn_perm(kLo47, kLo03, sel), hi = __builtin_amdgcn_perm(kHi47, kHi03, sel);
+        const uint32_t pick = ((x & 0x08080808u) >> 3) * 0xFFu;   // bytes of ones where bit 3 is set
+        return (hi & pick) | (lo & ~pick);
+    };
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-        const uint32_t w = ((w8[k] & 0x0F0F0F0Fu) << 4) | ((w8[k] >> 4) & 0x0F0F0F0Fu);   // base order = nibble order
-        const uint32_t t1 = w >> 1, t2 = w >> 2, t3 = w >> 3;
-        S[k] = ((t1 | t3) & m) | (((t2 | t3) & m) << 1);     // one-hot A C G T (1 2 4 8) -> 0..3
-        cntw[k] = (w & m) + (t1 & m) + (t2 & m) + (t3 & m);  // set bits per nibble
-        anybad |= cntw[k] ^ m;
-    }
-    if (anybad != 0u) {   // ambiguity codes (N = 15, '=' = 0, IUPAC): filtered base
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const uint32_t t = cntw[k] ^ m;
-            const uint32_t bad = (t | (t >> 1) | (t >> 2)) & m;
-            S[k] = (S[k] & ~(bad * 15u)) | (bad * 5u);
-        }
+        const uint32_t first = lookup4((w8[k] >> 4) & 0x0F0F0F0Fu), second = lookup4(w8[k] & 0x0F0F0F0Fu);
+        S[k] = first | (second << 4);
     }
     if (QV) {
         // qualities of the piece's bases, one byte each, from the aligned dwords around them; a base below min_qv
@@ -413,12 +413,16 @@ __global__ __launch_bounds__(256) void ingest_planes_kernel(ingest_args a)
     __shared__ uint32_t s_wsum[4], s_nlist;
     uint32_t *s_tile = s_tile_g + 8;
     const uint32_t tid = threadIdx.x, wid = tid >> 6, lane = tid & 63u;
-    // block -> (read tile, sweep): the tiles that share the 128-byte lines of a sweep are blocks b, b + 8, b + 16, ... — dealt
-    // to the same XCD one after the other — so their pieces of a line meet in one L2
-    const uint32_t b = blockIdx.x, xcd = b & 7u, jb = b >> 3, sub = jb % kSubTiles, g = jb / kSubTiles;
-    const uint32_t pair = g * 8u + xcd;
-    if (pair >= a.n_pairs) return;
-    const uint32_t tile = kSubTiles * (pair % a.n_groups) + sub, sweep = pair / a.n_groups;
+    // block -> (read tile, sweep).  Blocks b, b + 8, b + 16, ... are dealt to the same XCD one after the other; an XCD takes
+    // whole groups of 1024 reads (group = xcd, xcd + 8, ...), and of a group all sweeps in turn, the tiles of the group
+    // innermost.  So (a) the tiles that share the 128-byte lines of a sweep's planes meet in one L2, and (b) everything the
+    // sweeps of a group read again — the reads' offsets, run entries and per-sweep run indices, and the 128-byte lines of
+    // packed bases that straddle two sweeps (a sweep is 112 bytes of a read: 2.1 x the bases were fetched) — is in that L2
+    // when the next sweep asks for it: the prologue's scattered loads become L2 hits.
+    const uint32_t b = blockIdx.x, xcd = b & 7u, jb = b >> 3, sub = jb % kSubTiles, q = jb / kSubTiles;
+    const uint32_t group = xcd + 8u * (q / a.n_sweeps), sweep = q % a.n_sweeps;
+    if (group >= a.n_groups) return;
+    const uint32_t tile = kSubTiles * group + sub;
     const int X = (int)(sweep * kSweep), Xend = (int)min(a.n_cols, sweep * kSweep + kSweep);
     const uint64_t r = (uint64_t)tile * kTileReads + tid;
     const bool real = tid < kTileReads && r < a.n_reads;
@@ -558,7 +562,12 @@ __global__ __launch_bounds__(256) void ingest_planes_kernel(ingest_args a)
             const int lo_v = Q < 0 ? -Q : 0;
             uint32_t S[8];
             const uint64_t qb = QV ? (((uint64_t)s_qhi[j] << 32) | s_qlo[j]) : 0u;
-            piece_syms<QV>(a, v0, v1, Q, lo_v, qb, S);
+            if (JL_ING_SKIP(a, 6)) { S[0] = v0.x; S[1] = v0.y; S[2] = v0.z; S[3] = v0.w; S[4] = v1.x; S[5] = v1.y; S[6] = v1.z; S[7] = v1.w; }
+            else piece_syms<QV>(a, v0, v1, Q, lo_v, qb, S);
+            if (JL_ING_SKIP(a, 5)) {   // (probe: the codes are used, nothing is placed)
+                atomicXor(&s_tile[(j & 31u) * kRowI], S[0] ^ S[1] ^ S[2] ^ S[3] ^ S[4] ^ S[5] ^ S[6] ^ S[7]);
+                return;
+            }
             // the last entry whose query offset is at or before the piece's first base: eight entries' offsets at once
             const uint2 *ent = s_ent + e_off;
             const int Qs = Q + lo_v;
@@ -739,7 +748,7 @@ void jl_launch_ingest(jl_ctx *ctx, const int32_t *d_pos, const uint32_t *d_cigar
 #ifdef JL_TUNING
     if (const char *e = getenv("JL_ING_SKIP")) a.skip = (uint32_t)atoi(e);
 #endif
-    const uint32_t grid = (a.n_pairs + 7u) / 8u * 8u * kSubTiles;
+    const uint32_t grid = (a.n_groups + 7u) / 8u * ns * 8u * kSubTiles;   // (groups per XCD, rounded up) x sweeps x 8 XCDs x tiles of a group
     if (qv) hipLaunchKernelGGL(ingest_planes_kernel<true>, dim3(grid), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(ingest_planes_kernel<false>, dim3(grid), dim3(256), 0, st, a);
     const uint64_t cap = (uint64_t)ctx->n_reads * ns;

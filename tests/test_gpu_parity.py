@@ -944,6 +944,17 @@ def test_device_ingest_matches_rows(jl, n, l, partial, win):
     with pytest.raises(capi.JulietError) as err:
         jl.ingest_records(e - b, b, pos, bad, cig_off, seq4, seq_off)
     assert "cigar M" in str(err.value)
+    # every 4-bit base that is not exactly A, C, G or T — '=', the IUPAC ambiguity codes, N — is a filtered base: the N's of the
+    # records replaced by all twelve of them in turn give the same matrix
+    other = np.array([0, 3, 5, 6, 7, 9, 10, 11, 12, 13, 14, 15], dtype=np.uint8)
+    amb = seq4.copy()
+    hi, lo = amb >> 4, amb & 15
+    hi = np.where(hi == 15, other[rng.integers(0, len(other), len(amb))], hi)
+    lo = np.where(lo == 15, other[rng.integers(0, len(other), len(amb))], lo)
+    amb = ((hi << 4) | lo).astype(np.uint8)
+    assert (amb != seq4).any()
+    jl.ingest_records(e - b, b, pos, cigar, cig_off, amb, seq_off)
+    assert (msa.unpack_columns(jl.download_columns(), n) == rows[:, b:e]).all()
 
 
 @pytest.mark.parametrize("chunk,hints", [(1, (0, 0, 0, 0)), (37, (0, 0, 0, 0)), (256, (5000, 100000, 1 << 20, 1 << 21)), (10000, (0, 0, 0, 0))])
