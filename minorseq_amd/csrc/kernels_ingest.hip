@@ -317,7 +317,8 @@ __device__ __forceinline__ void piece_syms(const ingest_args &a, const uint4 &v0
     auto lookup4 = [&](uint32_t x) -> uint32_t {   // four bases, one per byte (0..15) -> four codes
         const uint32_t sel = x & 0x07070707u;
         const uint32_t lo = __builtin_amdgcn_perm(kLo47, kLo03, sel), hi = __builtin_amdgcn_perm(kHi47, kHi03, sel);
-        const uint32_t pick = ((x & 0x08080808u) >> 3) * 0xFFu;   // bytes of ones where bit 3 is set
+        // bytes of ones where bit 3 is set: 8 << 5 minus 8 >> 3 within each byte (a 32-bit multiply is a quarter-rate instruction)
+        const uint32_t b3 = x & 0x08080808u, pick = (b3 << 5) - (b3 >> 3);
         return (hi & pick) | (lo & ~pick);
     };
 #pragma unroll
@@ -432,8 +433,9 @@ __global__ __launch_bounds__(256) void ingest_planes_kernel(ingest_args a)
     uint64_t co = 0, so = 0;
     int32_t p = 0;
     if (real) {
-        f0 = a.first_run[r * (uint64_t)(a.n_sweeps + 1u) + sweep];
-        f1 = a.first_run[r * (uint64_t)(a.n_sweeps + 1u) + sweep + 1u];
+        const uint32_t *fr = a.first_run + r * (uint64_t)(a.n_sweeps + 1u) + sweep;
+        f0 = fr[0];
+        f1 = fr[1];
         nr = a.nruns[r];
         co = a.cig_off[r];
         so = a.seq_off[r];
@@ -635,13 +637,15 @@ __global__ __launch_bounds__(256) void ingest_planes_kernel(ingest_args a)
             nibble_rows_to_plane_words(R, out);
             const uint64_t byte = (uint64_t)tile * (kTileReads / 8u) + (uint64_t)G * 4u;
             if (byte < a.plane_stride && (!JL_ING_SKIP(a, 2) || out[0][0] == 0x12345u)) {
+                // (one 64-bit multiply for the first plane row, then a stride at a time: twenty-four of them were a tenth of the phase)
+                uint8_t *row = a.msa + (uint64_t)(((uint32_t)X + 8u * dwi) * 3u) * a.plane_stride + byte;
 #pragma unroll
                 for (uint32_t j = 0; j < 8u; ++j) {
                     const uint32_t c = (uint32_t)X + 8u * dwi + j;
-                    if ((int)c < Xend) {
 #pragma unroll
-                        for (uint32_t k = 0; k < 3u; ++k)
-                            *reinterpret_cast<uint32_t *>(a.msa + ((uint64_t)c * 3u + k) * a.plane_stride + byte) = out[j][k];
+                    for (uint32_t k = 0; k < 3u; ++k) {
+                        if ((int)c < Xend) *reinterpret_cast<uint32_t *>(row) = out[j][k];
+                        row += a.plane_stride;
                     }
                 }
             }
