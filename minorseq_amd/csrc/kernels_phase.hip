@@ -674,6 +674,15 @@ __device__ __forceinline__ bool phase_select_lds(const jl_win_phase &w, const pl
     const uint32_t lane = tid & 63u;
     uint32_t sl_keep[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};   // the first 1024 groups' slots: emptied from registers below
     // the two-word launch's half-key lists, for the same purpose: counts and each thread's first entries, requested now
+    // ... and what the selection needs further down and does not depend on the groups: this thread's variant row and the
+    // run counter (the parity of the result block) — requested here, beside the groups, instead of one round trip each later
+    uint32_t row_c = 0, row_cw = 0;
+    if (tid < nv) {
+        const uint32_t *row = reinterpret_cast<const uint32_t *>(S.variants + tid);
+        row_c = ld_coherent(row + 2);
+        row_cw = ld_coherent(row + 3);
+    }
+    const uint32_t seq_pre = __hip_atomic_load(S.seq_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     uint32_t tw_n[2] = {0, 0}, tw_first[2] = {0, 0};
     if (KW == 2) {
         tw_n[0] = ld_coherent(&tw->n_occ[0]);
@@ -729,7 +738,7 @@ __device__ __forceinline__ bool phase_select_lds(const jl_win_phase &w, const pl
     // the variant rows: column -> position index, codon (the table may come from another workgroup of this launch)
     for (uint32_t v = tid; v < nv; v += nt) {
         const uint32_t *row = reinterpret_cast<const uint32_t *>(S.variants + v);
-        const uint32_t c = ld_coherent(row + 2), cw = ld_coherent(row + 3);
+        const uint32_t c = v == tid ? row_c : ld_coherent(row + 2), cw = v == tid ? row_cw : ld_coherent(row + 3);
         uint32_t pos = 0xFFu;
         if (c + 2u < S.n_cols)
             for (uint32_t p = 0; p < vp; ++p) pos = L.cols[p] == c ? p : pos;
@@ -871,7 +880,7 @@ __device__ __forceinline__ bool phase_select_lds(const jl_win_phase &w, const pl
             for (uint32_t h = tid & 63u; h < H; h += 64u) S.hit[(uint64_t)v * JL_MAX_HAPLOTYPES + h] = T.hit[v * H + h];
     }
     JL_STAMP(26);
-    jl_pack *pk = S.pk + (__hip_atomic_load(S.seq_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 1u);
+    jl_pack *pk = S.pk + (seq_pre & 1u);
     jl_pack *dsts[2] = {pk, S.mirror};
     // Co-occurrence C[v][x] = sum over the haplotypes that carry both of their read counts.  The counts are cut into bit
     // planes (plane b = the haplotypes whose count has bit b set, as a 128-bit set): C = sum_b 2^b popcount(set_v & set_x &
