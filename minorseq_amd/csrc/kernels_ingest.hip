@@ -111,7 +111,8 @@ __global__ __launch_bounds__(256) void cigar_runs_kernel(uint64_t n_reads, const
     uint64_t cb[kRunsReadsPerWave + 1u];
 #pragma unroll
     for (uint32_t q = 0; q <= kRunsReadsPerWave; ++q)
-        cb[q] = ((uint64_t)(uint32_t)__shfl((int)(co_l >> 32), (int)q, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)co_l, (int)q, 64);
+        cb[q] = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(co_l >> 32), (int)q) << 32) |
+                (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)co_l, (int)q);   // (a lane known at compile time: no trip through the LDS crossbar)
     uint32_t cw0[kRunsReadsPerWave][2];
 #pragma unroll
     for (uint32_t q = 0; q < kRunsReadsPerWave; ++q) {
@@ -128,7 +129,7 @@ __global__ __launch_bounds__(256) void cigar_runs_kernel(uint64_t n_reads, const
         for (uint32_t s = lane; s < n_sweeps + 2u; s += 64u) hist[s] = 0;
         const uint64_t c_beg = cb[q], c_end = cb[q + 1u];
         uint2 *out = runs + c_beg + r;
-        const int64_t base = (int64_t)__shfl(pos_l, (int)q, 64) - (int64_t)win_begin;
+        const int64_t base = (int64_t)__builtin_amdgcn_readlane(pos_l, (int)q) - (int64_t)win_begin;
         // first sweep whose first column is at or behind the run's start (32-bit arithmetic: the offset is clamped to the
         // window first — a 64-bit division by the sweep width was a quarter of this kernel's instructions)
         const int64_t lim = (int64_t)n_sweeps * kSweep;
@@ -140,21 +141,29 @@ __global__ __launch_bounds__(256) void cigar_runs_kernel(uint64_t n_reads, const
         };
         uint32_t n_runs = 0, prev_kind = 0, ref_carry = 0, q_carry = 0;
         bool has_m = false;
-        for (uint64_t k0 = c_beg; k0 < c_end; k0 += 128u) {
+        // (op indices relative to the read's first, in 32 bits: a record's cigar has fewer than 2^32 ops)
+        const uint32_t n_ops = (uint32_t)min(c_end - c_beg, (uint64_t)0xFFFFFF00u);
+        const uint32_t *cig = cigar + c_beg;
+        for (uint32_t k0 = 0; k0 < n_ops; k0 += 128u) {
             uint32_t cw[2] = {cw0[q][0], cw0[q][1]};
-            if (k0 != c_beg) {
-                const uint64_t k = k0 + 2u * lane;
-                cw[0] = k < c_end ? cigar[k] : 0u;
-                cw[1] = k + 1u < c_end ? cigar[k + 1u] : 0u;
+            if (k0 != 0u) {
+                const uint32_t k = k0 + 2u * lane;
+                cw[0] = k < n_ops ? cig[k] : 0u;
+                cw[1] = k + 1u < n_ops ? cig[k + 1u] : 0u;
             }
             uint32_t kind[2], rl[2], ql[2];
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
+                // what an op does, from three constants indexed by its code (a chain of comparisons per property was a fifth of
+                // this kernel): D N = X consume the reference, I S = X the query; kind 1 for = X, 2 for D, 3 for N
                 const uint32_t op = cw[t] & 15u, len = cw[t] >> 4;   // (a missing op is the word 0: length 0, which is nothing)
-                rl[t] = cig_ref(op) ? len : 0u;
-                ql[t] = cig_query(op) ? len : 0u;
-                kind[t] = len == 0u ? 0u : (op == 7u || op == 8u) ? 1u : op == 2u ? 2u : op == 3u ? 3u : 0u;
-                has_m = has_m || (op == 0u && (k0 + 2u * lane + (uint32_t)t) < c_end);
+                constexpr uint32_t kRefOps = (1u << 2) | (1u << 3) | (1u << 7) | (1u << 8);
+                constexpr uint32_t kQueryOps = (1u << 1) | (1u << 4) | (1u << 7) | (1u << 8);
+                constexpr uint32_t kKinds = (2u << 4) | (3u << 6) | (1u << 14) | (1u << 16);   // two bits per op
+                rl[t] = ((kRefOps >> op) & 1u) ? len : 0u;
+                ql[t] = ((kQueryOps >> op) & 1u) ? len : 0u;
+                kind[t] = len == 0u ? 0u : (kKinds >> (2u * op)) & 3u;
+                has_m = has_m || (op == 0u && (k0 + 2u * lane + (uint32_t)t) < n_ops);
             }
             const uint32_t ri = wave_scan(rl[0] + rl[1]), qi = wave_scan(ql[0] + ql[1]);   // inclusive, per lane pair
             // the kind of the op before this lane's first one: the previous lane's second op
@@ -178,9 +187,9 @@ __global__ __launch_bounds__(256) void cigar_runs_kernel(uint64_t n_reads, const
                 if (idx >= 1u) atomicAdd(&hist[sweep_of(rb)], 1u);
             }
             n_runs += (uint32_t)__popcll(b0) + (uint32_t)__popcll(b1);
-            prev_kind = __shfl(kind[1], 63, 64);   // (only a full step has a successor)
-            ref_carry += __shfl(ri, 63, 64);
-            q_carry += __shfl(qi, 63, 64);
+            prev_kind = (uint32_t)__builtin_amdgcn_readlane((int)kind[1], 63);   // (only a full step has a successor)
+            ref_carry += (uint32_t)__builtin_amdgcn_readlane((int)ri, 63);
+            q_carry += (uint32_t)__builtin_amdgcn_readlane((int)qi, 63);
         }
         uint32_t code = __ballot(has_m) != 0ull ? 1u : 0u;
         if (!code) {
@@ -203,7 +212,7 @@ __global__ __launch_bounds__(256) void cigar_runs_kernel(uint64_t n_reads, const
             const uint32_t s = s0 + lane;
             const uint32_t v = wave_scan((s <= n_sweeps && !code) ? hist[s] : 0u);
             if (s <= n_sweeps) first_run[r * (uint64_t)(n_sweeps + 1u) + s] = carry + v;
-            carry += __shfl(v, 63, 64);
+            carry += (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
         }
         __builtin_amdgcn_wave_barrier();
     }
