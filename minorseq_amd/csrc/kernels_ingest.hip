@@ -54,21 +54,6 @@ static_assert(kSweep % 8u == 0 && kSweep + 31u <= 64u * kPiecesPerRead, "a sweep
 static_assert((JL_INGEST_TILE * kPiecesPerRead) % 256u == 0 && JL_INGEST_TILE % 32 == 0, "whole rounds of the four waves; whole plane dwords");
 static_assert(256u / kTileGroups >= kSweepDw, "a thread per 32 reads x 8 columns in the transposing phase");
 
-__device__ __forceinline__ bool cig_ref(uint32_t op) { return op == 2u || op == 3u || op == 7u || op == 8u; }    // D N = X
-__device__ __forceinline__ bool cig_query(uint32_t op) { return op == 1u || op == 4u || op == 7u || op == 8u; }  // I S = X
-
-// eight BAM base codes (nt16: A=1 C=2 G=4 T=8, everything else ambiguous) -> symbol codes 0..3 / 5, nibble-parallel
-__device__ __forceinline__ uint32_t nt16_to_sym8(uint32_t w)
-{
-    const uint32_t m = 0x11111111u;
-    const uint32_t b0 = w & m, b1 = (w >> 1) & m, b2 = (w >> 2) & m, b3 = (w >> 3) & m;
-    const uint32_t cnt = b0 + b1 + b2 + b3;          // set bits per nibble, 0..4
-    const uint32_t idx = b1 + 2u * b2 + 3u * b3;     // one-hot -> 0..3
-    const uint32_t t = cnt ^ m;                      // non-zero where the nibble is not one-hot
-    const uint32_t bad = (t | (t >> 1) | (t >> 2)) & m;
-    return (idx & ~(bad * 15u)) | (bad * 5u);
-}
-
 // ---------------------------------------------------------------------------------------- runs
 // inclusive prefix sum over the 64 lanes by DPP (four shifts within rows of 16, two row broadcasts)
 __device__ __forceinline__ uint32_t wave_scan(uint32_t v)
@@ -80,6 +65,25 @@ __device__ __forceinline__ uint32_t wave_scan(uint32_t v)
     v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);  // row_bcast:15 -> rows 1, 3
     v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);  // row_bcast:31 -> rows 2, 3
     return v;
+}
+// two independent sums scanned in step (a DPP read of a register needs two wait states behind the write: each chain fills
+// the other's)
+__device__ __forceinline__ void wave_scan2(uint32_t &a, uint32_t &b)
+{
+#define JL_SCAN_STEP(ctrl, rows, bc)                                                            \
+    {                                                                                           \
+        const uint32_t ta = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a, ctrl, rows, 0xF, bc); \
+        const uint32_t tb = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)b, ctrl, rows, 0xF, bc); \
+        a += ta;                                                                                \
+        b += tb;                                                                                \
+    }
+    JL_SCAN_STEP(0x111, 0xF, true)
+    JL_SCAN_STEP(0x112, 0xF, true)
+    JL_SCAN_STEP(0x114, 0xF, true)
+    JL_SCAN_STEP(0x118, 0xF, true)
+    JL_SCAN_STEP(0x142, 0xA, false)
+    JL_SCAN_STEP(0x143, 0xC, false)
+#undef JL_SCAN_STEP
 }
 
 // runs[cig_off[r] + r + i] = {reference offset of run i relative to the read's first base | kind << 30, query offset};
@@ -121,7 +125,6 @@ __global__ __launch_bounds__(256) void cigar_runs_kernel(uint64_t n_reads, const
         cw0[q][0] = (live && k < cb[q + 1u]) ? cigar[k] : 0u;
         cw0[q][1] = (live && k + 1u < cb[q + 1u]) ? cigar[k + 1u] : 0u;
     }
-    const uint64_t lt = (1ull << lane) - 1ull;
 #pragma unroll
     for (uint32_t q = 0; q < kRunsReadsPerWave; ++q) {
         const uint64_t r = r0 + q;
@@ -165,14 +168,17 @@ __global__ __launch_bounds__(256) void cigar_runs_kernel(uint64_t n_reads, const
                 kind[t] = len == 0u ? 0u : (kKinds >> (2u * op)) & 3u;
                 has_m = has_m || (op == 0u && (k0 + 2u * lane + (uint32_t)t) < n_ops);
             }
-            const uint32_t ri = wave_scan(rl[0] + rl[1]), qi = wave_scan(ql[0] + ql[1]);   // inclusive, per lane pair
+            uint32_t ri = rl[0] + rl[1], qi = ql[0] + ql[1];
+            wave_scan2(ri, qi);   // inclusive, per lane pair
             // the kind of the op before this lane's first one: the previous lane's second op
             uint32_t before = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)kind[1], 0x138, 0xF, 0xF, false);   // wave_shr:1
             if (lane == 0) before = prev_kind;
             const bool st0 = kind[0] != 0u && !(kind[0] == 1u && before == 1u);
             const bool st1 = kind[1] != 0u && !(kind[1] == 1u && kind[0] == 1u);
             const uint64_t b0 = __ballot(st0), b1 = __ballot(st1);
-            const uint32_t ahead = (uint32_t)__popcll(b0 & lt) + (uint32_t)__popcll(b1 & lt);   // run starts in the lanes before
+            // run starts in the lanes before this one (v_mbcnt: the set bits of a mask below the lane, with an addend)
+            const uint32_t ahead = __builtin_amdgcn_mbcnt_hi((uint32_t)(b1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b1,
+                                   __builtin_amdgcn_mbcnt_hi((uint32_t)(b0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b0, 0u))));
             const uint32_t rbeg0 = ref_carry + ri - rl[0] - rl[1], qbeg0 = q_carry + qi - ql[0] - ql[1];
             if (st0) {
                 const uint32_t idx = n_runs + ahead;
@@ -461,12 +467,7 @@ __global__ __launch_bounds__(256) void ingest_planes_kernel(ingest_args a)
     if (real && nr && f0 < nr) cnt = min(f1, nr - 1u) - f0 + 1u;
     uint32_t need = cnt ? cnt + 1u : 0u;   // + the entry behind the last run: its end
     // exclusive scan of `need` over the workgroup
-    uint32_t inc = need;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t u = __shfl_up(inc, o, 64);
-        if ((int)lane >= o) inc += u;
-    }
+    const uint32_t inc = wave_scan(need);
     if (lane == 63u) s_wsum[wid] = inc;
     __syncthreads();
     uint32_t off = inc - need;
