@@ -580,17 +580,18 @@ __global__ __launch_bounds__(256) void ingest_planes_kernel(ingest_args a)
                 atomicXor(&s_tile[(j & 31u) * kRowI], S[0] ^ S[1] ^ S[2] ^ S[3] ^ S[4] ^ S[5] ^ S[6] ^ S[7]);
                 return;
             }
-            // the last entry whose query offset is at or before the piece's first base: eight entries' offsets at once
+            // the last entry whose query offset is at or before the piece's first base: three entries' offsets at once (a read
+            // has one or two runs in a sweep, rarely more), the rest one by one
             const uint2 *ent = s_ent + e_off;
             const int Qs = Q + lo_v;
-            uint32_t qy[8];
+            uint32_t qy[4];
 #pragma unroll
-            for (uint32_t t = 1; t < 8u; ++t) qy[t] = ent[min(t, cn - 1u)].y;
+            for (uint32_t t = 1; t < 4u; ++t) qy[t] = ent[min(t, cn - 1u)].y;
             uint32_t i = 0;
 #pragma unroll
-            for (uint32_t t = 1; t < 8u; ++t) i += (t < cn && (int)qy[t] <= Qs) ? 1u : 0u;
-            if (i == 7u)
-                for (uint32_t t = 8; t < cn && (int)ent[t].y <= Qs; ++t) i = t;
+            for (uint32_t t = 1; t < 4u; ++t) i += (t < cn && (int)qy[t] <= Qs) ? 1u : 0u;
+            if (i == 3u)
+                for (uint32_t t = 4; t < cn && (int)ent[t].y <= Qs; ++t) i = t;
             const uint2 e = ent[i], nx = ent[i + 1u];
             uint32_t *row = s_tile + (j & 31u) * kRowI + (j >> 5) * kSweepDw;
             const int rb = (int)(e.x & kRunMask);
