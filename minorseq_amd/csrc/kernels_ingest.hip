@@ -260,7 +260,7 @@ __device__ __forceinline__ void transpose_nibbles_8x8(uint32_t (&m)[8])
 
 // 32 reads x 8 columns, R[i] = the 8 codes (nibbles) of read i -> out[j][k] = plane k of column j, bit i = read i.
 // Four 8 x 8 nibble transposes — block g holds reads g, g + 4, ..., g + 28, so that after it nibble n of M[g][j] is read
-// 4 n + g at column j — then bit k of the four blocks' nibbles interleaves into the 32 read bits with four and-or steps.
+// 4 n + g at column j — then the bits of the four blocks' nibbles change places (below).
 __device__ __forceinline__ void nibble_rows_to_plane_words(const uint32_t (&R)[32], uint32_t (&out)[8][3])
 {
     uint32_t M[4][8];
@@ -270,12 +270,20 @@ __device__ __forceinline__ void nibble_rows_to_plane_words(const uint32_t (&R)[3
         for (int i = 0; i < 8; ++i) M[g][i] = R[4 * i + g];
         transpose_nibbles_8x8(M[g]);
     }
-    constexpr uint32_t m = 0x11111111u;
+    // Plane k of column j wants, in nibble n, bit k of the four blocks' nibbles n (reads 4 n .. 4 n + 3): a 4 x 4 bit transpose
+    // between the four words, in every nibble at once — two rounds of masked swaps, 24 operations a column where pulling
+    // each bit out and shifting it into place took 33.
 #pragma unroll
-    for (int j = 0; j < 8; ++j)
-#pragma unroll
-        for (uint32_t k = 0; k < 3u; ++k)
-            out[j][k] = ((M[0][j] >> k) & m) | (((M[1][j] >> k) & m) << 1) | (((M[2][j] >> k) & m) << 2) | (((M[3][j] >> k) & m) << 3);
+    for (int j = 0; j < 8; ++j) {
+        uint32_t a0 = M[0][j], a1 = M[1][j], a2 = M[2][j], a3 = M[3][j], t;
+        t = ((a0 >> 1) ^ a1) & 0x55555555u; a1 ^= t; a0 ^= t << 1;
+        t = ((a2 >> 1) ^ a3) & 0x55555555u; a3 ^= t; a2 ^= t << 1;
+        t = ((a0 >> 2) ^ a2) & 0x33333333u; a2 ^= t; a0 ^= t << 2;
+        t = ((a1 >> 2) ^ a3) & 0x33333333u; a3 ^= t; a1 ^= t << 2;
+        out[j][0] = a0;
+        out[j][1] = a1;
+        out[j][2] = a2;   // (a3 would be bit 3 of the codes: always zero)
+    }
 }
 
 struct ingest_args {
