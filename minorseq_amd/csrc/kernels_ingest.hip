@@ -405,9 +405,13 @@ __device__ __forceinline__ void emit_run(const uint32_t (&S)[8], int Q, int lo_v
         P[2 * k + 1] = (S[2 * k] ^ 0x66666666u) & (uint32_t)mk;
         P[2 * k + 2] = (S[2 * k + 1] ^ 0x66666666u) & (uint32_t)(mk >> 32);
     }
-    uint32_t *dst = s_row + dd;
+    // Dword j of the row's part takes {P[j + 1], P[j]} >> (32 - s4).  v_alignbit_b32 does that in one instruction for shifts
+    // below 32; with s4 = 0 it returns P[j] — the value that belongs one dword further down — so the destination moves
+    // instead (P[0] = 0 lands in the guard).  (As 64-bit shifts these were two instructions and two moves each.)
+    uint32_t *dst = s_row + dd - (s4 == 0u ? 1 : 0);
+    const uint32_t sh = (32u - s4) & 31u;
 #pragma unroll
-    for (int j = 0; j < 9; ++j) atomicXor(&dst[j], (uint32_t)((((uint64_t)P[j + 1] << 32) | P[j]) >> (32u - s4)));
+    for (int j = 0; j < 9; ++j) atomicXor(&dst[j], __builtin_amdgcn_alignbit(P[j + 1], P[j], sh));
 }
 
 // every run from entry i on that the piece reaches (the general form: pieces that cross a run boundary, or begin in a gap)
