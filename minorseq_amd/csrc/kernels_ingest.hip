@@ -38,14 +38,20 @@ constexpr uint32_t kSweepDw = kSweep / 8u;          // dwords of 8 columns in a 
 #ifndef JL_INGEST_TILE
 #define JL_INGEST_TILE 128
 #endif
-constexpr uint32_t kTileReads = JL_INGEST_TILE;     // reads per workgroup: 128 (26 KB of LDS: six workgroups per CU) or 256
+constexpr uint32_t kTileReads = JL_INGEST_TILE;     // reads per workgroup: 128 (22.7 KB of LDS: seven workgroups per CU) or 256
 constexpr uint32_t kTileGroups = kTileReads / 32u;  // groups of 32 reads = dwords of a plane the tile writes per column
 constexpr uint32_t kSubTiles = 1024u / kTileReads;  // tiles that share the 128-byte lines of the planes
 // tile row of read r at (r & 31) * kRowI + (r >> 5) * kSweepDw: the eight reads a wave expands together lie an odd number of
 // banks apart, the 32-read groups of the transposing step four banks apart
 constexpr uint32_t kRowI = kTileGroups * kSweepDw + 1u;
 constexpr uint32_t kTileDw = 32u * kRowI;
-constexpr uint32_t kEntCap = 7u * kTileReads;       // run entries of the workgroup's reads in its sweep (LDS)
+#ifndef JL_INGEST_ENT_PER_READ
+#define JL_INGEST_ENT_PER_READ 4
+#endif
+// run entries of the workgroup's reads in its sweep (LDS).  Four per read on average (CCS reads need 2.6: a run, half a deletion,
+// the end entry) keep the workgroup below 22.8 KB of LDS: seven workgroups per CU instead of six (136 against 141 us); a tile
+// that needs more leaves its last reads to the slow kernel
+constexpr uint32_t kEntCap = JL_INGEST_ENT_PER_READ * kTileReads;
 constexpr uint32_t kRunMask = 0x3FFFFFFFu;          // reference offset of a run; kind in the two bits above
 constexpr uint32_t kMaxPieces = 1023u;              // pieces of a read in a sweep (10 bits; the deferral list holds 12)
 // 32-byte pieces (64 bases) of a read that a sweep takes from a 16-byte boundary on, insertions aside: a power of two of lanes
