@@ -57,8 +57,14 @@ constexpr uint32_t kMaxPieces = 1023u;              // pieces of a read in a swe
 // 32-byte pieces (64 bases) of a read that a sweep takes from a 16-byte boundary on, insertions aside: a power of two of lanes
 constexpr uint32_t kPiecesPerRead = (kSweep + 31u + 63u) / 64u <= 4u ? 4u : 8u;
 static_assert(kSweep % 8u == 0 && kSweep + 31u <= 64u * kPiecesPerRead, "a sweep is at most eight pieces of a read wide");
-static_assert((JL_INGEST_TILE * kPiecesPerRead) % 256u == 0 && JL_INGEST_TILE % 32 == 0, "whole rounds of the four waves; whole plane dwords");
-static_assert(256u / kTileGroups >= kSweepDw, "a thread per 32 reads x 8 columns in the transposing phase");
+// threads of a planes workgroup: two per read of the tile (a thread per read in the prologue, the waves share the expansion)
+#ifndef JL_INGEST_THREADS
+#define JL_INGEST_THREADS 256
+#endif
+constexpr uint32_t kThreads = JL_INGEST_THREADS, kWaves = kThreads / 64u;
+static_assert(kThreads % 64u == 0 && kThreads >= kTileReads && kThreads <= 256u, "whole waves, a thread per read at least");
+static_assert((JL_INGEST_TILE * kPiecesPerRead) % kThreads == 0 && JL_INGEST_TILE % 32 == 0, "whole rounds of the waves; whole plane dwords");
+static_assert(kThreads / kTileGroups >= kSweepDw, "a thread per 32 reads x 8 columns in the transposing phase");
 
 // ---------------------------------------------------------------------------------------- runs
 // inclusive prefix sum over the 64 lanes by DPP (four shifts within rows of 16, two row broadcasts)
@@ -437,7 +443,7 @@ __device__ __forceinline__ void emit_rest(const uint32_t (&S)[8], int Q, int lo_
 constexpr uint32_t kListCap = 2u * kTileReads;     // pieces a workgroup defers to its second pass
 
 template <bool QV>
-__global__ __launch_bounds__(256) void ingest_planes_kernel(ingest_args a)
+__global__ __launch_bounds__(kThreads) void ingest_planes_kernel(ingest_args a)
 {
     __shared__ uint32_t s_tile_g[kTileDw + 24u];   // guard dwords: 8 in front, 16 behind (see emit_run)
     __shared__ uint2 s_ent[kEntCap];
@@ -479,7 +485,7 @@ __global__ __launch_bounds__(256) void ingest_planes_kernel(ingest_args a)
             s_qhi[tid] = (uint32_t)(qo >> 32);
         }
     }
-    for (uint32_t i = tid; i < kTileDw + 24u; i += 256u) s_tile_g[i] = 0x66666666u;
+    for (uint32_t i = tid; i < kTileDw + 24u; i += kThreads) s_tile_g[i] = 0x66666666u;
     if (tid == 0) s_nlist = 0;
     uint32_t cnt = 0;
     if (real && nr && f0 < nr) cnt = min(f1, nr - 1u) - f0 + 1u;
@@ -568,7 +574,7 @@ __global__ __launch_bounds__(256) void ingest_planes_kernel(ingest_args a)
     // — in line, the loop over a piece's runs made every wave walk two or three runs for them.
     if (!JL_ING_SKIP(a, 0)) {
         constexpr uint32_t kReadsPerRound = 64u / kPiecesPerRead;              // reads a wave expands at a time
-        constexpr uint32_t kRounds = kTileReads / (4u * kReadsPerRound);       // rounds of a wave
+        constexpr uint32_t kRounds = kTileReads / (kWaves * kReadsPerRound);   // rounds of a wave
         const uint32_t slot = lane / kPiecesPerRead, piece = lane % kPiecesPerRead;
         auto fetch = [&](uint32_t j, uint32_t pc, uint4 &v0, uint4 &v1) {
             const read_info &q = s_info[j];
@@ -622,10 +628,10 @@ __global__ __launch_bounds__(256) void ingest_planes_kernel(ingest_args a)
         };
         uint4 va[kRounds], vb[kRounds];
 #pragma unroll
-        for (uint32_t it = 0; it < kRounds; ++it) fetch((wid + 4u * it) * kReadsPerRound + slot, piece, va[it], vb[it]);
+        for (uint32_t it = 0; it < kRounds; ++it) fetch((wid + kWaves * it) * kReadsPerRound + slot, piece, va[it], vb[it]);
 #pragma unroll
         for (uint32_t it = 0; it < kRounds; ++it) {
-            const uint32_t j = (wid + 4u * it) * kReadsPerRound + slot;
+            const uint32_t j = (wid + kWaves * it) * kReadsPerRound + slot;
             expand(j, piece, va[it], vb[it]);
             // a read with more pieces in the sweep (insertions)
             const uint32_t npj = s_info[j].ent >> 22;
@@ -639,7 +645,7 @@ __global__ __launch_bounds__(256) void ingest_planes_kernel(ingest_args a)
     __syncthreads();
     if (!JL_ING_SKIP(a, 3)) {   // the listed pieces, a lane each
         const uint32_t nl = min(s_nlist, kListCap);
-        for (uint32_t k = tid; k < nl; k += 256u) {
+        for (uint32_t k = tid; k < nl; k += kThreads) {
             const uint32_t it = s_list[k], j = it >> 24, pc = (it >> 12) & 0xFFFu;
             const read_info q = s_info[j];
             const uint64_t at = (((uint64_t)q.p0_hi << 32) | q.p0_lo) + 32u * pc;
@@ -782,8 +788,8 @@ void jl_launch_ingest(jl_ctx *ctx, const int32_t *d_pos, const uint32_t *d_cigar
     if (const char *e = getenv("JL_ING_SKIP")) a.skip = (uint32_t)atoi(e);
 #endif
     const uint32_t grid = (a.n_groups + 7u) / 8u * ns * 8u * kSubTiles;   // (groups per XCD, rounded up) x sweeps x 8 XCDs x tiles of a group
-    if (qv) hipLaunchKernelGGL(ingest_planes_kernel<true>, dim3(grid), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(ingest_planes_kernel<false>, dim3(grid), dim3(256), 0, st, a);
+    if (qv) hipLaunchKernelGGL(ingest_planes_kernel<true>, dim3(grid), dim3(kThreads), 0, st, a);
+    else hipLaunchKernelGGL(ingest_planes_kernel<false>, dim3(grid), dim3(kThreads), 0, st, a);
     const uint64_t cap = (uint64_t)ctx->n_reads * ns;
     hipLaunchKernelGGL(ingest_slow_kernel, dim3(256), dim3(256), 0, st, a, d_pos, (uint32_t)std::min<uint64_t>(cap, 0xFFFFFFFFu));
 }
