@@ -1,11 +1,11 @@
 # what the record ingest's kernels keep busy: derived metrics + raw unit counters, one rocprofv3 --pmc pass per group
+# (no GRBM_* counters: a pass with GRBM_GUI_ACTIVE / GRBM_TA_BUSY / ... never came back on this pool)
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/ingpmc3
 rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 i=0
 for set in "VALUBusy VALUUtilization MemUnitStalled OccupancyPercent" "MeanOccupancyPerActiveCU LDSBankConflict" \
-           "GRBM_GUI_ACTIVE GRBM_TA_BUSY GRBM_TC_BUSY GRBM_EA_BUSY GRBM_SPI_BUSY" \
            "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY" \
            "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_WAVES SQ_WAIT_INST_LDS" \
            "TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TA_TOTAL_WAVEFRONTS_sum TD_TD_BUSY_sum TD_TC_STALL_sum" \
@@ -13,7 +13,8 @@ for set in "VALUBusy VALUUtilization MemUnitStalled OccupancyPercent" "MeanOccup
            "TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_BUSY_sum TCC_TAG_STALL_sum" \
            "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_INSTS_LDS_ATOMIC SQ_INSTS_LDS_LOAD SQ_INSTS_LDS_STORE"; do
   i=$((i+1))
-  rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O/p$i -o p -- python3 $R/tools_tuning/ingest_time.py 100000 3000 4 > $O/out$i.txt 2> $O/err$i.txt || { echo "set $i failed: $set"; tail -2 $O/err$i.txt; }
+  echo "pass $i: $set"
+  timeout -k 5 150 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O/p$i -o p -- python3 $R/tools_tuning/ingest_time.py 100000 3000 4 > $O/out$i.txt 2> $O/err$i.txt || { echo "set $i failed: $set"; tail -2 $O/err$i.txt; }
 done
 python3 - <<PY
 import csv, glob, collections
