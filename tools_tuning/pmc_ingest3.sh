@@ -1,5 +1,6 @@
 # what the record ingest's kernels keep busy: derived metrics + raw unit counters, one rocprofv3 --pmc pass per group
-# (no GRBM_* counters: a pass with GRBM_GUI_ACTIVE / GRBM_TA_BUSY / ... never came back on this pool)
+# (SQ counters and derived metrics only: passes with GRBM_*, TA_* / TD_*, TCP_* or TCC_* counters never came back on this pool;
+# FETCH_SIZE / WRITE_SIZE alone do: pmc_ingest2.sh)
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/ingpmc3
 rm -rf $O; mkdir -p $O
@@ -8,9 +9,6 @@ i=0
 for set in "VALUBusy VALUUtilization MemUnitStalled OccupancyPercent" "MeanOccupancyPerActiveCU LDSBankConflict" \
            "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY" \
            "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_WAVES SQ_WAIT_INST_LDS" \
-           "TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TA_TOTAL_WAVEFRONTS_sum TD_TD_BUSY_sum TD_TC_STALL_sum" \
-           "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCR_TCP_STALL_CYCLES_sum TCP_GATE_EN1_sum" \
-           "TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_BUSY_sum TCC_TAG_STALL_sum" \
            "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_INSTS_LDS_ATOMIC SQ_INSTS_LDS_LOAD SQ_INSTS_LDS_STORE"; do
   i=$((i+1))
   echo "pass $i: $set"
