@@ -428,7 +428,8 @@ int jl_allgather_variants_many(jl_ctx *const *ctxs, uint32_t n_ctx, jl_comm *com
  * every window, which must then be collected before the group's next run.
  * Binding is a collective the first time a communicator is bound: the ranks try a 64-byte all-gather in pinned host memory
  * and agree on the outcome; where that does not work (or with JL_EXCHANGE_STAGED=1) the all-gather works in device memory
- * and a copy to the pinned region follows it (two operations).  comm = NULL unbinds.  In-process communicators block
+ * and a copy to the pinned region follows it (two operations).  comm = NULL unbinds; a group must be unbound or destroyed
+ * before its communicator is.  In-process communicators block
  * in the launching call, as all their exchanges do.  Match: SURVEY 8e "exchange the variant table", doc/JULIET.md:94-100.
  */
 int jl_group_exchange_bind(jl_group *group, jl_comm *comm);
