@@ -551,7 +551,7 @@ __device__ unsigned long long g_stamps[64];
 #else
 #define JL_STAMP(k) do { } while (0)
 #define JL_STAMP_ON 0
-__device__ unsigned long long g_stamps[1];
+__device__ unsigned long long g_stamps[32];   // (never written in this build: the stores sit behind JL_STAMP_ON)
 #endif
 constexpr uint32_t kLdsSlots = 1024;
 constexpr uint64_t kNoKey = ~0ull;
