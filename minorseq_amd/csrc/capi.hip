@@ -503,7 +503,7 @@ static int records_build(jl_ctx *src, jl_ctx *dst, uint32_t n_cols, uint32_t win
     }
     const uint32_t ns = jl_ingest_sweeps(n_cols);
     const size_t nr = (size_t)R.n_reads;
-    if (e == hipSuccess) e = ingest_room(dst, &dst->d_ing_runs, &dst->ing_cap_runs, (size_t)R.n_cig + nr + 1);
+    if (e == hipSuccess) e = ingest_room(dst, &dst->d_ing_runs, &dst->ing_cap_runs, (size_t)R.n_cig + nr + 1 + 4);   // (+ 4: the planes kernel reads entries four at a time)
     if (e == hipSuccess) e = ingest_room(dst, &dst->d_ing_nruns, &dst->ing_cap_reads, nr + 1);
     if (e == hipSuccess) e = ingest_room(dst, &dst->d_ing_first, &dst->ing_cap_first, (nr + 1) * (ns + 1));
     if (e == hipSuccess) e = ingest_room(dst, &dst->d_ing_slow, &dst->ing_cap_slow, (nr + 1) * ns);

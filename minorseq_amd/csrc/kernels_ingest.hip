@@ -472,9 +472,12 @@ __global__ __launch_bounds__(kThreads) void ingest_planes_kernel(ingest_args a)
     uint64_t co = 0, so = 0;
     int32_t p = 0;
     if (real) {
+        // (the two indices in one request: every scattered request of the prologue shows in the kernel's time)
         const uint32_t *fr = a.first_run + r * (uint64_t)(a.n_sweeps + 1u) + sweep;
-        f0 = fr[0];
-        f1 = fr[1];
+        typedef uint32_t u32x2 __attribute__((ext_vector_type(2), aligned(4)));
+        const u32x2 f01 = *reinterpret_cast<const u32x2 *>(fr);
+        f0 = f01.x;
+        f1 = f01.y;
         nr = a.nruns[r];
         co = a.cig_off[r];
         so = a.seq_off[r];
@@ -499,10 +502,11 @@ __global__ __launch_bounds__(kThreads) void ingest_planes_kernel(ingest_args a)
     bool slow = need != 0u && (cnt > 1022u || off + need > kEntCap);
     const uint2 *src = a.runs + co + r + f0;
     if (need && !slow) {
-        // (the first four entries' loads go out together: a load-store loop pays a trip to HBM per entry)
-        uint2 e4[4];
-#pragma unroll
-        for (uint32_t i = 0; i < 4u; ++i) e4[i] = src[min(i, need - 1u)];
+        // (the first four entries in two 16-byte requests that go out together — a load-store loop pays a trip to HBM per
+        // entry; entries past `need` belong to the next read or to the array's slack)
+        typedef uint32_t u32x4a8 __attribute__((ext_vector_type(4), aligned(8)));
+        const u32x4a8 e01 = *reinterpret_cast<const u32x4a8 *>(src), e23 = *reinterpret_cast<const u32x4a8 *>(src + 2);
+        const uint2 e4[4] = {make_uint2(e01.x, e01.y), make_uint2(e01.z, e01.w), make_uint2(e23.x, e23.y), make_uint2(e23.z, e23.w)};
 #pragma unroll
         for (uint32_t i = 0; i < 4u; ++i)
             if (i < need) s_ent[off + i] = e4[i];
