@@ -659,6 +659,10 @@ def once_through(capi, synth, torch, jl0, genes, refseq, prm, expect, rank, loca
             enqueue(j, j + rep)
             check(j)
     torch.cuda.synchronize()
+    # every CELL of a freshly built window against resident batch 0 (the same reads, filled by the generator on the device): the
+    # per-step check above compares results, which a wrong cell in a column without a variant would pass
+    if not (wins[0].download_columns() == jl0.download_columns()).all():
+        raise SystemExit("bench.py: once_through: a freshly ingested window differs from the resident batch cell by cell")
     t0 = time.perf_counter()
     busy = [False] * J
     for s in range(steps):
@@ -688,7 +692,7 @@ def once_through(capi, synth, torch, jl0, genes, refseq, prm, expect, rank, loca
     res = {"workload": f"a fresh window per step: records of {n} CCS reads x {l} bp (positions, cigars, 4-bit bases; resident in HBM) -> "
                        "ingest into the bit planes -> pileup + Fisher + phasing -> results on the host; 4 windows in flight, "
                        "every step's result verified",
-           "value": n / t, "unit": "reads/s", "ms_per_step": 1000.0 * t, "steps": steps,
+           "value": n / t, "unit": "reads/s", "ms_per_step": 1000.0 * t, "steps": steps, "cells_verified_before_loop": n * l,
            "record_bytes": record_bytes, "plane_bytes": plane_bytes,
            "bytes_per_step": io, "frac": io / t / 1e9 / HBM_PEAK_GBS,
            "frac_records_plus_planes_once": (record_bytes + plane_bytes) / t / 1e9 / HBM_PEAK_GBS,

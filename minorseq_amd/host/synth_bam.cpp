@@ -24,6 +24,11 @@ int main(int argc, char **argv)
     std::string raw_out;   // --raw-out file: the records as the arrays jl_records_append takes, no BAM (bench.py once_through)
     uint64_t ref_seed = 0;
     bool have_ref_seed = false;
+    // --raw-out only: what an ingest must ignore or mask, drawn by hashes of (read, column) so that every run gives the same
+    // records: insertions of 1-4 bases before a column (parts per million of the cells), soft and hard clips at the ends of
+    // half the reads, and aligned bases with a poor quality (ppm) — the cells a QV threshold turns into N
+    uint32_t ins_ppm = 0, low_qv_ppm = 0;
+    bool clips = false;
     for (int i = 1; i < argc; ++i) {
         const std::string a = argv[i];
         auto need = [&]() -> std::string { if (i + 1 >= argc) { std::cerr << a << " needs a value\n"; std::exit(1); } return argv[++i]; };
@@ -38,6 +43,9 @@ int main(int argc, char **argv)
         else if (a == "--ref-offset") ref_offset = (uint32_t)std::stoul(need());  // window starts here in a longer reference
         else if (a == "--rich-qv") rich_qv = true;
         else if (a == "--raw-out") raw_out = need();
+        else if (a == "--ins-ppm") ins_ppm = (uint32_t)std::stoul(need());
+        else if (a == "--low-qv-ppm") low_qv_ppm = (uint32_t)std::stoul(need());
+        else if (a == "--clips") clips = true;
         else if (a == "--ref-seed") { ref_seed = std::stoull(need()); have_ref_seed = true; }   // reference drawn from another seed than the reads
         else if (a == "--insert") {
             const std::string v = need();
@@ -125,22 +133,46 @@ int main(int argc, char **argv)
             auto flush = [&]() { if (run_len) cigar.push_back(run_len << 4 | run_op); run_len = 0; };
             uint32_t nb = 0;
             uint8_t half = 0;
+            auto push_base = [&](uint8_t code, uint8_t q) {
+                if (nb & 1u) seq4.push_back((uint8_t)(half << 4 | code));
+                else half = code;
+                ++nb;
+                qual.push_back(q);
+            };
+            const uint64_t hr = jl_splitmix64(seed * 0xD1B54A32D192ED03ull + 31ull * i + 5ull);
+            if (clips && st < en) {
+                if (hr & 1u) cigar.push_back((uint32_t)(1u + (hr >> 8) % 7u) << 4 | CIG_H);
+                if (hr & 2u) {
+                    const uint32_t k = 1u + (uint32_t)((hr >> 16) % 40u);
+                    cigar.push_back(k << 4 | CIG_S);
+                    for (uint32_t j = 0; j < k; ++j) push_base(nt16[(hr >> (24 + j % 20)) & 3u], 3);
+                }
+            }
             for (uint32_t c = st; c < en; ++c) {
+                const uint64_t hc = (ins_ppm || low_qv_ppm) ? jl_splitmix64(seed * 0xA24BAED4963EE407ull + (uint64_t)i * n_cols + c) : 0u;
+                if (ins_ppm && c > st && hc % 1000000u < ins_ppm) {
+                    flush();
+                    run_op = 99;
+                    const uint32_t k = 1u + (uint32_t)((hc >> 32) & 3u);
+                    cigar.push_back(k << 4 | CIG_I);
+                    for (uint32_t j = 0; j < k; ++j) push_base(nt16[(hc >> (40 + 2 * j)) & 3u], 2);
+                }
                 const uint32_t sy = jl_synth_cell(&pl, i, c, hap, st, en, ref[c]);
                 uint32_t op;
                 if (sy == 4) op = CIG_D;
                 else {
                     op = (sy < 4 && sy == ref[c]) ? CIG_EQ : CIG_X;
-                    const uint8_t code = nt16[sy < 4 ? sy : 4];
-                    if (nb & 1u) seq4.push_back((uint8_t)(half << 4 | code));
-                    else half = code;
-                    ++nb;
-                    qual.push_back(93);
+                    push_base(nt16[sy < 4 ? sy : 4], (low_qv_ppm && (hc >> 20) % 1000000u < low_qv_ppm) ? (uint8_t)(4u + (hc >> 50) % 12u) : (uint8_t)93);
                 }
                 if (op != run_op) { flush(); run_op = op; }
                 ++run_len;
             }
             flush();
+            if (clips && st < en && (hr & 4u)) {
+                const uint32_t k = 1u + (uint32_t)((hr >> 44) % 25u);
+                cigar.push_back(k << 4 | CIG_S);
+                for (uint32_t j = 0; j < k; ++j) push_base(nt16[(hr >> (3 + j % 30)) & 3u], 3);
+            }
             if (nb & 1u) seq4.push_back((uint8_t)(half << 4));
             cig_off[i + 1] = cigar.size();
             seq_off[i + 1] = seq4.size();

@@ -957,6 +957,66 @@ def test_device_ingest_matches_rows(jl, n, l, partial, win):
     assert (msa.unpack_columns(jl.download_columns(), n) == rows[:, b:e]).all()
 
 
+# ---- the ingest at the sizes the bench runs it at (VERDICT r04 task 2): every cell of every read, against the numpy statement of
+# "records -> matrix" (tests/records_expand.py, pinned on the CPU by tests/test_records_expand.py) and, for three groups of 1024
+# reads (the first, one served in a later round of its XCD, the last and partial one), against the generator's own rows.
+def _cells_equal(window, rec, n, n_cols, win_begin=0, min_qv=0):
+    import records_expand
+    packed = window.download_columns()
+    slab = 1 << 15
+    for r0 in range(0, n, slab):                      # (by slabs of reads: the expected matrix never exists whole)
+        r1 = min(n, r0 + slab)
+        exp = records_expand.expand(rec, n_cols, win_begin, min_qv, read_begin=r0, read_end=r1)
+        by = packed[:, r0 // 2:(r1 + 1) // 2]
+        got = np.empty((n_cols, 2 * by.shape[1]), dtype=np.uint8)
+        got[:, 0::2] = by & 15
+        got[:, 1::2] = by >> 4
+        if not (got[:, :r1 - r0].T == exp).all():
+            bad = np.argwhere(got[:, :r1 - r0].T != exp)[0]
+            return "read %d column %d: got %d, expected %d" % (r0 + bad[0], bad[1], got[bad[1], bad[0]], exp[bad[0], bad[1]])
+    return None
+
+
+@pytest.mark.parametrize("n,l", [(100_000, 3000), (333_333, 1000)])
+def test_device_ingest_at_size(jl, n, l):
+    """100k x 3000 (the bench's window: 98 groups of 1024 reads x 14 sweeps) and 333 333 x 1000 (326 groups: they do not divide
+    among the eight XCDs, an XCD serves forty of them in turn): jl_records_window of the resident records == every cell."""
+    rec = synth.raw_records(5, n, l)
+    jl.records_upload(rec["pos"], rec["cigar"], rec["cig_off"], rec["seq4"], rec["seq_off"])
+    w = capi.Juliet(0)
+    try:
+        w.records_window(jl, l, 0, 0)
+        assert _cells_equal(w, rec, n, l) is None
+        got = None
+        sp, ref = synth.SynthParams(seed=5), synth.reference(5, l)
+        packed = w.download_columns()
+        for g in (0, (n // 1024) // 2 + 3, n // 1024):
+            r0, r1 = 1024 * g, min(n, 1024 * g + 1024)
+            got = msa.unpack_columns(np.ascontiguousarray(packed[:, r0 // 2:(r1 + 1) // 2]), r1 - r0)
+            assert (got == synth.rows(sp, l, r0, r1, ref)).all(), g
+    finally:
+        w.close()
+        jl.records_drop()
+
+
+@pytest.mark.parametrize("n,l,win,min_qv", [(24_000, 1100, (37, 1039), 20), (24_000, 1100, (0, 1100), 0), (21_000, 700, (300, 693), 20)])
+def test_device_ingest_qv_and_ragged_window_at_size(jl, n, l, win, min_qv):
+    """Tens of groups through the QV path and through windows that begin inside the reads and end on no sweep boundary
+    (n_cols % 224 != 0), on records with what an ingest must ignore: insertions of 1-4 bases, soft and hard clips, and 2 % of
+    the aligned bases below the threshold."""
+    rec = synth.raw_records(9, n, l, extra=("--ins-ppm", "2500", "--clips", "--low-qv-ppm", "20000", "--partial", "0.3"))
+    b, e = win
+    assert (e - b) % 224 != 0
+    jl.records_upload(rec["pos"], rec["cigar"], rec["cig_off"], rec["seq4"], rec["seq_off"], rec["qual"], rec["qual_off"])
+    w = capi.Juliet(0)
+    try:
+        w.records_window(jl, e - b, b, min_qv)
+        assert _cells_equal(w, rec, n, e - b, b, min_qv) is None
+    finally:
+        w.close()
+        jl.records_drop()
+
+
 @pytest.mark.parametrize("chunk,hints", [(1, (0, 0, 0, 0)), (37, (0, 0, 0, 0)), (256, (5000, 100000, 1 << 20, 1 << 21)), (10000, (0, 0, 0, 0))])
 def test_device_ingest_in_chunks(jl, chunk, hints):
     """jl_records_begin / _append / _finish: any chunking (one read per append, ragged chunks, one chunk; device arrays
