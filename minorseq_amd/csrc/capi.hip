@@ -189,7 +189,7 @@ void jl_ctx_destroy(jl_ctx *ctx)
                     ctx->d_col2pos, ctx->d_varcol, ctx->d_keys, ctx->d_flagw, ctx->d_read_slot, ctx->d_read_hap,
                     ctx->d_slot_rep, ctx->d_slot_count, ctx->d_slot_key, ctx->d_slot_hap, ctx->d_occupied, ctx->d_hap_count,
                     ctx->d_hap_pattern, ctx->d_hit, ctx->d_cooc, ctx->d_pack, ctx->d_sync, ctx->d_timeline,
-                    ctx->d_ins_len, ctx->d_ins_base, ctx->d_ing_runs, ctx->d_ing_nruns, ctx->d_ing_first, ctx->d_ing_count, ctx->d_ing_slow,
+                    ctx->d_ins_len, ctx->d_ins_base, ctx->d_ing_runs, ctx->d_ing_nruns, ctx->d_ing_desc, ctx->d_ing_count, ctx->d_ing_slow,
                     ctx->d_exp_count,
                     ctx->d_exp_pattern, ctx->d_exp_hap, ctx->d_blockcat, ctx->d_slot_key_a, ctx->d_slot_key_b, ctx->d_occ_a, ctx->d_occ_b};
     for (void *p : ptrs)
@@ -472,6 +472,14 @@ int jl_ingest_verdict(jl_ctx *ctx)
     ctx->ing_check_pending = false;
     // (through the context's pinned block: a process's first pageable device-to-host copy costs the runtime milliseconds)
     unsigned long long both[2] = {0, ~0ull};
+#ifdef JL_TUNING
+    {   // the address checks of the tuning build's ingest kernels (kernels_ingest.hip JL_ING_CHECK)
+        uint32_t w[16] = {0};
+        if (int rc = jl_fetch_to_host(ctx, ctx->d_ing_count, 64, w, 64)) return rc;
+        for (int c = 1; c < 6; ++c)
+            if (w[4 + c]) fprintf(stderr, "ingest check %d failed %u times (a value: %u)\n", c, w[4 + c], w[10 + c]);
+    }
+#endif
     if (int rc = jl_fetch_to_host(ctx, ctx->d_ing_count, 16, both, 64)) return rc;
     const unsigned long long w = both[1];
     if (w == ~0ull) return JL_OK;
@@ -479,6 +487,7 @@ int jl_ingest_verdict(jl_ctx *ctx)
     const unsigned code = (unsigned)(w & 0xFFu);
     ctx->pileup_done = ctx->call_done = ctx->phase_done = false;
     if (code == 1u) return jl_fail(ctx, JL_ERR_ARG, "record %llu: cigar M is forbidden in PacBio-compliant BAM (doc/JULIET.md:53)", r);
+    if (code == 4u) return jl_fail(ctx, JL_ERR_ARG, "record %llu: its cigar spans 2^30 reference bases or more", r);
     return jl_fail(ctx, JL_ERR_ARG, "record %llu: its cigar consumes more %s than the record holds", r, code == 2u ? "bases" : "qualities");
 }
 
@@ -503,9 +512,9 @@ static int records_build(jl_ctx *src, jl_ctx *dst, uint32_t n_cols, uint32_t win
     }
     const uint32_t ns = jl_ingest_sweeps(n_cols);
     const size_t nr = (size_t)R.n_reads;
-    if (e == hipSuccess) e = ingest_room(dst, &dst->d_ing_runs, &dst->ing_cap_runs, (size_t)R.n_cig + nr + 1 + 4);   // (+ 4: the planes kernel reads entries four at a time)
+    if (e == hipSuccess) e = ingest_room(dst, &dst->d_ing_runs, &dst->ing_cap_runs, (size_t)R.n_cig + 3 * nr + 4);   // (three entries around a read's runs; + 4: the planes kernel reads entries four at a time)
     if (e == hipSuccess) e = ingest_room(dst, &dst->d_ing_nruns, &dst->ing_cap_reads, nr + 1);
-    if (e == hipSuccess) e = ingest_room(dst, &dst->d_ing_first, &dst->ing_cap_first, (nr + 1) * (ns + 1));
+    if (e == hipSuccess) e = ingest_room(dst, &dst->d_ing_desc, &dst->ing_cap_desc, (nr + 1) * ns);
     if (e == hipSuccess) e = ingest_room(dst, &dst->d_ing_slow, &dst->ing_cap_slow, (nr + 1) * ns);
     if (e == hipSuccess && !dst->d_ing_count) e = hipMalloc(&dst->d_ing_count, 64);
     dst->ins_valid = false;
@@ -529,8 +538,8 @@ static int records_build(jl_ctx *src, jl_ctx *dst, uint32_t n_cols, uint32_t win
     }
     if (e == hipSuccess) {
         jl_launch_ingest(dst, R.d_pos, R.d_cig, R.d_co, R.d_seq, R.d_so, R.have_qual ? R.d_qual : nullptr,
-                         R.have_qual ? R.d_qo : nullptr, min_qv, dst->d_ing_runs, dst->d_ing_nruns, dst->d_ing_first, dst->d_ing_count,
-                         dst->d_ing_slow);
+                         R.have_qual ? R.d_qo : nullptr, min_qv, dst->d_ing_runs, dst->d_ing_nruns, dst->d_ing_desc, dst->d_ing_count,
+                         dst->d_ing_slow, dst->ing_check_pending, R.n_seq, R.n_cig + 3 * nr + 4);
         e = hipGetLastError();
         dst->ing_check_pending = e == hipSuccess;
         if (e == hipSuccess && wait) e = hipStreamSynchronize(st);

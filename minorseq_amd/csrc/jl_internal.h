@@ -330,9 +330,10 @@ struct jl_ctx {
     // scratch of the record ingest INTO this context (kernels_ingest.hip), kept between builds: the reads' runs, the run at
     // every sweep's first column, the (read, sweep) pairs left to the slow kernel behind their counter
     uint2 *d_ing_runs = nullptr;
-    uint32_t *d_ing_nruns = nullptr, *d_ing_first = nullptr, *d_ing_count = nullptr;
+    uint32_t *d_ing_nruns = nullptr, *d_ing_count = nullptr;
+    uint4 *d_ing_desc = nullptr;      // one descriptor per (sweep, read): kernels_ingest.hip
     uint2 *d_ing_slow = nullptr;
-    size_t ing_cap_runs = 0, ing_cap_reads = 0, ing_cap_first = 0, ing_cap_slow = 0;
+    size_t ing_cap_runs = 0, ing_cap_reads = 0, ing_cap_desc = 0, ing_cap_slow = 0;
     bool ing_check_pending = false;   // an ingest ran (or is enqueued) whose verdict on the records has not been read yet
 
     // ---- phasing sharded by reads: the groups of this matrix exported for the merge (jl_phase_groups_async / _fetch)
@@ -504,8 +505,8 @@ extern "C" int jl_run_wait_seq(jl_ctx *ctx, uint32_t want);
 void jl_launch_consensus(jl_ctx *ctx, uint8_t *d_out);
 void jl_launch_ingest(jl_ctx *ctx, const int32_t *d_pos, const uint32_t *d_cigar, const uint64_t *d_cig_off,
                       const uint8_t *d_seq4, const uint64_t *d_seq_off, const uint8_t *d_qual,
-                      const uint64_t *d_qual_off, uint32_t min_qv, uint2 *d_runs, uint32_t *d_nruns, uint32_t *d_first,
-                      uint32_t *d_slow_count, uint2 *d_slow);
+                      const uint64_t *d_qual_off, uint32_t min_qv, uint2 *d_runs, uint32_t *d_nruns, uint4 *d_desc,
+                      uint32_t *d_slow_count, uint2 *d_slow, bool keep_verdict, uint64_t seq_bytes, uint64_t n_entries);
 uint32_t jl_ingest_sweeps(uint32_t n_cols);
 extern "C" int jl_ingest_verdict(jl_ctx *ctx);
 void jl_launch_regroup(jl_ctx *ctx, const uint16_t *d_hap_of_group, uint32_t n_groups, uint32_t n_haplotypes, bool phased);

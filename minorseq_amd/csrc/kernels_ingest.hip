@@ -1,28 +1,33 @@
 // kernels_ingest.hip — aligned BAM records -> the resident bit planes, entirely on the device.
 //
-// Behaviour: doc/JULIET.md:26-27 (insertions dropped, deletions '-'), :53 (PacBio cigars = X I D S H N; M is rejected on the
-// host), :256-259 (a QV-filtered base shows up as N).  Reads past n_reads (the padding of a plane up to its stride) and
-// columns outside a read's span are 'not covered' (code 6).
+// Behaviour: doc/JULIET.md:26-27 (insertions dropped, deletions '-'), :53 (PacBio cigars = X I D S H N; M is refused),
+// :256-259 (a QV-filtered base shows up as N).  Reads past n_reads (the padding of a plane up to its stride) and columns
+// outside a read's span are 'not covered' (code 6).
 //
-// Three launches, no by-row scratch in HBM (rounds 1-3 expanded every read into a by-row nibble matrix, transposed that
-// into a column-packed one and made the planes from it: 870 MB moved for the 270 MB that are needed):
-//   cigar_runs_kernel   one wave per read: prefix sums over the cigar -> the read's RUNS (stretches of '=' / 'X' merge into one
-//                       run of aligned bases; D and N are runs of their own; I / S / H / P only end a run), 8 bytes each, plus
-//                       for every column sweep of the window the index of the run that contains its first column.
-//   ingest_planes_kernel  one workgroup = 256 reads x one sweep of 224 columns.  It loads the handful of runs its reads have
-//                       in the sweep into LDS, then works INPUT-driven: a lane takes 16 aligned bytes = 32 bases of a read
-//                       straight from HBM (coalesced, all of a wave's loads in flight before the first is used), converts
-//                       them to symbol codes nibble-parallel, finds the run(s) they belong to and XORs them — shifted to
-//                       their columns — into a by-row nibble tile in LDS that starts out as 'not covered' (a cell is
-//                       written by exactly one run, so XOR against the initial code stores it; deletions are XORed in by a
-//                       pass over the D runs; reference skips need nothing).  The tile then leaves as planes: a thread
-//                       takes 32 reads x 8 columns, transposes four 8 x 8 nibble blocks in registers, splits the codes into
-//                       their three bits and stores a dword of each plane of each column; the four workgroups that share
-//                       the 128-byte lines of a sweep run on one XCD next to each other (blockIdx mapping), so the lines
-//                       are completed in that XCD's L2.
-//   ingest_slow_kernel  the (read, sweep) pairs a workgroup could not take — more runs in one sweep than its LDS list
-//                       holds (a deletion every other column), a huge insertion inside a sweep: column by column from the
-//                       runs in HBM, bits flipped with atomics.  Empty for real CCS data.
+// Three launches, no by-row scratch in HBM:
+//   cigar_runs_kernel   a wave takes four reads: prefix sums over the cigar -> the read's RUNS in WINDOW columns (stretches of
+//                       '=' / 'X' merge into one run of aligned bases; D and N are runs of their own; I / S / H / P only end a
+//                       run), 8 bytes each, between a leading 'not covered from column 0' entry and two trailing ones (the
+//                       read's end; 'never'), so that every column of the window lies in exactly one entry's interval.  Then,
+//                       for every column sweep, ONE 16-byte descriptor per read: where the sweep's entries are, how many, the
+//                       address of the first 16-byte piece of packed bases the sweep needs, how many pieces, the query offset
+//                       of that piece — everything ingest_planes_kernel needs to ask for its input in one round trip.
+//   ingest_planes_kernel  a workgroup = 128 reads x one sweep of 224 columns.  One request per read (the descriptor), then
+//                       the entries and the pieces together.  The pieces become symbol codes (nibbles) and go to LDS in QUERY
+//                       order with plain 16-byte stores — no run search, no masks.  Meanwhile two threads per read walk its
+//                       entries and fill a table: for every block of 8 columns, the LDS nibble address its eight codes begin
+//                       at — inside the read's bases when one aligned run covers the block, a constant dword of '-' or of
+//                       'not covered' when a deletion / nothing does; the few blocks with a run boundary inside are listed,
+//                       put together once by a general loop into a side dword, and the table points there.  GATHER AT THE
+//                       TRANSPOSE: a thread takes 32 reads x 8 columns, picks each read's dword by the table (two LDS reads
+//                       + one v_alignbit), transposes four 8 x 8 nibble blocks in registers and stores a dword of each plane of
+//                       each column; the eight workgroups that share the 128-byte lines of a sweep run on one XCD next to each
+//                       other (blockIdx mapping), so the lines are completed in that XCD's L2.
+//                       (Rounds 1-3 expanded every read into a by-row matrix in HBM: 870 MB moved for the 316 MB needed;
+//                       round 4 scattered the codes into a by-row LDS tile with masked, shifted XORs: 137 us.)
+//   ingest_slow_kernel  the (read, sweep) pairs a workgroup could not take — more entries or pieces in one sweep than its
+//                       LDS holds (a deletion every other column, a huge insertion inside a sweep): column by column from the
+//                       entries in HBM, bits flipped with atomics.  Empty for real CCS data.
 #include <stdlib.h>
 
 #include <algorithm>
@@ -34,50 +39,21 @@ namespace {
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr uint32_t kSweep = JL_INGEST_SWEEP;        // columns per workgroup
-constexpr uint32_t kSweepDw = kSweep / 8u;          // dwords of 8 columns in a tile row
+constexpr uint32_t kBlocks = kSweep / 8u;           // blocks of 8 columns = dwords of 8 codes
 #ifndef JL_INGEST_TILE
 #define JL_INGEST_TILE 128
 #endif
-constexpr uint32_t kTileReads = JL_INGEST_TILE;     // reads per workgroup: 128 (22.7 KB of LDS: seven workgroups per CU) or 256
+constexpr uint32_t kTileReads = JL_INGEST_TILE;     // reads per workgroup
 constexpr uint32_t kTileGroups = kTileReads / 32u;  // groups of 32 reads = dwords of a plane the tile writes per column
 constexpr uint32_t kSubTiles = 1024u / kTileReads;  // tiles that share the 128-byte lines of the planes
-// tile row of read r at (r & 31) * kRowI + (r >> 5) * kSweepDw: the eight reads a wave expands together lie an odd number of
-// banks apart, the 32-read groups of the transposing step four banks apart
-constexpr uint32_t kRowI = kTileGroups * kSweepDw + 1u;
-constexpr uint32_t kTileDw = 32u * kRowI;
-#ifndef JL_INGEST_ENT_PER_READ
-#define JL_INGEST_ENT_PER_READ 4
-#endif
-// run entries of the workgroup's reads in its sweep (LDS).  Four per read on average (CCS reads need 2.6: a run, half a deletion,
-// the end entry) keep the workgroup below 22.8 KB of LDS: seven workgroups per CU instead of six (136 against 141 us); a tile
-// that needs more leaves its last reads to the slow kernel
-constexpr uint32_t kEntCap = JL_INGEST_ENT_PER_READ * kTileReads;
-constexpr uint32_t kRunMask = 0x3FFFFFFFu;          // reference offset of a run; kind in the two bits above
-constexpr uint32_t kMaxPieces = 1023u;              // pieces of a read in a sweep (10 bits; the deferral list holds 12)
-// 32-byte pieces (64 bases) of a read that a sweep takes from a 16-byte boundary on, insertions aside: a power of two of lanes
-constexpr uint32_t kPiecesPerRead = (kSweep + 31u + 63u) / 64u <= 4u ? 4u : 8u;
-static_assert(kSweep % 8u == 0 && kSweep + 31u <= 64u * kPiecesPerRead, "a sweep is at most eight pieces of a read wide");
-// threads of a planes workgroup: two per read of the tile (a thread per read in the prologue, the waves share the expansion)
-#ifndef JL_INGEST_THREADS
-#define JL_INGEST_THREADS 256
-#endif
-constexpr uint32_t kThreads = JL_INGEST_THREADS, kWaves = kThreads / 64u;
-static_assert(kThreads % 64u == 0 && kThreads >= kTileReads && kThreads <= 256u, "whole waves, a thread per read at least");
-static_assert((JL_INGEST_TILE * kPiecesPerRead) % kThreads == 0 && JL_INGEST_TILE % 32 == 0, "whole rounds of the waves; whole plane dwords");
-static_assert(kThreads / kTileGroups >= kSweepDw, "a thread per 32 reads x 8 columns in the transposing phase");
+constexpr uint32_t kThreads = 2u * kTileReads;      // a thread per read in the prologue, two in the table fill
+constexpr uint32_t kWaves = kThreads / 64u;
+constexpr uint32_t kRunMask = 0x3FFFFFFFu;          // window column of an entry; kind in the two bits above
+static_assert(kSweep % 16u == 0 && kTileReads % 32u == 0 && kThreads <= 1024u, "whole blocks for both table threads, whole plane dwords");
+static_assert(kTileGroups * kBlocks <= kThreads, "a thread per 32 reads x 8 columns in the transposing phase");
 
 // ---------------------------------------------------------------------------------------- runs
-// inclusive prefix sum over the 64 lanes by DPP (four shifts within rows of 16, two row broadcasts)
-__device__ __forceinline__ uint32_t wave_scan(uint32_t v)
-{
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);   // row_shr:1
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true);   // row_shr:2
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true);   // row_shr:4
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true);   // row_shr:8
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);  // row_bcast:15 -> rows 1, 3
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);  // row_bcast:31 -> rows 2, 3
-    return v;
-}
+// inclusive prefix sums over the 64 lanes by DPP (four shifts within rows of 16, two row broadcasts);
 // two independent sums scanned in step (a DPP read of a register needs two wait states behind the write: each chain fills
 // the other's)
 __device__ __forceinline__ void wave_scan2(uint32_t &a, uint32_t &b)
@@ -97,38 +73,62 @@ __device__ __forceinline__ void wave_scan2(uint32_t &a, uint32_t &b)
     JL_SCAN_STEP(0x143, 0xC, false)
 #undef JL_SCAN_STEP
 }
+// the exact sum of a wave's values (the rare step that holds an op of 2^25 bases or more: a 32-bit scan could wrap)
+__device__ __forceinline__ uint64_t wave_sum64(uint32_t v)
+{
+    uint64_t t = 0;
+    for (int l = 0; l < 64; ++l) t += (uint32_t)__builtin_amdgcn_readlane((int)v, l);
+    return t;
+}
 
-// runs[cig_off[r] + r + i] = {reference offset of run i relative to the read's first base | kind << 30, query offset};
-// kind 1 aligned bases, 2 deletion, 3 reference skip; entry n_runs = {the read's reference length, its query length}.
-// first_run[r][s], s = 0 .. n_sweeps: the number of runs i >= 1 (the end entry included) that begin at or before window
-// column s * kSweep = the index of the run that contains that column (0 before the read, n_runs behind it).
-// A wave takes four consecutive reads, a lane two consecutive cigar ops (128 ops a step: a CCS read's cigar in one or two
-// steps); the offsets and the first step's cigar words of all four reads are requested before anything waits — with one
-// read per wave the kernel was a chain of three trips to HBM per wave and nothing else (51 us for 100k reads).
+// Entries of read r: runs[cig_off[r] + 3 r + i], i = 0 .. n_runs + 2, each {window column | kind << 30, query offset}; entry i
+// says what the read shows in the columns [its column, the next entry's column): kind 1 aligned bases (column c holds the
+// base at query offset + c - column), 2 deletion, 3 nothing ('not covered': before the read, a reference skip, behind it).
+// Entry 0 = {0, nothing}; entries 1 .. n_runs the read's runs, columns clamped to [0, n_cols] (a run that begins before the
+// window begins at column 0 with its query offset moved along); entry n_runs + 1 = the read's end {column, nothing, query
+// length}; entry n_runs + 2 = {kRunMask, nothing}: never reached.  The columns never decrease.
 constexpr uint32_t kRunsReadsPerWave = 4u;
-// The records are untrusted: a cigar with an 'M' (forbidden in PacBio BAM, doc/JULIET.md:53) or one that consumes more bases
-// (or qualities) than the record holds is reported — *bad = min over such reads of (read << 8 | code), code 1 'M', 2 bases,
-// 3 qualities — and the read is treated as covering nothing, so no later kernel follows its offsets anywhere.
+constexpr uint32_t kRunsLds = 64u;          // entries of a read kept in LDS for the descriptors (the rest is read back from HBM)
+constexpr uint32_t kDescSweeps = 15u;       // sweeps a row of sixteen lanes describes per pass (it needs sixteen bounds)
+constexpr uint32_t kDescMax = 255u;         // "more than the planes kernel takes": pieces or entries of a (read, sweep)
+
+// Descriptor of (sweep s, read r) at desc[s * n_reads + r]:
+//   x  index of the first 16-byte piece of packed bases (byte offset / 16), low 32 bits
+//   y  index of the sweep's first entry in runs[], low 32 bits
+//   z  query offset of the first piece's first base (>= -30: the piece may begin before the read's bases)
+//   w  piece index bits 32-39 | entry index bits 32-39 << 8 | pieces << 16 | entries << 24   (255 = too many)
+// The entries of a sweep: from the one that contains its first column to the first one that begins behind its last column.
+// Two entries = ONE entry covers the whole sweep, the common case: then `entries` reads 1, y = the query offset of the sweep's
+// first column and bits 8-9 of w = the entry's kind — the planes kernel never asks for the entries.
+
+// The records are untrusted: a cigar with an 'M' (forbidden in PacBio BAM, doc/JULIET.md:53), one that consumes more bases
+// (or qualities) than the record holds, or one that spans 2^30 reference bases or more is reported — *bad = min over such reads
+// of (read << 8 | code), code 1 'M', 2 bases, 3 qualities, 4 span — and the read is treated as covering nothing, so no later
+// kernel follows its offsets anywhere.  Lengths add up in 64 bits (a step that holds an op of 2^25 bases or more is summed
+// exactly, lane by lane), so no crafted cigar wraps a sum back into range.
 __global__ __launch_bounds__(256) void cigar_runs_kernel(uint64_t n_reads, const int32_t *__restrict__ pos, const uint32_t *__restrict__ cigar,
                                                          const uint64_t *__restrict__ cig_off, const uint64_t *__restrict__ seq_off,
                                                          const uint64_t *__restrict__ qual_off, uint32_t win_begin, uint32_t n_cols,
                                                          uint32_t n_sweeps, uint2 *__restrict__ runs, uint32_t *__restrict__ nruns,
-                                                         uint32_t *__restrict__ first_run, unsigned long long *__restrict__ bad)
+                                                         uint4 *__restrict__ desc, unsigned long long *__restrict__ bad)
 {
-    extern __shared__ uint32_t s_dyn[];
+    __shared__ uint2 s_run_all[4][kRunsReadsPerWave][kRunsLds];
     const uint32_t wid = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint64_t r0 = ((uint64_t)blockIdx.x * 4u + wid) * kRunsReadsPerWave;
     if (r0 >= n_reads) return;
-    uint32_t *hist = s_dyn + (size_t)wid * (n_sweeps + 2u);
+    uint2 (*s_run)[kRunsLds] = s_run_all[wid];
     // lanes 0..4: the cigar offsets of the wave's reads (one more than reads), lanes 0..3 their positions
     const uint64_t rl_ = r0 + lane;
     const uint64_t co_l = (lane <= kRunsReadsPerWave && rl_ <= n_reads) ? cig_off[rl_] : 0u;
     const int32_t pos_l = (lane < kRunsReadsPerWave && rl_ < n_reads) ? pos[rl_] : 0;
+    const uint64_t so_l = (lane <= kRunsReadsPerWave && rl_ <= n_reads) ? seq_off[rl_] : 0u;
+    const uint64_t qo_l = (qual_off && lane <= kRunsReadsPerWave && rl_ <= n_reads) ? qual_off[rl_] : 0u;
+    auto lane64 = [](uint64_t v, int l) -> uint64_t {   // (a lane known at compile time: no trip through the LDS crossbar)
+        return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(v >> 32), l) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l);
+    };
     uint64_t cb[kRunsReadsPerWave + 1u];
 #pragma unroll
-    for (uint32_t q = 0; q <= kRunsReadsPerWave; ++q)
-        cb[q] = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(co_l >> 32), (int)q) << 32) |
-                (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)co_l, (int)q);   // (a lane known at compile time: no trip through the LDS crossbar)
+    for (uint32_t q = 0; q <= kRunsReadsPerWave; ++q) cb[q] = lane64(co_l, (int)q);
     uint32_t cw0[kRunsReadsPerWave][2];
 #pragma unroll
     for (uint32_t q = 0; q < kRunsReadsPerWave; ++q) {
@@ -137,24 +137,22 @@ __global__ __launch_bounds__(256) void cigar_runs_kernel(uint64_t n_reads, const
         cw0[q][0] = (live && k < cb[q + 1u]) ? cigar[k] : 0u;
         cw0[q][1] = (live && k + 1u < cb[q + 1u]) ? cigar[k + 1u] : 0u;
     }
+    uint32_t n_runs_of[kRunsReadsPerWave] = {0, 0, 0, 0};
 #pragma unroll
     for (uint32_t q = 0; q < kRunsReadsPerWave; ++q) {
         const uint64_t r = r0 + q;
         if (r >= n_reads) break;
-        for (uint32_t s = lane; s < n_sweeps + 2u; s += 64u) hist[s] = 0;
         const uint64_t c_beg = cb[q], c_end = cb[q + 1u];
-        uint2 *out = runs + c_beg + r;
+        uint2 *out = runs + c_beg + 3u * r;
         const int64_t base = (int64_t)__builtin_amdgcn_readlane(pos_l, (int)q) - (int64_t)win_begin;
-        // first sweep whose first column is at or behind the run's start (32-bit arithmetic: the offset is clamped to the
-        // window first — a 64-bit division by the sweep width was a quarter of this kernel's instructions)
-        const int64_t lim = (int64_t)n_sweeps * kSweep;
-        auto sweep_of = [&](uint32_t rb) -> uint32_t {
+        // window column of reference offset rb, clamped to the window; `before`: how far in front of it
+        auto window_col = [&](uint32_t rb, uint32_t &before) -> uint32_t {
             const int64_t w = base + (int64_t)rb;
-            if (w <= 0) return 0u;
-            if (w > lim) return n_sweeps + 1u;
-            return ((uint32_t)w + kSweep - 1u) / kSweep;
+            before = w >= 0 ? 0u : (-w > (int64_t)0xFFFFFFFFll ? 0xFFFFFFFFu : (uint32_t)(-w));
+            return w < 0 ? 0u : (w > (int64_t)n_cols ? n_cols : (uint32_t)w);
         };
         uint32_t n_runs = 0, prev_kind = 0, ref_carry = 0, q_carry = 0;
+        uint64_t ref_total = 0, q_total = 0;
         bool has_m = false;
         // (op indices relative to the read's first, in 32 bits: a record's cigar has fewer than 2^32 ops)
         const uint32_t n_ops = (uint32_t)min(c_end - c_beg, (uint64_t)0xFFFFFF00u);
@@ -169,8 +167,8 @@ __global__ __launch_bounds__(256) void cigar_runs_kernel(uint64_t n_reads, const
             uint32_t kind[2], rl[2], ql[2];
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
-                // what an op does, from three constants indexed by its code (a chain of comparisons per property was a fifth of
-                // this kernel): D N = X consume the reference, I S = X the query; kind 1 for = X, 2 for D, 3 for N
+                // what an op does, from three constants indexed by its code: D N = X consume the reference, I S = X the query;
+                // kind 1 for = X, 2 for D, 3 for N
                 const uint32_t op = cw[t] & 15u, len = cw[t] >> 4;   // (a missing op is the word 0: length 0, which is nothing)
                 constexpr uint32_t kRefOps = (1u << 2) | (1u << 3) | (1u << 7) | (1u << 8);
                 constexpr uint32_t kQueryOps = (1u << 1) | (1u << 4) | (1u << 7) | (1u << 8);
@@ -180,8 +178,16 @@ __global__ __launch_bounds__(256) void cigar_runs_kernel(uint64_t n_reads, const
                 kind[t] = len == 0u ? 0u : (kKinds >> (2u * op)) & 3u;
                 has_m = has_m || (op == 0u && (k0 + 2u * lane + (uint32_t)t) < n_ops);
             }
-            uint32_t ri = rl[0] + rl[1], qi = ql[0] + ql[1];
+            const uint32_t rsum = rl[0] + rl[1], qsum = ql[0] + ql[1];
+            uint32_t ri = rsum, qi = qsum;
             wave_scan2(ri, qi);   // inclusive, per lane pair
+            if (__ballot((cw[0] | cw[1]) >= (1u << 29)) != 0ull) {   // an op of 2^25 bases or more: the step's sums may have wrapped
+                ref_total += wave_sum64(rl[0]) + wave_sum64(rl[1]);
+                q_total += wave_sum64(ql[0]) + wave_sum64(ql[1]);
+            } else {
+                ref_total += (uint32_t)__builtin_amdgcn_readlane((int)ri, 63);
+                q_total += (uint32_t)__builtin_amdgcn_readlane((int)qi, 63);
+            }
             // the kind of the op before this lane's first one: the previous lane's second op
             uint32_t before = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)kind[1], 0x138, 0xF, 0xF, false);   // wave_shr:1
             if (lane == 0) before = prev_kind;
@@ -191,18 +197,22 @@ __global__ __launch_bounds__(256) void cigar_runs_kernel(uint64_t n_reads, const
             // run starts in the lanes before this one (v_mbcnt: the set bits of a mask below the lane, with an addend)
             const uint32_t ahead = __builtin_amdgcn_mbcnt_hi((uint32_t)(b1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b1,
                                    __builtin_amdgcn_mbcnt_hi((uint32_t)(b0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b0, 0u))));
-            const uint32_t rbeg0 = ref_carry + ri - rl[0] - rl[1], qbeg0 = q_carry + qi - ql[0] - ql[1];
+            const uint32_t rbeg0 = ref_carry + ri - rsum, qbeg0 = q_carry + qi - qsum;
             if (st0) {
-                const uint32_t idx = n_runs + ahead;
-                const uint32_t rb = rbeg0 & kRunMask;
-                out[idx] = make_uint2(rb | (kind[0] << 30), qbeg0);
-                if (idx >= 1u) atomicAdd(&hist[sweep_of(rb)], 1u);
+                const uint32_t idx = 1u + n_runs + ahead;
+                uint32_t bf;
+                const uint32_t w = window_col(rbeg0, bf);
+                const uint2 e = make_uint2(w | (kind[0] << 30), qbeg0 + bf);
+                out[idx] = e;
+                if (idx < kRunsLds) s_run[q][idx] = e;
             }
             if (st1) {
-                const uint32_t idx = n_runs + ahead + (st0 ? 1u : 0u);
-                const uint32_t rb = (rbeg0 + rl[0]) & kRunMask;
-                out[idx] = make_uint2(rb | (kind[1] << 30), qbeg0 + ql[0]);
-                if (idx >= 1u) atomicAdd(&hist[sweep_of(rb)], 1u);
+                const uint32_t idx = 1u + n_runs + ahead + (st0 ? 1u : 0u);
+                uint32_t bf;
+                const uint32_t w = window_col(rbeg0 + rl[0], bf);
+                const uint2 e = make_uint2(w | (kind[1] << 30), qbeg0 + ql[0] + bf);
+                out[idx] = e;
+                if (idx < kRunsLds) s_run[q][idx] = e;
             }
             n_runs += (uint32_t)__popcll(b0) + (uint32_t)__popcll(b1);
             prev_kind = (uint32_t)__builtin_amdgcn_readlane((int)kind[1], 63);   // (only a full step has a successor)
@@ -211,40 +221,116 @@ __global__ __launch_bounds__(256) void cigar_runs_kernel(uint64_t n_reads, const
         }
         uint32_t code = __ballot(has_m) != 0ull ? 1u : 0u;
         if (!code) {
-            const uint64_t so0 = seq_off[r], so1 = seq_off[r + 1];
-            if ((uint64_t)q_carry > 2u * (so1 - so0)) code = 2u;
-            else if (qual_off && (uint64_t)q_carry > qual_off[r + 1] - qual_off[r]) code = 3u;
+            const uint64_t n_bases = 2u * (lane64(so_l, (int)q + 1) - lane64(so_l, (int)q));
+            if (q_total > n_bases || q_total > 0x7FFFFFFFull) code = 2u;
+            else if (qual_off && q_total > lane64(qo_l, (int)q + 1) - lane64(qo_l, (int)q)) code = 3u;
+            else if (ref_total > (uint64_t)kRunMask) code = 4u;
         }
+        uint32_t end_col = 0;
         if (code) {
             n_runs = 0;
             if (lane == 0) atomicMin(bad, ((unsigned long long)r << 8) | code);
+        } else {
+            uint32_t bf;
+            end_col = window_col((uint32_t)ref_total, bf);
         }
-        if (lane == 0) {
-            out[n_runs] = make_uint2(ref_carry & kRunMask, q_carry);
-            nruns[r] = n_runs;
-            if (n_runs) atomicAdd(&hist[sweep_of(ref_carry & kRunMask)], 1u);
+        if (lane < 3u) {
+            const uint32_t idx = lane == 0u ? 0u : n_runs + lane;
+            const uint2 e = lane == 0u ? make_uint2(3u << 30, 0u) : lane == 1u ? make_uint2(end_col | (3u << 30), (uint32_t)q_total) : make_uint2(kRunMask | (3u << 30), 0u);
+            out[idx] = e;
+            if (idx < kRunsLds) s_run[q][idx] = e;
+            if (lane == 0u) nruns[r] = n_runs;
         }
-        __builtin_amdgcn_wave_barrier();
-        uint32_t carry = 0;
-        for (uint32_t s0 = 0; s0 <= n_sweeps; s0 += 64u) {
-            const uint32_t s = s0 + lane;
-            const uint32_t v = wave_scan((s <= n_sweeps && !code) ? hist[s] : 0u);
-            if (s <= n_sweeps) first_run[r * (uint64_t)(n_sweeps + 1u) + s] = carry + v;
-            carry += (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+        n_runs_of[q] = n_runs;
+    }
+    // ---- the descriptors: a row of sixteen lanes per read, a lane per sweep (fifteen sweeps a pass: a sweep needs the bound of
+    // the next one too).  Entries beyond the LDS copy are read back from HBM: past this wave's own stores.
+    uint32_t n_max = 0;
+#pragma unroll
+    for (uint32_t q = 0; q < kRunsReadsPerWave; ++q) n_max = max(n_max, n_runs_of[q]);
+    if (n_max + 3u > kRunsLds) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t q = lane >> 4, sl = lane & 15u;
+    const uint64_t r = r0 + q;
+    const bool live = r < n_reads;
+    uint32_t n_ent_all = 3u;          // entries of this lane's read
+#pragma unroll
+    for (uint32_t t = 0; t < kRunsReadsPerWave; ++t)
+        if (q == t) n_ent_all = n_runs_of[t] + 3u;
+    uint64_t my_cb = cb[0], my_so = lane64(so_l, 0);
+#pragma unroll
+    for (uint32_t t = 1; t < kRunsReadsPerWave; ++t)
+        if (q == t) {
+            my_cb = cb[t];
+            my_so = lane64(so_l, (int)t);
         }
-        __builtin_amdgcn_wave_barrier();
+    const uint64_t ent0 = my_cb + 3u * r;     // index of the read's entry 0 in runs[]
+    auto entry = [&](uint32_t i) -> uint2 {
+        if (i < kRunsLds) return s_run[q][i];
+        const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(runs + ent0 + i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return make_uint2((uint32_t)v, (uint32_t)(v >> 32));
+    };
+    uint32_t top = 1u;                         // the highest power of two not above the longest list
+    while (2u * top <= n_max + 3u) top *= 2u;
+    for (uint32_t s0 = 0; s0 < n_sweeps; s0 += kDescSweeps) {
+        const uint32_t s = s0 + sl;
+        // f = the number of entries that begin at or before the sweep's first column (entry 0 always does, the last never)
+        const uint32_t X = min(s, n_sweeps) * kSweep;   // (lanes past the last bound repeat it)
+        uint32_t f = 0;
+        for (uint32_t step = top; step; step >>= 1) {
+            const uint32_t t = f + step;
+            if (live && t <= n_ent_all && (entry(t - 1u).x & kRunMask) <= X) f = t;
+        }
+        uint32_t f_next = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)f, 0x101, 0xF, 0xF, false);   // row_shl:1
+        if (!live || sl == kDescSweeps || s >= n_sweeps) continue;
+        const uint32_t Xend = min(n_cols, X + kSweep);
+        const uint32_t lo = f - 1u;
+        uint32_t n_ent = f_next - f + 2u;
+        uint32_t q_lo = 0xFFFFFFFFu, q_hi = 0;
+        uint2 e = entry(lo);
+        const uint2 first = e;
+        if (n_ent >= kDescMax) n_ent = kDescMax;
+        else {
+            for (uint32_t i = lo; i + 1u < lo + n_ent; ++i) {
+                const uint2 nx = entry(i + 1u);
+                if ((e.x >> 30) == 1u) {
+                    const uint32_t W = e.x & kRunMask, ca = max(W, X), cbv = min(nx.x & kRunMask, Xend);
+                    if (ca < cbv) {
+                        q_lo = min(q_lo, e.y + (ca - W));
+                        q_hi = max(q_hi, e.y + (cbv - W));
+                    }
+                }
+                e = nx;
+            }
+        }
+        uint64_t piece = 0;
+        uint32_t np = 0;
+        int32_t q0 = 0;
+        if (q_lo < q_hi) {
+            const uint64_t byte_lo = my_so + (q_lo >> 1), byte_hi = my_so + ((uint64_t)q_hi + 1u) / 2u;
+            const uint64_t p0 = byte_lo & ~(uint64_t)15;
+            piece = p0 >> 4;
+            np = (uint32_t)min((byte_hi - p0 + 15u) >> 4, (uint64_t)kDescMax);
+            q0 = (int32_t)(2 * ((int64_t)p0 - (int64_t)my_so));
+        }
+        const uint64_t e_idx = ent0 + lo;
+        uint4 d;
+        d.x = (uint32_t)piece;
+        d.z = (uint32_t)q0;
+        if (n_ent == 2u) {
+            // ONE entry covers the whole sweep (three reads in four of a CCS sample): the planes kernel needs no entries for it —
+            // what the entry is, and the query offset of the sweep's first column
+            d.y = first.y + (X - (first.x & kRunMask));
+            d.w = (uint32_t)((piece >> 32) & 0xFFu) | ((first.x >> 30) << 8) | (np << 16) | (1u << 24);
+        } else {
+            d.y = (uint32_t)e_idx;
+            d.w = (uint32_t)((piece >> 32) & 0xFFu) | ((uint32_t)((e_idx >> 32) & 0xFFu) << 8) | (np << 16) | (n_ent << 24);
+        }
+        desc[(uint64_t)s * n_reads + r] = d;
     }
 }
 
 // ---------------------------------------------------------------------------------------- the planes of one sweep
-struct read_info {     // what the expansion needs of one read of the tile (LDS)
-    int32_t base;      // window column of the read's first reference base
-    uint32_t ent;      // first entry in s_ent (bits 0-11) | entries (12-21) | pieces (22-31)
-    uint32_t p0_lo, p0_hi;   // byte offset, within the packed bases, of the read's first 16-byte piece in this sweep
-    int32_t q0;        // query offset of that piece's first base (>= -30: a piece may begin inside the previous read)
-    uint32_t pad_;
-};
-
 // 8 x 8 nibbles held as 8 dwords (row i = m[i], element j at bits 4j) -> their transpose
 __device__ __forceinline__ void transpose_nibbles_8x8(uint32_t (&m)[8])
 {
@@ -283,8 +369,7 @@ __device__ __forceinline__ void nibble_rows_to_plane_words(const uint32_t (&R)[3
         transpose_nibbles_8x8(M[g]);
     }
     // Plane k of column j wants, in nibble n, bit k of the four blocks' nibbles n (reads 4 n .. 4 n + 3): a 4 x 4 bit transpose
-    // between the four words, in every nibble at once — two rounds of masked swaps, 24 operations a column where pulling
-    // each bit out and shifting it into place took 33.
+    // between the four words, in every nibble at once — two rounds of masked swaps.
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         uint32_t a0 = M[0][j], a1 = M[1][j], a2 = M[2][j], a3 = M[3][j], t;
@@ -300,53 +385,85 @@ __device__ __forceinline__ void nibble_rows_to_plane_words(const uint32_t (&R)[3
 
 struct ingest_args {
     uint64_t n_reads;
-    uint32_t n_cols, n_sweeps, n_groups, n_pairs;   // n_groups: groups of 1024 reads (the tiles that share lines); n_pairs = n_groups * n_sweeps
-    uint32_t win_begin, min_qv;
-    const int32_t *pos;
-    const uint64_t *cig_off;
+    uint32_t n_cols, n_sweeps, n_groups;   // n_groups: groups of 1024 reads (the tiles that share lines)
+    uint32_t min_qv;
+    const uint64_t *cig_off;     // (the slow kernel: where a read's entries begin)
     const uint8_t *seq4;
-    const uint64_t *seq_off;
+    const uint64_t *seq_off;     // (the slow kernel)
     const uint8_t *qual;         // null: no QV masking
     const uint64_t *qual_off;
     const uint2 *runs;
-    const uint32_t *nruns, *first_run;
+    const uint32_t *nruns;
+    const uint4 *desc;
     uint32_t *slow_count;
     uint2 *slow_list;            // {read, sweep}
     uint8_t *msa;
     uint64_t plane_stride;
-    uint32_t skip;               // tuning builds: bit 0 no bases, bit 1 no deletions, bit 2 no stores, bit 3 no second pass, bit 4 no transposing
+    uint64_t seq_bytes, n_entries;   // (tuning builds check every address a descriptor leads to against these and report in dbg[])
+    uint32_t *dbg;
+    uint32_t skip;               // tuning builds: bit 0 no bases, bit 1 no table, bit 2 no stores, bit 3 no general pass, bit 4 no transposing, bit 6 no conversion
 };
 #ifdef JL_TUNING
 #define JL_ING_SKIP(a, bit) (((a).skip >> (bit)) & 1u)
+// an address that would leave its array: counted in dbg[code], the offending value kept in dbg[6 + code]; the access is redirected
+#define JL_ING_CHECK(a, ok, code, value, fix) \
+    if (!(ok)) {                               \
+        atomicAdd(&(a).dbg[code], 1u);         \
+        (a).dbg[6 + (code)] = (uint32_t)(value); \
+        fix;                                   \
+    }
 #else
 #define JL_ING_SKIP(a, bit) 0u
+#define JL_ING_CHECK(a, ok, code, value, fix)
 #endif
 
-constexpr int kPiece = 64;     // bases a lane expands at a time: 32 bytes of packed bases (two 16-byte loads)
+// LDS of a planes workgroup.  The staging area holds dwords of eight codes; a NIBBLE address into it fits 16 bits:
+//   dwords 0-1 'not covered' twice, 2-3 '-' twice (what a table entry of a block nothing / a deletion covers points at),
+//   4 .. 4 + kSideCap  the blocks the general loop puts together (one dword each),
+//   kRowBase ..        the reads' codes in query order, a 16-byte piece after the other.
+#ifndef JL_INGEST_SIDE
+#define JL_INGEST_SIDE 380
+#endif
+constexpr uint32_t kSideCap = JL_INGEST_SIDE;
+constexpr uint32_t kRowBase = 4u + kSideCap;
+#ifndef JL_INGEST_PIECES_X2
+#define JL_INGEST_PIECES_X2 17            // pieces per read and sweep the staging area has room for, times two (8.5: a sweep of
+#endif                                    // 224 columns is 8 pieces of a read from a 16-byte boundary on, insertions aside)
+constexpr uint32_t kPieceCap = kTileReads * JL_INGEST_PIECES_X2 / 2u;
+constexpr uint32_t kStageDw = kRowBase + 4u * kPieceCap + 4u;
+#ifndef JL_INGEST_ENT_PER_READ
+#define JL_INGEST_ENT_PER_READ 4
+#endif
+constexpr uint32_t kEntCap = JL_INGEST_ENT_PER_READ * kTileReads;   // entries of the reads that need them (a CCS read: 4 in a sweep with an indel)
+// the table: 32 entries (16 bits) a read — rows on 8-byte boundaries for the four-entries-at-a-time stores of the common case —
+// and 8 dwords of padding per 32 reads: the four 32-read groups of a wave's lanes read it 8 banks apart
+constexpr uint32_t kTabRow = 32u, kTabGroupPad = 16u;
+static_assert(kBlocks <= kTabRow, "a sweep is at most 32 blocks wide");
+constexpr uint32_t kTabSize = kTileReads * kTabRow + kTileGroups * kTabGroupPad;
+__device__ __forceinline__ uint32_t tab_row(uint32_t j) { return j * kTabRow + (j >> 5) * kTabGroupPad; }
+constexpr uint32_t kLanesPerRead = 8u;           // lanes that fetch a read's pieces together (8 x 16 bytes = a sweep's 112 bytes + alignment)
+static_assert(kRowBase % 4u == 0 && kStageDw * 8u <= 65536u, "16-byte pieces; 16-bit nibble addresses");
+static_assert((kTileReads * kLanesPerRead) % kThreads == 0, "whole rounds of the fetch");
+constexpr uint32_t kFetchRounds = kTileReads * kLanesPerRead / kThreads;
 
-// the nibbles [lo, hi) of the 64 a piece holds, as four 64-bit masks (part k = nibbles 16 k .. 16 k + 15)
-__device__ __forceinline__ uint64_t range_mask16(int lo, int hi, int k)
-{
-    const int l = min(max(lo - 16 * k, 0), 16), h = min(max(hi - 16 * k, 0), 16);
-    if (h <= l) return 0ull;
-    const uint64_t upto = h == 16 ? ~0ull : ((1ull << (4 * h)) - 1ull);
-    return upto & ~((1ull << (4 * l)) - 1ull);
-}
+struct read_info {          // what the later phases need of one read of the tile (LDS, 16 bytes)
+    uint32_t piece_lo;      // index of its first 16-byte piece, low 32 bits
+    uint32_t piece_hi_np;   // bits 32-39 of that | pieces << 8 | first entry in s_ent << 16
+    uint32_t row_nent;      // first dword of its pieces in the staging area | entries in s_ent << 16 (0: its table row is final)
+    int32_t nb;             // staging nibble address of its query offset 0 (row * 8 - q0)
+};
 
-// 32 bytes of packed bases (BAM order: first base in the high nibble) -> 64 symbol codes, base b in nibble b & 7 of S[b >> 3];
-// QV: bases whose quality is below min_qv become N.  Q = query offset of the piece's base 0, lo_v = its first base that is
-// the read's own.
+// 16 bytes of packed bases (BAM order: first base in the high nibble) -> 32 symbol codes, base b in nibble b & 7 of S[b >> 3];
+// QV: bases whose quality is below min_qv become N.  Q = query offset of the piece's base 0 (negative: the first -Q bases are
+// not the read's own).
 template <bool QV>
-__device__ __forceinline__ void piece_syms(const ingest_args &a, const uint4 &v0, const uint4 &v1, int Q, int lo_v, uint64_t qual_base,
-                                           uint32_t (&S)[8])
+__device__ __forceinline__ void piece_syms(const ingest_args &a, const u32x4 &v, int Q, uint64_t qual_base, uint32_t (&S)[4])
 {
-    const uint32_t w8[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+    const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
     // BAM's 4-bit base -> symbol code by table: A C G T (1 2 4 8) -> 0..3, everything else (N = 15, '=' = 0, the IUPAC
     // ambiguity codes) -> N, a filtered base.  v_perm_b32 looks four bytes up in an 8-byte table: the low three bits of a
     // base select in the table of the codes 0..7 and in that of 8..15, bit 3 picks between the two results.  The first base
     // of a byte is its HIGH nibble and goes to the lower column: the two halves are put together the other way round.
-    // (Counting the set bits of every nibble, mapping one-hot to index and patching the rest was 29 instructions a dword,
-    // and two pieces in three hold an N; this is 18.)
     constexpr uint32_t kLo03 = 0x05010005u, kLo47 = 0x05050502u;   // codes of 0..3 (bytes 0..3), of 4..7
     constexpr uint32_t kHi03 = 0x05050503u, kHi47 = 0x05050505u;   // codes of 8..11, of 12..15
     auto lookup4 = [&](uint32_t x) -> uint32_t {   // four bases, one per byte (0..15) -> four codes
@@ -357,333 +474,321 @@ __device__ __forceinline__ void piece_syms(const ingest_args &a, const uint4 &v0
         return (hi & pick) | (lo & ~pick);
     };
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const uint32_t first = lookup4((w8[k] >> 4) & 0x0F0F0F0Fu), second = lookup4(w8[k] & 0x0F0F0F0Fu);
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t first = lookup4((w4[k] >> 4) & 0x0F0F0F0Fu), second = lookup4(w4[k] & 0x0F0F0F0Fu);
         S[k] = first | (second << 4);
     }
     if (QV) {
         // qualities of the piece's bases, one byte each, from the aligned dwords around them; a base below min_qv
         // becomes N (0xFF = absent never does)
+        const int lo_v = Q < 0 ? -Q : 0;
         const uint64_t addr = qual_base + (uint64_t)(Q + lo_v);    // first quality wanted
         const uint32_t *qp = reinterpret_cast<const uint32_t *>(a.qual + (addr & ~(uint64_t)3));
         const uint32_t sh = (uint32_t)(addr & 3u);
-        uint32_t qw[17];
+        uint32_t qw[9];
 #pragma unroll
-        for (int i = 0; i < 17; ++i) qw[i] = qp[i];
+        for (int i = 0; i < 9; ++i) qw[i] = qp[i];
         const uint32_t T = a.min_qv * 0x01010101u;
-        uint64_t flags = 0;   // bit b: base lo_v + b is masked
+        uint32_t flags = 0;   // bit b: base lo_v + b is masked
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
+        for (int i = 0; i < 8; ++i) {
             const uint32_t x = __builtin_amdgcn_alignbyte(qw[i + 1], qw[i], sh);
             const uint32_t lt = ~((x | 0x80808080u) - T) & 0x80808080u;       // bytes below min_qv (and below 128)
             uint32_t f = lt >> 7;
             f = (f | (f >> 7)) & 0x00030003u;
             f = (f | (f >> 14)) & 0xFu;
-            flags |= (uint64_t)f << (4 * i);
+            flags |= f << (4 * i);
         }
-        flags <<= lo_v;   // by the piece's own base index (bases past 64 drop out)
+        flags <<= lo_v;   // by the piece's own base index (bases past 32 drop out; lo_v <= 30)
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            uint32_t b = (uint32_t)(flags >> (8 * k)) & 0xFFu;
+        for (int k = 0; k < 4; ++k) {
+            uint32_t b = (flags >> (8 * k)) & 0xFFu;
             b = (b | (b << 12)) & 0x000F000Fu;
             b = (b | (b << 6)) & 0x03030303u;
             b = (b | (b << 3)) & 0x11111111u;
-            const uint32_t mk = b * 15u;
+            const uint32_t mk = (b << 4) - b;   // 15 x b
             S[k] = (S[k] & ~mk) | ((uint32_t)JL_SYM_MASK * 0x11111111u & mk);
         }
     }
 }
 
-// The part of a piece (bases Q .. Q + 63 of the read, the first lo_v of them not its own) that lies in ONE run of aligned
-// bases {rb, q, len} and inside the sweep goes into the tile row: XOR against 'not covered', shifted to its columns.
-// s_row may be XORed up to eight dwords before and behind the row's own: the payload there is zero (the guard dwords of
-// the tile take what would fall outside it).
-__device__ __forceinline__ void emit_run(const uint32_t (&S)[8], int Q, int lo_v, int rb, int q, int len, int base, int X, int Xend, uint32_t *s_row)
-{
-    const int qa = max(q, Q + lo_v), qe = min(q + len, Q + kPiece);
-    if (qa >= qe) return;
-    const int col_a = base + rb + (qa - q);                 // window column of base qa
-    const int ca = max(col_a, X), cb = min(col_a + (qe - qa), Xend);
-    if (ca >= cb) return;
-    const int lo = qa - Q + (ca - col_a), hi = lo + (cb - ca);   // the piece's bases [lo, hi) go to tile columns ca - X ...
-    const int delta = (ca - X) - lo;                              // tile column of the piece's base 0
-    const uint32_t s4 = 4u * (uint32_t)(delta & 7);
-    const int dd = delta >> 3;
-    uint32_t P[10];
-    P[0] = 0; P[9] = 0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const uint64_t mk = range_mask16(lo, hi, k);
-        P[2 * k + 1] = (S[2 * k] ^ 0x66666666u) & (uint32_t)mk;
-        P[2 * k + 2] = (S[2 * k + 1] ^ 0x66666666u) & (uint32_t)(mk >> 32);
-    }
-    // Dword j of the row's part takes {P[j + 1], P[j]} >> (32 - s4).  v_alignbit_b32 does that in one instruction for shifts
-    // below 32; with s4 = 0 it returns P[j] — the value that belongs one dword further down — so the destination moves
-    // instead (P[0] = 0 lands in the guard).  (As 64-bit shifts these were two instructions and two moves each.)
-    uint32_t *dst = s_row + dd - (s4 == 0u ? 1 : 0);
-    const uint32_t sh = (32u - s4) & 31u;
-#pragma unroll
-    for (int j = 0; j < 9; ++j) atomicXor(&dst[j], __builtin_amdgcn_alignbit(P[j + 1], P[j], sh));
-}
-
-// every run from entry i on that the piece reaches (the general form: pieces that cross a run boundary, or begin in a gap)
-__device__ __forceinline__ void emit_rest(const uint32_t (&S)[8], int Q, int lo_v, const uint2 *ent, uint32_t i, uint32_t cnt, int base, int X,
-                                          int Xend, uint32_t *s_row)
-{
-    for (; i < cnt; ++i) {
-        const uint2 e = ent[i];
-        const int q = (int)e.y;
-        if (q >= Q + kPiece) break;
-        if ((e.x >> 30) != 1u) continue;
-        const int rb = (int)(e.x & kRunMask);
-        emit_run(S, Q, lo_v, rb, q, (int)(ent[i + 1u].x & kRunMask) - rb, base, X, Xend, s_row);
-    }
-}
-
-constexpr uint32_t kListCap = 2u * kTileReads;     // pieces a workgroup defers to its second pass
-
 template <bool QV>
 __global__ __launch_bounds__(kThreads) void ingest_planes_kernel(ingest_args a)
 {
-    __shared__ uint32_t s_tile_g[kTileDw + 24u];   // guard dwords: 8 in front, 16 behind (see emit_run)
+    __shared__ __attribute__((aligned(16))) uint32_t s_stage[kStageDw];
+    __shared__ __attribute__((aligned(16))) uint16_t s_tab[kTabSize];
     __shared__ uint2 s_ent[kEntCap];
     __shared__ read_info s_info[kTileReads];
     __shared__ uint32_t s_qlo[QV ? kTileReads : 1], s_qhi[QV ? kTileReads : 1];   // qual_off of every read
-    __shared__ uint32_t s_list[kListCap];
-    __shared__ uint32_t s_wsum[4], s_nlist;
-    uint32_t *s_tile = s_tile_g + 8;
+    __shared__ uint16_t s_list[kSideCap];
+    __shared__ uint8_t s_walk[kTileReads];        // the reads whose table rows come from a walk over their entries
+    __shared__ uint8_t s_over[kTileReads];        // the read's boundary blocks did not all fit the side dwords: the slow kernel takes it
+    __shared__ uint32_t s_wsum[2][kWaves], s_nlist;
     const uint32_t tid = threadIdx.x, wid = tid >> 6, lane = tid & 63u;
     // block -> (read tile, sweep).  Blocks b, b + 8, b + 16, ... are dealt to the same XCD one after the other; an XCD takes
     // whole groups of 1024 reads (group = xcd, xcd + 8, ...), and of a group all sweeps in turn, the tiles of the group
-    // innermost.  So (a) the tiles that share the 128-byte lines of a sweep's planes meet in one L2, and (b) everything the
-    // sweeps of a group read again — the reads' offsets, run entries and per-sweep run indices, and the 128-byte lines of
-    // packed bases that straddle two sweeps (a sweep is 112 bytes of a read: 2.1 x the bases were fetched) — is in that L2
-    // when the next sweep asks for it: the prologue's scattered loads become L2 hits.
-    const uint32_t b = blockIdx.x, xcd = b & 7u, jb = b >> 3, sub = jb % kSubTiles, q = jb / kSubTiles;
-    const uint32_t group = xcd + 8u * (q / a.n_sweeps), sweep = q % a.n_sweeps;
+    // innermost.  So (a) the tiles that share the 128-byte lines of a sweep's planes meet in one L2, and (b) what the
+    // sweeps of a group read again — the reads' entries, the 128-byte lines of packed bases that straddle two sweeps — is
+    // in that L2 when the next sweep asks for it.
+    const uint32_t b = blockIdx.x, xcd = b & 7u, jb = b >> 3, sub = jb % kSubTiles, qq = jb / kSubTiles;
+    const uint32_t group = xcd + 8u * (qq / a.n_sweeps), sweep = qq % a.n_sweeps;
     if (group >= a.n_groups) return;
     const uint32_t tile = kSubTiles * group + sub;
     const int X = (int)(sweep * kSweep), Xend = (int)min(a.n_cols, sweep * kSweep + kSweep);
     const uint64_t r = (uint64_t)tile * kTileReads + tid;
     const bool real = tid < kTileReads && r < a.n_reads;
 
-    // ---- 0. what this read has in the sweep (the loads fly while the tile is set to 'not covered')
-    uint32_t f0 = 0, f1 = 0, nr = 0;
-    uint64_t co = 0, so = 0;
-    int32_t p = 0;
+    // ---- 0. one request per read: its descriptor
+    uint4 d = make_uint4(0, 0, 0, 3u << 8 | 1u << 24);   // (no read: one entry of nothing)
     if (real) {
-        // (the two indices in one request: every scattered request of the prologue shows in the kernel's time)
-        const uint32_t *fr = a.first_run + r * (uint64_t)(a.n_sweeps + 1u) + sweep;
-        typedef uint32_t u32x2 __attribute__((ext_vector_type(2), aligned(4)));
-        const u32x2 f01 = *reinterpret_cast<const u32x2 *>(fr);
-        f0 = f01.x;
-        f1 = f01.y;
-        nr = a.nruns[r];
-        co = a.cig_off[r];
-        so = a.seq_off[r];
-        p = a.pos[r];
+        d = a.desc[(uint64_t)sweep * a.n_reads + r];
         if (QV) {
             const uint64_t qo = a.qual_off[r];
             s_qlo[tid] = (uint32_t)qo;
             s_qhi[tid] = (uint32_t)(qo >> 32);
         }
     }
-    for (uint32_t i = tid; i < kTileDw + 24u; i += kThreads) s_tile_g[i] = 0x66666666u;
+    if (tid < 4u) s_stage[tid] = tid < 2u ? 0x66666666u : 0x44444444u;
     if (tid == 0) s_nlist = 0;
-    uint32_t cnt = 0;
-    if (real && nr && f0 < nr) cnt = min(f1, nr - 1u) - f0 + 1u;
-    uint32_t need = cnt ? cnt + 1u : 0u;   // + the entry behind the last run: its end
-    // exclusive scan of `need` over the workgroup
-    const uint32_t inc = wave_scan(need);
-    if (lane == 63u) s_wsum[wid] = inc;
+    if (tid < kTileReads) s_over[tid] = 0;
+    uint32_t np = (d.w >> 16) & 0xFFu, n_ent = d.w >> 24;
+    bool slow = np == kDescMax || n_ent == kDescMax;
+    const bool simple = n_ent == 1u || slow;      // its table row is one entry's: written here
+    if (simple) n_ent = 0;
+    if (slow) np = 0;
+    // exclusive scans over the workgroup: of the entries (and, sixteen bits up, of the reads that have some), of the pieces
+    uint32_t inc_e = n_ent | (n_ent ? 1u << 16 : 0u), inc_p = np;
+    const uint32_t own_e = inc_e;
+    wave_scan2(inc_e, inc_p);
+    if (lane == 63u) {
+        s_wsum[0][wid] = inc_e;
+        s_wsum[1][wid] = inc_p;
+    }
     __syncthreads();
-    uint32_t off = inc - need;
-    for (uint32_t w = 0; w < wid; ++w) off += s_wsum[w];
-    bool slow = need != 0u && (cnt > 1022u || off + need > kEntCap);
-    const uint2 *src = a.runs + co + r + f0;
-    if (need && !slow) {
-        // (the first four entries in two 16-byte requests that go out together — a load-store loop pays a trip to HBM per
-        // entry; entries past `need` belong to the next read or to the array's slack)
-        typedef uint32_t u32x4a8 __attribute__((ext_vector_type(4), aligned(8)));
-        const u32x4a8 e01 = *reinterpret_cast<const u32x4a8 *>(src), e23 = *reinterpret_cast<const u32x4a8 *>(src + 2);
-        const uint2 e4[4] = {make_uint2(e01.x, e01.y), make_uint2(e01.z, e01.w), make_uint2(e23.x, e23.y), make_uint2(e23.z, e23.w)};
-#pragma unroll
-        for (uint32_t i = 0; i < 4u; ++i)
-            if (i < need) s_ent[off + i] = e4[i];
-        for (uint32_t i = 4; i < need; ++i) s_ent[off + i] = src[i];
-    }
-    // the bases the sweep takes of this read: query range -> 16-byte pieces of its packed bases
-    const int base = (int)((int64_t)p - (int64_t)a.win_begin);
-    uint32_t q_lo = 0xFFFFFFFFu, q_hi = 0;
-    if (need && !slow) {
-        for (uint32_t i = 0; i < cnt; ++i) {
-            const uint2 e = s_ent[off + i];
-            if ((e.x >> 30) != 1u) continue;
-            const int rb = (int)(e.x & kRunMask), len = (int)(s_ent[off + i + 1u].x & kRunMask) - rb;
-            const int W = base + rb;
-            const int ca = max(W, X), cb = min(W + len, Xend);
-            if (ca >= cb) continue;
-            q_lo = min(q_lo, e.y + (uint32_t)(ca - W));
-            q_hi = max(q_hi, e.y + (uint32_t)(cb - W));
+    uint32_t off_e = inc_e - own_e, off_p = inc_p - np, n_walk = 0;
+    for (uint32_t w = 0; w < kWaves; ++w) {
+        const uint32_t we = s_wsum[0][w];
+        if (w < wid) {
+            off_e += we;
+            off_p += s_wsum[1][w];
         }
+        n_walk += we >> 16;
     }
-    uint32_t np = 0;
-    uint64_t p0 = 0;
-    int32_t q0 = 0;
-    if (q_lo < q_hi) {
-        const uint64_t byte_lo = so + (q_lo >> 1), byte_hi = so + ((uint64_t)q_hi + 1u) / 2u;
-        p0 = byte_lo & ~(uint64_t)15;
-        const uint64_t n = (byte_hi - p0 + 31u) >> 5;                // pieces of 32 bytes from a 16-byte boundary on
-        q0 = (int32_t)(2 * ((int64_t)p0 - (int64_t)so));
-        if (n > kMaxPieces) slow = true;   // (an insertion of tens of thousands of bases inside the sweep)
-        else np = (uint32_t)n;
+    const uint32_t walk_at = off_e >> 16;
+    off_e &= 0xFFFFu;
+    if ((n_ent && off_e + n_ent > kEntCap) || (np && off_p + np > kPieceCap)) {
+        slow = true;
+        np = n_ent = 0;
     }
+    JL_ING_CHECK(a, !slow || real, 3, r, slow = false)
     if (slow) {
         const uint32_t at = atomicAdd(a.slow_count, 1u);
         a.slow_list[at] = make_uint2((uint32_t)r, sweep);
-        cnt = 0;
-        np = 0;
     }
-    read_info ri;
-    ri.base = base;
-    ri.ent = (off & 0xFFFu) | (cnt << 12) | (np << 22);
-    ri.p0_lo = (uint32_t)p0;
-    ri.p0_hi = (uint32_t)(p0 >> 32);
-    ri.q0 = q0;
-    ri.pad_ = 0;
-    if (tid < kTileReads) s_info[tid] = ri;
-    __syncthreads();
-
-    // ---- 1. deletions: every D run of this read inside the sweep ('-' = 4 = 'not covered' ^ 2)
-    if (tid < kTileReads && !JL_ING_SKIP(a, 1)) {
-        uint32_t *row = s_tile + (tid & 31u) * kRowI + (tid >> 5) * kSweepDw;
-        for (uint32_t i = 0; i < cnt; ++i) {
-            const uint2 e = s_ent[off + i];
-            if ((e.x >> 30) != 2u) continue;
-            const int rb = (int)(e.x & kRunMask), len = (int)(s_ent[off + i + 1u].x & kRunMask) - rb;
-            const int W = base + rb;
-            const int ta = max(W, X) - X, tb = min(W + len, Xend) - X;
-            for (int d = ta >> 3; ta < tb && d <= (tb - 1) >> 3; ++d) {
-                const int l = max(ta - 8 * d, 0), h = min(tb - 8 * d, 8);
-                const uint32_t m = (h - l == 8) ? 0xFFFFFFFFu : (((1u << (4 * (h - l))) - 1u) << (4 * l));
-                atomicXor(&row[d], 0x22222222u & m);
+    // the sweep's entries of this read: the first four in two 16-byte requests that go out together (entries past the
+    // read's own belong to the next read or to the array's slack)
+    typedef uint32_t u32x4a8 __attribute__((ext_vector_type(4), aligned(8)));
+    uint64_t src_at = n_ent ? ((((uint64_t)(d.w >> 8) & 0xFFu) << 32) | d.y) : 0u;
+    JL_ING_CHECK(a, src_at + n_ent + 2u <= a.n_entries, 2, src_at, src_at = 0)
+    const uint2 *src = a.runs + src_at;
+    u32x4a8 e01 = {0, 0, 0, 0}, e23 = {0, 0, 0, 0};
+    if (n_ent) {
+        e01 = *reinterpret_cast<const u32x4a8 *>(src);
+        e23 = *reinterpret_cast<const u32x4a8 *>(src + 2);
+    }
+    if (tid < kTileReads) {
+        const uint32_t row = kRowBase + 4u * off_p;
+        read_info ri;
+        ri.piece_lo = d.x;
+        ri.piece_hi_np = (d.w & 0xFFu) | (np << 8) | (off_e << 16);
+        ri.row_nent = row | (n_ent << 16);
+        ri.nb = (int32_t)(8u * row) - (int32_t)d.z;
+        s_info[tid] = ri;
+        if (own_e) s_walk[walk_at] = (uint8_t)tid;    // (counted before the room was known: a read without entries is skipped there)
+        if (!n_ent) {
+            // one entry covers the sweep: its blocks' addresses rise by eight codes a block (aligned bases) or stay (the
+            // dword of '-', of 'not covered'), four blocks a store
+            const uint32_t kind = slow ? 3u : (d.w >> 8) & 3u;
+            const uint32_t a0 = kind == 1u ? (uint32_t)ri.nb + d.y : kind == 2u ? 16u : 0u, st = kind == 1u ? 8u : 0u;
+            uint32_t lo = a0 | ((a0 + st) << 16), hi = lo + 2u * (st | st << 16);
+            const uint32_t step = 4u * (st | st << 16);
+            uint2 *row_p = reinterpret_cast<uint2 *>(s_tab + tab_row(tid));
+#pragma unroll
+            for (uint32_t k = 0; k < (kBlocks + 3u) / 4u; ++k) {
+                row_p[k] = make_uint2(lo, hi);
+                lo += step;
+                hi += step;
             }
         }
     }
+    __syncthreads();
 
-    // ---- 2. bases.  A wave takes sixteen reads at a time, four 32-byte pieces (64 bases) each — a sweep of 224 columns is
-    // at most four such pieces of a read from a 16-byte boundary on, insertions aside; the loads of a wave's rounds are all
-    // in flight before the first is used.  A lane puts the part of its piece that lies in the FIRST run it touches into the
-    // tile; the pieces that go on into another run (one in seven) are listed and finished in a second pass with full lanes
-    // — in line, the loop over a piece's runs made every wave walk two or three runs for them.
+    // ---- 1. the pieces: eight lanes a read, 16 bytes (32 bases) a lane; all of a thread's requests go out first (a lane without a
+    // piece asks for its read's first one again: the same number of requests in flight in every lane, so that the wait for
+    // the entries below does not wait for the pieces)
+    constexpr uint32_t kReadsPerRound = kThreads / kLanesPerRead;
+    const uint32_t f_slot = tid / kLanesPerRead, f_piece = tid % kLanesPerRead;
+    auto fetch = [&](uint32_t j, uint32_t pc) -> u32x4 {
+        const read_info q = s_info[j];
+        uint64_t at = ((((uint64_t)q.piece_hi_np & 0xFFu) << 32) | q.piece_lo) + (pc < ((q.piece_hi_np >> 8) & 0xFFu) ? pc : 0u);
+        JL_ING_CHECK(a, 16u * at + 16u <= a.seq_bytes + 64u, 1, at, at = 0)
+        // (plain loads: neighbouring lanes' pieces share lines, and so do the sweeps of a read)
+        return *reinterpret_cast<const u32x4 *>(a.seq4 + 16u * at);
+    };
+    auto stage = [&](uint32_t j, uint32_t pc, const u32x4 &v) {
+        const read_info q = s_info[j];
+        if (pc >= ((q.piece_hi_np >> 8) & 0xFFu)) return;
+        const uint32_t row = q.row_nent & 0xFFFFu;
+        const int Q = (int)(8u * row) - q.nb + 32 * (int)pc;        // query offset of the piece's first base
+        uint32_t S[4];
+        const uint64_t qb = QV ? (((uint64_t)s_qhi[j] << 32) | s_qlo[j]) : 0u;
+        if (JL_ING_SKIP(a, 6)) { S[0] = v.x; S[1] = v.y; S[2] = v.z; S[3] = v.w; }
+        else piece_syms<QV>(a, v, Q, qb, S);
+        u32x4 o = {S[0], S[1], S[2], S[3]};
+        *reinterpret_cast<u32x4 *>(&s_stage[row + 4u * pc]) = o;
+    };
+    u32x4 pv[kFetchRounds];
     if (!JL_ING_SKIP(a, 0)) {
-        constexpr uint32_t kReadsPerRound = 64u / kPiecesPerRead;              // reads a wave expands at a time
-        constexpr uint32_t kRounds = kTileReads / (kWaves * kReadsPerRound);   // rounds of a wave
-        const uint32_t slot = lane / kPiecesPerRead, piece = lane % kPiecesPerRead;
-        auto fetch = [&](uint32_t j, uint32_t pc, uint4 &v0, uint4 &v1) {
-            const read_info &q = s_info[j];
-            v0 = make_uint4(0, 0, 0, 0);
-            v1 = v0;
-            if (pc < (q.ent >> 22)) {
-                const uint64_t at = (((uint64_t)q.p0_hi << 32) | q.p0_lo) + 32u * pc;
-                // (plain loads: the two halves of a piece and the neighbouring lanes' pieces share lines, which a
-                // non-temporal load does not keep — 2.3 x the bytes crossed the HBM with them)
-                const u32x4 t0 = *reinterpret_cast<const u32x4 *>(a.seq4 + at);
-                const u32x4 t1 = *reinterpret_cast<const u32x4 *>(a.seq4 + at + 16u);
-                v0 = make_uint4(t0.x, t0.y, t0.z, t0.w);
-                v1 = make_uint4(t1.x, t1.y, t1.z, t1.w);
-            }
-        };
-        auto expand = [&](uint32_t j, uint32_t pc, const uint4 &v0, const uint4 &v1) {
+#pragma unroll
+        for (uint32_t it = 0; it < kFetchRounds; ++it) pv[it] = fetch(it * kReadsPerRound + f_slot, f_piece);
+    }
+    // the entries -> LDS (they were asked for before the pieces)
+    if (n_ent) {
+        const uint2 e4[4] = {make_uint2(e01.x, e01.y), make_uint2(e01.z, e01.w), make_uint2(e23.x, e23.y), make_uint2(e23.z, e23.w)};
+#pragma unroll
+        for (uint32_t i = 0; i < 4u; ++i)
+            if (i < n_ent) s_ent[off_e + i] = e4[i];
+        for (uint32_t i = 4; i < n_ent; ++i) s_ent[off_e + i] = src[i];
+    }
+    __syncthreads();
+
+    // ---- 2. the table rows of the reads with several entries in the sweep: two threads a read, half of the sweep's blocks each.
+    // Entry i of the read covers the columns [its column, the next entry's column); the last entry only ends the one before it.
+    // A block with a boundary inside is listed: the general loop puts it together in a side dword.
+    if (!JL_ING_SKIP(a, 1)) {
+        for (uint32_t t = tid; t < 2u * n_walk; t += kThreads) {
+            const uint32_t j = s_walk[t >> 1], half = t & 1u;
             const read_info q = s_info[j];
-            const uint32_t e_off = q.ent & 0xFFFu, cn = (q.ent >> 12) & 0x3FFu;
-            if (pc >= (q.ent >> 22) || cn == 0u) return;
-            const int Q = q.q0 + kPiece * (int)pc;
-            const int lo_v = Q < 0 ? -Q : 0;
-            uint32_t S[8];
-            const uint64_t qb = QV ? (((uint64_t)s_qhi[j] << 32) | s_qlo[j]) : 0u;
-            if (JL_ING_SKIP(a, 6)) { S[0] = v0.x; S[1] = v0.y; S[2] = v0.z; S[3] = v0.w; S[4] = v1.x; S[5] = v1.y; S[6] = v1.z; S[7] = v1.w; }
-            else piece_syms<QV>(a, v0, v1, Q, lo_v, qb, S);
-            if (JL_ING_SKIP(a, 5)) {   // (probe: the codes are used, nothing is placed)
-                atomicXor(&s_tile[(j & 31u) * kRowI], S[0] ^ S[1] ^ S[2] ^ S[3] ^ S[4] ^ S[5] ^ S[6] ^ S[7]);
-                return;
+            const uint32_t cnt = q.row_nent >> 16;
+            if (cnt < 2u) continue;
+            const uint2 *ent = s_ent + (q.piece_hi_np >> 16);
+            uint16_t *tab = s_tab + tab_row(j);
+            const uint32_t b0 = half * (kBlocks / 2u), b1 = b0 + kBlocks / 2u;
+            uint32_t i = 0, inside = 0;
+            uint2 e = ent[0], nx = ent[1];
+            for (uint32_t blk = b0; blk < b1; ++blk) {
+                const int c0 = X + 8 * (int)blk;
+                if (c0 >= Xend) break;       // (the transposing phase stops there too)
+                while (i + 2u < cnt && (int)(nx.x & kRunMask) <= c0) {
+                    ++i;
+                    e = nx;
+                    nx = ent[i + 1u];
+                }
+                const uint32_t kind = e.x >> 30;
+                const uint32_t A = kind == 1u ? (uint32_t)(q.nb + (int)e.y + (c0 - (int)(e.x & kRunMask))) : kind == 2u ? 16u : 0u;
+                if ((int)(nx.x & kRunMask) < c0 + 8) inside |= 1u << (blk - b0);
+                tab[blk] = (uint16_t)A;
             }
-            // the last entry whose query offset is at or before the piece's first base: three entries' offsets at once (a read
-            // has one or two runs in a sweep, rarely more), the rest one by one
-            const uint2 *ent = s_ent + e_off;
-            const int Qs = Q + lo_v;
-            uint32_t qy[4];
-#pragma unroll
-            for (uint32_t t = 1; t < 4u; ++t) qy[t] = ent[min(t, cn - 1u)].y;
-            uint32_t i = 0;
-#pragma unroll
-            for (uint32_t t = 1; t < 4u; ++t) i += (t < cn && (int)qy[t] <= Qs) ? 1u : 0u;
-            if (i == 3u)
-                for (uint32_t t = 4; t < cn && (int)ent[t].y <= Qs; ++t) i = t;
-            const uint2 e = ent[i], nx = ent[i + 1u];
-            uint32_t *row = s_tile + (j & 31u) * kRowI + (j >> 5) * kSweepDw;
-            const int rb = (int)(e.x & kRunMask);
-            if ((e.x >> 30) == 1u) emit_run(S, Q, lo_v, rb, (int)e.y, (int)(nx.x & kRunMask) - rb, q.base, X, Xend, row);
-            if (i + 1u < cn && (int)nx.y < Q + kPiece) {       // the piece reaches the next entry: later
-                const uint32_t at = atomicAdd(&s_nlist, 1u);
-                if (at < kListCap) s_list[at] = (j << 24) | (pc << 12) | (i + 1u);
-                else emit_rest(S, Q, lo_v, ent, i + 1u, cn, q.base, X, Xend, row);
-            }
-        };
-        uint4 va[kRounds], vb[kRounds];
-#pragma unroll
-        for (uint32_t it = 0; it < kRounds; ++it) fetch((wid + kWaves * it) * kReadsPerRound + slot, piece, va[it], vb[it]);
-#pragma unroll
-        for (uint32_t it = 0; it < kRounds; ++it) {
-            const uint32_t j = (wid + kWaves * it) * kReadsPerRound + slot;
-            expand(j, piece, va[it], vb[it]);
-            // a read with more pieces in the sweep (insertions)
-            const uint32_t npj = s_info[j].ent >> 22;
-            for (uint32_t pp = piece + kPiecesPerRead; __ballot(pp < npj) != 0ull; pp += kPiecesPerRead) {
-                uint4 w0, w1;
-                fetch(j, pp, w0, w1);
-                expand(j, pp, w0, w1);
+            while (inside) {
+                const uint32_t blk = b0 + (uint32_t)__ffs(inside) - 1u;
+                inside &= inside - 1u;
+                const uint32_t slot = atomicAdd(&s_nlist, 1u);
+                if (slot < kSideCap) {
+                    s_list[slot] = (uint16_t)((j << 5) | blk);
+                    tab[blk] = (uint16_t)(8u * (4u + slot));
+                } else s_over[j] = 1;
             }
         }
     }
-    __syncthreads();
-    if (!JL_ING_SKIP(a, 3)) {   // the listed pieces, a lane each
-        const uint32_t nl = min(s_nlist, kListCap);
-        for (uint32_t k = tid; k < nl; k += kThreads) {
-            const uint32_t it = s_list[k], j = it >> 24, pc = (it >> 12) & 0xFFFu;
-            const read_info q = s_info[j];
-            const uint64_t at = (((uint64_t)q.p0_hi << 32) | q.p0_lo) + 32u * pc;
-            const uint4 v0 = *reinterpret_cast<const uint4 *>(a.seq4 + at), v1 = *reinterpret_cast<const uint4 *>(a.seq4 + at + 16u);
-            const int Q = q.q0 + kPiece * (int)pc;
-            const int lo_v = Q < 0 ? -Q : 0;
-            uint32_t S[8];
-            const uint64_t qb = QV ? (((uint64_t)s_qhi[j] << 32) | s_qlo[j]) : 0u;
-            piece_syms<QV>(a, v0, v1, Q, lo_v, qb, S);
-            emit_rest(S, Q, lo_v, s_ent + (q.ent & 0xFFFu), it & 0xFFFu, (q.ent >> 12) & 0x3FFu, q.base, X, Xend,
-                      s_tile + (j & 31u) * kRowI + (j >> 5) * kSweepDw);
+    // ---- 3. the pieces -> codes -> the staging area, in query order
+    if (!JL_ING_SKIP(a, 0)) {
+#pragma unroll
+        for (uint32_t it = 0; it < kFetchRounds; ++it) {
+            const uint32_t j = it * kReadsPerRound + f_slot;
+            stage(j, f_piece, pv[it]);
+            // a read with more pieces in the sweep (insertions, an unlucky alignment)
+            const uint32_t npj = (s_info[j].piece_hi_np >> 8) & 0xFFu;
+            for (uint32_t pp = f_piece + kLanesPerRead; __ballot(pp < npj) != 0ull; pp += kLanesPerRead) stage(j, pp, fetch(j, pp));
         }
     }
     __syncthreads();
 
-    // ---- 3. the tile as planes: thread = 32 reads x 8 columns; neighbouring lanes write consecutive dwords of a plane
+    // ---- 4. the blocks with a boundary inside, a thread each; a read whose blocks did not fit: 'not covered' + the slow kernel
+    for (uint32_t t = tid; t < n_walk; t += kThreads) {
+        const uint32_t j = s_walk[t];
+        if (s_over[j]) {
+            uint2 *row_p = reinterpret_cast<uint2 *>(s_tab + tab_row(j));
+            for (uint32_t k = 0; k < kTabRow / 4u; ++k) row_p[k] = make_uint2(0u, 0u);
+            const uint32_t at = atomicAdd(a.slow_count, 1u);
+            a.slow_list[at] = make_uint2((uint32_t)((uint64_t)tile * kTileReads + j), sweep);
+        }
+    }
+    if (!JL_ING_SKIP(a, 3)) {
+        const uint32_t nl = min(s_nlist, kSideCap);
+        for (uint32_t k = tid; k < nl; k += kThreads) {
+            const uint32_t it = s_list[k], j = it >> 5, blk = it & 31u;
+            const read_info q = s_info[j];
+            const uint32_t cnt = q.row_nent >> 16;
+            const uint2 *ent = s_ent + (q.piece_hi_np >> 16);
+            const int c0 = X + 8 * (int)blk, c1 = c0 + 8;
+            uint32_t R = 0x66666666u;
+            uint2 e = ent[0];
+            for (uint32_t i = 0; i + 1u < cnt; ++i) {
+                const uint2 nx = ent[i + 1u];
+                const int W = (int)(e.x & kRunMask), Wn = (int)(nx.x & kRunMask);
+                if (W >= c1) break;
+                const int ca = max(W, c0), cb = min(Wn, c1);
+                const uint32_t kind = e.x >> 30;
+                if (ca < cb && kind != 3u) {
+                    const uint32_t m = (cb - ca == 8 ? 0xFFFFFFFFu : ((1u << (4 * (cb - ca))) - 1u)) << (4 * (ca - c0));
+                    uint32_t v = 0x44444444u;
+                    if (kind == 1u) {
+                        const uint32_t A = (uint32_t)(q.nb + (int)e.y + (ca - W));
+                        v = __builtin_amdgcn_alignbit(s_stage[(A >> 3) + 1u], s_stage[A >> 3], 4u * (A & 7u)) << (4 * (ca - c0));
+                    }
+                    R = (R & ~m) | (v & m);
+                }
+                e = nx;
+            }
+            s_stage[4u + k] = R;
+        }
+    }
+    __syncthreads();
+
+    // ---- 5. gather at the transpose: thread = 32 reads x 8 columns; neighbouring lanes write consecutive dwords of a plane
     {
-        const uint32_t G = tid % kTileGroups, dwi = tid / kTileGroups;
-        if (dwi < kSweepDw && X + 8 * (int)dwi < Xend && !JL_ING_SKIP(a, 4)) {
+        const uint32_t G = tid % kTileGroups, blk = tid / kTileGroups;
+        if (blk < kBlocks && X + 8 * (int)blk < Xend && !JL_ING_SKIP(a, 4)) {
             uint32_t R[32];
+            const uint16_t *tab = s_tab + tab_row(32u * G) + blk;
 #pragma unroll
-            for (uint32_t i = 0; i < 32u; ++i) R[i] = s_tile[i * kRowI + G * kSweepDw + dwi];
+            for (uint32_t i = 0; i < 32u; ++i) {
+                const uint32_t A = tab[i * kTabRow];
+                R[i] = __builtin_amdgcn_alignbit(s_stage[(A >> 3) + 1u], s_stage[A >> 3], 4u * (A & 7u));
+            }
             uint32_t out[8][3];
             nibble_rows_to_plane_words(R, out);
             const uint64_t byte = (uint64_t)tile * (kTileReads / 8u) + (uint64_t)G * 4u;
+#ifdef JL_TUNING
+            if (JL_ING_SKIP(a, 7)) {   // (probe: the same bytes in 16-byte stores, a quarter of the requests; wrong data by design)
+                uint8_t *row = a.msa + (uint64_t)(((uint32_t)X + 8u * blk) * 3u) * a.plane_stride + (uint64_t)tile * (kTileReads / 8u);
+                if (G == 0)
+                    for (uint32_t jj = 0; jj < 8u; ++jj)
+                        for (uint32_t k = 0; k < 3u; ++k) {
+                            if ((int)((uint32_t)X + 8u * blk + jj) < Xend) { u32x4 o = {out[jj][k], out[jj][0], out[jj][1], out[jj][2]}; *reinterpret_cast<u32x4 *>(row) = o; }
+                            row += a.plane_stride;
+                        }
+            } else
+#endif
             if (byte < a.plane_stride && (!JL_ING_SKIP(a, 2) || out[0][0] == 0x12345u)) {
-                // (one 64-bit multiply for the first plane row, then a stride at a time: twenty-four of them were a tenth of the phase)
-                uint8_t *row = a.msa + (uint64_t)(((uint32_t)X + 8u * dwi) * 3u) * a.plane_stride + byte;
+                // (one 64-bit multiply for the first plane row, then a stride at a time)
+                uint8_t *row = a.msa + (uint64_t)(((uint32_t)X + 8u * blk) * 3u) * a.plane_stride + byte;
 #pragma unroll
-                for (uint32_t j = 0; j < 8u; ++j) {
-                    const uint32_t c = (uint32_t)X + 8u * dwi + j;
+                for (uint32_t jj = 0; jj < 8u; ++jj) {
+                    const uint32_t c = (uint32_t)X + 8u * blk + jj;
 #pragma unroll
                     for (uint32_t k = 0; k < 3u; ++k) {
-                        if ((int)c < Xend) *reinterpret_cast<uint32_t *>(row) = out[j][k];
+                        if ((int)c < Xend) *reinterpret_cast<uint32_t *>(row) = out[jj][k];
                         row += a.plane_stride;
                     }
                 }
@@ -693,9 +798,9 @@ __global__ __launch_bounds__(kThreads) void ingest_planes_kernel(ingest_args a)
 }
 
 // ---------------------------------------------------------------------------------------- what the tiles left out
-// One wave per (read, sweep) pair: a lane per column looks its run up in HBM and flips the bits in which the symbol differs
+// One wave per (read, sweep) pair: a lane per column looks its entry up in HBM and flips the bits in which the symbol differs
 // from 'not covered' (which is what the tile's workgroup stored for the read).
-__global__ __launch_bounds__(256) void ingest_slow_kernel(ingest_args a, const int32_t *__restrict__ pos_, const uint32_t cap)
+__global__ __launch_bounds__(256) void ingest_slow_kernel(ingest_args a, const uint32_t cap)
 {
     const uint32_t wid = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     uint32_t n = *a.slow_count;
@@ -704,28 +809,30 @@ __global__ __launch_bounds__(256) void ingest_slow_kernel(ingest_args a, const i
         const uint2 pr = a.slow_list[it];
         const uint64_t r = pr.x;
         const uint32_t sweep = pr.y;
+#ifdef JL_TUNING
+        if (r >= a.n_reads || sweep >= a.n_sweeps) {
+            if (lane == 0) { atomicAdd(&a.dbg[4], 1u); a.dbg[10] = pr.x; }
+            continue;
+        }
+#endif
         const int X = (int)(sweep * kSweep), Xend = (int)min(a.n_cols, sweep * kSweep + kSweep);
-        const uint2 *runs = a.runs + a.cig_off[r] + r;
-        const uint32_t nr = a.nruns[r];
-        const int64_t base = (int64_t)pos_[r] - (int64_t)a.win_begin;
+        const uint2 *runs = a.runs + a.cig_off[r] + 3u * r;
+        const uint32_t ne = a.nruns[r] + 3u;
         const uint64_t so = a.seq_off[r];
         const uint64_t qo = a.qual ? a.qual_off[r] : 0u;
         for (int c = X + (int)lane; c < Xend; c += 64) {
-            const int64_t x = (int64_t)c - base;
-            if (x < 0 || nr == 0u) continue;
-            uint32_t lo = 0, hi = nr + 1u;   // entries 0 .. nr (the end entry); the last one with rbeg <= x
+            uint32_t lo = 0, hi = ne - 1u;   // the last entry that begins at or before c (entry 0 does, the last one never)
             while (hi - lo > 1u) {
                 const uint32_t mid = (lo + hi) >> 1;
-                if ((int64_t)(runs[mid].x & kRunMask) <= x) lo = mid;
+                if ((int)(runs[mid].x & kRunMask) <= c) lo = mid;
                 else hi = mid;
             }
-            if (lo >= nr) continue;          // behind the read
             const uint2 e = runs[lo];
             const uint32_t kind = e.x >> 30;
             uint32_t sym = 6u;
             if (kind == 2u) sym = 4u;
             else if (kind == 1u) {
-                const uint64_t q = (uint64_t)e.y + (uint64_t)(x - (int64_t)(e.x & kRunMask));
+                const uint64_t q = (uint64_t)e.y + (uint64_t)(c - (int)(e.x & kRunMask));
                 const uint32_t by = a.seq4[so + (q >> 1)];
                 const uint32_t b16 = (q & 1u) ? (by & 15u) : (by >> 4);
                 sym = (uint32_t)((0x5555555355525105ull >> (4u * b16)) & 15ull);   // A=1 C=2 G=4 T=8 -> 0..3, else 5
@@ -748,21 +855,22 @@ __global__ __launch_bounds__(256) void ingest_slow_kernel(ingest_args a, const i
 
 uint32_t jl_ingest_sweeps(uint32_t n_cols) { return (n_cols + kSweep - 1u) / kSweep; }
 
-// d_runs: n_cig + n_reads + 1 entries; d_nruns: n_reads; d_first: n_reads x (sweeps + 1); d_slow: n_reads x sweeps pairs behind
-// one counter word (zeroed here); d_slow_count[2..3] = the 64-bit word of the first malformed record (all ones: none).
+// d_runs: n_cig + 3 n_reads + 4 entries; d_nruns: n_reads; d_desc: n_reads x sweeps descriptors; d_slow: n_reads x sweeps pairs
+// behind one counter word (zeroed here); d_slow_count[2..3] = the 64-bit word of the first malformed record (all ones: none;
+// `keep_verdict`: an earlier build's word has not been read yet — this build's is folded into it, atomicMin).
 // Everything is enqueued on ctx->stream; nothing waits.
 void jl_launch_ingest(jl_ctx *ctx, const int32_t *d_pos, const uint32_t *d_cigar, const uint64_t *d_cig_off,
                       const uint8_t *d_seq4, const uint64_t *d_seq_off, const uint8_t *d_qual,
-                      const uint64_t *d_qual_off, uint32_t min_qv, uint2 *d_runs, uint32_t *d_nruns, uint32_t *d_first,
-                      uint32_t *d_slow_count, uint2 *d_slow)
+                      const uint64_t *d_qual_off, uint32_t min_qv, uint2 *d_runs, uint32_t *d_nruns, uint4 *d_desc,
+                      uint32_t *d_slow_count, uint2 *d_slow, bool keep_verdict, uint64_t seq_bytes, uint64_t n_entries)
 {
     hipStream_t st = ctx->stream;
     const uint32_t ns = jl_ingest_sweeps(ctx->n_cols);
     hipMemsetAsync(d_slow_count, 0, 4, st);
-    hipMemsetAsync(d_slow_count + 2, 0xFF, 8, st);
+    if (!keep_verdict) hipMemsetAsync(d_slow_count + 2, 0xFF, 8, st);
     if (ctx->n_reads)
-        hipLaunchKernelGGL(cigar_runs_kernel, dim3((uint32_t)((ctx->n_reads + 4u * kRunsReadsPerWave - 1u) / (4u * kRunsReadsPerWave))), dim3(256), 4u * (ns + 2u) * 4u, st, ctx->n_reads, d_pos,
-                           d_cigar, d_cig_off, d_seq_off, d_qual ? d_qual_off : nullptr, ctx->win_begin, ctx->n_cols, ns, d_runs, d_nruns, d_first,
+        hipLaunchKernelGGL(cigar_runs_kernel, dim3((uint32_t)((ctx->n_reads + 4u * kRunsReadsPerWave - 1u) / (4u * kRunsReadsPerWave))), dim3(256), 0, st, ctx->n_reads, d_pos,
+                           d_cigar, d_cig_off, d_seq_off, d_qual ? d_qual_off : nullptr, ctx->win_begin, ctx->n_cols, ns, d_runs, d_nruns, d_desc,
                            reinterpret_cast<unsigned long long *>(d_slow_count + 2));
     ingest_args a;
     a.n_reads = ctx->n_reads;
@@ -770,10 +878,7 @@ void jl_launch_ingest(jl_ctx *ctx, const int32_t *d_pos, const uint32_t *d_cigar
     a.n_sweeps = ns;
     const uint64_t reads_pad = ctx->plane_stride * 8u;                 // a multiple of 1024: whole line groups of tiles
     a.n_groups = (uint32_t)(reads_pad / 1024u);
-    a.n_pairs = a.n_groups * ns;
-    a.win_begin = ctx->win_begin;
     a.min_qv = std::min<uint32_t>(min_qv, 127u);   // (the byte-parallel compare of the QV path; BAM qualities end at 93)
-    a.pos = d_pos;
     a.cig_off = d_cig_off;
     a.seq4 = d_seq4;
     a.seq_off = d_seq_off;
@@ -782,18 +887,22 @@ void jl_launch_ingest(jl_ctx *ctx, const int32_t *d_pos, const uint32_t *d_cigar
     a.qual_off = qv ? d_qual_off : nullptr;
     a.runs = d_runs;
     a.nruns = d_nruns;
-    a.first_run = d_first;
+    a.desc = d_desc;
     a.slow_count = d_slow_count;
     a.slow_list = d_slow;
     a.msa = ctx->d_msa;
     a.plane_stride = ctx->plane_stride;
+    a.seq_bytes = seq_bytes;
+    a.n_entries = n_entries;
+    a.dbg = d_slow_count + 4;    // (twelve spare words of the 64-byte block)
     a.skip = 0;
 #ifdef JL_TUNING
+    hipMemsetAsync(d_slow_count + 4, 0, 48, st);
     if (const char *e = getenv("JL_ING_SKIP")) a.skip = (uint32_t)atoi(e);
 #endif
     const uint32_t grid = (a.n_groups + 7u) / 8u * ns * 8u * kSubTiles;   // (groups per XCD, rounded up) x sweeps x 8 XCDs x tiles of a group
     if (qv) hipLaunchKernelGGL(ingest_planes_kernel<true>, dim3(grid), dim3(kThreads), 0, st, a);
     else hipLaunchKernelGGL(ingest_planes_kernel<false>, dim3(grid), dim3(kThreads), 0, st, a);
-    const uint64_t cap = (uint64_t)ctx->n_reads * ns;
-    hipLaunchKernelGGL(ingest_slow_kernel, dim3(256), dim3(256), 0, st, a, d_pos, (uint32_t)std::min<uint64_t>(cap, 0xFFFFFFFFu));
+    const uint64_t cap = (uint64_t)ctx->n_reads * ns;   // (a pair is listed once: by the prologue, or when its boundary blocks overflow)
+    hipLaunchKernelGGL(ingest_slow_kernel, dim3(256), dim3(256), 0, st, a, (uint32_t)std::min<uint64_t>(cap, 0xFFFFFFFFu));
 }

@@ -1056,6 +1056,39 @@ def test_device_ingest_in_chunks(jl, chunk, hints):
     assert (msa.unpack_columns(jl.download_columns(), n) == rows).all()
 
 
+def test_device_ingest_refuses_cigars_whose_lengths_wrap(jl):
+    """Untrusted records through the C ABI: four insertions of 2^28 - 1 bases, a hundred matches and twelve more
+    insertions sum to 84 modulo 2^32 — below the hundred bases the record holds — while the run of matches sits at query offset
+    2^30; the lengths add up in 64 bits on the device and the record is refused.  Likewise a reference span of 2^30 or more."""
+    OPS = {"I": 1, "D": 2, "=": 7}
+    big = 268435455
+    good = [(100 << 4) | OPS["="]]
+    wrap = [(big << 4) | OPS["I"]] * 4 + [(100 << 4) | OPS["="]] + [(big << 4) | OPS["I"]] * 12
+    assert sum(w >> 4 for w in wrap) % (1 << 32) == 84
+    span = [(50 << 4) | OPS["="]] + [(big << 4) | OPS["D"]] * 5 + [(50 << 4) | OPS["="]]
+    seq50 = np.full(50, 0x12, dtype=np.uint8)
+
+    def build(cigars):
+        cig = np.array([w for c in cigars for w in c], dtype=np.uint32)
+        co = np.cumsum([0] + [len(c) for c in cigars]).astype(np.uint64)
+        n = len(cigars)
+        return (np.zeros(n, dtype=np.int32), cig, co, np.tile(seq50, n), (50 * np.arange(n + 1)).astype(np.uint64))
+
+    jl.ingest_records(120, 0, *build([good, good, good]))
+    assert (msa.unpack_columns(jl.download_columns(), 3)[:, :100] < 4).all()
+    with pytest.raises(capi.JulietError) as err:
+        jl.ingest_records(120, 0, *build([good, good, wrap, good]))
+    assert "record 2" in str(err.value) and "more bases" in str(err.value)
+    with pytest.raises(capi.JulietError) as err:
+        jl.ingest_records(120, 0, *build([good, span, wrap]))
+    assert "record 1" in str(err.value) and "2^30" in str(err.value)
+    # the same through a second step of 128 ops (the carries between steps)
+    long_wrap = [(1 << 4) | OPS["="], (1 << 4) | OPS["I"]] * 70 + wrap
+    with pytest.raises(capi.JulietError) as err:
+        jl.ingest_records(120, 0, *build([good, long_wrap]))
+    assert "record 1" in str(err.value) and "more bases" in str(err.value)
+
+
 def test_device_ingest_dense_runs_take_the_slow_kernel(jl):
     """A deletion at every other column: hundreds of runs per read and sweep, far more than a workgroup's LDS list holds
     — most (read, sweep) pairs go through ingest_slow_kernel (runs looked up in HBM, bits flipped with atomics), the first
