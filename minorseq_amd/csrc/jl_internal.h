@@ -32,7 +32,7 @@
 #define JL_INS_MAX_BASES 30u       // inserted bases tracked per insertion
 #define JL_GUESS_PAD 32u           // zero bytes after the last column's seed base
 #ifndef JL_INGEST_SWEEP
-#define JL_INGEST_SWEEP 224u        // columns a workgroup of the record ingest expands at a time (kernels_ingest.hip)
+#define JL_INGEST_SWEEP 256u        // columns a workgroup of the record ingest expands at a time (kernels_ingest.hip)
 #endif
 
 

@@ -47,13 +47,22 @@ constexpr uint32_t kTileReads = JL_INGEST_TILE;     // reads per workgroup
 constexpr uint32_t kTileGroups = kTileReads / 32u;  // groups of 32 reads = dwords of a plane the tile writes per column
 constexpr uint32_t kSubTiles = 1024u / kTileReads;  // tiles that share the 128-byte lines of the planes
 constexpr uint32_t kThreads = 2u * kTileReads;      // a thread per read in the prologue, two in the table fill
-constexpr uint32_t kWaves = kThreads / 64u;
 constexpr uint32_t kRunMask = 0x3FFFFFFFu;          // window column of an entry; kind in the two bits above
 static_assert(kSweep % 16u == 0 && kTileReads % 32u == 0 && kThreads <= 1024u, "whole blocks for both table threads, whole plane dwords");
 static_assert(kTileGroups * kBlocks <= kThreads, "a thread per 32 reads x 8 columns in the transposing phase");
 
 // ---------------------------------------------------------------------------------------- runs
-// inclusive prefix sums over the 64 lanes by DPP (four shifts within rows of 16, two row broadcasts);
+// inclusive prefix sum over the 64 lanes by DPP (four shifts within rows of 16, two row broadcasts)
+__device__ __forceinline__ uint32_t wave_scan(uint32_t v)
+{
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);   // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true);   // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true);   // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true);   // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);  // row_bcast:15 -> rows 1, 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);  // row_bcast:31 -> rows 2, 3
+    return v;
+}
 // two independent sums scanned in step (a DPP read of a register needs two wait states behind the write: each chain fills
 // the other's)
 __device__ __forceinline__ void wave_scan2(uint32_t &a, uint32_t &b)
@@ -265,69 +274,78 @@ __global__ __launch_bounds__(256) void cigar_runs_kernel(uint64_t n_reads, const
             my_so = lane64(so_l, (int)t);
         }
     const uint64_t ent0 = my_cb + 3u * r;     // index of the read's entry 0 in runs[]
-    auto entry = [&](uint32_t i) -> uint2 {
-        if (i < kRunsLds) return s_run[q][i];
-        const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(runs + ent0 + i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return make_uint2((uint32_t)v, (uint32_t)(v >> 32));
-    };
     uint32_t top = 1u;                         // the highest power of two not above the longest list
     while (2u * top <= n_max + 3u) top *= 2u;
-    for (uint32_t s0 = 0; s0 < n_sweeps; s0 += kDescSweeps) {
-        const uint32_t s = s0 + sl;
-        // f = the number of entries that begin at or before the sweep's first column (entry 0 always does, the last never)
-        const uint32_t X = min(s, n_sweeps) * kSweep;   // (lanes past the last bound repeat it)
-        uint32_t f = 0;
-        for (uint32_t step = top; step; step >>= 1) {
-            const uint32_t t = f + step;
-            if (live && t <= n_ent_all && (entry(t - 1u).x & kRunMask) <= X) f = t;
-        }
-        uint32_t f_next = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)f, 0x101, 0xF, 0xF, false);   // row_shl:1
-        if (!live || sl == kDescSweeps || s >= n_sweeps) continue;
-        const uint32_t Xend = min(n_cols, X + kSweep);
-        const uint32_t lo = f - 1u;
-        uint32_t n_ent = f_next - f + 2u;
-        uint32_t q_lo = 0xFFFFFFFFu, q_hi = 0;
-        uint2 e = entry(lo);
-        const uint2 first = e;
-        if (n_ent >= kDescMax) n_ent = kDescMax;
-        else {
-            for (uint32_t i = lo; i + 1u < lo + n_ent; ++i) {
-                const uint2 nx = entry(i + 1u);
-                if ((e.x >> 30) == 1u) {
-                    const uint32_t W = e.x & kRunMask, ca = max(W, X), cbv = min(nx.x & kRunMask, Xend);
-                    if (ca < cbv) {
-                        q_lo = min(q_lo, e.y + (ca - W));
-                        q_hi = max(q_hi, e.y + (cbv - W));
-                    }
-                }
-                e = nx;
+    // (`entry`: the read's i-th entry — out of the wave's LDS copy, or, for the lists that are longer than it, read back)
+    auto describe = [&](auto entry) {
+        for (uint32_t s0 = 0; s0 < n_sweeps; s0 += kDescSweeps) {
+            const uint32_t s = s0 + sl;
+            // f = the number of entries that begin at or before the sweep's first column (entry 0 always does, the last never)
+            const uint32_t X = min(s, n_sweeps) * kSweep;   // (lanes past the last bound repeat it)
+            uint32_t f = 0;
+            for (uint32_t step = top; step; step >>= 1) {
+                const uint32_t t = f + step;
+                if (live && t <= n_ent_all && (entry(t - 1u).x & kRunMask) <= X) f = t;
             }
+            const uint32_t f_next = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)f, 0x101, 0xF, 0xF, false);   // row_shl:1
+            if (!live || sl == kDescSweeps || s >= n_sweeps) continue;
+            const uint32_t Xend = min(n_cols, X + kSweep);
+            const uint32_t lo = f - 1u;
+            uint32_t n_ent = f_next - f + 2u;
+            uint32_t q_lo = 0xFFFFFFFFu, q_hi = 0;
+            uint2 e = entry(lo);
+            const uint2 first = e;
+            if (n_ent >= kDescMax) n_ent = kDescMax;
+            else {
+                for (uint32_t i = lo; i + 1u < lo + n_ent; ++i) {
+                    const uint2 nx = entry(i + 1u);
+                    if ((e.x >> 30) == 1u) {
+                        const uint32_t W = e.x & kRunMask, ca = max(W, X), cbv = min(nx.x & kRunMask, Xend);
+                        if (ca < cbv) {
+                            q_lo = min(q_lo, e.y + (ca - W));
+                            q_hi = max(q_hi, e.y + (cbv - W));
+                        }
+                    }
+                    e = nx;
+                }
+            }
+            // the 16-byte pieces of packed bases the sweep takes: from the one that holds its first base (byte offsets are even
+            // in bases: all of this in 32 bits relative to the read's first byte, the one 64-bit sum at the end)
+            uint64_t piece = 0;
+            uint32_t np = 0;
+            int32_t q0 = 0;
+            if (q_lo < q_hi) {
+                const uint32_t al = (uint32_t)my_so & 15u;                       // the read's first byte within its piece
+                const uint32_t b_lo = al + (q_lo >> 1), b_hi = al + (q_hi + 1u) / 2u;   // bytes from that piece's first on
+                const uint32_t p_lo = b_lo >> 4;
+                piece = (my_so >> 4) + p_lo;
+                np = min((b_hi + 15u - 16u * p_lo) >> 4, kDescMax);
+                q0 = (int32_t)(2u * (16u * p_lo - al));
+            }
+            const uint64_t e_idx = ent0 + lo;
+            uint4 d;
+            d.x = (uint32_t)piece;
+            d.z = (uint32_t)q0;
+            if (n_ent == 2u) {
+                // ONE entry covers the whole sweep (three reads in four of a CCS sample): the planes kernel needs no entries for it —
+                // what the entry is, and the query offset of the sweep's first column
+                d.y = first.y + (X - (first.x & kRunMask));
+                d.w = (uint32_t)((piece >> 32) & 0xFFu) | ((first.x >> 30) << 8) | (np << 16) | (1u << 24);
+            } else {
+                d.y = (uint32_t)e_idx;
+                d.w = (uint32_t)((piece >> 32) & 0xFFu) | ((uint32_t)((e_idx >> 32) & 0xFFu) << 8) | (np << 16) | (n_ent << 24);
+            }
+            desc[(uint64_t)s * n_reads + r] = d;
         }
-        uint64_t piece = 0;
-        uint32_t np = 0;
-        int32_t q0 = 0;
-        if (q_lo < q_hi) {
-            const uint64_t byte_lo = my_so + (q_lo >> 1), byte_hi = my_so + ((uint64_t)q_hi + 1u) / 2u;
-            const uint64_t p0 = byte_lo & ~(uint64_t)15;
-            piece = p0 >> 4;
-            np = (uint32_t)min((byte_hi - p0 + 15u) >> 4, (uint64_t)kDescMax);
-            q0 = (int32_t)(2 * ((int64_t)p0 - (int64_t)my_so));
-        }
-        const uint64_t e_idx = ent0 + lo;
-        uint4 d;
-        d.x = (uint32_t)piece;
-        d.z = (uint32_t)q0;
-        if (n_ent == 2u) {
-            // ONE entry covers the whole sweep (three reads in four of a CCS sample): the planes kernel needs no entries for it —
-            // what the entry is, and the query offset of the sweep's first column
-            d.y = first.y + (X - (first.x & kRunMask));
-            d.w = (uint32_t)((piece >> 32) & 0xFFu) | ((first.x >> 30) << 8) | (np << 16) | (1u << 24);
-        } else {
-            d.y = (uint32_t)e_idx;
-            d.w = (uint32_t)((piece >> 32) & 0xFFu) | ((uint32_t)((e_idx >> 32) & 0xFFu) << 8) | (np << 16) | (n_ent << 24);
-        }
-        desc[(uint64_t)s * n_reads + r] = d;
-    }
+    };
+    const uint2 *s_mine = s_run[q];
+    if (n_max + 3u <= kRunsLds) describe([&](uint32_t i) -> uint2 { return s_mine[i]; });
+    else
+        describe([&](uint32_t i) -> uint2 {
+            if (i < kRunsLds) return s_mine[i];
+            const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(runs + ent0 + i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return make_uint2((uint32_t)v, (uint32_t)(v >> 32));
+        });
 }
 
 // ---------------------------------------------------------------------------------------- the planes of one sweep
@@ -420,37 +438,41 @@ struct ingest_args {
 // LDS of a planes workgroup.  The staging area holds dwords of eight codes; a NIBBLE address into it fits 16 bits:
 //   dwords 0-1 'not covered' twice, 2-3 '-' twice (what a table entry of a block nothing / a deletion covers points at),
 //   4 .. 4 + kSideCap  the blocks the general loop puts together (one dword each),
-//   kRowBase ..        the reads' codes in query order, a 16-byte piece after the other.
+//   kRowBase ..        the reads' codes in query order: a row of kRowPieces 16-byte pieces per read — a sweep's bases from a
+//                      16-byte boundary on, + 8 dwords between the 32-read groups, so that the four reads a wave gathers from
+//                      at a time lie 8 banks apart.
 #ifndef JL_INGEST_SIDE
-#define JL_INGEST_SIDE 380
+#define JL_INGEST_SIDE 124
 #endif
 constexpr uint32_t kSideCap = JL_INGEST_SIDE;
 constexpr uint32_t kRowBase = 4u + kSideCap;
-#ifndef JL_INGEST_PIECES_X2
-#define JL_INGEST_PIECES_X2 17            // pieces per read and sweep the staging area has room for, times two (8.5: a sweep of
-#endif                                    // 224 columns is 8 pieces of a read from a 16-byte boundary on, insertions aside)
-constexpr uint32_t kPieceCap = kTileReads * JL_INGEST_PIECES_X2 / 2u;
-constexpr uint32_t kStageDw = kRowBase + 4u * kPieceCap + 4u;
+#ifndef JL_INGEST_ROW_EXTRA
+#define JL_INGEST_ROW_EXTRA 0             // pieces of a row beyond a sweep's own (room for inserted bases: 32 a piece)
+#endif
+constexpr uint32_t kRowPieces = (kSweep + 31u) / 32u + 1u + JL_INGEST_ROW_EXTRA, kRowDw = 4u * kRowPieces, kGroupPadDw = 8u;
+__device__ __forceinline__ uint32_t row_dw(uint32_t j) { return kRowBase + kRowDw * j + kGroupPadDw * (j >> 5); }
+constexpr uint32_t kStageDw = kRowBase + kRowDw * kTileReads + kGroupPadDw * kTileGroups + 4u;
 #ifndef JL_INGEST_ENT_PER_READ
 #define JL_INGEST_ENT_PER_READ 4
 #endif
-constexpr uint32_t kEntCap = JL_INGEST_ENT_PER_READ * kTileReads;   // entries of the reads that need them (a CCS read: 4 in a sweep with an indel)
-// the table: 32 entries (16 bits) a read — rows on 8-byte boundaries for the four-entries-at-a-time stores of the common case —
+// entries of the reads that need them (a CCS read: 4 in a sweep with an indel), 4 bytes each in LDS:
+// column - sweep's first (0..256: 9 bits) | kind << 9 | (query offset there - the row's first) << 11
+constexpr uint32_t kEntCap = JL_INGEST_ENT_PER_READ * kTileReads, kEntCapWave = kEntCap / 2u;
+// the table: 32 entries (16 bits) a read — rows on 8-byte boundaries for the four-entries-at-a-time stores —
 // and 8 dwords of padding per 32 reads: the four 32-read groups of a wave's lanes read it 8 banks apart
 constexpr uint32_t kTabRow = 32u, kTabGroupPad = 16u;
-static_assert(kBlocks <= kTabRow, "a sweep is at most 32 blocks wide");
+static_assert(kBlocks <= kTabRow && kBlocks % 4u == 0, "a sweep is at most 32 blocks wide, whole chunks of four");
 constexpr uint32_t kTabSize = kTileReads * kTabRow + kTileGroups * kTabGroupPad;
 __device__ __forceinline__ uint32_t tab_row(uint32_t j) { return j * kTabRow + (j >> 5) * kTabGroupPad; }
-constexpr uint32_t kLanesPerRead = 8u;           // lanes that fetch a read's pieces together (8 x 16 bytes = a sweep's 112 bytes + alignment)
 static_assert(kRowBase % 4u == 0 && kStageDw * 8u <= 65536u, "16-byte pieces; 16-bit nibble addresses");
-static_assert((kTileReads * kLanesPerRead) % kThreads == 0, "whole rounds of the fetch");
-constexpr uint32_t kFetchRounds = kTileReads * kLanesPerRead / kThreads;
+static_assert(kTileReads == 128u && kThreads == 256u, "two waves of read threads with an entry region each");
+constexpr uint32_t kFetchRounds = (kTileReads * kRowPieces + kThreads - 1u) / kThreads;
 
 struct read_info {          // what the later phases need of one read of the tile (LDS, 16 bytes)
     uint32_t piece_lo;      // index of its first 16-byte piece, low 32 bits
-    uint32_t piece_hi_np;   // bits 32-39 of that | pieces << 8 | first entry in s_ent << 16
-    uint32_t row_nent;      // first dword of its pieces in the staging area | entries in s_ent << 16 (0: its table row is final)
-    int32_t nb;             // staging nibble address of its query offset 0 (row * 8 - q0)
+    uint32_t meta;          // bits 32-39 of that | pieces << 8 | entries in s_ent << 16 (0: its table row is final)
+    uint32_t ent_off;       // its first entry in s_ent
+    int32_t q0;             // query offset of its first piece's first base
 };
 
 // 16 bytes of packed bases (BAM order: first base in the high nibble) -> 32 symbol codes, base b in nibble b & 7 of S[b >> 3];
@@ -512,19 +534,27 @@ __device__ __forceinline__ void piece_syms(const ingest_args &a, const u32x4 &v,
     }
 }
 
+__device__ __forceinline__ uint32_t ent_col(uint32_t e) { return e & 511u; }
+__device__ __forceinline__ uint32_t ent_kind(uint32_t e) { return (e >> 9) & 3u; }
+// staging nibble address of column c (relative to the sweep's first) in entry e of a read whose row begins at nibble row8
+__device__ __forceinline__ uint32_t ent_addr(uint32_t e, uint32_t row8, uint32_t c)
+{
+    const uint32_t kind = ent_kind(e);
+    return kind == 1u ? row8 + (e >> 11) + (c - ent_col(e)) : kind == 2u ? 16u : 0u;
+}
+
 template <bool QV>
 __global__ __launch_bounds__(kThreads) void ingest_planes_kernel(ingest_args a)
 {
     __shared__ __attribute__((aligned(16))) uint32_t s_stage[kStageDw];
     __shared__ __attribute__((aligned(16))) uint16_t s_tab[kTabSize];
-    __shared__ uint2 s_ent[kEntCap];
+    __shared__ uint32_t s_ent[kEntCap];
     __shared__ read_info s_info[kTileReads];
     __shared__ uint32_t s_qlo[QV ? kTileReads : 1], s_qhi[QV ? kTileReads : 1];   // qual_off of every read
-    __shared__ uint16_t s_list[kSideCap];
-    __shared__ uint8_t s_walk[kTileReads];        // the reads whose table rows come from a walk over their entries
+    __shared__ uint32_t s_list[kSideCap];         // the blocks with a boundary inside: read << 16 | first entry to look at << 8 | block
     __shared__ uint8_t s_over[kTileReads];        // the read's boundary blocks did not all fit the side dwords: the slow kernel takes it
-    __shared__ uint32_t s_wsum[2][kWaves], s_nlist;
-    const uint32_t tid = threadIdx.x, wid = tid >> 6, lane = tid & 63u;
+    __shared__ uint32_t s_nlist;
+    const uint32_t tid = threadIdx.x, wid = tid >> 6;
     // block -> (read tile, sweep).  Blocks b, b + 8, b + 16, ... are dealt to the same XCD one after the other; an XCD takes
     // whole groups of 1024 reads (group = xcd, xcd + 8, ...), and of a group all sweeps in turn, the tiles of the group
     // innermost.  So (a) the tiles that share the 128-byte lines of a sweep's planes meet in one L2, and (b) what the
@@ -534,87 +564,77 @@ __global__ __launch_bounds__(kThreads) void ingest_planes_kernel(ingest_args a)
     const uint32_t group = xcd + 8u * (qq / a.n_sweeps), sweep = qq % a.n_sweeps;
     if (group >= a.n_groups) return;
     const uint32_t tile = kSubTiles * group + sub;
-    const int X = (int)(sweep * kSweep), Xend = (int)min(a.n_cols, sweep * kSweep + kSweep);
-    const uint64_t r = (uint64_t)tile * kTileReads + tid;
-    const bool real = tid < kTileReads && r < a.n_reads;
+    const uint32_t X = sweep * kSweep, Xend = min(a.n_cols, X + kSweep), width = Xend - X;
 
-    // ---- 0. one request per read: its descriptor
-    uint4 d = make_uint4(0, 0, 0, 3u << 8 | 1u << 24);   // (no read: one entry of nothing)
-    if (real) {
-        d = a.desc[(uint64_t)sweep * a.n_reads + r];
-        if (QV) {
-            const uint64_t qo = a.qual_off[r];
-            s_qlo[tid] = (uint32_t)qo;
-            s_qhi[tid] = (uint32_t)(qo >> 32);
-        }
-    }
-    if (tid < 4u) s_stage[tid] = tid < 2u ? 0x66666666u : 0x44444444u;
-    if (tid == 0) s_nlist = 0;
-    if (tid < kTileReads) s_over[tid] = 0;
-    uint32_t np = (d.w >> 16) & 0xFFu, n_ent = d.w >> 24;
-    bool slow = np == kDescMax || n_ent == kDescMax;
-    const bool simple = n_ent == 1u || slow;      // its table row is one entry's: written here
-    if (simple) n_ent = 0;
-    if (slow) np = 0;
-    // exclusive scans over the workgroup: of the entries (and, sixteen bits up, of the reads that have some), of the pieces
-    uint32_t inc_e = n_ent | (n_ent ? 1u << 16 : 0u), inc_p = np;
-    const uint32_t own_e = inc_e;
-    wave_scan2(inc_e, inc_p);
-    if (lane == 63u) {
-        s_wsum[0][wid] = inc_e;
-        s_wsum[1][wid] = inc_p;
-    }
-    __syncthreads();
-    uint32_t off_e = inc_e - own_e, off_p = inc_p - np, n_walk = 0;
-    for (uint32_t w = 0; w < kWaves; ++w) {
-        const uint32_t we = s_wsum[0][w];
-        if (w < wid) {
-            off_e += we;
-            off_p += s_wsum[1][w];
-        }
-        n_walk += we >> 16;
-    }
-    const uint32_t walk_at = off_e >> 16;
-    off_e &= 0xFFFFu;
-    if ((n_ent && off_e + n_ent > kEntCap) || (np && off_p + np > kPieceCap)) {
-        slow = true;
-        np = n_ent = 0;
-    }
-    JL_ING_CHECK(a, !slow || real, 3, r, slow = false)
-    if (slow) {
-        const uint32_t at = atomicAdd(a.slow_count, 1u);
-        a.slow_list[at] = make_uint2((uint32_t)r, sweep);
-    }
-    // the sweep's entries of this read: the first four in two 16-byte requests that go out together (entries past the
-    // read's own belong to the next read or to the array's slack)
+    // ---- 0. the two read waves: one request per read (its descriptor); then its entries, its table row if one entry covers
+    // the sweep, what the other phases need of it.  Each wave has its own half of the entry area and its own list of the
+    // reads whose rows come from a walk: nothing crosses waves before the barrier.
     typedef uint32_t u32x4a8 __attribute__((ext_vector_type(4), aligned(8)));
-    uint64_t src_at = n_ent ? ((((uint64_t)(d.w >> 8) & 0xFFu) << 32) | d.y) : 0u;
-    JL_ING_CHECK(a, src_at + n_ent + 2u <= a.n_entries, 2, src_at, src_at = 0)
-    const uint2 *src = a.runs + src_at;
+    uint32_t n_ent = 0, off_e = 0;
+    int32_t q0 = 0;
+    const uint2 *src = a.runs;
     u32x4a8 e01 = {0, 0, 0, 0}, e23 = {0, 0, 0, 0};
-    if (n_ent) {
-        e01 = *reinterpret_cast<const u32x4a8 *>(src);
-        e23 = *reinterpret_cast<const u32x4a8 *>(src + 2);
-    }
     if (tid < kTileReads) {
-        const uint32_t row = kRowBase + 4u * off_p;
+        const uint64_t r = (uint64_t)tile * kTileReads + tid;
+        uint4 d = make_uint4(0, 0, 0, 3u << 8 | 1u << 24);   // (no read: one entry of nothing)
+        if (r < a.n_reads) {
+            d = a.desc[(uint64_t)sweep * a.n_reads + r];
+            if (QV) {
+                const uint64_t qo = a.qual_off[r];
+                s_qlo[tid] = (uint32_t)qo;
+                s_qhi[tid] = (uint32_t)(qo >> 32);
+            }
+        }
+        if (tid < 4u) s_stage[tid] = tid < 2u ? 0x66666666u : 0x44444444u;
+        if (tid == 0) s_nlist = 0;
+        s_over[tid] = 0;
+        uint32_t np = (d.w >> 16) & 0xFFu;
+        n_ent = d.w >> 24;
+        bool slow = np > kRowPieces || n_ent == kDescMax;
+        const bool simple = n_ent == 1u;
+        if (simple || slow) n_ent = 0;
+        // exclusive scan of the entries over the wave
+        const uint32_t inc = wave_scan(n_ent);
+        off_e = inc - n_ent;
+        if (n_ent && off_e + n_ent > kEntCapWave) {
+            slow = true;
+            n_ent = 0;
+        }
+        if (slow) {
+            JL_ING_CHECK(a, r < a.n_reads, 3, r, slow = false)
+            np = 0;
+        }
+        if (slow) {
+            const uint32_t at = atomicAdd(a.slow_count, 1u);
+            a.slow_list[at] = make_uint2((uint32_t)r, sweep);
+        }
+        off_e += wid * kEntCapWave;
+        // the sweep's entries of this read: the first four in two 16-byte requests that go out together (entries past the
+        // read's own belong to the next read or to the array's slack)
+        uint64_t src_at = n_ent ? ((((uint64_t)(d.w >> 8) & 0xFFu) << 32) | d.y) : 0u;
+        JL_ING_CHECK(a, src_at + n_ent + 2u <= a.n_entries, 2, src_at, src_at = 0)
+        src = a.runs + src_at;
+        if (n_ent) {
+            e01 = *reinterpret_cast<const u32x4a8 *>(src);
+            e23 = *reinterpret_cast<const u32x4a8 *>(src + 2);
+        }
+        q0 = (int32_t)d.z;
         read_info ri;
         ri.piece_lo = d.x;
-        ri.piece_hi_np = (d.w & 0xFFu) | (np << 8) | (off_e << 16);
-        ri.row_nent = row | (n_ent << 16);
-        ri.nb = (int32_t)(8u * row) - (int32_t)d.z;
+        ri.meta = (d.w & 0xFFu) | (np << 8) | (n_ent << 16);
+        ri.ent_off = off_e;
+        ri.q0 = q0;
         s_info[tid] = ri;
-        if (own_e) s_walk[walk_at] = (uint8_t)tid;    // (counted before the room was known: a read without entries is skipped there)
         if (!n_ent) {
             // one entry covers the sweep: its blocks' addresses rise by eight codes a block (aligned bases) or stay (the
             // dword of '-', of 'not covered'), four blocks a store
-            const uint32_t kind = slow ? 3u : (d.w >> 8) & 3u;
-            const uint32_t a0 = kind == 1u ? (uint32_t)ri.nb + d.y : kind == 2u ? 16u : 0u, st = kind == 1u ? 8u : 0u;
+            const uint32_t kind = (simple && !slow) ? (d.w >> 8) & 3u : 3u;
+            const uint32_t a0 = kind == 1u ? 8u * row_dw(tid) + (d.y - (uint32_t)q0) : kind == 2u ? 16u : 0u, st = kind == 1u ? 8u : 0u;
             uint32_t lo = a0 | ((a0 + st) << 16), hi = lo + 2u * (st | st << 16);
             const uint32_t step = 4u * (st | st << 16);
             uint2 *row_p = reinterpret_cast<uint2 *>(s_tab + tab_row(tid));
 #pragma unroll
-            for (uint32_t k = 0; k < (kBlocks + 3u) / 4u; ++k) {
+            for (uint32_t k = 0; k < kBlocks / 4u; ++k) {
                 row_p[k] = make_uint2(lo, hi);
                 lo += step;
                 hi += step;
@@ -623,128 +643,130 @@ __global__ __launch_bounds__(kThreads) void ingest_planes_kernel(ingest_args a)
     }
     __syncthreads();
 
-    // ---- 1. the pieces: eight lanes a read, 16 bytes (32 bases) a lane; all of a thread's requests go out first (a lane without a
-    // piece asks for its read's first one again: the same number of requests in flight in every lane, so that the wait for
-    // the entries below does not wait for the pieces)
-    constexpr uint32_t kReadsPerRound = kThreads / kLanesPerRead;
-    const uint32_t f_slot = tid / kLanesPerRead, f_piece = tid % kLanesPerRead;
-    auto fetch = [&](uint32_t j, uint32_t pc) -> u32x4 {
+    // ---- 1. the pieces: thread t takes pieces t, t + 256, ... of the tile's 128 x kRowPieces, 16 bytes (32 bases) each; all of a
+    // thread's requests go out first (a thread without a piece asks for its read's first one again: the same number of requests
+    // in flight in every lane, so that the wait for the entries below does not wait for the pieces)
+    auto fetch = [&](uint32_t p) -> u32x4 {
+        const uint32_t j = min(p / kRowPieces, kTileReads - 1u), pc = p - kRowPieces * j;
         const read_info q = s_info[j];
-        uint64_t at = ((((uint64_t)q.piece_hi_np & 0xFFu) << 32) | q.piece_lo) + (pc < ((q.piece_hi_np >> 8) & 0xFFu) ? pc : 0u);
+        uint64_t at = ((((uint64_t)q.meta & 0xFFu) << 32) | q.piece_lo) + (pc < ((q.meta >> 8) & 0xFFu) ? pc : 0u);
         JL_ING_CHECK(a, 16u * at + 16u <= a.seq_bytes + 64u, 1, at, at = 0)
         // (plain loads: neighbouring lanes' pieces share lines, and so do the sweeps of a read)
         return *reinterpret_cast<const u32x4 *>(a.seq4 + 16u * at);
     };
-    auto stage = [&](uint32_t j, uint32_t pc, const u32x4 &v) {
+    auto stage = [&](uint32_t p, const u32x4 &v) {
+        const uint32_t j = p / kRowPieces, pc = p - kRowPieces * j;
+        if (j >= kTileReads) return;
         const read_info q = s_info[j];
-        if (pc >= ((q.piece_hi_np >> 8) & 0xFFu)) return;
-        const uint32_t row = q.row_nent & 0xFFFFu;
-        const int Q = (int)(8u * row) - q.nb + 32 * (int)pc;        // query offset of the piece's first base
+        if (pc >= ((q.meta >> 8) & 0xFFu)) return;
+        const int Q = q.q0 + 32 * (int)pc;        // query offset of the piece's first base
         uint32_t S[4];
         const uint64_t qb = QV ? (((uint64_t)s_qhi[j] << 32) | s_qlo[j]) : 0u;
         if (JL_ING_SKIP(a, 6)) { S[0] = v.x; S[1] = v.y; S[2] = v.z; S[3] = v.w; }
         else piece_syms<QV>(a, v, Q, qb, S);
         u32x4 o = {S[0], S[1], S[2], S[3]};
-        *reinterpret_cast<u32x4 *>(&s_stage[row + 4u * pc]) = o;
+        *reinterpret_cast<u32x4 *>(&s_stage[row_dw(j) + 4u * pc]) = o;
     };
     u32x4 pv[kFetchRounds];
     if (!JL_ING_SKIP(a, 0)) {
 #pragma unroll
-        for (uint32_t it = 0; it < kFetchRounds; ++it) pv[it] = fetch(it * kReadsPerRound + f_slot, f_piece);
+        for (uint32_t it = 0; it < kFetchRounds; ++it) pv[it] = fetch(tid + kThreads * it);
     }
-    // the entries -> LDS (they were asked for before the pieces)
-    if (n_ent) {
-        const uint2 e4[4] = {make_uint2(e01.x, e01.y), make_uint2(e01.z, e01.w), make_uint2(e23.x, e23.y), make_uint2(e23.z, e23.w)};
+    // ---- 2. the reads with several entries in the sweep (they were asked for before the pieces): the entries -> LDS, four bytes
+    // each, for the general loop; the table row by the read's own thread, an entry at a time.  Entry i covers the columns
+    // [its column, the next entry's column) and the last one only ends the one before it, so the row is entry 0's addresses
+    // all along, overwritten from entry 1's first whole block on with entry 1's, and so on: four blocks a store, no search
+    // and no decision per block.  The block an entry begins INSIDE is listed: the general loop puts it together in a side dword.
+    if (n_ent && !JL_ING_SKIP(a, 1)) {
+        auto pack = [&](uint32_t x, uint32_t y) -> uint32_t {
+            const uint32_t W = x & kRunMask, kind = x >> 30;
+            const uint32_t wr = W <= X ? 0u : min(W - X, 256u);
+            const uint32_t yq = y + (W < X ? X - W : 0u);      // query offset at the sweep's first column of the entry
+            const uint32_t yr = (kind == 1u && wr < 256u) ? (yq - (uint32_t)q0) & 0x1FFFu : 0u;
+            return wr | (kind << 9) | (yr << 11);
+        };
+        const uint32_t e4[4] = {pack(e01.x, e01.y), pack(e01.z, e01.w), pack(e23.x, e23.y), pack(e23.z, e23.w)};
+        uint32_t *ent = s_ent + off_e;
 #pragma unroll
         for (uint32_t i = 0; i < 4u; ++i)
-            if (i < n_ent) s_ent[off_e + i] = e4[i];
-        for (uint32_t i = 4; i < n_ent; ++i) s_ent[off_e + i] = src[i];
-    }
-    __syncthreads();
-
-    // ---- 2. the table rows of the reads with several entries in the sweep: two threads a read, half of the sweep's blocks each.
-    // Entry i of the read covers the columns [its column, the next entry's column); the last entry only ends the one before it.
-    // A block with a boundary inside is listed: the general loop puts it together in a side dword.
-    if (!JL_ING_SKIP(a, 1)) {
-        for (uint32_t t = tid; t < 2u * n_walk; t += kThreads) {
-            const uint32_t j = s_walk[t >> 1], half = t & 1u;
-            const read_info q = s_info[j];
-            const uint32_t cnt = q.row_nent >> 16;
-            if (cnt < 2u) continue;
-            const uint2 *ent = s_ent + (q.piece_hi_np >> 16);
-            uint16_t *tab = s_tab + tab_row(j);
-            const uint32_t b0 = half * (kBlocks / 2u), b1 = b0 + kBlocks / 2u;
-            uint32_t i = 0, inside = 0;
-            uint2 e = ent[0], nx = ent[1];
-            for (uint32_t blk = b0; blk < b1; ++blk) {
-                const int c0 = X + 8 * (int)blk;
-                if (c0 >= Xend) break;       // (the transposing phase stops there too)
-                while (i + 2u < cnt && (int)(nx.x & kRunMask) <= c0) {
-                    ++i;
-                    e = nx;
-                    nx = ent[i + 1u];
+            if (i < n_ent) ent[i] = e4[i];
+        for (uint32_t i = 4; i < n_ent; ++i) {
+            const uint2 g = src[i];
+            ent[i] = pack(g.x, g.y);
+        }
+        const uint32_t row8 = 8u * row_dw(tid);
+        uint16_t *tab = s_tab + tab_row(tid);
+        uint32_t last_bb = 0xFFFFFFFFu;
+        for (uint32_t i = 0; i + 1u < n_ent; ++i) {
+            const uint32_t e = i == 0u ? e4[0] : ent[i];
+            const uint32_t wr = ent_col(e);
+            if (wr >= width) break;
+            uint32_t bf = wr >> 3;
+            if (wr & 7u) {
+                if (bf != last_bb) {
+                    last_bb = bf;
+                    const uint32_t slot = atomicAdd(&s_nlist, 1u);     // (one at a time: the compiler's wave-wide form of an LDS atomic with a per-lane addend handed out overlapping ranges)
+                    if (slot < kSideCap) {
+                        s_list[slot] = (tid << 16) | ((i - 1u) << 8) | bf;
+                        tab[bf] = (uint16_t)(8u * (4u + slot));
+                    } else s_over[tid] = 1;
                 }
-                const uint32_t kind = e.x >> 30;
-                const uint32_t A = kind == 1u ? (uint32_t)(q.nb + (int)e.y + (c0 - (int)(e.x & kRunMask))) : kind == 2u ? 16u : 0u;
-                if ((int)(nx.x & kRunMask) < c0 + 8) inside |= 1u << (blk - b0);
-                tab[blk] = (uint16_t)A;
+                ++bf;
             }
-            while (inside) {
-                const uint32_t blk = b0 + (uint32_t)__ffs(inside) - 1u;
-                inside &= inside - 1u;
-                const uint32_t slot = atomicAdd(&s_nlist, 1u);
-                if (slot < kSideCap) {
-                    s_list[slot] = (uint16_t)((j << 5) | blk);
-                    tab[blk] = (uint16_t)(8u * (4u + slot));
-                } else s_over[j] = 1;
+            // the entry's addresses from block bf on: singly up to a multiple of four, then four blocks a store
+            const uint32_t st = ent_kind(e) == 1u ? 8u : 0u;
+            uint32_t av = ent_addr(e, row8, 8u * bf);
+            for (; (bf & 3u) && bf < kBlocks; ++bf) {
+                tab[bf] = (uint16_t)av;
+                av += st;
+            }
+            uint32_t lo = (av & 0xFFFFu) | ((av + st) << 16), hi = lo + 2u * (st | st << 16);
+            const uint32_t step = 4u * (st | st << 16);
+            uint2 *row_p = reinterpret_cast<uint2 *>(tab);
+            for (uint32_t k = bf >> 2; k < kBlocks / 4u; ++k) {
+                row_p[k] = make_uint2(lo, hi);
+                lo += step;
+                hi += step;
             }
         }
     }
     // ---- 3. the pieces -> codes -> the staging area, in query order
     if (!JL_ING_SKIP(a, 0)) {
 #pragma unroll
-        for (uint32_t it = 0; it < kFetchRounds; ++it) {
-            const uint32_t j = it * kReadsPerRound + f_slot;
-            stage(j, f_piece, pv[it]);
-            // a read with more pieces in the sweep (insertions, an unlucky alignment)
-            const uint32_t npj = (s_info[j].piece_hi_np >> 8) & 0xFFu;
-            for (uint32_t pp = f_piece + kLanesPerRead; __ballot(pp < npj) != 0ull; pp += kLanesPerRead) stage(j, pp, fetch(j, pp));
-        }
+        for (uint32_t it = 0; it < kFetchRounds; ++it) stage(tid + kThreads * it, pv[it]);
     }
     __syncthreads();
 
     // ---- 4. the blocks with a boundary inside, a thread each; a read whose blocks did not fit: 'not covered' + the slow kernel
-    for (uint32_t t = tid; t < n_walk; t += kThreads) {
-        const uint32_t j = s_walk[t];
-        if (s_over[j]) {
-            uint2 *row_p = reinterpret_cast<uint2 *>(s_tab + tab_row(j));
-            for (uint32_t k = 0; k < kTabRow / 4u; ++k) row_p[k] = make_uint2(0u, 0u);
-            const uint32_t at = atomicAdd(a.slow_count, 1u);
-            a.slow_list[at] = make_uint2((uint32_t)((uint64_t)tile * kTileReads + j), sweep);
-        }
+    if (tid < kTileReads && s_over[tid]) {
+        uint2 *row_p = reinterpret_cast<uint2 *>(s_tab + tab_row(tid));
+        for (uint32_t k = 0; k < kTabRow / 4u; ++k) row_p[k] = make_uint2(0u, 0u);
+        const uint32_t at = atomicAdd(a.slow_count, 1u);
+        a.slow_list[at] = make_uint2((uint32_t)((uint64_t)tile * kTileReads + tid), sweep);
     }
     if (!JL_ING_SKIP(a, 3)) {
         const uint32_t nl = min(s_nlist, kSideCap);
         for (uint32_t k = tid; k < nl; k += kThreads) {
-            const uint32_t it = s_list[k], j = it >> 5, blk = it & 31u;
+            const uint32_t it = s_list[k], j = it >> 16, blk = it & 31u;
             const read_info q = s_info[j];
-            const uint32_t cnt = q.row_nent >> 16;
-            const uint2 *ent = s_ent + (q.piece_hi_np >> 16);
-            const int c0 = X + 8 * (int)blk, c1 = c0 + 8;
+            const uint32_t cnt = q.meta >> 16;
+            const uint32_t *ent = s_ent + q.ent_off;
+            const uint32_t row8 = 8u * row_dw(j), c0 = 8u * blk, c1 = c0 + 8u;
             uint32_t R = 0x66666666u;
-            uint2 e = ent[0];
-            for (uint32_t i = 0; i + 1u < cnt; ++i) {
-                const uint2 nx = ent[i + 1u];
-                const int W = (int)(e.x & kRunMask), Wn = (int)(nx.x & kRunMask);
+            uint32_t i = (it >> 8) & 0xFFu;          // the entry before the first one that begins inside the block
+            uint32_t e = ent[i];
+            for (; i + 1u < cnt; ++i) {
+                const uint32_t nx = ent[i + 1u];
+                const uint32_t W = ent_col(e), Wn = ent_col(nx);
                 if (W >= c1) break;
-                const int ca = max(W, c0), cb = min(Wn, c1);
-                const uint32_t kind = e.x >> 30;
+                const uint32_t ca = max(W, c0), cb = min(Wn, c1);
+                const uint32_t kind = ent_kind(e);
                 if (ca < cb && kind != 3u) {
-                    const uint32_t m = (cb - ca == 8 ? 0xFFFFFFFFu : ((1u << (4 * (cb - ca))) - 1u)) << (4 * (ca - c0));
+                    const uint32_t m = (cb - ca == 8u ? 0xFFFFFFFFu : ((1u << (4u * (cb - ca))) - 1u)) << (4u * (ca - c0));
                     uint32_t v = 0x44444444u;
                     if (kind == 1u) {
-                        const uint32_t A = (uint32_t)(q.nb + (int)e.y + (ca - W));
-                        v = __builtin_amdgcn_alignbit(s_stage[(A >> 3) + 1u], s_stage[A >> 3], 4u * (A & 7u)) << (4 * (ca - c0));
+                        const uint32_t A = ent_addr(e, row8, ca);
+                        v = __builtin_amdgcn_alignbit(s_stage[(A >> 3) + 1u], s_stage[A >> 3], 4u * (A & 7u)) << (4u * (ca - c0));
                     }
                     R = (R & ~m) | (v & m);
                 }
@@ -758,7 +780,7 @@ __global__ __launch_bounds__(kThreads) void ingest_planes_kernel(ingest_args a)
     // ---- 5. gather at the transpose: thread = 32 reads x 8 columns; neighbouring lanes write consecutive dwords of a plane
     {
         const uint32_t G = tid % kTileGroups, blk = tid / kTileGroups;
-        if (blk < kBlocks && X + 8 * (int)blk < Xend && !JL_ING_SKIP(a, 4)) {
+        if (blk < kBlocks && 8u * blk < width && !JL_ING_SKIP(a, 4)) {
             uint32_t R[32];
             const uint16_t *tab = s_tab + tab_row(32u * G) + blk;
 #pragma unroll
@@ -771,24 +793,24 @@ __global__ __launch_bounds__(kThreads) void ingest_planes_kernel(ingest_args a)
             const uint64_t byte = (uint64_t)tile * (kTileReads / 8u) + (uint64_t)G * 4u;
 #ifdef JL_TUNING
             if (JL_ING_SKIP(a, 7)) {   // (probe: the same bytes in 16-byte stores, a quarter of the requests; wrong data by design)
-                uint8_t *row = a.msa + (uint64_t)(((uint32_t)X + 8u * blk) * 3u) * a.plane_stride + (uint64_t)tile * (kTileReads / 8u);
+                uint8_t *row = a.msa + (uint64_t)((X + 8u * blk) * 3u) * a.plane_stride + (uint64_t)tile * (kTileReads / 8u);
                 if (G == 0)
                     for (uint32_t jj = 0; jj < 8u; ++jj)
                         for (uint32_t k = 0; k < 3u; ++k) {
-                            if ((int)((uint32_t)X + 8u * blk + jj) < Xend) { u32x4 o = {out[jj][k], out[jj][0], out[jj][1], out[jj][2]}; *reinterpret_cast<u32x4 *>(row) = o; }
+                            if (X + 8u * blk + jj < Xend) { u32x4 o = {out[jj][k], out[jj][0], out[jj][1], out[jj][2]}; *reinterpret_cast<u32x4 *>(row) = o; }
                             row += a.plane_stride;
                         }
             } else
 #endif
             if (byte < a.plane_stride && (!JL_ING_SKIP(a, 2) || out[0][0] == 0x12345u)) {
                 // (one 64-bit multiply for the first plane row, then a stride at a time)
-                uint8_t *row = a.msa + (uint64_t)(((uint32_t)X + 8u * blk) * 3u) * a.plane_stride + byte;
+                uint8_t *row = a.msa + (uint64_t)((X + 8u * blk) * 3u) * a.plane_stride + byte;
 #pragma unroll
                 for (uint32_t jj = 0; jj < 8u; ++jj) {
-                    const uint32_t c = (uint32_t)X + 8u * blk + jj;
+                    const uint32_t c = X + 8u * blk + jj;
 #pragma unroll
                     for (uint32_t k = 0; k < 3u; ++k) {
-                        if ((int)c < Xend) *reinterpret_cast<uint32_t *>(row) = out[jj][k];
+                        if (c < Xend) *reinterpret_cast<uint32_t *>(row) = out[jj][k];
                         row += a.plane_stride;
                     }
                 }
