@@ -478,6 +478,29 @@ int jl_ingest_verdict(jl_ctx *ctx)
         if (int rc = jl_fetch_to_host(ctx, ctx->d_ing_count, 64, w, 64)) return rc;
         for (int c = 1; c < 6; ++c)
             if (w[4 + c]) fprintf(stderr, "ingest check %d failed %u times (a value: %u)\n", c, w[4 + c], w[10 + c]);
+        if (getenv("JL_ING_STAMPS") && ctx->d_ing_slow) {   // phase stamps of the sampled workgroups (kernels_ingest.hip JL_ING_STAMP)
+            std::vector<unsigned long long> t(160 * 4 * 12);
+            hipMemcpy(t.data(), ctx->d_ing_slow, t.size() * 8, hipMemcpyDeviceToHost);
+            double sum[4][12] = {{0}};
+            int n = 0;
+            for (int g = 0; g < 160; ++g) {
+                const unsigned long long *q = &t[(size_t)g * 48];
+                if (!q[0] || !q[10]) continue;
+                ++n;
+                for (int wv = 0; wv < 4; ++wv)
+                    for (int k = 1; k <= 10; ++k)
+                        if (q[wv * 12 + k] && q[wv * 12 + k - 1]) sum[wv][k] += 0.01 * (double)(q[wv * 12 + k] - q[wv * 12 + k - 1]);
+                        else if (q[wv * 12 + k] && k >= 2 && q[wv * 12 + k - 2]) sum[wv][k] += 0.01 * (double)(q[wv * 12 + k] - q[wv * 12 + k - 2]);
+            }
+            if (n) {
+                fprintf(stderr, "ingest stamps, %d workgroups, us per step (desc, prologue, barrier, fetch+fill, pieces, stage, barrier, general, barrier, transpose):\n", n);
+                for (int wv = 0; wv < 4; ++wv) {
+                    fprintf(stderr, "  wave %d:", wv);
+                    for (int k = 1; k <= 10; ++k) fprintf(stderr, " %6.2f", sum[wv][k] / n);
+                    fprintf(stderr, "\n");
+                }
+            }
+        }
     }
 #endif
     if (int rc = jl_fetch_to_host(ctx, ctx->d_ing_count, 16, both, 64)) return rc;

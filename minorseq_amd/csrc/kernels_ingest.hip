@@ -419,6 +419,7 @@ struct ingest_args {
     uint64_t plane_stride;
     uint64_t seq_bytes, n_entries;   // (tuning builds check every address a descriptor leads to against these and report in dbg[])
     uint32_t *dbg;
+    unsigned long long *stamps;  // (tuning builds)
     uint32_t skip;               // tuning builds: bit 0 no bases, bit 1 no table, bit 2 no stores, bit 3 no general pass, bit 4 no transposing, bit 6 no conversion
 };
 #ifdef JL_TUNING
@@ -430,9 +431,14 @@ struct ingest_args {
         (a).dbg[6 + (code)] = (uint32_t)(value); \
         fix;                                   \
     }
+// wall-clock stamps (10 ns) of every 61st workgroup's waves at the phase boundaries, in the (empty) slow list's memory
+#define JL_ING_STAMP(a, k)                                                                                        \
+    if ((a).stamps && blockIdx.x % 61u == 0u && blockIdx.x / 61u < 160u && (threadIdx.x & 63u) == 0u)           \
+        (a).stamps[((blockIdx.x / 61u) * 4u + (threadIdx.x >> 6)) * 12u + (k)] = wall_clock64();
 #else
 #define JL_ING_SKIP(a, bit) 0u
 #define JL_ING_CHECK(a, ok, code, value, fix)
+#define JL_ING_STAMP(a, k)
 #endif
 
 // LDS of a planes workgroup.  The staging area holds dwords of eight codes; a NIBBLE address into it fits 16 bits:
@@ -565,6 +571,7 @@ __global__ __launch_bounds__(kThreads) void ingest_planes_kernel(ingest_args a)
     if (group >= a.n_groups) return;
     const uint32_t tile = kSubTiles * group + sub;
     const uint32_t X = sweep * kSweep, Xend = min(a.n_cols, X + kSweep), width = Xend - X;
+    JL_ING_STAMP(a, 0)
 
     // ---- 0. the two read waves: one request per read (its descriptor); then its entries, its table row if one entry covers
     // the sweep, what the other phases need of it.  Each wave has its own half of the entry area and its own list of the
@@ -585,6 +592,9 @@ __global__ __launch_bounds__(kThreads) void ingest_planes_kernel(ingest_args a)
                 s_qhi[tid] = (uint32_t)(qo >> 32);
             }
         }
+#ifdef JL_TUNING
+        if (a.stamps) { asm volatile("" ::"v"(d.w)); JL_ING_STAMP(a, 1) }   // (the descriptor has arrived)
+#endif
         if (tid < 4u) s_stage[tid] = tid < 2u ? 0x66666666u : 0x44444444u;
         if (tid == 0) s_nlist = 0;
         s_over[tid] = 0;
@@ -641,7 +651,9 @@ __global__ __launch_bounds__(kThreads) void ingest_planes_kernel(ingest_args a)
             }
         }
     }
+    JL_ING_STAMP(a, 2)
     __syncthreads();
+    JL_ING_STAMP(a, 3)
 
     // ---- 1. the pieces: thread t takes pieces t, t + 256, ... of the tile's 128 x kRowPieces, 16 bytes (32 bases) each; all of a
     // thread's requests go out first (a thread without a piece asks for its read's first one again: the same number of requests
@@ -730,12 +742,18 @@ __global__ __launch_bounds__(kThreads) void ingest_planes_kernel(ingest_args a)
             }
         }
     }
+    JL_ING_STAMP(a, 4)
     // ---- 3. the pieces -> codes -> the staging area, in query order
+#ifdef JL_TUNING
+    if (a.stamps) { asm volatile("" ::"v"(pv[kFetchRounds - 1u].x), "v"(pv[0].x)); JL_ING_STAMP(a, 5) }   // (the pieces have arrived)
+#endif
     if (!JL_ING_SKIP(a, 0)) {
 #pragma unroll
         for (uint32_t it = 0; it < kFetchRounds; ++it) stage(tid + kThreads * it, pv[it]);
     }
+    JL_ING_STAMP(a, 6)
     __syncthreads();
+    JL_ING_STAMP(a, 7)
 
     // ---- 4. the blocks with a boundary inside, a thread each; a read whose blocks did not fit: 'not covered' + the slow kernel
     if (tid < kTileReads && s_over[tid]) {
@@ -775,7 +793,9 @@ __global__ __launch_bounds__(kThreads) void ingest_planes_kernel(ingest_args a)
             s_stage[4u + k] = R;
         }
     }
+    JL_ING_STAMP(a, 8)
     __syncthreads();
+    JL_ING_STAMP(a, 9)
 
     // ---- 5. gather at the transpose: thread = 32 reads x 8 columns; neighbouring lanes write consecutive dwords of a plane
     {
@@ -817,6 +837,7 @@ __global__ __launch_bounds__(kThreads) void ingest_planes_kernel(ingest_args a)
             }
         }
     }
+    JL_ING_STAMP(a, 10)
 }
 
 // ---------------------------------------------------------------------------------------- what the tiles left out
@@ -918,7 +939,12 @@ void jl_launch_ingest(jl_ctx *ctx, const int32_t *d_pos, const uint32_t *d_cigar
     a.n_entries = n_entries;
     a.dbg = d_slow_count + 4;    // (twelve spare words of the 64-byte block)
     a.skip = 0;
+    a.stamps = nullptr;
 #ifdef JL_TUNING
+    if (getenv("JL_ING_STAMPS") && (uint64_t)ctx->n_reads * ns * 8u >= 160u * 4u * 12u * 8u) {
+        a.stamps = reinterpret_cast<unsigned long long *>(d_slow);
+        hipMemsetAsync(d_slow, 0, 160u * 4u * 12u * 8u, st);
+    }
     hipMemsetAsync(d_slow_count + 4, 0, 48, st);
     if (const char *e = getenv("JL_ING_SKIP")) a.skip = (uint32_t)atoi(e);
 #endif
