@@ -535,7 +535,7 @@ static int records_build(jl_ctx *src, jl_ctx *dst, uint32_t n_cols, uint32_t win
     }
     const uint32_t ns = jl_ingest_sweeps(n_cols);
     const size_t nr = (size_t)R.n_reads;
-    if (e == hipSuccess) e = ingest_room(dst, &dst->d_ing_runs, &dst->ing_cap_runs, (size_t)R.n_cig + 3 * nr + 4);   // (three entries around a read's runs; + 4: the planes kernel reads entries four at a time)
+    if (e == hipSuccess) e = ingest_room(dst, &dst->d_ing_runs, &dst->ing_cap_runs, (size_t)R.n_cig + 3 * nr + 8);   // (three entries around a read's runs; + 8: the planes kernel reads entries four and eight at a time)
     if (e == hipSuccess) e = ingest_room(dst, &dst->d_ing_nruns, &dst->ing_cap_reads, nr + 1);
     if (e == hipSuccess) e = ingest_room(dst, &dst->d_ing_desc, &dst->ing_cap_desc, (nr + 1) * ns);
     if (e == hipSuccess) e = ingest_room(dst, &dst->d_ing_slow, &dst->ing_cap_slow, (nr + 1) * ns);
@@ -562,7 +562,7 @@ static int records_build(jl_ctx *src, jl_ctx *dst, uint32_t n_cols, uint32_t win
     if (e == hipSuccess) {
         jl_launch_ingest(dst, R.d_pos, R.d_cig, R.d_co, R.d_seq, R.d_so, R.have_qual ? R.d_qual : nullptr,
                          R.have_qual ? R.d_qo : nullptr, min_qv, dst->d_ing_runs, dst->d_ing_nruns, dst->d_ing_desc, dst->d_ing_count,
-                         dst->d_ing_slow, dst->ing_check_pending, R.n_seq, R.n_cig + 3 * nr + 4);
+                         dst->d_ing_slow, dst->ing_check_pending, R.n_seq, R.n_cig + 3 * nr + 8);
         e = hipGetLastError();
         dst->ing_check_pending = e == hipSuccess;
         if (e == hipSuccess && wait) e = hipStreamSynchronize(st);

@@ -448,9 +448,9 @@ struct ingest_args {
 //                      16-byte boundary on, + 8 dwords between the 32-read groups, so that the four reads a wave gathers from
 //                      at a time lie 8 banks apart.
 #ifndef JL_INGEST_SIDE
-#define JL_INGEST_SIDE 124
+#define JL_INGEST_SIDE 504                // side dwords of a workgroup: half of them for each of its two read waves
 #endif
-constexpr uint32_t kSideCap = JL_INGEST_SIDE;
+constexpr uint32_t kSideCap = JL_INGEST_SIDE, kSideCapWave = kSideCap / 2u;
 constexpr uint32_t kRowBase = 4u + kSideCap;
 #ifndef JL_INGEST_ROW_EXTRA
 #define JL_INGEST_ROW_EXTRA 0             // pieces of a row beyond a sweep's own (room for inserted bases: 32 a piece)
@@ -472,14 +472,9 @@ constexpr uint32_t kTabSize = kTileReads * kTabRow + kTileGroups * kTabGroupPad;
 __device__ __forceinline__ uint32_t tab_row(uint32_t j) { return j * kTabRow + (j >> 5) * kTabGroupPad; }
 static_assert(kRowBase % 4u == 0 && kStageDw * 8u <= 65536u, "16-byte pieces; 16-bit nibble addresses");
 static_assert(kTileReads == 128u && kThreads == 256u, "two waves of read threads with an entry region each");
-constexpr uint32_t kFetchRounds = (kTileReads * kRowPieces + kThreads - 1u) / kThreads;
+// the pieces of a tile: threads 128..255 take kPieceRoundsB rounds of 128 pieces, the read threads — who also make the table — the rest
+constexpr uint32_t kPieceRoundsA = 2u, kPieceRoundsB = kRowPieces - kPieceRoundsA;
 
-struct read_info {          // what the later phases need of one read of the tile (LDS, 16 bytes)
-    uint32_t piece_lo;      // index of its first 16-byte piece, low 32 bits
-    uint32_t meta;          // bits 32-39 of that | pieces << 8 | entries in s_ent << 16 (0: its table row is final)
-    uint32_t ent_off;       // its first entry in s_ent
-    int32_t q0;             // query offset of its first piece's first base
-};
 
 // 16 bytes of packed bases (BAM order: first base in the high nibble) -> 32 symbol codes, base b in nibble b & 7 of S[b >> 3];
 // QV: bases whose quality is below min_qv become N.  Q = query offset of the piece's base 0 (negative: the first -Q bases are
@@ -549,18 +544,28 @@ __device__ __forceinline__ uint32_t ent_addr(uint32_t e, uint32_t row8, uint32_t
     return kind == 1u ? row8 + (e >> 11) + (c - ent_col(e)) : kind == 2u ? 16u : 0u;
 }
 
+// A workgroup = 128 reads x one sweep, four waves with two jobs.  Nothing a thread asks HBM for depends on another thread: every
+// thread reads the descriptors of the reads whose pieces it takes itself (neighbouring lanes share them), so the two trips —
+// descriptor, then pieces / entries — are the only waits before the first barrier, and there are two barriers in all.
+//   waves 2, 3  pieces: thread t takes pieces t, t + 128, ... of the tile's 128 x kRowPieces (7 of 9 rounds), 16 bytes = 32 bases
+//               each -> codes -> the staging area in query order.
+//   waves 0, 1  a thread per read: its descriptor -> the row of the table (one entry covers the sweep: at once; several: an entry
+//               at a time when they have arrived), the boundary blocks listed; then the other 2 rounds of pieces.
+//   barrier; the listed blocks put together, a thread each; barrier; gather at the transpose (waves 0, 1).
+// (Device stamps of the form before this one — the read waves made the table while the others waited, then everybody staged:
+// descriptor 0.75 us, prologue 0.9, table 4.7 of which 1.5 a third trip for the reads with more than four entries, staging 1.8,
+// general 1.1, transposing 2.6; waves 2, 3 waited 5.2 us of 14.6 at the first barrier.)
 template <bool QV>
 __global__ __launch_bounds__(kThreads) void ingest_planes_kernel(ingest_args a)
 {
     __shared__ __attribute__((aligned(16))) uint32_t s_stage[kStageDw];
     __shared__ __attribute__((aligned(16))) uint16_t s_tab[kTabSize];
     __shared__ uint32_t s_ent[kEntCap];
-    __shared__ read_info s_info[kTileReads];
-    __shared__ uint32_t s_qlo[QV ? kTileReads : 1], s_qhi[QV ? kTileReads : 1];   // qual_off of every read
-    __shared__ uint32_t s_list[kSideCap];         // the blocks with a boundary inside: read << 16 | first entry to look at << 8 | block
+    __shared__ uint32_t s_info[kTileReads];       // entries of the read in s_ent << 16 | its first one
+    __shared__ uint16_t s_list[kSideCap];         // the blocks with a boundary inside: read << 9 | first entry to look at (<= 15) << 5 | block
     __shared__ uint8_t s_over[kTileReads];        // the read's boundary blocks did not all fit the side dwords: the slow kernel takes it
-    __shared__ uint32_t s_nlist;
-    const uint32_t tid = threadIdx.x, wid = tid >> 6;
+    __shared__ uint32_t s_nlist[2];
+    const uint32_t tid = threadIdx.x, wid = tid >> 6, lane = tid & 63u;
     // block -> (read tile, sweep).  Blocks b, b + 8, b + 16, ... are dealt to the same XCD one after the other; an XCD takes
     // whole groups of 1024 reads (group = xcd, xcd + 8, ...), and of a group all sweeps in turn, the tiles of the group
     // innermost.  So (a) the tiles that share the 128-byte lines of a sweep's planes meet in one L2, and (b) what the
@@ -571,78 +576,130 @@ __global__ __launch_bounds__(kThreads) void ingest_planes_kernel(ingest_args a)
     if (group >= a.n_groups) return;
     const uint32_t tile = kSubTiles * group + sub;
     const uint32_t X = sweep * kSweep, Xend = min(a.n_cols, X + kSweep), width = Xend - X;
+    const uint4 *desc = a.desc + (uint64_t)sweep * a.n_reads;
+    const uint64_t r0 = (uint64_t)tile * kTileReads;
     JL_ING_STAMP(a, 0)
 
-    // ---- 0. the two read waves: one request per read (its descriptor); then its entries, its table row if one entry covers
-    // the sweep, what the other phases need of it.  Each wave has its own half of the entry area and its own list of the
-    // reads whose rows come from a walk: nothing crosses waves before the barrier.
-    typedef uint32_t u32x4a8 __attribute__((ext_vector_type(4), aligned(8)));
-    uint32_t n_ent = 0, off_e = 0;
-    int32_t q0 = 0;
-    const uint2 *src = a.runs;
-    u32x4a8 e01 = {0, 0, 0, 0}, e23 = {0, 0, 0, 0};
-    if (tid < kTileReads) {
-        const uint64_t r = (uint64_t)tile * kTileReads + tid;
-        uint4 d = make_uint4(0, 0, 0, 3u << 8 | 1u << 24);   // (no read: one entry of nothing)
-        if (r < a.n_reads) {
-            d = a.desc[(uint64_t)sweep * a.n_reads + r];
-            if (QV) {
-                const uint64_t qo = a.qual_off[r];
-                s_qlo[tid] = (uint32_t)qo;
-                s_qhi[tid] = (uint32_t)(qo >> 32);
+    // the pieces p0, p0 + 128, ... (K of them): the descriptors of their reads, then the pieces, all of a thread's requests in
+    // flight together; a piece that is not there (the read has fewer) asks for the read's first one again — the same number of
+    // requests in every lane, so that a wait for something asked earlier does not wait for these
+    struct piece_t { u32x4 v; uint32_t dst; int32_t Q; uint64_t qb; };    // dst: dword in the staging area, 0 = none
+    auto ask_descs = [&](uint32_t p0, uint32_t K, uint4 (&d)[kPieceRoundsB], uint64_t (&qo)[kPieceRoundsB]) {
+#pragma unroll
+        for (uint32_t k = 0; k < kPieceRoundsB; ++k) {
+            if (k >= K) break;
+            const uint32_t j = (p0 + kTileReads * k) / kRowPieces;
+            d[k] = make_uint4(0, 0, 0, 0);
+            qo[k] = 0;
+            if (r0 + j < a.n_reads) {
+                d[k] = desc[r0 + j];
+                if (QV) qo[k] = a.qual_off[r0 + j];
             }
         }
+    };
+    auto ask_pieces = [&](uint32_t p0, uint32_t K, const uint4 (&d)[kPieceRoundsB], const uint64_t (&qo)[kPieceRoundsB], piece_t (&pc)[kPieceRoundsB]) {
+#pragma unroll
+        for (uint32_t k = 0; k < kPieceRoundsB; ++k) {
+            if (k >= K) break;
+            const uint32_t p = p0 + kTileReads * k, j = p / kRowPieces, i = p - kRowPieces * j;
+            uint32_t np = (d[k].w >> 16) & 0xFFu;
+            if (np > kRowPieces || (d[k].w >> 24) == kDescMax) np = 0;      // (the slow kernel's)
+            uint64_t at = ((((uint64_t)d[k].w & 0xFFu) << 32) | d[k].x) + (i < np ? i : 0u);
+            JL_ING_CHECK(a, 16u * at + 16u <= a.seq_bytes + 64u, 1, at, at = 0)
+            // (plain loads: neighbouring lanes' pieces share lines, and so do the sweeps of a read)
+            pc[k].v = *reinterpret_cast<const u32x4 *>(a.seq4 + 16u * at);
+            pc[k].dst = i < np ? row_dw(j) + 4u * i : 0u;
+            pc[k].Q = (int32_t)d[k].z + 32 * (int32_t)i;
+            pc[k].qb = qo[k];
+        }
+    };
+    auto stage_pieces = [&](uint32_t K, const piece_t (&pc)[kPieceRoundsB]) {
+#pragma unroll
+        for (uint32_t k = 0; k < kPieceRoundsB; ++k) {
+            if (k >= K) break;
+            if (!pc[k].dst) continue;
+            uint32_t S[4];
+            if (JL_ING_SKIP(a, 6)) { S[0] = pc[k].v.x; S[1] = pc[k].v.y; S[2] = pc[k].v.z; S[3] = pc[k].v.w; }
+            else piece_syms<QV>(a, pc[k].v, pc[k].Q, pc[k].qb, S);
+            u32x4 o = {S[0], S[1], S[2], S[3]};
+            *reinterpret_cast<u32x4 *>(&s_stage[pc[k].dst]) = o;
+        }
+    };
+
+    if (tid >= kTileReads) {
+        // ---- waves 2, 3: pieces
+        uint4 d[kPieceRoundsB];
+        uint64_t qo[kPieceRoundsB];
+        piece_t pc[kPieceRoundsB];
+        const uint32_t p0 = tid - kTileReads;
+        ask_descs(p0, kPieceRoundsB, d, qo);
+        ask_pieces(p0, kPieceRoundsB, d, qo, pc);
+        JL_ING_STAMP(a, 3)
+        if (!JL_ING_SKIP(a, 0)) stage_pieces(kPieceRoundsB, pc);
+        JL_ING_STAMP(a, 6)
+    } else {
+        // ---- waves 0, 1: a thread per read
+        typedef uint32_t u32x4a8 __attribute__((ext_vector_type(4), aligned(8)));
+        uint4 dp[kPieceRoundsB];
+        uint64_t qo[kPieceRoundsB];
+        piece_t pc[kPieceRoundsB];
+        const uint32_t p0 = kTileReads * kPieceRoundsB + tid;
+        const uint64_t r = r0 + tid;
+        uint4 d = make_uint4(0, 0, 0, 3u << 8 | 1u << 24);   // (no read: one entry of nothing)
+        if (r < a.n_reads) d = desc[r];
+        ask_descs(p0, kPieceRoundsA, dp, qo);
 #ifdef JL_TUNING
         if (a.stamps) { asm volatile("" ::"v"(d.w)); JL_ING_STAMP(a, 1) }   // (the descriptor has arrived)
 #endif
         if (tid < 4u) s_stage[tid] = tid < 2u ? 0x66666666u : 0x44444444u;
-        if (tid == 0) s_nlist = 0;
+        if (lane == 0) s_nlist[wid] = 0;
         s_over[tid] = 0;
-        uint32_t np = (d.w >> 16) & 0xFFu;
-        n_ent = d.w >> 24;
+        const uint32_t np = (d.w >> 16) & 0xFFu;
+        uint32_t n_ent = d.w >> 24;
         bool slow = np > kRowPieces || n_ent == kDescMax;
         const bool simple = n_ent == 1u;
         if (simple || slow) n_ent = 0;
-        // exclusive scan of the entries over the wave
+        // exclusive scan of the entries over the wave: each read wave has its own half of the entry area
         const uint32_t inc = wave_scan(n_ent);
-        off_e = inc - n_ent;
+        uint32_t off_e = inc - n_ent;
         if (n_ent && off_e + n_ent > kEntCapWave) {
             slow = true;
             n_ent = 0;
         }
-        if (slow) {
-            JL_ING_CHECK(a, r < a.n_reads, 3, r, slow = false)
-            np = 0;
-        }
+        JL_ING_CHECK(a, !slow || r < a.n_reads, 3, r, slow = false)
         if (slow) {
             const uint32_t at = atomicAdd(a.slow_count, 1u);
             a.slow_list[at] = make_uint2((uint32_t)r, sweep);
         }
         off_e += wid * kEntCapWave;
-        // the sweep's entries of this read: the first four in two 16-byte requests that go out together (entries past the
-        // read's own belong to the next read or to the array's slack)
+        // the sweep's entries of this read: the first eight in four 16-byte requests that go out together (entries past the
+        // read's own belong to the next read or to the array's slack) — two deletions in a sweep are six entries, and a
+        // wave in which ONE read needs a ninth makes another trip for it
         uint64_t src_at = n_ent ? ((((uint64_t)(d.w >> 8) & 0xFFu) << 32) | d.y) : 0u;
-        JL_ING_CHECK(a, src_at + n_ent + 2u <= a.n_entries, 2, src_at, src_at = 0)
-        src = a.runs + src_at;
+        JL_ING_CHECK(a, src_at + (n_ent > 4u ? max(n_ent, 8u) : 4u) <= a.n_entries, 2, src_at, src_at = 0)
+        const uint2 *src = a.runs + src_at;
+        u32x4a8 e01 = {0, 0, 0, 0}, e23 = e01, e45 = e01, e67 = e01;
         if (n_ent) {
             e01 = *reinterpret_cast<const u32x4a8 *>(src);
             e23 = *reinterpret_cast<const u32x4a8 *>(src + 2);
         }
-        q0 = (int32_t)d.z;
-        read_info ri;
-        ri.piece_lo = d.x;
-        ri.meta = (d.w & 0xFFu) | (np << 8) | (n_ent << 16);
-        ri.ent_off = off_e;
-        ri.q0 = q0;
-        s_info[tid] = ri;
+        if (n_ent > 4u) {
+            e45 = *reinterpret_cast<const u32x4a8 *>(src + 4);
+            e67 = *reinterpret_cast<const u32x4a8 *>(src + 6);
+        }
+        ask_pieces(p0, kPieceRoundsA, dp, qo, pc);
+        const int32_t q0 = (int32_t)d.z;
+        s_info[tid] = (n_ent << 16) | off_e;
+        uint16_t *tab = s_tab + tab_row(tid);
+        const uint32_t row8 = 8u * row_dw(tid);
         if (!n_ent) {
             // one entry covers the sweep: its blocks' addresses rise by eight codes a block (aligned bases) or stay (the
             // dword of '-', of 'not covered'), four blocks a store
             const uint32_t kind = (simple && !slow) ? (d.w >> 8) & 3u : 3u;
-            const uint32_t a0 = kind == 1u ? 8u * row_dw(tid) + (d.y - (uint32_t)q0) : kind == 2u ? 16u : 0u, st = kind == 1u ? 8u : 0u;
+            const uint32_t a0 = kind == 1u ? row8 + (d.y - (uint32_t)q0) : kind == 2u ? 16u : 0u, st = kind == 1u ? 8u : 0u;
             uint32_t lo = a0 | ((a0 + st) << 16), hi = lo + 2u * (st | st << 16);
             const uint32_t step = 4u * (st | st << 16);
-            uint2 *row_p = reinterpret_cast<uint2 *>(s_tab + tab_row(tid));
+            uint2 *row_p = reinterpret_cast<uint2 *>(tab);
 #pragma unroll
             for (uint32_t k = 0; k < kBlocks / 4u; ++k) {
                 row_p[k] = make_uint2(lo, hi);
@@ -650,128 +707,90 @@ __global__ __launch_bounds__(kThreads) void ingest_planes_kernel(ingest_args a)
                 hi += step;
             }
         }
-    }
-    JL_ING_STAMP(a, 2)
-    __syncthreads();
-    JL_ING_STAMP(a, 3)
-
-    // ---- 1. the pieces: thread t takes pieces t, t + 256, ... of the tile's 128 x kRowPieces, 16 bytes (32 bases) each; all of a
-    // thread's requests go out first (a thread without a piece asks for its read's first one again: the same number of requests
-    // in flight in every lane, so that the wait for the entries below does not wait for the pieces)
-    auto fetch = [&](uint32_t p) -> u32x4 {
-        const uint32_t j = min(p / kRowPieces, kTileReads - 1u), pc = p - kRowPieces * j;
-        const read_info q = s_info[j];
-        uint64_t at = ((((uint64_t)q.meta & 0xFFu) << 32) | q.piece_lo) + (pc < ((q.meta >> 8) & 0xFFu) ? pc : 0u);
-        JL_ING_CHECK(a, 16u * at + 16u <= a.seq_bytes + 64u, 1, at, at = 0)
-        // (plain loads: neighbouring lanes' pieces share lines, and so do the sweeps of a read)
-        return *reinterpret_cast<const u32x4 *>(a.seq4 + 16u * at);
-    };
-    auto stage = [&](uint32_t p, const u32x4 &v) {
-        const uint32_t j = p / kRowPieces, pc = p - kRowPieces * j;
-        if (j >= kTileReads) return;
-        const read_info q = s_info[j];
-        if (pc >= ((q.meta >> 8) & 0xFFu)) return;
-        const int Q = q.q0 + 32 * (int)pc;        // query offset of the piece's first base
-        uint32_t S[4];
-        const uint64_t qb = QV ? (((uint64_t)s_qhi[j] << 32) | s_qlo[j]) : 0u;
-        if (JL_ING_SKIP(a, 6)) { S[0] = v.x; S[1] = v.y; S[2] = v.z; S[3] = v.w; }
-        else piece_syms<QV>(a, v, Q, qb, S);
-        u32x4 o = {S[0], S[1], S[2], S[3]};
-        *reinterpret_cast<u32x4 *>(&s_stage[row_dw(j) + 4u * pc]) = o;
-    };
-    u32x4 pv[kFetchRounds];
-    if (!JL_ING_SKIP(a, 0)) {
+        JL_ING_STAMP(a, 2)
+        // several entries: -> LDS, four bytes each, for the general loop; the table row an entry at a time.  Entry i covers the
+        // columns [its column, the next entry's column) and the last one only ends the one before it, so the row is entry 0's
+        // addresses all along, overwritten from entry 1's first whole block on with entry 1's, and so on: four blocks a
+        // store, no search and no decision per block.  The block an entry begins INSIDE is listed: the general loop puts it
+        // together in a side dword.
+        if (n_ent && !JL_ING_SKIP(a, 1)) {
+            auto pack = [&](uint32_t x, uint32_t y) -> uint32_t {
+                const uint32_t W = x & kRunMask, kind = x >> 30;
+                const uint32_t wr = W <= X ? 0u : min(W - X, 256u);
+                const uint32_t yq = y + (W < X ? X - W : 0u);      // query offset at the sweep's first column of the entry
+                const uint32_t yr = (kind == 1u && wr < 256u) ? (yq - (uint32_t)q0) & 0x1FFFu : 0u;
+                return wr | (kind << 9) | (yr << 11);
+            };
+            const uint32_t e8[8] = {pack(e01.x, e01.y), pack(e01.z, e01.w), pack(e23.x, e23.y), pack(e23.z, e23.w),
+                                    pack(e45.x, e45.y), pack(e45.z, e45.w), pack(e67.x, e67.y), pack(e67.z, e67.w)};
+            uint32_t *ent = s_ent + off_e;
 #pragma unroll
-        for (uint32_t it = 0; it < kFetchRounds; ++it) pv[it] = fetch(tid + kThreads * it);
-    }
-    // ---- 2. the reads with several entries in the sweep (they were asked for before the pieces): the entries -> LDS, four bytes
-    // each, for the general loop; the table row by the read's own thread, an entry at a time.  Entry i covers the columns
-    // [its column, the next entry's column) and the last one only ends the one before it, so the row is entry 0's addresses
-    // all along, overwritten from entry 1's first whole block on with entry 1's, and so on: four blocks a store, no search
-    // and no decision per block.  The block an entry begins INSIDE is listed: the general loop puts it together in a side dword.
-    if (n_ent && !JL_ING_SKIP(a, 1)) {
-        auto pack = [&](uint32_t x, uint32_t y) -> uint32_t {
-            const uint32_t W = x & kRunMask, kind = x >> 30;
-            const uint32_t wr = W <= X ? 0u : min(W - X, 256u);
-            const uint32_t yq = y + (W < X ? X - W : 0u);      // query offset at the sweep's first column of the entry
-            const uint32_t yr = (kind == 1u && wr < 256u) ? (yq - (uint32_t)q0) & 0x1FFFu : 0u;
-            return wr | (kind << 9) | (yr << 11);
-        };
-        const uint32_t e4[4] = {pack(e01.x, e01.y), pack(e01.z, e01.w), pack(e23.x, e23.y), pack(e23.z, e23.w)};
-        uint32_t *ent = s_ent + off_e;
-#pragma unroll
-        for (uint32_t i = 0; i < 4u; ++i)
-            if (i < n_ent) ent[i] = e4[i];
-        for (uint32_t i = 4; i < n_ent; ++i) {
-            const uint2 g = src[i];
-            ent[i] = pack(g.x, g.y);
-        }
-        const uint32_t row8 = 8u * row_dw(tid);
-        uint16_t *tab = s_tab + tab_row(tid);
-        uint32_t last_bb = 0xFFFFFFFFu;
-        for (uint32_t i = 0; i + 1u < n_ent; ++i) {
-            const uint32_t e = i == 0u ? e4[0] : ent[i];
-            const uint32_t wr = ent_col(e);
-            if (wr >= width) break;
-            uint32_t bf = wr >> 3;
-            if (wr & 7u) {
-                if (bf != last_bb) {
-                    last_bb = bf;
-                    const uint32_t slot = atomicAdd(&s_nlist, 1u);     // (one at a time: the compiler's wave-wide form of an LDS atomic with a per-lane addend handed out overlapping ranges)
-                    if (slot < kSideCap) {
-                        s_list[slot] = (tid << 16) | ((i - 1u) << 8) | bf;
-                        tab[bf] = (uint16_t)(8u * (4u + slot));
-                    } else s_over[tid] = 1;
+            for (uint32_t i = 0; i < 8u; ++i)
+                if (i < n_ent) ent[i] = e8[i];
+            for (uint32_t i = 8; i < n_ent; ++i) {
+                const uint2 g = src[i];
+                ent[i] = pack(g.x, g.y);
+            }
+            uint32_t last_bb = 0xFFFFFFFFu;
+            for (uint32_t i = 0; i + 1u < n_ent; ++i) {
+                const uint32_t e = i == 0u ? e8[0] : ent[i];
+                const uint32_t wr = ent_col(e);
+                if (wr >= width) break;
+                uint32_t bf = wr >> 3;
+                if (wr & 7u) {
+                    if (bf != last_bb) {
+                        last_bb = bf;
+                        const uint32_t slot = atomicAdd(&s_nlist[wid], 1u);     // (one at a time: the compiler's wave-wide form of an LDS atomic with a per-lane addend handed out overlapping ranges)
+                        if (slot < kSideCapWave) {
+                            s_list[wid * kSideCapWave + slot] = (uint16_t)((tid << 9) | (min(i - 1u, 15u) << 5) | bf);
+                            tab[bf] = (uint16_t)(8u * (4u + wid * kSideCapWave + slot));
+                        } else s_over[tid] = 1;
+                    }
+                    ++bf;
                 }
-                ++bf;
-            }
-            // the entry's addresses from block bf on: singly up to a multiple of four, then four blocks a store
-            const uint32_t st = ent_kind(e) == 1u ? 8u : 0u;
-            uint32_t av = ent_addr(e, row8, 8u * bf);
-            for (; (bf & 3u) && bf < kBlocks; ++bf) {
-                tab[bf] = (uint16_t)av;
-                av += st;
-            }
-            uint32_t lo = (av & 0xFFFFu) | ((av + st) << 16), hi = lo + 2u * (st | st << 16);
-            const uint32_t step = 4u * (st | st << 16);
-            uint2 *row_p = reinterpret_cast<uint2 *>(tab);
-            for (uint32_t k = bf >> 2; k < kBlocks / 4u; ++k) {
-                row_p[k] = make_uint2(lo, hi);
-                lo += step;
-                hi += step;
+                // the entry's addresses from block bf on: singly up to a multiple of four, then four blocks a store
+                const uint32_t st = ent_kind(e) == 1u ? 8u : 0u;
+                uint32_t av = ent_addr(e, row8, 8u * bf);
+                for (; (bf & 3u) && bf < kBlocks; ++bf) {
+                    tab[bf] = (uint16_t)av;
+                    av += st;
+                }
+                uint32_t lo = (av & 0xFFFFu) | ((av + st) << 16), hi = lo + 2u * (st | st << 16);
+                const uint32_t step = 4u * (st | st << 16);
+                uint2 *row_p = reinterpret_cast<uint2 *>(tab);
+                for (uint32_t k = bf >> 2; k < kBlocks / 4u; ++k) {
+                    row_p[k] = make_uint2(lo, hi);
+                    lo += step;
+                    hi += step;
+                }
             }
         }
+        JL_ING_STAMP(a, 4)
+        if (!JL_ING_SKIP(a, 0)) stage_pieces(kPieceRoundsA, pc);
+        JL_ING_STAMP(a, 6)
     }
-    JL_ING_STAMP(a, 4)
-    // ---- 3. the pieces -> codes -> the staging area, in query order
-#ifdef JL_TUNING
-    if (a.stamps) { asm volatile("" ::"v"(pv[kFetchRounds - 1u].x), "v"(pv[0].x)); JL_ING_STAMP(a, 5) }   // (the pieces have arrived)
-#endif
-    if (!JL_ING_SKIP(a, 0)) {
-#pragma unroll
-        for (uint32_t it = 0; it < kFetchRounds; ++it) stage(tid + kThreads * it, pv[it]);
-    }
-    JL_ING_STAMP(a, 6)
     __syncthreads();
     JL_ING_STAMP(a, 7)
 
-    // ---- 4. the blocks with a boundary inside, a thread each; a read whose blocks did not fit: 'not covered' + the slow kernel
+    // ---- the blocks with a boundary inside, a thread each; a read whose blocks did not fit: 'not covered' + the slow kernel
     if (tid < kTileReads && s_over[tid]) {
         uint2 *row_p = reinterpret_cast<uint2 *>(s_tab + tab_row(tid));
         for (uint32_t k = 0; k < kTabRow / 4u; ++k) row_p[k] = make_uint2(0u, 0u);
         const uint32_t at = atomicAdd(a.slow_count, 1u);
-        a.slow_list[at] = make_uint2((uint32_t)((uint64_t)tile * kTileReads + tid), sweep);
+        a.slow_list[at] = make_uint2((uint32_t)(r0 + tid), sweep);
     }
     if (!JL_ING_SKIP(a, 3)) {
-        const uint32_t nl = min(s_nlist, kSideCap);
-        for (uint32_t k = tid; k < nl; k += kThreads) {
-            const uint32_t it = s_list[k], j = it >> 16, blk = it & 31u;
-            const read_info q = s_info[j];
-            const uint32_t cnt = q.meta >> 16;
-            const uint32_t *ent = s_ent + q.ent_off;
+        // (thread t: the t-th block of wave t & 1's list... the two lists side by side, every other thread each)
+        const uint32_t w = tid & 1u, k = tid >> 1;
+        for (uint32_t kk = k; kk < min(s_nlist[w], kSideCapWave); kk += kThreads / 2u) {
+            const uint32_t slot = w * kSideCapWave + kk;
+            const uint32_t it = s_list[slot], j = it >> 9, blk = it & 31u;
+            const uint32_t meta = s_info[j];
+            const uint32_t cnt = meta >> 16;
+            const uint32_t *ent = s_ent + (meta & 0xFFFFu);
             const uint32_t row8 = 8u * row_dw(j), c0 = 8u * blk, c1 = c0 + 8u;
             uint32_t R = 0x66666666u;
-            uint32_t i = (it >> 8) & 0xFFu;          // the entry before the first one that begins inside the block
+            uint32_t i = (it >> 5) & 15u;          // an entry at or before the last one that begins before the block
             uint32_t e = ent[i];
             for (; i + 1u < cnt; ++i) {
                 const uint32_t nx = ent[i + 1u];
@@ -790,14 +809,14 @@ __global__ __launch_bounds__(kThreads) void ingest_planes_kernel(ingest_args a)
                 }
                 e = nx;
             }
-            s_stage[4u + k] = R;
+            s_stage[4u + slot] = R;
         }
     }
     JL_ING_STAMP(a, 8)
     __syncthreads();
     JL_ING_STAMP(a, 9)
 
-    // ---- 5. gather at the transpose: thread = 32 reads x 8 columns; neighbouring lanes write consecutive dwords of a plane
+    // ---- gather at the transpose: thread = 32 reads x 8 columns; neighbouring lanes write consecutive dwords of a plane
     {
         const uint32_t G = tid % kTileGroups, blk = tid / kTileGroups;
         if (blk < kBlocks && 8u * blk < width && !JL_ING_SKIP(a, 4)) {
@@ -811,17 +830,6 @@ __global__ __launch_bounds__(kThreads) void ingest_planes_kernel(ingest_args a)
             uint32_t out[8][3];
             nibble_rows_to_plane_words(R, out);
             const uint64_t byte = (uint64_t)tile * (kTileReads / 8u) + (uint64_t)G * 4u;
-#ifdef JL_TUNING
-            if (JL_ING_SKIP(a, 7)) {   // (probe: the same bytes in 16-byte stores, a quarter of the requests; wrong data by design)
-                uint8_t *row = a.msa + (uint64_t)((X + 8u * blk) * 3u) * a.plane_stride + (uint64_t)tile * (kTileReads / 8u);
-                if (G == 0)
-                    for (uint32_t jj = 0; jj < 8u; ++jj)
-                        for (uint32_t k = 0; k < 3u; ++k) {
-                            if (X + 8u * blk + jj < Xend) { u32x4 o = {out[jj][k], out[jj][0], out[jj][1], out[jj][2]}; *reinterpret_cast<u32x4 *>(row) = o; }
-                            row += a.plane_stride;
-                        }
-            } else
-#endif
             if (byte < a.plane_stride && (!JL_ING_SKIP(a, 2) || out[0][0] == 0x12345u)) {
                 // (one 64-bit multiply for the first plane row, then a stride at a time)
                 uint8_t *row = a.msa + (uint64_t)((X + 8u * blk) * 3u) * a.plane_stride + byte;
@@ -898,7 +906,7 @@ __global__ __launch_bounds__(256) void ingest_slow_kernel(ingest_args a, const u
 
 uint32_t jl_ingest_sweeps(uint32_t n_cols) { return (n_cols + kSweep - 1u) / kSweep; }
 
-// d_runs: n_cig + 3 n_reads + 4 entries; d_nruns: n_reads; d_desc: n_reads x sweeps descriptors; d_slow: n_reads x sweeps pairs
+// d_runs: n_cig + 3 n_reads + 8 entries; d_nruns: n_reads; d_desc: n_reads x sweeps descriptors; d_slow: n_reads x sweeps pairs
 // behind one counter word (zeroed here); d_slow_count[2..3] = the 64-bit word of the first malformed record (all ones: none;
 // `keep_verdict`: an earlier build's word has not been read yet — this build's is folded into it, atomicMin).
 // Everything is enqueued on ctx->stream; nothing waits.
