@@ -443,27 +443,23 @@ struct ingest_args {
 
 // LDS of a planes workgroup.  The staging area holds dwords of eight codes; a NIBBLE address into it fits 16 bits:
 //   dwords 0-1 'not covered' twice, 2-3 '-' twice (what a table entry of a block nothing / a deletion covers points at),
-//   4 .. 4 + kSideCap  the blocks the general loop puts together (one dword each),
+//   4 .. 4 + kEntCap   the blocks with a boundary inside, put together (a dword for every entry: the block it begins inside),
 //   kRowBase ..        the reads' codes in query order: a row of kRowPieces 16-byte pieces per read — a sweep's bases from a
 //                      16-byte boundary on, + 8 dwords between the 32-read groups, so that the four reads a wave gathers from
 //                      at a time lie 8 banks apart.
-#ifndef JL_INGEST_SIDE
-#define JL_INGEST_SIDE 504                // side dwords of a workgroup: half of them for each of its two read waves
-#endif
-constexpr uint32_t kSideCap = JL_INGEST_SIDE, kSideCapWave = kSideCap / 2u;
-constexpr uint32_t kRowBase = 4u + kSideCap;
-#ifndef JL_INGEST_ROW_EXTRA
-#define JL_INGEST_ROW_EXTRA 0             // pieces of a row beyond a sweep's own (room for inserted bases: 32 a piece)
-#endif
-constexpr uint32_t kRowPieces = (kSweep + 31u) / 32u + 1u + JL_INGEST_ROW_EXTRA, kRowDw = 4u * kRowPieces, kGroupPadDw = 8u;
-__device__ __forceinline__ uint32_t row_dw(uint32_t j) { return kRowBase + kRowDw * j + kGroupPadDw * (j >> 5); }
-constexpr uint32_t kStageDw = kRowBase + kRowDw * kTileReads + kGroupPadDw * kTileGroups + 4u;
 #ifndef JL_INGEST_ENT_PER_READ
 #define JL_INGEST_ENT_PER_READ 4
 #endif
 // entries of the reads that need them (a CCS read: 4 in a sweep with an indel), 4 bytes each in LDS:
 // column - sweep's first (0..256: 9 bits) | kind << 9 | (query offset there - the row's first) << 11
 constexpr uint32_t kEntCap = JL_INGEST_ENT_PER_READ * kTileReads, kEntCapWave = kEntCap / 2u;
+constexpr uint32_t kRowBase = 4u + kEntCap;     // (a side dword per entry: an entry begins inside one block at most)
+#ifndef JL_INGEST_ROW_EXTRA
+#define JL_INGEST_ROW_EXTRA 0             // pieces of a row beyond a sweep's own (room for inserted bases: 32 a piece)
+#endif
+constexpr uint32_t kRowPieces = (kSweep + 31u) / 32u + 1u + JL_INGEST_ROW_EXTRA, kRowDw = 4u * kRowPieces, kGroupPadDw = 8u;
+__device__ __forceinline__ uint32_t row_dw(uint32_t j) { return kRowBase + kRowDw * j + kGroupPadDw * (j >> 5); }
+constexpr uint32_t kStageDw = kRowBase + kRowDw * kTileReads + kGroupPadDw * kTileGroups + 4u;
 // the table: 32 entries (16 bits) a read — rows on 8-byte boundaries for the four-entries-at-a-time stores —
 // and 8 dwords of padding per 32 reads: the four 32-read groups of a wave's lanes read it 8 banks apart
 constexpr uint32_t kTabRow = 32u, kTabGroupPad = 16u;
@@ -560,11 +556,9 @@ __global__ __launch_bounds__(kThreads) void ingest_planes_kernel(ingest_args a)
 {
     __shared__ __attribute__((aligned(16))) uint32_t s_stage[kStageDw];
     __shared__ __attribute__((aligned(16))) uint16_t s_tab[kTabSize];
-    __shared__ uint32_t s_ent[kEntCap];
-    __shared__ uint32_t s_info[kTileReads];       // entries of the read in s_ent << 16 | its first one
-    __shared__ uint16_t s_list[kSideCap];         // the blocks with a boundary inside: read << 9 | first entry to look at (<= 15) << 5 | block
-    __shared__ uint8_t s_over[kTileReads];        // the read's boundary blocks did not all fit the side dwords: the slow kernel takes it
-    __shared__ uint32_t s_nlist[2];
+    __shared__ uint32_t s_ent[kEntCap];           // the entries of the reads with several in the sweep, a half per read wave
+    __shared__ uint8_t s_own[kEntCap];            // whose: the read | 0x80 for its last one
+    __shared__ uint32_t s_nent[2];                // entries in each half
     const uint32_t tid = threadIdx.x, wid = tid >> 6, lane = tid & 63u;
     // block -> (read tile, sweep).  Blocks b, b + 8, b + 16, ... are dealt to the same XCD one after the other; an XCD takes
     // whole groups of 1024 reads (group = xcd, xcd + 8, ...), and of a group all sweeps in turn, the tiles of the group
@@ -652,8 +646,7 @@ __global__ __launch_bounds__(kThreads) void ingest_planes_kernel(ingest_args a)
         if (a.stamps) { asm volatile("" ::"v"(d.w)); JL_ING_STAMP(a, 1) }   // (the descriptor has arrived)
 #endif
         if (tid < 4u) s_stage[tid] = tid < 2u ? 0x66666666u : 0x44444444u;
-        if (lane == 0) s_nlist[wid] = 0;
-        s_over[tid] = 0;
+        if (lane == 0) s_nent[wid] = 0;
         const uint32_t np = (d.w >> 16) & 0xFFu;
         uint32_t n_ent = d.w >> 24;
         bool slow = np > kRowPieces || n_ent == kDescMax;
@@ -689,7 +682,6 @@ __global__ __launch_bounds__(kThreads) void ingest_planes_kernel(ingest_args a)
         }
         ask_pieces(p0, kPieceRoundsA, dp, qo, pc);
         const int32_t q0 = (int32_t)d.z;
-        s_info[tid] = (n_ent << 16) | off_e;
         uint16_t *tab = s_tab + tab_row(tid);
         const uint32_t row8 = 8u * row_dw(tid);
         if (!n_ent) {
@@ -708,12 +700,8 @@ __global__ __launch_bounds__(kThreads) void ingest_planes_kernel(ingest_args a)
             }
         }
         JL_ING_STAMP(a, 2)
-        // several entries: -> LDS, four bytes each, for the general loop; the table row an entry at a time.  Entry i covers the
-        // columns [its column, the next entry's column) and the last one only ends the one before it, so the row is entry 0's
-        // addresses all along, overwritten from entry 1's first whole block on with entry 1's, and so on: four blocks a
-        // store, no search and no decision per block.  The block an entry begins INSIDE is listed: the general loop puts it
-        // together in a side dword.
-        if (n_ent && !JL_ING_SKIP(a, 1)) {
+        // several entries: -> LDS, four bytes each, with their owner; everybody makes table rows of them behind the barrier
+        if (n_ent) {
             auto pack = [&](uint32_t x, uint32_t y) -> uint32_t {
                 const uint32_t W = x & kRunMask, kind = x >> 30;
                 const uint32_t wr = W <= X ? 0u : min(W - X, 256u);
@@ -724,46 +712,19 @@ __global__ __launch_bounds__(kThreads) void ingest_planes_kernel(ingest_args a)
             const uint32_t e8[8] = {pack(e01.x, e01.y), pack(e01.z, e01.w), pack(e23.x, e23.y), pack(e23.z, e23.w),
                                     pack(e45.x, e45.y), pack(e45.z, e45.w), pack(e67.x, e67.y), pack(e67.z, e67.w)};
             uint32_t *ent = s_ent + off_e;
+            uint8_t *own = s_own + off_e;
 #pragma unroll
             for (uint32_t i = 0; i < 8u; ++i)
-                if (i < n_ent) ent[i] = e8[i];
+                if (i < n_ent) {
+                    ent[i] = e8[i];
+                    own[i] = (uint8_t)(tid | (i + 1u == n_ent ? 0x80u : 0u));
+                }
             for (uint32_t i = 8; i < n_ent; ++i) {
                 const uint2 g = src[i];
                 ent[i] = pack(g.x, g.y);
+                own[i] = (uint8_t)(tid | (i + 1u == n_ent ? 0x80u : 0u));
             }
-            uint32_t last_bb = 0xFFFFFFFFu;
-            for (uint32_t i = 0; i + 1u < n_ent; ++i) {
-                const uint32_t e = i == 0u ? e8[0] : ent[i];
-                const uint32_t wr = ent_col(e);
-                if (wr >= width) break;
-                uint32_t bf = wr >> 3;
-                if (wr & 7u) {
-                    if (bf != last_bb) {
-                        last_bb = bf;
-                        const uint32_t slot = atomicAdd(&s_nlist[wid], 1u);     // (one at a time: the compiler's wave-wide form of an LDS atomic with a per-lane addend handed out overlapping ranges)
-                        if (slot < kSideCapWave) {
-                            s_list[wid * kSideCapWave + slot] = (uint16_t)((tid << 9) | (min(i - 1u, 15u) << 5) | bf);
-                            tab[bf] = (uint16_t)(8u * (4u + wid * kSideCapWave + slot));
-                        } else s_over[tid] = 1;
-                    }
-                    ++bf;
-                }
-                // the entry's addresses from block bf on: singly up to a multiple of four, then four blocks a store
-                const uint32_t st = ent_kind(e) == 1u ? 8u : 0u;
-                uint32_t av = ent_addr(e, row8, 8u * bf);
-                for (; (bf & 3u) && bf < kBlocks; ++bf) {
-                    tab[bf] = (uint16_t)av;
-                    av += st;
-                }
-                uint32_t lo = (av & 0xFFFFu) | ((av + st) << 16), hi = lo + 2u * (st | st << 16);
-                const uint32_t step = 4u * (st | st << 16);
-                uint2 *row_p = reinterpret_cast<uint2 *>(tab);
-                for (uint32_t k = bf >> 2; k < kBlocks / 4u; ++k) {
-                    row_p[k] = make_uint2(lo, hi);
-                    lo += step;
-                    hi += step;
-                }
-            }
+            atomicMax(&s_nent[wid], off_e - wid * kEntCapWave + n_ent);
         }
         JL_ING_STAMP(a, 4)
         if (!JL_ING_SKIP(a, 0)) stage_pieces(kPieceRoundsA, pc);
@@ -772,44 +733,75 @@ __global__ __launch_bounds__(kThreads) void ingest_planes_kernel(ingest_args a)
     __syncthreads();
     JL_ING_STAMP(a, 7)
 
-    // ---- the blocks with a boundary inside, a thread each; a read whose blocks did not fit: 'not covered' + the slow kernel
-    if (tid < kTileReads && s_over[tid]) {
-        uint2 *row_p = reinterpret_cast<uint2 *>(s_tab + tab_row(tid));
-        for (uint32_t k = 0; k < kTabRow / 4u; ++k) row_p[k] = make_uint2(0u, 0u);
-        const uint32_t at = atomicAdd(a.slow_count, 1u);
-        a.slow_list[at] = make_uint2((uint32_t)(r0 + tid), sweep);
-    }
-    if (!JL_ING_SKIP(a, 3)) {
-        // (thread t: the t-th block of wave t & 1's list... the two lists side by side, every other thread each)
-        const uint32_t w = tid & 1u, k = tid >> 1;
-        for (uint32_t kk = k; kk < min(s_nlist[w], kSideCapWave); kk += kThreads / 2u) {
-            const uint32_t slot = w * kSideCapWave + kk;
-            const uint32_t it = s_list[slot], j = it >> 9, blk = it & 31u;
-            const uint32_t meta = s_info[j];
-            const uint32_t cnt = meta >> 16;
-            const uint32_t *ent = s_ent + (meta & 0xFFFFu);
-            const uint32_t row8 = 8u * row_dw(j), c0 = 8u * blk, c1 = c0 + 8u;
+    // ---- the table rows of the reads with several entries, everybody: a thread an entry.  Entry i
+    // of a read covers the columns [its column, the next entry's column) and the read's last one only ends the one before
+    // it: the blocks that lie WHOLLY inside are the entry's — addresses that rise by eight codes a block, or the dword of '-' /
+    // of 'not covered' — and every block is wholly inside one entry or has an entry that begins inside it; those are put
+    // together, by the thread of the first such entry, in that entry's side dword.  No list, no search, no loop per block.
+    if (!JL_ING_SKIP(a, 1)) {
+        const uint32_t n_a = s_nent[0], n_e = n_a + s_nent[1];
+        for (uint32_t si = tid; si < n_e; si += kThreads) {
+            const uint32_t slot = si < n_a ? si : kEntCapWave + (si - n_a);
+            const uint32_t own = s_own[slot], e = s_ent[slot], nx = s_ent[slot + 1u];
+            const uint32_t wr = ent_col(e);
+            if ((own & 0x80u) || wr >= width) continue;
+            const uint32_t row8 = 8u * row_dw(own);
+            uint16_t *tab = s_tab + tab_row(own);
+            // (a) the entry's whole blocks [bf, be): singly up to a multiple of four, four a store, singly again
+            const uint32_t wn = ent_col(nx);
+            const uint32_t be = wn >= width ? kBlocks : wn >> 3;
+            uint32_t bf = (wr + 7u) >> 3;
+            if (bf < be) {
+                const uint32_t st = ent_kind(e) == 1u ? 8u : 0u;
+                uint32_t av = ent_addr(e, row8, 8u * bf);
+#pragma unroll
+                for (uint32_t k = 0; k < 3u; ++k)
+                    if ((bf & 3u) && bf < be) {
+                        tab[bf] = (uint16_t)av;
+                        av += st;
+                        ++bf;
+                    }
+                uint32_t p01 = av | ((av + st) << 16);
+                const uint32_t p_st = st | st << 16;
+                for (; bf + 4u <= be; bf += 4u) {
+                    reinterpret_cast<uint2 *>(tab)[bf >> 2] = make_uint2(p01, p01 + 2u * p_st);
+                    p01 += 4u * p_st;
+                }
+                av = p01 & 0xFFFFu;
+#pragma unroll
+                for (uint32_t k = 0; k < 3u; ++k)
+                    if (bf < be) {
+                        tab[bf] = (uint16_t)av;
+                        av += st;
+                        ++bf;
+                    }
+            }
+            // (b) the block it begins inside, if it is the first entry to do so
+            const uint32_t bb = wr >> 3;
+            if (!(wr & 7u) || JL_ING_SKIP(a, 3)) continue;
+            uint32_t ee = s_ent[slot - 1u];        // (an entry that begins inside a block is not its read's first)
+            if (ent_col(ee) > 8u * bb) continue;
+            const uint32_t c0 = 8u * bb, c1 = c0 + 8u;
             uint32_t R = 0x66666666u;
-            uint32_t i = (it >> 5) & 15u;          // an entry at or before the last one that begins before the block
-            uint32_t e = ent[i];
-            for (; i + 1u < cnt; ++i) {
-                const uint32_t nx = ent[i + 1u];
-                const uint32_t W = ent_col(e), Wn = ent_col(nx);
-                if (W >= c1) break;
+            for (uint32_t kk = slot;; ++kk) {
+                const uint32_t nn = s_ent[kk];
+                const uint32_t W = ent_col(ee), Wn = ent_col(nn);
                 const uint32_t ca = max(W, c0), cb = min(Wn, c1);
-                const uint32_t kind = ent_kind(e);
+                const uint32_t kind = ent_kind(ee);
                 if (ca < cb && kind != 3u) {
                     const uint32_t m = (cb - ca == 8u ? 0xFFFFFFFFu : ((1u << (4u * (cb - ca))) - 1u)) << (4u * (ca - c0));
                     uint32_t v = 0x44444444u;
                     if (kind == 1u) {
-                        const uint32_t A = ent_addr(e, row8, ca);
+                        const uint32_t A = ent_addr(ee, row8, ca);
                         v = __builtin_amdgcn_alignbit(s_stage[(A >> 3) + 1u], s_stage[A >> 3], 4u * (A & 7u)) << (4u * (ca - c0));
                     }
                     R = (R & ~m) | (v & m);
                 }
-                e = nx;
+                if (Wn >= c1 || (s_own[kk] & 0x80u)) break;     // (the read's last entry is nothing: 'not covered' stays)
+                ee = nn;
             }
             s_stage[4u + slot] = R;
+            tab[bb] = (uint16_t)(8u * (4u + slot));
         }
     }
     JL_ING_STAMP(a, 8)
