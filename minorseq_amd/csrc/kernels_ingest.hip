@@ -374,10 +374,13 @@ __device__ __forceinline__ void transpose_nibbles_8x8(uint32_t (&m)[8])
     }
 }
 
-// 32 reads x 8 columns, R[i] = the 8 codes (nibbles) of read i -> out[j][k] = plane k of column j, bit i = read i.
+// 32 reads x 8 columns, R[i] = the 8 nibbles of read i -> out[j][k] = plane k of column j, bit i = read i.
 // Four 8 x 8 nibble transposes — block g holds reads g, g + 4, ..., g + 28, so that after it nibble n of M[g][j] is read
-// 4 n + g at column j — then the bits of the four blocks' nibbles change places (below).
-__device__ __forceinline__ void nibble_rows_to_plane_words(const uint32_t (&R)[32], uint32_t (&out)[8][3])
+// 4 n + g at column j — then the bits of the four blocks' nibbles change places: the four bit planes of the nibbles.
+// A read's nibbles are symbol codes already where its bit in `codes` is set (planes 0-2 are the answer); everywhere else they
+// are BAM's 4-bit bases, one plane per letter A C G T, and the symbol code is made HERE, 32 reads an instruction: exactly one
+// letter -> its index, anything else (N, '=', the ambiguity codes) -> 5, a filtered base.
+__device__ __forceinline__ void nibble_rows_to_plane_words(const uint32_t (&R)[32], uint32_t codes, uint32_t (&out)[8][3])
 {
     uint32_t M[4][8];
 #pragma unroll
@@ -395,9 +398,13 @@ __device__ __forceinline__ void nibble_rows_to_plane_words(const uint32_t (&R)[3
         t = ((a2 >> 1) ^ a3) & 0x55555555u; a3 ^= t; a2 ^= t << 1;
         t = ((a0 >> 2) ^ a2) & 0x33333333u; a2 ^= t; a0 ^= t << 2;
         t = ((a1 >> 2) ^ a3) & 0x33333333u; a3 ^= t; a1 ^= t << 2;
-        out[j][0] = a0;
-        out[j][1] = a1;
-        out[j][2] = a2;   // (a3 would be bit 3 of the codes: always zero)
+        // (three-input boolean functions are one v_bitop3 each)
+        const uint32_t one3 = (a0 ^ a1 ^ a2) & ~(a0 & a1 & a2), none3 = ~(a0 | a1 | a2);   // exactly one / none of A C G
+        const uint32_t letter = (one3 & ~a3) | (none3 & a3);                               // exactly one of A C G T
+        const uint32_t c0 = ~letter | a1 | a3, c1 = letter & (a2 | a3);                    // C T N odd; G T have bit 1; N has bit 2
+        out[j][0] = (codes & a0) | (~codes & c0);
+        out[j][1] = (codes & a1) | (~codes & c1);
+        out[j][2] = (codes & a2) | (~codes & ~letter);
     }
 }
 
@@ -472,34 +479,35 @@ static_assert(kTileReads == 128u && kThreads == 256u, "two waves of read threads
 constexpr uint32_t kPieceRoundsA = 2u, kPieceRoundsB = kRowPieces - kPieceRoundsA;
 
 
-// 16 bytes of packed bases (BAM order: first base in the high nibble) -> 32 symbol codes, base b in nibble b & 7 of S[b >> 3];
-// QV: bases whose quality is below min_qv become N.  Q = query offset of the piece's base 0 (negative: the first -Q bases are
-// not the read's own).
-template <bool QV>
-__device__ __forceinline__ void piece_syms(const ingest_args &a, const u32x4 &v, int Q, uint64_t qual_base, uint32_t (&S)[4])
+// Eight of BAM's 4-bit bases, one per nibble -> eight symbol codes: A C G T (1 2 4 8) -> 0..3, everything else (N = 15, '=' = 0, the
+// IUPAC ambiguity codes) -> N, a filtered base.  v_perm_b32 looks four bytes up in an 8-byte table: the low three bits of a
+// base select in the table of the codes 0..7 and in that of 8..15, bit 3 picks between the two results.  (Only the few blocks
+// with a run boundary inside go through this: everything else is converted as bit planes, behind the transposition.)
+__device__ __forceinline__ uint32_t codes_of_bases8(uint32_t x)
 {
-    const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
-    // BAM's 4-bit base -> symbol code by table: A C G T (1 2 4 8) -> 0..3, everything else (N = 15, '=' = 0, the IUPAC
-    // ambiguity codes) -> N, a filtered base.  v_perm_b32 looks four bytes up in an 8-byte table: the low three bits of a
-    // base select in the table of the codes 0..7 and in that of 8..15, bit 3 picks between the two results.  The first base
-    // of a byte is its HIGH nibble and goes to the lower column: the two halves are put together the other way round.
     constexpr uint32_t kLo03 = 0x05010005u, kLo47 = 0x05050502u;   // codes of 0..3 (bytes 0..3), of 4..7
     constexpr uint32_t kHi03 = 0x05050503u, kHi47 = 0x05050505u;   // codes of 8..11, of 12..15
-    auto lookup4 = [&](uint32_t x) -> uint32_t {   // four bases, one per byte (0..15) -> four codes
-        const uint32_t sel = x & 0x07070707u;
+    auto lookup4 = [&](uint32_t y) -> uint32_t {   // four bases, one per byte (0..15) -> four codes
+        const uint32_t sel = y & 0x07070707u;
         const uint32_t lo = __builtin_amdgcn_perm(kLo47, kLo03, sel), hi = __builtin_amdgcn_perm(kHi47, kHi03, sel);
-        // bytes of ones where bit 3 is set: 8 << 5 minus 8 >> 3 within each byte (a 32-bit multiply is a quarter-rate instruction)
-        const uint32_t b3 = x & 0x08080808u, pick = (b3 << 5) - (b3 >> 3);
+        const uint32_t b3 = y & 0x08080808u, pick = (b3 << 5) - (b3 >> 3);   // bytes of ones where bit 3 is set
         return (hi & pick) | (lo & ~pick);
     };
+    return lookup4(x & 0x0F0F0F0Fu) | (lookup4((x >> 4) & 0x0F0F0F0Fu) << 4);
+}
+
+// 16 bytes of packed bases (BAM order: first base in the high nibble) -> the same 32 bases in QUERY order, base b in nibble
+// b & 7 of S[b >> 3] — BAM's codes as they are: they become symbol codes as bit planes, behind the transposition, at an
+// eighth of the price per base.  QV: bases whose quality is below min_qv become 15 (N).  Q = query offset of the piece's base 0
+// (negative: the first -Q bases are not the read's own).
+template <bool QV>
+__device__ __forceinline__ void piece_bases(const ingest_args &a, const u32x4 &v, int Q, uint64_t qual_base, uint32_t (&S)[4])
+{
+    const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const uint32_t first = lookup4((w4[k] >> 4) & 0x0F0F0F0Fu), second = lookup4(w4[k] & 0x0F0F0F0Fu);
-        S[k] = first | (second << 4);
-    }
+    for (int k = 0; k < 4; ++k) S[k] = ((w4[k] >> 4) & 0x0F0F0F0Fu) | ((w4[k] & 0x0F0F0F0Fu) << 4);
     if (QV) {
-        // qualities of the piece's bases, one byte each, from the aligned dwords around them; a base below min_qv
-        // becomes N (0xFF = absent never does)
+        // qualities of the piece's bases, one byte each, from the aligned dwords around them (0xFF = absent never masks)
         const int lo_v = Q < 0 ? -Q : 0;
         const uint64_t addr = qual_base + (uint64_t)(Q + lo_v);    // first quality wanted
         const uint32_t *qp = reinterpret_cast<const uint32_t *>(a.qual + (addr & ~(uint64_t)3));
@@ -525,8 +533,7 @@ __device__ __forceinline__ void piece_syms(const ingest_args &a, const u32x4 &v,
             b = (b | (b << 12)) & 0x000F000Fu;
             b = (b | (b << 6)) & 0x03030303u;
             b = (b | (b << 3)) & 0x11111111u;
-            const uint32_t mk = (b << 4) - b;   // 15 x b
-            S[k] = (S[k] & ~mk) | ((uint32_t)JL_SYM_MASK * 0x11111111u & mk);
+            S[k] |= (b << 4) - b;   // 15 x b
         }
     }
 }
@@ -614,7 +621,7 @@ __global__ __launch_bounds__(kThreads) void ingest_planes_kernel(ingest_args a)
             if (!pc[k].dst) continue;
             uint32_t S[4];
             if (JL_ING_SKIP(a, 6)) { S[0] = pc[k].v.x; S[1] = pc[k].v.y; S[2] = pc[k].v.z; S[3] = pc[k].v.w; }
-            else piece_syms<QV>(a, pc[k].v, pc[k].Q, pc[k].qb, S);
+            else piece_bases<QV>(a, pc[k].v, pc[k].Q, pc[k].qb, S);
             u32x4 o = {S[0], S[1], S[2], S[3]};
             *reinterpret_cast<u32x4 *>(&s_stage[pc[k].dst]) = o;
         }
@@ -782,7 +789,7 @@ __global__ __launch_bounds__(kThreads) void ingest_planes_kernel(ingest_args a)
             uint32_t ee = s_ent[slot - 1u];        // (an entry that begins inside a block is not its read's first)
             if (ent_col(ee) > 8u * bb) continue;
             const uint32_t c0 = 8u * bb, c1 = c0 + 8u;
-            uint32_t R = 0x66666666u;
+            uint32_t bases = 0, m_al = 0, m_del = 0;      // the block's aligned bases (BAM's codes), where they are, where a deletion is
             for (uint32_t kk = slot;; ++kk) {
                 const uint32_t nn = s_ent[kk];
                 const uint32_t W = ent_col(ee), Wn = ent_col(nn);
@@ -790,16 +797,16 @@ __global__ __launch_bounds__(kThreads) void ingest_planes_kernel(ingest_args a)
                 const uint32_t kind = ent_kind(ee);
                 if (ca < cb && kind != 3u) {
                     const uint32_t m = (cb - ca == 8u ? 0xFFFFFFFFu : ((1u << (4u * (cb - ca))) - 1u)) << (4u * (ca - c0));
-                    uint32_t v = 0x44444444u;
                     if (kind == 1u) {
                         const uint32_t A = ent_addr(ee, row8, ca);
-                        v = __builtin_amdgcn_alignbit(s_stage[(A >> 3) + 1u], s_stage[A >> 3], 4u * (A & 7u)) << (4u * (ca - c0));
-                    }
-                    R = (R & ~m) | (v & m);
+                        bases |= (__builtin_amdgcn_alignbit(s_stage[(A >> 3) + 1u], s_stage[A >> 3], 4u * (A & 7u)) << (4u * (ca - c0))) & m;
+                        m_al |= m;
+                    } else m_del |= m;
                 }
                 if (Wn >= c1 || (s_own[kk] & 0x80u)) break;     // (the read's last entry is nothing: 'not covered' stays)
                 ee = nn;
             }
+            const uint32_t R = (codes_of_bases8(bases) & m_al) | (0x44444444u & m_del) | (0x66666666u & ~(m_al | m_del));
             s_stage[4u + slot] = R;
             tab[bb] = (uint16_t)(8u * (4u + slot));
         }
@@ -812,27 +819,37 @@ __global__ __launch_bounds__(kThreads) void ingest_planes_kernel(ingest_args a)
     {
         const uint32_t G = tid % kTileGroups, blk = tid / kTileGroups;
         if (blk < kBlocks && 8u * blk < width && !JL_ING_SKIP(a, 4)) {
-            uint32_t R[32];
+            // (the dwords in front of the reads' rows — 'not covered', '-', the boundary blocks — hold symbol codes already; `codes`
+            // collects, a bit a read, whose dword is one of those: v_alignbit shifts the sign of address - first row in)
+            uint32_t R[32], codes = 0;
             const uint16_t *tab = s_tab + tab_row(32u * G) + blk;
 #pragma unroll
-            for (uint32_t i = 0; i < 32u; ++i) {
-                const uint32_t A = tab[i * kTabRow];
+            for (int i = 31; i >= 0; --i) {
+                const uint32_t A = tab[(uint32_t)i * kTabRow];
                 R[i] = __builtin_amdgcn_alignbit(s_stage[(A >> 3) + 1u], s_stage[A >> 3], 4u * (A & 7u));
+                codes = __builtin_amdgcn_alignbit(codes, A - 8u * kRowBase, 31u);
             }
             uint32_t out[8][3];
-            nibble_rows_to_plane_words(R, out);
+            nibble_rows_to_plane_words(R, codes, out);
             const uint64_t byte = (uint64_t)tile * (kTileReads / 8u) + (uint64_t)G * 4u;
             if (byte < a.plane_stride && (!JL_ING_SKIP(a, 2) || out[0][0] == 0x12345u)) {
-                // (one 64-bit multiply for the first plane row, then a stride at a time)
+                // (one 64-bit multiply for the first plane row, then a stride at a time; a block of eight whole columns — all but
+                // the window's last — stores without a question per column: a predicate per store was a sixth of this phase)
                 uint8_t *row = a.msa + (uint64_t)((X + 8u * blk) * 3u) * a.plane_stride + byte;
+                if (8u * blk + 8u <= width) {
 #pragma unroll
-                for (uint32_t jj = 0; jj < 8u; ++jj) {
-                    const uint32_t c = X + 8u * blk + jj;
+                    for (uint32_t jj = 0; jj < 8u; ++jj)
 #pragma unroll
-                    for (uint32_t k = 0; k < 3u; ++k) {
-                        if (c < Xend) *reinterpret_cast<uint32_t *>(row) = out[jj][k];
-                        row += a.plane_stride;
-                    }
+                        for (uint32_t k = 0; k < 3u; ++k) {
+                            *reinterpret_cast<uint32_t *>(row) = out[jj][k];
+                            row += a.plane_stride;
+                        }
+                } else {
+                    for (uint32_t jj = 0; 8u * blk + jj < width; ++jj)
+                        for (uint32_t k = 0; k < 3u; ++k) {
+                            *reinterpret_cast<uint32_t *>(row) = jj == 0u ? out[0][k] : jj == 1u ? out[1][k] : jj == 2u ? out[2][k] : jj == 3u ? out[3][k] : jj == 4u ? out[4][k] : jj == 5u ? out[5][k] : out[6][k];
+                            row += a.plane_stride;
+                        }
                 }
             }
         }
