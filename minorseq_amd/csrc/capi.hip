@@ -368,7 +368,7 @@ int jl_records_begin(jl_ctx *ctx, uint64_t reads_hint, uint64_t cigar_words_hint
     hipError_t e = records_room(ctx, r.d_pos, r.cap_pos, 0, (size_t)reads_hint, 0);
     if (e == hipSuccess) e = records_room(ctx, r.d_co, r.cap_co, 0, (size_t)reads_hint + 1, 0);
     if (e == hipSuccess) e = records_room(ctx, r.d_so, r.cap_so, 0, (size_t)reads_hint + 1, 0);
-    if (e == hipSuccess) e = records_room(ctx, r.d_cig, r.cap_cig, 0, (size_t)cigar_words_hint, 0);
+    if (e == hipSuccess) e = records_room(ctx, r.d_cig, r.cap_cig, 0, (size_t)cigar_words_hint, 64);
     if (e == hipSuccess) e = records_room(ctx, r.d_seq, r.cap_seq, 0, (size_t)seq_bytes_hint, 64);
     if (e == hipSuccess && qual_bytes_hint) e = records_room(ctx, r.d_qual, r.cap_qual, 0, (size_t)qual_bytes_hint, 64);
     if (e == hipSuccess && qual_bytes_hint) e = records_room(ctx, r.d_qo, r.cap_qo, 0, (size_t)reads_hint + 1, 0);
@@ -412,7 +412,7 @@ int jl_records_append(jl_ctx *ctx, uint64_t n_reads, const int32_t *pos, const u
     hipError_t e = records_room(ctx, R.d_pos, R.cap_pos, nr, nr + n_reads, 0);
     if (e == hipSuccess) e = records_room(ctx, R.d_co, R.cap_co, nr + 1, nr + n_reads + 1, 0);
     if (e == hipSuccess) e = records_room(ctx, R.d_so, R.cap_so, nr + 1, nr + n_reads + 1, 0);
-    if (e == hipSuccess) e = records_room(ctx, R.d_cig, R.cap_cig, (size_t)R.n_cig, (size_t)R.n_cig + n_cig, 0);
+    if (e == hipSuccess) e = records_room(ctx, R.d_cig, R.cap_cig, (size_t)R.n_cig, (size_t)R.n_cig + n_cig, 64);
     // the kernel reads the bases in aligned 32-byte pieces: padding behind them
     if (e == hipSuccess) e = records_room(ctx, R.d_seq, R.cap_seq, (size_t)R.n_seq, (size_t)R.n_seq + n_seq, 64);
     if (e == hipSuccess && qual) e = records_room(ctx, R.d_qual, R.cap_qual, (size_t)R.n_qual, (size_t)R.n_qual + n_q, 64);
@@ -528,7 +528,7 @@ static int records_build(jl_ctx *src, jl_ctx *dst, uint32_t n_cols, uint32_t win
         e = records_room(src, R.d_co, R.cap_co, 0, 1, 0);
         if (e == hipSuccess) e = records_room(src, R.d_so, R.cap_so, 0, 1, 0);
         if (e == hipSuccess) e = records_room(src, R.d_pos, R.cap_pos, 0, 1, 0);
-        if (e == hipSuccess) e = records_room(src, R.d_cig, R.cap_cig, 0, 1, 0);
+        if (e == hipSuccess) e = records_room(src, R.d_cig, R.cap_cig, 0, 1, 64);
         if (e == hipSuccess) e = records_room(src, R.d_seq, R.cap_seq, 0, 1, 64);
         if (e == hipSuccess) e = hipMemsetAsync(R.d_co, 0, 8, st);
         if (e == hipSuccess) e = hipMemsetAsync(R.d_so, 0, 8, st);

@@ -63,40 +63,13 @@ __device__ __forceinline__ uint32_t wave_scan(uint32_t v)
     v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);  // row_bcast:31 -> rows 2, 3
     return v;
 }
-// two independent sums scanned in step (a DPP read of a register needs two wait states behind the write: each chain fills
-// the other's)
-__device__ __forceinline__ void wave_scan2(uint32_t &a, uint32_t &b)
-{
-#define JL_SCAN_STEP(ctrl, rows, bc)                                                            \
-    {                                                                                           \
-        const uint32_t ta = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a, ctrl, rows, 0xF, bc); \
-        const uint32_t tb = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)b, ctrl, rows, 0xF, bc); \
-        a += ta;                                                                                \
-        b += tb;                                                                                \
-    }
-    JL_SCAN_STEP(0x111, 0xF, true)
-    JL_SCAN_STEP(0x112, 0xF, true)
-    JL_SCAN_STEP(0x114, 0xF, true)
-    JL_SCAN_STEP(0x118, 0xF, true)
-    JL_SCAN_STEP(0x142, 0xA, false)
-    JL_SCAN_STEP(0x143, 0xC, false)
-#undef JL_SCAN_STEP
-}
-// the exact sum of a wave's values (the rare step that holds an op of 2^25 bases or more: a 32-bit scan could wrap)
-__device__ __forceinline__ uint64_t wave_sum64(uint32_t v)
-{
-    uint64_t t = 0;
-    for (int l = 0; l < 64; ++l) t += (uint32_t)__builtin_amdgcn_readlane((int)v, l);
-    return t;
-}
-
 // Entries of read r: runs[cig_off[r] + 3 r + i], i = 0 .. n_runs + 2, each {window column | kind << 30, query offset}; entry i
 // says what the read shows in the columns [its column, the next entry's column): kind 1 aligned bases (column c holds the
 // base at query offset + c - column), 2 deletion, 3 nothing ('not covered': before the read, a reference skip, behind it).
 // Entry 0 = {0, nothing}; entries 1 .. n_runs the read's runs, columns clamped to [0, n_cols] (a run that begins before the
 // window begins at column 0 with its query offset moved along); entry n_runs + 1 = the read's end {column, nothing, query
 // length}; entry n_runs + 2 = {kRunMask, nothing}: never reached.  The columns never decrease.
-constexpr uint32_t kRunsReadsPerWave = 4u;
+constexpr uint32_t kRunsReadsPerWave = 4u, kRunsBatches = 1u;   // a wave: batches of four reads, one after the other (more than one batch a wave measured slower: 63 against 51 us with four)
 constexpr uint32_t kRunsLds = 64u;          // entries of a read kept in LDS for the descriptors (the rest is read back from HBM)
 constexpr uint32_t kDescSweeps = 15u;       // sweeps a row of sixteen lanes describes per pass (it needs sixteen bounds)
 constexpr uint32_t kDescMax = 255u;         // "more than the planes kernel takes": pieces or entries of a (read, sweep)
@@ -113,167 +86,192 @@ constexpr uint32_t kDescMax = 255u;         // "more than the planes kernel take
 // The records are untrusted: a cigar with an 'M' (forbidden in PacBio BAM, doc/JULIET.md:53), one that consumes more bases
 // (or qualities) than the record holds, or one that spans 2^30 reference bases or more is reported — *bad = min over such reads
 // of (read << 8 | code), code 1 'M', 2 bases, 3 qualities, 4 span — and the read is treated as covering nothing, so no later
-// kernel follows its offsets anywhere.  Lengths add up in 64 bits (a step that holds an op of 2^25 bases or more is summed
+// kernel follows its offsets anywhere.  Lengths add up in 64 bits (a step that holds an op of 2^24 bases or more is summed
 // exactly, lane by lane), so no crafted cigar wraps a sum back into range.
-__global__ __launch_bounds__(256) void cigar_runs_kernel(uint64_t n_reads, const int32_t *__restrict__ pos, const uint32_t *__restrict__ cigar,
+#ifndef JL_RUNS_WAVES
+#define JL_RUNS_WAVES 1
+#endif
+__global__ __launch_bounds__(256, JL_RUNS_WAVES) void cigar_runs_kernel(uint64_t n_reads, const int32_t *__restrict__ pos, const uint32_t *__restrict__ cigar,
                                                          const uint64_t *__restrict__ cig_off, const uint64_t *__restrict__ seq_off,
                                                          const uint64_t *__restrict__ qual_off, uint32_t win_begin, uint32_t n_cols,
                                                          uint32_t n_sweeps, uint2 *__restrict__ runs, uint32_t *__restrict__ nruns,
                                                          uint4 *__restrict__ desc, unsigned long long *__restrict__ bad)
 {
+    // A ROW OF SIXTEEN LANES PER READ — a wave takes four reads at once — and EIGHT CONSECUTIVE OPS PER LANE (128 ops a step: a CCS
+    // read's cigar in one or two steps): a lane adds its eight ops up itself, the sixteen lanes' sums are scanned within the DPP
+    // row (four row_shr steps, no row broadcast), and a second pass over the lane's ops puts the entries out.  (One read at a
+    // time over the whole wave, two ops a lane, was 450 wave instructions a read; the scans, the ballots and the bookkeeping
+    // per step are now shared by four reads and eight ops a lane.)
     __shared__ uint2 s_run_all[4][kRunsReadsPerWave][kRunsLds];
     const uint32_t wid = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    const uint64_t r0 = ((uint64_t)blockIdx.x * 4u + wid) * kRunsReadsPerWave;
-    if (r0 >= n_reads) return;
+    const uint64_t r_wave = ((uint64_t)blockIdx.x * 4u + wid) * (kRunsReadsPerWave * kRunsBatches);
+    if (r_wave >= n_reads) return;
     uint2 (*s_run)[kRunsLds] = s_run_all[wid];
-    // lanes 0..4: the cigar offsets of the wave's reads (one more than reads), lanes 0..3 their positions
-    const uint64_t rl_ = r0 + lane;
-    const uint64_t co_l = (lane <= kRunsReadsPerWave && rl_ <= n_reads) ? cig_off[rl_] : 0u;
-    const int32_t pos_l = (lane < kRunsReadsPerWave && rl_ < n_reads) ? pos[rl_] : 0;
-    const uint64_t so_l = (lane <= kRunsReadsPerWave && rl_ <= n_reads) ? seq_off[rl_] : 0u;
-    const uint64_t qo_l = (qual_off && lane <= kRunsReadsPerWave && rl_ <= n_reads) ? qual_off[rl_] : 0u;
-    auto lane64 = [](uint64_t v, int l) -> uint64_t {   // (a lane known at compile time: no trip through the LDS crossbar)
-        return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(v >> 32), l) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l);
-    };
-    uint64_t cb[kRunsReadsPerWave + 1u];
-#pragma unroll
-    for (uint32_t q = 0; q <= kRunsReadsPerWave; ++q) cb[q] = lane64(co_l, (int)q);
-    uint32_t cw0[kRunsReadsPerWave][2];
-#pragma unroll
-    for (uint32_t q = 0; q < kRunsReadsPerWave; ++q) {
-        const uint64_t k = cb[q] + 2u * lane;
-        const bool live = r0 + q < n_reads;
-        cw0[q][0] = (live && k < cb[q + 1u]) ? cigar[k] : 0u;
-        cw0[q][1] = (live && k + 1u < cb[q + 1u]) ? cigar[k + 1u] : 0u;
-    }
-    uint32_t n_runs_of[kRunsReadsPerWave] = {0, 0, 0, 0};
-#pragma unroll
-    for (uint32_t q = 0; q < kRunsReadsPerWave; ++q) {
-        const uint64_t r = r0 + q;
-        if (r >= n_reads) break;
-        const uint64_t c_beg = cb[q], c_end = cb[q + 1u];
-        uint2 *out = runs + c_beg + 3u * r;
-        const int64_t base = (int64_t)__builtin_amdgcn_readlane(pos_l, (int)q) - (int64_t)win_begin;
-        // window column of reference offset rb, clamped to the window; `before`: how far in front of it
-        auto window_col = [&](uint32_t rb, uint32_t &before) -> uint32_t {
-            const int64_t w = base + (int64_t)rb;
-            before = w >= 0 ? 0u : (-w > (int64_t)0xFFFFFFFFll ? 0xFFFFFFFFu : (uint32_t)(-w));
-            return w < 0 ? 0u : (w > (int64_t)n_cols ? n_cols : (uint32_t)w);
-        };
-        uint32_t n_runs = 0, prev_kind = 0, ref_carry = 0, q_carry = 0;
-        uint64_t ref_total = 0, q_total = 0;
-        bool has_m = false;
-        // (op indices relative to the read's first, in 32 bits: a record's cigar has fewer than 2^32 ops)
-        const uint32_t n_ops = (uint32_t)min(c_end - c_beg, (uint64_t)0xFFFFFF00u);
-        const uint32_t *cig = cigar + c_beg;
-        for (uint32_t k0 = 0; k0 < n_ops; k0 += 128u) {
-            uint32_t cw[2] = {cw0[q][0], cw0[q][1]};
-            if (k0 != 0u) {
-                const uint32_t k = k0 + 2u * lane;
-                cw[0] = k < n_ops ? cig[k] : 0u;
-                cw[1] = k + 1u < n_ops ? cig[k + 1u] : 0u;
-            }
-            uint32_t kind[2], rl[2], ql[2];
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                // what an op does, from three constants indexed by its code: D N = X consume the reference, I S = X the query;
-                // kind 1 for = X, 2 for D, 3 for N
-                const uint32_t op = cw[t] & 15u, len = cw[t] >> 4;   // (a missing op is the word 0: length 0, which is nothing)
-                constexpr uint32_t kRefOps = (1u << 2) | (1u << 3) | (1u << 7) | (1u << 8);
-                constexpr uint32_t kQueryOps = (1u << 1) | (1u << 4) | (1u << 7) | (1u << 8);
-                constexpr uint32_t kKinds = (2u << 4) | (3u << 6) | (1u << 14) | (1u << 16);   // two bits per op
-                rl[t] = ((kRefOps >> op) & 1u) ? len : 0u;
-                ql[t] = ((kQueryOps >> op) & 1u) ? len : 0u;
-                kind[t] = len == 0u ? 0u : (kKinds >> (2u * op)) & 3u;
-                has_m = has_m || (op == 0u && (k0 + 2u * lane + (uint32_t)t) < n_ops);
-            }
-            const uint32_t rsum = rl[0] + rl[1], qsum = ql[0] + ql[1];
-            uint32_t ri = rsum, qi = qsum;
-            wave_scan2(ri, qi);   // inclusive, per lane pair
-            if (__ballot((cw[0] | cw[1]) >= (1u << 29)) != 0ull) {   // an op of 2^25 bases or more: the step's sums may have wrapped
-                ref_total += wave_sum64(rl[0]) + wave_sum64(rl[1]);
-                q_total += wave_sum64(ql[0]) + wave_sum64(ql[1]);
-            } else {
-                ref_total += (uint32_t)__builtin_amdgcn_readlane((int)ri, 63);
-                q_total += (uint32_t)__builtin_amdgcn_readlane((int)qi, 63);
-            }
-            // the kind of the op before this lane's first one: the previous lane's second op
-            uint32_t before = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)kind[1], 0x138, 0xF, 0xF, false);   // wave_shr:1
-            if (lane == 0) before = prev_kind;
-            const bool st0 = kind[0] != 0u && !(kind[0] == 1u && before == 1u);
-            const bool st1 = kind[1] != 0u && !(kind[1] == 1u && kind[0] == 1u);
-            const uint64_t b0 = __ballot(st0), b1 = __ballot(st1);
-            // run starts in the lanes before this one (v_mbcnt: the set bits of a mask below the lane, with an addend)
-            const uint32_t ahead = __builtin_amdgcn_mbcnt_hi((uint32_t)(b1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b1,
-                                   __builtin_amdgcn_mbcnt_hi((uint32_t)(b0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b0, 0u))));
-            const uint32_t rbeg0 = ref_carry + ri - rsum, qbeg0 = q_carry + qi - qsum;
-            if (st0) {
-                const uint32_t idx = 1u + n_runs + ahead;
-                uint32_t bf;
-                const uint32_t w = window_col(rbeg0, bf);
-                const uint2 e = make_uint2(w | (kind[0] << 30), qbeg0 + bf);
-                out[idx] = e;
-                if (idx < kRunsLds) s_run[q][idx] = e;
-            }
-            if (st1) {
-                const uint32_t idx = 1u + n_runs + ahead + (st0 ? 1u : 0u);
-                uint32_t bf;
-                const uint32_t w = window_col(rbeg0 + rl[0], bf);
-                const uint2 e = make_uint2(w | (kind[1] << 30), qbeg0 + ql[0] + bf);
-                out[idx] = e;
-                if (idx < kRunsLds) s_run[q][idx] = e;
-            }
-            n_runs += (uint32_t)__popcll(b0) + (uint32_t)__popcll(b1);
-            prev_kind = (uint32_t)__builtin_amdgcn_readlane((int)kind[1], 63);   // (only a full step has a successor)
-            ref_carry += (uint32_t)__builtin_amdgcn_readlane((int)ri, 63);
-            q_carry += (uint32_t)__builtin_amdgcn_readlane((int)qi, 63);
-        }
-        uint32_t code = __ballot(has_m) != 0ull ? 1u : 0u;
-        if (!code) {
-            const uint64_t n_bases = 2u * (lane64(so_l, (int)q + 1) - lane64(so_l, (int)q));
-            if (q_total > n_bases || q_total > 0x7FFFFFFFull) code = 2u;
-            else if (qual_off && q_total > lane64(qo_l, (int)q + 1) - lane64(qo_l, (int)q)) code = 3u;
-            else if (ref_total > (uint64_t)kRunMask) code = 4u;
-        }
-        uint32_t end_col = 0;
-        if (code) {
-            n_runs = 0;
-            if (lane == 0) atomicMin(bad, ((unsigned long long)r << 8) | code);
-        } else {
-            uint32_t bf;
-            end_col = window_col((uint32_t)ref_total, bf);
-        }
-        if (lane < 3u) {
-            const uint32_t idx = lane == 0u ? 0u : n_runs + lane;
-            const uint2 e = lane == 0u ? make_uint2(3u << 30, 0u) : lane == 1u ? make_uint2(end_col | (3u << 30), (uint32_t)q_total) : make_uint2(kRunMask | (3u << 30), 0u);
-            out[idx] = e;
-            if (idx < kRunsLds) s_run[q][idx] = e;
-            if (lane == 0u) nruns[r] = n_runs;
-        }
-        n_runs_of[q] = n_runs;
-    }
-    // ---- the descriptors: a row of sixteen lanes per read, a lane per sweep (fifteen sweeps a pass: a sweep needs the bound of
-    // the next one too).  Entries beyond the LDS copy are read back from HBM: past this wave's own stores.
-    uint32_t n_max = 0;
-#pragma unroll
-    for (uint32_t q = 0; q < kRunsReadsPerWave; ++q) n_max = max(n_max, n_runs_of[q]);
-    if (n_max + 3u > kRunsLds) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    __builtin_amdgcn_wave_barrier();
     const uint32_t q = lane >> 4, sl = lane & 15u;
+    typedef uint32_t u32x4a4 __attribute__((ext_vector_type(4), aligned(4)));
+    // A wave takes kRunsBatches batches of four reads one after the other, and what a batch waits for — its reads' offsets, then
+    // the first 128 ops of each — is asked for while the batch before is worked on: with a batch per wave the kernel was three
+    // rounds of waves that each waited two trips to HBM for a microsecond of work.
+    struct head_t { uint64_t cb, c_end, so, so1, qlen; int32_t pos; };
+    auto ask_head = [&](uint64_t rr) -> head_t {     // (the sixteen lanes of a row ask for the same words: one request)
+        head_t h = {0, 0, 0, 0, ~0ull, 0};
+        if (rr < n_reads) {
+            h.cb = cig_off[rr];
+            h.c_end = cig_off[rr + 1];
+            h.so = seq_off[rr];
+            h.so1 = seq_off[rr + 1];
+            if (qual_off) h.qlen = qual_off[rr + 1] - qual_off[rr];
+            h.pos = pos[rr];
+        }
+        return h;
+    };
+    auto ask_words = [&](const head_t &h, uint32_t k, u32x4a4 &wa, u32x4a4 &wb) {
+        const uint32_t n = (uint32_t)min(h.c_end - h.cb, (uint64_t)0xFFFFFF00u);
+        const u32x4a4 z = {0, 0, 0, 0};
+        wa = k < n ? *reinterpret_cast<const u32x4a4 *>(cigar + h.cb + k) : z;           // (words past the read's ops are masked where they are used)
+        wb = k + 4u < n ? *reinterpret_cast<const u32x4a4 *>(cigar + h.cb + k + 4u) : z;
+    };
+    head_t h_next = ask_head(r_wave + q);
+    u32x4a4 wa_next, wb_next;
+    ask_words(h_next, 8u * sl, wa_next, wb_next);
+    for (uint32_t batch = 0; batch < kRunsBatches; ++batch) {
+    const uint64_t r0 = r_wave + (uint64_t)batch * kRunsReadsPerWave;
+    if (r0 >= n_reads) break;
     const uint64_t r = r0 + q;
     const bool live = r < n_reads;
-    uint32_t n_ent_all = 3u;          // entries of this lane's read
-#pragma unroll
-    for (uint32_t t = 0; t < kRunsReadsPerWave; ++t)
-        if (q == t) n_ent_all = n_runs_of[t] + 3u;
-    uint64_t my_cb = cb[0], my_so = lane64(so_l, 0);
-#pragma unroll
-    for (uint32_t t = 1; t < kRunsReadsPerWave; ++t)
-        if (q == t) {
-            my_cb = cb[t];
-            my_so = lane64(so_l, (int)t);
-        }
+    const head_t h = h_next;
+    const u32x4a4 wa_first = wa_next, wb_first = wb_next;
+    if (batch + 1u < kRunsBatches) h_next = ask_head(r + kRunsReadsPerWave);
+    const uint64_t my_cb = h.cb, c_end = h.c_end, my_so = h.so, so1 = h.so1, qlen = h.qlen;
+    const int64_t base = (int64_t)h.pos - (int64_t)win_begin;
     const uint64_t ent0 = my_cb + 3u * r;     // index of the read's entry 0 in runs[]
+    uint2 *out = runs + ent0;
+    const uint32_t *cig = cigar + my_cb;
+    const uint32_t n_ops = (uint32_t)min(c_end - my_cb, (uint64_t)0xFFFFFF00u);   // (a record's cigar has fewer than 2^32 ops)
+    uint32_t max_ops = n_ops;                  // of the wave's four reads
+#pragma unroll
+    for (int t = 0; t < 4; ++t) max_ops = max(max_ops, (uint32_t)__builtin_amdgcn_readlane((int)n_ops, 16 * t));
+    // inclusive scan within the row of sixteen lanes
+    auto row_scan = [](uint32_t v) -> uint32_t {
+        v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);   // row_shr:1
+        v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true);   // row_shr:2
+        v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true);   // row_shr:4
+        v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true);   // row_shr:8
+        return v;
+    };
+    auto row_last = [&](uint32_t v) -> uint32_t {   // lane 15 of the row's value, in all of its lanes
+        return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(4u * (lane | 15u)), (int)v);
+    };
+    // window column of reference offset `ref`, clamped to the window; `before`: how far in front of it
+    auto window_col = [&](uint64_t ref, uint32_t &before) -> uint32_t {
+        const int64_t w = base + (int64_t)ref;      // (below 2^60: 28-bit lengths, fewer than 2^32 ops)
+        before = w >= 0 ? 0u : (-w > (int64_t)0xFFFFFFFFll ? 0xFFFFFFFFu : (uint32_t)(-w));
+        return w < 0 ? 0u : (w > (int64_t)n_cols ? n_cols : (uint32_t)w);
+    };
+    auto put = [&](uint32_t idx, uint2 e) {
+        out[idx] = e;
+        if (idx < kRunsLds) s_run[q][idx] = e;
+    };
+    uint64_t ref_total = 0, q_total = 0;       // (the row's: the same in its sixteen lanes)
+    uint32_t n_runs = 0, prev_kind = 0;
+    bool has_m = false;
+    for (uint32_t k0 = 0; k0 < max_ops; k0 += 128u) {
+        const uint32_t k = k0 + 8u * sl;
+        u32x4a4 wa = wa_first, wb = wb_first;
+        if (k0 != 0u) {
+            const u32x4a4 z = {0, 0, 0, 0};
+            wa = k < n_ops ? *reinterpret_cast<const u32x4a4 *>(cig + k) : z;           // (words past the read's ops are masked below)
+            wb = k + 4u < n_ops ? *reinterpret_cast<const u32x4a4 *>(cig + k + 4u) : z;
+        }
+        const uint32_t w8[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
+        // what an op does, from three constants indexed by its code: D N = X consume the reference, I S = X the query; kind 1
+        // for = X, 2 for D, 3 for N
+        constexpr uint32_t kRefOps = (1u << 2) | (1u << 3) | (1u << 7) | (1u << 8);
+        constexpr uint32_t kQueryOps = (1u << 1) | (1u << 4) | (1u << 7) | (1u << 8);
+        constexpr uint32_t kKinds = (2u << 4) | (3u << 6) | (1u << 14) | (1u << 16);   // two bits per op
+        uint32_t kinds = 0, rsum = 0, qsum = 0, big = 0;      // kinds: two bits an op
+#pragma unroll
+        for (uint32_t t = 0; t < 8u; ++t) {
+            const bool in = k + t < n_ops;
+            const uint32_t op = w8[t] & 15u, len = in ? w8[t] >> 4 : 0u;
+            kinds |= (len == 0u ? 0u : (kKinds >> (2u * op)) & 3u) << (2u * t);
+            has_m = has_m || (op == 0u && in);
+            rsum += ((kRefOps >> op) & 1u) ? len : 0u;
+            qsum += ((kQueryOps >> op) & 1u) ? len : 0u;
+            big |= len;
+        }
+        // the kind of the op before this lane's first one: the lane before's last (the row's first lane: the step before's)
+        uint32_t before = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(kinds >> 14), 0x111, 0xF, 0xF, true);   // row_shr:1
+        if (sl == 0u) before = prev_kind;
+        // bit 2 t: op t begins an entry — it has a kind, and not both it and the op before are aligned bases
+        const uint32_t prevs = (kinds << 2) | before;
+        const uint32_t any = (kinds | (kinds >> 1)) & 0x5555u, both1 = (kinds & ~(kinds >> 1)) & (prevs & ~(prevs >> 1)) & 0x5555u;
+        const uint32_t starts = any & ~both1;
+        const uint32_t n_st = (uint32_t)__popc(starts);
+        const uint32_t ri = row_scan(rsum), qi = row_scan(qsum), ni = row_scan(n_st);
+        // the row's sums so far, in 64 bits; a step that holds an op of 2^24 bases or more is summed exactly, lane by lane (a
+        // 32-bit scan of sixteen lanes of eight such ops could wrap)
+        uint64_t r_step = row_last(ri), q_step = row_last(qi);
+        if (__ballot(big >= (1u << 24)) != 0ull) {
+            r_step = 0;
+            q_step = 0;
+            for (uint32_t l = 0; l < 16u; ++l) {
+                r_step += (uint32_t)__builtin_amdgcn_ds_bpermute((int)(4u * ((lane & 48u) | l)), (int)rsum);
+                q_step += (uint32_t)__builtin_amdgcn_ds_bpermute((int)(4u * ((lane & 48u) | l)), (int)qsum);
+            }
+        }
+        // the entries
+        uint64_t ref_at = ref_total + (ri - rsum), q_at = q_total + (qi - qsum);
+        uint32_t idx = 1u + n_runs + (ni - n_st);
+#pragma unroll
+        for (uint32_t t = 0; t < 8u; ++t) {
+            const uint32_t op = w8[t] & 15u, len = k + t < n_ops ? w8[t] >> 4 : 0u;
+            if ((starts >> (2u * t)) & 1u) {
+                uint32_t bf;
+                const uint32_t w = window_col(ref_at, bf);
+                put(idx, make_uint2(w | (((kinds >> (2u * t)) & 3u) << 30), (uint32_t)q_at + bf));
+                ++idx;
+            }
+            ref_at += ((kRefOps >> op) & 1u) ? len : 0u;
+            q_at += ((kQueryOps >> op) & 1u) ? len : 0u;
+        }
+        n_runs += row_last(ni);
+        prev_kind = row_last(kinds >> 14);   // (only a full step has a successor)
+        ref_total += r_step;
+        q_total += q_step;
+    }
+    if (batch + 1u < kRunsBatches) ask_words(h_next, 8u * sl, wa_next, wb_next);     // (its offsets have had the walk to arrive)
+    // M anywhere in the row?  (a ballot's sixteen bits)
+    const uint64_t bm = __ballot(has_m);
+    uint32_t code = ((bm >> (16u * q)) & 0xFFFFull) != 0ull ? 1u : 0u;
+    if (!code) {
+        if (q_total > 2u * (so1 - my_so) || q_total > 0x7FFFFFFFull) code = 2u;
+        else if (q_total > qlen) code = 3u;
+        else if (ref_total > (uint64_t)kRunMask) code = 4u;
+    }
+    if (!live) code = 0;
+    uint32_t end_col = 0;
+    if (code) {
+        n_runs = 0;
+        if (sl == 0u) atomicMin(bad, ((unsigned long long)r << 8) | code);
+    } else {
+        uint32_t bf;
+        end_col = window_col(ref_total, bf);
+    }
+    if (live && sl < 3u) {
+        const uint32_t idx = sl == 0u ? 0u : n_runs + sl;
+        const uint2 e = sl == 0u ? make_uint2(3u << 30, 0u) : sl == 1u ? make_uint2(end_col | (3u << 30), (uint32_t)q_total) : make_uint2(kRunMask | (3u << 30), 0u);
+        put(idx, e);
+        if (sl == 0u) nruns[r] = n_runs;
+    }
+    // ---- the descriptors: a lane per sweep (fifteen sweeps a pass: a sweep needs the bound of the next one too).  Entries
+    // beyond the LDS copy are read back from HBM: past this wave's own stores.
+    uint32_t n_max = n_runs;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) n_max = max(n_max, (uint32_t)__builtin_amdgcn_readlane((int)n_runs, 16 * t));
+    if (n_max + 3u > kRunsLds) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t n_ent_all = n_runs + 3u;          // entries of this lane's read
     uint32_t top = 1u;                         // the highest power of two not above the longest list
     while (2u * top <= n_max + 3u) top *= 2u;
     // (`entry`: the read's i-th entry — out of the wave's LDS copy, or, for the lists that are longer than it, read back)
@@ -346,6 +344,8 @@ __global__ __launch_bounds__(256) void cigar_runs_kernel(uint64_t n_reads, const
             const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(runs + ent0 + i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             return make_uint2((uint32_t)v, (uint32_t)(v >> 32));
         });
+    __builtin_amdgcn_wave_barrier();      // (the next batch writes the LDS copy this one's descriptors were made from)
+    }
 }
 
 // ---------------------------------------------------------------------------------------- the planes of one sweep
@@ -929,7 +929,7 @@ void jl_launch_ingest(jl_ctx *ctx, const int32_t *d_pos, const uint32_t *d_cigar
     hipMemsetAsync(d_slow_count, 0, 4, st);
     if (!keep_verdict) hipMemsetAsync(d_slow_count + 2, 0xFF, 8, st);
     if (ctx->n_reads)
-        hipLaunchKernelGGL(cigar_runs_kernel, dim3((uint32_t)((ctx->n_reads + 4u * kRunsReadsPerWave - 1u) / (4u * kRunsReadsPerWave))), dim3(256), 0, st, ctx->n_reads, d_pos,
+        hipLaunchKernelGGL(cigar_runs_kernel, dim3((uint32_t)((ctx->n_reads + 4u * kRunsReadsPerWave * kRunsBatches - 1u) / (4u * kRunsReadsPerWave * kRunsBatches))), dim3(256), 0, st, ctx->n_reads, d_pos,
                            d_cigar, d_cig_off, d_seq_off, d_qual ? d_qual_off : nullptr, ctx->win_begin, ctx->n_cols, ns, d_runs, d_nruns, d_desc,
                            reinterpret_cast<unsigned long long *>(d_slow_count + 2));
     ingest_args a;
