@@ -348,6 +348,13 @@ int jl_comm_host_gather(jl_comm *c)
             for (size_t i = 0; i < kPart; ++i)
                 if (t[kPart * (size_t)r + i] != (uint8_t)(0xA5u ^ (uint8_t)(31 * r + (int)i))) ok = false;
     }
+    else {
+        // every rank issues the same collectives in the same order whatever happened to it: a rank that cannot try host memory
+        // (no pinned block, or the staged form forced on it alone) runs the trial in device memory — the arena is idle here —
+        // and says "not here" below; skipping the trial would pair its peers' 64-byte all-gather with the 8-byte one that follows
+        (void)jl_tp_allgather(c, c->d_arena + kPart * (size_t)c->rank, c->d_arena, kPart, c->stream);
+        (void)hipStreamSynchronize(c->stream);
+    }
     (void)hipGetLastError();
     // the verdicts of all ranks, in device memory (zeros: fine, ones: not here)
     std::vector<uint32_t> v(2 * (size_t)c->world, 1u);

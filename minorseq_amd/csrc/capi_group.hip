@@ -414,6 +414,11 @@ int jl_group_exchange_collect(jl_group *g, jl_variant *all_rows, uint32_t *all_c
     }
     g->x_pending[par] = false;
     ++g->x_collected;
+    // a window whose matrix an enqueued record ingest made: what that ingest found wrong with the records is reported before
+    // tables computed from it are handed out (the run is over: the verdict word is final)
+    for (jl_ctx *ctx : g->ctxs)
+        if (ctx->ing_check_pending)
+            if (int vrc = jl_ingest_verdict(ctx)) return group_fail(g, vrc, ctx->err.c_str());
     const uint32_t n = (uint32_t)g->ctxs.size();
     const uint8_t *base = g->x_host + g->x_region() * par;
     auto head = [&](int r, uint32_t k) { return reinterpret_cast<const jl_pack *>(base + g->x_part() * (size_t)r + (size_t)JL_PACK_HEAD_BYTES * k); };

@@ -616,9 +616,13 @@ static int xs_agree(jl_xwin *x, int local_rc)
     if (!x->d_tsend || !x->d_trecv || x->tblk < 16u) return local_rc ? local_rc : xs_fail(x, JL_ERR_STATE, "no table blocks for the status exchange");
     uint32_t *h = reinterpret_cast<uint32_t *>(x->h_tsend);
     h[0] = JL_XW_AGREE_MAGIC; h[1] = (uint32_t)(-local_rc); h[2] = x->gcap; h[3] = x->pstride;
-    if (hipMemcpyAsync(x->d_tsend, x->h_tsend, 16, hipMemcpyHostToDevice, pc->stream) != hipSuccess) return xs_fail(x, JL_ERR_DEVICE, "status upload");
+    // (a rank whose upload fails still takes part in the all-gather — with whatever its block holds: no magic word, which ends the
+    // step on every rank — instead of leaving its peers inside a collective it never joins)
+    const bool uploaded = hipMemcpyAsync(x->d_tsend, x->h_tsend, 16, hipMemcpyHostToDevice, pc->stream) == hipSuccess;
+    if (!uploaded) (void)hipMemsetAsync(x->d_tsend, 0, 16, pc->stream);
     if (jl_tp_allgather(x->comm, x->d_tsend, x->d_trecv, 16, pc->stream) != JL_OK)
         return xs_fail(x, JL_ERR_COMM, "status exchange before the column slices: " + x->comm->tp_error);
+    if (!uploaded) return xs_fail(x, JL_ERR_DEVICE, "status upload");
     if (int rc = xs_fetch_and_wait(x, x->d_trecv, x->h_trecv, 16u * (size_t)x->world)) return rc;
     for (int r = 0; r < x->world; ++r) {
         const uint32_t *q = reinterpret_cast<const uint32_t *>(x->h_trecv + 16u * (size_t)r);
