@@ -747,6 +747,8 @@ def config3_strong(capi, sharding, synth, torch, dist, distributed, comm, rank, 
         wins.append(w)
         xws.append(capi.Xwin([w], [x for x, _ in wb], [y - x for x, y in wb], list(range(world)), sb, comm if world > 1 else None))
     win, xw = wins[0], xws[0]
+    for w in wins:
+        w.run_pileup_clock(True)     # two clock nodes around the pileup of every run: the pileup as it runs IN the loop
 
     def enqueue(k):
         wins[k].run_async(genes, ref, prm, None, False, 10, False)
@@ -764,7 +766,7 @@ def config3_strong(capi, sharding, synth, torch, dist, distributed, comm, rank, 
     assert firsts[0] == firsts[2] and firsts[1] == firsts[3]
     fence()
     t0 = time.perf_counter()
-    per_step = []
+    per_step, in_loop = [], []
     enqueue(0)
     for i in range(reps):
         t_s = time.perf_counter()
@@ -775,6 +777,7 @@ def config3_strong(capi, sharding, synth, torch, dist, distributed, comm, rank, 
         if (r.n_variants, r.n_haplotypes, r.summary.reported_reads, r.summary.damaged_reads) != firsts[k]:
             raise SystemExit(f"bench.py: configs[{which}]: a step's result changed between runs")
         per_step.append(time.perf_counter() - t_s)
+        in_loop.append(wins[k].run_pileup_ms())      # (this sample's run is over: its table was waited for)
     fence()
     t = (time.perf_counter() - t0) / reps
     t_median = sorted(per_step)[len(per_step) // 2]
@@ -783,7 +786,7 @@ def config3_strong(capi, sharding, synth, torch, dist, distributed, comm, rank, 
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         t = float(tt.item())
     # one sample alone, the device idle before and after (what a step cost before the samples took turns)
-    solo = []
+    solo, solo_pileup = [], []
     for _ in range(5):
         fence()
         t_s = time.perf_counter()
@@ -791,7 +794,11 @@ def config3_strong(capi, sharding, synth, torch, dist, distributed, comm, rank, 
         xws[0].phase_raw(10)
         torch.cuda.synchronize()
         solo.append(time.perf_counter() - t_s)
+        solo_pileup.append(wins[0].run_pileup_ms())
     t_solo = sorted(solo)[len(solo) // 2]
+    k_solo = sorted(solo_pileup)[len(solo_pileup) // 2]
+    k_loop = sum(in_loop) / len(in_loop)
+    k_loop_median = sorted(in_loop)[len(in_loop) // 2]
     res = xw.phase(10, want_reads=True)
     s = res["summary"]
     assert s["reported_reads"] + s["insufficient_reads"] + s["damaged_reads"] == n      # doc/JULIET.md:378-379
@@ -813,9 +820,12 @@ def config3_strong(capi, sharding, synth, torch, dist, distributed, comm, rank, 
            # (3 bits per cell, as roofline.frac)
            "pileup_kernel_ms": t_k, "pileup_frac_of_hbm_peak": (n * (e - b) * 0.375) / (t_k * 1e-3) / 1e9 / HBM_PEAK_GBS,
            # what does NOT shrink like the pileup when the columns are split over more GPUs (the Amdahl term of 1 -> 8 scaling):
-           # exposed = what a step takes beyond its pileup with the samples taking turns; alone = the same for one sample by itself
-           "serial_residue_ms": 1000.0 * t - t_k, "serial_residue_ms_median": 1000.0 * t_median - t_k,
-           "serial_residue_ms_one_sample_alone": 1000.0 * t_solo - t_k}
+           # exposed = what a step takes beyond its pileup AS IT RAN IN THE LOOP (device clock nodes around the pileup launch of every
+           # run, jl_run_pileup_ms: beside the other sample's latency-bound stages it is slower than alone, which is why subtracting
+           # the isolated kernel gave a negative residue in round 4); nothing is clamped.  alone = the same for one sample by itself.
+           "pileup_in_loop_ms": k_loop, "pileup_in_loop_ms_median": k_loop_median,
+           "exposed_ms": 1000.0 * t - k_loop, "exposed_ms_median": 1000.0 * t_median - k_loop_median,
+           "pileup_in_run_ms_one_sample_alone": k_solo, "exposed_ms_one_sample_alone": 1000.0 * t_solo - k_solo}
     for x in xws:
         x.close()
     for w in wins:

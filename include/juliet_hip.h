@@ -366,6 +366,13 @@ int jl_time_pileup(jl_ctx *ctx, uint32_t reps, float *ms_avg);
 /* The same over several contexts' resident windows in rotation, all on the first context's stream: no launch finds
  * its input in the Infinity Cache (4 x 150 MB > 256 MiB), as in a pipelined loop over several batches. */
 int jl_time_pileup_set(jl_ctx *const *ctxs, uint32_t n_ctx, uint32_t reps, float *ms_avg);
+/* The pileup of a RUN, timed where it runs: `on` puts two one-thread nodes around the pileup launch of this context's runs
+ * (jl_run_async), each storing the device's constant-rate clock into pinned host memory; jl_run_pileup_ms (after jl_run_wait or
+ * a fetch of the run) gives the distance between the two of the LAST run in ms — the pileup as it ran beside whatever else the
+ * device was doing (another sample's latency-bound stages, another window's pileup), not alone (jl_time_pileup).  Off by
+ * default: two more nodes are 2-3 us of a run. */
+int jl_run_pileup_clock(jl_ctx *ctx, int on);
+int jl_run_pileup_ms(jl_ctx *ctx, float *ms);
 /* Name of the dominant kernel as rocprofv3 reports it. */
 const char *jl_pileup_kernel_name(void);
 

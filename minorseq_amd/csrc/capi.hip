@@ -1437,7 +1437,9 @@ static void enqueue_path(jl_ctx *ctx, const jl_params *prm, double n_tests, bool
     if (jl_pileup_needs_zero(ctx)) hipMemsetAsync(ctx->d_counts, 0, ctx->counts_words * sizeof(uint32_t), st);
     if (!ctx->have_ref) jl_launch_guess(ctx, st);
     jl_launch_stamp(ctx, 0);
+    if (ctx->pileup_clock) jl_launch_clock(ctx, st, 0);
     jl_launch_pileup(ctx, st);
+    if (ctx->pileup_clock) jl_launch_clock(ctx, st, 1);
     jl_launch_call(ctx, st, prm, n_tests, use_drm, phasing);
     jl_launch_stamp(ctx, 1);
     // The completion word (jl_run_wait) is stored by a one-thread node of its own behind the last stage: the end of
@@ -1768,6 +1770,27 @@ int jl_fisher_eval_tail(jl_ctx *ctx, const uint32_t *a, const uint32_t *c, const
 }
 
 /* ---------------------------------------------------------------- timing */
+
+int jl_run_pileup_clock(jl_ctx *ctx, int on)
+{
+    if (!ctx) return JL_ERR_ARG;
+    if (ctx->pileup_clock != (on != 0)) {
+        ctx->pileup_clock = on != 0;
+        ctx->alloc_version++;      // (the captured graphs of this context do not have / have the two nodes)
+    }
+    return JL_OK;
+}
+
+int jl_run_pileup_ms(jl_ctx *ctx, float *ms)
+{
+    if (!ctx || !ms) return JL_ERR_ARG;
+    if (!ctx->pileup_clock) return jl_fail(ctx, JL_ERR_STATE, "jl_run_pileup_ms: the clock is off (jl_run_pileup_clock)");
+    if (!ctx->pack_valid) return jl_fail(ctx, JL_ERR_STATE, "jl_run_pileup_ms needs a run");
+    if (int rc = jl_run_wait_impl(ctx)) return rc;
+    const volatile unsigned long long *t = reinterpret_cast<const volatile unsigned long long *>(const_cast<uint32_t *>(ctx->h_seq) + 8);
+    *ms = (float)((double)(t[1] - t[0]) * 1e-5);      // 100 MHz ticks
+    return JL_OK;
+}
 
 int jl_time_pileup(jl_ctx *ctx, uint32_t reps, float *ms_avg)
 {

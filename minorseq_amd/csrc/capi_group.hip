@@ -342,9 +342,10 @@ int jl_group_run_masked_async(jl_group *g, const jl_gene *genes, uint32_t n_gene
         jl_comm_direct_wait_begin(c);
         if (jl_tp_allgather(c, work + g->x_part() * (size_t)c->rank, work, g->x_part(), g->stream) != JL_OK && xrc == JL_OK) xrc = JL_ERR_COMM;
         jl_comm_direct_end(c);
-        if (g->x_staged && hipMemcpyAsync(g->x_host + g->x_region() * par, work, g->x_region(), hipMemcpyDeviceToHost, g->stream) != hipSuccess &&
-            xrc == JL_OK)
-            xrc = JL_ERR_DEVICE;
+        if (g->x_staged) {      // (the end of that kernel is what pushes its stores to the host out; the event behind it says so)
+            jl_launch_heads_to_host(work, g->x_host + g->x_region() * par, (uint32_t)(g->x_region() / JL_PACK_HEAD_BYTES), g->stream);
+            if (hipGetLastError() != hipSuccess && xrc == JL_OK) xrc = JL_ERR_DEVICE;
+        }
         if (hipEventRecord(g->x_done[par], g->stream) != hipSuccess && xrc == JL_OK) xrc = JL_ERR_DEVICE;
         g->x_pending[par] = true;
         ++g->x_launched;

@@ -252,6 +252,7 @@ struct jl_pileup_group_args { jl_win_pileup w[JL_GROUP_WINDOWS_MAX]; };
 #define JL_GATHER_MAX 32
 struct jl_gather_args { const uint8_t *src[JL_GATHER_MAX]; };
 void jl_launch_gather_heads(const uint8_t *const *srcs, uint32_t n, uint8_t *dst, hipStream_t st);
+void jl_launch_heads_to_host(const uint8_t *d_region, uint8_t *h_region, uint32_t n_heads, hipStream_t st);
 
 struct jl_comm;
 
@@ -440,6 +441,7 @@ struct jl_ctx {
     uint32_t exch_pending = 0;        // exchanges requested and not yet collected: each still reads one of the two result blocks
     std::vector<uint32_t> exch_runs;  // ... and the runs (values of runs_launched) whose blocks they read
     hipStream_t run_stream = nullptr;  // where the last run was enqueued (the ctx stream, or a group's)
+    bool pileup_clock = false;        // jl_run_pileup_clock: clock nodes around the pileup of a run -> h_seq[8..11] (two 64-bit stamps)
     uint64_t *d_timeline = nullptr;   // JL_TIMELINE=1 only: [JL_TIMELINE_ROWS][JL_TIMELINE_SLOTS] device clock stamps
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
@@ -503,6 +505,7 @@ extern "C" void jl_run_finish(jl_ctx *ctx, int phasing, int want_read_hap);
 extern "C" int jl_run_wait_impl(jl_ctx *ctx);
 extern "C" int jl_run_wait_seq(jl_ctx *ctx, uint32_t want);
 void jl_launch_consensus(jl_ctx *ctx, uint8_t *d_out);
+void jl_launch_clock(jl_ctx *ctx, hipStream_t st, uint32_t which);   // h_seq[8 + 2 which ..] = the device's 100 MHz clock
 void jl_launch_ingest(jl_ctx *ctx, const int32_t *d_pos, const uint32_t *d_cigar, const uint64_t *d_cig_off,
                       const uint8_t *d_seq4, const uint64_t *d_seq_off, const uint8_t *d_qual,
                       const uint64_t *d_qual_off, uint32_t min_qv, uint2 *d_runs, uint32_t *d_nruns, uint4 *d_desc,

@@ -250,6 +250,19 @@ void jl_launch_gather_heads(const uint8_t *const *srcs, uint32_t n, uint8_t *dst
     hipLaunchKernelGGL(gather_heads_kernel, dim3(n), dim3(256), 0, st, a, dst);
 }
 
+// the staged form of a group's exchange: the gathered heads, device region -> pinned host region, a workgroup a head (a kernel
+// on the group's stream costs the launching thread and the device a third of what a device-to-host hipMemcpyAsync of the
+// same 50 KB does)
+__global__ __launch_bounds__(256) void heads_to_host_kernel(const uint32_t *__restrict__ src, uint32_t *__restrict__ dst)
+{
+    const size_t at = (size_t)blockIdx.x * (JL_PACK_HEAD_BYTES / 4);
+    for (uint32_t i = threadIdx.x; i < JL_PACK_HEAD_BYTES / 4; i += 256) dst[at + i] = src[at + i];
+}
+void jl_launch_heads_to_host(const uint8_t *d_region, uint8_t *h_region, uint32_t n_heads, hipStream_t st)
+{
+    hipLaunchKernelGGL(heads_to_host_kernel, dim3(n_heads), dim3(256), 0, st, reinterpret_cast<const uint32_t *>(d_region), reinterpret_cast<uint32_t *>(h_region));
+}
+
 void jl_launch_done(jl_ctx *ctx)
 {
     hipLaunchKernelGGL(done_kernel, dim3(1), dim3(1), 0, ctx->stream, ctx->d_sync, ctx->h_seq);
@@ -257,6 +270,13 @@ void jl_launch_done(jl_ctx *ctx)
 void jl_launch_done_on(jl_ctx *ctx, hipStream_t st)
 {
     hipLaunchKernelGGL(done_kernel, dim3(1), dim3(1), 0, st, ctx->d_sync, ctx->h_seq);
+}
+
+// jl_run_pileup_clock: a one-thread node that stores the device's constant-rate (100 MHz) clock into pinned host memory
+__global__ void clock_kernel(volatile unsigned long long *dst) { *dst = wall_clock64(); }
+void jl_launch_clock(jl_ctx *ctx, hipStream_t st, uint32_t which)
+{
+    hipLaunchKernelGGL(clock_kernel, dim3(1), dim3(1), 0, st, reinterpret_cast<volatile unsigned long long *>(const_cast<uint32_t *>(ctx->h_seq) + 8u + 2u * which));
 }
 
 #ifdef JL_TUNING

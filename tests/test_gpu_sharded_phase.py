@@ -486,6 +486,77 @@ def test_session_with_several_ranks_in_one_process(oracle, n, world, k_windows):
     assert (ids == exp["read_hap"]).all()               # every read's id, each from the rank that owns its slice
 
 
+@pytest.mark.parametrize("n,world", [(6000, 2), (5000, 3), (900, 4)])
+def test_two_samples_take_turns_with_several_ranks_in_one_process(oracle, n, world):
+    """The strong-scaling loop of bench.py (config3_strong) as it runs at N > 1, with the ranks as threads over the in-process
+    transport: TWO samples (different reads of one reference), a window context and a cross-window session each on every
+    rank, both sessions on the rank's ONE communicator; sample k + 1's call stage is enqueued before sample k's session is
+    run, so its exchanges queue up behind a pileup that is already on the device.  Every step of every rank = the
+    unsharded oracle of that step's sample (variants, haplotypes, hit, co-occurrence, every read's id)."""
+    import ctypes as C
+    l, reps = 600, 6
+    genes = np.array([(1, l + 1)], dtype=capi.GENE)
+    samples, expect = [], []
+    for k in range(2):
+        sp = synth.SynthParams(seed=900 + 31 * k + n + world, minor_permille=(70, 60, 50, 40), partial_rate=0.1)
+        ref = synth.reference(900 + n + world, l)     # one reference, two samples
+        rows = synth.rows(sp, l, 0, n, ref)
+        rows[: n // 18, 40 + 300 * k:43 + 300 * k] = (rows[: n // 18, 40 + 300 * k:43 + 300 * k] + 1 + k) % 4     # haplotypes that span windows, other ones per sample
+        rows[n // 30: n // 11, 520:523] = (rows[n // 30: n // 11, 520:523] + 2) % 4
+        full = oracle.call(rows, genes, refseq=ref)
+        samples.append(rows)
+        expect.append((full, oracle.phase(rows, full)))
+    assert not (expect[0][1]["read_hap"] == expect[1][1]["read_hap"]).all()      # (two samples, two answers)
+    wb = sharding.window_bounds(l, world)
+    slice_begin = sharding.read_slices(n, world)
+    idbuf = np.frombuffer(np.random.default_rng(n + world).bytes(128), dtype=np.uint8).copy()
+    prm = capi.default_params(n_tests=sharding.default_n_tests(genes))
+
+    def body(rank):
+        b, e = wb[rank]
+        wins, xws = [], []
+        comm = C.c_void_p()
+        for k in range(2):
+            c = capi.Juliet(0)
+            c.upload_columns(msa.pack_columns(samples[k][:, b:e]), n, win_begin=b)
+            wins.append(c)
+        wins[0]._chk(wins[0].lib.jl_comm_create_inproc(wins[0].h, idbuf.ctypes.data_as(C.c_void_p), rank, world, C.byref(comm)))
+        for k in range(2):
+            xws.append(capi.Xwin([wins[k]], [x for x, _ in wb], [y - x for x, y in wb], list(range(world)), slice_begin, comm))
+        out = []
+        try:
+            wins[0].run_async(genes, ref, prm, None, False, 10, False)
+            for i in range(reps):
+                k = i & 1
+                if i + 1 < reps:
+                    wins[k ^ 1].run_async(genes, ref, prm, None, False, 10, False)     # the next sample's pileup queues up behind this one's
+                out.append(xws[k].phase(10))
+        finally:
+            for x in xws:
+                x.close()
+            wins[0].lib.jl_comm_destroy(comm)
+            for c in wins:
+                c.close()
+        return out
+
+    outs = _ranks_in_threads(world, body)
+    for i in range(reps):
+        full, exp = expect[i & 1]
+        ids = np.full(n, 0xABCD, dtype=np.uint16)
+        for rank in range(world):
+            r = outs[rank][i]
+            m = r["merged"]
+            assert len(m) == len(full), (i, rank)
+            for f in ("gene", "codon_pos", "col", "ref_codon", "codon", "count", "coverage", "expected"):
+                assert (m[f] == full[f]).all(), (i, rank, f)
+            assert r["summary"] == exp["summary"], (i, rank)
+            assert (r["hap_count"] == exp["hap_count"]).all() and (r["hap_pattern"] == exp["hap_pattern"]).all()
+            assert (r["hit"] == exp["hit"]).all() and (r["cooc"] == exp["cooc"]).all()
+            b0, cnt = r["slice"]
+            ids[b0:b0 + cnt] = r["read_hap"][:cnt]
+        assert (ids == exp["read_hap"]).all(), i
+
+
 def test_weak_scaling_exchange_with_two_ranks_in_one_process(oracle):
     """jl_allgather_variants (the call path's one collective) between two rank threads on one device: each rank's table
     arrives at both, through the asynchronous batch form and the blocking full-stride form."""
