@@ -401,6 +401,9 @@ def main():
         while done < k:
             if len(inflight) == n_flight:
                 last = collect(inflight.pop(0)[1])
+            # (a step count that is no multiple of G: the short launch goes last.  First — so that its latency-bound stages
+            # run beside the full launches' pileups — measured 36.8 against 25.3 us per step over 20 steps: tools_tuning/
+            # short_region_order.sh, round 5)
             count = min(G, k - done)
             inflight.append((u, launch(u, count)))
             if trace is not None:
