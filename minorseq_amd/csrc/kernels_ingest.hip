@@ -608,6 +608,10 @@ __global__ __launch_bounds__(kThreads) void ingest_planes_kernel(ingest_args a)
             uint64_t at = ((((uint64_t)d[k].w & 0xFFu) << 32) | d[k].x) + (i < np ? i : 0u);
             JL_ING_CHECK(a, 16u * at + 16u <= a.seq_bytes + 64u, 1, at, at = 0)
             // (plain loads: neighbouring lanes' pieces share lines, and so do the sweeps of a read)
+#ifdef JL_TUNING
+            if (JL_ING_SKIP(a, 9)) pc[k].v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(a.seq4 + 16u * at));   // (probe)
+            else
+#endif
             pc[k].v = *reinterpret_cast<const u32x4 *>(a.seq4 + 16u * at);
             pc[k].dst = i < np ? row_dw(j) + 4u * i : 0u;
             pc[k].Q = (int32_t)d[k].z + 32 * (int32_t)i;
@@ -832,6 +836,17 @@ __global__ __launch_bounds__(kThreads) void ingest_planes_kernel(ingest_args a)
             uint32_t out[8][3];
             nibble_rows_to_plane_words(R, codes, out);
             const uint64_t byte = (uint64_t)tile * (kTileReads / 8u) + (uint64_t)G * 4u;
+#ifdef JL_TUNING
+            if (JL_ING_SKIP(a, 7) || JL_ING_SKIP(a, 8)) {   // (probes, wrong data by design: 7 the same bytes in 16-byte stores, a quarter of the requests; 8 non-temporal stores)
+                uint8_t *row = a.msa + (uint64_t)((X + 8u * blk) * 3u) * a.plane_stride + (uint64_t)tile * (kTileReads / 8u) + (JL_ING_SKIP(a, 8) ? (uint64_t)G * 4u : 0u);
+                for (uint32_t jj = 0; jj < 8u; ++jj)
+                    for (uint32_t k = 0; k < 3u; ++k) {
+                        if (JL_ING_SKIP(a, 8)) __builtin_nontemporal_store(out[jj][k], reinterpret_cast<uint32_t *>(row));
+                        else if (G == 0) { u32x4 o = {out[jj][k], out[jj][0], out[jj][1], out[jj][2]}; *reinterpret_cast<u32x4 *>(row) = o; }
+                        row += a.plane_stride;
+                    }
+            } else
+#endif
             if (byte < a.plane_stride && (!JL_ING_SKIP(a, 2) || out[0][0] == 0x12345u)) {
                 // (one 64-bit multiply for the first plane row, then a stride at a time; a block of eight whole columns — all but
                 // the window's last — stores without a question per column: a predicate per store was a sixth of this phase)
