@@ -780,7 +780,7 @@ def config3_strong(capi, sharding, synth, torch, dist, distributed, comm, rank, 
         if (r.n_variants, r.n_haplotypes, r.summary.reported_reads, r.summary.damaged_reads) != firsts[k]:
             raise SystemExit(f"bench.py: configs[{which}]: a step's result changed between runs")
         per_step.append(time.perf_counter() - t_s)
-        in_loop.append(wins[k].run_pileup_ms())      # (this sample's run is over: its table was waited for)
+        in_loop.append(wins[k].run_pileup_interval())      # (this sample's run is over: its table was waited for)
     fence()
     t = (time.perf_counter() - t0) / reps
     t_median = sorted(per_step)[len(per_step) // 2]
@@ -800,8 +800,23 @@ def config3_strong(capi, sharding, synth, torch, dist, distributed, comm, rank, 
         solo_pileup.append(wins[0].run_pileup_ms())
     t_solo = sorted(solo)[len(solo) // 2]
     k_solo = sorted(solo_pileup)[len(solo_pileup) // 2]
-    k_loop = sum(in_loop) / len(in_loop)
-    k_loop_median = sorted(in_loop)[len(in_loop) // 2]
+    # the pileups of the loop on the device's time line: how long each took where it ran (two samples' pileups overlap, each
+    # slower for it), and how long the device was WITHOUT any pileup between the first one's begin and the last one's end
+    durs = [e_ - b_ for b_, e_ in in_loop]
+    k_loop = sum(durs) / len(durs)
+    k_loop_median = sorted(durs)[len(durs) // 2]
+    iv = sorted(in_loop)
+    covered, cur_b, cur_e = 0.0, iv[0][0], iv[0][1]
+    for b_, e_ in iv[1:]:
+        if b_ > cur_e:
+            covered += cur_e - cur_b
+            cur_b, cur_e = b_, e_
+        else:
+            cur_e = max(cur_e, e_)
+    covered += cur_e - cur_b
+    span = iv[-1][1] - iv[0][0]
+    idle_per_step = (span - covered) / len(iv)          # device time without a pileup, per step
+    busy_per_step = covered / len(iv)                   # device time with at least one pileup running, per step
     res = xw.phase(10, want_reads=True)
     s = res["summary"]
     assert s["reported_reads"] + s["insufficient_reads"] + s["damaged_reads"] == n      # doc/JULIET.md:378-379
@@ -823,11 +838,15 @@ def config3_strong(capi, sharding, synth, torch, dist, distributed, comm, rank, 
            # (3 bits per cell, as roofline.frac)
            "pileup_kernel_ms": t_k, "pileup_frac_of_hbm_peak": (n * (e - b) * 0.375) / (t_k * 1e-3) / 1e9 / HBM_PEAK_GBS,
            # what does NOT shrink like the pileup when the columns are split over more GPUs (the Amdahl term of 1 -> 8 scaling):
-           # exposed = what a step takes beyond its pileup AS IT RAN IN THE LOOP (device clock nodes around the pileup launch of every
-           # run, jl_run_pileup_ms: beside the other sample's latency-bound stages it is slower than alone, which is why subtracting
-           # the isolated kernel gave a negative residue in round 4); nothing is clamped.  alone = the same for one sample by itself.
+           # device clock nodes around the pileup launch of every run (jl_run_pileup_ms) put the loop's pileups on one time line.
+           # pileup_in_loop_ms: how long one took where it ran — the two samples' pileups OVERLAP (separate streams), each slower
+           # for it, which is why subtracting the isolated kernel gave a negative residue in round 4.  exposed_ms = the device time
+           # per step during which NO pileup was running (between the loop's first begin and last end): what the latency-bound
+           # stages do not hide.  exposed_ms_by_host_clock = the host's step minus the device time with a pileup running per step
+           # (the same thing seen from the host; nothing is clamped).  alone = one sample by itself.
            "pileup_in_loop_ms": k_loop, "pileup_in_loop_ms_median": k_loop_median,
-           "exposed_ms": 1000.0 * t - k_loop, "exposed_ms_median": 1000.0 * t_median - k_loop_median,
+           "pileup_busy_ms_per_step": busy_per_step, "exposed_ms": idle_per_step,
+           "exposed_ms_by_host_clock": 1000.0 * t - busy_per_step,
            "pileup_in_run_ms_one_sample_alone": k_solo, "exposed_ms_one_sample_alone": 1000.0 * t_solo - k_solo}
     for x in xws:
         x.close()

@@ -372,7 +372,9 @@ int jl_time_pileup_set(jl_ctx *const *ctxs, uint32_t n_ctx, uint32_t reps, float
  * device was doing (another sample's latency-bound stages, another window's pileup), not alone (jl_time_pileup).  Off by
  * default: two more nodes are 2-3 us of a run. */
 int jl_run_pileup_clock(jl_ctx *ctx, int on);
-int jl_run_pileup_ms(jl_ctx *ctx, float *ms);
+/* begin_ticks (may be null): the first of the two stamps, in ticks of that 100 MHz clock — one clock for all contexts of a
+ * device, so the pileups of several contexts can be laid on one time line (do they overlap?  how long is the device without one?). */
+int jl_run_pileup_ms(jl_ctx *ctx, float *ms, uint64_t *begin_ticks);
 /* Name of the dominant kernel as rocprofv3 reports it. */
 const char *jl_pileup_kernel_name(void);
 

@@ -207,7 +207,7 @@ def load_library(path=LIB_PATH):
     lib.jl_time_pileup.argtypes = [vp, u32, C.POINTER(C.c_float)]
     lib.jl_time_pileup_set.argtypes = [vp, u32, u32, C.POINTER(C.c_float)]
     lib.jl_run_pileup_clock.argtypes = [vp, C.c_int]
-    lib.jl_run_pileup_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    lib.jl_run_pileup_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(u64)]
     lib.jl_comm_unique_id.argtypes = [vp]
     lib.jl_comm_create.argtypes = [vp, vp, C.c_int, C.c_int, C.POINTER(vp)]
     lib.jl_comm_create_inproc.argtypes = [vp, vp, C.c_int, C.c_int, C.POINTER(vp)]
@@ -576,8 +576,14 @@ class Juliet:
     def run_pileup_ms(self):
         """ms the pileup of the last run took where it ran (jl_run_pileup_ms; waits for the run)."""
         ms = C.c_float()
-        self._chk(self.lib.jl_run_pileup_ms(self.h, C.byref(ms)))
+        self._chk(self.lib.jl_run_pileup_ms(self.h, C.byref(ms), None))
         return float(ms.value)
+
+    def run_pileup_interval(self):
+        """(begin, end) of the last run's pileup in ms of the device's 100 MHz clock (one clock for all contexts of a device)."""
+        ms, t0 = C.c_float(), C.c_uint64()
+        self._chk(self.lib.jl_run_pileup_ms(self.h, C.byref(ms), C.byref(t0)))
+        return 1e-5 * t0.value, 1e-5 * t0.value + float(ms.value)
 
     def time_pileup(self, reps=20):
         ms = C.c_float()

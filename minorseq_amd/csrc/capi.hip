@@ -1781,7 +1781,7 @@ int jl_run_pileup_clock(jl_ctx *ctx, int on)
     return JL_OK;
 }
 
-int jl_run_pileup_ms(jl_ctx *ctx, float *ms)
+int jl_run_pileup_ms(jl_ctx *ctx, float *ms, uint64_t *begin_ticks)
 {
     if (!ctx || !ms) return JL_ERR_ARG;
     if (!ctx->pileup_clock) return jl_fail(ctx, JL_ERR_STATE, "jl_run_pileup_ms: the clock is off (jl_run_pileup_clock)");
@@ -1789,6 +1789,7 @@ int jl_run_pileup_ms(jl_ctx *ctx, float *ms)
     if (int rc = jl_run_wait_impl(ctx)) return rc;
     const volatile unsigned long long *t = reinterpret_cast<const volatile unsigned long long *>(const_cast<uint32_t *>(ctx->h_seq) + 8);
     *ms = (float)((double)(t[1] - t[0]) * 1e-5);      // 100 MHz ticks
+    if (begin_ticks) *begin_ticks = t[0];
     return JL_OK;
 }
 

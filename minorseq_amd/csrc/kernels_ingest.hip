@@ -459,7 +459,8 @@ struct ingest_args {
 #endif
 // entries of the reads that need them (a CCS read: 4 in a sweep with an indel), 4 bytes each in LDS:
 // column - sweep's first (0..256: 9 bits) | kind << 9 | (query offset there - the row's first) << 11
-constexpr uint32_t kEntCap = JL_INGEST_ENT_PER_READ * kTileReads, kEntCapWave = kEntCap / 2u;
+constexpr uint32_t kReadWaves = kTileReads / 64u;     // waves of read threads, with a part of the entry area each
+constexpr uint32_t kEntCap = JL_INGEST_ENT_PER_READ * kTileReads, kEntCapWave = kEntCap / kReadWaves;
 constexpr uint32_t kRowBase = 4u + kEntCap;     // (a side dword per entry: an entry begins inside one block at most)
 #ifndef JL_INGEST_ROW_EXTRA
 #define JL_INGEST_ROW_EXTRA 0             // pieces of a row beyond a sweep's own (room for inserted bases: 32 a piece)
@@ -469,14 +470,15 @@ __device__ __forceinline__ uint32_t row_dw(uint32_t j) { return kRowBase + kRowD
 constexpr uint32_t kStageDw = kRowBase + kRowDw * kTileReads + kGroupPadDw * kTileGroups + 4u;
 // the table: 32 entries (16 bits) a read — rows on 8-byte boundaries for the four-entries-at-a-time stores —
 // and 8 dwords of padding per 32 reads: the four 32-read groups of a wave's lanes read it 8 banks apart
-constexpr uint32_t kTabRow = 32u, kTabGroupPad = 16u;
+constexpr uint32_t kTabRow = kBlocks > 16u ? 32u : 16u, kTabGroupPad = 16u;
 static_assert(kBlocks <= kTabRow && kBlocks % 4u == 0, "a sweep is at most 32 blocks wide, whole chunks of four");
 constexpr uint32_t kTabSize = kTileReads * kTabRow + kTileGroups * kTabGroupPad;
 __device__ __forceinline__ uint32_t tab_row(uint32_t j) { return j * kTabRow + (j >> 5) * kTabGroupPad; }
 static_assert(kRowBase % 4u == 0 && kStageDw * 8u <= 65536u, "16-byte pieces; 16-bit nibble addresses");
-static_assert(kTileReads == 128u && kThreads == 256u, "two waves of read threads with an entry region each");
-// the pieces of a tile: threads 128..255 take kPieceRoundsB rounds of 128 pieces, the read threads — who also make the table — the rest
-constexpr uint32_t kPieceRoundsA = 2u, kPieceRoundsB = kRowPieces - kPieceRoundsA;
+static_assert(kTileReads % 64u == 0 && kThreads == 2u * kTileReads && kBlocks <= 32u, "whole waves of read threads; a block index fits five bits");
+// the pieces of a tile: the upper half of the threads take kPieceRoundsB rounds of kTileReads pieces, the read threads — who have
+// their rows of the table to make as well — the rest
+constexpr uint32_t kPieceRoundsA = kRowPieces >= 8u ? 2u : 1u, kPieceRoundsB = kRowPieces - kPieceRoundsA;
 
 
 // Eight of BAM's 4-bit bases, one per nibble -> eight symbol codes: A C G T (1 2 4 8) -> 0..3, everything else (N = 15, '=' = 0, the
@@ -564,8 +566,8 @@ __global__ __launch_bounds__(kThreads) void ingest_planes_kernel(ingest_args a)
     __shared__ __attribute__((aligned(16))) uint32_t s_stage[kStageDw];
     __shared__ __attribute__((aligned(16))) uint16_t s_tab[kTabSize];
     __shared__ uint32_t s_ent[kEntCap];           // the entries of the reads with several in the sweep, a half per read wave
-    __shared__ uint8_t s_own[kEntCap];            // whose: the read | 0x80 for its last one
-    __shared__ uint32_t s_nent[2];                // entries in each half
+    __shared__ uint16_t s_own[kEntCap];           // whose: the read | 0x8000 for its last one
+    __shared__ uint32_t s_nent[kReadWaves];       // entries in each part
     const uint32_t tid = threadIdx.x, wid = tid >> 6, lane = tid & 63u;
     // block -> (read tile, sweep).  Blocks b, b + 8, b + 16, ... are dealt to the same XCD one after the other; an XCD takes
     // whole groups of 1024 reads (group = xcd, xcd + 8, ...), and of a group all sweeps in turn, the tiles of the group
@@ -723,17 +725,17 @@ __global__ __launch_bounds__(kThreads) void ingest_planes_kernel(ingest_args a)
             const uint32_t e8[8] = {pack(e01.x, e01.y), pack(e01.z, e01.w), pack(e23.x, e23.y), pack(e23.z, e23.w),
                                     pack(e45.x, e45.y), pack(e45.z, e45.w), pack(e67.x, e67.y), pack(e67.z, e67.w)};
             uint32_t *ent = s_ent + off_e;
-            uint8_t *own = s_own + off_e;
+            uint16_t *own = s_own + off_e;
 #pragma unroll
             for (uint32_t i = 0; i < 8u; ++i)
                 if (i < n_ent) {
                     ent[i] = e8[i];
-                    own[i] = (uint8_t)(tid | (i + 1u == n_ent ? 0x80u : 0u));
+                    own[i] = (uint16_t)(tid | (i + 1u == n_ent ? 0x8000u : 0u));
                 }
             for (uint32_t i = 8; i < n_ent; ++i) {
                 const uint2 g = src[i];
                 ent[i] = pack(g.x, g.y);
-                own[i] = (uint8_t)(tid | (i + 1u == n_ent ? 0x80u : 0u));
+                own[i] = (uint16_t)(tid | (i + 1u == n_ent ? 0x8000u : 0u));
             }
             atomicMax(&s_nent[wid], off_e - wid * kEntCapWave + n_ent);
         }
@@ -750,12 +752,24 @@ __global__ __launch_bounds__(kThreads) void ingest_planes_kernel(ingest_args a)
     // of 'not covered' — and every block is wholly inside one entry or has an entry that begins inside it; those are put
     // together, by the thread of the first such entry, in that entry's side dword.  No list, no search, no loop per block.
     if (!JL_ING_SKIP(a, 1)) {
-        const uint32_t n_a = s_nent[0], n_e = n_a + s_nent[1];
+        uint32_t n_e = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < kReadWaves; ++w) n_e += s_nent[w];
         for (uint32_t si = tid; si < n_e; si += kThreads) {
-            const uint32_t slot = si < n_a ? si : kEntCapWave + (si - n_a);
+            uint32_t slot = 0, rem = si;      // the si-th entry of the parts one behind the other
+            bool found = false;
+#pragma unroll
+            for (uint32_t w = 0; w < kReadWaves; ++w) {
+                const uint32_t nw = s_nent[w];
+                if (!found && rem < nw) {
+                    slot = w * kEntCapWave + rem;
+                    found = true;
+                }
+                if (!found) rem -= nw;
+            }
             const uint32_t own = s_own[slot], e = s_ent[slot], nx = s_ent[slot + 1u];
             const uint32_t wr = ent_col(e);
-            if ((own & 0x80u) || wr >= width) continue;
+            if ((own & 0x8000u) || wr >= width) continue;
             const uint32_t row8 = 8u * row_dw(own);
             uint16_t *tab = s_tab + tab_row(own);
             // (a) the entry's whole blocks [bf, be): singly up to a multiple of four, four a store, singly again
@@ -807,7 +821,7 @@ __global__ __launch_bounds__(kThreads) void ingest_planes_kernel(ingest_args a)
                         m_al |= m;
                     } else m_del |= m;
                 }
-                if (Wn >= c1 || (s_own[kk] & 0x80u)) break;     // (the read's last entry is nothing: 'not covered' stays)
+                if (Wn >= c1 || (s_own[kk] & 0x8000u)) break;     // (the read's last entry is nothing: 'not covered' stays)
                 ee = nn;
             }
             const uint32_t R = (codes_of_bases8(bases) & m_al) | (0x44444444u & m_del) | (0x66666666u & ~(m_al | m_del));

@@ -977,10 +977,13 @@ def _cells_equal(window, rec, n, n_cols, win_begin=0, min_qv=0):
     return None
 
 
-@pytest.mark.parametrize("n,l", [(100_000, 3000), (333_333, 1000)])
+@pytest.mark.parametrize("n,l", [(100_000, 3000), (333_333, 1000), (2000, 600), (5000, 640)])
 def test_device_ingest_at_size(jl, n, l):
-    """100k x 3000 (the bench's window: 98 groups of 1024 reads x 14 sweeps) and 333 333 x 1000 (326 groups: they do not divide
-    among the eight XCDs, an XCD serves forty of them in turn): jl_records_window of the resident records == every cell."""
+    """100k x 3000 (the bench's window: 98 groups of 1024 reads x 12 sweeps) and 333 333 x 1000 (326 groups: they do not divide
+    among the eight XCDs, an XCD serves forty of them in turn): jl_records_window of the resident records == every cell.
+    2000 x 600 and 5000 x 640: windows whose LAST sweep every read ends in — each read has several entries there, a workgroup's
+    entry list is longer than its thread count (a second pass of the table fill: round 5 shipped a slot mapping that was
+    wrong exactly there, for a few hours)."""
     rec = synth.raw_records(5, n, l)
     jl.records_upload(rec["pos"], rec["cigar"], rec["cig_off"], rec["seq4"], rec["seq_off"])
     w = capi.Juliet(0)
@@ -990,7 +993,8 @@ def test_device_ingest_at_size(jl, n, l):
         got = None
         sp, ref = synth.SynthParams(seed=5), synth.reference(5, l)
         packed = w.download_columns()
-        for g in (0, (n // 1024) // 2 + 3, n // 1024):
+        last = (n - 1) // 1024
+        for g in sorted({0, min((n // 1024) // 2 + 3, last), last}):
             r0, r1 = 1024 * g, min(n, 1024 * g + 1024)
             got = msa.unpack_columns(np.ascontiguousarray(packed[:, r0 // 2:(r1 + 1) // 2]), r1 - r0)
             assert (got == synth.rows(sp, l, r0, r1, ref)).all(), g
@@ -1002,11 +1006,11 @@ def test_device_ingest_at_size(jl, n, l):
 @pytest.mark.parametrize("n,l,win,min_qv", [(24_000, 1100, (37, 1039), 20), (24_000, 1100, (0, 1100), 0), (21_000, 700, (300, 693), 20)])
 def test_device_ingest_qv_and_ragged_window_at_size(jl, n, l, win, min_qv):
     """Tens of groups through the QV path and through windows that begin inside the reads and end on no sweep boundary
-    (n_cols % 224 != 0), on records with what an ingest must ignore: insertions of 1-4 bases, soft and hard clips, and 2 % of
+    (n_cols % 256 != 0), on records with what an ingest must ignore: insertions of 1-4 bases, soft and hard clips, and 2 % of
     the aligned bases below the threshold."""
     rec = synth.raw_records(9, n, l, extra=("--ins-ppm", "2500", "--clips", "--low-qv-ppm", "20000", "--partial", "0.3"))
     b, e = win
-    assert (e - b) % 224 != 0
+    assert (e - b) % 256 != 0
     jl.records_upload(rec["pos"], rec["cigar"], rec["cig_off"], rec["seq4"], rec["seq_off"], rec["qual"], rec["qual_off"])
     w = capi.Juliet(0)
     try:
