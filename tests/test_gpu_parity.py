@@ -1021,6 +1021,29 @@ def test_device_ingest_qv_and_ragged_window_at_size(jl, n, l, win, min_qv):
         jl.records_drop()
 
 
+def test_device_ingest_random_shapes(jl):
+    """A seeded slice of tools_tuning/ingest_stress.py: read counts, widths, indel and mask rates and windows drawn at random,
+    with and without qualities."""
+    rng = np.random.default_rng(2025)
+    for k in range(10):
+        n = int(rng.integers(1, 6000))
+        l = int(rng.integers(30, 1500))
+        sp = synth.SynthParams(seed=2000 + k, partial_rate=float(rng.uniform(0, 0.6)), del_rate=float(rng.choice([0.0, 0.002, 0.05, 0.3])),
+                               mask_rate=float(rng.choice([0.0, 0.02, 0.4])), sub_rate=0.01)
+        ref = synth.reference(sp.seed, l)
+        rows = synth.rows(sp, l, 0, n, ref)
+        if n > 8:
+            rows[5] = 6
+            rows[3, : l // 2] = 6
+        pos, cigar, cig_off, seq4, seq_off, qual, qual_off = rows_to_records(rows, ref, rng)
+        b = int(rng.integers(0, max(1, l // 2)))
+        e = int(rng.integers(b + 1, l + 1))
+        jl.ingest_records(e - b, b, pos, cigar, cig_off, seq4, seq_off)
+        assert (msa.unpack_columns(jl.download_columns(), n) == rows[:, b:e]).all(), (k, n, l, b, e)
+        jl.ingest_records(e - b, b, pos, cigar, cig_off, seq4, seq_off, qual, qual_off, min_qv=50)
+        assert (msa.unpack_columns(jl.download_columns(), n) == rows[:, b:e]).all(), ("qv", k, n, l, b, e)
+
+
 @pytest.mark.parametrize("chunk,hints", [(1, (0, 0, 0, 0)), (37, (0, 0, 0, 0)), (256, (5000, 100000, 1 << 20, 1 << 21)), (10000, (0, 0, 0, 0))])
 def test_device_ingest_in_chunks(jl, chunk, hints):
     """jl_records_begin / _append / _finish: any chunking (one read per append, ragged chunks, one chunk; device arrays
