@@ -563,7 +563,10 @@ __device__ __forceinline__ uint32_t ent_addr(uint32_t e, uint32_t row8, uint32_t
 template <bool QV>
 __global__ __launch_bounds__(kThreads) void ingest_planes_kernel(ingest_args a)
 {
-    __shared__ __attribute__((aligned(16))) uint32_t s_stage[kStageDw];
+#ifndef JL_INGEST_LDS_PAD
+#define JL_INGEST_LDS_PAD 0               // (tuning: bytes of LDS a workgroup holds on top of what it uses — fewer workgroups per CU)
+#endif
+    __shared__ __attribute__((aligned(16))) uint32_t s_stage[kStageDw + JL_INGEST_LDS_PAD / 4];
     __shared__ __attribute__((aligned(16))) uint16_t s_tab[kTabSize];
     __shared__ uint32_t s_ent[kEntCap];           // the entries of the reads with several in the sweep, a half per read wave
     __shared__ uint16_t s_own[kEntCap];           // whose: the read | 0x8000 for its last one
