@@ -474,6 +474,11 @@ constexpr uint32_t kTabRow = kBlocks > 16u ? 32u : 16u, kTabGroupPad = 16u;
 static_assert(kBlocks <= kTabRow && kBlocks % 4u == 0, "a sweep is at most 32 blocks wide, whole chunks of four");
 constexpr uint32_t kTabSize = kTileReads * kTabRow + kTileGroups * kTabGroupPad;
 __device__ __forceinline__ uint32_t tab_row(uint32_t j) { return j * kTabRow + (j >> 5) * kTabGroupPad; }
+// ... and within a row the chunks of four blocks change places by the read's number: the rows are 16 dwords apart, so that sixty-four
+// reads storing the same chunk of their rows met in two bank phases (8 b64 stores of a one-entry row took a sixteenth of their rate:
+// 13 of the kernel's 21 x 10^6 LDS cycles were bank conflicts)
+__device__ __forceinline__ uint32_t tab_at(uint32_t j, uint32_t blk) { return tab_row(j) + ((((blk >> 2) ^ j) & (kTabRow / 4u - 1u)) << 2) + (blk & 3u); }
+static_assert((kTabRow / 4u & (kTabRow / 4u - 1u)) == 0, "chunks of a row: a power of two");
 static_assert(kRowBase % 4u == 0 && kStageDw * 8u <= 65536u, "16-byte pieces; 16-bit nibble addresses");
 static_assert(kTileReads % 64u == 0 && kThreads == 2u * kTileReads && kBlocks <= 32u, "whole waves of read threads; a block index fits five bits");
 // the pieces of a tile: the upper half of the threads take kPieceRoundsB rounds of kTileReads pieces, the read threads — who have
@@ -698,7 +703,6 @@ __global__ __launch_bounds__(kThreads) void ingest_planes_kernel(ingest_args a)
         }
         ask_pieces(p0, kPieceRoundsA, dp, qo, pc);
         const int32_t q0 = (int32_t)d.z;
-        uint16_t *tab = s_tab + tab_row(tid);
         const uint32_t row8 = 8u * row_dw(tid);
         if (!n_ent) {
             // one entry covers the sweep: its blocks' addresses rise by eight codes a block (aligned bases) or stay (the
@@ -707,10 +711,9 @@ __global__ __launch_bounds__(kThreads) void ingest_planes_kernel(ingest_args a)
             const uint32_t a0 = kind == 1u ? row8 + (d.y - (uint32_t)q0) : kind == 2u ? 16u : 0u, st = kind == 1u ? 8u : 0u;
             uint32_t lo = a0 | ((a0 + st) << 16), hi = lo + 2u * (st | st << 16);
             const uint32_t step = 4u * (st | st << 16);
-            uint2 *row_p = reinterpret_cast<uint2 *>(tab);
 #pragma unroll
             for (uint32_t k = 0; k < kBlocks / 4u; ++k) {
-                row_p[k] = make_uint2(lo, hi);
+                *reinterpret_cast<uint2 *>(s_tab + tab_at(tid, 4u * k)) = make_uint2(lo, hi);
                 lo += step;
                 hi += step;
             }
@@ -774,7 +777,6 @@ __global__ __launch_bounds__(kThreads) void ingest_planes_kernel(ingest_args a)
             const uint32_t wr = ent_col(e);
             if ((own & 0x8000u) || wr >= width) continue;
             const uint32_t row8 = 8u * row_dw(own);
-            uint16_t *tab = s_tab + tab_row(own);
             // (a) the entry's whole blocks [bf, be): singly up to a multiple of four, four a store, singly again
             const uint32_t wn = ent_col(nx);
             const uint32_t be = wn >= width ? kBlocks : wn >> 3;
@@ -785,21 +787,21 @@ __global__ __launch_bounds__(kThreads) void ingest_planes_kernel(ingest_args a)
 #pragma unroll
                 for (uint32_t k = 0; k < 3u; ++k)
                     if ((bf & 3u) && bf < be) {
-                        tab[bf] = (uint16_t)av;
+                        s_tab[tab_at(own, bf)] = (uint16_t)av;
                         av += st;
                         ++bf;
                     }
                 uint32_t p01 = av | ((av + st) << 16);
                 const uint32_t p_st = st | st << 16;
                 for (; bf + 4u <= be; bf += 4u) {
-                    reinterpret_cast<uint2 *>(tab)[bf >> 2] = make_uint2(p01, p01 + 2u * p_st);
+                    *reinterpret_cast<uint2 *>(s_tab + tab_at(own, bf)) = make_uint2(p01, p01 + 2u * p_st);
                     p01 += 4u * p_st;
                 }
                 av = p01 & 0xFFFFu;
 #pragma unroll
                 for (uint32_t k = 0; k < 3u; ++k)
                     if (bf < be) {
-                        tab[bf] = (uint16_t)av;
+                        s_tab[tab_at(own, bf)] = (uint16_t)av;
                         av += st;
                         ++bf;
                     }
@@ -829,7 +831,7 @@ __global__ __launch_bounds__(kThreads) void ingest_planes_kernel(ingest_args a)
             }
             const uint32_t R = (codes_of_bases8(bases) & m_al) | (0x44444444u & m_del) | (0x66666666u & ~(m_al | m_del));
             s_stage[4u + slot] = R;
-            tab[bb] = (uint16_t)(8u * (4u + slot));
+            s_tab[tab_at(own, bb)] = (uint16_t)(8u * (4u + slot));
         }
     }
     JL_ING_STAMP(a, 8)
@@ -843,10 +845,13 @@ __global__ __launch_bounds__(kThreads) void ingest_planes_kernel(ingest_args a)
             // (the dwords in front of the reads' rows — 'not covered', '-', the boundary blocks — hold symbol codes already; `codes`
             // collects, a bit a read, whose dword is one of those: v_alignbit shifts the sign of address - first row in)
             uint32_t R[32], codes = 0;
-            const uint16_t *tab = s_tab + tab_row(32u * G) + blk;
+            // (the block's place in the rows of the reads i, i + 8, ...: eight offsets)
+            uint32_t at[8];
+#pragma unroll
+            for (uint32_t i = 0; i < 8u; ++i) at[i] = tab_at(32u * G + i, blk);
 #pragma unroll
             for (int i = 31; i >= 0; --i) {
-                const uint32_t A = tab[(uint32_t)i * kTabRow];
+                const uint32_t A = s_tab[at[i & 7] + (uint32_t)(i & ~7) * kTabRow];
                 R[i] = __builtin_amdgcn_alignbit(s_stage[(A >> 3) + 1u], s_stage[A >> 3], 4u * (A & 7u));
                 codes = __builtin_amdgcn_alignbit(codes, A - 8u * kRowBase, 31u);
             }
