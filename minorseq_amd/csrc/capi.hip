@@ -471,13 +471,13 @@ int jl_ingest_verdict(jl_ctx *ctx)
     if (!ctx->ing_check_pending) return JL_OK;
     ctx->ing_check_pending = false;
     // (through the context's pinned block: a process's first pageable device-to-host copy costs the runtime milliseconds)
-    unsigned long long both[2] = {0, ~0ull};
+    unsigned long long both[2] = {0, ~0ull};     // (the counters, the verdict: kernels_ingest.hip jl_launch_ingest)
 #ifdef JL_TUNING
     {   // the address checks of the tuning build's ingest kernels (kernels_ingest.hip JL_ING_CHECK)
         uint32_t w[16] = {0};
         if (int rc = jl_fetch_to_host(ctx, ctx->d_ing_count, 64, w, 64)) return rc;
-        for (int c = 1; c < 6; ++c)
-            if (w[4 + c]) fprintf(stderr, "ingest check %d failed %u times (a value: %u)\n", c, w[4 + c], w[10 + c]);
+        for (int c = 1; c < 5; ++c)
+            if (w[4 + c]) fprintf(stderr, "ingest check %d failed %u times (a value: %u)\n", c, w[4 + c], w[9 + c]);
         if (getenv("JL_ING_STAMPS") && ctx->d_ing_slow) {   // phase stamps of the sampled workgroups (kernels_ingest.hip JL_ING_STAMP)
             std::vector<unsigned long long> t(160 * 4 * 12);
             hipMemcpy(t.data(), ctx->d_ing_slow, t.size() * 8, hipMemcpyDeviceToHost);
@@ -538,7 +538,7 @@ static int records_build(jl_ctx *src, jl_ctx *dst, uint32_t n_cols, uint32_t win
     if (e == hipSuccess) e = ingest_room(dst, &dst->d_ing_runs, &dst->ing_cap_runs, (size_t)R.n_cig + 3 * nr + 8);   // (three entries around a read's runs; + 8: the planes kernel reads entries four and eight at a time)
     if (e == hipSuccess) e = ingest_room(dst, &dst->d_ing_nruns, &dst->ing_cap_reads, nr + 1);
     if (e == hipSuccess) e = ingest_room(dst, &dst->d_ing_desc, &dst->ing_cap_desc, (nr + 1) * ns);
-    if (e == hipSuccess) e = ingest_room(dst, &dst->d_ing_slow, &dst->ing_cap_slow, (nr + 1) * ns);
+    if (e == hipSuccess) e = ingest_room(dst, &dst->d_ing_slow, &dst->ing_cap_slow, jl_ingest_slow_room(dst));
     if (e == hipSuccess && !dst->d_ing_count) e = hipMalloc(&dst->d_ing_count, 64);
     dst->ins_valid = false;
     if (e == hipSuccess && dst->track_insertions) {

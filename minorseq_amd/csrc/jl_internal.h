@@ -511,6 +511,7 @@ void jl_launch_ingest(jl_ctx *ctx, const int32_t *d_pos, const uint32_t *d_cigar
                       const uint64_t *d_qual_off, uint32_t min_qv, uint2 *d_runs, uint32_t *d_nruns, uint4 *d_desc,
                       uint32_t *d_slow_count, uint2 *d_slow, bool keep_verdict, uint64_t seq_bytes, uint64_t n_entries);
 uint32_t jl_ingest_sweeps(uint32_t n_cols);
+size_t jl_ingest_slow_room(const jl_ctx *ctx);
 extern "C" int jl_ingest_verdict(jl_ctx *ctx);
 void jl_launch_regroup(jl_ctx *ctx, const uint16_t *d_hap_of_group, uint32_t n_groups, uint32_t n_haplotypes, bool phased);
 void jl_launch_insertions(jl_ctx *ctx, const int32_t *d_pos, const uint32_t *d_cigar, const uint64_t *d_cig_off,

@@ -37,6 +37,7 @@
 namespace {
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4a4 __attribute__((ext_vector_type(4), aligned(4)));
 
 constexpr uint32_t kSweep = JL_INGEST_SWEEP;        // columns per workgroup
 constexpr uint32_t kBlocks = kSweep / 8u;           // blocks of 8 columns = dwords of 8 codes
@@ -69,16 +70,21 @@ __device__ __forceinline__ uint32_t wave_scan(uint32_t v)
 // Entry 0 = {0, nothing}; entries 1 .. n_runs the read's runs, columns clamped to [0, n_cols] (a run that begins before the
 // window begins at column 0 with its query offset moved along); entry n_runs + 1 = the read's end {column, nothing, query
 // length}; entry n_runs + 2 = {kRunMask, nothing}: never reached.  The columns never decrease.
-constexpr uint32_t kRunsReadsPerWave = 4u, kRunsBatches = 1u;   // a wave: batches of four reads, one after the other (more than one batch a wave measured slower: 63 against 51 us with four)
-constexpr uint32_t kRunsLds = 64u;          // entries of a read kept in LDS for the descriptors (the rest is read back from HBM)
+constexpr uint32_t kRunsReadsPerWave = 4u;   // a wave takes four reads a turn
+// entries of a read kept in LDS for the descriptors: 64 — 8 KB a workgroup — in the launch that takes every read (a CCS read has
+// a dozen), which lists the reads with more; 512 — 64 KB, two workgroups a CU — in the launch that takes those (and reads
+// what is beyond even that back from HBM, a trip an entry: 1 ms instead of 0.12 for 100k reads with 1 % of indels, 236 ops
+// a read, when they all did)
+constexpr uint32_t kRunsLdsSmall = 64u, kRunsLdsLarge = 512u;
+constexpr uint32_t kRunsLongGrid = 1024u;     // workgroups of the second launch at most: its waves take 64 reads at a time, in turns
 constexpr uint32_t kDescSweeps = 15u;       // sweeps a row of sixteen lanes describes per pass (it needs sixteen bounds)
 constexpr uint32_t kDescMax = 255u;         // "more than the planes kernel takes": pieces or entries of a (read, sweep)
 
 // Descriptor of (sweep s, read r) at desc[s * n_reads + r]:
-//   x  index of the first 16-byte piece of packed bases (byte offset / 16), low 32 bits
+//   x  where the first 16-byte piece of packed bases begins (byte offset / 4: on a dword), low 32 bits
 //   y  index of the sweep's first entry in runs[], low 32 bits
-//   z  query offset of the first piece's first base (>= -30: the piece may begin before the read's bases)
-//   w  piece index bits 32-39 | entry index bits 32-39 << 8 | pieces << 16 | entries << 24   (255 = too many)
+//   z  query offset of the first piece's first base (>= -6: the piece may begin before the read's bases)
+//   w  x's bits 32-39 | entry index bits 32-39 << 8 | pieces << 16 | entries << 24   (255 = too many)
 // The entries of a sweep: from the one that contains its first column to the first one that begins behind its last column.
 // Two entries = ONE entry covers the whole sweep, the common case: then `entries` reads 1, y = the query offset of the sweep's
 // first column and bits 8-9 of w = the entry's kind — the planes kernel never asks for the entries.
@@ -91,6 +97,10 @@ constexpr uint32_t kDescMax = 255u;         // "more than the planes kernel take
 #ifndef JL_RUNS_WAVES
 #define JL_RUNS_WAVES 1
 #endif
+// The first launch takes every read, four a wave, with room for kRunsLdsSmall entries each in LDS; a read with more gets its
+// entries and its count there, but not its descriptors.  The second launch (LONG) takes those reads — it finds them by their
+// counts, sixty-four reads a wave at a time — with room for kRunsLdsLarge.
+template <uint32_t kRunsLds, bool LONG>
 __global__ __launch_bounds__(256, JL_RUNS_WAVES) void cigar_runs_kernel(uint64_t n_reads, const int32_t *__restrict__ pos, const uint32_t *__restrict__ cigar,
                                                          const uint64_t *__restrict__ cig_off, const uint64_t *__restrict__ seq_off,
                                                          const uint64_t *__restrict__ qual_off, uint32_t win_begin, uint32_t n_cols,
@@ -101,17 +111,12 @@ __global__ __launch_bounds__(256, JL_RUNS_WAVES) void cigar_runs_kernel(uint64_t
     // read's cigar in one or two steps): a lane adds its eight ops up itself, the sixteen lanes' sums are scanned within the DPP
     // row (four row_shr steps, no row broadcast), and a second pass over the lane's ops puts the entries out.  (One read at a
     // time over the whole wave, two ops a lane, was 450 wave instructions a read; the scans, the ballots and the bookkeeping
-    // per step are now shared by four reads and eight ops a lane.)
+    // per step are now shared by four reads and eight ops a lane.  Several batches of four a wave, the next one's words asked
+    // for ahead, measured slower: 63 against 51 us.)
     __shared__ uint2 s_run_all[4][kRunsReadsPerWave][kRunsLds];
     const uint32_t wid = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    const uint64_t r_wave = ((uint64_t)blockIdx.x * 4u + wid) * (kRunsReadsPerWave * kRunsBatches);
-    if (r_wave >= n_reads) return;
     uint2 (*s_run)[kRunsLds] = s_run_all[wid];
     const uint32_t q = lane >> 4, sl = lane & 15u;
-    typedef uint32_t u32x4a4 __attribute__((ext_vector_type(4), aligned(4)));
-    // A wave takes kRunsBatches batches of four reads one after the other, and what a batch waits for — its reads' offsets, then
-    // the first 128 ops of each — is asked for while the batch before is worked on: with a batch per wave the kernel was three
-    // rounds of waves that each waited two trips to HBM for a microsecond of work.
     struct head_t { uint64_t cb, c_end, so, so1, qlen; int32_t pos; };
     auto ask_head = [&](uint64_t rr) -> head_t {     // (the sixteen lanes of a row ask for the same words: one request)
         head_t h = {0, 0, 0, 0, ~0ull, 0};
@@ -131,17 +136,27 @@ __global__ __launch_bounds__(256, JL_RUNS_WAVES) void cigar_runs_kernel(uint64_t
         wa = k < n ? *reinterpret_cast<const u32x4a4 *>(cigar + h.cb + k) : z;           // (words past the read's ops are masked where they are used)
         wb = k + 4u < n ? *reinterpret_cast<const u32x4a4 *>(cigar + h.cb + k + 4u) : z;
     };
-    head_t h_next = ask_head(r_wave + q);
-    u32x4a4 wa_next, wb_next;
-    ask_words(h_next, 8u * sl, wa_next, wb_next);
-    for (uint32_t batch = 0; batch < kRunsBatches; ++batch) {
-    const uint64_t r0 = r_wave + (uint64_t)batch * kRunsReadsPerWave;
-    if (r0 >= n_reads) break;
-    const uint64_t r = r0 + q;
+    const uint64_t turn = (uint64_t)gridDim.x * 4u * (LONG ? 64u : kRunsReadsPerWave);
+    for (uint64_t i0 = ((uint64_t)blockIdx.x * 4u + wid) * (LONG ? 64u : kRunsReadsPerWave); i0 < n_reads; i0 += turn) {
+    // LONG: which of the sixty-four reads from i0 on are long ones, taken four at a time
+    uint64_t todo = 1;
+    if (LONG) todo = __ballot(i0 + lane < n_reads && nruns[min(i0 + lane, n_reads - 1u)] + 3u > kRunsLdsSmall);
+    while (todo) {
+    uint64_t r = i0 + q;
+    if (LONG) {
+        uint32_t at[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            at[t] = todo ? (uint32_t)__builtin_ctzll(todo) : 64u;
+            todo &= todo - 1u;
+        }
+        const uint32_t mine = q == 0u ? at[0] : q == 1u ? at[1] : q == 2u ? at[2] : at[3];
+        r = mine < 64u ? i0 + mine : n_reads;
+    } else todo = 0;
     const bool live = r < n_reads;
-    const head_t h = h_next;
-    const u32x4a4 wa_first = wa_next, wb_first = wb_next;
-    if (batch + 1u < kRunsBatches) h_next = ask_head(r + kRunsReadsPerWave);
+    const head_t h = ask_head(r);
+    u32x4a4 wa_first, wb_first;
+    ask_words(h, 8u * sl, wa_first, wb_first);
     const uint64_t my_cb = h.cb, c_end = h.c_end, my_so = h.so, so1 = h.so1, qlen = h.qlen;
     const int64_t base = (int64_t)h.pos - (int64_t)win_begin;
     const uint64_t ent0 = my_cb + 3u * r;     // index of the read's entry 0 in runs[]
@@ -240,7 +255,6 @@ __global__ __launch_bounds__(256, JL_RUNS_WAVES) void cigar_runs_kernel(uint64_t
         ref_total += r_step;
         q_total += q_step;
     }
-    if (batch + 1u < kRunsBatches) ask_words(h_next, 8u * sl, wa_next, wb_next);     // (its offsets have had the walk to arrive)
     // M anywhere in the row?  (a ballot's sixteen bits)
     const uint64_t bm = __ballot(has_m);
     uint32_t code = ((bm >> (16u * q)) & 0xFFFFull) != 0ull ? 1u : 0u;
@@ -258,6 +272,8 @@ __global__ __launch_bounds__(256, JL_RUNS_WAVES) void cigar_runs_kernel(uint64_t
         uint32_t bf;
         end_col = window_col(ref_total, bf);
     }
+    // a read with more entries than the LDS copy holds: for the second launch (its entries are written here all the same)
+    const bool is_long = !LONG && live && n_runs + 3u > kRunsLds;
     if (live && sl < 3u) {
         const uint32_t idx = sl == 0u ? 0u : n_runs + sl;
         const uint2 e = sl == 0u ? make_uint2(3u << 30, 0u) : sl == 1u ? make_uint2(end_col | (3u << 30), (uint32_t)q_total) : make_uint2(kRunMask | (3u << 30), 0u);
@@ -266,10 +282,11 @@ __global__ __launch_bounds__(256, JL_RUNS_WAVES) void cigar_runs_kernel(uint64_t
     }
     // ---- the descriptors: a lane per sweep (fifteen sweeps a pass: a sweep needs the bound of the next one too).  Entries
     // beyond the LDS copy are read back from HBM: past this wave's own stores.
-    uint32_t n_max = n_runs;
+    const uint32_t n_mine = is_long ? 0u : n_runs;
+    uint32_t n_max = n_mine;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) n_max = max(n_max, (uint32_t)__builtin_amdgcn_readlane((int)n_runs, 16 * t));
-    if (n_max + 3u > kRunsLds) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    for (int t = 0; t < 4; ++t) n_max = max(n_max, (uint32_t)__builtin_amdgcn_readlane((int)n_mine, 16 * t));
+    if (LONG && n_max + 3u > kRunsLds) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     __builtin_amdgcn_wave_barrier();
     const uint32_t n_ent_all = n_runs + 3u;          // entries of this lane's read
     uint32_t top = 1u;                         // the highest power of two not above the longest list
@@ -283,10 +300,10 @@ __global__ __launch_bounds__(256, JL_RUNS_WAVES) void cigar_runs_kernel(uint64_t
             uint32_t f = 0;
             for (uint32_t step = top; step; step >>= 1) {
                 const uint32_t t = f + step;
-                if (live && t <= n_ent_all && (entry(t - 1u).x & kRunMask) <= X) f = t;
+                if (live && !is_long && t <= n_ent_all && (entry(t - 1u).x & kRunMask) <= X) f = t;
             }
             const uint32_t f_next = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)f, 0x101, 0xF, 0xF, false);   // row_shl:1
-            if (!live || sl == kDescSweeps || s >= n_sweeps) continue;
+            if (!live || is_long || sl == kDescSweeps || s >= n_sweeps) continue;
             const uint32_t Xend = min(n_cols, X + kSweep);
             const uint32_t lo = f - 1u;
             uint32_t n_ent = f_next - f + 2u;
@@ -307,18 +324,19 @@ __global__ __launch_bounds__(256, JL_RUNS_WAVES) void cigar_runs_kernel(uint64_t
                     e = nx;
                 }
             }
-            // the 16-byte pieces of packed bases the sweep takes: from the one that holds its first base (byte offsets are even
-            // in bases: all of this in 32 bits relative to the read's first byte, the one 64-bit sum at the end)
+            // the 16-byte pieces of packed bases the sweep takes: from the DWORD that holds its first base on — at most seven bases
+            // before it, so that a row of the planes kernel (a sweep + 32 bases) has room for 25 inserted ones (byte offsets are
+            // even in bases: all of this in 32 bits relative to the read's first byte, the one 64-bit sum at the end)
             uint64_t piece = 0;
             uint32_t np = 0;
             int32_t q0 = 0;
             if (q_lo < q_hi) {
-                const uint32_t al = (uint32_t)my_so & 15u;                       // the read's first byte within its piece
-                const uint32_t b_lo = al + (q_lo >> 1), b_hi = al + (q_hi + 1u) / 2u;   // bytes from that piece's first on
-                const uint32_t p_lo = b_lo >> 4;
-                piece = (my_so >> 4) + p_lo;
-                np = min((b_hi + 15u - 16u * p_lo) >> 4, kDescMax);
-                q0 = (int32_t)(2u * (16u * p_lo - al));
+                const uint32_t al = (uint32_t)my_so & 3u;                        // the read's first byte within its dword
+                const uint32_t b_lo = al + (q_lo >> 1), b_hi = al + (q_hi + 1u) / 2u;   // bytes from that dword's first on
+                const uint32_t d_lo = b_lo >> 2;
+                piece = (my_so >> 2) + d_lo;
+                np = min((b_hi + 15u - 4u * d_lo) >> 4, kDescMax);
+                q0 = 2 * ((int32_t)(4u * d_lo) - (int32_t)al);
             }
             const uint64_t e_idx = ent0 + lo;
             uint4 d;
@@ -337,14 +355,16 @@ __global__ __launch_bounds__(256, JL_RUNS_WAVES) void cigar_runs_kernel(uint64_t
         }
     };
     const uint2 *s_mine = s_run[q];
-    if (n_max + 3u <= kRunsLds) describe([&](uint32_t i) -> uint2 { return s_mine[i]; });
+    if (!LONG || n_max + 3u <= kRunsLds) describe([&](uint32_t i) -> uint2 { return s_mine[i]; });
     else
         describe([&](uint32_t i) -> uint2 {
             if (i < kRunsLds) return s_mine[i];
             const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(runs + ent0 + i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             return make_uint2((uint32_t)v, (uint32_t)(v >> 32));
         });
-    __builtin_amdgcn_wave_barrier();      // (the next batch writes the LDS copy this one's descriptors were made from)
+    __builtin_amdgcn_wave_barrier();      // (the next four reads write the LDS copy these ones' descriptors were made from)
+    }
+    if (!LONG) break;                     // (the first launch has a wave for every four reads)
     }
 }
 
@@ -422,6 +442,7 @@ struct ingest_args {
     const uint4 *desc;
     uint32_t *slow_count;
     uint2 *slow_list;            // {read, sweep}
+    uint32_t *big_list;          // the units (block numbers) handed on to the kernel's second size; their number in slow_count[1]
     uint8_t *msa;
     uint64_t plane_stride;
     uint64_t seq_bytes, n_entries;   // (tuning builds check every address a descriptor leads to against these and report in dbg[])
@@ -431,11 +452,11 @@ struct ingest_args {
 };
 #ifdef JL_TUNING
 #define JL_ING_SKIP(a, bit) (((a).skip >> (bit)) & 1u)
-// an address that would leave its array: counted in dbg[code], the offending value kept in dbg[6 + code]; the access is redirected
+// an address that would leave its array: counted in dbg[code], the offending value kept in dbg[5 + code]; the access is redirected
 #define JL_ING_CHECK(a, ok, code, value, fix) \
     if (!(ok)) {                               \
         atomicAdd(&(a).dbg[code], 1u);         \
-        (a).dbg[6 + (code)] = (uint32_t)(value); \
+        (a).dbg[5 + (code)] = (uint32_t)(value); \
         fix;                                   \
     }
 // wall-clock stamps (10 ns) of every 61st workgroup's waves at the phase boundaries, in the (empty) slow list's memory
@@ -457,17 +478,27 @@ struct ingest_args {
 #ifndef JL_INGEST_ENT_PER_READ
 #define JL_INGEST_ENT_PER_READ 4
 #endif
-// entries of the reads that need them (a CCS read: 4 in a sweep with an indel), 4 bytes each in LDS:
-// column - sweep's first (0..256: 9 bits) | kind << 9 | (query offset there - the row's first) << 11
+#ifndef JL_INGEST_ENT_PER_READ_BIG
+#define JL_INGEST_ENT_PER_READ_BIG 16
+#endif
 constexpr uint32_t kReadWaves = kTileReads / 64u;     // waves of read threads, with a part of the entry area each
-constexpr uint32_t kEntCap = JL_INGEST_ENT_PER_READ * kTileReads, kEntCapWave = kEntCap / kReadWaves;
-constexpr uint32_t kRowBase = 4u + kEntCap;     // (a side dword per entry: an entry begins inside one block at most)
 #ifndef JL_INGEST_ROW_EXTRA
 #define JL_INGEST_ROW_EXTRA 0             // pieces of a row beyond a sweep's own (room for inserted bases: 32 a piece)
 #endif
 constexpr uint32_t kRowPieces = (kSweep + 31u) / 32u + 1u + JL_INGEST_ROW_EXTRA, kRowDw = 4u * kRowPieces, kGroupPadDw = 8u;
-__device__ __forceinline__ uint32_t row_dw(uint32_t j) { return kRowBase + kRowDw * j + kGroupPadDw * (j >> 5); }
-constexpr uint32_t kStageDw = kRowBase + kRowDw * kTileReads + kGroupPadDw * kTileGroups + 4u;
+// The kernel comes in two sizes of its entry area (entries of the reads that need them, 4 bytes each in LDS: column - sweep's first
+// (0..256: 9 bits) | kind << 9 | (query offset there - the row's first) << 11): four entries a read on average — a CCS read has 4
+// in a sweep with an indel — with five workgroups to a CU, and sixteen, with three: for the (tile, sweep) units whose reads have
+// more (an indel every 50 columns), which the first size hands on (ingest_args::big_list) instead of leaving read after read
+// to the column-by-column kernel (7 ms for 100k reads with 1 % of indels).
+template <uint32_t EPR>
+struct planes_shape {
+    static constexpr uint32_t kEntCap = EPR * kTileReads, kEntCapWave = kEntCap / kReadWaves;
+    static constexpr uint32_t kRowBase = 4u + kEntCap;     // (a side dword per entry: an entry begins inside one block at most)
+    static constexpr uint32_t kStageDw = kRowBase + kRowDw * kTileReads + kGroupPadDw * kTileGroups + 4u;
+    static __device__ __forceinline__ uint32_t row_dw(uint32_t j) { return kRowBase + kRowDw * j + kGroupPadDw * (j >> 5); }
+    static_assert(kRowBase % 4u == 0 && kStageDw * 8u <= 65536u, "16-byte pieces; 16-bit nibble addresses");
+};
 // the table: 32 entries (16 bits) a read — rows on 8-byte boundaries for the four-entries-at-a-time stores —
 // and 8 dwords of padding per 32 reads: the four 32-read groups of a wave's lanes read it 8 banks apart
 constexpr uint32_t kTabRow = kBlocks > 16u ? 32u : 16u, kTabGroupPad = 16u;
@@ -479,7 +510,6 @@ __device__ __forceinline__ uint32_t tab_row(uint32_t j) { return j * kTabRow + (
 // 13 of the kernel's 21 x 10^6 LDS cycles were bank conflicts)
 __device__ __forceinline__ uint32_t tab_at(uint32_t j, uint32_t blk) { return tab_row(j) + ((((blk >> 2) ^ j) & (kTabRow / 4u - 1u)) << 2) + (blk & 3u); }
 static_assert((kTabRow / 4u & (kTabRow / 4u - 1u)) == 0, "chunks of a row: a power of two");
-static_assert(kRowBase % 4u == 0 && kStageDw * 8u <= 65536u, "16-byte pieces; 16-bit nibble addresses");
 static_assert(kTileReads % 64u == 0 && kThreads == 2u * kTileReads && kBlocks <= 32u, "whole waves of read threads; a block index fits five bits");
 // the pieces of a tile: the upper half of the threads take kPieceRoundsB rounds of kTileReads pieces, the read threads — who have
 // their rows of the table to make as well — the rest
@@ -565,9 +595,11 @@ __device__ __forceinline__ uint32_t ent_addr(uint32_t e, uint32_t row8, uint32_t
 // (Device stamps of the form before this one — the read waves made the table while the others waited, then everybody staged:
 // descriptor 0.75 us, prologue 0.9, table 4.7 of which 1.5 a third trip for the reads with more than four entries, staging 1.8,
 // general 1.1, transposing 2.6; waves 2, 3 waited 5.2 us of 14.6 at the first barrier.)
-template <bool QV>
-__global__ __launch_bounds__(kThreads) void ingest_planes_kernel(ingest_args a)
+template <bool QV, uint32_t EPR, bool BIG>
+__device__ __forceinline__ void planes_unit(const ingest_args &a, const uint32_t b)
 {
+    using shape = planes_shape<EPR>;
+    constexpr uint32_t kEntCap = shape::kEntCap, kEntCapWave = shape::kEntCapWave, kRowBase = shape::kRowBase, kStageDw = shape::kStageDw;
 #ifndef JL_INGEST_LDS_PAD
 #define JL_INGEST_LDS_PAD 0               // (tuning: bytes of LDS a workgroup holds on top of what it uses — fewer workgroups per CU)
 #endif
@@ -575,14 +607,14 @@ __global__ __launch_bounds__(kThreads) void ingest_planes_kernel(ingest_args a)
     __shared__ __attribute__((aligned(16))) uint16_t s_tab[kTabSize];
     __shared__ uint32_t s_ent[kEntCap];           // the entries of the reads with several in the sweep, a half per read wave
     __shared__ uint16_t s_own[kEntCap];           // whose: the read | 0x8000 for its last one
-    __shared__ uint32_t s_nent[kReadWaves];       // entries in each part
+    __shared__ uint32_t s_nent[2u * kReadWaves];  // entries in each part; [kReadWaves + w]: wave w hands the unit on
     const uint32_t tid = threadIdx.x, wid = tid >> 6, lane = tid & 63u;
     // block -> (read tile, sweep).  Blocks b, b + 8, b + 16, ... are dealt to the same XCD one after the other; an XCD takes
     // whole groups of 1024 reads (group = xcd, xcd + 8, ...), and of a group all sweeps in turn, the tiles of the group
     // innermost.  So (a) the tiles that share the 128-byte lines of a sweep's planes meet in one L2, and (b) what the
     // sweeps of a group read again — the reads' entries, the 128-byte lines of packed bases that straddle two sweeps — is
     // in that L2 when the next sweep asks for it.
-    const uint32_t b = blockIdx.x, xcd = b & 7u, jb = b >> 3, sub = jb % kSubTiles, qq = jb / kSubTiles;
+    const uint32_t xcd = b & 7u, jb = b >> 3, sub = jb % kSubTiles, qq = jb / kSubTiles;
     const uint32_t group = xcd + 8u * (qq / a.n_sweeps), sweep = qq % a.n_sweeps;
     if (group >= a.n_groups) return;
     const uint32_t tile = kSubTiles * group + sub;
@@ -615,15 +647,15 @@ __global__ __launch_bounds__(kThreads) void ingest_planes_kernel(ingest_args a)
             const uint32_t p = p0 + kTileReads * k, j = p / kRowPieces, i = p - kRowPieces * j;
             uint32_t np = (d[k].w >> 16) & 0xFFu;
             if (np > kRowPieces || (d[k].w >> 24) == kDescMax) np = 0;      // (the slow kernel's)
-            uint64_t at = ((((uint64_t)d[k].w & 0xFFu) << 32) | d[k].x) + (i < np ? i : 0u);
-            JL_ING_CHECK(a, 16u * at + 16u <= a.seq_bytes + 64u, 1, at, at = 0)
+            uint64_t at = ((((uint64_t)d[k].w & 0xFFu) << 32) | d[k].x) + (i < np ? 4u * i : 0u);     // (in dwords)
+            JL_ING_CHECK(a, 4u * at + 16u <= a.seq_bytes + 64u, 1, at, at = 0)
             // (plain loads: neighbouring lanes' pieces share lines, and so do the sweeps of a read)
 #ifdef JL_TUNING
-            if (JL_ING_SKIP(a, 9)) pc[k].v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(a.seq4 + 16u * at));   // (probe)
+            if (JL_ING_SKIP(a, 9)) pc[k].v = __builtin_nontemporal_load(reinterpret_cast<const u32x4a4 *>(a.seq4 + 4u * at));   // (probe)
             else
 #endif
-            pc[k].v = *reinterpret_cast<const u32x4 *>(a.seq4 + 16u * at);
-            pc[k].dst = i < np ? row_dw(j) + 4u * i : 0u;
+            pc[k].v = *reinterpret_cast<const u32x4a4 *>(a.seq4 + 4u * at);
+            pc[k].dst = i < np ? shape::row_dw(j) + 4u * i : 0u;
             pc[k].Q = (int32_t)d[k].z + 32 * (int32_t)i;
             pc[k].qb = qo[k];
         }
@@ -641,6 +673,7 @@ __global__ __launch_bounds__(kThreads) void ingest_planes_kernel(ingest_args a)
         }
     };
 
+    bool slow_read = false;
     if (tid >= kTileReads) {
         // ---- waves 2, 3: pieces
         uint4 d[kPieceRoundsB];
@@ -667,7 +700,7 @@ __global__ __launch_bounds__(kThreads) void ingest_planes_kernel(ingest_args a)
         if (a.stamps) { asm volatile("" ::"v"(d.w)); JL_ING_STAMP(a, 1) }   // (the descriptor has arrived)
 #endif
         if (tid < 4u) s_stage[tid] = tid < 2u ? 0x66666666u : 0x44444444u;
-        if (lane == 0) s_nent[wid] = 0;
+        if (lane == 0) s_nent[wid] = 0, s_nent[kReadWaves + wid] = 0;
         const uint32_t np = (d.w >> 16) & 0xFFu;
         uint32_t n_ent = d.w >> 24;
         bool slow = np > kRowPieces || n_ent == kDescMax;
@@ -677,14 +710,15 @@ __global__ __launch_bounds__(kThreads) void ingest_planes_kernel(ingest_args a)
         const uint32_t inc = wave_scan(n_ent);
         uint32_t off_e = inc - n_ent;
         if (n_ent && off_e + n_ent > kEntCapWave) {
-            slow = true;
+            // more entries than the wave's part holds: the first size hands the whole unit on to the second (nothing of it is
+            // written here, and no read of it goes to the slow list: the second size lists its own); the second leaves the
+            // reads past the part's end to the slow kernel
+            if (!BIG) s_nent[kReadWaves + wid] = 1u;
+            else slow = true;
             n_ent = 0;
         }
         JL_ING_CHECK(a, !slow || r < a.n_reads, 3, r, slow = false)
-        if (slow) {
-            const uint32_t at = atomicAdd(a.slow_count, 1u);
-            a.slow_list[at] = make_uint2((uint32_t)r, sweep);
-        }
+        slow_read = slow;
         off_e += wid * kEntCapWave;
         // the sweep's entries of this read: the first eight in four 16-byte requests that go out together (entries past the
         // read's own belong to the next read or to the array's slack) — two deletions in a sweep are six entries, and a
@@ -703,7 +737,7 @@ __global__ __launch_bounds__(kThreads) void ingest_planes_kernel(ingest_args a)
         }
         ask_pieces(p0, kPieceRoundsA, dp, qo, pc);
         const int32_t q0 = (int32_t)d.z;
-        const uint32_t row8 = 8u * row_dw(tid);
+        const uint32_t row8 = 8u * shape::row_dw(tid);
         if (!n_ent) {
             // one entry covers the sweep: its blocks' addresses rise by eight codes a block (aligned bases) or stay (the
             // dword of '-', of 'not covered'), four blocks a store
@@ -751,6 +785,19 @@ __global__ __launch_bounds__(kThreads) void ingest_planes_kernel(ingest_args a)
     }
     __syncthreads();
     JL_ING_STAMP(a, 7)
+    if (!BIG) {
+        uint32_t handed = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < kReadWaves; ++w) handed |= s_nent[kReadWaves + w];
+        if (handed) {
+            if (tid == 0) a.big_list[atomicAdd(a.slow_count + 1, 1u)] = b;
+            return;
+        }
+    }
+    if (slow_read) {
+        const uint32_t at = atomicAdd(a.slow_count, 1u);
+        a.slow_list[at] = make_uint2((uint32_t)(r0 + tid), sweep);
+    }
 
     // ---- the table rows of the reads with several entries, everybody: a thread an entry.  Entry i
     // of a read covers the columns [its column, the next entry's column) and the read's last one only ends the one before
@@ -776,7 +823,7 @@ __global__ __launch_bounds__(kThreads) void ingest_planes_kernel(ingest_args a)
             const uint32_t own = s_own[slot], e = s_ent[slot], nx = s_ent[slot + 1u];
             const uint32_t wr = ent_col(e);
             if ((own & 0x8000u) || wr >= width) continue;
-            const uint32_t row8 = 8u * row_dw(own);
+            const uint32_t row8 = 8u * shape::row_dw(own);
             // (a) the entry's whole blocks [bf, be): singly up to a multiple of four, four a store, singly again
             const uint32_t wn = ent_col(nx);
             const uint32_t be = wn >= width ? kBlocks : wn >> 3;
@@ -894,6 +941,22 @@ __global__ __launch_bounds__(kThreads) void ingest_planes_kernel(ingest_args a)
     JL_ING_STAMP(a, 10)
 }
 
+// The first size: a workgroup a unit (blockIdx -> unit: planes_unit).  The second: the units the first handed on, in the
+// order they came, taken in turns by a grid that fills the chip once (an empty list costs a launch of 768 workgroups).
+constexpr uint32_t kBigGrid = 768u;
+template <bool QV, uint32_t EPR, bool BIG>
+__global__ __launch_bounds__(kThreads) void ingest_planes_kernel(ingest_args a)
+{
+    if (!BIG) planes_unit<QV, EPR, false>(a, blockIdx.x);
+    else {
+        const uint32_t n = a.slow_count[1];
+        for (uint32_t u = blockIdx.x; u < n; u += gridDim.x) {
+            planes_unit<QV, EPR, true>(a, a.big_list[u]);
+            __syncthreads();      // (the next unit's LDS)
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------- what the tiles left out
 // One wave per (read, sweep) pair: a lane per column looks its entry up in HBM and flips the bits in which the symbol differs
 // from 'not covered' (which is what the tile's workgroup stored for the read).
@@ -908,7 +971,7 @@ __global__ __launch_bounds__(256) void ingest_slow_kernel(ingest_args a, const u
         const uint32_t sweep = pr.y;
 #ifdef JL_TUNING
         if (r >= a.n_reads || sweep >= a.n_sweeps) {
-            if (lane == 0) { atomicAdd(&a.dbg[4], 1u); a.dbg[10] = pr.x; }
+            if (lane == 0) { atomicAdd(&a.dbg[4], 1u); a.dbg[9] = pr.x; }
             continue;
         }
 #endif
@@ -952,10 +1015,23 @@ __global__ __launch_bounds__(256) void ingest_slow_kernel(ingest_args a, const u
 
 uint32_t jl_ingest_sweeps(uint32_t n_cols) { return (n_cols + kSweep - 1u) / kSweep; }
 
-// d_runs: n_cig + 3 n_reads + 8 entries; d_nruns: n_reads; d_desc: n_reads x sweeps descriptors; d_slow: n_reads x sweeps pairs
-// behind one counter word (zeroed here); d_slow_count[2..3] = the 64-bit word of the first malformed record (all ones: none;
-// `keep_verdict`: an earlier build's word has not been read yet — this build's is folded into it, atomicMin).
-// Everything is enqueued on ctx->stream; nothing waits.
+// the planes kernel's workgroups: (groups of 1024 reads per XCD, rounded up) x sweeps x 8 XCDs x tiles of a group
+static uint32_t planes_units(const jl_ctx *ctx)
+{
+    const uint32_t groups = (uint32_t)(ctx->plane_stride * 8u / 1024u);    // (a multiple of 1024 reads: whole line groups of tiles)
+    return (groups + 7u) / 8u * jl_ingest_sweeps(ctx->n_cols) * 8u * kSubTiles;
+}
+
+// pairs of d_slow: every (read, sweep) once at most, and behind them the units handed on (a word each)
+size_t jl_ingest_slow_room(const jl_ctx *ctx)
+{
+    return (size_t)ctx->n_reads * jl_ingest_sweeps(ctx->n_cols) + planes_units(ctx) / 2u + 8u;
+}
+
+// d_runs: n_cig + 3 n_reads + 8 entries; d_nruns: n_reads; d_desc: n_reads x sweeps descriptors; d_slow: jl_ingest_slow_room() pairs.
+// d_slow_count, 64 bytes: [0] pairs listed, [1] units handed on — zeroed here; [2..3] the 64-bit word of the first malformed
+// record (all ones: none; `keep_verdict`: an earlier build's word has not been read yet — this build's is folded into it,
+// atomicMin); [4..15] the tuning build's checks.  Everything is enqueued on ctx->stream; nothing waits.
 void jl_launch_ingest(jl_ctx *ctx, const int32_t *d_pos, const uint32_t *d_cigar, const uint64_t *d_cig_off,
                       const uint8_t *d_seq4, const uint64_t *d_seq_off, const uint8_t *d_qual,
                       const uint64_t *d_qual_off, uint32_t min_qv, uint2 *d_runs, uint32_t *d_nruns, uint4 *d_desc,
@@ -963,12 +1039,18 @@ void jl_launch_ingest(jl_ctx *ctx, const int32_t *d_pos, const uint32_t *d_cigar
 {
     hipStream_t st = ctx->stream;
     const uint32_t ns = jl_ingest_sweeps(ctx->n_cols);
-    hipMemsetAsync(d_slow_count, 0, 4, st);
+    hipMemsetAsync(d_slow_count, 0, 8, st);
     if (!keep_verdict) hipMemsetAsync(d_slow_count + 2, 0xFF, 8, st);
     if (ctx->n_reads)
-        hipLaunchKernelGGL(cigar_runs_kernel, dim3((uint32_t)((ctx->n_reads + 4u * kRunsReadsPerWave * kRunsBatches - 1u) / (4u * kRunsReadsPerWave * kRunsBatches))), dim3(256), 0, st, ctx->n_reads, d_pos,
-                           d_cigar, d_cig_off, d_seq_off, d_qual ? d_qual_off : nullptr, ctx->win_begin, ctx->n_cols, ns, d_runs, d_nruns, d_desc,
-                           reinterpret_cast<unsigned long long *>(d_slow_count + 2));
+    if (ctx->n_reads) {
+        const uint32_t per_wg = 4u * kRunsReadsPerWave;
+        unsigned long long *bad = reinterpret_cast<unsigned long long *>(d_slow_count + 2);
+        const uint64_t *qo = d_qual ? d_qual_off : nullptr;
+        hipLaunchKernelGGL((cigar_runs_kernel<kRunsLdsSmall, false>), dim3((uint32_t)((ctx->n_reads + per_wg - 1u) / per_wg)), dim3(256), 0, st,
+                           ctx->n_reads, d_pos, d_cigar, d_cig_off, d_seq_off, qo, ctx->win_begin, ctx->n_cols, ns, d_runs, d_nruns, d_desc, bad);
+        hipLaunchKernelGGL((cigar_runs_kernel<kRunsLdsLarge, true>), dim3((uint32_t)std::min<uint64_t>(kRunsLongGrid, (ctx->n_reads + 255u) / 256u)), dim3(256), 0, st,
+                           ctx->n_reads, d_pos, d_cigar, d_cig_off, d_seq_off, qo, ctx->win_begin, ctx->n_cols, ns, d_runs, d_nruns, d_desc, bad);
+    }
     ingest_args a;
     a.n_reads = ctx->n_reads;
     a.n_cols = ctx->n_cols;
@@ -987,6 +1069,7 @@ void jl_launch_ingest(jl_ctx *ctx, const int32_t *d_pos, const uint32_t *d_cigar
     a.desc = d_desc;
     a.slow_count = d_slow_count;
     a.slow_list = d_slow;
+    a.big_list = reinterpret_cast<uint32_t *>(d_slow + (uint64_t)ctx->n_reads * ns);
     a.msa = ctx->d_msa;
     a.plane_stride = ctx->plane_stride;
     a.seq_bytes = seq_bytes;
@@ -1002,9 +1085,15 @@ void jl_launch_ingest(jl_ctx *ctx, const int32_t *d_pos, const uint32_t *d_cigar
     hipMemsetAsync(d_slow_count + 4, 0, 48, st);
     if (const char *e = getenv("JL_ING_SKIP")) a.skip = (uint32_t)atoi(e);
 #endif
-    const uint32_t grid = (a.n_groups + 7u) / 8u * ns * 8u * kSubTiles;   // (groups per XCD, rounded up) x sweeps x 8 XCDs x tiles of a group
-    if (qv) hipLaunchKernelGGL(ingest_planes_kernel<true>, dim3(grid), dim3(kThreads), 0, st, a);
-    else hipLaunchKernelGGL(ingest_planes_kernel<false>, dim3(grid), dim3(kThreads), 0, st, a);
+    const uint32_t grid = planes_units(ctx);
+    constexpr uint32_t E = JL_INGEST_ENT_PER_READ, EB = JL_INGEST_ENT_PER_READ_BIG;
+    if (qv) {
+        hipLaunchKernelGGL((ingest_planes_kernel<true, E, false>), dim3(grid), dim3(kThreads), 0, st, a);
+        hipLaunchKernelGGL((ingest_planes_kernel<true, EB, true>), dim3(kBigGrid), dim3(kThreads), 0, st, a);
+    } else {
+        hipLaunchKernelGGL((ingest_planes_kernel<false, E, false>), dim3(grid), dim3(kThreads), 0, st, a);
+        hipLaunchKernelGGL((ingest_planes_kernel<false, EB, true>), dim3(kBigGrid), dim3(kThreads), 0, st, a);
+    }
     const uint64_t cap = (uint64_t)ctx->n_reads * ns;   // (a pair is listed once: by the prologue, or when its boundary blocks overflow)
     hipLaunchKernelGGL(ingest_slow_kernel, dim3(256), dim3(256), 0, st, a, (uint32_t)std::min<uint64_t>(cap, 0xFFFFFFFFu));
 }

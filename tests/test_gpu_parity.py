@@ -1021,6 +1021,29 @@ def test_device_ingest_qv_and_ragged_window_at_size(jl, n, l, win, min_qv):
         jl.records_drop()
 
 
+@pytest.mark.parametrize("n,l,ins_ppm,del_rate,min_qv", [(8_000, 3000, 5000, 0.005, 0), (8_000, 3000, 10000, 0.01, 20), (6_000, 3000, 20000, 0.02, 0),
+                                                         (1_200, 24000, 10000, 0.01, 0)])
+def test_device_ingest_indel_rich_reads(jl, n, l, ins_ppm, del_rate, min_qv):
+    """Reads with an indel every 100, 50, 25 columns: (tile, sweep) units with more entries than the planes kernel's first size
+    holds (handed on to its second), reads with more entries than cigar_runs' first launch keeps in LDS (left to its second; at
+    24 000 columns more than the second keeps, too), sweeps with more inserted bases than a staging row has room for and units
+    that overflow even the second size (the column-by-column kernel) — every cell against the records' expansion."""
+    rec = synth.raw_records(11, n, l, extra=("--ins-ppm", str(ins_ppm), "--del", str(del_rate), "--low-qv-ppm", "20000"))
+    assert len(rec["cigar"]) / n > 64
+    if min_qv:
+        jl.records_upload(rec["pos"], rec["cigar"], rec["cig_off"], rec["seq4"], rec["seq_off"], rec["qual"], rec["qual_off"])
+    else:
+        jl.records_upload(rec["pos"], rec["cigar"], rec["cig_off"], rec["seq4"], rec["seq_off"])
+    w = capi.Juliet(0)
+    try:
+        for b, e in ((0, l), (131, l - 77)):
+            w.records_window(jl, e - b, b, min_qv)
+            assert _cells_equal(w, rec, n, e - b, b, min_qv) is None, (b, e)
+    finally:
+        w.close()
+        jl.records_drop()
+
+
 def test_device_ingest_random_shapes(jl):
     """A seeded slice of tools_tuning/ingest_stress.py: read counts, widths, indel and mask rates and windows drawn at random,
     with and without qualities."""
