@@ -20,6 +20,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <type_traits>
 
 #include "call_eval.h"
 #include "jl_internal.h"
@@ -651,10 +652,14 @@ static_assert(offsetof(sel_lds, hmask) % 8 == 0, "a variant's haplotype set is r
 
 // KW = 2: the main table's key of a group is the pair (slot of its first word in table A, slot of its second word in
 // table B); the words themselves are one more round trip away (jl_two_word).
-template <int KW>
+// `ranked(bits)`: called by every thread once the slot -> haplotype table is complete and performed (the ids depend on nothing
+// else): the caller releases the workgroups that wait for it and writes its own reads' ids THERE, so that the rest of the
+// selection — hit matrix, co-occurrence, result block: 3.5 us at five positions, 11 at sixteen — runs beside the other
+// workgroups' ids instead of in front of them.
+template <int KW, typename Ranked>
 __device__ __forceinline__ bool phase_select_lds(const jl_win_phase &w, const plan_state &L, uint32_t vp, uint32_t nv,
                                                  uint32_t n_rows, sel_lds &T, const jl_two_word *tw, uint32_t n_occ, uint32_t occ0,
-                                                 const uint32_t *cat, uint32_t *id_bits_out)
+                                                 const uint32_t *cat, uint32_t *id_bits_out, Ranked &&ranked)
 {
     // n_occ, occ0: the group count and this thread's first entry of the group list, loaded by the caller beside the read
     // categories (occ0 is only meaningful below n_occ); cat: the read categories of the whole window (LDS)
@@ -835,8 +840,10 @@ __device__ __forceinline__ bool phase_select_lds(const jl_win_phase &w, const pl
         const uint32_t rs = wave_sum_all(ca);
         if ((tid & 63u) == 0 && rs) atomicAdd(&T.reported, rs);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the table's stores, the scan's among them, are performed)
     __syncthreads();
     JL_STAMP(25);
+    ranked(id_bits_for(H));
     // hit[v][h] and, per variant, the set of haplotypes that carry it as bits: a lane per haplotype (its pattern words in
     // registers), a wave per variant (no division per element; the set makes the co-occurrence sums a walk over a few
     // common bits instead of H terms).  Beside it the patterns as bytes, [h][p], in the scratch the ranking is done with.
@@ -1092,16 +1099,20 @@ __device__ __forceinline__ void phase_fused1_body(const jl_win_phase &w, const j
     unsigned long long *slot_key = w.slot_key;
     uint32_t *slot_rep = w.slot_rep, *slot_count = w.slot_count, *occupied = w.occupied, *read_slot = w.read_slot;
     const select_args &S = w.S;
-    // one LDS block: the grouping tables (8 + 3 x 4 KB), lent to the selection once the grouping is done
-    __shared__ unsigned long long s_tables[kLdsSlots * 5u / 2u];
-    unsigned long long *s_key = s_tables;                                          // [kLdsSlots]
-    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_tables + kLdsSlots);          // [kLdsSlots]
-    uint32_t *s_first = s_cnt + kLdsSlots, *s_gslot = s_first + kLdsSlots;         // [kLdsSlots] each
+    // one LDS block per table set: the grouping tables (8 + 3 x 4 KB), lent to the selection once the grouping is done.  The
+    // two-word launch has two sets: its first two rounds — the two words of the patterns, independent of each other — run
+    // together, one set each.
+    constexpr uint32_t NS = KW == 2 ? 2u : 1u;
+    __shared__ unsigned long long s_tables[NS][kLdsSlots * 5u / 2u];
+    auto s_key = [&](uint32_t z) -> unsigned long long * { return s_tables[z]; };                                          // [kLdsSlots]
+    auto s_cnt = [&](uint32_t z) -> uint32_t * { return reinterpret_cast<uint32_t *>(s_tables[z] + kLdsSlots); };          // [kLdsSlots]
+    auto s_first = [&](uint32_t z) -> uint32_t * { return s_cnt(z) + kLdsSlots; };                                         // [kLdsSlots]
+    auto s_gslot = [&](uint32_t z) -> uint32_t * { return s_cnt(z) + 2u * kLdsSlots; };                                    // [kLdsSlots]
     __shared__ plan_state s_plan;
-    __shared__ unsigned long long s_dom;
-    __shared__ uint32_t s_domcnt, s_domfirst, s_domslot;
-    __shared__ uint32_t s_last, s_cat[4], s_idbits, s_scan[4], s_running, s_nlist;
-    __shared__ uint16_t s_list[kLdsSlots];
+    __shared__ unsigned long long s_dom[NS];
+    __shared__ uint32_t s_domcnt[NS], s_domfirst, s_domslot[NS], s_nlist[NS];
+    __shared__ uint32_t s_last, s_cat[4], s_idbits, s_scan[4], s_running;
+    __shared__ uint16_t s_list[NS][kLdsSlots];
     const uint32_t tid = threadIdx.x;
     const bool from_called = S.called != nullptr;
     // whole-path runs launch one workgroup more than the reads need: it compacts the called rows meanwhile
@@ -1162,8 +1173,14 @@ __device__ __forceinline__ void phase_fused1_body(const jl_win_phase &w, const j
 #pragma unroll
     for (int r = 0; r < 8; ++r) gslot[r] = 0;
     if (work && !plan_block) {
-    for (uint32_t i = tid; i < kLdsSlots; i += 256u) { s_key[i] = kNoKey; s_cnt[i] = 0; s_first[i] = 0xFFFFFFFFu; }
-    if (tid == 0) { s_dom = kNoKey; s_domcnt = 0; s_domfirst = 0xFFFFFFFFu; s_domslot = 0; s_nlist = 0; }
+    auto clear_sets = [&](uint32_t n_sets) {
+        for (uint32_t z = 0; z < n_sets; ++z) {
+            for (uint32_t i = tid; i < kLdsSlots; i += 256u) { s_key(z)[i] = kNoKey; s_cnt(z)[i] = 0; s_first(z)[i] = 0xFFFFFFFFu; }
+            if (tid == 0) { s_dom[z] = kNoKey; s_domcnt[z] = 0; s_domslot[z] = 0; s_nlist[z] = 0; }
+        }
+        if (tid == 0) s_domfirst = 0xFFFFFFFFu;
+    };
+    clear_sets(NS);
     if (tid < 4) s_cat[tid] = 0;
     __syncthreads();
 
@@ -1256,13 +1273,16 @@ __device__ __forceinline__ void phase_fused1_body(const jl_win_phase &w, const j
             if (n_par) atomicAdd(&s_cat[3], n_par);
         }
     }
-    // One ROUND of grouping: the clean reads' 64-bit keys `kk` -> the slot of each in the global table T (gs[r]).
-    // The one-word launch runs it once, on the patterns themselves; the two-word launch three times (jl_two_word).
-    auto group_round = [&](const uint64_t (&kk)[8], unsigned long long *T_key, uint32_t *T_rep, uint32_t *T_cnt, uint32_t *T_occ,
-                           uint32_t *T_nocc, uint32_t (&gs)[8], bool first_round) {
+    // One ROUND of grouping: the clean reads' 64-bit keys kk[z] -> the slot of each in the global table T[z] (gs[z][r]), for N
+    // independent key words at once (they share the round's barriers and their trips to the global tables overlap: a round is
+    // 6.5 us whatever it carries).  The one-word launch runs one round of one, on the patterns themselves; the two-word
+    // launch a round of two — the words of the patterns — and a round of one on the pairs of their slots (jl_two_word).
+    struct table_t { unsigned long long *key; uint32_t *rep, *cnt, *occ, *nocc; };
+    auto group_round = [&](auto n_const, const uint64_t (&kk)[decltype(n_const)::value][8], const table_t (&T)[decltype(n_const)::value],
+                           uint32_t (&gs)[decltype(n_const)::value][8], bool first_round) {
+        constexpr uint32_t N = decltype(n_const)::value;
         if (!first_round) {   // (the first round's tables were cleared while the columns were on their way)
-            for (uint32_t i = tid; i < kLdsSlots; i += 256u) { s_key[i] = kNoKey; s_cnt[i] = 0; s_first[i] = 0xFFFFFFFFu; }
-            if (tid == 0) { s_dom = kNoKey; s_domcnt = 0; s_domfirst = 0xFFFFFFFFu; s_domslot = 0; s_nlist = 0; }
+            clear_sets(N);
             __syncthreads();
         }
         // ---- 2. dominant key of the block = key of its first clean read
@@ -1279,38 +1299,49 @@ __device__ __forceinline__ void phase_fused1_body(const jl_win_phase &w, const j
         if (domfirst != 0xFFFFFFFFu && (uint64_t)(domfirst >> 3) == t) {
 #pragma unroll
             for (int r = 0; r < 8; ++r)  // static indices keep the keys in registers
-                if ((domfirst & 7u) == (uint32_t)r) s_dom = kk[r];
+                if ((domfirst & 7u) == (uint32_t)r) {
+#pragma unroll
+                    for (uint32_t z = 0; z < N; ++z) s_dom[z] = kk[z][r];
+                }
         }
         __syncthreads();
-        const unsigned long long dom = s_dom;
-        uint32_t isdom = 0;  // bit 4r
+        unsigned long long dom[N];
+        uint32_t isdom[N];  // bit 4r
 #pragma unroll
-        for (int r = 0; r < 8; ++r)
-            if (((cleanm >> (4 * r)) & 1u) && kk[r] == dom) isdom |= 1u << (4 * r);
-        {
-            const uint32_t c = wave_sum_all(__popc(isdom));
-            if ((tid & 63u) == 0 && c) atomicAdd(&s_domcnt, c);
+        for (uint32_t z = 0; z < N; ++z) {
+            dom[z] = s_dom[z];
+            isdom[z] = 0;
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+                if (((cleanm >> (4 * r)) & 1u) && kk[z][r] == dom[z]) isdom[z] |= 1u << (4 * r);
+            const uint32_t c = wave_sum_all(__popc(isdom[z]));
+            if ((tid & 63u) == 0 && c) atomicAdd(&s_domcnt[z], c);
         }
         JL_STAMP(3);
         // ---- 3. everything else through the LDS table
-        uint32_t rest = cleanm & ~isdom;
-        uint32_t myslot[8];
+        uint32_t myslot[N][8];
 #pragma unroll
-        for (int r = 0; r < 8; ++r) myslot[r] = 0xFFFFFFFFu;
+        for (uint32_t z = 0; z < N; ++z) {
+            const uint32_t rest = cleanm & ~isdom[z];
+            unsigned long long *tk = s_key(z);
+            uint32_t *tc = s_cnt(z), *tf = s_first(z);
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            if ((rest >> (4 * r)) & 1u) {
-                const unsigned long long k = kk[r];
-                uint32_t s = (uint32_t)mix64(k) & (kLdsSlots - 1u);
-                for (uint32_t probe = 0; probe < kLdsSlots; ++probe) {
-                    const unsigned long long old = atomicCAS(&s_key[s], (unsigned long long)kNoKey, k);
-                    if (old == kNoKey || old == k) {
-                        atomicAdd(&s_cnt[s], 1u);
-                        atomicMin(&s_first[s], (uint32_t)(t * 8u + r));
-                        myslot[r] = s;
-                        break;
+            for (int r = 0; r < 8; ++r) myslot[z][r] = 0xFFFFFFFFu;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                if ((rest >> (4 * r)) & 1u) {
+                    const unsigned long long k = kk[z][r];
+                    uint32_t sl = (uint32_t)mix64(k) & (kLdsSlots - 1u);
+                    for (uint32_t probe = 0; probe < kLdsSlots; ++probe) {
+                        const unsigned long long old = atomicCAS(&tk[sl], (unsigned long long)kNoKey, k);
+                        if (old == kNoKey || old == k) {
+                            atomicAdd(&tc[sl], 1u);
+                            atomicMin(&tf[sl], (uint32_t)(t * 8u + r));
+                            myslot[z][r] = sl;
+                            break;
+                        }
+                        sl = (sl + 1u) & (kLdsSlots - 1u);
                     }
-                    s = (s + 1u) & (kLdsSlots - 1u);
                 }
             }
         }
@@ -1319,45 +1350,62 @@ __device__ __forceinline__ void phase_fused1_body(const jl_win_phase &w, const j
         // One global insert per distinct key of the block, ALL AT ONCE: the keys are listed densely first, so thread i takes
         // the i-th (a sweep over the 1024 table slots, four per thread, made the thread that owned two occupied slots — and
         // thread 0, which also had the dominant key — do its inserts one after the other: 8.7 us of a 25 us launch at a
-        // million reads, two to three dependent round trips each).  The dominant key goes with the last thread, which has
-        // a list entry of its own only in blocks with 256 or more distinct keys.
+        // million reads, two to three dependent round trips each).  The lists of a round of two lie one behind the other.
+        // The dominant keys go with the last threads, which have list entries of their own only in blocks with some 250
+        // distinct keys or more.
         {
-            // (the list is made by a sweep over the table: four LDS reads per thread and a barrier)
-            for (uint32_t s = tid; s < kLdsSlots; s += 256u)
-                if (s_cnt[s]) s_list[atomicAdd(&s_nlist, 1u)] = (uint16_t)s;
+            // (the lists are made by a sweep over the tables: four LDS reads per thread and set, and a barrier)
+#pragma unroll
+            for (uint32_t z = 0; z < N; ++z)
+                for (uint32_t sl = tid; sl < kLdsSlots; sl += 256u)
+                    if (s_cnt(z)[sl]) s_list[z][atomicAdd(&s_nlist[z], 1u)] = (uint16_t)sl;
             __syncthreads();
-            const uint32_t n_list = s_nlist;
-            for (uint32_t i = tid; i < n_list; i += 256u) {
-                const uint32_t s = s_list[i];
-                s_gslot[s] = global_insert64(s_key[s], s_cnt[s], s_first[s], slots_mask, T_key, T_rep, T_cnt, T_occ, T_nocc);
+            const uint32_t n0 = s_nlist[0], n_all = n0 + (N == 2u ? s_nlist[N - 1u] : 0u);
+            for (uint32_t i = tid; i < n_all; i += 256u) {
+                const uint32_t z = (N == 2u && i >= n0) ? 1u : 0u;
+                const uint32_t sl = s_list[z][i - (z ? n0 : 0u)];
+                s_gslot(z)[sl] = global_insert64(s_key(z)[sl], s_cnt(z)[sl], s_first(z)[sl], slots_mask, T[z].key, T[z].rep, T[z].cnt, T[z].occ, T[z].nocc);
             }
-            if (tid == 255u && s_domcnt)
-                s_domslot = global_insert64(dom, s_domcnt, s_domfirst, slots_mask, T_key, T_rep, T_cnt, T_occ, T_nocc);
+#pragma unroll
+            for (uint32_t z = 0; z < N; ++z)
+                if (tid == 255u - z && s_domcnt[z])
+                    s_domslot[z] = global_insert64(dom[z], s_domcnt[z], s_domfirst, slots_mask, T[z].key, T[z].rep, T[z].cnt, T[z].occ, T[z].nocc);
         }
         __syncthreads();
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            if ((cleanm >> (4 * r)) & 1u) {
-                uint32_t g;
-                if ((isdom >> (4 * r)) & 1u) g = s_domslot;
-                else if (myslot[r] != 0xFFFFFFFFu) g = s_gslot[myslot[r]];
-                else  // LDS table full (> 1024 distinct keys in 2048 reads): straight to the global table
-                    g = global_insert64(kk[r], 1u, (uint32_t)(t * 8u + r), slots_mask, T_key, T_rep, T_cnt, T_occ, T_nocc);
-                gs[r] = g;
+        for (uint32_t z = 0; z < N; ++z)
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                if ((cleanm >> (4 * r)) & 1u) {
+                    uint32_t g;
+                    if ((isdom[z] >> (4 * r)) & 1u) g = s_domslot[z];
+                    else if (myslot[z][r] != 0xFFFFFFFFu) g = s_gslot(z)[myslot[z][r]];
+                    else  // LDS table full (> 1024 distinct keys in 2048 reads): straight to the global table
+                        g = global_insert64(kk[z][r], 1u, (uint32_t)(t * 8u + r), slots_mask, T[z].key, T[z].rep, T[z].cnt, T[z].occ, T[z].nocc);
+                    gs[z][r] = g;
+                }
             }
-        }
         if (KW == 2) __syncthreads();   // the next round clears the LDS tables this one still reads
     };
+    const table_t T_main = {slot_key, slot_rep, slot_count, occupied, &meta->n_occupied};
     if constexpr (KW == 1) {
-        group_round(key, slot_key, slot_rep, slot_count, occupied, &meta->n_occupied, gslot, true);
+        const uint64_t (&k1)[1][8] = reinterpret_cast<const uint64_t (&)[1][8]>(key);
+        uint32_t (&g1)[1][8] = reinterpret_cast<uint32_t (&)[1][8]>(gslot);
+        const table_t T1[1] = {T_main};
+        group_round(std::integral_constant<uint32_t, 1u>{}, k1, T1, g1, true);
     } else {
-        uint32_t g0[8] = {0, 0, 0, 0, 0, 0, 0, 0}, g1[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        group_round(key, tw->key_a, nullptr, nullptr, tw->occ_a, tw->n_occ, g0, true);
-        group_round(key1, tw->key_b, nullptr, nullptr, tw->occ_b, tw->n_occ + 1, g1, false);
-        uint64_t key2[8];
+        uint64_t kk2[2][8];
 #pragma unroll
-        for (int r = 0; r < 8; ++r) key2[r] = ((uint64_t)g0[r] << 32) | g1[r];   // never all ones: slots are 31-bit numbers
-        group_round(key2, slot_key, slot_rep, slot_count, occupied, &meta->n_occupied, gslot, false);
+        for (int r = 0; r < 8; ++r) { kk2[0][r] = key[r]; kk2[1][r] = key1[r]; }
+        uint32_t g01[2][8] = {{0, 0, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0, 0, 0}};
+        const table_t T2[2] = {{tw->key_a, nullptr, nullptr, tw->occ_a, tw->n_occ}, {tw->key_b, nullptr, nullptr, tw->occ_b, tw->n_occ + 1}};
+        group_round(std::integral_constant<uint32_t, 2u>{}, kk2, T2, g01, true);
+        uint64_t kk3[1][8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) kk3[0][r] = ((uint64_t)g01[0][r] << 32) | g01[1][r];   // never all ones: slots are 31-bit numbers
+        uint32_t (&g1)[1][8] = reinterpret_cast<uint32_t (&)[1][8]>(gslot);
+        const table_t T1[1] = {T_main};
+        group_round(std::integral_constant<uint32_t, 1u>{}, kk3, T1, g1, false);
     }
     // read categories of this workgroup's reads: written through to its own four words; the selection adds the workgroups
     // up (four atomics per workgroup on ONE cache line were the longest queue of the launch at a million reads)
@@ -1372,6 +1420,19 @@ __device__ __forceinline__ void phase_fused1_body(const jl_win_phase &w, const j
     clean_keep = cleanm;
     }  // work
     if (!S.run) return;  // the generic pipeline has its own select launch
+    bool ids_written = false;
+    auto write_ids = [&](uint32_t bits) {
+        if (live && bits) {
+            uint16_t h[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                h[r] = JL_HAP_DAMAGED;
+                if ((clean_keep >> (4 * r)) & 1u)
+                    h[r] = (uint16_t)__hip_atomic_load(&S.slot_hap[gslot[r]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            store_ids(S.read_hap, t, h, bits);
+        }
+    };
     // ---- hand-off: the block that arrives last ranks the groups and writes the result block.  Everything the
     // selection reads was written by agent-scope atomics or write-through stores (slot keys and counts, the occupied
     // list, the read-category counters, the compacted rows): no release fence — an L2 write-back per block serialises
@@ -1448,8 +1509,14 @@ __device__ __forceinline__ void phase_fused1_body(const jl_win_phase &w, const j
         bool done = false;
         uint32_t sel_bits = 0;   // width of the ids, when the selection out of LDS ran
         if (work && !S.exp_count)
-            done = phase_select_lds<KW>(w, s_plan, vp, nv, n_rows, *reinterpret_cast<sel_lds *>(s_tables), tw, n_occ_pre, occ_pre, s_cat,
-                                        &sel_bits);
+            done = phase_select_lds<KW>(w, s_plan, vp, nv, n_rows, *reinterpret_cast<sel_lds *>(s_tables[0]), tw, n_occ_pre, occ_pre, s_cat,
+                                        &sel_bits, [&](uint32_t bits) {
+                                            if (!S.fold) return;
+                                            if (tid == 0) __hip_atomic_store(S.flag, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                            JL_STAMP(19);
+                                            write_ids(bits);
+                                            ids_written = true;
+                                        });
         if (KW == 2 && !done) {
             // More candidates / rows than the selection out of LDS holds (or nothing to phase): the general routine reads
             // one-word keys, so the run is handed to the multi-word pipeline — tables emptied, the run flagged as one that
@@ -1479,7 +1546,7 @@ __device__ __forceinline__ void phase_fused1_body(const jl_win_phase &w, const j
             __syncthreads();
             phase_select_block<true>(S.min_reads, reads_pad, keys, meta, slot_rep, slot_count, occupied, S.slot_hap, S.variants,
                                      S.col2pos, S.n_cols, S.hap_count, S.hap_pattern, S.hit, S.n_rows, w.vpcols, S.cooc, S.cooc_cap,
-                                     S.pk, S.mirror, slot_key, S.seq_dev, reinterpret_cast<uint32_t *>(s_tables), S.exp_count,
+                                     S.pk, S.mirror, slot_key, S.seq_dev, reinterpret_cast<uint32_t *>(s_tables[0]), S.exp_count,
                                      S.exp_pattern, S.exp_cap, S.exp_stride, nullptr, nullptr, 0u, S.exp_head);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1503,9 +1570,11 @@ __device__ __forceinline__ void phase_fused1_body(const jl_win_phase &w, const j
         if (tid == 0) {
             const uint32_t bits = done ? sel_bits : ld_coherent(&meta->id_bits);
             s_idbits = bits;
-            __hip_atomic_store(S.flag, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (!ids_written) {     // (the selection out of LDS released them as soon as it had ranked)
+                __hip_atomic_store(S.flag, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                JL_STAMP(19);
+            }
         }
-        JL_STAMP(19);
         __syncthreads();
     } else {
         // wait for the selection.  Every workgroup of this launch is resident (the host folds only small grids), so
@@ -1536,16 +1605,7 @@ __device__ __forceinline__ void phase_fused1_body(const jl_win_phase &w, const j
         __syncthreads();
     }
     // ---- per-read haplotype ids of this workgroup's own reads, straight from the slots still in registers
-    if (live && s_idbits) {
-        uint16_t h[8];
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            h[r] = JL_HAP_DAMAGED;
-            if ((clean_keep >> (4 * r)) & 1u)
-                h[r] = (uint16_t)__hip_atomic_load(&S.slot_hap[gslot[r]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        store_ids(S.read_hap, t, h, s_idbits);
-    }
+    if (!ids_written) write_ids(s_idbits);
     // Second arrival: every workgroup is past the flag by now, so the one that arrives last resets it (and the
     // counter) for the next launch and, when this launch ends a run, stores the completion word behind all the ids.
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
