@@ -325,7 +325,7 @@ def main():
         state["gathered_rows"] = int(all_counts[: len(members) * world].sum())
         host["drain"] += time.perf_counter() - t_in
 
-    def collect(members, final=False, check=True):
+    def collect(members, final=False, check=True, retire=True):
         last = None
         pick = state["checked"] % len(members)
         grp = member_group.get(id(members[0]), {}).get(len(members)) if G > 1 else None
@@ -386,7 +386,8 @@ def main():
             # (hipStreamSynchronize on the launch's stream, about 10 us of host time) overlaps with the launches still
             # running.  Left to the closing torch.cuda.synchronize() the same bookkeeping is done stream after stream
             # behind the last result: 10 us per stream that has run since the last fence (tools_tuning/sync_cost.py).
-            members[0].sync()
+            if retire:
+                members[0].sync()
         return last
 
     trace = [] if os.environ.get("JL_BENCH_TRACE") else None   # tuning aid: host time stamps of the timed steps
@@ -410,8 +411,19 @@ def main():
                 trace.append(("launched", time.perf_counter()))
             done += count
             u = (u + 1) % n_units
+        # the launches still in flight at the end are collected as they COMPLETE (a short launch issued last shares the chip
+        # with the full ones in front of it and is done first: collected in launch order, its 14 us of host work — views,
+        # check, stream retirement — came behind the last result instead of beside the other launches' kernels)
+        newest = inflight[-1][1] if inflight else None
         while inflight:
-            last = collect(inflight.pop(0)[1], final=True)
+            i_done = None
+            while i_done is None and len(inflight) > 1:      # (polling the completion words: 0.14 us each)
+                i_done = next((i for i, (_, m) in enumerate(inflight) if all(c.run_done() for c in m)), None)
+            i_done = i_done or 0
+            members = inflight.pop(i_done)[1]
+            out = collect(members, final=True, retire=bool(inflight))   # (the closing fence retires the last launch's stream)
+            if members is newest:
+                last = out
             if trace is not None:
                 trace.append(("collected+synced", time.perf_counter()))
         if comm is not None:
