@@ -7,6 +7,7 @@
 #   g  one-rank emulation of the N > 1 step loop: exchange carried by the launch (default), worker-thread form, staged form, plain -> r05_g_*
 #   h  the record ingest alone: kernel stats + PMC FETCH_SIZE / WRITE_SIZE of its kernels            -> r05_h_ingest_*
 #      + the tuning build: phases switched off (times), SQ instruction counters, wall-clock stamps of the phases of sampled workgroups
+#      + reads with 0 .. 2 % of indels (the planes kernel's second size, cigar_runs' second launch, the column-by-column kernel)
 set -e
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r05
@@ -44,5 +45,6 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/hw -o hw -- 
 SKIPS="0 1 2 8 16 4 3 19" bash $R/tools_tuning/skip_ingest.sh > $O/h_skip.txt 2>&1 || true
 bash $R/tools_tuning/pmc_ingest3.sh > $O/h_sq.txt 2>&1 || true
 JL_ING_STAMPS=1 JL_LIB=$R/tools_tuning/lib_exp/libjuliet_hip.so python3 $R/tools_tuning/ingest_time.py 100000 3000 2 > $O/h_stamps.txt 2>&1 || true
+bash $R/tools_tuning/noisy_sweep.sh > $O/h_noisy.txt 2>&1 || true
 echo "h done"
 find $O -name "*.csv" | head -40

@@ -8,5 +8,5 @@ for lib in "$@"; do
   O=$R/gpurun_out/ingvar/$lib; rm -rf $O; mkdir -p $O
   rocprofv3 --kernel-trace --stats --output-format csv -d $O -o k -- python3 $R/tools_tuning/ingest_time.py 100000 3000 6 > $O/out.txt 2> $O/err.txt
   f=$(find $O -name "*kernel_stats.csv" | head -1)
-  echo "$lib verified=$chk $(grep ingest_planes $f | awk -F, '{print "planes min", $(NF-2)}') $(grep cigar_runs $f | awk -F, '{print "runs min", $(NF-2)}') $(grep 'builds:' $O/out.txt)"
+  echo "$lib verified=$chk $(grep ingest_planes $f | grep "4u, false" | awk -F, '{print "planes min", $(NF-2)}') $(grep "cigar_runs_kernel<64u" $f | awk -F, '{print "runs min", $(NF-2)}') $(grep 'builds:' $O/out.txt)"
 done

@@ -19,7 +19,8 @@ import csv, glob, collections
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob("$O/p*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        k = "ingest_planes" if "ingest_planes" in r["Kernel_Name"] else "cigar_runs" if "cigar_runs" in r["Kernel_Name"] else None
+        n = r["Kernel_Name"]   # (the first size / the first launch: the second forms find nothing to do on these reads)
+        k = "ingest_planes" if ("ingest_planes" in n and "4u, false>" in n) else "cigar_runs" if "cigar_runs_kernel<64u" in n else None
         if k: agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, d in agg.items():
     print(k)

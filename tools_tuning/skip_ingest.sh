@@ -8,5 +8,5 @@ for sk in ${SKIPS:-0 1 2 3 4 8 16 20 21 23 31}; do
   O=$R/gpurun_out/ingskip/$sk; rm -rf $O; mkdir -p $O
   JL_ING_SKIP=$sk rocprofv3 --kernel-trace --stats --output-format csv -d $O -o k -- python3 $R/tools_tuning/ingest_time.py 100000 3000 6 > $O/out.txt 2> $O/err.txt
   f=$(find $O -name "*kernel_stats.csv" | head -1)
-  echo "skip=$sk $(grep ingest_planes $f | awk -F, '{print "planes avg", $(NF-4), "min", $(NF-2)}') $(grep cigar_runs $f | awk -F, '{print "runs min", $(NF-2)}')"
+  echo "skip=$sk $(grep ingest_planes $f | grep "4u, false" | awk -F, '{print "planes avg", $(NF-4), "min", $(NF-2)}') $(grep "cigar_runs_kernel<64u" $f | awk -F, '{print "runs min", $(NF-2)}')"
 done
