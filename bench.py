@@ -712,7 +712,7 @@ def once_through(capi, synth, torch, jl0, genes, refseq, prm, expect, rank, loca
            "bytes_per_step": io, "frac": io / t / 1e9 / HBM_PEAK_GBS,
            "frac_records_plus_planes_once": (record_bytes + plane_bytes) / t / 1e9 / HBM_PEAK_GBS,
            "ingest_ms": t_ing, "ingest_frac": (record_bytes + plane_bytes) / (t_ing * 1e-3) / 1e9 / HBM_PEAK_GBS,
-           "ingest_kernels": "cigar_runs_kernel + ingest_planes_kernel + ingest_slow_kernel (torch events on the window's stream, "
+           "ingest_kernels": "cigar_runs_kernel + ingest_planes_kernel, the second forms of both included (torch events on the window's stream, "
                              f"{reps} back-to-back builds rotating over 4 record copies)"}
     for c in wins + recs:
         c.close()

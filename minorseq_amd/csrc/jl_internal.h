@@ -329,7 +329,7 @@ struct jl_ctx {
     // ---- aligned records on their way in (jl_records_begin / _append / _finish)
     jl_records rec;
     // scratch of the record ingest INTO this context (kernels_ingest.hip), kept between builds: the reads' runs, the run at
-    // every sweep's first column, the (read, sweep) pairs left to the slow kernel behind their counter
+    // every sweep's first column, the units handed on to the planes kernel's second size
     uint2 *d_ing_runs = nullptr;
     uint32_t *d_ing_nruns = nullptr, *d_ing_count = nullptr;
     uint4 *d_ing_desc = nullptr;      // one descriptor per (sweep, read): kernels_ingest.hip

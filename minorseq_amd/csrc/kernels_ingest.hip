@@ -4,30 +4,34 @@
 // :256-259 (a QV-filtered base shows up as N).  Reads past n_reads (the padding of a plane up to its stride) and columns
 // outside a read's span are 'not covered' (code 6).
 //
-// Three launches, no by-row scratch in HBM:
+// Four launches, two of which find nothing to do on CCS reads; no by-row scratch in HBM:
 //   cigar_runs_kernel   a wave takes four reads: prefix sums over the cigar -> the read's RUNS in WINDOW columns (stretches of
 //                       '=' / 'X' merge into one run of aligned bases; D and N are runs of their own; I / S / H / P only end a
 //                       run), 8 bytes each, between a leading 'not covered from column 0' entry and two trailing ones (the
 //                       read's end; 'never'), so that every column of the window lies in exactly one entry's interval.  Then,
 //                       for every column sweep, ONE 16-byte descriptor per read: where the sweep's entries are, how many, the
-//                       address of the first 16-byte piece of packed bases the sweep needs, how many pieces, the query offset
-//                       of that piece — everything ingest_planes_kernel needs to ask for its input in one round trip.
-//   ingest_planes_kernel  a workgroup = 128 reads x one sweep of 224 columns.  One request per read (the descriptor), then
-//                       the entries and the pieces together.  The pieces become symbol codes (nibbles) and go to LDS in QUERY
-//                       order with plain 16-byte stores — no run search, no masks.  Meanwhile two threads per read walk its
-//                       entries and fill a table: for every block of 8 columns, the LDS nibble address its eight codes begin
-//                       at — inside the read's bases when one aligned run covers the block, a constant dword of '-' or of
-//                       'not covered' when a deletion / nothing does; the few blocks with a run boundary inside are listed,
-//                       put together once by a general loop into a side dword, and the table points there.  GATHER AT THE
-//                       TRANSPOSE: a thread takes 32 reads x 8 columns, picks each read's dword by the table (two LDS reads
-//                       + one v_alignbit), transposes four 8 x 8 nibble blocks in registers and stores a dword of each plane of
-//                       each column; the eight workgroups that share the 128-byte lines of a sweep run on one XCD next to each
-//                       other (blockIdx mapping), so the lines are completed in that XCD's L2.
+//                       dword the first 16-byte piece of packed bases the sweep needs begins on, how many pieces, the query
+//                       offset of that piece — everything ingest_planes_kernel needs to ask for its input in one round trip.
+//                       The first launch keeps 64 entries a read in LDS (a CCS read has a dozen); the reads with more get
+//                       their descriptors from a second launch that keeps 512 (an indel every 50 columns of a 3 kb read).
+//   ingest_planes_kernel  a workgroup = 128 reads x one sweep of 256 columns.  One request per read (the descriptor), then
+//                       the entries and the pieces together.  The pieces become nibbles in QUERY order in LDS with plain
+//                       16-byte stores — no run search, no masks.  Meanwhile a thread per read fills a table: for every block
+//                       of 8 columns, the LDS nibble address its eight codes begin at — inside the read's bases when one
+//                       aligned run covers the block, a constant dword of '-' or of 'not covered' when a deletion / nothing
+//                       does; the few blocks with a run boundary inside are put together into a side dword, a thread per
+//                       entry, and the table points there.  GATHER AT THE TRANSPOSE: a thread takes 32 reads x 8 columns,
+//                       picks each read's dword by the table (two LDS reads + one v_alignbit), transposes four 8 x 8 nibble
+//                       blocks in registers, turns BAM's base codes into symbol codes as bit planes and stores a dword of
+//                       each plane of each column; the eight workgroups that share the 128-byte lines of a sweep run on one
+//                       XCD next to each other (blockIdx mapping), so the lines are completed in that XCD's L2.
+//                       The first launch has room for four entries a read on average; a (tile, sweep) unit with more is
+//                       handed on to a second launch of the same kernel with room for sixteen (three workgroups a CU
+//                       instead of five).  A read the workgroup has no room for at all — more inserted bases in a sweep than
+//                       a staging row holds, more than 254 entries in a sweep, entries beyond the second size — is written
+//                       column by column from its entries in HBM by a wave of the SAME workgroup behind its stores (slow_pair).
 //                       (Rounds 1-3 expanded every read into a by-row matrix in HBM: 870 MB moved for the 316 MB needed;
 //                       round 4 scattered the codes into a by-row LDS tile with masked, shifted XORs: 137 us.)
-//   ingest_slow_kernel  the (read, sweep) pairs a workgroup could not take — more entries or pieces in one sweep than its
-//                       LDS holds (a deletion every other column, a huge insertion inside a sweep): column by column from the
-//                       entries in HBM, bits flipped with atomics.  Empty for real CCS data.
 #include <stdlib.h>
 
 #include <algorithm>
@@ -432,16 +436,15 @@ struct ingest_args {
     uint64_t n_reads;
     uint32_t n_cols, n_sweeps, n_groups;   // n_groups: groups of 1024 reads (the tiles that share lines)
     uint32_t min_qv;
-    const uint64_t *cig_off;     // (the slow kernel: where a read's entries begin)
+    const uint64_t *cig_off;     // (slow_pair: where a read's entries begin)
     const uint8_t *seq4;
-    const uint64_t *seq_off;     // (the slow kernel)
+    const uint64_t *seq_off;     // (slow_pair)
     const uint8_t *qual;         // null: no QV masking
     const uint64_t *qual_off;
     const uint2 *runs;
     const uint32_t *nruns;
     const uint4 *desc;
-    uint32_t *slow_count;
-    uint2 *slow_list;            // {read, sweep}
+    uint32_t *slow_count;        // the 64-byte block of counters: [1] units handed on
     uint32_t *big_list;          // the units (block numbers) handed on to the kernel's second size; their number in slow_count[1]
     uint8_t *msa;
     uint64_t plane_stride;
@@ -584,6 +587,47 @@ __device__ __forceinline__ uint32_t ent_addr(uint32_t e, uint32_t row8, uint32_t
     return kind == 1u ? row8 + (e >> 11) + (c - ent_col(e)) : kind == 2u ? 16u : 0u;
 }
 
+// ---------------------------------------------------------------------------------------- what a tile cannot take
+// A (read, sweep) pair with more pieces or entries than a workgroup has room for, by ONE WAVE of the tile's own workgroup,
+// behind its stores: a lane per column looks its entry up in HBM and flips the bits in which the symbol differs from 'not
+// covered' — which is what the workgroup has stored for the read (the words are the tile's own: 32 reads of it each).
+__device__ __forceinline__ void slow_pair(const ingest_args &a, uint64_t r, uint32_t sweep, uint32_t lane)
+{
+    const int X = (int)(sweep * kSweep), Xend = (int)min(a.n_cols, sweep * kSweep + kSweep);
+    const uint2 *runs = a.runs + a.cig_off[r] + 3u * r;
+    const uint32_t ne = a.nruns[r] + 3u;
+    const uint64_t so = a.seq_off[r];
+    const uint64_t qo = a.qual ? a.qual_off[r] : 0u;
+    for (int c = X + (int)lane; c < Xend; c += 64) {
+        uint32_t lo = 0, hi = ne - 1u;   // the last entry that begins at or before c (entry 0 does, the last one never)
+        while (hi - lo > 1u) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if ((int)(runs[mid].x & kRunMask) <= c) lo = mid;
+            else hi = mid;
+        }
+        const uint2 e = runs[lo];
+        const uint32_t kind = e.x >> 30;
+        uint32_t sym = 6u;
+        if (kind == 2u) sym = 4u;
+        else if (kind == 1u) {
+            const uint64_t q = (uint64_t)e.y + (uint64_t)(c - (int)(e.x & kRunMask));
+            const uint32_t by = a.seq4[so + (q >> 1)];
+            const uint32_t b16 = (q & 1u) ? (by & 15u) : (by >> 4);
+            sym = (uint32_t)((0x5555555355525105ull >> (4u * b16)) & 15ull);   // A=1 C=2 G=4 T=8 -> 0..3, else 5
+            if (a.qual) {
+                const uint32_t qv = a.qual[qo + q];
+                if (qv != 0xFFu && qv < a.min_qv) sym = JL_SYM_MASK;
+            }
+        }
+        const uint32_t flip = sym ^ 6u;
+        const uint32_t bit = 1u << (uint32_t)(r & 31u);
+#pragma unroll
+        for (uint32_t k = 0; k < 3u; ++k)
+            if ((flip >> k) & 1u)
+                atomicXor(reinterpret_cast<uint32_t *>(a.msa + ((uint64_t)c * 3u + k) * a.plane_stride + (r >> 5) * 4u), bit);
+    }
+}
+
 // A workgroup = 128 reads x one sweep, four waves with two jobs.  Nothing a thread asks HBM for depends on another thread: every
 // thread reads the descriptors of the reads whose pieces it takes itself (neighbouring lanes share them), so the two trips —
 // descriptor, then pieces / entries — are the only waits before the first barrier, and there are two barriers in all.
@@ -608,6 +652,8 @@ __device__ __forceinline__ void planes_unit(const ingest_args &a, const uint32_t
     __shared__ uint32_t s_ent[kEntCap];           // the entries of the reads with several in the sweep, a half per read wave
     __shared__ uint16_t s_own[kEntCap];           // whose: the read | 0x8000 for its last one
     __shared__ uint32_t s_nent[2u * kReadWaves];  // entries in each part; [kReadWaves + w]: wave w hands the unit on
+    __shared__ uint32_t s_nslow;                  // reads left to slow_pair
+    __shared__ uint8_t s_slow[kTileReads];
     const uint32_t tid = threadIdx.x, wid = tid >> 6, lane = tid & 63u;
     // block -> (read tile, sweep).  Blocks b, b + 8, b + 16, ... are dealt to the same XCD one after the other; an XCD takes
     // whole groups of 1024 reads (group = xcd, xcd + 8, ...), and of a group all sweeps in turn, the tiles of the group
@@ -646,7 +692,7 @@ __device__ __forceinline__ void planes_unit(const ingest_args &a, const uint32_t
             if (k >= K) break;
             const uint32_t p = p0 + kTileReads * k, j = p / kRowPieces, i = p - kRowPieces * j;
             uint32_t np = (d[k].w >> 16) & 0xFFu;
-            if (np > kRowPieces || (d[k].w >> 24) == kDescMax) np = 0;      // (the slow kernel's)
+            if (np > kRowPieces || (d[k].w >> 24) == kDescMax) np = 0;      // (slow_pair's)
             uint64_t at = ((((uint64_t)d[k].w & 0xFFu) << 32) | d[k].x) + (i < np ? 4u * i : 0u);     // (in dwords)
             JL_ING_CHECK(a, 4u * at + 16u <= a.seq_bytes + 64u, 1, at, at = 0)
             // (plain loads: neighbouring lanes' pieces share lines, and so do the sweeps of a read)
@@ -700,6 +746,7 @@ __device__ __forceinline__ void planes_unit(const ingest_args &a, const uint32_t
         if (a.stamps) { asm volatile("" ::"v"(d.w)); JL_ING_STAMP(a, 1) }   // (the descriptor has arrived)
 #endif
         if (tid < 4u) s_stage[tid] = tid < 2u ? 0x66666666u : 0x44444444u;
+        if (tid == 4u) s_nslow = 0;
         if (lane == 0) s_nent[wid] = 0, s_nent[kReadWaves + wid] = 0;
         const uint32_t np = (d.w >> 16) & 0xFFu;
         uint32_t n_ent = d.w >> 24;
@@ -712,7 +759,7 @@ __device__ __forceinline__ void planes_unit(const ingest_args &a, const uint32_t
         if (n_ent && off_e + n_ent > kEntCapWave) {
             // more entries than the wave's part holds: the first size hands the whole unit on to the second (nothing of it is
             // written here, and no read of it goes to the slow list: the second size lists its own); the second leaves the
-            // reads past the part's end to the slow kernel
+            // reads past the part's end to slow_pair
             if (!BIG) s_nent[kReadWaves + wid] = 1u;
             else slow = true;
             n_ent = 0;
@@ -794,10 +841,7 @@ __device__ __forceinline__ void planes_unit(const ingest_args &a, const uint32_t
             return;
         }
     }
-    if (slow_read) {
-        const uint32_t at = atomicAdd(a.slow_count, 1u);
-        a.slow_list[at] = make_uint2((uint32_t)(r0 + tid), sweep);
-    }
+    if (slow_read) s_slow[atomicAdd(&s_nslow, 1u)] = (uint8_t)tid;      // (its row of the table says 'not covered')
 
     // ---- the table rows of the reads with several entries, everybody: a thread an entry.  Entry i
     // of a read covers the columns [its column, the next entry's column) and the read's last one only ends the one before
@@ -884,6 +928,7 @@ __device__ __forceinline__ void planes_unit(const ingest_args &a, const uint32_t
     JL_ING_STAMP(a, 8)
     __syncthreads();
     JL_ING_STAMP(a, 9)
+    const uint32_t n_slow = s_nslow;
 
     // ---- gather at the transpose: thread = 32 reads x 8 columns; neighbouring lanes write consecutive dwords of a plane
     {
@@ -939,6 +984,12 @@ __device__ __forceinline__ void planes_unit(const ingest_args &a, const uint32_t
         }
     }
     JL_ING_STAMP(a, 10)
+    // ---- the reads left out (none, in a CCS sample): column by column behind the workgroup's own stores, a wave a read
+    if (n_slow) {       // (the same in every thread)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (uint32_t i = wid; i < n_slow; i += kThreads / 64u) slow_pair(a, r0 + s_slow[i], sweep, lane);
+    }
 }
 
 // The first size: a workgroup a unit (blockIdx -> unit: planes_unit).  The second: the units the first handed on, in the
@@ -957,60 +1008,6 @@ __global__ __launch_bounds__(kThreads) void ingest_planes_kernel(ingest_args a)
     }
 }
 
-// ---------------------------------------------------------------------------------------- what the tiles left out
-// One wave per (read, sweep) pair: a lane per column looks its entry up in HBM and flips the bits in which the symbol differs
-// from 'not covered' (which is what the tile's workgroup stored for the read).
-__global__ __launch_bounds__(256) void ingest_slow_kernel(ingest_args a, const uint32_t cap)
-{
-    const uint32_t wid = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    uint32_t n = *a.slow_count;
-    if (n > cap) n = cap;
-    for (uint32_t it = blockIdx.x * 4u + wid; it < n; it += gridDim.x * 4u) {
-        const uint2 pr = a.slow_list[it];
-        const uint64_t r = pr.x;
-        const uint32_t sweep = pr.y;
-#ifdef JL_TUNING
-        if (r >= a.n_reads || sweep >= a.n_sweeps) {
-            if (lane == 0) { atomicAdd(&a.dbg[4], 1u); a.dbg[9] = pr.x; }
-            continue;
-        }
-#endif
-        const int X = (int)(sweep * kSweep), Xend = (int)min(a.n_cols, sweep * kSweep + kSweep);
-        const uint2 *runs = a.runs + a.cig_off[r] + 3u * r;
-        const uint32_t ne = a.nruns[r] + 3u;
-        const uint64_t so = a.seq_off[r];
-        const uint64_t qo = a.qual ? a.qual_off[r] : 0u;
-        for (int c = X + (int)lane; c < Xend; c += 64) {
-            uint32_t lo = 0, hi = ne - 1u;   // the last entry that begins at or before c (entry 0 does, the last one never)
-            while (hi - lo > 1u) {
-                const uint32_t mid = (lo + hi) >> 1;
-                if ((int)(runs[mid].x & kRunMask) <= c) lo = mid;
-                else hi = mid;
-            }
-            const uint2 e = runs[lo];
-            const uint32_t kind = e.x >> 30;
-            uint32_t sym = 6u;
-            if (kind == 2u) sym = 4u;
-            else if (kind == 1u) {
-                const uint64_t q = (uint64_t)e.y + (uint64_t)(c - (int)(e.x & kRunMask));
-                const uint32_t by = a.seq4[so + (q >> 1)];
-                const uint32_t b16 = (q & 1u) ? (by & 15u) : (by >> 4);
-                sym = (uint32_t)((0x5555555355525105ull >> (4u * b16)) & 15ull);   // A=1 C=2 G=4 T=8 -> 0..3, else 5
-                if (a.qual) {
-                    const uint32_t qv = a.qual[qo + q];
-                    if (qv != 0xFFu && qv < a.min_qv) sym = JL_SYM_MASK;
-                }
-            }
-            const uint32_t flip = sym ^ 6u;
-            const uint32_t bit = 1u << (uint32_t)(r & 31u);
-#pragma unroll
-            for (uint32_t k = 0; k < 3u; ++k)
-                if ((flip >> k) & 1u)
-                    atomicXor(reinterpret_cast<uint32_t *>(a.msa + ((uint64_t)c * 3u + k) * a.plane_stride + (r >> 5) * 4u), bit);
-        }
-    }
-}
-
 }  // namespace
 
 uint32_t jl_ingest_sweeps(uint32_t n_cols) { return (n_cols + kSweep - 1u) / kSweep; }
@@ -1022,11 +1019,9 @@ static uint32_t planes_units(const jl_ctx *ctx)
     return (groups + 7u) / 8u * jl_ingest_sweeps(ctx->n_cols) * 8u * kSubTiles;
 }
 
-// pairs of d_slow: every (read, sweep) once at most, and behind them the units handed on (a word each)
-size_t jl_ingest_slow_room(const jl_ctx *ctx)
-{
-    return (size_t)ctx->n_reads * jl_ingest_sweeps(ctx->n_cols) + planes_units(ctx) / 2u + 8u;
-}
+// pairs (8 bytes) of d_slow: the tuning build's stamps, and behind them the units handed on (a word each)
+constexpr uint32_t kStampPairs = 160u * 4u * 12u;
+size_t jl_ingest_slow_room(const jl_ctx *ctx) { return (size_t)kStampPairs + planes_units(ctx) / 2u + 8u; }
 
 // d_runs: n_cig + 3 n_reads + 8 entries; d_nruns: n_reads; d_desc: n_reads x sweeps descriptors; d_slow: jl_ingest_slow_room() pairs.
 // d_slow_count, 64 bytes: [0] pairs listed, [1] units handed on — zeroed here; [2..3] the 64-bit word of the first malformed
@@ -1068,8 +1063,7 @@ void jl_launch_ingest(jl_ctx *ctx, const int32_t *d_pos, const uint32_t *d_cigar
     a.nruns = d_nruns;
     a.desc = d_desc;
     a.slow_count = d_slow_count;
-    a.slow_list = d_slow;
-    a.big_list = reinterpret_cast<uint32_t *>(d_slow + (uint64_t)ctx->n_reads * ns);
+    a.big_list = reinterpret_cast<uint32_t *>(d_slow + kStampPairs);
     a.msa = ctx->d_msa;
     a.plane_stride = ctx->plane_stride;
     a.seq_bytes = seq_bytes;
@@ -1078,9 +1072,9 @@ void jl_launch_ingest(jl_ctx *ctx, const int32_t *d_pos, const uint32_t *d_cigar
     a.skip = 0;
     a.stamps = nullptr;
 #ifdef JL_TUNING
-    if (getenv("JL_ING_STAMPS") && (uint64_t)ctx->n_reads * ns * 8u >= 160u * 4u * 12u * 8u) {
+    if (getenv("JL_ING_STAMPS")) {
         a.stamps = reinterpret_cast<unsigned long long *>(d_slow);
-        hipMemsetAsync(d_slow, 0, 160u * 4u * 12u * 8u, st);
+        hipMemsetAsync(d_slow, 0, kStampPairs * 8u, st);
     }
     hipMemsetAsync(d_slow_count + 4, 0, 48, st);
     if (const char *e = getenv("JL_ING_SKIP")) a.skip = (uint32_t)atoi(e);
@@ -1094,6 +1088,4 @@ void jl_launch_ingest(jl_ctx *ctx, const int32_t *d_pos, const uint32_t *d_cigar
         hipLaunchKernelGGL((ingest_planes_kernel<false, E, false>), dim3(grid), dim3(kThreads), 0, st, a);
         hipLaunchKernelGGL((ingest_planes_kernel<false, EB, true>), dim3(kBigGrid), dim3(kThreads), 0, st, a);
     }
-    const uint64_t cap = (uint64_t)ctx->n_reads * ns;   // (a pair is listed once: by the prologue, or when its boundary blocks overflow)
-    hipLaunchKernelGGL(ingest_slow_kernel, dim3(256), dim3(256), 0, st, a, (uint32_t)std::min<uint64_t>(cap, 0xFFFFFFFFu));
 }

@@ -34,7 +34,7 @@ subprocess.check_call([sys.executable, os.path.join(here, "make_pmc_traffic.py")
 # the ingest's kernels: one line per dispatch, then the averages
 # (the first launch of cigar_runs and the first size of the planes kernel do the work on CCS reads; their second forms and the
 # column-by-column kernel find nothing to do there and are listed beside them)
-match = {"cigar_runs_kernel": "cigar_runs_kernel<64u", "ingest_planes_kernel": "4u, false>", "ingest_slow_kernel": "ingest_slow_kernel",
+match = {"cigar_runs_kernel": "cigar_runs_kernel<64u", "ingest_planes_kernel": "4u, false>",
          "cigar_runs_kernel, second launch": "cigar_runs_kernel<512u", "ingest_planes_kernel, second size": "16u, true>"}
 names = tuple(match)
 avg = {n: {} for n in names}

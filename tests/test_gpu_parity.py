@@ -1139,10 +1139,11 @@ def test_device_ingest_refuses_cigars_whose_lengths_wrap(jl):
     assert "record 1" in str(err.value) and "more bases" in str(err.value)
 
 
-def test_device_ingest_dense_runs_take_the_slow_kernel(jl):
-    """A deletion at every other column: hundreds of runs per read and sweep, far more than a workgroup's LDS list holds
-    — most (read, sweep) pairs go through ingest_slow_kernel (runs looked up in HBM, bits flipped with atomics), the first
-    few reads of every tile through the tile path; both with and without QV masking, and as windows of one upload."""
+def test_device_ingest_dense_runs_take_the_slow_path(jl):
+    """A deletion at every other column: hundreds of runs per read and sweep, far more than a workgroup's entry area holds
+    in either size — most (read, sweep) pairs are written column by column (slow_pair: runs looked up in HBM, bits flipped
+    with atomics behind the workgroup's own stores), the first few reads of every tile through the tile path; both with and
+    without QV masking, and as windows of one upload."""
     n, l = 700, 1000
     rng = np.random.default_rng(5)
     sp = synth.SynthParams(seed=41, partial_rate=0.2, mask_rate=0.02, sub_rate=0.01)

@@ -1,5 +1,5 @@
 """The record ingest on reads with many indels (juliet-synth --ins-ppm / --del): how many (read, sweep) pairs leave the tiles for
-the slow kernel, and what the kernels take.  usage: ingest_noisy.py reads cols ins_ppm del_rate   (under rocprofv3 for the times)"""
+the column-by-column path, and what the kernels take.  usage: ingest_noisy.py reads cols ins_ppm del_rate   (under rocprofv3 for the times)"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
