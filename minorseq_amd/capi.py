@@ -693,16 +693,22 @@ class Juliet:
                          ids=_view(v.read_hap_packed, np.uint8, 2 * v.n_reads) if v.read_hap_packed else None)
             self._rv_cache = {key: c}
         nv = v.n_variants
-        out = dict(variants=c["variants"][:nv])
-        if v.phased:
-            h, vp, nvp = v.n_haplotypes, v.n_positions, v.n_var_phase
-            s = {n: getattr(v.summary, n) for n in SUMMARY_FIELDS}
-            out["phase"] = dict(summary=s, pos_cols=c["pos_cols"][:vp], hap_count=c["hap_count"][:h],
-                                hap_pattern=c["hap_pattern"][:h * vp].reshape(h, vp),
-                                hit=c["hit"][:nvp * h].reshape(nvp, h),
-                                read_hap=_LazyIds(c["ids"], v.read_hap_bits, v.n_reads) if c["ids"] is not None else None,
-                                cooc=None if c["cooc"] is None or not v.cooc else c["cooc"][:nvp * nvp].reshape(nvp, nvp))
-        return out
+        if not v.phased:
+            return dict(variants=c["variants"][:nv])
+        # the sliced and reshaped views are kept while the results keep their shape (a step loop's runs do): they look at
+        # the same pinned block, whose contents the run has replaced; the summary and the ids' holder are made per run
+        h, vp, nvp = v.n_haplotypes, v.n_positions, v.n_var_phase
+        shape = (nv, h, vp, nvp, bool(v.cooc))
+        sh = c.get("shaped")
+        if sh is None or sh[0] != shape:
+            sh = c["shaped"] = (shape, c["variants"][:nv],
+                                dict(pos_cols=c["pos_cols"][:vp], hap_count=c["hap_count"][:h],
+                                     hap_pattern=c["hap_pattern"][:h * vp].reshape(h, vp), hit=c["hit"][:nvp * h].reshape(nvp, h),
+                                     cooc=None if c["cooc"] is None or not v.cooc else c["cooc"][:nvp * nvp].reshape(nvp, nvp)))
+        ph = dict(sh[2])
+        ph["summary"] = {n: getattr(v.summary, n) for n in SUMMARY_FIELDS}
+        ph["read_hap"] = _LazyIds(c["ids"], v.read_hap_bits, v.n_reads) if c["ids"] is not None else None
+        return dict(variants=sh[1], phase=ph)
 
     def run(self, genes, refseq=None, params=None, drm_masks=None, phasing=True, min_reads=10):
         """The whole hot path, blocking; arrays are copies."""
