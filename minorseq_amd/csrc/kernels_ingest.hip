@@ -245,7 +245,12 @@ __global__ __launch_bounds__(256, JL_RUNS_WAVES) void cigar_runs_kernel(uint64_t
 #pragma unroll
         for (uint32_t t = 0; t < 8u; ++t) {
             const uint32_t op = w8[t] & 15u, len = k + t < n_ops ? w8[t] >> 4 : 0u;
-            if ((starts >> (2u * t)) & 1u) {
+#if defined(JL_RUNS_PROBE) && JL_RUNS_PROBE >= 2     // (tuning: ... and without the entries)
+            if (false)
+#else
+            if ((starts >> (2u * t)) & 1u)
+#endif
+            {
                 uint32_t bf;
                 const uint32_t w = window_col(ref_at, bf);
                 put(idx, make_uint2(w | (((kinds >> (2u * t)) & 3u) << 30), (uint32_t)q_at + bf));
@@ -284,6 +289,9 @@ __global__ __launch_bounds__(256, JL_RUNS_WAVES) void cigar_runs_kernel(uint64_t
         put(idx, e);
         if (sl == 0u) nruns[r] = n_runs;
     }
+#if defined(JL_RUNS_PROBE) && JL_RUNS_PROBE >= 1     // (tuning: the kernel without its descriptors — wrong results by design)
+    if (n_reads) continue;
+#endif
     // ---- the descriptors: a lane per sweep (fifteen sweeps a pass: a sweep needs the bound of the next one too).  Entries
     // beyond the LDS copy are read back from HBM: past this wave's own stores.
     const uint32_t n_mine = is_long ? 0u : n_runs;
@@ -1046,6 +1054,9 @@ void jl_launch_ingest(jl_ctx *ctx, const int32_t *d_pos, const uint32_t *d_cigar
         hipLaunchKernelGGL((cigar_runs_kernel<kRunsLdsLarge, true>), dim3((uint32_t)std::min<uint64_t>(kRunsLongGrid, (ctx->n_reads + 255u) / 256u)), dim3(256), 0, st,
                            ctx->n_reads, d_pos, d_cigar, d_cig_off, d_seq_off, qo, ctx->win_begin, ctx->n_cols, ns, d_runs, d_nruns, d_desc, bad);
     }
+#ifdef JL_TUNING
+    if (getenv("JL_ING_ONLY_RUNS")) return;     // (probe builds of cigar_runs leave descriptors nobody may follow)
+#endif
     ingest_args a;
     a.n_reads = ctx->n_reads;
     a.n_cols = ctx->n_cols;
