@@ -487,10 +487,13 @@ def main():
         one_batch()
     fence()
     latency_ms = 1000.0 * (time.perf_counter() - t1) / 20
+    # ... and the same loop inside the library (jl_time_run: launch -> completion word -> run view -> next launch, host clock):
+    # what a C or C++ caller sees; the figure above has this interpreter between the runs (4-6 us: ctypes, the numpy views)
+    latency_c_ms = jl.time_run(genes, refseq, prm, None, True, 10, True, reps=40)
 
     # the same for a window with SIXTEEN variant positions (the reference's own screenshots show 9-13 and more,
     # doc/JULIET.md:350, 362): beyond ten positions a pattern takes two key words — the two-word fused launch
-    many_ms = None
+    many_ms = many_c_ms = None
     if world == 1 and (n, l) == (N_READS, N_COLS):
         from minorseq_amd import msa
         mp = capi.Juliet(local_rank)
@@ -514,6 +517,7 @@ def main():
             mv = many()
         fence()
         many_ms = 1000.0 * (time.perf_counter() - t2) / 20
+        many_c_ms = mp.time_run(genes, refseq, prm, None, True, 10, True, reps=40)
         many_positions = int(mv["phase"]["summary"]["n_positions"])
         mp.close()
 
@@ -567,8 +571,8 @@ def main():
                    "parallelism": f"window-sharded x{world}, {exchange}" if distributed
                    else "single GPU",
                    "batches_per_launch": G, "launches_in_flight": n_flight, "resident_batches": len(ctxs),
-                   "one_batch_latency_ms": latency_ms,
-                   "many_positions_latency_ms": many_ms, "many_positions": many_positions if many_ms is not None else None,
+                   "one_batch_latency_ms": latency_ms, "one_batch_latency_c_abi_ms": latency_c_ms,
+                   "many_positions_latency_ms": many_ms, "many_positions_latency_c_abi_ms": many_c_ms, "many_positions": many_positions if many_ms is not None else None,
                    "variants_called": state["gathered_rows"] if comm is not None else len(table),
                    "haplotypes": ph["summary"]["n_haplotypes"],
                    "windows_verified_in_loop": state["checked"]},

@@ -361,6 +361,11 @@ int jl_fisher_eval_tail(jl_ctx *ctx, const uint32_t *a, const uint32_t *c, const
 
 /* ---------------------------------------------------------------- timing hooks (bench) */
 
+/* Latency of the whole path at this boundary, host clock: `reps` runs one after the other, each jl_run_async ->
+ * jl_run_view_get (which waits for the completion word) before the next is launched; average ms per run. */
+int jl_time_run(jl_ctx *ctx, const jl_gene *genes, uint32_t n_genes, const uint8_t *refseq, uint32_t ref_len,
+                const jl_params *prm, const uint64_t *drm_masks, int phasing, uint32_t min_reads, int want_read_hap,
+                uint32_t reps, float *ms_avg);
 /* Average device time in ms of `reps` back-to-back launches of the pileup kernel alone, by HIP events on the ctx stream. */
 int jl_time_pileup(jl_ctx *ctx, uint32_t reps, float *ms_avg);
 /* The same over several contexts' resident windows in rotation, all on the first context's stream: no launch finds

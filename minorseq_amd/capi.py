@@ -33,7 +33,7 @@ EXPORTS = ("jl_abi_version", "jl_strerror", "jl_device_count", "jl_ctx_create", 
            "jl_msa_ingest_records", "jl_records_begin", "jl_records_append", "jl_records_finish", "jl_records_window", "jl_records_window_async", "jl_records_drop", "jl_msa_track_insertions", "jl_insertions_fetch", "jl_msa_download", "jl_synth_fill", "jl_synth_fill_window", "jl_pileup_async", "jl_n_positions", "jl_pileup_fetch",
            "jl_consensus_fetch", "jl_call_async", "jl_call_fetch", "jl_variant_table_device", "jl_phase_async", "jl_phase_fetch",
            "jl_ctx_stream", "jl_run_async", "jl_run_wait", "jl_run_done", "jl_run_view_get", "jl_group_create", "jl_group_destroy",
-           "jl_group_last_error", "jl_group_run_async", "jl_group_run_masked_async", "jl_group_views", "jl_group_time_pileup", "jl_fisher_eval", "jl_fisher_eval_tail", "jl_expand_read_hap", "jl_time_pileup", "jl_time_pileup_set", "jl_run_pileup_clock", "jl_run_pileup_ms", "jl_pileup_kernel_name", "jl_comm_unique_id", "jl_comm_create", "jl_comm_create_inproc", "jl_comm_destroy",
+           "jl_group_last_error", "jl_group_run_async", "jl_group_run_masked_async", "jl_group_views", "jl_group_time_pileup", "jl_fisher_eval", "jl_fisher_eval_tail", "jl_expand_read_hap", "jl_time_run", "jl_time_pileup", "jl_time_pileup_set", "jl_run_pileup_clock", "jl_run_pileup_ms", "jl_pileup_kernel_name", "jl_comm_unique_id", "jl_comm_create", "jl_comm_create_inproc", "jl_comm_destroy",
            "jl_allgather_variants", "jl_allgather_variants_async", "jl_allgather_variants_async_many", "jl_allgather_variants_many", "jl_group_exchange_bind", "jl_group_exchange_collect", "jl_xwin_plan", "jl_xwin_assemble_local",
            "jl_xwin_assemble_rccl", "jl_xwin_assemble_slice_local", "jl_xwin_assemble_slice_rccl", "jl_phase_groups_async",
            "jl_phase_groups_fetch", "jl_phase_regroup", "jl_merge_tables", "jl_merge_groups", "jl_select_haplotypes",
@@ -189,6 +189,7 @@ def load_library(path=LIB_PATH):
     lib.jl_phase_async.argtypes = [vp, vp, u32, u32]
     lib.jl_phase_fetch.argtypes = [vp] * 8 + [u32]
     lib.jl_run_async.argtypes = [vp, vp, u32, vp, u32, C.POINTER(Params), vp, C.c_int, u32, C.c_int]
+    lib.jl_time_run.argtypes = [vp, vp, u32, vp, u32, C.POINTER(Params), vp, C.c_int, u32, C.c_int, u32, C.POINTER(C.c_float)]
     lib.jl_group_create.argtypes = [vp, u32, C.POINTER(vp)]
     lib.jl_group_destroy.argtypes = [vp]
     lib.jl_group_destroy.restype = None
@@ -584,6 +585,18 @@ class Juliet:
         ms, t0 = C.c_float(), C.c_uint64()
         self._chk(self.lib.jl_run_pileup_ms(self.h, C.byref(ms), C.byref(t0)))
         return 1e-5 * t0.value, 1e-5 * t0.value + float(ms.value)
+
+    def time_run(self, genes, refseq=None, params=None, drm_masks=None, phasing=True, min_reads=10, want_read_hap=True, reps=20):
+        """jl_time_run: average ms per run of `reps` runs one after the other, launched and waited for inside the library
+        (the latency of the path at the C ABI, without this interpreter between the runs)."""
+        g = np.ascontiguousarray(genes, dtype=GENE)
+        r = None if refseq is None else np.ascontiguousarray(refseq, dtype=np.uint8)
+        d = None if drm_masks is None else np.ascontiguousarray(drm_masks, dtype=np.uint64)
+        prm = params or default_params()
+        ms = C.c_float()
+        self._chk(self.lib.jl_time_run(self.h, _p(g), len(g), _p(r), 0 if r is None else len(r), C.byref(prm), _p(d),
+                                       1 if phasing else 0, min_reads, 1 if want_read_hap else 0, reps, C.byref(ms)))
+        return float(ms.value)
 
     def time_pileup(self, reps=20):
         ms = C.c_float()

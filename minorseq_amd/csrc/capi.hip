@@ -7,10 +7,8 @@
 #include <string.h>
 
 #include <algorithm>
-#include <new>
-#ifdef JL_TUNING
 #include <chrono>
-#endif
+#include <new>
 
 #include "jl_internal.h"
 
@@ -1790,6 +1788,29 @@ int jl_run_pileup_ms(jl_ctx *ctx, float *ms, uint64_t *begin_ticks)
     const volatile unsigned long long *t = reinterpret_cast<const volatile unsigned long long *>(const_cast<uint32_t *>(ctx->h_seq) + 8);
     *ms = (float)((double)(t[1] - t[0]) * 1e-5);      // 100 MHz ticks
     if (begin_ticks) *begin_ticks = t[0];
+    return JL_OK;
+}
+
+// Latency of the whole path at THIS boundary: `reps` runs one after the other, each launched when the one before has put
+// its results into the pinned block and the caller has looked at them (jl_run_async -> jl_run_wait -> jl_run_view_get);
+// host clock around the loop.  What a C or C++ caller sees; a Python caller adds its interpreter on top (bench.py
+// reports both).
+int jl_time_run(jl_ctx *ctx, const jl_gene *genes, uint32_t n_genes, const uint8_t *refseq, uint32_t ref_len,
+                const jl_params *prm, const uint64_t *drm_masks, int phasing, uint32_t min_reads, int want_read_hap,
+                uint32_t reps, float *ms_avg)
+{
+    if (!ctx || !ms_avg || reps == 0) return JL_ERR_ARG;
+    jl_run_view v;
+    for (int warm = 0; warm < 2; ++warm) {      // (the second run of a configuration captures its graph)
+        if (int rc = jl_run_async(ctx, genes, n_genes, refseq, ref_len, prm, drm_masks, phasing, min_reads, want_read_hap)) return rc;
+        if (int rc = jl_run_view_get(ctx, &v)) return rc;
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint32_t r = 0; r < reps; ++r) {
+        if (int rc = jl_run_async(ctx, genes, n_genes, refseq, ref_len, prm, drm_masks, phasing, min_reads, want_read_hap)) return rc;
+        if (int rc = jl_run_view_get(ctx, &v)) return rc;     // (waits for the completion word)
+    }
+    *ms_avg = (float)(std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / (double)reps);
     return JL_OK;
 }
 

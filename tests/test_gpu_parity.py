@@ -462,6 +462,13 @@ def test_run_view_and_completion_word(jl, oracle):
             f = j.run_fetch(True, True, cap_var=64)
             assert (f["variants"] == v["variants"]).all()
             assert (f["phase"]["read_hap"] == v["phase"]["read_hap"]).all()
+    # jl_time_run: the same runs launched and waited for inside the library leave the last run's results behind
+    j, ref = ctxs[1]
+    ms = j.time_run(genes, ref, prm, None, True, 10, True, reps=5)
+    assert 0.0 < ms < 50.0
+    v = j.run_view()
+    assert_variants_equal(v["variants"], exps[1][0])
+    assert_phase_equal(v["phase"], exps[1][1], len(exps[1][0]))
     # phasing off: the view carries only the table
     j, ref = ctxs[0]
     j.run_async(genes, ref, prm, None, False, 10, False)
