@@ -79,7 +79,10 @@ constexpr uint32_t kRunsReadsPerWave = 4u;   // a wave takes four reads a turn
 // a dozen), which lists the reads with more; 512 — 64 KB, two workgroups a CU — in the launch that takes those (and reads
 // what is beyond even that back from HBM, a trip an entry: 1 ms instead of 0.12 for 100k reads with 1 % of indels, 236 ops
 // a read, when they all did)
-constexpr uint32_t kRunsLdsSmall = 64u, kRunsLdsLarge = 512u;
+#ifndef JL_RUNS_LDS_SMALL
+#define JL_RUNS_LDS_SMALL 64u
+#endif
+constexpr uint32_t kRunsLdsSmall = JL_RUNS_LDS_SMALL, kRunsLdsLarge = 512u;
 constexpr uint32_t kRunsLongGrid = 1024u;     // workgroups of the second launch at most: its waves take 64 reads at a time, in turns
 constexpr uint32_t kDescSweeps = 15u;       // sweeps a row of sixteen lanes describes per pass (it needs sixteen bounds)
 constexpr uint32_t kDescMax = 255u;         // "more than the planes kernel takes": pieces or entries of a (read, sweep)
@@ -658,7 +661,8 @@ __device__ __forceinline__ void planes_unit(const ingest_args &a, const uint32_t
     __shared__ __attribute__((aligned(16))) uint32_t s_stage[kStageDw + JL_INGEST_LDS_PAD / 4];
     __shared__ __attribute__((aligned(16))) uint16_t s_tab[kTabSize];
     __shared__ uint32_t s_ent[kEntCap];           // the entries of the reads with several in the sweep, a half per read wave
-    __shared__ uint16_t s_own[kEntCap];           // whose: the read | 0x8000 for its last one
+    __shared__ uint8_t s_own[kEntCap];            // whose: the read | 0x80 for its last one
+    static_assert(kTileReads <= 128u, "a read of the tile and a flag in a byte");
     __shared__ uint32_t s_nent[2u * kReadWaves];  // entries in each part; [kReadWaves + w]: wave w hands the unit on
     __shared__ uint32_t s_nslow;                  // reads left to slow_pair
     __shared__ uint8_t s_slow[kTileReads];
@@ -820,17 +824,17 @@ __device__ __forceinline__ void planes_unit(const ingest_args &a, const uint32_t
             const uint32_t e8[8] = {pack(e01.x, e01.y), pack(e01.z, e01.w), pack(e23.x, e23.y), pack(e23.z, e23.w),
                                     pack(e45.x, e45.y), pack(e45.z, e45.w), pack(e67.x, e67.y), pack(e67.z, e67.w)};
             uint32_t *ent = s_ent + off_e;
-            uint16_t *own = s_own + off_e;
+            uint8_t *own = s_own + off_e;
 #pragma unroll
             for (uint32_t i = 0; i < 8u; ++i)
                 if (i < n_ent) {
                     ent[i] = e8[i];
-                    own[i] = (uint16_t)(tid | (i + 1u == n_ent ? 0x8000u : 0u));
+                    own[i] = (uint8_t)(tid | (i + 1u == n_ent ? 0x80u : 0u));
                 }
             for (uint32_t i = 8; i < n_ent; ++i) {
                 const uint2 g = src[i];
                 ent[i] = pack(g.x, g.y);
-                own[i] = (uint16_t)(tid | (i + 1u == n_ent ? 0x8000u : 0u));
+                own[i] = (uint8_t)(tid | (i + 1u == n_ent ? 0x80u : 0u));
             }
             atomicMax(&s_nent[wid], off_e - wid * kEntCapWave + n_ent);
         }
@@ -874,7 +878,7 @@ __device__ __forceinline__ void planes_unit(const ingest_args &a, const uint32_t
             }
             const uint32_t own = s_own[slot], e = s_ent[slot], nx = s_ent[slot + 1u];
             const uint32_t wr = ent_col(e);
-            if ((own & 0x8000u) || wr >= width) continue;
+            if ((own & 0x80u) || wr >= width) continue;
             const uint32_t row8 = 8u * shape::row_dw(own);
             // (a) the entry's whole blocks [bf, be): singly up to a multiple of four, four a store, singly again
             const uint32_t wn = ent_col(nx);
@@ -925,7 +929,7 @@ __device__ __forceinline__ void planes_unit(const ingest_args &a, const uint32_t
                         m_al |= m;
                     } else m_del |= m;
                 }
-                if (Wn >= c1 || (s_own[kk] & 0x8000u)) break;     // (the read's last entry is nothing: 'not covered' stays)
+                if (Wn >= c1 || (s_own[kk] & 0x80u)) break;     // (the read's last entry is nothing: 'not covered' stays)
                 ee = nn;
             }
             const uint32_t R = (codes_of_bases8(bases) & m_al) | (0x44444444u & m_del) | (0x66666666u & ~(m_al | m_del));
