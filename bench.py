@@ -24,9 +24,11 @@ Prints ONE JSON line on rank 0 (see the driver contract in the task brief), incl
                format since round 4, DESIGN.md "Data layout") — so `frac` is physical: what crosses the HBM over the kernel's
                time (`traffic` from the PMC counters agrees within a few percent).  `step_frac` = the same bytes over the whole
                timed step.  (`frac_in_nibble_units`: the same time against SURVEY 8d's 4-bit cell, for comparison with rounds 1-3.)
-  once_through a FRESH window per step: aligned records resident in HBM -> ingest (cigar expansion + plane split, three
+  once_through a FRESH window per step: aligned records resident in HBM -> ingest (cigar expansion + plane split, four
                launches) -> pileup -> Fisher -> phasing -> results on the host; reads/s and the fraction of the HBM peak in
                record bytes read + plane bytes written + plane bytes read.
+  once_through_qv  the same on the input the reference documents (`ccs --richQVs`, doc/JULIET.md:256-259): filtered bases keep
+               their letter and carry a low quality, one quality byte per base resident beside the bases, min_qv = 20.
   cpu_baseline this repo's CPU restatement (oracle/, kind "port": the reference ships no source) on the host cores.
 """
 import argparse
@@ -134,13 +136,75 @@ def same(sig, out):
             and ph["summary"] == sig["summary"])
 
 
-def main():
-    # The contract is ONE JSON line on stdout.  Libraries print banners there (RCCL with NCCL_DEBUG=VERSION, gloo's
-    # connection notice), so stdout is pointed at stderr for the duration and the line is written to the real one.
-    sys.stdout.flush()
-    real_stdout = os.dup(1)
-    os.dup2(2, 1)
+def launch_ranks(args, argv):
+    """`python3 bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks as CHILD processes (the driver's
+    own form: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py ...),
+    forward rank 0's JSON line, return the children's exit code.  This process never imports torch and never touches a GPU
+    (a process that has initialised the GPU must not exec or be replaced: the ranks are fresh children).  Whatever happens
+    — a rank that dies, a collective that stalls, no GPU at all — ONE line goes out: the children's, or one that says why
+    there is none."""
+    import signal
+    import socket
+    import subprocess
 
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # this pool's driver supports dmabuf IPC only (RCCL across processes)
+    env["JL_BENCH_LAUNCHED"] = "1"
+    sys.stderr.write("bench.py: starting %d ranks: %s\n" % (args.gpus, " ".join(cmd)))
+    sys.stderr.flush()
+    child = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, start_new_session=True)   # (its own process group: killed as one)
+    lines = []
+
+    def reader():
+        for raw in child.stdout:
+            lines.append(raw.decode(errors="replace"))
+    th = threading.Thread(target=reader, daemon=True)
+    th.start()
+    deadline = args.run_timeout + 90.0       # the ranks' own watchdog fires first and still writes a line
+    reason = None
+    try:
+        rc = child.wait(timeout=deadline)
+    except subprocess.TimeoutExpired:
+        reason = f"the ranks did not finish within {deadline:.0f} s; their process group was killed"
+        for sig in (signal.SIGTERM, signal.SIGKILL):
+            try:
+                os.killpg(child.pid, sig)    # exactly the group started above
+            except ProcessLookupError:
+                break
+            try:
+                child.wait(timeout=10)
+                break
+            except subprocess.TimeoutExpired:
+                continue
+        rc = child.returncode if child.returncode is not None else 124
+    th.join(timeout=5)
+    line = None
+    for ln in lines:
+        t = ln.strip()
+        if t.startswith("{"):
+            try:
+                if "metric" in json.loads(t):
+                    line = t
+            except ValueError:
+                pass
+    if line is None:
+        line = json.dumps({"metric": "aligned CCS reads/sec through juliet call+phase", "value": None, "unit": "reads/s", "n_gpus": args.gpus,
+                           "steps": args.steps, "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": "weak",
+                           "vs_baseline": None, "data": "synthetic",
+                           "error": reason or f"the ranks ended with exit code {rc} and without a result line (their messages are on stderr)"})
+        if rc == 0:
+            rc = 1
+    sys.stdout.write(line + "\n")
+    sys.stdout.flush()
+    return rc
+
+
+def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=16000)   # 2000 launches of 8 windows, about 0.4 s timed
@@ -158,7 +222,18 @@ def main():
     ap.add_argument("--group", type=int, default=8,
                     help="batches (windows) per launch: 1 = one graph per batch (jl_run_async), G > 1 = group runs "
                          "(jl_group_run_async: one pileup / call / phase launch for G windows)")
+    ap.add_argument("--run-timeout", type=float, default=900.0,
+                    help="N > 1: seconds the whole run may take; then rank 0 writes the line with what was measured and every rank exits 3")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher around us: be the launcher (decided before torch is imported or any GPU call is made)
+        sys.exit(launch_ranks(args, sys.argv[1:]))
+
+    # The contract is ONE JSON line on stdout.  Libraries print banners there (RCCL with NCCL_DEBUG=VERSION, gloo's
+    # connection notice), so stdout is pointed at stderr for the duration and the line is written to the real one.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
 
     import torch
     import torch.distributed as dist
@@ -175,12 +250,58 @@ def main():
     # a launcher that narrows the visible devices per rank (HIP_VISIBLE_DEVICES) leaves one device, index 0
     n_dev = torch.cuda.device_count()
     if n_dev < 1:
-        raise SystemExit("bench.py: no GPU visible (the product path has no CPU fallback)")
+        sys.stderr.write(f"bench.py: rank {rank}: no GPU visible (the product path has no CPU fallback)\n")
+        sys.stderr.flush()
+        if world > 1:
+            time.sleep(0.5)   # (the peers were started at the same moment: let them say so too before the launcher ends the group)
+        raise SystemExit(4)
     local_rank %= n_dev
     torch.cuda.set_device(local_rank)
     # JL_BENCH_FORCE_DIST=1 drives the N > 1 code path (process group, RCCL bootstrap, all-gather) with one rank
     distributed = world > 1 or os.environ.get("JL_BENCH_FORCE_DIST") == "1"
+
+    # What the line holds so far: filled in as the legs complete.  At N > 1 ONE watchdog covers the whole run, armed before the
+    # process group and the communicator are made — the first real ncclAllGather between two devices, the grouped send / recv
+    # and the in-place all-gather in pinned host memory have never run on hardware: whatever stalls, rank 0 writes
+    # the line with what was measured plus "error", and every rank leaves with a fresh exit (never a re-exec).
+    out = {"metric": "aligned CCS reads/sec through juliet call+phase", "value": None, "unit": "reads/s", "n_gpus": world,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "u3 symbols as bit planes / u32 counts / f64 p-values", "data": "synthetic"}
+    stage = {"at": "start"}
+    left = threading.Lock()
+
+    def leave(reason, code=3):
+        if not left.acquire(blocking=False):
+            return               # (another timer is already writing the line)
+        out["error"] = f"{reason} (rank {rank}, at: {stage['at']})"
+        if not args.no_config3:
+            out.setdefault("config3_strong", {"error": reason, "scaling": "strong", "n_gpus": world})
+            out.setdefault("config4_strong", {"error": reason, "scaling": "strong", "n_gpus": world})
+        if rank == 0:
+            os.write(real_stdout, (json.dumps(out) + "\n").encode())
+        sys.stderr.write(f"bench.py: rank {rank}: {out['error']}\n")
+        sys.stderr.flush()
+        os._exit(code)           # the line is out, and the failure shows in the exit code too
+
+    run_watchdog = threading.Timer(args.run_timeout, leave, (f"no result after --run-timeout {args.run_timeout:.0f} s",))
+    run_watchdog.daemon = True
     if distributed:
+        run_watchdog.start()
+        _LEAVE[0] = leave        # (an exception on this rank: the peers are inside a collective — see the bottom of the file)
+        # A launcher that ends the ranks because ONE of them failed sends SIGTERM: rank 0 still writes the line.  The main
+        # thread may be inside a C call (a collective that waits for the failed peer) where no Python handler runs, so the
+        # signal's number goes to a pipe (set_wakeup_fd: written by the C-level handler at once) that a thread waits on.
+        import signal
+        rfd, wfd = os.pipe()
+        os.set_blocking(wfd, False)
+        signal.signal(signal.SIGTERM, lambda *_: None)
+        signal.set_wakeup_fd(wfd, warn_on_full_buffer=False)
+
+        def on_term():
+            os.read(rfd, 1)
+            leave("terminated by the launcher (SIGTERM: a peer rank failed or the job was cancelled)")
+        threading.Thread(target=on_term, daemon=True).start()
+        stage["at"] = "process group (gloo)"
         # control plane only (id broadcast, barrier, max-reduce of the timing): gloo.  The data-path collective is
         # RCCL through the C ABI (jl_allgather_variants).  A torch NCCL process group would add watchdog threads
         # that measurably slow the single-threaded step loop (0.071 vs 0.046 ms/step at world = 1).
@@ -229,6 +350,7 @@ def main():
         dist.broadcast(t, 0)
         idbuf = t.cpu().numpy()
         comm = C.c_void_p()
+        stage["at"] = "jl_comm_create (ncclCommInitRank)"
         jl._chk(jl.lib.jl_comm_create(jl.h, idbuf.ctypes.data_as(C.c_void_p), rank, world, C.byref(comm)))
         # room for the exchanges of one launch's windows, collected by ONE call (jl_allgather_variants_many); 128 rows per
         # rank and window is the stride the compact exchange itself carries (JL_PACK_MAX_VAR)
@@ -243,9 +365,19 @@ def main():
     bound = comm is not None and G > 1 and os.environ.get("JL_BENCH_EXCHANGE", "bound") == "bound"
     gpending = {}                        # bound form: exchanges in flight per group
     if bound:
+        stage["at"] = "jl_group_exchange_bind (trial all-gather in pinned host memory)"
         for grp_ in groups:
             grp_.bind_exchange(comm)
         exchange = "RCCL all-gather of the table heads, carried by the launch (jl_group_exchange_bind)"
+    rccl_ranks = exchange_form = None
+    if comm is not None:
+        ci = [C.c_int(0) for _ in range(4)]
+        jl._chk(jl.lib.jl_comm_info(comm, *[C.byref(x) for x in ci]))
+        rccl_ranks = ci[0].value
+        exchange_form = ("bound-host: in-place all-gather in pinned host memory" if ci[3].value == 1 else
+                         "staged: device region + heads_to_host kernel" if ci[3].value == 0 else
+                         "worker: gather kernel + all-gather + copy on the communicator's stream")
+    stage["at"] = "set-up runs"
     pending = {id(c): 0 for c in ctxs}   # exchanges enqueued and not yet collected, per context
     state = dict(checked=0, gathered_rows=0)
 
@@ -417,8 +549,11 @@ def main():
         newest = inflight[-1][1] if inflight else None
         while inflight:
             i_done = None
+            t_poll = time.perf_counter()
             while i_done is None and len(inflight) > 1:      # (polling the completion words: 0.14 us each)
                 i_done = next((i for i, (_, m) in enumerate(inflight) if all(c.run_done() for c in m)), None)
+                if i_done is None and time.perf_counter() - t_poll > 20.0:
+                    break            # a run that never stores its completion word: the in-order collect below waits on its stream and reports
             i_done = i_done or 0
             members = inflight.pop(i_done)[1]
             out = collect(members, final=True, retire=bool(inflight))   # (the closing fence retires the last launch's stream)
@@ -453,8 +588,10 @@ def main():
         for c in ctxs:
             drain(c, pending[id(c)])
     fence()
+    stage["at"] = "warm-up steps"
     run_steps(args.warmup)
     fence()
+    stage["at"] = "timed steps"
     t0 = time.perf_counter()
     if trace is not None:
         del trace[:]
@@ -474,6 +611,11 @@ def main():
         elapsed = float(tt.item())
     ms_per_step = 1000.0 * elapsed / args.steps
     table, ph = last["variants"], last["phase"]
+    # (the headline figure is measured: whatever happens from here on, it is in the line)
+    out.update({"metric": "aligned CCS reads/sec through juliet call+phase" + (" (weak scaling: independent windows per GPU; strong scaling "
+                                                                                  "of one reference: config3_strong, config4_strong)" if world > 1 else ""),
+                "value": world * n / (ms_per_step * 1e-3), "ms_per_step": ms_per_step})
+    stage["at"] = "latency legs"
 
     # latency of ONE batch through the path (its own graph, nothing else on the GPU), for the record
     def one_batch():
@@ -548,28 +690,16 @@ def main():
             traffic = None
 
     step_bytes = n * l * 3.0 / 8.0
-    out = {
-        # at N > 1 `value` is WEAK scaling (one independent 100k x 3kb window per GPU and batch); ONE reference split over
-        # the GPUs (strong scaling) is config3_strong / config4_strong in the same line
-        "metric": "aligned CCS reads/sec through juliet call+phase" + (" (weak scaling: independent windows per GPU; strong scaling "
-                                                                        "of one reference: config3_strong, config4_strong)" if world > 1 else ""),
-        "value": world * n / (ms_per_step * 1e-3),
-        "unit": "reads/s",
-        "n_gpus": world,
-        "steps": args.steps,
-        "warmup": args.warmup,
-        "ms_per_step": ms_per_step,
-        "higher_is_better": True,
-        "scaling": "weak",
-        "vs_baseline": None,
-        "dtype": "u3 symbols as bit planes / u32 counts / f64 p-values",
-        "data": "synthetic",
+    # at N > 1 `value` is WEAK scaling (one independent 100k x 3kb window per GPU and batch); ONE reference split over
+    # the GPUs (strong scaling) is config3_strong / config4_strong in the same line
+    out.update({
         "config": {"workload": f"configs[2]: {n} CCS reads x {l} bp reference per GPU, pileup + Fisher-exact + phasing "
                                "(96% major + four 1% minor haplotypes, sub 1.75e-4, del 1.3e-3, N 2e-2); every resident "
                                "batch holds different reads",
                    "reads_per_gpu": n, "ref_columns_per_gpu": l,
                    "parallelism": f"window-sharded x{world}, {exchange}" if distributed
                    else "single GPU",
+                   "rccl_ranks": rccl_ranks, "exchange_form": exchange_form,
                    "batches_per_launch": G, "launches_in_flight": n_flight, "resident_batches": len(ctxs),
                    "one_batch_latency_ms": latency_ms, "one_batch_latency_c_abi_ms": latency_c_ms,
                    "many_positions_latency_ms": many_ms, "many_positions_latency_c_abi_ms": many_c_ms, "many_positions": many_positions if many_ms is not None else None,
@@ -590,7 +720,7 @@ def main():
                      "one_batch_frac": step_bytes / (latency_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                      "step_achieved": step_bytes / (ms_per_step * 1e-3) / 1e9,
                      "step_frac": step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
-    }
+    })
     for g in (groups or []) + list(partial_groups.values()):
         g.close()
     if not args.no_once_through and (n, l) == (N_READS, N_COLS):
@@ -599,17 +729,17 @@ def main():
                                                win_begin, args.once_steps)
         except (OSError, capi.JulietError) as exc:   # the generator binary is missing, or the leg failed: the main figures stand
             out["once_through"] = {"error": repr(exc)}
+        try:
+            out["once_through_qv"] = once_through(capi, synth, torch, jl, genes, refseq, prm, expected[id(jl)], rank, local_rank, n, l,
+                                                  win_begin, args.once_steps, qv=True)
+        except (OSError, capi.JulietError) as exc:
+            out["once_through_qv"] = {"error": repr(exc)}
     if not args.no_config3:
         # The weak-scaling measurement above is complete.  The strong-scaling form adds two exchanges that have only ever
         # run with one rank on hardware: should it fail or stall on some rank, every rank leaves after
         # `--config3-timeout` seconds and the line still goes out with what was measured, the failure named in it.
-        def leave(reason):
-            out.setdefault("config3_strong", {"error": reason, "scaling": "strong", "n_gpus": world})
-            out.setdefault("config4_strong", {"error": reason, "scaling": "strong", "n_gpus": world})
-            if rank == 0:
-                os.write(real_stdout, (json.dumps(out) + "\n").encode())
-            os._exit(3)   # the line is out, and the failure shows in the exit code too
-        watchdog = threading.Timer(args.config3_timeout, leave, (f"no result after {args.config3_timeout} s",))
+        stage["at"] = "configs[3] / configs[4] strong scaling"
+        watchdog = threading.Timer(args.config3_timeout, leave, (f"configs[3]/[4]: no result after {args.config3_timeout} s",))
         watchdog.daemon = True
         if distributed:
             watchdog.start()
@@ -631,7 +761,8 @@ def main():
         ncores = usable_cores()
         if ncores > 1:
             out["cpu_baseline_all_cores"], _ = cpu_baseline(jl, genes, refseq, None, budget_s=6.0, threads=ncores, rows=rows_host)
-    if rank == 0:
+    run_watchdog.cancel()
+    if rank == 0 and left.acquire(blocking=False):
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if comm is not None:
@@ -642,29 +773,39 @@ def main():
         dist.destroy_process_group()
 
 
-def once_through(capi, synth, torch, jl0, genes, refseq, prm, expect, rank, local_rank, n, l, win_begin, steps):
+def once_through(capi, synth, torch, jl0, genes, refseq, prm, expect, rank, local_rank, n, l, win_begin, steps, qv=False):
     """A FRESH window per step: aligned records (positions, cigars, BAM's packed bases — what a BAM decoder
-    holds, resident in HBM as the brief prescribes for `value`) -> ingest into the bit planes (jl_records_window_async: three
+    holds, resident in HBM as the brief prescribes for `value`) -> ingest into the bit planes (jl_records_window_async: four
     launches) -> pileup -> Fisher -> phasing -> results in pinned host memory, the whole chain enqueued on one stream per
     window, four windows in flight.  The reads are those of resident batch 0 (same seed), so every step's result is compared
     with that batch's; four copies of the records at different addresses and four window matrices rotate, so no step finds
     its records or its planes in the 256 MiB Infinity Cache."""
-    rec = synth.raw_records(1000 * (rank + 1), n, l, ref_seed=2 + rank)
+    # qv (`once_through_qv`): the input the reference documents (`ccs --richQVs`, doc/JULIET.md:256-259, 273-276) — a filtered base
+    # keeps its LETTER and carries a low quality, so the cigars hold the true deletions and mismatches only (ten ops a read, not 127)
+    # and the records bring one quality byte per base (+300 MB a window); the N's appear when the ingest applies min_qv = 20
+    rec = synth.raw_records(1000 * (rank + 1), n, l, ref_seed=2 + rank, extra=("--rich-qv",) if qv else ())
+    min_qv = 20 if qv else 0
     K = J = 4
     recs, wins, streams = [], [], []
     for k in range(K):
         c = capi.Juliet(local_rank)
-        c.records_upload(rec["pos"], rec["cigar"], rec["cig_off"], rec["seq4"], rec["seq_off"])
+        if qv:
+            c.records_upload(rec["pos"], rec["cigar"], rec["cig_off"], rec["seq4"], rec["seq_off"], rec["qual"], rec["qual_off"])
+        else:
+            c.records_upload(rec["pos"], rec["cigar"], rec["cig_off"], rec["seq4"], rec["seq_off"])
         recs.append(c)
     for j in range(J):
         st = torch.cuda.Stream()
         streams.append(st)
         wins.append(capi.Juliet(local_rank, stream=st.cuda_stream))
-    record_bytes = sum(rec[k].nbytes for k in ("pos", "cigar", "cig_off", "seq4", "seq_off"))
+    rec_keys = ("pos", "cigar", "cig_off", "seq4", "seq_off") + (("qual", "qual_off") if qv else ())
+    record_bytes = sum(rec[k].nbytes for k in rec_keys)
+    parts = {k: int(rec[k].nbytes) for k in rec_keys}
+    ops_per_read = len(rec["cigar"]) / max(1, n)
     del rec
 
     def enqueue(j, s):
-        wins[j].records_window(recs[s % K], l, win_begin, 0, wait=False)
+        wins[j].records_window(recs[s % K], l, win_begin, min_qv, wait=False)
         wins[j].run_async(genes, refseq, prm, None, True, 10, True)
 
     def check(j):
@@ -701,16 +842,19 @@ def once_through(capi, synth, torch, jl0, genes, refseq, prm, expect, rank, loca
     with torch.cuda.stream(streams[0]):
         e0.record()
     for q in range(reps):
-        wins[0].records_window(recs[q % K], l, win_begin, 0, wait=False)
+        wins[0].records_window(recs[q % K], l, win_begin, min_qv, wait=False)
     with torch.cuda.stream(streams[0]):
         e1.record()
     e1.synchronize()
     t_ing = e0.elapsed_time(e1) / reps
     plane_bytes = 3 * l * wins[0].plane_stride
     io = record_bytes + 2 * plane_bytes          # records read + planes written (ingest) + planes read (pileup)
-    res = {"workload": f"a fresh window per step: records of {n} CCS reads x {l} bp (positions, cigars, 4-bit bases; resident in HBM) -> "
-                       "ingest into the bit planes -> pileup + Fisher + phasing -> results on the host; 4 windows in flight, "
+    res = {"workload": f"a fresh window per step: records of {n} CCS reads x {l} bp (positions, cigars, 4-bit bases"
+                       + (", one quality byte per base: the documented `ccs --richQVs` shape, filtered bases keep their letter, min_qv = 20"
+                          if qv else "; filtered bases travel as N letters") + "; resident in HBM) -> "
+                       "ingest into the bit planes (four launches) -> pileup + Fisher + phasing -> results on the host; 4 windows in flight, "
                        "every step's result verified",
+           "min_qv": min_qv, "cigar_ops_per_read": ops_per_read, "record_bytes_by_array": parts,
            "value": n / t, "unit": "reads/s", "ms_per_step": 1000.0 * t, "steps": steps, "cells_verified_before_loop": n * l,
            "record_bytes": record_bytes, "plane_bytes": plane_bytes,
            "bytes_per_step": io, "frac": io / t / 1e9 / HBM_PEAK_GBS,
@@ -872,5 +1016,18 @@ def config3_strong(capi, sharding, synth, torch, dist, distributed, comm, rank, 
 
 
 
+_LEAVE = [None]   # main()'s leave(reason), once a whole-run watchdog exists (N > 1)
+
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except SystemExit:
+        raise
+    except BaseException as exc:   # noqa: BLE001
+        # At N > 1 the other ranks are (or will be) inside a collective with this one: say what happened in the line (rank 0) and
+        # leave with a fresh exit; the peers leave by the launcher's SIGTERM or by their watchdogs.
+        if _LEAVE[0] is None:
+            raise
+        import traceback
+        traceback.print_exc()
+        _LEAVE[0](f"{exc!r}")

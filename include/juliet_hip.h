@@ -397,6 +397,11 @@ int jl_comm_create(jl_ctx *ctx, const uint8_t id[128], int rank, int world, jl_c
  * world calls this once.  Everything that takes a jl_comm works on it unchanged. */
 int jl_comm_create_inproc(jl_ctx *ctx, const uint8_t id[128], int rank, int world, jl_comm **out);
 void jl_comm_destroy(jl_comm *comm);
+/* What the communicator is, for a caller's records: rccl_ranks = what ncclCommCount reports (0: the in-process form, which has
+ * no RCCL communicator), rank / world as given at creation, exchange_form = how a group's bound exchange travels on it
+ * (-1 not decided yet: nothing was bound; 1 the all-gather works in place in pinned host memory; 0 staged: device region +
+ * heads_to_host kernel).  Any pointer may be null.  Match: SURVEY 8e (one all-gather of the variant table). */
+int jl_comm_info(jl_comm *comm, int *rccl_ranks, int *rank, int *world, int *exchange_form);
 /*
  * The one collective of the path: all-gather of the fixed-stride variant table over RCCL/xGMI.
  * all_rows[world*cap_rows], all_counts[world] are HOST outputs; rows of rank r start at r*cap_rows.

@@ -33,7 +33,7 @@ EXPORTS = ("jl_abi_version", "jl_strerror", "jl_device_count", "jl_ctx_create", 
            "jl_msa_ingest_records", "jl_records_begin", "jl_records_append", "jl_records_finish", "jl_records_window", "jl_records_window_async", "jl_records_drop", "jl_msa_track_insertions", "jl_insertions_fetch", "jl_msa_download", "jl_synth_fill", "jl_synth_fill_window", "jl_pileup_async", "jl_n_positions", "jl_pileup_fetch",
            "jl_consensus_fetch", "jl_call_async", "jl_call_fetch", "jl_variant_table_device", "jl_phase_async", "jl_phase_fetch",
            "jl_ctx_stream", "jl_run_async", "jl_run_wait", "jl_run_done", "jl_run_view_get", "jl_group_create", "jl_group_destroy",
-           "jl_group_last_error", "jl_group_run_async", "jl_group_run_masked_async", "jl_group_views", "jl_group_time_pileup", "jl_fisher_eval", "jl_fisher_eval_tail", "jl_expand_read_hap", "jl_time_run", "jl_time_pileup", "jl_time_pileup_set", "jl_run_pileup_clock", "jl_run_pileup_ms", "jl_pileup_kernel_name", "jl_comm_unique_id", "jl_comm_create", "jl_comm_create_inproc", "jl_comm_destroy",
+           "jl_group_last_error", "jl_group_run_async", "jl_group_run_masked_async", "jl_group_views", "jl_group_time_pileup", "jl_fisher_eval", "jl_fisher_eval_tail", "jl_expand_read_hap", "jl_time_run", "jl_time_pileup", "jl_time_pileup_set", "jl_run_pileup_clock", "jl_run_pileup_ms", "jl_pileup_kernel_name", "jl_comm_unique_id", "jl_comm_create", "jl_comm_create_inproc", "jl_comm_destroy", "jl_comm_info",
            "jl_allgather_variants", "jl_allgather_variants_async", "jl_allgather_variants_async_many", "jl_allgather_variants_many", "jl_group_exchange_bind", "jl_group_exchange_collect", "jl_xwin_plan", "jl_xwin_assemble_local",
            "jl_xwin_assemble_rccl", "jl_xwin_assemble_slice_local", "jl_xwin_assemble_slice_rccl", "jl_phase_groups_async",
            "jl_phase_groups_fetch", "jl_phase_regroup", "jl_merge_tables", "jl_merge_groups", "jl_select_haplotypes",
@@ -214,6 +214,7 @@ def load_library(path=LIB_PATH):
     lib.jl_comm_create_inproc.argtypes = [vp, vp, C.c_int, C.c_int, C.POINTER(vp)]
     lib.jl_comm_destroy.argtypes = [vp]
     lib.jl_comm_destroy.restype = None
+    lib.jl_comm_info.argtypes = [vp] + [C.POINTER(C.c_int)] * 4
     lib.jl_allgather_variants.argtypes = [vp, vp, vp, vp, u32]
     lib.jl_allgather_variants_async.argtypes = [vp, vp]
     lib.jl_allgather_variants_async_many.argtypes = [vp, u32, vp]

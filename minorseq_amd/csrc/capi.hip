@@ -368,7 +368,9 @@ int jl_records_begin(jl_ctx *ctx, uint64_t reads_hint, uint64_t cigar_words_hint
     if (e == hipSuccess) e = records_room(ctx, r.d_so, r.cap_so, 0, (size_t)reads_hint + 1, 0);
     if (e == hipSuccess) e = records_room(ctx, r.d_cig, r.cap_cig, 0, (size_t)cigar_words_hint, 64);
     if (e == hipSuccess) e = records_room(ctx, r.d_seq, r.cap_seq, 0, (size_t)seq_bytes_hint, 64);
-    if (e == hipSuccess && qual_bytes_hint) e = records_room(ctx, r.d_qual, r.cap_qual, 0, (size_t)qual_bytes_hint, 64);
+    // (the qualities begin 16 bytes into their array: the ingest reads a piece's 32 qualities from up to six bytes before a read's first)
+    r.n_qual = 16;
+    if (e == hipSuccess && qual_bytes_hint) e = records_room(ctx, r.d_qual, r.cap_qual, 0, (size_t)qual_bytes_hint + 16, 64);
     if (e == hipSuccess && qual_bytes_hint) e = records_room(ctx, r.d_qo, r.cap_qo, 0, (size_t)reads_hint + 1, 0);
     if (e != hipSuccess) {
         records_drop(ctx);
@@ -1575,6 +1577,7 @@ int jl_run_async(jl_ctx *ctx, const jl_gene *genes, uint32_t n_genes, const uint
         JL_HIP(ctx, hipGetLastError());
     }
     ctx->runs_launched++;
+    ctx->clock_run = ctx->pileup_clock ? ctx->runs_launched : 0u;   // (the run whose pileup the two clock nodes bracket)
     ctx->pileup_done = ctx->call_done = true;
     ctx->phase_done = phasing != 0;
     ctx->pack_valid = true;
@@ -1784,6 +1787,10 @@ int jl_run_pileup_ms(jl_ctx *ctx, float *ms, uint64_t *begin_ticks)
     if (!ctx || !ms) return JL_ERR_ARG;
     if (!ctx->pileup_clock) return jl_fail(ctx, JL_ERR_STATE, "jl_run_pileup_ms: the clock is off (jl_run_pileup_clock)");
     if (!ctx->pack_valid) return jl_fail(ctx, JL_ERR_STATE, "jl_run_pileup_ms needs a run");
+    // the two stamps belong to the last jl_run_async with the clock on; a group run, a run of another path or one enqueued
+    // before the clock was switched on carries no clock nodes: its stamps would be an older run's
+    if (ctx->clock_run == 0u || ctx->clock_run != ctx->runs_launched)
+        return jl_fail(ctx, JL_ERR_STATE, "jl_run_pileup_ms: the context's last run carried no clock nodes (only jl_run_async runs with the clock on do; group runs do not)");
     if (int rc = jl_run_wait_impl(ctx)) return rc;
     const volatile unsigned long long *t = reinterpret_cast<const volatile unsigned long long *>(const_cast<uint32_t *>(ctx->h_seq) + 8);
     *ms = (float)((double)(t[1] - t[0]) * 1e-5);      // 100 MHz ticks

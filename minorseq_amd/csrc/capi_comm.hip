@@ -465,6 +465,18 @@ static int comm_create(jl_ctx *ctx, const uint8_t id[128], int rank, int world, 
 
 int jl_comm_create(jl_ctx *ctx, const uint8_t id[128], int rank, int world, jl_comm **out) { return comm_create(ctx, id, rank, world, false, out); }
 
+int jl_comm_info(jl_comm *c, int *rccl_ranks, int *rank, int *world, int *exchange_form)
+{
+    if (!c) return JL_ERR_ARG;
+    int n = 0;
+    if (c->comm && ncclCommCount(c->comm, &n) != ncclSuccess) return JL_ERR_COMM;
+    if (rccl_ranks) *rccl_ranks = n;
+    if (rank) *rank = c->rank;
+    if (world) *world = c->world;
+    if (exchange_form) *exchange_form = c->host_gather;
+    return JL_OK;
+}
+
 int jl_comm_create_inproc(jl_ctx *ctx, const uint8_t id[128], int rank, int world, jl_comm **out)
 {
     return comm_create(ctx, id, rank, world, true, out);

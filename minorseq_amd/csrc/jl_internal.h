@@ -442,6 +442,7 @@ struct jl_ctx {
     std::vector<uint32_t> exch_runs;  // ... and the runs (values of runs_launched) whose blocks they read
     hipStream_t run_stream = nullptr;  // where the last run was enqueued (the ctx stream, or a group's)
     bool pileup_clock = false;        // jl_run_pileup_clock: clock nodes around the pileup of a run -> h_seq[8..11] (two 64-bit stamps)
+    uint32_t clock_run = 0;           // value of runs_launched of the run those stamps belong to (0: none)
     uint64_t *d_timeline = nullptr;   // JL_TIMELINE=1 only: [JL_TIMELINE_ROWS][JL_TIMELINE_SLOTS] device clock stamps
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;

@@ -312,10 +312,15 @@ __global__ __launch_bounds__(256, JL_RUNS_WAVES) void cigar_runs_kernel(uint64_t
             const uint32_t s = s0 + sl;
             // f = the number of entries that begin at or before the sweep's first column (entry 0 always does, the last never)
             const uint32_t X = min(s, n_sweeps) * kSweep;   // (lanes past the last bound repeat it)
+            // The bound BEHIND the window's last sweep is the window's last column, not n_sweeps * kSweep: every run beyond the
+            // window is clamped to column n_cols, and counted up to there all of a long read's runs behind the window were
+            // entries of its last sweep (six of them and the unit went to the second size, 255 and the read to slow_pair: right
+            // cells, but `juliet --windows N` paid for it in every window).  Up to n_cols - 1 the first clamped entry closes the list.
+            const uint32_t X_bound = s >= n_sweeps ? n_cols - 1u : X;
             uint32_t f = 0;
             for (uint32_t step = top; step; step >>= 1) {
                 const uint32_t t = f + step;
-                if (live && !is_long && t <= n_ent_all && (entry(t - 1u).x & kRunMask) <= X) f = t;
+                if (live && !is_long && t <= n_ent_all && (entry(t - 1u).x & kRunMask) <= X_bound) f = t;
             }
             const uint32_t f_next = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)f, 0x101, 0xF, 0xF, false);   // row_shl:1
             if (!live || is_long || sl == kDescSweeps || s >= n_sweeps) continue;
@@ -558,33 +563,26 @@ __device__ __forceinline__ void piece_bases(const ingest_args &a, const u32x4 &v
 #pragma unroll
     for (int k = 0; k < 4; ++k) S[k] = ((w4[k] >> 4) & 0x0F0F0F0Fu) | ((w4[k] & 0x0F0F0F0Fu) << 4);
     if (QV) {
-        // qualities of the piece's bases, one byte each, from the aligned dwords around them (0xFF = absent never masks)
-        const int lo_v = Q < 0 ? -Q : 0;
-        const uint64_t addr = qual_base + (uint64_t)(Q + lo_v);    // first quality wanted
-        const uint32_t *qp = reinterpret_cast<const uint32_t *>(a.qual + (addr & ~(uint64_t)3));
-        const uint32_t sh = (uint32_t)(addr & 3u);
-        uint32_t qw[9];
-#pragma unroll
-        for (int i = 0; i < 9; ++i) qw[i] = qp[i];
+        // The qualities of the piece's 32 bases, one byte each: two 16-byte loads at the BYTE address of the first (gfx950 takes
+        // unaligned dwordx4 loads; Q < 0 — the piece begins up to six bases before the read's own — reads the read before's
+        // last bytes, or the 16 bytes in front of the first read's (jl_records_begin): those bases are nobody's, whatever mask they
+        // get).  A base is masked when its quality is below min_qv (0xFF = absent, and anything above 127, never masks).
+        // Eight bases a step, the byte-parallel compare done on the even and on the odd bases' bytes apart (v_perm), so that the
+        // two results interleave into one flag per NIBBLE — the bases' own layout — with one shift: 13 instructions for eight
+        // bases (round 5: nine dword loads, eight v_alignbyte, flags gathered into bits and spread again: 30).
+        typedef uint32_t u32x4a1 __attribute__((ext_vector_type(4), aligned(1)));
+        const uint8_t *qp = a.qual + (int64_t)qual_base + (int64_t)Q;
+        const u32x4 qa = *reinterpret_cast<const u32x4a1 *>(qp), qb = *reinterpret_cast<const u32x4a1 *>(qp + 16);
+        const uint32_t q8[8] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w};
         const uint32_t T = a.min_qv * 0x01010101u;
-        uint32_t flags = 0;   // bit b: base lo_v + b is masked
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const uint32_t x = __builtin_amdgcn_alignbyte(qw[i + 1], qw[i], sh);
-            const uint32_t lt = ~((x | 0x80808080u) - T) & 0x80808080u;       // bytes below min_qv (and below 128)
-            uint32_t f = lt >> 7;
-            f = (f | (f >> 7)) & 0x00030003u;
-            f = (f | (f >> 14)) & 0xFu;
-            flags |= f << (4 * i);
-        }
-        flags <<= lo_v;   // by the piece's own base index (bases past 32 drop out; lo_v <= 30)
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            uint32_t b = (flags >> (8 * k)) & 0xFFu;
-            b = (b | (b << 12)) & 0x000F000Fu;
-            b = (b | (b << 6)) & 0x03030303u;
-            b = (b | (b << 3)) & 0x11111111u;
-            S[k] |= (b << 4) - b;   // 15 x b
+            const uint32_t ev = __builtin_amdgcn_perm(q8[2 * k + 1], q8[2 * k], 0x06040200u);   // qualities of bases 0 2 4 6 of the eight
+            const uint32_t od = __builtin_amdgcn_perm(q8[2 * k + 1], q8[2 * k], 0x07050301u);   // of bases 1 3 5 7
+            const uint32_t lt_e = ~((ev | 0x80808080u) - T) & ~ev & 0x80808080u;                // bit 7 of byte i: base 2 i is below min_qv
+            const uint32_t lt_o = ~((od | 0x80808080u) - T) & ~od & 0x80808080u;
+            const uint32_t c = lt_o | (lt_e >> 4);          // bit 3 of nibble j: base j is masked
+            S[k] |= c | (c - (c >> 3));                     // 8 -> 15 (N) in those nibbles
         }
     }
 }
@@ -1048,7 +1046,6 @@ void jl_launch_ingest(jl_ctx *ctx, const int32_t *d_pos, const uint32_t *d_cigar
     const uint32_t ns = jl_ingest_sweeps(ctx->n_cols);
     hipMemsetAsync(d_slow_count, 0, 8, st);
     if (!keep_verdict) hipMemsetAsync(d_slow_count + 2, 0xFF, 8, st);
-    if (ctx->n_reads)
     if (ctx->n_reads) {
         const uint32_t per_wg = 4u * kRunsReadsPerWave;
         unsigned long long *bad = reinterpret_cast<unsigned long long *>(d_slow_count + 2);

@@ -20,7 +20,7 @@ int main(int argc, char **argv)
     std::string out, cfg_out, from_rows, ref_string;
     struct Plant { uint32_t col, len, permille; };
     std::vector<Plant> plants;   // --insert col:len:permille — insertions before window column `col` in that share of the reads
-    bool rich_qv = false;  // filtered bases keep their letter and get a low substitution QV (sq tag) instead of 'N'
+    bool rich_qv = false;  // filtered bases keep their letter and get a low QV (BAM: the sq tag; --raw-out: the quality byte) instead of 'N'
     std::string raw_out;   // --raw-out file: the records as the arrays jl_records_append takes, no BAM (bench.py once_through)
     uint64_t ref_seed = 0;
     bool have_ref_seed = false;
@@ -160,7 +160,12 @@ int main(int argc, char **argv)
                 const uint32_t sy = jl_synth_cell(&pl, i, c, hap, st, en, ref[c]);
                 uint32_t op;
                 if (sy == 4) op = CIG_D;
-                else {
+                else if (rich_qv && sy == 5) {
+                    // as `ccs --richQVs` output looks (doc/JULIET.md:256-259, 273-276): the filtered base keeps its letter — a match
+                    // in the cigar — and carries a quality below any threshold; the N appears when the ingest applies min_qv
+                    op = CIG_EQ;
+                    push_base(nt16[ref[c]], (uint8_t)(2u + (jl_splitmix64(seed + 977ull * i + c) & 7u)));
+                } else {
                     op = (sy < 4 && sy == ref[c]) ? CIG_EQ : CIG_X;
                     push_base(nt16[sy < 4 ? sy : 4], (low_qv_ppm && (hc >> 20) % 1000000u < low_qv_ppm) ? (uint8_t)(4u + (hc >> 50) % 12u) : (uint8_t)93);
                 }

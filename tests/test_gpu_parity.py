@@ -1010,6 +1010,37 @@ def test_device_ingest_at_size(jl, n, l):
         jl.records_drop()
 
 
+def test_device_ingest_rich_qv_at_size(jl):
+    """The documented input shape at the bench's size (bench.py once_through_qv; doc/JULIET.md:256-259, 273-276): 100k x 3000
+    `ccs --richQVs`-style records — a filtered base keeps its letter and carries a low quality, ten cigar ops a read, one quality
+    byte per base — through the QV instantiations of both ingest kernels with min_qv = 20: every cell against the numpy
+    statement, three groups of 1024 reads against the generator's own rows (where the filtered bases are N), and the same
+    records without a threshold (min_qv = 0) keep their letters."""
+    n, l = 100_000, 3000
+    rec = synth.raw_records(5, n, l, extra=("--rich-qv",))
+    assert len(rec["cigar"]) / n < 16 and len(rec["qual"]) >= n * (l - 50)
+    jl.records_upload(rec["pos"], rec["cigar"], rec["cig_off"], rec["seq4"], rec["seq_off"], rec["qual"], rec["qual_off"])
+    w = capi.Juliet(0)
+    try:
+        w.records_window(jl, l, 0, 20)
+        assert _cells_equal(w, rec, n, l, 0, 20) is None
+        sp, ref = synth.SynthParams(seed=5), synth.reference(5, l)
+        packed = w.download_columns()
+        last = (n - 1) // 1024
+        for g in sorted({0, 52, last}):
+            r0, r1 = 1024 * g, min(n, 1024 * g + 1024)
+            got = msa.unpack_columns(np.ascontiguousarray(packed[:, r0 // 2:(r1 + 1) // 2]), r1 - r0)
+            assert (got == synth.rows(sp, l, r0, r1, ref)).all(), g
+        # a window that begins and ends inside the reads, on no sweep boundary
+        w.records_window(jl, 1777, 611, 20)
+        assert _cells_equal(w, rec, n, 1777, 611, 20) is None
+        w.records_window(jl, l, 0, 0)
+        assert _cells_equal(w, rec, n, l, 0, 0) is None
+    finally:
+        w.close()
+        jl.records_drop()
+
+
 @pytest.mark.parametrize("n,l,win,min_qv", [(24_000, 1100, (37, 1039), 20), (24_000, 1100, (0, 1100), 0), (21_000, 700, (300, 693), 20)])
 def test_device_ingest_qv_and_ragged_window_at_size(jl, n, l, win, min_qv):
     """Tens of groups through the QV path and through windows that begin inside the reads and end on no sweep boundary
@@ -1043,7 +1074,9 @@ def test_device_ingest_indel_rich_reads(jl, n, l, ins_ppm, del_rate, min_qv):
         jl.records_upload(rec["pos"], rec["cigar"], rec["cig_off"], rec["seq4"], rec["seq_off"])
     w = capi.Juliet(0)
     try:
-        for b, e in ((0, l), (131, l - 77)):
+        # (the third window ends in the MIDDLE of the reads: all of a read's runs behind it are clamped to its last column — ADVICE
+        # r05: counted as entries of the last sweep they sent every unit to the second size or to slow_pair)
+        for b, e in ((0, l), (131, l - 77), (200, l // 2 + 13)):
             w.records_window(jl, e - b, b, min_qv)
             assert _cells_equal(w, rec, n, e - b, b, min_qv) is None, (b, e)
     finally:

@@ -1,6 +1,6 @@
 """Record ingest on the device: 100k x 3000 synthetic records (juliet-synth --raw-out) -> planes, `reps` builds rotating over
 four record copies and two windows; run under rocprofv3 --kernel-trace --stats for the per-kernel times.
-usage: ingest_time.py [reads] [cols] [reps] [min_qv]"""
+usage: ingest_time.py [reads] [cols] [reps] [min_qv]   (min_qv > 0: rich-QV records, qualities resident)"""
 import os
 import sys
 import time
@@ -17,8 +17,9 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 100_000
 l = int(sys.argv[2]) if len(sys.argv) > 2 else 3000
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 40
 min_qv = int(sys.argv[4]) if len(sys.argv) > 4 else 0
-rec = synth.raw_records(2, n, l)
-print(f"{len(rec['cigar']) / n:.1f} ops per read, {sum(v.nbytes for k, v in rec.items() if not k.startswith('qual')) / 1e6:.1f} MB of records",
+# min_qv > 0: the documented `ccs --richQVs` shape — filtered bases keep their letter and carry a low quality (ten ops a read)
+rec = synth.raw_records(2, n, l, extra=("--rich-qv",) if min_qv else ())
+print(f"{len(rec['cigar']) / n:.1f} ops per read, {sum(v.nbytes for k, v in rec.items() if min_qv or not k.startswith('qual')) / 1e6:.1f} MB of records",
       flush=True)
 recs = []
 for k in range(4):
