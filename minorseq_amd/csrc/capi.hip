@@ -182,7 +182,7 @@ void jl_ctx_destroy(jl_ctx *ctx)
     if (ctx->h_scratch) hipHostFree(ctx->h_scratch);
     free_msa(ctx);
     records_drop(ctx);
-    void *ptrs[] = {ctx->d_pos_gene, ctx->d_pos_codon, ctx->d_pos_col, ctx->d_pos_refcfg, ctx->d_guess, ctx->d_chunks,
+    void *ptrs[] = {ctx->d_pos_gene, ctx->d_pos_codon, ctx->d_pos_col, ctx->d_pos_refcfg, ctx->d_col_head, ctx->d_pos_next, ctx->d_guess, ctx->d_chunks,
                     ctx->d_counts, ctx->d_called, ctx->d_staged, ctx->d_drm, ctx->d_variants, ctx->d_nvar, ctx->d_meta, ctx->d_vpcols,
                     ctx->d_col2pos, ctx->d_varcol, ctx->d_keys, ctx->d_flagw, ctx->d_read_slot, ctx->d_read_hap,
                     ctx->d_slot_rep, ctx->d_slot_count, ctx->d_slot_key, ctx->d_slot_hap, ctx->d_occupied, ctx->d_hap_count,
@@ -712,6 +712,7 @@ static int reserve_columns(jl_ctx *ctx)
         if ((rc = regrow(ctx, &ctx->d_guess, (size_t)ctx->n_cols + JL_GUESS_PAD))) return rc;
         if ((rc = regrow(ctx, &ctx->d_col2pos, ctx->n_cols))) return rc;
         if ((rc = regrow(ctx, &ctx->d_varcol, ctx->n_cols))) return rc;
+        if ((rc = regrow(ctx, &ctx->d_col_head, ctx->n_cols))) return rc;
         ctx->counts_words = (size_t)ctx->n_cols * (6 + 64);
         if ((rc = regrow(ctx, &ctx->d_counts, ctx->counts_words))) return rc;
         ctx->col_capacity = ctx->n_cols;
@@ -820,6 +821,7 @@ static int build_plan(jl_ctx *ctx, const jl_gene *genes, uint32_t n_genes, const
         if ((rc = regrow(ctx, &ctx->d_pos_codon, P))) return rc;
         if ((rc = regrow(ctx, &ctx->d_pos_col, P))) return rc;
         if ((rc = regrow(ctx, &ctx->d_pos_refcfg, P))) return rc;
+        if ((rc = regrow(ctx, &ctx->d_pos_next, P))) return rc;
         if ((rc = regrow(ctx, &ctx->d_called, P))) return rc;
         if ((rc = regrow(ctx, &ctx->d_staged, P * 64))) return rc;
         if ((rc = regrow(ctx, &ctx->d_drm, P))) return rc;
@@ -845,7 +847,15 @@ static int build_plan(jl_ctx *ctx, const jl_gene *genes, uint32_t n_genes, const
     JL_HIP(ctx, hipMemcpyAsync(ctx->d_chunks, recs.data(), recs.size() * 8, hipMemcpyHostToDevice, st));
     // the pad behind the last column is zero; in majority mode guess_kernel overwrites [0, n_cols) only
     JL_HIP(ctx, hipMemcpyAsync(ctx->d_guess, guess.data(), guess.size(), hipMemcpyHostToDevice, st));
+    // the positions by column (the folded Fisher stage looks its positions up by the column it has just counted)
+    std::vector<uint32_t> col_head(ctx->n_cols, 0xFFFFFFFFu), pos_next(P, 0xFFFFFFFFu);
+    for (uint32_t q = ctx->P; q-- > 0;) {      // (from the last: the lists come out in position order)
+        pos_next[q] = col_head[ctx->h_pos_col[q]];
+        col_head[ctx->h_pos_col[q]] = q;
+    }
+    if (ctx->n_cols) JL_HIP(ctx, hipMemcpyAsync(ctx->d_col_head, col_head.data(), (size_t)ctx->n_cols * 4, hipMemcpyHostToDevice, st));
     if (ctx->P) {
+        JL_HIP(ctx, hipMemcpyAsync(ctx->d_pos_next, pos_next.data(), P * 4, hipMemcpyHostToDevice, st));
         JL_HIP(ctx, hipMemcpyAsync(ctx->d_pos_gene, ctx->h_pos_gene.data(), P * 4, hipMemcpyHostToDevice, st));
         JL_HIP(ctx, hipMemcpyAsync(ctx->d_pos_codon, ctx->h_pos_codon.data(), P * 4, hipMemcpyHostToDevice, st));
         JL_HIP(ctx, hipMemcpyAsync(ctx->d_pos_col, ctx->h_pos_col.data(), P * 4, hipMemcpyHostToDevice, st));
@@ -1438,9 +1448,18 @@ static void enqueue_path(jl_ctx *ctx, const jl_params *prm, double n_tests, bool
     if (!ctx->have_ref) jl_launch_guess(ctx, st);
     jl_launch_stamp(ctx, 0);
     if (ctx->pileup_clock) jl_launch_clock(ctx, st, 0);
-    jl_launch_pileup(ctx, st);
-    if (ctx->pileup_clock) jl_launch_clock(ctx, st, 1);
-    jl_launch_call(ctx, st, prm, n_tests, use_drm, phasing);
+    if (jl_pileup_can_fold(ctx)) {
+        // every chunk is counted by ONE workgroup: it tests its codon from the histogram still in LDS (kernels_pileup.hip) —
+        // no call launch, 8 us of a 64 us window
+        jl_win_call w;
+        jl_fill_win_call(ctx, prm, n_tests, use_drm, phasing, &w);
+        jl_launch_pileup_fold(ctx, st, &w);
+        if (ctx->pileup_clock) jl_launch_clock(ctx, st, 1);
+    } else {
+        jl_launch_pileup(ctx, st);
+        if (ctx->pileup_clock) jl_launch_clock(ctx, st, 1);
+        jl_launch_call(ctx, st, prm, n_tests, use_drm, phasing);
+    }
     jl_launch_stamp(ctx, 1);
     // The completion word (jl_run_wait) is stored by a one-thread node of its own behind the last stage: the end of
     // that stage's kernel is what pushes the results every compute die wrote for the host out of the dies' L2s.

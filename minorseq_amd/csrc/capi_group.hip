@@ -43,6 +43,7 @@ struct jl_group {
     jl_done_ent *d_done = nullptr;
     std::vector<jl_win_pileup> h_pile;
     std::vector<jl_win_call> h_call;
+    std::vector<jl_win_fold> h_fold;      // the Fisher stage as the pileup launch's epilogue (every chunk is counted by one workgroup)
     std::vector<jl_win_compact> h_compact;
     std::vector<jl_win_phase> h_phase;
     struct chunk_t { uint32_t first, n, max_chunks, max_call_blocks, max_phase_blocks; bool fold; };
@@ -87,7 +88,8 @@ static int group_fail(jl_group *g, int status, const char *msg)
 // the latency-bound stages of one chunk, on `st`
 static void chunk_tail(jl_group *g, const jl_group::chunk_t &c, hipStream_t st)
 {
-    jl_launch_call_group(g->h_call.data() + c.first, c.n, c.max_call_blocks, st);
+    // (the Fisher stage ran in the pileup launch's epilogue: kernels_pileup.hip FOLD)
+    if (!jl_fold_enabled()) jl_launch_call_group(g->h_call.data() + c.first, c.n, c.max_call_blocks, st);
     if (!g->phasing) {
         jl_launch_compact_group(g->h_compact.data() + c.first, c.n, st);
     } else {
@@ -110,7 +112,8 @@ static int group_enqueue(jl_group *g)
     bool side_used[JL_GROUP_SIDE_STREAMS] = {false, false};
     for (size_t k = 0; k < nc; ++k) {
         const jl_group::chunk_t &c = g->chunks[k];
-        int rc = jl_launch_pileup_group(g->ctxs.data() + c.first, c.n, g->h_pile.data() + c.first, c.max_chunks, g->stream);
+        int rc = jl_fold_enabled() ? jl_launch_pileup_fold_group(g->ctxs.data() + c.first, c.n, g->h_pile.data() + c.first, g->h_fold.data() + c.first, c.max_chunks, g->stream)
+                                   : jl_launch_pileup_group(g->ctxs.data() + c.first, c.n, g->h_pile.data() + c.first, c.max_chunks, g->stream);
         if (rc) return rc;
         if (k + 1 < nc) {   // the tail runs beside the next chunk's pileup
             hipStream_t st = g->side[k % JL_GROUP_SIDE_STREAMS];
@@ -146,6 +149,7 @@ int jl_group_create(jl_ctx *const *ctxs, uint32_t n_ctx, jl_group **out)
     g->ctxs.assign(ctxs, ctxs + n_ctx);
     g->h_pile.resize(n_ctx);
     g->h_call.resize(n_ctx);
+    g->h_fold.resize(n_ctx);
     g->h_compact.resize(n_ctx);
     g->h_phase.resize(n_ctx);
     bool ok = hipSetDevice(g->device) == hipSuccess &&
@@ -287,6 +291,7 @@ int jl_group_run_masked_async(jl_group *g, const jl_gene *genes, uint32_t n_gene
                 jl_ctx *x = g->ctxs[k];
                 jl_fill_win_pileup(x, &g->h_pile[k]);
                 jl_fill_win_call(x, prm, n_tests[k], drm_masks && drm_masks[k], phasing != 0, &g->h_call[k]);
+                jl_fill_win_fold(x, &g->h_call[k], &g->h_fold[k]);
                 jl_fill_win_compact(x, false, true, false, &g->h_compact[k]);
                 jl_fill_win_phase(x, min_reads, false, c.fold ? 0xFFFFFFFFu : 0u, true, &g->h_phase[k]);
                 c.max_chunks = std::max(c.max_chunks, g->h_pile[k].n_chunks);
@@ -477,7 +482,9 @@ int jl_group_time_pileup(jl_group *const *groups, uint32_t n_groups, uint32_t re
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return group_fail(g0, JL_ERR_DEVICE, "events");
     auto launch = [&](jl_group *g) {
         const jl_group::chunk_t &c = g->chunks[0];
-        return jl_launch_pileup_group(g->ctxs.data() + c.first, c.n, g->h_pile.data() + c.first, c.max_chunks, g0->stream);
+        // (the launch the group's runs make: the pileup with the Fisher stage in its epilogue)
+        if (!jl_fold_enabled()) return jl_launch_pileup_group(g->ctxs.data() + c.first, c.n, g->h_pile.data() + c.first, c.max_chunks, g0->stream);
+        return jl_launch_pileup_fold_group(g->ctxs.data() + c.first, c.n, g->h_pile.data() + c.first, g->h_fold.data() + c.first, c.max_chunks, g0->stream);
     };
     int rc = JL_OK;
     for (uint32_t k = 0; k < n_groups && rc == JL_OK; ++k) rc = launch(groups[k]);   // warm-up, once per group

@@ -246,6 +246,13 @@ struct jl_call_group_args { jl_win_call w[JL_GROUP_MAX]; };
 struct jl_compact_group_args { jl_win_compact w[JL_GROUP_MAX]; };
 struct jl_phase_group_args { jl_win_phase w[JL_GROUP_MAX]; };
 struct jl_pileup_group_args { jl_win_pileup w[JL_GROUP_WINDOWS_MAX]; };
+// the Fisher stage of a window, evaluated by the pileup workgroup that counted the codon (one workgroup per chunk): the call
+// stage's own argument block + the positions by column
+struct jl_win_fold {
+    jl_win_call c;
+    const uint32_t *col_head, *pos_next;
+};
+struct jl_pileup_fold_group_args { jl_win_pileup w[JL_GROUP_MAX]; jl_win_fold f[JL_GROUP_MAX]; };
 
 // exchange: the heads of the result blocks of up to JL_GATHER_MAX windows copied next to each other (one send buffer,
 // one all-gather for the launch)
@@ -365,6 +372,10 @@ struct jl_ctx {
     uint32_t *d_pos_gene = nullptr, *d_pos_codon = nullptr, *d_pos_col = nullptr;
     uint8_t *d_pos_refcfg = nullptr;
     size_t pos_capacity = 0;
+    // the positions by column, for the Fisher stage folded into the pileup launch (kernels_pileup.hip): col_head[c] = the first
+    // position whose codon begins at column c (all ones: none), pos_next[p] = the next one at the same column (genes that overlap
+    // in one frame)
+    uint32_t *d_col_head = nullptr, *d_pos_next = nullptr;
     uint8_t *d_guess = nullptr;    // [n_cols + JL_GUESS_PAD] base the codon compare is seeded with (never affects
                                    // results); the zeroed pad lets the kernel fetch it as aligned dwords
     size_t col_capacity = 0;
@@ -469,6 +480,13 @@ int jl_fail(jl_ctx *ctx, int status, const char *fmt, ...);
 // kernel launchers (defined in the .hip files) -------------------------------------------------
 void jl_launch_guess(jl_ctx *ctx, hipStream_t st);
 void jl_launch_pileup(jl_ctx *ctx, hipStream_t st);
+// The pileup launch with the Fisher stage in its epilogue (runs only; every chunk counted by ONE workgroup): false = not
+// possible for this shape (the reads of a column are split over several workgroups), nothing was launched.
+bool jl_pileup_can_fold(jl_ctx *ctx);
+bool jl_fold_enabled(void);
+void jl_launch_pileup_fold(jl_ctx *ctx, hipStream_t st, const jl_win_call *call);
+void jl_fill_win_fold(jl_ctx *ctx, const jl_win_call *call, jl_win_fold *f);
+int jl_launch_pileup_fold_group(jl_ctx *const *ctxs, uint32_t n_win, const jl_win_pileup *h_wins, const jl_win_fold *h_fold, uint32_t max_chunks, hipStream_t st);
 uint32_t jl_pileup_rsplit(jl_ctx *ctx);
 bool jl_pileup_needs_zero(jl_ctx *ctx);
 void jl_prepare_pileup(jl_ctx *ctx);

@@ -83,6 +83,7 @@ constexpr uint32_t kRunsReadsPerWave = 4u;   // a wave takes four reads a turn
 #define JL_RUNS_LDS_SMALL 64u
 #endif
 constexpr uint32_t kRunsLdsSmall = JL_RUNS_LDS_SMALL, kRunsLdsLarge = 512u;
+constexpr uint32_t kRunsDeferred = 0xFFFFFFFFu;   // nruns[r] of a read the first launch (cigar_walk_kernel) leaves to the second
 constexpr uint32_t kRunsLongGrid = 1024u;     // workgroups of the second launch at most: its waves take 64 reads at a time, in turns
 constexpr uint32_t kDescSweeps = 15u;       // sweeps a row of sixteen lanes describes per pass (it needs sixteen bounds)
 constexpr uint32_t kDescMax = 255u;         // "more than the planes kernel takes": pieces or entries of a (read, sweep)
@@ -147,7 +148,7 @@ __global__ __launch_bounds__(256, JL_RUNS_WAVES) void cigar_runs_kernel(uint64_t
     for (uint64_t i0 = ((uint64_t)blockIdx.x * 4u + wid) * (LONG ? 64u : kRunsReadsPerWave); i0 < n_reads; i0 += turn) {
     // LONG: which of the sixty-four reads from i0 on are long ones, taken four at a time
     uint64_t todo = 1;
-    if (LONG) todo = __ballot(i0 + lane < n_reads && nruns[min(i0 + lane, n_reads - 1u)] + 3u > kRunsLdsSmall);
+    if (LONG) todo = __ballot(i0 + lane < n_reads && nruns[min(i0 + lane, n_reads - 1u)] == kRunsDeferred);   // (left to this launch by cigar_walk_kernel)
     while (todo) {
     uint64_t r = i0 + q;
     if (LONG) {
@@ -386,6 +387,181 @@ __global__ __launch_bounds__(256, JL_RUNS_WAVES) void cigar_runs_kernel(uint64_t
     }
     if (!LONG) break;                     // (the first launch has a wave for every four reads)
     }
+}
+
+// ---------------------------------------------------------------------------------------- runs, a thread a read
+// The first launch of a build (round 6; it replaces cigar_runs_kernel<64, false>, which gave a row of sixteen lanes to every read:
+// 24 x 10^6 wave instructions and 47-50 us for 100k reads of 127 ops, 36 us for the ten ops of a `ccs --richQVs` read — the scans,
+// the LDS copy of the entries and a binary search per sweep done by every row, for lists a dozen entries long).  A workgroup takes
+// 64 reads:
+//   1  ONE THREAD a read (the first wave): the ops, sixteen a step in registers (four 16-byte loads in flight, the next step's
+//      asked for before this one's are looked at) -> the read's ENTRIES in LDS.  No store to HBM in this pass: vmcnt counts loads
+//      and stores in one order, and forms of this kernel that stored entries while walking waited for every store's
+//      acknowledgement at each new load of ops (32-61 us for ten ops, 144-720 us for 127).
+//   2  a thread a (read, sweep) pair, all four waves — the 64 lanes of a wave write one sweep's descriptors of the 64 reads, 1 KB a
+//      store: the last entry that begins at or before the sweep's first column by bisection, then the sweep's entries up to the
+//      first that begins behind its last column.  Then the entries go out.
+// (One thread a read for BOTH passes — a dozen descriptors one after the other — was 25 us for ten ops: a wave is alone on its
+// SIMD then, 1563 waves for 1024 SIMDs, and the length of the dependent chain is all that counts.)
+// A read with more than kWalkOps ops or more than kWalkEnt entries is left, whole, to the launch with a row of lanes a read:
+// nruns[r] = kRunsDeferred.
+constexpr uint32_t kWalkOps = 192u;
+constexpr uint32_t kWalkEnt = 24u;      // entries of a read in LDS (a CCS read has a dozen)
+constexpr uint32_t kWalkReads = 64u;    // reads of a workgroup
+
+__global__ __launch_bounds__(256) void cigar_walk_kernel(uint64_t n_reads, const int32_t *__restrict__ pos, const uint32_t *__restrict__ cigar,
+                                                         const uint64_t *__restrict__ cig_off, const uint64_t *__restrict__ seq_off,
+                                                         const uint64_t *__restrict__ qual_off, uint32_t win_begin, uint32_t n_cols,
+                                                         uint32_t n_sweeps, uint2 *__restrict__ runs, uint32_t *__restrict__ nruns,
+                                                         uint4 *__restrict__ desc, unsigned long long *__restrict__ bad)
+{
+    __shared__ uint2 s_ent[kWalkEnt * kWalkReads];      // entry i of read j at [i * 64 + j]
+    __shared__ uint32_t s_nruns[kWalkReads];            // kRunsDeferred: no descriptors from here
+    __shared__ uint64_t s_ent0[kWalkReads], s_so[kWalkReads];
+    const uint32_t tid = threadIdx.x, j = tid & (kWalkReads - 1u);
+    const uint64_t r = (uint64_t)blockIdx.x * kWalkReads + j;
+    if (tid < kWalkReads) {
+        uint32_t n_runs = kRunsDeferred;
+        if (r < n_reads) {
+            const uint64_t my_cb = cig_off[r], c_end = cig_off[r + 1], my_so = seq_off[r], so1 = seq_off[r + 1];
+            const uint64_t qlen = qual_off ? qual_off[r + 1] - qual_off[r] : ~0ull;
+            const int64_t base = (int64_t)pos[r] - (int64_t)win_begin;
+            const uint32_t n_ops = (uint32_t)min(c_end - my_cb, (uint64_t)0xFFFFFF00u);
+            s_ent0[j] = my_cb + 3u * r;
+            s_so[j] = my_so;
+            if (n_ops <= kWalkOps) {
+                const uint32_t *cig = cigar + my_cb;
+                auto window_col = [&](uint64_t ref, uint32_t &before) -> uint32_t {
+                    const int64_t w = base + (int64_t)ref;
+                    before = w >= 0 ? 0u : (-w > (int64_t)0xFFFFFFFFll ? 0xFFFFFFFFu : (uint32_t)(-w));
+                    return w < 0 ? 0u : (w > (int64_t)n_cols ? n_cols : (uint32_t)w);
+                };
+                constexpr uint32_t kRefOps = (1u << 2) | (1u << 3) | (1u << 7) | (1u << 8);
+                constexpr uint32_t kQueryOps = (1u << 1) | (1u << 4) | (1u << 7) | (1u << 8);
+                constexpr uint32_t kKinds = (2u << 4) | (3u << 6) | (1u << 14) | (1u << 16);   // two bits per op
+                // (the loads take sixteen words from the step's first op on whatever the read's length: words past its ops are the
+                // next read's or the array's slack, and are not looked at)
+                struct ops16 { u32x4a4 a, b, c, d; };
+                auto ask = [&](uint32_t k0) -> ops16 {
+                    ops16 o;
+                    const uint32_t *p = cig + k0;
+                    o.a = *reinterpret_cast<const u32x4a4 *>(p);
+                    o.b = *reinterpret_cast<const u32x4a4 *>(p + 4);
+                    o.c = *reinterpret_cast<const u32x4a4 *>(p + 8);
+                    o.d = *reinterpret_cast<const u32x4a4 *>(p + 12);
+                    return o;
+                };
+                uint64_t ref_at = 0, q_at = 0;
+                uint32_t prev_kind = 0;
+                bool has_m = false;
+                n_runs = 0;
+                s_ent[j] = make_uint2(3u << 30, 0u);
+                ops16 cur = ask(0);
+                for (uint32_t k0 = 0; k0 < n_ops; k0 += 16u) {
+                    const ops16 nxt = ask(k0 + 16u < n_ops ? k0 + 16u : 0u);
+                    const uint32_t w16[16] = {cur.a.x, cur.a.y, cur.a.z, cur.a.w, cur.b.x, cur.b.y, cur.b.z, cur.b.w,
+                                              cur.c.x, cur.c.y, cur.c.z, cur.c.w, cur.d.x, cur.d.y, cur.d.z, cur.d.w};
+#pragma unroll
+                    for (uint32_t t = 0; t < 16u; ++t) {
+                        const bool in = k0 + t < n_ops;
+                        const uint32_t op = w16[t] & 15u, len = in ? w16[t] >> 4 : 0u;
+                        const uint32_t kind = len == 0u ? 0u : (kKinds >> (2u * op)) & 3u;
+                        has_m = has_m || (in && op == 0u);
+                        if (kind != 0u && !(kind == 1u && prev_kind == 1u)) {     // an entry begins: not both this op and the one before are aligned bases
+                            uint32_t bf;
+                            const uint32_t col = window_col(ref_at, bf);
+                            ++n_runs;
+                            if (n_runs < kWalkEnt) s_ent[n_runs * kWalkReads + j] = make_uint2(col | (kind << 30), (uint32_t)q_at + bf);
+                        }
+                        if (in) prev_kind = kind;
+                        ref_at += ((kRefOps >> op) & 1u) ? len : 0u;
+                        q_at += ((kQueryOps >> op) & 1u) ? len : 0u;
+                    }
+                    cur = nxt;
+                }
+                if (n_runs + 3u > kWalkEnt) n_runs = kRunsDeferred;
+                else {
+                    uint32_t code = has_m ? 1u : 0u;
+                    if (!code) {
+                        if (q_at > 2u * (so1 - my_so) || q_at > 0x7FFFFFFFull) code = 2u;
+                        else if (q_at > qlen) code = 3u;
+                        else if (ref_at > (uint64_t)kRunMask) code = 4u;
+                    }
+                    uint32_t end_col = 0, bf;
+                    if (code) {      // a malformed record covers nothing (see cigar_runs_kernel)
+                        atomicMin(bad, ((unsigned long long)r << 8) | code);
+                        n_runs = 0;
+                    } else end_col = window_col(ref_at, bf);
+                    s_ent[(n_runs + 1u) * kWalkReads + j] = make_uint2(end_col | (3u << 30), (uint32_t)q_at);
+                    s_ent[(n_runs + 2u) * kWalkReads + j] = make_uint2(kRunMask | (3u << 30), 0u);
+                }
+            }
+            nruns[r] = n_runs;
+        }
+        s_nruns[j] = n_runs;
+    }
+    __syncthreads();
+    const uint32_t n_runs = s_nruns[j];
+    if (n_runs == kRunsDeferred) return;       // (no read, or one for the other launch; no barrier follows)
+    const uint32_t n_ent_all = n_runs + 3u;
+    const uint64_t ent0 = s_ent0[j], my_so = s_so[j];
+    auto ent = [&](uint32_t i) -> uint2 { return s_ent[i * kWalkReads + j]; };
+    // ---- 2: the descriptors, sweeps wave, wave + 4, ... of the 64 reads (see cigar_runs_kernel's `describe`)
+    for (uint32_t s = tid >> 6; s < n_sweeps; s += 4u) {
+        const uint32_t X = s * kSweep, Xend = min(n_cols, X + kSweep);
+        // (the window's last sweep ends at its last column: the runs behind the window are all clamped to column n_cols)
+        const uint32_t bound = s + 1u < n_sweeps ? X + kSweep : n_cols - 1u;
+        // lo: the last entry that begins at or before X (entry 0 does, the last one never)
+        uint32_t lo = 0, hi = n_ent_all - 1u;
+        while (hi - lo > 1u) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if ((ent(mid).x & kRunMask) <= X) lo = mid;
+            else hi = mid;
+        }
+        const uint2 first = ent(lo);
+        uint2 e = first;
+        uint32_t q_lo = 0xFFFFFFFFu, q_hi = 0, i = lo;
+        for (;;) {
+            ++i;
+            const uint2 nx = ent(i);
+            if ((e.x >> 30) == 1u) {
+                const uint32_t W = e.x & kRunMask, ca = max(W, X), cbv = min(nx.x & kRunMask, Xend);
+                if (ca < cbv) {
+                    q_lo = min(q_lo, e.y + (ca - W));
+                    q_hi = max(q_hi, e.y + (cbv - W));
+                }
+            }
+            if ((nx.x & kRunMask) > bound) break;      // it begins behind the sweep: the closing entry
+            e = nx;
+        }
+        const uint32_t n_ent = i - lo + 1u;      // (< kWalkEnt < kDescMax)
+        uint64_t piece = 0;
+        uint32_t np = 0;
+        int32_t q0 = 0;
+        if (q_lo < q_hi) {
+            const uint32_t al = (uint32_t)my_so & 3u;
+            const uint32_t b_lo = al + (q_lo >> 1), b_hi = al + (q_hi + 1u) / 2u;
+            const uint32_t d_lo = b_lo >> 2;
+            piece = (my_so >> 2) + d_lo;
+            np = min((b_hi + 15u - 4u * d_lo) >> 4, kDescMax);
+            q0 = 2 * ((int32_t)(4u * d_lo) - (int32_t)al);
+        }
+        const uint64_t at = ent0 + lo;
+        uint4 d;
+        d.x = (uint32_t)piece;
+        d.z = (uint32_t)q0;
+        if (n_ent == 2u) {      // ONE entry covers the whole sweep: what it is, and the query offset of the sweep's first column
+            d.y = first.y + (X - (first.x & kRunMask));
+            d.w = (uint32_t)((piece >> 32) & 0xFFu) | ((first.x >> 30) << 8) | (np << 16) | (1u << 24);
+        } else {
+            d.y = (uint32_t)at;
+            d.w = (uint32_t)((piece >> 32) & 0xFFu) | ((uint32_t)((at >> 32) & 0xFFu) << 8) | (np << 16) | (n_ent << 24);
+        }
+        desc[(uint64_t)s * n_reads + r] = d;
+    }
+    // ---- the entries: thread (read, part) writes entries part, part + 4, ...
+    uint2 *out = runs + ent0;
+    for (uint32_t i = tid >> 6; i < n_ent_all; i += 4u) out[i] = ent(i);
 }
 
 // ---------------------------------------------------------------------------------------- the planes of one sweep
@@ -1050,7 +1226,8 @@ void jl_launch_ingest(jl_ctx *ctx, const int32_t *d_pos, const uint32_t *d_cigar
         const uint32_t per_wg = 4u * kRunsReadsPerWave;
         unsigned long long *bad = reinterpret_cast<unsigned long long *>(d_slow_count + 2);
         const uint64_t *qo = d_qual ? d_qual_off : nullptr;
-        hipLaunchKernelGGL((cigar_runs_kernel<kRunsLdsSmall, false>), dim3((uint32_t)((ctx->n_reads + per_wg - 1u) / per_wg)), dim3(256), 0, st,
+        (void)per_wg;
+        hipLaunchKernelGGL(cigar_walk_kernel, dim3((uint32_t)((ctx->n_reads + kWalkReads - 1u) / kWalkReads)), dim3(256), 0, st,
                            ctx->n_reads, d_pos, d_cigar, d_cig_off, d_seq_off, qo, ctx->win_begin, ctx->n_cols, ns, d_runs, d_nruns, d_desc, bad);
         hipLaunchKernelGGL((cigar_runs_kernel<kRunsLdsLarge, true>), dim3((uint32_t)std::min<uint64_t>(kRunsLongGrid, (ctx->n_reads + 255u) / 256u)), dim3(256), 0, st,
                            ctx->n_reads, d_pos, d_cigar, d_cig_off, d_seq_off, qo, ctx->win_begin, ctx->n_cols, ns, d_runs, d_nruns, d_desc, bad);

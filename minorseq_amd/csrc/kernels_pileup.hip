@@ -27,6 +27,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include "call_eval.h"
 #include "jl_internal.h"
 
 namespace {
@@ -221,10 +222,15 @@ __device__ __forceinline__ void pileup_planes_stream(const uint8_t JL_AS1 *plane
     }
 }
 
-template <int W, int NQ>
+// FOLD (round 6): the Fisher stage of the chunk's codons in the workgroup that has just counted them — the histogram is still in
+// LDS — instead of a call launch that reads it back from HBM (8 us of a 64 us window, 20 of the 72 us an eight-window launch's
+// tail exposes).  Only where ONE workgroup counts a chunk (gridDim.y = 1).  Wave j & 3 takes the codon that begins at the chunk's
+// column j — the positions at that column from the host's lists (jl_win_fold) — behind the kernel's last barrier: the other
+// waves store the histogram and leave, so what the evaluation holds for its 2-3 us is one wave's registers, not the workgroup's.
+template <int W, int NQ, bool FOLD>
 __device__ __forceinline__ void pileup_planes_body(const uint8_t JL_AS1 *planes, uint64_t plane_stride, uint32_t n_cols, uint32_t n_tiles,
                                                    const uint2 JL_AS1 *chunks, const uint32_t JL_AS1 *guess32, uint32_t JL_AS1 *counts,
-                                                   uint32_t JL_AS1 *hist)
+                                                   uint32_t JL_AS1 *hist, const jl_win_fold *fold)
 {
     __shared__ uint32_t s_hist[W][64];
     __shared__ uint32_t s_col[W][6];   // A C G T - N
@@ -281,6 +287,24 @@ __device__ __forceinline__ void pileup_planes_body(const uint8_t JL_AS1 *planes,
             else if (v) atomicAdd((uint32_t *)(hist + (uint64_t)(c0 + j) * 64u + (i & 63u)), v);
         }
     }
+    if (FOLD) {
+        const jl_win_call &c = fold->c;
+        if (blockIdx.x == 0 && tid == 0 && c.meta) {   // counters of the phasing launch that follows on the stream (call_kernel's first block did this)
+            c.meta->n_occupied = 0;
+            c.meta->overflow = 0;
+            jl_phase_summary z = {0, 0, 0, 0, 0, 0, 0, 0};
+            c.meta->summary = z;
+        }
+        const uint32_t wid = tid >> 6, lane = tid & 63u;
+#pragma unroll
+        for (int j = 0; j < W; ++j) {
+            if (((uint32_t)j & 3u) != wid || !(startf & (1u << j))) continue;      // (wave-uniform)
+            const uint32_t col = c0 + (uint32_t)j;
+            const uint32_t h = s_hist[j][lane];
+            for (uint32_t p = fold->col_head[col]; p != 0xFFFFFFFFu; p = fold->pos_next[p])
+                jl_call_position<false>(c.A, p, col, h, c.pos_refcfg[p], c.pos_gene[p], c.pos_codon[p], c.drm, c.called, c.staged);
+        }
+    }
 }
 
 template <int W, int NQ>
@@ -289,8 +313,8 @@ __global__ __launch_bounds__(256) void pileup_planes_kernel(const uint8_t *__res
                                                             const uint32_t *__restrict__ guess32, uint32_t *__restrict__ counts,
                                                             uint32_t *__restrict__ hist)
 {
-    pileup_planes_body<W, NQ>((const uint8_t JL_AS1 *)planes, plane_stride, n_cols, n_tiles, (const uint2 JL_AS1 *)chunks,
-                          (const uint32_t JL_AS1 *)guess32, (uint32_t JL_AS1 *)counts, (uint32_t JL_AS1 *)hist);
+    pileup_planes_body<W, NQ, false>((const uint8_t JL_AS1 *)planes, plane_stride, n_cols, n_tiles, (const uint2 JL_AS1 *)chunks,
+                                     (const uint32_t JL_AS1 *)guess32, (uint32_t JL_AS1 *)counts, (uint32_t JL_AS1 *)hist, nullptr);
 }
 
 template <int W, int NQ>
@@ -298,8 +322,25 @@ __global__ __launch_bounds__(256) void pileup_planes_group_kernel(jl_pileup_grou
 {
     const jl_win_pileup &w = args.w[blockIdx.z];
     if (blockIdx.x >= w.n_chunks) return;
-    pileup_planes_body<W, NQ>((const uint8_t JL_AS1 *)w.msa, w.plane_stride, w.n_cols, w.n_tiles, (const uint2 JL_AS1 *)w.chunks,
-                          (const uint32_t JL_AS1 *)w.guess32, (uint32_t JL_AS1 *)w.counts, (uint32_t JL_AS1 *)w.hist);
+    pileup_planes_body<W, NQ, false>((const uint8_t JL_AS1 *)w.msa, w.plane_stride, w.n_cols, w.n_tiles, (const uint2 JL_AS1 *)w.chunks,
+                                     (const uint32_t JL_AS1 *)w.guess32, (uint32_t JL_AS1 *)w.counts, (uint32_t JL_AS1 *)w.hist, nullptr);
+}
+
+// ... and with the Fisher stage folded in (runs whose chunks are counted by one workgroup each; gridDim.y = 1)
+template <int W, int NQ>
+__global__ __launch_bounds__(256) void pileup_fold_kernel(jl_win_pileup w, jl_win_fold f)
+{
+    pileup_planes_body<W, NQ, true>((const uint8_t JL_AS1 *)w.msa, w.plane_stride, w.n_cols, w.n_tiles, (const uint2 JL_AS1 *)w.chunks,
+                                    (const uint32_t JL_AS1 *)w.guess32, (uint32_t JL_AS1 *)w.counts, (uint32_t JL_AS1 *)w.hist, &f);
+}
+
+template <int W, int NQ>
+__global__ __launch_bounds__(256) void pileup_fold_group_kernel(jl_pileup_fold_group_args args)
+{
+    const jl_win_pileup &w = args.w[blockIdx.z];
+    if (blockIdx.x >= w.n_chunks) return;
+    pileup_planes_body<W, NQ, true>((const uint8_t JL_AS1 *)w.msa, w.plane_stride, w.n_cols, w.n_tiles, (const uint2 JL_AS1 *)w.chunks,
+                                    (const uint32_t JL_AS1 *)w.guess32, (uint32_t JL_AS1 *)w.counts, (uint32_t JL_AS1 *)w.hist, &args.f[blockIdx.z]);
 }
 
 // Seed base per column for majority-codon mode: majority base among the first 2048 reads of the column.
@@ -411,6 +452,55 @@ void jl_launch_pileup(jl_ctx *ctx, hipStream_t st)
     else if (planes_nq(ctx, false) == 4) JL_LAUNCH_PLANES(3, 4);
     else JL_LAUNCH_PLANES(3, 2);
 #undef JL_LAUNCH_PLANES
+}
+
+// (JL_NO_FOLD_CALL: the separate call launch instead, for A/B measurements; read once, like JL_NO_GRAPH)
+bool jl_fold_enabled(void)
+{
+    static const bool on = !getenv("JL_NO_FOLD_CALL");
+    return on;
+}
+bool jl_pileup_can_fold(jl_ctx *ctx) { return jl_fold_enabled() && ctx->P != 0 && jl_pileup_rsplit(ctx) == 1u; }
+
+void jl_fill_win_fold(jl_ctx *ctx, const jl_win_call *call, jl_win_fold *f)
+{
+    f->c = *call;
+    f->col_head = ctx->d_col_head;
+    f->pos_next = ctx->d_pos_next;
+}
+
+void jl_launch_pileup_fold(jl_ctx *ctx, hipStream_t st, const jl_win_call *call)
+{
+    jl_win_pileup w;
+    jl_win_fold f;
+    w.msa = ctx->d_msa;
+    w.plane_stride = ctx->plane_stride;
+    w.n_cols = ctx->n_cols;
+    w.n_tiles = planes_tiles(ctx, false);
+    w.n_chunks = ctx->n_chunks;
+    w.pad_ = 0;
+    w.chunks = (const uint2 *)ctx->d_chunks;
+    w.guess32 = (const uint32_t *)ctx->d_guess;
+    w.counts = ctx->d_counts;
+    w.hist = ctx->d_hist;
+    jl_fill_win_fold(ctx, call, &f);
+    if (ctx->pileup_w == 6) hipLaunchKernelGGL((pileup_fold_kernel<6, 2>), dim3(ctx->n_chunks, 1), dim3(256), 0, st, w, f);
+    else if (planes_nq(ctx, false) == 4) hipLaunchKernelGGL((pileup_fold_kernel<3, 4>), dim3(ctx->n_chunks, 1), dim3(256), 0, st, w, f);
+    else hipLaunchKernelGGL((pileup_fold_kernel<3, 2>), dim3(ctx->n_chunks, 1), dim3(256), 0, st, w, f);
+}
+
+int jl_launch_pileup_fold_group(jl_ctx *const *ctxs, uint32_t n_win, const jl_win_pileup *h_wins, const jl_win_fold *h_fold, uint32_t max_chunks, hipStream_t st)
+{
+    if (n_win == 0 || n_win > JL_GROUP_MAX) return JL_ERR_ARG;
+    for (uint32_t k = 1; k < n_win; ++k)
+        if (ctxs[k]->pileup_w != ctxs[0]->pileup_w) return JL_ERR_ARG;
+    jl_pileup_fold_group_args args;
+    memset(&args, 0, sizeof args);
+    memcpy(args.w, h_wins, sizeof(jl_win_pileup) * n_win);
+    memcpy(args.f, h_fold, sizeof(jl_win_fold) * n_win);
+    if (ctxs[0]->pileup_w == 3) hipLaunchKernelGGL((pileup_fold_group_kernel<3, 4>), dim3(max_chunks, 1, n_win), dim3(256), 0, st, args);
+    else hipLaunchKernelGGL((pileup_fold_group_kernel<6, 2>), dim3(max_chunks, 1, n_win), dim3(256), 0, st, args);
+    return JL_OK;
 }
 
 void jl_fill_win_pileup(jl_ctx *ctx, jl_win_pileup *w)

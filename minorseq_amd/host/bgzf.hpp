@@ -215,6 +215,8 @@ public:
     {
         if (!f_) throw std::runtime_error("cannot create " + path);
         buf_.reserve(kBlock);
+        const unsigned hc = std::thread::hardware_concurrency();
+        threads_ = std::max(1u, std::min(hc ? hc : 1u, 16u));
     }
     ~BgzfWriter()
     {
@@ -228,13 +230,14 @@ public:
             buf_.insert(buf_.end(), p, p + take);
             p += take;
             n -= take;
-            if (buf_.size() == kBlock) flush_block();
+            if (buf_.size() == kBlock) queue_block();
         }
     }
     void close()
     {
         if (!f_) return;
-        if (!buf_.empty()) flush_block();
+        if (!buf_.empty()) queue_block();
+        flush_batch();
         static const uint8_t eof[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0,
                                         0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         fwrite(eof, 1, sizeof eof, f_);
@@ -244,35 +247,62 @@ public:
 
 private:
     static constexpr size_t kBlock = 0xff00;
-    void flush_block()
+    static constexpr size_t kBatch = 256;      // blocks deflated together, by the threads in turns (BGZF members are independent)
+    // one BGZF member (header, deflate data, crc32, isize) of `in`
+    static void deflate_block(const std::vector<uint8_t> &in, std::vector<uint8_t> &out)
     {
-        std::vector<uint8_t> comp(compressBound((uLong)buf_.size()) + 64);
+        out.resize(compressBound((uLong)in.size()) + 64 + 26);
         z_stream z;
         memset(&z, 0, sizeof z);
         if (deflateInit2(&z, 6, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) throw std::runtime_error("deflateInit2");
-        z.next_in = buf_.data();
-        z.avail_in = (uInt)buf_.size();
-        z.next_out = comp.data();
-        z.avail_out = (uInt)comp.size();
+        z.next_in = const_cast<uint8_t *>(in.data());
+        z.avail_in = (uInt)in.size();
+        z.next_out = out.data() + 18;
+        z.avail_out = (uInt)(out.size() - 26);
         if (deflate(&z, Z_FINISH) != Z_STREAM_END) throw std::runtime_error("deflate");
         const size_t clen = z.total_out;
         deflateEnd(&z);
-        const uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), buf_.data(), (uInt)buf_.size());
+        const uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), in.data(), (uInt)in.size());
         const uint16_t bsize = (uint16_t)(clen + 25);  // total block size - 1
-        uint8_t hdr[18] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, 0, 0};
-        hdr[16] = (uint8_t)(bsize & 0xff);
-        hdr[17] = (uint8_t)(bsize >> 8);
-        fwrite(hdr, 1, 18, f_);
-        fwrite(comp.data(), 1, clen, f_);
-        uint8_t tail[8];
-        const uint32_t isize = (uint32_t)buf_.size();
-        memcpy(tail, &crc, 4);
-        memcpy(tail + 4, &isize, 4);
-        fwrite(tail, 1, 8, f_);
-        buf_.clear();
+        const uint8_t hdr[18] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, (uint8_t)(bsize & 0xff), (uint8_t)(bsize >> 8)};
+        memcpy(out.data(), hdr, 18);
+        const uint32_t isize = (uint32_t)in.size();
+        memcpy(out.data() + 18 + clen, &crc, 4);
+        memcpy(out.data() + 18 + clen + 4, &isize, 4);
+        out.resize(18 + clen + 8);
+    }
+    void queue_block()
+    {
+        batch_.emplace_back();
+        batch_.back().swap(buf_);
+        buf_.reserve(kBlock);
+        if (batch_.size() == kBatch) flush_batch();
+    }
+    void flush_batch()
+    {
+        if (batch_.empty()) return;
+        std::vector<std::vector<uint8_t>> comp(batch_.size());
+        const unsigned nt = (unsigned)std::min<size_t>(threads_, batch_.size());
+        std::atomic<size_t> next{0};
+        std::atomic<bool> failed{false};
+        auto work = [&]() {
+            try {
+                for (size_t i = next++; i < batch_.size(); i = next++) deflate_block(batch_[i], comp[i]);
+            } catch (...) { failed = true; }
+        };
+        std::vector<std::thread> pool;
+        for (unsigned t = 1; t < nt; ++t) pool.emplace_back(work);
+        work();
+        for (std::thread &t : pool) t.join();
+        if (failed) throw std::runtime_error("deflate");
+        for (const std::vector<uint8_t> &c : comp)
+            if (fwrite(c.data(), 1, c.size(), f_) != c.size()) throw std::runtime_error("short write");
+        batch_.clear();
     }
     FILE *f_;
     std::vector<uint8_t> buf_;
+    std::vector<std::vector<uint8_t>> batch_;
+    unsigned threads_ = 1;
 };
 
 }  // namespace jlhost

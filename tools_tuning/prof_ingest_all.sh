@@ -31,7 +31,7 @@ python3 - <<PY > $O/summary.txt
 import csv, glob, collections, json
 O = "$O"
 def short(n):
-    for k in ("ingest_planes_kernel", "cigar_runs_kernel"):
+    for k in ("ingest_planes_kernel", "cigar_runs_kernel", "cigar_walk_kernel"):
         if k in n:
             return k + n[n.index("<"):n.index(">") + 1] if "<" in n else k
     return None
