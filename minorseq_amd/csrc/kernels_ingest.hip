@@ -677,6 +677,10 @@ struct ingest_args {
 #define JL_INGEST_ENT_PER_READ_BIG 16
 #endif
 constexpr uint32_t kReadWaves = kTileReads / 64u;     // waves of read threads, with a part of the entry area each
+#ifndef JL_INGEST_QUAL_AHEAD
+#define JL_INGEST_QUAL_AHEAD 7            // pieces whose qualities a thread has asked for ahead of their turn (8 registers each; all seven: the QV
+                                          // kernel's time does not depend on how many workgroups a CU holds, tools_tuning/lds_sensitivity.sh)
+#endif
 #ifndef JL_INGEST_ROW_EXTRA
 #define JL_INGEST_ROW_EXTRA 0             // pieces of a row beyond a sweep's own (room for inserted bases: 32 a piece)
 #endif
@@ -732,35 +736,53 @@ __device__ __forceinline__ uint32_t codes_of_bases8(uint32_t x)
 // b & 7 of S[b >> 3] — BAM's codes as they are: they become symbol codes as bit planes, behind the transposition, at an
 // eighth of the price per base.  QV: bases whose quality is below min_qv become 15 (N).  Q = query offset of the piece's base 0
 // (negative: the first -Q bases are not the read's own).
+// The qualities of a piece's 32 bases, one byte each: two 16-byte loads at the BYTE address of the first (gfx950 takes unaligned
+// dwordx4 loads; Q < 0 — the piece begins up to six bases before the read's own — reads the read before's last bytes, or the 16
+// bytes in front of the first read's (jl_records_begin): those bases are nobody's, whatever mask they get).
+struct piece_quals { u32x4 a, b; };
+__device__ __forceinline__ piece_quals ask_quals(const ingest_args &a, int Q, uint64_t qual_base)
+{
+    typedef uint32_t u32x4a1 __attribute__((ext_vector_type(4), aligned(1)));
+    const uint8_t *qp = a.qual + (int64_t)qual_base + (int64_t)Q;
+    piece_quals q;
+#ifdef JL_TUNING
+    if (JL_ING_SKIP(a, 10)) {      // (probe: streaming loads)
+        q.a = __builtin_nontemporal_load(reinterpret_cast<const u32x4a1 *>(qp));
+        q.b = __builtin_nontemporal_load(reinterpret_cast<const u32x4a1 *>(qp + 16));
+        return q;
+    }
+#endif
+    q.a = *reinterpret_cast<const u32x4a1 *>(qp);
+    q.b = *reinterpret_cast<const u32x4a1 *>(qp + 16);
+    return q;
+}
+
+// 32 bases in query order (S) and their qualities (pq): a base is masked — becomes 15, N — when its quality is below min_qv (0xFF =
+// absent, and anything above 127, never masks).  Eight bases a step, the byte-parallel compare done on the even and on the odd
+// bases' bytes apart (v_perm), so that the two results interleave into one flag per NIBBLE — the bases' own layout — with one
+// shift: 13 instructions for eight bases (round 5: nine dword loads, eight v_alignbyte, flags gathered into bits and spread again: 30).
+__device__ __forceinline__ void mask_low_quals(const ingest_args &a, const piece_quals &pq, uint32_t (&S)[4])
+{
+    const uint32_t q8[8] = {pq.a.x, pq.a.y, pq.a.z, pq.a.w, pq.b.x, pq.b.y, pq.b.z, pq.b.w};
+    const uint32_t T = a.min_qv * 0x01010101u;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t ev = __builtin_amdgcn_perm(q8[2 * k + 1], q8[2 * k], 0x06040200u);   // qualities of bases 0 2 4 6 of the eight
+        const uint32_t od = __builtin_amdgcn_perm(q8[2 * k + 1], q8[2 * k], 0x07050301u);   // of bases 1 3 5 7
+        const uint32_t lt_e = ~((ev | 0x80808080u) - T) & ~ev & 0x80808080u;                // bit 7 of byte i: base 2 i is below min_qv
+        const uint32_t lt_o = ~((od | 0x80808080u) - T) & ~od & 0x80808080u;
+        const uint32_t c = lt_o | (lt_e >> 4);          // bit 3 of nibble j: base j is masked
+        S[k] |= c | (c - (c >> 3));                     // 8 -> 15 (N) in those nibbles
+    }
+}
+
 template <bool QV>
-__device__ __forceinline__ void piece_bases(const ingest_args &a, const u32x4 &v, int Q, uint64_t qual_base, uint32_t (&S)[4])
+__device__ __forceinline__ void piece_bases(const ingest_args &a, const u32x4 &v, const piece_quals &pq, uint32_t (&S)[4])
 {
     const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
     for (int k = 0; k < 4; ++k) S[k] = ((w4[k] >> 4) & 0x0F0F0F0Fu) | ((w4[k] & 0x0F0F0F0Fu) << 4);
-    if (QV) {
-        // The qualities of the piece's 32 bases, one byte each: two 16-byte loads at the BYTE address of the first (gfx950 takes
-        // unaligned dwordx4 loads; Q < 0 — the piece begins up to six bases before the read's own — reads the read before's
-        // last bytes, or the 16 bytes in front of the first read's (jl_records_begin): those bases are nobody's, whatever mask they
-        // get).  A base is masked when its quality is below min_qv (0xFF = absent, and anything above 127, never masks).
-        // Eight bases a step, the byte-parallel compare done on the even and on the odd bases' bytes apart (v_perm), so that the
-        // two results interleave into one flag per NIBBLE — the bases' own layout — with one shift: 13 instructions for eight
-        // bases (round 5: nine dword loads, eight v_alignbyte, flags gathered into bits and spread again: 30).
-        typedef uint32_t u32x4a1 __attribute__((ext_vector_type(4), aligned(1)));
-        const uint8_t *qp = a.qual + (int64_t)qual_base + (int64_t)Q;
-        const u32x4 qa = *reinterpret_cast<const u32x4a1 *>(qp), qb = *reinterpret_cast<const u32x4a1 *>(qp + 16);
-        const uint32_t q8[8] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w};
-        const uint32_t T = a.min_qv * 0x01010101u;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const uint32_t ev = __builtin_amdgcn_perm(q8[2 * k + 1], q8[2 * k], 0x06040200u);   // qualities of bases 0 2 4 6 of the eight
-            const uint32_t od = __builtin_amdgcn_perm(q8[2 * k + 1], q8[2 * k], 0x07050301u);   // of bases 1 3 5 7
-            const uint32_t lt_e = ~((ev | 0x80808080u) - T) & ~ev & 0x80808080u;                // bit 7 of byte i: base 2 i is below min_qv
-            const uint32_t lt_o = ~((od | 0x80808080u) - T) & ~od & 0x80808080u;
-            const uint32_t c = lt_o | (lt_e >> 4);          // bit 3 of nibble j: base j is masked
-            S[k] |= c | (c - (c >> 3));                     // 8 -> 15 (N) in those nibbles
-        }
-    }
+    if (QV) mask_low_quals(a, pq, S);
 }
 
 __device__ __forceinline__ uint32_t ent_col(uint32_t e) { return e & 511u; }
@@ -859,16 +881,25 @@ __device__ __forceinline__ void planes_unit(const ingest_args &a, const uint32_t
     // flight together; a piece that is not there (the read has fewer) asks for the read's first one again — the same number of
     // requests in every lane, so that a wait for something asked earlier does not wait for these
     struct piece_t { u32x4 v; uint32_t dst; int32_t Q; uint64_t qb; };    // dst: dword in the staging area, 0 = none
+    // (every load is asked for whatever the read's number — a read past the last asks for the first one's, and is set to nothing
+    // afterwards: loads inside a branch made the compiler wait for each before it asked for the next)
     auto ask_descs = [&](uint32_t p0, uint32_t K, uint4 (&d)[kPieceRoundsB], uint64_t (&qo)[kPieceRoundsB]) {
+        bool in[kPieceRoundsB];
 #pragma unroll
         for (uint32_t k = 0; k < kPieceRoundsB; ++k) {
             if (k >= K) break;
             const uint32_t j = (p0 + kTileReads * k) / kRowPieces;
-            d[k] = make_uint4(0, 0, 0, 0);
-            qo[k] = 0;
-            if (r0 + j < a.n_reads) {
-                d[k] = desc[r0 + j];
-                if (QV) qo[k] = a.qual_off[r0 + j];
+            in[k] = r0 + j < a.n_reads;
+            const uint64_t at = in[k] ? r0 + j : 0u;
+            d[k] = desc[at];
+            qo[k] = QV ? a.qual_off[at] : 0u;
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < kPieceRoundsB; ++k) {
+            if (k >= K) break;
+            if (!in[k]) {
+                d[k] = make_uint4(0, 0, 0, 0);
+                qo[k] = 0;
             }
         }
     };
@@ -888,20 +919,32 @@ __device__ __forceinline__ void planes_unit(const ingest_args &a, const uint32_t
 #endif
             pc[k].v = *reinterpret_cast<const u32x4a4 *>(a.seq4 + 4u * at);
             pc[k].dst = i < np ? shape::row_dw(j) + 4u * i : 0u;
-            pc[k].Q = (int32_t)d[k].z + 32 * (int32_t)i;
+            pc[k].Q = (int32_t)d[k].z + (i < np ? 32 * (int32_t)i : 0);      // (a piece that is not there: its read's first one's qualities)
             pc[k].qb = qo[k];
         }
     };
+    // (QV: a piece's qualities are asked for kQualAhead pieces ahead of its turn, outside any branch — the loads of a piece that is
+    // not there ask for its read's first piece's again.  Asked for inside the piece's own turn, as round 5 had it, every piece
+    // of a thread waited for its own trip to HBM, seven in a row: 184 us against 111 without qualities.)
+    constexpr uint32_t kQualAhead = JL_INGEST_QUAL_AHEAD;
     auto stage_pieces = [&](uint32_t K, const piece_t (&pc)[kPieceRoundsB]) {
+        piece_quals pq[kPieceRoundsB];
+        if (QV) {
+#pragma unroll
+            for (uint32_t k = 0; k < kPieceRoundsB; ++k)
+                if (k < K && k < kQualAhead) pq[k] = ask_quals(a, pc[k].Q, pc[k].qb);
+        }
 #pragma unroll
         for (uint32_t k = 0; k < kPieceRoundsB; ++k) {
             if (k >= K) break;
-            if (!pc[k].dst) continue;
-            uint32_t S[4];
-            if (JL_ING_SKIP(a, 6)) { S[0] = pc[k].v.x; S[1] = pc[k].v.y; S[2] = pc[k].v.z; S[3] = pc[k].v.w; }
-            else piece_bases<QV>(a, pc[k].v, pc[k].Q, pc[k].qb, S);
-            u32x4 o = {S[0], S[1], S[2], S[3]};
-            *reinterpret_cast<u32x4 *>(&s_stage[pc[k].dst]) = o;
+            if (QV && k + kQualAhead < K && k + kQualAhead < kPieceRoundsB) pq[k + kQualAhead] = ask_quals(a, pc[k + kQualAhead].Q, pc[k + kQualAhead].qb);
+            if (pc[k].dst) {
+                uint32_t S[4];
+                if (JL_ING_SKIP(a, 6)) { S[0] = pc[k].v.x; S[1] = pc[k].v.y; S[2] = pc[k].v.z; S[3] = pc[k].v.w; }
+                else piece_bases<QV>(a, pc[k].v, pq[k], S);
+                u32x4 o = {S[0], S[1], S[2], S[3]};
+                *reinterpret_cast<u32x4 *>(&s_stage[pc[k].dst]) = o;
+            }
         }
     };
 
@@ -1119,7 +1162,9 @@ __device__ __forceinline__ void planes_unit(const ingest_args &a, const uint32_t
     // ---- gather at the transpose: thread = 32 reads x 8 columns; neighbouring lanes write consecutive dwords of a plane
     {
         const uint32_t G = tid % kTileGroups, blk = tid / kTileGroups;
-        if (blk < kBlocks && 8u * blk < width && !JL_ING_SKIP(a, 4)) {
+        const bool act = blk < kBlocks && 8u * blk < width && !JL_ING_SKIP(a, 4);
+        uint32_t out[8][3];
+        if (act) {
             // (the dwords in front of the reads' rows — 'not covered', '-', the boundary blocks — hold symbol codes already; `codes`
             // collects, a bit a read, whose dword is one of those: v_alignbit shifts the sign of address - first row in)
             uint32_t R[32], codes = 0;
@@ -1133,8 +1178,9 @@ __device__ __forceinline__ void planes_unit(const ingest_args &a, const uint32_t
                 R[i] = __builtin_amdgcn_alignbit(s_stage[(A >> 3) + 1u], s_stage[A >> 3], 4u * (A & 7u));
                 codes = __builtin_amdgcn_alignbit(codes, A - 8u * kRowBase, 31u);
             }
-            uint32_t out[8][3];
             nibble_rows_to_plane_words(R, codes, out);
+        }
+        if (act) {
             const uint64_t byte = (uint64_t)tile * (kTileReads / 8u) + (uint64_t)G * 4u;
 #ifdef JL_TUNING
             if (JL_ING_SKIP(a, 7) || JL_ING_SKIP(a, 8)) {   // (probes, wrong data by design: 7 the same bytes in 16-byte stores, a quarter of the requests; 8 non-temporal stores)
@@ -1194,6 +1240,14 @@ __global__ __launch_bounds__(kThreads) void ingest_planes_kernel(ingest_args a)
     }
 }
 
+// the counters of a build: [0] pairs listed, [1] units handed on = 0; [2..3] the verdict word = all ones unless an earlier build's is still unread
+__global__ void ingest_init_kernel(uint32_t *count, uint32_t fresh_verdict)
+{
+    const uint32_t t = threadIdx.x;
+    if (t < 2u) count[t] = 0u;
+    else if (t < 4u && fresh_verdict) count[t] = 0xFFFFFFFFu;
+}
+
 }  // namespace
 
 uint32_t jl_ingest_sweeps(uint32_t n_cols) { return (n_cols + kSweep - 1u) / kSweep; }
@@ -1220,8 +1274,8 @@ void jl_launch_ingest(jl_ctx *ctx, const int32_t *d_pos, const uint32_t *d_cigar
 {
     hipStream_t st = ctx->stream;
     const uint32_t ns = jl_ingest_sweeps(ctx->n_cols);
-    hipMemsetAsync(d_slow_count, 0, 8, st);
-    if (!keep_verdict) hipMemsetAsync(d_slow_count + 2, 0xFF, 8, st);
+    // (one small launch instead of two fills: each was a launch of its own, 4 us on the stream)
+    hipLaunchKernelGGL(ingest_init_kernel, dim3(1), dim3(64), 0, st, d_slow_count, keep_verdict ? 0u : 1u);
     if (ctx->n_reads) {
         const uint32_t per_wg = 4u * kRunsReadsPerWave;
         unsigned long long *bad = reinterpret_cast<unsigned long long *>(d_slow_count + 2);
