@@ -677,9 +677,18 @@ struct ingest_args {
 #define JL_INGEST_ENT_PER_READ_BIG 16
 #endif
 constexpr uint32_t kReadWaves = kTileReads / 64u;     // waves of read threads, with a part of the entry area each
+#ifndef JL_INGEST_MIN_WGS
+#define JL_INGEST_MIN_WGS 4               // workgroups a CU must be able to hold: 128 registers for the first size (two tiles a workgroup with qualities: 129 without the bound)
+#endif
+#ifndef JL_INGEST_NT
+#define JL_INGEST_NT 1                    // sibling tiles a workgroup of the planes kernel's first size takes (1, 2, 4); with qualities:
+#endif
+#ifndef JL_INGEST_NT_QV
+#define JL_INGEST_NT_QV 2
+#endif
 #ifndef JL_INGEST_QUAL_AHEAD
-#define JL_INGEST_QUAL_AHEAD 7            // pieces whose qualities a thread has asked for ahead of their turn (8 registers each; all seven: the QV
-                                          // kernel's time does not depend on how many workgroups a CU holds, tools_tuning/lds_sensitivity.sh)
+#define JL_INGEST_QUAL_AHEAD 3            // pieces whose qualities a thread has asked for ahead of their turn (8 registers each; with all
+                                          // seven ahead one tile a workgroup is 5 us faster, two tiles a workgroup 11 us slower)
 #endif
 #ifndef JL_INGEST_ROW_EXTRA
 #define JL_INGEST_ROW_EXTRA 0             // pieces of a row beyond a sweep's own (room for inserted bases: 32 a piece)
@@ -846,8 +855,11 @@ __device__ __forceinline__ void slow_pair(const ingest_args &a, uint64_t r, uint
 // (Device stamps of the form before this one — the read waves made the table while the others waited, then everybody staged:
 // descriptor 0.75 us, prologue 0.9, table 4.7 of which 1.5 a third trip for the reads with more than four entries, staging 1.8,
 // general 1.1, transposing 2.6; waves 2, 3 waited 5.2 us of 14.6 at the first barrier.)
-template <bool QV, uint32_t EPR, bool BIG>
-__device__ __forceinline__ void planes_unit(const ingest_args &a, const uint32_t b)
+// DEFER (the first size, several sibling tiles a workgroup: ingest_planes_kernel): the unit's plane words are handed back in `keep`
+// instead of being stored — returns whether the unit made any (false: outside the window's groups, or handed on) — and a read
+// the workgroup has no room for hands the unit on instead of going through slow_pair (whose bit flips need the stores done).
+template <bool QV, uint32_t EPR, bool BIG, bool DEFER = false>
+__device__ __forceinline__ bool planes_unit(const ingest_args &a, const uint32_t b, uint32_t (&keep)[8][3])
 {
     using shape = planes_shape<EPR>;
     constexpr uint32_t kEntCap = shape::kEntCap, kEntCapWave = shape::kEntCapWave, kRowBase = shape::kRowBase, kStageDw = shape::kStageDw;
@@ -862,7 +874,10 @@ __device__ __forceinline__ void planes_unit(const ingest_args &a, const uint32_t
     __shared__ uint32_t s_nent[2u * kReadWaves];  // entries in each part; [kReadWaves + w]: wave w hands the unit on
     __shared__ uint32_t s_nslow;                  // reads left to slow_pair
     __shared__ uint8_t s_slow[kTileReads];
-    const uint32_t tid = threadIdx.x, wid = tid >> 6, lane = tid & 63u;
+    uint32_t tid_ = threadIdx.x;
+    if (DEFER) asm volatile("" : "+v"(tid_));      // (the units of a workgroup run in a loop: what follows from the thread's number is not to be
+                                                   // kept in registers across it — hoisted, it was 110 of them)
+    const uint32_t tid = tid_, wid = tid >> 6, lane = tid & 63u;
     // block -> (read tile, sweep).  Blocks b, b + 8, b + 16, ... are dealt to the same XCD one after the other; an XCD takes
     // whole groups of 1024 reads (group = xcd, xcd + 8, ...), and of a group all sweeps in turn, the tiles of the group
     // innermost.  So (a) the tiles that share the 128-byte lines of a sweep's planes meet in one L2, and (b) what the
@@ -870,7 +885,7 @@ __device__ __forceinline__ void planes_unit(const ingest_args &a, const uint32_t
     // in that L2 when the next sweep asks for it.
     const uint32_t xcd = b & 7u, jb = b >> 3, sub = jb % kSubTiles, qq = jb / kSubTiles;
     const uint32_t group = xcd + 8u * (qq / a.n_sweeps), sweep = qq % a.n_sweeps;
-    if (group >= a.n_groups) return;
+    if (group >= a.n_groups) return false;
     const uint32_t tile = kSubTiles * group + sub;
     const uint32_t X = sweep * kSweep, Xend = min(a.n_cols, X + kSweep), width = Xend - X;
     const uint4 *desc = a.desc + (uint64_t)sweep * a.n_reads;
@@ -993,6 +1008,10 @@ __device__ __forceinline__ void planes_unit(const ingest_args &a, const uint32_t
             else slow = true;
             n_ent = 0;
         }
+        if (DEFER && slow) {
+            s_nent[kReadWaves + wid] = 1u;
+            slow = false;
+        }
         JL_ING_CHECK(a, !slow || r < a.n_reads, 3, r, slow = false)
         slow_read = slow;
         off_e += wid * kEntCapWave;
@@ -1067,7 +1086,7 @@ __device__ __forceinline__ void planes_unit(const ingest_args &a, const uint32_t
         for (uint32_t w = 0; w < kReadWaves; ++w) handed |= s_nent[kReadWaves + w];
         if (handed) {
             if (tid == 0) a.big_list[atomicAdd(a.slow_count + 1, 1u)] = b;
-            return;
+            return false;
         }
     }
     if (slow_read) s_slow[atomicAdd(&s_nslow, 1u)] = (uint8_t)tid;      // (its row of the table says 'not covered')
@@ -1180,7 +1199,12 @@ __device__ __forceinline__ void planes_unit(const ingest_args &a, const uint32_t
             }
             nibble_rows_to_plane_words(R, codes, out);
         }
-        if (act) {
+        if (DEFER) {
+#pragma unroll
+            for (uint32_t jj = 0; jj < 8u; ++jj)
+#pragma unroll
+                for (uint32_t k = 0; k < 3u; ++k) keep[jj][k] = out[jj][k];
+        } else if (act) {
             const uint64_t byte = (uint64_t)tile * (kTileReads / 8u) + (uint64_t)G * 4u;
 #ifdef JL_TUNING
             if (JL_ING_SKIP(a, 7) || JL_ING_SKIP(a, 8)) {   // (probes, wrong data by design: 7 the same bytes in 16-byte stores, a quarter of the requests; 8 non-temporal stores)
@@ -1189,6 +1213,13 @@ __device__ __forceinline__ void planes_unit(const ingest_args &a, const uint32_t
                     for (uint32_t k = 0; k < 3u; ++k) {
                         if (JL_ING_SKIP(a, 8)) __builtin_nontemporal_store(out[jj][k], reinterpret_cast<uint32_t *>(row));
                         else if (G == 0) { u32x4 o = {out[jj][k], out[jj][0], out[jj][1], out[jj][2]}; *reinterpret_cast<u32x4 *>(row) = o; }
+                        row += a.plane_stride;
+                    }
+            } else if (JL_ING_SKIP(a, 11)) {   // (probe, wrong data by design: the same bytes as 64-byte requests — a quarter of the rows, four tiles wide)
+                uint8_t *row = a.msa + (uint64_t)((X + 8u * blk) * 3u) * a.plane_stride + (uint64_t)(tile & ~3u) * (kTileReads / 8u) + (uint64_t)G * 16u;
+                for (uint32_t jj = 0; jj < 8u; ++jj)
+                    for (uint32_t k = 0; k < 3u; ++k) {
+                        if (((jj * 3u + k) & 3u) == (sub & 3u)) { u32x4 o = {out[jj][k], out[jj][0], out[jj][1], out[jj][2]}; *reinterpret_cast<u32x4 *>(row) = o; }
                         row += a.plane_stride;
                     }
             } else
@@ -1217,25 +1248,111 @@ __device__ __forceinline__ void planes_unit(const ingest_args &a, const uint32_t
     }
     JL_ING_STAMP(a, 10)
     // ---- the reads left out (none, in a CCS sample): column by column behind the workgroup's own stores, a wave a read
-    if (n_slow) {       // (the same in every thread)
+    if (!DEFER && n_slow) {       // (the same in every thread)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         for (uint32_t i = wid; i < n_slow; i += kThreads / 64u) slow_pair(a, r0 + s_slow[i], sweep, lane);
     }
+    return true;
 }
 
 // The first size: a workgroup a unit (blockIdx -> unit: planes_unit).  The second: the units the first handed on, in the
 // order they came, taken in turns by a grid that fills the chip once (an empty list costs a launch of 768 workgroups).
 constexpr uint32_t kBigGrid = 768u;
-template <bool QV, uint32_t EPR, bool BIG>
-__global__ __launch_bounds__(kThreads) void ingest_planes_kernel(ingest_args a)
+// NT (the first size): sibling tiles a workgroup takes one after the other, their plane words kept in registers and stored
+// TOGETHER at the end — NT x 16 bytes of a line a request instead of 16.  The L2 takes a write request per (row, tile): 7 x 10^6 a
+// window, more than all its read requests; the same bytes as 64-byte requests (a probe: JL_ING_SKIP bit 11) took 19 us off the
+// launch's 113 and 29 off the 180 with qualities.  The tiles' words change places between the lanes of a DPP row (16 lanes = four
+// blocks of 8 columns x four 32-read groups): the lane at position u of a run of NT blocks ends up with tile u's words of all NT
+// blocks (log2 NT rounds of two DPP moves a word), and 4 NT neighbouring lanes write NT x 16 contiguous bytes of a row.
+template <bool QV, uint32_t EPR, bool BIG, uint32_t NT = 1u>
+__global__ __launch_bounds__(kThreads, (BIG ? 1 : JL_INGEST_MIN_WGS)) void ingest_planes_kernel(ingest_args a)
 {
-    if (!BIG) planes_unit<QV, EPR, false>(a, blockIdx.x);
-    else {
+    static_assert(NT == 1u || NT == 2u || NT == 4u, "a DPP row holds four blocks");
+    if (BIG) {
+        uint32_t none[8][3];
         const uint32_t n = a.slow_count[1];
         for (uint32_t u = blockIdx.x; u < n; u += gridDim.x) {
-            planes_unit<QV, EPR, true>(a, a.big_list[u]);
+            planes_unit<QV, EPR, true>(a, a.big_list[u], none);
             __syncthreads();      // (the next unit's LDS)
+        }
+    } else if (NT == 1u) {
+        uint32_t none[8][3];
+        planes_unit<QV, EPR, false>(a, blockIdx.x, none);
+    } else {
+        // workgroup w -> the units (planes_unit's block numbers) of NT consecutive tiles of one (group, sweep), on w's XCD
+        const uint32_t w = blockIdx.x, xcd = w & 7u, jw = w >> 3, h = jw % (kSubTiles / NT), qq = jw / (kSubTiles / NT);
+        const uint32_t b0 = xcd + 8u * (qq * kSubTiles + NT * h);
+        uint32_t D[NT][8][3];
+        uint32_t ok = 0;
+#pragma unroll 1
+        for (uint32_t i = 0; i < NT; ++i) {
+            // (the words kept so far move down a place: after the last tile D[t] is tile t's)
+#pragma unroll
+            for (uint32_t t = 0; t + 1u < NT; ++t)
+#pragma unroll
+                for (uint32_t jj = 0; jj < 8u; ++jj)
+#pragma unroll
+                    for (uint32_t k = 0; k < 3u; ++k) D[t][jj][k] = D[t + 1u][jj][k];
+            const bool got = planes_unit<QV, EPR, false, true>(a, b0 + 8u * i, D[NT - 1u]);
+            ok = (ok >> 1) | (got ? 1u << (NT - 1u) : 0u);
+            __syncthreads();      // (the next tile's LDS)
+        }
+        if (!ok) return;
+        const uint32_t tid = threadIdx.x;
+        if (tid >= kTileGroups * kBlocks) return;           // (the transposing threads)
+        const uint32_t G = tid % kTileGroups, blk = tid / kTileGroups, u = blk & (NT - 1u);
+        // ---- the tiles' words change places: round s swaps, between blocks 2^s apart, the words of the tiles whose bit s differs
+#pragma unroll
+        for (uint32_t sft = 0; (1u << sft) < NT; ++sft) {
+#pragma unroll
+            for (uint32_t t0 = 0; t0 < NT; ++t0) {
+                if (t0 & (1u << sft)) continue;
+                const uint32_t t1 = t0 | (1u << sft);
+#pragma unroll
+                for (uint32_t jj = 0; jj < 8u; ++jj)
+#pragma unroll
+                    for (uint32_t k = 0; k < 3u; ++k) {
+                        const int x0 = (int)D[t0][jj][k], x1 = (int)D[t1][jj][k];
+                        // lanes whose block has bit s clear take the partner's (4 << s lanes up) tile-t0 words into slot t1,
+                        // the others the partner's tile-t1 words into slot t0 (bank = block within the row)
+                        if (sft == 0u) {
+                            D[t1][jj][k] = (uint32_t)__builtin_amdgcn_update_dpp(x1, x0, 0x104, 0xF, 0x5, false);   // row_shl:4, banks 0 2
+                            D[t0][jj][k] = (uint32_t)__builtin_amdgcn_update_dpp(x0, x1, 0x114, 0xF, 0xA, false);   // row_shr:4, banks 1 3
+                        } else {
+                            D[t1][jj][k] = (uint32_t)__builtin_amdgcn_update_dpp(x1, x0, 0x108, 0xF, 0x3, false);   // row_shl:8, banks 0 1
+                            D[t0][jj][k] = (uint32_t)__builtin_amdgcn_update_dpp(x0, x1, 0x118, 0xF, 0xC, false);   // row_shr:8, banks 2 3
+                        }
+                    }
+            }
+        }
+        // ---- D[p] = this lane's tile's (tile u of the NT) words of block (blk & ~(NT - 1)) + p: NT x 4 lanes a row
+        if (!((ok >> u) & 1u)) return;                      // (this lane's tile was handed on)
+        const uint32_t sub0 = NT * h, group = xcd + 8u * (qq / a.n_sweeps), sweep = qq % a.n_sweeps;
+        const uint32_t X = sweep * kSweep, width = min(a.n_cols, X + kSweep) - X;
+        const uint64_t byte = (uint64_t)(kSubTiles * group + sub0 + u) * (kTileReads / 8u) + (uint64_t)G * 4u;
+#pragma unroll
+        for (uint32_t p = 0; p < NT; ++p) {
+            const uint32_t bp = (blk & ~(NT - 1u)) + p;
+            if (8u * bp >= width) continue;
+            uint8_t *row = a.msa + (uint64_t)((X + 8u * bp) * 3u) * a.plane_stride + byte;
+            if (8u * bp + 8u <= width) {
+#pragma unroll
+                for (uint32_t jj = 0; jj < 8u; ++jj)
+#pragma unroll
+                    for (uint32_t k = 0; k < 3u; ++k) {
+                        *reinterpret_cast<uint32_t *>(row) = D[p][jj][k];
+                        row += a.plane_stride;
+                    }
+            } else {
+#pragma unroll
+                for (uint32_t jj = 0; jj < 8u; ++jj)
+#pragma unroll
+                    for (uint32_t k = 0; k < 3u; ++k) {
+                        if (8u * bp + jj < width) *reinterpret_cast<uint32_t *>(row) = D[p][jj][k];
+                        row += a.plane_stride;
+                    }
+            }
         }
     }
 }
@@ -1324,11 +1441,13 @@ void jl_launch_ingest(jl_ctx *ctx, const int32_t *d_pos, const uint32_t *d_cigar
 #endif
     const uint32_t grid = planes_units(ctx);
     constexpr uint32_t E = JL_INGEST_ENT_PER_READ, EB = JL_INGEST_ENT_PER_READ_BIG;
+    // (sibling tiles a workgroup, tools_tuning/nt_probe.sh: with qualities two — 170 us against 179 with one, 213-219 with four (the
+    // registers leave two workgroups a CU); without qualities one: 111-113 with one or two, 132 with four)
     if (qv) {
-        hipLaunchKernelGGL((ingest_planes_kernel<true, E, false>), dim3(grid), dim3(kThreads), 0, st, a);
+        hipLaunchKernelGGL((ingest_planes_kernel<true, E, false, JL_INGEST_NT_QV>), dim3(grid / JL_INGEST_NT_QV), dim3(kThreads), 0, st, a);
         hipLaunchKernelGGL((ingest_planes_kernel<true, EB, true>), dim3(kBigGrid), dim3(kThreads), 0, st, a);
     } else {
-        hipLaunchKernelGGL((ingest_planes_kernel<false, E, false>), dim3(grid), dim3(kThreads), 0, st, a);
+        hipLaunchKernelGGL((ingest_planes_kernel<false, E, false, JL_INGEST_NT>), dim3(grid / JL_INGEST_NT), dim3(kThreads), 0, st, a);
         hipLaunchKernelGGL((ingest_planes_kernel<false, EB, true>), dim3(kBigGrid), dim3(kThreads), 0, st, a);
     }
 }
