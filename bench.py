@@ -689,7 +689,8 @@ def main():
         run_steps(n_units * G)   # the timing hook reads each group's argument table: every group has run
         fence()
         t_pileup_ms, alg_bytes = capi.time_pileup_groups(groups, reps=max(20, args.steps // G))
-        kernel_name = "pileup_planes_group_kernel"
+        # (round 6: the launch the runs make — the pileup with the Fisher stage of its codons in the epilogue; JL_NO_FOLD_CALL=1: the plain one)
+        kernel_name = "pileup_planes_group_kernel" if os.environ.get("JL_NO_FOLD_CALL") else "pileup_fold_group_kernel"
     else:
         alg_bytes = n * l * 3.0 / 8.0
         kernel_name = jl.lib.jl_pileup_kernel_name().decode()

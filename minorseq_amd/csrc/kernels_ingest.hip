@@ -4,16 +4,18 @@
 // :256-259 (a QV-filtered base shows up as N).  Reads past n_reads (the padding of a plane up to its stride) and columns
 // outside a read's span are 'not covered' (code 6).
 //
-// Four launches, two of which find nothing to do on CCS reads; no by-row scratch in HBM:
-//   cigar_runs_kernel   a wave takes four reads: prefix sums over the cigar -> the read's RUNS in WINDOW columns (stretches of
-//                       '=' / 'X' merge into one run of aligned bases; D and N are runs of their own; I / S / H / P only end a
-//                       run), 8 bytes each, between a leading 'not covered from column 0' entry and two trailing ones (the
-//                       read's end; 'never'), so that every column of the window lies in exactly one entry's interval.  Then,
-//                       for every column sweep, ONE 16-byte descriptor per read: where the sweep's entries are, how many, the
-//                       dword the first 16-byte piece of packed bases the sweep needs begins on, how many pieces, the query
-//                       offset of that piece — everything ingest_planes_kernel needs to ask for its input in one round trip.
-//                       The first launch keeps 64 entries a read in LDS (a CCS read has a dozen); the reads with more get
-//                       their descriptors from a second launch that keeps 512 (an indel every 50 columns of a 3 kb read).
+// Five launches, two of which find nothing to do on CCS reads (and one that only zeroes two counters); no by-row scratch in HBM:
+//   cigar_walk_kernel   (round 6) a workgroup takes 64 reads.  One thread a read walks its cigar, sixteen ops a step in registers ->
+//                       the read's RUNS in WINDOW columns (stretches of '=' / 'X' merge into one run of aligned bases; D and N are
+//                       runs of their own; I / S / H / P only end a run), 8 bytes each, between a leading 'not covered from column
+//                       0' entry and two trailing ones (the read's end; 'never'), so that every column of the window lies in exactly
+//                       one entry's interval — into LDS.  Then a thread a (read, sweep) pair: ONE 16-byte descriptor per read and
+//                       column sweep: where the sweep's entries are, how many, the dword the first 16-byte piece of packed bases
+//                       the sweep needs begins on, how many pieces, the query offset of that piece — everything
+//                       ingest_planes_kernel needs to ask for its input in one round trip.  Reads of more than 192 ops or 21 runs
+//                       are left to
+//   cigar_runs_kernel   a row of sixteen lanes a read, prefix sums over the cigar, 512 entries a read in LDS and what is beyond
+//                       read back from HBM (rounds 4-5: also the first launch, with 64 entries a read).
 //   ingest_planes_kernel  a workgroup = 128 reads x one sweep of 256 columns.  One request per read (the descriptor), then
 //                       the entries and the pieces together.  The pieces become nibbles in QUERY order in LDS with plain
 //                       16-byte stores — no run search, no masks.  Meanwhile a thread per read fills a table: for every block
@@ -30,6 +32,9 @@
 //                       instead of five).  A read the workgroup has no room for at all — more inserted bases in a sweep than
 //                       a staging row holds, more than 254 entries in a sweep, entries beyond the second size — is written
 //                       column by column from its entries in HBM by a wave of the SAME workgroup behind its stores (slow_pair).
+//                       With qualities a workgroup of the first size takes TWO sibling tiles one after the other and stores
+//                       their plane words together, 32 bytes of a line a request (round 6: the L2 takes a write request per row
+//                       and tile, 7 x 10^6 a window — the stores were 34 us of the launch's 111, 70 of 184 with qualities).
 //                       (Rounds 1-3 expanded every read into a by-row matrix in HBM: 870 MB moved for the 316 MB needed;
 //                       round 4 scattered the codes into a by-row LDS tile with masked, shifted XORs: 137 us.)
 #include <stdlib.h>

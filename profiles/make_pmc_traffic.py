@@ -19,7 +19,7 @@ def rows(d, counter):
     out = []
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
-            if ("pileup_group_kernel" in r["Kernel_Name"] or "pileup_planes_group_kernel" in r["Kernel_Name"]) and r["Counter_Name"] == counter:
+            if any(k in r["Kernel_Name"] for k in ("pileup_group_kernel", "pileup_planes_group_kernel", "pileup_fold_group_kernel")) and r["Counter_Name"] == counter:
                 out.append(r)
     return out
 
@@ -31,7 +31,8 @@ def condense(rs, counter):
         w = csv.writer(f)
         w.writerow(keep)
         for r in rs:
-            name = "pileup_planes_group_kernel<3,4>" if "planes_group_kernel<3" in r["Kernel_Name"] else r["Kernel_Name"][:60]
+            name = ("pileup_planes_group_kernel<3,4>" if "planes_group_kernel<3" in r["Kernel_Name"] else
+                    "pileup_fold_group_kernel<3,4>" if "fold_group_kernel<3" in r["Kernel_Name"] else r["Kernel_Name"][:60])
             w.writerow([r["Dispatch_Id"], name] + [r[k] for k in keep[2:]])
     # full launches only (the set-up pass also launches partial groups)
     full = max(int(r["Grid_Size"]) for r in rs)
@@ -46,7 +47,7 @@ alg = windows * 100_000 * 3000 * 3 // 8   # 3 bits per cell: every cell of the r
 hbm = int(round((2.0 * fa + wa) * 1024))
 old = json.load(open(os.path.join(here, "pmc_traffic.json")))
 new = {
-    "kernel": "pileup_planes_group_kernel<3,4>",
+    "kernel": "pileup_fold_group_kernel<3,4> (round 6: the pileup with the Fisher stage of its codons in the epilogue; rounds 4-5: pileup_planes_group_kernel<3,4>)",
     "layout": "bit planes: 3 bits per cell, the one resident format (112.5 MB of cells per 100k x 3000 window; the library pads a plane to whole 128-byte lines: 112.9 MB allocated)",
     "windows_per_launch": windows,
     "workload": f"{windows} windows of 100000 reads x 3000 columns per launch (bench default: --group {windows})",
