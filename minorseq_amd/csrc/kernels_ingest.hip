@@ -87,7 +87,7 @@ constexpr uint32_t kRunsReadsPerWave = 4u;   // a wave takes four reads a turn
 #ifndef JL_RUNS_LDS_SMALL
 #define JL_RUNS_LDS_SMALL 64u
 #endif
-constexpr uint32_t kRunsLdsSmall = JL_RUNS_LDS_SMALL, kRunsLdsLarge = 512u;
+constexpr uint32_t kRunsLdsLarge = 512u;
 constexpr uint32_t kRunsDeferred = 0xFFFFFFFFu;   // nruns[r] of a read the first launch (cigar_walk_kernel) leaves to the second
 constexpr uint32_t kRunsLongGrid = 1024u;     // workgroups of the second launch at most: its waves take 64 reads at a time, in turns
 constexpr uint32_t kDescSweeps = 15u;       // sweeps a row of sixteen lanes describes per pass (it needs sixteen bounds)
