@@ -29,7 +29,13 @@ Prints ONE JSON line on rank 0 (see the driver contract in the task brief), incl
                record bytes read + plane bytes written + plane bytes read.
   once_through_qv  the same on the input the reference documents (`ccs --richQVs`, doc/JULIET.md:256-259): filtered bases keep
                their letter and carry a low quality, one quality byte per base resident beside the bases, min_qv = 20.
+  end_to_end   the kept surface: juliet-synth writes a 100k x 3 kb rich-QV BAM, `juliet --timing -c cfg.json --mode-phasing
+               --min-qv 20 in.bam out.json` runs three times as a child process (before this process opens a GPU context), the stage
+               laps are parsed and the JSON is compared with the resident batch that holds the same reads; `--e2e-reads N`: a second size.
   cpu_baseline this repo's CPU restatement (oracle/, kind "port": the reference ships no source) on the host cores.
+
+`--gpus N` (N > 1) without a launcher around it: this process starts the N ranks itself (python -m torch.distributed.run ... as a
+child) and forwards rank 0's line; whatever happens to the ranks, ONE line goes out (launch_ranks; --run-timeout).
 """
 import argparse
 import ctypes as C
