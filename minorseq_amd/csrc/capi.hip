@@ -506,6 +506,8 @@ int jl_ingest_verdict(jl_ctx *ctx)
     if (int rc = jl_fetch_to_host(ctx, ctx->d_ing_count, 16, both, 64)) return rc;
     const unsigned long long w = both[1];
     if (w == ~0ull) return JL_OK;
+    // (read: the word is all ones again for the builds to come — behind whatever this context has enqueued)
+    JL_HIP(ctx, hipMemsetAsync(ctx->d_ing_count + 2, 0xFF, 8, ctx->stream));
     const unsigned long long r = w >> 8;
     const unsigned code = (unsigned)(w & 0xFFu);
     ctx->pileup_done = ctx->call_done = ctx->phase_done = false;
@@ -539,7 +541,12 @@ static int records_build(jl_ctx *src, jl_ctx *dst, uint32_t n_cols, uint32_t win
     if (e == hipSuccess) e = ingest_room(dst, &dst->d_ing_nruns, &dst->ing_cap_reads, nr + 1);
     if (e == hipSuccess) e = ingest_room(dst, &dst->d_ing_desc, &dst->ing_cap_desc, (nr + 1) * ns);
     if (e == hipSuccess) e = ingest_room(dst, &dst->d_ing_slow, &dst->ing_cap_slow, jl_ingest_slow_room(dst));
-    if (e == hipSuccess && !dst->d_ing_count) e = hipMalloc(&dst->d_ing_count, 64);
+    if (e == hipSuccess && !dst->d_ing_count) {
+        e = hipMalloc(&dst->d_ing_count, 64);
+        // (counters zero, the verdict word — [2..3] — all ones: no malformed record seen; kernels_ingest.hip jl_launch_ingest)
+        if (e == hipSuccess) e = hipMemsetAsync(dst->d_ing_count, 0, 64, st);
+        if (e == hipSuccess) e = hipMemsetAsync(dst->d_ing_count + 2, 0xFF, 8, st);
+    }
     dst->ins_valid = false;
     if (e == hipSuccess && dst->track_insertions) {
         if (dst->ins_capacity < n_cols) {
@@ -1644,7 +1651,8 @@ int jl_phase_rerun_unfolded(jl_ctx *ctx)
     JL_HIP(ctx, hipSetDevice(ctx->device));
     JL_HIP(ctx, hipStreamSynchronize(st));
     uint32_t ovf = 0;
-    JL_HIP(ctx, hipMemcpy(&ovf, &ctx->d_meta->overflow, 4, hipMemcpyDeviceToHost));
+    JL_HIP(ctx, hipMemcpyAsync(&ovf, &ctx->d_meta->overflow, 4, hipMemcpyDeviceToHost, st));
+    JL_HIP(ctx, hipStreamSynchronize(st));
     if (!(ovf & 32u)) return jl_fail(ctx, JL_ERR_DEVICE, "the run's result block was not written (no folded launch timed out)");
     ctx->no_fold = true;
     ctx->fold_reruns++;

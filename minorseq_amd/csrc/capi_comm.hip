@@ -446,8 +446,9 @@ static int comm_create(jl_ctx *ctx, const uint8_t id[128], int rank, int world, 
               hipMalloc(&c->d_send, (size_t)JL_PACK_HEAD_BYTES * JL_COMM_SLOTS) == hipSuccess &&
               hipMalloc(&c->d_zero, (size_t)JL_PACK_HEAD_BYTES * JL_GATHER_MAX) == hipSuccess &&
               hipMalloc(&c->d_poison, 8) == hipSuccess &&
-              hipMemset(c->d_zero, 0, (size_t)JL_PACK_HEAD_BYTES * JL_GATHER_MAX) == hipSuccess &&
-              hipMemset(c->d_poison, 0xFF, 8) == hipSuccess &&
+              hipMemsetAsync(c->d_zero, 0, (size_t)JL_PACK_HEAD_BYTES * JL_GATHER_MAX, c->stream) == hipSuccess &&      // (the communicator's own stream: see capi_group.hip)
+              hipMemsetAsync(c->d_poison, 0xFF, 8, c->stream) == hipSuccess &&
+              hipStreamSynchronize(c->stream) == hipSuccess &&
               hipHostMalloc(&c->h_arena, stride * JL_COMM_SLOTS, hipHostMallocDefault) == hipSuccess;
     for (int k = 0; ok && k < JL_COMM_SLOTS; ++k) {
         c->slots[k].d_heads = c->d_arena + stride * (size_t)k;

@@ -303,8 +303,14 @@ int jl_group_run_masked_async(jl_group *g, const jl_gene *genes, uint32_t n_gene
         {
             std::vector<jl_done_ent> ents(n);
             for (uint32_t k = 0; k < n; ++k) { ents[k].seq_dev = g->ctxs[k]->d_sync; ents[k].seq_host = g->ctxs[k]->h_seq; }
-            if (hipMemcpy(g->d_done, ents.data(), sizeof(jl_done_ent) * n, hipMemcpyHostToDevice) != hipSuccess)
-                return group_fail(g, JL_ERR_DEVICE, "argument tables");
+            // (on the group's own stream, not the null stream: rank threads of one process run side by side, and a synchronous copy
+            // on the null stream while another thread captures its graph failed once in a few hundred runs of the suite)
+            hipError_t he = hipMemcpyAsync(g->d_done, ents.data(), sizeof(jl_done_ent) * n, hipMemcpyHostToDevice, g->stream);
+            if (he == hipSuccess) he = hipStreamSynchronize(g->stream);
+            if (he != hipSuccess) {
+                g->err = std::string("argument tables: ") + hipGetErrorString(he);
+                return JL_ERR_DEVICE;
+            }
         }
         g->sig = sig;
     }
@@ -390,7 +396,8 @@ int jl_group_exchange_bind(jl_group *g, jl_comm *c)
     g->x_staged = jl_comm_host_gather(c) == 0;   // (a collective the first time a communicator is asked)
     bool ok = hipHostMalloc(&g->x_host, 2 * g->x_region(), hipHostMallocDefault) == hipSuccess;
     if (ok) memset(g->x_host, 0, 2 * g->x_region());
-    if (ok && g->x_staged) ok = hipMalloc(&g->x_dev, 2 * g->x_region()) == hipSuccess && hipMemset(g->x_dev, 0, 2 * g->x_region()) == hipSuccess;
+    if (ok && g->x_staged) ok = hipMalloc(&g->x_dev, 2 * g->x_region()) == hipSuccess && hipMemsetAsync(g->x_dev, 0, 2 * g->x_region(), g->stream) == hipSuccess &&
+                                hipStreamSynchronize(g->stream) == hipSuccess;
     for (auto &e : g->x_done)
         if (ok && !e) ok = hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
     if (!ok) {

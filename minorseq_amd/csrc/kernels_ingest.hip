@@ -4,7 +4,7 @@
 // :256-259 (a QV-filtered base shows up as N).  Reads past n_reads (the padding of a plane up to its stride) and columns
 // outside a read's span are 'not covered' (code 6).
 //
-// Five launches, two of which find nothing to do on CCS reads (and one that only zeroes two counters); no by-row scratch in HBM:
+// Four launches, two of which find nothing to do on CCS reads; no by-row scratch in HBM:
 //   cigar_walk_kernel   (round 6) a workgroup takes 64 reads.  One thread a read walks its cigar, sixteen ops a step in registers ->
 //                       the read's RUNS in WINDOW columns (stretches of '=' / 'X' merge into one run of aligned bases; D and N are
 //                       runs of their own; I / S / H / P only end a run), 8 bytes each, between a leading 'not covered from column
@@ -12,7 +12,7 @@
 //                       one entry's interval — into LDS.  Then a thread a (read, sweep) pair: ONE 16-byte descriptor per read and
 //                       column sweep: where the sweep's entries are, how many, the dword the first 16-byte piece of packed bases
 //                       the sweep needs begins on, how many pieces, the query offset of that piece — everything
-//                       ingest_planes_kernel needs to ask for its input in one round trip.  Reads of more than 192 ops or 21 runs
+//                       ingest_planes_kernel needs to ask for its input in one round trip.  Reads of more than 192 ops or 29 runs
 //                       are left to
 //   cigar_runs_kernel   a row of sixteen lanes a read, prefix sums over the cigar, 512 entries a read in LDS and what is beyond
 //                       read back from HBM (rounds 4-5: also the first launch, with 64 entries a read).
@@ -411,15 +411,19 @@ __global__ __launch_bounds__(256, JL_RUNS_WAVES) void cigar_runs_kernel(uint64_t
 // A read with more than kWalkOps ops or more than kWalkEnt entries is left, whole, to the launch with a row of lanes a read:
 // nruns[r] = kRunsDeferred.
 constexpr uint32_t kWalkOps = 192u;
-constexpr uint32_t kWalkEnt = 24u;      // entries of a read in LDS (a CCS read has a dozen)
+constexpr uint32_t kWalkEnt = 32u;      // entries of a read in LDS (a CCS read has a dozen; with 24 two reads in a thousand went to the other launch)
 constexpr uint32_t kWalkReads = 64u;    // reads of a workgroup
 
 __global__ __launch_bounds__(256) void cigar_walk_kernel(uint64_t n_reads, const int32_t *__restrict__ pos, const uint32_t *__restrict__ cigar,
                                                          const uint64_t *__restrict__ cig_off, const uint64_t *__restrict__ seq_off,
                                                          const uint64_t *__restrict__ qual_off, uint32_t win_begin, uint32_t n_cols,
                                                          uint32_t n_sweeps, uint2 *__restrict__ runs, uint32_t *__restrict__ nruns,
-                                                         uint4 *__restrict__ desc, unsigned long long *__restrict__ bad)
+                                                         uint4 *__restrict__ desc, unsigned long long *__restrict__ bad,
+                                                         uint32_t *__restrict__ count)
 {
+    // (the build's counters — [0] pairs listed, [1] units handed on — begin at zero: the planes kernels, which count, come behind this
+    // launch on the stream; a launch of its own for this was 4 us of a build)
+    if (blockIdx.x == 0 && threadIdx.x < 2u) count[threadIdx.x] = 0u;
     __shared__ uint2 s_ent[kWalkEnt * kWalkReads];      // entry i of read j at [i * 64 + j]
     __shared__ uint32_t s_nruns[kWalkReads];            // kRunsDeferred: no descriptors from here
     __shared__ uint64_t s_ent0[kWalkReads], s_so[kWalkReads];
@@ -1386,9 +1390,10 @@ constexpr uint32_t kStampPairs = 160u * 4u * 12u;
 size_t jl_ingest_slow_room(const jl_ctx *ctx) { return (size_t)kStampPairs + planes_units(ctx) / 2u + 8u; }
 
 // d_runs: n_cig + 3 n_reads + 8 entries; d_nruns: n_reads; d_desc: n_reads x sweeps descriptors; d_slow: jl_ingest_slow_room() pairs.
-// d_slow_count, 64 bytes: [0] pairs listed, [1] units handed on — zeroed here; [2..3] the 64-bit word of the first malformed
-// record (all ones: none; `keep_verdict`: an earlier build's word has not been read yet — this build's is folded into it,
-// atomicMin); [4..15] the tuning build's checks.  Everything is enqueued on ctx->stream; nothing waits.
+// d_slow_count, 64 bytes: [0] pairs listed, [1] units handed on — zeroed by the build's first launch; [2..3] the 64-bit word of the
+// first malformed record (all ones: none — so it is allocated, and so jl_ingest_verdict leaves it when it has read one; a build
+// whose predecessor's word has not been read yet folds its own into it, atomicMin); [4..15] the tuning build's checks.
+// Everything is enqueued on ctx->stream; nothing waits.
 void jl_launch_ingest(jl_ctx *ctx, const int32_t *d_pos, const uint32_t *d_cigar, const uint64_t *d_cig_off,
                       const uint8_t *d_seq4, const uint64_t *d_seq_off, const uint8_t *d_qual,
                       const uint64_t *d_qual_off, uint32_t min_qv, uint2 *d_runs, uint32_t *d_nruns, uint4 *d_desc,
@@ -1396,15 +1401,17 @@ void jl_launch_ingest(jl_ctx *ctx, const int32_t *d_pos, const uint32_t *d_cigar
 {
     hipStream_t st = ctx->stream;
     const uint32_t ns = jl_ingest_sweeps(ctx->n_cols);
-    // (one small launch instead of two fills: each was a launch of its own, 4 us on the stream)
-    hipLaunchKernelGGL(ingest_init_kernel, dim3(1), dim3(64), 0, st, d_slow_count, keep_verdict ? 0u : 1u);
+    // The counters are zeroed by the first launch (cigar_walk_kernel); the verdict word is all ones from its allocation on and again
+    // whenever a verdict has been read (jl_ingest_verdict): a build whose predecessor's verdict is still unread folds its own into it.
+    (void)keep_verdict;
+    if (!ctx->n_reads) hipLaunchKernelGGL(ingest_init_kernel, dim3(1), dim3(64), 0, st, d_slow_count, 0u);
     if (ctx->n_reads) {
         const uint32_t per_wg = 4u * kRunsReadsPerWave;
         unsigned long long *bad = reinterpret_cast<unsigned long long *>(d_slow_count + 2);
         const uint64_t *qo = d_qual ? d_qual_off : nullptr;
         (void)per_wg;
         hipLaunchKernelGGL(cigar_walk_kernel, dim3((uint32_t)((ctx->n_reads + kWalkReads - 1u) / kWalkReads)), dim3(256), 0, st,
-                           ctx->n_reads, d_pos, d_cigar, d_cig_off, d_seq_off, qo, ctx->win_begin, ctx->n_cols, ns, d_runs, d_nruns, d_desc, bad);
+                           ctx->n_reads, d_pos, d_cigar, d_cig_off, d_seq_off, qo, ctx->win_begin, ctx->n_cols, ns, d_runs, d_nruns, d_desc, bad, d_slow_count);
         hipLaunchKernelGGL((cigar_runs_kernel<kRunsLdsLarge, true>), dim3((uint32_t)std::min<uint64_t>(kRunsLongGrid, (ctx->n_reads + 255u) / 256u)), dim3(256), 0, st,
                            ctx->n_reads, d_pos, d_cigar, d_cig_off, d_seq_off, qo, ctx->win_begin, ctx->n_cols, ns, d_runs, d_nruns, d_desc, bad);
     }

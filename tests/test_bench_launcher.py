@@ -93,7 +93,7 @@ def test_two_ranks_on_one_gpu_end_with_an_error_line():
 def test_whole_run_watchdog_writes_the_line_and_exits_3():
     """One rank driving the N > 1 path (JL_BENCH_FORCE_DIST=1) with a --run-timeout that expires inside the later legs: the line
     holds what was measured so far (the headline figure) plus "error", the exit code is 3."""
-    rc, out, err, dt = _run(["--steps", "64", "--warmup", "16", "--no-cpu-baseline", "--run-timeout", "6"], timeout=300,
+    rc, out, err, dt = _run(["--steps", "64", "--warmup", "16", "--no-cpu-baseline", "--run-timeout", "2"], timeout=300,
                             env_extra={"JL_BENCH_FORCE_DIST": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29671", "RANK": "0",
                                        "WORLD_SIZE": "1", "LOCAL_RANK": "0"})
     lines = _json_lines(out)
