@@ -1084,6 +1084,36 @@ def test_device_ingest_indel_rich_reads(jl, n, l, ins_ppm, del_rate, min_qv):
         jl.records_drop()
 
 
+def test_device_ingest_random_qv_shapes(jl):
+    """A seeded slice of tools_tuning/ingest_stress_qv.py: rich-QV and plain records with insertions, clips, poor qualities and
+    deletion rates drawn at random, windows that begin and end inside the reads, thresholds from 1 to 127 — every cell against
+    the numpy statement (the quality path: unaligned 16-byte quality loads, masks per nibble, two tiles a workgroup)."""
+    import records_expand
+    rng = np.random.default_rng(606)
+    w = capi.Juliet(0)
+    try:
+        for k in range(8):
+            n = int(rng.integers(1, 9000))
+            l = int(rng.integers(40, 2600))
+            extra = ["--rich-qv"] if rng.random() < 0.7 else []
+            extra += ["--ins-ppm", str(int(rng.choice([0, 800, 5000, 30000]))), "--low-qv-ppm", str(int(rng.choice([0, 20000, 300000]))),
+                      "--del", str(float(rng.choice([0.0, 0.0013, 0.01, 0.08]))), "--partial", str(float(rng.choice([0.0, 0.3, 0.9])))]
+            if rng.random() < 0.5:
+                extra += ["--clips"]
+            rec = synth.raw_records(3000 + k, n, l, extra=tuple(extra))
+            jl.records_upload(rec["pos"], rec["cigar"], rec["cig_off"], rec["seq4"], rec["seq_off"], rec["qual"], rec["qual_off"])
+            for _ in range(2):
+                b = int(rng.integers(0, max(1, l // 2)))
+                e = int(rng.integers(b + 1, l + 1))
+                min_qv = int(rng.choice([1, 5, 13, 20, 60, 94, 127]))
+                w.records_window(jl, e - b, b, min_qv)
+                got = msa.unpack_columns(w.download_columns(), n)
+                assert (got == records_expand.expand(rec, e - b, b, min_qv)).all(), (k, n, l, b, e, min_qv, extra)
+            jl.records_drop()
+    finally:
+        w.close()
+
+
 def test_device_ingest_random_shapes(jl):
     """A seeded slice of tools_tuning/ingest_stress.py: read counts, widths, indel and mask rates and windows drawn at random,
     with and without qualities."""
