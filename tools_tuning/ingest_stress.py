@@ -1,5 +1,5 @@
 """Randomised check of the device ingest against synth.rows: many seeds, indel and mask rates, window offsets, with and
-without qualities (the helpers of tests/test_gpu_parity.py).  usage: ingest_stress.py [rounds]"""
+without qualities (the helpers of tests/test_gpu_parity.py).  usage: ingest_stress.py [rounds [seed]]"""
 import os
 import sys
 
@@ -13,7 +13,7 @@ from test_gpu_parity import rows_to_records  # noqa: E402
 
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 jl = capi.Juliet(0)
-rng = np.random.default_rng(2024)
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2024)
 for k in range(rounds):
     n = int(rng.integers(1, 6000))
     l = int(rng.integers(30, 1500))

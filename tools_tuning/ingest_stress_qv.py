@@ -1,6 +1,6 @@
 """Randomised check of the device ingest's QUALITY path against the numpy statement (tests/records_expand.py): juliet-synth raw
 records in the rich-QV shape with insertions, clips, extra poor qualities and deletion rates drawn at random, random windows that
-begin and end inside the reads, random thresholds — every cell.  usage: ingest_stress_qv.py [rounds]"""
+begin and end inside the reads, random thresholds — every cell.  usage: ingest_stress_qv.py [rounds [seed]]"""
 import os
 import sys
 
@@ -15,7 +15,7 @@ from minorseq_amd import capi, msa, synth  # noqa: E402
 if os.environ.get("JL_LIB"):
     capi.load_library(os.environ["JL_LIB"])
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 30
-rng = np.random.default_rng(606)
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 606)
 jl = capi.Juliet(0)
 w = capi.Juliet(0)
 for k in range(rounds):
