@@ -8,6 +8,7 @@ cp $R/include/juliet_hip.h $B/include/
 mkdir -p $B/csrc_root/minorseq_amd; mv $B/csrc $B/csrc_root/minorseq_amd/csrc; cp -r $B/include $B/csrc_root/
 make -s -j8 -C $B/csrc_root/minorseq_amd/csrc clean >/dev/null 2>&1 || true
 make -s -j8 -C $B/csrc_root/minorseq_amd/csrc EXTRA="-DJL_TUNING $1"
+mkdir -p $R/tools_tuning/lib_exp
 cp $B/csrc_root/minorseq_amd/libjuliet_hip.so $R/tools_tuning/lib_exp/${2:-libjuliet_hip.so}
 rm -rf $B
 echo built $R/tools_tuning/lib_exp/${2:-libjuliet_hip.so}
