@@ -806,7 +806,7 @@ def main():
 
 def once_through(capi, synth, torch, jl0, genes, refseq, prm, expect, rank, local_rank, n, l, win_begin, steps, qv=False):
     """A FRESH window per step: aligned records (positions, cigars, BAM's packed bases — what a BAM decoder
-    holds, resident in HBM as the brief prescribes for `value`) -> ingest into the bit planes (jl_records_window_async: four
+    holds, resident in HBM as the brief prescribes for `value`) -> ingest into the bit planes (jl_records_window_async: three or four
     launches) -> pileup -> Fisher -> phasing -> results in pinned host memory, the whole chain enqueued on one stream per
     window, four windows in flight.  The reads are those of resident batch 0 (same seed), so every step's result is compared
     with that batch's; four copies of the records at different addresses and four window matrices rotate, so no step finds
@@ -883,7 +883,7 @@ def once_through(capi, synth, torch, jl0, genes, refseq, prm, expect, rank, loca
     res = {"workload": f"a fresh window per step: records of {n} CCS reads x {l} bp (positions, cigars, 4-bit bases"
                        + (", one quality byte per base: the documented `ccs --richQVs` shape, filtered bases keep their letter, min_qv = 20"
                           if qv else "; filtered bases travel as N letters") + "; resident in HBM) -> "
-                       "ingest into the bit planes (four launches) -> pileup + Fisher + phasing -> results on the host; 4 windows in flight, "
+                       "ingest into the bit planes (three launches for these reads, four when a read may be a long one) -> pileup + Fisher + phasing -> results on the host; 4 windows in flight, "
                        "every step's result verified",
            "min_qv": min_qv, "cigar_ops_per_read": ops_per_read, "record_bytes_by_array": parts,
            "value": n / t, "unit": "reads/s", "ms_per_step": 1000.0 * t, "steps": steps, "cells_verified_before_loop": n * l,

@@ -399,9 +399,19 @@ int jl_records_append(jl_ctx *ctx, uint64_t n_reads, const int32_t *pos, const u
         records_drop(ctx);
         return jl_fail(ctx, JL_ERR_ARG, what, (unsigned long long)(first + r), (unsigned long long)v);
     };
-    for (uint64_t r = 0; r < n_reads; ++r)
+    // ... and whether a read needs the ingest's launch for long reads: only a read with more ops than entries fit can, and a CCS
+    // sample has few of those — their cigars are looked at here, a word per read of the chunk at most (then: "maybe")
+    const uint64_t short_ops = jl_ingest_short_ops();
+    uint64_t looked = 0;
+    for (uint64_t r = 0; r < n_reads; ++r) {
         if (cig_off[r + 1] < cig_off[r] || seq_off[r + 1] < seq_off[r] || (qual && qual_off[r + 1] < qual_off[r]))
             return bad(r, "record %llu: offsets must not decrease", 0);
+        const uint64_t n_ops = cig_off[r + 1] - cig_off[r];
+        if (n_ops > short_ops && !R.maybe_long) {
+            looked += n_ops;
+            R.maybe_long = looked > n_reads + 4096u || jl_ingest_read_is_long(cigar + cig_off[r], n_ops);
+        }
+    }
     JL_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     // the chunk's arrays start wherever its offsets say; on the device everything is one run of arrays
@@ -513,6 +523,7 @@ int jl_ingest_verdict(jl_ctx *ctx)
     ctx->pileup_done = ctx->call_done = ctx->phase_done = false;
     if (code == 1u) return jl_fail(ctx, JL_ERR_ARG, "record %llu: cigar M is forbidden in PacBio-compliant BAM (doc/JULIET.md:53)", r);
     if (code == 4u) return jl_fail(ctx, JL_ERR_ARG, "record %llu: its cigar spans 2^30 reference bases or more", r);
+    if (code == 5u) return jl_fail(ctx, JL_ERR_STATE, "record %llu: a long cigar the upload had not seen (jl_ingest_read_is_long and cigar_walk_kernel disagree)", r);
     return jl_fail(ctx, JL_ERR_ARG, "record %llu: its cigar consumes more %s than the record holds", r, code == 2u ? "bases" : "qualities");
 }
 
@@ -569,7 +580,7 @@ static int records_build(jl_ctx *src, jl_ctx *dst, uint32_t n_cols, uint32_t win
     if (e == hipSuccess) {
         jl_launch_ingest(dst, R.d_pos, R.d_cig, R.d_co, R.d_seq, R.d_so, R.have_qual ? R.d_qual : nullptr,
                          R.have_qual ? R.d_qo : nullptr, min_qv, dst->d_ing_runs, dst->d_ing_nruns, dst->d_ing_desc, dst->d_ing_count,
-                         dst->d_ing_slow, dst->ing_check_pending, R.n_seq, R.n_cig + 3 * nr + 8);
+                         dst->d_ing_slow, R.maybe_long, R.n_seq, R.n_cig + 3 * nr + 8);
         e = hipGetLastError();
         dst->ing_check_pending = e == hipSuccess;
         if (e == hipSuccess && wait) e = hipStreamSynchronize(st);

@@ -302,6 +302,9 @@ struct jl_records {
     int32_t *d_pos = nullptr;
     size_t cap_seq = 0, cap_qual = 0, cap_cig = 0, cap_co = 0, cap_so = 0, cap_qo = 0, cap_pos = 0;
     uint64_t n_reads = 0, n_cig = 0, n_seq = 0, n_qual = 0;
+    // does any read need the ingest's launch for long reads (kernels_ingest.hip jl_ingest_read_is_long)?  Found out at the upload for
+    // the few reads a CCS sample has with more ops than entries fit; `true` as soon as looking would cost more than the launch
+    bool maybe_long = false;
 };
 
 struct jl_ctx {
@@ -525,10 +528,12 @@ extern "C" int jl_run_wait_impl(jl_ctx *ctx);
 extern "C" int jl_run_wait_seq(jl_ctx *ctx, uint32_t want);
 void jl_launch_consensus(jl_ctx *ctx, uint8_t *d_out);
 void jl_launch_clock(jl_ctx *ctx, hipStream_t st, uint32_t which);   // h_seq[8 + 2 which ..] = the device's 100 MHz clock
+uint32_t jl_ingest_short_ops();
+bool jl_ingest_read_is_long(const uint32_t *cigar, uint64_t n_ops);
 void jl_launch_ingest(jl_ctx *ctx, const int32_t *d_pos, const uint32_t *d_cigar, const uint64_t *d_cig_off,
                       const uint8_t *d_seq4, const uint64_t *d_seq_off, const uint8_t *d_qual,
                       const uint64_t *d_qual_off, uint32_t min_qv, uint2 *d_runs, uint32_t *d_nruns, uint4 *d_desc,
-                      uint32_t *d_slow_count, uint2 *d_slow, bool keep_verdict, uint64_t seq_bytes, uint64_t n_entries);
+                      uint32_t *d_slow_count, uint2 *d_slow, bool maybe_long, uint64_t seq_bytes, uint64_t n_entries);
 uint32_t jl_ingest_sweeps(uint32_t n_cols);
 size_t jl_ingest_slow_room(const jl_ctx *ctx);
 extern "C" int jl_ingest_verdict(jl_ctx *ctx);

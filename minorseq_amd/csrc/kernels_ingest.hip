@@ -4,7 +4,9 @@
 // :256-259 (a QV-filtered base shows up as N).  Reads past n_reads (the padding of a plane up to its stride) and columns
 // outside a read's span are 'not covered' (code 6).
 //
-// Four launches, two of which find nothing to do on CCS reads; no by-row scratch in HBM:
+// Four launches at most, three for a CCS sample (the upload looks at the cigars of the few reads that could be long ones —
+// jl_ingest_read_is_long — and cigar_runs_kernel is launched only if there may be one; the planes kernel's second size finds nothing
+// to do on CCS reads); no by-row scratch in HBM:
 //   cigar_walk_kernel   (round 6) a workgroup takes 64 reads.  One thread a read walks its cigar, sixteen ops a step in registers ->
 //                       the read's RUNS in WINDOW columns (stretches of '=' / 'X' merge into one run of aligned bases; D and N are
 //                       runs of their own; I / S / H / P only end a run), 8 bytes each, between a leading 'not covered from column
@@ -12,7 +14,7 @@
 //                       one entry's interval — into LDS.  Then a thread a (read, sweep) pair: ONE 16-byte descriptor per read and
 //                       column sweep: where the sweep's entries are, how many, the dword the first 16-byte piece of packed bases
 //                       the sweep needs begins on, how many pieces, the query offset of that piece — everything
-//                       ingest_planes_kernel needs to ask for its input in one round trip.  Reads of more than 192 ops or 29 runs
+//                       ingest_planes_kernel needs to ask for its input in one round trip.  Reads of more than 192 ops or 37 runs
 //                       are left to
 //   cigar_runs_kernel   a row of sixteen lanes a read, prefix sums over the cigar, 512 entries a read in LDS and what is beyond
 //                       read back from HBM (rounds 4-5: also the first launch, with 64 entries a read).
@@ -104,7 +106,7 @@ constexpr uint32_t kDescMax = 255u;         // "more than the planes kernel take
 
 // The records are untrusted: a cigar with an 'M' (forbidden in PacBio BAM, doc/JULIET.md:53), one that consumes more bases
 // (or qualities) than the record holds, or one that spans 2^30 reference bases or more is reported — *bad = min over such reads
-// of (read << 8 | code), code 1 'M', 2 bases, 3 qualities, 4 span — and the read is treated as covering nothing, so no later
+// of (read << 8 | code), code 1 'M', 2 bases, 3 qualities, 4 span (5: see cigar_walk_kernel) — and the read is treated as covering nothing, so no later
 // kernel follows its offsets anywhere.  Lengths add up in 64 bits (a step that holds an op of 2^24 bases or more is summed
 // exactly, lane by lane), so no crafted cigar wraps a sum back into range.
 #ifndef JL_RUNS_WAVES
@@ -411,7 +413,12 @@ __global__ __launch_bounds__(256, JL_RUNS_WAVES) void cigar_runs_kernel(uint64_t
 // A read with more than kWalkOps ops or more than kWalkEnt entries is left, whole, to the launch with a row of lanes a read:
 // nruns[r] = kRunsDeferred.
 constexpr uint32_t kWalkOps = 192u;
-constexpr uint32_t kWalkEnt = 32u;      // entries of a read in LDS (a CCS read has a dozen; with 24 two reads in a thousand went to the other launch)
+#ifndef JL_WALK_ENT
+#define JL_WALK_ENT 40
+#endif
+// entries of a read in LDS: a CCS read has a dozen.  With 24 two reads in a thousand went to the other launch; with 32 two in 100 000
+// (fifteen deletions) — enough for the upload to have to ask for that launch in every build; with 40 none of a CCS sample does (48: 26 KB of LDS a workgroup, six a CU — not all 1563 of a 100k-read build at once: 28 us instead of 22)
+constexpr uint32_t kWalkEnt = JL_WALK_ENT;
 constexpr uint32_t kWalkReads = 64u;    // reads of a workgroup
 
 __global__ __launch_bounds__(256) void cigar_walk_kernel(uint64_t n_reads, const int32_t *__restrict__ pos, const uint32_t *__restrict__ cigar,
@@ -419,8 +426,11 @@ __global__ __launch_bounds__(256) void cigar_walk_kernel(uint64_t n_reads, const
                                                          const uint64_t *__restrict__ qual_off, uint32_t win_begin, uint32_t n_cols,
                                                          uint32_t n_sweeps, uint2 *__restrict__ runs, uint32_t *__restrict__ nruns,
                                                          uint4 *__restrict__ desc, unsigned long long *__restrict__ bad,
-                                                         uint32_t *__restrict__ count)
+                                                         uint32_t *__restrict__ count, uint32_t second)
 {
+    // second = 0: the host has looked at the cigars (jl_ingest_read_is_long, at the upload) and found no read for the other launch, which
+    // is then not made (6 us of a build).  Should this kernel find one all the same, the read covers nothing and the build fails with
+    // code 5 — never descriptors nobody wrote.
     // (the build's counters — [0] pairs listed, [1] units handed on — begin at zero: the planes kernels, which count, come behind this
     // launch on the stream; a launch of its own for this was 4 us of a build)
     if (blockIdx.x == 0 && threadIdx.x < 2u) count[threadIdx.x] = 0u;
@@ -438,6 +448,13 @@ __global__ __launch_bounds__(256) void cigar_walk_kernel(uint64_t n_reads, const
             const uint32_t n_ops = (uint32_t)min(c_end - my_cb, (uint64_t)0xFFFFFF00u);
             s_ent0[j] = my_cb + 3u * r;
             s_so[j] = my_so;
+            if (n_ops > kWalkOps && !second) {
+                atomicMin(bad, ((unsigned long long)r << 8) | 5u);
+                n_runs = 0;
+                s_ent[j] = make_uint2(3u << 30, 0u);
+                s_ent[kWalkReads + j] = make_uint2(3u << 30, 0u);
+                s_ent[2u * kWalkReads + j] = make_uint2(kRunMask | (3u << 30), 0u);
+            }
             if (n_ops <= kWalkOps) {
                 const uint32_t *cig = cigar + my_cb;
                 auto window_col = [&](uint64_t ref, uint32_t &before) -> uint32_t {
@@ -488,9 +505,9 @@ __global__ __launch_bounds__(256) void cigar_walk_kernel(uint64_t n_reads, const
                     }
                     cur = nxt;
                 }
-                if (n_runs + 3u > kWalkEnt) n_runs = kRunsDeferred;
+                if (n_runs + 3u > kWalkEnt && second) n_runs = kRunsDeferred;
                 else {
-                    uint32_t code = has_m ? 1u : 0u;
+                    uint32_t code = n_runs + 3u > kWalkEnt ? 5u : has_m ? 1u : 0u;
                     if (!code) {
                         if (q_at > 2u * (so1 - my_so) || q_at > 0x7FFFFFFFull) code = 2u;
                         else if (q_at > qlen) code = 3u;
@@ -1389,6 +1406,24 @@ static uint32_t planes_units(const jl_ctx *ctx)
 constexpr uint32_t kStampPairs = 160u * 4u * 12u;
 size_t jl_ingest_slow_room(const jl_ctx *ctx) { return (size_t)kStampPairs + planes_units(ctx) / 2u + 8u; }
 
+// The host's copy of cigar_walk_kernel's rule — which reads it leaves to the second launch (more than kWalkOps ops, or more entries
+// than a read has room for in its LDS) — for the upload (jl_records_append), which looks at the few reads of a CCS sample with more
+// ops than a read has entries: when it finds none, jl_launch_ingest does not make that launch.
+uint32_t jl_ingest_short_ops() { return kWalkEnt - 3u; }      // a read of so many ops at most cannot be a long one
+bool jl_ingest_read_is_long(const uint32_t *cigar, uint64_t n_ops)
+{
+    if (n_ops > kWalkOps) return true;
+    constexpr uint32_t kKinds = (2u << 4) | (3u << 6) | (1u << 14) | (1u << 16);   // two bits per op: D, N, =, X (cigar_walk_kernel)
+    uint32_t n_runs = 0, prev_kind = 0;
+    for (uint64_t t = 0; t < n_ops; ++t) {
+        const uint32_t op = cigar[t] & 15u, len = cigar[t] >> 4;
+        const uint32_t kind = len == 0u ? 0u : (kKinds >> (2u * op)) & 3u;
+        if (kind != 0u && !(kind == 1u && prev_kind == 1u)) ++n_runs;
+        prev_kind = kind;
+    }
+    return n_runs + 3u > kWalkEnt;
+}
+
 // d_runs: n_cig + 3 n_reads + 8 entries; d_nruns: n_reads; d_desc: n_reads x sweeps descriptors; d_slow: jl_ingest_slow_room() pairs.
 // d_slow_count, 64 bytes: [0] pairs listed, [1] units handed on — zeroed by the build's first launch; [2..3] the 64-bit word of the
 // first malformed record (all ones: none — so it is allocated, and so jl_ingest_verdict leaves it when it has read one; a build
@@ -1397,13 +1432,12 @@ size_t jl_ingest_slow_room(const jl_ctx *ctx) { return (size_t)kStampPairs + pla
 void jl_launch_ingest(jl_ctx *ctx, const int32_t *d_pos, const uint32_t *d_cigar, const uint64_t *d_cig_off,
                       const uint8_t *d_seq4, const uint64_t *d_seq_off, const uint8_t *d_qual,
                       const uint64_t *d_qual_off, uint32_t min_qv, uint2 *d_runs, uint32_t *d_nruns, uint4 *d_desc,
-                      uint32_t *d_slow_count, uint2 *d_slow, bool keep_verdict, uint64_t seq_bytes, uint64_t n_entries)
+                      uint32_t *d_slow_count, uint2 *d_slow, bool maybe_long, uint64_t seq_bytes, uint64_t n_entries)
 {
     hipStream_t st = ctx->stream;
     const uint32_t ns = jl_ingest_sweeps(ctx->n_cols);
     // The counters are zeroed by the first launch (cigar_walk_kernel); the verdict word is all ones from its allocation on and again
     // whenever a verdict has been read (jl_ingest_verdict): a build whose predecessor's verdict is still unread folds its own into it.
-    (void)keep_verdict;
     if (!ctx->n_reads) hipLaunchKernelGGL(ingest_init_kernel, dim3(1), dim3(64), 0, st, d_slow_count, 0u);
     if (ctx->n_reads) {
         const uint32_t per_wg = 4u * kRunsReadsPerWave;
@@ -1411,7 +1445,9 @@ void jl_launch_ingest(jl_ctx *ctx, const int32_t *d_pos, const uint32_t *d_cigar
         const uint64_t *qo = d_qual ? d_qual_off : nullptr;
         (void)per_wg;
         hipLaunchKernelGGL(cigar_walk_kernel, dim3((uint32_t)((ctx->n_reads + kWalkReads - 1u) / kWalkReads)), dim3(256), 0, st,
-                           ctx->n_reads, d_pos, d_cigar, d_cig_off, d_seq_off, qo, ctx->win_begin, ctx->n_cols, ns, d_runs, d_nruns, d_desc, bad, d_slow_count);
+                           ctx->n_reads, d_pos, d_cigar, d_cig_off, d_seq_off, qo, ctx->win_begin, ctx->n_cols, ns, d_runs, d_nruns, d_desc, bad, d_slow_count, maybe_long ? 1u : 0u);
+        // (the launch for the long reads: not when the upload has looked and found none — every CCS sample: 6 us of a build)
+        if (maybe_long)
         hipLaunchKernelGGL((cigar_runs_kernel<kRunsLdsLarge, true>), dim3((uint32_t)std::min<uint64_t>(kRunsLongGrid, (ctx->n_reads + 255u) / 256u)), dim3(256), 0, st,
                            ctx->n_reads, d_pos, d_cigar, d_cig_off, d_seq_off, qo, ctx->win_begin, ctx->n_cols, ns, d_runs, d_nruns, d_desc, bad);
     }

@@ -1084,6 +1084,69 @@ def test_device_ingest_indel_rich_reads(jl, n, l, ins_ppm, del_rate, min_qv):
         jl.records_drop()
 
 
+def _records_from_cigars(cigars, rng, pos=None):
+    """records (the dict of synth.raw_records) from lists of (op letter, length); bases drawn at random, qualities 93"""
+    OPS = {"M": 0, "I": 1, "D": 2, "N": 3, "S": 4, "H": 5, "P": 6, "=": 7, "X": 8}
+    rec = {"pos": [], "cigar": [], "cig_off": [0], "seq4": [], "seq_off": [0], "qual": [], "qual_off": [0]}
+    for i, ops in enumerate(cigars):
+        rec["pos"].append(0 if pos is None else pos[i])
+        rec["cigar"] += [(ln << 4) | OPS[op] for op, ln in ops]
+        rec["cig_off"].append(len(rec["cigar"]))
+        nq = sum(ln for op, ln in ops if op in "=XIS")
+        codes = [int(x) for x in rng.choice([1, 2, 4, 8], nq)] + [0]
+        rec["seq4"] += [(codes[k] << 4) | codes[k + 1] for k in range(0, nq, 2)]
+        rec["seq_off"].append(len(rec["seq4"]))
+        rec["qual"] += [93] * nq
+        rec["qual_off"].append(len(rec["qual"]))
+    kinds = {"pos": np.int32, "cigar": np.uint32, "cig_off": np.uint64, "seq4": np.uint8, "seq_off": np.uint64, "qual": np.uint8, "qual_off": np.uint64}
+    return {k: np.array(v, dtype=kinds[k]) for k, v in rec.items()}
+
+
+@pytest.mark.parametrize("with_long", [False, True])
+def test_device_ingest_reads_at_the_long_read_boundary(jl, with_long):
+    """cigar_walk_kernel leaves a read of more than 192 ops or more than 37 runs to the launch for long reads, and the upload looks
+    at the cigars (jl_ingest_read_is_long) to find out whether that launch is needed at all: reads of exactly 35..37 runs, of 192
+    ops that are one run ('=' and 'X' in turns), with insertions and zero-length ops that end runs — none long (the launch is not
+    made), then the same with reads of 38, 39 and 60 runs and of 193 ops among them (it is) — every cell."""
+    rng = np.random.default_rng(29 + with_long)
+    l = 700
+
+    def alternating(n_runs, gap="D"):      # n_runs runs: aligned, gap, aligned, ... over about 600 columns
+        n_al = (n_runs + 1) // 2
+        ops = []
+        for k in range(n_runs):
+            ops.append(("=", 600 // n_runs) if k % 2 == 0 else (gap, 1 + k % 3))
+        assert sum(1 for op, _ in ops if op == "=") == n_al
+        return ops
+
+    cigars = []
+    for n_runs in (1, 5, 35, 36, 37):
+        cigars += [alternating(n_runs), alternating(n_runs, "N"), [("S", 3)] + alternating(n_runs) + [("H", 2)]]
+    cigars.append([("=", 2) if k % 2 == 0 else ("X", 1) for k in range(192)])                       # 192 ops, one run
+    cigars.append(sum(([("=", 20), ("I", 2)] for _ in range(14)), []) + [("=", 20)])                # insertions end runs: 15 runs, 29 ops
+    cigars.append(sum(([("=", 9), ("D", 0), ("X", 1)] for _ in range(36)), []) + [("=", 5)])        # zero-length ops end runs: 37 runs, 109 ops
+    cigars.append(sum(([("=", 9), ("P", 1), ("X", 1)] for _ in range(14)), []))                     # so do pads: 15 runs
+    if with_long:
+        for n_runs in (38, 39, 60):
+            cigars += [alternating(n_runs), alternating(n_runs, "N")]
+        cigars.append([("=", 2) if k % 2 == 0 else ("X", 1) for k in range(193)])                   # one run, but 193 ops
+        cigars.append(sum(([("=", 9), ("D", 0), ("X", 1)] for _ in range(37)), []) + [("=", 5)])    # 38 runs
+    order = rng.permutation(len(cigars))
+    cigars = [cigars[i] for i in order] * 3             # (several tiles' worth would need thousands: three copies, different starts)
+    pos = [int(p) for p in rng.integers(0, 60, len(cigars))]
+    rec = _records_from_cigars(cigars, rng, pos)
+    n = len(cigars)
+    jl.records_upload(rec["pos"], rec["cigar"], rec["cig_off"], rec["seq4"], rec["seq_off"], rec["qual"], rec["qual_off"])
+    w = capi.Juliet(0)
+    try:
+        for b, e, min_qv in ((0, l, 0), (17, 640, 20), (300, 301, 0)):
+            w.records_window(jl, e - b, b, min_qv)
+            assert _cells_equal(w, rec, n, e - b, b, min_qv) is None, (b, e, min_qv)
+    finally:
+        w.close()
+        jl.records_drop()
+
+
 def test_device_ingest_random_qv_shapes(jl):
     """A seeded slice of tools_tuning/ingest_stress_qv.py: rich-QV and plain records with insertions, clips, poor qualities and
     deletion rates drawn at random, windows that begin and end inside the reads, thresholds from 1 to 127 — every cell against
