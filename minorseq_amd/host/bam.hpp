@@ -56,10 +56,15 @@ public:
 
     // aux fields from offset o: `rq` (float) and the rich-QV strings dq / iq / sq are interpreted; everything else is
     // skipped by type
-    static void parse_aux(const uint8_t *p, size_t o, size_t block, BamRecord &r)
+    // what a record's tags say that this reader uses: rq, and where the rich-QV tracks dq / iq / sq lie in the record (not copied)
+    struct AuxViews {
+        float rq = -1.f;
+        const char *track[3] = {nullptr, nullptr, nullptr};   // dq, iq, sq
+        size_t len[3] = {0, 0, 0};
+    };
+    static void scan_aux(const uint8_t *p, size_t o, size_t block, AuxViews &v)
     {
-        r.rq = -1.f;
-        r.dq.clear(); r.iq.clear(); r.sq.clear();
+        v = AuxViews();
         while (o + 3 <= block) {
             const char t0 = (char)p[o], t1 = (char)p[o + 1], ty = (char)p[o + 2];
             o += 3;
@@ -68,7 +73,11 @@ public:
             case 'A': case 'c': case 'C': len = 1; break;
             case 's': case 'S': len = 2; break;
             case 'i': case 'I': case 'f': len = 4; break;
-            case 'Z': case 'H': while (o + len < block && p[o + len]) ++len; ++len; break;
+            case 'Z': case 'H': {     // to the terminating NUL (memchr: the rich-QV tracks are a byte per base, three times a read)
+                const void *z = memchr(p + o, 0, block - o);
+                len = (z ? (size_t)((const uint8_t *)z - (p + o)) : block - o) + 1;
+                break;
+            }
             case 'B': {
                 if (o + 5 > block) throw std::runtime_error("truncated BAM aux array");
                 const char sub = (char)p[o];
@@ -80,13 +89,23 @@ public:
             default: throw std::runtime_error("unknown BAM aux type");
             }
             if (o + len > block) throw std::runtime_error("truncated BAM aux field");
-            if (t0 == 'r' && t1 == 'q' && ty == 'f') memcpy(&r.rq, p + o, 4);
+            if (t0 == 'r' && t1 == 'q' && ty == 'f') memcpy(&v.rq, p + o, 4);
             if (ty == 'Z' && t1 == 'q' && (t0 == 'd' || t0 == 'i' || t0 == 's')) {
-                std::string &dst = t0 == 'd' ? r.dq : t0 == 'i' ? r.iq : r.sq;
-                dst.assign((const char *)p + o, len - 1);
+                const int k = t0 == 'd' ? 0 : t0 == 'i' ? 1 : 2;
+                v.track[k] = (const char *)p + o;
+                v.len[k] = len - 1;
             }
             o += len;
         }
+    }
+    static void parse_aux(const uint8_t *p, size_t o, size_t block, BamRecord &r)
+    {
+        AuxViews v;
+        scan_aux(p, o, block, v);
+        r.rq = v.rq;
+        r.dq.assign(v.track[0] ? v.track[0] : "", v.len[0]);
+        r.iq.assign(v.track[1] ? v.track[1] : "", v.len[1]);
+        r.sq.assign(v.track[2] ? v.track[2] : "", v.len[2]);
     }
 
     // the bytes of the next record (after its block_size word), in place when they lie inside the reader's inflated

@@ -5,6 +5,8 @@
 // (doc/JULIET.md:62-66, 121, 160-163, 195, 270-271, 342-344, 352-354, 370).  Everything the reference text
 // leaves open is an explicit flag with the docs/SPEC.md default.  All compute happens on the GPU through
 // the C ABI; without a gfx950 device the tool exits with status 3.
+#include <unistd.h>
+
 #include <chrono>
 #include <condition_variable>
 #include <deque>
@@ -211,6 +213,70 @@ void die_jl(jl_ctx *ctx, const char *what)
     std::exit(3);
 }
 
+// A few threads that copy: the uploader's gather is 0.45 GB into pages nobody has touched yet (1.35 GB of a 100k-read rich-QV BAM's
+// records become 0.45 GB of arrays).  As range inserts on the uploader thread it was 120-140 ms — a vector with an allocator of its own
+// inserts element by element — more than the whole decode takes since the quality tracks are folded sixteen bases an instruction;
+// as memcpy in 1 MB pieces by these threads and the uploader 18-34 ms.  add() splits a copy; wait() helps until every piece is done.
+class CopyCrew {
+public:
+    explicit CopyCrew(unsigned n)
+    {
+        for (unsigned i = 0; i < n; ++i) th_.emplace_back([this] { work(false); });
+    }
+    ~CopyCrew()
+    {
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        for (auto &t : th_) t.join();
+    }
+    void add(void *dst, const void *src, size_t bytes)
+    {
+        const size_t piece = (size_t)1 << 20;
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            for (size_t o = 0; o < bytes; o += piece) {
+                q_.push_back({(uint8_t *)dst + o, (const uint8_t *)src + o, std::min(piece, bytes - o)});
+                ++pending_;
+            }
+        }
+        cv_.notify_all();
+    }
+    void wait() { work(true); }
+
+private:
+    struct Job { uint8_t *dst; const uint8_t *src; size_t n; };
+    void work(bool until_idle)
+    {
+        std::unique_lock<std::mutex> lk(m_);
+        for (;;) {
+            if (!q_.empty()) {
+                const Job j = q_.front();
+                q_.pop_front();
+                lk.unlock();
+                memcpy(j.dst, j.src, j.n);
+                lk.lock();
+                if (--pending_ == 0) done_.notify_all();
+                continue;
+            }
+            if (until_idle) {
+                done_.wait(lk, [this] { return pending_ == 0; });
+                return;
+            }
+            if (stop_) return;
+            cv_.wait(lk, [this] { return stop_ || !q_.empty(); });
+        }
+    }
+    std::mutex m_;
+    std::condition_variable cv_, done_;
+    std::deque<Job> q_;
+    size_t pending_ = 0;
+    bool stop_ = false;
+    std::vector<std::thread> th_;
+};
+
 // Hands decoded records to the device chunk by chunk while the parser works on the next chunk: the upload (0.03 s for
 // 100k reads) hides under the decode whenever the GPU context is up before the file ends; chunks that arrive earlier
 // simply wait.  One consumer thread: chunks stay in file order.
@@ -282,19 +348,27 @@ private:
     // source range first, and sixty-one chunks of a few MB, each a buffer the runtime has not seen, cost 16-25 ms where the same
     // 200 MB out of five arrays cost 5-6 (tools_tuning/h2d_threads.cpp: 21 against 36 GB/s on first touch).  The gathering
     // itself runs beside the decode, on this thread.
+    // (the large arrays — bases, qualities, cigar words — by the copy crew: the chunk and `big_` must stay as they are until crew_.wait())
+    template <typename V, typename W> void gather_array(V &dst, const W &src)
+    {
+        const size_t at = dst.size();
+        if (at + src.size() > dst.capacity()) crew_.wait();      // (it moves: nobody may be copying into the old place)
+        dst.resize(at + src.size());
+        crew_.add(dst.data() + at, src.data(), src.size() * sizeof(src[0]));
+    }
     void gather(const RecordArrays &c)
     {
         const size_t n = c.pos.size();
         const uint64_t cb = big_.cigar.size(), sb = big_.seq4.size(), qb = big_.qual.size();
         big_.pos.insert(big_.pos.end(), c.pos.begin(), c.pos.end());
-        big_.cigar.insert(big_.cigar.end(), c.cigar.begin(), c.cigar.end());
-        big_.seq4.insert(big_.seq4.end(), c.seq4.begin(), c.seq4.end());
+        gather_array(big_.cigar, c.cigar);
+        gather_array(big_.seq4, c.seq4);
         for (size_t i = 1; i <= n; ++i) {
             big_.cig_off.push_back(cb + c.cig_off[i] - c.cig_off[0]);
             big_.seq_off.push_back(sb + c.seq_off[i] - c.seq_off[0]);
         }
         if (want_qual_) {
-            big_.qual.insert(big_.qual.end(), c.qual.begin(), c.qual.end());
+            gather_array(big_.qual, c.qual);
             for (size_t i = 1; i <= n; ++i) big_.qual_off.push_back(qb + c.qual_off[i] - c.qual_off[0]);
         }
     }
@@ -362,15 +436,20 @@ private:
                 got.swap(q_);
                 finished = done_ && got.empty();
             }
-            for (RecordArrays &c : got) {
-                auto t = std::chrono::steady_clock::now();
-                gather(c);
-                ms_gather += ms_since(t);
-                t = std::chrono::steady_clock::now();
+            auto t = std::chrono::steady_clock::now();
+            for (RecordArrays &c : got) gather(c);
+            ms_gather += ms_since(t);
+            t = std::chrono::steady_clock::now();
+            for (RecordArrays &c : got) {      // (beside the crew's copies)
                 n_reads += c.pos.size();
                 for (std::string &nm : c.names) names.push_back(std::move(nm));
+            }
+            ms_names += ms_since(t);
+            t = std::chrono::steady_clock::now();
+            crew_.wait();
+            ms_gather += ms_since(t);
+            for (RecordArrays &c : got) {
                 c.clear();
-                ms_names += ms_since(t);
                 std::lock_guard<std::mutex> lk(m_);
                 if (pool_.size() < 8) pool_.push_back(std::move(c));
             }
@@ -397,6 +476,12 @@ private:
     std::vector<RecordArrays> pool_;
     bool done_ = false, ready_ = false;
     RecordArrays big_;
+    static unsigned crew_size()
+    {
+        if (const char *e = getenv("JL_COPY_THREADS")) return std::max(1, atoi(e));     // (tuning)
+        return 3;      // (1, 3, 8 on the 16-thread box: 23-34, 18-25, 19-28 ms for the 0.45 GB — the uploader thread copies too)
+    }
+    CopyCrew crew_{crew_size()};
     int rc_ = JL_OK;
     std::vector<jl_ctx *> ctxs_;
     jl_ctx *failed_ = nullptr;
@@ -1069,6 +1154,15 @@ int main(int argc, char **argv)
             else f << render_html(root);
         }
         tick("json / html");
+        // Everything is written and closed.  What a `return` would still do — free a gigabyte of record arrays page by page, take down
+        // the uploader and the decode pool, destroy the GPU contexts and the HIP runtime's own state — the operating system does at
+        // once when the process ends: 40-60 ms of the wall time of a 100k-read run (JL_SLOW_EXIT=1: the long way, for leak checkers).
+        if (!getenv("JL_SLOW_EXIT")) {
+            std::cout.flush();
+            std::cerr.flush();
+            fflush(nullptr);
+            _exit(0);
+        }
         return 0;
     } catch (const std::exception &e) {
         std::cerr << "juliet: " << e.what() << "\n";

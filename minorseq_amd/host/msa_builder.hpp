@@ -1,6 +1,9 @@
 // msa_builder.hpp — aligned BAM records -> by-row symbol matrix of one reference window
 // (doc/JULIET.md:50-58 input contract; :26-27 insertions ignored, deletions are '-'; :256-259 filtered base = N).
 #pragma once
+#if defined(__SSE2__)
+#include <emmintrin.h>
+#endif
 #include <sys/mman.h>
 
 #include <filesystem>
@@ -19,19 +22,37 @@ struct IngestOptions {
     double min_rq = 0.0;    // skip reads with a lower rq tag; 0 = off (doc/JULIET.md:56 leaves this to the user)
 };
 
+// dst[i] = min(dst[i], track[i] - 33) over n bases, as unsigned bytes: a rich-QV track (phred + 33, a character per base) folded into
+// the effective qualities — 0xFF, "nothing known", is the largest byte, so the minimum takes whatever the track says.  Sixteen bases
+// an instruction: with a byte at a time over QUAL and three tracks this loop was 2.5-3.4 s of the 3.5-4.5 s of CPU time the decode of
+// a 100k-read rich-QV BAM took (tools_tuning/decode_stats.cpp).
+inline void min_with_track(uint8_t *dst, const char *track, size_t n)
+{
+    size_t i = 0;
+#if defined(__SSE2__)
+    const __m128i k33 = _mm_set1_epi8(33);
+    for (; i + 16 <= n; i += 16) {
+        const __m128i d = _mm_loadu_si128(reinterpret_cast<const __m128i *>(dst + i));
+        const __m128i t = _mm_loadu_si128(reinterpret_cast<const __m128i *>(track + i));
+        _mm_storeu_si128(reinterpret_cast<__m128i *>(dst + i), _mm_min_epu8(d, _mm_sub_epi8(t, k33)));
+    }
+#endif
+    for (; i < n; ++i) {
+        const uint8_t v = (uint8_t)(track[i] - 33);
+        if (v < dst[i]) dst[i] = v;
+    }
+}
+
 // lowest phred over QUAL and whichever rich-QV tracks the record carries, per base (0xFF = nothing known)
+// (dst holds QUAL — always l_seq entries, 0xFF = absent — on entry)
+inline void fold_tracks(uint8_t *dst, size_t l_seq, const BamRecord &tags)
+{
+    for (const std::string *t : {&tags.dq, &tags.iq, &tags.sq}) min_with_track(dst, t->data(), std::min(t->size(), l_seq));
+}
 inline void effective_quals(const BamRecord &r, std::vector<uint8_t> &out)
 {
-    out.assign(r.qual.size(), 0xFF);   // QUAL always holds l_seq entries (0xFF = absent)
-    for (size_t i = 0; i < out.size(); ++i) {
-        uint8_t q = i < r.qual.size() ? r.qual[i] : 0xFF;
-        for (const std::string *t : {&r.dq, &r.iq, &r.sq})
-            if (i < t->size()) {
-                const uint8_t v = (uint8_t)((*t)[i] - 33);
-                if (q == 0xFF || v < q) q = v;
-            }
-        out[i] = q;
-    }
+    out.assign(r.qual.begin(), r.qual.end());
+    fold_tracks(out.data(), out.size(), r);
 }
 
 inline bool keep_record(const BamRecord &r)
@@ -144,6 +165,10 @@ struct HugeAlloc {
         if (n * sizeof(T) < ((size_t)2 << 20)) ::operator delete(p);
         else std::free(p);
     }
+    // resize() leaves new elements as they are (default-initialised) instead of writing zeros: what grows a vector of this kind is
+    // filled by the caller — by several threads at once in the uploader's gather — and the zeros were a first pass over every page
+    template <typename U> void construct(U *p) noexcept(std::is_nothrow_default_constructible<U>::value) { ::new (static_cast<void *>(p)) U; }
+    template <typename U, typename... Args> void construct(U *p, Args &&...args) { ::new (static_cast<void *>(p)) U(std::forward<Args>(args)...); }
     template <typename U> bool operator==(const HugeAlloc<U> &) const { return true; }
     template <typename U> bool operator!=(const HugeAlloc<U> &) const { return false; }
 };
@@ -185,11 +210,12 @@ inline bool parse_record(const uint8_t *p, size_t len, const IngestOptions &opt,
     // "Reads that are not primary or supplementary alignments, get ignored" (doc/JULIET.md:58)
     if ((flag & 0x4) || (flag & 0x100) || rid < 0 || pos < 0) return false;
     const bool need_tags = want_qual || opt.min_rq > 0.0;
+    BamReader::AuxViews aux;      // (the tracks stay where they are in the record: folded into the qualities below)
     if (need_tags) {
-        scratch.qual.assign(p + o_qual, p + o_aux);
-        BamReader::parse_aux(p, o_aux, len, scratch);
-        if (opt.min_rq > 0.0 && scratch.rq >= 0.f && scratch.rq < opt.min_rq) return false;
+        BamReader::scan_aux(p, o_aux, len, aux);
+        if (opt.min_rq > 0.0 && aux.rq >= 0.f && aux.rq < opt.min_rq) return false;
     }
+    (void)scratch;
     if (ref_id < 0) ref_id = rid;
     if (rid != ref_id) return false;
     const size_t c_at = out.cigar.size();
@@ -218,11 +244,17 @@ inline bool parse_record(const uint8_t *p, size_t len, const IngestOptions &opt,
     e.max_end = std::max<int64_t>(e.max_end, (int64_t)pos + span);
     out.pos.push_back(pos);
     out.cig_off.push_back(out.cigar.size());
-    out.seq4.insert(out.seq4.end(), p + o_seq, p + o_qual);
+    // (resize + memcpy: a range insert into a vector with an allocator of its own goes through construct(), element by element)
+    const size_t s_at = out.seq4.size();
+    out.seq4.resize(s_at + (o_qual - o_seq));
+    memcpy(out.seq4.data() + s_at, p + o_seq, o_qual - o_seq);
     out.seq_off.push_back(out.seq4.size());
     if (want_qual) {
-        effective_quals(scratch, eq);
-        out.qual.insert(out.qual.end(), eq.begin(), eq.end());
+        (void)eq;
+        const size_t q_at = out.qual.size();
+        out.qual.resize(q_at + l_seq);
+        memcpy(out.qual.data() + q_at, p + o_qual, l_seq);
+        for (int k = 0; k < 3; ++k) min_with_track(out.qual.data() + q_at, aux.track[k], std::min<size_t>(aux.len[k], l_seq));
         out.qual_off.push_back(out.qual.size());
     }
     out.names.emplace_back((const char *)p + 32, l_name ? l_name - 1 : 0);

@@ -109,6 +109,54 @@ def test_rich_qv_tracks_mask_bases(tmp_path):
     assert (rows0[:, :l][exp != 5] == exp[exp != 5]).all()
 
 
+def test_quality_tracks_fold_like_the_byte_by_byte_rule(tmp_path):
+    """msa_builder.hpp effective_quals (sixteen bases an instruction) against the rule it restates, a base at a time: the lowest of
+    QUAL (0xFF = absent) and the dq / iq / sq characters - 33 that the record holds for the base — tracks shorter than the read,
+    characters below '!' (they wrap to large values), every length from 0 to 70."""
+    import textwrap
+    src = tmp_path / "fold.cpp"
+    src.write_text(textwrap.dedent(r"""
+        #include <cstdio>
+        #include <random>
+        #include "juliet_hip.h"
+        #include "msa_builder.hpp"
+        using namespace jlhost;
+        int main() {
+            std::mt19937 g(5);
+            for (int rep = 0; rep < 4000; ++rep) {
+                BamRecord r;
+                const size_t n = g() % 71;
+                r.qual.resize(n);
+                for (auto &q : r.qual) q = (g() % 4 == 0) ? 0xFF : (uint8_t)(g() % 94);
+                for (std::string *t : {&r.dq, &r.iq, &r.sq}) {
+                    const size_t m = (g() % 3 == 0) ? g() % (n + 1) : (g() % 5 == 0 ? 0 : n);
+                    t->resize(m);
+                    for (auto &c : *t) c = (char)(g() % 7 == 0 ? g() % 256 : 33 + g() % 94);
+                }
+                std::vector<uint8_t> got, want(n);
+                effective_quals(r, got);
+                for (size_t i = 0; i < n; ++i) {
+                    uint8_t q = r.qual[i];
+                    for (const std::string *t : {&r.dq, &r.iq, &r.sq})
+                        if (i < t->size()) {
+                            const uint8_t v = (uint8_t)((*t)[i] - 33);
+                            if (q == 0xFF || v < q) q = v;
+                        }
+                    want[i] = q;
+                }
+                if (got != want) { printf("differs at repetition %d\n", rep); return 1; }
+            }
+            printf("ok\n");
+            return 0;
+        }
+        """))
+    exe = str(tmp_path / "fold")
+    host = os.path.join(ROOT, "minorseq_amd", "host")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-I" + host, "-I" + os.path.join(ROOT, "include"), "-o", exe, str(src), "-lz", "-lpthread"])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.strip() == "ok", out.stdout + out.stderr
+
+
 def test_min_rq_filter_reads_the_rq_tag(tmp_path):
     """doc/JULIET.md:56: filtering on predicted accuracy is left to the user; --min-rq applies it from the rq tag.
     The generator writes rq = 0.999 on every read."""
