@@ -1131,17 +1131,18 @@ int main(int argc, char **argv)
                 hj.set("frequency", Json::of(ps.reported_reads ? (double)hap_count[h] / (double)ps.reported_reads : 0.0));
                 Json cods = Json::array();
                 for (uint32_t p = 0; p < ps.n_positions; ++p) cods.push(Json::of(codon_string(hap_pattern[(size_t)h * R.pat_stride + p])));
-                hj.set("codons", cods);
-                Json rn = Json::array();
+                hj.set("codons", std::move(cods));
+                Json rn = Json::array();      // (moved on, level by level: a copy of this list per level was most of the stage at a million reads)
+                rn.arr.reserve(members[h].size());
                 for (uint32_t i : members[h]) rn.push(Json::of(names[i]));
-                hj.set("read_names", rn);
-                hs.push(hj);
+                hj.set("read_names", std::move(rn));
+                hs.push(std::move(hj));
             }
-            hb.set("haplotypes", hs);
+            hb.set("haplotypes", std::move(hs));
             Json pc = Json::array();
             for (uint32_t p = 0; p < ps.n_positions; ++p) pc.push(Json::of(win_begin + pos_cols[p] + 1));
-            hb.set("variant_positions_abs", pc);
-            root.set("haplotype", hb);
+            hb.set("variant_positions_abs", std::move(pc));
+            root.set("haplotype", std::move(hb));
         }
 
         std::string text;
