@@ -142,6 +142,7 @@ public:
                           std::vector<BamRef> *refs, std::string *header_text, unsigned threads = 0)
     {
         unsigned nt = threads ? threads : std::min(64u, usable_cpus());
+        if (const char *e = getenv("JL_DECODE_THREADS")) nt = (unsigned)std::max(1, atoi(e));     // (tuning)
         if (const char *env = getenv("JL_BGZF_THREADS")) { const int v = atoi(env); if (v > 0 && v <= 256) nt = (unsigned)v; }
         PipelinedBamReader r(bam, opt, ref_id, want_qual, nt);
         return r.drive(sink, refs, header_text);
