@@ -11,7 +11,7 @@ for round in 1 2; do
   i=0
   for f in "$@"; do
     i=$((i+1))
-    JL_LIB=$R/tools_tuning/lib_exp/libjuliet_v$i.so python3 bench.py --steps ${STEPS:-16000} --no-config3 --no-cpu-baseline --no-end-to-end 2>/dev/null | python3 -c "
+    JL_LIB=$R/tools_tuning/lib_exp/libjuliet_v$i.so python3 bench.py --steps ${STEPS:-16000} --no-config3 --no-cpu-baseline --no-end-to-end ${BENCH_ARGS:-} 2>/dev/null | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
 q,o=d['once_through_qv'],d['once_through']
