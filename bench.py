@@ -24,7 +24,7 @@ Prints ONE JSON line on rank 0 (see the driver contract in the task brief), incl
                format since round 4, DESIGN.md "Data layout") — so `frac` is physical: what crosses the HBM over the kernel's
                time (`traffic` from the PMC counters agrees within a few percent).  `step_frac` = the same bytes over the whole
                timed step.  (`frac_in_nibble_units`: the same time against SURVEY 8d's 4-bit cell, for comparison with rounds 1-3.)
-  once_through a FRESH window per step: aligned records resident in HBM -> ingest (cigar expansion + plane split, four
+  once_through a FRESH window per step: aligned records resident in HBM -> ingest (cigar expansion + plane split, three or four
                launches) -> pileup -> Fisher -> phasing -> results on the host; reads/s and the fraction of the HBM peak in
                record bytes read + plane bytes written + plane bytes read.
   once_through_qv  the same on the input the reference documents (`ccs --richQVs`, doc/JULIET.md:256-259): filtered bases keep
