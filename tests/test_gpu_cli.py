@@ -181,6 +181,23 @@ def test_no_config_majority_mode_and_html(sample, oracle):
     assert os.path.getsize(d / "both.html") > 0 and json.load(open(d / "both.json"))["genes"]
 
 
+def test_the_long_way_out_writes_the_same_files(sample):
+    """The front end ends its process as soon as its output is written and closed (`_exit`); with JL_SLOW_EXIT=1 it returns from main
+    — destructors, the runtime's own teardown: what a profiler or a leak checker needs.  Same JSON, same HTML, exit code 0 both ways."""
+    d, bam, cfg, rows, ref = sample
+    outs = {}
+    for tag, env in (("fast", {}), ("slow", {"JL_SLOW_EXIT": "1"})):
+        j, h = str(d / f"exit_{tag}.json"), str(d / f"exit_{tag}.html")
+        r = subprocess.run([JULIET, "-c", cfg, "--mode-phasing", bam, j, h], env=dict(os.environ, **env), capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        outs[tag] = (open(j).read(), open(h).read())
+    fj, sj = (json.loads(outs[t][0]) for t in ("fast", "slow"))
+    for doc in (fj, sj):      # (the run's own stamp and command line)
+        doc["input"].pop("timestamp")
+        doc["input"].pop("command_line")
+    assert fj == sj and abs(len(outs["fast"][1]) - len(outs["slow"][1])) < 64 and fj["genes"]
+
+
 def test_consensus_by_product(sample, oracle):
     """--consensus: majority base per column, majority-deletion columns dropped (doc/FUSE.md:17-24, without insertions)."""
     d, bam, cfg, rows, ref = sample
