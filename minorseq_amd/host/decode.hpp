@@ -296,8 +296,6 @@ private:
         const uint64_t c0 = thread_cpu_ns();
         try {
             if (s.error.empty()) {
-                BamRecord scratch;
-                std::vector<uint8_t> eq;
                 int rid = s.ref_id;
                 take_chunk(s.chunk);
                 {   // a CCS record is about a third packed bases, a few cigar words per 100 bases; growing by doubling
@@ -311,7 +309,7 @@ private:
                     uint32_t block;
                     memcpy(&block, p, 4);
                     (void)n;
-                    if (rid >= 0) parse_record(p + 4, block, opt_, want_qual_, rid, s.chunk, s.extent, scratch, eq);
+                    if (rid >= 0) parse_record(p + 4, block, opt_, want_qual_, rid, s.chunk, s.extent);
                 };
                 if (!s.joined.empty()) one(s.joined.data(), s.joined.size());
                 size_t o = s.rec_begin;

@@ -197,7 +197,7 @@ struct RecordSink {
 // One record of the stream -> the arrays the device ingests (shared by the sequential and the pipelined reader).
 // `ref_id`: -1 = not known yet (the first kept record decides; sequential reader only).  Returns whether it was kept.
 inline bool parse_record(const uint8_t *p, size_t len, const IngestOptions &opt, bool want_qual, int &ref_id, RecordArrays &out,
-                         ReadExtent &e, BamRecord &scratch, std::vector<uint8_t> &eq)
+                         ReadExtent &e)
 {
     auto u32 = [&](size_t o) { uint32_t v; memcpy(&v, p + o, 4); return v; };
     auto u16 = [&](size_t o) { uint16_t v; memcpy(&v, p + o, 2); return v; };
@@ -215,7 +215,6 @@ inline bool parse_record(const uint8_t *p, size_t len, const IngestOptions &opt,
         BamReader::scan_aux(p, o_aux, len, aux);
         if (opt.min_rq > 0.0 && aux.rq >= 0.f && aux.rq < opt.min_rq) return false;
     }
-    (void)scratch;
     if (ref_id < 0) ref_id = rid;
     if (rid != ref_id) return false;
     const size_t c_at = out.cigar.size();
@@ -250,7 +249,6 @@ inline bool parse_record(const uint8_t *p, size_t len, const IngestOptions &opt,
     memcpy(out.seq4.data() + s_at, p + o_seq, o_qual - o_seq);
     out.seq_off.push_back(out.seq4.size());
     if (want_qual) {
-        (void)eq;
         const size_t q_at = out.qual.size();
         out.qual.resize(q_at + l_seq);
         memcpy(out.qual.data() + q_at, p + o_qual, l_seq);
@@ -287,12 +285,10 @@ inline ReadExtent collect_records(const std::string &bam, const IngestOptions &o
             } catch (const std::bad_alloc &) {}   // doubling takes over
         }
     }
-    BamRecord r;   // only its tag fields and qualities are used, and only when a filter needs them
-    std::vector<uint8_t> eq;
     const uint8_t *p;
     size_t len;
     while (in.next_raw(p, len)) {
-        parse_record(p, len, opt, want_qual, e.ref_id, out, e, r, eq);
+        parse_record(p, len, opt, want_qual, e.ref_id, out, e);
         if (sink && out.pos.size() >= sink->chunk_reads) sink->give(out);
     }
     if (sink && !out.pos.empty()) sink->give(out);
