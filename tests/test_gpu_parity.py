@@ -1180,7 +1180,7 @@ def test_device_ingest_random_qv_shapes(jl):
 def test_device_ingest_random_shapes(jl):
     """A seeded slice of tools_tuning/ingest_stress.py: read counts, widths, indel and mask rates and windows drawn at random,
     with and without qualities."""
-    rng = np.random.default_rng(2025)
+    rng = np.random.default_rng(int(os.environ.get("JL_TEST_SEED", "2025")))     # (JL_TEST_SEED: a soak with other draws)
     for k in range(10):
         n = int(rng.integers(1, 6000))
         l = int(rng.integers(30, 1500))
@@ -1413,7 +1413,7 @@ def test_ten_million_reads_against_oracle(oracle):
 # --------------------------------------------------------------------------------------------- randomized sweep
 def test_random_shapes_and_plans_against_oracle(oracle):
     """Forty random (reads, columns, gene layout, parameter) combinations through jl_run_async vs the oracle."""
-    rng = np.random.default_rng(20260101)
+    rng = np.random.default_rng(int(os.environ.get("JL_TEST_SEED", "20260101")))     # (JL_TEST_SEED: a soak with other draws)
     j = capi.Juliet(0)
     for case in range(40):
         n = int(rng.integers(1, 4000))

@@ -1,6 +1,8 @@
 """Cross-window phasing with the READS sharded (SURVEY.md §8e option A): every shard groups its slice of the reads on the
 device, the group tables are merged on the host, the merged groups' haplotype ids go back to the shards.  The result must
 be the unsharded one — summary, haplotypes, hit, co-occurrence and every read's id — for any number of shards."""
+import os
+
 import numpy as np
 import pytest
 
@@ -186,7 +188,7 @@ def test_state_and_argument_errors_are_loud(oracle):
 def test_random_shapes_against_the_unsharded_oracle(oracle):
     """Random reads, window counts, shard counts, error rates (up to 200 variant positions = 20-word keys; samples where
     not one read is clean): the sharded run equals the unsharded oracle in everything."""
-    rng = np.random.default_rng(12345)
+    rng = np.random.default_rng(int(os.environ.get("JL_TEST_SEED", "12345")))     # (JL_TEST_SEED: a soak with other draws)
     seen_many, seen_none = False, False
     for trial in range(12):
         n = int(rng.integers(300, 30000))
@@ -207,7 +209,8 @@ def test_random_shapes_against_the_unsharded_oracle(oracle):
         seen_none |= exp["summary"]["n_positions"] > 0 and exp["summary"]["reported_reads"] + exp["summary"]["insufficient_reads"] == 0
         for c in ctxs:
             c.close()
-    assert seen_many and seen_none
+    if "JL_TEST_SEED" not in os.environ:      # (what the default draws are known to contain)
+        assert seen_many and seen_none
 
 
 # ---------------------------------------------------------------------------------------------------------------------
