@@ -417,7 +417,8 @@ constexpr uint32_t kWalkOps = 192u;
 #define JL_WALK_ENT 40
 #endif
 // entries of a read in LDS: a CCS read has a dozen.  With 24 two reads in a thousand went to the other launch; with 32 two in 100 000
-// (fifteen deletions) — enough for the upload to have to ask for that launch in every build; with 40 none of a CCS sample does (48: 26 KB of LDS a workgroup, six a CU — not all 1563 of a 100k-read build at once: 28 us instead of 22)
+// (fifteen deletions) — enough for the upload to have to ask for that launch in every build; with 40 none of a CCS sample does
+// (48: 26 KB of LDS a workgroup, six a CU — not all 1563 of a 100k-read build at once: 28 us instead of 22)
 constexpr uint32_t kWalkEnt = JL_WALK_ENT;
 constexpr uint32_t kWalkReads = 64u;    // reads of a workgroup
 
@@ -1462,8 +1463,8 @@ void jl_launch_ingest(jl_ctx *ctx, const int32_t *d_pos, const uint32_t *d_cigar
                            ctx->n_reads, d_pos, d_cigar, d_cig_off, d_seq_off, qo, ctx->win_begin, ctx->n_cols, ns, d_runs, d_nruns, d_desc, bad, d_slow_count, maybe_long ? 1u : 0u);
         // (the launch for the long reads: not when the upload has looked and found none — every CCS sample: 6 us of a build)
         if (maybe_long)
-        hipLaunchKernelGGL((cigar_runs_kernel<kRunsLdsLarge, true>), dim3((uint32_t)std::min<uint64_t>(kRunsLongGrid, (ctx->n_reads + 255u) / 256u)), dim3(256), 0, st,
-                           ctx->n_reads, d_pos, d_cigar, d_cig_off, d_seq_off, qo, ctx->win_begin, ctx->n_cols, ns, d_runs, d_nruns, d_desc, bad);
+            hipLaunchKernelGGL((cigar_runs_kernel<kRunsLdsLarge, true>), dim3((uint32_t)std::min<uint64_t>(kRunsLongGrid, (ctx->n_reads + 255u) / 256u)), dim3(256), 0, st,
+                               ctx->n_reads, d_pos, d_cigar, d_cig_off, d_seq_off, qo, ctx->win_begin, ctx->n_cols, ns, d_runs, d_nruns, d_desc, bad);
     }
 #ifdef JL_TUNING
     if (getenv("JL_ING_ONLY_RUNS")) return;     // (probe builds of cigar_runs leave descriptors nobody may follow)
