@@ -994,7 +994,7 @@ __device__ __forceinline__ bool planes_unit(const ingest_args &a, const uint32_t
     // WITHOUT QUALITIES a wave that still has its requests to HBM to make and its rows to stage goes before the waves that transpose
     // (s_setprio: the CU's arbiter picks by it among the waves ready to issue).  Without it the transposing waves of the CU's other
     // workgroups — three quarters of all instructions — hold up the few instructions that put the next tile's loads in flight: the
-    // launch 110-113 -> 100-103 us, a whole build 171 -> 164 us on one stream and 159 -> 152 with two builds overlapping.  With
+    // launch 110-113 -> 100-107 us, a whole build 171 -> 164 us on one stream and 159 -> 152 with two builds overlapping.  With
     // qualities the launch alone gains 3 us of 169 and the build LOSES 3-7 (two streams: 191 -> 198; in bench.py's once_through_qv
     // 185 -> 202): its raised waves also go before the waves of whatever else is on the device — the next build's cigar walk, the
     // pileup and the phasing of the windows before — so there it stays off.  (JL_INGEST_PRIO=0 for A/B.  Raised only until the loads
