@@ -7,7 +7,7 @@ for f in "$@"; do
   i=$((i+1))
   bash tools_tuning/build_tuning_lib.sh "$f" libjuliet_v$i.so > /dev/null 2>&1 || { echo "build $i failed: $f"; exit 1; }
 done
-for round in 1 2; do
+for round in $(seq 1 ${ROUNDS:-2}); do
   i=0
   for f in "$@"; do
     i=$((i+1))
